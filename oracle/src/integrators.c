@@ -1,0 +1,171 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see common.h).
+ *
+ * Integrator kernels on the hot path, restated from
+ *   VerletNVT::GronbechJensen_ns::integrateGPU<step> (K11)   Integrator/VerletNVT/GronbechJensen.cu:28-62
+ *   VerletNVT::Basic_ns::integrateGPU<step>          (K11)   Integrator/VerletNVT/Basic.cu:86-114
+ *   VerletNVT::Basic_ns::initialVelocities                   Integrator/VerletNVT/Basic.cu:12-29
+ *   BD::EulerMaruyama_ns::integrateGPU               (K12)   Integrator/BrownianDynamics.cu:119-144
+ *   BDHI::FCM_ns::integrateEulerMaruyamaD            (K20)   Integrator/BDHI/BDHI_FCM.cu:67-92  (no orientations)
+ *   BDHI::EulerMaruyama_ns::integrateGPUD            (K21)   Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113
+ *
+ * Argument-evaluation order: `make_real3(rng.gf(..), rng.gf(..).x)` has unspecified order in C++;
+ * the oracle pins left-to-right (first draw -> x,y; second draw -> z), which is what clang-based
+ * device compilers (and the HIP side of this repo) do.
+ * The Gaussians go through logf/sinf/cosf: compared with a tolerance, never bit-exact.
+ */
+#include "common.h"
+#include "saru.h"
+
+static inline void gf_real(Saru *s, real mean, real std, real *a, real *b) {
+  float x, y;
+  saru_gf(s, (float)mean, (float)std, &x, &y);
+  *a = x; *b = y;
+}
+
+/* GronbechJensen.cu:28-62.  vel is real3 (stride 3).  mass nullable (defaultMass>0 wins). */
+ORACLE_API void oracle_verletnvt_gj(int step, real4 *pos, real *vel3, real4 *force, const real *mass, real defaultMass,
+                                    const int *indexIterator, int N, real dt, real friction, int is2D,
+                                    real noiseAmplitude_in, uint stepNum, uint seed) {
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    real noiseAmplitude = noiseAmplitude_in;
+    const real invMass = (real)1.0 / (defaultMass > 0 ? defaultMass : mass[i]);
+    real3 v = mk3(vel3[3 * i], vel3[3 * i + 1], vel3[3 * i + 2]);
+    real3 f = mk3(force[i].x, force[i].y, force[i].z);
+    if (step == 1) {
+      Saru rng = saru3((uint)id, stepNum, seed);
+      noiseAmplitude *= (real)1.0 / SQRT(invMass); /* rsqrt(invMass) */
+      real3 noisei;
+      real tmp;
+      gf_real(&rng, 0, noiseAmplitude, &noisei.x, &noisei.y);
+      if (is2D) noisei.z = 0;
+      else gf_real(&rng, 0, noiseAmplitude, &noisei.z, &tmp);
+      const real gdthalfinvMass = friction * dt * (real)0.5;
+      const real b = (real)1.0 / ((real)1.0 + gdthalfinvMass);
+      const real a = ((real)1.0 - gdthalfinvMass) * b;
+      real3 p = mk3(pos[i].x, pos[i].y, pos[i].z);
+      /* p = p + b*dt*vel + 0.5*invMass*dt*b*(dt*force + noise) */
+      const real bdt = b * dt;
+      const real c = (real)0.5 * invMass * dt * b;
+      p.x = FMA(c, FMA(dt, f.x, noisei.x), FMA(bdt, v.x, p.x));
+      p.y = FMA(c, FMA(dt, f.y, noisei.y), FMA(bdt, v.y, p.y));
+      p.z = FMA(c, FMA(dt, f.z, noisei.z), FMA(bdt, v.z, p.z));
+      pos[i].x = p.x; pos[i].y = p.y; pos[i].z = p.z;
+      /* vel = a*vel + dt*0.5*invMass*a*force + b*invMass*noise */
+      const real d = dt * (real)0.5 * invMass * a;
+      const real e = b * invMass;
+      v.x = FMA(e, noisei.x, FMA(d, f.x, a * v.x));
+      v.y = FMA(e, noisei.y, FMA(d, f.y, a * v.y));
+      v.z = FMA(e, noisei.z, FMA(d, f.z, a * v.z));
+      force[i].x = 0; force[i].y = 0; force[i].z = 0; force[i].w = 0;
+    } else {
+      const real d = dt * (real)0.5 * invMass;
+      v.x = FMA(d, f.x, v.x);
+      v.y = FMA(d, f.y, v.y);
+      v.z = FMA(d, f.z, v.z);
+    }
+    if (is2D) v.z = (real)0.0;
+    vel3[3 * i] = v.x; vel3[3 * i + 1] = v.y; vel3[3 * i + 2] = v.z;
+  }
+}
+
+/* Basic.cu:86-114 */
+ORACLE_API void oracle_verletnvt_basic(int step, real4 *pos, real *vel3, real4 *force, const real *mass,
+                                       real defaultMass, const int *indexIterator, int N, real dt, real friction,
+                                       int is2D, real noiseAmplitude_in, uint stepNum, uint seed) {
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    const real invMass = (real)1.0 / (defaultMass > 0 ? defaultMass : mass[i]);
+    Saru rng = saru3((uint)(id + N * (step - 1)), stepNum, seed);
+    real noiseAmplitude = noiseAmplitude_in * (real)sqrtf((float)(0.5 * (double)invMass));
+    real3 noisei;
+    real tmp;
+    gf_real(&rng, 0, noiseAmplitude, &noisei.x, &noisei.y);
+    gf_real(&rng, 0, noiseAmplitude, &noisei.z, &tmp);
+    real3 v = mk3(vel3[3 * i], vel3[3 * i + 1], vel3[3 * i + 2]);
+    real3 f = mk3(force[i].x, force[i].y, force[i].z);
+    const real hdt = dt * (real)0.5;
+    /* vel += (force*invMass - friction*vel)*(dt*0.5) + noise */
+    v.x = v.x + FMA(FMA(f.x, invMass, -(friction * v.x)), hdt, noisei.x);
+    v.y = v.y + FMA(FMA(f.y, invMass, -(friction * v.y)), hdt, noisei.y);
+    v.z = v.z + FMA(FMA(f.z, invMass, -(friction * v.z)), hdt, noisei.z);
+    if (is2D) v.z = (real)0.0;
+    vel3[3 * i] = v.x; vel3[3 * i + 1] = v.y; vel3[3 * i + 2] = v.z;
+    if (step == 1) {
+      pos[i].x = FMA(v.x, dt, pos[i].x);
+      pos[i].y = FMA(v.y, dt, pos[i].y);
+      pos[i].z = FMA(v.z, dt, pos[i].z);
+      force[i].x = 0; force[i].y = 0; force[i].z = 0; force[i].w = 0;
+    }
+  }
+}
+
+/* Basic.cu:12-29 — ignores mass, double-indexes the iterator (reproduced). */
+ORACLE_API void oracle_verletnvt_initial_velocities(real *vel3, const int *indexIterator, real vamp, int is2D, int N,
+                                                    uint seed) {
+  for (int id = 0; id < N; id++) {
+    Saru rng = saru2((uint)id, seed);
+    int i = indexIterator ? indexIterator[id] : id;
+    double mass_i = 1.0;
+    double nx, ny, nz = 0.0, tmp;
+    saru_gd(&rng, 0, (double)vamp / mass_i, &nx, &ny);
+    if (!is2D) saru_gd(&rng, 0, (double)vamp / mass_i, &nz, &tmp);
+    int index = indexIterator ? indexIterator[i] : i;
+    vel3[3 * index] = (real)nx; vel3[3 * index + 1] = (real)ny; vel3[3 * index + 2] = (real)nz;
+  }
+}
+
+/* BrownianDynamics.cu:119-144.  K = shear matrix rows (9 reals, nullable = zero). */
+ORACLE_API void oracle_bd_euler_maruyama(real4 *pos, const int *indexIterator, const real4 *force, const real *K9,
+                                         real selfMobility, const real *radius, real dt, int is2D, real temperature,
+                                         int N, uint stepNum, uint seed) {
+  real3 Kx = mk3(0, 0, 0), Ky = Kx, Kz = Kx;
+  if (K9) { Kx = mk3(K9[0], K9[1], K9[2]); Ky = mk3(K9[3], K9[4], K9[5]); Kz = mk3(K9[6], K9[7], K9[8]); }
+  for (int id = 0; id < N; id++) {
+    int i = indexIterator ? indexIterator[id] : id;
+    real3 R = mk3(pos[i].x, pos[i].y, pos[i].z);
+    real3 F = mk3(force[i].x, force[i].y, force[i].z);
+    real3 KR = mk3(dot3(Kx, R), dot3(Ky, R), dot3(Kz, R));
+    real M = selfMobility * (radius ? ((real)1.0 / radius[i]) : (real)1.0);
+    /* R += dt*(KR + M*F) */
+    R.x = FMA(dt, FMA(M, F.x, KR.x), R.x);
+    R.y = FMA(dt, FMA(M, F.y, KR.y), R.y);
+    R.z = FMA(dt, FMA(M, F.z, KR.z), R.z);
+    if (temperature > 0) {
+      Saru rng = saru3((uint)i, stepNum, seed);
+      real B = SQRT((real)2.0 * temperature * M * dt);
+      real3 dW;
+      real tmp;
+      gf_real(&rng, 0, B, &dW.x, &dW.y);
+      gf_real(&rng, 0, B, &dW.z, &tmp);
+      R.x += dW.x; R.y += dW.y; R.z += dW.z;
+    }
+    pos[i].x = R.x;
+    pos[i].y = R.y;
+    if (!is2D) pos[i].z = R.z;
+  }
+}
+
+/* BDHI_FCM.cu:67-92 without orientations: pos[i] += linearV[id]*dt */
+ORACLE_API void oracle_fcm_euler_maruyama(real4 *pos, const int *indexIterator, const real *linearV3, int N, real dt) {
+  for (int id = 0; id < N; id++) {
+    int i = indexIterator ? indexIterator[id] : id;
+    pos[i].x = FMA(linearV3[3 * id], dt, pos[i].x);
+    pos[i].y = FMA(linearV3[3 * id + 1], dt, pos[i].y);
+    pos[i].z = FMA(linearV3[3 * id + 2], dt, pos[i].z);
+  }
+}
+
+/* Raw Saru streams for the tests: n draws of u32 from Saru(s1[,s2[,s3]]) */
+ORACLE_API void oracle_saru_u32(int nseeds, uint s1, uint s2, uint s3, int n, uint *out) {
+  Saru s = nseeds == 1 ? saru1(s1) : (nseeds == 2 ? saru2(s1, s2) : saru3(s1, s2, s3));
+  for (int i = 0; i < n; i++) out[i] = saru_u32(&s);
+}
+ORACLE_API void oracle_saru_f_range(uint s1, float low, float high, int n, float *out) {
+  Saru s = saru1(s1);
+  for (int i = 0; i < n; i++) out[i] = saru_f_range(&s, low, high);
+}
+ORACLE_API void oracle_saru_gf(uint s1, uint s2, uint s3, float mean, float std, int npairs, float *out) {
+  Saru s = saru3(s1, s2, s3);
+  for (int i = 0; i < npairs; i++) saru_gf(&s, mean, std, &out[2 * i], &out[2 * i + 1]);
+}

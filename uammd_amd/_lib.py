@@ -1,0 +1,99 @@
+"""ctypes binding of libuammd_hip.so — the C ABI declared in include/uammd_hip.h.
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, an exception is
+raised (UammdHipError carries uammd_hip_last_error()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libuammd_hip.so")
+
+
+class UammdHipError(RuntimeError):
+    pass
+
+
+class LJPairParameters(C.Structure):
+    _fields_ = [("cutOff2", C.c_float), ("sigma2", C.c_float), ("epsilonDivSigma2", C.c_float), ("shift", C.c_float)]
+
+
+class CellListData(C.Structure):
+    _fields_ = [("d_cellStart", C.c_void_p), ("d_cellEnd", C.c_void_p), ("d_sortPos", C.c_void_p),
+                ("d_groupIndex", C.c_void_p), ("d_sortHash", C.c_void_p), ("cellDim", C.c_int * 3),
+                ("boxSize", C.c_float * 3), ("periodic", C.c_int * 3), ("VALID_CELL", C.c_uint),
+                ("numberParticles", C.c_int)]
+
+
+_f3 = C.c_float * 3
+_i3 = C.c_int * 3
+_vp = C.c_void_p
+_f = C.c_float
+_i = C.c_int
+_u = C.c_uint
+
+# name -> (restype, argtypes).  Every symbol include/uammd_hip.h declares must be listed here:
+# tests/test_abi.py checks header, library and this table against each other.
+SIGNATURES = {
+    "uammd_hip_abi_version": (_i, []),
+    "uammd_hip_last_error": (C.c_char_p, []),
+    "uammd_hip_device_count": (_i, [C.POINTER(_i)]),
+    "uammd_hip_set_device": (_i, [_i]),
+    "uammd_hip_set_tunable": (_i, [C.c_char_p, _i]),
+    "uammd_celllist_create": (_i, [C.POINTER(_vp)]),
+    "uammd_celllist_destroy": (_i, [_vp]),
+    "uammd_celllist_create_grid": (_i, [_f3, _i3, _f3, _i3, _f3, _i3]),
+    "uammd_celllist_update": (_i, [_vp, _vp, _i, _f3, _i3, _i3, _vp]),
+    "uammd_celllist_get": (_i, [_vp, C.POINTER(CellListData)]),
+    "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "uammd_sort_pairs": (_i, [_vp, _vp, _i, _i, _vp]),
+    "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),
+    "uammd_lj_transverse_celllist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _i, _vp]),
+    "uammd_lj_transverse_nbody": (_i, [_vp, _i, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_verletnvt_gj": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
+    "uammd_verletnvt_basic": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
+    "uammd_verletnvt_initial_velocities": (_i, [_vp, _vp, _f, _i, _i, _u, _vp]),
+    "uammd_bd_euler_maruyama": (_i, [_vp, _vp, _vp, C.POINTER(_f), _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
+    "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
+    "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed to load it) and installs the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UammdHipError(f"{LIB_PATH} is missing: build it with `python -m uammd_amd.build` "
+                            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.uammd_hip_abi_version() != 1:
+        raise UammdHipError("libuammd_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().uammd_hip_last_error()
+        raise UammdHipError(f"libuammd_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def f3(v):
+    import numpy as np
+    a = np.broadcast_to(np.asarray(v, dtype=np.float32), (3,))
+    return _f3(float(a[0]), float(a[1]), float(a[2]))
+
+
+def i3(v):
+    import numpy as np
+    a = np.broadcast_to(np.asarray(v), (3,))
+    return _i3(int(a[0]), int(a[1]), int(a[2]))

@@ -1,0 +1,437 @@
+// Path A — cell-list construction for gfx950.
+//
+// What the reference does (behaviour to match bit-for-bit; NOT its implementation):
+//   K1 assignHash            utils/ParticleSorter.cuh:102-111   hash = Morton(getCell(pos)), index = i
+//   K2 stable radix sort     utils/ParticleSorter.cuh:303-321   on key bits [0, maxbit)
+//   K3 reorder               utils/ParticleSorter.cuh:178-187   sortPos[i] = pos[index[i]]
+//   K4 fillCellList          Interactor/NeighbourList/CellList/CellListBase.cuh:68-94
+//   epoch trick              CellListBase.cuh:210-230           cellStart holds start + VALID_CELL
+//
+// MI355X design: the sorted order of a stable sort by Morton key is unique — (key, original index)
+// lexicographic — so it does not have to come from a multi-pass radix sort.  The default build is
+// a COUNTING sort over the (small) Morton key space:
+//   hash+count  : one pass over pos; per-key histogram with a returning atomic (the returned value
+//                 is a provisional, order-nondeterministic rank inside the key);
+//   scan        : exclusive scan of the histogram (<= 2^maxbit entries, L2 resident) -> keyStart[];
+//   rank+scatter: each particle re-derives its STABLE rank = #{same-key particles with a smaller
+//                 original index} from the provisional per-key member list (~13 members, L2 hits),
+//                 then writes index/hash/sortPos at keyStart[key] + rank.  Deterministic, bit-equal
+//                 to the radix sort, ~3 streaming passes instead of ~8;
+//   cell tables : cellStart/cellEnd come straight from keyStart (one thread per *cell*).
+// When the key space is too large for that (very sparse / huge grids) the build falls back to
+// rocPRIM's stable radix sort + a boundary-detection pass.
+// keyStart[] is kept: the LDS-tiled traversal (lj.hip) uses it to find the particle range of an
+// aligned 4x4x4 brick of cells in O(1) (64 consecutive Morton keys).
+#include "celllist.hpp"
+
+#include <cstring>
+#include <string>
+#include <rocprim/rocprim.hpp>
+
+#include <cstring>
+#include <cstdarg>
+#include <cstdio>
+#include <limits>
+
+namespace uammd_hip {
+
+thread_local char g_last_error[1024] = "";
+void set_last_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
+
+// ---- small device buffer helper ----------------------------------------------------------------
+int DeviceBuffer::reserve(size_t bytes) {
+  if (bytes <= cap) return 0;
+  if (ptr) UH_CHECK(hipFree(ptr));
+  ptr = nullptr;
+  cap = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  UH_CHECK(hipMalloc(&ptr, want));
+  cap = want;
+  return 0;
+}
+DeviceBuffer::~DeviceBuffer() {
+  if (ptr) (void)hipFree(ptr);
+}
+
+// utils/ParticleSorter.cuh:93-100 + :264-266 (clz by smearing; maxbit = 32 - clz(maxHash))
+static int sort_end_bit(uint maxHash) {
+  int msb = -1;
+  for (int b = 31; b >= 0; --b)
+    if (maxHash & (1u << b)) { msb = b; break; }
+  return msb + 1;  // 0 when maxHash == 0 (the sort is then a no-op)
+}
+
+// ---- kernels -------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+
+// K1 (+ histogram): one thread per particle.
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos, int N, GridT<float> grid,
+                                                 uint *__restrict__ hash, int *__restrict__ index,
+                                                 uint *__restrict__ keyCount, uint *__restrict__ provRank,
+                                                 int *__restrict__ errorFlag) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const float4 p = pos[i];
+  int3 c = grid.getCell(real3f{p.x, p.y, p.z});
+  // A particle outside a non periodic box (or a NaN) has no cell: flag it (the reference raises the
+  // same flag in fillCellList, CellListBase.cuh:82-85) and clamp so that no table is overrun.
+  if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z) {
+    errorFlag[0] = 1;
+    c.x = min(max(c.x, 0), grid.cellDim.x - 1);
+    c.y = min(max(c.y, 0), grid.cellDim.y - 1);
+    c.z = min(max(c.z, 0), grid.cellDim.z - 1);
+  }
+  const uint h = morton_hash(c);
+  hash[i] = h;
+  if (COUNT) {
+    provRank[i] = atomicAdd(&keyCount[h], 1u);  // provisional rank inside the key
+  } else {
+    index[i] = i;
+  }
+}
+
+// Writes the provisional member list: members[keyStart[h] + provRank[i]] = i
+__global__ void __launch_bounds__(kBlock) k_members(const uint *__restrict__ hash, const uint *__restrict__ provRank,
+                                                    const uint *__restrict__ keyStart, int N,
+                                                    int *__restrict__ members) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  members[keyStart[hash[i]] + provRank[i]] = i;
+}
+
+// Stable rank + scatter (K2+K3 fused): sorted slot = keyStart[h] + #{members of h with index < i}.
+__global__ void __launch_bounds__(kBlock) k_rank_scatter(const float4 *__restrict__ pos, const uint *__restrict__ hash,
+                                                         const uint *__restrict__ keyStart,
+                                                         const int *__restrict__ members, int N,
+                                                         uint *__restrict__ sortHash, int *__restrict__ index,
+                                                         float4 *__restrict__ sortPos) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const uint h = hash[i];
+  const uint s = keyStart[h], e = keyStart[h + 1];
+  uint rank = 0;
+  for (uint m = s; m < e; ++m) rank += (members[m] < i) ? 1u : 0u;
+  const uint dst = s + rank;
+  sortHash[dst] = h;
+  index[dst] = i;
+  sortPos[dst] = pos[i];
+}
+
+// Cell tables from keyStart: one thread per cell (linear index).  Non-empty: start + VALID_CELL;
+// empty: 0 (< VALID_CELL).  The reference leaves stale values in empty cells; both mean "empty".
+__global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__ keyStart, int3 cellDim, uint validCell,
+                                                        uint *__restrict__ cellStart, int *__restrict__ cellEnd) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int ncells = cellDim.x * cellDim.y * cellDim.z;
+  if (c >= ncells) return;
+  int3 cc;
+  cc.x = c % cellDim.x;
+  cc.y = (c / cellDim.x) % cellDim.y;
+  cc.z = c / (cellDim.x * cellDim.y);
+  const uint h = morton_hash(cc);
+  const uint s = keyStart[h], e = keyStart[h + 1];
+  cellStart[c] = (e > s) ? s + validCell : 0u;
+  cellEnd[c] = (int)e;
+}
+
+// Radix path: K3 + K4 fused.  One thread per sorted slot; the previous particle's cell comes from a
+// wave shuffle (lane 0 recomputes it).
+__global__ void __launch_bounds__(kBlock) k_reorder_fill(const float4 *__restrict__ pos, const int *__restrict__ index,
+                                                         int N, GridT<float> grid, uint validCell,
+                                                         float4 *__restrict__ sortPos, uint *__restrict__ cellStart,
+                                                         int *__restrict__ cellEnd, int *__restrict__ errorFlag) {
+  const int id = blockIdx.x * kBlock + threadIdx.x;
+  const bool active = id < N;
+  float4 p = make_float4(0, 0, 0, 0);
+  uint icell = 0;
+  if (active) {
+    p = pos[index[id]];
+    sortPos[id] = p;
+    icell = (uint)grid.getCellIndex(grid.getCell(real3f{p.x, p.y, p.z}));
+  }
+  uint icell2 = __shfl_up(icell, 1, 64);
+  if (!active) return;
+  if ((threadIdx.x & 63) == 0) {
+    if (id > 0) {
+      const float4 q = pos[index[id - 1]];
+      icell2 = (uint)grid.getCellIndex(grid.getCell(real3f{q.x, q.y, q.z}));
+    } else
+      icell2 = 0;
+  }
+  const uint ncells = (uint)grid.getNumberCells();
+  if (icell >= ncells || icell2 >= ncells) {
+    errorFlag[0] = 1;
+    return;
+  }
+  if (icell != icell2 || id == 0) {
+    cellStart[icell] = (uint)id + validCell;
+    if (id > 0) cellEnd[icell2] = id;
+  }
+  if (id == N - 1) cellEnd[icell] = N;
+}
+
+// keyStart from sorted keys (radix path): keyStart[h] = first sorted index with key >= h.
+__global__ void __launch_bounds__(kBlock) k_key_start_from_sorted(const uint *__restrict__ sortHash, int N, uint nkeys,
+                                                                  uint *__restrict__ keyStart) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > N) return;
+  const uint lo = (i == 0) ? 0u : sortHash[i - 1] + 1u;
+  const uint hi = (i == N) ? nkeys : sortHash[i];  // inclusive upper key that starts at i
+  for (uint h = lo; h <= hi && h <= nkeys; ++h) keyStart[h] = (uint)i;
+}
+
+__global__ void __launch_bounds__(kBlock) k_iota(int *__restrict__ v, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+template <int BYTES> struct Elem { char b[BYTES]; };
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_gather(const T *__restrict__ in, const int *__restrict__ index,
+                                                   T *__restrict__ out, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = in[index[i]];
+}
+
+static inline int nblocks(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// ---- CellList ------------------------------------------------------------------------------------
+int CellList::next_valid_cell(int numberParticles, bool *needsClear) {
+  // CellListBase::updateCurrentValidCell, CellListBase.cuh:210-230
+  if (numberParticles != lastN) validCounter = -1;
+  const bool uninit = validCounter < 0;
+  const unsigned long long nextMax = (unsigned long long)numberParticles * (unsigned long long)(validCounter + 2);
+  const unsigned long long maxStorable = (unsigned long long)std::numeric_limits<uint>::max() - 1ull;
+  if (uninit || nextMax >= maxStorable) {
+    validCell = (uint)numberParticles;
+    validCounter = 1;
+    *needsClear = true;
+  } else {
+    validCounter++;
+    validCell = (uint)numberParticles * (uint)validCounter;
+    *needsClear = false;
+  }
+  lastN = numberParticles;
+  return 0;
+}
+
+int CellList::update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3],
+                     const int cellDim_[3], hipStream_t st) {
+  if (numberParticles < 0 || cellDim_[0] <= 0 || cellDim_[1] <= 0 || cellDim_[2] < 0) {
+    set_last_error("CellList encountered an invalid grid and/or cutoff (N=%d cellDim=%d %d %d)", numberParticles,
+                   cellDim_[0], cellDim_[1], cellDim_[2]);
+    return -2;
+  }
+  const BoxT<float> box = make_box<float>(L, periodic);
+  grid = make_grid<float>(box, make_int3(cellDim_[0], cellDim_[1], cellDim_[2]));
+  for (int k = 0; k < 3; ++k) { boxL[k] = L[k]; boxPeriodic[k] = periodic[k] != 0; }
+  const int N = numberParticles;
+  const long long ncells = (long long)grid.cellDim.x * grid.cellDim.y * grid.cellDim.z;
+  if (ncells > (1ll << 30)) {
+    set_last_error("CellList: too many cells (%lld)", ncells);
+    return -2;
+  }
+  bool needsClear = false;
+  const bool cellsResized = (long long)nCellsAlloc != ncells;
+  next_valid_cell(N, &needsClear);
+  if (int e = cellStart.reserve(sizeof(uint) * (size_t)ncells)) return e;
+  if (int e = cellEnd.reserve(sizeof(int) * (size_t)ncells)) return e;
+  if (cellsResized || needsClear) UH_CHECK(hipMemsetAsync(cellStart.ptr, 0, sizeof(uint) * (size_t)ncells, st));
+  nCellsAlloc = (int)ncells;
+  if (int e = hash.reserve(sizeof(uint) * (size_t)(N + 1))) return e;
+  if (int e = sortHash.reserve(sizeof(uint) * (size_t)(N + 1))) return e;
+  if (int e = index.reserve(sizeof(int) * (size_t)(N + 1))) return e;
+  if (int e = sortPos.reserve(sizeof(float4) * (size_t)(N + 1))) return e;
+  if (int e = errorFlag.reserve(sizeof(int))) return e;
+  numberParticlesBuilt = N;
+
+  const uint maxHash = morton_hash(make_int3(grid.cellDim.x - 1, grid.cellDim.y - 1, grid.cellDim.z - 1));
+  endBit = sort_end_bit(maxHash);
+  nKeys = (endBit >= 31) ? 0u : (1u << endBit);  // number of distinct keys the grid can produce (pow2 envelope)
+  if (N == 0) return 0;
+  UH_CHECK(hipMemsetAsync(errorFlag.ptr, 0, sizeof(int), st));
+
+  // Counting-sort build when the key table is comparable to the particle count.
+  const bool counting = forceRadix ? false : (nKeys != 0 && (unsigned long long)nKeys <= 8ull * (unsigned long long)N + 4096ull);
+  usedCounting = counting;
+  if (counting) {
+    if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
+    if (int e = keyCount.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
+    if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
+    if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
+    UH_CHECK(hipMemsetAsync(keyCount.ptr, 0, sizeof(uint) * ((size_t)nKeys + 1), st));
+    hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
+                       (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr);
+    size_t tmpBytes = 0;
+    UH_CHECK(rocprim::exclusive_scan(nullptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
+                                     (size_t)nKeys + 1, rocprim::plus<uint>(), st));
+    if (int e = scratch.reserve(tmpBytes)) return e;
+    UH_CHECK(rocprim::exclusive_scan(scratch.ptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
+                                     (size_t)nKeys + 1, rocprim::plus<uint>(), st));
+    hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
+                       (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr);
+    hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const uint *)hash.ptr,
+                       (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
+                       (int *)index.ptr, (float4 *)sortPos.ptr);
+    hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
+                       grid.cellDim, validCell, (uint *)cellStart.ptr, (int *)cellEnd.ptr);
+  } else {
+    if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
+    hipLaunchKernelGGL(k_hash<false>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
+                       (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, (int *)errorFlag.ptr);
+    if (endBit > 0) {
+      size_t tmpBytes = 0;
+      UH_CHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, (uint *)hash.ptr, (uint *)sortHash.ptr,
+                                         (int *)indexAlt.ptr, (int *)index.ptr, (size_t)N, 0u, (unsigned)endBit, st));
+      if (int e = scratch.reserve(tmpBytes)) return e;
+      UH_CHECK(rocprim::radix_sort_pairs(scratch.ptr, tmpBytes, (uint *)hash.ptr, (uint *)sortHash.ptr,
+                                         (int *)indexAlt.ptr, (int *)index.ptr, (size_t)N, 0u, (unsigned)endBit, st));
+    } else {
+      UH_CHECK(hipMemcpyAsync(sortHash.ptr, hash.ptr, sizeof(uint) * (size_t)N, hipMemcpyDeviceToDevice, st));
+      UH_CHECK(hipMemcpyAsync(index.ptr, indexAlt.ptr, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(k_reorder_fill, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const int *)index.ptr, N, grid,
+                       validCell, (float4 *)sortPos.ptr, (uint *)cellStart.ptr, (int *)cellEnd.ptr,
+                       (int *)errorFlag.ptr);
+    if (nKeys != 0 && nKeys <= (1u << 27)) {
+      if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
+      hipLaunchKernelGGL(k_key_start_from_sorted, dim3(nblocks(N + 1)), dim3(kBlock), 0, st,
+                         (const uint *)sortHash.ptr, N, nKeys, (uint *)keyStart.ptr);
+      haveKeyStart = true;
+    } else
+      haveKeyStart = false;
+  }
+  if (counting) haveKeyStart = true;
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+// ---- C ABI -----------------------------------------------------------------------------------------
+extern "C" {
+
+int uammd_hip_abi_version(void) { return UAMMD_HIP_ABI_VERSION; }
+const char *uammd_hip_last_error(void) { return g_last_error; }
+
+int uammd_hip_device_count(int *count) {
+  UH_CHECK(hipGetDeviceCount(count));
+  return 0;
+}
+int uammd_hip_set_device(int device) {
+  UH_CHECK(hipSetDevice(device));
+  return 0;
+}
+
+int uammd_celllist_create(uammd_celllist **out) {
+  if (!out) { set_last_error("uammd_celllist_create: null output"); return -1; }
+  *out = reinterpret_cast<uammd_celllist *>(new CellList());
+  return 0;
+}
+int uammd_celllist_destroy(uammd_celllist *h) {
+  delete reinterpret_cast<CellList *>(h);
+  return 0;
+}
+
+int uammd_celllist_create_grid(const float L_in[3], const int periodic_in[3], const float cutOff[3],
+                               int cellDim_out[3], float L_out[3], int periodic_out[3]) {
+  // Behaviour of CellList::createUpdateGrid (Interactor/NeighbourList/CellList.cuh:100-126)
+  const float inf = std::numeric_limits<float>::max();
+  for (int k = 0; k < 3; ++k) {
+    float L = L_in[k];
+    const bool inputPeriodic = periodic_in[k] && !(L == 0.0f || std::isinf(L));
+    if (L >= inf) L = 64 * cutOff[k];
+    L_out[k] = L;
+    periodic_out[k] = (inputPeriodic && L < inf) ? 1 : 0;
+    int cd = (int)(L / cutOff[k]);  // Grid(Box, real3 minCellSize): C truncation in float
+    if (k == 2 && cd == 0) cd = 1;
+    if (cd <= 3) cd = 1;
+    cellDim_out[k] = cd;
+  }
+  return 0;
+}
+
+int uammd_celllist_update(uammd_celllist *h, const float *d_pos, int numberParticles, const float L[3],
+                          const int periodic[3], const int cellDim[3], void *stream) {
+  if (!h) { set_last_error("uammd_celllist_update: null handle"); return -1; }
+  return reinterpret_cast<CellList *>(h)->update(reinterpret_cast<const float4 *>(d_pos), numberParticles, L,
+                                                 periodic, cellDim, (hipStream_t)stream);
+}
+
+int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_celllist_set_option: null argument"); return -1; }
+  CellList *cl = reinterpret_cast<CellList *>(h);
+  if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
+  set_last_error("uammd_celllist_set_option: unknown option %s", name);
+  return -1;
+}
+
+int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out) {
+  if (!h || !out) { set_last_error("uammd_celllist_get: null argument"); return -1; }
+  CellList *cl = reinterpret_cast<CellList *>(h);
+  out->d_cellStart = (const unsigned int *)cl->cellStart.ptr;
+  out->d_cellEnd = (const int *)cl->cellEnd.ptr;
+  out->d_sortPos = (const float *)cl->sortPos.ptr;
+  out->d_groupIndex = (const int *)cl->index.ptr;
+  out->d_sortHash = (const unsigned int *)cl->sortHash.ptr;
+  out->cellDim[0] = cl->grid.cellDim.x; out->cellDim[1] = cl->grid.cellDim.y; out->cellDim[2] = cl->grid.cellDim.z;
+  for (int k = 0; k < 3; ++k) { out->boxSize[k] = cl->boxL[k]; out->periodic[k] = cl->boxPeriodic[k]; }
+  out->VALID_CELL = cl->validCell;
+  out->numberParticles = cl->numberParticlesBuilt;
+  return 0;
+}
+
+int uammd_sort_pairs(unsigned int *d_keys, int *d_values, int n, int end_bit, void *stream) {
+  if (n <= 1 || end_bit <= 0) return 0;
+  if (end_bit > 32) end_bit = 32;
+  hipStream_t st = (hipStream_t)stream;
+  // Stable LSD radix sort on [0,end_bit) — the contract of the SortPairs call at
+  // utils/ParticleSorter.cuh:316-320.  Temporary storage is per call (stream ordered).
+  uint *keysAlt = nullptr;
+  int *valsAlt = nullptr;
+  void *tmp = nullptr;
+  UH_CHECK(hipMallocAsync((void **)&keysAlt, sizeof(uint) * (size_t)n, st));
+  UH_CHECK(hipMallocAsync((void **)&valsAlt, sizeof(int) * (size_t)n, st));
+  size_t tmpBytes = 0;
+  UH_CHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, d_keys, keysAlt, d_values, valsAlt, (size_t)n, 0u,
+                                     (unsigned)end_bit, st));
+  UH_CHECK(hipMallocAsync(&tmp, tmpBytes ? tmpBytes : 16, st));
+  UH_CHECK(rocprim::radix_sort_pairs(tmp, tmpBytes, d_keys, keysAlt, d_values, valsAlt, (size_t)n, 0u,
+                                     (unsigned)end_bit, st));
+  UH_CHECK(hipMemcpyAsync(d_keys, keysAlt, sizeof(uint) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  UH_CHECK(hipMemcpyAsync(d_values, valsAlt, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  UH_CHECK(hipFreeAsync(tmp, st));
+  UH_CHECK(hipFreeAsync(keysAlt, st));
+  UH_CHECK(hipFreeAsync(valsAlt, st));
+  return 0;
+}
+
+int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(nblocks(n)), b(kBlock);
+  switch (elem_bytes) {
+    case 4: hipLaunchKernelGGL(k_gather<uint>, g, b, 0, st, (const uint *)d_in, d_index, (uint *)d_out, n); break;
+    case 8: hipLaunchKernelGGL(k_gather<uint2>, g, b, 0, st, (const uint2 *)d_in, d_index, (uint2 *)d_out, n); break;
+    case 12: hipLaunchKernelGGL(k_gather<Elem<12>>, g, b, 0, st, (const Elem<12> *)d_in, d_index, (Elem<12> *)d_out, n); break;
+    case 16: hipLaunchKernelGGL(k_gather<uint4>, g, b, 0, st, (const uint4 *)d_in, d_index, (uint4 *)d_out, n); break;
+    default: set_last_error("uammd_gather: unsupported element size %d", elem_bytes); return -1;
+  }
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream) {
+  UH_CHECK(hipMemsetAsync(d_ptr, 0, bytes, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

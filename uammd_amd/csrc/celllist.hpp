@@ -1,0 +1,46 @@
+// Host-side state of one cell list (owned through the opaque uammd_celllist handle).
+#pragma once
+#include "device_common.hpp"
+#include "../../include/uammd_hip.h"
+
+#include <string>
+
+namespace uammd_hip {
+
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
+  ~DeviceBuffer();
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+};
+
+struct CellList {
+  // outputs (device)
+  DeviceBuffer hash, sortHash, index, indexAlt, sortPos, cellStart, cellEnd, errorFlag;
+  // counting-sort build state
+  DeviceBuffer keyCount, keyStart, provRank, members, scratch;
+  GridT<float> grid{};
+  float boxL[3] = {0, 0, 0};
+  int boxPeriodic[3] = {0, 0, 0};
+  uint validCell = 0;
+  long long validCounter = -1;
+  int lastN = -1;
+  int nCellsAlloc = -1;
+  int numberParticlesBuilt = 0;
+  int endBit = 0;
+  uint nKeys = 0;          // 2^endBit (0 if the key space is not tabulated)
+  bool haveKeyStart = false;
+  bool usedCounting = false;
+  bool forceRadix = false;  // test hook: always take the rocPRIM radix path
+
+  int next_valid_cell(int numberParticles, bool *needsClear);
+  int update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3], const int cellDim[3],
+             hipStream_t st);
+};
+
+extern thread_local char g_last_error[1024];
+
+}  // namespace uammd_hip

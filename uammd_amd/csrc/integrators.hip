@@ -1,0 +1,238 @@
+// Streaming integrator kernels for gfx950 (one thread per particle, 256-thread workgroups,
+// coalesced float4 / 3xfloat accesses; these are HBM-bound: ~132 B per particle per MD step).
+//
+// Reference behaviour:
+//   VerletNVT::GronbechJensen_ns::integrateGPU<step>   Integrator/VerletNVT/GronbechJensen.cu:28-62
+//   VerletNVT::Basic_ns::integrateGPU<step>            Integrator/VerletNVT/Basic.cu:86-114
+//   VerletNVT::Basic_ns::initialVelocities             Integrator/VerletNVT/Basic.cu:12-29
+//   BD::EulerMaruyama_ns::integrateGPU                 Integrator/BrownianDynamics.cu:119-144
+//   BDHI::FCM_ns::integrateEulerMaruyamaD              Integrator/BDHI/BDHI_FCM.cu:67-92
+// Noise streams are keyed exactly as in the reference: Saru(thread index in group, step, seed).
+#include "celllist.hpp"
+#include "saru.hpp"
+
+namespace uammd_hip {
+
+constexpr int kIB = 256;
+
+template <int STEP>
+__global__ void __launch_bounds__(kIB) k_verletnvt_gj(float4 *__restrict__ pos, float *__restrict__ vel,
+                                                      float4 *__restrict__ force, const float *__restrict__ mass,
+                                                      float defaultMass, const int *__restrict__ index, int N,
+                                                      float dt, float friction, int is2D, float noiseAmplitude,
+                                                      uint stepNum, uint seed) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  const float invMass = 1.0f / (defaultMass > 0 ? defaultMass : mass[i]);
+  float3 v = make_float3(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]);
+  const float4 f4 = force[i];
+  if (STEP == 1) {
+    Saru rng((uint)id, stepNum, seed);
+    noiseAmplitude *= 1.0f / sqrtf(invMass);
+    const float2 n01 = rng.gf(0.0f, noiseAmplitude);
+    float nz = 0.0f;
+    if (!is2D) nz = rng.gf(0.0f, noiseAmplitude).x;
+    const float gdthalfinvMass = friction * dt * 0.5f;
+    const float b = 1.0f / (1.0f + gdthalfinvMass);
+    const float a = (1.0f - gdthalfinvMass) * b;
+    float4 p = pos[i];
+    const float bdt = b * dt;
+    const float c = 0.5f * invMass * dt * b;
+    p.x = fmaf(c, fmaf(dt, f4.x, n01.x), fmaf(bdt, v.x, p.x));
+    p.y = fmaf(c, fmaf(dt, f4.y, n01.y), fmaf(bdt, v.y, p.y));
+    p.z = fmaf(c, fmaf(dt, f4.z, nz), fmaf(bdt, v.z, p.z));
+    pos[i] = p;
+    const float d = dt * 0.5f * invMass * a;
+    const float e = b * invMass;
+    v.x = fmaf(e, n01.x, fmaf(d, f4.x, a * v.x));
+    v.y = fmaf(e, n01.y, fmaf(d, f4.y, a * v.y));
+    v.z = fmaf(e, nz, fmaf(d, f4.z, a * v.z));
+    force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const float d = dt * 0.5f * invMass;
+    v.x = fmaf(d, f4.x, v.x);
+    v.y = fmaf(d, f4.y, v.y);
+    v.z = fmaf(d, f4.z, v.z);
+  }
+  if (is2D) v.z = 0.0f;
+  vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z;
+}
+
+template <int STEP>
+__global__ void __launch_bounds__(kIB) k_verletnvt_basic(float4 *__restrict__ pos, float *__restrict__ vel,
+                                                         float4 *__restrict__ force, const float *__restrict__ mass,
+                                                         float defaultMass, const int *__restrict__ index, int N,
+                                                         float dt, float friction, int is2D, float noiseAmplitude,
+                                                         uint stepNum, uint seed) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  const float invMass = 1.0f / (defaultMass > 0 ? defaultMass : mass[i]);
+  Saru rng((uint)(id + N * (STEP - 1)), stepNum, seed);
+  noiseAmplitude *= sqrtf((float)(0.5 * (double)invMass));
+  const float2 n01 = rng.gf(0.0f, noiseAmplitude);
+  const float nz = rng.gf(0.0f, noiseAmplitude).x;
+  float3 v = make_float3(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]);
+  const float4 f4 = force[i];
+  const float hdt = dt * 0.5f;
+  v.x = v.x + fmaf(fmaf(f4.x, invMass, -(friction * v.x)), hdt, n01.x);
+  v.y = v.y + fmaf(fmaf(f4.y, invMass, -(friction * v.y)), hdt, n01.y);
+  v.z = v.z + fmaf(fmaf(f4.z, invMass, -(friction * v.z)), hdt, nz);
+  if (is2D) v.z = 0.0f;
+  vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z;
+  if (STEP == 1) {
+    float4 p = pos[i];
+    p.x = fmaf(v.x, dt, p.x);
+    p.y = fmaf(v.y, dt, p.y);
+    p.z = fmaf(v.z, dt, p.z);
+    pos[i] = p;
+    force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// Basic.cu:12-29: mass ignored, iterator applied twice (reproduced on purpose), gd() = float
+// uniforms + float libm scaled in double.
+__global__ void __launch_bounds__(kIB) k_initial_velocities(float *__restrict__ vel, const int *__restrict__ index,
+                                                            float vamp, int is2D, int N, uint seed) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  Saru rng((uint)id, seed);
+  const int i = index ? index[id] : id;
+  auto gd = [&](double mean, double std, double &o0, double &o1) {
+    const double pi2 = 2.0 * 3.14159265358979323846;
+    double u0;
+    do { u0 = rng.f(); } while (u0 <= 2.2250738585072014e-308);
+    const double u1 = rng.f();
+    const double r = sqrtf((float)(-2.0 * logf((float)u0)));
+    const double theta = pi2 * u1;
+    o0 = r * sinf((float)theta) * std + mean;
+    o1 = r * cosf((float)theta) * std + mean;
+  };
+  double nx, ny, nz = 0.0, tmp;
+  gd(0.0, (double)vamp, nx, ny);
+  if (!is2D) gd(0.0, (double)vamp, nz, tmp);
+  const int idx = index ? index[i] : i;
+  vel[3 * idx] = (float)nx; vel[3 * idx + 1] = (float)ny; vel[3 * idx + 2] = (float)nz;
+}
+
+struct Shear { float3 Kx, Ky, Kz; };
+
+__global__ void __launch_bounds__(kIB) k_bd_euler_maruyama(float4 *__restrict__ pos, const int *__restrict__ index,
+                                                           const float4 *__restrict__ force, Shear K,
+                                                           float selfMobility, const float *__restrict__ radius,
+                                                           float dt, int is2D, float temperature, int N, uint stepNum,
+                                                           uint seed) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  float4 p = pos[i];
+  const float4 F = force[i];
+  const real3f R{p.x, p.y, p.z};
+  const float KRx = dot3(real3f{K.Kx.x, K.Kx.y, K.Kx.z}, R);
+  const float KRy = dot3(real3f{K.Ky.x, K.Ky.y, K.Ky.z}, R);
+  const float KRz = dot3(real3f{K.Kz.x, K.Kz.y, K.Kz.z}, R);
+  const float M = selfMobility * (radius ? (1.0f / radius[i]) : 1.0f);
+  float rx = fmaf(dt, fmaf(M, F.x, KRx), p.x);
+  float ry = fmaf(dt, fmaf(M, F.y, KRy), p.y);
+  float rz = fmaf(dt, fmaf(M, F.z, KRz), p.z);
+  if (temperature > 0) {
+    Saru rng((uint)i, stepNum, seed);
+    const float B = sqrtf(2.0f * temperature * M * dt);
+    const float2 d01 = rng.gf(0.0f, B);
+    const float dz = rng.gf(0.0f, B).x;
+    rx += d01.x; ry += d01.y; rz += dz;
+  }
+  p.x = rx;
+  p.y = ry;
+  if (!is2D) p.z = rz;
+  pos[i] = p;
+}
+
+__global__ void __launch_bounds__(kIB) k_fcm_euler_maruyama(float4 *__restrict__ pos, const int *__restrict__ index,
+                                                            const float *__restrict__ linearV, int N, float dt) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  float4 p = pos[i];
+  p.x = fmaf(linearV[3 * id], dt, p.x);
+  p.y = fmaf(linearV[3 * id + 1], dt, p.y);
+  p.z = fmaf(linearV[3 * id + 2], dt, p.z);
+  pos[i] = p;
+}
+
+static inline int nb(int n) { return (n + kIB - 1) / kIB; }
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+int uammd_verletnvt_gj(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                       const int *d_index, int N, float dt, float friction, int is2D, float noiseAmplitude,
+                       unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_verletnvt_gj: no mass array and defaultMass <= 0"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (step == 1)
+    hipLaunchKernelGGL(k_verletnvt_gj<1>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed);
+  else
+    hipLaunchKernelGGL(k_verletnvt_gj<2>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_verletnvt_basic(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass,
+                          float defaultMass, const int *d_index, int N, float dt, float friction, int is2D,
+                          float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_verletnvt_basic: no mass array and defaultMass <= 0"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (step == 1)
+    hipLaunchKernelGGL(k_verletnvt_basic<1>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed);
+  else
+    hipLaunchKernelGGL(k_verletnvt_basic<2>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_verletnvt_initial_velocities(float *d_vel, const int *d_index, float velAmplitude, int is2D, int N,
+                                       unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_initial_velocities, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, d_vel, d_index,
+                     velAmplitude, is2D, N, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_bd_euler_maruyama(float *d_pos, const int *d_index, const float *d_force, const float K[9],
+                            float selfMobility, const float *d_radius, float dt, int is2D, float temperature, int N,
+                            unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  Shear S{make_float3(0, 0, 0), make_float3(0, 0, 0), make_float3(0, 0, 0)};
+  if (K) {
+    S.Kx = make_float3(K[0], K[1], K[2]);
+    S.Ky = make_float3(K[3], K[4], K[5]);
+    S.Kz = make_float3(K[6], K[7], K[8]);
+  }
+  hipLaunchKernelGGL(k_bd_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index,
+                     (const float4 *)d_force, S, selfMobility, d_radius, dt, is2D, temperature, N, stepNum, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_linearVelocity, int N, float dt,
+                             void *stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_fcm_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index,
+                     d_linearVelocity, N, dt);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+"""Host-side mirror of the UAMMD interfaces on path A (short-range pair forces + integrators).
+
+Same names, argument meaning and error behaviour as the reference classes; all compute happens in
+libuammd_hip.so.  Citations (relative to /root/reference/src):
+  Box                          utils/Box.cuh:16-58
+  ParticleData                 ParticleData/ParticleData.cuh:161-465
+  CellList                     Interactor/NeighbourList/CellList.cuh:83-205
+  Potential.LJ                 Interactor/Potential/Potential.cuh:25-85, RadialPotential.cuh:49-154
+  PairForces                   Interactor/PairForces.cuh:23-64, PairForces.cu:43-78
+  Integrator / Interactor      Integrator/Integrator.cuh:33-125, Interactor/Interactor.cuh:56-119
+  VerletNVT.{Basic,GronbechJensen}  Integrator/VerletNVT.cuh, VerletNVT/Basic.cu, GronbechJensen.cu
+  BD.EulerMaruyama             Integrator/BrownianDynamics.cuh/.cu
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CellListData, LJPairParameters, check, f3, i3
+
+
+def current_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Xorshift128plus:
+    """System::rng() (utils/utils.h:38-115): seeds for the integrators come from next32()."""
+
+    def __init__(self, s0=12679825035178159220, s1=15438657923749336752):
+        self.s = [s0 & 0xFFFFFFFFFFFFFFFF, s1 & 0xFFFFFFFFFFFFFFFF]
+
+    def set_seed(self, s0):
+        m = 0xFFFFFFFFFFFFFFFF
+        self.s = [s0 & m, ((s0 + 15438657923749336752) & ((1 << 65) - 1)) % m]
+
+    def next(self):
+        m = 0xFFFFFFFFFFFFFFFF
+        x, y = self.s
+        self.s[0] = y
+        x ^= (x << 23) & m
+        x ^= x >> 17
+        x ^= y ^ (y >> 26)
+        self.s[1] = x
+        return (x + y) & m
+
+    def next32(self):
+        return self.next() % 0xFFFFFFFF
+
+
+class Box:
+    def __init__(self, L, periodic=(True, True, True)):
+        L = np.broadcast_to(np.asarray(L, dtype=np.float32), (3,)).copy()
+        self.boxSize = L
+        self.periodic = [bool(p) and not (l == 0 or np.isinf(l)) for p, l in zip(np.broadcast_to(periodic, (3,)), L)]
+
+    def setPeriodicity(self, x, y, z):
+        self.periodic = [self.periodic[0] and bool(x), self.periodic[1] and bool(y), self.periodic[2] and bool(z)]
+
+    def __eq__(self, o):
+        return isinstance(o, Box) and np.array_equal(self.boxSize, o.boxSize) and list(self.periodic) == list(o.periodic)
+
+
+class ParticleData:
+    """Particle properties in HBM.  pos/force are real4 (xyz + type / unused), vel is real3."""
+
+    def __init__(self, numberParticles, device="cuda", seed=0xf31337Bada55D00d):
+        self.N = int(numberParticles)
+        self.device = torch.device(device)
+        self._props = {}
+        self.rng = Xorshift128plus()
+        self.rng.set_seed(seed)
+        self._pos_write_callbacks = []
+        self.id = torch.arange(self.N, dtype=torch.int32, device=self.device)
+
+    def getNumParticles(self):
+        return self.N
+
+    def _get(self, name, width, dtype=torch.float32):
+        if name not in self._props:
+            shape = (self.N, width) if width > 1 else (self.N,)
+            self._props[name] = torch.zeros(shape, dtype=dtype, device=self.device)
+        return self._props[name]
+
+    def isAllocated(self, name):
+        return name in self._props
+
+    def getPos(self, mode="read"):
+        if mode != "read":
+            for cb in self._pos_write_callbacks:  # ParticleData::getPosWriteRequestedSignal
+                cb()
+        return self._get("pos", 4)
+
+    def getForce(self, mode="read"):
+        return self._get("force", 4)
+
+    def getVel(self, mode="read"):
+        return self._get("vel", 3)
+
+    def getEnergy(self, mode="read"):
+        return self._get("energy", 1)
+
+    def getVirial(self, mode="read"):
+        return self._get("virial", 1)
+
+    def getMass(self, mode="read"):
+        return self._get("mass", 1)
+
+    def getRadius(self, mode="read"):
+        return self._get("radius", 1)
+
+    def setPos(self, pos4):
+        p = self.getPos("write")
+        p.copy_(torch.as_tensor(np.ascontiguousarray(pos4, dtype=np.float32)).to(self.device))
+
+    def connectPosWrite(self, cb):
+        self._pos_write_callbacks.append(cb)
+
+    def sortParticles(self, box, cell_size=None):
+        """ParticleData::sortParticles (ParticleData.cuh:492-522): reorder every allocated property by the
+        Morton hash of a fine grid so that neighbours in space are neighbours in memory."""
+        lib = _lib.load()
+        pos = self._get("pos", 4)
+        cl = CellList()
+        L = box.boxSize
+        cs = cell_size if cell_size is not None else 1.5
+        cd = [max(1, min(1023, int(l / cs))) if l > 0 else 1 for l in L]
+        cl.update_grid(pos, box, cd)
+        idx = cl.group_index()
+        for name, t in list(self._props.items()):
+            out = torch.empty_like(t)
+            eb = t.element_size() * (t.shape[1] if t.dim() > 1 else 1)
+            check(lib.uammd_gather(_ptr(t), _ptr(idx), _ptr(out), self.N, eb, current_stream()))
+            self._props[name] = out
+        out = torch.empty_like(self.id)
+        check(lib.uammd_gather(_ptr(self.id), _ptr(idx), _ptr(out), self.N, 4, current_stream()))
+        self.id = out
+        for cb in self._pos_write_callbacks:
+            cb()
+
+
+class CellList:
+    """NeighbourList concept: update(box, cutoff) + transverseList (LJ fast path) + getCellList."""
+
+    def __init__(self, pd=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.uammd_celllist_create(C.byref(h)))
+        self.h = h
+        self.pd = pd
+        self.force_next_update = True
+        self.currentCutOff = None
+        self.currentBox = None
+        self.N = 0
+        if pd is not None:
+            pd.connectPosWrite(self._handle_pos_write)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_celllist_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _handle_pos_write(self):
+        self.force_next_update = True
+
+    def set_option(self, name, value):
+        check(self.lib.uammd_celllist_set_option(self.h, name.encode(), int(value)))
+
+    @staticmethod
+    def create_update_grid(box, cutoff):
+        lib = _lib.load()
+        cd, Lo, po = i3(0), f3(0), i3(0)
+        check(lib.uammd_celllist_create_grid(f3(box.boxSize), i3([int(p) for p in box.periodic]), f3(cutoff), cd, Lo, po))
+        return list(cd), Box(list(Lo), [bool(p) for p in po])
+
+    def needsRebuild(self, box, cutoff):
+        if self.force_next_update:
+            return True
+        if self.currentCutOff is None or not np.array_equal(np.broadcast_to(cutoff, (3,)), self.currentCutOff):
+            return True
+        return not (box == self.currentBox)
+
+    def update(self, box, cutoff, pos=None):
+        """CellList::update(box, cutOff, st) (CellList.cuh:149-163)."""
+        if pos is None:
+            pos = self.pd.getPos("read")
+        if self.needsRebuild(box, cutoff):
+            self.currentBox = box
+            self.currentCutOff = np.broadcast_to(np.asarray(cutoff, dtype=np.float32), (3,)).copy()
+            cd, ubox = self.create_update_grid(box, cutoff)
+            self.update_grid(pos, ubox, cd)
+            self.force_next_update = False
+
+    def update_grid(self, pos, box, cellDim):
+        """CellListBase::update(pos, N, grid, st) (CellListBase.cuh:124-140)."""
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 4
+        self.N = pos.shape[0]
+        self._pos_ref = pos
+        check(self.lib.uammd_celllist_update(self.h, _ptr(pos), self.N, f3(box.boxSize),
+                                             i3([int(p) for p in box.periodic]), i3(cellDim), current_stream()))
+
+    def getCellList(self):
+        d = CellListData()
+        check(self.lib.uammd_celllist_get(self.h, C.byref(d)))
+        return d
+
+    def _wrap(self, ptr, shape, dtype):
+        n = int(np.prod(shape))
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device="cuda")
+        # zero-copy view of library-owned device memory through __cuda_array_interface__
+        class _Raw:
+            pass
+        r = _Raw()
+        typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+        r.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(r, device="cuda")
+
+    def group_index(self):
+        d = self.getCellList()
+        return self._wrap(d.d_groupIndex, (d.numberParticles,), torch.int32)
+
+    def to_host(self):
+        """Copies the list to numpy (tests): hash, index, sortPos, cellStart, cellEnd, VALID_CELL."""
+        d = self.getCellList()
+        n = d.numberParticles
+        nc = d.cellDim[0] * d.cellDim[1] * d.cellDim[2]
+        torch.cuda.synchronize()
+        out = dict(
+            index=self._wrap(d.d_groupIndex, (n,), torch.int32).cpu().numpy(),
+            hash=self._wrap(d.d_sortHash, (n,), torch.int32).cpu().numpy().view(np.uint32),
+            sortPos=self._wrap(d.d_sortPos, (n, 4), torch.float32).cpu().numpy(),
+            cellStart=self._wrap(d.d_cellStart, (nc,), torch.int32).cpu().numpy().view(np.uint32),
+            cellEnd=self._wrap(d.d_cellEnd, (nc,), torch.int32).cpu().numpy(),
+            validCell=int(d.VALID_CELL), cellDim=np.array(list(d.cellDim), np.int32),
+            L=np.array(list(d.boxSize), np.float32), periodic=np.array(list(d.periodic), np.int32))
+        return out
+
+    def transverse_lj(self, param_table, ntypes, box, force=None, energy=None, virial=None, global_index=None,
+                      algo=0):
+        check(self.lib.uammd_lj_transverse_celllist(self.h, _ptr(param_table), int(ntypes), f3(box.boxSize),
+                                                    i3([int(p) for p in box.periodic]), _ptr(force), _ptr(energy),
+                                                    _ptr(virial), _ptr(global_index), int(algo), current_stream()))
+
+
+class Interactor:
+    """Interactor::sum(Computables, stream) (Interactor/Interactor.cuh:94-114)."""
+
+    def sum(self, force=True, energy=False, virial=False):
+        raise NotImplementedError
+
+    def updateSimulationTime(self, t):
+        pass
+
+    def updateTimeStep(self, dt):
+        pass
+
+    def updateTemperature(self, T):
+        pass
+
+    def updateBox(self, box):
+        pass
+
+
+class _LJ:
+    """Potential::LJ = Radial<LJFunctor> with BasicParameterHandler (RadialPotential.cuh, ParameterHandler.cuh)."""
+
+    class InputPairParameters:
+        def __init__(self, cutOff=2.5, sigma=1.0, epsilon=1.0, shift=False):
+            self.cutOff, self.sigma, self.epsilon, self.shift = cutOff, sigma, epsilon, shift
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.ntypes = 1
+        self.cutOff = 0.0
+        self.table = np.zeros((1, 4), np.float32)
+        self._dev = None
+
+    def setPotParameters(self, ti, tj, p):
+        self.cutOff = max(float(p.cutOff), self.cutOff)
+        new = max(self.ntypes, ti + 1, tj + 1)
+        if new != self.ntypes:
+            tmp = np.zeros((new * new, 4), np.float32)
+            for i in range(self.ntypes):
+                for j in range(self.ntypes):
+                    tmp[i + new * j] = self.table[i + self.ntypes * j]
+            self.table, self.ntypes = tmp, new
+        out = LJPairParameters()
+        check(self.lib.uammd_lj_process_pair_parameters(p.cutOff, p.sigma, p.epsilon, int(bool(p.shift)), C.byref(out)))
+        row = np.array([out.cutOff2, out.sigma2, out.epsilonDivSigma2, out.shift], np.float32)
+        self.table[ti + self.ntypes * tj] = row
+        if ti != tj:
+            self.table[tj + self.ntypes * ti] = row
+        self._dev = None
+
+    def getCutOff(self):
+        return self.cutOff
+
+    def device_table(self):
+        if self._dev is None:
+            self._dev = torch.from_numpy(self.table.copy()).cuda()
+        return self._dev
+
+
+class Potential:
+    LJ = _LJ
+
+
+class PairForces(Interactor):
+    """PairForces<Potential::LJ, CellList> (PairForces.cu:43-78): neighbour list unless the box is <= 3 rc in
+    every direction, then all pairs."""
+
+    def __init__(self, pd, box, pot, nl=None, algo=0):
+        self.lib = _lib.load()
+        self.pd, self.box, self.pot, self.nl, self.algo = pd, box, pot, nl, algo
+
+    def sum(self, force=True, energy=False, virial=False):
+        pd = self.pd
+        f = pd.getForce("readwrite") if force else None
+        e = pd.getEnergy("readwrite") if energy else None
+        v = pd.getVirial("readwrite") if virial else None
+        rc = np.float32(self.pot.getCutOff())
+        L = self.box.boxSize
+        useNL = not (L[0] <= 3 * rc and L[1] <= 3 * rc and L[2] <= 3 * rc)
+        tbl = self.pot.device_table()
+        if useNL:
+            if self.nl is None:
+                self.nl = CellList(pd)
+            self.nl.update(self.box, rc)
+            self.nl.transverse_lj(tbl, self.pot.ntypes, self.box, f, e, v, None, self.algo)
+        else:
+            check(self.lib.uammd_lj_transverse_nbody(_ptr(pd.getPos("read")), pd.N, _ptr(tbl), self.pot.ntypes,
+                                                     f3(L), i3([int(p) for p in self.box.periodic]), _ptr(f), _ptr(e),
+                                                     _ptr(v), None, current_stream()))
+
+
+class Integrator:
+    """Integrator::forwardTime / addInteractor (Integrator/Integrator.cuh:72-125)."""
+
+    def __init__(self, pd):
+        self.pd = pd
+        self.lib = _lib.load()
+        self.interactors = []
+        self.steps = 0
+
+    def addInteractor(self, it):
+        self.interactors.append(it)
+
+    def getInteractors(self):
+        return self.interactors
+
+    def forwardTime(self):
+        raise NotImplementedError
+
+
+class _VerletNVTBasic(Integrator):
+    kind = "basic"
+
+    class Parameters:
+        def __init__(self, temperature=0.0, dt=0.0, friction=1.0, is2D=False, initVelocities=True, mass=-1.0):
+            self.temperature, self.dt, self.friction = temperature, dt, friction
+            self.is2D, self.initVelocities, self.mass = is2D, initVelocities, mass
+
+    def __init__(self, pd, par):
+        super().__init__(pd)
+        rng = pd.rng
+        rng.next32(); rng.next32()                       # Basic.cu:36-38
+        self.seed = rng.next32()
+        self.dt, self.temperature, self.friction, self.is2D = par.dt, par.temperature, par.friction, par.is2D
+        self.noiseAmplitude = math.sqrt(2 * par.dt * par.friction * par.temperature)
+        useDefaultMass = not pd.isAllocated("mass")
+        self.defaultMass = par.mass
+        if useDefaultMass and self.defaultMass < 0:
+            self.defaultMass = 1.0
+        if par.initVelocities:
+            self.initVelocities()
+
+    def initVelocities(self):
+        vel = self.pd.getVel("write")
+        vamp = math.sqrt(3.0 * self.temperature)
+        check(self.lib.uammd_verletnvt_initial_velocities(_ptr(vel), None, vamp, int(self.is2D), self.pd.N,
+                                                          self.pd.rng.next32(), current_stream()))
+
+    def _mass(self):
+        return None if self.defaultMass > 0 else self.pd.getMass("read")
+
+    def _integrate(self, step):
+        pd = self.pd
+        fn = self.lib.uammd_verletnvt_gj if self.kind == "gj" else self.lib.uammd_verletnvt_basic
+        check(fn(step, _ptr(pd.getPos("readwrite")), _ptr(pd.getVel("readwrite")), _ptr(pd.getForce("read")),
+                 _ptr(self._mass()), self.defaultMass, None, pd.N, self.dt, self.friction, int(self.is2D),
+                 self.noiseAmplitude, self.steps, self.seed, current_stream()))
+
+    def forwardTime(self):
+        for it in self.interactors:
+            it.updateSimulationTime(self.steps * self.dt)
+        self.steps += 1
+        if self.steps == 1:
+            self.pd.getForce("write").zero_()
+            for it in self.interactors:
+                it.updateTemperature(self.temperature)
+                it.updateTimeStep(self.dt)
+            for it in self.interactors:
+                it.sum(force=True)
+        self._integrate(1)
+        for it in self.interactors:
+            it.sum(force=True)
+        self._integrate(2)
+
+
+class _VerletNVTGJ(_VerletNVTBasic):
+    kind = "gj"
+
+
+class VerletNVT:
+    Basic = _VerletNVTBasic
+    GronbechJensen = _VerletNVTGJ
+
+
+class _BDEulerMaruyama(Integrator):
+    class Parameters:
+        def __init__(self, temperature=0.0, viscosity=1.0, hydrodynamicRadius=-1.0, dt=0.0, is2D=False, K=None):
+            self.temperature, self.viscosity, self.hydrodynamicRadius = temperature, viscosity, hydrodynamicRadius
+            self.dt, self.is2D, self.K = dt, is2D, K
+
+    def __init__(self, pd, par):
+        super().__init__(pd)
+        self.par = par
+        self.seed = pd.rng.next32()
+        self.selfMobility = 1.0 / (6.0 * math.pi * par.viscosity)   # BrownianDynamics.cu:12-20
+        self.radius_from_pd = False
+        if par.hydrodynamicRadius != -1.0:
+            self.selfMobility /= par.hydrodynamicRadius
+        elif pd.isAllocated("radius"):
+            self.radius_from_pd = True
+
+    def forwardTime(self):
+        pd, par = self.pd, self.par
+        self.steps += 1
+        pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+        K = None
+        if par.K is not None:
+            K = (C.c_float * 9)(*[float(x) for x in np.asarray(par.K, dtype=np.float32).reshape(9)])
+        radius = pd.getRadius("read") if self.radius_from_pd else None
+        check(self.lib.uammd_bd_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(pd.getForce("read")), K,
+                                               self.selfMobility, _ptr(radius), par.dt, int(par.is2D),
+                                               par.temperature, pd.N, self.steps, self.seed, current_stream()))
+
+
+class BD:
+    EulerMaruyama = _BDEulerMaruyama
