@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload lj|fcm]
+
+Workload "lj" (default; BASELINE.json configs[2], the configuration the metric is quoted on):
+  1e6 Lennard-Jones particles, rho* = 0.8 (L = 107.7217345 -> 43^3 cells), r_c = 2.5 sigma,
+  VerletNVT::GronbechJensen (T = 1, friction 1, dt = 0.005), CellList rebuilt every step,
+  PairForces<LJ>.  One "step" = one integrator->forwardTime() = cell-list build + traversal +
+  two integrate kernels, exactly the reference's step.  Inputs are synthetic (jittered
+  simple-cubic lattice, seed 1234), resident in HBM before the timed region.
+
+One JSON line on stdout (rank 0).  `value` = particle-steps/s summed over all ranks.
+The `roofline` object is for the dominant kernel (the LJ traversal): achieved = algorithmic flops
+per launch / mean launch time measured with HIP events on the launch stream inside the timed loop.
+`cpu_baseline` = the oracle (CPU port of the reference algorithm; the reference has no CPU path)
+timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# SURVEY §8(d) per-unit figures for the traversal kernel (stated in DESIGN.md §roofline)
+FLOP_PER_PARTICLE = 1.0e4            # 27*12.58 ~ 340 candidate pairs x ~30 flop
+BYTES_COMPULSORY_PER_PARTICLE = 52.6  # sortPos_i + groupIndex + force RMW + tables
+BYTES_STREAMED_PER_PARTICLE = 5650.0  # 27 cells x 12.58 x 16 B + tables: what a thread-per-particle walk issues
+PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def lattice(n, L, seed, jitter=0.1):
+    from util import lattice_positions
+    return lattice_positions(n, L, seed=seed, jitter=jitter)
+
+
+def lj_setup(hip, n, L, seed, T=1.0, dt=0.005):
+    pos = lattice(n, L, seed)
+    pd = hip.ParticleData(n, seed=seed)
+    pd.setPos(pos)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+    par = hip.VerletNVT.GronbechJensen.Parameters(temperature=T, dt=dt, friction=1.0, initVelocities=True)
+    verlet = hip.VerletNVT.GronbechJensen(pd, par)
+    pf = hip.PairForces(pd, box, pot)
+    verlet.addInteractor(pf)
+    return pd, box, pot, verlet, pf, pos
+
+
+class TimedPairForces:
+    """Wraps PairForces.sum with a HIP event pair around the traversal launch (same stream)."""
+
+    def __init__(self, pf):
+        self.pf = pf
+        self.events = []
+        self.enabled = False
+        self._orig = pf.nl.transverse_lj if pf.nl is not None else None
+
+    def install(self):
+        nl = self.pf.nl
+        orig = nl.transverse_lj
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return orig(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.events.append((e0, e1))
+            return r
+
+        nl.transverse_lj = timed
+
+    def mean_ms(self):
+        if not self.events:
+            return float("nan")
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def cpu_baseline_lj(n, L, seed, sample_steps):
+    """Oracle ("port" of the reference algorithm, oracle/src/*.c, OpenMP over particles) on the host cores."""
+    import oracle
+    o = oracle.get("f32")
+    pos = lattice(n, L, seed)
+    vel = np.zeros((n, 3), np.float32)
+    force = np.zeros((n, 4), np.float32)
+    par = o.lj_params(2.5, 1.0, 1.0)
+    dt, T = 0.005, 1.0
+    noise = math.sqrt(2 * dt * T)
+
+    def forces(p):
+        cd, oL, oper = o.celllist_create_grid(L, 1, 2.5)
+        cl = o.celllist_build(p, oL, oper, cd)
+        f, _, _ = o.lj_transverse_celllist(cl, L, 1, par, 1, n)
+        return f
+
+    force = forces(pos)
+    t0 = time.perf_counter()
+    for s in range(1, sample_steps + 1):
+        o.verletnvt_gj(1, pos, vel, force, dt, 1.0, noise, s, 1234)
+        force = forces(pos)
+        o.verletnvt_gj(2, pos, vel, force, dt, 1.0, noise, s, 1234)
+    el = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return {"value": n * sample_steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_steps} full NVT steps of the same 1e6-particle LJ box (oracle: cell list single "
+                      f"thread, traversal OpenMP over {cores} threads), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--workload", default="lj", choices=["lj"])
+    ap.add_argument("--particles", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--brick-bits", type=int, default=None)
+    ap.add_argument("--algo", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    import uammd_amd as hip
+    from uammd_amd._lib import check, load
+    if args.brick_bits is not None:
+        check(load().uammd_hip_set_tunable(b"lj_brick_bits", args.brick_bits))
+
+    n = args.particles
+    L = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
+    # Multi-GPU: the LJ path shards by spatial domain; this round each rank integrates an independent
+    # replica box of the same size (weak scaling, no data-path collective) — see DESIGN.md §multi-GPU.
+    pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank)
+    pf.algo = args.algo
+    verlet.forwardTime()  # creates the neighbour list
+    timer = TimedPairForces(pf)
+    timer.install()
+
+    def run(k, timed):
+        for j in range(k):
+            if timed and j % 500 == 0:
+                pd.sortParticles()  # examples/misc/benchmark.cu:154-156
+            verlet.forwardTime()
+
+    run(args.warmup, False)
+    pd.sortParticles()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    pos = pd.getPos().cpu().numpy()
+    assert np.isfinite(pos).all(), "non finite positions after the run"
+    ms_per_step = el / args.steps * 1e3
+    value = n * world * args.steps / el
+    k_ms = timer.mean_ms()
+    achieved_tflops = FLOP_PER_PARTICLE * n / (k_ms * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic_lj_traversal.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, CellList rebuilt every step, "
+                               "VerletNVT::GronbechJensen T=1 dt=0.005 (BASELINE configs[2])",
+                   "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
+                   "parallelism": "1 process per GPU, independent replica boxes" if world > 1 else "single GPU"},
+        "pair_interactions_per_s": 52.36 * value,
+        "roofline": {"bound": "mfma", "kernel": "k_lj_brick (LJ traversal)", "achieved": achieved_tflops,
+                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+                     "traffic": traffic, "kernel_ms": k_ms,
+                     "note": "f32 VALU-bound kernel; peak = f32 vector (= f32 MFMA) peak; model 1.0e4 flop/particle",
+                     "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "hbm_frac_streamed_neighbour_model": BYTES_STREAMED_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,9 +93,10 @@ typedef struct { float cutOff2, sigma2, epsilonDivSigma2, shift; } uammd_lj_pair
 int uammd_lj_process_pair_parameters(float cutOff, float sigma, float epsilon, int shift, uammd_lj_pair_parameters *out);
 
 /* flags for `algo` */
-#define UAMMD_LJ_ALGO_AUTO 0    /* LDS-tiled brick kernel when the grid allows it, else the general one */
+#define UAMMD_LJ_ALGO_AUTO 0    /* the kernel measured fastest for the grid (currently GENERAL) */
 #define UAMMD_LJ_ALGO_GENERAL 1 /* thread-per-particle walk of the 27 cells (any grid) */
 #define UAMMD_LJ_ALGO_BRICK 2   /* force the LDS-tiled kernel (error if the grid does not allow it) */
+#define UAMMD_LJ_ALGO_QUAD 3    /* force the uniform-j (scalar-streamed neighbours) kernel */
 
 /* d_paramTable: ntypes*ntypes PairParameters indexed [ti + ntypes*tj] (ParameterHandler.cuh:17-37);
  * d_force real4[·], d_energy/d_virial real[·] are nullable and ACCUMULATED into at the particle's

@@ -74,7 +74,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos, int N, GridT<float> grid,
                                                  uint *__restrict__ hash, int *__restrict__ index,
                                                  uint *__restrict__ keyCount, uint *__restrict__ provRank,
-                                                 int *__restrict__ errorFlag) {
+                                                 int *__restrict__ errorFlag, unsigned char *__restrict__ keyOutside) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   const float4 p = pos[i];
@@ -89,6 +89,13 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
   }
   const uint h = morton_hash(c);
   hash[i] = h;
+  // Per-key flag "some particle of this cell is stored outside the primary box" (unwrapped coordinates):
+  // the uniform-j traversal may only replace the minimum-image arithmetic by a per-cell shift when the
+  // flag is clear for both cells of a pair.  Benign race: every writer stores 1.
+  if (keyOutside) {
+    const float hx = 0.5f * grid.box.boxSize.x, hy = 0.5f * grid.box.boxSize.y, hz = 0.5f * grid.box.boxSize.z;
+    if (!(p.x >= -hx && p.x < hx && p.y >= -hy && p.y < hy && p.z >= -hz && p.z < hz)) keyOutside[h] = 1;
+  }
   if (COUNT) {
     provRank[i] = atomicAdd(&keyCount[h], 1u);  // provisional rank inside the key
   } else {
@@ -125,8 +132,11 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter(const float4 *__restric
 
 // Cell tables from keyStart: one thread per cell (linear index).  Non-empty: start + VALID_CELL;
 // empty: 0 (< VALID_CELL).  The reference leaves stale values in empty cells; both mean "empty".
-__global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__ keyStart, int3 cellDim, uint validCell,
-                                                        uint *__restrict__ cellStart, int *__restrict__ cellEnd) {
+__global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__ keyStart,
+                                                        const unsigned char *__restrict__ keyOutside, int3 cellDim,
+                                                        uint validCell, uint *__restrict__ cellStart,
+                                                        int *__restrict__ cellEnd,
+                                                        unsigned char *__restrict__ cellOutside) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   const int ncells = cellDim.x * cellDim.y * cellDim.z;
   if (c >= ncells) return;
@@ -136,8 +146,11 @@ __global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__
   cc.z = c / (cellDim.x * cellDim.y);
   const uint h = morton_hash(cc);
   const uint s = keyStart[h], e = keyStart[h + 1];
-  cellStart[c] = (e > s) ? s + validCell : 0u;
-  cellEnd[c] = (int)e;
+  if (cellStart) {
+    cellStart[c] = (e > s) ? s + validCell : 0u;
+    cellEnd[c] = (int)e;
+  }
+  if (cellOutside) cellOutside[c] = keyOutside[h];
 }
 
 // Radix path: K3 + K4 fused.  One thread per sorted slot; the previous particle's cell comes from a
@@ -257,6 +270,11 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   if (N == 0) return 0;
   UH_CHECK(hipMemsetAsync(errorFlag.ptr, 0, sizeof(int), st));
 
+  const bool tabulated = nKeys != 0 && nKeys <= (1u << 27);
+  if (tabulated) {
+    if (int e = keyOutside.reserve((size_t)nKeys + 16)) return e;
+    UH_CHECK(hipMemsetAsync(keyOutside.ptr, 0, (size_t)nKeys, st));
+  }
   // Counting-sort build when the key table is comparable to the particle count.
   const bool counting = forceRadix ? false : (nKeys != 0 && (unsigned long long)nKeys <= 8ull * (unsigned long long)N + 4096ull);
   usedCounting = counting;
@@ -267,7 +285,8 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
     UH_CHECK(hipMemsetAsync(keyCount.ptr, 0, sizeof(uint) * ((size_t)nKeys + 1), st));
     hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
-                       (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr);
+                       (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr,
+                       (unsigned char *)keyOutside.ptr);
     size_t tmpBytes = 0;
     UH_CHECK(rocprim::exclusive_scan(nullptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
                                      (size_t)nKeys + 1, rocprim::plus<uint>(), st));
@@ -279,12 +298,16 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const uint *)hash.ptr,
                        (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
                        (int *)index.ptr, (float4 *)sortPos.ptr);
+    if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
     hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
-                       grid.cellDim, validCell, (uint *)cellStart.ptr, (int *)cellEnd.ptr);
+                       (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
+                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr);
+    haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
     hipLaunchKernelGGL(k_hash<false>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
-                       (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, (int *)errorFlag.ptr);
+                       (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, (int *)errorFlag.ptr,
+                       tabulated ? (unsigned char *)keyOutside.ptr : (unsigned char *)nullptr);
     if (endBit > 0) {
       size_t tmpBytes = 0;
       UH_CHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, (uint *)hash.ptr, (uint *)sortHash.ptr,
@@ -299,13 +322,20 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     hipLaunchKernelGGL(k_reorder_fill, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const int *)index.ptr, N, grid,
                        validCell, (float4 *)sortPos.ptr, (uint *)cellStart.ptr, (int *)cellEnd.ptr,
                        (int *)errorFlag.ptr);
-    if (nKeys != 0 && nKeys <= (1u << 27)) {
+    if (tabulated) {
       if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
       hipLaunchKernelGGL(k_key_start_from_sorted, dim3(nblocks(N + 1)), dim3(kBlock), 0, st,
                          (const uint *)sortHash.ptr, N, nKeys, (uint *)keyStart.ptr);
       haveKeyStart = true;
-    } else
+      if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
+      hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
+                         (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)nullptr,
+                         (int *)nullptr, (unsigned char *)cellOutside.ptr);
+      haveCellOutside = true;
+    } else {
       haveKeyStart = false;
+      haveCellOutside = false;
+    }
   }
   if (counting) haveKeyStart = true;
   UH_CHECK(hipGetLastError());

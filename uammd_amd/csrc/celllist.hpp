@@ -21,7 +21,7 @@ struct CellList {
   // outputs (device)
   DeviceBuffer hash, sortHash, index, indexAlt, sortPos, cellStart, cellEnd, errorFlag;
   // counting-sort build state
-  DeviceBuffer keyCount, keyStart, provRank, members, scratch;
+  DeviceBuffer keyCount, keyStart, provRank, members, scratch, keyOutside, cellOutside;
   GridT<float> grid{};
   float boxL[3] = {0, 0, 0};
   int boxPeriodic[3] = {0, 0, 0};
@@ -33,6 +33,7 @@ struct CellList {
   int endBit = 0;
   uint nKeys = 0;          // 2^endBit (0 if the key space is not tabulated)
   bool haveKeyStart = false;
+  bool haveCellOutside = false;
   bool usedCounting = false;
   bool forceRadix = false;  // test hook: always take the rocPRIM radix path
 

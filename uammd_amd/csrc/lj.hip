@@ -52,20 +52,103 @@ UH_D LJParams lj_lookup(const LJParams *tbl, int ntypes, int ti, int tj) {
 
 struct Acc { float fx = 0.f, fy = 0.f, fz = 0.f, e = 0.f, v = 0.f; };
 
-// One pair (compute + default accumulate).  PBC=false is only instantiated where the minimum image
-// offset is provably zero.
-template <bool PBC, bool WE, bool WV>
-UH_D void lj_pair(Acc &a, const BoxT<float> &box, const LJParams &p, const float4 &ri, const float4 &rj) {
-  real3f r12{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
+// One pair, branch free: returns |f|/r (0 outside the cut-off or at r = 0) and the pair energy.  A
+// masked pair contributes fma(0, r12, acc) == acc, bit-identical to skipping it.
+template <bool PBC, bool WE>
+UH_D void lj_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, const float4 &rj, real3f &r12,
+                  float &fm, float &e) {
+  r12 = real3f{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
   if (PBC) r12 = box.apply_pbc(r12);
   const float r2 = dot3(r12, r12);
-  if (r2 == 0.0f) return;
-  if (WE) a.e += lj_energy(r2, p);
-  const float fm = lj_force(r2, p);
+  const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
+  const float invr2 = p.sigma2 / r2;
+  const float invr6 = invr2 * invr2 * invr2;
+  const float f = p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
+  fm = in ? f : 0.0f;
+  if (WE) {
+    const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
+    e = in ? 0.5f * E : 0.0f;
+  } else
+    e = 0.0f;
+}
+
+template <bool WE, bool WV>
+UH_D void lj_acc(Acc &a, const real3f &r12, float fm, float e) {
+  if (WE) a.e += e;
   a.fx = fmaf(fm, r12.x, a.fx);
   a.fy = fmaf(fm, r12.y, a.fy);
   a.fz = fmaf(fm, r12.z, a.fz);
   if (WV) a.v += dot3(real3f{fm * r12.x, fm * r12.y, fm * r12.z}, r12);
+}
+
+// ---- two-phase pair evaluation ---------------------------------------------------------------------
+// Only ~15 % of the candidate pairs of a 27-cell walk are inside the cut-off (4.19 rc^3 of 27 rc^3),
+// and on gfx950 the IEEE division + force polynomial cost ~3x the distance test.  So each lane first
+// SCANS its candidates (distance test only) and appends the index of every candidate inside the
+// cut-off to a small per-lane FIFO in LDS; when any lane's FIFO is nearly full (wave-uniform test)
+// the wave DRAINS: every lane evaluates its queued pairs, in FIFO order.  The order of the float
+// accumulation is therefore still the reference's j order and the results stay bit-identical.
+template <class QT, int QCAP, int QSTRIDE> struct PairQueue {
+  QT *slot;  // this lane's entry 0; entry t lives at slot[t * QSTRIDE]
+  int n;
+};
+
+template <bool PBC> UH_D float lj_dist2(const BoxT<float> &box, const float4 &ri, const float4 &rj) {
+  real3f r12{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
+  if (PBC) r12 = box.apply_pbc(r12);
+  return dot3(r12, r12);
+}
+
+template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
+UH_D void lj_drain(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, const float4 *__restrict__ P, const float4 &pi,
+                   const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
+  const int n = Q.n;
+  for (int t = 0; t < n; t += 2) {
+    const int ja = (int)Q.slot[t * QSTRIDE];
+    const int jc = (int)Q.slot[min(t + 1, n - 1) * QSTRIDE];
+    const float4 ca = P[ja], cb = P[jc];
+    real3f ra, rb;
+    float fa, fb, ea, eb;
+    if (NT1) {
+      lj_eval<PBC, WE>(box, p1, pi, ca, ra, fa, ea);
+      lj_eval<PBC, WE>(box, p1, pi, cb, rb, fb, eb);
+    } else {
+      lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)ca.w), pi, ca, ra, fa, ea);
+      lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)cb.w), pi, cb, rb, fb, eb);
+    }
+    const bool mb = t + 1 < n;
+    lj_acc<WE, WV>(acc, ra, fa, ea);
+    lj_acc<WE, WV>(acc, rb, mb ? fb : 0.0f, mb ? eb : 0.0f);
+  }
+  Q.n = 0;
+}
+
+// Scans j in [jb, je) in order; rc2 = largest squared cut-off of the type table (a superset filter,
+// the drain applies the exact per-pair cut-off).  !(r2 >= rc2) keeps NaN pairs, like the reference.
+template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
+UH_D void lj_scan(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, const float4 *__restrict__ P, int jb,
+                  int je, const float4 &pi, const BoxT<float> &box, float rc2, const LJParams &p1,
+                  const LJParams *tbl, int ntypes) {
+  const int last = je - 1;
+  for (int j = jb; j < je; j += 4) {
+    if (__any(Q.n > QCAP - 4)) {  // wave-uniform; the full minimum image is exact for every queued pair
+      if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+      else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+    }
+    const float4 c0 = P[j], c1 = P[min(j + 1, last)], c2 = P[min(j + 2, last)], c3 = P[min(j + 3, last)];
+    const float d0 = lj_dist2<PBC>(box, pi, c0), d1 = lj_dist2<PBC>(box, pi, c1);
+    const float d2 = lj_dist2<PBC>(box, pi, c2), d3 = lj_dist2<PBC>(box, pi, c3);
+    if (!(d0 >= rc2)) { Q.slot[Q.n * QSTRIDE] = (QT)j; ++Q.n; }
+    if (!(d1 >= rc2) && j + 1 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 1); ++Q.n; }
+    if (!(d2 >= rc2) && j + 2 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 2); ++Q.n; }
+    if (!(d3 >= rc2) && j + 3 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 3); ++Q.n; }
+  }
+}
+
+UH_D float lj_max_cutoff2(const LJParams *tbl, int ntypes) {
+  float m = 0.0f;
+  for (int t = 0; t < ntypes * ntypes; ++t) m = fmaxf(m, tbl[t].cutOff2);
+  return m;
 }
 
 struct ListView {
@@ -75,6 +158,7 @@ struct ListView {
   const int *groupIndex;
   const uint *sortHash;
   const uint *keyStart;
+  const unsigned char *cellOutside;  // per linear cell: some particle stored outside the primary box (nullable)
   uint validCell;
   int N;
 };
@@ -96,47 +180,77 @@ UH_D void write_out(const Outputs &o, int ori, const Acc &a) {
   if (o.virial) o.virial[ori] += a.v;
 }
 
+constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
+constexpr int kQCapBrick = 32;    // per-lane FIFO depth of the brick kernel (ushort LDS indices)
+
 // ---- general walk (also the in-kernel fallback of the brick kernel) ------------------------------
-template <bool NT1, bool WE, bool WV>
-UH_D void walk_global(Acc &acc, const ListView &cl, const GridT<float> &grid, const BoxT<float> &box,
-                      const LJParams *tbl, int ntypes, const LJParams &p1, const float4 &pi) {
+template <bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
+UH_D void walk_global(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, const ListView &cl, const GridT<float> &grid,
+                      const BoxT<float> &box, const LJParams *tbl, int ntypes, const LJParams &p1, float rc2,
+                      const float4 &pi) {
   const int3 n = grid.cellDim;
   const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
   const int numberNeighbourCells = npx * npy * npz;
   const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  // The minimum image is the identity (offset 0, r + 0*L == r) for a pair whose two particles are stored
+  // inside the primary box and whose cells are direct (unwrapped) neighbours on a grid with >= 5 cells
+  // per dimension: then |d| <= 2 cells <= 0.4 L and floor(d*(-1/L)+0.5) == 0 exactly.  Skipping it is
+  // decided per neighbour cell for the whole wave (ballot), so the code stays convergent.
+  const bool sameBox = box.boxSize.x == grid.box.boxSize.x && box.boxSize.y == grid.box.boxSize.y &&
+                       box.boxSize.z == grid.box.boxSize.z && box.px() == grid.box.px() &&
+                       box.py() == grid.box.py() && box.pz() == grid.box.pz();
+  const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5 || !cl.cellOutside || !sameBox;
+  const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
+  const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
+  bool drainPBC = false;
   for (int cc = 0; cc < numberNeighbourCells; ++cc) {
     int3 cellj = celli;
     if (npx > 1) cellj.x += cc % 3 - 1;
     if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
     if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    const int3 raw = cellj;
     cellj.x = grid.pbc_x(cellj.x);
     cellj.y = grid.pbc_y(cellj.y);
     cellj.z = grid.pbc_z(cellj.z);
     // outside a non periodic box: no such cell (see DESIGN.md "non-periodic neighbours")
-    if (cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z) continue;
-    const int icellj = grid.getCellIndex(cellj);
-    const uint cs = cl.cellStart[icellj];
-    if (cs < cl.validCell) continue;
-    const int first = (int)(cs - cl.validCell), last = cl.cellEnd[icellj];
-    for (int j = first; j < last; ++j) {
-      const float4 pj = cl.sortPos[j];
-      if (NT1) lj_pair<true, WE, WV>(acc, box, p1, pi, pj);
-      else lj_pair<true, WE, WV>(acc, box, lj_lookup(tbl, ntypes, (int)pi.w, (int)pj.w), pi, pj);
+    const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+    int first = 0, last = 0;
+    bool needPBC = false;
+    if (exists) {
+      const int icellj = grid.getCellIndex(cellj);
+      const uint cs = cl.cellStart[icellj];
+      if (cs >= cl.validCell) {
+        first = (int)(cs - cl.validCell);
+        last = cl.cellEnd[icellj];
+        const bool wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
+        needPBC = smallGrid || iOut || wrapped || cl.cellOutside[icellj] != 0;
+      }
+    }
+    if (__any(needPBC)) {
+      drainPBC = true;
+      lj_scan<true, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
+    } else {
+      lj_scan<false, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
     }
   }
+  if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, cl.sortPos, pi, box, p1, tbl, ntypes);
+  else lj_drain<false, NT1, WE, WV>(acc, Q, cl.sortPos, pi, box, p1, tbl, ntypes);
 }
 
 template <bool NT1, bool WE, bool WV>
 __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> grid, BoxT<float> box,
                                                      const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
+  __shared__ uint gq[kQCapGeneral * 128];
   const int id = blockIdx.x * 128 + threadIdx.x;
   if (id >= cl.N) return;
   const int gi = cl.groupIndex[id];
   const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
   const float4 pi = cl.sortPos[id];
   LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  PairQueue<uint, kQCapGeneral, 128> Q{gq + threadIdx.x, 0};
   Acc acc;
-  walk_global<NT1, WE, WV>(acc, cl, grid, box, tbl, ntypes, p1, pi);
+  walk_global<NT1, WE, WV>(acc, Q, cl, grid, box, tbl, ntypes, p1, rc2, pi);
   write_out(out, ori, acc);
 }
 
@@ -148,8 +262,43 @@ template <int K> struct Brick {
   static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
   static constexpr int NH = HX * HY * HZ;
   static constexpr int NCELL = 1 << K;
-  static constexpr int THREADS = (K == 3) ? 128 : 256;
+  // ~12.6 particles per cell at liquid density: 2^K cells -> 101/201/403/805 i-particles per brick
+  static constexpr int THREADS = (K == 3) ? 128 : (K == 4) ? 256 : (K == 5) ? 512 : 1024;
 };
+
+// Flat walk of the 9 rows of one i-particle from the LDS tile.  Every lane keeps its own (row, j)
+// cursor, so lanes whose rows have different lengths do not wait for each other at row ends; the wave
+// only reconverges for the queue drains.  Rows are multiples of 4 slots (cells are padded with +inf
+// dummies), so the body needs no tail handling.  `d < rc2` (not !(d >= rc2)): dummies and NaN fail.
+template <class Bk, bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
+UH_D void brick_walk(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool active, const float4 *__restrict__ spos,
+                     const int *__restrict__ off, int cbase, const float4 &pi, const BoxT<float> &box, float rc2,
+                     const LJParams &p1, const LJParams *stbl, int ntypes) {
+  int r = -1, j = 0, je = 0;
+  bool more = active;
+  while (__any(more)) {
+    if (more) {
+      while (j == je) {  // next non-empty row
+        if (++r == 9) { more = false; break; }
+        const int c0 = cbase + Bk::HX * ((r % 3) + Bk::HY * (r / 3));
+        j = off[c0];
+        je = off[c0 + 3];
+      }
+    }
+    if (__any(Q.n > QCAP - 4)) lj_drain<PBC, NT1, WE, WV>(acc, Q, spos, pi, box, p1, stbl, ntypes);
+    if (more) {
+      const float4 c0 = spos[j], c1 = spos[j + 1], c2 = spos[j + 2], c3 = spos[j + 3];
+      const float d0 = lj_dist2<PBC>(box, pi, c0), d1 = lj_dist2<PBC>(box, pi, c1);
+      const float d2 = lj_dist2<PBC>(box, pi, c2), d3 = lj_dist2<PBC>(box, pi, c3);
+      if (d0 < rc2) { Q.slot[Q.n * QSTRIDE] = (QT)j; ++Q.n; }
+      if (d1 < rc2) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 1); ++Q.n; }
+      if (d2 < rc2) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 2); ++Q.n; }
+      if (d3 < rc2) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 3); ++Q.n; }
+      j += 4;
+    }
+  }
+  lj_drain<PBC, NT1, WE, WV>(acc, Q, spos, pi, box, p1, stbl, ntypes);
+}
 
 constexpr int kMaxTypesLds = 8;  // type tables up to 8x8 are cached in LDS by the brick kernel
 
@@ -163,8 +312,10 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   float4 *spos = reinterpret_cast<float4 *>(smem);                                   // [capacity]
   int *off = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)capacity);       // [NH+1]
   int *gstart = off + (Bk::NH + 1);                                                    // [NH]
-  int *misc = gstart + Bk::NH;                                                         // [4]: total, allInBox
-  LJParams *stbl = reinterpret_cast<LJParams *>(misc + 4);                             // [kMaxTypesLds^2] if !NT1
+  int *cnt = gstart + Bk::NH;                                                          // [NH]
+  int *misc = cnt + Bk::NH;                                                            // [4]: total, allInBox
+  LJParams *stbl = reinterpret_cast<LJParams *>(misc + 4);                             // [kMaxTypesLds^2]
+  unsigned short *queue = reinterpret_cast<unsigned short *>(stbl + kMaxTypesLds * kMaxTypesLds);  // [T*kQCapBrick]
 
   const int tid = threadIdx.x;
   const uint b = brickList ? (uint)brickList[blockIdx.x] : blockIdx.x;
@@ -194,11 +345,12 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
       c = (int)cl.keyStart[hh + 1] - s;
     }
     gstart[t] = s;
-    off[t + 1] = c;  // counts, scanned in place below
+    cnt[t] = c;
+    off[t + 1] = (c + 3) & ~3;  // padded counts (every cell occupies a multiple of 4 slots), scanned below
   }
   if (tid == 0) off[0] = 0;
   __syncthreads();
-  // 2. exclusive scan of NH (<= 216) counts: a single wave does it with shuffles.
+  // 2. exclusive scan of NH (<= 216) padded counts: a single wave does it with shuffles.
   if (tid < 64) {
     constexpr int PER = (Bk::NH + 63) / 64;
     int v[PER];
@@ -230,6 +382,7 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   __syncthreads();
   const int total = misc[0];
   const LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(stbl, ntypes);
 
   if (total > capacity) {
     // Too dense for the LDS tile (block-uniform): walk global memory like k_lj_general.
@@ -238,23 +391,29 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
       const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
       const float4 pi = cl.sortPos[i];
       Acc acc;
-      walk_global<NT1, WE, WV>(acc, cl, grid, box, tbl, ntypes, p1, pi);
+      PairQueue<uint, kQCapGeneral, T> Qg{reinterpret_cast<uint *>(smem) + tid, 0};  // the unused tile region
+      walk_global<NT1, WE, WV>(acc, Qg, cl, grid, box, tbl, ntypes, p1, rc2, pi);
       write_out(out, ori, acc);
     }
     return;
   }
 
-  // 3. stage the halo: 16-lane groups copy one cell at a time (a cell is ~13 contiguous float4).
+  // 3. stage the halo: 16-lane groups copy one cell at a time (a cell is ~13 contiguous float4) and
+  //    fill the cell's padding slots with +inf positions (r2 = inf or NaN: never inside the cut-off).
   {
     const int g = tid >> 4, l = tid & 15;
     const float hxL = 0.5f * box.boxSize.x, hyL = 0.5f * box.boxSize.y, hzL = 0.5f * box.boxSize.z;
+    const float inf = __builtin_inff();
     bool inBox = true;
     for (int t = g; t < Bk::NH; t += T / 16) {
-      const int s = gstart[t], o = off[t], c = off[t + 1] - o;
-      for (int k = l; k < c; k += 16) {
-        const float4 p = cl.sortPos[s + k];
+      const int s = gstart[t], o = off[t], c = cnt[t], cpad = off[t + 1] - o;
+      for (int k = l; k < cpad; k += 16) {
+        float4 p = make_float4(inf, inf, inf, 0.0f);
+        if (k < c) {
+          p = cl.sortPos[s + k];
+          inBox = inBox && (p.x >= -hxL && p.x < hxL && p.y >= -hyL && p.y < hyL && p.z >= -hzL && p.z < hzL);
+        }
         spos[o + k] = p;
-        inBox = inBox && (p.x >= -hxL && p.x < hxL && p.y >= -hyL && p.y < hyL && p.z >= -hzL && p.z < hzL);
       }
     }
     if (!inBox) misc[1] = 0;  // benign race: every writer stores 0
@@ -263,7 +422,8 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const bool allInBox = misc[1] != 0;
   const bool smallGrid = (n.x < 5) || (n.y < 5) || (n.z < 5);
 
-  // 4. traversal: one i-particle per lane, 9 contiguous LDS rows each.
+  // 4. traversal: one i-particle per lane; its 9 (dy,dz) rows are contiguous, 4-aligned LDS ranges that
+  //    the lane walks as ONE flat loop (no per-row reconvergence), 4 candidates per trip.
   for (int i0 = pStart + (tid & ~63); i0 < pEnd; i0 += T) {  // wave-uniform trip count
     const int i = i0 + (tid & 63);
     const bool active = i < pEnd;
@@ -281,27 +441,141 @@ k_lj_brick(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     }
     const bool needPBC = !allInBox || smallGrid || (__ballot(atFace) != 0ull);  // wave-uniform
     Acc acc;
+    PairQueue<unsigned short, kQCapBrick, T> Q{queue + tid, 0};
+    const int cbase = lx + Bk::HX * (ly + Bk::HY * lz);
+    if (needPBC) brick_walk<Bk, true, NT1, WE, WV>(acc, Q, active, spos, off, cbase, pi, box, rc2, p1, stbl, ntypes);
+    else brick_walk<Bk, false, NT1, WE, WV>(acc, Q, active, spos, off, cbase, pi, box, rc2, p1, stbl, ntypes);
     if (active) {
-      const int cbase = lx + Bk::HX * (ly + Bk::HY * lz);
+      const int gi = cl.groupIndex[i];
+      const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
+      write_out(out, ori, acc);
+    }
+  }
+}
+
+// ---- uniform-j "quad" kernel ------------------------------------------------------------------------
+// One wave owns a Morton-aligned 2x2x1 quad of cells (keys 4q..4q+3): its i-particles are one
+// contiguous range of sortPos (~50 of 64 lanes at liquid density).  The wave then streams the 4x4x3
+// block of cells around the quad in the reference's order (z, y, x ascending; particles ascending).
+// The candidate j is WAVE-UNIFORM: its position is fetched by the scalar unit (s_load) and used as
+// an SGPR operand, the loop control is scalar, and each lane pays only 3 subs + 3 FMAs + 1 compare
+// per candidate; lanes whose own cell is not a neighbour of the j-cell are masked.  Candidates
+// inside the cut-off are appended to the lane's FIFO and evaluated later in FIFO order (lj_drain),
+// so every lane still accumulates exactly the reference's sequence of pairs.
+// Minimum image: when every particle of the i-lanes and of the j-cell lies in the primary box and
+// the grid has >= 5 cells per dimension, floor(d*(-1/L)+0.5) is the same for every pair of the two
+// cells (0, or -/+1 across a face), so r = d + off*L is applied as a per-cell scalar shift — the
+// same float operations the reference performs, minus the floor.  Otherwise the full arithmetic runs.
+constexpr int kQCapQuad = 24;
+
+template <int MODE>  // 0: no image shift, 1: per-cell shift, 2: full minimum image
+UH_D float quad_dist2(const BoxT<float> &box, const float4 &ri, const float4 &rj, float sx, float sy, float sz) {
+  real3f r12{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
+  if (MODE == 1) { r12.x += sx; r12.y += sy; r12.z += sz; }
+  if (MODE == 2) r12 = box.apply_pbc(r12);
+  return dot3(r12, r12);
+}
+
+template <int MODE, bool NT1, bool WE, bool WV>
+UH_D void quad_scan(Acc &acc, PairQueue<uint, kQCapQuad, 64> &Q, bool &drainPBC, const float4 *__restrict__ P, int cs,
+                    int ce, bool mine, const float4 &pi, const BoxT<float> &box, float sx, float sy, float sz,
+                    float rc2, const LJParams &p1, const LJParams *tbl, int ntypes) {
+  const int last = ce - 1;
+  for (int s = cs; s < ce; s += 4) {  // s, cs, ce are wave-uniform
+    if (__any(Q.n > kQCapQuad - 4)) {
+      if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+      else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+    }
+    const int s1 = min(s + 1, last), s2 = min(s + 2, last), s3 = min(s + 3, last);
+    const float4 c0 = P[s], c1 = P[s1], c2 = P[s2], c3 = P[s3];
+    const float d0 = quad_dist2<MODE>(box, pi, c0, sx, sy, sz), d1 = quad_dist2<MODE>(box, pi, c1, sx, sy, sz);
+    const float d2 = quad_dist2<MODE>(box, pi, c2, sx, sy, sz), d3 = quad_dist2<MODE>(box, pi, c3, sx, sy, sz);
+    if (mine && d0 < rc2) { Q.slot[Q.n * 64] = (uint)s; ++Q.n; }
+    if (mine && d1 < rc2 && s + 1 < ce) { Q.slot[Q.n * 64] = (uint)(s + 1); ++Q.n; }
+    if (mine && d2 < rc2 && s + 2 < ce) { Q.slot[Q.n * 64] = (uint)(s + 2); ++Q.n; }
+    if (mine && d3 < rc2 && s + 3 < ce) { Q.slot[Q.n * 64] = (uint)(s + 3); ++Q.n; }
+  }
+}
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(256)
+k_lj_quad(const float4 *__restrict__ P, const uint *__restrict__ sortHash, const uint *__restrict__ keyStart,
+          const int *__restrict__ groupIndex, const unsigned char *__restrict__ keyOutside, GridT<float> grid,
+          BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, float4 *__restrict__ oForce,
+          float *__restrict__ oEnergy, float *__restrict__ oVirial, const int *__restrict__ globalIndex, uint nQuads) {
+  // every global array is a separate __restrict__ parameter so that the uniform position loads can be
+  // proven unclobbered and selected as scalar (SMEM) loads
+  __shared__ uint queue[4 * kQCapQuad * 64];
+  const Outputs out{oForce, oEnergy, oVirial, globalIndex};
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const uint q = blockIdx.x * 4u + (uint)wave;
+  if (q >= nQuads) return;
+  const uint key0 = q << 2;
+  const int pStart = (int)keyStart[key0], pEnd = (int)keyStart[key0 + 4];
+  if (pStart == pEnd) return;
+  const int x0 = (int)compact10(key0), y0 = (int)compact10(key0 >> 1), z0 = (int)compact10(key0 >> 2);
+  const int3 n = grid.cellDim;
+  const bool smallGrid = (n.x < 5) || (n.y < 5) || (n.z < 5);
+  const LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  const float hxL = 0.5f * box.boxSize.x, hyL = 0.5f * box.boxSize.y, hzL = 0.5f * box.boxSize.z;
+
+  for (int i0 = pStart; i0 < pEnd; i0 += 64) {  // one trip unless the quad holds more than 64 particles
+    const int i = i0 + lane;
+    const bool active = i < pEnd;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lx = 0, ly = 0;
+    if (active) {
+      pi = P[i];
+      const uint h = sortHash[i] - key0;
+      lx = (int)(h & 1u);
+      ly = (int)((h >> 1) & 1u);
+    }
+    const bool iIn = !active || (pi.x >= -hxL && pi.x < hxL && pi.y >= -hyL && pi.y < hyL && pi.z >= -hzL && pi.z < hzL);
+    const bool allIIn = __all(iIn) != 0;
+    bool drainPBC = false;
+    Acc acc;
+    PairQueue<uint, kQCapQuad, 64> Q{queue + wave * (kQCapQuad * 64) + lane, 0};
 #pragma unroll 1
-      for (int r = 0; r < 9; ++r) {
-        const int c0 = cbase + Bk::HX * ((r % 3) + Bk::HY * (r / 3));
-        const int jb = off[c0], je = off[c0 + 3];
-        if (needPBC) {
-          for (int j = jb; j < je; ++j) {
-            const float4 pj = spos[j];
-            if (NT1) lj_pair<true, WE, WV>(acc, box, p1, pi, pj);
-            else lj_pair<true, WE, WV>(acc, box, lj_lookup(stbl, ntypes, (int)pi.w, (int)pj.w), pi, pj);
-          }
-        } else {
-          for (int j = jb; j < je; ++j) {
-            const float4 pj = spos[j];
-            if (NT1) lj_pair<false, WE, WV>(acc, box, p1, pi, pj);
-            else lj_pair<false, WE, WV>(acc, box, lj_lookup(stbl, ntypes, (int)pi.w, (int)pj.w), pi, pj);
+    for (int dz = -1; dz <= 1; ++dz) {
+      int gz = z0 + dz;
+      float sz = 0.0f;
+      if (gz < 0) { gz += n.z; sz = -box.boxSize.z; } else if (gz >= n.z) { gz -= n.z; sz = box.boxSize.z; }
+#pragma unroll 1
+      for (int jy = -1; jy <= 2; ++jy) {
+        int gy = y0 + jy;
+        if (gy > n.y) continue;  // beyond the +1 neighbour of the last existing row
+        float sy = 0.0f;
+        if (gy < 0) { gy += n.y; sy = -box.boxSize.y; } else if (gy >= n.y) { gy -= n.y; sy = box.boxSize.y; }
+        const bool mineY = active && (jy - ly <= 1) && (ly - jy <= 1);
+#pragma unroll 1
+        for (int jx = -1; jx <= 2; ++jx) {
+          int gx = x0 + jx;
+          if (gx > n.x) continue;
+          float sx = 0.0f;
+          if (gx < 0) { gx += n.x; sx = -box.boxSize.x; } else if (gx >= n.x) { gx -= n.x; sx = box.boxSize.x; }
+          const uint hh = morton_hash(make_int3(gx, gy, gz));
+          const int cs = (int)keyStart[hh], ce = (int)keyStart[hh + 1];
+          if (cs == ce) continue;
+          const bool mine = mineY && (jx - lx <= 1) && (lx - jx <= 1);
+          const bool shiftOK = allIIn && !smallGrid && keyOutside[hh] == 0;
+          if (!shiftOK) {
+            drainPBC = true;
+            quad_scan<2, NT1, WE, WV>(acc, Q, drainPBC, P, cs, ce, mine, pi, box, 0.f, 0.f, 0.f, rc2, p1, tbl, ntypes);
+          } else if (sx != 0.0f || sy != 0.0f || sz != 0.0f) {
+            drainPBC = true;  // queued pairs of this cell need the image; the full arithmetic gives the same bits
+            quad_scan<1, NT1, WE, WV>(acc, Q, drainPBC, P, cs, ce, mine, pi, box, sx, sy, sz, rc2, p1, tbl, ntypes);
+          } else {
+            quad_scan<0, NT1, WE, WV>(acc, Q, drainPBC, P, cs, ce, mine, pi, box, 0.f, 0.f, 0.f, rc2, p1, tbl, ntypes);
           }
         }
       }
-      const int gi = cl.groupIndex[i];
+    }
+    if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+    else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+    if (active) {
+      const int gi = groupIndex[i];
       const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
       write_out(out, ori, acc);
     }
@@ -313,11 +587,14 @@ template <bool NT1, bool WE, bool WV>
 __global__ void __launch_bounds__(128) k_lj_nbody(const float4 *__restrict__ pos, int N, BoxT<float> box,
                                                    const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
   __shared__ float4 tile[128];
+  __shared__ unsigned short nq[kQCapBrick * 128];
   const int t = blockIdx.x * 128 + threadIdx.x;
   const bool active = t < N;
   const int id = active ? (out.globalIndex ? out.globalIndex[t] : t) : 0;
   const float4 pi = active ? pos[id] : make_float4(0.f, 0.f, 0.f, 0.f);
   const LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  PairQueue<unsigned short, kQCapBrick, 128> Q{nq + threadIdx.x, 0};
   Acc acc;
   const int numTiles = (N + 127) / 128;
   for (int tileIdx = 0; tileIdx < numTiles; ++tileIdx) {
@@ -326,11 +603,8 @@ __global__ void __launch_bounds__(128) k_lj_nbody(const float4 *__restrict__ pos
     __syncthreads();
     if (active) {
       const int cnt = min(128, N - tileIdx * 128);
-      for (int c = 0; c < cnt; ++c) {
-        const float4 pj = tile[c];
-        if (NT1) lj_pair<true, WE, WV>(acc, box, p1, pi, pj);
-        else lj_pair<true, WE, WV>(acc, box, lj_lookup(tbl, ntypes, (int)pi.w, (int)pj.w), pi, pj);
-      }
+      lj_scan<true, NT1, WE, WV>(acc, Q, true, tile, 0, cnt, pi, box, rc2, p1, tbl, ntypes);
+      lj_drain<true, NT1, WE, WV>(acc, Q, tile, pi, box, p1, tbl, ntypes);  // queue indices are tile-local
     }
     __syncthreads();
   }
@@ -343,8 +617,9 @@ static int launch_brick(const ListView &cl, const GridT<float> &grid, const BoxT
                         int ntypes, const Outputs &out, uint nKeys, hipStream_t st) {
   using Bk = Brick<K>;
   // LDS budget: positions + tables.  Sized for ~1.5x the mean halo population at liquid density.
-  const int ldsBytes = (K == 3) ? 24 * 1024 : (K == 4) ? 40 * 1024 : (K == 5) ? 52 * 1024 : 64 * 1024;
-  const int fixed = (int)(sizeof(int) * (2 * Bk::NH + 1 + 4) + sizeof(LJParams) * kMaxTypesLds * kMaxTypesLds + 16);
+  const int ldsBytes = (K == 3) ? 30 * 1024 : (K == 4) ? 50 * 1024 : (K == 5) ? 78 * 1024 : 140 * 1024;
+  const int fixed = (int)(sizeof(int) * (3 * Bk::NH + 1 + 4) + sizeof(LJParams) * kMaxTypesLds * kMaxTypesLds +
+                          sizeof(unsigned short) * kQCapBrick * Bk::THREADS + 16);
   const int capacity = (ldsBytes - fixed) / (int)sizeof(float4);
   const uint nBricks = (nKeys + Bk::NCELL - 1) >> K;
   auto kern = k_lj_brick<K, NT1, WE, WV>;
@@ -368,6 +643,7 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
   cl.groupIndex = (const int *)h->index.ptr;
   cl.sortHash = (const uint *)h->sortHash.ptr;
   cl.keyStart = (const uint *)h->keyStart.ptr;
+  cl.cellOutside = h->haveCellOutside ? (const unsigned char *)h->cellOutside.ptr : nullptr;
   cl.validCell = h->validCell;
   cl.N = h->numberParticlesBuilt;
   const GridT<float> &g = h->grid;
@@ -378,7 +654,24 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
                    "per dimension (cellDim = %d %d %d) and <= %d types", g.cellDim.x, g.cellDim.y, g.cellDim.z, kMaxTypesLds);
     return -3;
   }
-  if (brickOK && algo != UAMMD_LJ_ALGO_GENERAL) {
+  const bool sameBox = box.boxSize.x == g.box.boxSize.x && box.boxSize.y == g.box.boxSize.y &&
+                       box.boxSize.z == g.box.boxSize.z && box.px() && box.py() && box.pz();
+  const bool quadOK = brickOK && sameBox && h->keyOutside.ptr != nullptr;
+  if (algo == UAMMD_LJ_ALGO_QUAD && !quadOK) {
+    set_last_error("uammd_lj_transverse_celllist: the uniform-j kernel needs a fully periodic grid with >= 4 cells per "
+                   "dimension built on the same box as the potential");
+    return -3;
+  }
+  // AUTO currently resolves to the thread-per-particle kernel: measured fastest on MI355X at C2/C3
+  // (profiles/r01_lj_kernels.md); the brick and uniform-j kernels stay selectable.
+  if (quadOK && algo == UAMMD_LJ_ALGO_QUAD) {
+    const uint nQuads = h->nKeys >> 2;
+    hipLaunchKernelGGL((k_lj_quad<NT1, WE, WV>), dim3((nQuads + 3) / 4), dim3(256), 0, st, cl.sortPos, cl.sortHash,
+                       cl.keyStart, cl.groupIndex, (const unsigned char *)h->keyOutside.ptr, g, box, tbl, ntypes,
+                       out.force, out.energy, out.virial, out.globalIndex, nQuads);
+    return 0;
+  }
+  if (brickOK && algo == UAMMD_LJ_ALGO_BRICK) {
     switch (brickBits) {
       case 3: return launch_brick<3, NT1, WE, WV>(cl, g, box, tbl, ntypes, out, h->nKeys, st);
       case 4: return launch_brick<4, NT1, WE, WV>(cl, g, box, tbl, ntypes, out, h->nKeys, st);

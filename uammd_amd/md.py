@@ -121,15 +121,21 @@ class ParticleData:
     def connectPosWrite(self, cb):
         self._pos_write_callbacks.append(cb)
 
-    def sortParticles(self, box, cell_size=None):
-        """ParticleData::sortParticles (ParticleData.cuh:492-522): reorder every allocated property by the
-        Morton hash of a fine grid so that neighbours in space are neighbours in memory."""
+    def hintSortByHash(self, hash_box, hash_cutOff):
+        """ParticleData::hintSortByHash (ParticleData.cuh:389-394)."""
+        self._hint_box, self._hint_cutoff = hash_box, np.broadcast_to(np.asarray(hash_cutOff, np.float32), (3,))
+
+    def sortParticles(self):
+        """ParticleData::sortParticles (ParticleData.cuh:492-522): reorder every allocated property by the Morton
+        hash of the hint grid (default Box(128), cutOff 10: ParticleData.cuh:164-169) and emit the reorder signal."""
         lib = _lib.load()
         pos = self._get("pos", 4)
+        box = getattr(self, "_hint_box", None) or Box(128.0)
+        rc = getattr(self, "_hint_cutoff", np.full(3, 10.0, np.float32))
+        cd = [int(np.float32(l) / np.float32(c)) for l, c in zip(box.boxSize, rc)]
+        if cd[2] == 0:
+            cd[2] = 1
         cl = CellList()
-        L = box.boxSize
-        cs = cell_size if cell_size is not None else 1.5
-        cd = [max(1, min(1023, int(l / cs))) if l > 0 else 1 for l in L]
         cl.update_grid(pos, box, cd)
         idx = cl.group_index()
         for name, t in list(self._props.items()):
