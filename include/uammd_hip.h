@@ -133,6 +133,79 @@ int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_li
                              float dt, void *stream);
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Path B — Immersed Boundary spreading / interpolation on a regular grid.  Replaces
+ *   IBM<Kernel,Grid,LinearIndex3D>::spread / gather     misc/IBM.cuh:99-203
+ *   IBM_ns::particles2GridD / grid2ParticlesDTPP        misc/IBM.cu:83-147, :164-235
+ * A user-defined window functor cannot cross a C ABI; the windows UAMMD ships are selected by `kind`
+ * (generic functors go through the header template in include/uammd/misc/IBM.cuh, compiled by hipcc
+ * with the user's translation unit — same as the reference).
+ * ---------------------------------------------------------------------------------------------- */
+#define UAMMD_IBM_KERNEL_GAUSSIAN 0 /* prefactor*exp(tau r^2), 0 for r >= rmax   misc/IBM_kernels.cuh:28-40, BDHI/FCM/FCM_kernels.cuh:22-58 */
+#define UAMMD_IBM_KERNEL_PESKIN3 1  /* Peskin::threePoint                          misc/IBM_kernels.cuh:115-137 */
+#define UAMMD_IBM_KERNEL_PESKIN4 2  /* Peskin::fourPoint                           misc/IBM_kernels.cuh:140-160 */
+#define UAMMD_IBM_KERNEL_CONSTANT 3 /* phi = 1 (test/misc/ibm/test_ibm_regular.cu:11-14) */
+typedef struct {
+  int kind;
+  int support[3];
+  float prefactor, tau, rmax; /* Gaussian */
+  float invh[3];              /* Peskin: 1/h per axis */
+} uammd_ibm_kernel;
+
+/* FCM_ns::Kernels::Gaussian(h, tolerance) (BDHI/FCM/FCM_kernels.cuh:22-58), host: fills `out` and returns the
+ * effective hydrodynamic radius a = h*u(tol)*sqrt(pi) in *a_eff. */
+int uammd_fcm_gaussian_kernel(float h, float tolerance, uammd_ibm_kernel *out, float *a_eff);
+/* Kernel::adviseGridSize (FCM_kernels.cuh:47-50), host */
+float uammd_fcm_advise_grid_size(float hydrodynamicRadius, float tolerance);
+
+/* d_pos: float[posStride*N] (xyz first; posStride 3 or 4).  d_quantity / d_out: float[ncomp*N].  d_grid:
+ * float[ncomp * nxStride*ny*nz], components interleaved, node index i + nxStride*(j + ny*k)
+ * (LinearIndex3D(nxStride, ny, nz)).  spread ADDS into the grid, gather ADDS into d_out (as the reference).
+ * ncomp is 1 or 3.  A grid with cellDim[2] == 1 is treated as 2D (IBM.cuh:182-194). */
+int uammd_ibm_spread(const float *d_pos, int posStride, const float *d_quantity, int ncomp, int numberParticles,
+                     const float L[3], const int periodic[3], const int cellDim[3], int nxStride,
+                     const uammd_ibm_kernel *kernel, float *d_grid, void *stream);
+int uammd_ibm_gather(const float *d_pos, int posStride, float *d_out, int ncomp, int numberParticles,
+                     const float L[3], const int periodic[3], const int cellDim[3], int nxStride,
+                     const uammd_ibm_kernel *kernel, const float *d_grid, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Path B — Force Coupling Method (triply periodic Stokes).  Replaces
+ *   FCM_impl<Gaussian,GaussianTorque>  ctor / computeHydrodynamicDisplacements / getSelfMobility
+ *                                       Integrator/BDHI/FCM/FCM_impl.cuh:56-129, :652-693
+ *   spreadForces, forwardTransform, convolveFourier, addBrownianNoise, inverseTransform, interpolateVelocity
+ *                                       FCM_impl.cuh:245-262, :293-304, :399-411, :514-581
+ *   BDHI::FCM::computeMF                Integrator/BDHI/BDHI_FCM.cuh:131-142
+ * The solver owns its grids (3 planar padded real grids transformed in place by rocFFT).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_fcm uammd_fcm;
+typedef struct {
+  float boxSize[3];
+  int cells[3];
+  float viscosity;
+  unsigned int seed;        /* FCM_impl::Parameters::seed (0 is NOT replaced here: the C++ header draws it) */
+  uammd_ibm_kernel kernel;  /* spreading window (uammd_fcm_gaussian_kernel) */
+  float hydrodynamicRadius; /* reported by getHydrodynamicRadius / used by getSelfMobility */
+} uammd_fcm_parameters;
+int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out);
+int uammd_fcm_destroy(uammd_fcm *h);
+/* FCM_impl::computeHydrodynamicDisplacements(pos, force, torque=nullptr, N, T, prefactor, st):
+ * d_linearVelocity real3[N] is OVERWRITTEN with M F + prefactor*sqrt(2 T) M^{1/2} dW.  d_force may be NULL
+ * (noise only).  Every call with temperature > 0 advances the noise stream (the reference's static seed2). */
+int uammd_fcm_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int numberParticles,
+                            float temperature, float prefactor, float *d_linearVelocity, void *stream);
+/* Hasimoto-corrected self mobility, FCM_impl::getSelfMobility (FCM_impl.cuh:102-119), host */
+double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx);
+/* noise call counter (the reference's process-global `static uint seed2`, FCM_impl.cuh:517; per handle here) */
+int uammd_fcm_get_seed2(uammd_fcm *h, unsigned int *seed2);
+int uammd_fcm_set_seed2(uammd_fcm *h, unsigned int seed2);
+/* test hooks: run the pipeline up to the Fourier-space kernel (stage = 1; stage = 0 is the full solve) and copy the
+ * Fourier grid out as complex3[nz*ny*(nx/2+1)] = {x.re,x.im,y.re,y.im,z.re,z.im} (the reference's layout) */
+int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float *d_force, int numberParticles,
+                                   float temperature, float prefactor, float *d_linearVelocity, int stage,
+                                   void *stream);
+int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,101 @@ class Oracle:
                                      C.c_double(epsilon), _p(f))
         return f
 
+
+    # ---- path B: IBM -----------------------------------------------------------------------------
+    def ibm_kernel(self, kind, support, prefactor=0.0, tau=0.0, rmax=np.inf, invh=(0, 0, 0)):
+        """kind: 'gaussian' | 'peskin3' | 'peskin4' | 'constant' (oracle/src/ibm.c IBMKernel)."""
+        kinds = {"gaussian": 0, "peskin3": 1, "peskin4": 2, "constant": 3}
+        creal = self.creal
+
+        class K(C.Structure):
+            _fields_ = [("kind", C.c_int), ("support", C.c_int * 3), ("prefactor", creal), ("tau", creal),
+                        ("rmax", creal), ("invh", creal * 3)]
+        sup = np.broadcast_to(np.asarray(support), (3,))
+        ih = np.broadcast_to(np.asarray(invh, dtype=np.float64), (3,))
+        k = K(kinds[kind], (C.c_int * 3)(int(sup[0]), int(sup[1]), int(sup[2])), prefactor, tau, rmax,
+              (creal * 3)(float(ih[0]), float(ih[1]), float(ih[2])))
+        return k
+
+    def fcm_gaussian(self, h, tolerance):
+        """FCM_ns::Kernels::Gaussian(h, tol) -> dict(support, upsampling, width, prefactor, tau, rmax, a_eff, kernel)."""
+        out = np.zeros(6, self.real)
+        self.lib.oracle_fcm_gaussian_init.restype = C.c_int
+        sup = self.lib.oracle_fcm_gaussian_init(self.creal(h), self.creal(tolerance), _p(out))
+        d = dict(support=int(sup), upsampling=float(out[0]), width=float(out[1]), prefactor=float(out[2]),
+                 tau=float(out[3]), rmax=float(out[4]), a_eff=float(out[5]))
+        d["kernel"] = self.ibm_kernel("gaussian", sup, out[2], out[3], out[4])
+        return d
+
+    def fcm_advise_grid_size(self, a, tolerance):
+        self.lib.oracle_fcm_advise_grid_size.restype = self.creal
+        return float(self.lib.oracle_fcm_advise_grid_size(self.creal(a), self.creal(tolerance)))
+
+    def ibm_spread(self, pos, v, L, periodic, cell_dim, kernel, grid=None, nx_stride=None):
+        pos = self.r(pos)
+        v = self.r(v)
+        n = len(pos)
+        ncomp = 1 if v.ndim == 1 else v.shape[1]
+        L, per = self._box(L, periodic)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        nxs = int(cd[0]) if nx_stride is None else int(nx_stride)
+        if grid is None:
+            grid = np.zeros((int(cd[2]), int(cd[1]), nxs, ncomp), self.real)
+        self.lib.oracle_ibm_spread(_p(pos), pos.shape[1], _p(v), ncomp, n, _p(L), _p(per), _p(cd), nxs,
+                                   C.byref(kernel), _p(grid))
+        return grid
+
+    def ibm_gather(self, pos, grid, L, periodic, cell_dim, kernel, out=None, nx_stride=None):
+        pos = self.r(pos)
+        grid = self.r(grid)
+        n = len(pos)
+        ncomp = grid.shape[-1] if grid.ndim == 4 else 1
+        L, per = self._box(L, periodic)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        nxs = int(cd[0]) if nx_stride is None else int(nx_stride)
+        if out is None:
+            out = np.zeros((n, ncomp), self.real)
+        self.lib.oracle_ibm_gather(_p(pos), pos.shape[1], _p(out), ncomp, n, _p(L), _p(per), _p(cd), nxs,
+                                   C.byref(kernel), _p(grid))
+        return out
+
+    def ibm_stencil(self, pos3, L, periodic, cell_dim, kernel):
+        L, per = self._box(L, periodic)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        p = self.r(pos3)
+        ci, P, sup = np.zeros(3, np.int32), np.zeros(3, np.int32), np.zeros(3, np.int32)
+        wx, wy, wz = np.zeros(64, self.real), np.zeros(64, self.real), np.zeros(64, self.real)
+        self.lib.oracle_ibm_stencil(_p(p), _p(L), _p(per), _p(cd), C.byref(kernel), _p(ci), _p(P), _p(sup), _p(wx),
+                                    _p(wy), _p(wz))
+        return ci, P, sup, wx[:sup[0]], wy[:sup[1]], wz[:sup[2]]
+
+    # ---- path B: FCM k-space ------------------------------------------------------------------------
+    def fcm_force_fourier_to_vel(self, grid_k, viscosity, L, cell_dim):
+        """grid_k: complex array [nz, ny, nx/2+1, 3] of this precision; in place."""
+        L, _ = self._box(L, 1)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        assert grid_k.flags.c_contiguous
+        self.lib.oracle_fcm_force_fourier_to_vel(_p(grid_k), self.creal(viscosity), _p(L), _p(cd))
+        return grid_k
+
+    def fcm_fourier_brownian_noise(self, grid_k, L, cell_dim, noise_prefactor, viscosity, seed1, seed2):
+        L, _ = self._box(L, 1)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        assert grid_k.flags.c_contiguous
+        self.lib.oracle_fcm_fourier_brownian_noise(_p(grid_k), _p(L), _p(cd), self.creal(noise_prefactor),
+                                                   self.creal(viscosity), C.c_uint(seed1), C.c_uint(seed2))
+        return grid_k
+
+    def fcm_noise_prefactor(self, prefactor, temperature, L, cell_dim):
+        L, _ = self._box(L, 1)
+        cd = np.ascontiguousarray(cell_dim, dtype=np.int32)
+        self.lib.oracle_fcm_noise_prefactor.restype = self.creal
+        return float(self.lib.oracle_fcm_noise_prefactor(self.creal(prefactor), self.creal(temperature), _p(L), _p(cd)))
+
+    def fcm_self_mobility(self, a, viscosity, Lx):
+        self.lib.oracle_fcm_self_mobility.restype = C.c_double
+        return float(self.lib.oracle_fcm_self_mobility(C.c_double(a), C.c_double(viscosity), C.c_double(Lx)))
+
     # ---- integrators -----------------------------------------------------------------------------
     def verletnvt_gj(self, step, pos4, vel3, force4, dt, friction, noise_amplitude, step_num, seed, default_mass=1.0,
                      mass=None, index=None, is2D=False):

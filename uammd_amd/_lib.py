@@ -25,6 +25,16 @@ class CellListData(C.Structure):
                 ("numberParticles", C.c_int)]
 
 
+class IBMKernel(C.Structure):
+    _fields_ = [("kind", C.c_int), ("support", C.c_int * 3), ("prefactor", C.c_float), ("tau", C.c_float),
+                ("rmax", C.c_float), ("invh", C.c_float * 3)]
+
+
+class FCMParameters(C.Structure):
+    _fields_ = [("boxSize", C.c_float * 3), ("cells", C.c_int * 3), ("viscosity", C.c_float), ("seed", C.c_uint),
+                ("kernel", IBMKernel), ("hydrodynamicRadius", C.c_float)]
+
+
 _f3 = C.c_float * 3
 _i3 = C.c_int * 3
 _vp = C.c_void_p
@@ -57,6 +67,18 @@ SIGNATURES = {
     "uammd_bd_euler_maruyama": (_i, [_vp, _vp, _vp, C.POINTER(_f), _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
     "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
+    "uammd_fcm_gaussian_kernel": (_i, [_f, _f, C.POINTER(IBMKernel), C.POINTER(_f)]),
+    "uammd_fcm_advise_grid_size": (_f, [_f, _f]),
+    "uammd_ibm_spread": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
+    "uammd_ibm_gather": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
+    "uammd_fcm_create": (_i, [C.POINTER(FCMParameters), C.POINTER(_vp)]),
+    "uammd_fcm_destroy": (_i, [_vp]),
+    "uammd_fcm_displacements": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
+    "uammd_fcm_displacements_staged": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _i, _vp]),
+    "uammd_fcm_export_fourier": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_self_mobility": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+    "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),
+    "uammd_fcm_set_seed2": (_i, [_vp, _u]),
 }
 
 _lib = None

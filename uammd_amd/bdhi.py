@@ -1,0 +1,276 @@
+"""Host-side mirror of the UAMMD interfaces on path B (IBM + BDHI::FCM).
+
+Citations (relative to /root/reference/src):
+  IBM<Kernel>::spread/gather             misc/IBM.cuh:99-203
+  IBM_kernels / FCM_ns::Kernels          misc/IBM_kernels.cuh, Integrator/BDHI/FCM/FCM_kernels.cuh:22-58
+  BDHI::Parameters                       Integrator/BDHI/BDHI.cuh:13-24
+  BDHI::FCM (Method concept)             Integrator/BDHI/BDHI_FCM.cuh:84-147
+  BDHI::FCMIntegrator                    Integrator/BDHI/BDHI_FCM.cuh:149-198, BDHI_FCM.cu:95-119
+  BDHI::EulerMaruyama<Method>            Integrator/BDHI/BDHI_EulerMaruyama.cu:82-166
+  FCM_impl                               Integrator/BDHI/FCM/FCM_impl.cuh:56-129, :652-693
+All compute happens in libuammd_hip.so through the C ABI.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FCMParameters, IBMKernel, check, f3, i3
+from .md import Box, Integrator, _ptr, current_stream
+
+
+def nextFFTWiseSize3D(size):
+    """utils/Grid.cuh:142-213: next size of the form 2^a 3^b 5^c 7^d 11^e (a >= 1) per dimension; the `continue`
+    in the forbidden-size loop of the reference only continues that inner loop, so forbidden sizes are NOT skipped
+    (reproduced)."""
+    out = []
+    for s in size:
+        n = max(int(s), 1)
+        c = n
+        while True:
+            m = c
+            if m % 2 == 0:
+                for p in (2, 3, 5, 7, 11):
+                    while m % p == 0:
+                        m //= p
+                if m == 1 and _exponents_ok(c):
+                    break
+            c += 1
+        out.append(c)
+    return out
+
+
+def _exponents_ok(c):
+    lim = {2: 64, 3: 64, 5: 5, 7: 4, 11: 3}  # loop bounds n5=6, n7=5, n11=4 of Grid.cuh:146-150
+    for p, mx in lim.items():
+        e = 0
+        while c % p == 0:
+            c //= p
+            e += 1
+        if e > mx:
+            return False
+    return True
+
+
+class Kernels:
+    """Spreading windows that can cross the C ABI (include/uammd_hip.h uammd_ibm_kernel)."""
+
+    @staticmethod
+    def Gaussian(h, tolerance):
+        """FCM_ns::Kernels::Gaussian(h, tolerance) -> (kernel, a_eff)."""
+        lib = _lib.load()
+        k = IBMKernel()
+        a = C.c_float(0)
+        check(lib.uammd_fcm_gaussian_kernel(float(h), float(tolerance), C.byref(k), C.byref(a)))
+        return k, float(a.value)
+
+    @staticmethod
+    def adviseGridSize(hydrodynamicRadius, tolerance):
+        return float(_lib.load().uammd_fcm_advise_grid_size(float(hydrodynamicRadius), float(tolerance)))
+
+    @staticmethod
+    def Peskin3pt(h):
+        h = np.broadcast_to(np.asarray(h, dtype=np.float32), (3,))
+        inv = [float(np.float32(1.0) / x) if x > 0 else 0.0 for x in h]
+        return IBMKernel(1, (C.c_int * 3)(3, 3, 3), 0.0, 0.0, float("inf"), (C.c_float * 3)(*inv))
+
+    @staticmethod
+    def Peskin4pt(h):
+        h = np.broadcast_to(np.asarray(h, dtype=np.float32), (3,))
+        inv = [float(np.float32(1.0) / x) if x > 0 else 0.0 for x in h]
+        return IBMKernel(2, (C.c_int * 3)(4, 4, 4), 0.0, 0.0, float("inf"), (C.c_float * 3)(*inv))
+
+    @staticmethod
+    def Constant(support):
+        s = np.broadcast_to(np.asarray(support), (3,))
+        return IBMKernel(3, (C.c_int * 3)(int(s[0]), int(s[1]), int(s[2])), 0.0, 0.0, float("inf"), (C.c_float * 3)(0, 0, 0))
+
+
+class IBM:
+    """IBM<Kernel, Grid, LinearIndex3D>(kernel, grid[, cell2index]) — misc/IBM.cuh:99-203."""
+
+    def __init__(self, kernel, box, cellDim, nxStride=None):
+        self.lib = _lib.load()
+        self.kernel, self.box = kernel, box
+        self.cellDim = [int(c) for c in cellDim]
+        self.nxStride = int(nxStride) if nxStride is not None else self.cellDim[0]
+
+    def _args(self):
+        return f3(self.box.boxSize), i3([int(p) for p in self.box.periodic]), i3(self.cellDim), self.nxStride, C.byref(self.kernel)
+
+    def spread(self, pos, v, gridData):
+        """gridData += S v.  pos: float[N,3|4]; v: float[N] or float[N,3]; gridData float[nz,ny,nxStride(,3)]."""
+        ncomp = 1 if v.dim() == 1 else v.shape[1]
+        L, per, cd, nxs, k = self._args()
+        check(self.lib.uammd_ibm_spread(_ptr(pos), pos.shape[1], _ptr(v), ncomp, pos.shape[0], L, per, cd, nxs, k,
+                                        _ptr(gridData), current_stream()))
+
+    def gather(self, pos, Jq, gridData):
+        """Jq += J q."""
+        ncomp = 1 if Jq.dim() == 1 else Jq.shape[1]
+        L, per, cd, nxs, k = self._args()
+        check(self.lib.uammd_ibm_gather(_ptr(pos), pos.shape[1], _ptr(Jq), ncomp, pos.shape[0], L, per, cd, nxs, k,
+                                        _ptr(gridData), current_stream()))
+
+
+class _Parameters:
+    """BDHI::Parameters + FCM_impl::Parameters (BDHI.cuh:13-24, FCM_impl.cuh:47-54)."""
+
+    def __init__(self, temperature=0.0, viscosity=1.0, hydrodynamicRadius=-1.0, tolerance=1e-3, dt=0.0, box=None,
+                 cells=(-1, -1, -1), seed=0, adaptBoxSize=False):
+        self.temperature, self.viscosity, self.hydrodynamicRadius = temperature, viscosity, hydrodynamicRadius
+        self.tolerance, self.dt, self.box, self.cells, self.seed = tolerance, dt, box, list(cells), seed
+        self.adaptBoxSize = adaptBoxSize
+
+
+class FCM_impl:
+    """FCM_impl<Gaussian, GaussianTorque> without torques: owns the solver handle."""
+
+    def __init__(self, box, cells, kernel, viscosity, seed, hydrodynamicRadius):
+        self.lib = _lib.load()
+        p = FCMParameters()
+        for k in range(3):
+            p.boxSize[k] = float(box.boxSize[k])
+            p.cells[k] = int(cells[k])
+        p.viscosity, p.seed, p.kernel, p.hydrodynamicRadius = float(viscosity), int(seed) & 0xFFFFFFFF, kernel, float(hydrodynamicRadius)
+        if box.boxSize[0] <= 0:
+            raise RuntimeError("Invalid arguments")  # FCM_impl.cuh:74-77
+        h = C.c_void_p()
+        check(self.lib.uammd_fcm_create(C.byref(p), C.byref(h)))
+        self.h, self.box, self.cells = h, box, [int(c) for c in cells]
+        self.viscosity, self.hydrodynamicRadius = viscosity, hydrodynamicRadius
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_fcm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def getHydrodynamicRadius(self):
+        return self.hydrodynamicRadius
+
+    def getSelfMobility(self):
+        return float(self.lib.uammd_fcm_self_mobility(self.hydrodynamicRadius, self.viscosity, float(self.box.boxSize[0])))
+
+    def getBox(self):
+        return self.box
+
+    def computeHydrodynamicDisplacements(self, pos, force, numberParticles, temperature, prefactor, out=None):
+        """Returns linear velocities real3[N] (torques are not on this round's path)."""
+        if out is None:
+            out = torch.empty((numberParticles, 3), dtype=torch.float32, device=pos.device)
+        check(self.lib.uammd_fcm_displacements(self.h, _ptr(pos), _ptr(force), int(numberParticles), float(temperature),
+                                               float(prefactor), _ptr(out), current_stream()))
+        return out
+
+    def fourier_grid(self, pos, force, numberParticles, temperature, prefactor):
+        """Test hook: the Fourier grid after the k-space kernel as complex3[nz,ny,nx/2+1,3]."""
+        nkx = self.cells[0] // 2 + 1
+        out = torch.empty((self.cells[2], self.cells[1], nkx, 6), dtype=torch.float32, device=pos.device)
+        check(self.lib.uammd_fcm_displacements_staged(self.h, _ptr(pos), _ptr(force), int(numberParticles),
+                                                      float(temperature), float(prefactor), None, 1, current_stream()))
+        check(self.lib.uammd_fcm_export_fourier(self.h, _ptr(out), current_stream()))
+        return out
+
+    def seed2(self, value=None):
+        if value is None:
+            v = C.c_uint(0)
+            check(self.lib.uammd_fcm_get_seed2(self.h, C.byref(v)))
+            return int(v.value)
+        check(self.lib.uammd_fcm_set_seed2(self.h, int(value)))
+
+
+def _initialize(par, rng):
+    """detail::initializeGrid / initializeKernel (BDHI_FCM.cuh:29-66) + the ctor body of BDHI::FCM (:98-110)."""
+    if par.seed == 0:
+        par.seed = rng.next32()
+    box = par.box
+    if par.cells[0] <= 0:
+        if par.hydrodynamicRadius <= 0:
+            raise RuntimeError("[BDHI::FCM] I need an hydrodynamic radius if cell dimensions are not provided!")
+        h = np.float32(Kernels.adviseGridSize(par.hydrodynamicRadius, par.tolerance))
+        cd = [int(np.float32(l) / h) for l in box.boxSize]
+        cd = nextFFTWiseSize3D(cd)
+        if par.adaptBoxSize:
+            box = Box([np.float32(c) * h for c in cd])
+    else:
+        cd = [int(c) for c in par.cells]
+    cs = [np.float32(l) / np.float32(c) for l, c in zip(box.boxSize, cd)]
+    hmin = float(min(cs))
+    kernel, a_eff = Kernels.Gaussian(hmin, par.tolerance)
+    return box, cd, kernel, a_eff
+
+
+class FCM:
+    """BDHI::FCM — the Method concept used by BDHI::EulerMaruyama (BDHI_FCM.cuh:84-147)."""
+    Parameters = _Parameters
+
+    def __init__(self, pd, par):
+        self.pd = pd
+        self.temperature, self.dt = par.temperature, par.dt
+        box, cd, kernel, a_eff = _initialize(par, pd.rng)
+        self.fcm = FCM_impl(box, cd, kernel, par.viscosity, par.seed, a_eff)  # fixHydrodynamicRadius returns a_eff
+
+    def setup_step(self):
+        pass
+
+    def computeMF(self, MF):
+        pd = self.pd
+        self.fcm.computeHydrodynamicDisplacements(pd.getPos("read"), pd.getForce("read"), pd.N, self.temperature,
+                                                  1.0 / math.sqrt(self.dt), out=MF)
+
+    def computeBdW(self, BdW):
+        pass  # included in Fourier space when computing MF (BDHI_FCM.cuh:144-146)
+
+    def finish_step(self):
+        pass
+
+    def getHydrodynamicRadius(self):
+        return self.fcm.getHydrodynamicRadius()
+
+    def getSelfMobility(self):
+        return self.fcm.getSelfMobility()
+
+
+class FCMIntegrator(Integrator):
+    """BDHI::FCMIntegrator::forwardTime (BDHI_FCM.cu:95-119): forces -> displacements -> pos += v dt."""
+    Parameters = _Parameters
+
+    def __init__(self, pd, par):
+        super().__init__(pd)
+        self.temperature, self.dt = par.temperature, par.dt
+        box, cd, kernel, a_eff = _initialize(par, pd.rng)
+        self.fcm = FCM_impl(box, cd, kernel, par.viscosity, par.seed, a_eff)
+        self._v = torch.empty((pd.N, 3), dtype=torch.float32, device=pd.device)
+
+    def getFCM_impl(self):
+        return self.fcm
+
+    def forwardTime(self):
+        pd = self.pd
+        self.steps += 1
+        for it in self.interactors:
+            it.updateSimulationTime(self.steps * self.dt)
+        if self.steps == 1:
+            for it in self.interactors:
+                it.updateTimeStep(self.dt)
+                it.updateTemperature(self.temperature)
+                it.updateBox(self.fcm.getBox())
+        pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+        self.fcm.computeHydrodynamicDisplacements(pd.getPos("read"), pd.getForce("read"), pd.N, self.temperature,
+                                                  1.0 / math.sqrt(self.dt), out=self._v)
+        check(self.lib.uammd_fcm_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(self._v), pd.N, self.dt,
+                                                current_stream()))
+
+
+class BDHI:
+    FCM = FCM
+    FCMIntegrator = FCMIntegrator
+    FCM_impl = FCM_impl
+    Kernels = Kernels

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
                                                  uint *__restrict__ keyCount, uint *__restrict__ provRank,
                                                  int *__restrict__ errorFlag, unsigned char *__restrict__ keyOutside) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
+  if (i >= N) return;  // exited lanes drop out of the ballots below
   const float4 p = pos[i];
   int3 c = grid.getCell(real3f{p.x, p.y, p.z});
   // A particle outside a non periodic box (or a NaN) has no cell: flag it (the reference raises the
@@ -97,7 +97,11 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
     if (!(p.x >= -hx && p.x < hx && p.y >= -hy && p.y < hy && p.z >= -hz && p.z < hz)) keyOutside[h] = 1;
   }
   if (COUNT) {
-    provRank[i] = atomicAdd(&keyCount[h], 1u);  // provisional rank inside the key
+    // One returning atomic per particle.  (A wave-aggregated variant — one atomic per distinct key per
+    // wave — was measured SLOWER at C3: ParticleData::sortParticles only sorts on a coarse 10-sigma grid, so
+    // a wave still holds ~64 distinct fine keys; profiles/r01_lj_kernels.md.)
+    const uint rank = atomicAdd(&keyCount[h], 1u);
+    provRank[i] = rank;
   } else {
     index[i] = i;
   }
@@ -123,7 +127,12 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter(const float4 *__restric
   const uint h = hash[i];
   const uint s = keyStart[h], e = keyStart[h + 1];
   uint rank = 0;
-  for (uint m = s; m < e; ++m) rank += (members[m] < i) ? 1u : 0u;
+  uint m = s;
+  for (; m + 4 <= e; m += 4) {  // 4 loads in flight
+    const int a = members[m], b = members[m + 1], c = members[m + 2], d = members[m + 3];
+    rank += (a < i) + (b < i) + (c < i) + (d < i);
+  }
+  for (; m < e; ++m) rank += (members[m] < i) ? 1u : 0u;
   const uint dst = s + rank;
   sortHash[dst] = h;
   index[dst] = i;

@@ -1,0 +1,389 @@
+// Path B — Force Coupling Method (triply periodic Stokes solver) for gfx950.
+//
+// Reference pipeline (Integrator/BDHI/FCM/FCM_impl.cuh:652-693):
+//   spreadForces (IBM, :245-262) -> 3 batched R2C FFTs (:293-304) -> forceFourier2Vel (:375-397)
+//   -> fourierBrownianNoise (:437-512) -> 3 batched C2R FFTs (:544-557) -> interpolateVelocity (:559-581)
+//
+// MI355X design
+//   * The three Cartesian components live in three PLANAR padded grids [nz][ny][2(nx/2+1)] instead of the
+//     reference's xyz-interleaved real3 grid: every rocFFT pass then streams unit-stride rows, and the
+//     R2C/C2R transforms run IN PLACE (the padded real layout is exactly the Hermitian layout), so the
+//     solver touches 1 grid-size of HBM per transform direction instead of 2 and needs no second buffer.
+//   * forceFourier2Vel and fourierBrownianNoise are ONE kernel in gather form: every Fourier node adds
+//     its own draw and, on the kx = 0 / kx = nx/2 planes, the conjugate of its partner's draw, which it
+//     regenerates from the same Saru(id, seed, seed2) stream.  No node is written by two threads (the
+//     reference's scatter form races on the kx = nx/2 plane) and the result is deterministic.
+//   * spread/gather: one wave per particle, weights by ds_bpermute, f32 hardware atomics into L2 for the
+//     spread (see also the tile-owned variant below).
+//   * all work buffers are owned by the handle; steady state allocates nothing.
+#include "ibm.hpp"
+#include "celllist.hpp"
+#include "saru.hpp"
+
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <mutex>
+
+namespace uammd_hip {
+
+#define UH_ROCFFT(expr)                                                                      \
+  do {                                                                                       \
+    rocfft_status s_ = (expr);                                                               \
+    if (s_ != rocfft_status_success) {                                                       \
+      set_last_error("%s failed with rocfft_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+      return -10 - (int)s_;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+struct FCM {
+  uammd_fcm_parameters par;
+  GridT<float> grid;
+  IBMKernelDev kern;
+  int nxpad = 0;           // 2*(nx/2+1)
+  size_t planeReal = 0;    // floats per component plane
+  size_t planeCplx = 0;    // complex per component plane
+  DeviceBuffer gridBuf, work;
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  size_t workBytes = 0;
+  unsigned int seed2 = 0;  // the reference's `static uint seed2` (FCM_impl.cuh:517): per-handle here
+  ~FCM() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+
+static std::once_flag g_rocfft_once;
+
+// ---- spread / gather on the planar grids ---------------------------------------------------------------
+template <bool SPREAD>
+__global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos, const float4 *__restrict__ force,
+                                                  float *__restrict__ vout, float *__restrict__ g0, int N,
+                                                  GridT<float> grid, int nxpad, size_t plane, IBMKernelDev kern,
+                                                  FastDiv dsx, FastDiv dsxy) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= N) return;
+  const float4 p4 = pos[id];
+  const real3f pi{p4.x, p4.y, p4.z};
+  const Stencil s = make_stencil(grid, kern, pi, false, lane);
+  const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
+  const int nn = sx * sy * sz;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  if (SPREAD) { const float4 f4 = force[id]; fx = f4.x; fy = f4.y; fz = f4.z; }
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  const float dV = grid.cellVolume;
+  float *g1 = g0 + plane, *g2 = g0 + 2 * plane;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < nn;
+    const uint iu = in ? (uint)i : 0u;
+    const uint kk = dsxy.div(iu);
+    const uint rem = iu - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const float wx = __shfl(s.w, (int)ii, 64);
+    const float wy = __shfl(s.w, sx + (int)jj, 64);
+    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    if (!in) continue;
+    // triply periodic: a single wrap is enough because support < cellDim (checked at create)
+    int cx = s.celli.x + (int)ii - s.P.x, cy = s.celli.y + (int)jj - s.P.y, cz = s.celli.z + (int)kk - s.P.z;
+    cx = cx < 0 ? cx + grid.cellDim.x : (cx >= grid.cellDim.x ? cx - grid.cellDim.x : cx);
+    cy = cy < 0 ? cy + grid.cellDim.y : (cy >= grid.cellDim.y ? cy - grid.cellDim.y : cy);
+    cz = cz < 0 ? cz + grid.cellDim.z : (cz >= grid.cellDim.z ? cz - grid.cellDim.z : cz);
+    const size_t node = (size_t)cx + (size_t)nxpad * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz);
+    if (SPREAD) {
+      unsafeAtomicAdd(&g0[node], fx * wx * wy * wz);
+      unsafeAtomicAdd(&g1[node], fy * wx * wy * wz);
+      unsafeAtomicAdd(&g2[node], fz * wx * wy * wz);
+    } else {
+      ax = fmaf(dV, g0[node] * wx * wy * wz, ax);
+      ay = fmaf(dV, g1[node] * wx * wy * wz, ay);
+      az = fmaf(dV, g2[node] * wx * wy * wz, az);
+    }
+  }
+  if (!SPREAD) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ax += __shfl_xor(ax, o, 64);
+      ay += __shfl_xor(ay, o, 64);
+      az += __shfl_xor(az, o, 64);
+    }
+    if (lane == 0) { vout[3 * (size_t)id] = ax; vout[3 * (size_t)id + 1] = ay; vout[3 * (size_t)id + 2] = az; }
+  }
+}
+
+// ---- Fourier space ---------------------------------------------------------------------------------------
+struct C3 { float xr, xi, yr, yi, zr, zi; };
+
+UH_D int3 index_to_wavenumber(int i, int3 nk) {  // FCM/utils.cuh:27-35
+  int ikx = i % (nk.x / 2 + 1);
+  int iky = (i / (nk.x / 2 + 1)) % nk.y;
+  int ikz = i / ((nk.x / 2 + 1) * nk.y);
+  ikx -= nk.x * (ikx >= (nk.x / 2 + 1));
+  iky -= nk.y * (iky >= (nk.y / 2 + 1));
+  ikz -= nk.z * (ikz >= (nk.z / 2 + 1));
+  return make_int3(ikx, iky, ikz);
+}
+UH_D real3f wavevector(int3 ik, real3f L) {  // FCM/utils.cuh:37-39
+  const float twopi = 2.0f * 3.14159265358979323846f;
+  return real3f{(twopi / L.x) * (float)ik.x, (twopi / L.y) * (float)ik.y, (twopi / L.z) * (float)ik.z};
+}
+UH_D real3f gradient_fourier(int3 ik, int3 nk, real3f k) {  // FCM/utils.cuh:41-51: unpaired (Nyquist) components -> 0
+  return real3f{ik.x == (nk.x - ik.x) ? 0.0f : k.x, ik.y == (nk.y - ik.y) ? 0.0f : k.y, ik.z == (nk.z - ik.z) ? 0.0f : k.z};
+}
+UH_D real3f project(float k2, real3f dk, real3f fr) {  // FCM/utils.cuh:70-74
+  const float invk2 = 1.0f / k2;
+  const float s = dot3(fr, real3f{dk.x * invk2, dk.y * invk2, dk.z * invk2});
+  return real3f{fmaf(-dk.x, s, fr.x), fmaf(-dk.y, s, fr.y), fmaf(-dk.z, s, fr.z)};
+}
+UH_D C3 project(float k2, real3f dk, C3 f) {
+  const real3f re = project(k2, dk, real3f{f.xr, f.yr, f.zr});
+  const real3f im = project(k2, dk, real3f{f.xi, f.yi, f.zi});
+  return C3{re.x, im.x, re.y, im.y, re.z, im.z};
+}
+UH_D bool is_nyquist(int3 c, int3 n) {  // FCM/utils.cuh:133-167
+  const bool X = (c.x == n.x - c.x) && (n.x % 2 == 0), Y = (c.y == n.y - c.y) && (n.y % 2 == 0),
+             Z = (c.z == n.z - c.z) && (n.z % 2 == 0);
+  return (X && c.y == 0 && c.z == 0) || (X && Y && c.z == 0) || (c.x == 0 && Y && c.z == 0) || (X && c.y == 0 && Z) ||
+         (c.x == 0 && c.y == 0 && Z) || (c.x == 0 && Y && Z) || (X && Y && Z);
+}
+UH_D bool noise_skipped(int id, int3 c, int3 n) {  // FCM_impl.cuh:456-463: nodes that do not draw
+  return id == 0 || (c.x == 0 && c.y == 0 && 2 * c.z >= n.z + 1) || (c.x == 0 && 2 * c.y >= n.y + 1);
+}
+UH_D C3 draw_noise(float prefactor, uint id, uint seed1, uint seed2, bool nyquist) {  // FCM/utils.cuh:117-131 + :466-476
+  Saru rng(id, seed1, seed2);
+  const float sc = 0.707106781186547f * prefactor;
+  const float2 a = rng.gf(0.0f, sc), b = rng.gf(0.0f, sc), c = rng.gf(0.0f, sc);
+  C3 n{a.x, a.y, b.x, b.y, c.x, c.y};
+  if (nyquist) {
+    const float q = 1.41421356237310f;
+    n.xr *= q; n.xi = 0.0f; n.yr *= q; n.yi = 0.0f; n.zr *= q; n.zi = 0.0f;
+  }
+  return n;
+}
+
+// One thread per Fourier node.  grid: 3 planar complex grids (float2), in place.
+__global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, size_t planeC, int3 nk, real3f L,
+                                                     float viscosity, bool haveForce, float noisePrefactor,
+                                                     uint seed1, uint seed2) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int nkx = nk.x / 2 + 1;
+  const int total = nk.z * nk.y * nkx;
+  if (id >= total) return;
+  float2 *g1 = g0 + planeC, *g2 = g0 + 2 * planeC;
+  const int3 cell = make_int3(id % nkx, (id / nkx) % nk.y, id / (nkx * nk.y));
+  C3 v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int3 ik = index_to_wavenumber(id, nk);
+  const real3f k = wavevector(ik, L);
+  const float k2 = dot3(k, k);
+  const real3f dk = gradient_fourier(ik, nk, k);
+  if (haveForce && id != 0) {  // forceFourier2Vel, FCM_impl.cuh:375-397
+    const float2 a = g0[id], b = g1[id], c = g2[id];
+    const float B = 1.0f / (viscosity * k2);
+    const float sc = B / (float)(nk.x * nk.y * nk.z);
+    const C3 pr = project(k2, dk, C3{a.x, a.y, b.x, b.y, c.x, c.y});
+    v = C3{pr.xr * sc, pr.xi * sc, pr.yr * sc, pr.yi * sc, pr.zr * sc, pr.zi * sc};
+  }
+  if (noisePrefactor != 0.0f && id != 0) {  // fourierBrownianNoise, FCM_impl.cuh:437-512, in gather form
+    const float Bsq = sqrtf(1.0f / (k2 * viscosity));
+    const bool own = !noise_skipped(id, cell, nk);
+    // conjugate partner: only stored (and only written by the reference) on the kx == 0 / kx == nx - kx planes
+    int idp = -1;
+    if (cell.x == 0 || cell.x == nk.x - cell.x) {
+      const int3 pc = make_int3(cell.x, (cell.y > 0) * (nk.y - cell.y), (cell.z > 0) * (nk.z - cell.z));
+      const int cand = pc.x + nkx * (pc.y + pc.z * nk.y);
+      if (cand != id && !noise_skipped(cand, pc, nk) && !is_nyquist(pc, nk)) idp = cand;
+    }
+    C3 mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, theirs = mine;
+    if (own) {
+      const C3 n = draw_noise(noisePrefactor, (uint)id, seed1, seed2, is_nyquist(cell, nk));
+      mine = project(k2, dk, C3{n.xr * Bsq, n.xi * Bsq, n.yr * Bsq, n.yi * Bsq, n.zr * Bsq, n.zi * Bsq});
+    }
+    if (idp >= 0) {
+      const C3 n = draw_noise(noisePrefactor, (uint)idp, seed1, seed2, false);
+      C3 f{n.xr * Bsq, n.xi * Bsq, n.yr * Bsq, n.yi * Bsq, n.zr * Bsq, n.zi * Bsq};
+      f.xi *= -1.0f; f.yi *= -1.0f; f.zi *= -1.0f;
+      theirs = project(k2, dk, f);
+    }
+    // same order of the two += as a sequential sweep over node ids
+    const C3 first = (idp >= 0 && idp < id) ? theirs : mine, second = (idp >= 0 && idp < id) ? mine : theirs;
+    v.xr += first.xr; v.xi += first.xi; v.yr += first.yr; v.yi += first.yi; v.zr += first.zr; v.zi += first.zi;
+    v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
+  }
+  g0[id] = make_float2(v.xr, v.xi);
+  g1[id] = make_float2(v.yr, v.yi);
+  g2[id] = make_float2(v.zr, v.zi);
+}
+
+// test hook: interleave the planar complex grids into complex3[Nk]
+__global__ void k_fcm_export(const float2 *__restrict__ g0, size_t planeC, int total, float *__restrict__ out6) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const float2 a = g0[id], b = g0[planeC + id], c = g0[2 * planeC + id];
+  out6[6 * (size_t)id + 0] = a.x; out6[6 * (size_t)id + 1] = a.y;
+  out6[6 * (size_t)id + 2] = b.x; out6[6 * (size_t)id + 3] = b.y;
+  out6[6 * (size_t)id + 4] = c.x; out6[6 * (size_t)id + 5] = c.y;
+}
+
+static int fcm_make_plans(FCM *f) {
+  std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
+  const size_t nx = (size_t)f->grid.cellDim.x, ny = (size_t)f->grid.cellDim.y, nz = (size_t)f->grid.cellDim.z;
+  const size_t nkx = nx / 2 + 1;
+  const size_t lengths[3] = {nx, ny, nz};
+  const size_t rstr[3] = {1, (size_t)f->nxpad, (size_t)f->nxpad * ny};
+  const size_t cstr[3] = {1, nkx, nkx * ny};
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                     nullptr, nullptr, 3, rstr, f->planeReal, 3, cstr, f->planeCplx));
+  UH_ROCFFT(rocfft_plan_create(&f->fwd, rocfft_placement_inplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_single, 3, lengths, 3, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                     nullptr, nullptr, 3, cstr, f->planeCplx, 3, rstr, f->planeReal));
+  UH_ROCFFT(rocfft_plan_create(&f->inv, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
+                               rocfft_precision_single, 3, lengths, 3, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  size_t wf = 0, wi = 0;
+  UH_ROCFFT(rocfft_plan_get_work_buffer_size(f->fwd, &wf));
+  UH_ROCFFT(rocfft_plan_get_work_buffer_size(f->inv, &wi));
+  f->workBytes = wf > wi ? wf : wi;
+  if (f->workBytes) {
+    if (int e = f->work.reserve(f->workBytes)) return e;
+  }
+  UH_ROCFFT(rocfft_execution_info_create(&f->info));
+  if (f->workBytes) UH_ROCFFT(rocfft_execution_info_set_work_buffer(f->info, f->work.ptr, f->workBytes));
+  return 0;
+}
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
+  if (!par || !out) { set_last_error("uammd_fcm_create: null argument"); return -1; }
+  // FCM_impl ctor checks, FCM_impl.cuh:56-92
+  if (!(par->boxSize[0] > 0) || !(par->boxSize[1] > 0) || !(par->boxSize[2] > 0)) {
+    set_last_error("FCM_impl requires a valid box");
+    return -2;
+  }
+  if (par->cells[0] <= 0 || par->cells[1] <= 0 || par->cells[2] <= 0) {
+    set_last_error("FCM_impl requires a valid grid dimension");
+    return -2;
+  }
+  if (par->kernel.kind != UAMMD_IBM_KERNEL_GAUSSIAN && par->kernel.kind != UAMMD_IBM_KERNEL_PESKIN3 &&
+      par->kernel.kind != UAMMD_IBM_KERNEL_PESKIN4) {
+    set_last_error("FCM_impl requires instances of the spreading kernels");
+    return -2;
+  }
+  for (int a = 0; a < 3; ++a) {
+    if (par->kernel.support[a] < 1 || par->kernel.support[a] > kMaxSupport) {
+      set_last_error("uammd_fcm_create: kernel support %d outside [1, %d]", par->kernel.support[a], kMaxSupport);
+      return -2;
+    }
+    if (par->kernel.support[a] >= par->cells[a]) {  // BDHI_FCM.cuh:58-64 (the reference logs an ERROR)
+      set_last_error("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
+      return -2;
+    }
+  }
+  FCM *f = new FCM();
+  f->par = *par;
+  const int periodic[3] = {1, 1, 1};
+  const BoxT<float> box = make_box<float>(par->boxSize, periodic);
+  f->grid = make_grid<float>(box, make_int3(par->cells[0], par->cells[1], par->cells[2]));
+  f->kern = to_dev(par->kernel);
+  f->nxpad = 2 * (par->cells[0] / 2 + 1);
+  f->planeReal = (size_t)f->nxpad * par->cells[1] * par->cells[2];
+  f->planeCplx = f->planeReal / 2;
+  if (int e = f->gridBuf.reserve(sizeof(float) * 3 * f->planeReal)) { delete f; return e; }
+  if (int e = fcm_make_plans(f)) { delete f; return e; }
+  *out = reinterpret_cast<uammd_fcm *>(f);
+  return 0;
+}
+
+int uammd_fcm_destroy(uammd_fcm *h) {
+  delete reinterpret_cast<FCM *>(h);
+  return 0;
+}
+
+int uammd_fcm_get_seed2(uammd_fcm *h, unsigned int *seed2) {
+  if (!h || !seed2) { set_last_error("uammd_fcm_get_seed2: null argument"); return -1; }
+  *seed2 = reinterpret_cast<FCM *>(h)->seed2;
+  return 0;
+}
+int uammd_fcm_set_seed2(uammd_fcm *h, unsigned int seed2) {
+  if (!h) { set_last_error("uammd_fcm_set_seed2: null handle"); return -1; }
+  reinterpret_cast<FCM *>(h)->seed2 = seed2;
+  return 0;
+}
+
+int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
+  if (!h || !d_out6) { set_last_error("uammd_fcm_export_fourier: null argument"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  const int total = (int)f->planeCplx;
+  hipLaunchKernelGGL(k_fcm_export, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float2 *)f->gridBuf.ptr, f->planeCplx, total, d_out6);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// stage: 0 = full pipeline; 1 = stop after spread+FFT+k-space (the Fourier grid can then be exported)
+int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
+                                   float prefactor, float *d_linearVelocity, int stage, void *stream) {
+  if (!h || !d_pos || (!d_linearVelocity && stage == 0)) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 0) return 0;
+  float *g = (float *)f->gridBuf.ptr;
+  const dim3 gp((N + 3) / 4), bp(256);
+  const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+  UH_ROCFFT(rocfft_execution_info_set_stream(f->info, (void *)st));
+  void *bufs[1] = {g};
+  if (d_force) {
+    UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
+    hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, (float *)nullptr,
+                       g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+    UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+  }
+  float noisePrefactor = 0.0f;
+  if (temperature > 0.0f) {  // addBrownianNoise, FCM_impl.cuh:514-542
+    f->seed2++;
+    const float dV = f->grid.cellVolume;
+    const float fourierNormalization =
+        (float)(1.0 / ((double)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z));
+    noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / dV);
+  }
+  const int total = (int)f->planeCplx;
+  hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, f->planeCplx,
+                     f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
+                     d_force != nullptr, noisePrefactor, f->par.seed, f->seed2);
+  if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
+  UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
+  hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, d_linearVelocity,
+                     g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_fcm_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
+                            float prefactor, float *d_linearVelocity, void *stream) {
+  return uammd_fcm_displacements_staged(h, d_pos, d_force, N, temperature, prefactor, d_linearVelocity, 0, stream);
+}
+
+double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx) {
+  // FCM_impl::getSelfMobility, FCM_impl.cuh:102-119 (Hasimoto 1959, O(a^8))
+  const long double rh = hydrodynamicRadius, L = Lx;
+  const long double a = rh / L, a2 = a * a, a3 = a2 * a;
+  const long double c = 2.83729747948061947666591710460773907l, b = 0.19457l;
+  const long double pi = 3.141592653589793238462643383279502884L;
+  const long double a6pref = 16.0l * pi * pi / 45.0l + 630.0L * b * b;
+  return (double)(1.0l / (6.0l * pi * viscosity * rh) * (1.0l - c * a + (4.0l / 3.0l) * pi * a3 - a6pref * a3 * a3));
+}
+
+}  // extern "C"

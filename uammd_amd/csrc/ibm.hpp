@@ -1,0 +1,105 @@
+// Immersed-boundary stencil machinery shared by the generic IBM entry points and the FCM solver.
+//
+// Reference behaviour (misc/IBM.cu:10-65, misc/IBM.cuh:65-97, utils/Grid.cuh:124-131):
+//   celli   = Grid::getCell(pos)
+//   P       = support/2, minus 1 when the left-most node is farther than support*h/2 (even supports)
+//   w_a[i]  = phi_a(distanceToCellCenter(pos, celli + i - P).a)      for i in [0, support.a)
+//   node (ii,jj,kk) = pbc_cell(celli + (ii,jj,kk) - P), skipped when outside a non periodic grid
+// One 64-lane wave handles one particle: lanes 0..3*support-1 evaluate the 1-D weights (one exp each),
+// the rest of the wave reads them back with ds_bpermute while walking the support^3 nodes.
+#pragma once
+#include "device_common.hpp"
+#include "../../include/uammd_hip.h"
+
+namespace uammd_hip {
+
+enum { kKernelGaussian = 0, kKernelPeskin3 = 1, kKernelPeskin4 = 2, kKernelConstant = 3 };
+constexpr int kMaxSupport = 21;  // 3*support weights must fit in one wave
+
+struct IBMKernelDev {
+  int kind;
+  int3 support;
+  float prefactor, tau, rmax;
+  float invhx, invhy, invhz;
+};
+
+UH_D float phi_gaussian(const IBMKernelDev &k, float r) {
+  // FCM_ns::Kernels::Gaussian::phi cuts only r >= rmax (BDHI/FCM/FCM_kernels.cuh:55-57)
+  return (r >= k.rmax) ? 0.0f : k.prefactor * expf(k.tau * r * r);
+}
+UH_D float phi_peskin3(float invh, float rr) {  // misc/IBM_kernels.cuh:120-136
+  const float r = fabsf(rr) * invh;
+  if (r < 0.5f) return invh * (float)(1 / 3.0) * (1.0f + sqrtf(fmaf(-3.0f * r, r, 1.0f)));
+  if (r < 1.5f) {
+    const float omr = 1.0f - r;
+    return invh * (float)(1 / 6.0) * (fmaf(-3.0f, r, 5.0f) - sqrtf(fmaf(-3.0f * omr, omr, 1.0f)));
+  }
+  return 0.0f;
+}
+UH_D float phi_peskin4(float invh, float rr) {  // misc/IBM_kernels.cuh:145-158
+  const float r = fabsf(rr) * invh;
+  if (r < 1.0f) return invh * 0.125f * (fmaf(-2.0f, r, 3.0f) + sqrtf(fmaf(4.0f * r, (1.0f - r), 1.0f)));
+  if (r < 2.0f) return invh * 0.125f * (fmaf(-2.0f, r, 5.0f) - sqrtf(fmaf(-(4.0f * r), r, fmaf(12.0f, r, -7.0f))));
+  return 0.0f;
+}
+UH_D float phi_axis(const IBMKernelDev &k, int axis, float r) {
+  switch (k.kind) {
+    case kKernelGaussian: return phi_gaussian(k, r);
+    case kKernelPeskin3: return phi_peskin3(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    case kKernelPeskin4: return phi_peskin4(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    default: return 1.0f;
+  }
+}
+
+// Per-particle stencil, identical in every lane of the wave except `w` (lane l < 3*support holds one weight).
+struct Stencil {
+  int3 celli, P, support;
+  float w;  // lanes [0,sx): x weights, [sx,sx+sy): y weights, [sx+sy, sx+sy+sz): z weights
+};
+
+UH_D int3 compute_support_shift(const GridT<float> &g, real3f pos, int3 celli, int3 support) {  // IBM.cu:10-31
+  int3 P = make_int3(support.x / 2, support.y / 2, support.z / 2);
+  real3f d = g.distanceToCellCenter(pos, make_int3(celli.x - P.x, celli.y - P.y, celli.z - P.z));
+  d.x = fabsf(d.x); d.y = fabsf(d.y); d.z = fabsf(d.z);
+  if (g.cellSize.x > 0 && d.x > (float)support.x * g.cellSize.x / 2.0f) P.x -= 1;
+  if (g.cellSize.y > 0 && d.y > (float)support.y * g.cellSize.y / 2.0f) P.y -= 1;
+  if (g.cellSize.z > 0 && d.z > (float)support.z * g.cellSize.z / 2.0f) P.z -= 1;
+  return P;
+}
+
+UH_D Stencil make_stencil(const GridT<float> &g, const IBMKernelDev &k, real3f pi, bool is2D, int lane) {
+  Stencil s;
+  s.celli = g.getCell(pi);
+  s.support = k.support;
+  s.P = compute_support_shift(g, pi, s.celli, s.support);
+  if (is2D) { s.P.z = 0; s.support.z = 1; }
+  s.w = 0.0f;
+  const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
+  if (lane < sx) {
+    const int cx = g.pbc_x(s.celli.x + lane - s.P.x);
+    if (cx >= 0) s.w = phi_axis(k, 0, g.distanceToCellCenter(pi, make_int3(cx, s.celli.y, s.celli.z)).x);
+  } else if (lane < sx + sy) {
+    const int cy = g.pbc_y(s.celli.y + (lane - sx) - s.P.y);
+    if (cy >= 0) s.w = phi_axis(k, 1, g.distanceToCellCenter(pi, make_int3(s.celli.x, cy, s.celli.z)).y);
+  } else if (lane < sx + sy + sz) {
+    const int cz = g.pbc_z(s.celli.z + (lane - sx - sy) - s.P.z);
+    if (cz >= 0) s.w = phi_axis(k, 2, g.distanceToCellCenter(pi, make_int3(s.celli.x, s.celli.y, cz)).z);
+    // 2D: the Peskin windows of the reference tests return phiZ = 1 (test/misc/ibm/test_ibm_regular.cu:83-85)
+    if (is2D && (k.kind == kKernelPeskin3 || k.kind == kKernelPeskin4)) s.w = 1.0f;
+  }
+  return s;
+}
+
+// exact i / d for 0 <= i < 2^32 / d with a host-precomputed M = ceil(2^32 / d) (d >= 2); d == 1 -> identity
+struct FastDiv {
+  uint M, d;
+  UH_D uint div(uint i) const { return d == 1u ? i : __umulhi(i, M); }
+};
+inline FastDiv make_fastdiv(int d) {
+  if (d <= 1) return FastDiv{0u, 1u};
+  return FastDiv{(uint)((0x100000000ull + (unsigned long long)d - 1ull) / (unsigned long long)d), (uint)d};
+}
+
+IBMKernelDev to_dev(const uammd_ibm_kernel &k);
+
+}  // namespace uammd_hip
