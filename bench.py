@@ -123,15 +123,130 @@ def cpu_baseline_lj(n, L, seed, sample_steps):
                       f"thread, traversal OpenMP over {cores} threads), {el:.1f} s"}
 
 
+
+# FCM (BASELINE configs[3]): algorithmic HBM bytes per step = 10*G + 60*N with G = 12 * 2(nx/2+1)*ny*nz
+def fcm_bytes_per_step(n, cells):
+    G = 12 * 2 * (cells[0] // 2 + 1) * cells[1] * cells[2]
+    return 10 * G + 60 * n
+
+
+class FixedForce:
+    """test/BDHI/FCM/FCM.cu:41-55 miniInteractor: an Interactor that applies a fixed force."""
+
+    def __init__(self, pd, force):
+        self.pd, self.force = pd, force
+
+    def sum(self, force=True, energy=False, virial=False):
+        self.pd.getForce("readwrite").add_(self.force)
+
+    def updateSimulationTime(self, t):
+        pass
+
+    def updateTimeStep(self, dt):
+        pass
+
+    def updateTemperature(self, T):
+        pass
+
+    def updateBox(self, box):
+        pass
+
+
+def fcm_setup(hip, n, cells, L, seed, T=1.0, dt=0.01):
+    rng = np.random.default_rng(seed)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = np.random.default_rng(4321).normal(0, 1, (n, 3))
+    pd = hip.ParticleData(n, seed=seed)
+    pd.setPos(pos)
+    par = hip.BDHI.FCMIntegrator.Parameters(temperature=T, viscosity=1.0, tolerance=1e-3, dt=dt, box=hip.Box(L),
+                                            cells=cells, seed=1234)
+    integ = hip.BDHI.FCMIntegrator(pd, par)
+    integ.addInteractor(FixedForce(pd, torch.from_numpy(force).cuda()))
+    return pd, integ, pos, force
+
+
+def run_fcm(hip, args, world, rank, dist):
+    n, cells, L = 100_000, [128, 128, 128], 128.0
+    pd, integ, pos, force = fcm_setup(hip, n, cells, L, seed=1234 + rank)
+    if args.fcm_sort:
+        pd.hintSortByHash(hip.Box(L), args.fcm_sort)
+        pd.sortParticles()
+        integ.interactors[0].force = pd._props.get("fixedforce", integ.interactors[0].force)
+    for _ in range(args.fcm_warmup):
+        integ.forwardTime()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.fcm_steps):
+        integ.forwardTime()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert np.isfinite(pd.getPos().cpu().numpy()).all()
+    ms = el / args.fcm_steps * 1e3
+    gbs = fcm_bytes_per_step(n, cells) / (ms * 1e-3) / 1e9
+    out = {"metric": "FCM-BDHI steps/s @128^3 (1e5 particles, tol 1e-3, T=1)", "value": world * args.fcm_steps / el,
+           "unit": "steps/s", "ms_per_step": ms, "steps": args.fcm_steps, "warmup": args.fcm_warmup,
+           "config": {"workload": "BDHI::FCMIntegrator 1e5 particles, 128^3 grid, L=128, Gaussian support 6, "
+                                  "fixed forces + Fourier-space noise (BASELINE configs[3])"},
+           "roofline": {"bound": "hbm", "kernel": "whole FCM step (spread, 2x3 FFT, k-space, gather)",
+                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "traffic": None, "algorithmic_bytes_per_step": fcm_bytes_per_step(n, cells)}}
+    return out
+
+
+def cpu_baseline_fcm(sample_steps):
+    import oracle
+    from oracle.fcm import FCMOracle
+    o = oracle.get("f32")
+    n, cells, L = 100_000, [128, 128, 128], 128.0
+    rng = np.random.default_rng(1234)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = np.random.default_rng(4321).normal(0, 1, (n, 3))
+    f = FCMOracle(o, L, cells, tolerance=1e-3, viscosity=1.0, seed=1234)
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        v = f.displacements(pos, force, temperature=1.0, prefactor=10.0)
+        o.fcm_euler_maruyama(pos, v, 0.01)
+    el = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return {"value": sample_steps / el, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_steps} FCM steps at 128^3 / 1e5 particles (oracle: C spread single thread, gather and "
+                      f"scipy pocketfft FFTs on {cores} threads, k-space single thread), {el:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--workload", default="lj", choices=["lj"])
+    ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both"])
+    ap.add_argument("--fcm-steps", type=int, default=200)
+    ap.add_argument("--fcm-warmup", type=int, default=20)
+    ap.add_argument("--cpu-fcm-steps", type=int, default=40)
+    ap.add_argument("--fcm-sort", type=float, default=0.0, help="sort particles on a grid of this cell size first")
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-steps", type=int, default=20)
     ap.add_argument("--brick-bits", type=int, default=None)
     ap.add_argument("--algo", type=int, default=0)
     args = ap.parse_args()
@@ -153,6 +268,17 @@ def main():
     if args.brick_bits is not None:
         check(load().uammd_hip_set_tunable(b"lj_brick_bits", args.brick_bits))
 
+    if args.workload == "fcm":
+        out = run_fcm(hip, args, world, rank, dist)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
+        out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                    "data": "synthetic"})
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     n = args.particles
     L = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
     # Multi-GPU: the LJ path shards by spatial domain; this round each rank integrates an independent
@@ -212,13 +338,18 @@ def main():
                    "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
                    "parallelism": "1 process per GPU, independent replica boxes" if world > 1 else "single GPU"},
         "pair_interactions_per_s": 52.36 * value,
-        "roofline": {"bound": "mfma", "kernel": "k_lj_brick (LJ traversal)", "achieved": achieved_tflops,
+        "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal)", "achieved": achieved_tflops,
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
                      "traffic": traffic, "kernel_ms": k_ms,
                      "note": "f32 VALU-bound kernel; peak = f32 vector (= f32 MFMA) peak; model 1.0e4 flop/particle",
                      "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "hbm_frac_streamed_neighbour_model": BYTES_STREAMED_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
     }
+    if args.workload == "both":
+        fcm = run_fcm(hip, args, world, rank, dist)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            fcm["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
+        out["fcm"] = fcm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:
