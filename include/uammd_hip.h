@@ -206,6 +206,23 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
                                    void *stream);
 int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Lanczos sqrt(M) v.  Replaces lanczos::Solver (misc/LanczosAlgorithm.cuh:32-83,
+ * misc/LanczosAlgorithm/LanczosAlgorithm.cu:27-262) and the MatrixDot functor (LanczosAlgorithm/MatrixDot.h:7-25):
+ * the matrix is a host callback that ENQUEUES d_Mv = M d_v (n floats, device pointers) on `stream` and returns 0.
+ * uammd_lanczos_run returns 0 and the iteration count, or an error whose message is the reference's exception text
+ * ("[Lanczos] Could not converge", "[Lanczos] Unknown error (found NaN in result guess) at iteration i").
+ * The adaptive convergence-check schedule (starts at 3) is kept per handle, as per Solver instance.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_lanczos uammd_lanczos;
+typedef int (*uammd_matvec_fn)(void *ctx, const float *d_v, float *d_Mv, int n, void *stream);
+int uammd_lanczos_create(uammd_lanczos **out);
+int uammd_lanczos_destroy(uammd_lanczos *h);
+int uammd_lanczos_run(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v,
+                      float tolerance, int n, void *stream, int *iterations);
+int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
+int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps);
+
 #ifdef __cplusplus
 }
 #endif

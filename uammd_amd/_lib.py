@@ -79,7 +79,14 @@ SIGNATURES = {
     "uammd_fcm_self_mobility": (C.c_double, [C.c_double, C.c_double, C.c_double]),
     "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),
     "uammd_fcm_set_seed2": (_i, [_vp, _u]),
+    "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
+    "uammd_lanczos_destroy": (_i, [_vp]),
+    "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),
+    "uammd_lanczos_set_iteration_hard_limit": (_i, [_vp, _i]),
+    "uammd_lanczos_get_last_run_required_steps": (_i, [_vp, C.POINTER(_i)]),
 }
+
+MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
 _lib = None
 

@@ -269,7 +269,63 @@ class FCMIntegrator(Integrator):
                                                 current_stream()))
 
 
+class LanczosSolver:
+    """lanczos::Solver (misc/LanczosAlgorithm.cuh:32-83).  `dot(v, Mv)` is a Python callable on torch tensors that
+    writes Mv = M v (the MatrixDot concept, LanczosAlgorithm/MatrixDot.h)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.uammd_lanczos_create(C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_lanczos_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def setIterationHardLimit(self, n):
+        check(self.lib.uammd_lanczos_set_iteration_hard_limit(self.h, int(n)))
+
+    def getLastRunRequiredSteps(self):
+        v = C.c_int(0)
+        check(self.lib.uammd_lanczos_get_last_run_required_steps(self.h, C.byref(v)))
+        return int(v.value)
+
+    def run(self, dot, Bv, v, tolerance, N=None):
+        n = int(N if N is not None else v.numel())
+        dev = v.device
+
+        def _wrap(ptr, count):
+            class _Raw:
+                pass
+            r = _Raw()
+            r.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(r, device=dev)
+        err = []
+
+        def cb(ctx, d_v, d_Mv, nn, stream):
+            try:
+                dot(_wrap(d_v, nn), _wrap(d_Mv, nn))
+                return 0
+            except Exception as e:  # surfaced after the C call returns
+                err.append(e)
+                return -99
+        fn = _lib.MATVEC_FN(cb)
+        it = C.c_int(0)
+        rc = self.lib.uammd_lanczos_run(self.h, C.cast(fn, C.c_void_p), None, _ptr(Bv), _ptr(v), float(tolerance), n,
+                                        current_stream(), C.byref(it))
+        if err:
+            raise err[0]
+        check(rc)
+        return int(it.value)
+
+
 class BDHI:
+    LanczosSolver = LanczosSolver
     FCM = FCM
     FCMIntegrator = FCMIntegrator
     FCM_impl = FCM_impl

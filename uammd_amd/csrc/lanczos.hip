@@ -1,0 +1,315 @@
+// Lanczos sqrt(M) v — Krylov approximation of the square root of a symmetric positive matrix applied to a
+// vector, for the Brownian increments of BDHI methods (PSE near field, open-boundary RPY).
+//
+// Reference behaviour (misc/LanczosAlgorithm/LanczosAlgorithm.cu):
+//   Krylov recurrence                 :102-157  w = M v_i - h_(i-1,i) v_(i-1); h_ii = w.v_i; w -= h_ii v_i;
+//                                               h_(i,i+1) = |w|; breakdown guard h < 1e-3 h_ii/|z| -> 0, w = e1
+//   estimate  y = |z| V_m H^(1/2) e1   :43-82, :162-172 (LAPACKE steqr + CBLAS gemv on the host)
+//   convergence |Bz_i - Bz_(i-1)|/|Bz_(i-1)| <= tol, first check after an adaptive number of steps (starts at 3),
+//   hard limit 200, "Could not converge"        :202-262
+// The reference synchronises with the host for EVERY BLAS-1 scalar (cuBLAS host pointer mode: >= 6 syncs per
+// iteration) and re-allocates V every iteration behind a cudaDeviceSynchronize (:86-99).
+//
+// MI355X design: the recurrence scalars live in HBM and never visit the host.  Each iteration is the user's
+// M v plus three streaming kernels; every reduction is "partials + every consumer block re-sums the 1 KB of
+// partials", so there is no finalize launch, no atomics, and the result is deterministic.  The host only sees
+// hdiag/hsup when a convergence check is due (one small D2H copy), solves the m x m tridiagonal problem there
+// (implicit QL, double precision) and sends back the m coefficients of H^(1/2) e1; the tall-skinny product
+// V_m y is a bandwidth-bound streaming kernel (N x m floats read once) — MFMA would buy nothing for one RHS.
+#include "celllist.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace uammd_hip {
+
+constexpr int kLB = 256;       // threads per block
+constexpr int kLParts = 256;   // reduction partials (one per block)
+
+struct Lanczos {
+  DeviceBuffer V, w, Bold, parts, scal, ycoef;
+  int capCols = 0, capN = 0;
+  int check_convergence_steps = 3;  // Solver::Solver(), LanczosAlgorithm.cu:175
+  int iterationHardLimit = 200;
+  int lastRunRequiredSteps = 0;
+};
+
+UH_D float block_sum(float x, float *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wv] = x;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x < 64) {
+    t = (threadIdx.x < kLB / 64) ? sh[threadIdx.x] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  }
+  __syncthreads();
+  return t;  // valid in wave 0
+}
+UH_D float sum_parts(const float *__restrict__ parts, int nparts, float *sh) {  // every block: same order, same result
+  float x = 0.f;
+  for (int k = threadIdx.x; k < nparts; k += kLB) x += parts[k];
+  float t = block_sum(x, sh);
+  if (threadIdx.x == 0) sh[8] = t;
+  __syncthreads();
+  t = sh[8];
+  __syncthreads();
+  return t;
+}
+
+// scal layout (device floats): [0] = |z|, [1..] hdiag[i] at 1+i, hsup[i] at 1+cap+i
+// parts <- partial sums of x[i]^2
+__global__ void __launch_bounds__(kLB) k_l_norm2(const float *__restrict__ x, int n, float *__restrict__ parts) {
+  __shared__ float sh[16];
+  float a = 0.f;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) a = fmaf(x[i], x[i], a);
+  const float t = block_sum(a, sh);
+  if (threadIdx.x == 0) parts[blockIdx.x] = t;
+}
+// v0 = z / |z| ; scal[0] = |z|
+__global__ void __launch_bounds__(kLB) k_l_first(const float *__restrict__ z, int n, const float *__restrict__ parts,
+                                                 int nparts, float *__restrict__ v0, float *__restrict__ scal) {
+  __shared__ float sh[16];
+  const float normz = sqrtf(sum_parts(parts, nparts, sh));
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = normz;
+  const float inv = 1.0f / normz;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) v0[i] = z[i] * inv;
+}
+// w -= hsup[i-1] * v_(i-1) (if i > 0); parts <- partial w . v_i
+__global__ void __launch_bounds__(kLB) k_l_a(float *__restrict__ w, const float *__restrict__ vprev,
+                                             const float *__restrict__ vi, int n, const float *__restrict__ hsupPrev,
+                                             float *__restrict__ parts) {
+  __shared__ float sh[16];
+  const float hp = hsupPrev ? *hsupPrev : 0.f;
+  float a = 0.f;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
+    float x = w[i];
+    if (vprev) { x = fmaf(-hp, vprev[i], x); w[i] = x; }
+    a = fmaf(x, vi[i], a);
+  }
+  const float t = block_sum(a, sh);
+  if (threadIdx.x == 0) parts[blockIdx.x] = t;
+}
+// hdiag_i = sum(partsA); w -= hdiag_i * v_i; partsB <- partial |w|^2
+__global__ void __launch_bounds__(kLB) k_l_b(float *__restrict__ w, const float *__restrict__ vi, int n,
+                                             const float *__restrict__ partsA, int nparts, float *__restrict__ hdiag_i,
+                                             float *__restrict__ partsB) {
+  __shared__ float sh[16];
+  const float h = sum_parts(partsA, nparts, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hdiag_i = h;
+  float a = 0.f;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
+    const float x = fmaf(-h, vi[i], w[i]);
+    w[i] = x;
+    a = fmaf(x, x, a);
+  }
+  const float t = block_sum(a, sh);
+  if (threadIdx.x == 0) partsB[blockIdx.x] = t;
+}
+// hsup_i = |w| with the breakdown guard; v_(i+1) = w / hsup_i  (or e1)
+__global__ void __launch_bounds__(kLB) k_l_c(const float *__restrict__ w, int n, const float *__restrict__ partsB,
+                                             int nparts, const float *__restrict__ hdiag_i,
+                                             const float *__restrict__ normz, float *__restrict__ hsup_i,
+                                             float *__restrict__ vnext) {
+  __shared__ float sh[16];
+  float hs = sqrtf(sum_parts(partsB, nparts, sh));
+  const float tol = 1e-3f * (*hdiag_i) / (*normz);
+  if (hs < tol) hs = 0.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hsup_i = hs;
+  const float inv = hs > 0.0f ? 1.0f / hs : 0.0f;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB)
+    vnext[i] = hs > 0.0f ? w[i] * inv : (i == 0 ? 1.0f : 0.0f);
+}
+// Bz = |z| * V[:, :m] * y ; partials of |Bold|^2 and |Bz - Bold|^2 ; then Bold <- Bz
+__global__ void __launch_bounds__(kLB) k_l_estimate(const float *__restrict__ V, int n, int m,
+                                                    const float *__restrict__ y, const float *__restrict__ normz,
+                                                    float *__restrict__ Bz, float *__restrict__ Bold,
+                                                    float *__restrict__ parts) {
+  __shared__ float sh[16];
+  const float nz = *normz;
+  float a = 0.f, b = 0.f;
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
+    float s = 0.f;
+    for (int c = 0; c < m; ++c) s = fmaf(V[(size_t)c * n + i], y[c], s);
+    s *= nz;
+    const float o = Bold[i];
+    a = fmaf(o, o, a);
+    const float d = s - o;
+    b = fmaf(d, d, b);
+    Bz[i] = s;
+    Bold[i] = s;
+  }
+  const float ta = block_sum(a, sh);
+  if (threadIdx.x == 0) parts[blockIdx.x] = ta;
+  const float tb = block_sum(b, sh);
+  if (threadIdx.x == 0) parts[kLParts + blockIdx.x] = tb;
+}
+
+// Symmetric tridiagonal eigenproblem by implicit QL with eigenvector accumulation; d (diag, size m) returns the
+// eigenvalues, e (sub-diagonal, e[0..m-2]) is destroyed, z (m x m, row major z[i*m+j]) must be the identity on
+// entry and returns the eigenvectors in its columns.  Returns 0, or i+1 if eigenvalue i failed to converge.
+static int tridiag_ql(std::vector<double> &d, std::vector<double> &e, std::vector<double> &z, int m) {
+  e.resize(m, 0.0);
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+        if (std::fabs(e[mm]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 60) return l + 1;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) { d[i + 1] -= p; e[mm] = 0.0; break; }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < m; ++k) {
+            f = z[(size_t)k * m + i + 1];
+            z[(size_t)k * m + i + 1] = s * z[(size_t)k * m + i] + c * f;
+            z[(size_t)k * m + i] = c * z[(size_t)k * m + i] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  return 0;
+}
+
+static inline int lgrid(int n) { return std::min(kLParts, (n + kLB - 1) / kLB); }
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+int uammd_lanczos_create(uammd_lanczos **out) {
+  if (!out) { set_last_error("uammd_lanczos_create: null output"); return -1; }
+  *out = reinterpret_cast<uammd_lanczos *>(new Lanczos());
+  return 0;
+}
+int uammd_lanczos_destroy(uammd_lanczos *h) {
+  delete reinterpret_cast<Lanczos *>(h);
+  return 0;
+}
+int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit) {
+  if (!h || limit < 1) { set_last_error("uammd_lanczos_set_iteration_hard_limit: bad arguments"); return -1; }
+  reinterpret_cast<Lanczos *>(h)->iterationHardLimit = limit;
+  return 0;
+}
+int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps) {
+  if (!h || !steps) { set_last_error("uammd_lanczos_get_last_run_required_steps: null argument"); return -1; }
+  *steps = reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps;
+  return 0;
+}
+
+int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance,
+                      int n, void *stream, int *iterations) {
+  if (!hh || !dot || !d_Bv || !d_v || n < 1) { set_last_error("uammd_lanczos_run: bad arguments"); return -1; }
+  Lanczos *L = reinterpret_cast<Lanczos *>(hh);
+  hipStream_t st = (hipStream_t)stream;
+  const int cap = L->iterationHardLimit + 2;
+  if (L->capCols < cap || L->capN < n) {
+    UH_CHECK(hipStreamSynchronize(st));
+    if (int e = L->V.reserve(sizeof(float) * (size_t)n * cap)) return e;
+    if (int e = L->w.reserve(sizeof(float) * (size_t)n)) return e;
+    if (int e = L->Bold.reserve(sizeof(float) * (size_t)n)) return e;
+    if (int e = L->parts.reserve(sizeof(float) * 2 * kLParts)) return e;
+    if (int e = L->scal.reserve(sizeof(float) * (2 * cap + 2))) return e;
+    if (int e = L->ycoef.reserve(sizeof(float) * cap)) return e;
+    L->capCols = cap;
+    L->capN = n;
+  }
+  float *V = (float *)L->V.ptr, *w = (float *)L->w.ptr, *Bold = (float *)L->Bold.ptr, *parts = (float *)L->parts.ptr;
+  float *scal = (float *)L->scal.ptr, *ycoef = (float *)L->ycoef.ptr;
+  float *hdiag = scal + 1, *hsup = scal + 1 + cap;
+  const int g = lgrid(n);
+  UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(float) * (size_t)n, st));   // oldBz = 0, :205-206
+  hipLaunchKernelGGL(k_l_norm2, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
+  hipLaunchKernelGGL(k_l_first, dim3(g), dim3(kLB), 0, st, d_v, n, (const float *)parts, g, V, scal);
+  const int checkConvergenceSteps = std::min(L->check_convergence_steps, L->iterationHardLimit - 2);
+  std::vector<float> hbuf(2 * cap + 2);
+  std::vector<double> dd, ee, zz;
+  std::vector<float> yy;
+  for (int i = 0; i < L->iterationHardLimit; ++i) {
+    float *vi = V + (size_t)i * n;
+    if (int rc = dot(ctx, vi, w, n, stream)) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the matrix-vector callback failed (%d)", rc);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_l_a, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const float *)(V + (size_t)(i - 1) * n) : nullptr,
+                       (const float *)vi, n, i > 0 ? (const float *)(hsup + i - 1) : nullptr, parts);
+    hipLaunchKernelGGL(k_l_b, dim3(g), dim3(kLB), 0, st, w, (const float *)vi, n, (const float *)parts, g, hdiag + i,
+                       parts + kLParts);
+    hipLaunchKernelGGL(k_l_c, dim3(g), dim3(kLB), 0, st, (const float *)w, n, (const float *)(parts + kLParts), g,
+                       (const float *)(hdiag + i), (const float *)scal, hsup + i, V + (size_t)(i + 1) * n);
+    if (i >= checkConvergenceSteps) {
+      const int m = i + 1;
+      UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(float) * (2 * cap + 1), hipMemcpyDeviceToHost, st));
+      UH_CHECK(hipStreamSynchronize(st));
+      dd.assign(m, 0.0);
+      ee.assign(m, 0.0);
+      zz.assign((size_t)m * m, 0.0);
+      for (int k = 0; k < m; ++k) { dd[k] = hbuf[1 + k]; zz[(size_t)k * m + k] = 1.0; }
+      for (int k = 0; k + 1 < m; ++k) ee[k] = hbuf[1 + cap + k];
+      if (int info = tridiag_ql(dd, ee, zz, m)) {
+        set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
+        return -20;
+      }
+      yy.assign(m, 0.f);
+      // H^(1/2) e1 = P * (sqrt(lambda_j) * P[0][j])   (:64-82); a negative eigenvalue gives NaN as in the reference
+      for (int r = 0; r < m; ++r) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
+        yy[r] = (float)s;
+      }
+      UH_CHECK(hipMemcpyAsync(ycoef, yy.data(), sizeof(float) * m, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_l_estimate, dim3(g), dim3(kLB), 0, st, (const float *)V, n, m, (const float *)ycoef,
+                         (const float *)scal, d_Bv, Bold, parts);
+      if (i > 0) {
+        float hp[2 * kLParts];
+        UH_CHECK(hipMemcpyAsync(hp, parts, sizeof(float) * 2 * kLParts, hipMemcpyDeviceToHost, st));
+        UH_CHECK(hipStreamSynchronize(st));
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < g; ++k) { a += hp[k]; b += hp[kLParts + k]; }
+        const float err = std::fabs((float)(std::sqrt(b) / std::sqrt(a)));
+        if (std::isnan(err)) {
+          set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
+          return -21;
+        }
+        if (err <= tolerance) {
+          // registerRequiredStepsForConverge, :253-262
+          L->lastRunRequiredSteps = i;
+          if (i - 2 > L->check_convergence_steps) L->check_convergence_steps += 1;
+          else L->check_convergence_steps = std::max(1, L->check_convergence_steps - 2);
+          if (iterations) *iterations = i;
+          UH_CHECK(hipGetLastError());
+          return 0;
+        }
+      }
+    }
+  }
+  UH_CHECK(hipGetLastError());
+  set_last_error("[Lanczos] Could not converge");
+  return -22;
+}
+
+}  // extern "C"
