@@ -125,6 +125,11 @@ def test_ibm_2d_adjoint_reference_test(hip):
     assert abs(out.item() / (integ * integ) - 1.0) <= 1e-4
 
 
+def fcm_kernel(hip, cells, L, tol):
+    hmin = float(min(np.broadcast_to(np.asarray(L, np.float32), (3,)) / np.asarray(cells, np.float32)))
+    return hip.Kernels.Gaussian(hmin, tol)[0]
+
+
 def _fcm_case(hip, o32, n, cells, L, tol, seed=1234):
     from oracle.fcm import FCMOracle
     rng = np.random.default_rng(seed)
@@ -146,6 +151,14 @@ def _fcm_case(hip, o32, n, cells, L, tol, seed=1234):
 def test_fcm_deterministic(hip, o32, cells, L, tol):
     n = 256
     pos, force, fcm, ofcm = _fcm_case(hip, o32, n, cells, L, tol)
+    # 32^3 takes the tile-owned spread (grid divisible by 8, >= 3 tiles); also run the atomic variant on it
+    if cells == [32, 32, 32]:
+        fa = hip.BDHI.FCM_impl(hip.Box(L), cells, fcm_kernel(hip, cells, L, tol), 1.3, 987654, fcm.hydrodynamicRadius)
+        fa.set_option("atomic_spread", 1)
+        va = fa.computeHydrodynamicDisplacements(torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda(), n, 0.0, 0.0)
+        vt = fcm.computeHydrodynamicDisplacements(torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda(), n, 0.0, 0.0)
+        torch.cuda.synchronize()
+        assert np.linalg.norm((va - vt).cpu().numpy()) <= 1e-5 * np.linalg.norm(va.cpu().numpy())
     dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
     grids = {}
     vref = ofcm.displacements(pos, force, grids=grids)
@@ -245,3 +258,33 @@ def test_fcm_full_size_properties(hip):
     assert np.linalg.norm(v12 - (2 * v1 - 3 * v2)) <= 1e-4 * np.linalg.norm(v12)
     assert (f1[:, :3].astype(np.float64) * v1).sum() > 0
     assert np.isfinite(v12).all()
+
+
+def test_fcm_tile_spread_edge_cases(hip, o32):
+    """Tile-owned spread/prepared gather on a non cubic grid (40x24x32: 5x3x4 tiles), particles clustered on tile
+    corners, on the box faces and outside the primary box (unwrapped coordinates)."""
+    from oracle.fcm import FCMOracle
+    cells, L = [40, 24, 32], np.array([40.0, 24.0, 32.0], np.float32)
+    rng = np.random.default_rng(11)
+    n = 600
+    pos = np.zeros((n, 4), np.float32)
+    pos[:200, :3] = rng.uniform(-0.5, 0.5, (200, 3)) * L
+    corners = (rng.integers(0, 6, (200, 3)) * 8).astype(np.float32) - L / 2
+    pos[200:400, :3] = corners + rng.normal(0, 0.3, (200, 3))
+    pos[400:, :3] = rng.uniform(-1.5, 1.5, (200, 3)) * L
+    pos[0, :3] = -L / 2
+    pos[1, :3] = L / 2 - np.float32(1e-3)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    ofcm = FCMOracle(o32, L, cells, tolerance=1e-3, viscosity=0.9, seed=5)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    vref = ofcm.displacements(pos, force)
+    assert np.linalg.norm(v - vref) <= 1e-5 * np.linalg.norm(vref)
+    gk = fcm.fourier_grid(dp, df, n, 0.0, 0.0).cpu().numpy()
+    grids = {}
+    ofcm.displacements(pos, force, grids=grids)
+    rk = grids["fourier"].view(np.float32).reshape(gk.shape)
+    assert np.abs(gk - rk).max() <= 2e-5 * np.abs(rk).max()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: tools/pmc_any.sh <tag> <kernel-name-pattern> <bench args...>
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=$1; PAT=$2; shift; shift
+i=0
+for CNT in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "SQ_THREAD_CYCLES_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_BRANCH SQ_LDS_ATOMIC_RETURN SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL"; do
+  i=$((i+1))
+  rm -rf /tmp/pmc_${TAG}_$i
+  rocprofv3 --pmc $CNT -d /tmp/pmc_${TAG}_$i -o pmc -- python $R/bench.py "$@" > /tmp/pmc_${TAG}_$i.log 2>&1
+  python3 - <<PY > $R/gpurun_out/pmc_${TAG}_$i.txt
+import sqlite3, glob
+for f in glob.glob('/tmp/pmc_${TAG}_$i/**/*.db', recursive=True):
+    db = sqlite3.connect(f); c = db.cursor()
+    q = "select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%$PAT%' group by kernel_name, counter_name"
+    for r in c.execute(q): print(r[0][:50], r[1], r[2], r[3])
+PY
+done
+cat $R/gpurun_out/pmc_${TAG}_*.txt

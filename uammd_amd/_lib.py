@@ -79,6 +79,7 @@ SIGNATURES = {
     "uammd_fcm_self_mobility": (C.c_double, [C.c_double, C.c_double, C.c_double]),
     "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),
     "uammd_fcm_set_seed2": (_i, [_vp, _u]),
+    "uammd_fcm_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),

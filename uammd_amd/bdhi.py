@@ -176,6 +176,9 @@ class FCM_impl:
         check(self.lib.uammd_fcm_export_fourier(self.h, _ptr(out), current_stream()))
         return out
 
+    def set_option(self, name, value):
+        check(self.lib.uammd_fcm_set_option(self.h, name.encode(), int(value)))
+
     def seed2(self, value=None):
         if value is None:
             v = C.c_uint(0)

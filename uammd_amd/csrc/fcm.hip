@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <mutex>
+#include <string>
 
 namespace uammd_hip {
 
@@ -43,7 +44,11 @@ struct FCM {
   int nxpad = 0;           // 2*(nx/2+1)
   size_t planeReal = 0;    // floats per component plane
   size_t planeCplx = 0;    // complex per component plane
-  DeviceBuffer gridBuf, work;
+  DeviceBuffer gridBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
+  bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
+  int3 ntiles{0, 0, 0};
+  int prepCapN = 0;
+  bool forceAtomicSpread = false;  // test hook
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   size_t workBytes = 0;
@@ -113,6 +118,203 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
     }
     if (lane == 0) { vout[3 * (size_t)id] = ax; vout[3 * (size_t)id + 1] = ay; vout[3 * (size_t)id + 2] = az; }
   }
+}
+
+
+// ---- tile-owned spreading (no global atomics, no grid memset) -------------------------------------------
+// The grid is cut into T^3-node tiles; a workgroup OWNS one tile: it accumulates the contributions of every
+// particle whose stencil overlaps the tile into an LDS copy of the tile (LDS float atomics, conflicts stay
+// inside the CU) and then stores the tile with plain coalesced writes.  Particles are binned by tile with a
+// small counting sort; the per-particle stencil origin and the 3*support 1-D weights are computed ONCE
+// (k_fcm_prepare) and reused by every tile that the particle touches and by the gather.
+constexpr int kTile = 8;
+
+struct FcmPrep {
+  // all arrays below are in TILE-SORTED order (slot = tileStart[tile] + rank) except tileOf/rank
+  int4 *origin;     // int4[N]: first stencil node per axis (celli - P), unwrapped; .w = original particle index
+  float *weights;   // float[wstride*N]
+  float4 *force;    // float4[N] (xyz)
+  int *tileOf;      // int[N]   (original order)
+  int *rank;        // int[N]   (original order)
+  int *tileCount;   // int[ntiles]
+  int *tileStart;   // int[ntiles+1]
+  int wstride;
+};
+
+__global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict__ pos, int N, GridT<float> grid,
+                                                        int3 ntiles, FcmPrep pr) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  const float4 p4 = pos[id];
+  const int3 celli = grid.getCell(real3f{p4.x, p4.y, p4.z});
+  const int t = (celli.x / kTile) + ntiles.x * ((celli.y / kTile) + ntiles.y * (celli.z / kTile));
+  pr.tileOf[id] = t;
+  pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
+}
+
+__global__ void __launch_bounds__(1024) k_fcm_tile_scan(const int *__restrict__ count, int ntiles, int *__restrict__ start) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ntiles ? count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < ntiles) start[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[ntiles] = carry;
+}
+
+// Stencil origin + the 3*support 1-D weights of every particle, written at the particle's tile-sorted slot.
+__global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ pos, const float4 *__restrict__ force,
+                                                      int N, GridT<float> grid, IBMKernelDev kern, FcmPrep pr) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  const float4 p4 = pos[id];
+  const real3f pi{p4.x, p4.y, p4.z};
+  const int3 celli = grid.getCell(pi);
+  const int3 P = compute_support_shift(grid, pi, celli, kern.support);
+  const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
+  const int slot = pr.tileStart[pr.tileOf[id]] + pr.rank[id];
+  pr.origin[slot] = make_int4(ox, oy, oz, id);
+  pr.force[slot] = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float *w = pr.weights + (size_t)pr.wstride * slot;
+  const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
+  for (int i = 0; i < sx; ++i) w[i] = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + i), celli.y, celli.z)).x);
+  for (int i = 0; i < sy; ++i) w[sx + i] = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(celli.x, grid.pbc_y(oy + i), celli.z)).y);
+  for (int i = 0; i < sz; ++i) w[sx + sy + i] = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(celli.x, celli.y, grid.pbc_z(oz + i))).z);
+}
+
+// One workgroup (4 waves) per tile.  The 27 surrounding tiles' particle ranges are dealt to the waves; for each
+// range the lanes test one particle each (does its stencil reach this tile?) and the wave then spreads the
+// accepted particles one at a time, the lanes covering the nodes of the stencil-tile intersection.
+__global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane,
+                                                          int3 support, int3 ntiles, FcmPrep pr) {
+  // LDS float atomics retire ~1 lane per clock on gfx950 (measured: ds_add_f32 kept the LDS pipe 90 % busy and the
+  // kernel at 400 us).  Instead every wave owns a PRIVATE copy of the tile and updates it with plain
+  // read-modify-write (the lanes of one particle touch distinct nodes, a wave's LDS ops retire in order);
+  // the four copies are summed when the tile is stored.
+  constexpr int T3 = kTile * kTile * kTile;
+  __shared__ float acc[4 * 3 * T3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 3 * T3; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+  float *mine = acc + wave * 3 * T3;
+  const int tx = blockIdx.x % ntiles.x, ty = (blockIdx.x / ntiles.x) % ntiles.y, tz = blockIdx.x / (ntiles.x * ntiles.y);
+  const int x0 = tx * kTile, y0 = ty * kTile, z0 = tz * kTile;
+  const int sx = support.x, sy = support.y, sz = support.z;
+  for (int nb = wave; nb < 27; nb += 4) {
+    int ux = tx + nb % 3 - 1, uy = ty + (nb / 3) % 3 - 1, uz = tz + nb / 9 - 1;
+    int shx = -x0, shy = -y0, shz = -z0;  // image shift (in nodes) + change to this tile's frame
+    if (ux < 0) { ux += ntiles.x; shx -= n.x; } else if (ux >= ntiles.x) { ux -= ntiles.x; shx += n.x; }
+    if (uy < 0) { uy += ntiles.y; shy -= n.y; } else if (uy >= ntiles.y) { uy -= ntiles.y; shy += n.y; }
+    if (uz < 0) { uz += ntiles.z; shz -= n.z; } else if (uz >= ntiles.z) { uz -= ntiles.z; shz += n.z; }
+    const int t = ux + ntiles.x * (uy + ntiles.y * uz);
+    const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
+    for (int base = s; base < e; base += 64) {
+      const int k = base + lane;
+      int ox = 0, oy = 0, oz = 0;
+      bool accept = false;
+      if (k < e) {
+        const int4 o = pr.origin[k];
+        ox = o.x + shx; oy = o.y + shy; oz = o.z + shz;
+        accept = ox < kTile && ox + sx > 0 && oy < kTile && oy + sy > 0 && oz < kTile && oz + sz > 0;
+      }
+      unsigned long long todo = __ballot(accept);
+      while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int px = __shfl(ox, j, 64), py = __shfl(oy, j, 64), pz = __shfl(oz, j, 64);
+        const int kp = base + j;
+        const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * kp + lane] : 0.0f;
+        const float4 f = pr.force[kp];
+        const int ax = max(px, 0), bx = min(px + sx, kTile);
+        const int ay = max(py, 0), by = min(py + sy, kTile);
+        const int az = max(pz, 0), bz = min(pz + sz, kTile);
+        const int nx = bx - ax, ny = by - ay, nz = bz - az;
+        const int nxy = nx * ny, cnt = nxy * nz;
+        // all three extents are in [1, 8]: exact small-integer division by float reciprocal
+        const float rxy = 1.0f / (float)nxy, rx = 1.0f / (float)nx;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {  // wave-uniform trip count (shuffles inside)
+          const int i = i0 + lane;
+          const bool in = i < cnt;
+          const int iu = in ? i : 0;
+          int kk = (int)(((float)iu + 0.5f) * rxy);
+          const int r = iu - kk * nxy;
+          int jj = (int)(((float)r + 0.5f) * rx);
+          const int ii = r - jj * nx;
+          const int lx = ax + ii, ly = ay + jj, lz = az + kk;
+          const float wx = __shfl(wl, lx - px, 64), wy = __shfl(wl, sx + ly - py, 64), wz = __shfl(wl, sx + sy + lz - pz, 64);
+          if (!in) continue;
+          const float wt = wx * wy * wz;
+          const int node = lx + kTile * (ly + kTile * lz);
+          mine[node] += f.x * wt;
+          mine[T3 + node] += f.y * wt;
+          mine[2 * T3 + node] += f.z * wt;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T3; i += 256) {
+    const int lx = i % kTile, ly = (i / kTile) % kTile, lz = i / (kTile * kTile);
+    const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * ((size_t)(y0 + ly) + (size_t)n.y * (size_t)(z0 + lz));
+    g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
+    g0[plane + node] = (acc[T3 + i] + acc[4 * T3 + i]) + (acc[7 * T3 + i] + acc[10 * T3 + i]);
+    g0[2 * plane + node] = (acc[2 * T3 + i] + acc[5 * T3 + i]) + (acc[8 * T3 + i] + acc[11 * T3 + i]);
+  }
+}
+
+// Gather with the precomputed origin/weights: one wave per tile-sorted slot (neighbouring waves touch the same
+// nodes), result written at the particle's original index.
+__global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vout, const float *__restrict__ g0, int N,
+                                                          int3 n, int nxpad, size_t plane, int3 support, float dV,
+                                                          FastDiv dsx, FastDiv dsxy, FcmPrep pr) {
+  const int lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= N) return;
+  const int4 o = pr.origin[slot];
+  const int sx = support.x, sy = support.y, sz = support.z;
+  const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * slot + lane] : 0.0f;
+  const int nn = sx * sy * sz;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < nn;
+    const uint iu = in ? (uint)i : 0u;
+    const uint kk = dsxy.div(iu);
+    const uint rem = iu - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const float wx = __shfl(wl, (int)ii, 64), wy = __shfl(wl, sx + (int)jj, 64), wz = __shfl(wl, sx + sy + (int)kk, 64);
+    if (!in) continue;
+    int cx = o.x + (int)ii, cy = o.y + (int)jj, cz = o.z + (int)kk;
+    cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
+    cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
+    cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
+    const size_t node = (size_t)cx + (size_t)nxpad * ((size_t)cy + (size_t)n.y * (size_t)cz);
+    ax = fmaf(dV, g0[node] * wx * wy * wz, ax);
+    ay = fmaf(dV, g0[plane + node] * wx * wy * wz, ay);
+    az = fmaf(dV, g0[2 * plane + node] * wx * wy * wz, az);
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) {
+    ax += __shfl_xor(ax, o2, 64);
+    ay += __shfl_xor(ay, o2, 64);
+    az += __shfl_xor(az, o2, 64);
+  }
+  if (lane == 0) { vout[3 * (size_t)o.w] = ax; vout[3 * (size_t)o.w + 1] = ay; vout[3 * (size_t)o.w + 2] = az; }
 }
 
 // ---- Fourier space ---------------------------------------------------------------------------------------
@@ -302,6 +504,12 @@ int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
   f->planeReal = (size_t)f->nxpad * par->cells[1] * par->cells[2];
   f->planeCplx = f->planeReal / 2;
   if (int e = f->gridBuf.reserve(sizeof(float) * 3 * f->planeReal)) { delete f; return e; }
+  f->useTiles = par->cells[0] % kTile == 0 && par->cells[1] % kTile == 0 && par->cells[2] % kTile == 0 &&
+                par->cells[0] / kTile >= 3 && par->cells[1] / kTile >= 3 && par->cells[2] / kTile >= 3 &&
+                // a stencil may reach support/2+1 nodes outside the particle's tile: adjacent tiles only
+                par->kernel.support[0] <= 2 * (kTile - 1) && par->kernel.support[1] <= 2 * (kTile - 1) &&
+                par->kernel.support[2] <= 2 * (kTile - 1);
+  f->ntiles = make_int3(par->cells[0] / kTile, par->cells[1] / kTile, par->cells[2] / kTile);
   if (int e = fcm_make_plans(f)) { delete f; return e; }
   *out = reinterpret_cast<uammd_fcm *>(f);
   return 0;
@@ -345,10 +553,42 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
   UH_ROCFFT(rocfft_execution_info_set_stream(f->info, (void *)st));
   void *bufs[1] = {g};
+  const bool tiles = f->useTiles && !f->forceAtomicSpread;
+  FcmPrep pr{};
+  if (tiles) {
+    const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+    const int wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
+    if (f->prepCapN < N) {
+      UH_CHECK(hipStreamSynchronize(st));
+      if (int e = f->prepOrigin.reserve(sizeof(int4) * (size_t)N)) return e;
+      if (int e = f->prepWeights.reserve(sizeof(float) * (size_t)wstride * N)) return e;
+      if (int e = f->prepSorted.reserve(sizeof(float4) * (size_t)N)) return e;
+      if (int e = f->prepTileOf.reserve(sizeof(int) * (size_t)N)) return e;
+      if (int e = f->prepRank.reserve(sizeof(int) * (size_t)N)) return e;
+      if (int e = f->prepTileCount.reserve(sizeof(int) * (size_t)nt)) return e;
+      if (int e = f->prepTileStart.reserve(sizeof(int) * ((size_t)nt + 1))) return e;
+      f->prepCapN = N;
+    }
+    pr = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
+                 (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
+                 (int *)f->prepTileStart.ptr, wstride};
+    UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
+    hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
+                       f->ntiles, pr);
+    hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, (const int *)pr.tileCount, nt, pr.tileStart);
+    hipLaunchKernelGGL(k_fcm_prepare, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,
+                       (const float4 *)d_force, N, f->grid, f->kern, pr);
+  }
   if (d_force) {
-    UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
-    hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, (float *)nullptr,
-                       g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+    if (tiles) {
+      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), 0, st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+                         f->kern.support, f->ntiles, pr);
+    } else {
+      UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
+      hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
+                         (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+    }
     UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
   }
   float noisePrefactor = 0.0f;
@@ -365,10 +605,21 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
                      d_force != nullptr, noisePrefactor, f->par.seed, f->seed2);
   if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
   UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
-  hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, d_linearVelocity,
-                     g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+  if (tiles)
+    hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
+                       f->planeReal, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
+  else
+    hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr,
+                       d_linearVelocity, g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+
+int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
+  if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
+  set_last_error("uammd_fcm_set_option: unknown option %s", name);
+  return -1;
 }
 
 int uammd_fcm_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
