@@ -234,6 +234,77 @@ def cpu_baseline_fcm(sample_steps):
                       f"scipy pocketfft FFTs on {cores} threads, k-space single thread), {el:.1f} s"}
 
 
+
+def run_lj_distributed(hip, args, world, rank, dist):
+    """N > 1 (or --force-distributed): z-slab domain decomposition, one slab of `--particles` particles per rank
+    (weak scaling: the global box grows along z), halo exchange + migration over torch.distributed P2P."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    from uammd_amd.parallel import DistributedLJ, SlabDecomposition
+    lib = load()
+    n = args.particles
+    L1 = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
+    rc, dt, T = 2.5, 0.005, 1.0
+    noise = math.sqrt(2 * dt * 1.0 * T)
+    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world)
+    pos = torch.from_numpy(lattice(n, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
+    vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, math.sqrt(3 * T), 0, n, 77 + rank, None))
+    ids = torch.arange(n, dtype=torch.int32, device="cuda") + rank * n
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    cl = hip.CellList()
+    trav_events = []
+
+    def forces_fn(allpos, box_L, periodic):
+        box = hip.Box(box_L, periodic)
+        cd, ubox = hip.CellList.create_update_grid(box, rc)
+        cl.update_grid(allpos.contiguous(), ubox, cd)
+        f = torch.zeros((allpos.shape[0], 4), dtype=torch.float32, device=allpos.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, args.algo)
+        e1.record()
+        trav_events.append((e0, e1))
+        return f
+
+    def integrate_fn(step, p, v, f, step_num):
+        check(lib.uammd_verletnvt_gj(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
+                                     1.0, None, p.shape[0], dt, 1.0, 0, noise, step_num, 4242 + rank,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    sim = DistributedLJ(d, forces_fn, integrate_fn)
+    force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    for _ in range(args.warmup):
+        pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    trav_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nloc = torch.tensor([float(pos.shape[0]), el], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = nloc[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ntot = nloc[:1].clone()
+        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
+        el, total = float(tmax.item()), float(ntot.item())
+    else:
+        total = float(pos.shape[0])
+    assert torch.isfinite(pos).all()
+    assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
+    k_ms = sum(a.elapsed_time(b) for a, b in trav_events) / max(1, len(trav_events))
+    return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +320,7 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
     ap.add_argument("--brick-bits", type=int, default=None)
     ap.add_argument("--algo", type=int, default=0)
+    ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -281,6 +353,28 @@ def main():
         return
     n = args.particles
     L = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
+    if world > 1 or args.force_distributed:
+        value, ms_per_step, k_ms, L1 = run_lj_distributed(hip, args, world, rank, dist)
+        ghost_frac = 2 * 2.5 / L1 if world > 1 else 0.0
+        achieved_tflops = FLOP_PER_PARTICLE * n * (1 + ghost_frac) / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, z-slab domain decomposition (one 43-cell "
+                                   "slab per GPU, global box L x L x N*L), halo positions + migration by RCCL send/recv",
+                       "particles_per_gpu": n, "box": [L1, L1, L1 * world],
+                       "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange"},
+            "pair_interactions_per_s": 52.36 * value,
+            "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal, owned + ghost particles)",
+                         "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     # Multi-GPU: the LJ path shards by spatial domain; this round each rank integrates an independent
     # replica box of the same size (weak scaling, no data-path collective) — see DESIGN.md §multi-GPU.
     pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank)

@@ -1,0 +1,175 @@
+"""Multi-GPU path A: z-slab domain decomposition of the short-range pair-force path.
+
+The reference is single-GPU (no NCCL/MPI anywhere), so this is new design, not a mirror:
+  * one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests);
+  * rank r owns the particles with z in [zlo_r, zhi_r) (equal slabs of the periodic global box);
+  * the reference computes FULL per-particle forces (no Newton-3 halving, common.cuh:10-34), so only POSITIONS of a
+    one-cutoff halo cross the slab faces and forces need no reduction: per force evaluation each rank sends the
+    particles within rc of its two faces to its two neighbours (point-to-point, one xGMI link each) and receives
+    their ghosts — no ring all-reduce, no all-gather of the whole system;
+  * after the integration step the particles that left the slab migrate to the neighbour rank.
+Everything here is device-agnostic torch (boolean masks, cat, P2P), so the same code runs on CPU tensors under gloo;
+the force evaluation itself is a callback (`forces_fn`): the HIP cell list + LJ traversal on the GPU, the oracle in
+the CPU tests.
+
+Local frame: rank r works in coordinates z' = z - zc_r (zc_r = slab centre, periodic images chosen next to the
+slab), with a local box (Lx, Ly, slab + 2 rc) that is periodic in x, y and NOT periodic in z.
+"""
+import torch
+import torch.distributed as dist
+
+
+class SlabDecomposition:
+    def __init__(self, L, rc, rank=None, world=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.L = [float(x) for x in L]
+        self.rc = float(rc)
+        self.width = self.L[2] / self.world
+        if self.world > 1 and self.width < self.rc:
+            raise ValueError("slab thinner than the cut-off: halo would need second neighbours")
+        self.zlo = -self.L[2] / 2 + self.rank * self.width
+        self.zhi = self.zlo + self.width
+        self.zc = 0.5 * (self.zlo + self.zhi)
+        self.up = (self.rank + 1) % self.world
+        self.down = (self.rank - 1) % self.world
+
+    # ---- helpers ---------------------------------------------------------------------------------------
+    def fold_z(self, z):
+        """z folded into the global box [-Lz/2, Lz/2)."""
+        Lz = self.L[2]
+        return z - torch.floor(z / Lz + 0.5) * Lz
+
+    def owner_of(self, z):
+        r = torch.floor((self.fold_z(z) + self.L[2] / 2) / self.width).to(torch.int64)
+        return torch.clamp(r, 0, self.world - 1)
+
+    def local_box(self):
+        """(L, periodic) of the local frame."""
+        # 1 % slack so that a ghost sitting exactly on the halo face (or rounded one ulp past it) is still inside
+        return [self.L[0], self.L[1], self.width + 2.02 * self.rc], [True, True, False]
+
+    def to_local(self, pos):
+        """Global coordinates -> local frame (z relative to the slab centre, image nearest to the slab)."""
+        out = pos.clone()
+        dz = pos[:, 2] - self.zc
+        Lz = self.L[2]
+        out[:, 2] = dz - torch.floor(dz / Lz + 0.5) * Lz
+        return out
+
+    def _exchange(self, send_up, send_down):
+        """Sends `send_up` to rank+1 and `send_down` to rank-1, returns (from_down, from_up).  Rows are float32."""
+        if self.world == 1:
+            return send_down.new_zeros((0, send_down.shape[1])), send_up.new_zeros((0, send_up.shape[1]))
+        dev = send_up.device
+        ncol = send_up.shape[1]
+        counts = torch.tensor([send_up.shape[0], send_down.shape[0]], dtype=torch.int64, device=dev)
+        allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(allc, counts, group=self.group)
+        n_from_down = int(allc[self.down][0])   # what `down` sends up
+        n_from_up = int(allc[self.up][1])       # what `up` sends down
+        from_down = torch.empty((n_from_down, ncol), dtype=send_up.dtype, device=dev)
+        from_up = torch.empty((n_from_up, ncol), dtype=send_up.dtype, device=dev)
+        # zero-row messages are skipped on both sides (every rank knows all counts); with 2 ranks both neighbours
+        # are the same peer and the two messages are told apart by tag (gloo) / by issue order (RCCL)
+        t1, t2 = (1, 2) if self.world == 2 else (0, 0)
+        ops = []
+        if send_up.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, send_up.contiguous(), self.up, self.group, tag=t1))
+        if n_from_down > 0:
+            ops.append(dist.P2POp(dist.irecv, from_down, self.down, self.group, tag=t1))
+        if send_down.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, send_down.contiguous(), self.down, self.group, tag=t2))
+        if n_from_up > 0:
+            ops.append(dist.P2POp(dist.irecv, from_up, self.up, self.group, tag=t2))
+        if not ops:
+            return from_down, from_up
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return from_down, from_up
+
+    # ---- halo ---------------------------------------------------------------------------------------------
+    def halo_exchange(self, pos_local):
+        """pos_local: real4[N] of the OWNED particles in the local frame (|z'| <= width/2).  Returns real4[N+G]:
+        owned particles followed by the ghosts received from below and above, already shifted into this frame."""
+        if self.world == 1:
+            return pos_local, 0
+        z = pos_local[:, 2]
+        half = 0.5 * self.width
+        up_mask = z >= half - self.rc
+        down_mask = z < -half + self.rc
+        send_up = pos_local[up_mask].clone()
+        send_down = pos_local[down_mask].clone()
+        # into the receiver's frame: its centre is one slab width above / below mine
+        send_up[:, 2] -= self.width
+        send_down[:, 2] += self.width
+        from_down, from_up = self._exchange(send_up, send_down)
+        ghosts = torch.cat([from_down, from_up], dim=0)
+        return torch.cat([pos_local, ghosts], dim=0), ghosts.shape[0]
+
+    # ---- migration ------------------------------------------------------------------------------------------
+    def migrate(self, pos_local, *others):
+        """Moves the particles that left the slab (|z'| > width/2 after integration) to the neighbour ranks together
+        with the per-particle arrays in `others` (vel, id, ...).  Returns the new (pos_local, *others)."""
+        if self.world == 1:
+            return (pos_local,) + tuple(others)
+        z = pos_local[:, 2]
+        half = 0.5 * self.width
+        go_up = z >= half
+        go_down = z < -half
+        stay = ~(go_up | go_down)
+        # int32 arrays (particle ids) travel bit-cast to float32 in the same message
+        cols = [pos_local] + [(o.to(torch.int32).view(torch.float32) if o.dtype != torch.float32 else o).reshape(o.shape[0], -1)
+                              for o in others]
+        widths = [c.shape[1] for c in cols]
+        packed = torch.cat(cols, dim=1)
+        up_rows = packed[go_up].clone()
+        down_rows = packed[go_down].clone()
+        up_rows[:, 2] -= self.width
+        down_rows[:, 2] += self.width
+        from_down, from_up = self._exchange(up_rows, down_rows)
+        new = torch.cat([packed[stay], from_down, from_up], dim=0)
+        out, c0 = [], 0
+        for w, ref in zip(widths, [pos_local] + list(others)):
+            block = new[:, c0:c0 + w]
+            c0 += w
+            block = block.contiguous()
+            if ref.dtype != torch.float32:
+                block = block.view(torch.int32).to(ref.dtype)
+            out.append(block.reshape((new.shape[0],) + tuple(ref.shape[1:])).contiguous())
+        return tuple(out)
+
+    # ---- distribution of an initial configuration ------------------------------------------------------------
+    def scatter_initial(self, pos_global):
+        """Every rank passes the same global configuration; returns the owned subset in the local frame + global ids."""
+        own = self.owner_of(pos_global[:, 2]) == self.rank
+        ids = torch.nonzero(own, as_tuple=False).flatten().to(torch.int32)
+        return self.to_local(pos_global[own]), ids
+
+
+class DistributedLJ:
+    """VerletNVT::GronbechJensen + PairForces<LJ> on a z-slab decomposition.  `forces_fn(pos_all, box_L, box_periodic)`
+    returns real4 forces for every row of pos_all (owned + ghosts); `integrate_fn(step, pos, vel, force, step_num)` is
+    the GJ kernel on the owned particles."""
+
+    def __init__(self, decomp, forces_fn, integrate_fn):
+        self.d, self.forces_fn, self.integrate_fn = decomp, forces_fn, integrate_fn
+        self.steps = 0
+
+    def compute_forces(self, pos_local):
+        allpos, nghost = self.d.halo_exchange(pos_local)
+        L, per = self.d.local_box()
+        f = self.forces_fn(allpos, L, per)
+        return f[:pos_local.shape[0]]
+
+    def forward_time(self, pos, vel, force, ids):
+        """One step; returns the (possibly re-sized) owned arrays."""
+        self.steps += 1
+        if self.steps == 1:
+            force = self.compute_forces(pos)
+        self.integrate_fn(1, pos, vel, force, self.steps)
+        pos, vel, ids = self.d.migrate(pos, vel, ids)
+        force = self.compute_forces(pos)
+        self.integrate_fn(2, pos, vel, force, self.steps)
+        return pos, vel, force, ids
