@@ -38,6 +38,15 @@ PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 M
 PEAK_HBM_GBS = 8000.0
 
 
+def read_traffic(name):
+    """HBM bytes per launch from the committed PMC summary (tools/pmc_traffic.sh -> profiles/), or None."""
+    tp = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(tp)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def lattice(n, L, seed, jitter=0.1):
     from util import lattice_positions
     return lattice_positions(n, L, seed=seed, jitter=jitter)
@@ -204,7 +213,8 @@ def run_fcm(hip, args, world, rank, dist):
                                   "fixed forces + Fourier-space noise (BASELINE configs[3])"},
            "roofline": {"bound": "hbm", "kernel": "whole FCM step (spread, 2x3 FFT, k-space, gather)",
                         "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "traffic": None, "algorithmic_bytes_per_step": fcm_bytes_per_step(n, cells)}}
+                        "traffic": read_traffic("traffic_fcm_step.json"),
+                        "algorithmic_bytes_per_step": fcm_bytes_per_step(n, cells)}}
     return out
 
 
@@ -370,6 +380,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal, owned + ghost particles)",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
+        if args.workload == "both":
+            # path B does not shard this round: N independent FCM replicas, one per GPU
+            out["fcm"] = run_fcm(hip, args, world, rank, dist)
+            out["fcm"]["config"]["parallelism"] = f"{world} independent replicas (no collective)"
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:
@@ -415,13 +429,7 @@ def main():
     value = n * world * args.steps / el
     k_ms = timer.mean_ms()
     achieved_tflops = FLOP_PER_PARTICLE * n / (k_ms * 1e-3) / 1e12
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic_lj_traversal.json")
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic = read_traffic("traffic_lj_traversal.json")
     out = {
         "metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,778 @@
+// uammd.h — UAMMD's host-side C++14 interface on top of libuammd_hip (MI355X / gfx950).
+//
+// Same class names, member functions, parameter structs and error behaviour as the reference headers for the two
+// hot paths (citations relative to the reference's src/):
+//   System                        System/System.h:63-316            (log levels, rng(), finish())
+//   Box, Grid                     utils/Box.cuh:16-92, utils/Grid.cuh:21-139
+//   ParticleData, property_ptr    ParticleData/ParticleData.cuh:161-465, ParticleData/Property.cuh:49-147
+//   Interactor / Integrator       Interactor/Interactor.cuh:56-119, Integrator/Integrator.cuh:33-125
+//   CellList                      Interactor/NeighbourList/CellList.cuh:83-205
+//   Potential::LJ                 Interactor/Potential/Potential.cuh:25-85, RadialPotential.cuh:49-154
+//   PairForces<Potential, NL>     Interactor/PairForces.cuh:23-64, PairForces.cu:43-78
+//   VerletNVT::{Basic,GronbechJensen}   Integrator/VerletNVT.cuh:55-115
+//   BD::EulerMaruyama             Integrator/BrownianDynamics.cuh
+//   BDHI::FCM, BDHI::FCMIntegrator, BDHI::EulerMaruyama<Method>   Integrator/BDHI/BDHI_FCM.cuh:84-198, BDHI_EulerMaruyama.cuh
+//   IBM                           misc/IBM.cuh:99-203   (windows UAMMD ships; see uammd_hip.h)
+//   lanczos::Solver, MatrixDot    misc/LanczosAlgorithm.cuh:32-83, LanczosAlgorithm/MatrixDot.h:7-25
+//
+// This header is plain host C++14: compile with any C++ compiler,
+//     g++ -std=c++14 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude main.cpp \
+//         -Luammd_amd/lib -luammd_hip -L/opt/rocm/lib -lamdhip64
+// Every device computation goes through the C ABI of uammd_hip.h; there is no CPU fallback.  User-defined DEVICE
+// functors (custom Transversers / IBM windows) are the one thing that cannot cross a C ABI: they need hipcc, as they
+// need nvcc in the reference.  Streams are hipStream_t where the reference says cudaStream_t.
+#ifndef UAMMD_MI355X_UAMMD_H
+#define UAMMD_MI355X_UAMMD_H
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../uammd_hip.h"
+
+namespace uammd {
+
+using std::make_shared;
+using std::shared_ptr;
+
+// ---- global/defines.h:33-44 ------------------------------------------------------------------------------------
+using real = float;
+struct real2 { real x, y; };
+struct real3 { real x, y, z; };
+struct real4 { real x, y, z, w; };
+struct int3_t { int x, y, z; };
+using int3 = int3_t;
+using uint = unsigned int;
+using ullint = unsigned long long;
+inline real3 make_real3(real x, real y, real z) { return {x, y, z}; }
+inline real3 make_real3(real v) { return {v, v, v}; }
+inline real3 make_real3(real4 a) { return {a.x, a.y, a.z}; }
+inline real4 make_real4(real x, real y, real z, real w) { return {x, y, z, w}; }
+inline real4 make_real4(real v) { return {v, v, v, v}; }
+inline real4 make_real4(real3 a, real w) { return {a.x, a.y, a.z, w}; }
+inline int3 make_int3(int x, int y, int z) { return {x, y, z}; }
+
+// ---- errors: utils/debugTools.h:20-64, utils/exception.h ---------------------------------------------------------
+struct cuda_generic_error : public std::runtime_error {
+  cuda_generic_error(const std::string &m, int code) : std::runtime_error(m), code(code) {}
+  int code;
+};
+struct illegal_property_access : public std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+namespace detail {
+inline void check(int rc) {
+  if (rc != 0) throw cuda_generic_error(std::string(uammd_hip_last_error()), rc);
+}
+inline void hipCheck(hipError_t e, const char *what) {
+  if (e != hipSuccess) throw cuda_generic_error(std::string(what) + ": " + hipGetErrorString(e), (int)e);
+}
+template <class T> struct DeviceArray {  // owning device buffer (thrust::device_vector stand-in for host code)
+  T *d = nullptr;
+  size_t n = 0;
+  DeviceArray() = default;
+  explicit DeviceArray(size_t n_) { resize(n_); }
+  DeviceArray(const DeviceArray &) = delete;
+  DeviceArray &operator=(const DeviceArray &) = delete;
+  ~DeviceArray() { if (d) (void)hipFree(d); }
+  void resize(size_t m) {
+    if (m == n) return;
+    if (d) (void)hipFree(d);
+    d = nullptr;
+    n = m;
+    if (m) {
+      hipCheck(hipMalloc((void **)&d, sizeof(T) * m), "hipMalloc");
+      hipCheck(hipMemset(d, 0, sizeof(T) * m), "hipMemset");
+    }
+  }
+  void swap(DeviceArray &o) { std::swap(d, o.d); std::swap(n, o.n); }
+};
+}  // namespace detail
+
+// ---- utils/utils.h:38-115 ----------------------------------------------------------------------------------------
+class Xorshift128plus {
+  uint64_t s[2];
+public:
+  Xorshift128plus() { s[0] = 12679825035178159220ULL; s[1] = 15438657923749336752ULL; }
+  explicit Xorshift128plus(uint64_t s0) { setSeed(s0); }
+  uint64_t next() {
+    uint64_t x = s[0];
+    const uint64_t y = s[1];
+    s[0] = y;
+    x ^= x << 23;
+    x ^= x >> 17;
+    x ^= y ^ (y >> 26);
+    s[1] = x;
+    return x + y;
+  }
+  uint32_t next32() { return next() % std::numeric_limits<uint32_t>::max(); }
+  double uniform(double min, double max) { return min + (next() / ((double)0xFFffFFffFFffFFffULL)) * (max - min); }
+  real3 uniform3(double min, double max) {
+    const double a = uniform(min, max), b = uniform(min, max), c = uniform(min, max);
+    return {(real)a, (real)b, (real)c};
+  }
+  void setSeed(uint64_t s0) { s[0] = s0; s[1] = (s0 + 15438657923749336752ULL) % 0xFFffFFffFFffFFffULL; }
+};
+
+// ---- System/System.h -----------------------------------------------------------------------------------------------
+class System {
+  Xorshift128plus m_rng;
+public:
+  enum LogLevel { CRITICAL = 0, ERROR, EXCEPTION, WARNING, MESSAGE, STDERR, STDOUT, DEBUG, DEBUG1, DEBUG2, DEBUG3, DEBUG4, DEBUG5, DEBUG6, DEBUG7 };
+  System() : System(0, nullptr) {}
+  System(int argc, char **argv) {
+    const auto now = std::chrono::steady_clock::now().time_since_epoch();
+    m_rng.setSeed(0xf31337Bada55D00dULL ^ (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now).count());
+    int dev = -1;
+    for (int i = 1; argv && i < argc; ++i)
+      if (std::string(argv[i]) == "--device" && i + 1 < argc) dev = std::atoi(argv[i + 1]);  // System.h:128-139
+    if (dev >= 0) detail::check(uammd_hip_set_device(dev));
+  }
+  Xorshift128plus &rng() { return m_rng; }
+  template <LogLevel level> static void log(const char *fmt, ...) {
+    if (level > maxLogLevel()) return;
+    va_list ap;
+    va_start(ap, fmt);
+    char buf[1024];
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (level == CRITICAL) throw std::runtime_error(std::string("[CRITICAL] ") + buf);  // System.h:251-257
+    std::fprintf(stderr, "[%s] %s\n", level <= EXCEPTION ? "ERROR" : (level == WARNING ? "WARNING" : "MESSAGE"), buf);
+  }
+  static int &maxLogLevel() { static int l = WARNING; return l; }
+  void finish() { (void)hipDeviceSynchronize(); }
+};
+
+// ---- utils/Box.cuh ----------------------------------------------------------------------------------------------------
+struct Box {
+  real3 boxSize, minusInvBoxSize;
+  Box() : Box(real(0)) {}
+  Box(real L) : Box(make_real3(L)) {}
+  Box(real3 L) : boxSize(L), minusInvBoxSize{real(-1.0) / L.x, real(-1.0) / L.y, real(-1.0) / L.z} {
+    if (boxSize.x == real(0.0) || std::isinf(boxSize.x)) minusInvBoxSize.x = real(0.0);
+    if (boxSize.y == real(0.0) || std::isinf(boxSize.y)) minusInvBoxSize.y = real(0.0);
+    if (boxSize.z == real(0.0) || std::isinf(boxSize.z)) minusInvBoxSize.z = real(0.0);
+  }
+  void setPeriodicity(bool x, bool y, bool z) {
+    if (!x) minusInvBoxSize.x = 0;
+    if (!y) minusInvBoxSize.y = 0;
+    if (!z) minusInvBoxSize.z = 0;
+  }
+  bool isPeriodicX() const { return minusInvBoxSize.x != 0; }
+  bool isPeriodicY() const { return minusInvBoxSize.y != 0; }
+  bool isPeriodicZ() const { return minusInvBoxSize.z != 0; }
+  real3 apply_pbc(real3 r) const {
+    const real ox = std::floor(r.x * minusInvBoxSize.x + real(0.5)), oy = std::floor(r.y * minusInvBoxSize.y + real(0.5)),
+               oz = std::floor(r.z * minusInvBoxSize.z + real(0.5));
+    r.x += isPeriodicX() ? ox * boxSize.x : 0;
+    r.y += isPeriodicY() ? oy * boxSize.y : 0;
+    r.z += isPeriodicZ() ? oz * boxSize.z : 0;
+    return r;
+  }
+  real getVolume() const { return boxSize.z != real(0.0) ? boxSize.x * boxSize.y * boxSize.z : boxSize.x * boxSize.y; }
+  bool operator==(const Box &o) const {
+    return boxSize.x == o.boxSize.x && boxSize.y == o.boxSize.y && boxSize.z == o.boxSize.z &&
+           isPeriodicX() == o.isPeriodicX() && isPeriodicY() == o.isPeriodicY() && isPeriodicZ() == o.isPeriodicZ();
+  }
+  bool operator!=(const Box &o) const { return !(*this == o); }
+  // helpers for the C ABI
+  void toArrays(float L[3], int per[3]) const {
+    L[0] = boxSize.x; L[1] = boxSize.y; L[2] = boxSize.z;
+    per[0] = isPeriodicX(); per[1] = isPeriodicY(); per[2] = isPeriodicZ();
+  }
+};
+
+// ---- access, property_ptr, ParticleData ---------------------------------------------------------------------------------
+namespace access {
+enum location { cpu, gpu, managed, nodevice };
+enum mode { read, write, readwrite, nomode };
+}  // namespace access
+
+template <class T> class Property;
+// RAII handle on a property (Property.cuh:49-147): releases the lock (and uploads host writes) when destroyed
+template <class T> class property_ptr {
+  T *ptr = nullptr;
+  size_t m_size = 0;
+  Property<T> *owner = nullptr;
+  access::location loc = access::nodevice;
+  access::mode mod = access::nomode;
+public:
+  property_ptr() = default;
+  property_ptr(T *p, size_t n, Property<T> *o, access::location l, access::mode m) : ptr(p), m_size(n), owner(o), loc(l), mod(m) {}
+  property_ptr(property_ptr &&o) noexcept { *this = std::move(o); }
+  property_ptr &operator=(property_ptr &&o) noexcept {
+    release();
+    ptr = o.ptr; m_size = o.m_size; owner = o.owner; loc = o.loc; mod = o.mod;
+    o.owner = nullptr; o.ptr = nullptr;
+    return *this;
+  }
+  property_ptr(const property_ptr &) = delete;
+  property_ptr &operator=(const property_ptr &) = delete;
+  ~property_ptr() { release(); }
+  void release();
+  T *raw() const { return ptr; }
+  T *get() const { return ptr; }
+  T *begin() const { return ptr; }
+  T *end() const { return ptr + m_size; }
+  size_t size() const { return m_size; }
+  T &operator[](size_t i) const { return ptr[i]; }
+  access::location location() const { return loc; }
+};
+
+template <class T> class Property {
+  std::string name;
+  size_t n = 0;
+  detail::DeviceArray<T> dev;
+  std::vector<T> host;
+  bool allocated = false, hostStale = true, deviceStale = false;
+  bool isBeingWritten = false;
+  int readers = 0;
+  friend class property_ptr<T>;
+public:
+  explicit Property(std::string nm) : name(std::move(nm)) {}
+  void resize(size_t m) { n = m; }
+  bool isAllocated() const { return allocated; }
+  size_t size() const { return n; }
+  property_ptr<T> data(access::location loc, access::mode mode) {
+    if (!allocated) { dev.resize(n); allocated = true; hostStale = true; }
+    // Property.cuh:310-338: one writer XOR many readers
+    if (isBeingWritten || (mode != access::read && readers > 0))
+      throw illegal_property_access("[Property] You cant request " + name + " while it is locked");
+    if (mode == access::read) ++readers; else isBeingWritten = true;
+    if (loc == access::cpu) {
+      if (host.size() != n) { host.resize(n); hostStale = true; }
+      if (hostStale && mode != access::write) {
+        detail::hipCheck(hipMemcpy(host.data(), dev.d, sizeof(T) * n, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+      }
+      hostStale = false;
+      return property_ptr<T>(host.data(), n, this, loc, mode);
+    }
+    if (deviceStale) {
+      detail::hipCheck(hipMemcpy(dev.d, host.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy H2D");
+      deviceStale = false;
+    }
+    if (mode != access::read) hostStale = true;
+    return property_ptr<T>(dev.d, n, this, loc, mode);
+  }
+  void unlock(access::location loc, access::mode mode) {
+    if (mode == access::read) --readers; else isBeingWritten = false;
+    if (loc == access::cpu && mode != access::read) {  // host writes go back to the device when the handle dies
+      detail::hipCheck(hipMemcpy(dev.d, host.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    }
+  }
+  T *deviceRaw() { return dev.d; }
+  void swapDeviceBuffer(detail::DeviceArray<T> &alt) { dev.swap(alt); hostStale = true; }
+};
+template <class T> void property_ptr<T>::release() {
+  if (owner) owner->unlock(loc, mod);
+  owner = nullptr;
+}
+
+class ParticleData {
+  int numberParticles;
+  shared_ptr<System> sys;
+  Property<real4> pos{"pos"}, force{"force"};
+  Property<real3> vel{"vel"};
+  Property<real> energy{"energy"}, virial{"virial"}, mass{"mass"}, radius{"radius"};
+  Property<int> id{"id"};
+  std::vector<std::function<void()>> posWriteCallbacks, reorderCallbacks;
+  struct Hints { Box hash_box = Box(real(128)); real3 hash_cutOff = make_real3(10.0); } hints;  // ParticleData.cuh:164-169
+  template <class T> property_ptr<T> get(Property<T> &p, access::location l, access::mode m) { return p.data(l, m); }
+public:
+  ParticleData(int N, shared_ptr<System> s = nullptr) : numberParticles(N), sys(s ? s : make_shared<System>()) {
+    for (auto *p : {&pos, &force}) p->resize(N);
+    vel.resize(N); energy.resize(N); virial.resize(N); mass.resize(N); radius.resize(N); id.resize(N);
+    auto ids = id.data(access::cpu, access::write);  // ParticleData.cuh:471-490
+    for (int i = 0; i < N; ++i) ids[i] = i;
+  }
+  shared_ptr<System> getSystem() { return sys; }
+  int getNumParticles() const { return numberParticles; }
+  property_ptr<real4> getPos(access::location l, access::mode m) {
+    if (m != access::read) for (auto &cb : posWriteCallbacks) cb();  // getPosWriteRequestedSignal, ParticleData.cuh:182-194
+    return pos.data(l, m);
+  }
+  property_ptr<real4> getForce(access::location l, access::mode m) { return force.data(l, m); }
+  property_ptr<real3> getVel(access::location l, access::mode m) { return vel.data(l, m); }
+  property_ptr<real> getEnergy(access::location l, access::mode m) { return energy.data(l, m); }
+  property_ptr<real> getVirial(access::location l, access::mode m) { return virial.data(l, m); }
+  property_ptr<real> getMass(access::location l, access::mode m) { return mass.data(l, m); }
+  property_ptr<real> getRadius(access::location l, access::mode m) { return radius.data(l, m); }
+  property_ptr<int> getId(access::location l, access::mode m) { return id.data(l, m); }
+  property_ptr<real> getMassIfAllocated(access::location l, access::mode m) { return mass.isAllocated() ? mass.data(l, m) : property_ptr<real>(); }
+  property_ptr<real> getRadiusIfAllocated(access::location l, access::mode m) { return radius.isAllocated() ? radius.data(l, m) : property_ptr<real>(); }
+  bool isPosAllocated() const { return pos.isAllocated(); }
+  bool isVelAllocated() const { return vel.isAllocated(); }
+  bool isForceAllocated() const { return force.isAllocated(); }
+  bool isMassAllocated() const { return mass.isAllocated(); }
+  bool isRadiusAllocated() const { return radius.isAllocated(); }
+  void connectPosWriteRequested(std::function<void()> cb) { posWriteCallbacks.push_back(std::move(cb)); }
+  void connectReorder(std::function<void()> cb) { reorderCallbacks.push_back(std::move(cb)); }
+  void hintSortByHash(Box hash_box, real3 hash_cutOff) { hints.hash_box = hash_box; hints.hash_cutOff = hash_cutOff; }
+  // ParticleData::sortParticles (ParticleData.cuh:492-522): Morton order on the hint grid, every allocated property
+  void sortParticles(hipStream_t st = 0) {
+    uammd_celllist *cl = nullptr;
+    detail::check(uammd_celllist_create(&cl));
+    float L[3]; int per[3];
+    hints.hash_box.toArrays(L, per);
+    int cd[3] = {(int)(L[0] / hints.hash_cutOff.x), (int)(L[1] / hints.hash_cutOff.y), (int)(L[2] / hints.hash_cutOff.z)};
+    if (cd[2] == 0) cd[2] = 1;
+    {
+      auto p = pos.data(access::gpu, access::read);
+      detail::check(uammd_celllist_update(cl, (const float *)p.raw(), numberParticles, L, per, cd, (void *)st));
+    }
+    uammd_celllist_data d;
+    detail::check(uammd_celllist_get(cl, &d));
+    reorder(pos, d.d_groupIndex, st); reorder(force, d.d_groupIndex, st); reorder(vel, d.d_groupIndex, st);
+    reorder(energy, d.d_groupIndex, st); reorder(virial, d.d_groupIndex, st); reorder(mass, d.d_groupIndex, st);
+    reorder(radius, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
+    detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    detail::check(uammd_celllist_destroy(cl));
+    for (auto &cb : posWriteCallbacks) cb();
+    for (auto &cb : reorderCallbacks) cb();
+  }
+private:
+  template <class T> void reorder(Property<T> &p, const int *d_index, hipStream_t st) {
+    if (!p.isAllocated()) return;
+    auto h = p.data(access::gpu, access::readwrite);
+    detail::DeviceArray<T> alt(numberParticles);
+    detail::check(uammd_gather(h.raw(), d_index, alt.d, numberParticles, (int)sizeof(T), (void *)st));
+    detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    h.release();
+    p.swapDeviceBuffer(alt);
+  }
+};
+
+// ---- misc/ParameterUpdatable.h:72-80, Interactor, Integrator ------------------------------------------------------------------
+class ParameterUpdatable {
+public:
+  virtual ~ParameterUpdatable() = default;
+  virtual void updateTimeStep(real) {}
+  virtual void updateSimulationTime(real) {}
+  virtual void updateBox(Box) {}
+  virtual void updateTemperature(real) {}
+  virtual void updateViscosity(real) {}
+};
+
+class Interactor : public virtual ParameterUpdatable {
+protected:
+  shared_ptr<ParticleData> pd;
+  shared_ptr<System> sys;
+  std::string name;
+public:
+  struct Computables { bool force = false, energy = false, virial = false, stress = false; };
+  Interactor(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  virtual ~Interactor() = default;
+  virtual void sum(Computables comp, hipStream_t st = 0) = 0;
+  std::string getName() { return name; }
+};
+
+class Integrator {
+protected:
+  shared_ptr<ParticleData> pd;
+  shared_ptr<System> sys;
+  std::string name;
+  std::vector<shared_ptr<Interactor>> interactors;
+  std::vector<shared_ptr<ParameterUpdatable>> updatables;
+public:
+  Integrator(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  virtual ~Integrator() = default;
+  virtual void forwardTime() = 0;
+  virtual real sumEnergy() { return 0; }
+  void addInteractor(shared_ptr<Interactor> an_interactor) { interactors.push_back(an_interactor); addUpdatable(an_interactor); }
+  std::vector<shared_ptr<Interactor>> getInteractors() { return interactors; }
+  void addUpdatable(shared_ptr<ParameterUpdatable> u) { updatables.push_back(u); }
+};
+
+// ---- CellList ----------------------------------------------------------------------------------------------------------------
+class CellList {
+  shared_ptr<ParticleData> pd;
+  uammd_celllist *h = nullptr;
+  bool force_next_update = true;
+  real3 currentCutOff{0, 0, 0};
+  Box currentBox;
+public:
+  using CellListData = uammd_celllist_data;
+  explicit CellList(shared_ptr<ParticleData> pd) : pd(pd) {
+    detail::check(uammd_celllist_create(&h));
+    pd->connectPosWriteRequested([this]() { force_next_update = true; });  // CellList.cuh:94-98
+  }
+  CellList(const CellList &) = delete;
+  ~CellList() { uammd_celllist_destroy(h); }
+  void update(Box box, real cutOff, hipStream_t st = 0) { update(box, make_real3(cutOff), st); }
+  void update(Box box, real3 cutOff, hipStream_t st = 0) {
+    const bool rebuild = force_next_update || cutOff.x != currentCutOff.x || cutOff.y != currentCutOff.y ||
+                         cutOff.z != currentCutOff.z || box != currentBox;  // CellList.cuh:192-204
+    if (!rebuild) return;
+    currentBox = box;
+    currentCutOff = cutOff;
+    float L[3], Lo[3], rc[3] = {cutOff.x, cutOff.y, cutOff.z};
+    int per[3], cd[3], po[3];
+    box.toArrays(L, per);
+    detail::check(uammd_celllist_create_grid(L, per, rc, cd, Lo, po));
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_celllist_update(h, (const float *)pos.raw(), pd->getNumParticles(), Lo, po, cd, (void *)st));
+    force_next_update = false;
+  }
+  CellListData getCellList() { CellListData d; detail::check(uammd_celllist_get(h, &d)); return d; }
+  uammd_celllist *handle() { return h; }
+};
+
+// ---- Potential::LJ ---------------------------------------------------------------------------------------------------------------
+namespace Potential {
+class LJ {
+  std::vector<uammd_lj_pair_parameters> table;
+  detail::DeviceArray<uammd_lj_pair_parameters> d_table;
+  int ntypes = 1;
+  real cutOff = 0;
+  bool dirty = true;
+public:
+  struct InputPairParameters { real cutOff, sigma, epsilon; bool shift = false; };
+  LJ() : table(1) {}
+  void setPotParameters(int ti, int tj, InputPairParameters p) {  // ParameterHandler.cuh:17-37
+    cutOff = std::max(p.cutOff, cutOff);
+    const int nn = std::max(ntypes, std::max(ti, tj) + 1);
+    if (nn != ntypes) {
+      std::vector<uammd_lj_pair_parameters> tmp((size_t)nn * nn);
+      for (int i = 0; i < ntypes; ++i) for (int j = 0; j < ntypes; ++j) tmp[i + nn * j] = table[i + ntypes * j];
+      table.swap(tmp);
+      ntypes = nn;
+    }
+    uammd_lj_pair_parameters q;
+    detail::check(uammd_lj_process_pair_parameters(p.cutOff, p.sigma, p.epsilon, p.shift, &q));
+    table[ti + ntypes * tj] = q;
+    if (ti != tj) table[tj + ntypes * ti] = q;
+    dirty = true;
+  }
+  real getCutOff() { return cutOff; }
+  int getNumberTypes() const { return ntypes; }
+  const uammd_lj_pair_parameters *deviceTable() {
+    if (dirty) {
+      d_table.resize(table.size());
+      detail::hipCheck(hipMemcpy(d_table.d, table.data(), sizeof(table[0]) * table.size(), hipMemcpyHostToDevice), "hipMemcpy");
+      dirty = false;
+    }
+    return d_table.d;
+  }
+};
+}  // namespace Potential
+
+// ---- PairForces<Potential::LJ, CellList> -------------------------------------------------------------------------------------------
+template <class MyPotential, class NL = CellList> class PairForces;
+template <class NL> class PairForces<Potential::LJ, NL> : public Interactor {
+  Box box;
+  shared_ptr<Potential::LJ> pot;
+  shared_ptr<NL> nl;
+public:
+  struct Parameters { Box box; shared_ptr<NL> nl = nullptr; };
+  PairForces(shared_ptr<ParticleData> pd, Parameters par, shared_ptr<Potential::LJ> pot = make_shared<Potential::LJ>())
+      : Interactor(pd, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
+  void updateBox(Box b) override { box = b; }
+  void sum(Computables comp, hipStream_t st = 0) override {  // PairForces.cu:43-78
+    float L[3]; int per[3];
+    box.toArrays(L, per);
+    const real rcut = pot->getCutOff();
+    const int N = pd->getNumParticles();
+    const bool useNL = !(box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut);
+    if (useNL) {
+      if (!nl) nl = make_shared<NL>(pd);
+      nl->update(box, rcut, st);
+    }
+    auto force = comp.force ? pd->getForce(access::gpu, access::readwrite) : property_ptr<real4>();
+    auto energy = comp.energy ? pd->getEnergy(access::gpu, access::readwrite) : property_ptr<real>();
+    auto virial = comp.virial ? pd->getVirial(access::gpu, access::readwrite) : property_ptr<real>();
+    if (useNL) {
+      detail::check(uammd_lj_transverse_celllist(nl->handle(), pot->deviceTable(), pot->getNumberTypes(), L, per,
+                                                 (float *)force.raw(), energy.raw(), virial.raw(), nullptr,
+                                                 UAMMD_LJ_ALGO_AUTO, (void *)st));
+    } else {
+      auto pos = pd->getPos(access::gpu, access::read);
+      detail::check(uammd_lj_transverse_nbody((const float *)pos.raw(), N, pot->deviceTable(), pot->getNumberTypes(), L,
+                                              per, (float *)force.raw(), energy.raw(), virial.raw(), nullptr, (void *)st));
+    }
+  }
+};
+
+// ---- VerletNVT -----------------------------------------------------------------------------------------------------------------------
+namespace VerletNVT {
+class Basic : public Integrator {
+public:
+  struct Parameters { real temperature = 0, dt = 0, friction = 1.0; bool is2D = false, initVelocities = true; real mass = -1.0; };
+protected:
+  real noiseAmplitude, dt, temperature, friction, defaultMass;
+  uint seed;
+  bool is2D;
+  int steps = 0;
+  hipStream_t stream = 0;
+  virtual int kernelKind() const { return 0; }
+  void callIntegrate(int step) {
+    const int N = pd->getNumParticles();
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    auto vel = pd->getVel(access::gpu, access::readwrite);
+    auto force = pd->getForce(access::gpu, access::readwrite);
+    auto mass = defaultMass > 0 ? property_ptr<real>() : pd->getMassIfAllocated(access::gpu, access::read);
+    auto fn = kernelKind() == 1 ? uammd_verletnvt_gj : uammd_verletnvt_basic;
+    detail::check(fn(step, (float *)pos.raw(), (float *)vel.raw(), (float *)force.raw(), mass.raw(), defaultMass, nullptr, N, dt,
+                     friction, is2D, noiseAmplitude, (uint)steps, seed, (void *)stream));
+  }
+  void resetForces() {
+    auto force = pd->getForce(access::gpu, access::write);
+    detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
+  }
+public:
+  Basic(shared_ptr<ParticleData> pd, Parameters par, std::string name = "VerletNVT::Basic")
+      : Integrator(pd, name), dt(par.dt), temperature(par.temperature), friction(par.friction), is2D(par.is2D) {
+    sys->rng().next32();  // Basic.cu:36-38
+    sys->rng().next32();
+    seed = sys->rng().next32();
+    noiseAmplitude = std::sqrt(2 * dt * friction * temperature);
+    defaultMass = par.mass;
+    if (!pd->isMassAllocated() && defaultMass < 0) defaultMass = 1.0;
+    if (par.initVelocities) {
+      auto vel = pd->getVel(access::gpu, access::write);
+      detail::check(uammd_verletnvt_initial_velocities((float *)vel.raw(), nullptr, (real)std::sqrt(3.0 * temperature), is2D,
+                                                       pd->getNumParticles(), sys->rng().next32(), nullptr));
+    }
+  }
+  void forwardTime() override {  // Basic.cu:148-171, GronbechJensen.cu:88-115
+    for (auto &u : updatables) u->updateSimulationTime(steps * dt);
+    steps++;
+    if (steps == 1) {
+      resetForces();
+      for (auto &u : updatables) { u->updateTemperature(temperature); u->updateTimeStep(dt); }
+      for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
+      detail::hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    callIntegrate(1);
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
+    callIntegrate(2);
+  }
+};
+class GronbechJensen final : public Basic {
+  int kernelKind() const override { return 1; }
+public:
+  using Parameters = Basic::Parameters;
+  GronbechJensen(shared_ptr<ParticleData> pd, Parameters par) : Basic(pd, par, "VerletNVT::GronbechJensen") {}
+};
+}  // namespace VerletNVT
+
+// ---- BD::EulerMaruyama -------------------------------------------------------------------------------------------------------------------
+namespace BD {
+struct Parameters {
+  std::vector<real3> K;
+  real temperature = 0, viscosity = 1.0, hydrodynamicRadius = -1.0, dt = 0.0;
+  bool is2D = false;
+};
+class EulerMaruyama : public Integrator {
+public:
+  using Parameters = BD::Parameters;
+private:
+  Parameters par;
+  real selfMobility;
+  uint seed;
+  int steps = 0;
+  hipStream_t st = 0;
+public:
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : Integrator(pd, "BD::EulerMaruyama"), par(par) {
+    seed = sys->rng().next32();
+    selfMobility = 1.0 / (6.0 * M_PI * par.viscosity);  // BrownianDynamics.cu:12-23
+    if (par.hydrodynamicRadius != real(-1.0)) selfMobility /= par.hydrodynamicRadius;
+  }
+  void forwardTime() override {  // BrownianDynamics.cu:146-170
+    steps++;
+    for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
+    if (steps == 1) for (auto &u : updatables) { u->updateTemperature(par.temperature); u->updateTimeStep(par.dt); }
+    {
+      auto force = pd->getForce(access::gpu, access::write);
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
+    }
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
+    float K[9] = {0};
+    const bool shear = par.K.size() == 3;
+    if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
+    auto radius = (par.hydrodynamicRadius == real(-1.0)) ? pd->getRadiusIfAllocated(access::gpu, access::read) : property_ptr<real>();
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    auto force = pd->getForce(access::gpu, access::read);
+    detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), nullptr, (const float *)force.raw(), shear ? K : nullptr, selfMobility,
+                                          radius.raw(), par.dt, par.is2D, par.temperature, pd->getNumParticles(), (uint)steps, seed,
+                                          (void *)st));
+  }
+};
+}  // namespace BD
+
+// ---- BDHI::FCM ----------------------------------------------------------------------------------------------------------------------------
+namespace BDHI {
+struct Parameters {
+  std::vector<real3> K;
+  real temperature = 0, viscosity = 1, hydrodynamicRadius = -1, tolerance = 1e-3, dt = 0;
+  bool is2D = false;
+  Box box;
+  // FCM_impl::Parameters, FCM_impl.cuh:47-54
+  int3 cells = make_int3(-1, -1, -1);
+  uint seed = 0;
+  bool adaptBoxSize = false;
+};
+class FCM_impl {
+  uammd_fcm *h = nullptr;
+  Box box;
+  real viscosity, hydrodynamicRadius;
+public:
+  using Parameters = BDHI::Parameters;
+  explicit FCM_impl(Parameters par) : box(par.box), viscosity(par.viscosity) {
+    if (par.box.boxSize.x <= 0 || par.cells.x <= 0) throw std::runtime_error("Invalid arguments");  // FCM_impl.cuh:74-82
+    uammd_fcm_parameters p{};
+    p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
+    p.cells[0] = par.cells.x; p.cells[1] = par.cells.y; p.cells[2] = par.cells.z;
+    p.viscosity = par.viscosity;
+    p.seed = par.seed;
+    const real hx = p.boxSize[0] / p.cells[0], hy = p.boxSize[1] / p.cells[1], hz = p.boxSize[2] / p.cells[2];
+    float a_eff = 0;
+    detail::check(uammd_fcm_gaussian_kernel(std::min(hx, std::min(hy, hz)), par.tolerance, &p.kernel, &a_eff));
+    hydrodynamicRadius = p.hydrodynamicRadius = a_eff;  // Kernel::fixHydrodynamicRadius (FCM_kernels.cuh:52)
+    detail::check(uammd_fcm_create(&p, &h));
+  }
+  FCM_impl(const FCM_impl &) = delete;
+  ~FCM_impl() { uammd_fcm_destroy(h); }
+  real getHydrodynamicRadius() { return hydrodynamicRadius; }
+  real getSelfMobility() { return (real)uammd_fcm_self_mobility(hydrodynamicRadius, viscosity, box.boxSize.x); }
+  Box getBox() { return box; }
+  // linear velocities into d_linearVelocity (real3[N]); torques are not on this round's path
+  void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, real3 *d_linearVelocity, int N, real temperature,
+                                        real prefactor, hipStream_t st) {
+    detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
+                                          (float *)d_linearVelocity, (void *)st));
+  }
+};
+namespace detail_fcm {
+inline BDHI::Parameters initialize(BDHI::Parameters par, System &sys) {  // BDHI_FCM.cuh:29-66, :98-110
+  if (par.seed == 0) par.seed = sys.rng().next32();
+  if (par.cells.x <= 0) {
+    if (par.hydrodynamicRadius <= 0) System::log<System::CRITICAL>("[BDHI::FCM] I need an hydrodynamic radius if cell dimensions are not provided!");
+    const real h = uammd_fcm_advise_grid_size(par.hydrodynamicRadius, par.tolerance);
+    int c[3] = {(int)(par.box.boxSize.x / h), (int)(par.box.boxSize.y / h), (int)(par.box.boxSize.z / h)};
+    for (int &v : c) {  // nextFFTWiseSize3D, utils/Grid.cuh:142-213
+      for (;; ++v) {
+        int m = v;
+        if (m % 2) continue;
+        for (int p : {2, 3, 5, 7, 11}) while (m % p == 0) m /= p;
+        if (m == 1) break;
+      }
+    }
+    par.cells = make_int3(c[0], c[1], c[2]);
+    if (par.adaptBoxSize) par.box = Box(make_real3(c[0] * h, c[1] * h, c[2] * h));
+  }
+  return par;
+}
+}  // namespace detail_fcm
+class FCM {  // the Method concept of BDHI::EulerMaruyama (BDHI_FCM.cuh:84-147)
+  shared_ptr<ParticleData> pd;
+  shared_ptr<FCM_impl> fcm;
+  real temperature, dt;
+public:
+  using Parameters = BDHI::Parameters;
+  FCM(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), temperature(par.temperature), dt(par.dt) {
+    fcm = make_shared<FCM_impl>(detail_fcm::initialize(par, *pd->getSystem()));
+  }
+  void setup_step(hipStream_t = 0) {}
+  void computeMF(real3 *MF, hipStream_t st = 0) {
+    auto force = pd->getForce(access::gpu, access::read);
+    auto pos = pd->getPos(access::gpu, access::read);
+    fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), MF, pd->getNumParticles(), temperature, 1.0 / std::sqrt(dt), st);
+  }
+  void computeBdW(real3 *, hipStream_t = 0) {}
+  void finish_step(hipStream_t = 0) {}
+  real getHydrodynamicRadius() { return fcm->getHydrodynamicRadius(); }
+  real getSelfMobility() { return fcm->getSelfMobility(); }
+};
+class FCMIntegrator : public Integrator {  // BDHI_FCM.cu:95-119
+  shared_ptr<FCM_impl> fcm;
+  detail::DeviceArray<real3> linearV;
+  real temperature, dt;
+  uint steps = 0;
+  hipStream_t st = 0;
+public:
+  using Parameters = BDHI::Parameters;
+  FCMIntegrator(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "BDHI::FCMIntegrator"), linearV(pd->getNumParticles()), temperature(par.temperature), dt(par.dt) {
+    fcm = make_shared<FCM_impl>(detail_fcm::initialize(par, *sys));
+  }
+  shared_ptr<FCM_impl> getFCM_impl() { return fcm; }
+  void forwardTime() override {
+    steps++;
+    for (auto &u : updatables) u->updateSimulationTime(steps * dt);
+    if (steps == 1) for (auto &u : updatables) { u->updateTimeStep(dt); u->updateTemperature(temperature); u->updateBox(fcm->getBox()); }
+    {
+      auto force = pd->getForce(access::gpu, access::write);
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
+    }
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
+    const int N = pd->getNumParticles();
+    {
+      auto pos = pd->getPos(access::gpu, access::read);
+      auto force = pd->getForce(access::gpu, access::read);
+      fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), linearV.d, N, temperature, 1.0 / std::sqrt(dt), st);
+    }
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    detail::check(uammd_fcm_euler_maruyama((float *)pos.raw(), nullptr, (const float *)linearV.d, N, dt, (void *)st));
+  }
+};
+}  // namespace BDHI
+
+// ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------
+namespace lanczos {
+struct MatrixDot {
+  void setSize(int newsize) { m_size = newsize; }
+  virtual void operator()(real *v, real *Mv) = 0;
+  virtual ~MatrixDot() = default;
+protected:
+  int m_size = 0;
+};
+class Solver {
+  uammd_lanczos *h = nullptr;
+  static int trampoline(void *ctx, const float *v, float *Mv, int n, void *) {
+    try {
+      auto *dot = static_cast<MatrixDot *>(ctx);
+      dot->setSize(n);
+      (*dot)(const_cast<real *>(v), Mv);
+      return 0;
+    } catch (...) { return -99; }
+  }
+public:
+  Solver() { detail::check(uammd_lanczos_create(&h)); }
+  Solver(const Solver &) = delete;
+  ~Solver() { uammd_lanczos_destroy(h); }
+  int run(MatrixDot *dot, real *Bv, const real *v, real tolerance, int N, hipStream_t st = 0) {
+    int it = 0;
+    const int rc = uammd_lanczos_run(h, &Solver::trampoline, dot, Bv, v, tolerance, N, (void *)st, &it);
+    if (rc != 0) throw std::runtime_error(uammd_hip_last_error());  // "[Lanczos] Could not converge", LanczosAlgorithm.cu:227
+    return it;
+  }
+  int run(MatrixDot &dot, real *Bv, const real *v, real tolerance, int N, hipStream_t st = 0) { return run(&dot, Bv, v, tolerance, N, st); }
+  void setIterationHardLimit(int newLimit) { detail::check(uammd_lanczos_set_iteration_hard_limit(h, newLimit)); }
+  int getLastRunRequiredSteps() { int s = 0; detail::check(uammd_lanczos_get_last_run_required_steps(h, &s)); return s; }
+};
+}  // namespace lanczos
+
+// ---- utils/InitialConditions.cuh: simple cubic stand-in for initLattice(L, N, sc) -------------------------------------------------------------
+inline std::vector<real4> initLatticeSC(real3 L, uint N) {
+  const int m = (int)std::ceil(std::cbrt((double)N));
+  std::vector<real4> pos(N);
+  for (uint i = 0; i < N; ++i) {
+    const int ix = i % m, iy = (i / m) % m, iz = i / (m * m);
+    pos[i] = {(ix + real(0.5)) / m * L.x - L.x / 2, (iy + real(0.5)) / m * L.y - L.y / 2, (iz + real(0.5)) / m * L.z - L.z / 2, 0};
+  }
+  return pos;
+}
+
+}  // namespace uammd
+#endif
