@@ -123,6 +123,14 @@ UH_HD uint compact10(uint x) {  // inverse of spread10
   x = (x | x >> 16) & 0x3ffu;
   return x;
 }
+// MI355X deals consecutive workgroups round-robin to its 8 XCDs, each with its own 4 MB L2.  Kernels whose neighbouring
+// workgroups share data (Morton-sorted particles, adjacent grid tiles) remap the block index so that every XCD gets one
+// CONTIGUOUS range of the work: the shared lines are then fetched into one L2 instead of eight.
+UH_D uint xcd_contiguous_block(uint b, uint nb) {
+  const uint per = nb >> 3;
+  if (b >= (per << 3)) return b;  // tail of an incomplete round keeps its place
+  return (b & 7u) * per + (b >> 3);
+}
 UH_HD uint morton_hash(int3 c) { return spread10((uint)c.x) | (spread10((uint)c.y) << 1) | (spread10((uint)c.z) << 2); }
 
 // ---- error plumbing ------------------------------------------------------------------------------

@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
   for (int i = threadIdx.x; i < 4 * 3 * T3; i += 256) acc[i] = 0.0f;
   __syncthreads();
   float *mine = acc + wave * 3 * T3;
-  const int tx = blockIdx.x % ntiles.x, ty = (blockIdx.x / ntiles.x) % ntiles.y, tz = blockIdx.x / (ntiles.x * ntiles.y);
+  const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
   const int x0 = tx * kTile, y0 = ty * kTile, z0 = tz * kTile;
   const int sx = support.x, sy = support.y, sz = support.z;
   for (int nb = wave; nb < 27; nb += 4) {
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vou
                                                           int3 n, int nxpad, size_t plane, int3 support, float dV,
                                                           FastDiv dsx, FastDiv dsxy, FcmPrep pr) {
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (slot >= N) return;
   const int4 o = pr.origin[slot];
   const int sx = support.x, sy = support.y, sz = support.z;

@@ -241,7 +241,7 @@ template <bool NT1, bool WE, bool WV>
 __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> grid, BoxT<float> box,
                                                      const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
   __shared__ uint gq[kQCapGeneral * 128];
-  const int id = blockIdx.x * 128 + threadIdx.x;
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
   if (id >= cl.N) return;
   const int gi = cl.groupIndex[id];
   const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
