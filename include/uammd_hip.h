@@ -209,6 +209,33 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream);
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value);
 
 /* ------------------------------------------------------------------------------------------------
+ * Path B on several GPUs — z-slab decomposition of the FCM grid (the reference is single GPU, so these
+ * have no reference counterpart: they are the per-rank compute stages of uammd_fcm_displacements, cut where the
+ * exchanges happen.  The exchanges themselves are RCCL calls of the host layer, uammd_amd/parallel_fcm.py).
+ * Rank layouts (float2 = one complex):
+ *   real window  float  [nzLocal + 2*halo][3][ny][2*(nx/2+1)]   owned planes are [halo, halo + nzLocal)
+ *   xy spectrum  float2 [nzLocal][3][ny][nx/2+1]                 = the owned planes after the in-place 2-D R2C
+ *   z buffer     float2 [nz][3][nyLocal][nx/2+1]                 rows y0 .. y0 + nyLocal of the Fourier grid
+ * Sequence per step: slab_spread -> (halo planes ADDED into the neighbours) -> slab_forward_xy -> (all-to-all) ->
+ * slab_fft_z(0) -> slab_kspace -> slab_fft_z(1) -> (all-to-all) -> slab_inverse_xy -> (halo planes COPIED from the
+ * neighbours) -> slab_gather.  Positions are in the window frame: z relative to the centre of the owned slab.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_fcm_slab uammd_fcm_slab;
+int uammd_fcm_slab_create(const uammd_fcm_parameters *par, int nzLocal, int z0, int halo, int nyLocal, int y0,
+                          uammd_fcm_slab **out);
+int uammd_fcm_slab_destroy(uammd_fcm_slab *h);
+int uammd_fcm_slab_set_option(uammd_fcm_slab *h, const char *name, int value);
+int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const float *d_force, int numberParticles,
+                          float *d_grid, void *stream);
+int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int numberParticles, const float *d_grid,
+                          float *d_linearVelocity, void *stream);
+int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream); /* in place on the owned planes */
+int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
+int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream);
+int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor,
+                          unsigned int seed2, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Lanczos sqrt(M) v.  Replaces lanczos::Solver (misc/LanczosAlgorithm.cuh:32-83,
  * misc/LanczosAlgorithm/LanczosAlgorithm.cu:27-262) and the MatrixDot functor (LanczosAlgorithm/MatrixDot.h:7-25):
  * the matrix is a host callback that ENQUEUES d_Mv = M d_v (n floats, device pointers) on `stream` and returns 0.

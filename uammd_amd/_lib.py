@@ -80,6 +80,15 @@ SIGNATURES = {
     "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),
     "uammd_fcm_set_seed2": (_i, [_vp, _u]),
     "uammd_fcm_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "uammd_fcm_slab_create": (_i, [C.POINTER(FCMParameters), _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "uammd_fcm_slab_destroy": (_i, [_vp]),
+    "uammd_fcm_slab_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "uammd_fcm_slab_spread": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_fcm_slab_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "uammd_fcm_slab_forward_xy": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_slab_fft_z": (_i, [_vp, _vp, _i, _vp]),
+    "uammd_fcm_slab_kspace": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),
     "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),

@@ -66,8 +66,8 @@ static std::once_flag g_rocfft_once;
 template <bool SPREAD>
 __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos, const float4 *__restrict__ force,
                                                   float *__restrict__ vout, float *__restrict__ g0, int N,
-                                                  GridT<float> grid, int nxpad, size_t plane, IBMKernelDev kern,
-                                                  FastDiv dsx, FastDiv dsxy) {
+                                                  GridT<float> grid, int nxpad, size_t plane, size_t zstride,
+                                                  IBMKernelDev kern, FastDiv dsx, FastDiv dsxy) {
   const int lane = threadIdx.x & 63;
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= N) return;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
     cx = cx < 0 ? cx + grid.cellDim.x : (cx >= grid.cellDim.x ? cx - grid.cellDim.x : cx);
     cy = cy < 0 ? cy + grid.cellDim.y : (cy >= grid.cellDim.y ? cy - grid.cellDim.y : cy);
     cz = cz < 0 ? cz + grid.cellDim.z : (cz >= grid.cellDim.z ? cz - grid.cellDim.z : cz);
-    const size_t node = (size_t)cx + (size_t)nxpad * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz);
+    const size_t node = (size_t)cx + (size_t)nxpad * (size_t)cy + zstride * (size_t)cz;
     if (SPREAD) {
       unsafeAtomicAdd(&g0[node], fx * wx * wy * wz);
       unsafeAtomicAdd(&g1[node], fy * wx * wy * wz);
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
 // One workgroup (4 waves) per tile.  The 27 surrounding tiles' particle ranges are dealt to the waves; for each
 // range the lanes test one particle each (does its stencil reach this tile?) and the wave then spreads the
 // accepted particles one at a time, the lanes covering the nodes of the stencil-tile intersection.
-__global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane,
+__global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride,
                                                           int3 support, int3 ntiles, FcmPrep pr) {
   // LDS float atomics retire ~1 lane per clock on gfx950 (measured: ds_add_f32 kept the LDS pipe 90 % busy and the
   // kernel at 400 us).  Instead every wave owns a PRIVATE copy of the tile and updates it with plain
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
   __syncthreads();
   for (int i = threadIdx.x; i < T3; i += 256) {
     const int lx = i % kTile, ly = (i / kTile) % kTile, lz = i / (kTile * kTile);
-    const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * ((size_t)(y0 + ly) + (size_t)n.y * (size_t)(z0 + lz));
+    const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * (size_t)(y0 + ly) + zstride * (size_t)(z0 + lz);
     g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
     g0[plane + node] = (acc[T3 + i] + acc[4 * T3 + i]) + (acc[7 * T3 + i] + acc[10 * T3 + i]);
     g0[2 * plane + node] = (acc[2 * T3 + i] + acc[5 * T3 + i]) + (acc[8 * T3 + i] + acc[11 * T3 + i]);
@@ -280,8 +280,8 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
 // Gather with the precomputed origin/weights: one wave per tile-sorted slot (neighbouring waves touch the same
 // nodes), result written at the particle's original index.
 __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vout, const float *__restrict__ g0, int N,
-                                                          int3 n, int nxpad, size_t plane, int3 support, float dV,
-                                                          FastDiv dsx, FastDiv dsxy, FcmPrep pr) {
+                                                          int3 n, int nxpad, size_t plane, size_t zstride, int3 support,
+                                                          float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr) {
   const int lane = threadIdx.x & 63;
   const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (slot >= N) return;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vou
     cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
     cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
     cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
-    const size_t node = (size_t)cx + (size_t)nxpad * ((size_t)cy + (size_t)n.y * (size_t)cz);
+    const size_t node = (size_t)cx + (size_t)nxpad * (size_t)cy + zstride * (size_t)cz;
     ax = fmaf(dV, g0[node] * wx * wy * wz, ax);
     ay = fmaf(dV, g0[plane + node] * wx * wy * wz, ay);
     az = fmaf(dV, g0[2 * plane + node] * wx * wy * wz, az);
@@ -368,23 +368,28 @@ UH_D C3 draw_noise(float prefactor, uint id, uint seed1, uint seed2, bool nyquis
   return n;
 }
 
-// One thread per Fourier node.  grid: 3 planar complex grids (float2), in place.
-__global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, size_t planeC, int3 nk, real3f L,
+// One thread per (local) Fourier node, in place.  KLayout says where node (kx, y0 + yl, z) of component c lives:
+// g0[kx + nkx*yl + zStride*z + compStride*c].  Single GPU: 3 planar grids (nyl = ny, zStride = nkx*ny, compStride = plane);
+// slab-decomposed: the y-pencil layout [z][c][yl][kx] that the all-to-all transpose delivers.
+struct KLayout { int nyl, y0; size_t compStride, zStride; };
+__global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLayout lay, int3 nk, real3f L,
                                                      float viscosity, bool haveForce, float noisePrefactor,
                                                      uint seed1, uint seed2) {
-  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.x * 256 + threadIdx.x;
   const int nkx = nk.x / 2 + 1;
-  const int total = nk.z * nk.y * nkx;
-  if (id >= total) return;
-  float2 *g1 = g0 + planeC, *g2 = g0 + 2 * planeC;
-  const int3 cell = make_int3(id % nkx, (id / nkx) % nk.y, id / (nkx * nk.y));
+  const int total = nk.z * lay.nyl * nkx;
+  if (t >= total) return;
+  const int3 cell = make_int3(t % nkx, lay.y0 + (t / nkx) % lay.nyl, t / (nkx * lay.nyl));
+  const int id = cell.x + nkx * (cell.y + nk.y * cell.z);  // the reference's linear node index (it seeds the noise)
+  const size_t a0 = (size_t)cell.x + (size_t)nkx * (size_t)(cell.y - lay.y0) + lay.zStride * (size_t)cell.z;
+  float2 *g1 = g0 + lay.compStride, *g2 = g0 + 2 * lay.compStride;
   C3 v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int3 ik = index_to_wavenumber(id, nk);
   const real3f k = wavevector(ik, L);
   const float k2 = dot3(k, k);
   const real3f dk = gradient_fourier(ik, nk, k);
   if (haveForce && id != 0) {  // forceFourier2Vel, FCM_impl.cuh:375-397
-    const float2 a = g0[id], b = g1[id], c = g2[id];
+    const float2 a = g0[a0], b = g1[a0], c = g2[a0];
     const float B = 1.0f / (viscosity * k2);
     const float sc = B / (float)(nk.x * nk.y * nk.z);
     const C3 pr = project(k2, dk, C3{a.x, a.y, b.x, b.y, c.x, c.y});
@@ -416,9 +421,9 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, siz
     v.xr += first.xr; v.xi += first.xi; v.yr += first.yr; v.yi += first.yi; v.zr += first.zr; v.zi += first.zi;
     v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
   }
-  g0[id] = make_float2(v.xr, v.xi);
-  g1[id] = make_float2(v.yr, v.yi);
-  g2[id] = make_float2(v.zr, v.zi);
+  g0[a0] = make_float2(v.xr, v.xi);
+  g1[a0] = make_float2(v.yr, v.yi);
+  g2[a0] = make_float2(v.zr, v.zi);
 }
 
 // test hook: interleave the planar complex grids into complex3[Nk]
@@ -460,6 +465,108 @@ static int fcm_make_plans(FCM *f) {
   }
   UH_ROCFFT(rocfft_execution_info_create(&f->info));
   if (f->workBytes) UH_ROCFFT(rocfft_execution_info_set_work_buffer(f->info, f->work.ptr, f->workBytes));
+  return 0;
+}
+
+// bins the particles by tile and fills the tile-sorted stencil origins / weights / forces (reused by spread and gather)
+static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, int N, hipStream_t st, FcmPrep *out) {
+  const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+  const int wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
+  if (f->prepCapN < N) {
+    UH_CHECK(hipStreamSynchronize(st));
+    if (int e = f->prepOrigin.reserve(sizeof(int4) * (size_t)N)) return e;
+    if (int e = f->prepWeights.reserve(sizeof(float) * (size_t)wstride * N)) return e;
+    if (int e = f->prepSorted.reserve(sizeof(float4) * (size_t)N)) return e;
+    if (int e = f->prepTileOf.reserve(sizeof(int) * (size_t)N)) return e;
+    if (int e = f->prepRank.reserve(sizeof(int) * (size_t)N)) return e;
+    if (int e = f->prepTileCount.reserve(sizeof(int) * (size_t)nt)) return e;
+    if (int e = f->prepTileStart.reserve(sizeof(int) * ((size_t)nt + 1))) return e;
+    f->prepCapN = N;
+  }
+  FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
+             (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
+             (int *)f->prepTileStart.ptr, wstride};
+  UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
+  hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
+                     f->ntiles, pr);
+  hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, (const int *)pr.tileCount, nt, pr.tileStart);
+  hipLaunchKernelGGL(k_fcm_prepare, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,
+                     (const float4 *)d_force, N, f->grid, f->kern, pr);
+  *out = pr;
+  return 0;
+}
+
+// tile-owned spreading is possible when the grid is a whole number (>= 3) of tiles per axis and a stencil only
+// reaches the adjacent tiles
+static bool fcm_tiles_usable(const int cells[3], const int support[3]) {
+  for (int a = 0; a < 3; ++a)
+    if (cells[a] % kTile != 0 || cells[a] / kTile < 3 || support[a] > 2 * (kTile - 1)) return false;
+  return true;
+}
+
+// ---- z-slab decomposed solver (SURVEY §8e path B; BASELINE configs[4]) ------------------------------------------
+// One rank owns nzLocal xy-planes of the real grid (plus `halo` planes each side that receive the stencils of its own
+// particles) and, after the transpose, nyLocal y-rows of the Fourier grid with all of z.  Layouts:
+//   real     [zloc (nzLocal + 2 halo)][c (3)][y (ny)][x (nxpad)]   -> a halo slice is one contiguous block
+//   cplx xy  [zl (nzLocal)][c][y (ny)][kx (nkx)]                     the owned planes after the in-place batched 2-D R2C
+//   cplx z   [z (nz)][c][yl (nyLocal)][kx]                           what the all-to-all delivers; 1-D FFT along z, stride 3*nyl*nkx
+// The exchanges themselves (halo add, transpose, halo fill) are NOT in here: they are RCCL calls made by the host layer.
+struct FCMSlab {
+  FCM loc;  // local window: grid (nx, ny, nzLocal + 2 halo), tile machinery, kernel
+  int3 cells{0, 0, 0};
+  real3f L{0, 0, 0};
+  int nzl = 0, z0 = 0, halo = 0, nyl = 0, y0 = 0, nkx = 0;
+  rocfft_plan fwdXY = nullptr, invXY = nullptr, fwdZ = nullptr, invZ = nullptr;
+  ~FCMSlab() {
+    for (rocfft_plan p : {fwdXY, invXY, fwdZ, invZ})
+      if (p) rocfft_plan_destroy(p);
+  }
+};
+
+static int fcm_slab_make_plans(FCMSlab *s) {
+  std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
+  FCM *f = &s->loc;
+  const size_t nx = (size_t)s->cells.x, ny = (size_t)s->cells.y, nz = (size_t)s->cells.z, nkx = (size_t)s->nkx;
+  const size_t len2[2] = {nx, ny};
+  const size_t rstr[2] = {1, (size_t)f->nxpad}, cstr[2] = {1, nkx};
+  const size_t rdist = (size_t)f->nxpad * ny, cdist = nkx * ny, batchXY = 3 * (size_t)s->nzl;
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                     nullptr, nullptr, 2, rstr, rdist, 2, cstr, cdist));
+  UH_ROCFFT(rocfft_plan_create(&s->fwdXY, rocfft_placement_inplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_single, 2, len2, batchXY, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                     nullptr, nullptr, 2, cstr, cdist, 2, rstr, rdist));
+  UH_ROCFFT(rocfft_plan_create(&s->invXY, rocfft_placement_inplace, rocfft_transform_type_real_inverse,
+                               rocfft_precision_single, 2, len2, batchXY, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  const size_t S = 3 * (size_t)s->nyl * nkx;
+  const size_t len1[1] = {nz}, zstr[1] = {S};
+  for (int inverse = 0; inverse < 2; ++inverse) {
+    UH_ROCFFT(rocfft_plan_description_create(&d));
+    UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_complex_interleaved,
+                                                       rocfft_array_type_complex_interleaved, nullptr, nullptr, 1, zstr, 1, 1,
+                                                       zstr, 1));
+    UH_ROCFFT(rocfft_plan_create(inverse ? &s->invZ : &s->fwdZ, rocfft_placement_inplace,
+                                 inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                 rocfft_precision_single, 1, len1, S, d));
+    UH_ROCFFT(rocfft_plan_description_destroy(d));
+  }
+  size_t w = 0;
+  for (rocfft_plan p : {s->fwdXY, s->invXY, s->fwdZ, s->invZ}) {
+    size_t wi = 0;
+    UH_ROCFFT(rocfft_plan_get_work_buffer_size(p, &wi));
+    w = wi > w ? wi : w;
+  }
+  f->workBytes = w;
+  if (w) {
+    if (int e = f->work.reserve(w)) return e;
+  }
+  UH_ROCFFT(rocfft_execution_info_create(&f->info));
+  if (w) UH_ROCFFT(rocfft_execution_info_set_work_buffer(f->info, f->work.ptr, w));
   return 0;
 }
 
@@ -505,11 +612,7 @@ int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
   f->planeReal = (size_t)f->nxpad * par->cells[1] * par->cells[2];
   f->planeCplx = f->planeReal / 2;
   if (int e = f->gridBuf.reserve(sizeof(float) * 3 * f->planeReal)) { delete f; return e; }
-  f->useTiles = par->cells[0] % kTile == 0 && par->cells[1] % kTile == 0 && par->cells[2] % kTile == 0 &&
-                par->cells[0] / kTile >= 3 && par->cells[1] / kTile >= 3 && par->cells[2] / kTile >= 3 &&
-                // a stencil may reach support/2+1 nodes outside the particle's tile: adjacent tiles only
-                par->kernel.support[0] <= 2 * (kTile - 1) && par->kernel.support[1] <= 2 * (kTile - 1) &&
-                par->kernel.support[2] <= 2 * (kTile - 1);
+  f->useTiles = fcm_tiles_usable(par->cells, par->kernel.support);
   f->ntiles = make_int3(par->cells[0] / kTile, par->cells[1] / kTile, par->cells[2] / kTile);
   if (int e = fcm_make_plans(f)) { delete f; return e; }
   *out = reinterpret_cast<uammd_fcm *>(f);
@@ -554,41 +657,21 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
   UH_ROCFFT(rocfft_execution_info_set_stream(f->info, (void *)st));
   void *bufs[1] = {g};
+  const size_t zs = (size_t)f->nxpad * f->grid.cellDim.y;  // planar component grids: z stride = one xy plane
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
   FcmPrep pr{};
   if (tiles) {
-    const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-    const int wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
-    if (f->prepCapN < N) {
-      UH_CHECK(hipStreamSynchronize(st));
-      if (int e = f->prepOrigin.reserve(sizeof(int4) * (size_t)N)) return e;
-      if (int e = f->prepWeights.reserve(sizeof(float) * (size_t)wstride * N)) return e;
-      if (int e = f->prepSorted.reserve(sizeof(float4) * (size_t)N)) return e;
-      if (int e = f->prepTileOf.reserve(sizeof(int) * (size_t)N)) return e;
-      if (int e = f->prepRank.reserve(sizeof(int) * (size_t)N)) return e;
-      if (int e = f->prepTileCount.reserve(sizeof(int) * (size_t)nt)) return e;
-      if (int e = f->prepTileStart.reserve(sizeof(int) * ((size_t)nt + 1))) return e;
-      f->prepCapN = N;
-    }
-    pr = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
-                 (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
-                 (int *)f->prepTileStart.ptr, wstride};
-    UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
-    hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
-                       f->ntiles, pr);
-    hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, (const int *)pr.tileCount, nt, pr.tileStart);
-    hipLaunchKernelGGL(k_fcm_prepare, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,
-                       (const float4 *)d_force, N, f->grid, f->kern, pr);
+    if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr)) return e;
   }
   if (d_force) {
     if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), 0, st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                         f->kern.support, f->ntiles, pr);
+                         zs, f->kern.support, f->ntiles, pr);
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
-                         (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+                         (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
     }
     UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
   }
@@ -601,17 +684,18 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / dV);
   }
   const int total = (int)f->planeCplx;
-  hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, f->planeCplx,
+  const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y};
+  hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, lay,
                      f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
                      d_force != nullptr, noisePrefactor, f->par.seed, f->seed2);
   if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
   UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
   if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
-                       f->planeReal, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
+                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
   else
     hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr,
-                       d_linearVelocity, g, N, f->grid, f->nxpad, f->planeReal, f->kern, dsx, dsxy);
+                       d_linearVelocity, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
   UH_CHECK(hipGetLastError());
   return 0;
 }
@@ -626,6 +710,176 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
 int uammd_fcm_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
                             float prefactor, float *d_linearVelocity, void *stream) {
   return uammd_fcm_displacements_staged(h, d_pos, d_force, N, temperature, prefactor, d_linearVelocity, 0, stream);
+}
+
+// ---- slab-decomposed FCM building blocks --------------------------------------------------------------------------
+int uammd_fcm_slab_create(const uammd_fcm_parameters *par, int nzLocal, int z0, int halo, int nyLocal, int y0,
+                          uammd_fcm_slab **out) {
+  if (!par || !out) { set_last_error("uammd_fcm_slab_create: null argument"); return -1; }
+  if (par->cells[0] <= 0 || par->cells[1] <= 0 || par->cells[2] <= 0 || !(par->boxSize[0] > 0) || !(par->boxSize[1] > 0) ||
+      !(par->boxSize[2] > 0)) {
+    set_last_error("FCM_impl requires a valid box and grid dimension");
+    return -2;
+  }
+  if (nzLocal <= 0 || z0 < 0 || z0 + nzLocal > par->cells[2] || nyLocal <= 0 || y0 < 0 || y0 + nyLocal > par->cells[1] ||
+      halo < 0) {
+    set_last_error("uammd_fcm_slab_create: slab [%d,%d) x rows [%d,%d) outside the %d x %d x %d grid", z0, z0 + nzLocal, y0,
+                   y0 + nyLocal, par->cells[0], par->cells[1], par->cells[2]);
+    return -2;
+  }
+  for (int a = 0; a < 3; ++a)
+    if (par->kernel.support[a] < 1 || par->kernel.support[a] > kMaxSupport) {
+      set_last_error("uammd_fcm_slab_create: kernel support %d outside [1, %d]", par->kernel.support[a], kMaxSupport);
+      return -2;
+    }
+  if (halo < par->kernel.support[2] / 2 + 1) {
+    set_last_error("uammd_fcm_slab_create: halo %d cannot hold a stencil of support %d", halo, par->kernel.support[2]);
+    return -2;
+  }
+  FCMSlab *s = new FCMSlab();
+  s->cells = make_int3(par->cells[0], par->cells[1], par->cells[2]);
+  s->L = real3f{par->boxSize[0], par->boxSize[1], par->boxSize[2]};
+  s->nzl = nzLocal; s->z0 = z0; s->halo = halo; s->nyl = nyLocal; s->y0 = y0;
+  s->nkx = par->cells[0] / 2 + 1;
+  FCM *f = &s->loc;
+  f->par = *par;
+  const int lc[3] = {par->cells[0], par->cells[1], nzLocal + 2 * halo};
+  const float hz = par->boxSize[2] / (float)par->cells[2];
+  const float lL[3] = {par->boxSize[0], par->boxSize[1], hz * (float)lc[2]};
+  const int periodic[3] = {1, 1, 1};  // the window never wraps in z: the halo holds every stencil of an owned particle
+  f->grid = make_grid<float>(make_box<float>(lL, periodic), make_int3(lc[0], lc[1], lc[2]));
+  f->kern = to_dev(par->kernel);
+  f->nxpad = 2 * s->nkx;
+  f->planeReal = (size_t)f->nxpad * lc[1];  // component stride of the interleaved-plane layout
+  f->useTiles = fcm_tiles_usable(lc, par->kernel.support);
+  f->ntiles = make_int3(lc[0] / kTile, lc[1] / kTile, lc[2] / kTile);
+  if (int e = fcm_slab_make_plans(s)) { delete s; return e; }
+  *out = reinterpret_cast<uammd_fcm_slab *>(s);
+  return 0;
+}
+
+int uammd_fcm_slab_destroy(uammd_fcm_slab *h) {
+  delete reinterpret_cast<FCMSlab *>(h);
+  return 0;
+}
+
+int uammd_fcm_slab_set_option(uammd_fcm_slab *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_fcm_slab_set_option: null argument"); return -1; }
+  if (std::string(name) == "atomic_spread") { reinterpret_cast<FCMSlab *>(h)->loc.forceAtomicSpread = value != 0; return 0; }
+  set_last_error("uammd_fcm_slab_set_option: unknown option %s", name);
+  return -1;
+}
+
+// d_posLocal: real4[N] in the window frame (z relative to the centre of the owned slab).  d_grid: the real window,
+// 3*nxpad*ny*(nzLocal+2 halo) floats, OVERWRITTEN.  d_force may be NULL (the grid is zeroed, the stencils are still prepared
+// for the gather).
+int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const float *d_force, int N, float *d_grid,
+                          void *stream) {
+  if (!h || !d_grid || (N > 0 && !d_posLocal)) { set_last_error("uammd_fcm_slab_spread: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  FCM *f = &s->loc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t zs = 3 * f->planeReal;
+  const size_t total = zs * (size_t)f->grid.cellDim.z;
+  const bool tiles = f->useTiles && !f->forceAtomicSpread;
+  if (N <= 0 || !d_force || !tiles) UH_CHECK(hipMemsetAsync(d_grid, 0, sizeof(float) * total, st));
+  if (N <= 0) return 0;
+  FcmPrep pr{};
+  if (tiles) {
+    if (int e = fcm_prepare_tiles(f, d_posLocal, d_force, N, st, &pr)) return e;
+    if (d_force) {
+      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), 0, st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
+                         f->kern.support, f->ntiles, pr);
+    }
+  } else if (d_force) {
+    const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+    hipLaunchKernelGGL((k_fcm_ibm<true>), dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_posLocal,
+                       (const float4 *)d_force, (float *)nullptr, d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx,
+                       dsxy);
+  }
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Interpolates the window at the particles; in tile mode it reuses the stencils prepared by the last spread call, which
+// must have been made with the same d_posLocal.
+int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, const float *d_grid, float *d_vel,
+                          void *stream) {
+  if (!h || !d_grid || (N > 0 && (!d_posLocal || !d_vel))) { set_last_error("uammd_fcm_slab_gather: null argument"); return -1; }
+  if (N <= 0) return 0;
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  FCM *f = &s->loc;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t zs = 3 * f->planeReal;
+  const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+  const bool tiles = f->useTiles && !f->forceAtomicSpread;
+  if (tiles) {
+    if (f->prepCapN < N) { set_last_error("uammd_fcm_slab_gather: call uammd_fcm_slab_spread with these positions first"); return -3; }
+    FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
+               (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
+               (int *)f->prepTileStart.ptr, f->kern.support.x + f->kern.support.y + f->kern.support.z};
+    hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
+                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
+  } else {
+    hipLaunchKernelGGL((k_fcm_ibm<false>), dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_posLocal,
+                       (const float4 *)nullptr, d_vel, (float *)d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
+  }
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// batched 2-D R2C of the nzLocal OWNED planes of the window, IN PLACE: afterwards the owned part of the window holds
+// float2 [zl][c][y][kx] (a padded real row and its half spectrum occupy the same 2*(nx/2+1) floats)
+int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
+  if (!h || !d_grid) { set_last_error("uammd_fcm_slab_forward_xy: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
+  void *io[1] = {(void *)(d_grid + (size_t)s->halo * 3 * s->loc.planeReal)};
+  UH_ROCFFT(rocfft_execute(s->fwdXY, io, nullptr, s->loc.info));
+  return 0;
+}
+
+// batched 2-D C2R of the owned part of the window, in place; the halo planes are left untouched
+int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
+  if (!h || !d_grid) { set_last_error("uammd_fcm_slab_inverse_xy: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
+  void *io[1] = {(void *)(d_grid + (size_t)s->halo * 3 * s->loc.planeReal)};
+  UH_ROCFFT(rocfft_execute(s->invXY, io, nullptr, s->loc.info));
+  return 0;
+}
+
+// 1-D complex FFT along z of d_cplxZ [z][c][yl][kx], in place
+int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream) {
+  if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_fft_z: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
+  void *io[1] = {d_cplxZ};
+  UH_ROCFFT(rocfft_execute(inverse ? s->invZ : s->fwdZ, io, nullptr, s->loc.info));
+  return 0;
+}
+
+// forceFourier2Vel + fourierBrownianNoise on this rank's y-rows of the Fourier grid.  seed2 is the value of the reference's
+// call counter AFTER its increment for this call (all ranks pass the same one); ignored when temperature == 0.
+int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor,
+                          unsigned int seed2, void *stream) {
+  if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_kspace: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  float noisePrefactor = 0.0f;
+  if (temperature > 0.0f) {
+    const float gL[3] = {s->L.x, s->L.y, s->L.z};
+    const int per[3] = {1, 1, 1};
+    const GridT<float> g = make_grid<float>(make_box<float>(gL, per), s->cells);
+    const float fourierNormalization = (float)(1.0 / ((double)s->cells.x * s->cells.y * s->cells.z));
+    noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / g.cellVolume);
+  }
+  const KLayout lay{s->nyl, s->y0, (size_t)s->nyl * s->nkx, 3 * (size_t)s->nyl * s->nkx};
+  const int total = s->cells.z * s->nyl * s->nkx;
+  hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_cplxZ, lay,
+                     s->cells, s->L, s->loc.par.viscosity, haveForce != 0, noisePrefactor, s->loc.par.seed, seed2);
+  UH_CHECK(hipGetLastError());
+  return 0;
 }
 
 double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx) {

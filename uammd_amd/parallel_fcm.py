@@ -1,0 +1,252 @@
+"""Multi-GPU path B: z-slab decomposition of the FCM Stokes solver (BASELINE configs[4]).
+
+The reference is single GPU; this is new design.  One process per GPU (`torch.distributed`, backend "nccl" = RCCL over
+xGMI; "gloo" in the CPU tests).  Rank r owns
+  * the particles with z in its slab (the same `SlabDecomposition` as path A: local frame, migration),
+  * nzLocal = nz/P xy-planes of the real grid, kept in a WINDOW of nzLocal + 2*halo planes so that every stencil of an
+    owned particle lands inside it,
+  * after the transpose, nyLocal = ny/P y-rows of the Fourier grid with all of z.
+Per call of `displacements` (= FCM_impl::computeHydrodynamicDisplacements, FCM_impl.cuh:652-693):
+
+    spread (local)  ->  halo planes SENT to the two neighbours and ADDED           2 P2P messages of He planes
+    2-D R2C (x,y) of the owned planes  ->  all-to-all transpose                    1 all-to-all, 1/P of the grid per peer
+    1-D FFT (z)  ->  Stokes + Fourier noise on the y-rows  ->  1-D inverse FFT (z)
+    all-to-all transpose back  ->  2-D C2R into the owned planes                   1 all-to-all
+    halo planes COPIED from the neighbours  ->  gather (local)                     2 P2P messages
+
+No grid data goes through a ring all-reduce.  The Fourier noise needs NO communication: node `id` draws from
+Saru(id, seed, seed2) and the k-space kernel regenerates the draw of a node's conjugate partner locally (gather form,
+uammd_amd/csrc/fcm.hip), so every rank only needs the same (seed, seed2), which advance in lock step.
+
+The per-rank compute stages are a backend: `HipSlabBackend` (libuammd_hip.so, uammd_fcm_slab_* in include/uammd_hip.h) is
+the product; the CPU tests plug a numpy backend built on the oracle to check the exchange logic under gloo.  `ranks` may
+hold ALL P rank states in one process (exchanges become tensor copies): that is how the decomposition is verified
+against the single-GPU solver on one MI355X.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from .parallel import SlabDecomposition
+
+
+class SlabGeometry:
+    """Who owns what.  cells = (nx, ny, nz) of the global grid, `support` of the spreading kernel along z."""
+
+    def __init__(self, cells, L, world, support_z, tile=8):
+        self.cells = [int(c) for c in cells]
+        self.L = [float(x) for x in L]
+        self.world = int(world)
+        nx, ny, nz = self.cells
+        if nz % world or ny % world:
+            raise ValueError(f"grid {self.cells} does not split into {world} z-slabs and y-row blocks")
+        self.nzl, self.nyl = nz // world, ny // world
+        self.nkx = nx // 2 + 1
+        self.nxpad = 2 * self.nkx
+        # planes a stencil of an owned particle can reach outside the slab: support/2 (+1 for the even-support shift,
+        # IBM.cu:10-31) +1 for a particle whose local cell rounds one plane outside the slab
+        self.he = int(support_z) // 2 + 2
+        # the window keeps whole tiles when the tile-owned spread kernel can be used (cells % tile == 0)
+        tiled = nx % tile == 0 and ny % tile == 0 and self.nzl % tile == 0
+        self.halo = -(-self.he // tile) * tile if tiled else self.he
+        if self.nzl < self.he:
+            raise ValueError("slab thinner than the spreading stencil: halo would need second neighbours")
+        self.nzw = self.nzl + 2 * self.halo
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class HipSlabBackend:
+    """The compute stages of one rank on its GPU (include/uammd_hip.h, uammd_fcm_slab_*).  No CPU fallback."""
+
+    def __init__(self, geom, rank, kernel, viscosity, seed, device=None):
+        from . import _lib
+        from ._lib import FCMParameters, check
+        self._check = check
+        self.lib = _lib.load()
+        self.g, self.rank = geom, rank
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        p = FCMParameters()
+        for k in range(3):
+            p.boxSize[k] = geom.L[k]
+            p.cells[k] = geom.cells[k]
+        p.viscosity, p.seed, p.kernel, p.hydrodynamicRadius = float(viscosity), int(seed) & 0xFFFFFFFF, kernel, 0.0
+        h = C.c_void_p()
+        check(self.lib.uammd_fcm_slab_create(C.byref(p), geom.nzl, rank * geom.nzl, geom.halo, geom.nyl, rank * geom.nyl,
+                                             C.byref(h)))
+        self.h = h
+        self.grid = torch.zeros((geom.nzw, 3, geom.cells[1], geom.nxpad), dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_fcm_slab_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _st():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def set_option(self, name, value):
+        self._check(self.lib.uammd_fcm_slab_set_option(self.h, name.encode(), int(value)))
+
+    def spread(self, pos_local, force):
+        self._check(self.lib.uammd_fcm_slab_spread(self.h, self._p(pos_local), self._p(force), pos_local.shape[0],
+                                                   self._p(self.grid), self._st()))
+        return self.grid
+
+    def forward_xy(self, grid):
+        """In place; returns the owned planes viewed as complex [zl][c][y][kx][re,im]."""
+        g = self.g
+        self._check(self.lib.uammd_fcm_slab_forward_xy(self.h, self._p(grid), self._st()))
+        return grid[g.halo:g.halo + g.nzl].view(g.nzl, 3, g.cells[1], g.nkx, 2)
+
+    def spectrum_view(self, grid):
+        g = self.g
+        return grid[g.halo:g.halo + g.nzl].view(g.nzl, 3, g.cells[1], g.nkx, 2)
+
+    def fft_z(self, buf, inverse):
+        self._check(self.lib.uammd_fcm_slab_fft_z(self.h, self._p(buf), int(inverse), self._st()))
+
+    def kspace(self, buf, have_force, temperature, prefactor, seed2):
+        self._check(self.lib.uammd_fcm_slab_kspace(self.h, self._p(buf), int(have_force), float(temperature), float(prefactor),
+                                                   int(seed2) & 0xFFFFFFFF, self._st()))
+
+    def inverse_xy(self, grid):
+        self._check(self.lib.uammd_fcm_slab_inverse_xy(self.h, self._p(grid), self._st()))
+
+    def gather(self, pos_local, grid):
+        out = torch.empty((pos_local.shape[0], 3), dtype=torch.float32, device=self.device)
+        self._check(self.lib.uammd_fcm_slab_gather(self.h, self._p(pos_local), pos_local.shape[0], self._p(grid), self._p(out),
+                                                   self._st()))
+        return out
+
+    def new_zbuffer(self):
+        g = self.g
+        return torch.empty((g.cells[2], 3, g.nyl, g.nkx, 2), dtype=torch.float32, device=self.device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class _Exchange:
+    """The three communication patterns, for either ONE local rank under torch.distributed or ALL ranks in-process."""
+
+    def __init__(self, world, local_ranks, group=None):
+        self.world, self.local, self.group = world, list(local_ranks), group
+        self.in_process = len(self.local) == world
+        if not self.in_process and len(self.local) != 1:
+            raise ValueError("hold either one rank (torch.distributed) or all of them (in-process)")
+
+    def neighbours(self, to_up, to_down):
+        """to_up[i] goes to rank+1, to_down[i] to rank-1 (periodic).  Returns (from_down, from_up) lists."""
+        P = self.world
+        if self.in_process:
+            return [to_up[(r - 1) % P] for r in range(P)], [to_down[(r + 1) % P] for r in range(P)]
+        r = self.local[0]
+        up, down = (r + 1) % P, (r - 1) % P
+        if P == 1:
+            return [to_up[0]], [to_down[0]]
+        from_down, from_up = torch.empty_like(to_up[0]), torch.empty_like(to_down[0])
+        # with 2 ranks both neighbours are the same peer: the messages are told apart by tag (gloo) / issue order (RCCL)
+        t1, t2 = (1, 2) if P == 2 else (0, 0)
+        ops = [dist.P2POp(dist.isend, to_up[0].contiguous(), up, self.group, tag=t1),
+               dist.P2POp(dist.irecv, from_down, down, self.group, tag=t1),
+               dist.P2POp(dist.isend, to_down[0].contiguous(), down, self.group, tag=t2),
+               dist.P2POp(dist.irecv, from_up, up, self.group, tag=t2)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return [from_down], [from_up]
+
+    def all_to_all(self, blocks):
+        """blocks[i]: tensor [P, ...], slice d goes to rank d.  Returns tensors [P, ...] with slice s received from rank s."""
+        P = self.world
+        if self.in_process:
+            return [torch.stack([blocks[s][r] for s in range(P)], dim=0) for r in range(P)]
+        if P == 1:
+            return [blocks[0]]
+        out = torch.empty_like(blocks[0])
+        dist.all_to_all_single(out, blocks[0].contiguous(), group=self.group)
+        return [out]
+
+
+class DistributedFCM:
+    """FCM_impl over z-slabs.  `backends`: one per local rank (see _Exchange)."""
+
+    def __init__(self, geom, backends, local_ranks, seed2=0, group=None):
+        self.g, self.b = geom, list(backends)
+        self.x = _Exchange(geom.world, local_ranks, group)
+        self.seed2 = int(seed2)  # the reference's `static uint seed2` (FCM_impl.cuh:517)
+        self._z = [None] * len(self.b)
+
+    def displacements(self, pos_locals, forces, temperature, prefactor):
+        """pos_locals[i]: real4[N_i] of local rank i in its window frame; forces[i]: real4[N_i] or None (all ranks alike).
+        Returns the list of real3[N_i] velocities  M F + prefactor sqrt(2T) M^(1/2) dW."""
+        g, P = self.g, self.g.world
+        H, He, nzl, nyl = g.halo, g.he, g.nzl, g.nyl
+        have_force = forces[0] is not None
+        if temperature > 0:
+            self.seed2 += 1
+        n = len(self.b)
+        grids = [self.b[i].spread(pos_locals[i], forces[i]) for i in range(n)]
+        zbufs = []
+        if have_force:
+            fd, fu = self.x.neighbours([gr[H + nzl:H + nzl + He] for gr in grids], [gr[H - He:H] for gr in grids])
+            for i, gr in enumerate(grids):
+                gr[H:H + He] += fd[i]
+                gr[H + nzl - He:H + nzl] += fu[i]
+            xy = [self.b[i].forward_xy(grids[i]) for i in range(n)]
+            send = [a.view(nzl, 3, P, nyl, g.nkx, 2).permute(2, 0, 1, 3, 4, 5).contiguous() for a in xy]
+            recv = self.x.all_to_all(send)      # [src][zl][c][yl][kx] == [z][c][yl][kx]
+            for i in range(n):
+                zb = recv[i].reshape(g.cells[2], 3, nyl, g.nkx, 2)
+                self.b[i].fft_z(zb, False)
+                zbufs.append(zb)
+        else:
+            for i in range(n):
+                if self._z[i] is None:
+                    self._z[i] = self.b[i].new_zbuffer()
+                zbufs.append(self._z[i])
+        for i in range(n):
+            self.b[i].kspace(zbufs[i], have_force, temperature, prefactor, self.seed2)
+            self.b[i].fft_z(zbufs[i], True)
+        back = self.x.all_to_all([zb.view(P, nzl, 3, nyl, g.nkx, 2) for zb in zbufs])   # [src(y block)][zl][c][yl][kx]
+        out = []
+        for i in range(n):
+            # [src][zl][c][yl][kx] -> [zl][c][y = (src, yl)][kx], written straight into the owned planes of the window
+            self.b[i].spectrum_view(grids[i]).view(nzl, 3, P, nyl, g.nkx, 2).copy_(back[i].permute(1, 2, 0, 3, 4, 5))
+            self.b[i].inverse_xy(grids[i])
+        fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in grids], [gr[H:H + He] for gr in grids])
+        for i, gr in enumerate(grids):
+            gr[H - He:H] = fd[i]
+            gr[H + nzl:H + nzl + He] = fu[i]
+            out.append(self.b[i].gather(pos_locals[i], gr))
+        return out
+
+
+class DistributedFCMIntegrator:
+    """BDHI::FCMIntegrator::forwardTime (BDHI_FCM.cu:95-119) on slabs, one rank per process: forces -> displacements ->
+    pos += v dt -> migrate.  `forces_fn(pos_local, *carried) -> real4[N]` is the Interactor stack (None: noise only);
+    `carried` are per-particle arrays (ids, fixed forces, ...) that migrate with the particles."""
+
+    def __init__(self, fcm, decomp, temperature, dt, forces_fn):
+        self.fcm, self.d = fcm, decomp
+        self.temperature, self.dt, self.forces_fn = float(temperature), float(dt), forces_fn
+        self.steps = 0
+
+    def forward_time(self, pos_local, *carried):
+        self.steps += 1
+        force = self.forces_fn(pos_local, *carried)
+        v = self.fcm.displacements([pos_local], [force], self.temperature, 1.0 / self.dt ** 0.5)[0]
+        pos_local[:, :3] += v * self.dt                      # integrateEulerMaruyamaD, BDHI_FCM.cu:67-92
+        return self.d.migrate(pos_local, *carried)
+
+
+def make_decomposition(geom, rank, group=None):
+    """Particle ownership that matches the grid slabs: z in [-Lz/2 + r Lz/P, ...), cut-off = the stencil reach."""
+    hz = geom.L[2] / geom.cells[2]
+    return SlabDecomposition(geom.L, geom.he * hz, rank, geom.world, group)
