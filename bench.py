@@ -52,7 +52,7 @@ def lattice(n, L, seed, jitter=0.1):
     return lattice_positions(n, L, seed=seed, jitter=jitter)
 
 
-def lj_setup(hip, n, L, seed, T=1.0, dt=0.005):
+def lj_setup(hip, n, L, seed, T=1.0, dt=0.005, nl="cell"):
     pos = lattice(n, L, seed)
     pd = hip.ParticleData(n, seed=seed)
     pd.setPos(pos)
@@ -61,7 +61,7 @@ def lj_setup(hip, n, L, seed, T=1.0, dt=0.005):
     pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
     par = hip.VerletNVT.GronbechJensen.Parameters(temperature=T, dt=dt, friction=1.0, initVelocities=True)
     verlet = hip.VerletNVT.GronbechJensen(pd, par)
-    pf = hip.PairForces(pd, box, pot)
+    pf = hip.PairForces(pd, box, pot, nl=(hip.VerletList(pd) if nl == "verlet" else None))
     verlet.addInteractor(pf)
     return pd, box, pot, verlet, pf, pos
 
@@ -387,6 +387,9 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
     ap.add_argument("--brick-bits", type=int, default=None)
     ap.add_argument("--algo", type=int, default=0)
+    ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
+                    help="neighbour list of PairForces: CellList (BASELINE configs[2], default) or VerletList (the "
+                         "reference's examples/misc/benchmark.cu default)")
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
 
@@ -446,7 +449,7 @@ def main():
         return
     # Multi-GPU: the LJ path shards by spatial domain; this round each rank integrates an independent
     # replica box of the same size (weak scaling, no data-path collective) — see DESIGN.md §multi-GPU.
-    pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank)
+    pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank, nl=args.nl)
     pf.algo = args.algo
     verlet.forwardTime()  # creates the neighbour list
     timer = TimedPairForces(pf)
@@ -490,12 +493,14 @@ def main():
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, CellList rebuilt every step, "
+        "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, " +
+                               ("CellList rebuilt every step, " if args.nl == "cell" else
+                                f"VerletList (1.08 rc, {getattr(pf.nl, 'rebuilds', 0)} rebuilds in {args.warmup + args.steps + 1} steps), ") +
                                "VerletNVT::GronbechJensen T=1 dt=0.005 (BASELINE configs[2])",
                    "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
                    "parallelism": "1 process per GPU, independent replica boxes" if world > 1 else "single GPU"},
         "pair_interactions_per_s": 52.36 * value,
-        "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal)", "achieved": achieved_tflops,
+        "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal)" if args.nl == "cell" else "k_lj_verlet (list traversal; the flop model is the CellList walk's, so this is an effective rate)", "achieved": achieved_tflops,
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
                      "traffic": traffic, "kernel_ms": k_ms,
                      "note": "f32 VALU-bound kernel; peak = f32 vector (= f32 MFMA) peak; model 1.0e4 flop/particle",

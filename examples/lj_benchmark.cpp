@@ -2,6 +2,7 @@
 // (the C3 workload of BASELINE.json), written against the same class names.
 #include "uammd.cuh"
 #include "Interactor/NeighbourList/CellList.cuh"
+#include "Interactor/NeighbourList/VerletList.cuh"
 #include "Interactor/PairForces.cuh"
 #include "Interactor/Potential/Potential.cuh"
 #include "Integrator/VerletNVT.cuh"
@@ -28,7 +29,12 @@ int main(int argc, char *argv[]) {
   par.dt = 0.005;
   par.friction = 1.0;
   auto verlet = std::make_shared<VerletNVT::GronbechJensen>(pd, par);
-  using PairForces = PairForces<Potential::LJ, CellList>;
+#ifdef USE_CELLLIST
+  using NeighbourList = CellList;
+#else
+  using NeighbourList = VerletList;  // examples/misc/benchmark.cu:82-84
+#endif
+  using PairForces = PairForces<Potential::LJ, NeighbourList>;
   auto pot = std::make_shared<Potential::LJ>();
   {
     Potential::LJ::InputPairParameters p;

@@ -7,6 +7,7 @@
 //   ParticleData, property_ptr    ParticleData/ParticleData.cuh:161-465, ParticleData/Property.cuh:49-147
 //   Interactor / Integrator       Interactor/Interactor.cuh:56-119, Integrator/Integrator.cuh:33-125
 //   CellList                      Interactor/NeighbourList/CellList.cuh:83-205
+//   VerletList                    Interactor/NeighbourList/VerletList.cuh:83-201
 //   Potential::LJ                 Interactor/Potential/Potential.cuh:25-85, RadialPotential.cuh:49-154
 //   PairForces<Potential, NL>     Interactor/PairForces.cuh:23-64, PairForces.cu:43-78
 //   VerletNVT::{Basic,GronbechJensen}   Integrator/VerletNVT.cuh:55-115
@@ -428,6 +429,45 @@ public:
   uammd_celllist *handle() { return h; }
 };
 
+// ---- VerletList (Interactor/NeighbourList/VerletList.cuh:83-201) ------------------------------------------------------------------
+class VerletList {
+  shared_ptr<ParticleData> pd;
+  uammd_verletlist *h = nullptr;
+  bool forceNextUpdate = true;
+  Box currentBox;
+  real currentCutOff = 0;
+public:
+  using VerletListData = uammd_verletlist_data;
+  explicit VerletList(shared_ptr<ParticleData> pd) : pd(pd) {
+    detail::check(uammd_verletlist_create(&h));
+    pd->connectPosWriteRequested([this]() { forceNextUpdate = true; });                                         // :171-175
+    pd->connectReorder([this]() { forceNextUpdate = true; uammd_verletlist_force_next_update(h); });            // :177-182
+  }
+  VerletList(const VerletList &) = delete;
+  ~VerletList() { uammd_verletlist_destroy(h); }
+  void update(Box box, real cutOff, hipStream_t st = 0) {  // :112-124
+    const bool rebuild = forceNextUpdate || box != currentBox || cutOff != currentCutOff;
+    forceNextUpdate = false;
+    if (!rebuild) return;
+    pd->hintSortByHash(box, make_real3(cutOff * real(0.5)));
+    currentBox = box;
+    currentCutOff = cutOff;
+    float L[3]; int per[3];
+    box.toArrays(L, per);
+    // VerletList reads the positions with access::read: that does not raise the pos-write signal (Property access only)
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_verletlist_update(h, (const float *)pos.raw(), pd->getNumParticles(), L, per, cutOff, (void *)st, nullptr));
+  }
+  void update(Box box, real3 cutOff, hipStream_t st = 0) {  // :130-136
+    if (cutOff.x != cutOff.y || cutOff.x != cutOff.z) throw std::runtime_error("[VerletList] Invalid argument");
+    update(box, cutOff.x, st);
+  }
+  VerletListData getVerletList() { VerletListData d; detail::check(uammd_verletlist_get(h, &d)); return d; }
+  void setCutOffMultiplier(real newMultiplier) { forceNextUpdate = true; detail::check(uammd_verletlist_set_cutoff_multiplier(h, newMultiplier)); }
+  int getNumberOfStepsSinceLastUpdate() { int s = 0; detail::check(uammd_verletlist_get_steps_since_last_update(h, &s)); return s; }
+  uammd_verletlist *handle() { return h; }
+};
+
 // ---- Potential::LJ ---------------------------------------------------------------------------------------------------------------
 namespace Potential {
 class LJ {
@@ -473,6 +513,15 @@ template <class NL> class PairForces<Potential::LJ, NL> : public Interactor {
   Box box;
   shared_ptr<Potential::LJ> pot;
   shared_ptr<NL> nl;
+  // NL::transverseList(Radial<LJFunctor>::Transverser): one fused entry point per neighbour-list type
+  static int transverse(uammd_celllist *h, const uammd_lj_pair_parameters *t, int nt, const float *L, const int *per, float *f,
+                        float *e, float *v, void *st) {
+    return uammd_lj_transverse_celllist(h, t, nt, L, per, f, e, v, nullptr, UAMMD_LJ_ALGO_AUTO, st);
+  }
+  static int transverse(uammd_verletlist *h, const uammd_lj_pair_parameters *t, int nt, const float *L, const int *per, float *f,
+                        float *e, float *v, void *st) {
+    return uammd_lj_transverse_verletlist(h, t, nt, L, per, f, e, v, nullptr, st);
+  }
 public:
   struct Parameters { Box box; shared_ptr<NL> nl = nullptr; };
   PairForces(shared_ptr<ParticleData> pd, Parameters par, shared_ptr<Potential::LJ> pot = make_shared<Potential::LJ>())
@@ -492,9 +541,8 @@ public:
     auto energy = comp.energy ? pd->getEnergy(access::gpu, access::readwrite) : property_ptr<real>();
     auto virial = comp.virial ? pd->getVirial(access::gpu, access::readwrite) : property_ptr<real>();
     if (useNL) {
-      detail::check(uammd_lj_transverse_celllist(nl->handle(), pot->deviceTable(), pot->getNumberTypes(), L, per,
-                                                 (float *)force.raw(), energy.raw(), virial.raw(), nullptr,
-                                                 UAMMD_LJ_ALGO_AUTO, (void *)st));
+      detail::check(transverse(nl->handle(), pot->deviceTable(), pot->getNumberTypes(), L, per, (float *)force.raw(),
+                               energy.raw(), virial.raw(), (void *)st));
     } else {
       auto pos = pd->getPos(access::gpu, access::read);
       detail::check(uammd_lj_transverse_nbody((const float *)pos.raw(), N, pot->deviceTable(), pot->getNumberTypes(), L,

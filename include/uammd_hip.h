@@ -109,6 +109,43 @@ int uammd_lj_transverse_nbody(const float *d_pos, int numberParticles, const uam
                               float *d_energy, float *d_virial, const int *d_globalIndex, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Path A — Verlet list.  Replaces
+ *   VerletListBase::{update,needsRebuild,getVerletList,setCutOffMultiplier,forceNextUpdate,getNumberOfStepsSinceLastUpdate}
+ *                                                               Interactor/NeighbourList/VerletList/VerletListBase.cuh:73-199
+ *   BasicNeighbourListBase::{update,getBasicNeighbourList}      Interactor/NeighbourList/BasicList/BasicListBase.cuh:76-215
+ *   fillBasicNeighbourList (K7), checkMaximumDrift (K8)         BasicListBase.cuh:41-75, VerletListBase.cuh:55-69
+ *   VerletList::transverseList<Radial<LJFunctor>::Transverser>  Interactor/NeighbourList/VerletList.cuh:138-155
+ * The list is built on the cell list of the STORED positions with cut-off multiplier*cutOff (1.08), capacity 32 per
+ * particle growing by 32; entry k of sorted particle i is d_neighbourList[k*particleStride + i]; the particle itself is
+ * one of its neighbours (r2 = 0 <= cutOff2, as in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_verletlist uammd_verletlist;
+/* BasicNeighbourListBase::BasicNeighbourListData (BasicListBase.cuh:144-152), with VerletListBase's current sortPos */
+typedef struct {
+  const int *d_neighbourList;
+  const int *d_numberNeighbours;
+  const float *d_sortPos;   /* real4[N]: CURRENT positions in the order of the last build */
+  const int *d_groupIndex;  /* sorted index -> index in the input array */
+  int particleStride;       /* = numberParticles */
+  int maxNeighboursPerParticle;
+  int numberParticles;
+} uammd_verletlist_data;
+int uammd_verletlist_create(uammd_verletlist **out);
+int uammd_verletlist_destroy(uammd_verletlist *h);
+/* VerletListBase::update(pos, N, box, cutOff, st): rebuilds if forced / box, cutOff or N changed / some particle drifted
+ * >= (multiplier*cutOff - cutOff)/2 from its stored position (one 4-byte read-back, as in the reference), then refreshes
+ * sortPos.  *rebuilt (nullable) tells whether the list was rebuilt. */
+int uammd_verletlist_update(uammd_verletlist *h, const float *d_pos, int numberParticles, const float L[3],
+                            const int periodic[3], float cutOff, void *stream, int *rebuilt);
+int uammd_verletlist_force_next_update(uammd_verletlist *h);
+int uammd_verletlist_set_cutoff_multiplier(uammd_verletlist *h, float newMultiplier);
+int uammd_verletlist_get_steps_since_last_update(uammd_verletlist *h, int *steps);
+int uammd_verletlist_get(uammd_verletlist *h, uammd_verletlist_data *out);
+int uammd_lj_transverse_verletlist(uammd_verletlist *h, const uammd_lj_pair_parameters *d_paramTable, int ntypes,
+                                   const float boxL[3], const int boxPeriodic[3], float *d_force, float *d_energy,
+                                   float *d_virial, const int *d_globalIndex, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Integrator kernels.  Replace
  *   VerletNVT::GronbechJensen_ns::integrateGPU<step>   Integrator/VerletNVT/GronbechJensen.cu:28-62
  *   VerletNVT::Basic_ns::integrateGPU<step>            Integrator/VerletNVT/Basic.cu:86-114

@@ -149,6 +149,41 @@ class Oracle:
         return f
 
 
+    # ---- path A: VerletList ----------------------------------------------------------------------
+    def verletlist_fill(self, cl, box_L, box_periodic, cutoff2, max_neighbours, n):
+        """fillBasicNeighbourList on a built cell list.  Returns (tooManyFlag, neighbourList[(max+1)*n], numberNeighbours[n])."""
+        bl, bp = self._box(box_L, box_periodic)
+        nl = np.full((max_neighbours + 1) * n, -1, np.int32)
+        nn = np.zeros(n, np.int32)
+        self.lib.oracle_verletlist_fill.restype = C.c_int
+        flag = self.lib.oracle_verletlist_fill(_p(cl["sortPos"]), n, _p(cl["cellStart"]), _p(cl["cellEnd"]),
+                                               C.c_uint(cl["validCell"]), _p(cl["L"]), _p(cl["periodic"]), _p(cl["cellDim"]),
+                                               _p(bl), _p(bp), self.creal(cutoff2), int(max_neighbours), _p(nl), _p(nn))
+        return int(flag), nl, nn
+
+    def verletlist_check_drift(self, current, stored, max_dist, box_L, box_periodic):
+        bl, bp = self._box(box_L, box_periodic)
+        cur, sto = self.r(current), self.r(stored)
+        self.lib.oracle_verletlist_check_drift.restype = C.c_uint
+        return int(self.lib.oracle_verletlist_check_drift(_p(cur), _p(sto), len(cur), self.creal(max_dist), _p(bl), _p(bp)))
+
+    def lj_transverse_verletlist(self, sort_pos, group_index, nl, nn, box_L, box_periodic, param_table, ntypes,
+                                 want_force=True, want_energy=False, want_virial=False, global_index=None):
+        n = len(sort_pos)
+        bl, bp = self._box(box_L, box_periodic)
+        tbl = self.r(param_table)
+        sp = self.r(sort_pos)
+        f = np.zeros((n, 4), self.real) if want_force else None
+        e = np.zeros(n, self.real) if want_energy else None
+        v = np.zeros(n, self.real) if want_virial else None
+        gi = None if global_index is None else np.ascontiguousarray(global_index, dtype=np.int32)
+        self.lib.oracle_lj_transverse_verletlist(_p(sp), _p(np.ascontiguousarray(group_index, dtype=np.int32)), _p(gi), n,
+                                                 _p(np.ascontiguousarray(nl, dtype=np.int32)),
+                                                 _p(np.ascontiguousarray(nn, dtype=np.int32)), _p(bl), _p(bp), _p(tbl),
+                                                 int(ntypes), _p(f), _p(e), _p(v))
+        return f, e, v
+
+
     # ---- path B: IBM -----------------------------------------------------------------------------
     def ibm_kernel(self, kind, support, prefactor=0.0, tau=0.0, rmax=np.inf, invh=(0, 0, 0)):
         """kind: 'gaussian' | 'peskin3' | 'peskin4' | 'constant' (oracle/src/ibm.c IBMKernel)."""

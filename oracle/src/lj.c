@@ -170,3 +170,93 @@ ORACLE_API void oracle_lj_nbody_f64(const double *pos4, int N, const double *L, 
     force3[3 * i] = fx; force3[3 * i + 1] = fy; force3[3 * i + 2] = fz;
   }
 }
+
+/* ---- VerletList -----------------------------------------------------------------------------------------
+ *   BasicNeighbourList_ns::fillBasicNeighbourList (K7)   Interactor/NeighbourList/BasicList/BasicListBase.cuh:41-75
+ *   BasicNeighbourList_ns::NeighbourIterator              Interactor/NeighbourList/BasicList/NeighbourContainer.cuh:54-104
+ *   VerletListBase_ns::checkMaximumDrift (K8)             Interactor/NeighbourList/VerletList/VerletListBase.cuh:55-69
+ * Details that are easy to "fix" by accident: the particle itself IS in its own list (r2 = 0 <= cutOff2); the test is
+ * `<=`; a particle that reaches maxNeighboursPerParticle raises the flag with atomicMax(nneigh) and returns WITHOUT writing
+ * numberNeighbours; entry k of particle i lives at neighbourList[k*N + i].  Same non-periodic deviation as above. */
+ORACLE_API int oracle_verletlist_fill(const real4 *sortPos, int N, const uint *cellStart, const int *cellEnd, uint validCell,
+                                      const real *gridL, const int *gridPeriodic, const int *cellDim, const real *boxL,
+                                      const int *boxPeriodic, real cutOff2, int maxNeighboursPerParticle, int *neighbourList,
+                                      int *numberNeighbours) {
+  Box gbox = box_from(gridL, gridPeriodic);
+  Grid grid = grid_make(gbox, mki3(cellDim[0], cellDim[1], cellDim[2]));
+  Box box = box_from(boxL, boxPeriodic);
+  const int3 n = grid.cellDim;
+  const int3 nperdim = mki3((n.x > 1 ? 3 : 1), (n.y > 1 ? 3 : 1), (n.z > 1 ? 3 : 1));
+  const int numberNeighbourCells = nperdim.x * nperdim.y * nperdim.z;
+  int tooMany = 0;
+  for (int id = 0; id < N; id++) {
+    int nneigh = 0, aborted = 0;
+    const real4 pi = sortPos[id];
+    const int3 celli = grid_get_cell(&grid, mk3(pi.x, pi.y, pi.z));
+    for (int currentCell = 0; currentCell < numberNeighbourCells && !aborted; currentCell++) {
+      int3 cellj = celli;
+      if (nperdim.x > 1) cellj.x += currentCell % 3 - 1;
+      if (nperdim.y > 1) cellj.y += (currentCell / nperdim.x) % 3 - 1;
+      if (nperdim.z > 1) cellj.z += currentCell / (nperdim.x * nperdim.y) - 1;
+      cellj = grid_pbc_cell(&grid, cellj);
+      if (cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z) continue;
+      const int icellj = grid_cell_index(&grid, cellj);
+      const uint cs = cellStart[icellj];
+      if (cs < validCell) continue;
+      const int first = (int)(cs - validCell), last = cellEnd[icellj];
+      for (int j = first; j < last; j++) {
+        const real4 pj = sortPos[j];
+        const real3 rij = box_apply_pbc(&box, mk3(pj.x - pi.x, pj.y - pi.y, pj.z - pi.z));
+        if (dot3(rij, rij) <= cutOff2) {
+          nneigh++;
+          if (nneigh >= maxNeighboursPerParticle) {
+            if (nneigh > tooMany) tooMany = nneigh;
+            aborted = 1;
+            break;
+          }
+          neighbourList[(size_t)(nneigh - 1) * N + id] = j;
+        }
+      }
+    }
+    if (!aborted) numberNeighbours[id] = nneigh;
+  }
+  return tooMany;
+}
+
+/* number of particles with |pbc(current - stored)|^2 >= maxDistAllowed^2 */
+ORACLE_API unsigned oracle_verletlist_check_drift(const real4 *currentPos, const real4 *storedPos, int N, real maxDistAllowed,
+                                                  const real *boxL, const int *boxPeriodic) {
+  Box box = box_from(boxL, boxPeriodic);
+  unsigned flag = 0;
+  for (int id = 0; id < N; id++) {
+    const real3 rij = box_apply_pbc(&box, mk3(currentPos[id].x - storedPos[id].x, currentPos[id].y - storedPos[id].y,
+                                              currentPos[id].z - storedPos[id].z));
+    if (dot3(rij, rij) >= maxDistAllowed * maxDistAllowed) flag++;
+  }
+  return flag;
+}
+
+/* transverseWithNeighbourContainer (common.cuh:10-34) driven by the list: neighbours k = 0..numberNeighbours[i]-1 in list
+ * order, positions from the CURRENT sortPos (VerletListBase::updateSortedPositions, VerletListBase.cuh:140-151). */
+ORACLE_API void oracle_lj_transverse_verletlist(const real4 *sortPos, const int *groupIndex, const int *globalIndex, int N,
+                                                const int *neighbourList, const int *numberNeighbours, const real *boxL,
+                                                const int *boxPeriodic, const real *paramTable, int ntypes, real4 *force,
+                                                real *energy, real *virial) {
+  Box box = box_from(boxL, boxPeriodic);
+  const LJPairParameters *tbl = (const LJPairParameters *)paramTable;
+#pragma omp parallel for schedule(static)
+  for (int id = 0; id < N; id++) {
+    const int gi = groupIndex[id];
+    const int ori = globalIndex ? globalIndex[gi] : gi;
+    const real4 pi = sortPos[id];
+    FEV quantity = {{0, 0, 0}, 0, 0};
+    const int nn = numberNeighbours[id];
+    for (int k = 0; k < nn; k++) {
+      const int j = neighbourList[(size_t)k * N + id];
+      lj_pair_acc(&quantity, &box, tbl, ntypes, pi, sortPos[j], force || virial, energy != NULL, virial != NULL);
+    }
+    if (force) { force[ori].x += quantity.force.x; force[ori].y += quantity.force.y; force[ori].z += quantity.force.z; force[ori].w += 0; }
+    if (energy) energy[ori] += quantity.energy;
+    if (virial) virial[ori] += quantity.virial;
+  }
+}

@@ -25,6 +25,12 @@ class CellListData(C.Structure):
                 ("numberParticles", C.c_int)]
 
 
+class VerletListData(C.Structure):
+    _fields_ = [("d_neighbourList", C.c_void_p), ("d_numberNeighbours", C.c_void_p), ("d_sortPos", C.c_void_p),
+                ("d_groupIndex", C.c_void_p), ("particleStride", C.c_int), ("maxNeighboursPerParticle", C.c_int),
+                ("numberParticles", C.c_int)]
+
+
 class IBMKernel(C.Structure):
     _fields_ = [("kind", C.c_int), ("support", C.c_int * 3), ("prefactor", C.c_float), ("tau", C.c_float),
                 ("rmax", C.c_float), ("invh", C.c_float * 3)]
@@ -61,6 +67,14 @@ SIGNATURES = {
     "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),
     "uammd_lj_transverse_celllist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _i, _vp]),
     "uammd_lj_transverse_nbody": (_i, [_vp, _i, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_verletlist_create": (_i, [C.POINTER(_vp)]),
+    "uammd_verletlist_destroy": (_i, [_vp]),
+    "uammd_verletlist_update": (_i, [_vp, _vp, _i, _f3, _i3, _f, _vp, C.POINTER(_i)]),
+    "uammd_verletlist_force_next_update": (_i, [_vp]),
+    "uammd_verletlist_set_cutoff_multiplier": (_i, [_vp, _f]),
+    "uammd_verletlist_get_steps_since_last_update": (_i, [_vp, C.POINTER(_i)]),
+    "uammd_verletlist_get": (_i, [_vp, C.POINTER(VerletListData)]),
+    "uammd_lj_transverse_verletlist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
     "uammd_verletnvt_gj": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_basic": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_initial_velocities": (_i, [_vp, _vp, _f, _i, _i, _u, _vp]),

@@ -23,63 +23,11 @@
 //                 primary box (then floor(d*(-1/L)+0.5) == 0 for every pair).
 //   k_lj_nbody    all pairs with LDS tiles (small boxes; PairForces.cu:49-53).
 #include "celllist.hpp"
+#include "lj_common.hpp"
 
 #include <string>
 
 namespace uammd_hip {
-
-struct LJParams { float cutOff2, sigma2, epsilonDivSigma2, shift; };
-
-UH_D float lj_force(float r2, const LJParams &p) {  // |f|/r
-  if (r2 >= p.cutOff2) return 0.0f;
-  const float invr2 = p.sigma2 / r2;
-  const float invr6 = invr2 * invr2 * invr2;
-  return p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
-}
-UH_D float lj_energy(float r2, const LJParams &p) {  // half the pair energy
-  if (r2 >= p.cutOff2) return 0.0f;
-  const float invr2 = p.sigma2 / r2;
-  const float invr6 = invr2 * invr2 * invr2;
-  const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
-  return 0.5f * E;
-}
-UH_D LJParams lj_lookup(const LJParams *tbl, int ntypes, int ti, int tj) {
-  if (ti > tj) { const int t = ti; ti = tj; tj = t; }
-  int typeIndex = ti + ntypes * tj;
-  if (ti >= ntypes || tj >= ntypes) typeIndex = 0;
-  return tbl[typeIndex];
-}
-
-struct Acc { float fx = 0.f, fy = 0.f, fz = 0.f, e = 0.f, v = 0.f; };
-
-// One pair, branch free: returns |f|/r (0 outside the cut-off or at r = 0) and the pair energy.  A
-// masked pair contributes fma(0, r12, acc) == acc, bit-identical to skipping it.
-template <bool PBC, bool WE>
-UH_D void lj_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, const float4 &rj, real3f &r12,
-                  float &fm, float &e) {
-  r12 = real3f{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
-  if (PBC) r12 = box.apply_pbc(r12);
-  const float r2 = dot3(r12, r12);
-  const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
-  const float invr2 = p.sigma2 / r2;
-  const float invr6 = invr2 * invr2 * invr2;
-  const float f = p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
-  fm = in ? f : 0.0f;
-  if (WE) {
-    const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
-    e = in ? 0.5f * E : 0.0f;
-  } else
-    e = 0.0f;
-}
-
-template <bool WE, bool WV>
-UH_D void lj_acc(Acc &a, const real3f &r12, float fm, float e) {
-  if (WE) a.e += e;
-  a.fx = fmaf(fm, r12.x, a.fx);
-  a.fy = fmaf(fm, r12.y, a.fy);
-  a.fz = fmaf(fm, r12.z, a.fz);
-  if (WV) a.v += dot3(real3f{fm * r12.x, fm * r12.y, fm * r12.z}, r12);
-}
 
 // ---- two-phase pair evaluation ---------------------------------------------------------------------
 // Only ~15 % of the candidate pairs of a 27-cell walk are inside the cut-off (4.19 rc^3 of 27 rc^3),
@@ -92,12 +40,6 @@ template <class QT, int QCAP, int QSTRIDE> struct PairQueue {
   QT *slot;  // this lane's entry 0; entry t lives at slot[t * QSTRIDE]
   int n;
 };
-
-template <bool PBC> UH_D float lj_dist2(const BoxT<float> &box, const float4 &ri, const float4 &rj) {
-  real3f r12{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
-  if (PBC) r12 = box.apply_pbc(r12);
-  return dot3(r12, r12);
-}
 
 template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
 UH_D void lj_drain(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, const float4 *__restrict__ P, const float4 &pi,
@@ -145,12 +87,6 @@ UH_D void lj_scan(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, cons
   }
 }
 
-UH_D float lj_max_cutoff2(const LJParams *tbl, int ntypes) {
-  float m = 0.0f;
-  for (int t = 0; t < ntypes * ntypes; ++t) m = fmaxf(m, tbl[t].cutOff2);
-  return m;
-}
-
 struct ListView {
   const uint *cellStart;
   const int *cellEnd;
@@ -162,23 +98,6 @@ struct ListView {
   uint validCell;
   int N;
 };
-
-struct Outputs {
-  float4 *force;
-  float *energy;
-  float *virial;
-  const int *globalIndex;
-};
-
-UH_D void write_out(const Outputs &o, int ori, const Acc &a) {
-  if (o.force) {
-    float4 f = o.force[ori];
-    f.x += a.fx; f.y += a.fy; f.z += a.fz; f.w += 0.0f;
-    o.force[ori] = f;
-  }
-  if (o.energy) o.energy[ori] += a.e;
-  if (o.virial) o.virial[ori] += a.v;
-}
 
 constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
 constexpr int kQCapBrick = 32;    // per-lane FIFO depth of the brick kernel (ushort LDS indices)

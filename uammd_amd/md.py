@@ -5,6 +5,7 @@ libuammd_hip.so.  Citations (relative to /root/reference/src):
   Box                          utils/Box.cuh:16-58
   ParticleData                 ParticleData/ParticleData.cuh:161-465
   CellList                     Interactor/NeighbourList/CellList.cuh:83-205
+  VerletList                   Interactor/NeighbourList/VerletList.cuh:83-201
   Potential.LJ                 Interactor/Potential/Potential.cuh:25-85, RadialPotential.cuh:49-154
   PairForces                   Interactor/PairForces.cuh:23-64, PairForces.cu:43-78
   Integrator / Interactor      Integrator/Integrator.cuh:33-125, Interactor/Interactor.cuh:56-119
@@ -18,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CellListData, LJPairParameters, check, f3, i3
+from ._lib import CellListData, LJPairParameters, VerletListData, check, f3, i3
 
 
 def current_stream():
@@ -76,6 +77,7 @@ class ParticleData:
         self.rng = Xorshift128plus()
         self.rng.set_seed(seed)
         self._pos_write_callbacks = []
+        self._reorder_callbacks = []
         self.id = torch.arange(self.N, dtype=torch.int32, device=self.device)
 
     def getNumParticles(self):
@@ -121,6 +123,10 @@ class ParticleData:
     def connectPosWrite(self, cb):
         self._pos_write_callbacks.append(cb)
 
+    def connectReorder(self, cb):
+        """ParticleData::getReorderSignal (ParticleData.cuh:196-208)."""
+        self._reorder_callbacks.append(cb)
+
     def hintSortByHash(self, hash_box, hash_cutOff):
         """ParticleData::hintSortByHash (ParticleData.cuh:389-394)."""
         self._hint_box, self._hint_cutoff = hash_box, np.broadcast_to(np.asarray(hash_cutOff, np.float32), (3,))
@@ -147,6 +153,8 @@ class ParticleData:
         check(lib.uammd_gather(_ptr(self.id), _ptr(idx), _ptr(out), self.N, 4, current_stream()))
         self.id = out
         for cb in self._pos_write_callbacks:
+            cb()
+        for cb in self._reorder_callbacks:
             cb()
 
 
@@ -255,6 +263,90 @@ class CellList:
         check(self.lib.uammd_lj_transverse_celllist(self.h, _ptr(param_table), int(ntypes), f3(box.boxSize),
                                                     i3([int(p) for p in box.periodic]), _ptr(force), _ptr(energy),
                                                     _ptr(virial), _ptr(global_index), int(algo), current_stream()))
+
+
+class VerletList:
+    """VerletList (Interactor/NeighbourList/VerletList.cuh:83-201): the NeighbourList concept on an explicit list that is
+    only rebuilt when a particle has drifted (1.08 rc - rc)/2 from where it was at the last build."""
+
+    def __init__(self, pd=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.uammd_verletlist_create(C.byref(h)))
+        self.h = h
+        self.pd = pd
+        self.force_next_update = True
+        self.currentCutOff = None
+        self.currentBox = None
+        self.rebuilds = 0
+        if pd is not None:
+            pd.connectPosWrite(self._handle_pos_write)
+            pd.connectReorder(self._handle_reorder)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_verletlist_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _handle_pos_write(self):            # VerletList.cuh:171-175
+        self.force_next_update = True
+
+    def _handle_reorder(self):              # VerletList.cuh:177-182
+        self.force_next_update = True
+        check(self.lib.uammd_verletlist_force_next_update(self.h))
+
+    def setCutOffMultiplier(self, m):
+        self.force_next_update = True
+        check(self.lib.uammd_verletlist_set_cutoff_multiplier(self.h, float(m)))
+
+    def getNumberOfStepsSinceLastUpdate(self):
+        v = C.c_int(0)
+        check(self.lib.uammd_verletlist_get_steps_since_last_update(self.h, C.byref(v)))
+        return int(v.value)
+
+    def update(self, box, cutoff, pos=None):
+        """VerletList::update(box, cutOff, st) (VerletList.cuh:112-124)."""
+        c = np.broadcast_to(np.asarray(cutoff, dtype=np.float32), (3,))
+        if c[0] != c[1] or c[0] != c[2]:
+            raise RuntimeError("[VerletList] Invalid argument")      # VerletList.cuh:130-136
+        rc = float(c[0])
+        need = self.force_next_update or self.currentBox is None or not (box == self.currentBox) or rc != self.currentCutOff
+        self.force_next_update = False
+        if not need:
+            return
+        if pos is None:
+            self.pd.hintSortByHash(box, [rc * 0.5] * 3)
+            pos = self.pd.getPos("read")
+        self.currentBox, self.currentCutOff = box, rc
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 4
+        rebuilt = C.c_int(0)
+        check(self.lib.uammd_verletlist_update(self.h, _ptr(pos), pos.shape[0], f3(box.boxSize),
+                                               i3([int(p) for p in box.periodic]), rc, current_stream(), C.byref(rebuilt)))
+        self.rebuilds += int(rebuilt.value)
+
+    def getVerletList(self):
+        d = VerletListData()
+        check(self.lib.uammd_verletlist_get(self.h, C.byref(d)))
+        return d
+
+    def to_host(self):
+        d = self.getVerletList()
+        n, m = d.numberParticles, d.maxNeighboursPerParticle
+        torch.cuda.synchronize()
+        w = CellList._wrap
+        return dict(neighbourList=w(None, d.d_neighbourList, ((m + 1) * n,), torch.int32).cpu().numpy(),
+                    numberNeighbours=w(None, d.d_numberNeighbours, (n,), torch.int32).cpu().numpy(),
+                    sortPos=w(None, d.d_sortPos, (n, 4), torch.float32).cpu().numpy(),
+                    index=w(None, d.d_groupIndex, (n,), torch.int32).cpu().numpy(), stride=d.particleStride,
+                    maxNeighboursPerParticle=m)
+
+    def transverse_lj(self, param_table, ntypes, box, force=None, energy=None, virial=None, global_index=None, algo=0):
+        check(self.lib.uammd_lj_transverse_verletlist(self.h, _ptr(param_table), int(ntypes), f3(box.boxSize),
+                                                      i3([int(p) for p in box.periodic]), _ptr(force), _ptr(energy),
+                                                      _ptr(virial), _ptr(global_index), current_stream()))
 
 
 class Interactor:
