@@ -168,6 +168,10 @@ int uammd_bd_euler_maruyama(float *d_pos, const int *d_index, const float *d_for
                             int numberParticles, unsigned int stepNum, unsigned int seed, void *stream);
 int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_linearVelocity, int numberParticles,
                              float dt, void *stream);
+/* BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113): pos += dt (K pos + MF) + sqrt2Tdt BdW;
+ * d_MF, d_BdW real3[N] (d_BdW nullable), K row-major 3x3 (nullable) */
+int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_MF, const float *d_BdW, const float K[9],
+                              int numberParticles, float sqrt2Tdt, float dt, int is2D, void *stream);
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -271,6 +275,45 @@ int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
 int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream);
 int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor,
                           unsigned int seed2, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Path B, spectral Ewald variant — Positively Split Ewald RPY (BDHI::PSE).  Replaces
+ *   pse_ns::NearField  ctor / Mdot / computeStochasticDisplacements / setShearStrain
+ *                                              Integrator/BDHI/PSE/NearField.cuh:29-99, :239-285
+ *   RPYPSE_near::FandG + TabulatedFunction     Integrator/BDHI/PSE/RPY_PSE.cuh:45-128, misc/TabulatedFunction.cuh:63-157
+ *   pse_ns::FarField   ctor / computeHydrodynamicDisplacements / setShearStrain
+ *                                              Integrator/BDHI/PSE/FarField.cuh:25-41, :85-308, :318-342, :569-654
+ * Seeds: the reference draws `seed` from System::rng() in each constructor (near first, then far) and a fresh `seed2`
+ * from the same generator at every stochastic call; they are explicit here (the C++/Python layers draw them).
+ * The far field is a uammd_fcm handle in PSE mode (same spread / rocFFT / gather machinery, other greens function).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_pse_near uammd_pse_near;
+/* errors with the reference's text "[BDHI::PSE] Cut off is too large, try increasing psi" when rcut > L/2 */
+int uammd_pse_near_create(const float boxSize[3], float viscosity, float hydrodynamicRadius, float tolerance, float psi,
+                          float shearStrain, unsigned int seed, uammd_pse_near **out, float *rcut_out,
+                          int *nPointsTable_out);
+int uammd_pse_near_destroy(uammd_pse_near *h);
+int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain);
+/* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */
+int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int numberParticles, float *d_MF,
+                        void *stream);
+/* d_BdW real3[N] = prefactor sqrt(2 T) M_near^(1/2) dW by Lanczos (OVERWRITES d_BdW, as the reference); no-op at T == 0 */
+int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int numberParticles, float temperature,
+                              float prefactor, unsigned int seed2, float *d_BdW, void *stream, int *iterations);
+/* test hooks: the Saru noise vector, and the raw product d_Mv3 = M_near d_v3 (what the Lanczos callback computes) */
+int uammd_pse_near_noise(uammd_pse_near *h, int numberParticles, float variance, unsigned int seed2, float *d_out3,
+                         void *stream);
+int uammd_pse_near_dot(uammd_pse_near *h, const float *d_pos, const float *d_v3, int numberParticles, float *d_Mv3,
+                       void *stream);
+/* FarField::initializeGrid: grid cells BEFORE nextFFTWiseSize3D (utils/Grid.cuh:142-213, host logic of the caller) */
+int uammd_pse_far_raw_cells(const float boxSize[3], float psi, float tolerance, int cells_out[3]);
+int uammd_pse_far_create(const float boxSize[3], const int cells[3], float viscosity, float hydrodynamicRadius,
+                         float tolerance, float psi, float shearStrain, unsigned int seed, uammd_fcm **out,
+                         int *support_out, float *eta_out);
+int uammd_pse_far_set_shear_strain(uammd_fcm *h, float shearStrain);
+/* d_MF real3[N] += M_far F + prefactor sqrt(2T) M_far^(1/2) dW   (IBM::gather adds; d_force NULL = noise only) */
+int uammd_pse_far_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int numberParticles,
+                                float temperature, float prefactor, unsigned int seed2, float *d_MF, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Lanczos sqrt(M) v.  Replaces lanczos::Solver (misc/LanczosAlgorithm.cuh:32-83,

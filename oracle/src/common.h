@@ -35,6 +35,8 @@ typedef double real;
 #define SQRT(a) sqrt(a)
 #define EXP(a) exp(a)
 #define FABS(a) fabs(a)
+#define ROUND(a) round(a)
+#define SIN(a) sin(a)
 #else
 typedef float real;
 #define FMA(a, b, c) fmaf((a), (b), (c))
@@ -42,6 +44,8 @@ typedef float real;
 #define SQRT(a) sqrtf(a)
 #define EXP(a) expf(a)
 #define FABS(a) fabsf(a)
+#define ROUND(a) roundf(a)
+#define SIN(a) sinf(a)
 #endif
 
 typedef unsigned int uint;

@@ -156,6 +156,29 @@ ORACLE_API void oracle_fcm_euler_maruyama(real4 *pos, const int *indexIterator, 
   }
 }
 
+/* BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113).  K: 9 reals row major or NULL.
+ * Contract: dot(K[r], p) = fma(Kz,pz, fma(Ky,py, Kx*px)); every `p += a*b` is one FMA. */
+ORACLE_API void oracle_bdhi_euler_maruyama(real4 *pos, const int *indexIterator, const real *MF3, const real *BdW3, const real *K,
+                                           int N, real sqrt2Tdt, real dt, int is2D) {
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    real4 p = pos[i];
+    if (K) {
+      const real krx = FMA(K[2], p.z, FMA(K[1], p.y, K[0] * p.x));
+      const real kry = FMA(K[5], p.z, FMA(K[4], p.y, K[3] * p.x));
+      const real krz = is2D ? 0 : FMA(K[8], p.z, FMA(K[7], p.y, K[6] * p.x));
+      p.x = FMA(krx, dt, p.x); p.y = FMA(kry, dt, p.y); p.z = FMA(krz, dt, p.z);
+    }
+    p.x = FMA(MF3[3 * id], dt, p.x); p.y = FMA(MF3[3 * id + 1], dt, p.y); p.z = FMA(MF3[3 * id + 2], dt, p.z);
+    if (BdW3) {
+      p.x = FMA(sqrt2Tdt, BdW3[3 * id], p.x);
+      p.y = FMA(sqrt2Tdt, BdW3[3 * id + 1], p.y);
+      p.z = FMA(sqrt2Tdt, is2D ? 0 : BdW3[3 * id + 2], p.z);
+    }
+    pos[i] = p;
+  }
+}
+
 /* Raw Saru streams for the tests: n draws of u32 from Saru(s1[,s2[,s3]]) */
 ORACLE_API void oracle_saru_u32(int nseeds, uint s1, uint s2, uint s3, int n, uint *out) {
   Saru s = nseeds == 1 ? saru1(s1) : (nseeds == 2 ? saru2(s1, s2) : saru3(s1, s2, s3));

@@ -1,0 +1,202 @@
+"""GPU parity, SURVEY rows a28/a29: BDHI::PSE (uammd_pse_near_*, uammd_pse_far_*) vs the oracle, plus the reference's
+own known-answer tests (test/BDHI/PSE/pse_test.cu) run on the product.
+
+Tolerances: near-field products keep the reference's pair order and the oracle's FMA placement; tables come from the
+same double closed form -> expected bit-identical, asserted <= 1e-6 of max|Mv|.  Far field: 1e-5 relative L2 (FFT
+factorisation, spread order).  Lanczos results: the iteration is stopped at a relative change <= tolerance, so two
+implementations agree to a few times that tolerance.  Saru Gaussians use device log/sin/cos: 1e-6.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RH, VISC = 1.012312, 1.12321
+
+
+def _pair(hip, o32, L, tol, psi, n, seed=1, shear=0.0):
+    from oracle.pse import PSEOracle
+    pd = hip.ParticleData(n, seed=seed)
+    rng = np.random.default_rng(7)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    pd.setPos(pos)
+    par = hip.BDHI.PSE.Parameters(psi=psi, shearStrain=shear, temperature=0.0, viscosity=VISC, hydrodynamicRadius=RH,
+                                  tolerance=tol, dt=1.0, box=hip.Box(L))
+    pse = hip.BDHI.PSE(pd, par)
+    # the same System::rng() stream gives the oracle its seeds
+    r = hip.md.Xorshift128plus() if hasattr(hip, "md") else None
+    from uammd_amd.md import Xorshift128plus
+    r = Xorshift128plus()
+    r.set_seed(seed)
+    ref = PSEOracle(o32, [L] * 3, RH, VISC, tol, psi, shearStrain=shear, seed_near=r.next32(), seed_far=r.next32())
+    return pd, pse, ref, pos, r
+
+
+@pytest.mark.parametrize("psi,tol,shear", [(0.6, 1e-3, 0.0), (1.0, 1e-4, 0.0), (0.8, 1e-3, 0.15)])
+def test_setup_and_near_dot(hip, o32, psi, tol, shear):
+    L, n = 20.0, 3000
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n, shear=shear)
+    assert pse.nPointsTable == ref.nPointsTable and abs(pse.rcut - float(ref.rcut)) == 0.0
+    assert list(pse.cells) == list(ref.cells) and pse.support == ref.support
+    assert abs(pse.eta - float(ref.eta)) <= 1e-6 * float(ref.eta)
+    rng = np.random.default_rng(2)
+    v = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d_v = torch.from_numpy(v).cuda()
+    out = torch.full((n, 3), 7.0, dtype=torch.float32, device="cuda")      # the Dotctor zeroes Mv first
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    check(pse.lib.uammd_pse_near_dot(pse.near, _ptr(pd.getPos()), _ptr(d_v), n, _ptr(out), current_stream()))
+    expect = np.zeros((n, 3), np.float32)
+    cl = ref._near_list(pos)
+    ref._near_dot(cl, v, 3, expect)
+    got = out.cpu().numpy()
+    assert np.abs(got - expect).max() <= 1e-6 * np.abs(expect).max()
+    print("differing words:", np.count_nonzero(got.view(np.uint32) != expect.view(np.uint32)), "of", got.size)
+    # Mdot with real4 forces ACCUMULATES into MF
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = v
+    MF = torch.ones((n, 3), dtype=torch.float32, device="cuda")
+    check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(torch.from_numpy(f4).cuda()), n, _ptr(MF), current_stream()))
+    assert np.abs(MF.cpu().numpy() - (1.0 + expect)).max() <= 2e-6 * max(1.0, np.abs(expect).max())
+
+
+@pytest.mark.parametrize("psi,tol,shear", [(0.6, 1e-3, 0.0), (1.0, 1e-4, 0.0), (0.8, 1e-3, 0.15)])
+def test_far_field_deterministic_and_noise(hip, o32, psi, tol, shear):
+    L, n = 20.0, 2000
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n, shear=shear)
+    rng = np.random.default_rng(4)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    for T, pref, force, seed2 in [(0.0, 0.0, d_f, 0), (0.9, 1.7, d_f, 4242), (0.9, 1.7, None, 77)]:
+        MF = torch.full((n, 3), 0.5, dtype=torch.float32, device="cuda")       # the gather ADDS
+        check(pse.lib.uammd_pse_far_displacements(pse.far, _ptr(pd.getPos()), _ptr(force), n, T, pref, seed2, _ptr(MF),
+                                                  current_stream()))
+        expect = np.full((n, 3), 0.5, np.float32)
+        ref.far(pos, None if force is None else f4, expect, T, pref, seed2)
+        got = MF.cpu().numpy()
+        err = np.linalg.norm(got - expect) / np.linalg.norm(expect - 0.5)
+        assert err <= 1e-5, (T, force is None, err)
+
+
+def test_near_noise_and_lanczos(hip, o32):
+    L, n, tol, psi = 16.0, 1500, 1e-3, 0.7
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    nz = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(pse.lib.uammd_pse_near_noise(pse.near, n, 1.3, 999, _ptr(nz), current_stream()))
+    exp_noise = ref.near_noise(n, 1.3, 999)
+    assert np.abs(nz.cpu().numpy() - exp_noise).max() <= 1e-6 * np.abs(exp_noise).max()
+    import ctypes as C
+    BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    it = C.c_int(0)
+    check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, 0.8, 1.1, 555, _ptr(BdW), current_stream(), C.byref(it)))
+    exp = ref.near_stochastic(pos, 0.8, 1.1, 555)
+    got = BdW.cpu().numpy()
+    assert 1 <= it.value <= 30
+    assert np.linalg.norm(got - exp) <= 5 * tol * np.linalg.norm(exp)
+    # M^(1/2) property: |B dW|^2 / |dW|^2 is a Rayleigh quotient of M_near -> between its extreme eigenvalues (all > 0)
+    assert 0 < np.linalg.norm(got) < np.linalg.norm(ref.near_noise(n, 1.1 * math.sqrt(2 * 0.8), 555))
+
+
+def test_self_mobility_reference_test(hip):
+    """pse_test.cu:64-118 on the product: pulling one particle gives the Hasimoto mobility within the tolerance (float:
+    tolerance 1e-4 and a floor of 2e-6 for single precision), 6 random positions x 3 directions."""
+    tol, L = 1e-4, 32 * RH
+    pd = hip.ParticleData(1, seed=3)
+    par = hip.BDHI.PSE.Parameters(psi=1.0, temperature=0.0, viscosity=VISC, hydrodynamicRadius=RH, tolerance=tol, dt=1.0,
+                                  box=hip.Box(L))
+    pse = hip.BDHI.PSE(pd, par)
+    m0 = pse.getSelfMobility()
+    rng = np.random.default_rng(1234)
+    MF = torch.zeros((1, 3), dtype=torch.float32, device="cuda")
+    for j in range(6):
+        p = np.zeros((1, 4), np.float32)
+        p[0, :3] = rng.uniform(-0.5, 0.5, 3) * L
+        pd.setPos(p)
+        for d in range(3):
+            f = torch.zeros((1, 4), dtype=torch.float32, device="cuda")
+            f[0, d] = 1.0
+            pse.computeHydrodynamicDisplacements(f, MF, 0.0, 0.0)
+            expect = np.zeros(3)
+            expect[d] = m0
+            assert np.abs(MF.cpu().numpy()[0] - expect).max() <= tol
+
+
+def test_self_diffusion_reference_tests(hip):
+    """pse_test.cu:121-205: <dx^2> = 2 T M0 within 1e-2, through computeHydrodynamicDisplacements (T = 1, prefactor 1) and
+    through computeMF + computeBdW (dt = 1)."""
+    L = 32 * RH
+    temperature = 1.12312
+    pd = hip.ParticleData(1, seed=99)
+    par = hip.BDHI.PSE.Parameters(psi=1.0, temperature=temperature, viscosity=VISC, hydrodynamicRadius=RH, tolerance=1e-4,
+                                  dt=1.0, box=hip.Box(L))
+    pse = hip.BDHI.PSE(pd, par)
+    m0 = pse.getSelfMobility()
+    rng = np.random.default_rng(5)
+    ntest = 1000
+    acc1 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    acc2 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    MF = torch.zeros((1, 3), dtype=torch.float32, device="cuda")
+    BdW = torch.zeros((1, 3), dtype=torch.float32, device="cuda")
+    pd.getForce("write").zero_()
+    for j in range(ntest):
+        p = np.zeros((1, 4), np.float32)
+        p[0, :3] = rng.uniform(-0.5, 0.5, 3) * L
+        pd.setPos(p)
+        pse.computeHydrodynamicDisplacements(None, MF, 1.0, 1.0)
+        acc1 += MF[0].double() ** 2
+        pse.computeMF(MF)
+        pse.computeBdW(BdW)
+        acc2 += (MF[0] + BdW[0]).double() ** 2
+    d1 = (acc1 / ntest).cpu().numpy()
+    d2 = (acc2 / ntest).cpu().numpy()
+    assert np.abs(d1 - 2.0 * m0).max() <= 1e-2
+    # computeMF carries the far noise with prefactor 1/sqrt(dt); computeBdW the near noise with prefactor 1: with dt = 1 and the
+    # integrator's sqrt(2 T dt) on BdW only, the reference test sums them as is (pse_test.cu:189-203) and compares with 2 T M0
+    assert np.abs(d2 - 2.0 * temperature * m0).max() <= 1.5e-2
+
+
+def test_euler_maruyama_pse_step_matches_oracle(hip, o32):
+    """BDHI::EulerMaruyama<PSE>::forwardTime at T = 0 with a constant-force interactor and a shear matrix K."""
+    L, n, tol, psi, dt = 18.0, 800, 1e-3, 0.8, 0.05
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+    rng = np.random.default_rng(8)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+
+    class Const:
+        def __init__(self, pd, f):
+            self.pd, self.f = pd, f
+
+        def sum(self, force=True, energy=False, virial=False):
+            self.pd.getForce("readwrite").add_(self.f)
+
+        def updateSimulationTime(self, t): pass
+        def updateTimeStep(self, dt): pass
+        def updateTemperature(self, T): pass
+        def updateBox(self, b): pass
+    K = [[0.0, 0.3, 0.0], [0.0, 0.0, 0.0], [0.1, 0.0, -0.2]]
+    par = hip.BDHI.PSE.Parameters(psi=psi, temperature=0.0, viscosity=VISC, hydrodynamicRadius=RH, tolerance=tol, dt=dt,
+                                  box=hip.Box(L))
+    par.K = K
+    integ = hip.BDHI.EulerMaruyama(pd, par, method=pse)
+    integ.addInteractor(Const(pd, torch.from_numpy(f4).cuda()))
+    integ.forwardTime()
+    got = pd.getPos().cpu().numpy()
+    MF = np.zeros((n, 3), np.float32)
+    ref.far(pos, f4, MF, 0.0, 0.0, 0)
+    ref.near_mdot(pos, f4, MF)
+    import ctypes as C
+    from oracle.oracle import _p
+    p = pos.copy()
+    Kf = np.asarray(K, np.float32).reshape(-1)
+    o32.lib.oracle_bdhi_euler_maruyama(_p(p), None, _p(MF), None, _p(Kf), n, C.c_float(0.0), C.c_float(dt), 0)
+    assert np.abs(got - p).max() <= 1e-5 * np.abs(p - pos).max() + 1e-6

@@ -80,6 +80,7 @@ SIGNATURES = {
     "uammd_verletnvt_initial_velocities": (_i, [_vp, _vp, _f, _i, _i, _u, _vp]),
     "uammd_bd_euler_maruyama": (_i, [_vp, _vp, _vp, C.POINTER(_f), _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
     "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
+    "uammd_bdhi_euler_maruyama": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _f, _f, _i, _vp]),
     "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
     "uammd_fcm_gaussian_kernel": (_i, [_f, _f, C.POINTER(IBMKernel), C.POINTER(_f)]),
     "uammd_fcm_advise_grid_size": (_f, [_f, _f]),
@@ -103,6 +104,17 @@ SIGNATURES = {
     "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_slab_fft_z": (_i, [_vp, _vp, _i, _vp]),
     "uammd_fcm_slab_kspace": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),
+    "uammd_pse_near_create": (_i, [_f3, _f, _f, _f, _f, _f, _u, C.POINTER(_vp), C.POINTER(_f), C.POINTER(_i)]),
+    "uammd_pse_near_destroy": (_i, [_vp]),
+    "uammd_pse_near_set_shear_strain": (_i, [_vp, _f]),
+    "uammd_pse_near_mdot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_pse_near_stochastic": (_i, [_vp, _vp, _i, _f, _f, _u, _vp, _vp, C.POINTER(_i)]),
+    "uammd_pse_near_noise": (_i, [_vp, _i, _f, _u, _vp, _vp]),
+    "uammd_pse_near_dot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_pse_far_raw_cells": (_i, [_f3, _f, _f, _i3]),
+    "uammd_pse_far_create": (_i, [_f3, _i3, _f, _f, _f, _f, _f, _u, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f)]),
+    "uammd_pse_far_set_shear_strain": (_i, [_vp, _f]),
+    "uammd_pse_far_displacements": (_i, [_vp, _vp, _vp, _i, _f, _f, _u, _vp, _vp]),
     "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),

@@ -7,6 +7,7 @@ Citations (relative to /root/reference/src):
   BDHI::FCM (Method concept)             Integrator/BDHI/BDHI_FCM.cuh:84-147
   BDHI::FCMIntegrator                    Integrator/BDHI/BDHI_FCM.cuh:149-198, BDHI_FCM.cu:95-119
   BDHI::EulerMaruyama<Method>            Integrator/BDHI/BDHI_EulerMaruyama.cu:82-166
+  BDHI::PSE (Method)                     Integrator/BDHI/BDHI_PSE.cuh:79-176, PSE/NearField.cuh, PSE/FarField.cuh
   FCM_impl                               Integrator/BDHI/FCM/FCM_impl.cuh:56-129, :652-693
 All compute happens in libuammd_hip.so through the C ABI.
 """
@@ -272,6 +273,148 @@ class FCMIntegrator(Integrator):
                                                 current_stream()))
 
 
+class _PSEParameters(_Parameters):
+    """pse_ns::Parameters (PSE/utils.cuh:17-24)."""
+
+    def __init__(self, psi=0.5, shearStrain=0.0, **kw):
+        super().__init__(**kw)
+        self.psi, self.shearStrain = psi, shearStrain
+
+
+class PSE:
+    """BDHI::PSE — Positively Split Ewald RPY, the Method concept of BDHI::EulerMaruyama (BDHI_PSE.cuh:79-176)."""
+    Parameters = _PSEParameters
+
+    def __init__(self, pd, par):
+        self.lib = _lib.load()
+        self.pd = pd
+        self.hydrodynamicRadius, self.temperature, self.dt = par.hydrodynamicRadius, par.temperature, par.dt
+        L = [float(x) for x in par.box.boxSize]
+        self.M0 = float(self.lib.uammd_fcm_self_mobility(par.hydrodynamicRadius, par.viscosity, L[0]))  # initialization.cu:31-47
+        # pse_ns::checkInputValidity, PSE/initialization.cu:11-29
+        if L[0] == 0 and L[1] == 0 and L[2] == 0:
+            raise ValueError("Box of size zero detected")
+        if par.tolerance > 0.1:
+            raise ValueError("Tolerance too high")
+        # NearField ctor draws its seed first, then FarField (initialization.cu:57-59)
+        seed_near = pd.rng.next32()
+        h, rc, npts = C.c_void_p(), C.c_float(0), C.c_int(0)
+        check(self.lib.uammd_pse_near_create(f3(L), float(par.viscosity), float(par.hydrodynamicRadius), float(par.tolerance),
+                                             float(par.psi), float(par.shearStrain), seed_near, C.byref(h), C.byref(rc),
+                                             C.byref(npts)))
+        self.near, self.rcut, self.nPointsTable = h, float(rc.value), int(npts.value)
+        seed_far = pd.rng.next32()
+        raw = i3(0)
+        check(self.lib.uammd_pse_far_raw_cells(f3(L), float(par.psi), float(par.tolerance), raw))
+        self.cells = nextFFTWiseSize3D(list(raw))
+        hf, sup, eta = C.c_void_p(), C.c_int(0), C.c_float(0)
+        check(self.lib.uammd_pse_far_create(f3(L), i3(self.cells), float(par.viscosity), float(par.hydrodynamicRadius),
+                                            float(par.tolerance), float(par.psi), float(par.shearStrain), seed_far, C.byref(hf),
+                                            C.byref(sup), C.byref(eta)))
+        self.far, self.support, self.eta = hf, int(sup.value), float(eta.value)
+        self.lastLanczosIterations = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "near", None):
+                self.lib.uammd_pse_near_destroy(self.near)
+                self.near = None
+            if getattr(self, "far", None):
+                self.lib.uammd_fcm_destroy(self.far)
+                self.far = None
+        except Exception:
+            pass
+
+    def setup_step(self):
+        pass
+
+    def finish_step(self):
+        pass
+
+    def setShearStrain(self, g):
+        check(self.lib.uammd_pse_near_set_shear_strain(self.near, float(g)))
+        check(self.lib.uammd_pse_far_set_shear_strain(self.far, float(g)))
+
+    def getHydrodynamicRadius(self):
+        return self.hydrodynamicRadius
+
+    def getSelfMobility(self):
+        return self.M0
+
+    def _far(self, force, MF, temperature, prefactor):
+        pd = self.pd
+        seed2 = pd.rng.next32() if temperature > 0 else 0        # FarField.cuh:499: drawn only when T > 0
+        check(self.lib.uammd_pse_far_displacements(self.far, _ptr(pd.getPos("read")), _ptr(force), pd.N, float(temperature),
+                                                   float(prefactor), seed2, _ptr(MF), current_stream()))
+
+    def _near_stochastic(self, BdW, temperature, prefactor):
+        pd = self.pd
+        if temperature == 0:
+            return
+        seed2 = pd.rng.next32()                                   # NearField.cuh:276
+        it = C.c_int(0)
+        check(self.lib.uammd_pse_near_stochastic(self.near, _ptr(pd.getPos("read")), pd.N, float(temperature), float(prefactor),
+                                                 seed2, _ptr(BdW), current_stream(), C.byref(it)))
+        self.lastLanczosIterations = int(it.value)
+
+    def computeMF(self, MF):
+        """MF = M_far F + far noise (prefactor 1/sqrt(dt)) + M_near F   (BDHI_PSE.cuh:92-120)."""
+        pd = self.pd
+        MF.zero_()
+        force = pd.getForce("read")
+        self._far(force, MF, self.temperature, 1.0 / math.sqrt(self.dt))
+        check(self.lib.uammd_pse_near_mdot(self.near, _ptr(pd.getPos("read")), _ptr(force), pd.N, _ptr(MF), current_stream()))
+
+    def computeBdW(self, BdW):
+        self._near_stochastic(BdW, self.temperature, 1.0)       # BDHI_PSE.cuh:122-126
+
+    def computeHydrodynamicDisplacements(self, force, MF, temperature, noise_prefactor):
+        """BDHI_PSE.cuh:135-155, statement for statement: with forces AND T > 0 the Lanczos result overwrites the near
+        deterministic term (reference behaviour, kept)."""
+        pd = self.pd
+        MF.zero_()
+        check(self.lib.uammd_pse_near_mdot(self.near, _ptr(pd.getPos("read")), _ptr(force), pd.N, _ptr(MF), current_stream()))
+        self._near_stochastic(MF, temperature, noise_prefactor)
+        self._far(force, MF, temperature, noise_prefactor)
+
+
+class EulerMaruyama(Integrator):
+    """BDHI::EulerMaruyama<Method> (BDHI_EulerMaruyama.cu:125-166): dR = dt (K R + M F) + sqrt(2 T dt) B dW."""
+
+    def __init__(self, pd, par, method=None, Method=None):
+        super().__init__(pd)
+        self.par = par
+        self.bdhi = method if method is not None else Method(pd, par)
+        self.MF = torch.zeros((pd.N, 3), dtype=torch.float32, device=pd.device)
+        self.BdW = torch.zeros((pd.N + 1, 3), dtype=torch.float32, device=pd.device)
+        K = getattr(par, "K", None)
+        self.K = None if not K else (C.c_float * 9)(*[float(x) for row in K for x in row])
+        self.is2D = bool(getattr(par, "is2D", False))
+
+    def forwardTime(self):
+        pd, par = self.pd, self.par
+        self.steps += 1
+        for it in self.interactors:
+            it.updateSimulationTime(self.steps * par.dt)
+        if self.steps == 1:
+            for it in self.interactors:
+                it.updateTimeStep(par.dt)
+                it.updateTemperature(par.temperature)
+                it.updateBox(par.box)
+        pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+        self.bdhi.setup_step()
+        self.bdhi.computeMF(self.MF)
+        if par.temperature > 0:
+            self.bdhi.computeBdW(self.BdW)
+        sqrt2Tdt = math.sqrt(2 * par.dt * par.temperature)
+        self.bdhi.finish_step()
+        check(self.lib.uammd_bdhi_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(self.MF),
+                                                 _ptr(self.BdW) if par.temperature > 0 else None, self.K, pd.N, sqrt2Tdt,
+                                                 float(par.dt), int(self.is2D), current_stream()))
+
+
 class LanczosSolver:
     """lanczos::Solver (misc/LanczosAlgorithm.cuh:32-83).  `dot(v, Mv)` is a Python callable on torch tensors that
     writes Mv = M v (the MatrixDot concept, LanczosAlgorithm/MatrixDot.h)."""
@@ -330,6 +473,8 @@ class LanczosSolver:
 class BDHI:
     LanczosSolver = LanczosSolver
     FCM = FCM
+    PSE = PSE
+    EulerMaruyama = EulerMaruyama
     FCMIntegrator = FCMIntegrator
     FCM_impl = FCM_impl
     Kernels = Kernels

@@ -37,6 +37,9 @@ namespace uammd_hip {
     }                                                                                        \
   } while (0)
 
+// PSE far field (FarField.cuh:85-119): hydrodynamic radius, Ewald splitting, kernel splitting, shear strain
+struct PseGreens { float rh, split, eta, shear; bool on; };
+
 struct FCM {
   uammd_fcm_parameters par;
   GridT<float> grid;
@@ -49,6 +52,8 @@ struct FCM {
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
   bool forceAtomicSpread = false;  // test hook
+  bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
+  PseGreens pse{0.f, 0.f, 0.f, 0.f, false};  // PSE far field: Hasimoto-split RPY greens function instead of 1/(eta k^2)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   size_t workBytes = 0;
@@ -67,7 +72,7 @@ template <bool SPREAD>
 __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos, const float4 *__restrict__ force,
                                                   float *__restrict__ vout, float *__restrict__ g0, int N,
                                                   GridT<float> grid, int nxpad, size_t plane, size_t zstride,
-                                                  IBMKernelDev kern, FastDiv dsx, FastDiv dsxy) {
+                                                  IBMKernelDev kern, FastDiv dsx, FastDiv dsxy, bool accumulate) {
   const int lane = threadIdx.x & 63;
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= N) return;
@@ -116,7 +121,10 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
       ay += __shfl_xor(ay, o, 64);
       az += __shfl_xor(az, o, 64);
     }
-    if (lane == 0) { vout[3 * (size_t)id] = ax; vout[3 * (size_t)id + 1] = ay; vout[3 * (size_t)id + 2] = az; }
+    if (lane == 0) {
+      float *o = vout + 3 * (size_t)id;  // IBM::gather ADDS (IBM.cu:227-233); the FCM solver starts from zero
+      if (accumulate) { o[0] += ax; o[1] += ay; o[2] += az; } else { o[0] = ax; o[1] = ay; o[2] = az; }
+    }
   }
 }
 
@@ -281,7 +289,7 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
 // nodes), result written at the particle's original index.
 __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vout, const float *__restrict__ g0, int N,
                                                           int3 n, int nxpad, size_t plane, size_t zstride, int3 support,
-                                                          float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr) {
+                                                          float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr, bool accumulate) {
   const int lane = threadIdx.x & 63;
   const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (slot >= N) return;
@@ -315,7 +323,10 @@ __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vou
     ay += __shfl_xor(ay, o2, 64);
     az += __shfl_xor(az, o2, 64);
   }
-  if (lane == 0) { vout[3 * (size_t)o.w] = ax; vout[3 * (size_t)o.w + 1] = ay; vout[3 * (size_t)o.w + 2] = az; }
+  if (lane == 0) {
+    float *out = vout + 3 * (size_t)o.w;
+    if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
+  }
 }
 
 // ---- Fourier space ---------------------------------------------------------------------------------------
@@ -372,9 +383,36 @@ UH_D C3 draw_noise(float prefactor, uint id, uint seed1, uint seed2, bool nyquis
 // g0[kx + nkx*yl + zStride*z + compStride*c].  Single GPU: 3 planar grids (nyl = ny, zStride = nkx*ny, compStride = plane);
 // slab-decomposed: the y-pencil layout [z][c][yl][kx] that the all-to-all transpose delivers.
 struct KLayout { int nyl, y0; size_t compStride, zStride; };
+// PSE far field (FarField.cuh): B = sinc^2(k a) Hasimoto(k, xi, eta) / (eta_visc a^2 k^2 N) with the sheared wave vector,
+// projection with the sheared k (no Nyquist zeroing), noise scaled by sqrt(B) AFTER the projection.
+UH_D real3f pse_shear(real3f k, float shear) { k.y = fmaf(-shear, k.x, k.y); return k; }
+UH_D float pse_greens(real3f k, const PseGreens &p, float viscosity, int3 n) {  // FarField.cuh:85-119
+  const float k2 = dot3(k, k);
+  if (k2 == 0.0f) return 0.0f;
+  const real3f kE = pse_shear(k, p.shear);
+  const float kE2 = dot3(kE, kE), kN2 = k2;
+  const float kmod = sqrtf(kE2);
+  const float invk2 = 1.0f / kE2;
+  const float sink = sinf(kmod * p.rh);
+  const float kEw = kE2 / (4.0f * p.split * p.split);
+  const float kNU = kN2 / (4.0f * p.split * p.split);
+  const float tau = fmaf(p.eta, kNU, -kEw);
+  const float hashimoto = (1.0f + kEw) * expf(tau) / kE2;
+  float B = sink * sink * invk2 * hashimoto / (viscosity * p.rh * p.rh);
+  B /= (float)(n.x * n.y * n.z);
+  return B;
+}
+UH_D C3 pse_project(real3f k, const C3 &f) {  // FarField.cuh:53-73
+  const float invk2 = 1.0f / dot3(k, k);
+  const float kfr = dot3(k, real3f{f.xr, f.yr, f.zr}) * invk2;
+  const float kfi = dot3(k, real3f{f.xi, f.yi, f.zi}) * invk2;
+  return C3{fmaf(-k.x, kfr, f.xr), fmaf(-k.x, kfi, f.xi), fmaf(-k.y, kfr, f.yr), fmaf(-k.y, kfi, f.yi), fmaf(-k.z, kfr, f.zr),
+            fmaf(-k.z, kfi, f.zi)};
+}
+
 __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLayout lay, int3 nk, real3f L,
                                                      float viscosity, bool haveForce, float noisePrefactor,
-                                                     uint seed1, uint seed2) {
+                                                     uint seed1, uint seed2, PseGreens pse) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int nkx = nk.x / 2 + 1;
   const int total = nk.z * lay.nyl * nkx;
@@ -388,6 +426,44 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
   const real3f k = wavevector(ik, L);
   const float k2 = dot3(k, k);
   const real3f dk = gradient_fourier(ik, nk, k);
+  if (pse.on) {
+    if (id != 0) {
+      const float B = pse_greens(k, pse, viscosity, nk);
+      const real3f ks = pse_shear(k, pse.shear);
+      if (haveForce) {  // forceFourier2Vel, FarField.cuh:137-158: project(B * f)
+        const float2 a = g0[a0], b = g1[a0], c = g2[a0];
+        v = pse_project(ks, C3{a.x * B, a.y * B, b.x * B, b.y * B, c.x * B, c.y * B});
+      }
+      if (noisePrefactor != 0.0f) {  // fourierBrownianNoise, FarField.cuh:235-308, in gather form
+        const float Bsq = sqrtf(B);
+        const bool own = !noise_skipped(id, cell, nk);
+        int idp = -1;
+        if (cell.x == 0 || cell.x == nk.x - cell.x) {
+          const int3 pc = make_int3(cell.x, (cell.y > 0) * (nk.y - cell.y), (cell.z > 0) * (nk.z - cell.z));
+          const int cand = pc.x + nkx * (pc.y + pc.z * nk.y);
+          if (cand != id && !noise_skipped(cand, pc, nk) && !is_nyquist(pc, nk)) idp = cand;
+        }
+        C3 mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, theirs = mine;
+        if (own) {
+          const C3 z = pse_project(ks, draw_noise(noisePrefactor, (uint)id, seed1, seed2, is_nyquist(cell, nk)));
+          mine = C3{z.xr * Bsq, z.xi * Bsq, z.yr * Bsq, z.yi * Bsq, z.zr * Bsq, z.zi * Bsq};
+        }
+        if (idp >= 0) {
+          C3 f = draw_noise(noisePrefactor, (uint)idp, seed1, seed2, false);
+          f.xi *= -1.0f; f.yi *= -1.0f; f.zi *= -1.0f;
+          const C3 z = pse_project(ks, f);
+          theirs = C3{z.xr * Bsq, z.xi * Bsq, z.yr * Bsq, z.yi * Bsq, z.zr * Bsq, z.zi * Bsq};
+        }
+        const C3 first = (idp >= 0 && idp < id) ? theirs : mine, second = (idp >= 0 && idp < id) ? mine : theirs;
+        v.xr += first.xr; v.xi += first.xi; v.yr += first.yr; v.yi += first.yi; v.zr += first.zr; v.zi += first.zi;
+        v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
+      }
+    }
+    g0[a0] = make_float2(v.xr, v.xi);
+    g1[a0] = make_float2(v.yr, v.yi);
+    g2[a0] = make_float2(v.zr, v.zi);
+    return;
+  }
   if (haveForce && id != 0) {  // forceFourier2Vel, FCM_impl.cuh:375-397
     const float2 a = g0[a0], b = g1[a0], c = g2[a0];
     const float B = 1.0f / (viscosity * k2);
@@ -671,31 +747,32 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
-                         (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
+                         (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
     }
     UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
   }
   float noisePrefactor = 0.0f;
   if (temperature > 0.0f) {  // addBrownianNoise, FCM_impl.cuh:514-542
-    f->seed2++;
+    if (!f->pse.on) f->seed2++;  // PSE: the caller supplies seed2 (System::rng().next32() per call, FarField.cuh:499)
     const float dV = f->grid.cellVolume;
     const float fourierNormalization =
         (float)(1.0 / ((double)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z));
     noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / dV);
+    if (f->pse.on) noisePrefactor = prefactor * sqrtf(2 * temperature / dV);  // FarField.cuh:503: the 1/N lives in B
   }
   const int total = (int)f->planeCplx;
   const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y};
   hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, lay,
                      f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
-                     d_force != nullptr, noisePrefactor, f->par.seed, f->seed2);
+                     d_force != nullptr, noisePrefactor, f->par.seed, f->seed2, f->pse);
   if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
   UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
   if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
-                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
+                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   else
     hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr,
-                       d_linearVelocity, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
+                       d_linearVelocity, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, f->accumulate);
   UH_CHECK(hipGetLastError());
   return 0;
 }
@@ -796,7 +873,7 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
     const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
     hipLaunchKernelGGL((k_fcm_ibm<true>), dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_posLocal,
                        (const float4 *)d_force, (float *)nullptr, d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx,
-                       dsxy);
+                       dsxy, false);
   }
   UH_CHECK(hipGetLastError());
   return 0;
@@ -820,10 +897,10 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
                (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
                (int *)f->prepTileStart.ptr, f->kern.support.x + f->kern.support.y + f->kern.support.z};
     hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
-                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr);
+                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   } else {
     hipLaunchKernelGGL((k_fcm_ibm<false>), dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_posLocal,
-                       (const float4 *)nullptr, d_vel, (float *)d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy);
+                       (const float4 *)nullptr, d_vel, (float *)d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
   }
   UH_CHECK(hipGetLastError());
   return 0;
@@ -877,9 +954,78 @@ int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, floa
   const KLayout lay{s->nyl, s->y0, (size_t)s->nyl * s->nkx, 3 * (size_t)s->nyl * s->nkx};
   const int total = s->cells.z * s->nyl * s->nkx;
   hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_cplxZ, lay,
-                     s->cells, s->L, s->loc.par.viscosity, haveForce != 0, noisePrefactor, s->loc.par.seed, seed2);
+                     s->cells, s->L, s->loc.par.viscosity, haveForce != 0, noisePrefactor, s->loc.par.seed, seed2, s->loc.pse);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+
+// ---- PSE far field: the same pipeline with the Hasimoto-split RPY greens function -------------------------
+// FarField::initializeGrid (FarField.cuh:646-654): cells before nextFFTWiseSize3D
+int uammd_pse_far_raw_cells(const float boxSize[3], float psi, float tolerance, int cells_out[3]) {
+  if (!boxSize || !cells_out) { set_last_error("uammd_pse_far_raw_cells: null argument"); return -1; }
+  const float kcut = (float)(2 * psi * std::sqrt(-std::log(tolerance)));
+  const double hgrid = 2 * M_PI / kcut;
+  for (int k = 0; k < 3; ++k) cells_out[k] = (int)(2 * boxSize[k] / hgrid) + 1;
+  return 0;
+}
+
+// FarField ctor (FarField.cuh:318-342): kernel from initializeKernel (:605-644) on the given (FFT-friendly) grid
+int uammd_pse_far_create(const float boxSize[3], const int cells[3], float viscosity, float hydrodynamicRadius, float tolerance,
+                         float psi, float shearStrain, unsigned int seed, uammd_fcm **out, int *support_out, float *eta_out) {
+  if (!boxSize || !cells || !out) { set_last_error("uammd_pse_far_create: null argument"); return -1; }
+  // Gaussian window: m standard deviations inside the support, support odd (sec. 4.1 of Lindbo & Tornberg)
+  const double C = 0.976;
+  double m = 1;
+  while (std::erfc(m / std::sqrt(2.0)) > 0.1 * tolerance) m += 0.01;
+  int support;
+  while ((support = int(std::pow(m / C, 2) / M_PI + 0.5) + 1) % 2 == 0) m += tolerance;
+  int P = support / 2;
+  const int minCellDim = std::min(cells[0], std::min(cells[1], cells[2]));
+  if (support > minCellDim) {
+    support = minCellDim;
+    if (support % 2 == 0) support--;
+    P = support / 2;
+    m = C * std::sqrt(M_PI * support);
+  }
+  const double pw = 2 * P + 1;
+  const float cs[3] = {boxSize[0] / (float)cells[0], boxSize[1] / (float)cells[1], boxSize[2] / (float)cells[2]};
+  const double h = std::min(cs[0], std::min(cs[1], cs[2]));
+  const double w = pw * h / 2.0;
+  const float eta = (float)std::pow(2.0 * psi * w / m, 2);
+  const float width = (float)(std::sqrt(eta) / (2.0 * psi));  // pse_ns::Kernel(P, width), FarField.cuh:25-41
+  uammd_fcm_parameters p{};
+  for (int k = 0; k < 3; ++k) { p.boxSize[k] = boxSize[k]; p.cells[k] = cells[k]; }
+  p.viscosity = viscosity;
+  p.seed = seed;
+  p.hydrodynamicRadius = hydrodynamicRadius;
+  p.kernel.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+  p.kernel.support[0] = p.kernel.support[1] = p.kernel.support[2] = 2 * P + 1;
+  p.kernel.prefactor = (float)std::cbrt(1.0 / (width * width * width * std::pow(2.0 * M_PI, 1.5)));
+  p.kernel.tau = (float)(-0.5 / (width * width));
+  p.kernel.rmax = INFINITY;  // this window is not cut (FarField.cuh:37-39)
+  if (int e = uammd_fcm_create(&p, out)) return e;
+  FCM *f = reinterpret_cast<FCM *>(*out);
+  f->pse = PseGreens{hydrodynamicRadius, psi, eta, shearStrain, true};
+  f->accumulate = true;  // ibm.gather adds into MF (FarField.cuh:563-566)
+  if (support_out) *support_out = 2 * P + 1;
+  if (eta_out) *eta_out = eta;
+  return 0;
+}
+
+int uammd_pse_far_set_shear_strain(uammd_fcm *h, float shearStrain) {
+  if (!h) { set_last_error("uammd_pse_far_set_shear_strain: null handle"); return -1; }
+  reinterpret_cast<FCM *>(h)->pse.shear = shearStrain;
+  return 0;
+}
+
+// FarField::computeHydrodynamicDisplacements (FarField.cuh:569-589): d_MF real3[N] += M_far F + noise
+int uammd_pse_far_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
+                                float prefactor, unsigned int seed2, float *d_MF, void *stream) {
+  if (!h) { set_last_error("uammd_pse_far_displacements: null handle"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  if (!f->pse.on) { set_last_error("uammd_pse_far_displacements: not a PSE far-field handle"); return -1; }
+  f->seed2 = seed2;
+  return uammd_fcm_displacements_staged(h, d_pos, d_force, N, temperature, prefactor, d_MF, 0, stream);
 }
 
 double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx) {

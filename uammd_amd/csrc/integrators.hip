@@ -161,6 +161,34 @@ __global__ void __launch_bounds__(kIB) k_fcm_euler_maruyama(float4 *__restrict__
   pos[i] = p;
 }
 
+// BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113): dR = dt (K R + M F) + sqrt(2 T dt) B dW
+struct Shear9 { float k[9]; };
+__global__ void __launch_bounds__(kIB) k_bdhi_euler_maruyama(float4 *__restrict__ pos, const int *__restrict__ index,
+                                                             const float *__restrict__ MF, const float *__restrict__ BdW,
+                                                             Shear9 K, bool haveK, int N, float sqrt2Tdt, float dt, bool is2D) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  float4 p = pos[i];
+  if (haveK) {
+    const float krx = fmaf(K.k[2], p.z, fmaf(K.k[1], p.y, K.k[0] * p.x));
+    const float kry = fmaf(K.k[5], p.z, fmaf(K.k[4], p.y, K.k[3] * p.x));
+    const float krz = is2D ? 0.0f : fmaf(K.k[8], p.z, fmaf(K.k[7], p.y, K.k[6] * p.x));
+    p.x = fmaf(krx, dt, p.x);
+    p.y = fmaf(kry, dt, p.y);
+    p.z = fmaf(krz, dt, p.z);
+  }
+  p.x = fmaf(MF[3 * id], dt, p.x);
+  p.y = fmaf(MF[3 * id + 1], dt, p.y);
+  p.z = fmaf(MF[3 * id + 2], dt, p.z);
+  if (BdW) {
+    p.x = fmaf(sqrt2Tdt, BdW[3 * id], p.x);
+    p.y = fmaf(sqrt2Tdt, BdW[3 * id + 1], p.y);
+    p.z = fmaf(sqrt2Tdt, is2D ? 0.0f : BdW[3 * id + 2], p.z);
+  }
+  pos[i] = p;
+}
+
 static inline int nb(int n) { return (n + kIB - 1) / kIB; }
 
 }  // namespace uammd_hip
@@ -231,6 +259,18 @@ int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_li
   if (N <= 0) return 0;
   hipLaunchKernelGGL(k_fcm_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index,
                      d_linearVelocity, N, dt);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_MF, const float *d_BdW, const float K[9],
+                              int N, float sqrt2Tdt, float dt, int is2D, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_MF) { set_last_error("uammd_bdhi_euler_maruyama: null argument"); return -1; }
+  Shear9 k{};
+  if (K) for (int t = 0; t < 9; ++t) k.k[t] = K[t];
+  hipLaunchKernelGGL(k_bdhi_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index, d_MF,
+                     d_BdW, k, K != nullptr, N, sqrt2Tdt, dt, is2D != 0);
   UH_CHECK(hipGetLastError());
   return 0;
 }

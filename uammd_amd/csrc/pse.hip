@@ -1,0 +1,349 @@
+// Path B, spectral Ewald variant — PSE near field for gfx950.
+//
+// Reference behaviour:
+//   RPYPSE_near::FandG                                   Integrator/BDHI/PSE/RPY_PSE.cuh:45-128 (host, double, closed form)
+//   TabulatedFunction<real2> (linear interpolation)     misc/TabulatedFunction.cuh:63-157
+//   NearField::initializeDeterministicPart               Integrator/BDHI/PSE/NearField.cuh:65-99
+//   RPYNearTransverser::compute/set over a CellList      NearField.cuh:120-196, NeighbourList/common.cuh:10-34
+//   NearField::Mdot / computeStochasticDisplacements     NearField.cuh:239-285  (Saru noise -> lanczos::Solver)
+// M_near v is a sparse matrix-vector product: (M v)_i = sum_j F(r) v_j + (G(r) - F(r)) (r.v_j) r / r^2 over the 27 cells,
+// F and G read from a table of 2^14..2^22 real2 points.  The reference gathers v_j through the group index for every
+// neighbour (getInfo); here v is gathered ONCE into cell order (same values, contiguous with the positions).
+#include "celllist.hpp"
+#include "saru.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace uammd_hip {
+
+struct PSENear {
+  CellList cl;
+  uammd_lanczos *lanczos = nullptr;
+  DeviceBuffer table, sortV, noise;
+  int nPointsTable = 0;
+  float rcut = 0.f, shear = 0.f, tolerance = 0.f;
+  float boxL[3] = {0, 0, 0};
+  unsigned int seed = 0;
+  int N = 0;
+  hipStream_t cbStream = 0;
+  ~PSENear() {
+    if (lanczos) uammd_lanczos_destroy(lanczos);
+  }
+};
+
+// the closed form of eq. A3-A4 of Fiore et al. 2017 as the reference evaluates it (coefficient sets f0..f7, g0..g7)
+static void rpy_near_FandG(double r, double rh, double psi, double rcut, double *F, double *G) {
+  *F = *G = 0.0;
+  if (r >= rcut) return;
+  const double spi = std::sqrt(M_PI);
+  if (r <= 0.0) {
+    *F = (1.0 / (4 * spi * psi * rh)) * (1 - std::exp(-4 * rh * rh * psi * psi) + 4 * spi * rh * psi * std::erfc(2 * rh * psi));
+    return;
+  }
+  const double r2 = r * r, r3 = r2 * r, r4 = r3 * r;
+  const double a2mr = 2 * rh - r, a2pr = 2 * rh + r;
+  const double rh2 = rh * rh, rh4 = rh2 * rh2;
+  const double psi2 = psi * psi, psi3 = psi2 * psi, psi4 = psi2 * psi2;
+  double f[8], g[8];
+  if (r > 2 * rh) {
+    f[0] = (64.0 * rh4 * psi4 + 96.0 * rh2 * r2 * psi4 - 128.0 * rh * r3 * psi4 + 36.0 * r4 * psi4 - 3.0) / (128.0 * rh * r3 * psi4);
+    f[4] = (3.0 - 4.0 * psi4 * a2mr * a2mr * (4.0 * rh2 + 4.0 * rh * r + 9.0 * r2)) / (256.0 * rh * r3 * psi4);
+    f[5] = 0;
+    g[0] = (-64.0 * rh4 * psi4 + 96.0 * rh2 * r2 * psi4 - 64.0 * rh * r3 * psi4 + 12.0 * r4 * psi4 + 3.0) / (64.0 * rh * r3 * psi4);
+    g[4] = (4.0 * psi4 * a2mr * a2mr * a2mr * (2.0 * rh + 3.0 * r) - 3.0) / (128.0 * rh * r3 * psi4);
+    g[5] = 0;
+  } else {
+    f[0] = (-16.0 * rh4 - 24.0 * rh2 * r2 + 32.0 * rh * r3 - 9.0 * r4) / (32.0 * rh * r3);
+    f[4] = 0;
+    f[5] = (4.0 * psi4 * a2mr * a2mr * (4.0 * rh2 + 4.0 * rh * r + 9.0 * r2) - 3.0) / (256.0 * rh * r3 * psi4);
+    g[0] = a2mr * a2mr * a2mr * (2.0 * rh + 3.0 * r) / (16.0 * rh * r3);
+    g[4] = 0;
+    g[5] = (3.0 - 4.0 * psi4 * a2mr * a2mr * a2mr * (2.0 * rh + 3.0 * r)) / (128.0 * rh * r3 * psi4);
+  }
+  f[1] = (-2.0 * psi2 * a2pr * (4.0 * rh2 - 4.0 * rh * r + 9.0 * r2) + 2.0 * rh - 3.0 * r) / (128.0 * rh * r3 * psi3 * spi);
+  f[2] = (2.0 * psi2 * a2mr * (4.0 * rh2 + 4.0 * rh * r + 9.0 * r2) - 2.0 * rh - 3.0 * r) / (128.0 * rh * r3 * psi3 * spi);
+  f[3] = 3.0 * (6.0 * r2 * psi2 + 1.0) / (64.0 * spi * rh * r2 * psi3);
+  f[6] = (4.0 * psi4 * a2pr * a2pr * (4.0 * rh2 - 4.0 * rh * r + 9.0 * r2) - 3.0) / (256.0 * rh * r3 * psi4);
+  f[7] = 3.0 * (1.0 - 12.0 * r4 * psi4) / (128.0 * rh * r3 * psi4);
+  g[1] = (2.0 * psi2 * a2pr * a2pr * (2.0 * rh - 3.0 * r) - 2.0 * rh + 3.0 * r) / (64.0 * spi * rh * r3 * psi3);
+  g[2] = (-2.0 * psi2 * a2mr * a2mr * (2.0 * rh + 3.0 * r) + 2.0 * rh + 3.0 * r) / (64.0 * spi * rh * r3 * psi3);
+  g[3] = (3.0 * (2.0 * r2 * psi2 - 1.0)) / (32.0 * spi * rh * r2 * psi3);
+  g[6] = (3.0 - 4.0 * psi4 * (2.0 * rh - 3.0 * r) * a2pr * a2pr * a2pr) / (128.0 * rh * r3 * psi4);
+  g[7] = -3.0 * (4.0 * r4 * psi4 + 1.0) / (64.0 * rh * r3 * psi4);
+  const double e[8] = {1.0,
+                       std::exp(-psi2 * a2pr * a2pr),
+                       std::exp(-a2mr * a2mr * psi2),
+                       std::exp(-psi2 * r2),
+                       std::erfc(a2mr * psi),
+                       std::erfc(-a2mr * psi),
+                       std::erfc(a2pr * psi),
+                       std::erfc(r * psi)};
+  // the reference sums the eight terms left to right (RPY_PSE.cuh:124-127)
+  double sf = f[0], sg = g[0];
+  for (int t = 1; t < 8; ++t) { sf += f[t] * e[t]; sg += g[t] * e[t]; }
+  *F = sf;
+  *G = sg;
+}
+
+struct TableView {
+  const float2 *table;
+  int Ntable;
+  float rmax, interval, dr;
+};
+
+// TabulatedFunction::operator() with LinearInterpolation and lerp (TabulatedFunction.cuh:36-45, :63-75, :148-157), rmin = 0
+UH_D float2 table_get(const TableView &t, float rs) {
+  const float r = rs * t.interval;
+  if (rs >= t.rmax) return make_float2(0.f, 0.f);
+  if (r <= 0.0f) return t.table[0];
+  const int i = (int)(r * (float)t.Ntable);
+  const float r0 = (float)i * t.dr;
+  const float2 v0 = t.table[i], v1 = t.table[i + 1];
+  const float w = (r - r0) * (float)t.Ntable;
+  return make_float2(fmaf(w, v1.x, fmaf(-w, v0.x, v0.x)), fmaf(w, v1.y, fmaf(-w, v0.y, v0.y)));
+}
+
+// RPYNearTransverser::computeShearedDistancePBC (NearField.cuh:134-152)
+UH_D real3f sheared_distance(const float4 &pi, const float4 &pj, real3f L, float shear) {
+  real3f rij{pj.x - pi.x, pj.y - pi.y, pj.z - pi.z};
+  rij.x = fmaf(shear, rij.y, rij.x);
+  const float s1 = roundf(rij.y / L.y);
+  rij.x = fmaf(-(shear * L.y), s1, rij.x);
+  rij.y = fmaf(-L.y, s1, rij.y);
+  rij.z = fmaf(-L.z, roundf(rij.z / L.z), rij.z);
+  rij.x = fmaf(-L.x, roundf(rij.x / L.x), rij.x);
+  return rij;
+}
+
+template <int VSTRIDE>
+__global__ void __launch_bounds__(256) k_pse_gather_v(const float *__restrict__ v, const int *__restrict__ groupIndex,
+                                                       float4 *__restrict__ sortV, int N) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  const float *p = v + (size_t)VSTRIDE * groupIndex[id];
+  sortV[id] = make_float4(p[0], p[1], p[2], 0.f);
+}
+
+// thread per sorted particle, 27-cell walk in the reference's order; Mv[ori] += total
+__global__ void __launch_bounds__(128) k_pse_near(const float4 *__restrict__ sortPos, const float4 *__restrict__ sortV,
+                                                   const int *__restrict__ groupIndex, const uint *__restrict__ cellStart,
+                                                   const int *__restrict__ cellEnd, uint validCell, int N, GridT<float> grid,
+                                                   real3f L, float shear, float rcut2, TableView tab, float *__restrict__ Mv) {
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  if (id >= N) return;
+  const float4 pi = sortPos[id];
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += cc % 3 - 1;
+    if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+    if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    if (cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z) continue;
+    const int icellj = grid.getCellIndex(cellj);
+    const uint cs = cellStart[icellj];
+    if (cs < validCell) continue;
+    const int first = (int)(cs - validCell), last = cellEnd[icellj];
+    for (int j = first; j < last; ++j) {
+      const real3f rij = sheared_distance(pi, sortPos[j], L, shear);
+      const float r2 = dot3(rij, rij);
+      if (r2 >= rcut2) continue;
+      const float4 vj = sortV[j];
+      const float2 fg = table_get(tab, sqrtf(r2));
+      const float f = fg.x, g = fg.y;
+      float rx, ry, rz;
+      if (r2 == 0.0f) {
+        rx = f * vj.x; ry = f * vj.y; rz = f * vj.z;
+      } else {
+        const float invr2 = 1.0f / r2;
+        const float gmfv = (g - f) * dot3(rij, real3f{vj.x, vj.y, vj.z}) * invr2;
+        rx = fmaf(gmfv, rij.x, f * vj.x);
+        ry = fmaf(gmfv, rij.y, f * vj.y);
+        rz = fmaf(gmfv, rij.z, f * vj.z);
+      }
+      tx += rx; ty += ry; tz += rz;
+    }
+  }
+  float *o = Mv + 3 * (size_t)groupIndex[id];
+  o[0] += tx; o[1] += ty; o[2] += tz;
+}
+
+// SaruTransform (NearField.cuh:218-228): make_real3(gf(0,1), gf(0,1).x) * variance
+__global__ void __launch_bounds__(256) k_pse_noise(float *__restrict__ out3, int N, float variance, uint seed1, uint seed2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  Saru rng((uint)i, seed1, seed2);
+  const float2 a = rng.gf(0.0f, 1.0f);
+  const float2 b = rng.gf(0.0f, 1.0f);
+  out3[3 * (size_t)i] = a.x * variance;
+  out3[3 * (size_t)i + 1] = a.y * variance;
+  out3[3 * (size_t)i + 2] = b.x * variance;
+}
+
+static TableView make_view(const PSENear *p) {
+  TableView t;
+  t.table = (const float2 *)p->table.ptr;
+  t.Ntable = p->nPointsTable - 1;
+  t.rmax = p->rcut;
+  t.interval = (float)(1.0 / (p->rcut - 0.0f));
+  t.dr = (float)(1.0 / (float)t.Ntable);
+  return t;
+}
+
+// cl->update(box, rcut * safetyFactor) (NearField.cuh:231-237)
+static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st) {
+  const float g = p->shear;
+  const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
+  const float rc = p->rcut * safety;
+  const float rc3[3] = {rc, rc, rc};
+  const int per[3] = {1, 1, 1};
+  int cd[3], gper[3];
+  float gL[3];
+  if (int e = uammd_celllist_create_grid(p->boxL, per, rc3, cd, gL, gper)) return e;
+  p->N = N;
+  return p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st);
+}
+
+template <int VSTRIDE>
+static int pse_dot(PSENear *p, const float *d_v, float *d_Mv, hipStream_t st) {
+  const int N = p->N;
+  if (int e = p->sortV.reserve(sizeof(float4) * (size_t)N)) return e;
+  hipLaunchKernelGGL((k_pse_gather_v<VSTRIDE>), dim3((N + 255) / 256), dim3(256), 0, st, d_v, (const int *)p->cl.index.ptr,
+                     (float4 *)p->sortV.ptr, N);
+  hipLaunchKernelGGL(k_pse_near, dim3((N + 127) / 128), dim3(128), 0, st, (const float4 *)p->cl.sortPos.ptr,
+                     (const float4 *)p->sortV.ptr, (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr,
+                     (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, real3f{p->boxL[0], p->boxL[1], p->boxL[2]},
+                     p->shear, p->rcut * p->rcut, make_view(p), d_Mv);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// pse_ns::Dotctor (NearField.cuh:201-216): Mv = 0; cl->transverseList(Mv_tr)
+static int pse_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) {
+  PSENear *p = static_cast<PSENear *>(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(d_Mv, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return -1;
+  return pse_dot<3>(p, d_v, d_Mv, st);
+}
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+int uammd_pse_near_create(const float boxSize[3], float viscosity, float hydrodynamicRadius, float tolerance, float psi,
+                          float shearStrain, unsigned int seed, uammd_pse_near **out, float *rcut_out, int *nPointsTable_out) {
+  if (!boxSize || !out) { set_last_error("uammd_pse_near_create: null argument"); return -1; }
+  // NearField::initializeDeterministicPart, NearField.cuh:65-99
+  const double split = psi;
+  const float rcut = (float)(std::sqrt(-std::log(tolerance)) / split);
+  if (0.5 * boxSize[0] < rcut) {
+    set_last_error("[BDHI::PSE] Cut off is too large, try increasing psi");
+    return -2;
+  }
+  const double a = hydrodynamicRadius;
+  const float textureTolerance = (float)(a * tolerance);
+  double np = rcut / textureTolerance + 0.5;
+  if (np > 2e30) np = 2e30;
+  unsigned nPointsTable = np >= 4294967295.0 ? 4294967295u : (unsigned)np;
+  nPointsTable = std::min(1u << 22, std::max(1u << 14, nPointsTable));
+  PSENear *p = new PSENear();
+  for (int k = 0; k < 3; ++k) p->boxL[k] = boxSize[k];
+  p->rcut = rcut;
+  p->shear = shearStrain;
+  p->tolerance = tolerance;
+  p->seed = seed;
+  p->nPointsTable = (int)nPointsTable;
+  // TabulatedFunction<real2>(table, nPointsTable, 0, rcut, rpy): Ntable = nPointsTable - 1 intervals, Ntable + 1 samples
+  const int Ntable = (int)nPointsTable - 1;
+  const float normalization = (float)(6 * M_PI * a * viscosity);
+  std::vector<float2> host((size_t)Ntable + 1);
+  for (int i = 0; i <= Ntable; ++i) {
+    const double x = (i / (double)Ntable) * (rcut - 0.0f) + 0.0f;
+    double F, G;
+    rpy_near_FandG(x, (double)hydrodynamicRadius, (double)psi, (double)rcut, &F, &G);
+    host[i] = make_float2((float)(F / (double)normalization), (float)(G / (double)normalization));
+  }
+  if (p->table.reserve(sizeof(float2) * host.size()) ||
+      hipMemcpy(p->table.ptr, host.data(), sizeof(float2) * host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    delete p;
+    set_last_error("uammd_pse_near_create: could not upload the RPY table");
+    return -3;
+  }
+  if (int e = uammd_lanczos_create(&p->lanczos)) { delete p; return e; }
+  *out = reinterpret_cast<uammd_pse_near *>(p);
+  if (rcut_out) *rcut_out = rcut;
+  if (nPointsTable_out) *nPointsTable_out = (int)nPointsTable;
+  return 0;
+}
+
+int uammd_pse_near_destroy(uammd_pse_near *h) {
+  delete reinterpret_cast<PSENear *>(h);
+  return 0;
+}
+
+int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain) {
+  if (!h) { set_last_error("uammd_pse_near_set_shear_strain: null handle"); return -1; }
+  reinterpret_cast<PSENear *>(h)->shear = shearStrain;
+  return 0;
+}
+
+// NearField::Mdot (NearField.cuh:239-250): d_MF real3[N] += M_near F, forces real4[N] (NULL: nothing to do)
+int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int N, float *d_MF, void *stream) {
+  if (!h || (N > 0 && (!d_pos || !d_MF))) { set_last_error("uammd_pse_near_mdot: null argument"); return -1; }
+  if (!d_force || N <= 0) return 0;
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  if (int e = pse_update_list(p, d_pos, N, (hipStream_t)stream)) return e;
+  return pse_dot<4>(p, d_force, d_MF, (hipStream_t)stream);
+}
+
+// NearField::computeStochasticDisplacements (NearField.cuh:252-285): d_BdW real3[N] = prefactor sqrt(2 T) M_near^(1/2) dW
+// (the Lanczos result OVERWRITES d_BdW).  seed2 = the per-call draw of System::rng().  Nothing happens when T == 0.
+int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, float temperature, float prefactor,
+                              unsigned int seed2, float *d_BdW, void *stream, int *iterations) {
+  if (!h || (N > 0 && (!d_pos || !d_BdW))) { set_last_error("uammd_pse_near_stochastic: null argument"); return -1; }
+  if (iterations) *iterations = 0;
+  if (temperature == 0.0f || N <= 0) return 0;
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = pse_update_list(p, d_pos, N, st)) return e;
+  if (int e = p->noise.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+  const float noise_prefactor = prefactor * sqrtf(2 * temperature);
+  hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
+                     seed2);
+  UH_CHECK(hipGetLastError());
+  int it = 0;
+  const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot, p, d_BdW, (const float *)p->noise.ptr, p->tolerance, 3 * N,
+                                   stream, &it);
+  if (iterations) *iterations = it;
+  return rc;
+}
+
+// test hook: the Saru noise vector of computeStochasticDisplacements (real3[N])
+int uammd_pse_near_noise(uammd_pse_near *h, int N, float variance, unsigned int seed2, float *d_out3, void *stream) {
+  if (!h || !d_out3) { set_last_error("uammd_pse_near_noise: null argument"); return -1; }
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_out3, N, variance, p->seed, seed2);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// test hook: raw M_near v for a real3 vector (what the Lanczos callback computes), d_Mv overwritten
+int uammd_pse_near_dot(uammd_pse_near *h, const float *d_pos, const float *d_v3, int N, float *d_Mv3, void *stream) {
+  if (!h || !d_pos || !d_v3 || !d_Mv3) { set_last_error("uammd_pse_near_dot: null argument"); return -1; }
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  if (int e = pse_update_list(p, d_pos, N, (hipStream_t)stream)) return e;
+  return pse_lanczos_dot(p, d_v3, d_Mv3, 3 * N, stream);
+}
+
+}  // extern "C"
