@@ -1,0 +1,45 @@
+// test/BDHI/PSE/pse_test.cu "SelfMobilityIsCorrectUpToTolerance" against the C++ interface: pull one particle with BDHI::PSE
+// and compare with the Hasimoto-corrected mobility; then one BDHI::EulerMaruyama<BDHI::PSE> step at T > 0.
+#include "uammd.cuh"
+#include "Integrator/BDHI/BDHI_EulerMaruyama.cuh"
+#include "Integrator/BDHI/BDHI_PSE.cuh"
+#include <cstdio>
+using namespace uammd;
+
+int main(int argc, char *argv[]) {
+  auto sys = std::make_shared<System>(argc, argv);
+  sys->rng().setSeed(1234);
+  const real rh = 1.012312;
+  BDHI::PSE::Parameters par;
+  par.viscosity = 1.12321;
+  par.tolerance = 1e-4;
+  par.dt = 1;
+  par.box = Box(make_real3(32 * rh));
+  par.hydrodynamicRadius = rh;
+  par.psi = 1.0;
+  par.temperature = 0;
+  auto pd = std::make_shared<ParticleData>(1, sys);
+  { auto pos = pd->getPos(access::cpu, access::write); pos[0] = make_real4(3.1, -7.2, 11.3, 0); }
+  auto pse = std::make_shared<BDHI::PSE>(pd, par);
+  detail::DeviceArray<real4> force(1);
+  detail::DeviceArray<real3> MF(1);
+  const real4 fx = make_real4(0, 1, 0, 0);
+  (void)hipMemcpy(force.d, &fx, sizeof(fx), hipMemcpyHostToDevice);
+  pse->computeHydrodynamicDisplacements(force.d, MF.d, 0, 0);
+  real3 v;
+  (void)hipMemcpy(&v, MF.d, sizeof(v), hipMemcpyDeviceToHost);
+  const double m0 = pse->getSelfMobility();
+  std::printf("PSE self mobility %.7f expected %.7f (off-diagonal %.2e %.2e)\n", v.y, m0, v.x, v.z);
+  const bool ok1 = std::abs(v.y - m0) < par.tolerance && std::abs(v.x) < par.tolerance && std::abs(v.z) < par.tolerance;
+  // a thermal step: the particle must move, finitely
+  par.temperature = 1.0;
+  par.dt = 0.01;
+  auto bd = std::make_shared<BDHI::EulerMaruyama<BDHI::PSE>>(pd, par);
+  bd->forwardTime();
+  real4 p;
+  { auto pos = pd->getPos(access::cpu, access::read); p = pos[0]; }
+  const double d2 = (p.x - 3.1) * (p.x - 3.1) + (p.y + 7.2) * (p.y + 7.2) + (p.z - 11.3) * (p.z - 11.3);
+  std::printf("thermal displacement^2 %.3e (6 D dt = %.3e)\n", d2, 6 * m0 * par.dt);
+  sys->finish();
+  return (ok1 && std::isfinite(d2) && d2 > 0 && d2 < 100 * 6 * m0 * par.dt) ? 0 : 1;
+}

@@ -14,6 +14,7 @@
 //   BD::EulerMaruyama             Integrator/BrownianDynamics.cuh
 //   BDHI::FCM, BDHI::FCMIntegrator, BDHI::EulerMaruyama<Method>   Integrator/BDHI/BDHI_FCM.cuh:84-198, BDHI_EulerMaruyama.cuh
 //   IBM                           misc/IBM.cuh:99-203   (windows UAMMD ships; see uammd_hip.h)
+//   BDHI::PSE, BDHI::EulerMaruyama<Method>   Integrator/BDHI/BDHI_PSE.cuh:79-176, BDHI_EulerMaruyama.cu:125-166
 //   lanczos::Solver, MatrixDot    misc/LanczosAlgorithm.cuh:32-83, LanczosAlgorithm/MatrixDot.h:7-25
 //
 // This header is plain host C++14: compile with any C++ compiler,
@@ -78,6 +79,14 @@ inline void check(int rc) {
 }
 inline void hipCheck(hipError_t e, const char *what) {
   if (e != hipSuccess) throw cuda_generic_error(std::string(what) + ": " + hipGetErrorString(e), (int)e);
+}
+inline int nextFFTWiseSize(int v) {  // utils/Grid.cuh:142-213, one dimension
+  for (;; ++v) {
+    int m = v;
+    if (m % 2) continue;
+    for (int p : {2, 3, 5, 7, 11}) while (m % p == 0) m /= p;
+    if (m == 1) return v;
+  }
 }
 template <class T> struct DeviceArray {  // owning device buffer (thrust::device_vector stand-in for host code)
   T *d = nullptr;
@@ -772,6 +781,121 @@ public:
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
     detail::check(uammd_fcm_euler_maruyama((float *)pos.raw(), nullptr, (const float *)linearV.d, N, dt, (void *)st));
+  }
+};
+}  // namespace BDHI
+
+// ---- BDHI::PSE (Integrator/BDHI/BDHI_PSE.cuh:79-176) and BDHI::EulerMaruyama<Method> (BDHI_EulerMaruyama.cu:125-166) --------------
+namespace BDHI {
+namespace pse_ns {
+struct Parameters : BDHI::Parameters {  // PSE/utils.cuh:17-24
+  real psi = 0.5;
+  real shearStrain = 0;
+};
+}  // namespace pse_ns
+class PSE {
+  shared_ptr<ParticleData> pd;
+  uammd_pse_near *nearField = nullptr;
+  uammd_fcm *farField = nullptr;
+  real hydrodynamicRadius, M0, temperature, dt;
+  void far(const real4 *force, real3 *MF, real T, real prefactor, hipStream_t st) {
+    const uint seed2 = T > 0 ? pd->getSystem()->rng().next32() : 0u;  // FarField.cuh:499
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_far_displacements(farField, (const float *)pos.raw(), (const float *)force, pd->getNumParticles(), T,
+                                              prefactor, seed2, (float *)MF, (void *)st));
+  }
+  void nearStochastic(real3 *BdW, real T, real prefactor, hipStream_t st) {
+    if (T == real(0.0)) return;
+    const uint seed2 = pd->getSystem()->rng().next32();  // NearField.cuh:276
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_near_stochastic(nearField, (const float *)pos.raw(), pd->getNumParticles(), T, prefactor, seed2,
+                                            (float *)BdW, (void *)st, nullptr));
+  }
+public:
+  using Parameters = pse_ns::Parameters;
+  PSE(shared_ptr<ParticleData> pd, Parameters par)
+      : pd(pd), hydrodynamicRadius(par.hydrodynamicRadius), temperature(par.temperature), dt(par.dt) {
+    M0 = (real)uammd_fcm_self_mobility(par.hydrodynamicRadius, par.viscosity, par.box.boxSize.x);
+    const real3 L3 = par.box.boxSize;
+    if (L3.x == real(0.0) && L3.y == real(0.0) && L3.z == real(0.0)) throw std::invalid_argument("Box of size zero detected");
+    if (par.tolerance > 0.1) throw std::invalid_argument("Tolerance too high");  // PSE/initialization.cu:11-29
+    const float L[3] = {L3.x, L3.y, L3.z};
+    auto &rng = pd->getSystem()->rng();
+    const uint seedNear = rng.next32();  // NearField ctor first, then FarField (initialization.cu:57-59)
+    detail::check(uammd_pse_near_create(L, par.viscosity, par.hydrodynamicRadius, par.tolerance, par.psi, par.shearStrain, seedNear,
+                                        &nearField, nullptr, nullptr));
+    const uint seedFar = rng.next32();
+    int c[3];
+    detail::check(uammd_pse_far_raw_cells(L, par.psi, par.tolerance, c));
+    for (int &v : c) v = detail::nextFFTWiseSize(v);
+    detail::check(uammd_pse_far_create(L, c, par.viscosity, par.hydrodynamicRadius, par.tolerance, par.psi, par.shearStrain, seedFar,
+                                       &farField, nullptr, nullptr));
+  }
+  PSE(const PSE &) = delete;
+  ~PSE() { uammd_pse_near_destroy(nearField); uammd_fcm_destroy(farField); }
+  void setup_step(hipStream_t = 0) {}
+  void finish_step(hipStream_t = 0) {}
+  void computeMF(real3 *MF, hipStream_t st = 0) {  // :92-120
+    const int N = pd->getNumParticles();
+    detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
+    auto force = pd->getForce(access::gpu, access::read);
+    far(force.raw(), MF, temperature, real(1.0 / std::sqrt(dt)), st);
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
+  }
+  void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
+  void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
+    const int N = pd->getNumParticles();
+    detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
+    {
+      auto pos = pd->getPos(access::gpu, access::read);
+      detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force, N, (float *)MF, (void *)st));
+    }
+    nearStochastic(MF, T, noise_prefactor, st);
+    far(force, MF, T, noise_prefactor, st);
+  }
+  void setShearStrain(real g) {
+    detail::check(uammd_pse_near_set_shear_strain(nearField, g));
+    detail::check(uammd_pse_far_set_shear_strain(farField, g));
+  }
+  real getHydrodynamicRadius() { return hydrodynamicRadius; }
+  real getSelfMobility() { return M0; }
+};
+
+template <class Method> class EulerMaruyama : public Integrator {
+  using Parameters_t = typename Method::Parameters;
+  Parameters_t par;
+  shared_ptr<Method> bdhi;
+  detail::DeviceArray<real3> MF, BdW;
+  int steps = 0;
+  hipStream_t stream = 0;
+public:
+  using Parameters = Parameters_t;
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(pd, par)), MF(pd->getNumParticles()),
+        BdW(pd->getNumParticles() + 1) {}
+  shared_ptr<Method> getMethod() { return bdhi; }
+  void forwardTime() override {
+    steps++;
+    for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
+    if (steps == 1)
+      for (auto &u : updatables) { u->updateTimeStep(par.dt); u->updateTemperature(par.temperature); u->updateBox(par.box); u->updateViscosity(par.viscosity); }
+    {
+      auto force = pd->getForce(access::gpu, access::write);
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
+    }
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
+    bdhi->setup_step(stream);
+    bdhi->computeMF(MF.d, stream);
+    if (par.temperature > 0) bdhi->computeBdW(BdW.d, stream);
+    const real sqrt2Tdt = std::sqrt(2 * par.dt * par.temperature);
+    bdhi->finish_step(stream);
+    float K[9] = {0};
+    const bool shear = par.K.size() == 3;
+    if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    detail::check(uammd_bdhi_euler_maruyama((float *)pos.raw(), nullptr, (const float *)MF.d, par.temperature > 0 ? (const float *)BdW.d : nullptr,
+                                            shear ? K : nullptr, pd->getNumParticles(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
   }
 };
 }  // namespace BDHI

@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility"]
+PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility"]
 
 
 def _make():
@@ -26,7 +26,8 @@ def test_reference_include_paths_exist():
     inc = os.path.join(ROOT, "include", "uammd")
     for h in ["uammd.cuh", "Interactor/PairForces.cuh", "Interactor/NeighbourList/CellList.cuh",
               "Interactor/Potential/Potential.cuh", "Integrator/VerletNVT.cuh", "Integrator/BrownianDynamics.cuh",
-              "Integrator/BDHI/BDHI_FCM.cuh", "misc/LanczosAlgorithm.cuh"]:
+              "Integrator/BDHI/BDHI_FCM.cuh", "Integrator/BDHI/BDHI_PSE.cuh", "Integrator/BDHI/BDHI_EulerMaruyama.cuh",
+              "Interactor/NeighbourList/VerletList.cuh", "misc/LanczosAlgorithm.cuh"]:
         assert os.path.exists(os.path.join(inc, h)), h
 
 
@@ -37,7 +38,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
-                                       ("fcm_selfmobility", [])])
+                                       ("fcm_selfmobility", []), ("pse_selfmobility", [])])
 def test_examples_run(prog, args):
     _make()
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
