@@ -203,3 +203,66 @@ def test_lj_full_size_properties(hip):
     tot = fb[:, :3].astype(np.float64).sum(axis=0)
     assert np.abs(tot).max() <= 1e-4 * np.abs(fb[:, :3]).max() * np.sqrt(n)
     assert np.isfinite(fb).all()
+
+
+# ---- cell-per-wave kernel: same pairs, another summation order -> tolerance, not bits ----------------------------------
+@pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7", "noncubic"])
+def test_lj_cellwave_force_parity(hip, o32, L):
+    rc = 2.5
+    vol = float(np.prod(np.broadcast_to(L, (3,))))
+    n = int(0.8 * vol)
+    pos, box, pot = _setup(hip, o32, n, L, rc, outside=True)
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, 4)
+    fmax = np.abs(ref[:, :3]).max()
+    err = np.abs(got[:, :3] - ref[:, :3]).max() / fmax
+    print(f"[cellwave cellDim={list(cd)}] max |dF| / max|F| = {err:.3e}")
+    assert err <= 1e-5 and np.all(got[:, 3] == 0)                       # 1e-5 of max|F|
+
+
+def test_lj_cellwave_energy_virial_multitype_and_odd_grids(hip, o32):
+    n, L, rc = 12000, 25.0, 2.5
+    pos, box, pot = _setup(hip, o32, n, L, rc, ntypes=3, seed=99)
+    (rf, re, rv), cd = _oracle(o32, pos, box, pot, pot.getCutOff(), (True, True, True))
+    gf, ge, gv = _run(hip, pos, box, pot, pot.getCutOff(), 4, (True, True, True))
+    assert np.abs(gf[:, :3] - rf[:, :3]).max() <= 1e-5 * np.abs(rf[:, :3]).max()
+    assert np.abs(ge - re).max() <= 1e-5 * np.abs(re).max()
+    assert np.abs(gv - rv).max() <= 1e-5 * np.abs(rv).max()
+    for Lc, periodic in [((30.0, 30.0, 9.0), (1, 1, 1)), ((40.0, 40.0, 40.0), (1, 0, 1)), ((9.0, 30.0, 30.0), (1, 1, 0))]:
+        n = int(0.5 * np.prod(Lc))
+        pos, box, pot = _setup(hip, o32, n, Lc, rc, periodic=periodic)
+        L3 = np.asarray(Lc, np.float32)
+        for k in range(3):
+            if not periodic[k]:
+                pos[:, k] = np.clip(pos[:, k], -L3[k] / 2 + 0.01, L3[k] / 2 - 0.01)
+        (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+        got, _, _ = _run(hip, pos, box, pot, rc, 4)
+        assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max(), (Lc, periodic)
+
+
+def test_lj_cellwave_dense_cells_and_full_size(hip, o32):
+    """> 512 candidates per cell (several chunks), > 64 particles per cell (several i blocks), and the C3 box."""
+    n, L, rc = 30000, 20.0, 2.5      # rho = 3.75: ~59 particles per cell -> ~1600 candidates
+    pos = lattice_positions(n, L, seed=11, jitter=0.02)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 0.5, 1.0, False))
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    got, _, _ = _run(hip, pos, box, pot, rc, 4)
+    assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max()
+    n, L = 9000, 12.0                # rho = 5.2 with rc 2.9 -> 4 cells of 3.0: ~140 particles per cell
+    pos = lattice_positions(n, L, seed=12, jitter=0.02)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.9, 0.4, 1.0, False))
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, 2.9)
+    got, _, _ = _run(hip, pos, box, pot, 2.9, 4)
+    assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max()
+    n, L, rc = 1_000_000, 107.7217345, 2.5
+    pos = lattice_positions(n, L, seed=1234, jitter=0.1)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
+    fc, _, _ = _run(hip, pos, box, pot, rc, 4)
+    assert np.abs(fc - fg).max() <= 1e-5 * np.abs(fg).max()

@@ -71,13 +71,15 @@ template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
 UH_D void lj_scan(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, const float4 *__restrict__ P, int jb,
                   int je, const float4 &pi, const BoxT<float> &box, float rc2, const LJParams &p1,
                   const LJParams *tbl, int ntypes) {
-  const int last = je - 1;
   for (int j = jb; j < je; j += 4) {
     if (__any(Q.n > QCAP - 4)) {  // wave-uniform; the full minimum image is exact for every queued pair
       if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
       else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
     }
-    const float4 c0 = P[j], c1 = P[min(j + 1, last)], c2 = P[min(j + 2, last)], c3 = P[min(j + 3, last)];
+    // four candidates from ONE address (immediate offsets); entries past the end of the cell are other particles or the
+    // padding of the array (CellList::update allocates N + 4) and are masked by j + u < je below
+    const float4 *__restrict__ pj = P + j;
+    const float4 c0 = pj[0], c1 = pj[1], c2 = pj[2], c3 = pj[3];
     const float d0 = lj_dist2<PBC>(box, pi, c0), d1 = lj_dist2<PBC>(box, pi, c1);
     const float d2 = lj_dist2<PBC>(box, pi, c2), d3 = lj_dist2<PBC>(box, pi, c3);
     if (!(d0 >= rc2)) { Q.slot[Q.n * QSTRIDE] = (QT)j; ++Q.n; }
@@ -171,6 +173,177 @@ __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> gr
   Acc acc;
   walk_global<NT1, WE, WV>(acc, Q, cl, grid, box, tbl, ntypes, p1, rc2, pi);
   write_out(out, ori, acc);
+}
+
+// ---- cell-per-wave kernel (tolerance-level: same pairs, different summation order) -------------------------------
+// The thread-per-particle walk keeps the reference's summation order but pays for it: the lanes of a wave belong to ~5
+// different cells whose neighbour cells have different populations, so 40 % of the lanes idle (measured), and every lane
+// tests its own 340 candidates.  Here a WAVE owns one cell A: the ~340 particles of the 27 neighbour cells are loaded
+// once (5-6 per lane, kept in registers and in LDS) and reused for all ~13 particles i of A:
+//   phase 1  each lane tests its candidates against i (broadcast through SGPRs); hits are compacted across the wave
+//            (ballot + mbcnt) into a list in LDS;
+//   phase 2  the ~52 hits of i are evaluated 64 at a time, one per lane (81 % lane use instead of 15 %), then one wave
+//            reduction gives F_i.
+// The sum over j is in a different order than the reference's -> forces agree to rounding (tests: <= 1e-5 max|F|, the
+// bar of SURVEY 8d), not bit for bit; the bit-exact kernels above stay selectable (UAMMD_LJ_ALGO_GENERAL).
+constexpr int kCWSlots = 8;
+constexpr int kCWChunk = 64 * kCWSlots;
+
+// sum over the 64 lanes with DPP adds (no LDS crossbar): quad swaps, row rotations, then the row_bcast steps of the GCN/CDNA
+// reduction idiom; the total lands in lane 63 and is returned wave-uniform
+template <int CTRL, int ROWMASK> UH_D float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+UH_D float wave_sum(float v) {
+  v = dpp_add<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);  // row_ror:8  -> every lane of a row holds the row total
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+UH_D float lane_value(float v, int k) {  // k wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+UH_D void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool PBC, bool NT1, bool WE, bool WV>
+UH_D void cellwave_rows(Acc &mine, const float4 (&pj)[kCWSlots], int nC, const float4 &pA, int nI, int lane,
+                        const float4 *__restrict__ cand, unsigned short *__restrict__ lst, const BoxT<float> &box, float rc2,
+                        const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
+  const int nSlots = (nC + 63) >> 6;
+  for (int k = 0; k < nI; ++k) {
+    const float4 pi = make_float4(lane_value(pA.x, k), lane_value(pA.y, k), lane_value(pA.z, k), lane_value(pA.w, k));
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < kCWSlots; ++s) {
+      if (s < nSlots) {
+        const int c = s * 64 + lane;
+        const float r2 = lj_dist2<PBC>(box, pi, pj[s]);
+        const bool in = c < nC && !(r2 >= rc2) && r2 != 0.0f;
+        const unsigned long long m = __ballot(in);
+        if (in) lst[cnt + (int)__builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u))] = (unsigned short)c;
+        cnt += (int)__popcll(m);
+      }
+    }
+    wave_lds_fence();
+    Acc a;
+    for (int b = 0; b < cnt; b += 64) {
+      const int q = b + lane;
+      if (q < cnt) {
+        const float4 cj = cand[lst[q]];
+        real3f r12;
+        float fm, e;
+        if (NT1) lj_eval<PBC, WE>(box, p1, pi, cj, r12, fm, e);
+        else lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)cj.w), pi, cj, r12, fm, e);
+        lj_acc<WE, WV>(a, r12, fm, e);
+      }
+    }
+    wave_lds_fence();  // the list is rewritten for the next i
+    const float fx = wave_sum(a.fx), fy = wave_sum(a.fy), fz = wave_sum(a.fz);
+    float e = 0.f, v = 0.f;
+    if (WE) e = wave_sum(a.e);
+    if (WV) v = wave_sum(a.v);
+    if (lane == k) { mine.fx += fx; mine.fy += fy; mine.fz += fz; mine.e += e; mine.v += v; }
+  }
+}
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(256) k_lj_cellwave(ListView cl, GridT<float> grid, BoxT<float> box,
+                                                      const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
+  __shared__ float4 candAll[4 * kCWChunk];
+  __shared__ unsigned short lstAll[4 * kCWChunk];
+  __shared__ int rngFirst[4 * 32], rngPre[4 * 32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int3 n = grid.cellDim;
+  const int ncells = n.x * n.y * n.z;
+  const int cell = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wave;
+  if (cell >= ncells) return;  // whole waves leave; there is no block-level barrier below
+  const uint csA = cl.cellStart[cell];
+  if (csA < cl.validCell) return;
+  const int aStart = (int)(csA - cl.validCell), aLen = cl.cellEnd[cell] - aStart;
+  float4 *cand = candAll + wave * kCWChunk;
+  unsigned short *lst = lstAll + wave * kCWChunk;
+  int *rFirst = rngFirst + wave * 32, *rPre = rngPre + wave * 32;
+  const int3 celli = make_int3(cell % n.x, (cell / n.x) % n.y, cell / (n.x * n.y));
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int nnc = npx * npy * npz;
+  // lanes 0..nnc-1: the range of one neighbour cell each
+  int myFirst = 0, myLen = 0;
+  bool myPBC = false;
+  if (lane < nnc) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += lane % 3 - 1;
+    if (npy > 1) cellj.y += (lane / npx) % 3 - 1;
+    if (npz > 1) cellj.z += lane / (npx * npy) - 1;
+    const int3 raw = cellj;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+    if (exists) {
+      const int icellj = grid.getCellIndex(cellj);
+      const uint cs = cl.cellStart[icellj];
+      if (cs >= cl.validCell) {
+        myFirst = (int)(cs - cl.validCell);
+        myLen = cl.cellEnd[icellj] - myFirst;
+        myPBC = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z || !cl.cellOutside || cl.cellOutside[icellj] != 0;
+      }
+    }
+  }
+  int incl = myLen;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, nnc - 1, 64);
+  if (lane < 32) { rFirst[lane] = myFirst; rPre[lane] = lane < nnc ? incl - myLen : total; }
+  wave_lds_fence();
+  // minimum image needed? (see walk_global: direct neighbours on a >= 5-cell grid with particles stored inside the box)
+  const bool sameBox = box.boxSize.x == grid.box.boxSize.x && box.boxSize.y == grid.box.boxSize.y &&
+                       box.boxSize.z == grid.box.boxSize.z && box.px() == grid.box.px() &&
+                       box.py() == grid.box.py() && box.pz() == grid.box.pz();
+  const bool needPBC = __any(myPBC) || n.x < 5 || n.y < 5 || n.z < 5 || !sameBox;
+  const LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  for (int ib = 0; ib < aLen; ib += 64) {
+    const int nI = min(64, aLen - ib);
+    const float4 pA = lane < nI ? cl.sortPos[aStart + ib + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    Acc mine;
+    for (int chunk = 0; chunk < total; chunk += kCWChunk) {
+      const int nC = min(kCWChunk, total - chunk);
+      float4 pj[kCWSlots];
+#pragma unroll
+      for (int s = 0; s < kCWSlots; ++s) {
+        const int c = chunk + s * 64 + lane;
+        pj[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < total) {
+          int lo = 0, hi = nnc;  // rPre[lo] <= c < rPre[hi]
+#pragma unroll
+          for (int it = 0; it < 5; ++it) {
+            const int mid = (lo + hi) >> 1;
+            if (rPre[mid] <= c) lo = mid; else hi = mid;
+          }
+          pj[s] = cl.sortPos[rFirst[lo] + (c - rPre[lo])];
+          cand[s * 64 + lane] = pj[s];
+        }
+      }
+      wave_lds_fence();
+      if (needPBC) cellwave_rows<true, NT1, WE, WV>(mine, pj, nC, pA, nI, lane, cand, lst, box, rc2, p1, tbl, ntypes);
+      else cellwave_rows<false, NT1, WE, WV>(mine, pj, nC, pA, nI, lane, cand, lst, box, rc2, p1, tbl, ntypes);
+      wave_lds_fence();
+    }
+    if (lane < nI) {
+      const int gi = cl.groupIndex[aStart + ib + lane];
+      write_out(out, out.globalIndex ? out.globalIndex[gi] : gi, mine);
+    }
+  }
 }
 
 // ---- LDS-tiled brick kernel ------------------------------------------------------------------------
@@ -597,6 +770,11 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
       case 5: return launch_brick<5, NT1, WE, WV>(cl, g, box, tbl, ntypes, out, h->nKeys, st);
       default: return launch_brick<6, NT1, WE, WV>(cl, g, box, tbl, ntypes, out, h->nKeys, st);
     }
+  }
+  if (algo == UAMMD_LJ_ALGO_CELLWAVE) {
+    const int ncells = g.cellDim.x * g.cellDim.y * g.cellDim.z;
+    hipLaunchKernelGGL((k_lj_cellwave<NT1, WE, WV>), dim3((ncells + 3) / 4), dim3(256), 0, st, cl, g, box, tbl, ntypes, out);
+    return 0;
   }
   hipLaunchKernelGGL((k_lj_general<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
   return 0;
