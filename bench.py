@@ -400,8 +400,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # debugging hooks (single-GPU box): UAMMD_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and UAMMD_BENCH_BACKEND=gloo
+        # replaces RCCL (which refuses two ranks on one device), so that the N > 1 code path can be exercised on one GPU
+        if os.environ.get("UAMMD_BENCH_SAME_DEVICE") == "1":
+            local_rank = 0
+        backend = os.environ.get("UAMMD_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
 

@@ -58,21 +58,58 @@ class SlabDecomposition:
         out[:, 2] = dz - torch.floor(dz / Lz + 0.5) * Lz
         return out
 
-    def _exchange(self, send_up, send_down):
-        """Sends `send_up` to rank+1 and `send_down` to rank-1, returns (from_down, from_up).  Rows are float32."""
+    # Boolean-mask indexing and an all_gather of message sizes cost one host sync EACH (a handful per exchange).  Instead the
+    # two message sizes go to the two neighbours only, and ONE host read returns all four numbers an exchange needs; the
+    # rows are then selected with nonzero_static (static size, no sync).
+    def _counts(self, mask_up, mask_down):
+        """-> (n_to_up, n_to_down, n_from_down, n_from_up) as host ints, one device->host sync."""
+        mine = torch.stack([mask_up.sum(), mask_down.sum()])
         if self.world == 1:
-            return send_down.new_zeros((0, send_down.shape[1])), send_up.new_zeros((0, send_up.shape[1]))
-        dev = send_up.device
+            a, b = mine.tolist()
+            return a, b, 0, 0
+        # whole tensors, not views, as message buffers (a backend that stages through the host may not write a view back)
+        to_up, to_down = self._wire(mine[0:1].clone()), self._wire(mine[1:2].clone())
+        from_down, from_up = torch.zeros_like(to_up), torch.zeros_like(to_up)
+        t1, t2 = (1, 2) if self.world == 2 else (0, 0)
+        ops = [dist.P2POp(dist.isend, to_up, self.up, self.group, tag=t1),
+               dist.P2POp(dist.irecv, from_down, self.down, self.group, tag=t1),
+               dist.P2POp(dist.isend, to_down, self.down, self.group, tag=t2),
+               dist.P2POp(dist.irecv, from_up, self.up, self.group, tag=t2)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        a, b, c, d = torch.cat([to_up, to_down, from_down, from_up]).tolist()
+        return a, b, c, d
+
+    def _wire(self, t):
+        """Message buffers live where the backend can reach them: gloo moves host memory only (its use with device tensors is
+        a single-GPU debugging aid, bench.py UAMMD_BENCH_BACKEND=gloo); RCCL sends device memory directly."""
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            return t.cpu()
+        return t
+
+    @staticmethod
+    def _select(rows, mask, count):
+        """rows[mask] when the number of hits is already known on the host (no sync)."""
+        if count == 0:
+            return rows.new_zeros((0,) + tuple(rows.shape[1:]))
+        try:
+            idx = torch.nonzero_static(mask, size=count).flatten()
+        except (RuntimeError, NotImplementedError):
+            idx = torch.nonzero(mask).flatten()
+        return rows.index_select(0, idx)
+
+    def _exchange(self, send_up, send_down, n_from_down, n_from_up):
+        """Sends `send_up` to rank+1 and `send_down` to rank-1, returns (from_down, from_up).  Rows are float32; the
+        receive sizes come from _counts."""
         ncol = send_up.shape[1]
-        counts = torch.tensor([send_up.shape[0], send_down.shape[0]], dtype=torch.int64, device=dev)
-        allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(allc, counts, group=self.group)
-        n_from_down = int(allc[self.down][0])   # what `down` sends up
-        n_from_up = int(allc[self.up][1])       # what `up` sends down
-        from_down = torch.empty((n_from_down, ncol), dtype=send_up.dtype, device=dev)
-        from_up = torch.empty((n_from_up, ncol), dtype=send_up.dtype, device=dev)
-        # zero-row messages are skipped on both sides (every rank knows all counts); with 2 ranks both neighbours
-        # are the same peer and the two messages are told apart by tag (gloo) / by issue order (RCCL)
+        dev = send_up.device
+        if self.world == 1:
+            return send_up.new_empty((0, ncol)), send_up.new_empty((0, ncol))
+        send_up, send_down = self._wire(send_up), self._wire(send_down)
+        from_down = torch.empty((n_from_down, ncol), dtype=send_up.dtype, device=send_up.device)
+        from_up = torch.empty((n_from_up, ncol), dtype=send_up.dtype, device=send_up.device)
+        # zero-row messages are skipped on both sides (each side knows the size of what it sends and receives); with 2 ranks
+        # both neighbours are the same peer and the two messages are told apart by tag (gloo) / by issue order (RCCL)
         t1, t2 = (1, 2) if self.world == 2 else (0, 0)
         ops = []
         if send_up.shape[0] > 0:
@@ -83,11 +120,10 @@ class SlabDecomposition:
             ops.append(dist.P2POp(dist.isend, send_down.contiguous(), self.down, self.group, tag=t2))
         if n_from_up > 0:
             ops.append(dist.P2POp(dist.irecv, from_up, self.up, self.group, tag=t2))
-        if not ops:
-            return from_down, from_up
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        return from_down, from_up
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return from_down.to(dev), from_up.to(dev)
 
     # ---- halo ---------------------------------------------------------------------------------------------
     def halo_exchange(self, pos_local):
@@ -99,14 +135,14 @@ class SlabDecomposition:
         half = 0.5 * self.width
         up_mask = z >= half - self.rc
         down_mask = z < -half + self.rc
-        send_up = pos_local[up_mask].clone()
-        send_down = pos_local[down_mask].clone()
+        n_up, n_down, n_from_down, n_from_up = self._counts(up_mask, down_mask)
+        send_up = self._select(pos_local, up_mask, n_up)
+        send_down = self._select(pos_local, down_mask, n_down)
         # into the receiver's frame: its centre is one slab width above / below mine
         send_up[:, 2] -= self.width
         send_down[:, 2] += self.width
-        from_down, from_up = self._exchange(send_up, send_down)
-        ghosts = torch.cat([from_down, from_up], dim=0)
-        return torch.cat([pos_local, ghosts], dim=0), ghosts.shape[0]
+        from_down, from_up = self._exchange(send_up, send_down, n_from_down, n_from_up)
+        return torch.cat([pos_local, from_down, from_up], dim=0), n_from_down + n_from_up
 
     # ---- migration ------------------------------------------------------------------------------------------
     def migrate(self, pos_local, *others):
@@ -118,18 +154,19 @@ class SlabDecomposition:
         half = 0.5 * self.width
         go_up = z >= half
         go_down = z < -half
-        stay = ~(go_up | go_down)
+        n_up, n_down, n_from_down, n_from_up = self._counts(go_up, go_down)
         # int32 arrays (particle ids) travel bit-cast to float32 in the same message
         cols = [pos_local] + [(o.to(torch.int32).view(torch.float32) if o.dtype != torch.float32 else o).reshape(o.shape[0], -1)
                               for o in others]
         widths = [c.shape[1] for c in cols]
         packed = torch.cat(cols, dim=1)
-        up_rows = packed[go_up].clone()
-        down_rows = packed[go_down].clone()
+        up_rows = self._select(packed, go_up, n_up)
+        down_rows = self._select(packed, go_down, n_down)
         up_rows[:, 2] -= self.width
         down_rows[:, 2] += self.width
-        from_down, from_up = self._exchange(up_rows, down_rows)
-        new = torch.cat([packed[stay], from_down, from_up], dim=0)
+        from_down, from_up = self._exchange(up_rows, down_rows, n_from_down, n_from_up)
+        kept = self._select(packed, ~(go_up | go_down), packed.shape[0] - n_up - n_down) if n_up + n_down > 0 else packed
+        new = torch.cat([kept, from_down, from_up], dim=0) if n_from_down + n_from_up > 0 else kept
         out, c0 = [], 0
         for w, ref in zip(widths, [pos_local] + list(others)):
             block = new[:, c0:c0 + w]
