@@ -247,7 +247,8 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
                                    float temperature, float prefactor, float *d_linearVelocity, int stage,
                                    void *stream);
 int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream);
-/* "atomic_spread" = 1 forces the one-wave-per-particle atomic spread/gather instead of the tile-owned kernels */
+/* "atomic_spread" = 1 forces the one-wave-per-particle atomic spread/gather instead of the tile-owned kernels;
+ * "tile_gather" = 1 selects the LDS-staged gather (supports <= 6; slower than the default at 24 particles per tile) */
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value);
 
 /* ------------------------------------------------------------------------------------------------

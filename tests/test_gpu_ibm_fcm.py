@@ -165,6 +165,11 @@ def test_fcm_deterministic(hip, o32, cells, L, tol):
     gk = fcm.fourier_grid(dp, df, n, 0.0, 0.0).cpu().numpy()
     rk = grids["fourier"].view(np.float32).reshape(gk.shape)
     assert np.abs(gk - rk).max() <= 2e-5 * np.abs(rk).max()
+    # the optional LDS-staged gather gives the same velocities
+    fcm.set_option("tile_gather", 1)
+    v2 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    assert np.linalg.norm(v2 - vref) <= 1e-5 * np.linalg.norm(vref)
+    fcm.set_option("tile_gather", 0)
     v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0)
     torch.cuda.synchronize()
     err = np.linalg.norm(v.cpu().numpy() - vref) / np.linalg.norm(vref)

@@ -52,6 +52,7 @@ struct FCM {
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
   bool forceAtomicSpread = false;  // test hook
+  bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
   bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
   PseGreens pse{0.f, 0.f, 0.f, 0.f, false};  // PSE far field: Hasimoto-split RPY greens function instead of 1/(eta k^2)
   rocfft_plan fwd = nullptr, inv = nullptr;
@@ -326,6 +327,75 @@ __global__ void __launch_bounds__(256) k_fcm_gather_prep(float *__restrict__ vou
   if (lane == 0) {
     float *out = vout + 3 * (size_t)o.w;
     if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
+  }
+}
+
+// Tile-staged gather (supports <= 6), OPTIONAL ("tile_gather" = 1).  A wave-per-particle gather from global memory pulls 36
+// (y,z) rows x 3 components = 108 cache lines per particle for 216 x 12 useful bytes; here a workgroup owns a tile, copies the
+// 16^3 window (tile + 4 nodes each side) of the three velocity grids into LDS once with 8-byte coalesced reads, and its
+// particles (contiguous in the tile-sorted prep arrays) interpolate from LDS.  MEASURED at C4: 112 us against 78 us for the
+// global gather — 49 KB of window per ~24 particles (3 workgroups per CU, a barrier between load and use) costs more than
+// the redundant L1 traffic it saves; kept for dense suspensions (>> 24 particles per tile), off by default.
+constexpr int kGW = 16;                     // window edge
+constexpr int kGRS = 17;                    // row stride (floats): odd, spreads the rows over the banks
+constexpr int kGPS = 16 * kGRS + 4;         // plane stride
+constexpr int kGComp = kGW * kGPS;          // floats per component
+__global__ void __launch_bounds__(256) k_fcm_gather_tile(float *__restrict__ vout, const float *__restrict__ g0, int3 n,
+                                                          int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
+                                                          float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr, bool accumulate) {
+  __shared__ float win[3 * kGComp];
+  const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int first = pr.tileStart[tile], last = pr.tileStart[tile + 1];
+  if (first == last) return;  // the whole workgroup leaves: no particle interpolates from this window
+  const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
+  const int wx0 = tx * kTile - 4, wy0 = ty * kTile - 4, wz0 = tz * kTile - 4;  // window origin, unwrapped
+  for (int e = threadIdx.x; e < 3 * kGW * kGW * (kGW / 2); e += 256) {
+    const int q = e & 7, row = e >> 3;
+    const int y = row & 15, z = (row >> 4) & 15, c = row >> 8;
+    int gx = wx0 + 2 * q, gy = wy0 + y, gz = wz0 + z;
+    gx = gx < 0 ? gx + n.x : (gx >= n.x ? gx - n.x : gx);  // n.x is a multiple of the tile: a pair never straddles the seam
+    gy = gy < 0 ? gy + n.y : (gy >= n.y ? gy - n.y : gy);
+    gz = gz < 0 ? gz + n.z : (gz >= n.z ? gz - n.z : gz);
+    const float2 v = *reinterpret_cast<const float2 *>(g0 + (size_t)c * plane + (size_t)gx + (size_t)nxpad * (size_t)gy +
+                                                       zstride * (size_t)gz);
+    float *w = win + c * kGComp + 2 * q + kGRS * y + kGPS * z;
+    w[0] = v.x;
+    w[1] = v.y;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sx = support.x, sy = support.y, sz = support.z;
+  const int nn = sx * sy * sz;
+  for (int slot = first + wave; slot < last; slot += 4) {
+    const int4 o = pr.origin[slot];
+    const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * slot + lane] : 0.0f;
+    const int lx = o.x - wx0, ly = o.y - wy0, lz = o.z - wz0;  // 1..9: the stencil stays inside the window
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int i0 = 0; i0 < nn; i0 += 64) {
+      const int i = i0 + lane;
+      const bool in = i < nn;
+      const uint iu = in ? (uint)i : 0u;
+      const uint kk = dsxy.div(iu);
+      const uint rem = iu - kk * (uint)(sx * sy);
+      const uint jj = dsx.div(rem);
+      const uint ii = rem - jj * (uint)sx;
+      const float wx = __shfl(wl, (int)ii, 64), wy = __shfl(wl, sx + (int)jj, 64), wz = __shfl(wl, sx + sy + (int)kk, 64);
+      if (!in) continue;
+      const float *w = win + (lx + (int)ii) + kGRS * (ly + (int)jj) + kGPS * (lz + (int)kk);
+      ax = fmaf(dV, w[0] * wx * wy * wz, ax);
+      ay = fmaf(dV, w[kGComp] * wx * wy * wz, ay);
+      az = fmaf(dV, w[2 * kGComp] * wx * wy * wz, az);
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      ax += __shfl_xor(ax, o2, 64);
+      ay += __shfl_xor(ay, o2, 64);
+      az += __shfl_xor(az, o2, 64);
+    }
+    if (lane == 0) {
+      float *out = vout + 3 * (size_t)o.w;
+      if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
+    }
   }
 }
 
@@ -767,7 +837,12 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
                      d_force != nullptr, noisePrefactor, f->par.seed, f->seed2, f->pse);
   if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
   UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
-  if (tiles)
+  const bool smallSupport = f->kern.support.x <= 6 && f->kern.support.y <= 6 && f->kern.support.z <= 6;
+  if (tiles && smallSupport && f->tileGather)
+    hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), bp, 0, st, d_linearVelocity,
+                       (const float *)g, f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles,
+                       f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+  else if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
                        f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   else
@@ -780,6 +855,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
+  if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
   set_last_error("uammd_fcm_set_option: unknown option %s", name);
   return -1;
 }
@@ -896,8 +972,13 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
     FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
                (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
                (int *)f->prepTileStart.ptr, f->kern.support.x + f->kern.support.y + f->kern.support.z};
-    hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
-                       f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+    if (f->kern.support.x <= 6 && f->kern.support.y <= 6 && f->kern.support.z <= 6 && f->tileGather)
+      hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), dim3(256), 0, st, d_vel, d_grid,
+                         f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, f->grid.cellVolume, dsx, dsxy,
+                         pr, f->accumulate);
+    else
+      hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
+                         f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   } else {
     hipLaunchKernelGGL((k_fcm_ibm<false>), dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_posLocal,
                        (const float4 *)nullptr, d_vel, (float *)d_grid, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
