@@ -47,11 +47,12 @@ struct FCM {
   int nxpad = 0;           // 2*(nx/2+1)
   size_t planeReal = 0;    // floats per component plane
   size_t planeCplx = 0;    // complex per component plane
-  DeviceBuffer gridBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
+  DeviceBuffer gridBuf, interBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
   bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
   bool forceAtomicSpread = false;  // test hook
+  bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
   bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
   PseGreens pse{0.f, 0.f, 0.f, 0.f, false};  // PSE far field: Hasimoto-split RPY greens function instead of 1/(eta k^2)
@@ -241,34 +242,39 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
         ox = o.x + shx; oy = o.y + shy; oz = o.z + shz;
         accept = ox < kTile && ox + sx > 0 && oy < kTile && oy + sy > 0 && oz < kTile && oz + sz > 0;
       }
+      // Per-particle set-up is done by the particle's own lane (all candidates of the batch in parallel); the spreading
+      // loop then pulls it with v_readlane (the lane index j is wave-uniform), so those values live in SGPRs and the loop
+      // spends its VALU slots on the nodes only.  (The kernel is VALU-issue bound: 5.5e7 wave-instructions per call.)
+      const int ax = max(ox, 0), ay = max(oy, 0), az = max(oz, 0);
+      const int nx = min(ox + sx, kTile) - ax, ny = min(oy + sy, kTile) - ay, nz = min(oz + sz, kTile) - az;
+      const int nxy = nx * ny, cnt = nxy * nz;
+      // extents are in [1, 8]: exact small-integer division by an approximate reciprocal (+0.5 keeps it away from the edges)
+      const float rxy = __builtin_amdgcn_rcpf((float)max(nxy, 1)), rx = __builtin_amdgcn_rcpf((float)max(nx, 1));
       unsigned long long todo = __ballot(accept);
       while (todo) {
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int px = __shfl(ox, j, 64), py = __shfl(oy, j, 64), pz = __shfl(oz, j, 64);
         const int kp = base + j;
         const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * kp + lane] : 0.0f;
         const float4 f = pr.force[kp];
-        const int ax = max(px, 0), bx = min(px + sx, kTile);
-        const int ay = max(py, 0), by = min(py + sy, kTile);
-        const int az = max(pz, 0), bz = min(pz + sz, kTile);
-        const int nx = bx - ax, ny = by - ay, nz = bz - az;
-        const int nxy = nx * ny, cnt = nxy * nz;
-        // all three extents are in [1, 8]: exact small-integer division by float reciprocal
-        const float rxy = 1.0f / (float)nxy, rx = 1.0f / (float)nx;
-        for (int i0 = 0; i0 < cnt; i0 += 64) {  // wave-uniform trip count (shuffles inside)
+        const int sAx = __builtin_amdgcn_readlane(ax, j), sAy = __builtin_amdgcn_readlane(ay, j), sAz = __builtin_amdgcn_readlane(az, j);
+        const int sDx = sAx - __builtin_amdgcn_readlane(ox, j), sDy = sx + sAy - __builtin_amdgcn_readlane(oy, j),
+                  sDz = sx + sy + sAz - __builtin_amdgcn_readlane(oz, j);
+        const int sNx = __builtin_amdgcn_readlane(nx, j), sNxy = __builtin_amdgcn_readlane(nxy, j), sCnt = __builtin_amdgcn_readlane(cnt, j);
+        const float sRxy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy), j));
+        const float sRx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), j));
+        for (int i0 = 0; i0 < sCnt; i0 += 64) {  // wave-uniform trip count (shuffles inside)
           const int i = i0 + lane;
-          const bool in = i < cnt;
+          const bool in = i < sCnt;
           const int iu = in ? i : 0;
-          int kk = (int)(((float)iu + 0.5f) * rxy);
-          const int r = iu - kk * nxy;
-          int jj = (int)(((float)r + 0.5f) * rx);
-          const int ii = r - jj * nx;
-          const int lx = ax + ii, ly = ay + jj, lz = az + kk;
-          const float wx = __shfl(wl, lx - px, 64), wy = __shfl(wl, sx + ly - py, 64), wz = __shfl(wl, sx + sy + lz - pz, 64);
+          const int kk = (int)(((float)iu + 0.5f) * sRxy);
+          const int r = iu - kk * sNxy;
+          const int jj = (int)(((float)r + 0.5f) * sRx);
+          const int ii = r - jj * sNx;
+          const float wx = __shfl(wl, sDx + ii, 64), wy = __shfl(wl, sDy + jj, 64), wz = __shfl(wl, sDz + kk, 64);
           if (!in) continue;
           const float wt = wx * wy * wz;
-          const int node = lx + kTile * (ly + kTile * lz);
+          const int node = (sAx + ii) + kTile * ((sAy + jj) + kTile * (sAz + kk));
           mine[node] += f.x * wt;
           mine[T3 + node] += f.y * wt;
           mine[2 * T3 + node] += f.z * wt;
@@ -396,6 +402,62 @@ __global__ void __launch_bounds__(256) k_fcm_gather_tile(float *__restrict__ vou
       float *out = vout + 3 * (size_t)o.w;
       if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
     }
+  }
+}
+
+// Interleaved gather.  The wave-per-particle gather is bound by cache-line requests, not bytes: a stencil row is 6 nodes =
+// 24 contiguous bytes in each of the three planar component grids, so one particle touches ~190 lines for 2.6 KB of data.
+// k_fcm_interleave copies the three velocity grids into ONE float4-per-node grid (a streaming pass); a stencil row is then
+// 96 contiguous bytes and the gather needs a third of the line requests (measured at C4: 78 us -> 48 + 10 us).
+__global__ void __launch_bounds__(256) k_fcm_interleave(const float *__restrict__ g0, int3 n, int nxpad, size_t plane,
+                                                         size_t zstride, float4 *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)n.x * n.y * n.z;
+  if (t >= total) return;
+  const int x = (int)(t % n.x), y = (int)((t / n.x) % n.y), z = (int)(t / ((size_t)n.x * n.y));
+  const size_t node = (size_t)x + (size_t)nxpad * (size_t)y + zstride * (size_t)z;
+  out[t] = make_float4(g0[node], g0[plane + node], g0[2 * plane + node], 0.0f);
+}
+
+__global__ void __launch_bounds__(256) k_fcm_gather_inter(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
+                                                           int3 support, float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr,
+                                                           bool accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (slot >= N) return;
+  const int4 o = pr.origin[slot];
+  const int sx = support.x, sy = support.y, sz = support.z;
+  const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * slot + lane] : 0.0f;
+  const int nn = sx * sy * sz;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < nn;
+    const uint iu = in ? (uint)i : 0u;
+    const uint kk = dsxy.div(iu);
+    const uint rem = iu - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const float wx = __shfl(wl, (int)ii, 64), wy = __shfl(wl, sx + (int)jj, 64), wz = __shfl(wl, sx + sy + (int)kk, 64);
+    if (!in) continue;
+    int cx = o.x + (int)ii, cy = o.y + (int)jj, cz = o.z + (int)kk;
+    cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
+    cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
+    cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
+    const float4 v = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];
+    ax = fmaf(dV, v.x * wx * wy * wz, ax);
+    ay = fmaf(dV, v.y * wx * wy * wz, ay);
+    az = fmaf(dV, v.z * wx * wy * wz, az);
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) {
+    ax += __shfl_xor(ax, o2, 64);
+    ay += __shfl_xor(ay, o2, 64);
+    az += __shfl_xor(az, o2, 64);
+  }
+  if (lane == 0) {
+    float *out = vout + 3 * (size_t)o.w;
+    if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
   }
 }
 
@@ -842,7 +904,14 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), bp, 0, st, d_linearVelocity,
                        (const float *)g, f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles,
                        f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
-  else if (tiles)
+  else if (tiles && f->interGather) {
+    const size_t nodes = (size_t)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z;
+    if (int e = f->interBuf.reserve(sizeof(float4) * nodes)) return e;
+    hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
+                       f->planeReal, zs, (float4 *)f->interBuf.ptr);
+    hipLaunchKernelGGL(k_fcm_gather_inter, gp, bp, 0, st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim,
+                       f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+  } else if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
                        f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   else
@@ -856,6 +925,7 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
+  if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
   set_last_error("uammd_fcm_set_option: unknown option %s", name);
   return -1;
 }
