@@ -2,6 +2,7 @@
 // and compare with the Hasimoto-corrected mobility; then one BDHI::EulerMaruyama<BDHI::PSE> step at T > 0.
 #include "uammd.cuh"
 #include "Integrator/BDHI/BDHI_EulerMaruyama.cuh"
+#include "Integrator/BDHI/BDHI_Lanczos.cuh"
 #include "Integrator/BDHI/BDHI_PSE.cuh"
 #include <cstdio>
 using namespace uammd;
@@ -40,6 +41,11 @@ int main(int argc, char *argv[]) {
   { auto pos = pd->getPos(access::cpu, access::read); p = pos[0]; }
   const double d2 = (p.x - 3.1) * (p.x - 3.1) + (p.y + 7.2) * (p.y + 7.2) + (p.z - 11.3) * (p.z - 11.3);
   std::printf("thermal displacement^2 %.3e (6 D dt = %.3e)\n", d2, 6 * m0 * par.dt);
+  // open-boundary RPY with the Lanczos noise: same integrator template, another Method
+  BDHI::Lanczos::Parameters lpar;
+  lpar.viscosity = par.viscosity; lpar.hydrodynamicRadius = rh; lpar.temperature = 1.0; lpar.dt = 0.01; lpar.tolerance = 1e-3;
+  auto bdl = std::make_shared<BDHI::EulerMaruyama<BDHI::Lanczos>>(pd, lpar);
+  bdl->forwardTime();
   sys->finish();
   return (ok1 && std::isfinite(d2) && d2 > 0 && d2 < 100 * 6 * m0 * par.dt) ? 0 : 1;
 }

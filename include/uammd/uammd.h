@@ -862,6 +862,55 @@ public:
   real getSelfMobility() { return M0; }
 };
 
+// BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67): open boundaries, dense RPY mobility, matrix free
+class Lanczos {
+  shared_ptr<ParticleData> pd;
+  BDHI::Parameters par;
+  uammd_lanczos *solver = nullptr;
+  detail::DeviceArray<real3> noise;
+  Xorshift128plus gen;  // the reference uses cuRAND here (stream unpinned): Box-Muller on the System generator family instead
+public:
+  using Parameters = BDHI::Parameters;
+  Lanczos(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), par(par), noise(pd->getNumParticles()) {
+    if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
+      System::log<System::CRITICAL>("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the individual particle radius.");
+    detail::check(uammd_lanczos_create(&solver));
+    gen.setSeed(pd->getSystem()->rng().next());
+  }
+  Lanczos(const Lanczos &) = delete;
+  ~Lanczos() { uammd_lanczos_destroy(solver); }
+  void setup_step(hipStream_t = 0) {}
+  void finish_step(hipStream_t = 0) {}
+  real getHydrodynamicRadius() { return par.hydrodynamicRadius; }
+  real getSelfMobility() { return par.hydrodynamicRadius < 0 ? real(-1.0) : real(1.0 / (6.0 * M_PI * par.viscosity * par.hydrodynamicRadius)); }
+  void computeMF(real3 *MF, hipStream_t st = 0) {
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto force = pd->getForce(access::gpu, access::read);
+    auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
+    detail::check(uammd_rpy_nbody_mdot((const float *)pos.raw(), (const float *)force.raw(), 4, radius.raw(), par.hydrodynamicRadius,
+                                       par.viscosity, pd->getNumParticles(), (float *)MF, (void *)st));
+  }
+  void computeBdW(real3 *BdW, hipStream_t st = 0) {
+    if (!(par.temperature > real(0.0))) return;
+    const int N = pd->getNumParticles();
+    std::vector<real3> h(N);
+    for (auto &v : h) {  // standard normals, Box-Muller
+      real g[4];
+      for (int k = 0; k < 4; k += 2) {
+        const double u1 = gen.uniform(1e-300, 1.0), u2 = gen.uniform(0.0, 1.0);
+        const double r = std::sqrt(-2.0 * std::log(u1));
+        g[k] = real(r * std::cos(2 * M_PI * u2)); g[k + 1] = real(r * std::sin(2 * M_PI * u2));
+      }
+      v = make_real3(g[0], g[1], g[2]);
+    }
+    detail::hipCheck(hipMemcpy(noise.d, h.data(), sizeof(real3) * N, hipMemcpyHostToDevice), "hipMemcpy");
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
+    detail::check(uammd_rpy_lanczos_bdw(solver, (const float *)pos.raw(), radius.raw(), par.hydrodynamicRadius, par.viscosity, N,
+                                        (const float *)noise.d, par.tolerance, (float *)BdW, (void *)st, nullptr));
+  }
+};
+
 template <class Method> class EulerMaruyama : public Integrator {
   using Parameters_t = typename Method::Parameters;
   Parameters_t par;

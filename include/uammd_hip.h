@@ -334,6 +334,18 @@ int uammd_lanczos_run(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d
 int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps);
 
+/* BDHI::Lanczos (open boundaries, dense RPY mobility, matrix free).  Replaces
+ *   Lanczos_ns::NbodyMatrixFreeMobilityDot + NBody::transverse   Integrator/BDHI/BDHI_Lanczos.cu:56-118, Interactor/NBodyBase.cuh:46-159
+ *   RotnePragerYamakawa                                           Integrator/BDHI/BDHI.cuh:27-96
+ *   Lanczos::computeMF / computeBdW                               BDHI_Lanczos.cu:120-188
+ * d_Mv real3[N] is OVERWRITTEN.  The reference draws the noise of computeBdW with cuRAND (parity unpinned):
+ * the caller supplies 3N standard normal numbers. */
+int uammd_rpy_nbody_mdot(const float *d_pos, const float *d_v, int vstride, const float *d_radius, float hydrodynamicRadius,
+                         float viscosity, int numberParticles, float *d_Mv, void *stream);
+int uammd_rpy_lanczos_bdw(uammd_lanczos *solver, const float *d_pos, const float *d_radius, float hydrodynamicRadius,
+                          float viscosity, int numberParticles, const float *d_noise, float tolerance, float *d_BdW,
+                          void *stream, int *iterations);
+
 #ifdef __cplusplus
 }
 #endif

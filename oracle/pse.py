@@ -157,3 +157,14 @@ class PSEOracle:
             MF[:] = b
         self.far(pos, force4, MF, temperature, prefactor, seed2_far)
         return MF
+
+
+def rpy_nbody_mdot(oracle, pos4, v, viscosity, rh=-1.0, radius=None):
+    """Lanczos_ns::NbodyMatrixFreeMobilityDot through NBody::transverse (BDHI_Lanczos.cu:56-118): Mv real3[N]."""
+    pos4 = oracle.r(pos4)
+    v = oracle.r(v)
+    n = len(pos4)
+    out = np.zeros((n, 3), oracle.real)
+    rad = None if radius is None else oracle.r(radius)
+    oracle.lib.oracle_rpy_nbody_mdot(_p(pos4), _p(v), int(v.shape[1]), _p(rad), oracle.creal(rh), oracle.creal(viscosity), n, _p(out))
+    return out

@@ -369,3 +369,58 @@ ORACLE_API void oracle_pse_fourier_brownian_noise(real *grid6, const real *L3, c
     }
   }
 }
+
+/* ---- BDHI::Lanczos (open boundary, dense RPY mobility) -------------------------------------------------------------------
+ *   RotnePragerYamakawa::{RPY_differentSizes, operator()}       Integrator/BDHI/BDHI.cuh:27-96
+ *   Lanczos_ns::NbodyMatrixFreeMobilityDot::{compute,accumulate,set}   Integrator/BDHI/BDHI_Lanczos.cu:56-118
+ *   NBody::transverse order: j ascending over the group         Interactor/NBodyBase.cuh:79-110
+ * Contract: f*vj + gv*rij -> FMA(gv, rij.k, f*vj.k); total += cur plain add; set OVERWRITES Mv[id]. */
+static inline void rpy_different_sizes(real M0, real r, real ai, real aj, real *c1, real *c2) {
+  const real asum = ai + aj;
+  const real asub = FABS(ai - aj);
+  if (r > asum) {
+    const real invr = (real)1.0 / r;
+    const real pref = M0 * (real)3.0 * (real)0.25 * invr;
+    const real denom = FMA(ai, ai, aj * aj) / ((real)3.0 * r * r);
+    *c1 = pref * ((real)1.0 + denom);
+    *c2 = pref * FMA((real)-3.0, denom, (real)1.0) * invr * invr;
+  } else if (r > asub) {
+    const real pref = M0 / (ai * aj * (real)32.0 * r * r * r);
+    real num = FMA((real)3.0 * r, r, asub * asub);
+    *c1 = pref * FMA((real)16.0 * r * r * r, asum, -(num * num));
+    num = FMA(-r, r, asub * asub);
+    *c2 = pref * ((real)3.0 * num * num) / (r * r);
+  } else {
+    *c1 = M0 / (ai > aj ? ai : aj);
+    *c2 = 0;
+  }
+}
+
+ORACLE_API void oracle_rpy_nbody_mdot(const real4 *pos, const real *v, int vstride, const real *radius, real rh, real viscosity,
+                                      int N, real *Mv3) {
+  const real M0 = (real)(1 / (6 * M_PI * viscosity)); /* BDHI.cuh:29 */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; i++) {
+    const real4 pi = pos[i];
+    const real ai = radius ? radius[i] : rh;
+    real3 total = mk3(0, 0, 0);
+    for (int j = 0; j < N; j++) {
+      const real4 pj = pos[j];
+      const real aj = radius ? radius[j] : rh;
+      const real3 rij = mk3(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+      const real r = SQRT(dot3(rij, rij));
+      const real3 vj = mk3(v[(size_t)vstride * j], v[(size_t)vstride * j + 1], v[(size_t)vstride * j + 2]);
+      real f, gdivr2;
+      rpy_different_sizes(M0, r, ai, aj, &f, &gdivr2);
+      real3 cur;
+      if (r == (real)0.0) {
+        cur = mk3(f * vj.x, f * vj.y, f * vj.z);
+      } else {
+        const real gv = gdivr2 * dot3(rij, vj);
+        cur = mk3(FMA(gv, rij.x, f * vj.x), FMA(gv, rij.y, f * vj.y), FMA(gv, rij.z, f * vj.z));
+      }
+      total.x += cur.x; total.y += cur.y; total.z += cur.z;
+    }
+    Mv3[3 * i] = total.x; Mv3[3 * i + 1] = total.y; Mv3[3 * i + 2] = total.z;
+  }
+}

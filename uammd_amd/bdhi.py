@@ -8,6 +8,7 @@ Citations (relative to /root/reference/src):
   BDHI::FCMIntegrator                    Integrator/BDHI/BDHI_FCM.cuh:149-198, BDHI_FCM.cu:95-119
   BDHI::EulerMaruyama<Method>            Integrator/BDHI/BDHI_EulerMaruyama.cu:82-166
   BDHI::PSE (Method)                     Integrator/BDHI/BDHI_PSE.cuh:79-176, PSE/NearField.cuh, PSE/FarField.cuh
+  BDHI::Lanczos (Method)                 Integrator/BDHI/BDHI_Lanczos.cuh:20-67, BDHI_Lanczos.cu
   FCM_impl                               Integrator/BDHI/FCM/FCM_impl.cuh:56-129, :652-693
 All compute happens in libuammd_hip.so through the C ABI.
 """
@@ -470,10 +471,64 @@ class LanczosSolver:
         return int(it.value)
 
 
+class Lanczos:
+    """BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67, .cu): open-boundary RPY mobility applied matrix free as an
+    all-pairs product, noise by the Lanczos iteration.  The Method concept of BDHI::EulerMaruyama."""
+    Parameters = _Parameters
+
+    def __init__(self, pd, par):
+        self.lib = _lib.load()
+        self.pd, self.par = pd, par
+        self.hydrodynamicRadius, self.temperature, self.tolerance = par.hydrodynamicRadius, par.temperature, par.tolerance
+        if par.hydrodynamicRadius < 0 and not pd.isAllocated("radius"):
+            raise RuntimeError("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the "
+                               "individual particle radius.")
+        self.solver = LanczosSolver()
+        # the reference seeds cuRAND from System::rng().next() here (BDHI_Lanczos.cu:45-46); torch's generator stands in
+        self.gen = torch.Generator(device=pd.device)
+        self.gen.manual_seed(pd.rng.next() & 0x7FFFFFFFFFFFFFFF)
+        self.lastIterations = 0
+
+    def _radius(self):
+        return None if self.hydrodynamicRadius > 0 else self.pd.getRadius("read")
+
+    def setup_step(self):
+        pass
+
+    def finish_step(self):
+        pass
+
+    def getHydrodynamicRadius(self):
+        return self.par.hydrodynamicRadius
+
+    def getSelfMobility(self):
+        rh = self.par.hydrodynamicRadius
+        return -1.0 if rh < 0 else 1.0 / (6.0 * math.pi * self.par.viscosity * rh)
+
+    def computeMF(self, MF):
+        pd = self.pd
+        check(self.lib.uammd_rpy_nbody_mdot(_ptr(pd.getPos("read")), _ptr(pd.getForce("read")), 4, _ptr(self._radius()),
+                                            float(self.hydrodynamicRadius), float(self.par.viscosity), pd.N, _ptr(MF),
+                                            current_stream()))
+
+    def computeBdW(self, BdW, noise=None):
+        if not self.temperature > 0:
+            return
+        pd = self.pd
+        if noise is None:
+            noise = torch.randn((pd.N, 3), dtype=torch.float32, device=pd.device, generator=self.gen)
+        it = C.c_int(0)
+        check(self.lib.uammd_rpy_lanczos_bdw(self.solver.h, _ptr(pd.getPos("read")), _ptr(self._radius()),
+                                             float(self.hydrodynamicRadius), float(self.par.viscosity), pd.N, _ptr(noise),
+                                             float(self.tolerance), _ptr(BdW), current_stream(), C.byref(it)))
+        self.lastIterations = int(it.value)
+
+
 class BDHI:
     LanczosSolver = LanczosSolver
     FCM = FCM
     PSE = PSE
+    Lanczos = Lanczos
     EulerMaruyama = EulerMaruyama
     FCMIntegrator = FCMIntegrator
     FCM_impl = FCM_impl

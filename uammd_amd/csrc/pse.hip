@@ -235,6 +235,80 @@ static int pse_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void
   return pse_dot<3>(p, d_v, d_Mv, st);
 }
 
+// ---- BDHI::Lanczos: dense open-boundary RPY mobility, matrix free (Integrator/BDHI/BDHI_Lanczos.cu:56-118, BDHI.cuh:27-96) ----
+UH_D void rpy_different_sizes(float M0, float r, float ai, float aj, float &c1, float &c2) {
+  const float asum = ai + aj;
+  const float asub = fabsf(ai - aj);
+  if (r > asum) {
+    const float invr = 1.0f / r;
+    const float pref = M0 * 3.0f * 0.25f * invr;
+    const float denom = fmaf(ai, ai, aj * aj) / (3.0f * r * r);
+    c1 = pref * (1.0f + denom);
+    c2 = pref * fmaf(-3.0f, denom, 1.0f) * invr * invr;
+  } else if (r > asub) {
+    const float pref = M0 / (ai * aj * 32.0f * r * r * r);
+    float num = fmaf(3.0f * r, r, asub * asub);
+    c1 = pref * fmaf(16.0f * r * r * r, asum, -(num * num));
+    num = fmaf(-r, r, asub * asub);
+    c2 = pref * (3.0f * num * num) / (r * r);
+  } else {
+    c1 = M0 / (ai > aj ? ai : aj);
+    c2 = 0.0f;
+  }
+}
+
+// NBody::transverse with NbodyMatrixFreeMobilityDot: thread per particle i, all j in ascending order through LDS tiles
+// (positions + radius in one float4, v in another); Mv[i] = total (overwrites).
+template <int VSTRIDE>
+__global__ void __launch_bounds__(128) k_rpy_nbody(const float4 *__restrict__ pos, const float *__restrict__ v,
+                                                    const float *__restrict__ radius, float rh, float M0, int N,
+                                                    float *__restrict__ Mv) {
+  __shared__ float4 tp[128], tv[128];
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const bool active = i < N;
+  const float4 pi = active ? pos[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float ai = active ? (radius ? radius[i] : rh) : 1.0f;
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  for (int base = 0; base < N; base += 128) {
+    const int j = base + threadIdx.x;
+    if (j < N) {
+      const float4 p = pos[j];
+      tp[threadIdx.x] = make_float4(p.x, p.y, p.z, radius ? radius[j] : rh);
+      const float *vj = v + (size_t)VSTRIDE * j;
+      tv[threadIdx.x] = make_float4(vj[0], vj[1], vj[2], 0.f);
+    }
+    __syncthreads();
+    const int cnt = min(128, N - base);
+    if (active) {
+      for (int t = 0; t < cnt; ++t) {
+        const float4 pj = tp[t], vj = tv[t];
+        const real3f rij{pi.x - pj.x, pi.y - pj.y, pi.z - pj.z};
+        const float r = sqrtf(dot3(rij, rij));
+        float f, g;
+        rpy_different_sizes(M0, r, ai, pj.w, f, g);
+        if (r == 0.0f) {
+          tx += f * vj.x; ty += f * vj.y; tz += f * vj.z;
+        } else {
+          const float gv = g * dot3(rij, real3f{vj.x, vj.y, vj.z});
+          tx += fmaf(gv, rij.x, f * vj.x);
+          ty += fmaf(gv, rij.y, f * vj.y);
+          tz += fmaf(gv, rij.z, f * vj.z);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (active) { Mv[3 * (size_t)i] = tx; Mv[3 * (size_t)i + 1] = ty; Mv[3 * (size_t)i + 2] = tz; }
+}
+
+struct RpyDotCtx { const float *pos, *radius; float rh, M0; int N; };
+static int rpy_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) {
+  const RpyDotCtx *c = static_cast<const RpyDotCtx *>(ctx);
+  hipLaunchKernelGGL((k_rpy_nbody<3>), dim3((c->N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)c->pos, d_v,
+                     c->radius, c->rh, c->M0, c->N, d_Mv);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace uammd_hip
 
 using namespace uammd_hip;
@@ -344,6 +418,42 @@ int uammd_pse_near_dot(uammd_pse_near *h, const float *d_pos, const float *d_v3,
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (int e = pse_update_list(p, d_pos, N, (hipStream_t)stream)) return e;
   return pse_lanczos_dot(p, d_v3, d_Mv3, 3 * N, stream);
+}
+
+// BDHI::Lanczos::computeMF / Dotctor (BDHI_Lanczos.cu:120-160): d_Mv real3[N] = M_RPY v, v with stride 3 (real3) or 4 (real4
+// forces); d_radius nullable (then every particle has hydrodynamicRadius).  Open boundaries: no box.
+int uammd_rpy_nbody_mdot(const float *d_pos, const float *d_v, int vstride, const float *d_radius, float hydrodynamicRadius,
+                         float viscosity, int N, float *d_Mv, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_v || !d_Mv || (vstride != 3 && vstride != 4)) { set_last_error("uammd_rpy_nbody_mdot: bad arguments"); return -1; }
+  if (!d_radius && !(hydrodynamicRadius > 0)) {
+    set_last_error("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the individual particle radius.");
+    return -2;
+  }
+  const float M0 = (float)(1 / (6 * M_PI * viscosity));
+  if (vstride == 3)
+    hipLaunchKernelGGL((k_rpy_nbody<3>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)d_pos, d_v,
+                       d_radius, hydrodynamicRadius, M0, N, d_Mv);
+  else
+    hipLaunchKernelGGL((k_rpy_nbody<4>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)d_pos, d_v,
+                       d_radius, hydrodynamicRadius, M0, N, d_Mv);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// BDHI::Lanczos::computeBdW (BDHI_Lanczos.cu:162-188): d_BdW real3[N] = M_RPY^(1/2) d_noise by the Lanczos iteration.  The
+// reference draws the noise with cuRAND (third party, stream unpinned): here the caller supplies N(0,1) numbers.
+int uammd_rpy_lanczos_bdw(uammd_lanczos *solver, const float *d_pos, const float *d_radius, float hydrodynamicRadius,
+                          float viscosity, int N, const float *d_noise, float tolerance, float *d_BdW, void *stream,
+                          int *iterations) {
+  if (iterations) *iterations = 0;
+  if (N <= 0) return 0;
+  if (!solver || !d_pos || !d_noise || !d_BdW) { set_last_error("uammd_rpy_lanczos_bdw: null argument"); return -1; }
+  RpyDotCtx ctx{d_pos, d_radius, hydrodynamicRadius, (float)(1 / (6 * M_PI * viscosity)), N};
+  int it = 0;
+  const int rc = uammd_lanczos_run(solver, &rpy_lanczos_dot, &ctx, d_BdW, d_noise, tolerance, 3 * N, stream, &it);
+  if (iterations) *iterations = it;
+  return rc;
 }
 
 }  // extern "C"
