@@ -514,7 +514,7 @@ UH_D C3 draw_noise(float prefactor, uint id, uint seed1, uint seed2, bool nyquis
 // One thread per (local) Fourier node, in place.  KLayout says where node (kx, y0 + yl, z) of component c lives:
 // g0[kx + nkx*yl + zStride*z + compStride*c].  Single GPU: 3 planar grids (nyl = ny, zStride = nkx*ny, compStride = plane);
 // slab-decomposed: the y-pencil layout [z][c][yl][kx] that the all-to-all transpose delivers.
-struct KLayout { int nyl, y0; size_t compStride, zStride; };
+struct KLayout { int nyl, y0; size_t compStride, zStride; FastDiv divNkx, divNyl; };
 // PSE far field (FarField.cuh): B = sinc^2(k a) Hasimoto(k, xi, eta) / (eta_visc a^2 k^2 N) with the sheared wave vector,
 // projection with the sheared k (no Nyquist zeroing), noise scaled by sqrt(B) AFTER the projection.
 UH_D real3f pse_shear(real3f k, float shear) { k.y = fmaf(-shear, k.x, k.y); return k; }
@@ -549,12 +549,17 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
   const int nkx = nk.x / 2 + 1;
   const int total = nk.z * lay.nyl * nkx;
   if (t >= total) return;
-  const int3 cell = make_int3(t % nkx, lay.y0 + (t / nkx) % lay.nyl, t / (nkx * lay.nyl));
+  // (kx, yl, z) of this thread: three integer divisions by run-time constants would cost ~100 VALU slots; multiply-high instead
+  const uint tq = lay.divNkx.div((uint)t);          // t / nkx
+  const uint tz = lay.divNyl.div(tq);               // t / (nkx * nyl)
+  const int3 cell = make_int3(t - (int)tq * nkx, lay.y0 + (int)(tq - tz * (uint)lay.nyl), (int)tz);
   const int id = cell.x + nkx * (cell.y + nk.y * cell.z);  // the reference's linear node index (it seeds the noise)
   const size_t a0 = (size_t)cell.x + (size_t)nkx * (size_t)(cell.y - lay.y0) + lay.zStride * (size_t)cell.z;
   float2 *g1 = g0 + lay.compStride, *g2 = g0 + 2 * lay.compStride;
   C3 v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int3 ik = index_to_wavenumber(id, nk);
+  // indexToWaveNumber (FCM/utils.cuh:27-35) from the cell coordinates it would recompute by division
+  const int3 ik = make_int3(cell.x - nk.x * (cell.x >= nkx), cell.y - nk.y * (cell.y >= nk.y / 2 + 1),
+                            cell.z - nk.z * (cell.z >= nk.z / 2 + 1));
   const real3f k = wavevector(ik, L);
   const float k2 = dot3(k, k);
   const real3f dk = gradient_fourier(ik, nk, k);
@@ -893,7 +898,8 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     if (f->pse.on) noisePrefactor = prefactor * sqrtf(2 * temperature / dV);  // FarField.cuh:503: the 1/N lives in B
   }
   const int total = (int)f->planeCplx;
-  const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y};
+  const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y,
+                    make_fastdiv(f->grid.cellDim.x / 2 + 1), make_fastdiv(f->grid.cellDim.y)};
   hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, lay,
                      f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
                      d_force != nullptr, noisePrefactor, f->par.seed, f->seed2, f->pse);
@@ -1102,7 +1108,7 @@ int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, floa
     const float fourierNormalization = (float)(1.0 / ((double)s->cells.x * s->cells.y * s->cells.z));
     noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / g.cellVolume);
   }
-  const KLayout lay{s->nyl, s->y0, (size_t)s->nyl * s->nkx, 3 * (size_t)s->nyl * s->nkx};
+  const KLayout lay{s->nyl, s->y0, (size_t)s->nyl * s->nkx, 3 * (size_t)s->nyl * s->nkx, make_fastdiv(s->nkx), make_fastdiv(s->nyl)};
   const int total = s->cells.z * s->nyl * s->nkx;
   hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_cplxZ, lay,
                      s->cells, s->L, s->loc.par.viscosity, haveForce != 0, noisePrefactor, s->loc.par.seed, seed2, s->loc.pse);
