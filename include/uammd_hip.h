@@ -251,6 +251,18 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream);
  * "tile_gather" = 1 selects the LDS-staged gather (supports <= 6; slower than the default at 24 particles per tile) */
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value);
 
+/* Torques and rotation (FCM_impl.cuh:306-358, :590-649; FCM_kernels.cuh:60-80; BDHI_FCM.cu:67-92).  The torque window is
+ * GaussianTorque(width = a/(6 sqrt(pi))^(1/3), h, tolerance); torques are spread with it, half their curl is added to the
+ * Fourier forces, and the angular velocity is half the curl of the Fourier velocity interpolated with the same window.
+ * d_dir: orientation quaternions real4 (n, vx, vy, vz), nullable. */
+int uammd_fcm_torque_gaussian_kernel(float hydrodynamicRadius, float h, float tolerance, uammd_ibm_kernel *out);
+int uammd_fcm_set_torque_kernel(uammd_fcm *h, const uammd_ibm_kernel *kernelTorque);
+int uammd_fcm_displacements_torque(uammd_fcm *h, const float *d_pos, const float *d_force, const float *d_torque,
+                                   int numberParticles, float temperature, float prefactor, float *d_linearVelocity,
+                                   float *d_angularVelocity, void *stream);
+int uammd_fcm_euler_maruyama_dir(float *d_pos, float *d_dir, const int *d_index, const float *d_linearVelocity,
+                                 const float *d_angularVelocity, int numberParticles, float dt, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Path B on several GPUs — z-slab decomposition of the FCM grid (the reference is single GPU, so these
  * have no reference counterpart: they are the per-rank compute stages of uammd_fcm_displacements, cut where the

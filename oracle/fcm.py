@@ -71,3 +71,44 @@ class FCMOracle:
         if grids is not None:
             grids.update(spread=gr, fourier=gk, velocity=gv)
         return v
+
+
+    # -- torques (FCM_impl.cuh:652-693 with torque != nullptr) ----------------------------------------------------
+    def torque_kernel(self, hydrodynamicRadius=None, tolerance=1e-3):
+        """detail::initializeKernelTorque (BDHI_FCM.cuh:69-80) -> oracle IBM kernel."""
+        import ctypes as C
+        from .oracle import _p
+        a = self.hydrodynamicRadius if hydrodynamicRadius is None else hydrodynamicRadius
+        out = np.zeros(3, self.real)
+        self.o.lib.oracle_fcm_torque_gaussian_init.restype = C.c_int
+        sup = self.o.lib.oracle_fcm_torque_gaussian_init(self.o.creal(a), self.o.creal(self.h), self.o.creal(tolerance), _p(out))
+        return self.o.ibm_kernel("gaussian", int(sup), out[0], out[1], out[2]), int(sup)
+
+    def _half_curl(self, gin, gout, accumulate):
+        from .oracle import _p
+        self.o.lib.oracle_fcm_half_curl_fourier(_p(gin), _p(gout), _p(self.L), _p(self.cells), int(accumulate))
+
+    def displacements_torque(self, pos, force, torque, kernel_torque, temperature=0.0, prefactor=0.0):
+        """Returns (linear real3[N], angular real3[N])."""
+        o = self.o
+        pos = o.r(pos)
+        nx, ny, nz = (int(c) for c in self.cells)
+        if force is not None:
+            gk = self.forward(self.spread(pos, o.r(np.asarray(force)[:, :3])))
+        else:
+            gk = np.zeros((nz, ny, nx // 2 + 1, 3), self.cplx)
+        gt = o.ibm_spread(pos, o.r(np.asarray(torque)[:, :3]), self.L, 1, self.cells, kernel_torque, nx_stride=self.nxpad)
+        gtk = self.forward(gt)
+        self._half_curl(gtk, gk, True)
+        o.fcm_force_fourier_to_vel(gk, self.viscosity, self.L, self.cells)
+        if temperature > 0:
+            self.seed2 += 1
+            npf = o.fcm_noise_prefactor(prefactor, temperature, self.L, self.cells)
+            o.fcm_fourier_brownian_noise(gk, self.L, self.cells, npf, self.viscosity, self.seed, self.seed2)
+        gak = np.zeros_like(gk)
+        self._half_curl(gk, gak, False)
+        ga = self.inverse(gak)
+        w = o.ibm_gather(pos, ga, self.L, 1, self.cells, kernel_torque, nx_stride=self.nxpad)
+        gv = self.inverse(gk)
+        v = o.ibm_gather(pos, gv, self.L, 1, self.cells, self.kernel, nx_stride=self.nxpad)
+        return v, w

@@ -37,6 +37,7 @@ typedef double real;
 #define FABS(a) fabs(a)
 #define ROUND(a) round(a)
 #define SIN(a) sin(a)
+#define COS(a) cos(a)
 #else
 typedef float real;
 #define FMA(a, b, c) fmaf((a), (b), (c))
@@ -46,6 +47,7 @@ typedef float real;
 #define FABS(a) fabsf(a)
 #define ROUND(a) roundf(a)
 #define SIN(a) sinf(a)
+#define COS(a) cosf(a)
 #endif
 
 typedef unsigned int uint;

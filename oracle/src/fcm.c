@@ -167,3 +167,44 @@ ORACLE_API double oracle_fcm_self_mobility(double hydrodynamicRadius, double vis
   long double a6pref = 16.0l * pi * pi / 45.0l + 630.0L * b * b;
   return (double)(1.0l / (6.0l * pi * viscosity * rh) * (1.0l - c * a + (4.0l / 3.0l) * pi * a3 - a6pref * a3 * a3));
 }
+
+/* ---- torques / rotation ------------------------------------------------------------------------------------
+ *   FCM_ns::Kernels::GaussianTorque(width, h, tolerance)     Integrator/BDHI/FCM/FCM_kernels.cuh:60-80
+ *   detail::initializeKernelTorque (width = a/(6 sqrt(pi))^(1/3))  Integrator/BDHI/BDHI_FCM.cuh:69-80
+ *   addTorqueCurl / computeVelocityCurlFourier               Integrator/BDHI/FCM/FCM_impl.cuh:306-327, :590-617
+ *   FCM_ns::integrateEulerMaruyamaD with orientations        Integrator/BDHI/BDHI_FCM.cu:67-92, utils/quaternion.cuh:179-196
+ */
+ORACLE_API int oracle_fcm_torque_gaussian_init(real hydrodynamicRadius, real h, real tolerance, real *out3) {
+  const real width = (real)(hydrodynamicRadius / (pow(6 * sqrt(M_PI), 1 / 3.)));
+  const real prefactor = (real)pow(2.0 * M_PI * (double)width * (double)width, -0.5);
+  const real tau = (real)(-0.5 / ((double)width * (double)width));
+  const real dr = (real)(0.5 * h);
+  real r = dr;
+  while (prefactor * EXP(tau * r * r) > tolerance) r += dr;
+  int support = (int)(2 * r / h + 0.5);
+  if (support < 3) support = 3;
+  out3[0] = prefactor; out3[1] = tau; out3[2] = (real)support * h;
+  return support;
+}
+
+/* half * i dk x g : the operator shared by addTorqueCurl (accumulate = 1: out += ...) and computeVelocityCurlFourier
+ * (accumulate = 0: out = ...).  Component expressions exactly as written in the reference. */
+ORACLE_API void oracle_fcm_half_curl_fourier(const real *in6, real *out6, const real *L3, const int *cellDim, int accumulate) {
+  const complex3 *in = (const complex3 *)in6;
+  complex3 *out = (complex3 *)out6;
+  const int3 n = mki3(cellDim[0], cellDim[1], cellDim[2]);
+  const real3 L = mk3(L3[0], L3[1], L3[2]);
+  const int nk = n.z * n.y * (n.x / 2 + 1);
+  const real half = (real)0.5;
+  for (int id = 0; id < nk; id++) {
+    const int3 ik = indexToWaveNumber(id, n);
+    const real3 dk = getGradientFourier(ik, n, L);
+    const complex3 g = in[id];
+    complex3 c;
+    c.xr = half * FMA(-dk.y, g.zi, dk.z * g.yi); c.xi = half * FMA(dk.y, g.zr, -(dk.z * g.yr));
+    c.yr = half * FMA(-dk.z, g.xi, dk.x * g.zi); c.yi = half * FMA(dk.z, g.xr, -(dk.x * g.zr));
+    c.zr = half * FMA(-dk.x, g.yi, dk.y * g.xi); c.zi = half * FMA(dk.x, g.yr, -(dk.y * g.xr));
+    if (accumulate) c3add(&out[id], c);
+    else out[id] = c;
+  }
+}

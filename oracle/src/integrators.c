@@ -192,3 +192,35 @@ ORACLE_API void oracle_saru_gf(uint s1, uint s2, uint s3, float mean, float std,
   Saru s = saru3(s1, s2, s3);
   for (int i = 0; i < npairs; i++) saru_gf(&s, mean, std, &out[2 * i], &out[2 * i + 1]);
 }
+
+/* FCM_ns::integrateEulerMaruyamaD (BDHI_FCM.cu:67-92) with orientations: dir = rotVec2Quaternion(angularV*dt) * dir
+ * (utils/quaternion.cuh:179-196; Quat product :86-96: (n1 n2 - v1.v2, n1 v2 + n2 v1 + v1 x v2)).  dir = (n, vx, vy, vz). */
+ORACLE_API void oracle_fcm_euler_maruyama_dir(real4 *pos, real4 *dir, const int *indexIterator, const real *linearV3,
+                                              const real *angularV3, int N, real dt) {
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    pos[i].x = FMA(linearV3[3 * id], dt, pos[i].x);
+    pos[i].y = FMA(linearV3[3 * id + 1], dt, pos[i].y);
+    pos[i].z = FMA(linearV3[3 * id + 2], dt, pos[i].z);
+    if (dir) {
+      real3 d = mk3(angularV3[3 * id] * dt, angularV3[3 * id + 1] * dt, angularV3[3 * id + 2] * dt);
+      const real phi = SQRT(dot3(d, d));
+      const real norm = dot3(d, d);
+      real qn = 1, qx = 0, qy = 0, qz = 0;
+      if (norm != (real)0.0) {
+        const real inv = (real)1.0 / SQRT(norm);
+        d.x *= inv; d.y *= inv; d.z *= inv;
+        const real c = COS(phi * (real)0.5), s = SIN(phi * (real)0.5);
+        qn = c; qx = s * d.x; qy = s * d.y; qz = s * d.z;
+      }
+      const real4 o = dir[i]; /* (n, v) */
+      const real n2 = o.x, vx = o.y, vy = o.z, vz = o.w;
+      real4 r;
+      r.x = qn * n2 - (qx * vx + qy * vy + qz * vz);
+      r.y = qn * vx + n2 * qx + (qy * vz - qz * vy);
+      r.z = qn * vy + n2 * qy + (qz * vx - qx * vz);
+      r.w = qn * vz + n2 * qz + (qx * vy - qy * vx);
+      dir[i] = r;
+    }
+  }
+}

@@ -95,6 +95,10 @@ SIGNATURES = {
     "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),
     "uammd_fcm_set_seed2": (_i, [_vp, _u]),
     "uammd_fcm_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "uammd_fcm_torque_gaussian_kernel": (_i, [_f, _f, _f, C.POINTER(IBMKernel)]),
+    "uammd_fcm_set_torque_kernel": (_i, [_vp, C.POINTER(IBMKernel)]),
+    "uammd_fcm_displacements_torque": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "uammd_fcm_euler_maruyama_dir": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "uammd_fcm_slab_create": (_i, [C.POINTER(FCMParameters), _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "uammd_fcm_slab_destroy": (_i, [_vp]),
     "uammd_fcm_slab_set_option": (_i, [_vp, C.c_char_p, _i]),

@@ -169,6 +169,24 @@ class FCM_impl:
                                                float(prefactor), _ptr(out), current_stream()))
         return out
 
+    def setTorqueKernel(self, kernelTorque=None, tolerance=1e-3):
+        """FCM_impl::Parameters::kernelTorque; default = detail::initializeKernelTorque (BDHI_FCM.cuh:69-80)."""
+        if kernelTorque is None:
+            h = min(float(np.float32(l) / np.float32(c)) for l, c in zip(self.box.boxSize, self.cells))
+            kernelTorque = IBMKernel()
+            check(self.lib.uammd_fcm_torque_gaussian_kernel(float(self.hydrodynamicRadius), h, float(tolerance), C.byref(kernelTorque)))
+        check(self.lib.uammd_fcm_set_torque_kernel(self.h, C.byref(kernelTorque)))
+        self.kernelTorque = kernelTorque
+        return kernelTorque
+
+    def computeHydrodynamicDisplacementsTorque(self, pos, force, torque, numberParticles, temperature, prefactor):
+        """FCM_impl::computeHydrodynamicDisplacements(pos, force, torque, ...) -> (linear real3[N], angular real3[N])."""
+        v = torch.empty((numberParticles, 3), dtype=torch.float32, device=pos.device)
+        w = torch.empty((numberParticles, 3), dtype=torch.float32, device=pos.device)
+        check(self.lib.uammd_fcm_displacements_torque(self.h, _ptr(pos), _ptr(force), _ptr(torque), int(numberParticles),
+                                                      float(temperature), float(prefactor), _ptr(v), _ptr(w), current_stream()))
+        return v, w
+
     def fourier_grid(self, pos, force, numberParticles, temperature, prefactor):
         """Test hook: the Fourier grid after the k-space kernel as complex3[nz,ny,nx/2+1,3]."""
         nkx = self.cells[0] // 2 + 1

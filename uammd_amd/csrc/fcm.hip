@@ -44,10 +44,12 @@ struct FCM {
   uammd_fcm_parameters par;
   GridT<float> grid;
   IBMKernelDev kern;
+  IBMKernelDev kernT{};    // torque window (FCM_ns::Kernels::GaussianTorque), set by uammd_fcm_set_torque_kernel
+  bool haveTorqueKernel = false;
   int nxpad = 0;           // 2*(nx/2+1)
   size_t planeReal = 0;    // floats per component plane
   size_t planeCplx = 0;    // complex per component plane
-  DeviceBuffer gridBuf, interBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
+  DeviceBuffer gridBuf, gridBufT, interBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
   bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
@@ -639,6 +641,32 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
   g2[a0] = make_float2(v.zr, v.zi);
 }
 
+// half * (i dk) x g on the planar complex grids: addTorqueCurl (ACC: out += ...) and computeVelocityCurlFourier (out = ...),
+// FCM_impl.cuh:306-327, :590-617.  dk has its unpaired (Nyquist) components zeroed (getGradientFourier).
+template <bool ACC>
+__global__ void __launch_bounds__(256) k_fcm_half_curl(const float2 *__restrict__ in, float2 *__restrict__ out, size_t planeC,
+                                                        int3 nk, real3f L, FastDiv divNkx, FastDiv divNy) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int nkx = nk.x / 2 + 1;
+  if (id >= nk.z * nk.y * nkx) return;
+  const uint tq = divNkx.div((uint)id), tz = divNy.div(tq);
+  const int cx = id - (int)tq * nkx, cy = (int)(tq - tz * (uint)nk.y), cz = (int)tz;
+  const int3 ik = make_int3(cx - nk.x * (cx >= nkx), cy - nk.y * (cy >= nk.y / 2 + 1), cz - nk.z * (cz >= nk.z / 2 + 1));
+  const real3f dk = gradient_fourier(ik, nk, wavevector(ik, L));
+  const float2 gx = in[id], gy = in[planeC + id], gz = in[2 * planeC + id];
+  const float h = 0.5f;
+  float2 cxv = make_float2(h * fmaf(-dk.y, gz.y, dk.z * gy.y), h * fmaf(dk.y, gz.x, -(dk.z * gy.x)));
+  float2 cyv = make_float2(h * fmaf(-dk.z, gx.y, dk.x * gz.y), h * fmaf(dk.z, gx.x, -(dk.x * gz.x)));
+  float2 czv = make_float2(h * fmaf(-dk.x, gy.y, dk.y * gx.y), h * fmaf(dk.x, gy.x, -(dk.y * gx.x)));
+  if (ACC) {
+    const float2 ox = out[id], oy = out[planeC + id], oz = out[2 * planeC + id];
+    cxv.x += ox.x; cxv.y += ox.y; cyv.x += oy.x; cyv.y += oy.y; czv.x += oz.x; czv.y += oz.y;
+  }
+  out[id] = cxv;
+  out[planeC + id] = cyv;
+  out[2 * planeC + id] = czv;
+}
+
 // test hook: interleave the planar complex grids into complex3[Nk]
 __global__ void k_fcm_export(const float2 *__restrict__ g0, size_t planeC, int total, float *__restrict__ out6) {
   const int id = blockIdx.x * 256 + threadIdx.x;
@@ -1183,6 +1211,103 @@ int uammd_pse_far_displacements(uammd_fcm *h, const float *d_pos, const float *d
   if (!f->pse.on) { set_last_error("uammd_pse_far_displacements: not a PSE far-field handle"); return -1; }
   f->seed2 = seed2;
   return uammd_fcm_displacements_staged(h, d_pos, d_force, N, temperature, prefactor, d_MF, 0, stream);
+}
+
+// ---- torques / rotation -------------------------------------------------------------------------------------
+// FCM_ns::Kernels::GaussianTorque(width = a / (6 sqrt(pi))^(1/3), h, tolerance): FCM_kernels.cuh:60-80, BDHI_FCM.cuh:69-80
+int uammd_fcm_torque_gaussian_kernel(float hydrodynamicRadius, float h, float tolerance, uammd_ibm_kernel *out) {
+  if (!out || !(h > 0) || !(tolerance > 0) || !(hydrodynamicRadius > 0)) { set_last_error("uammd_fcm_torque_gaussian_kernel: bad arguments"); return -1; }
+  const float width = (float)(hydrodynamicRadius / (std::pow(6 * std::sqrt(M_PI), 1 / 3.)));
+  const float prefactor = (float)std::pow(2.0 * M_PI * (double)width * (double)width, -0.5);
+  const float tau = (float)(-0.5 / ((double)width * (double)width));
+  const float dr = (float)(0.5 * h);
+  float r = dr;
+  while (prefactor * expf(tau * r * r) > tolerance) r += dr;
+  int support = (int)(2 * r / h + 0.5);
+  if (support < 3) support = 3;
+  out->kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+  out->support[0] = out->support[1] = out->support[2] = support;
+  out->prefactor = prefactor;
+  out->tau = tau;
+  out->rmax = (float)support * h;
+  out->invh[0] = out->invh[1] = out->invh[2] = 0.0f;
+  return 0;
+}
+
+int uammd_fcm_set_torque_kernel(uammd_fcm *h, const uammd_ibm_kernel *kernelTorque) {
+  if (!h || !kernelTorque) { set_last_error("uammd_fcm_set_torque_kernel: null argument"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  for (int a = 0; a < 3; ++a)
+    if (kernelTorque->support[a] < 1 || kernelTorque->support[a] > kMaxSupport || kernelTorque->support[a] >= f->par.cells[a]) {
+      set_last_error("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
+      return -2;
+    }
+  f->kernT = to_dev(*kernelTorque);
+  f->haveTorqueKernel = true;
+  return f->gridBufT.reserve(sizeof(float) * 3 * f->planeReal);
+}
+
+// FCM_impl::computeHydrodynamicDisplacements with torques (FCM_impl.cuh:652-693): d_torque real4[N] (NULL = the plain call);
+// d_angularVelocity real3[N] is OVERWRITTEN (only touched when d_torque is given).
+int uammd_fcm_displacements_torque(uammd_fcm *h, const float *d_pos, const float *d_force, const float *d_torque, int N,
+                                   float temperature, float prefactor, float *d_linearVelocity, float *d_angularVelocity,
+                                   void *stream) {
+  if (!d_torque) return uammd_fcm_displacements(h, d_pos, d_force, N, temperature, prefactor, d_linearVelocity, stream);
+  if (!h || !d_pos || !d_linearVelocity || !d_angularVelocity) { set_last_error("uammd_fcm_displacements_torque: null argument"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  if (!f->haveTorqueKernel) { set_last_error("uammd_fcm_displacements_torque: no torque kernel (uammd_fcm_set_torque_kernel)"); return -2; }
+  if (f->pse.on) { set_last_error("uammd_fcm_displacements_torque: not available for the PSE far field"); return -2; }
+  if (N <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  float *g = (float *)f->gridBuf.ptr, *gT = (float *)f->gridBufT.ptr;
+  const size_t zs = (size_t)f->nxpad * f->grid.cellDim.y;
+  const dim3 gp((N + 3) / 4), bp(256);
+  UH_ROCFFT(rocfft_execution_info_set_stream(f->info, (void *)st));
+  void *bufs[1] = {g}, *bufsT[1] = {gT};
+  const int total = (int)f->planeCplx;
+  const dim3 gk((total + 255) / 256);
+  const real3f L{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]};
+  const FastDiv dNkx = make_fastdiv(f->grid.cellDim.x / 2 + 1), dNy = make_fastdiv(f->grid.cellDim.y);
+  // forces (the generic one-wave-per-particle spread: the torque path is not the tuned one)
+  {
+    const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+    UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
+    if (d_force) {
+      hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, (float *)nullptr, g, N,
+                         f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
+      UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+    }
+  }
+  // torques: spread with the torque window, transform, add half the curl to the Fourier forces
+  const FastDiv tsx = make_fastdiv(f->kernT.support.x), tsxy = make_fastdiv(f->kernT.support.x * f->kernT.support.y);
+  UH_CHECK(hipMemsetAsync(gT, 0, sizeof(float) * 3 * f->planeReal, st));
+  hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_torque, (float *)nullptr, gT, N,
+                     f->grid, f->nxpad, f->planeReal, zs, f->kernT, tsx, tsxy, false);
+  UH_ROCFFT(rocfft_execute(f->fwd, bufsT, nullptr, f->info));
+  hipLaunchKernelGGL((k_fcm_half_curl<true>), gk, bp, 0, st, (const float2 *)gT, (float2 *)g, f->planeCplx, f->grid.cellDim, L, dNkx, dNy);
+  // Stokes + noise (the grid holds Fourier forces even when d_force is NULL: it was zeroed above)
+  float noisePrefactor = 0.0f;
+  if (temperature > 0.0f) {
+    f->seed2++;
+    const float fourierNormalization = (float)(1.0 / ((double)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z));
+    noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / f->grid.cellVolume);
+  }
+  const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y, dNkx, dNy};
+  hipLaunchKernelGGL(k_fcm_kspace, gk, bp, 0, st, (float2 *)g, lay, f->grid.cellDim, L, f->par.viscosity, true, noisePrefactor,
+                     f->par.seed, f->seed2, f->pse);
+  // angular velocity = half the curl of the velocity, interpolated with the torque window
+  hipLaunchKernelGGL((k_fcm_half_curl<false>), gk, bp, 0, st, (const float2 *)g, (float2 *)gT, f->planeCplx, f->grid.cellDim, L, dNkx, dNy);
+  UH_ROCFFT(rocfft_execute(f->inv, bufsT, nullptr, f->info));
+  hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, d_angularVelocity, gT, N,
+                     f->grid, f->nxpad, f->planeReal, zs, f->kernT, tsx, tsxy, false);
+  UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
+  {
+    const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+    hipLaunchKernelGGL((k_fcm_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, d_linearVelocity, g, N,
+                       f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
+  }
+  UH_CHECK(hipGetLastError());
+  return 0;
 }
 
 double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx) {

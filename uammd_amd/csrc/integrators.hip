@@ -189,6 +189,40 @@ __global__ void __launch_bounds__(kIB) k_bdhi_euler_maruyama(float4 *__restrict_
   pos[i] = p;
 }
 
+// FCM_ns::integrateEulerMaruyamaD with orientations (BDHI_FCM.cu:67-92): dir = rotVec2Quaternion(angularV dt) * dir
+__global__ void __launch_bounds__(kIB) k_fcm_euler_maruyama_dir(float4 *__restrict__ pos, float4 *__restrict__ dir,
+                                                                const int *__restrict__ index, const float *__restrict__ linearV,
+                                                                const float *__restrict__ angularV, int N, float dt) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  float4 p = pos[i];
+  p.x = fmaf(linearV[3 * id], dt, p.x);
+  p.y = fmaf(linearV[3 * id + 1], dt, p.y);
+  p.z = fmaf(linearV[3 * id + 2], dt, p.z);
+  pos[i] = p;
+  if (dir) {
+    float dx = angularV[3 * id] * dt, dy = angularV[3 * id + 1] * dt, dz = angularV[3 * id + 2] * dt;
+    const float norm = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    float qn = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    if (norm != 0.0f) {
+      const float phi = sqrtf(norm);
+      const float inv = 1.0f / phi;
+      dx *= inv; dy *= inv; dz *= inv;
+      float sn, cs;
+      sincosf(phi * 0.5f, &sn, &cs);
+      qn = cs; qx = sn * dx; qy = sn * dy; qz = sn * dz;
+    }
+    const float4 o = dir[i];  // (n, v)
+    float4 r;
+    r.x = qn * o.x - (qx * o.y + qy * o.z + qz * o.w);
+    r.y = qn * o.y + o.x * qx + (qy * o.w - qz * o.z);
+    r.z = qn * o.z + o.x * qy + (qz * o.y - qx * o.w);
+    r.w = qn * o.w + o.x * qz + (qx * o.z - qy * o.y);
+    dir[i] = r;
+  }
+}
+
 static inline int nb(int n) { return (n + kIB - 1) / kIB; }
 
 }  // namespace uammd_hip
@@ -271,6 +305,16 @@ int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_M
   if (K) for (int t = 0; t < 9; ++t) k.k[t] = K[t];
   hipLaunchKernelGGL(k_bdhi_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index, d_MF,
                      d_BdW, k, K != nullptr, N, sqrt2Tdt, dt, is2D != 0);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_fcm_euler_maruyama_dir(float *d_pos, float *d_dir, const int *d_index, const float *d_linearVelocity,
+                                 const float *d_angularVelocity, int N, float dt, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_linearVelocity || (d_dir && !d_angularVelocity)) { set_last_error("uammd_fcm_euler_maruyama_dir: null argument"); return -1; }
+  hipLaunchKernelGGL(k_fcm_euler_maruyama_dir, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, (float4 *)d_dir,
+                     d_index, d_linearVelocity, d_angularVelocity, N, dt);
   UH_CHECK(hipGetLastError());
   return 0;
 }
