@@ -46,7 +46,8 @@ void set_last_error(const char *fmt, ...) {
 // ---- small device buffer helper ----------------------------------------------------------------
 int DeviceBuffer::reserve(size_t bytes) {
   if (bytes <= cap) return 0;
-  if (ptr) UH_CHECK(hipFree(ptr));
+  if (ptr && owned) UH_CHECK(hipFree(ptr));
+  owned = true;
   ptr = nullptr;
   cap = 0;
   size_t want = bytes + bytes / 8 + 256;
@@ -55,7 +56,7 @@ int DeviceBuffer::reserve(size_t bytes) {
   return 0;
 }
 DeviceBuffer::~DeviceBuffer() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr && owned) (void)hipFree(ptr);
 }
 
 // utils/ParticleSorter.cuh:93-100 + :264-266 (clz by smearing; maxbit = 32 - clz(maxHash))
@@ -271,29 +272,30 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   if (int e = index.reserve(sizeof(int) * (size_t)(N + 1))) return e;
   // +4: the traversal kernels read candidates in groups of four from one base address (reads past a cell are masked)
   if (int e = sortPos.reserve(sizeof(float4) * (size_t)(N + 4))) return e;
-  if (int e = errorFlag.reserve(sizeof(int))) return e;
   numberParticlesBuilt = N;
 
   const uint maxHash = morton_hash(make_int3(grid.cellDim.x - 1, grid.cellDim.y - 1, grid.cellDim.z - 1));
   endBit = sort_end_bit(maxHash);
   nKeys = (endBit >= 31) ? 0u : (1u << endBit);  // number of distinct keys the grid can produce (pow2 envelope)
-  if (N == 0) return 0;
-  UH_CHECK(hipMemsetAsync(errorFlag.ptr, 0, sizeof(int), st));
-
   const bool tabulated = nKeys != 0 && nKeys <= (1u << 27);
-  if (tabulated) {
-    if (int e = keyOutside.reserve((size_t)nKeys + 16)) return e;
-    UH_CHECK(hipMemsetAsync(keyOutside.ptr, 0, (size_t)nKeys, st));
-  }
   // Counting-sort build when the key table is comparable to the particle count.
   const bool counting = forceRadix ? false : (nKeys != 0 && (unsigned long long)nKeys <= 8ull * (unsigned long long)N + 4096ull);
   usedCounting = counting;
+  {  // everything that must start at zero sits in one block: error flag, per-key "outside" flags, per-key counters
+    const size_t errB = 16, koB = tabulated ? (((size_t)nKeys + 16 + 15) & ~(size_t)15) : 0,
+                 kcB = counting ? sizeof(uint) * ((size_t)nKeys + 4) : 0;
+    if (int e = zeroBlock.reserve(errB + koB + kcB)) return e;
+    char *base = (char *)zeroBlock.ptr;
+    errorFlag.alias(base, errB);
+    keyOutside.alias(tabulated ? base + errB : nullptr, koB);
+    keyCount.alias(counting ? base + errB + koB : nullptr, kcB);
+    if (N == 0) { UH_CHECK(hipMemsetAsync(base, 0, errB, st)); return 0; }
+    UH_CHECK(hipMemsetAsync(base, 0, errB + koB + kcB, st));
+  }
   if (counting) {
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
-    if (int e = keyCount.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
     if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
-    UH_CHECK(hipMemsetAsync(keyCount.ptr, 0, sizeof(uint) * ((size_t)nKeys + 1), st));
     hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                        (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr,
                        (unsigned char *)keyOutside.ptr);

@@ -10,7 +10,9 @@ namespace uammd_hip {
 struct DeviceBuffer {
   void *ptr = nullptr;
   size_t cap = 0;
+  bool owned = true;
   int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
+  void alias(void *p, size_t bytes) { ptr = p; cap = bytes; owned = false; }  // a view into another buffer
   ~DeviceBuffer();
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer &) = delete;
@@ -22,6 +24,7 @@ struct CellList {
   DeviceBuffer hash, sortHash, index, indexAlt, sortPos, cellStart, cellEnd, errorFlag;
   // counting-sort build state
   DeviceBuffer keyCount, keyStart, provRank, members, scratch, keyOutside, cellOutside;
+  DeviceBuffer zeroBlock;  // errorFlag | keyOutside | keyCount live here: ONE memset per build instead of three
   GridT<float> grid{};
   float boxL[3] = {0, 0, 0};
   int boxPeriodic[3] = {0, 0, 0};
