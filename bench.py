@@ -515,6 +515,24 @@ def main():
                      "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "hbm_frac_streamed_neighbour_model": BYTES_STREAMED_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
     }
+    if args.workload == "both" and args.nl == "cell" and world == 1:
+        # the same box with the reference benchmark's neighbour list (examples/misc/benchmark.cu:82-84): extra information,
+        # `value` above stays the CellList configuration BASELINE.json names
+        del pd, verlet, pf, timer
+        pd2, _, _, verlet2, pf2, _ = lj_setup(hip, n, L, seed=1234, nl="verlet")
+        for _ in range(150):
+            verlet2.forwardTime()
+        pd2.sortParticles()
+        torch.cuda.synchronize()
+        r0 = pf2.nl.rebuilds
+        t1 = time.perf_counter()
+        for _ in range(300):
+            verlet2.forwardTime()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t1
+        out["lj_verletlist"] = {"ms_per_step": t1 / 300 * 1e3, "value": n * 300 / t1, "unit": "particle-steps/s", "steps": 300,
+                                "list_rebuilds": pf2.nl.rebuilds - r0, "cutOffMultiplier": 1.08}
+        del pd2, verlet2, pf2
     if args.workload == "both":
         fcm = run_fcm(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -48,7 +48,8 @@ __global__ void __launch_bounds__(128) k_verlet_fill(const float4 *__restrict__ 
                                                       const int *__restrict__ cellEnd, uint validCell, int N,
                                                       GridT<float> grid, BoxT<float> box, float cutOff2,
                                                       int maxNeighboursPerParticle, int *__restrict__ neighbourList,
-                                                      int *__restrict__ numberNeighbours, int *__restrict__ tooManyFlag) {
+                                                      int *__restrict__ numberNeighbours, int *__restrict__ tooManyFlag,
+                                                      const unsigned char *__restrict__ cellOutside) {
   __shared__ int q[kFillQCap * 128];
   const int idRaw = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
   const bool valid = idRaw < N;
@@ -61,6 +62,14 @@ __global__ void __launch_bounds__(128) k_verlet_fill(const float4 *__restrict__ 
   const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
   int base = 0, cnt = 0;  // rows [0, base) are stored, rows [base, base + cnt) are in the FIFO
   bool overflow = false;
+  // exact minimum-image skipping, as in the force traversal (lj.hip walk_global): for direct, unwrapped neighbour cells on a
+  // >= 5-cell grid whose particles are stored inside the primary box the image offset is exactly zero
+  const bool sameBox = box.boxSize.x == grid.box.boxSize.x && box.boxSize.y == grid.box.boxSize.y &&
+                       box.boxSize.z == grid.box.boxSize.z && box.px() == grid.box.px() && box.py() == grid.box.py() &&
+                       box.pz() == grid.box.pz();
+  const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5 || !cellOutside || !sameBox;
+  const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
+  const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
   int *mine = neighbourList + id;
   auto flush = [&]() {
     int kmin = cnt > 0 ? base : 0x7fffffff, kmax = cnt > 0 ? base + cnt : 0;
@@ -81,18 +90,24 @@ __global__ void __launch_bounds__(128) k_verlet_fill(const float4 *__restrict__ 
     if (npx > 1) cellj.x += cc % 3 - 1;
     if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
     if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    const int3 raw = cellj;
     cellj.x = grid.pbc_x(cellj.x);
     cellj.y = grid.pbc_y(cellj.y);
     cellj.z = grid.pbc_z(cellj.z);
     // outside a non periodic box: no such cell (DESIGN.md "non-periodic neighbours")
     const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
     int first = 0, last = 0;
+    bool needPBC = false;
     if (exists) {
       const int icellj = grid.getCellIndex(cellj);
       const uint cs = cellStart[icellj];
-      if (cs >= validCell) { first = (int)(cs - validCell); last = cellEnd[icellj]; }
+      if (cs >= validCell) {
+        first = (int)(cs - validCell);
+        last = cellEnd[icellj];
+        needPBC = smallGrid || iOut || raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z || cellOutside[icellj] != 0;
+      }
     }
-    const int l1 = last - 1;
+    const bool wavePBC = __any(needPBC);
     // all lanes iterate together (the FIFO flush is a wave-level operation): up to the longest cell of the wave
     int len = last - first;
 #pragma unroll
@@ -101,10 +116,16 @@ __global__ void __launch_bounds__(128) k_verlet_fill(const float4 *__restrict__ 
       if (__any(cnt > kFillQCap - 4)) flush();
       const int j = first + s;
       if (j < last) {
-        const float4 c0 = sortPos[j], c1 = sortPos[min(j + 1, l1)], c2 = sortPos[min(j + 2, l1)], c3 = sortPos[min(j + 3, l1)];
-        const float d0 = lj_dist2<true>(box, pi, c0), d1 = lj_dist2<true>(box, pi, c1);
-        const float d2 = lj_dist2<true>(box, pi, c2), d3 = lj_dist2<true>(box, pi, c3);
-        const float dd[4] = {d0, d1, d2, d3};
+        const float4 *__restrict__ pj = sortPos + j;  // reads past the cell are masked below (the array has 4 spare entries)
+        const float4 c0 = pj[0], c1 = pj[1], c2 = pj[2], c3 = pj[3];
+        float dd[4];
+        if (wavePBC) {
+          dd[0] = lj_dist2<true>(box, pi, c0); dd[1] = lj_dist2<true>(box, pi, c1);
+          dd[2] = lj_dist2<true>(box, pi, c2); dd[3] = lj_dist2<true>(box, pi, c3);
+        } else {
+          dd[0] = lj_dist2<false>(box, pi, c0); dd[1] = lj_dist2<false>(box, pi, c1);
+          dd[2] = lj_dist2<false>(box, pi, c2); dd[3] = lj_dist2<false>(box, pi, c3);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (j + u < last && dd[u] <= cutOff2 && !overflow) {
@@ -215,7 +236,7 @@ static int verlet_rebuild(VerletList *v, hipStream_t st) {
     hipLaunchKernelGGL(k_verlet_fill, dim3((N + 127) / 128), dim3(128), 0, st, (const float4 *)v->cl.sortPos.ptr,
                        (const uint *)v->cl.cellStart.ptr, (const int *)v->cl.cellEnd.ptr, v->cl.validCell, N, v->cl.grid, box,
                        rcut * rcut, v->maxNeighboursPerParticle, (int *)v->neighbourList.ptr, (int *)v->numberNeighbours.ptr,
-                       (int *)v->flags.ptr + 1);
+                       (int *)v->flags.ptr + 1, v->cl.haveCellOutside ? (const unsigned char *)v->cl.cellOutside.ptr : nullptr);
     UH_CHECK(hipGetLastError());
     uint flag = 0;
     if (int e = verlet_read_flag(v, 1, st, &flag)) return e;
