@@ -313,7 +313,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
     L1 = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
     rc, dt, T = 2.5, 0.005, 1.0
     noise = math.sqrt(2 * dt * 1.0 * T)
-    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world)
+    # cached exchange: skin 0.4 sigma, ownership + halo lists refreshed every 10 steps (|v_z| dt * 10 < 0.3 at T = 1)
+    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=args.skin)
     pos = torch.from_numpy(lattice(n, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
     vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, math.sqrt(3 * T), 0, n, 77 + rank, None))
@@ -327,6 +328,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
         box = hip.Box(box_L, periodic)
         cd, ubox = hip.CellList.create_update_grid(box, rc)
         cl.update_grid(allpos.contiguous(), ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
         f = torch.zeros((allpos.shape[0], 4), dtype=torch.float32, device=allpos.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -340,17 +342,35 @@ def run_lj_distributed(hip, args, world, rank, dist):
                                      1.0, None, p.shape[0], dt, 1.0, 0, noise, step_num, 4242 + rank,
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    sim = DistributedLJ(d, forces_fn, integrate_fn)
+    sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every)
     force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    sorter = hip.CellList()
+
+    def sort_owned(pos, vel, force, ids):
+        """ParticleData::sortParticles on the owned particles (examples/misc/benchmark.cu:154-156 does it every 500 steps):
+        Morton order on a coarse grid of the local frame keeps the per-step cell-list build and the traversal coherent."""
+        if os.environ.get("UAMMD_BENCH_NOSORT") == "1":
+            return pos, vel, force, ids
+        bl, per = d.local_box()
+        cd = [max(1, int(x / 10.0)) for x in bl]
+        sorter.update_grid(pos.contiguous(), hip.Box(bl, per), cd)
+        order = sorter.group_index().long()
+        sim.reordered()
+        return pos[order].contiguous(), vel[order].contiguous(), force[order].contiguous(), ids[order].contiguous()
+
+    pos, vel, force, ids = sort_owned(pos, vel, force, ids)
     for _ in range(args.warmup):
         pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
+    pos, vel, force, ids = sort_owned(pos, vel, force, ids)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     trav_events.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for j in range(args.steps):
+        if j > 0 and j % 500 == 0:
+            pos, vel, force, ids = sort_owned(pos, vel, force, ids)
         pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
     torch.cuda.synchronize()
     if dist is not None:
@@ -368,6 +388,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
         total = float(pos.shape[0])
     assert torch.isfinite(pos).all()
     assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
+    sim.check_skin()
     k_ms = sum(a.elapsed_time(b) for a, b in trav_events) / max(1, len(trav_events))
     return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
 
@@ -390,6 +411,8 @@ def main():
     ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
                     help="neighbour list of PairForces: CellList (BASELINE configs[2], default) or VerletList (the "
                          "reference's examples/misc/benchmark.cu default)")
+    ap.add_argument("--skin", type=float, default=0.4, help="slab decomposition: skin of the cached halo exchange (0 = exchange sizes every step)")
+    ap.add_argument("--exchange-every", type=int, default=10, help="slab decomposition: steps between ownership / halo-list refreshes")
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
 

@@ -69,7 +69,9 @@ int uammd_celllist_create_grid(const float L[3], const int periodic[3], const fl
 int uammd_celllist_update(uammd_celllist *h, const float *d_pos, int numberParticles, const float L[3],
                           const int periodic[3], const int cellDim[3], void *stream);
 int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out);
-/* test/tuning hooks: "force_radix" = 1 makes the build use the stable radix sort path */
+/* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
+ * particles with input index >= n as ghosts of a domain decomposition: they are neighbours of the others but the LJ
+ * traversal computes nothing for them (n < 0 turns it off) */
 int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value);
 /* library-wide tunables: "lj_brick_bits" in 3..6 (cells per LDS brick = 2^k) */
 int uammd_hip_set_tunable(const char *name, int value);

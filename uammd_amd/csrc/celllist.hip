@@ -412,6 +412,7 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_celllist_set_option: null argument"); return -1; }
   CellList *cl = reinterpret_cast<CellList *>(h);
   if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
+  if (std::string(name) == "num_owned") { cl->numOwned = value < 0 ? 0x7fffffff : value; return 0; }
   set_last_error("uammd_celllist_set_option: unknown option %s", name);
   return -1;
 }

@@ -39,6 +39,7 @@ struct CellList {
   bool haveCellOutside = false;
   bool usedCounting = false;
   bool forceRadix = false;  // test hook: always take the rocPRIM radix path
+  int numOwned = 0x7fffffff;  // traversal option: particles with input index >= numOwned are ghosts (neighbours only, no output)
 
   int next_valid_cell(int numberParticles, bool *needsClear);
   int update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3], const int cellDim[3],

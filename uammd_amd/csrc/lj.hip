@@ -99,6 +99,7 @@ struct ListView {
   const unsigned char *cellOutside;  // per linear cell: some particle stored outside the primary box (nullable)
   uint validCell;
   int N;
+  int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
 };
 
 constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> gr
   const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
   if (id >= cl.N) return;
   const int gi = cl.groupIndex[id];
+  if (gi >= cl.numOwned) return;  // a ghost: ghost cells are whole waves at the slab faces, so this skips their walks
   const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
   const float4 pi = cl.sortPos[id];
   LJParams p1 = tbl[0];
@@ -738,6 +740,11 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
   cl.cellOutside = h->haveCellOutside ? (const unsigned char *)h->cellOutside.ptr : nullptr;
   cl.validCell = h->validCell;
   cl.N = h->numberParticlesBuilt;
+  cl.numOwned = h->numOwned;
+  if (h->numOwned != 0x7fffffff && algo != UAMMD_LJ_ALGO_AUTO && algo != UAMMD_LJ_ALGO_GENERAL) {
+    set_last_error("uammd_lj_transverse_celllist: the num_owned option is implemented by the general kernel only");
+    return -3;
+  }
   const GridT<float> &g = h->grid;
   const bool brickOK = h->haveKeyStart && g.box.px() && g.box.py() && g.box.pz() && g.cellDim.x >= 4 &&
                        g.cellDim.y >= 4 && g.cellDim.z >= 4 && (NT1 || ntypes <= kMaxTypesLds);

@@ -20,15 +20,22 @@ import torch.distributed as dist
 
 
 class SlabDecomposition:
-    def __init__(self, L, rc, rank=None, world=None, group=None):
+    def __init__(self, L, rc, rank=None, world=None, group=None, skin=0.0):
+        """skin = delta > 0 turns on the cached exchange: ownership and the halo membership lists are refreshed only every
+        few steps (DistributedLJ.exchange_every), in between a rank re-sends the CURRENT positions of the listed particles —
+        no size messages, no host synchronisation.  Valid while no particle moves more than delta between refreshes: the
+        lists then hold everything within rc + 3 delta of a face (owners may sit up to delta outside their slab, so may the
+        particle that needs them, and a listed particle may drift delta itself), and the local box is rc + 4 delta thick."""
         self.group = group
+        self.skin = float(skin)
+        self._halo_cache = None
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.L = [float(x) for x in L]
         self.rc = float(rc)
         self.width = self.L[2] / self.world
-        if self.world > 1 and self.width < self.rc:
-            raise ValueError("slab thinner than the cut-off: halo would need second neighbours")
+        if self.world > 1 and self.width < self.rc + 3.0 * self.skin:
+            raise ValueError("slab thinner than the cut-off (+ skin): halo would need second neighbours")
         self.zlo = -self.L[2] / 2 + self.rank * self.width
         self.zhi = self.zlo + self.width
         self.zc = 0.5 * (self.zlo + self.zhi)
@@ -48,7 +55,7 @@ class SlabDecomposition:
     def local_box(self):
         """(L, periodic) of the local frame."""
         # 1 % slack so that a ghost sitting exactly on the halo face (or rounded one ulp past it) is still inside
-        return [self.L[0], self.L[1], self.width + 2.02 * self.rc], [True, True, False]
+        return [self.L[0], self.L[1], self.width + 2.02 * (self.rc + 4.0 * self.skin)], [True, True, False]
 
     def to_local(self, pos):
         """Global coordinates -> local frame (z relative to the slab centre, image nearest to the slab)."""
@@ -64,9 +71,9 @@ class SlabDecomposition:
     def _counts(self, mask_up, mask_down):
         """-> (n_to_up, n_to_down, n_from_down, n_from_up) as host ints, one device->host sync."""
         mine = torch.stack([mask_up.sum(), mask_down.sum()])
-        if self.world == 1:
+        if self.world == 1:  # the only rank is its own neighbour on both sides (periodic images through the loop-back)
             a, b = mine.tolist()
-            return a, b, 0, 0
+            return a, b, a, b
         # whole tensors, not views, as message buffers (a backend that stages through the host may not write a view back)
         to_up, to_down = self._wire(mine[0:1].clone()), self._wire(mine[1:2].clone())
         from_down, from_up = torch.zeros_like(to_up), torch.zeros_like(to_up)
@@ -88,15 +95,19 @@ class SlabDecomposition:
         return t
 
     @staticmethod
+    def _index(mask, count):
+        """Indices of the set entries of `mask` when their number is already known on the host (no sync)."""
+        if count == 0:
+            return torch.zeros(0, dtype=torch.int64, device=mask.device)
+        try:
+            return torch.nonzero_static(mask, size=count).flatten()
+        except (RuntimeError, NotImplementedError):
+            return torch.nonzero(mask).flatten()
+
+    @staticmethod
     def _select(rows, mask, count):
         """rows[mask] when the number of hits is already known on the host (no sync)."""
-        if count == 0:
-            return rows.new_zeros((0,) + tuple(rows.shape[1:]))
-        try:
-            idx = torch.nonzero_static(mask, size=count).flatten()
-        except (RuntimeError, NotImplementedError):
-            idx = torch.nonzero(mask).flatten()
-        return rows.index_select(0, idx)
+        return rows.index_select(0, SlabDecomposition._index(mask, count))
 
     def _exchange(self, send_up, send_down, n_from_down, n_from_up):
         """Sends `send_up` to rank+1 and `send_down` to rank-1, returns (from_down, from_up).  Rows are float32; the
@@ -104,7 +115,7 @@ class SlabDecomposition:
         ncol = send_up.shape[1]
         dev = send_up.device
         if self.world == 1:
-            return send_up.new_empty((0, ncol)), send_up.new_empty((0, ncol))
+            return send_up, send_down
         send_up, send_down = self._wire(send_up), self._wire(send_down)
         from_down = torch.empty((n_from_down, ncol), dtype=send_up.dtype, device=send_up.device)
         from_up = torch.empty((n_from_up, ncol), dtype=send_up.dtype, device=send_up.device)
@@ -126,18 +137,23 @@ class SlabDecomposition:
         return from_down.to(dev), from_up.to(dev)
 
     # ---- halo ---------------------------------------------------------------------------------------------
-    def halo_exchange(self, pos_local):
-        """pos_local: real4[N] of the OWNED particles in the local frame (|z'| <= width/2).  Returns real4[N+G]:
-        owned particles followed by the ghosts received from below and above, already shifted into this frame."""
-        if self.world == 1:
-            return pos_local, 0
-        z = pos_local[:, 2]
+    def halo_exchange(self, pos_local, refresh=True):
+        """pos_local: real4[N] of the OWNED particles in the local frame.  Returns real4[N+G]: owned particles followed by
+        the ghosts received from below and above, already shifted into this frame.  refresh=False re-uses the membership
+        lists (and the message sizes) of the last refresh: nothing but the payload moves, and nothing synchronises."""
         half = 0.5 * self.width
-        up_mask = z >= half - self.rc
-        down_mask = z < -half + self.rc
-        n_up, n_down, n_from_down, n_from_up = self._counts(up_mask, down_mask)
-        send_up = self._select(pos_local, up_mask, n_up)
-        send_down = self._select(pos_local, down_mask, n_down)
+        reach = self.rc + 3.0 * self.skin
+        if refresh or self._halo_cache is None:
+            z = pos_local[:, 2]
+            up_mask = z >= half - reach
+            down_mask = z < -half + reach
+            n_up, n_down, n_from_down, n_from_up = self._counts(up_mask, down_mask)
+            idx_up = self._index(up_mask, n_up)
+            idx_down = self._index(down_mask, n_down)
+            self._halo_cache = (idx_up, idx_down, n_from_down, n_from_up)
+        idx_up, idx_down, n_from_down, n_from_up = self._halo_cache
+        send_up = pos_local.index_select(0, idx_up)
+        send_down = pos_local.index_select(0, idx_down)
         # into the receiver's frame: its centre is one slab width above / below mine
         send_up[:, 2] -= self.width
         send_down[:, 2] += self.width
@@ -148,13 +164,12 @@ class SlabDecomposition:
     def migrate(self, pos_local, *others):
         """Moves the particles that left the slab (|z'| > width/2 after integration) to the neighbour ranks together
         with the per-particle arrays in `others` (vel, id, ...).  Returns the new (pos_local, *others)."""
-        if self.world == 1:
-            return (pos_local,) + tuple(others)
         z = pos_local[:, 2]
         half = 0.5 * self.width
         go_up = z >= half
         go_down = z < -half
         n_up, n_down, n_from_down, n_from_up = self._counts(go_up, go_down)
+        self._halo_cache = None  # ownership changes: the membership lists are stale
         # int32 arrays (particle ids) travel bit-cast to float32 in the same message
         cols = [pos_local] + [(o.to(torch.int32).view(torch.float32) if o.dtype != torch.float32 else o).reshape(o.shape[0], -1)
                               for o in others]
@@ -190,13 +205,16 @@ class DistributedLJ:
     returns real4 forces for every row of pos_all (owned + ghosts); `integrate_fn(step, pos, vel, force, step_num)` is
     the GJ kernel on the owned particles."""
 
-    def __init__(self, decomp, forces_fn, integrate_fn):
+    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1):
         self.d, self.forces_fn, self.integrate_fn = decomp, forces_fn, integrate_fn
         self.steps = 0
+        self.exchange_every = int(exchange_every) if decomp.skin > 0 else 1
+        self.max_drift = None   # device scalar: largest excursion outside the slab seen at a refresh (skin check)
 
-    def compute_forces(self, pos_local):
-        allpos, nghost = self.d.halo_exchange(pos_local)
+    def compute_forces(self, pos_local, refresh=True):
+        allpos, nghost = self.d.halo_exchange(pos_local, refresh)
         L, per = self.d.local_box()
+        self.n_owned = pos_local.shape[0]  # rows [n_owned, ...) of allpos are ghosts: forces_fn may skip their forces
         f = self.forces_fn(allpos, L, per)
         return f[:pos_local.shape[0]]
 
@@ -206,7 +224,21 @@ class DistributedLJ:
         if self.steps == 1:
             force = self.compute_forces(pos)
         self.integrate_fn(1, pos, vel, force, self.steps)
-        pos, vel, ids = self.d.migrate(pos, vel, ids)
-        force = self.compute_forces(pos)
+        refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
+        if refresh:
+            if self.d.skin > 0:  # how far outside its slab did the worst particle get since the last refresh?
+                self.max_drift = (pos[:, 2].abs().max() - 0.5 * self.d.width).clamp(min=0.0)
+            pos, vel, ids = self.d.migrate(pos, vel, ids)
+        force = self.compute_forces(pos, refresh)
         self.integrate_fn(2, pos, vel, force, self.steps)
         return pos, vel, force, ids
+
+    def reordered(self):
+        """Call after permuting the owned arrays (a sort): the cached membership lists index the old order."""
+        self.d._halo_cache = None
+
+    def check_skin(self):
+        """Host check (synchronises): the cached exchange is exact only if nobody out-ran the skin."""
+        if self.max_drift is not None and float(self.max_drift) > self.d.skin:
+            raise RuntimeError(f"a particle moved {float(self.max_drift):.3f} outside its slab between refreshes, more than the "
+                               f"skin {self.d.skin}: lower exchange_every or raise the skin")
