@@ -236,7 +236,8 @@ def run_fcm_distributed(hip, args, world, rank, dist):
     force[:, :3] = np.random.default_rng(4321 + rank).normal(0, 1, (n, 3))
     pos, force = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
     ids = torch.arange(n, dtype=torch.int32, device="cuda") + rank * n
-    integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, T, dt, lambda p, i, f: f)
+    # thermal steps are ~0.03 h: with 3 spare halo planes the particles are re-assigned to their slabs every 20 steps
+    integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, T, dt, lambda p, i, f: f, migrate_every=20)
     for _ in range(args.fcm_warmup):
         pos, ids, force = integ.forward_time(pos, ids, force)
     torch.cuda.synchronize()
@@ -259,6 +260,7 @@ def run_fcm_distributed(hip, args, world, rank, dist):
         el = float(t.item())
     assert torch.isfinite(pos).all()
     assert abs(float(cnt.item()) - n * world) < 0.5, "particles were lost or duplicated in migration"
+    integ.check_drift()
     ms = el / args.fcm_steps * 1e3
     nbytes = fcm_bytes_per_step(n * world, cells)
     gbs = nbytes / (ms * 1e-3) / 1e9

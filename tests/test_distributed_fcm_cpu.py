@@ -28,6 +28,7 @@ def _free_port():
 
 
 def _config():
+    global CELLS, LBOX
     rng = np.random.default_rng(11)
     pos = np.zeros((NPART, 4), np.float32)
     pos[:, :3] = rng.uniform(-0.5, 0.5, (NPART, 3)) * np.asarray(LBOX, np.float32)
@@ -110,7 +111,10 @@ def _reference(temperature, prefactor, ncalls):
     return [f.displacements(pos, force, temperature, prefactor) for _ in range(ncalls)], f
 
 
-def _worker(rank, world, port, out_dir, temperature, prefactor, ncalls):
+def _worker(rank, world, port, out_dir, temperature, prefactor, ncalls, cells=None, every=1):
+    global CELLS, LBOX
+    if cells is not None:
+        CELLS, LBOX = list(cells), [float(c) for c in cells]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -128,13 +132,14 @@ def _worker(rank, world, port, out_dir, temperature, prefactor, ncalls):
         fcm = DistributedFCM(geom, [back], [rank])
         vs = [fcm.displacements([lpos], [lforce], temperature, prefactor)[0].numpy().copy() for _ in range(ncalls)]
         # a few deterministic Euler-Maruyama steps with a large dt: particles cross slab faces and migrate with their forces
-        integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, 0.0, 2.0, lambda p, i, f: f)
+        integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, 0.0, 2.0, lambda p, i, f: f, migrate_every=every)
         p, i, f = lpos.clone(), ids.clone(), lforce.clone()
         nmig = 0
-        for _ in range(3):
+        for _ in range(4 if every > 1 else 3):
             before = set(i.tolist())
             p, i, f = integ.forward_time(p, i, f)
             nmig += len(set(i.tolist()) - before)
+        integ.check_drift()
         gp = p.clone()
         gp[:, 2] += d.zc
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ids=ids.numpy(), v=np.stack(vs), ids_end=i.numpy(), pos_end=gp.numpy(),
@@ -143,8 +148,21 @@ def _worker(rank, world, port, out_dir, temperature, prefactor, ncalls):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,temperature", [(2, 0.0), (2, 0.8), (3, 0.8)])
-def test_slab_fcm_matches_single_domain(world, temperature, tmp_path):
+@pytest.mark.parametrize("world,temperature,cells,every", [(2, 0.0, None, 1), (2, 0.8, None, 1), (3, 0.8, None, 1),
+                                                            (2, 0.0, (16, 16, 32), 2)])
+def test_slab_fcm_matches_single_domain(world, temperature, cells, every, tmp_path):
+    """The last case has a tile-sized halo (3 spare planes): particles are re-assigned to their slabs every 2nd step only."""
+    global CELLS, LBOX
+    saved = (CELLS, LBOX)
+    if cells is not None:
+        CELLS, LBOX = list(cells), [float(c) for c in cells]
+    try:
+        _run_case(world, temperature, cells, every, tmp_path)
+    finally:
+        CELLS, LBOX = saved
+
+
+def _run_case(world, temperature, cells, every, tmp_path):
     prefactor, ncalls = 2.0, 2
     v_ref, f = _reference(temperature, prefactor, ncalls)
     # single-domain Euler-Maruyama reference for the migration part (T = 0, dt = 2, 3 steps)
@@ -154,11 +172,11 @@ def test_slab_fcm_matches_single_domain(world, temperature, tmp_path):
     pos, force = _config()
     fo = FCMOracle(o, LBOX, CELLS, tolerance=TOL, viscosity=VISC, seed=SEED)
     p_ref = pos.copy()
-    for _ in range(3):
+    for _ in range(4 if every > 1 else 3):
         v = fo.displacements(p_ref, force, 0.0, 0.0)
         p_ref[:, :3] += v * np.float32(2.0)
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), temperature, prefactor, ncalls), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), temperature, prefactor, ncalls, cells, every), nprocs=world, join=True)
     seen, seen_end, nmig = [], [], 0
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
@@ -179,9 +197,9 @@ def test_slab_fcm_matches_single_domain(world, temperature, tmp_path):
 def test_geometry():
     from uammd_amd.parallel_fcm import SlabGeometry
     g = SlabGeometry([128, 128, 256], [128.0, 128.0, 256.0], 8, 6)
-    assert (g.nzl, g.nyl, g.he, g.halo, g.nzw) == (32, 16, 5, 8, 48)      # whole 8-node tiles in the window
+    assert (g.nzl, g.nyl, g.he, g.halo, g.nzw, g.drift_planes) == (32, 16, 8, 8, 48, 3)   # whole 8-node tiles in the window
     g = SlabGeometry([36, 36, 36], [36.0] * 3, 2, 6)
-    assert (g.halo, g.nzw) == (5, 28)                                     # not tileable: halo = stencil reach
+    assert (g.halo, g.nzw, g.drift_planes) == (5, 28, 0)                  # not tileable: halo = stencil reach
     with pytest.raises(ValueError):
         SlabGeometry([32, 32, 30], [1.0] * 3, 4, 6)
     with pytest.raises(ValueError):

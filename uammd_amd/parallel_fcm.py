@@ -50,6 +50,10 @@ class SlabGeometry:
         # the window keeps whole tiles when the tile-owned spread kernel can be used (cells % tile == 0)
         tiled = nx % tile == 0 and ny % tile == 0 and self.nzl % tile == 0
         self.halo = -(-self.he // tile) * tile if tiled else self.he
+        # planes actually exchanged: the whole halo.  The spare planes beyond the stencil reach (3 when the halo is rounded up
+        # to a tile) let an owned particle sit that far outside its slab, so migration need not run every step.
+        self.drift_planes = self.halo - self.he
+        self.he = self.halo
         if self.nzl < self.he:
             raise ValueError("slab thinner than the spreading stencil: halo would need second neighbours")
         self.nzw = self.nzl + 2 * self.halo
@@ -233,17 +237,33 @@ class DistributedFCMIntegrator:
     pos += v dt -> migrate.  `forces_fn(pos_local, *carried) -> real4[N]` is the Interactor stack (None: noise only);
     `carried` are per-particle arrays (ids, fixed forces, ...) that migrate with the particles."""
 
-    def __init__(self, fcm, decomp, temperature, dt, forces_fn):
+    def __init__(self, fcm, decomp, temperature, dt, forces_fn, migrate_every=1):
         self.fcm, self.d = fcm, decomp
         self.temperature, self.dt, self.forces_fn = float(temperature), float(dt), forces_fn
         self.steps = 0
+        # with spare halo planes the owned particles may overshoot their slab for a while: migrate (one host sync, a repack
+        # of every per-particle array) only every `migrate_every` steps; check_drift() verifies that it was enough
+        self.migrate_every = int(migrate_every) if fcm.g.drift_planes > 0 else 1
+        self.max_drift = None
 
     def forward_time(self, pos_local, *carried):
         self.steps += 1
         force = self.forces_fn(pos_local, *carried)
         v = self.fcm.displacements([pos_local], [force], self.temperature, 1.0 / self.dt ** 0.5)[0]
         pos_local[:, :3] += v * self.dt                      # integrateEulerMaruyamaD, BDHI_FCM.cu:67-92
-        return self.d.migrate(pos_local, *carried)
+        if self.steps % self.migrate_every == 0:
+            if self.migrate_every > 1:
+                self.max_drift = (pos_local[:, 2].abs().max() - 0.5 * self.d.width).clamp(min=0.0)
+            return self.d.migrate(pos_local, *carried)
+        return (pos_local,) + tuple(carried)
+
+    def check_drift(self):
+        """Host check (synchronises): no particle may have left its slab by more than the spare halo planes allow."""
+        g = self.fcm.g
+        allowed = (g.drift_planes - 0.5) * g.L[2] / g.cells[2]
+        if self.max_drift is not None and float(self.max_drift) > allowed:
+            raise RuntimeError(f"a particle moved {float(self.max_drift):.3f} outside its slab between migrations, more than the "
+                               f"{allowed:.3f} the spare halo planes allow: lower migrate_every")
 
 
 def make_decomposition(geom, rank, group=None):
