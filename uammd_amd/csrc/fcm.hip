@@ -1080,7 +1080,14 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
       hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), dim3(256), 0, st, d_vel, d_grid,
                          f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, f->grid.cellVolume, dsx, dsxy,
                          pr, f->accumulate);
-    else
+    else if (f->interGather) {
+      const size_t nodes = (size_t)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z;
+      if (int e = f->interBuf.reserve(sizeof(float4) * nodes)) return e;
+      hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, st, d_grid, f->grid.cellDim,
+                         f->nxpad, f->planeReal, zs, (float4 *)f->interBuf.ptr);
+      hipLaunchKernelGGL(k_fcm_gather_inter, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, (const float4 *)f->interBuf.ptr, N,
+                         f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+    } else
       hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   } else {
