@@ -39,6 +39,7 @@ struct CellList {
   bool haveCellOutside = false;
   bool usedCounting = false;
   bool forceRadix = false;  // test hook: always take the rocPRIM radix path
+  bool aggregateHash = true;  // k_hash_agg (LDS-aggregated histogram) instead of one global atomic per particle
   int numOwned = 0x7fffffff;  // traversal option: particles with input index >= numOwned are ghosts (neighbours only, no output)
 
   int next_valid_cell(int numberParticles, bool *needsClear);
