@@ -110,7 +110,7 @@ ORACLE_API void oracle_verletnvt_initial_velocities(real *vel3, const int *index
     double nx, ny, nz = 0.0, tmp;
     saru_gd(&rng, 0, (double)vamp / mass_i, &nx, &ny);
     if (!is2D) saru_gd(&rng, 0, (double)vamp / mass_i, &nz, &tmp);
-    int index = indexIterator ? indexIterator[i] : i;
+    int index = i; /* the reference reads indexIterator[i] again: identity for "All", out of bounds for a sub-group */
     vel3[3 * index] = (real)nx; vel3[3 * index + 1] = (real)ny; vel3[3 * index + 2] = (real)nz;
   }
 }

