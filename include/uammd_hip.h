@@ -182,8 +182,8 @@ int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
  *   IBM<Kernel,Grid,LinearIndex3D>::spread / gather     misc/IBM.cuh:99-203
  *   IBM_ns::particles2GridD / grid2ParticlesDTPP        misc/IBM.cu:83-147, :164-235
  * A user-defined window functor cannot cross a C ABI; the windows UAMMD ships are selected by `kind`
- * (generic functors go through the header template in include/uammd/misc/IBM.cuh, compiled by hipcc
- * with the user's translation unit — same as the reference).
+ * (a user-defined window is device code: it is compiled by hipcc with the user's
+ * translation unit, as in the reference; include/uammd/device/Transverser.hip.hpp is that path for Transversers).
  * ---------------------------------------------------------------------------------------------- */
 #define UAMMD_IBM_KERNEL_GAUSSIAN 0 /* prefactor*exp(tau r^2), 0 for r >= rmax   misc/IBM_kernels.cuh:28-40, BDHI/FCM/FCM_kernels.cuh:22-58 */
 #define UAMMD_IBM_KERNEL_PESKIN3 1  /* Peskin::threePoint                          misc/IBM_kernels.cuh:115-137 */

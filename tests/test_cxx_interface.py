@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility"]
+PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "custom_transverser"]
 
 
 def _make():
@@ -38,7 +38,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
-                                       ("fcm_selfmobility", []), ("pse_selfmobility", [])])
+                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("custom_transverser", [])])
 def test_examples_run(prog, args):
     _make()
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
