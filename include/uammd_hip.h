@@ -346,6 +346,12 @@ int uammd_lanczos_destroy(uammd_lanczos *h);
 int uammd_lanczos_run(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v,
                       float tolerance, int n, void *stream, int *iterations);
 int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
+/* Vectors sharded over several ranks (Lanczos row): `n` is then the LOCAL length, the matvec callback computes the
+ * local rows of M v, and every dot product / norm of the recurrence is completed by `reduce`, which must sum d_values[0..count)
+ * in place over all ranks on `stream` (RCCL all-reduce of 1 float, 3 per iteration + 2 per convergence check).  ownsFirstElement:
+ * non-zero on the rank that holds global element 0.  reduce == NULL restores the single-rank behaviour. */
+typedef int (*uammd_allreduce_fn)(void *ctx, float *d_values, int count, void *stream);
+int uammd_lanczos_set_allreduce(uammd_lanczos *h, uammd_allreduce_fn reduce, void *ctx, int ownsFirstElement);
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps);
 
 /* BDHI::Lanczos (open boundaries, dense RPY mobility, matrix free).  Replaces

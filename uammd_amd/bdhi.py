@@ -455,6 +455,39 @@ class LanczosSolver:
     def setIterationHardLimit(self, n):
         check(self.lib.uammd_lanczos_set_iteration_hard_limit(self.h, int(n)))
 
+    def setAllReduce(self, group=None, owns_first_element=None, enabled=True):
+        """Sharded vectors (one slice per rank): the dot products of the recurrence are summed over `group` with
+        torch.distributed.all_reduce (RCCL on the GPUs; host staging under gloo, which cannot move device memory)."""
+        import torch.distributed as dist
+        if not enabled:
+            check(self.lib.uammd_lanczos_set_allreduce(self.h, None, None, 1))
+            self._reduce_cb = None
+            return
+        staged = dist.get_backend(group) == "gloo"
+
+        def _wrap(ptr, count):
+            class _Raw:
+                pass
+            r = _Raw()
+            r.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(r, device="cuda")
+
+        def cb(ctx, d_values, count, stream):
+            try:
+                t = _wrap(d_values, count)
+                if staged:
+                    h = t.cpu()
+                    dist.all_reduce(h, group=group)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, group=group)
+                return 0
+            except Exception:  # surfaced as a library error
+                return -98
+        self._reduce_cb = _lib.ALLREDUCE_FN(cb)     # keep the trampoline alive
+        first = (dist.get_rank(group) == 0) if owns_first_element is None else bool(owns_first_element)
+        check(self.lib.uammd_lanczos_set_allreduce(self.h, C.cast(self._reduce_cb, C.c_void_p), None, int(first)))
+
     def getLastRunRequiredSteps(self):
         v = C.c_int(0)
         check(self.lib.uammd_lanczos_get_last_run_required_steps(self.h, C.byref(v)))

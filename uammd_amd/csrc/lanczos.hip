@@ -32,6 +32,10 @@ struct Lanczos {
   int check_convergence_steps = 3;  // Solver::Solver(), LanczosAlgorithm.cu:175
   int iterationHardLimit = 200;
   int lastRunRequiredSteps = 0;
+  // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
+  uammd_allreduce_fn reduce = nullptr;
+  void *reduceCtx = nullptr;
+  bool ownsFirstElement = true;  // the rank that holds global element 0 (the breakdown fallback w = e1)
 };
 
 UH_D float block_sum(float x, float *sh) {
@@ -93,6 +97,12 @@ __global__ void __launch_bounds__(kLB) k_l_a(float *__restrict__ w, const float 
   const float t = block_sum(a, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = t;
 }
+// sharded vectors: parts[0] <- sum of the g partials of this rank (then all-reduced by the caller's callback)
+__global__ void __launch_bounds__(kLB) k_l_collapse(float *__restrict__ parts, int nparts) {
+  __shared__ float sh[16];
+  const float t = sum_parts(parts, nparts, sh);
+  if (threadIdx.x == 0) parts[0] = t;
+}
 // hdiag_i = sum(partsA); w -= hdiag_i * v_i; partsB <- partial |w|^2
 __global__ void __launch_bounds__(kLB) k_l_b(float *__restrict__ w, const float *__restrict__ vi, int n,
                                              const float *__restrict__ partsA, int nparts, float *__restrict__ hdiag_i,
@@ -113,7 +123,7 @@ __global__ void __launch_bounds__(kLB) k_l_b(float *__restrict__ w, const float 
 __global__ void __launch_bounds__(kLB) k_l_c(const float *__restrict__ w, int n, const float *__restrict__ partsB,
                                              int nparts, const float *__restrict__ hdiag_i,
                                              const float *__restrict__ normz, float *__restrict__ hsup_i,
-                                             float *__restrict__ vnext) {
+                                             float *__restrict__ vnext, bool ownsFirstElement) {
   __shared__ float sh[16];
   float hs = sqrtf(sum_parts(partsB, nparts, sh));
   const float tol = 1e-3f * (*hdiag_i) / (*normz);
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(kLB) k_l_c(const float *__restrict__ w, int n,
   if (blockIdx.x == 0 && threadIdx.x == 0) *hsup_i = hs;
   const float inv = hs > 0.0f ? 1.0f / hs : 0.0f;
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB)
-    vnext[i] = hs > 0.0f ? w[i] * inv : (i == 0 ? 1.0f : 0.0f);
+    vnext[i] = hs > 0.0f ? w[i] * inv : ((i == 0 && ownsFirstElement) ? 1.0f : 0.0f);
 }
 // Bz = |z| * V[:, :m] * y ; partials of |Bold|^2 and |Bz - Bold|^2 ; then Bold <- Bz
 __global__ void __launch_bounds__(kLB) k_l_estimate(const float *__restrict__ V, int n, int m,
@@ -221,6 +231,15 @@ int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps) {
   return 0;
 }
 
+int uammd_lanczos_set_allreduce(uammd_lanczos *h, uammd_allreduce_fn reduce, void *ctx, int ownsFirstElement) {
+  if (!h) { set_last_error("uammd_lanczos_set_allreduce: null handle"); return -1; }
+  Lanczos *L = reinterpret_cast<Lanczos *>(h);
+  L->reduce = reduce;
+  L->reduceCtx = ctx;
+  L->ownsFirstElement = reduce ? ownsFirstElement != 0 : true;
+  return 0;
+}
+
 int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance,
                       int n, void *stream, int *iterations) {
   if (!hh || !dot || !d_Bv || !d_v || n < 1) { set_last_error("uammd_lanczos_run: bad arguments"); return -1; }
@@ -242,9 +261,18 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
   float *scal = (float *)L->scal.ptr, *ycoef = (float *)L->ycoef.ptr;
   float *hdiag = scal + 1, *hsup = scal + 1 + cap;
   const int g = lgrid(n);
+  // with sharded vectors a finished set of partials is collapsed to one number and summed over the ranks; the consumers
+  // then "re-sum" a single partial
+  const int np = L->reduce ? 1 : g;
+  auto complete = [&](float *p) -> int {
+    if (!L->reduce) return 0;
+    hipLaunchKernelGGL(k_l_collapse, dim3(1), dim3(kLB), 0, st, p, g);
+    return L->reduce(L->reduceCtx, p, 1, stream);
+  };
   UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(float) * (size_t)n, st));   // oldBz = 0, :205-206
   hipLaunchKernelGGL(k_l_norm2, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
-  hipLaunchKernelGGL(k_l_first, dim3(g), dim3(kLB), 0, st, d_v, n, (const float *)parts, g, V, scal);
+  if (int rc = complete(parts)) return rc;
+  hipLaunchKernelGGL(k_l_first, dim3(g), dim3(kLB), 0, st, d_v, n, (const float *)parts, np, V, scal);
   const int checkConvergenceSteps = std::min(L->check_convergence_steps, L->iterationHardLimit - 2);
   std::vector<float> hbuf(2 * cap + 2);
   std::vector<double> dd, ee, zz;
@@ -257,10 +285,12 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
     }
     hipLaunchKernelGGL(k_l_a, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const float *)(V + (size_t)(i - 1) * n) : nullptr,
                        (const float *)vi, n, i > 0 ? (const float *)(hsup + i - 1) : nullptr, parts);
-    hipLaunchKernelGGL(k_l_b, dim3(g), dim3(kLB), 0, st, w, (const float *)vi, n, (const float *)parts, g, hdiag + i,
+    if (int rc = complete(parts)) return rc;
+    hipLaunchKernelGGL(k_l_b, dim3(g), dim3(kLB), 0, st, w, (const float *)vi, n, (const float *)parts, np, hdiag + i,
                        parts + kLParts);
-    hipLaunchKernelGGL(k_l_c, dim3(g), dim3(kLB), 0, st, (const float *)w, n, (const float *)(parts + kLParts), g,
-                       (const float *)(hdiag + i), (const float *)scal, hsup + i, V + (size_t)(i + 1) * n);
+    if (int rc = complete(parts + kLParts)) return rc;
+    hipLaunchKernelGGL(k_l_c, dim3(g), dim3(kLB), 0, st, (const float *)w, n, (const float *)(parts + kLParts), np,
+                       (const float *)(hdiag + i), (const float *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
     if (i >= checkConvergenceSteps) {
       const int m = i + 1;
       UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(float) * (2 * cap + 1), hipMemcpyDeviceToHost, st));
@@ -285,11 +315,13 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
       hipLaunchKernelGGL(k_l_estimate, dim3(g), dim3(kLB), 0, st, (const float *)V, n, m, (const float *)ycoef,
                          (const float *)scal, d_Bv, Bold, parts);
       if (i > 0) {
+        if (int rc = complete(parts)) return rc;
+        if (int rc = complete(parts + kLParts)) return rc;
         float hp[2 * kLParts];
         UH_CHECK(hipMemcpyAsync(hp, parts, sizeof(float) * 2 * kLParts, hipMemcpyDeviceToHost, st));
         UH_CHECK(hipStreamSynchronize(st));
         double a = 0.0, b = 0.0;
-        for (int k = 0; k < g; ++k) { a += hp[k]; b += hp[kLParts + k]; }
+        for (int k = 0; k < np; ++k) { a += hp[k]; b += hp[kLParts + k]; }
         const float err = std::fabs((float)(std::sqrt(b) / std::sqrt(a)));
         if (std::isnan(err)) {
           set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
