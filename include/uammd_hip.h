@@ -189,6 +189,9 @@ int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
 #define UAMMD_IBM_KERNEL_PESKIN3 1  /* Peskin::threePoint                          misc/IBM_kernels.cuh:115-137 */
 #define UAMMD_IBM_KERNEL_PESKIN4 2  /* Peskin::fourPoint                           misc/IBM_kernels.cuh:140-160 */
 #define UAMMD_IBM_KERNEL_CONSTANT 3 /* phi = 1 (test/misc/ibm/test_ibm_regular.cu:11-14) */
+#define UAMMD_IBM_KERNEL_BARNETT_MAGLAND 4 /* exp(beta(sqrt(1-(r/(a alpha))^2)-1))/(a norm); prefactor=1/norm, tau=beta, rmax=alpha,
+                                             invh[0]=a (a LENGTH, not an inverse)  misc/IBM_kernels.cuh:82-112, FCM_kernels.cuh:82-155 */
+#define UAMMD_IBM_KERNEL_SIXPOINT 5 /* GaussianFlexible::sixPoint, support 6, invh = 1/h        misc/IBM_kernels.cuh:162-236 */
 typedef struct {
   int kind;
   int support[3];
@@ -199,6 +202,12 @@ typedef struct {
 /* FCM_ns::Kernels::Gaussian(h, tolerance) (BDHI/FCM/FCM_kernels.cuh:22-58), host: fills `out` and returns the
  * effective hydrodynamic radius a = h*u(tol)*sqrt(pi) in *a_eff. */
 int uammd_fcm_gaussian_kernel(float h, float tolerance, uammd_ibm_kernel *out, float *a_eff);
+/* IBM_kernels::BarnettMagland(alpha, beta) (misc/IBM_kernels.cuh:82-112), host: alpha = half support in length
+ * units of `lengthUnit`, norm by the reference's 20000-interval Simpson rule.  `support` = nodes per axis (the
+ * reference leaves it to the caller's getSupport).  lengthUnit = 1 is the plain window; the FCM wrapper
+ * FCM_ns::Kernels::BarnettMagland(h, tol) is (alpha = w/2, beta = 3.6 w, support = w, lengthUnit = h),
+ * BDHI/FCM/FCM_kernels.cuh:82-155. */
+int uammd_ibm_barnett_magland_kernel(float alpha, float beta, int support, float lengthUnit, uammd_ibm_kernel *out);
 /* Kernel::adviseGridSize (FCM_kernels.cuh:47-50), host */
 float uammd_fcm_advise_grid_size(float hydrodynamicRadius, float tolerance);
 

@@ -186,8 +186,8 @@ class Oracle:
 
     # ---- path B: IBM -----------------------------------------------------------------------------
     def ibm_kernel(self, kind, support, prefactor=0.0, tau=0.0, rmax=np.inf, invh=(0, 0, 0)):
-        """kind: 'gaussian' | 'peskin3' | 'peskin4' | 'constant' (oracle/src/ibm.c IBMKernel)."""
-        kinds = {"gaussian": 0, "peskin3": 1, "peskin4": 2, "constant": 3}
+        """kind: 'gaussian' | 'peskin3' | 'peskin4' | 'constant' | 'barnett_magland' | 'sixpoint' (oracle/src/ibm.c)."""
+        kinds = {"gaussian": 0, "peskin3": 1, "peskin4": 2, "constant": 3, "barnett_magland": 4, "sixpoint": 5}
         creal = self.creal
 
         class K(C.Structure):
@@ -198,6 +198,18 @@ class Oracle:
         k = K(kinds[kind], (C.c_int * 3)(int(sup[0]), int(sup[1]), int(sup[2])), prefactor, tau, rmax,
               (creal * 3)(float(ih[0]), float(ih[1]), float(ih[2])))
         return k
+
+    def bm_kernel(self, alpha, beta, support, length_unit=1.0):
+        """IBM_kernels::BarnettMagland(alpha, beta) with the reference's Simpson-rule norm."""
+        self.lib.oracle_bm_norm.restype = self.creal
+        self.lib.oracle_bm_norm.argtypes = [self.creal, self.creal]
+        norm = self.real(self.lib.oracle_bm_norm(alpha, beta))
+        return self.ibm_kernel("barnett_magland", support, prefactor=float(self.real(1.0 / float(norm))), tau=beta, rmax=alpha, invh=[length_unit] * 3)
+
+    def phi_sixpoint(self, h, r):
+        self.lib.oracle_phi_sixpoint.restype = self.creal
+        self.lib.oracle_phi_sixpoint.argtypes = [self.creal, self.creal]
+        return np.array([self.lib.oracle_phi_sixpoint(1.0 / h, float(x)) for x in np.atleast_1d(r)])
 
     def fcm_gaussian(self, h, tolerance):
         """FCM_ns::Kernels::Gaussian(h, tol) -> dict(support, upsampling, width, prefactor, tau, rmax, a_eff, kernel)."""

@@ -32,6 +32,7 @@
 typedef double real;
 #define FMA(a, b, c) fma((a), (b), (c))
 #define FLOOR(a) floor(a)
+#define CEIL(a) ceil(a)
 #define SQRT(a) sqrt(a)
 #define EXP(a) exp(a)
 #define FABS(a) fabs(a)
@@ -42,6 +43,7 @@ typedef double real;
 typedef float real;
 #define FMA(a, b, c) fmaf((a), (b), (c))
 #define FLOOR(a) floorf(a)
+#define CEIL(a) ceilf(a)
 #define SQRT(a) sqrtf(a)
 #define EXP(a) expf(a)
 #define FABS(a) fabsf(a)

@@ -17,7 +17,8 @@
  */
 #include "common.h"
 
-enum { KERNEL_GAUSSIAN = 0, KERNEL_PESKIN3 = 1, KERNEL_PESKIN4 = 2, KERNEL_CONSTANT = 3 };
+enum { KERNEL_GAUSSIAN = 0, KERNEL_PESKIN3 = 1, KERNEL_PESKIN4 = 2, KERNEL_CONSTANT = 3, KERNEL_BARNETT_MAGLAND = 4,
+       KERNEL_SIXPOINT = 5 };
 
 /* Window description shared with the C ABI (include/uammd_hip.h: uammd_ibm_kernel) */
 typedef struct {
@@ -54,11 +55,76 @@ static inline real phi_peskin4(real invh, real rr) { /* IBM_kernels.cuh:145-158 
   }
   return 0;
 }
+/* IBM_kernels.cuh:82-90 (BM) and :107-109; prefactor = 1/norm, tau = beta, rmax = alpha */
+static inline real bm_window(real zz, real alpha, real beta) {
+  const real z = zz / alpha;
+  const real z2 = z * z;
+  const real dz2 = (real)1.0 - z2;
+  return (dz2 < (real)0.0) ? (real)0.0 : EXP(beta * (SQRT(dz2) - (real)1.0));
+}
+/* invh[0] = length unit a: phi(r) = bm.phi(r/a)/a (FCM_kernels.cuh:151-154); a = 1 is the plain window */
+static inline real phi_barnett_magland(const IBMKernel *k, real r) {
+  return bm_window(r / k->invh[0], k->rmax, k->tau) * k->prefactor / k->invh[0];
+}
+/* IBM_kernels.cuh:93-97 with detail::integrate (:56-77) and detail::kahanSum (:44-54) */
+ORACLE_API real oracle_bm_norm(real alpha, real beta) {
+  int Nr = 20000;
+  const real rmin = 0, rmax = alpha;
+  const real dx = (rmax - rmin) / Nr;
+  real sum = 0, c = 0;
+  for (int i = 0; i <= Nr; i++) {
+    real weight;
+    if (i == 0 || i == Nr) weight = 1;
+    else if (i % 2 == 1) weight = 4;
+    else weight = 2;
+    const real f = weight * bm_window(rmin + i * dx, alpha, beta);
+    const real y = f - c;
+    const real t = sum + y;
+    c = (t - sum) - y;
+    sum = t;
+  }
+  const double integral = dx / 3.0 * sum;
+  return (real)(2.0 * integral);
+}
+/* IBM_kernels.cuh:171-221 (phi_impl) and :230-232 (phi) */
+static inline real phi_sixpoint(real invh, real rr) {
+  const real r = FABS(rr) * invh;
+  const real K = (real)0.714075092976608;
+  if (r >= (real)3) return 0;
+  const real R = r - CEIL(r) + (real)1.0;
+  const real R2 = R * R;
+  const real R3 = R2 * R;
+  const real alpha = (real)28.;
+  const real beta = (real)(9.0 / 4.0) - (real)1.5 * (K + R2) + ((real)(22. / 3) - (real)7.0 * K) * R - (real)(7. / 3.) * R3;
+  const real gamma = (real)0.25 * ((real)0.5 * ((real)161. / (real)36 - (real)59. / (real)6 * K + (real)5 * K * K) * R2 +
+                                   (real)1. / (real)3 * ((real)-109. / (real)24 + (real)5 * K) * R2 * R2 +
+                                   (real)5. / (real)18 * R3 * R3);
+  const real discr = beta * beta - (real)4.0 * alpha * gamma;
+  const real prefactor = (real)1. / ((real)2 * alpha) * (-beta + SQRT(discr)); /* sign(3/2 - K) = +1 */
+  real v = 0;
+  if (r <= (real)0) {
+    const real rp1 = r + (real)1.0;
+    v = (real)2. * prefactor + (real)0.25 + (real)(1. / 6) * ((real)4 - (real)3 * K) * rp1 - (real)(1. / 6) * rp1 * rp1 * rp1;
+  } else if (r <= (real)1) {
+    v = (real)2.0 * prefactor + (real)(5. / 8) - (real)0.25 * (K + r * r);
+  } else if (r <= (real)2) {
+    const real rm1 = r + (real)-1.0;
+    v = (real)-3.0 * prefactor + (real)0.25 - (real)(1. / 6.) * ((real)4 - (real)3 * K) * rm1 + (real)(1. / 6) * rm1 * rm1 * rm1;
+  } else if (r <= (real)3) {
+    const real rm2 = r + (real)-2.0;
+    v = prefactor - (real)(1. / 16) + (real)(1. / 8) * (K + rm2 * rm2) - (real)(1. / 12) * ((real)3 * K - (real)1) * rm2 -
+        (real)(1. / 12) * rm2 * rm2 * rm2;
+  }
+  return v * invh;
+}
+ORACLE_API real oracle_phi_sixpoint(real invh, real r) { return phi_sixpoint(invh, r); }
 static inline real phi_axis(const IBMKernel *k, int axis, real r) {
   switch (k->kind) {
     case KERNEL_GAUSSIAN: return phi_gaussian(k, r);
     case KERNEL_PESKIN3: return phi_peskin3(k->invh[axis], r);
     case KERNEL_PESKIN4: return phi_peskin4(k->invh[axis], r);
+    case KERNEL_BARNETT_MAGLAND: return phi_barnett_magland(k, r);
+    case KERNEL_SIXPOINT: return phi_sixpoint(k->invh[axis], r);
     default: return (real)1.0;
   }
 }

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _okernel(o32, k):
-    kinds = {0: "gaussian", 1: "peskin3", 2: "peskin4", 3: "constant"}
+    kinds = {0: "gaussian", 1: "peskin3", 2: "peskin4", 3: "constant", 4: "barnett_magland", 5: "sixpoint"}
     return o32.ibm_kernel(kinds[k.kind], list(k.support), k.prefactor, k.tau, k.rmax, list(k.invh))
 
 
@@ -56,7 +56,7 @@ def test_peskin_spread_reference_test(hip, o32):
     assert np.abs(field.cpu().numpy() - expected).max() <= 1e-7  # reference: 1e-10 in double
 
 
-@pytest.mark.parametrize("kind", ["gaussian6", "gaussian5", "peskin3", "peskin4"])
+@pytest.mark.parametrize("kind", ["gaussian6", "gaussian5", "peskin3", "peskin4", "bm", "sixpoint"])
 @pytest.mark.parametrize("ncomp", [1, 3])
 def test_ibm_spread_gather_vs_oracle(hip, o32, kind, ncomp):
     rng = np.random.default_rng(7)
@@ -68,6 +68,12 @@ def test_ibm_spread_gather_vs_oracle(hip, o32, kind, ncomp):
         k, _ = hip.Kernels.Gaussian(h, 1e-2)
     elif kind == "peskin3":
         k = hip.Kernels.Peskin3pt(L / np.array(cd, np.float32))
+    elif kind == "bm":
+        k = hip.Kernels.BarnettMagland(2.5, 18.0, 5, lengthUnit=h)
+        okb = o32.bm_kernel(2.5, 18.0, 5, length_unit=h)
+        assert okb.prefactor == k.prefactor  # same Simpson/Kahan norm, bit for bit
+    elif kind == "sixpoint":
+        k = hip.Kernels.GaussianFlexibleSixPoint(L / np.array(cd, np.float32))
     else:
         k = hip.Kernels.Peskin4pt(L / np.array(cd, np.float32))
     n = 500
@@ -293,3 +299,47 @@ def test_fcm_tile_spread_edge_cases(hip, o32):
     ofcm.displacements(pos, force, grids=grids)
     rk = grids["fourier"].view(np.float32).reshape(gk.shape)
     assert np.abs(gk - rk).max() <= 2e-5 * np.abs(rk).max()
+
+
+@pytest.mark.parametrize("name,rtol", [("Gaussian", 2e-3), ("BarnettMagland", None), ("Peskin3pt", 6e-2),
+                                        ("Peskin4pt", 3e-2), ("GaussianFlexible6pt", 1e-2)])
+def test_fcm_alternative_kernels_self_mobility(hip, o32, name, rtol):
+    """FCM_impl<Kernel> with the windows of BDHI/FCM/FCM_kernels.cuh: the grid spacing comes from adviseGridSize,
+    the hydrodynamic radius from fixHydrodynamicRadius, and a particle pulled by a unit force moves with the
+    periodic self mobility M0(a_fix, L) (Hasimoto) at any position inside a cell, within the window's
+    translational-invariance error.  The velocities also match the oracle's pipeline with the same window."""
+    from oracle.fcm import FCMOracle
+    a, tol, eta, n = 1.0, 1e-3, 1.0 / (6 * np.pi), 32
+    h = hip.FCMKernels.adviseGridSize(name, a, tol)
+    L = float(np.float32(h) * n)
+    k, afix = hip.FCMKernels.make(name, h, tol)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), [n] * 3, k, eta, 777, afix)
+    rng = np.random.default_rng(5)
+    npart = 64
+    pos = np.zeros((npart, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (npart, 3)) * L
+    vs = []
+    for i in range(npart):  # one particle at a time: pure self mobility
+        f = np.zeros((1, 4), np.float32)
+        f[0, 0] = 1.0
+        v = fcm.computeHydrodynamicDisplacements(torch.from_numpy(pos[i:i + 1]).cuda(), torch.from_numpy(f).cuda(), 1, 0.0, 0.0)
+        vs.append(v.cpu().numpy()[0])
+    vs = np.array(vs)
+    m0 = fcm.getSelfMobility()
+    if rtol is not None:
+        assert abs(vs[:, 0].mean() / m0 - 1.0) <= rtol, (name, vs[:, 0].mean(), m0)
+        assert np.abs(vs[:, 0] / m0 - 1.0).max() <= 4 * rtol
+        assert np.abs(vs[:, 1:]).max() <= 4 * rtol * m0
+    # (the reference's BarnettMagland wrapper, commented out in FCM_impl.cuh:39 and exercised by none of its tests,
+    # pairs alpha = w/2, beta = 3.6 w with an upsampling fit that does not reproduce M0: measured 1.87 M0 with a
+    # +-25 % position dependence at tol 1e-3.  It is restated as written and only checked against the oracle.)
+    # same pipeline in the oracle with the same window
+    kinds = {0: "gaussian", 1: "peskin3", 2: "peskin4", 4: "barnett_magland", 5: "sixpoint"}
+    ok = o32.ibm_kernel(kinds[k.kind], list(k.support), k.prefactor, k.tau, k.rmax, list(k.invh))
+    ofcm = FCMOracle(o32, L, [n] * 3, tolerance=tol, viscosity=eta, seed=777,
+                     kernel={"kernel": ok, "a_eff": afix, "support": k.support[0]})
+    force = np.zeros((npart, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (npart, 3))
+    vref = ofcm.displacements(pos, force)
+    v = fcm.computeHydrodynamicDisplacements(torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda(), npart, 0.0, 0.0)
+    assert np.linalg.norm(v.cpu().numpy() - vref) <= 2e-5 * np.linalg.norm(vref)

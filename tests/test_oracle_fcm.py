@@ -172,3 +172,37 @@ def test_fcm_noise_is_hermitian_and_balanced(o32):
     sel = np.zeros(K2.shape, bool); sel[1:5, 1:6, 1:8] = True  # generic nodes (no Nyquist, no kx=0 plane)
     ratio = (meas[..., 0][sel] / expect[..., 0][sel]).mean()
     assert abs(ratio - 1.0) < 0.05
+
+
+def test_sixpoint_window_moments(o64):
+    """GaussianFlexible::sixPoint (IBM_kernels.cuh:162-236; Bao, Kaye & Peskin 2016): the window is built so that
+    sum_j phi(x-j) = 1, sum_j (x-j) phi = 0, sum_j (x-j)^2 phi = K and sum_j (x-j)^3 phi = 0 for every x."""
+    h = 0.7
+    K = 0.714075092976608
+    for x in np.linspace(-0.5, 0.5, 41) * h:
+        r = x - np.arange(-4, 5) * h
+        phi = o64.phi_sixpoint(h, r) * h
+        assert abs(phi.sum() - 1.0) <= 1e-12
+        assert abs((r / h * phi).sum()) <= 1e-12
+        assert abs(((r / h) ** 2 * phi).sum() - K) <= 1e-12
+        assert abs(((r / h) ** 3 * phi).sum()) <= 1e-12
+    assert np.abs(o64.phi_sixpoint(h, [3.0 * h, -3.0 * h])).max() <= 1e-10 and o64.phi_sixpoint(h, [3.5 * h])[0] == 0.0
+
+
+def test_barnett_magland_norm_and_support(o64, o32):
+    """IBM_kernels::BarnettMagland (IBM_kernels.cuh:82-112): unit integral by the 20000-interval Simpson rule, zero
+    beyond alpha; the FCM wrapper evaluates bm.phi(r/h)/h (FCM_kernels.cuh:151-154)."""
+    alpha, beta = 2.0, 14.4
+    for o, tol in ((o64, 1e-9), (o32, 2e-6)):
+        k = o.bm_kernel(alpha, beta, 4)
+        xs = np.linspace(-alpha, alpha, 200001)
+        z2 = 1 - (xs / alpha) ** 2
+        integ = np.trapezoid(np.exp(beta * (np.sqrt(np.maximum(z2, 0)) - 1)), xs) * float(k.prefactor)
+        assert abs(integ - 1.0) <= tol
+    # spread of one particle: nodes beyond alpha get nothing, the integral over the grid is ~1
+    h = 0.5
+    k = o64.bm_kernel(alpha, beta, 4, length_unit=h)
+    n, L = 16, 8.0
+    g = o64.ibm_spread(np.array([[0.1, -0.07, 0.2]]), np.ones(1), L, 1, [n] * 3, k)[..., 0]
+    assert np.count_nonzero(g) <= 4 ** 3
+    assert abs(g.sum() * h ** 3 - 1.0) <= 2e-3  # ES window: partition of unity only up to its design tolerance

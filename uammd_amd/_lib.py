@@ -84,6 +84,7 @@ SIGNATURES = {
     "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
     "uammd_fcm_gaussian_kernel": (_i, [_f, _f, C.POINTER(IBMKernel), C.POINTER(_f)]),
     "uammd_fcm_advise_grid_size": (_f, [_f, _f]),
+    "uammd_ibm_barnett_magland_kernel": (_i, [_f, _f, _i, _f, C.POINTER(IBMKernel)]),
     "uammd_ibm_spread": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
     "uammd_ibm_gather": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
     "uammd_fcm_create": (_i, [C.POINTER(FCMParameters), C.POINTER(_vp)]),

@@ -85,9 +85,75 @@ class Kernels:
         return IBMKernel(2, (C.c_int * 3)(4, 4, 4), 0.0, 0.0, float("inf"), (C.c_float * 3)(*inv))
 
     @staticmethod
+    def BarnettMagland(alpha, beta, support, lengthUnit=1.0):
+        """IBM_kernels::BarnettMagland(alpha, beta): phi(r) = exp(beta(sqrt(1-(r/alpha)^2)-1))/norm, 0 beyond alpha
+        (r in units of lengthUnit, as FCM_ns::Kernels::BarnettMagland::phi does with the cell size)."""
+        k = IBMKernel()
+        check(_lib.load().uammd_ibm_barnett_magland_kernel(float(alpha), float(beta), int(support), float(lengthUnit),
+                                                           C.byref(k)))
+        return k
+
+    @staticmethod
+    def GaussianFlexibleSixPoint(h):
+        """IBM_kernels::GaussianFlexible::sixPoint(h), support 6."""
+        h = np.broadcast_to(np.asarray(h, dtype=np.float32), (3,))
+        inv = [float(np.float32(1.0) / x) if x > 0 else 0.0 for x in h]
+        return IBMKernel(5, (C.c_int * 3)(6, 6, 6), 0.0, 0.0, float("inf"), (C.c_float * 3)(*inv))
+
+    @staticmethod
     def Constant(support):
         s = np.broadcast_to(np.asarray(support), (3,))
         return IBMKernel(3, (C.c_int * 3)(int(s[0]), int(s[1]), int(s[2])), 0.0, 0.0, float("inf"), (C.c_float * 3)(0, 0, 0))
+
+
+class FCMKernels:
+    """FCM_ns::Kernels::* (BDHI/FCM/FCM_kernels.cuh): each entry builds the window for a cell size h and a tolerance
+    and carries the two static helpers FCM needs: adviseGridSize(a, tol) and fixHydrodynamicRadius(a, h).
+    Use: kernel, a_eff = FCMKernels.make(name, h, tol); FCM_impl(box, cells, kernel, eta, seed, a_eff)."""
+
+    @staticmethod
+    def _bm_support(tolerance):  # BarnettMagland::computeSupport, FCM_kernels.cuh:91-95
+        i_w = max(1.5, int(-math.log10(tolerance) + 2) / 2.0)
+        i_w = min(float(np.float32(9.0)), i_w)
+        return int(math.ceil(np.float32(i_w)))
+
+    @staticmethod
+    def _bm_upsampling(w):       # FCM_kernels.cuh:97-101
+        return 1.36409985665115 * math.pow(float(np.float32(w)), -0.53028415751646)
+
+    @staticmethod
+    def adviseGridSize(name, hydrodynamicRadius, tolerance):
+        a = float(hydrodynamicRadius)
+        if name == "Gaussian":
+            return Kernels.adviseGridSize(a, tolerance)
+        if name == "BarnettMagland":   # :140-144
+            return float(np.float32(a * FCMKernels._bm_upsampling(FCMKernels._bm_support(tolerance))))
+        if name == "Peskin3pt":        # :167-169
+            return a
+        if name == "Peskin4pt":        # :185-189
+            return float(np.float32(a) / np.float32(1.31))
+        if name == "GaussianFlexible6pt":  # :207-211
+            return float(np.float32(a) / np.float32(1.5195))
+        raise ValueError(name)
+
+    @staticmethod
+    def make(name, h, tolerance):
+        """-> (kernel, fixHydrodynamicRadius(.., h))."""
+        h = float(np.float32(h))
+        if name == "Gaussian":
+            return Kernels.Gaussian(h, tolerance)
+        if name == "BarnettMagland":   # :85-89, :130-133, :146-149
+            w = FCMKernels._bm_support(tolerance)
+            alpha = float(np.float32(w * 0.5))
+            k = Kernels.BarnettMagland(alpha, float(np.float32(1.8 * w * 2)), int(math.ceil(2 * alpha)), lengthUnit=h)
+            return k, float(np.float32(h / FCMKernels._bm_upsampling(k.support[0])))
+        if name == "Peskin3pt":
+            return Kernels.Peskin3pt(h), h
+        if name == "Peskin4pt":
+            return Kernels.Peskin4pt(h), float(np.float32(h) * np.float32(1.31))
+        if name == "GaussianFlexible6pt":
+            return Kernels.GaussianFlexibleSixPoint(h), float(np.float32(h) * np.float32(1.5195))
+        raise ValueError(name)
 
 
 class IBM:

@@ -829,7 +829,8 @@ int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
     return -2;
   }
   if (par->kernel.kind != UAMMD_IBM_KERNEL_GAUSSIAN && par->kernel.kind != UAMMD_IBM_KERNEL_PESKIN3 &&
-      par->kernel.kind != UAMMD_IBM_KERNEL_PESKIN4) {
+      par->kernel.kind != UAMMD_IBM_KERNEL_PESKIN4 && par->kernel.kind != UAMMD_IBM_KERNEL_BARNETT_MAGLAND &&
+      par->kernel.kind != UAMMD_IBM_KERNEL_SIXPOINT) {
     set_last_error("FCM_impl requires instances of the spreading kernels");
     return -2;
   }

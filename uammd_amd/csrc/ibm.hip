@@ -104,7 +104,7 @@ static int check_ibm_args(const char *fn, int posStride, int ncomp, const int ce
       set_last_error("%s: kernel support %d outside [1, %d]", fn, k->support[a], kMaxSupport);
       return -1;
     }
-  if (k->kind < 0 || k->kind > kKernelConstant) { set_last_error("%s: unknown kernel kind %d", fn, k->kind); return -1; }
+  if (k->kind < 0 || k->kind > kKernelSixPoint) { set_last_error("%s: unknown kernel kind %d", fn, k->kind); return -1; }
   return 0;
 }
 
@@ -187,6 +187,36 @@ int uammd_fcm_gaussian_kernel(float h, float tolerance, uammd_ibm_kernel *out, f
   out->rmax = (float)support * h;
   out->invh[0] = out->invh[1] = out->invh[2] = 0.0f;
   if (a_eff) *a_eff = (float)((double)(h * ups) * sqrt(M_PI));
+  return 0;
+}
+
+int uammd_ibm_barnett_magland_kernel(float alpha, float beta, int support, float lengthUnit, uammd_ibm_kernel *out) {
+  if (!out || !(alpha > 0) || !(lengthUnit > 0) || support < 1 || support > kMaxSupport) {
+    set_last_error("uammd_ibm_barnett_magland_kernel: bad arguments");
+    return -1;
+  }
+  // norm = 2 * Simpson(BM, 0, alpha, 20000 intervals), single-precision samples added with a compensated sum
+  // (misc/IBM_kernels.cuh:44-79, :93-97)
+  const int Nr = 20000;
+  const float dx = (alpha - 0.0f) / (float)Nr;
+  float sum = 0.0f, c = 0.0f;
+  for (int i = 0; i <= Nr; i++) {
+    const float weight = (i == 0 || i == Nr) ? 1.0f : ((i % 2 == 1) ? 4.0f : 2.0f);
+    const float z = (0.0f + (float)i * dx) / alpha;
+    const float dz2 = 1.0f - z * z;
+    const float f = weight * ((dz2 < 0.0f) ? 0.0f : expf(beta * (sqrtf(dz2) - 1.0f)));
+    const float y = f - c;
+    const float t = sum + y;
+    c = (t - sum) - y;
+    sum = t;
+  }
+  const float norm = (float)(2.0 * ((double)dx / 3.0 * (double)sum));
+  out->kind = UAMMD_IBM_KERNEL_BARNETT_MAGLAND;
+  out->support[0] = out->support[1] = out->support[2] = support;
+  out->prefactor = (float)(1.0 / (double)norm);
+  out->tau = beta;
+  out->rmax = alpha;
+  out->invh[0] = out->invh[1] = out->invh[2] = lengthUnit;
   return 0;
 }
 

@@ -13,7 +13,8 @@
 
 namespace uammd_hip {
 
-enum { kKernelGaussian = 0, kKernelPeskin3 = 1, kKernelPeskin4 = 2, kKernelConstant = 3 };
+enum { kKernelGaussian = 0, kKernelPeskin3 = 1, kKernelPeskin4 = 2, kKernelConstant = 3, kKernelBarnettMagland = 4,
+       kKernelSixPoint = 5 };
 constexpr int kMaxSupport = 21;  // 3*support weights must fit in one wave
 
 struct IBMKernelDev {
@@ -42,11 +43,52 @@ UH_D float phi_peskin4(float invh, float rr) {  // misc/IBM_kernels.cuh:145-158
   if (r < 2.0f) return invh * 0.125f * (fmaf(-2.0f, r, 5.0f) - sqrtf(fmaf(-(4.0f * r), r, fmaf(12.0f, r, -7.0f))));
   return 0.0f;
 }
+// "Exponential of a semicircle" window, misc/IBM_kernels.cuh:82-112: prefactor = 1/norm, tau = beta, rmax = alpha.
+// invhx holds the length unit a of the FCM wrapper, phi(r) = bm.phi(r/a)/a (BDHI/FCM/FCM_kernels.cuh:151-154);
+// a = 1 gives the plain window exactly.
+UH_D float phi_barnett_magland(const IBMKernelDev &k, float r) {
+  const float z = (r / k.invhx) / k.rmax;
+  const float dz2 = 1.0f - z * z;
+  const float w = (dz2 < 0.0f) ? 0.0f : expf(k.tau * (sqrtf(dz2) - 1.0f));
+  return w * k.prefactor / k.invhx;
+}
+// Six-point C3 window of Bao, Kaye & Peskin (GaussianFlexible::sixPoint, misc/IBM_kernels.cuh:162-236).
+// The operation order follows the reference's single-precision expression, term by term.
+UH_D float phi_sixpoint(float invh, float rr) {
+  const float r = fabsf(rr) * invh;
+  if (r >= 3.0f) return 0.0f;
+  const float K = 0.714075092976608f;
+  const float R = r - ceilf(r) + 1.0f;
+  const float R2 = R * R;
+  const float R3 = R2 * R;
+  const float b = (float)(9.0 / 4.0) - 1.5f * (K + R2) + ((float)(22. / 3) - 7.0f * K) * R - (float)(7. / 3.) * R3;
+  const float g = 0.25f * (0.5f * (161.0f / 36.0f - 59.0f / 6.0f * K + 5.0f * K * K) * R2 +
+                           1.0f / 3.0f * (-109.0f / 24.0f + 5.0f * K) * R2 * R2 + 5.0f / 18.0f * R3 * R3);
+  const float discr = b * b - 4.0f * 28.0f * g;
+  const float pre = 1.0f / (2.0f * 28.0f) * (-b + sqrtf(discr));
+  float v;
+  if (r <= 0.0f) {
+    const float t = r + 1.0f;
+    v = 2.0f * pre + 0.25f + (float)(1. / 6) * (4.0f - 3.0f * K) * t - (float)(1. / 6) * t * t * t;
+  } else if (r <= 1.0f) {
+    v = 2.0f * pre + (float)(5. / 8) - 0.25f * (K + r * r);
+  } else if (r <= 2.0f) {
+    const float t = r + -1.0f;
+    v = -3.0f * pre + 0.25f - (float)(1. / 6.) * (4.0f - 3.0f * K) * t + (float)(1. / 6) * t * t * t;
+  } else {
+    const float t = r + -2.0f;
+    v = pre - (float)(1. / 16) + (float)(1. / 8) * (K + t * t) - (float)(1. / 12) * (3.0f * K - 1.0f) * t -
+        (float)(1. / 12) * t * t * t;
+  }
+  return v * invh;
+}
 UH_D float phi_axis(const IBMKernelDev &k, int axis, float r) {
   switch (k.kind) {
     case kKernelGaussian: return phi_gaussian(k, r);
     case kKernelPeskin3: return phi_peskin3(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
     case kKernelPeskin4: return phi_peskin4(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    case kKernelBarnettMagland: return phi_barnett_magland(k, r);
+    case kKernelSixPoint: return phi_sixpoint(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
     default: return 1.0f;
   }
 }

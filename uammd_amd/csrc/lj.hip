@@ -102,7 +102,7 @@ struct ListView {
   int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
 };
 
-constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
+constexpr int kQCapGeneral = 16;  // per-lane FIFO depth of the global-memory kernels (uint entries)
 constexpr int kQCapBrick = 32;    // per-lane FIFO depth of the brick kernel (ushort LDS indices)
 
 // ---- general walk (also the in-kernel fallback of the brick kernel) ------------------------------
