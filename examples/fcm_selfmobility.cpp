@@ -15,6 +15,36 @@ struct PullX : public Interactor {
   }
 };
 
+// a constant torque on particle 0 (the reference's Interactors write pd->getTorque the same way)
+struct TwistZ : public Interactor {
+  using Interactor::Interactor;
+  void sum(Computables, hipStream_t) override {
+    auto t = pd->getTorque(access::cpu, access::readwrite);
+    t[0] = make_real4(0, 0, 1, 0);
+  }
+};
+
+// rotational self mobility with orientations allocated: dir = rotVec2Quaternion(w dt) * dir, w = tau/(8 pi eta a^3)
+// up to the periodic correction (small at a/L = 1/32); also run with the six-point window FCM_impl.cuh:42 names.
+template <class Integrator> static int rotation(shared_ptr<System> sys, const char *name, double tolerance) {
+  auto pd = std::make_shared<ParticleData>(1, sys);
+  { auto pos = pd->getPos(access::cpu, access::write); pos[0] = make_real4(0.3, -1.2, 2.1, 0); }
+  { auto dir = pd->getDir(access::cpu, access::write); dir[0] = make_real4(1, 0, 0, 0); }
+  typename Integrator::Parameters par;
+  par.temperature = 0; par.viscosity = 1.0; par.hydrodynamicRadius = 1.0; par.dt = 0.5; par.box = Box(32.0); par.tolerance = 1e-3;
+  auto fcm = std::make_shared<Integrator>(pd, par);
+  fcm->addInteractor(std::make_shared<TwistZ>(pd, "twist"));
+  fcm->forwardTime();
+  real4 q;
+  { auto dir = pd->getDir(access::cpu, access::read); q = dir[0]; }
+  const double a = fcm->getFCM_impl()->getHydrodynamicRadius();
+  const double w = 2 * std::atan2((double)q.w, (double)q.x) / par.dt;  // rotation about z: q = (cos(phi/2), 0, 0, sin(phi/2))
+  const double w0 = 1.0 / (8 * M_PI * par.viscosity * a * a * a);
+  std::printf("%s: angular velocity %.6f, isolated sphere %.6f (a = %.5f), |q| = %.7f\n", name, w, w0, a,
+              std::sqrt((double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w));
+  return (std::abs(w / w0 - 1) < tolerance && std::abs(q.y) < 1e-6 && std::abs(q.z) < 1e-6) ? 0 : 1;
+}
+
 int main(int argc, char *argv[]) {
   auto sys = std::make_shared<System>(argc, argv);
   auto pd = std::make_shared<ParticleData>(1, sys);
@@ -38,6 +68,9 @@ int main(int argc, char *argv[]) {
   const double M = (after.x - before.x) / par.dt;
   const double M0 = fcm->getFCM_impl()->getSelfMobility();
   std::printf("self mobility %.6f expected %.6f (a = %.5f)\n", M, M0, fcm->getFCM_impl()->getHydrodynamicRadius());
+  int bad = std::abs(M / M0 - 1) < 2e-3 ? 0 : 1;
+  bad += rotation<BDHI::FCMIntegrator>(sys, "Gaussian", 0.02);
+  bad += rotation<BDHI::FCMIntegratorT<BDHI::FCM_ns::Kernels::GaussianFlexible::sixPoint>>(sys, "sixPoint", 0.15);
   sys->finish();
-  return std::abs(M / M0 - 1) < 2e-3 ? 0 : 1;
+  return bad;
 }

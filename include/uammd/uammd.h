@@ -292,7 +292,7 @@ template <class T> void property_ptr<T>::release() {
 class ParticleData {
   int numberParticles;
   shared_ptr<System> sys;
-  Property<real4> pos{"pos"}, force{"force"};
+  Property<real4> pos{"pos"}, force{"force"}, torque{"torque"}, dir{"dir"};
   Property<real3> vel{"vel"};
   Property<real> energy{"energy"}, virial{"virial"}, mass{"mass"}, radius{"radius"};
   Property<int> id{"id"};
@@ -314,6 +314,23 @@ public:
   }
   property_ptr<real4> getForce(access::location l, access::mode m) { return force.data(l, m); }
   property_ptr<real3> getVel(access::location l, access::mode m) { return vel.data(l, m); }
+  // torques (real4) and orientation quaternions (n, vx, vy, vz) are allocated on first request, as every UAMMD property
+  property_ptr<real4> getTorque(access::location l, access::mode m) {
+    if (!torque.isAllocated()) torque.resize(numberParticles);
+    return torque.data(l, m);
+  }
+  property_ptr<real4> getDir(access::location l, access::mode m) {
+    if (!dir.isAllocated()) {
+      dir.resize(numberParticles);
+      auto d = dir.data(access::cpu, access::write);
+      for (int i = 0; i < numberParticles; ++i) d[i] = make_real4(1, 0, 0, 0);
+    }
+    return dir.data(l, m);
+  }
+  property_ptr<real4> getTorqueIfAllocated(access::location l, access::mode m) { return torque.isAllocated() ? torque.data(l, m) : property_ptr<real4>(); }
+  property_ptr<real4> getDirIfAllocated(access::location l, access::mode m) { return dir.isAllocated() ? dir.data(l, m) : property_ptr<real4>(); }
+  bool isTorqueAllocated() const { return torque.isAllocated(); }
+  bool isDirAllocated() const { return dir.isAllocated(); }
   property_ptr<real> getEnergy(access::location l, access::mode m) { return energy.data(l, m); }
   property_ptr<real> getVirial(access::location l, access::mode m) { return virial.data(l, m); }
   property_ptr<real> getMass(access::location l, access::mode m) { return mass.data(l, m); }
@@ -344,6 +361,7 @@ public:
     uammd_celllist_data d;
     detail::check(uammd_celllist_get(cl, &d));
     reorder(pos, d.d_groupIndex, st); reorder(force, d.d_groupIndex, st); reorder(vel, d.d_groupIndex, st);
+    reorder(torque, d.d_groupIndex, st); reorder(dir, d.d_groupIndex, st);
     reorder(energy, d.d_groupIndex, st); reorder(virial, d.d_groupIndex, st); reorder(mass, d.d_groupIndex, st);
     reorder(radius, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
@@ -679,7 +697,61 @@ struct Parameters {
   uint seed = 0;
   bool adaptBoxSize = false;
 };
-class FCM_impl {
+// FCM_ns::Kernels (BDHI/FCM/FCM_kernels.cuh): the windows FCM_impl can be instantiated with.  Each tag fills the
+// C-ABI window for a cell size h and a tolerance, returns fixHydrodynamicRadius(.., h), and has adviseGridSize.
+namespace FCM_ns {
+namespace Kernels {
+struct Gaussian {  // :22-58
+  static real make(real h, real tol, uammd_ibm_kernel *k) { float a = 0; uammd::detail::check(uammd_fcm_gaussian_kernel(h, tol, k, &a)); return a; }
+  static real adviseGridSize(real a, real tol) { return uammd_fcm_advise_grid_size(a, tol); }
+};
+struct BarnettMagland {  // :82-155
+  static int computeSupport(real tol) {
+    real w = std::max(1.5, int(-std::log10(tol) + 2) / 2.0);
+    w = std::min(real(9.0), w);
+    return (int)std::ceil(w);
+  }
+  static real computeUpsampling(real w) { return 1.36409985665115 * std::pow(w, -0.53028415751646); }
+  static real make(real h, real tol, uammd_ibm_kernel *k) {
+    const int w = computeSupport(tol);
+    const real alpha = w * 0.5;
+    uammd::detail::check(uammd_ibm_barnett_magland_kernel(alpha, real(1.8 * w * 2), (int)std::ceil(2 * alpha), h, k));
+    return h / computeUpsampling(k->support[0]);
+  }
+  static real adviseGridSize(real a, real tol) { return a * computeUpsampling(computeSupport(tol)); }
+};
+namespace detail {
+inline void gridWindow(int kind, int support, real h, uammd_ibm_kernel *k) {
+  *k = uammd_ibm_kernel{};
+  k->kind = kind;
+  k->support[0] = k->support[1] = k->support[2] = support;
+  k->rmax = std::numeric_limits<float>::infinity();
+  k->invh[0] = k->invh[1] = k->invh[2] = real(1.0) / h;
+}
+}  // namespace detail
+namespace Peskin {
+struct threePoint {  // :159-176
+  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN3, 3, h, k); return h; }
+  static real adviseGridSize(real a, real) { return a; }
+};
+struct fourPoint {  // :178-196
+  static constexpr real fac = 1.31;
+  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN4, 4, h, k); return h * fac; }
+  static real adviseGridSize(real a, real) { return a / fac; }
+};
+}  // namespace Peskin
+namespace GaussianFlexible {
+struct sixPoint {  // :199-219
+  static constexpr real fac = 1.5195;
+  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_SIXPOINT, 6, h, k); return h * fac; }
+  static real adviseGridSize(real a, real) { return a / fac; }
+};
+}  // namespace GaussianFlexible
+struct GaussianTorque {};  // :60-80, built by uammd_fcm_torque_gaussian_kernel
+}  // namespace Kernels
+}  // namespace FCM_ns
+
+template <class Kernel = FCM_ns::Kernels::Gaussian, class KernelTorque = FCM_ns::Kernels::GaussianTorque> class FCM_impl {
   uammd_fcm *h = nullptr;
   Box box;
   real viscosity, hydrodynamicRadius;
@@ -693,29 +765,40 @@ public:
     p.viscosity = par.viscosity;
     p.seed = par.seed;
     const real hx = p.boxSize[0] / p.cells[0], hy = p.boxSize[1] / p.cells[1], hz = p.boxSize[2] / p.cells[2];
-    float a_eff = 0;
-    detail::check(uammd_fcm_gaussian_kernel(std::min(hx, std::min(hy, hz)), par.tolerance, &p.kernel, &a_eff));
-    hydrodynamicRadius = p.hydrodynamicRadius = a_eff;  // Kernel::fixHydrodynamicRadius (FCM_kernels.cuh:52)
+    const real hmin = std::min(hx, std::min(hy, hz));
+    // initializeKernel + fixHydrodynamicRadius (BDHI_FCM.cuh:49-66, :104-106)
+    hydrodynamicRadius = p.hydrodynamicRadius = Kernel::make(hmin, par.tolerance, &p.kernel);
     detail::check(uammd_fcm_create(&p, &h));
+    uammd_ibm_kernel kt;  // initializeKernelTorque, BDHI_FCM.cuh:69-80
+    detail::check(uammd_fcm_torque_gaussian_kernel(hydrodynamicRadius, hmin, par.tolerance, &kt));
+    detail::check(uammd_fcm_set_torque_kernel(h, &kt));
   }
   FCM_impl(const FCM_impl &) = delete;
   ~FCM_impl() { uammd_fcm_destroy(h); }
   real getHydrodynamicRadius() { return hydrodynamicRadius; }
   real getSelfMobility() { return (real)uammd_fcm_self_mobility(hydrodynamicRadius, viscosity, box.boxSize.x); }
   Box getBox() { return box; }
-  // linear velocities into d_linearVelocity (real3[N]); torques are not on this round's path
+  // linear velocities into d_linearVelocity (real3[N])
   void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, real3 *d_linearVelocity, int N, real temperature,
                                         real prefactor, hipStream_t st) {
     detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
                                           (float *)d_linearVelocity, (void *)st));
   }
+  // with torques (FCM_impl.cuh:306-358): linear and angular velocities; torque == nullptr falls back to the call above
+  void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, const real4 *torque, real3 *d_linearVelocity,
+                                        real3 *d_angularVelocity, int N, real temperature, real prefactor, hipStream_t st) {
+    if (!torque) return computeHydrodynamicDisplacements(pos, force, d_linearVelocity, N, temperature, prefactor, st);
+    detail::check(uammd_fcm_displacements_torque(h, (const float *)pos, (const float *)force, (const float *)torque, N, temperature,
+                                                 prefactor, (float *)d_linearVelocity, (float *)d_angularVelocity, (void *)st));
+  }
 };
 namespace detail_fcm {
+template <class Kernel = FCM_ns::Kernels::Gaussian>
 inline BDHI::Parameters initialize(BDHI::Parameters par, System &sys) {  // BDHI_FCM.cuh:29-66, :98-110
   if (par.seed == 0) par.seed = sys.rng().next32();
   if (par.cells.x <= 0) {
     if (par.hydrodynamicRadius <= 0) System::log<System::CRITICAL>("[BDHI::FCM] I need an hydrodynamic radius if cell dimensions are not provided!");
-    const real h = uammd_fcm_advise_grid_size(par.hydrodynamicRadius, par.tolerance);
+    const real h = Kernel::adviseGridSize(par.hydrodynamicRadius, par.tolerance);
     int c[3] = {(int)(par.box.boxSize.x / h), (int)(par.box.boxSize.y / h), (int)(par.box.boxSize.z / h)};
     for (int &v : c) {  // nextFFTWiseSize3D, utils/Grid.cuh:142-213
       for (;; ++v) {
@@ -733,12 +816,12 @@ inline BDHI::Parameters initialize(BDHI::Parameters par, System &sys) {  // BDHI
 }  // namespace detail_fcm
 class FCM {  // the Method concept of BDHI::EulerMaruyama (BDHI_FCM.cuh:84-147)
   shared_ptr<ParticleData> pd;
-  shared_ptr<FCM_impl> fcm;
+  shared_ptr<FCM_impl<>> fcm;
   real temperature, dt;
 public:
   using Parameters = BDHI::Parameters;
   FCM(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), temperature(par.temperature), dt(par.dt) {
-    fcm = make_shared<FCM_impl>(detail_fcm::initialize(par, *pd->getSystem()));
+    fcm = make_shared<FCM_impl<>>(detail_fcm::initialize(par, *pd->getSystem()));
   }
   void setup_step(hipStream_t = 0) {}
   void computeMF(real3 *MF, hipStream_t st = 0) {
@@ -751,19 +834,22 @@ public:
   real getHydrodynamicRadius() { return fcm->getHydrodynamicRadius(); }
   real getSelfMobility() { return fcm->getSelfMobility(); }
 };
-class FCMIntegrator : public Integrator {  // BDHI_FCM.cu:95-119
-  shared_ptr<FCM_impl> fcm;
-  detail::DeviceArray<real3> linearV;
+// BDHI_FCM.cuh:155-199, BDHI_FCM.cu:7-119.  The reference fixes Kernel = Gaussian; the template parameter exposes the
+// alternatives it keeps commented out in FCM_impl.cuh:39-42.
+template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : public Integrator {
+  shared_ptr<FCM_impl<Kernel>> fcm;
+  detail::DeviceArray<real3> linearV, angularV;
   real temperature, dt;
   uint steps = 0;
   hipStream_t st = 0;
 public:
   using Parameters = BDHI::Parameters;
-  FCMIntegrator(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "BDHI::FCMIntegrator"), linearV(pd->getNumParticles()), temperature(par.temperature), dt(par.dt) {
-    fcm = make_shared<FCM_impl>(detail_fcm::initialize(par, *sys));
+  FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "BDHI::FCMIntegrator"), linearV(pd->getNumParticles()), angularV(pd->getNumParticles()),
+        temperature(par.temperature), dt(par.dt) {
+    fcm = make_shared<FCM_impl<Kernel>>(detail_fcm::initialize<Kernel>(par, *sys));
   }
-  shared_ptr<FCM_impl> getFCM_impl() { return fcm; }
+  shared_ptr<FCM_impl<Kernel>> getFCM_impl() { return fcm; }
   void forwardTime() override {
     steps++;
     for (auto &u : updatables) u->updateSimulationTime(steps * dt);
@@ -772,17 +858,26 @@ public:
       auto force = pd->getForce(access::gpu, access::write);
       detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
     }
+    if (pd->isDirAllocated()) {  // computeCurrentForces, BDHI_FCM.cu:50-57
+      auto torque = pd->getTorque(access::gpu, access::write);
+      detail::check(uammd_fill_zero(torque.raw(), sizeof(real4) * torque.size(), (void *)st));
+    }
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
     const int N = pd->getNumParticles();
     {
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
-      fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), linearV.d, N, temperature, 1.0 / std::sqrt(dt), st);
+      auto torque = pd->getTorqueIfAllocated(access::gpu, access::read);
+      fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), torque.raw(), linearV.d, angularV.d, N, temperature,
+                                            1.0 / std::sqrt(dt), st);
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
-    detail::check(uammd_fcm_euler_maruyama((float *)pos.raw(), nullptr, (const float *)linearV.d, N, dt, (void *)st));
+    auto dir = pd->getDirIfAllocated(access::gpu, access::readwrite);
+    detail::check(uammd_fcm_euler_maruyama_dir((float *)pos.raw(), (float *)dir.raw(), nullptr, (const float *)linearV.d,
+                                               dir.raw() ? (const float *)angularV.d : nullptr, N, dt, (void *)st));
   }
 };
+using FCMIntegrator = FCMIntegratorT<>;
 }  // namespace BDHI
 
 // ---- BDHI::PSE (Integrator/BDHI/BDHI_PSE.cuh:79-176) and BDHI::EulerMaruyama<Method> (BDHI_EulerMaruyama.cu:125-166) --------------

@@ -77,3 +77,54 @@ def test_orientation_update_matches_oracle(hip, o32):
     assert np.array_equal(dpos.cpu().numpy(), rp)
     assert np.abs(dq.cpu().numpy() - rq).max() <= 2e-6
     assert np.abs(np.linalg.norm(dq.cpu().numpy(), axis=1) - 1).max() <= 1e-5   # unit quaternions stay unit
+
+
+def test_fcm_integrator_with_orientations_matches_oracle(hip, o32):
+    """BDHI::FCMIntegrator::forwardTime with dir allocated (BDHI_FCM.cu:7-119): forces and torques are reset, the
+    interactors write both, positions and quaternions advance with the linear/angular velocities of the torque path."""
+    import ctypes as C
+    from oracle.fcm import FCMOracle
+    from oracle.oracle import _p
+    n, L, cells, dt, visc, seed = 300, 32.0, [32, 32, 32], 0.02, 1.1, 4242
+    rng = np.random.default_rng(21)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    torque = np.zeros((n, 4), np.float32)
+    torque[:, :3] = rng.normal(0, 1, (n, 3))
+    q0 = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+
+    pd = hip.ParticleData(n)
+    pd.setPos(pos)
+    pd.getDir("write").copy_(torch.from_numpy(q0))
+
+    class Both(hip.Interactor):
+        def __init__(self, pd):
+            self.pd = pd
+
+        def sum(self, force=False, energy=False, virial=False):
+            # the integrator must have zeroed both before calling the interactors
+            assert float(self.pd.getForce("read").abs().max()) == 0.0 and float(self.pd.getTorque("read").abs().max()) == 0.0
+            self.pd.getForce("readwrite").add_(torch.from_numpy(globals_["force"]).cuda())
+            self.pd.getTorque("readwrite").add_(torch.from_numpy(globals_["torque"]).cuda())
+
+    globals_ = {"force": force, "torque": torque}
+    par = hip.BDHI.FCMIntegrator.Parameters(temperature=0.0, viscosity=visc, tolerance=1e-3, dt=dt, box=hip.Box(L), cells=cells,
+                                            seed=seed)
+    integ = hip.BDHI.FCMIntegrator(pd, par)
+    integ.addInteractor(Both(pd))
+    integ.forwardTime()
+    torch.cuda.synchronize()
+
+    ref = FCMOracle(o32, L, cells, tolerance=1e-3, viscosity=visc, seed=seed)
+    okt, _ = ref.torque_kernel(tolerance=1e-3)
+    rv, rw = ref.displacements_torque(pos, force, torque, okt, 0.0, 0.0)
+    rp, rq = pos.copy(), q0.copy()
+    rv32, rw32 = np.ascontiguousarray(rv, np.float32), np.ascontiguousarray(rw, np.float32)
+    o32.lib.oracle_fcm_euler_maruyama_dir(_p(rp), _p(rq), None, _p(rv32), _p(rw32), n, C.c_float(dt))
+    gp, gq = pd.getPos("read").cpu().numpy(), pd.getDir("read").cpu().numpy()
+    assert np.abs(gp - rp).max() <= 1e-5 * dt * np.abs(rv).max() + 2e-6
+    assert np.abs(gq - rq).max() <= 1e-5
+    assert np.abs(gq - q0).max() > 1e-4   # the orientations did move

@@ -326,7 +326,8 @@ class FCM:
 
 
 class FCMIntegrator(Integrator):
-    """BDHI::FCMIntegrator::forwardTime (BDHI_FCM.cu:95-119): forces -> displacements -> pos += v dt."""
+    """BDHI::FCMIntegrator (BDHI_FCM.cuh:155-199, BDHI_FCM.cu:7-119): forces (and torques when the particles carry
+    orientations) -> linear/angular velocities -> pos += v dt, dir = rotVec2Quaternion(w dt) * dir."""
     Parameters = _Parameters
 
     def __init__(self, pd, par):
@@ -334,6 +335,7 @@ class FCMIntegrator(Integrator):
         self.temperature, self.dt = par.temperature, par.dt
         box, cd, kernel, a_eff = _initialize(par, pd.rng)
         self.fcm = FCM_impl(box, cd, kernel, par.viscosity, par.seed, a_eff)
+        self.fcm.setTorqueKernel(getattr(par, "kernelTorque", None), par.tolerance)  # detail::initializeKernelTorque
         self._v = torch.empty((pd.N, 3), dtype=torch.float32, device=pd.device)
 
     def getFCM_impl(self):
@@ -350,12 +352,26 @@ class FCMIntegrator(Integrator):
                 it.updateTemperature(self.temperature)
                 it.updateBox(self.fcm.getBox())
         pd.getForce("write").zero_()
+        if pd.isDirAllocated():            # computeCurrentForces, BDHI_FCM.cu:50-57
+            pd.getTorque("write").zero_()
         for it in self.interactors:
             it.sum(force=True)
-        self.fcm.computeHydrodynamicDisplacements(pd.getPos("read"), pd.getForce("read"), pd.N, self.temperature,
-                                                  1.0 / math.sqrt(self.dt), out=self._v)
-        check(self.lib.uammd_fcm_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(self._v), pd.N, self.dt,
-                                                current_stream()))
+        torque = pd.getTorqueIfAllocated("read")
+        dirs = pd.getDirIfAllocated("readwrite")
+        w = None
+        if torque is not None:
+            v, w = self.fcm.computeHydrodynamicDisplacementsTorque(pd.getPos("read"), pd.getForce("read"), torque, pd.N,
+                                                                   self.temperature, 1.0 / math.sqrt(self.dt))
+        else:
+            v = self.fcm.computeHydrodynamicDisplacements(pd.getPos("read"), pd.getForce("read"), pd.N, self.temperature,
+                                                          1.0 / math.sqrt(self.dt), out=self._v)
+        if dirs is None:
+            check(self.lib.uammd_fcm_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(v), pd.N, self.dt,
+                                                    current_stream()))
+        else:
+            check(self.lib.uammd_fcm_euler_maruyama_dir(_ptr(pd.getPos("readwrite")), _ptr(dirs), None, _ptr(v),
+                                                        _ptr(w) if w is not None else None, pd.N, self.dt,
+                                                        current_stream()))
 
 
 class _PSEParameters(_Parameters):

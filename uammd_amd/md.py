@@ -105,6 +105,28 @@ class ParticleData:
     def getVel(self, mode="read"):
         return self._get("vel", 3)
 
+    def getTorque(self, mode="read"):
+        return self._get("torque", 4)
+
+    def getDir(self, mode="read"):
+        """Orientation quaternions real4 (n, vx, vy, vz), initialised to the identity (ParticleData.cuh: dir)."""
+        if "dir" not in self._props:
+            d = self._get("dir", 4)
+            d[:, 0] = 1.0
+        return self._props["dir"]
+
+    def getTorqueIfAllocated(self, mode="read"):
+        return self._props.get("torque")
+
+    def getDirIfAllocated(self, mode="read"):
+        return self._props.get("dir")
+
+    def isDirAllocated(self):
+        return "dir" in self._props
+
+    def isTorqueAllocated(self):
+        return "torque" in self._props
+
     def getEnergy(self, mode="read"):
         return self._get("energy", 1)
 
