@@ -1,0 +1,132 @@
+"""Oracle pins for the triply periodic Poisson solver (Interactor/SpectralEwaldPoisson.cu), from the reference's tests:
+  * test/Potentials/Poisson/TriplyPeriodic/test_poisson.cu:189-222   SingleSimulationTest (force and field vs the analytic field)
+  * test_poisson.cu:224-271                                           InfiniteBoxSizeTest, thinned: L -> infinity extrapolation
+  * test/Potentials/Poisson/TriplyPeriodic/test_tp_quadrupole.cu + common/quadrupole_test_base.cuh   point quadrupole
+plus consistency checks the restatement must satisfy (split independence, table vs closed form, Newton's third law).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.poisson import PoissonOracle
+
+
+def theoretical_field(r, gw):   # test_poisson.cu:14-18
+    return -math.exp(-r * r / (4.0 * gw * gw)) / (4 * math.pi * math.sqrt(math.pi) * gw * r) - math.erf(r / (2.0 * gw)) / (4 * math.pi * r * r)
+
+
+def _three_charges(L, r, rng):   # test_poisson.cu:126-139
+    ori = rng.uniform(-0.5, 0.5, 3) * L
+    pos = np.array([[-r * 0.5, 0, 0], [r * 0.5, 0, 0], [r * 0.5, 0, 0]]) + ori
+    return pos, np.array([1.0, -0.5, -0.5])
+
+
+def _force_and_field(o, L, r, tol, gw, split, rng):
+    pos, q = _three_charges(L, r, rng)
+    p = PoissonOracle(o, L, 1.0, gw, tol, split)
+    f = np.zeros((3, 4), o.real)
+    e = np.zeros(3, o.real)
+    p.sum(pos, q, f, e, force=True)
+    fp = p.computeFieldPotentialAtParticles(pos, q)
+    return f[0], fp[0]
+
+
+def test_single_simulation(o64):
+    """test_poisson.cu:189-222: L = 100, r = 2, tolerance 1e-7, gw = 1e-3, split 0.2; relative error < 1e-3."""
+    rng = np.random.default_rng(1)
+    force, field = _force_and_field(o64, 100.0, 2.0, 1e-7, 0.001, 0.2, rng)
+    th = theoretical_field(2.0, 0.001)
+    for v in (force, field):
+        assert abs(v[1]) < 1e-10 and abs(v[2]) < 1e-10 and v[0] > 0
+        assert abs(1.0 - abs(v[0] / th)) < 1e-3
+
+
+@pytest.mark.slow
+def test_infinite_box_extrapolation(o64):
+    """test_poisson.cu:224-271 with every fourth box size and r in {2, 10}: the constant term of the 1/L polynomial fit
+    matches the free-space field to 1e-4."""
+    rng = np.random.default_rng(2)
+    tol, gw = 1e-7, 0.001
+    for r in (2.0, 10.0):
+        Ls, vals = [], []
+        L = max(16.0, 4 * r)
+        while L <= 450.0:
+            split = max(1.0 - (L - 16.0) / (128.0 - 16.0) * 0.9, 0.1)
+            force, _ = _force_and_field(o64, L, r, tol, gw, split, rng)
+            Ls.append(L)
+            vals.append(float(np.linalg.norm(force[:3])))
+            L += 16.0
+        A = np.vander(1.0 / np.array(Ls), 6, increasing=True)
+        coef = np.linalg.lstsq(A, np.array(vals), rcond=None)[0]
+        assert abs(1.0 - abs(coef[0] / theoretical_field(r, gw))) < 1e-4, (r, coef[0])
+
+
+@pytest.mark.slow
+def test_quadrupole(o64):
+    """test_tp_quadrupole.cu:4-24: box 50, gw = 0.2 sqrt(2/3), tolerance 1e-14, split 1.53093, charges (+,-,-,+) at
+    (-d, 0, 0, d), d = 0.01; field and potential at 996 neutral probes on x in [1.5, 4) vs the point quadrupole,
+    absolute errors < 1e-8 (field) and < 1e-7 (potential)."""
+    d, N = 0.01, 1000
+    pos = np.zeros((N, 3))
+    q = np.zeros(N)
+    pos[0, 0], pos[3, 0] = -d, d
+    q[:4] = [1.0, -1.0, -1.0, 1.0]
+    pos[4:, 0] = 1.5 + (np.arange(4, N) - 4.0) / (N - 4.0) * 2.5
+    p = PoissonOracle(o64, 50.0, 1.0, 0.2 * math.sqrt(2.0 / 3.0), 1e-14, 1.53093)
+    fp = p.computeFieldPotentialAtParticles(pos, q)[4:]
+    r = pos[4:, 0]
+    ex = 2.0 / (4.0 * math.pi) * (3 * d * d / r ** 4)      # quadrupole_test_base.cuh:12-20
+    phi = 2.0 / (4.0 * math.pi) * (d * d / r ** 3)
+    assert np.abs(fp[:, 0] - ex).max() < 1e-8
+    assert np.abs(fp[:, 3] - phi).max() < 1e-7
+
+
+def test_split_independence_and_third_law(o64):
+    """SpectralEwaldPoisson.cuh:38-41: two different splits agree; forces sum to zero for a neutral set.  At tolerance 1e-6
+    the grid heuristic picks h = 0.7 sigma, whose aliasing error is ~exp(-(pi sigma/h)^2/2) ~ 5e-5: the splits agree to
+    ~2e-4 of the largest force, not to the nominal tolerance (the reference lists this heuristic as a TODO, .cu:3)."""
+    rng = np.random.default_rng(3)
+    n, L = 40, 24.0
+    pos = rng.uniform(-L / 2, L / 2, (n, 3))
+    q = rng.normal(0, 1, n)
+    q -= q.mean()
+    res = []
+    for split in (0.6, 0.9):
+        p = PoissonOracle(o64, L, 1.3, 0.4, 1e-6, split)
+        f = np.zeros((n, 4))
+        e = np.zeros(n)
+        p.sum(pos, q, f, e, force=True, energy_flag=True)
+        res.append((f.copy(), e.copy(), p.computeFieldPotentialAtParticles(pos, q)))
+    (f0, e0, fp0), (f1, e1, fp1) = res
+    scale = np.abs(f0[:, :3]).max()
+    assert np.abs(f0 - f1).max() <= 5e-4 * scale
+    assert np.abs(e0 - e1).max() <= 5e-4 * np.abs(e0).max()
+    assert np.abs(fp0 - fp1).max() <= 5e-4 * np.abs(fp0).max()
+    assert np.abs(f0[:, :3].sum(axis=0)).max() <= 1e-6 * scale * n
+    # force = q E and energy = q phi (UnZip2Real4 for the far field, the Transversers for the near field)
+    assert np.abs(f0[:, :3] - q[:, None] * fp0[:, :3]).max() <= 1e-9 * scale
+    assert np.abs(e0 - q * fp0[:, 3]).max() <= 1e-9 * np.abs(e0).max()
+
+
+def test_tables_match_closed_forms(o32, o64):
+    """TabulatedFunction samples and linear interpolation against the closed forms; 0 at and beyond the cut-off."""
+    for o, tol in ((o64, 2e-6), (o32, 2e-5)):
+        p = PoissonOracle(o, 32.0, 1.0, 0.5, 1e-5, 1.0)
+        rc = float(p.nearFieldCutOff)
+        rs = np.linspace(0.01, rc * 0.999, 500).astype(o.real)
+        got = np.zeros_like(rs)
+        o.lib.oracle_poisson_table_get(o_p(p.tableField), p.ntable, o.creal(rc), o_p(rs), len(rs), o_p(got))
+        o.lib.oracle_poisson_greens_field.restype = o.creal
+        ref = np.array([o.lib.oracle_poisson_greens_field(o.creal(float(r)), o.creal(0.5), o.creal(1.0), o.creal(1.0)) for r in rs])
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+        edge = np.array([rc, rc * 1.5], o.real)
+        out = np.ones(2, o.real)
+        o.lib.oracle_poisson_table_get(o_p(p.tableField), p.ntable, o.creal(rc), o_p(edge), 2, o_p(out))
+        assert out.tolist() == [0.0, 0.0]
+        assert p.ntable >= 4096 and abs(p.tablePotential[-1]) <= 1e-5 * 1.05   # the cut-off is where |G| drops below the tolerance
+
+
+def o_p(a):
+    from oracle.oracle import _p
+    return _p(a)
