@@ -275,6 +275,44 @@ int uammd_fcm_euler_maruyama_dir(float *d_pos, float *d_dir, const int *d_index,
                                  const float *d_angularVelocity, int numberParticles, float dt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Triply periodic electrostatics (another consumer of the spread / FFT / gather engine).  Replaces
+ *   Poisson::Poisson / sum / computeFieldPotentialAtParticles    Interactor/SpectralEwaldPoisson.cuh:83-136, .cu:71-160
+ *   farField (spread q, R2C, chargeFourier2FieldAndPotential, 4 x C2R, gather + UnZip2Real4)   .cu:332-360, :410-559
+ *   nearFieldForce / nearFieldEnergy / nearFieldFieldPotential over a CellList                 .cu:222-329, :362-408
+ * split <= 0 disables the Ewald splitting (far field only).  As in the reference, Parameters::cells and ::support are
+ * not consulted (the grid comes from upsampling or the tolerance heuristic).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_poisson uammd_poisson;
+typedef struct {
+  float boxSize[3];
+  float epsilon;    /* permittivity */
+  float tolerance;
+  float gw;         /* Gaussian source width */
+  float split;      /* Ewald splitting parameter, <= 0: no splitting */
+  float upsampling; /* > 0: h = 1/upsampling */
+} uammd_poisson_parameters;
+typedef struct {
+  int cells[3];
+  int support;
+  float nearFieldCutOff;
+  int nTable;
+  float h;
+} uammd_poisson_info;
+/* Errors (-2) carry the reference's messages: kernel support too large (.cu:95-102), near field cut off too large (:111-116). */
+int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **out, uammd_poisson_info *info);
+int uammd_poisson_destroy(uammd_poisson *h);
+/* Poisson::sum.  d_pos real4[N], d_charge real[N] (pd->getCharge).  The far field ADDS q E to d_force (real4[N]) and q phi
+ * to d_energy (real[N]) whenever the pointer is non-null — the reference's interpolateFields adds both regardless of the
+ * Computables (.cu:561-579), so a faithful caller passes both; nearForce / nearEnergy select the near-field passes
+ * (comp.force / comp.energy). */
+int uammd_poisson_sum(uammd_poisson *h, const float *d_pos, const float *d_charge, int numberParticles, float *d_force,
+                      float *d_energy, int nearForce, int nearEnergy, void *stream);
+/* Poisson::computeFieldPotentialAtParticles: d_fieldPotential real4[N] (Ex, Ey, Ez, phi) is ADDED to (the reference
+ * zero-fills it first).  d_force / d_energy (nullable) receive the far-field side effect the reference's call has. */
+int uammd_poisson_field_potential(uammd_poisson *h, const float *d_pos, const float *d_charge, int numberParticles,
+                                  float *d_fieldPotential, float *d_force, float *d_energy, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Path B on several GPUs — z-slab decomposition of the FCM grid (the reference is single GPU, so these
  * have no reference counterpart: they are the per-rank compute stages of uammd_fcm_displacements, cut where the
  * exchanges happen.  The exchanges themselves are RCCL calls of the host layer, uammd_amd/parallel_fcm.py).

@@ -130,3 +130,11 @@ def test_tables_match_closed_forms(o32, o64):
 def o_p(a):
     from oracle.oracle import _p
     return _p(a)
+
+
+def test_constructor_errors(o32):
+    """.cu:95-102 (support larger than cellDim.x/2 - 1) and :111-116 (near cut-off beyond L/2)."""
+    with pytest.raises(ValueError, match="support is too large"):
+        PoissonOracle(o32, 8.0, 1.0, 0.5, 1e-6, 0.2)
+    with pytest.raises(ValueError, match="cut off is too large"):
+        PoissonOracle(o32, 12.0, 1e-12, 0.3, 1e-3, 1.0)

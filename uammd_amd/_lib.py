@@ -41,6 +41,16 @@ class FCMParameters(C.Structure):
                 ("kernel", IBMKernel), ("hydrodynamicRadius", C.c_float)]
 
 
+class PoissonParameters(C.Structure):
+    _fields_ = [("boxSize", C.c_float * 3), ("epsilon", C.c_float), ("tolerance", C.c_float), ("gw", C.c_float),
+                ("split", C.c_float), ("upsampling", C.c_float)]
+
+
+class PoissonInfo(C.Structure):
+    _fields_ = [("cells", C.c_int * 3), ("support", C.c_int), ("nearFieldCutOff", C.c_float), ("nTable", C.c_int),
+                ("h", C.c_float)]
+
+
 _f3 = C.c_float * 3
 _i3 = C.c_int * 3
 _vp = C.c_void_p
@@ -87,6 +97,10 @@ SIGNATURES = {
     "uammd_ibm_barnett_magland_kernel": (_i, [_f, _f, _i, _f, C.POINTER(IBMKernel)]),
     "uammd_ibm_spread": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
     "uammd_ibm_gather": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
+    "uammd_poisson_create": (_i, [C.POINTER(PoissonParameters), C.POINTER(_vp), C.POINTER(PoissonInfo)]),
+    "uammd_poisson_destroy": (_i, [_vp]),
+    "uammd_poisson_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "uammd_poisson_field_potential": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "uammd_fcm_create": (_i, [C.POINTER(FCMParameters), C.POINTER(_vp)]),
     "uammd_fcm_destroy": (_i, [_vp]),
     "uammd_fcm_displacements": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp]),

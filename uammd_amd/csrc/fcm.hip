@@ -70,6 +70,10 @@ struct FCM {
 };
 
 static std::once_flag g_rocfft_once;
+int rocfft_setup_once() {  // shared with poisson.hip
+  std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
+  return 0;
+}
 
 // ---- spread / gather on the planar grids ---------------------------------------------------------------
 template <bool SPREAD>

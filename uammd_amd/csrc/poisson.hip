@@ -1,0 +1,544 @@
+// Triply periodic electrostatics by spectral Ewald splitting — the Poisson Interactor of the reference, a second consumer
+// of the spread / FFT / gather engine of Path B.
+//
+// Reference behaviour (Interactor/SpectralEwaldPoisson.cu, .cuh):
+//   ctor      grid from the Gaussian far-field width, window support, near cut-off by a 1e-3 gw march, two tables   .cu:71-160
+//   farField  spread q -> R2C -> (E, phi)(k) = (-i k, 1) q(k) / (eps k^2 Ncells) -> 4 x C2R -> gather real4,
+//             force += q E, energy += q phi (always both)                                                          .cu:332-360, :410-559
+//   nearField CellList at the near cut-off, tabulated G(r^2) and G'(r), self pair included                        .cu:222-329, :362-408
+// HIP design: the charge grid is transformed in place; the four outputs are written as component PLANES by the k-space
+// kernel (one batched in-place C2R), then interleaved once into a float4 grid so that the gather issues one 16-byte
+// request per node instead of four (the gather is bound by cache-line requests on gfx950).  The near field
+// runs one thread per Morton-sorted particle over a packed (x, y, z, q) array in the reference's neighbour order.
+#include "celllist.hpp"
+#include "ibm.hpp"
+
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace uammd_hip {
+
+int rocfft_setup_once();  // fcm.hip
+
+#define UH_ROCFFT(expr)                                                                      \
+  do {                                                                                       \
+    rocfft_status s_ = (expr);                                                               \
+    if (s_ != rocfft_status_success) {                                                       \
+      set_last_error("%s failed with rocfft_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+      return -10 - (int)s_;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+struct Poisson {
+  uammd_poisson_parameters par{};
+  float L[3] = {0, 0, 0};
+  int cells[3] = {0, 0, 0};
+  GridT<float> grid{};
+  uammd_ibm_kernel kernel{};
+  IBMKernelDev kern{};
+  int nxpad = 0;
+  size_t planeReal = 0, planeCplx = 0;
+  float cutoff = 0.f;
+  int ntable = 0;
+  DeviceBuffer tableField, tablePotential, gridQ, planes, inter, packed, work;
+  CellList cl;
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  ~Poisson() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+
+// ---- host: closed forms and heuristics (double arithmetic on float arguments, as the reference's host code) ----------
+static float greens(float r2, float gw, float split, float epsilon) {  // .cu:15-38
+  double G = 0;
+  if (r2 > gw * gw * gw * gw) {
+    const double r = sqrtf(r2);
+    const float farw = sqrtf(4 * gw * gw + 1 / (split * split));
+    G = (1.0 / (4.0 * M_PI * epsilon * r) * (erf(r / (2 * gw)) - erf(r / farw)));
+  } else {
+    const double pi32 = pow(M_PI, 1.5);
+    const double gw2 = gw * gw;
+    const double invsp2 = 1.0 / (split * split);
+    const double selfterm = 1.0 / (4 * pi32 * gw) - 1.0 / (2 * pi32 * sqrt(4 * gw2 + invsp2));
+    const double r2term = 1.0 / (6.0 * pi32 * pow(4.0 * gw2 + invsp2, 1.5)) - 1.0 / (48.0 * pi32 * gw2 * gw);
+    const double r4term = 1.0 / (640.0 * pi32 * gw2 * gw2 * gw) - 1.0 / (20.0 * pi32 * pow(4 * gw2 + invsp2, 2.5));
+    G = 1.0 / epsilon * (selfterm + r2 * r2term + r2 * r2 * r4term);
+  }
+  return (float)G;
+}
+static float greens_field(float r, float gw, float split, float epsilon) {  // .cu:40-62
+  const double r2 = r * r;
+  const double gw2 = gw * gw;
+  const double newgw = sqrt(gw2 + 1 / (4.0 * split * split));
+  const double newgw2 = newgw * newgw;
+  double fmod = 0;
+  if (r2 > gw * gw * gw * gw) {
+    const double invrterm = exp(-0.25 * r2 / newgw2) / sqrt(M_PI * newgw2) - exp(-0.25 * r2 / gw2) / sqrt(M_PI * gw2);
+    const double invr2term = erf(0.5 * r / newgw) - erf(0.5 * r / gw);
+    fmod += 1 / (4 * M_PI) * (invrterm / r - invr2term / r2);
+  } else if (r2 > 0) {
+    const double pi32 = pow(M_PI, 1.5);
+    const double rterm = 1 / (24 * pi32) * (1.0 / (gw2 * gw) - 1 / (newgw2 * newgw));
+    const double r3term = 1 / (160 * pi32) * (1.0 / (newgw2 * newgw2 * newgw) - 1.0 / (gw2 * gw2 * gw));
+    fmod += r * rterm + r2 * r * r3term;
+  }
+  return (float)(fmod / epsilon);
+}
+static double far_width(float gw, float split) {
+  double w = gw;
+  if (split > 0) w = sqrt(gw * gw + 1.0 / (4.0 * split * split));
+  return w;
+}
+// nextFFTWiseSize3D (utils/Grid.cuh:142-213): smallest even 2^a 3^b 5^c 7^d 11^e >= n with c<=5, d<=4, e<=3
+static int next_fft_wise(int n) {
+  static const int primes[5] = {2, 3, 5, 7, 11}, maxExp[5] = {64, 64, 5, 4, 3};
+  for (int c = std::max(n, 1);; ++c) {
+    if (c % 2) continue;
+    int m = c;
+    bool ok = true;
+    for (int p = 0; p < 5; ++p) {
+      int e = 0;
+      while (m % primes[p] == 0) { m /= primes[p]; ++e; }
+      ok = ok && e <= maxExp[p];
+    }
+    if (ok && m == 1) return c;
+  }
+}
+
+// ---- device ------------------------------------------------------------------------------------------------------
+struct Table1 {
+  const float *table;
+  int Nm1;
+  float rmax, interval, dr;
+};
+// TabulatedFunction::operator() with LinearInterpolation (misc/TabulatedFunction.cuh:63-75, :148-157), rmin = 0
+UH_D float table_get1(const Table1 &t, float rs) {
+  const float r = rs * t.interval;
+  if (rs >= t.rmax) return 0.0f;
+  if (r <= 0.0f) return t.table[0];
+  const int i = (int)(r * (float)t.Nm1);
+  const float r0 = (float)i * t.dr;
+  const float v0 = t.table[i], v1 = t.table[i + 1];
+  const float w = (r - r0) * (float)t.Nm1;
+  return fmaf(w, v1, fmaf(-w, v0, v0));
+}
+
+// chargeFourier2FieldAndPotential (.cu:433-476); planes: Ex, Ey, Ez, phi, each complex[nz][ny][nkx]
+__global__ void __launch_bounds__(256) k_poisson_convolve(const float2 *__restrict__ qk, float2 *__restrict__ planes, size_t planeCplx,
+                                                          int3 n, real3f L, float epsilon, FastDiv dkx, FastDiv dny) {
+  const uint id = blockIdx.x * 256 + threadIdx.x;
+  const int nkx = n.x / 2 + 1;
+  if (id >= (uint)(nkx * n.y * n.z)) return;
+  const uint row = dkx.div(id);
+  const int cx = (int)(id - row * (uint)nkx);
+  const int cz = (int)dny.div(row);
+  const int cy = (int)(row - (uint)cz * (uint)n.y);
+  float2 ex{0.f, 0.f}, ey{0.f, 0.f}, ez{0.f, 0.f}, ph{0.f, 0.f};
+  const bool xn = (cx == n.x - cx) && (n.x % 2 == 0), yn = (cy == n.y - cy) && (n.y % 2 == 0), zn = (cz == n.z - cz) && (n.z % 2 == 0);
+  const bool nyquist = (xn && cy == 0 && cz == 0) || (xn && yn && cz == 0) || (cx == 0 && yn && cz == 0) || (xn && cy == 0 && zn) ||
+                       (cx == 0 && cy == 0 && zn) || (cx == 0 && yn && zn) || (xn && yn && zn);
+  if (!(cx == 0 && cy == 0 && cz == 0) && !nyquist) {
+    const float px = (2.0f * (float)M_PI) / L.x, py = (2.0f * (float)M_PI) / L.y, pz = (2.0f * (float)M_PI) / L.z;
+    float kx = (float)cx * px, ky = (float)cy * py, kz = (float)cz * pz;
+    if (cx >= n.x / 2 + 1) kx -= (float)n.x * px;
+    if (cy >= n.y / 2 + 1) ky -= (float)n.y * py;
+    if (cz >= n.z / 2 + 1) kz -= (float)n.z * pz;
+    const float k2 = fmaf(kz, kz, fmaf(ky, ky, kx * kx));
+    const float2 fk = qk[id];
+    const float B = 1.0f / (k2 * epsilon * (float)(n.x * n.y * n.z));
+    ex = make_float2(kx * fk.y * B, -kx * fk.x * B);
+    ey = make_float2(ky * fk.y * B, -ky * fk.x * B);
+    ez = make_float2(kz * fk.y * B, -kz * fk.x * B);
+    ph = make_float2(fk.x * B, fk.y * B);
+  }
+  planes[id] = ex;
+  planes[planeCplx + id] = ey;
+  planes[2 * planeCplx + id] = ez;
+  planes[3 * planeCplx + id] = ph;
+}
+
+__global__ void __launch_bounds__(256) k_poisson_interleave(const float *__restrict__ planes, size_t planeReal,
+                                                            float4 *__restrict__ out, uint total) {
+  const uint i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  out[i] = make_float4(planes[i], planes[planeReal + i], planes[2 * planeReal + i], planes[3 * planeReal + i]);
+}
+
+// IBM::gather of the real4 grid fused with UnZip2Real4 (.cu:529-559): one wave per particle, one float4 per node
+__global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict__ pos, const float *__restrict__ charge,
+                                                        const float4 *__restrict__ grid4, float4 *__restrict__ force,
+                                                        float *__restrict__ energy, float4 *__restrict__ fieldPotential, int N,
+                                                        GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx,
+                                                        FastDiv dsxy) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= N) return;
+  const float4 p = pos[id];
+  const Stencil s = make_stencil(grid, kern, real3f{p.x, p.y, p.z}, false, lane);
+  const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
+  const int nn = sx * sy * sz;
+  const float dV = grid.cellVolume;
+  float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < nn;
+    const uint iu = in ? (uint)i : 0u;
+    const uint kk = dsxy.div(iu);
+    const uint rem = iu - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const float wx = __shfl(s.w, (int)ii, 64);
+    const float wy = __shfl(s.w, sx + (int)jj, 64);
+    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    if (!in) continue;
+    const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
+    const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
+    const int cz = grid.pbc_z(s.celli.z + (int)kk - s.P.z);
+    const float4 g = grid4[(size_t)cx + (size_t)nxStride * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz)];
+    ax = fmaf(dV, g.x * wx * wy * wz, ax);
+    ay = fmaf(dV, g.y * wx * wy * wz, ay);
+    az = fmaf(dV, g.z * wx * wy * wz, az);
+    aw = fmaf(dV, g.w * wx * wy * wz, aw);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ax += __shfl_xor(ax, o, 64);
+    ay += __shfl_xor(ay, o, 64);
+    az += __shfl_xor(az, o, 64);
+    aw += __shfl_xor(aw, o, 64);
+  }
+  if (lane != 0) return;
+  const float q = charge[id];
+  if (force) {
+    float4 f = force[id];
+    f.x += q * ax; f.y += q * ay; f.z += q * az; f.w += q * 0.0f;
+    force[id] = f;
+  }
+  if (energy) energy[id] += q * aw;
+  if (fieldPotential) {
+    float4 f = fieldPotential[id];
+    f.x += ax; f.y += ay; f.z += az; f.w += aw;
+    fieldPotential[id] = f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_poisson_pack(const float4 *__restrict__ sortPos, const int *__restrict__ groupIndex,
+                                                      const float *__restrict__ charge, float4 *__restrict__ packed, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float4 p = sortPos[i];
+  packed[i] = make_float4(p.x, p.y, p.z, charge[groupIndex[i]]);
+}
+
+// transverseList with NearField{Force,Energy,FieldPotential}Transverser (.cu:222-329).  MODE 0: force4 += (total, 0);
+// 1: energy += total; 2: fieldPotential4 += (E, phi).  Neighbour order = NeighbourList/common.cuh:10-34.
+template <int MODE>
+__global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__ packed, const int *__restrict__ groupIndex,
+                                                      const uint *__restrict__ cellStart, const int *__restrict__ cellEnd,
+                                                      uint validCell, int N, GridT<float> grid, BoxT<float> box, Table1 tabF,
+                                                      Table1 tabP, float *__restrict__ out) {
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  if (id >= N) return;
+  const float4 pi = packed[id];
+  const float qi = pi.w;
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
+  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += cc % 3 - 1;
+    if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+    if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    if (cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z) continue;
+    const int icellj = grid.getCellIndex(cellj);
+    const uint cs = cellStart[icellj];
+    if (cs < validCell) continue;
+    const int first = (int)(cs - validCell), last = cellEnd[icellj];
+    for (int j = first; j < last; ++j) {
+      const float4 pj = packed[j];
+      const real3f rij = box.apply_pbc(real3f{pj.x - pi.x, pj.y - pi.y, pj.z - pi.z});
+      const float r2 = dot3(rij, rij);
+      if (MODE == 1) {
+        tw += qi * pj.w * table_get1(tabP, r2);
+      } else if (MODE == 0) {
+        const float r = sqrtf(r2);
+        const float fmod = -qi * pj.w * table_get1(tabF, r);
+        if (r2 > 0.0f) {
+          const float invr = 1.0f / r;  // real3 / real multiplies by the reciprocal (utils/vector.cuh:191-193)
+          tx += invr * (fmod * rij.x); ty += invr * (fmod * rij.y); tz += invr * (fmod * rij.z);
+        }
+      } else {
+        const float phi = pj.w * table_get1(tabP, r2);
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        if (r2 > 0.0f) {
+          const float r = sqrtf(r2);
+          const float fmod = -pj.w * table_get1(tabF, r);
+          const float invr = 1.0f / r;
+          ex = invr * (fmod * rij.x); ey = invr * (fmod * rij.y); ez = invr * (fmod * rij.z);
+        }
+        tx += ex; ty += ey; tz += ez; tw += phi;
+      }
+    }
+  }
+  const int ori = groupIndex[id];
+  if (MODE == 1) {
+    out[ori] += tw;
+  } else {
+    float4 *o = reinterpret_cast<float4 *>(out) + ori;
+    float4 v = *o;
+    v.x += tx; v.y += ty; v.z += tz; v.w += (MODE == 0 ? 0.0f : tw);
+    *o = v;
+  }
+}
+
+static Table1 view(const DeviceBuffer &b, int ntable, float rmax) {
+  Table1 t;
+  t.table = (const float *)b.ptr;
+  t.Nm1 = ntable - 1;
+  t.rmax = rmax;
+  t.interval = (float)(1.0 / (rmax - 0.0f));
+  t.dr = (float)(1.0 / (float)t.Nm1);
+  return t;
+}
+
+static int poisson_make_plans(Poisson *p) {
+  if (int e = rocfft_setup_once()) return e;
+  const size_t nx = p->cells[0], ny = p->cells[1], nz = p->cells[2], nkx = nx / 2 + 1;
+  const size_t lengths[3] = {nx, ny, nz};
+  const size_t rstr[3] = {1, (size_t)p->nxpad, (size_t)p->nxpad * ny};
+  const size_t cstr[3] = {1, nkx, nkx * ny};
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                                                     nullptr, 3, rstr, p->planeReal, 3, cstr, p->planeCplx));
+  UH_ROCFFT(rocfft_plan_create(&p->fwd, rocfft_placement_inplace, rocfft_transform_type_real_forward, rocfft_precision_single, 3,
+                               lengths, 1, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  UH_ROCFFT(rocfft_plan_description_create(&d));
+  UH_ROCFFT(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                                                     nullptr, 3, cstr, p->planeCplx, 3, rstr, p->planeReal));
+  UH_ROCFFT(rocfft_plan_create(&p->inv, rocfft_placement_inplace, rocfft_transform_type_real_inverse, rocfft_precision_single, 3,
+                               lengths, 4, d));
+  UH_ROCFFT(rocfft_plan_description_destroy(d));
+  size_t wf = 0, wi = 0;
+  UH_ROCFFT(rocfft_plan_get_work_buffer_size(p->fwd, &wf));
+  UH_ROCFFT(rocfft_plan_get_work_buffer_size(p->inv, &wi));
+  const size_t w = std::max(wf, wi);
+  UH_ROCFFT(rocfft_execution_info_create(&p->info));
+  if (w) {
+    if (int e = p->work.reserve(w)) return e;
+    UH_ROCFFT(rocfft_execution_info_set_work_buffer(p->info, p->work.ptr, w));
+  }
+  return 0;
+}
+
+// farField (.cu:332-360): any of d_force / d_energy / d_fieldPotential may be null
+static int poisson_far(Poisson *p, const float *d_pos, const float *d_charge, int N, float *d_force, float *d_energy,
+                       float *d_fieldPotential, hipStream_t st) {
+  const int per[3] = {1, 1, 1};
+  float *gq = (float *)p->gridQ.ptr;
+  UH_CHECK(hipMemsetAsync(gq, 0, sizeof(float) * p->planeReal, st));
+  if (int e = uammd_ibm_spread(d_pos, 4, d_charge, 1, N, p->L, per, p->cells, p->nxpad, &p->kernel, gq, (void *)st)) return e;
+  UH_ROCFFT(rocfft_execution_info_set_stream(p->info, (void *)st));
+  void *bq[1] = {gq};
+  UH_ROCFFT(rocfft_execute(p->fwd, bq, nullptr, p->info));
+  const int3 n = p->grid.cellDim;
+  const int nkx = n.x / 2 + 1;
+  const uint total = (uint)p->planeCplx;
+  hipLaunchKernelGGL(k_poisson_convolve, dim3((total + 255) / 256), dim3(256), 0, st, (const float2 *)gq, (float2 *)p->planes.ptr,
+                     p->planeCplx, n, real3f{p->L[0], p->L[1], p->L[2]}, p->par.epsilon, make_fastdiv(nkx), make_fastdiv(n.y));
+  void *bp[1] = {p->planes.ptr};
+  UH_ROCFFT(rocfft_execute(p->inv, bp, nullptr, p->info));
+  const uint nreal = (uint)p->planeReal;
+  hipLaunchKernelGGL(k_poisson_interleave, dim3((nreal + 255) / 256), dim3(256), 0, st, (const float *)p->planes.ptr, p->planeReal,
+                     (float4 *)p->inter.ptr, nreal);
+  hipLaunchKernelGGL(k_poisson_gather, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_pos, d_charge,
+                     (const float4 *)p->inter.ptr, (float4 *)d_force, d_energy, (float4 *)d_fieldPotential, N, p->grid, p->nxpad,
+                     p->kern, make_fastdiv(p->kern.support.x), make_fastdiv(p->kern.support.x * p->kern.support.y));
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// nl->update(box, nearFieldCutOff) + pack (x, y, z, q) in sorted order
+static int poisson_list(Poisson *p, const float *d_pos, const float *d_charge, int N, hipStream_t st) {
+  const float rc3[3] = {p->cutoff, p->cutoff, p->cutoff};
+  const int per[3] = {1, 1, 1};
+  int cd[3], gper[3];
+  float gL[3];
+  if (int e = uammd_celllist_create_grid(p->L, per, rc3, cd, gL, gper)) return e;
+  if (int e = p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st)) return e;
+  if (int e = p->packed.reserve(sizeof(float4) * (size_t)N)) return e;
+  hipLaunchKernelGGL(k_poisson_pack, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)p->cl.sortPos.ptr,
+                     (const int *)p->cl.index.ptr, d_charge, (float4 *)p->packed.ptr, N);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <int MODE> static int poisson_near(Poisson *p, int N, float *d_out, hipStream_t st) {
+  const int per[3] = {1, 1, 1};
+  const BoxT<float> box = make_box<float>(p->L, per);
+  hipLaunchKernelGGL((k_poisson_near<MODE>), dim3((N + 127) / 128), dim3(128), 0, st, (const float4 *)p->packed.ptr,
+                     (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr,
+                     p->cl.validCell, N, p->cl.grid, box, view(p->tableField, p->ntable, p->cutoff),
+                     view(p->tablePotential, p->ntable, p->cutoff * p->cutoff), d_out);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **out, uammd_poisson_info *info) {
+  if (!par || !out) { set_last_error("uammd_poisson_create: null argument"); return -1; }
+  if (!(par->boxSize[0] > 0) || !(par->boxSize[1] > 0) || !(par->boxSize[2] > 0) || !(par->epsilon > 0) || !(par->gw > 0) ||
+      !(par->tolerance > 0)) {
+    set_last_error("uammd_poisson_create: box, epsilon, gw and tolerance must be positive");
+    return -2;
+  }
+  Poisson *p = new (std::nothrow) Poisson();
+  if (!p) { set_last_error("uammd_poisson_create: out of host memory"); return -3; }
+  p->par = *par;
+  const float gw = par->gw, split = par->split, epsilon = par->epsilon, tolerance = par->tolerance;
+  for (int a = 0; a < 3; ++a) p->L[a] = par->boxSize[a];
+  // grid (.cu:75-90)
+  const double fw = far_width(gw, split);
+  double h;
+  if (par->upsampling > 0) h = 1.0 / par->upsampling;
+  else h = (1.3 - std::min((double)((-log10f(tolerance)) / 10.0), 0.9)) * fw;
+  h = std::min(h, p->L[0] / 32.0);
+  const float hr = (float)h;
+  for (int a = 0; a < 3; ++a) p->cells[a] = next_fft_wise((int)(p->L[a] / hr));
+  const int per[3] = {1, 1, 1};
+  p->grid = make_grid(make_box<float>(p->L, per), make_int3(p->cells[0], p->cells[1], p->cells[2]));
+  const float hx = p->grid.cellSize.x;
+  // window (SpectralEwaldPoisson.cuh:65-70, .cu:93-104)
+  const float width = (float)fw;
+  const float prefactor = (float)cbrt(pow(2 * M_PI * width * width, -1.5));
+  const float tau = (float)(-1.0 / (2.0 * width * width));
+  const float rmax = (float)sqrt(log(tolerance * sqrt(2 * M_PI * width * width)) / tau);
+  int support = std::max(3, (int)(2 * rmax / hx + 0.5));
+  if (support > p->cells[0] / 2 - 1) {
+    set_last_error("[Poisson] Kernel support (%d) is too large for this configuration (max is %d), try increasing splitting "
+                   "parameter or decrasing tolerance", support, p->cells[0] / 2 - 1);
+    delete p;
+    return -2;
+  }
+  support = std::min(support, p->cells[0] / 2 - 2);
+  if (support > kMaxSupport) {
+    set_last_error("uammd_poisson_create: window support %d exceeds the %d nodes per axis one wave evaluates (single precision "
+                   "tolerances below ~1e-7 are not meaningful anyway)", support, kMaxSupport);
+    delete p;
+    return -2;
+  }
+  p->kernel.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+  p->kernel.support[0] = p->kernel.support[1] = p->kernel.support[2] = support;
+  p->kernel.prefactor = prefactor;
+  p->kernel.tau = tau;
+  p->kernel.rmax = INFINITY;  // Poisson_ns::Gaussian::phi has no cut
+  p->kernel.invh[0] = p->kernel.invh[1] = p->kernel.invh[2] = 0.f;
+  p->kern = to_dev(p->kernel);
+  // near field cut-off and tables (.cu:105-118, :140-160)
+  if (split > 0) {
+    long double E = 1;
+    long double r = fw;
+    while (fabsl(E) > tolerance) {
+      r += 0.001l * gw;
+      E = greens((float)(r * r), gw, split, epsilon);
+    }
+    p->cutoff = (float)r;
+    if (p->cutoff > p->L[0] / 2.0) {
+      set_last_error("[Poisson] Near field cut off is too large, increase splitting parameter.");
+      delete p;
+      return -2;
+    }
+    p->ntable = std::max(4096, std::min(1 << 16, (int)(p->cutoff / (gw * tolerance * 1e3))));
+    const int Nm1 = p->ntable - 1;
+    std::vector<float> tf(p->ntable), tp(p->ntable);
+    const float rmaxF = p->cutoff, rmaxP = p->cutoff * p->cutoff;
+    for (int i = 0; i <= Nm1; ++i) {  // TabulatedFunction ctor, misc/TabulatedFunction.cuh:103-117
+      const double xf = (i / (double)Nm1) * (rmaxF - 0.0f) + 0.0f;
+      tf[i] = greens_field((float)xf, gw, split, epsilon);
+      const double xp = (i / (double)Nm1) * (rmaxP - 0.0f) + 0.0f;
+      tp[i] = greens((float)xp, gw, split, epsilon);
+    }
+    int e = p->tableField.reserve(sizeof(float) * tf.size());
+    if (!e) e = p->tablePotential.reserve(sizeof(float) * tp.size());
+    if (e) { delete p; return e; }
+    if (hipMemcpy(p->tableField.ptr, tf.data(), sizeof(float) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->tablePotential.ptr, tp.data(), sizeof(float) * tp.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      set_last_error("uammd_poisson_create: table upload failed");
+      delete p;
+      return -4;
+    }
+  }
+  p->nxpad = 2 * (p->cells[0] / 2 + 1);
+  p->planeReal = (size_t)p->nxpad * p->cells[1] * p->cells[2];
+  p->planeCplx = (size_t)(p->cells[0] / 2 + 1) * p->cells[1] * p->cells[2];
+  int e = p->gridQ.reserve(sizeof(float) * p->planeReal);
+  if (!e) e = p->planes.reserve(sizeof(float) * 4 * p->planeReal);
+  if (!e) e = p->inter.reserve(sizeof(float4) * p->planeReal);
+  if (!e) e = poisson_make_plans(p);
+  if (e) { delete p; return e; }
+  if (info) {
+    for (int a = 0; a < 3; ++a) info->cells[a] = p->cells[a];
+    info->support = support;
+    info->nearFieldCutOff = p->cutoff;
+    info->nTable = p->ntable;
+    info->h = hx;
+  }
+  *out = reinterpret_cast<uammd_poisson *>(p);
+  return 0;
+}
+
+int uammd_poisson_destroy(uammd_poisson *h) {
+  delete reinterpret_cast<Poisson *>(h);
+  return 0;
+}
+
+int uammd_poisson_sum(uammd_poisson *h, const float *d_pos, const float *d_charge, int N, float *d_force, float *d_energy,
+                      int nearForce, int nearEnergy, void *stream) {
+  if (!h || !d_pos || !d_charge) { set_last_error("uammd_poisson_sum: null argument"); return -1; }
+  if ((nearForce && !d_force) || (nearEnergy && !d_energy)) { set_last_error("uammd_poisson_sum: missing output array"); return -1; }
+  if (N <= 0) return 0;
+  Poisson *p = reinterpret_cast<Poisson *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = poisson_far(p, d_pos, d_charge, N, d_force, d_energy, nullptr, st)) return e;
+  if (p->par.split > 0 && (nearForce || nearEnergy)) {
+    if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
+    if (nearForce)
+      if (int e = poisson_near<0>(p, N, d_force, st)) return e;
+    if (nearEnergy)
+      if (int e = poisson_near<1>(p, N, d_energy, st)) return e;
+  }
+  return 0;
+}
+
+int uammd_poisson_field_potential(uammd_poisson *h, const float *d_pos, const float *d_charge, int N, float *d_fieldPotential,
+                                  float *d_force, float *d_energy, void *stream) {
+  if (!h || !d_pos || !d_charge || !d_fieldPotential) { set_last_error("uammd_poisson_field_potential: null argument"); return -1; }
+  if (N <= 0) return 0;
+  Poisson *p = reinterpret_cast<Poisson *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = poisson_far(p, d_pos, d_charge, N, d_force, d_energy, d_fieldPotential, st)) return e;
+  if (p->par.split > 0) {
+    if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
+    if (int e = poisson_near<2>(p, N, d_fieldPotential, st)) return e;
+  }
+  return 0;
+}
+
+}  // extern "C"

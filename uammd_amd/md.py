@@ -136,6 +136,9 @@ class ParticleData:
     def getMass(self, mode="read"):
         return self._get("mass", 1)
 
+    def getCharge(self, mode="read"):
+        return self._get("charge", 1)
+
     def getRadius(self, mode="read"):
         return self._get("radius", 1)
 
