@@ -1,0 +1,4 @@
+// Forwarding header: same include path as the reference's src/Interactor/SpectralEwaldPoisson.cuh.
+// The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).
+#pragma once
+#include "../uammd.h"

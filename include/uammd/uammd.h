@@ -294,7 +294,7 @@ class ParticleData {
   shared_ptr<System> sys;
   Property<real4> pos{"pos"}, force{"force"}, torque{"torque"}, dir{"dir"};
   Property<real3> vel{"vel"};
-  Property<real> energy{"energy"}, virial{"virial"}, mass{"mass"}, radius{"radius"};
+  Property<real> energy{"energy"}, virial{"virial"}, mass{"mass"}, radius{"radius"}, charge{"charge"};
   Property<int> id{"id"};
   std::vector<std::function<void()>> posWriteCallbacks, reorderCallbacks;
   struct Hints { Box hash_box = Box(real(128)); real3 hash_cutOff = make_real3(10.0); } hints;  // ParticleData.cuh:164-169
@@ -335,6 +335,10 @@ public:
   property_ptr<real> getVirial(access::location l, access::mode m) { return virial.data(l, m); }
   property_ptr<real> getMass(access::location l, access::mode m) { return mass.data(l, m); }
   property_ptr<real> getRadius(access::location l, access::mode m) { return radius.data(l, m); }
+  property_ptr<real> getCharge(access::location l, access::mode m) {
+    if (!charge.isAllocated()) charge.resize(numberParticles);
+    return charge.data(l, m);
+  }
   property_ptr<int> getId(access::location l, access::mode m) { return id.data(l, m); }
   property_ptr<real> getMassIfAllocated(access::location l, access::mode m) { return mass.isAllocated() ? mass.data(l, m) : property_ptr<real>(); }
   property_ptr<real> getRadiusIfAllocated(access::location l, access::mode m) { return radius.isAllocated() ? radius.data(l, m) : property_ptr<real>(); }
@@ -363,7 +367,7 @@ public:
     reorder(pos, d.d_groupIndex, st); reorder(force, d.d_groupIndex, st); reorder(vel, d.d_groupIndex, st);
     reorder(torque, d.d_groupIndex, st); reorder(dir, d.d_groupIndex, st);
     reorder(energy, d.d_groupIndex, st); reorder(virial, d.d_groupIndex, st); reorder(mass, d.d_groupIndex, st);
-    reorder(radius, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
+    reorder(radius, d.d_groupIndex, st); reorder(charge, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     detail::check(uammd_celllist_destroy(cl));
     for (auto &cb : posWriteCallbacks) cb();
@@ -1045,6 +1049,65 @@ public:
 }  // namespace BDHI
 
 // ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------
+// ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald ----------------------
+class Poisson : public Interactor {
+  uammd_poisson *h = nullptr;
+  uammd_poisson_info info{};
+public:
+  struct Parameters {  // SpectralEwaldPoisson.cuh:94-103; cells and support are never read by the reference's constructor
+    real upsampling = -1.0;
+    int3 cells = make_int3(-1, -1, -1);
+    Box box;
+    real epsilon = -1;
+    real tolerance = 1e-5;
+    real gw = -1;
+    int support = -1;
+    real split = -1;
+  };
+  Poisson(shared_ptr<ParticleData> pd, Parameters par) : Interactor(pd, "IBM::Poisson") {
+    uammd_poisson_parameters p{};
+    p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
+    p.epsilon = par.epsilon; p.tolerance = par.tolerance; p.gw = par.gw; p.split = par.split; p.upsampling = par.upsampling;
+    if (uammd_poisson_create(&p, &h, &info) != 0) {
+      const std::string msg = uammd_hip_last_error();
+      if (msg.find("[Poisson]") != std::string::npos) throw std::invalid_argument(msg);  // .cu:95-102, :111-116
+      throw std::runtime_error(msg);
+    }
+  }
+  Poisson(const Poisson &) = delete;
+  ~Poisson() { uammd_poisson_destroy(h); }
+  // far field (always adds q E to the forces AND q phi to the energies, .cu:561-579), then the near-field passes
+  void sum(Computables comp, hipStream_t st = 0) override {
+    if (comp.virial) throw std::runtime_error("[Poisson] not implemented");
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto charge = pd->getCharge(access::gpu, access::read);
+    auto force = pd->getForce(access::gpu, access::readwrite);
+    auto energy = pd->getEnergy(access::gpu, access::readwrite);
+    detail::check(uammd_poisson_sum(h, (const float *)pos.raw(), charge.raw(), pd->getNumParticles(), (float *)force.raw(),
+                                    energy.raw(), comp.force, comp.energy, (void *)st));
+  }
+  // (Ex, Ey, Ez, phi) at the particles; like the reference's call, the far field also lands on the forces and energies
+  std::vector<real4> computeFieldPotentialAtParticles() {
+    const int N = pd->getNumParticles();
+    detail::DeviceArray<real4> fp(N);
+    detail::check(uammd_fill_zero(fp.d, sizeof(real4) * (size_t)N, nullptr));
+    {
+      auto pos = pd->getPos(access::gpu, access::read);
+      auto charge = pd->getCharge(access::gpu, access::read);
+      auto force = pd->getForce(access::gpu, access::readwrite);
+      auto energy = pd->getEnergy(access::gpu, access::readwrite);
+      detail::check(uammd_poisson_field_potential(h, (const float *)pos.raw(), charge.raw(), N, (float *)fp.d, (float *)force.raw(),
+                                                  energy.raw(), nullptr));
+    }
+    std::vector<real4> out(N);
+    detail::hipCheck(hipMemcpy(out.data(), fp.d, sizeof(real4) * (size_t)N, hipMemcpyDeviceToHost), "hipMemcpy");
+    return out;
+  }
+  int3 getCells() const { return make_int3(info.cells[0], info.cells[1], info.cells[2]); }
+  int getSupport() const { return info.support; }
+  real getNearFieldCutOff() const { return info.nearFieldCutOff; }
+};
+
 namespace lanczos {
 struct MatrixDot {
   void setSize(int newsize) { m_size = newsize; }

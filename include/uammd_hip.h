@@ -301,6 +301,8 @@ typedef struct {
 /* Errors (-2) carry the reference's messages: kernel support too large (.cu:95-102), near field cut off too large (:111-116). */
 int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **out, uammd_poisson_info *info);
 int uammd_poisson_destroy(uammd_poisson *h);
+/* "atomic_spread" = 1: spread the charges with global atomics instead of the tile-owned LDS kernel (test hook) */
+int uammd_poisson_set_option(uammd_poisson *h, const char *name, int value);
 /* Poisson::sum.  d_pos real4[N], d_charge real[N] (pd->getCharge).  The far field ADDS q E to d_force (real4[N]) and q phi
  * to d_energy (real[N]) whenever the pointer is non-null — the reference's interpolateFields adds both regardless of the
  * Computables (.cu:561-579), so a faithful caller passes both; nearForce / nearEnergy select the near-field passes

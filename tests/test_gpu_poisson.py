@@ -49,6 +49,14 @@ def test_sum_and_field_match_oracle(hip, o32, n, L, gw, tol, split):
     assert np.abs(f - rf).max() <= 2e-5 * np.abs(rf).max()
     assert np.abs(e - re).max() <= 2e-5 * np.abs(re).max()
     assert np.all(f[:, 3] == 0)
+    # the global-atomic spread gives the same forces as the tile-owned one
+    poisson.set_option("atomic_spread", 1)
+    pd.getForce("write").zero_()
+    pd.getEnergy("write").zero_()
+    poisson.sum(force=True, energy=True)
+    fa = pd.getForce("read").cpu().numpy()
+    assert np.abs(fa - f).max() <= 1e-5 * np.abs(f).max()
+    poisson.set_option("atomic_spread", 0)
     # force only: the far field still adds the energy (reference behaviour), the near field does not
     rf2, re2 = np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
     ref.sum(pos, q, rf2, re2, force=True, energy_flag=False)

@@ -99,6 +99,7 @@ SIGNATURES = {
     "uammd_ibm_gather": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
     "uammd_poisson_create": (_i, [C.POINTER(PoissonParameters), C.POINTER(_vp), C.POINTER(PoissonInfo)]),
     "uammd_poisson_destroy": (_i, [_vp]),
+    "uammd_poisson_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_poisson_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "uammd_poisson_field_potential": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "uammd_fcm_create": (_i, [C.POINTER(FCMParameters), C.POINTER(_vp)]),

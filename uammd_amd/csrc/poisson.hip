@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
 #include <vector>
 
 namespace uammd_hip {
@@ -44,6 +45,17 @@ struct Poisson {
   float cutoff = 0.f;
   int ntable = 0;
   DeviceBuffer tableField, tablePotential, gridQ, planes, inter, packed, work;
+  // tile-owned spread: tile dimensions (divisors of the grid, >= support-1), particles binned by the tile of their
+  // stencil origin
+  struct TileSet {
+    bool on = false;
+    int3 tile{0, 0, 0}, ntiles{0, 0, 0};
+    int waves = 0, row = 0, plane = 0;  // waves per workgroup, padded LDS strides (in elements)
+    DeviceBuffer count, start, rank, pos, idx;
+    int numTiles() const { return ntiles.x * ntiles.y * ntiles.z; }
+  };
+  TileSet spreadTiles;
+  bool forceAtomicSpread = false;
   CellList cl;
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
@@ -171,15 +183,15 @@ __global__ void __launch_bounds__(256) k_poisson_interleave(const float *__restr
 }
 
 // IBM::gather of the real4 grid fused with UnZip2Real4 (.cu:529-559): one wave per particle, one float4 per node
-__global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict__ pos, const float *__restrict__ charge,
+__global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict__ packed, const int *__restrict__ groupIndex,
                                                         const float4 *__restrict__ grid4, float4 *__restrict__ force,
                                                         float *__restrict__ energy, float4 *__restrict__ fieldPotential, int N,
                                                         GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx,
                                                         FastDiv dsxy) {
   const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (id >= N) return;
-  const float4 p = pos[id];
+  const int sid = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (sid >= N) return;
+  const float4 p = packed[sid];  // Morton-sorted (x, y, z, q): neighbouring waves read the same grid lines
   const Stencil s = make_stencil(grid, kern, real3f{p.x, p.y, p.z}, false, lane);
   const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
   const int nn = sx * sy * sz;
@@ -214,7 +226,8 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
     aw += __shfl_xor(aw, o, 64);
   }
   if (lane != 0) return;
-  const float q = charge[id];
+  const float q = p.w;
+  const int id = groupIndex[sid];
   if (force) {
     float4 f = force[id];
     f.x += q * ax; f.y += q * ay; f.z += q * az; f.w += q * 0.0f;
@@ -225,6 +238,240 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
     float4 f = fieldPotential[id];
     f.x += ax; f.y += ay; f.z += az; f.w += aw;
     fieldPotential[id] = f;
+  }
+}
+
+// IBM::spread of the charges (misc/IBM.cu:83-147), one wave per Morton-sorted particle: the atomics of neighbouring waves
+// land on the same lines of one XCD's L2 (7.2 ms -> see DESIGN for the unsorted figure)
+__global__ void __launch_bounds__(256) k_poisson_spread(const float4 *__restrict__ packed, float *__restrict__ gridQ, int N,
+                                                        GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx,
+                                                        FastDiv dsxy) {
+  const int lane = threadIdx.x & 63;
+  const int sid = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (sid >= N) return;
+  const float4 p = packed[sid];
+  const Stencil s = make_stencil(grid, kern, real3f{p.x, p.y, p.z}, false, lane);
+  const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
+  const int nn = sx * sy * sz;
+  for (int i0 = 0; i0 < nn; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < nn;
+    const uint iu = in ? (uint)i : 0u;
+    const uint kk = dsxy.div(iu);
+    const uint rem = iu - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const float wx = __shfl(s.w, (int)ii, 64);
+    const float wy = __shfl(s.w, sx + (int)jj, 64);
+    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    if (!in) continue;
+    const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
+    const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
+    const int cz = grid.pbc_z(s.celli.z + (int)kk - s.P.z);
+    unsafeAtomicAdd(&gridQ[(size_t)cx + (size_t)nxStride * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz)], p.w * wx * wy * wz);
+  }
+}
+
+// ---- tile-owned spread --------------------------------------------------------------------------------------------
+// 1e6 charges x 10^3 nodes is 1e9 node updates: global f32 atomics manage ~1.4e11/s on gfx950 (7 ms), and LESS when the
+// particles are Morton sorted (same-line conflicts).  Instead the grid is cut into tiles (tX x tY x tZ nodes, divisors of
+// the grid), the particles are counting-sorted by the tile holding their stencil ORIGIN, and one workgroup per tile
+// spreads ITS particles into a halo-extended copy of the tile in LDS ((T + support - 1)^3 nodes: every stencil fits, no
+// clipping, each particle is visited once), every wave in a private copy (LDS float atomics retire ~1 lane/clk), lanes
+// over the support^2 (y, z) rows with the x loop innermost: read-modify-write of consecutive words, rows padded to an odd
+// stride.  The extended tile is then added to the grid with one global atomic per node.
+struct TileGeom {
+  int3 t, nt;  // tile dimensions, tiles per axis
+  int txp;     // padded row stride of the halo-extended tile (odd)
+  int plane;   // padded xy-plane stride
+};
+
+UH_D int3 stencil_origin(const GridT<float> &g, const IBMKernelDev &k, real3f pi) {  // wrapped into [0, n)
+  const int3 c = g.getCell(pi);
+  const int3 P = compute_support_shift(g, pi, c, k.support);
+  int3 o = make_int3(c.x - P.x, c.y - P.y, c.z - P.z);
+  if (o.x < 0) o.x += g.cellDim.x;
+  if (o.y < 0) o.y += g.cellDim.y;
+  if (o.z < 0) o.z += g.cellDim.z;
+  return o;
+}
+
+__global__ void __launch_bounds__(256) k_poisson_tile_count(const float4 *__restrict__ packed, int N, GridT<float> grid,
+                                                            IBMKernelDev kern, TileGeom tg, FastDiv dx, FastDiv dy, FastDiv dz,
+                                                            int *__restrict__ count, int *__restrict__ rank) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float4 p = packed[i];
+  const int3 o = stencil_origin(grid, kern, real3f{p.x, p.y, p.z});
+  const int t = (int)dx.div((uint)o.x) + tg.nt.x * ((int)dy.div((uint)o.y) + tg.nt.y * (int)dz.div((uint)o.z));
+  rank[i] = atomicAdd(&count[t], 1);  // rank within the tile (order of arrival)
+  rank[N + i] = t;
+}
+
+// exclusive scan of the tile counts by ONE workgroup (the tile table is small)
+__global__ void __launch_bounds__(1024) k_poisson_tile_scan(const int *__restrict__ count, int *__restrict__ start, int ntiles) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ntiles ? count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < ntiles) start[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[ntiles] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_poisson_tile_place(const float4 *__restrict__ packed, const int *__restrict__ groupIndex,
+                                                            int N, const int *__restrict__ start, const int *__restrict__ rank,
+                                                            float4 *__restrict__ tilePos, int *__restrict__ tileIdx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int slot = start[rank[N + i]] + rank[i];
+  tilePos[slot] = packed[i];
+  tileIdx[slot] = groupIndex[i];
+}
+
+// 1-D weights of a particle (wave-uniform position): lane l < 3s evaluates node l of its axis — the expression of make_stencil
+UH_D float tile_weights(const GridT<float> &grid, const IBMKernelDev &kern, float px, float py, float pz, int ox, int oy, int oz,
+                        int s, int lane) {
+  const real3f pi{px, py, pz};
+  const int axis = lane < s ? 0 : (lane < 2 * s ? 1 : 2);
+  const int li = lane - axis * s;
+  float wl = 0.0f;
+  if (lane < 3 * s) {
+    if (axis == 0) wl = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + li), 0, 0)).x);
+    else if (axis == 1) wl = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(0, grid.pbc_y(oy + li), 0)).y);
+    else wl = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(0, 0, grid.pbc_z(oz + li))).z);
+  }
+  return wl;
+}
+
+// S = support (compile time, rows fully unrolled: all the LDS reads of a row are in flight together) or 0 (any support)
+template <int S>
+__global__ void __launch_bounds__(256) k_poisson_spread_tile(const float4 *__restrict__ tilePos, const int *__restrict__ start,
+                                                             float *__restrict__ gridQ, GridT<float> grid, int nxStride,
+                                                             IBMKernelDev kern, TileGeom tg) {
+  extern __shared__ float acc[];  // one private copy of the halo-extended tile per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int s = S ? S : kern.support.x;  // cubic support (Poisson_ns::Gaussian has one)
+  const int ex = tg.txp, ey = tg.t.y + s - 1, ez = tg.t.z + s - 1;
+  const int plane = tg.plane;  // >= ex*ey, padded so that the lanes of a pass fall on distinct banks
+  const int copyN = plane * ez;
+  for (int i = threadIdx.x; i < NW * copyN; i += blockDim.x) acc[i] = 0.0f;
+  __syncthreads();
+  float *mine = acc + wave * copyN;
+  const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tx = tile % tg.nt.x, ty = (tile / tg.nt.x) % tg.nt.y, tz = tile / (tg.nt.x * tg.nt.y);
+  const int x0 = tx * tg.t.x, y0 = ty * tg.t.y, z0 = tz * tg.t.z;
+  const int3 n = grid.cellDim;
+  const int b0 = start[tile], b1 = start[tile + 1];
+  const int rows = s * s;
+  const float rs = __builtin_amdgcn_rcpf((float)s);
+  for (int base = b0; base < b1; base += 64) {
+    const int k = base + lane;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rx = 0, ry = 0, rz = 0;
+    if (k < b1) {
+      p = tilePos[k];
+      const int3 o = stencil_origin(grid, kern, real3f{p.x, p.y, p.z});
+      rx = o.x - x0; ry = o.y - y0; rz = o.z - z0;  // in [0, T): the particles are binned by the tile of their origin
+    }
+    const int cnt = min(64, b1 - base);
+#define PARTICLE(j, W, RX, RY, RZ, Q)                                                                                         \
+    const float Q = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.w), j));                                       \
+    const int RX = __builtin_amdgcn_readlane(rx, j), RY = __builtin_amdgcn_readlane(ry, j), RZ = __builtin_amdgcn_readlane(rz, j); \
+    const float W = tile_weights(grid, kern, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), j)),             \
+                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), j)),                          \
+                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), j)), x0 + RX, y0 + RY, z0 + RZ, s, lane);
+    // particles of the batch dealt to the waves; the weights of the NEXT particle are evaluated before the current one is
+    // spread, so that the exp chain overlaps the LDS round trips
+    int j = wave;
+    if (j >= cnt) continue;
+    float wl, q;
+    int sRx, sRy, sRz;
+    { PARTICLE(j, w0, a0, a1, a2, q0) wl = w0; q = q0; sRx = a0; sRy = a1; sRz = a2; }
+    while (j < cnt) {
+      const int jn = j + NW;
+      float wlN = 0.f, qN = 0.f;
+      int nRx = 0, nRy = 0, nRz = 0;
+      if (jn < cnt) { PARTICLE(jn, w1, c0, c1, c2, q1) wlN = w1; qN = q1; nRx = c0; nRy = c1; nRz = c2; }
+      if (S) {
+        float qwx[S ? S : 1];
+#pragma unroll
+        for (int ii = 0; ii < S; ++ii) qwx[ii] = q * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), ii));
+        for (int r0 = 0; r0 < rows; r0 += 64) {  // lanes over the s*s (y, z) rows of the stencil; wave-uniform trip count
+          const int r = r0 + lane;
+          const bool in = r < rows;
+          const int ru = in ? r : 0;
+          const int kk = (int)(((float)ru + 0.5f) * rs);  // exact for these small integers
+          const int jj = ru - kk * s;
+          const float wyz = __shfl(wl, s + jj, 64) * __shfl(wl, 2 * s + kk, 64);
+          float *row = mine + sRx + ex * (sRy + jj) + plane * (sRz + kk);
+          float v[S ? S : 1];
+#pragma unroll
+          for (int ii = 0; ii < S; ++ii) v[ii] = row[ii];
+          if (in) {
+#pragma unroll
+            for (int ii = 0; ii < S; ++ii) row[ii] = fmaf(qwx[ii], wyz, v[ii]);
+          }
+        }
+      } else {
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+          const int r = r0 + lane;
+          const bool in = r < rows;
+          const int ru = in ? r : 0;
+          const int kk = (int)(((float)ru + 0.5f) * rs);
+          const int jj = ru - kk * s;
+          const float wyz = __shfl(wl, s + jj, 64) * __shfl(wl, 2 * s + kk, 64);
+          float *row = mine + sRx + ex * (sRy + jj) + plane * (sRz + kk);
+          for (int i0 = 0; i0 < s; i0 += 4) {  // groups of four: reads back to back, then the FMAs, then the writes
+            float v[4], qwx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int ii = min(i0 + u, s - 1);
+              qwx[u] = q * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), ii));
+              v[u] = row[ii];
+            }
+            if (in) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (i0 + u < s) row[i0 + u] = fmaf(qwx[u], wyz, v[u]);
+            }
+          }
+        }
+      }
+      j = jn; wl = wlN; q = qN; sRx = nRx; sRy = nRy; sRz = nRz;
+    }
+#undef PARTICLE
+  }
+  __syncthreads();
+  // flush: the halo-extended tile overlaps its neighbours, so the store is an atomic add (one per node and tile: ~2e7 for a
+  // 128^3 grid against the 1e9 node updates done in LDS)
+  const int fx = tg.t.x + s - 1;
+  const int total = fx * ey * ez;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int lx = i % fx, ly = (i / fx) % ey, lz = i / (fx * ey);
+    const int a = lx + ex * ly + plane * lz;
+    float v = acc[a];
+    for (int w = 1; w < NW; ++w) v += acc[w * copyN + a];
+    if (v == 0.0f) continue;
+    int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+    if (gx >= n.x) gx -= n.x;
+    if (gy >= n.y) gy -= n.y;
+    if (gz >= n.z) gz -= n.z;
+    unsafeAtomicAdd(&gridQ[(size_t)gx + (size_t)nxStride * ((size_t)gy + (size_t)n.y * (size_t)gz)], v);
   }
 }
 
@@ -269,6 +516,12 @@ __global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__
       const float4 pj = packed[j];
       const real3f rij = box.apply_pbc(real3f{pj.x - pi.x, pj.y - pi.y, pj.z - pi.z});
       const float r2 = dot3(rij, rij);
+      // both tables return 0 at and beyond the cut-off (TabulatedFunction.cuh:150-151): such pairs add exactly zero, so
+      // skipping them (85 % of the 27-cell candidates) changes no bit of the result
+      // (each mode tests the table(s) it reads: r2 against rc^2 for G, sqrt(r2) against rc for the field)
+      if (MODE == 1 && r2 >= tabP.rmax) continue;
+      if (MODE == 0 && sqrtf(r2) >= tabF.rmax) continue;
+      if (MODE == 2 && r2 >= tabP.rmax && sqrtf(r2) >= tabF.rmax) continue;
       if (MODE == 1) {
         tw += qi * pj.w * table_get1(tabP, r2);
       } else if (MODE == 0) {
@@ -343,13 +596,56 @@ static int poisson_make_plans(Poisson *p) {
   return 0;
 }
 
+// counting sort of the packed particles by the tile of their stencil origin
+static int poisson_bin(Poisson *p, Poisson::TileSet &ts, int N, hipStream_t st) {
+  const int nt = ts.numTiles();
+  const TileGeom tg{ts.tile, ts.ntiles, ts.row, ts.plane};
+  if (int e = ts.rank.reserve(sizeof(int) * 2 * (size_t)N)) return e;
+  if (int e = ts.pos.reserve(sizeof(float4) * (size_t)N)) return e;
+  if (int e = ts.idx.reserve(sizeof(int) * (size_t)N)) return e;
+  UH_CHECK(hipMemsetAsync(ts.count.ptr, 0, sizeof(int) * (size_t)nt, st));
+  hipLaunchKernelGGL(k_poisson_tile_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)p->packed.ptr, N, p->grid, p->kern,
+                     tg, make_fastdiv(ts.tile.x), make_fastdiv(ts.tile.y), make_fastdiv(ts.tile.z), (int *)ts.count.ptr,
+                     (int *)ts.rank.ptr);
+  hipLaunchKernelGGL(k_poisson_tile_scan, dim3(1), dim3(1024), 0, st, (const int *)ts.count.ptr, (int *)ts.start.ptr, nt);
+  hipLaunchKernelGGL(k_poisson_tile_place, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)p->packed.ptr,
+                     (const int *)p->cl.index.ptr, N, (const int *)ts.start.ptr, (const int *)ts.rank.ptr, (float4 *)ts.pos.ptr,
+                     (int *)ts.idx.ptr);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 // farField (.cu:332-360): any of d_force / d_energy / d_fieldPotential may be null
-static int poisson_far(Poisson *p, const float *d_pos, const float *d_charge, int N, float *d_force, float *d_energy,
-                       float *d_fieldPotential, hipStream_t st) {
-  const int per[3] = {1, 1, 1};
+// (the particles have been sorted and packed by poisson_list)
+static int poisson_far(Poisson *p, int N, float *d_force, float *d_energy, float *d_fieldPotential, hipStream_t st) {
   float *gq = (float *)p->gridQ.ptr;
+  const FastDiv dsx = make_fastdiv(p->kern.support.x), dsxy = make_fastdiv(p->kern.support.x * p->kern.support.y);
+  const int s = p->kern.support.x;
   UH_CHECK(hipMemsetAsync(gq, 0, sizeof(float) * p->planeReal, st));
-  if (int e = uammd_ibm_spread(d_pos, 4, d_charge, 1, N, p->L, per, p->cells, p->nxpad, &p->kernel, gq, (void *)st)) return e;
+  const bool tileSpread = p->spreadTiles.on && !p->forceAtomicSpread;
+  if (tileSpread) {
+    Poisson::TileSet &ts = p->spreadTiles;
+    if (int e = poisson_bin(p, ts, N, st)) return e;
+    const TileGeom tg{ts.tile, ts.ntiles, ts.row, ts.plane};
+    const size_t lds = sizeof(float) * (size_t)ts.waves * ts.plane * (ts.tile.z + s - 1);
+    const float4 *tp = (const float4 *)ts.pos.ptr;
+    const int *tst = (const int *)ts.start.ptr;
+    const dim3 g(ts.numTiles()), b(64 * ts.waves);
+#define UH_SPREAD(S_) hipLaunchKernelGGL((k_poisson_spread_tile<S_>), g, b, lds, st, tp, tst, gq, p->grid, p->nxpad, p->kern, tg)
+    switch (s) {
+      case 7: UH_SPREAD(7); break;
+      case 8: UH_SPREAD(8); break;
+      case 9: UH_SPREAD(9); break;
+      case 10: UH_SPREAD(10); break;
+      case 11: UH_SPREAD(11); break;
+      case 12: UH_SPREAD(12); break;
+      default: UH_SPREAD(0); break;
+    }
+#undef UH_SPREAD
+  } else {
+    hipLaunchKernelGGL(k_poisson_spread, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)p->packed.ptr, gq, N, p->grid,
+                       p->nxpad, p->kern, dsx, dsxy);
+  }
   UH_ROCFFT(rocfft_execution_info_set_stream(p->info, (void *)st));
   void *bq[1] = {gq};
   UH_ROCFFT(rocfft_execute(p->fwd, bq, nullptr, p->info));
@@ -363,16 +659,21 @@ static int poisson_far(Poisson *p, const float *d_pos, const float *d_charge, in
   const uint nreal = (uint)p->planeReal;
   hipLaunchKernelGGL(k_poisson_interleave, dim3((nreal + 255) / 256), dim3(256), 0, st, (const float *)p->planes.ptr, p->planeReal,
                      (float4 *)p->inter.ptr, nreal);
-  hipLaunchKernelGGL(k_poisson_gather, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)d_pos, d_charge,
-                     (const float4 *)p->inter.ptr, (float4 *)d_force, d_energy, (float4 *)d_fieldPotential, N, p->grid, p->nxpad,
-                     p->kern, make_fastdiv(p->kern.support.x), make_fastdiv(p->kern.support.x * p->kern.support.y));
+  {
+    hipLaunchKernelGGL(k_poisson_gather, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)p->packed.ptr,
+                       (const int *)p->cl.index.ptr, (const float4 *)p->inter.ptr, (float4 *)d_force, d_energy,
+                       (float4 *)d_fieldPotential, N, p->grid, p->nxpad, p->kern, dsx, dsxy);
+  }
   UH_CHECK(hipGetLastError());
   return 0;
 }
 
 // nl->update(box, nearFieldCutOff) + pack (x, y, z, q) in sorted order
+// Without splitting there is no near field; the list is still built (cells of half a window) because the spread and the
+// gather want the particles in Morton order.
 static int poisson_list(Poisson *p, const float *d_pos, const float *d_charge, int N, hipStream_t st) {
-  const float rc3[3] = {p->cutoff, p->cutoff, p->cutoff};
+  const float rc = p->par.split > 0 ? p->cutoff : 0.5f * (float)p->kern.support.x * p->grid.cellSize.x;
+  const float rc3[3] = {rc, rc, rc};
   const int per[3] = {1, 1, 1};
   int cd[3], gper[3];
   float gL[3];
@@ -492,6 +793,36 @@ int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **ou
   if (!e) e = p->planes.reserve(sizeof(float) * 4 * p->planeReal);
   if (!e) e = p->inter.reserve(sizeof(float4) * p->planeReal);
   if (!e) e = poisson_make_plans(p);
+  // Spread tiles: per axis the divisor of the grid in [4, 12] closest to 8, as many private float copies (waves) as fit 64 KB.
+  // (An LDS-tile GATHER of the float4 grid was built too: the halo-extended float4 tile only fits for 4-node-thick tiles,
+  // whose 12-27x halo reload made it no faster than the global gather — 1.2-1.9 ms against 1.6 ms — so it was dropped.)
+  {
+    auto closest = [&](int n, int target) {
+      int best = 0;
+      for (int d = 4; d <= 12; ++d)
+        if (n % d == 0 && (!best || std::abs(d - target) < std::abs(best - target))) best = d;
+      return best;
+    };
+    const int t[3] = {closest(p->cells[0], 8), closest(p->cells[1], 8), closest(p->cells[2], 8)};
+    Poisson::TileSet &ts = p->spreadTiles;
+    if (t[0] && t[1] && t[2]) {
+      // rows padded to an odd stride; planes padded so that row r = jj + s*kk of a pass starts at bank (row*r) mod 32:
+      // the 64 lanes of a pass then cover every bank twice, the minimum
+      ts.row = (t[0] + support - 1) | 1;
+      ts.plane = ts.row * (t[1] + support - 1);
+      while ((ts.plane - ts.row * support) % 32 != 0) ++ts.plane;
+      const size_t copyBytes = sizeof(float) * (size_t)ts.plane * (t[2] + support - 1);
+      ts.waves = (int)std::min<size_t>(4, 65536 / copyBytes);
+      ts.on = ts.waves >= 1;
+      if (ts.on) {
+        ts.tile = make_int3(t[0], t[1], t[2]);
+        ts.ntiles = make_int3(p->cells[0] / t[0], p->cells[1] / t[1], p->cells[2] / t[2]);
+        const size_t nt = (size_t)ts.numTiles();
+        if (!e) e = ts.count.reserve(sizeof(int) * nt);
+        if (!e) e = ts.start.reserve(sizeof(int) * (nt + 1));
+      }
+    }
+  }
   if (e) { delete p; return e; }
   if (info) {
     for (int a = 0; a < 3; ++a) info->cells[a] = p->cells[a];
@@ -502,6 +833,14 @@ int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **ou
   }
   *out = reinterpret_cast<uammd_poisson *>(p);
   return 0;
+}
+
+int uammd_poisson_set_option(uammd_poisson *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_poisson_set_option: null argument"); return -1; }
+  Poisson *p = reinterpret_cast<Poisson *>(h);
+  if (std::string(name) == "atomic_spread") { p->forceAtomicSpread = value != 0; return 0; }
+  set_last_error("uammd_poisson_set_option: unknown option %s", name);
+  return -1;
 }
 
 int uammd_poisson_destroy(uammd_poisson *h) {
@@ -516,9 +855,9 @@ int uammd_poisson_sum(uammd_poisson *h, const float *d_pos, const float *d_charg
   if (N <= 0) return 0;
   Poisson *p = reinterpret_cast<Poisson *>(h);
   hipStream_t st = (hipStream_t)stream;
-  if (int e = poisson_far(p, d_pos, d_charge, N, d_force, d_energy, nullptr, st)) return e;
+  if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
+  if (int e = poisson_far(p, N, d_force, d_energy, nullptr, st)) return e;
   if (p->par.split > 0 && (nearForce || nearEnergy)) {
-    if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
     if (nearForce)
       if (int e = poisson_near<0>(p, N, d_force, st)) return e;
     if (nearEnergy)
@@ -533,9 +872,9 @@ int uammd_poisson_field_potential(uammd_poisson *h, const float *d_pos, const fl
   if (N <= 0) return 0;
   Poisson *p = reinterpret_cast<Poisson *>(h);
   hipStream_t st = (hipStream_t)stream;
-  if (int e = poisson_far(p, d_pos, d_charge, N, d_force, d_energy, d_fieldPotential, st)) return e;
+  if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
+  if (int e = poisson_far(p, N, d_force, d_energy, d_fieldPotential, st)) return e;
   if (p->par.split > 0) {
-    if (int e = poisson_list(p, d_pos, d_charge, N, st)) return e;
     if (int e = poisson_near<2>(p, N, d_fieldPotential, st)) return e;
   }
   return 0;

@@ -49,6 +49,9 @@ class Poisson(Interactor):
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        check(self.lib.uammd_poisson_set_option(self.h, name.encode(), int(value)))
+
     def sum(self, force=False, energy=False, virial=False):
         """Poisson::sum (SpectralEwaldPoisson.cuh:110-123): far field (adds to force AND energy), then the near-field passes."""
         if virial:
