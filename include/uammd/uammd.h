@@ -29,6 +29,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <fstream>
+#include <iostream>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -340,6 +342,12 @@ public:
     return charge.data(l, m);
   }
   property_ptr<int> getId(access::location l, access::mode m) { return id.data(l, m); }
+  property_ptr<real4> getPosIfAllocated(access::location l, access::mode m) { return pos.isAllocated() ? pos.data(l, m) : property_ptr<real4>(); }
+  property_ptr<real4> getForceIfAllocated(access::location l, access::mode m) { return force.isAllocated() ? force.data(l, m) : property_ptr<real4>(); }
+  property_ptr<real3> getVelIfAllocated(access::location l, access::mode m) { return vel.isAllocated() ? vel.data(l, m) : property_ptr<real3>(); }
+  property_ptr<real> getEnergyIfAllocated(access::location l, access::mode m) { return energy.isAllocated() ? energy.data(l, m) : property_ptr<real>(); }
+  property_ptr<real> getVirialIfAllocated(access::location l, access::mode m) { return virial.isAllocated() ? virial.data(l, m) : property_ptr<real>(); }
+  property_ptr<real> getChargeIfAllocated(access::location l, access::mode m) { return charge.isAllocated() ? charge.data(l, m) : property_ptr<real>(); }
   property_ptr<real> getMassIfAllocated(access::location l, access::mode m) { return mass.isAllocated() ? mass.data(l, m) : property_ptr<real>(); }
   property_ptr<real> getRadiusIfAllocated(access::location l, access::mode m) { return radius.isAllocated() ? radius.data(l, m) : property_ptr<real>(); }
   bool isPosAllocated() const { return pos.isAllocated(); }
@@ -384,6 +392,72 @@ private:
     p.swapDeviceBuffer(alt);
   }
 };
+
+// ---- utils/checkpoint.h:29-76: the text checkpoint of a real UAMMD run -----------------------------------------------------------
+// "# version V" / "# N" / one "# Name" block per allocated property in the order of ParticleData's property list, N lines each in
+// particle-ID order, default stream formatting.  Id is not written.
+namespace detail {
+inline std::ostream &put(std::ostream &o, const real &v) { return o << v; }
+inline std::ostream &put(std::ostream &o, const real3 &v) { return o << v.x << " " << v.y << " " << v.z; }
+inline std::ostream &put(std::ostream &o, const real4 &v) { return o << v.x << " " << v.y << " " << v.z << " " << v.w; }
+inline std::istream &get(std::istream &i, real &v) { return i >> v; }
+inline std::istream &get(std::istream &i, real3 &v) { return i >> v.x >> v.y >> v.z; }
+inline std::istream &get(std::istream &i, real4 &v) { return i >> v.x >> v.y >> v.z >> v.w; }
+template <class T> void saveBlock(property_ptr<T> prop, const std::vector<int> &id2index, const char *name, std::ostream &out) {
+  if (!prop.raw()) return;
+  out << "# " << name << std::endl;
+  for (size_t i = 0; i < prop.size(); ++i) { put(out, prop[id2index[i]]); out << "\n"; }
+}
+template <class T> void readBlock(property_ptr<T> prop, std::istream &in) {
+  for (size_t i = 0; i < prop.size(); ++i) get(in, prop[i]);
+}
+}  // namespace detail
+inline void saveParticleData(const std::string &fileName, shared_ptr<ParticleData> pd) {
+  std::ofstream out(fileName);
+  out << "# version " << "3.0.0" << std::endl;  // UAMMD_VERSION, global/defines.h:7
+  const int N = pd->getNumParticles();
+  out << "# " << N << std::endl;
+  std::vector<int> id2index(N);
+  {
+    auto id = pd->getId(access::cpu, access::read);
+    for (int i = 0; i < N; ++i) id2index[id[i]] = i;  // ParticleData::getIdOrderedIndices
+  }
+  detail::saveBlock(pd->getPosIfAllocated(access::cpu, access::read), id2index, "Pos", out);
+  detail::saveBlock(pd->getMassIfAllocated(access::cpu, access::read), id2index, "Mass", out);
+  detail::saveBlock(pd->getForceIfAllocated(access::cpu, access::read), id2index, "Force", out);
+  detail::saveBlock(pd->getVirialIfAllocated(access::cpu, access::read), id2index, "Virial", out);
+  detail::saveBlock(pd->getEnergyIfAllocated(access::cpu, access::read), id2index, "Energy", out);
+  detail::saveBlock(pd->getVelIfAllocated(access::cpu, access::read), id2index, "Vel", out);
+  detail::saveBlock(pd->getRadiusIfAllocated(access::cpu, access::read), id2index, "Radius", out);
+  detail::saveBlock(pd->getChargeIfAllocated(access::cpu, access::read), id2index, "Charge", out);
+  detail::saveBlock(pd->getTorqueIfAllocated(access::cpu, access::read), id2index, "Torque", out);
+  detail::saveBlock(pd->getDirIfAllocated(access::cpu, access::read), id2index, "Dir", out);
+}
+inline shared_ptr<ParticleData> restoreParticleData(const std::string &fileName, shared_ptr<System> sys) {
+  std::ifstream in(fileName);
+  std::string str;
+  in >> str >> str >> str;
+  if (str != "3.0.0") System::log<System::WARNING>("This restore file was saved with a different UAMMD version (%s)", str.c_str());
+  int N = 0;
+  in >> str >> N;
+  auto pd = make_shared<ParticleData>(N, sys);
+  while (in >> str) {
+    std::string name;
+    in >> name;
+    if (name == "Pos") detail::readBlock(pd->getPos(access::cpu, access::write), in);
+    else if (name == "Mass") detail::readBlock(pd->getMass(access::cpu, access::write), in);
+    else if (name == "Force") detail::readBlock(pd->getForce(access::cpu, access::write), in);
+    else if (name == "Virial") detail::readBlock(pd->getVirial(access::cpu, access::write), in);
+    else if (name == "Energy") detail::readBlock(pd->getEnergy(access::cpu, access::write), in);
+    else if (name == "Vel") detail::readBlock(pd->getVel(access::cpu, access::write), in);
+    else if (name == "Radius") detail::readBlock(pd->getRadius(access::cpu, access::write), in);
+    else if (name == "Charge") detail::readBlock(pd->getCharge(access::cpu, access::write), in);
+    else if (name == "Torque") detail::readBlock(pd->getTorque(access::cpu, access::write), in);
+    else if (name == "Dir") detail::readBlock(pd->getDir(access::cpu, access::write), in);
+    else if (name == "AngVel") { real4 skip; for (int i = 0; i < N; ++i) detail::get(in, skip); }  // not a property of this build
+  }
+  return pd;
+}
 
 // ---- misc/ParameterUpdatable.h:72-80, Interactor, Integrator ------------------------------------------------------------------
 class ParameterUpdatable {
