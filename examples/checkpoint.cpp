@@ -11,11 +11,13 @@ int main(int argc, char *argv[]) {
   const char *file = argc > 1 ? argv[1] : "/tmp/uammd_pd.dat";
   {
     auto pd = std::make_shared<ParticleData>(N, sys);
-    auto pos = pd->getPos(access::cpu, access::write);
-    for (auto &p : pos) p = make_real4(1, 1, 1, 1);
-    auto charge = pd->getCharge(access::cpu, access::write);
-    for (auto &c : charge) c = 2;
-    pos[3] = make_real4(0.125, -2.5, 1e-7, 3);
+    {
+      auto pos = pd->getPos(access::cpu, access::write);
+      for (auto &p : pos) p = make_real4(1, 1, 1, 1);
+      auto charge = pd->getCharge(access::cpu, access::write);
+      for (auto &c : charge) c = 2;
+      pos[3] = make_real4(0.125, -2.5, 1e-7, 3);
+    }  // the handles are released before the properties are requested again
     saveParticleData(file, pd);
   }
   auto pd = restoreParticleData(file, sys);
