@@ -46,6 +46,11 @@ int main(int argc, char *argv[]) {
   lpar.viscosity = par.viscosity; lpar.hydrodynamicRadius = rh; lpar.temperature = 1.0; lpar.dt = 0.01; lpar.tolerance = 1e-3;
   auto bdl = std::make_shared<BDHI::EulerMaruyama<BDHI::Lanczos>>(pd, lpar);
   bdl->forwardTime();
+  // ... and the dense Cholesky variant (rocSOLVER potrf behind the C ABI)
+  auto bdc = std::make_shared<BDHI::EulerMaruyama<BDHI::Cholesky>>(pd, lpar);
+  bdc->forwardTime();
+  { auto pos = pd->getPos(access::cpu, access::read); p = pos[0]; }
+  if (!std::isfinite(p.x + p.y + p.z)) return 1;
   sys->finish();
   return (ok1 && std::isfinite(d2) && d2 > 0 && d2 < 100 * 6 * m0 * par.dt) ? 0 : 1;
 }

@@ -1,0 +1,3 @@
+// Forwarding header: same include path as the reference's src/Integrator/BDHI/BDHI_Cholesky.cuh.
+#pragma once
+#include "../../uammd.h"

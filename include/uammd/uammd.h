@@ -1084,6 +1084,58 @@ public:
   }
 };
 
+// BDHI::Cholesky (Integrator/BDHI/BDHI_Cholesky.cuh:37-80): open boundaries, dense RPY mobility stored in full, Cholesky factor for
+// the noise (rocSOLVER potrf + rocBLAS symv / trmv behind uammd_bdhi_cholesky_*)
+class Cholesky {
+  shared_ptr<ParticleData> pd;
+  BDHI::Parameters par;
+  uammd_bdhi_cholesky *h = nullptr;
+  Xorshift128plus gen;  // cuRAND in the reference (stream unpinned): Box-Muller on the System generator family instead
+public:
+  using Parameters = BDHI::Parameters;
+  Cholesky(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), par(par) {
+    if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
+      System::log<System::CRITICAL>("[BDHI::Cholesky] You need to provide Cholesky with either an hydrodynamic radius or via the individual particle radius.");
+    detail::check(uammd_bdhi_cholesky_create(pd->getNumParticles(), par.viscosity, par.hydrodynamicRadius, &h));
+    gen.setSeed(pd->getSystem()->rng().next());
+  }
+  Cholesky(const Cholesky &) = delete;
+  ~Cholesky() { uammd_bdhi_cholesky_destroy(h); }
+  void init() {}
+  void finish_step(hipStream_t = 0) {}
+  real getHydrodynamicRadius() { return par.hydrodynamicRadius; }
+  real getSelfMobility() { return par.hydrodynamicRadius < 0 ? real(-1.0) : real(1.0 / (6.0 * M_PI * par.viscosity * par.hydrodynamicRadius)); }
+  void setup_step(hipStream_t st = 0) {
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+    detail::check(uammd_bdhi_cholesky_setup_step(h, (const float *)pos.raw(), nullptr, radius.raw(), (void *)st));
+  }
+  void computeMF(real3 *MF, hipStream_t st = 0) {
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto force = pd->getForce(access::gpu, access::read);
+    auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+    detail::check(uammd_bdhi_cholesky_mf(h, (const float *)pos.raw(), (const float *)force.raw(), nullptr, radius.raw(), (float *)MF, (void *)st));
+  }
+  void computeBdW(real3 *BdW, hipStream_t st = 0) {
+    const int N = pd->getNumParticles();
+    std::vector<real3> hn(N);
+    for (auto &v : hn) {  // standard normals, Box-Muller
+      real g[4];
+      for (int k = 0; k < 4; k += 2) {
+        const double u1 = gen.uniform(1e-300, 1.0), u2 = gen.uniform(0.0, 1.0);
+        const double r = std::sqrt(-2.0 * std::log(u1));
+        g[k] = real(r * std::cos(2 * M_PI * u2)); g[k + 1] = real(r * std::sin(2 * M_PI * u2));
+      }
+      v = make_real3(g[0], g[1], g[2]);
+    }
+    detail::hipCheck(hipMemcpyAsync(BdW, hn.data(), sizeof(real3) * N, hipMemcpyHostToDevice, st), "hipMemcpy");
+    detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+    detail::check(uammd_bdhi_cholesky_bdw(h, (const float *)pos.raw(), nullptr, radius.raw(), (float *)BdW, (void *)st));
+  }
+};
+
 template <class Method> class EulerMaruyama : public Integrator {
   using Parameters_t = typename Method::Parameters;
   Parameters_t par;

@@ -275,6 +275,24 @@ int uammd_fcm_euler_maruyama_dir(float *d_pos, float *d_dir, const int *d_index,
                                  const float *d_angularVelocity, int numberParticles, float dt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * BDHI::Cholesky — dense open-boundary RPY mobility with an explicit Cholesky factor (the other half of
+ * test/BDHI/Lanczos_Cholesky).  Replaces Integrator/BDHI/BDHI_Cholesky.cu:
+ *   setup_step (fillMobilityRPYD :34-80, :158-178)   computeMF (symv, :196-233)   computeBdW (potrf + trmv, :235-262)
+ * d_index: group index iterator (nullable = all particles); d_radius nullable when hydrodynamicRadius > 0.
+ * rocSOLVER / rocBLAS are loaded on first use (not load-time dependencies of this library).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_bdhi_cholesky uammd_bdhi_cholesky;
+int uammd_bdhi_cholesky_create(int numberParticles, float viscosity, float hydrodynamicRadius, uammd_bdhi_cholesky **out);
+int uammd_bdhi_cholesky_destroy(uammd_bdhi_cholesky *h);
+int uammd_bdhi_cholesky_setup_step(uammd_bdhi_cholesky *h, const float *d_pos, const int *d_index, const float *d_radius, void *stream);
+/* d_force real4[N]; d_MF real3[N] (overwritten).  Rebuilds M first if computeBdW consumed it, like the reference. */
+int uammd_bdhi_cholesky_mf(uammd_bdhi_cholesky *h, const float *d_pos, const float *d_force, const int *d_index, const float *d_radius,
+                           float *d_MF, void *stream);
+/* d_BdW real3[N]: N(0,1) draws on entry (the reference's cuRAND stream is unpinned third party), B dW on exit. */
+int uammd_bdhi_cholesky_bdw(uammd_bdhi_cholesky *h, const float *d_pos, const int *d_index, const float *d_radius, float *d_BdW,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Triply periodic electrostatics (another consumer of the spread / FFT / gather engine).  Replaces
  *   Poisson::Poisson / sum / computeFieldPotentialAtParticles    Interactor/SpectralEwaldPoisson.cuh:83-136, .cu:71-160
  *   farField (spread q, R2C, chargeFourier2FieldAndPotential, 4 x C2R, gather + UnZip2Real4)   .cu:332-360, :410-559

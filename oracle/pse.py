@@ -168,3 +168,32 @@ def rpy_nbody_mdot(oracle, pos4, v, viscosity, rh=-1.0, radius=None):
     rad = None if radius is None else oracle.r(radius)
     oracle.lib.oracle_rpy_nbody_mdot(_p(pos4), _p(v), int(v.shape[1]), _p(rad), oracle.creal(rh), oracle.creal(viscosity), n, _p(out))
     return out
+
+
+def rpy_dense(oracle, pos, radius, hydrodynamicRadius, viscosity):
+    """BDHI::Cholesky's mobility matrix (BDHI_Cholesky.cu:34-80) as a full symmetric [3N, 3N] array."""
+    o = oracle
+    pos = o.r(pos)
+    n = len(pos)
+    M = np.zeros((3 * n, 3 * n), o.real)
+    rad = None if radius is None else o.r(radius)
+    o.lib.oracle_rpy_dense(_p(pos), _p(rad) if rad is not None else None, o.creal(hydrodynamicRadius), o.creal(viscosity), n, _p(M))
+    return M   # symmetric: row/column major agree
+
+
+class CholeskyOracle:
+    """BDHI::Cholesky (BDHI_Cholesky.cu:158-262): MF = M F, BdW = U^T dW with M = U^T U (potrf upper, trmv transposed)."""
+
+    def __init__(self, oracle, hydrodynamicRadius, viscosity):
+        self.o, self.rh, self.viscosity = oracle, hydrodynamicRadius, viscosity
+
+    def matrix(self, pos, radius=None):
+        return rpy_dense(self.o, pos, None if self.rh > 0 else radius, self.rh, self.viscosity)
+
+    def computeMF(self, pos, force, radius=None):
+        f3 = self.o.r(np.asarray(force)[:, :3]).reshape(-1)
+        return (self.matrix(pos, radius) @ f3).reshape(-1, 3)
+
+    def computeBdW(self, pos, noise, radius=None):
+        L = np.linalg.cholesky(self.matrix(pos, radius).astype(np.float64))   # M = L L^T, L = U^T
+        return (L @ np.asarray(noise, np.float64).reshape(-1)).reshape(-1, 3)

@@ -424,3 +424,33 @@ ORACLE_API void oracle_rpy_nbody_mdot(const real4 *pos, const real *v, int vstri
     Mv3[3 * i] = total.x; Mv3[3 * i + 1] = total.y; Mv3[3 * i + 2] = total.z;
   }
 }
+
+/* Cholesky_ns::fillMobilityRPYD (Integrator/BDHI/BDHI_Cholesky.cu:34-80) completed to the full symmetric matrix: column
+ * major 3N x 3N, M[3i+k + n(3j+l)] = c2 rij_k rij_l + c1 delta_kl with rij = pos_j - pos_i, self blocks (M0/a_i) I. */
+ORACLE_API void oracle_rpy_dense(const real4 *pos, const real *radius, real rh, real viscosity, int N, real *M) {
+  const real M0 = (real)(1 / (6 * M_PI * viscosity));
+  const size_t n = 3 * (size_t)N;
+  for (int i = 0; i < N; i++) {
+    const real ai = radius ? radius[i] : rh;
+    for (int j = i; j < N; j++) {
+      const real aj = radius ? radius[j] : rh;
+      real b[3][3];
+      real c1, c2;
+      if (i == j) {
+        rpy_different_sizes(M0, 0, ai, ai, &c1, &c2);
+        for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) b[k][l] = k == l ? c1 : 0;
+      } else {
+        const real rij[3] = {pos[j].x - pos[i].x, pos[j].y - pos[i].y, pos[j].z - pos[i].z};
+        const real r = SQRT(FMA(rij[2], rij[2], FMA(rij[1], rij[1], rij[0] * rij[0])));
+        rpy_different_sizes(M0, r, ai, aj, &c1, &c2);
+        for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) b[k][l] = c2 * rij[k] * rij[l];
+        for (int k = 0; k < 3; k++) b[k][k] += c1;
+      }
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          M[3 * (size_t)i + k + n * (3 * (size_t)j + l)] = b[k][l];
+          M[3 * (size_t)j + l + n * (3 * (size_t)i + k)] = b[k][l];
+        }
+    }
+  }
+}

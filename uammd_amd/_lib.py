@@ -97,6 +97,11 @@ SIGNATURES = {
     "uammd_ibm_barnett_magland_kernel": (_i, [_f, _f, _i, _f, C.POINTER(IBMKernel)]),
     "uammd_ibm_spread": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
     "uammd_ibm_gather": (_i, [_vp, _i, _vp, _i, _i, _f3, _i3, _i3, _i, C.POINTER(IBMKernel), _vp, _vp]),
+    "uammd_bdhi_cholesky_create": (_i, [_i, _f, _f, C.POINTER(_vp)]),
+    "uammd_bdhi_cholesky_destroy": (_i, [_vp]),
+    "uammd_bdhi_cholesky_setup_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi_cholesky_mf": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi_cholesky_bdw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "uammd_poisson_create": (_i, [C.POINTER(PoissonParameters), C.POINTER(_vp), C.POINTER(PoissonInfo)]),
     "uammd_poisson_destroy": (_i, [_vp]),
     "uammd_poisson_set_option": (_i, [_vp, C.c_char_p, _i]),

@@ -479,6 +479,57 @@ class PSE:
         self._far(force, MF, temperature, noise_prefactor)
 
 
+class Cholesky:
+    """BDHI::Cholesky — the Method concept of BDHI::EulerMaruyama with a dense mobility matrix and its Cholesky factor
+    (Integrator/BDHI/BDHI_Cholesky.cuh:37-80, .cu:83-262).  noise_fn() -> float[3N] N(0,1) replaces the reference's cuRAND
+    generator (third party, stream unpinned); default torch.randn on the particles' device."""
+    Parameters = _Parameters
+
+    def __init__(self, pd, par, noise_fn=None):
+        self.lib = _lib.load()
+        self.pd, self.par = pd, par
+        if par.hydrodynamicRadius < 0 and not pd.isAllocated("radius"):
+            raise RuntimeError("[BDHI::Cholesky] You need to provide Cholesky with either an hydrodynamic radius or via the "
+                               "individual particle radius.")   # BDHI_Cholesky.cu:98-101
+        h = C.c_void_p()
+        check(self.lib.uammd_bdhi_cholesky_create(pd.N, float(par.viscosity), float(par.hydrodynamicRadius), C.byref(h)))
+        self.h = h
+        self.temperature, self.dt = par.temperature, par.dt
+        self.noise_fn = noise_fn or (lambda: torch.randn(3 * pd.N, dtype=torch.float32, device=pd.device))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_bdhi_cholesky_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _radius(self):
+        return _ptr(self.pd.getRadius("read")) if self.pd.isAllocated("radius") else None
+
+    def setup_step(self):
+        check(self.lib.uammd_bdhi_cholesky_setup_step(self.h, _ptr(self.pd.getPos("read")), None, self._radius(), current_stream()))
+
+    def computeMF(self, MF):
+        check(self.lib.uammd_bdhi_cholesky_mf(self.h, _ptr(self.pd.getPos("read")), _ptr(self.pd.getForce("read")), None,
+                                              self._radius(), _ptr(MF), current_stream()))
+
+    def computeBdW(self, BdW):
+        BdW.view(-1)[:3 * self.pd.N].copy_(self.noise_fn())
+        check(self.lib.uammd_bdhi_cholesky_bdw(self.h, _ptr(self.pd.getPos("read")), None, self._radius(), _ptr(BdW), current_stream()))
+
+    def finish_step(self):
+        pass
+
+    def getHydrodynamicRadius(self):
+        return self.par.hydrodynamicRadius
+
+    def getSelfMobility(self):
+        rh = self.par.hydrodynamicRadius
+        return -1.0 if rh < 0 else 1.0 / (6.0 * math.pi * self.par.viscosity * rh)
+
+
 class EulerMaruyama(Integrator):
     """BDHI::EulerMaruyama<Method> (BDHI_EulerMaruyama.cu:125-166): dR = dt (K R + M F) + sqrt(2 T dt) B dW."""
 
@@ -662,6 +713,7 @@ class BDHI:
     FCM = FCM
     PSE = PSE
     Lanczos = Lanczos
+    Cholesky = Cholesky
     EulerMaruyama = EulerMaruyama
     FCMIntegrator = FCMIntegrator
     FCM_impl = FCM_impl
