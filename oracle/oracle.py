@@ -187,7 +187,8 @@ class Oracle:
     # ---- path B: IBM -----------------------------------------------------------------------------
     def ibm_kernel(self, kind, support, prefactor=0.0, tau=0.0, rmax=np.inf, invh=(0, 0, 0)):
         """kind: 'gaussian' | 'peskin3' | 'peskin4' | 'constant' | 'barnett_magland' | 'sixpoint' (oracle/src/ibm.c)."""
-        kinds = {"gaussian": 0, "peskin3": 1, "peskin4": 2, "constant": 3, "barnett_magland": 4, "sixpoint": 5}
+        kinds = {"gaussian": 0, "peskin3": 1, "peskin4": 2, "constant": 3, "barnett_magland": 4, "sixpoint": 5, "gauss2d": 6,
+                 "gauss2d_drift_x": 7, "gauss2d_drift_y": 8}
         creal = self.creal
 
         class K(C.Structure):

@@ -18,7 +18,7 @@
 #include "common.h"
 
 enum { KERNEL_GAUSSIAN = 0, KERNEL_PESKIN3 = 1, KERNEL_PESKIN4 = 2, KERNEL_CONSTANT = 3, KERNEL_BARNETT_MAGLAND = 4,
-       KERNEL_SIXPOINT = 5 };
+       KERNEL_SIXPOINT = 5, KERNEL_GAUSS2D = 6, KERNEL_GAUSS2D_DRIFT_X = 7, KERNEL_GAUSS2D_DRIFT_Y = 8 };
 
 /* Window description shared with the C ABI (include/uammd_hip.h: uammd_ibm_kernel) */
 typedef struct {
@@ -125,6 +125,10 @@ static inline real phi_axis(const IBMKernel *k, int axis, real r) {
     case KERNEL_PESKIN4: return phi_peskin4(k->invh[axis], r);
     case KERNEL_BARNETT_MAGLAND: return phi_barnett_magland(k, r);
     case KERNEL_SIXPOINT: return phi_sixpoint(k->invh[axis], r);
+    /* BDHI2D_ns::Gaussian / GaussianThermalDrift<dir> (Integrator/Hydro/BDHI_quasi2D.cuh:112-153): phiZ = 1 */
+    case KERNEL_GAUSS2D: return k->prefactor * EXP(k->tau * r * r);
+    case KERNEL_GAUSS2D_DRIFT_X: return k->prefactor * EXP(k->tau * r * r) * (axis == 0 ? r : (real)1.0);
+    case KERNEL_GAUSS2D_DRIFT_Y: return k->prefactor * EXP(k->tau * r * r) * (axis == 1 ? r : (real)1.0);
     default: return (real)1.0;
   }
 }
@@ -164,7 +168,7 @@ static void make_stencil(Stencil *s, const Grid *g, const IBMKernel *k, real3 pi
     int3 cj = mki3(s->celli.x, s->celli.y, grid_pbc_coord(g, 2, s->celli.z + i - s->P.z));
     s->wz[i] = (cj.z >= 0) ? phi_axis(k, 2, grid_distance_to_cell_center(g, pi, cj).z) : 0;
     /* 2D: the Peskin windows of the reference tests return phiZ = 1 (test_ibm_regular.cu:83-85) */
-    if (is2D && (k->kind == KERNEL_PESKIN3 || k->kind == KERNEL_PESKIN4)) s->wz[i] = 1;
+    if (is2D && (k->kind == KERNEL_PESKIN3 || k->kind == KERNEL_PESKIN4 || k->kind >= KERNEL_GAUSS2D)) s->wz[i] = 1;
   }
 }
 
