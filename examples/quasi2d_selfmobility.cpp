@@ -1,0 +1,47 @@
+// BDHI::Quasi2D and BDHI::True2D pulling one particle: the self mobilities of the reference's test/BDHI/quasi2D/quasi2d_test.cu
+// (computeSelfMobility, :56-138).  Plain g++ (C++14), linked against libuammd_hip.so.
+#include "uammd.cuh"
+#include "Integrator/Hydro/BDHI_quasi2D.cuh"
+#include <cmath>
+#include <cstdio>
+using namespace uammd;
+
+struct Pull : public Interactor {
+  using Interactor::Interactor;
+  void sum(Computables, hipStream_t) override {
+    auto f = pd->getForce(access::cpu, access::write);
+    f[0] = make_real4(1, 0, 0, 0);
+  }
+};
+
+template <class Scheme> static double selfMobility(shared_ptr<System> sys, real lbox, real a) {
+  auto pd = std::make_shared<ParticleData>(1, sys);
+  typename Scheme::Parameters par;
+  par.temperature = 0; par.viscosity = 1.12312; par.dt = 0.1; par.hydrodynamicRadius = a; par.box = Box(make_real3(lbox, lbox, 0));
+  auto bdhi = std::make_shared<Scheme>(pd, par);
+  bdhi->addInteractor(std::make_shared<Pull>(pd, "puller"));
+  double M = 0;
+  const int ntest = 20;
+  for (int i = 0; i < ntest; ++i) {
+    const real4 p0 = make_real4(sys->rng().uniform(-0.5, 0.5) * lbox, sys->rng().uniform(-0.5, 0.5) * lbox, 0, 0);
+    { auto pos = pd->getPos(access::cpu, access::write); pos[0] = p0; }
+    bdhi->forwardTime();
+    auto pos = pd->getPos(access::cpu, access::read);
+    M += (double)pos[0].x - (double)p0.x;
+  }
+  return par.viscosity * M / (ntest * par.dt);
+}
+
+int main(int argc, char *argv[]) {
+  auto sys = std::make_shared<System>(argc, argv);
+  const real a = 1.21312;
+  int bad = 0;
+  for (real lbox : {32.0, 128.0}) {
+    const double mq = selfMobility<BDHI::Quasi2D>(sys, lbox * a, a), tq = 1.0 / (6 * M_PI * a) / (1 + 4.41 / lbox);
+    const double mt = selfMobility<BDHI::True2D>(sys, lbox * a, a), tt = (std::log(lbox) - 1.3105329259115095183) / (4 * M_PI);
+    std::printf("L/a = %3.0f  Quasi2D %.5f (theory %.5f)   True2D %.5f (theory %.5f)\n", (double)lbox, mq, tq, mt, tt);
+    bad += !(std::abs(mq - tq) < 1e-3) + !(std::abs(mt - tt) < 1e-3);
+  }
+  sys->finish();
+  return bad;
+}

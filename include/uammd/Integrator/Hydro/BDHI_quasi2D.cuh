@@ -1,0 +1,3 @@
+// Forwarding header: same include path as the reference's src/Integrator/Hydro/BDHI_quasi2D.cuh (BDHI::True2D, BDHI::Quasi2D).
+#pragma once
+#include "../../uammd.h"

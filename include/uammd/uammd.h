@@ -1175,6 +1175,63 @@ public:
 }  // namespace BDHI
 
 // ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------
+// ---- BDHI::True2D / BDHI::Quasi2D (Integrator/Hydro/BDHI_quasi2D.cuh:155-257): hydrodynamics of particles confined to a plane ------
+namespace BDHI {
+namespace BDHI2D_ns {
+struct True2D { static constexpr int id = UAMMD_BDHI2D_TRUE2D; static constexpr bool hasThermalDrift() { return false; } };
+struct Quasi2D { static constexpr int id = UAMMD_BDHI2D_QUASI2D; static constexpr bool hasThermalDrift() { return true; } };
+}  // namespace BDHI2D_ns
+template <class HydroKernel> class BDHI2D : public Integrator {
+  uammd_bdhi2d *h = nullptr;
+  detail::DeviceArray<real2> particleVels;
+  Box box;
+  real temperature, dt, viscosity;
+  int step = 0;
+  int cellsOut[2] = {0, 0}, support = 0;
+  hipStream_t st = 0;
+public:
+  struct Parameters : BDHI::Parameters {
+    int2 cells = make_int2(-1, -1);
+  };
+  BDHI2D(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "BDHI::BDHI2D"), particleVels(pd->getNumParticles()), box(make_real3(par.box.boxSize.x, par.box.boxSize.y, 0)),
+        temperature(par.temperature), dt(par.dt), viscosity(par.viscosity) {
+    uammd_bdhi2d_parameters p{};
+    p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y;
+    p.hydrodynamicRadius = par.hydrodynamicRadius; p.viscosity = par.viscosity; p.temperature = par.temperature; p.dt = par.dt;
+    p.cells[0] = par.cells.x; p.cells[1] = par.cells.y;
+    p.seed = sys->rng().next32();  // .cu:28
+    p.kernel = HydroKernel::id;
+    if (uammd_bdhi2d_create(&p, &h, cellsOut, &support) != 0) throw std::runtime_error(uammd_hip_last_error());  // "Invalid box" / "Invalid hydrodynamic radius"
+  }
+  BDHI2D(const BDHI2D &) = delete;
+  ~BDHI2D() { uammd_bdhi2d_destroy(h); }
+  int2 getCells() const { return make_int2(cellsOut[0], cellsOut[1]); }
+  int getSupport() const { return support; }
+  void forwardTime() override {
+    for (auto &u : updatables) u->updateSimulationTime(step * dt);
+    step++;
+    if (step == 1) for (auto &u : updatables) { u->updateTemperature(temperature); u->updateBox(box); u->updateTimeStep(dt); }
+    {
+      auto force = pd->getForce(access::gpu, access::write);
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
+    }
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
+    const int N = pd->getNumParticles();
+    {
+      auto pos = pd->getPos(access::gpu, access::read);
+      auto force = pd->getForce(access::gpu, access::read);
+      detail::check(uammd_bdhi2d_velocities(h, (const float *)pos.raw(), interactors.empty() ? nullptr : (const float *)force.raw(), N,
+                                            (float *)particleVels.d, (void *)st));
+    }
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    detail::check(uammd_bdhi2d_update_positions((float *)pos.raw(), (const float *)particleVels.d, N, dt, (void *)st));
+  }
+};
+using True2D = BDHI2D<BDHI2D_ns::True2D>;
+using Quasi2D = BDHI2D<BDHI2D_ns::Quasi2D>;
+}  // namespace BDHI
+
 // ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald ----------------------
 class Poisson : public Interactor {
   uammd_poisson *h = nullptr;

@@ -192,6 +192,9 @@ int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
 #define UAMMD_IBM_KERNEL_BARNETT_MAGLAND 4 /* exp(beta(sqrt(1-(r/(a alpha))^2)-1))/(a norm); prefactor=1/norm, tau=beta, rmax=alpha,
                                              invh[0]=a (a LENGTH, not an inverse)  misc/IBM_kernels.cuh:82-112, FCM_kernels.cuh:82-155 */
 #define UAMMD_IBM_KERNEL_SIXPOINT 5 /* GaussianFlexible::sixPoint, support 6, invh = 1/h        misc/IBM_kernels.cuh:162-236 */
+#define UAMMD_IBM_KERNEL_GAUSS2D 6         /* BDHI2D_ns::Gaussian: prefactor*exp(tau r^2) in x and y, 1 in z   Integrator/Hydro/BDHI_quasi2D.cuh:112-132 */
+#define UAMMD_IBM_KERNEL_GAUSS2D_DRIFT_X 7 /* GaussianThermalDrift<0>: the same times r along x                  BDHI_quasi2D.cuh:134-153 */
+#define UAMMD_IBM_KERNEL_GAUSS2D_DRIFT_Y 8 /* GaussianThermalDrift<1> */
 typedef struct {
   int kind;
   int support[3];
@@ -291,6 +294,34 @@ int uammd_bdhi_cholesky_mf(uammd_bdhi_cholesky *h, const float *d_pos, const flo
 /* d_BdW real3[N]: N(0,1) draws on entry (the reference's cuRAND stream is unpinned third party), B dW on exit. */
 int uammd_bdhi_cholesky_bdw(uammd_bdhi_cholesky *h, const float *d_pos, const int *d_index, const float *d_radius, float *d_BdW,
                             void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BDHI::True2D / BDHI::Quasi2D — hydrodynamics of particles confined to a plane.  Replaces
+ *   BDHI2D<HydroKernel>::BDHI2D / forwardTime      Integrator/Hydro/BDHI_quasi2D.cuh:155-257, .cu:18-205
+ *   spreadThermalDrift / spreadParticleForces / forceFourier2Vel / fourierBrownianNoise / interpolateVelocities /
+ *   updateParticlePositions                         .cu:234-541
+ * cells[0] <= 0: grid from h = 0.8 a (the tolerance parameter is ignored by the reference, .cu:143-145).
+ * ---------------------------------------------------------------------------------------------- */
+#define UAMMD_BDHI2D_TRUE2D 0  /* BDHI2D_ns::True2D:  f_k = 0, g_k = 1/k^4                       BDHI_quasi2D.cuh:83-93 */
+#define UAMMD_BDHI2D_QUASI2D 1 /* BDHI2D_ns::Quasi2D: 3D Stokes integrated over z, thermal drift  BDHI_quasi2D.cuh:95-110 */
+typedef struct uammd_bdhi2d uammd_bdhi2d;
+typedef struct {
+  float boxSize[2];
+  float hydrodynamicRadius, viscosity, temperature, dt;
+  int cells[2];
+  unsigned int seed; /* the reference draws it from System::rng().next32() */
+  int kernel;        /* UAMMD_BDHI2D_* */
+} uammd_bdhi2d_parameters;
+/* Errors (-2) carry the reference's messages ("Invalid box", "Invalid hydrodynamic radius"). */
+int uammd_bdhi2d_create(const uammd_bdhi2d_parameters *par, uammd_bdhi2d **out, int cells[2], int *support);
+int uammd_bdhi2d_destroy(uammd_bdhi2d *h);
+/* One step's particle velocities (through interpolateVelocities): d_pos real4[N]; d_force real4[N] or NULL when no
+ * Interactor is attached (then only the thermal terms act); d_vel real2[N], overwritten. */
+int uammd_bdhi2d_velocities(uammd_bdhi2d *h, const float *d_pos, const float *d_force, int numberParticles, float *d_vel,
+                            void *stream);
+/* pos += make_real4(vel * dt) */
+int uammd_bdhi2d_update_positions(float *d_pos, const float *d_vel, int numberParticles, float dt, void *stream);
+int uammd_bdhi2d_get_counter(uammd_bdhi2d *h, unsigned int *counter); /* number of stochastic steps taken (Saru seed) */
 
 /* ------------------------------------------------------------------------------------------------
  * Triply periodic electrostatics (another consumer of the spread / FFT / gather engine).  Replaces

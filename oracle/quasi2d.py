@@ -88,6 +88,8 @@ class BDHI2DOracle:
     def forwardTime(self, pos, force2=None):
         """pos real4[N] advanced in place: pos += make_real4(vel * dt) (.cu:521-541)."""
         v = self.velocities(pos, force2)
-        pos[:, 0] += (v[:, 0] * self.real(self.dt)).astype(pos.dtype)
-        pos[:, 1] += (v[:, 1] * self.real(self.dt)).astype(pos.dtype)
+        # one rounding, as the fused multiply-add the GPU issues (the product of two floats is exact in double)
+        dt = np.float64(self.real(self.dt))
+        pos[:, 0] = (v[:, 0].astype(np.float64) * dt + pos[:, 0].astype(np.float64)).astype(pos.dtype)
+        pos[:, 1] = (v[:, 1].astype(np.float64) * dt + pos[:, 1].astype(np.float64)).astype(pos.dtype)
         return v

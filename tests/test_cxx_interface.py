@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "custom_transverser"]
+PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "custom_transverser"]
 
 
 def _make():
@@ -27,7 +27,7 @@ def test_reference_include_paths_exist():
     for h in ["uammd.cuh", "Interactor/PairForces.cuh", "Interactor/NeighbourList/CellList.cuh",
               "Interactor/Potential/Potential.cuh", "Integrator/VerletNVT.cuh", "Integrator/BrownianDynamics.cuh",
               "Integrator/BDHI/BDHI_FCM.cuh", "Integrator/BDHI/BDHI_PSE.cuh", "Integrator/BDHI/BDHI_EulerMaruyama.cuh", "Integrator/BDHI/BDHI_Cholesky.cuh",
-              "Interactor/NeighbourList/VerletList.cuh", "misc/LanczosAlgorithm.cuh", "Interactor/SpectralEwaldPoisson.cuh", "utils/checkpoint.h"]:
+              "Interactor/NeighbourList/VerletList.cuh", "misc/LanczosAlgorithm.cuh", "Interactor/SpectralEwaldPoisson.cuh", "utils/checkpoint.h", "Integrator/Hydro/BDHI_quasi2D.cuh"]:
         assert os.path.exists(os.path.join(inc, h)), h
 
 
@@ -38,7 +38,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
-                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []),
+                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []),
                                        ("custom_transverser", [])])
 def test_examples_run(prog, args):
     _make()

@@ -41,6 +41,11 @@ class FCMParameters(C.Structure):
                 ("kernel", IBMKernel), ("hydrodynamicRadius", C.c_float)]
 
 
+class BDHI2DParameters(C.Structure):
+    _fields_ = [("boxSize", C.c_float * 2), ("hydrodynamicRadius", C.c_float), ("viscosity", C.c_float), ("temperature", C.c_float),
+                ("dt", C.c_float), ("cells", C.c_int * 2), ("seed", C.c_uint), ("kernel", C.c_int)]
+
+
 class PoissonParameters(C.Structure):
     _fields_ = [("boxSize", C.c_float * 3), ("epsilon", C.c_float), ("tolerance", C.c_float), ("gw", C.c_float),
                 ("split", C.c_float), ("upsampling", C.c_float)]
@@ -102,6 +107,11 @@ SIGNATURES = {
     "uammd_bdhi_cholesky_setup_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_mf": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_bdw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi2d_create": (_i, [C.POINTER(BDHI2DParameters), C.POINTER(_vp), C.POINTER(C.c_int * 2), C.POINTER(_i)]),
+    "uammd_bdhi2d_destroy": (_i, [_vp]),
+    "uammd_bdhi2d_velocities": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_bdhi2d_update_positions": (_i, [_vp, _vp, _i, _f, _vp]),
+    "uammd_bdhi2d_get_counter": (_i, [_vp, C.POINTER(_u)]),
     "uammd_poisson_create": (_i, [C.POINTER(PoissonParameters), C.POINTER(_vp), C.POINTER(PoissonInfo)]),
     "uammd_poisson_destroy": (_i, [_vp]),
     "uammd_poisson_set_option": (_i, [_vp, C.c_char_p, _i]),

@@ -479,6 +479,75 @@ class PSE:
         self._far(force, MF, temperature, noise_prefactor)
 
 
+class _BDHI2D(Integrator):
+    """BDHI2D<HydroKernel> (Integrator/Hydro/BDHI_quasi2D.cuh:155-257): forwardTime = reset, interactors, spread, Fourier-space
+    Green's function and noise, gather, Euler update — for particles confined to z = 0."""
+    kernel = None
+
+    class Parameters(_Parameters):
+        def __init__(self, cells=(-1, -1), **kw):
+            super().__init__(**kw)
+            self.cells = list(cells)
+
+    def __init__(self, pd, par):
+        super().__init__(pd)
+        from ._lib import BDHI2DParameters
+        p = BDHI2DParameters()
+        L = par.box.boxSize
+        p.boxSize[0], p.boxSize[1] = float(L[0]), float(L[1])
+        p.hydrodynamicRadius, p.viscosity, p.temperature, p.dt = (float(par.hydrodynamicRadius), float(par.viscosity),
+                                                                  float(par.temperature), float(par.dt))
+        p.cells[0], p.cells[1] = int(par.cells[0]), int(par.cells[1])
+        self.seed = par.seed if par.seed else pd.rng.next32()          # seed = sys->rng().next32(), .cu:28
+        p.seed, p.kernel = int(self.seed) & 0xFFFFFFFF, int(self.kernel)
+        h, cells, sup = C.c_void_p(), (C.c_int * 2)(), C.c_int(0)
+        try:
+            check(self.lib.uammd_bdhi2d_create(C.byref(p), C.byref(h), C.byref(cells), C.byref(sup)))
+        except _lib.UammdHipError as e:
+            if "Invalid" in str(e):       # std::runtime_error("Invalid box" / "Invalid hydrodynamic radius"), .cu:46-57
+                raise RuntimeError(str(e)) from e
+            raise
+        self.h, self.cells, self.support = h, [cells[0], cells[1]], int(sup.value)
+        self.par = par
+        self.box = Box([float(L[0]), float(L[1]), 0.0])
+        self._vel = torch.zeros((pd.N, 2), dtype=torch.float32, device=pd.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_bdhi2d_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def forwardTime(self):
+        pd, par = self.pd, self.par
+        for it in self.interactors:
+            it.updateSimulationTime(self.steps * par.dt)
+        self.steps += 1
+        if self.steps == 1:
+            for it in self.interactors:
+                it.updateTemperature(par.temperature)
+                it.updateBox(self.box)
+                it.updateTimeStep(par.dt)
+        pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+        force = _ptr(pd.getForce("read")) if self.interactors else None
+        check(self.lib.uammd_bdhi2d_velocities(self.h, _ptr(pd.getPos("read")), force, pd.N, _ptr(self._vel), current_stream()))
+        check(self.lib.uammd_bdhi2d_update_positions(_ptr(pd.getPos("readwrite")), _ptr(self._vel), pd.N, float(par.dt), current_stream()))
+
+
+class True2D(_BDHI2D):
+    """BDHI::True2D = BDHI2D<BDHI2D_ns::True2D> (BDHI_quasi2D.cuh:252)."""
+    kernel = 0
+
+
+class Quasi2D(_BDHI2D):
+    """BDHI::Quasi2D = BDHI2D<BDHI2D_ns::Quasi2D> (BDHI_quasi2D.cuh:253)."""
+    kernel = 1
+
+
 class Cholesky:
     """BDHI::Cholesky — the Method concept of BDHI::EulerMaruyama with a dense mobility matrix and its Cholesky factor
     (Integrator/BDHI/BDHI_Cholesky.cuh:37-80, .cu:83-262).  noise_fn() -> float[3N] N(0,1) replaces the reference's cuRAND
@@ -714,6 +783,8 @@ class BDHI:
     PSE = PSE
     Lanczos = Lanczos
     Cholesky = Cholesky
+    True2D = True2D
+    Quasi2D = Quasi2D
     EulerMaruyama = EulerMaruyama
     FCMIntegrator = FCMIntegrator
     FCM_impl = FCM_impl

@@ -104,7 +104,7 @@ static int check_ibm_args(const char *fn, int posStride, int ncomp, const int ce
       set_last_error("%s: kernel support %d outside [1, %d]", fn, k->support[a], kMaxSupport);
       return -1;
     }
-  if (k->kind < 0 || k->kind > kKernelSixPoint) { set_last_error("%s: unknown kernel kind %d", fn, k->kind); return -1; }
+  if (k->kind < 0 || k->kind > kKernelGauss2DDriftY) { set_last_error("%s: unknown kernel kind %d", fn, k->kind); return -1; }
   return 0;
 }
 

@@ -14,7 +14,7 @@
 namespace uammd_hip {
 
 enum { kKernelGaussian = 0, kKernelPeskin3 = 1, kKernelPeskin4 = 2, kKernelConstant = 3, kKernelBarnettMagland = 4,
-       kKernelSixPoint = 5 };
+       kKernelSixPoint = 5, kKernelGauss2D = 6, kKernelGauss2DDriftX = 7, kKernelGauss2DDriftY = 8 };
 constexpr int kMaxSupport = 21;  // 3*support weights must fit in one wave
 
 struct IBMKernelDev {
@@ -89,6 +89,10 @@ UH_D float phi_axis(const IBMKernelDev &k, int axis, float r) {
     case kKernelPeskin4: return phi_peskin4(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
     case kKernelBarnettMagland: return phi_barnett_magland(k, r);
     case kKernelSixPoint: return phi_sixpoint(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    // BDHI2D_ns::Gaussian / GaussianThermalDrift<dir> (Integrator/Hydro/BDHI_quasi2D.cuh:112-153); phiZ = 1 (make_stencil)
+    case kKernelGauss2D: return k.prefactor * expf(k.tau * r * r);
+    case kKernelGauss2DDriftX: return k.prefactor * expf(k.tau * r * r) * (axis == 0 ? r : 1.0f);
+    case kKernelGauss2DDriftY: return k.prefactor * expf(k.tau * r * r) * (axis == 1 ? r : 1.0f);
     default: return 1.0f;
   }
 }
@@ -127,7 +131,7 @@ UH_D Stencil make_stencil(const GridT<float> &g, const IBMKernelDev &k, real3f p
     const int cz = g.pbc_z(s.celli.z + (lane - sx - sy) - s.P.z);
     if (cz >= 0) s.w = phi_axis(k, 2, g.distanceToCellCenter(pi, make_int3(s.celli.x, s.celli.y, cz)).z);
     // 2D: the Peskin windows of the reference tests return phiZ = 1 (test/misc/ibm/test_ibm_regular.cu:83-85)
-    if (is2D && (k.kind == kKernelPeskin3 || k.kind == kKernelPeskin4)) s.w = 1.0f;
+    if (is2D && (k.kind == kKernelPeskin3 || k.kind == kKernelPeskin4 || k.kind >= kKernelGauss2D)) s.w = 1.0f;
   }
   return s;
 }
