@@ -558,6 +558,29 @@ def main():
         out["lj_verletlist"] = {"ms_per_step": t1 / 300 * 1e3, "value": n * 300 / t1, "unit": "particle-steps/s", "steps": 300,
                                 "list_rebuilds": pf2.nl.rebuilds - r0, "cutOffMultiplier": 1.08}
         del pd2, verlet2, pf2
+        # The reference's one published benchmark (examples/misc/benchmark.cu:8 "~90 FPS" on a GTX 980; parameters :172-181):
+        # N = 2^20 on an FCC lattice in a 128^3 box (rho* = 0.5), rc = 2.5, dt = 0.01, T = 1, friction 1, VerletList with
+        # rcutmult 1.2, sortParticles every 500 steps, 500 warm-up + 500 timed steps.
+        nb, Lb = 1 << 20, 128.0
+        pd3, _, _, verlet3, pf3, _ = lj_setup(hip, nb, Lb, seed=1234, dt=0.01, nl="verlet")
+        pf3.nl.setCutOffMultiplier(1.2)
+        pd3.sortParticles()
+        for _ in range(500):
+            verlet3.forwardTime()
+        torch.cuda.synchronize()
+        r0 = pf3.nl.rebuilds
+        t2 = time.perf_counter()
+        for j in range(500):
+            verlet3.forwardTime()
+            if j % 500 == 0:
+                pd3.sortParticles()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        out["reference_benchmark"] = {"config": "examples/misc/benchmark.cu: 1048576 LJ particles, box 128^3, rc 2.5, dt 0.01, GronbechJensen, "
+                                                "VerletList x1.2, sort every 500 steps", "steps_per_s": 500 / t2,
+                                      "ms_per_step": t2 / 500 * 1e3, "list_rebuilds": pf3.nl.rebuilds - r0,
+                                      "published": "~90 steps/s on a GTX 980 (benchmark.cu:8), other hardware: orientation only"}
+        del pd3, verlet3, pf3
     if args.workload == "both":
         fcm = run_fcm(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
