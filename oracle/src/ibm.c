@@ -44,6 +44,7 @@ static inline real phi_peskin3(real invh, real rr) { /* IBM_kernels.cuh:120-136 
   }
   return 0;
 }
+ORACLE_API real oracle_phi_peskin3(real invh, real r) { return phi_peskin3(invh, r); }
 static inline real phi_peskin4(real invh, real rr) { /* IBM_kernels.cuh:145-158 */
   const real r = FABS(rr) * invh;
   const real onediv8 = (real)0.125;
