@@ -2,6 +2,7 @@
 // (computeSelfMobility, :56-138).  Plain g++ (C++14), linked against libuammd_hip.so.
 #include "uammd.cuh"
 #include "Integrator/Hydro/BDHI_quasi2D.cuh"
+#include "Integrator/BDHI/FIB.cuh"
 #include <cmath>
 #include <cstdio>
 using namespace uammd;
@@ -41,6 +42,23 @@ int main(int argc, char *argv[]) {
     const double mt = selfMobility<BDHI::True2D>(sys, lbox * a, a), tt = (std::log(lbox) - 1.3105329259115095183) / (4 * M_PI);
     std::printf("L/a = %3.0f  Quasi2D %.5f (theory %.5f)   True2D %.5f (theory %.5f)\n", (double)lbox, mq, tq, mt, tt);
     bad += !(std::abs(mq - tq) < 1e-3) + !(std::abs(mt - tt) < 1e-3);
+  }
+  {  // BDHI::FIB: the same pull in a cubic box, against FIB::getSelfMobility() (+- 1 %, FIB.cuh:35-37)
+    auto pd = std::make_shared<ParticleData>(1, sys);
+    BDHI::FIB::Parameters par;
+    par.temperature = 0; par.viscosity = 1.0; par.dt = 0.01; par.hydrodynamicRadius = 1.0; par.box = Box(64.0);
+    auto fib = std::make_shared<BDHI::FIB>(pd, par);
+    fib->addInteractor(std::make_shared<Pull>(pd, "puller"));
+    double M = 0;
+    for (int i = 0; i < 20; ++i) {
+      const real4 p0 = make_real4(sys->rng().uniform(-32, 32), sys->rng().uniform(-32, 32), sys->rng().uniform(-32, 32), 0);
+      { auto pos = pd->getPos(access::cpu, access::write); pos[0] = p0; }
+      fib->forwardTime();
+      auto pos = pd->getPos(access::cpu, access::read);
+      M += ((double)pos[0].x - (double)p0.x) / (20 * par.dt);
+    }
+    std::printf("FIB  a = %.4f  mobility %.5f (getSelfMobility %.5f)\n", (double)fib->getHydrodynamicRadius(), M, (double)fib->getSelfMobility());
+    bad += !(std::abs(M / fib->getSelfMobility() - 1) < 0.02);
   }
   sys->finish();
   return bad;

@@ -1232,6 +1232,61 @@ using True2D = BDHI2D<BDHI2D_ns::True2D>;
 using Quasi2D = BDHI2D<BDHI2D_ns::Quasi2D>;
 }  // namespace BDHI
 
+// ---- BDHI::FIB (Integrator/BDHI/FIB/FIB.cuh:131-236): fluctuating immersed boundary on a staggered grid ------------------------------
+namespace BDHI {
+class FIB : public Integrator {
+  uammd_fib *h = nullptr;
+  Box box;
+  real temperature, viscosity, dt, hydrodynamicRadius = 0;
+  int cellsOut[3] = {0, 0, 0};
+  unsigned long long step = 0;
+public:
+  enum Scheme { MIDPOINT, IMPROVED_MIDPOINT };
+  struct Parameters {
+    real temperature = 0;
+    real viscosity = 1;
+    real hydrodynamicRadius = -1;
+    real dt = 0;
+    Box box;
+    int3 cells = make_int3(-1, -1, -1);
+    Scheme scheme = Scheme::IMPROVED_MIDPOINT;
+    real tolerance = 1e-5;
+  };
+  FIB(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "BDHI::FIB"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt) {
+    uammd_fib_parameters p{};
+    p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
+    p.temperature = par.temperature; p.viscosity = par.viscosity; p.hydrodynamicRadius = par.hydrodynamicRadius; p.dt = par.dt;
+    p.cells[0] = par.cells.x; p.cells[1] = par.cells.y; p.cells[2] = par.cells.z;
+    p.scheme = (int)par.scheme;
+    p.seed = sys->rng().next32();
+    float rh = 0;
+    if (uammd_fib_create(&p, &h, cellsOut, &rh) != 0) System::log<System::CRITICAL>("%s", uammd_hip_last_error());  // FIB.cu:95-103
+    hydrodynamicRadius = rh;
+  }
+  FIB(const FIB &) = delete;
+  ~FIB() { uammd_fib_destroy(h); }
+  real getSelfMobility() { return uammd_fib_self_mobility(hydrodynamicRadius, viscosity, box.boxSize.x); }
+  real getHydrodynamicRadius() { return hydrodynamicRadius; }
+  real getCellSize() { return box.boxSize.x / cellsOut[0]; }
+  void forwardTime() override {
+    step++;
+    if (step == 1) for (auto &u : updatables) { u->updateSimulationTime(0); u->updateTimeStep(dt); u->updateTemperature(temperature); u->updateBox(box); }
+    {
+      auto force = pd->getForce(access::gpu, access::write);
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));
+    }
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, 0); }
+    {
+      auto pos = pd->getPos(access::gpu, access::readwrite);
+      auto force = pd->getForce(access::gpu, access::read);
+      detail::check(uammd_fib_forward(h, (float *)pos.raw(), (const float *)force.raw(), pd->getNumParticles(), nullptr));
+    }
+    for (auto &u : updatables) u->updateSimulationTime(step * dt);
+  }
+};
+}  // namespace BDHI
+
 // ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald ----------------------
 class Poisson : public Interactor {
   uammd_poisson *h = nullptr;

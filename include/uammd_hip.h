@@ -324,6 +324,31 @@ int uammd_bdhi2d_update_positions(float *d_pos, const float *d_vel, int numberPa
 int uammd_bdhi2d_get_counter(uammd_bdhi2d *h, unsigned int *counter); /* number of stochastic steps taken (Saru seed) */
 
 /* ------------------------------------------------------------------------------------------------
+ * BDHI::FIB — Fluctuating Immersed Boundary on a staggered grid.  Replaces
+ *   FIB::FIB / forwardTime / forwardMidpoint     Integrator/BDHI/FIB/FIB.cuh:131-236, FIB.cu:87-135, :965-1000, :1058-1079
+ *   addRandomAdvection, spreadParticleForces, solveStokesFourier, midPointStep     FIB.cu:274-391, :528-597, :667-724, :726-823
+ * As in the reference both Scheme values run the simple midpoint scheme (FIB.cu:1072-1079) and the RFD thermal drift
+ * is disabled (:400).  Exactly one of hydrodynamicRadius > 0 / cells[0] > 0 must be given (the other negative).
+ * ---------------------------------------------------------------------------------------------- */
+#define UAMMD_FIB_MIDPOINT 0
+#define UAMMD_FIB_IMPROVED_MIDPOINT 1
+typedef struct uammd_fib uammd_fib;
+typedef struct {
+  float boxSize[3];
+  float temperature, viscosity, hydrodynamicRadius, dt;
+  int cells[3];
+  int scheme;        /* UAMMD_FIB_*; both run forwardMidpoint, as in the reference */
+  unsigned int seed; /* the reference seeds cuRAND from System::rng(); here Saru(cell, seed, step) */
+} uammd_fib_parameters;
+int uammd_fib_create(const uammd_fib_parameters *par, uammd_fib **out, int cells[3], float *hydrodynamicRadius);
+int uammd_fib_destroy(uammd_fib *h);
+/* One step after the Interactors have filled d_force (real4[N]; NULL = no forces): d_pos real4[N] is advanced in place. */
+int uammd_fib_forward(uammd_fib *h, float *d_pos, const float *d_force, int numberParticles, void *stream);
+/* Test hook: take the 6*ncells fluid random numbers (slot-major: XX, YY, ZZ, XY, XZ, YZ) from this device array. */
+int uammd_fib_set_noise(uammd_fib *h, const float *d_random);
+float uammd_fib_self_mobility(float hydrodynamicRadius, float viscosity, float L); /* FIB::getSelfMobility, FIB.cuh:152-163 */
+
+/* ------------------------------------------------------------------------------------------------
  * Triply periodic electrostatics (another consumer of the spread / FFT / gather engine).  Replaces
  *   Poisson::Poisson / sum / computeFieldPotentialAtParticles    Interactor/SpectralEwaldPoisson.cuh:83-136, .cu:71-160
  *   farField (spread q, R2C, chargeFourier2FieldAndPotential, 4 x C2R, gather + UnZip2Real4)   .cu:332-360, :410-559

@@ -41,6 +41,11 @@ class FCMParameters(C.Structure):
                 ("kernel", IBMKernel), ("hydrodynamicRadius", C.c_float)]
 
 
+class FIBParameters(C.Structure):
+    _fields_ = [("boxSize", C.c_float * 3), ("temperature", C.c_float), ("viscosity", C.c_float), ("hydrodynamicRadius", C.c_float),
+                ("dt", C.c_float), ("cells", C.c_int * 3), ("scheme", C.c_int), ("seed", C.c_uint)]
+
+
 class BDHI2DParameters(C.Structure):
     _fields_ = [("boxSize", C.c_float * 2), ("hydrodynamicRadius", C.c_float), ("viscosity", C.c_float), ("temperature", C.c_float),
                 ("dt", C.c_float), ("cells", C.c_int * 2), ("seed", C.c_uint), ("kernel", C.c_int)]
@@ -107,6 +112,11 @@ SIGNATURES = {
     "uammd_bdhi_cholesky_setup_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_mf": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_bdw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_fib_create": (_i, [C.POINTER(FIBParameters), C.POINTER(_vp), C.POINTER(_i3), C.POINTER(_f)]),
+    "uammd_fib_destroy": (_i, [_vp]),
+    "uammd_fib_forward": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "uammd_fib_set_noise": (_i, [_vp, _vp]),
+    "uammd_fib_self_mobility": (_f, [_f, _f, _f]),
     "uammd_bdhi2d_create": (_i, [C.POINTER(BDHI2DParameters), C.POINTER(_vp), C.POINTER(C.c_int * 2), C.POINTER(_i)]),
     "uammd_bdhi2d_destroy": (_i, [_vp]),
     "uammd_bdhi2d_velocities": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

@@ -548,6 +548,77 @@ class Quasi2D(_BDHI2D):
     kernel = 1
 
 
+class FIB(Integrator):
+    """BDHI::FIB (Integrator/BDHI/FIB/FIB.cuh:131-236): fluctuating Stokes on a staggered grid, Peskin 3-point window, midpoint
+    scheme.  As in the reference, Scheme.IMPROVED_MIDPOINT runs the simple midpoint scheme too (FIB.cu:1072-1079)."""
+    MIDPOINT, IMPROVED_MIDPOINT = 0, 1
+
+    class Parameters:
+        def __init__(self, temperature=0.0, viscosity=1.0, hydrodynamicRadius=-1.0, dt=0.0, box=None, cells=(-1, -1, -1), scheme=1,
+                     tolerance=1e-5, seed=0):
+            self.temperature, self.viscosity, self.hydrodynamicRadius, self.dt = temperature, viscosity, hydrodynamicRadius, dt
+            self.box, self.cells, self.scheme, self.tolerance, self.seed = box, list(cells), scheme, tolerance, seed
+
+    def __init__(self, pd, par):
+        super().__init__(pd)
+        from ._lib import FIBParameters
+        p = FIBParameters()
+        for k in range(3):
+            p.boxSize[k] = float(par.box.boxSize[k])
+            p.cells[k] = int(par.cells[k])
+        p.temperature, p.viscosity, p.hydrodynamicRadius, p.dt = (float(par.temperature), float(par.viscosity),
+                                                                  float(par.hydrodynamicRadius), float(par.dt))
+        p.scheme = int(par.scheme)
+        p.seed = int(par.seed if par.seed else pd.rng.next32()) & 0xFFFFFFFF
+        h, cells, rh = C.c_void_p(), (C.c_int * 3)(), C.c_float(0)
+        try:
+            check(self.lib.uammd_fib_create(C.byref(p), C.byref(h), C.byref(cells), C.byref(rh)))
+        except _lib.UammdHipError as e:
+            if "FIB]" in str(e):      # System::CRITICAL in the reference (FIB.cu:95-103)
+                raise RuntimeError(str(e)) from e
+            raise
+        self.h, self.cells, self.hydrodynamicRadius = h, [int(c) for c in cells], float(rh.value)
+        self.par, self.box = par, par.box
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_fib_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def getHydrodynamicRadius(self):
+        return self.hydrodynamicRadius
+
+    def getCellSize(self):
+        return float(np.float32(self.box.boxSize[0]) / np.float32(self.cells[0]))
+
+    def getSelfMobility(self):
+        return float(self.lib.uammd_fib_self_mobility(self.hydrodynamicRadius, float(self.par.viscosity), float(self.box.boxSize[0])))
+
+    def set_noise(self, random):
+        """Test hook: device float[6, ncells] used as the fluid random numbers of the following steps (None: Saru)."""
+        self._noise = random
+        check(self.lib.uammd_fib_set_noise(self.h, _ptr(random) if random is not None else None))
+
+    def forwardTime(self):
+        pd, par = self.pd, self.par
+        self.steps += 1
+        if self.steps == 1:
+            for it in self.interactors:
+                it.updateSimulationTime(0)
+                it.updateTimeStep(par.dt)
+                it.updateTemperature(par.temperature)
+                it.updateBox(self.box)
+        pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+        check(self.lib.uammd_fib_forward(self.h, _ptr(pd.getPos("readwrite")), _ptr(pd.getForce("read")), pd.N, current_stream()))
+        for it in self.interactors:
+            it.updateSimulationTime(self.steps * par.dt)
+
+
 class Cholesky:
     """BDHI::Cholesky — the Method concept of BDHI::EulerMaruyama with a dense mobility matrix and its Cholesky factor
     (Integrator/BDHI/BDHI_Cholesky.cuh:37-80, .cu:83-262).  noise_fn() -> float[3N] N(0,1) replaces the reference's cuRAND
@@ -784,6 +855,7 @@ class BDHI:
     Lanczos = Lanczos
     Cholesky = Cholesky
     True2D = True2D
+    FIB = FIB
     Quasi2D = Quasi2D
     EulerMaruyama = EulerMaruyama
     FCMIntegrator = FCMIntegrator
