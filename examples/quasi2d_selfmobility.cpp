@@ -3,6 +3,7 @@
 #include "uammd.cuh"
 #include "Integrator/Hydro/BDHI_quasi2D.cuh"
 #include "Integrator/BDHI/FIB.cuh"
+#include "Integrator/Hydro/ICM.cuh"
 #include <cmath>
 #include <cstdio>
 using namespace uammd;
@@ -59,6 +60,23 @@ int main(int argc, char *argv[]) {
     }
     std::printf("FIB  a = %.4f  mobility %.5f (getSelfMobility %.5f)\n", (double)fib->getHydrodynamicRadius(), M, (double)fib->getSelfMobility());
     bad += !(std::abs(M / fib->getSelfMobility() - 1) < 0.02);
+  }
+  {  // Hydro::ICM: a fluid at rest stays at rest, a tethered-free particle in it does not move, and the API answers
+    auto pd = std::make_shared<ParticleData>(8, sys);
+    Hydro::ICM::Parameters par;
+    par.temperature = 0; par.viscosity = 1.0; par.density = 1.0; par.dt = 0.01; par.hydrodynamicRadius = 1.0; par.box = Box(32.0);
+    auto icm = std::make_shared<Hydro::ICM>(pd, par);
+    icm->addInteractor(std::make_shared<Pull>(pd, "puller"));
+    for (int i = 0; i < 50; ++i) icm->forwardTime();
+    const int3 n = icm->getNumberFluidCells();
+    const real3 *v = icm->getFluidVelocities(access::cpu);
+    double vmax = 0, mom = 0;
+    for (int i = 0; i < n.x * n.y * n.z; ++i) { vmax = std::max(vmax, (double)std::abs(v[i].x)); mom += v[i].x; }
+    real4 p0;
+    { auto pos = pd->getPos(access::cpu, access::read); p0 = pos[0]; }
+    std::printf("ICM  a = %.4f  cells %d^3  particle 0 moved to x = %.5f, max |v_x| = %.3e, mean v_x = %.1e\n",
+                (double)icm->getHydrodynamicRadius(), n.x, (double)p0.x, vmax, mom / (n.x * n.y * n.z));
+    bad += !(p0.x > 0 && vmax > 0 && std::abs(mom / (n.x * n.y * n.z)) < 1e-6 * vmax + 1e-9);
   }
   sys->finish();
   return bad;

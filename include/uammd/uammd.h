@@ -1287,6 +1287,86 @@ public:
 };
 }  // namespace BDHI
 
+// ---- Hydro::ICM (Integrator/Hydro/ICM.cuh:123-231): inertial coupling to an incompressible fluctuating fluid ---------------------
+namespace Hydro {
+class ICM : public Integrator {
+  uammd_icm *h = nullptr;
+  Box box;
+  real temperature, viscosity, dt, hydrodynamicRadius = 0;
+  int cellsOut[3] = {0, 0, 0};
+  uint step = 0;
+  detail::DeviceArray<real3> collocated;
+  std::vector<real3> h_collocated;
+public:
+  struct Parameters {
+    real temperature = 0;
+    real viscosity = -1;
+    real density = -1;
+    real hydrodynamicRadius = -1;
+    real dt = 0;
+    Box box;
+    int3 cells = make_int3(-1, -1, -1);
+    bool sumThermalDrift = false;
+    bool removeTotalMomentum = true;
+  };
+  ICM(shared_ptr<ParticleData> pd, Parameters par)
+      : Integrator(pd, "Hydro::ICM"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt), collocated(0) {
+    uammd_icm_parameters p{};
+    p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
+    p.temperature = par.temperature; p.viscosity = par.viscosity; p.density = par.density; p.hydrodynamicRadius = par.hydrodynamicRadius;
+    p.dt = par.dt;
+    p.cells[0] = par.cells.x; p.cells[1] = par.cells.y; p.cells[2] = par.cells.z;
+    p.sumThermalDrift = par.sumThermalDrift; p.removeTotalMomentum = par.removeTotalMomentum;
+    p.seed = sys->rng().next32();
+    float rh = 0;
+    if (uammd_icm_create(&p, &h, cellsOut, &rh) != 0) System::log<System::CRITICAL>("%s", uammd_hip_last_error());  // ICM.cu:833-839, :869-872
+    hydrodynamicRadius = rh;
+  }
+  ICM(const ICM &) = delete;
+  ~ICM() { uammd_icm_destroy(h); }
+  real sumEnergy() { return 0; }
+  real getSelfMobility() { return 1.0 / (6 * M_PI * viscosity * hydrodynamicRadius) * (1 - 2.837297 * hydrodynamicRadius / box.boxSize.x); }
+  real getHydrodynamicRadius() { return hydrodynamicRadius; }
+  int3 getNumberFluidCells() { return make_int3(cellsOut[0], cellsOut[1], cellsOut[2]); }
+  // cell-centred fluid velocities, cell (i,j,k) at i + (j + k*n.y)*n.x (ICM.cuh:176-199)
+  const real3 *getFluidVelocities(access::location dev) {
+    const size_t nc = (size_t)cellsOut[0] * cellsOut[1] * cellsOut[2];
+    collocated.resize(nc);
+    detail::check(uammd_icm_get_fluid_velocity(h, (float *)collocated.d, 1, nullptr));
+    if (dev == access::gpu) return collocated.d;
+    if (dev != access::cpu) throw std::runtime_error("Invalid device");
+    h_collocated.resize(nc);
+    detail::hipCheck(hipMemcpy(h_collocated.data(), collocated.d, sizeof(real3) * nc, hipMemcpyDeviceToHost), "hipMemcpy");
+    return h_collocated.data();
+  }
+  void forwardTime() override {
+    step++;
+    Interactor::Computables c; c.force = true;
+    if (step == 1) {
+      for (auto &u : updatables) { u->updateTemperature(temperature); u->updateTimeStep(dt); u->updateBox(box); u->updateSimulationTime(0); }
+      for (auto &f : interactors) f->sum(c, 0);
+    }
+    const int N = pd->getNumParticles();
+    {
+      auto pos = pd->getPos(access::gpu, access::readwrite);
+      detail::check(uammd_icm_predictor(h, (float *)pos.raw(), N, nullptr));
+    }
+    for (auto &u : updatables) u->updateSimulationTime((step - 0.5) * dt);
+    if (!interactors.empty()) {
+      { auto force = pd->getForce(access::gpu, access::write); detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr)); }
+      for (auto &f : interactors) f->sum(c, 0);
+    }
+    {
+      auto pos = pd->getPos(access::gpu, access::readwrite);
+      auto force = pd->getForce(access::gpu, access::readwrite);
+      detail::check(uammd_icm_fluid_and_corrector(h, (float *)pos.raw(), interactors.empty() ? nullptr : (const float *)force.raw(), N, nullptr));
+      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));  // correctorStep, :1176-1181
+    }
+    for (auto &u : updatables) u->updateSimulationTime(step * dt);
+  }
+};
+}  // namespace Hydro
+
 // ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald ----------------------
 class Poisson : public Interactor {
   uammd_poisson *h = nullptr;

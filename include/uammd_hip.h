@@ -349,6 +349,33 @@ int uammd_fib_set_noise(uammd_fib *h, const float *d_random);
 float uammd_fib_self_mobility(float hydrodynamicRadius, float viscosity, float L); /* FIB::getSelfMobility, FIB.cuh:152-163 */
 
 /* ------------------------------------------------------------------------------------------------
+ * Hydro::ICM — Inertial Coupling Method, zero excess mass.  Replaces
+ *   ICM::ICM / forwardTime                         Integrator/Hydro/ICM.cuh:123-231, ICM.cu:825-888, :1191-1224
+ *   midPointStep, updateCellVelocityUnperturbed, spreadParticleForces, addThermalDrift, solveStokesFourier
+ *                                                  ICM.cu:413-500, :793-822, :86-159, :161-275, :349-411
+ * The fluid velocity persists in the handle between steps.  Exactly one of hydrodynamicRadius > 0 / cells[0] > 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uammd_icm uammd_icm;
+typedef struct {
+  float boxSize[3];
+  float temperature, viscosity, density, hydrodynamicRadius, dt;
+  int cells[3];
+  int sumThermalDrift;     /* default 0 in the reference */
+  int removeTotalMomentum; /* default 1 in the reference */
+  unsigned int seed;
+} uammd_icm_parameters;
+int uammd_icm_create(const uammd_icm_parameters *par, uammd_icm **out, int cells[3], float *hydrodynamicRadius);
+int uammd_icm_destroy(uammd_icm *h);
+/* One step = predictor (d_pos real4[N]: q^n -> q^{n+1/2}), the caller's Interactors at q^{n+1/2}, then the fluid update and the
+ * corrector (d_pos -> q^{n+1}); d_force real4[N] or NULL when no Interactor is attached. */
+int uammd_icm_predictor(uammd_icm *h, float *d_pos, int numberParticles, void *stream);
+int uammd_icm_fluid_and_corrector(uammd_icm *h, float *d_pos, const float *d_force, int numberParticles, void *stream);
+/* real3[nz][ny][nx]: the face-centred field, or (collocated = 1) ICM::getFluidVelocities (ICM.cuh:96-119, :176-199) */
+int uammd_icm_get_fluid_velocity(uammd_icm *h, float *d_out, int collocated, void *stream);
+int uammd_icm_set_fluid_velocity(uammd_icm *h, const float *d_in, void *stream);
+int uammd_icm_set_noise(uammd_icm *h, const float *d_random); /* test hook: 6*ncells fluid random numbers, slot-major */
+
+/* ------------------------------------------------------------------------------------------------
  * Triply periodic electrostatics (another consumer of the spread / FFT / gather engine).  Replaces
  *   Poisson::Poisson / sum / computeFieldPotentialAtParticles    Interactor/SpectralEwaldPoisson.cuh:83-136, .cu:71-160
  *   farField (spread q, R2C, chargeFourier2FieldAndPotential, 4 x C2R, gather + UnZip2Real4)   .cu:332-360, :410-559

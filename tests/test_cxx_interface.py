@@ -27,7 +27,7 @@ def test_reference_include_paths_exist():
     for h in ["uammd.cuh", "Interactor/PairForces.cuh", "Interactor/NeighbourList/CellList.cuh",
               "Interactor/Potential/Potential.cuh", "Integrator/VerletNVT.cuh", "Integrator/BrownianDynamics.cuh",
               "Integrator/BDHI/BDHI_FCM.cuh", "Integrator/BDHI/BDHI_PSE.cuh", "Integrator/BDHI/BDHI_EulerMaruyama.cuh", "Integrator/BDHI/BDHI_Cholesky.cuh",
-              "Interactor/NeighbourList/VerletList.cuh", "misc/LanczosAlgorithm.cuh", "Interactor/SpectralEwaldPoisson.cuh", "utils/checkpoint.h", "Integrator/Hydro/BDHI_quasi2D.cuh", "Integrator/BDHI/FIB.cuh", "Integrator/BDHI/FIB/FIB.cuh"]:
+              "Interactor/NeighbourList/VerletList.cuh", "misc/LanczosAlgorithm.cuh", "Interactor/SpectralEwaldPoisson.cuh", "utils/checkpoint.h", "Integrator/Hydro/BDHI_quasi2D.cuh", "Integrator/BDHI/FIB.cuh", "Integrator/BDHI/FIB/FIB.cuh", "Integrator/Hydro/ICM.cuh"]:
         assert os.path.exists(os.path.join(inc, h)), h
 
 

@@ -11,6 +11,7 @@ from ._lib import UammdHipError, load  # noqa: F401
 from .md import (BD, Box, CellList, Integrator, Interactor, PairForces, ParticleData, ParticleGroup, Potential,  # noqa: F401
                  VerletList, VerletNVT, current_stream)
 from .electrostatics import Poisson  # noqa: F401
+from .hydro import Hydro  # noqa: F401
 from .checkpoint import restoreParticleData, saveParticleData  # noqa: F401
 from .bdhi import BDHI, IBM, FCMKernels, Kernels, nextFFTWiseSize3D  # noqa: F401
 

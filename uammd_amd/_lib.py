@@ -41,6 +41,12 @@ class FCMParameters(C.Structure):
                 ("kernel", IBMKernel), ("hydrodynamicRadius", C.c_float)]
 
 
+class ICMParameters(C.Structure):
+    _fields_ = [("boxSize", C.c_float * 3), ("temperature", C.c_float), ("viscosity", C.c_float), ("density", C.c_float),
+                ("hydrodynamicRadius", C.c_float), ("dt", C.c_float), ("cells", C.c_int * 3), ("sumThermalDrift", C.c_int),
+                ("removeTotalMomentum", C.c_int), ("seed", C.c_uint)]
+
+
 class FIBParameters(C.Structure):
     _fields_ = [("boxSize", C.c_float * 3), ("temperature", C.c_float), ("viscosity", C.c_float), ("hydrodynamicRadius", C.c_float),
                 ("dt", C.c_float), ("cells", C.c_int * 3), ("scheme", C.c_int), ("seed", C.c_uint)]
@@ -112,6 +118,13 @@ SIGNATURES = {
     "uammd_bdhi_cholesky_setup_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_mf": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uammd_bdhi_cholesky_bdw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_icm_create": (_i, [C.POINTER(ICMParameters), C.POINTER(_vp), C.POINTER(_i3), C.POINTER(_f)]),
+    "uammd_icm_destroy": (_i, [_vp]),
+    "uammd_icm_predictor": (_i, [_vp, _vp, _i, _vp]),
+    "uammd_icm_fluid_and_corrector": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "uammd_icm_get_fluid_velocity": (_i, [_vp, _vp, _i, _vp]),
+    "uammd_icm_set_fluid_velocity": (_i, [_vp, _vp, _vp]),
+    "uammd_icm_set_noise": (_i, [_vp, _vp]),
     "uammd_fib_create": (_i, [C.POINTER(FIBParameters), C.POINTER(_vp), C.POINTER(_i3), C.POINTER(_f)]),
     "uammd_fib_destroy": (_i, [_vp]),
     "uammd_fib_forward": (_i, [_vp, _vp, _vp, _i, _vp]),

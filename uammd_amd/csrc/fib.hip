@@ -66,103 +66,6 @@ static int next_fft_wise3(int n) {  // FIB_ns::nextFFTWiseSize3D (FIB.cu:31-84) 
   }
 }
 
-// spreadParticleForces (:528-597): one wave per particle, 81 atomics
-__global__ void __launch_bounds__(256) k_fib_spread(const float4 *__restrict__ pos, const float4 *__restrict__ force, float *__restrict__ g,
-                                                    size_t plane, int nxpad, int N, GridT<float> grid, float invh) {
-  const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (id >= N) return;
-  const float4 p = pos[id], f = force[id];
-  for (int l = lane; l < 81; l += 64) {
-    const StagNode s = stag_node(grid, nxpad, invh, real3f{p.x, p.y, p.z}, l);
-    const int c = l / 27;
-    const float fc = c == 0 ? f.x : (c == 1 ? f.y : f.z);
-    unsafeAtomicAdd(&g[c * plane + s.node], s.w * fc);
-  }
-}
-
-// midPointStep (:726-823).  MODE 0 predictor, 1 corrector, 2 euler
-template <int MODE>
-__global__ void __launch_bounds__(256) k_fib_midpoint(float4 *__restrict__ pos, float4 *__restrict__ posOld, const float *__restrict__ g,
-                                                      size_t plane, int nxpad, int N, GridT<float> grid, float invh, float dt) {
-  const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (id >= N) return;
-  const float4 p = pos[id];
-  const float dV = grid.cellSize.x * grid.cellSize.y * grid.cellSize.z;
-  float acc[3] = {0.f, 0.f, 0.f};
-  for (int l = lane; l < 81; l += 64) {
-    const StagNode s = stag_node(grid, nxpad, invh, real3f{p.x, p.y, p.z}, l);
-    const int c = l / 27;
-    const float v = s.w * g[c * plane + s.node] * dV;
-    acc[0] += c == 0 ? v : 0.0f; acc[1] += c == 1 ? v : 0.0f; acc[2] += c == 2 ? v : 0.0f;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    acc[0] += __shfl_xor(acc[0], o, 64); acc[1] += __shfl_xor(acc[1], o, 64); acc[2] += __shfl_xor(acc[2], o, 64);
-  }
-  if (lane != 0) return;
-  if (MODE == 0) {
-    posOld[id] = p;
-    const float pref = dt * 0.5f;
-    pos[id] = make_float4(p.x + pref * acc[0], p.y + pref * acc[1], p.z + pref * acc[2], p.w);
-  } else {
-    const float4 po = posOld[id];
-    pos[id] = make_float4(po.x + dt * acc[0], po.y + dt * acc[1], po.z + dt * acc[2], po.w);
-  }
-}
-
-// solveStokesFourier (:667-724) on the three complex planes [nz][ny][nkx]
-__global__ void __launch_bounds__(256) k_fib_stokes(float2 *__restrict__ g, size_t planeCplx, int3 n, real3f L, float viscosity, FastDiv dkx,
-                                                    FastDiv dny) {
-  const uint id = blockIdx.x * 256 + threadIdx.x;
-  const int nkx = n.x / 2 + 1;
-  if (id >= (uint)(nkx * n.y * n.z)) return;
-  const uint row = dkx.div(id);
-  const int cx = (int)(id - row * (uint)nkx);
-  const int cz = (int)dny.div(row);
-  const int cy = (int)(row - (uint)cz * (uint)n.y);
-  float2 v[3] = {g[id], g[planeCplx + id], g[2 * planeCplx + id]};
-  if (id == 0) {
-    v[0] = v[1] = v[2] = make_float2(0.f, 0.f);
-  } else {
-    const float hx = L.x / (float)n.x, hy = L.y / (float)n.y, hz = L.z / (float)n.z;
-    const float px = 2.0f * (float)M_PI / L.x, py = 2.0f * (float)M_PI / L.y, pz = 2.0f * (float)M_PI / L.z;
-    float kx = (float)cx * px, ky = (float)cy * py, kz = (float)cz * pz;  // cellToWaveNumber with the (n+1)/2 threshold (:603-617)
-    if (cx >= (n.x + 1) / 2) kx -= (float)n.x * px;
-    if (cy >= (n.y + 1) / 2) ky -= (float)n.y * py;
-    if (cz >= (n.z + 1) / 2) kz -= (float)n.z * pz;
-    float sn[3], cs[3];
-    sincosf(kx * hx * 0.5f, &sn[0], &cs[0]);
-    sincosf(ky * hy * 0.5f, &sn[1], &cs[1]);
-    sincosf(kz * hz * 0.5f, &sn[2], &cs[2]);
-    const real3f keff{2.0f * (1.0f / hx) * sn[0], 2.0f * (1.0f / hy) * sn[1], 2.0f * (1.0f / hz) * sn[2]};
-    float re[3], im[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {  // faces -> centres: phase (cos, -sin)
-      re[c] = v[c].x * cs[c] - v[c].y * (-sn[c]);
-      im[c] = v[c].y * cs[c] + v[c].x * (-sn[c]);
-    }
-    const float k2 = dot3(keff, keff);
-    const float invL = -1.0f / k2;
-    const float pref = -1.0f * invL / viscosity;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { re[c] *= pref; im[c] *= pref; }
-    const float invk2 = 1.0f / k2;
-    const float kfr = dot3(keff, real3f{re[0], re[1], re[2]}) * invk2, kfi = dot3(keff, real3f{im[0], im[1], im[2]}) * invk2;
-    const float ke[3] = {keff.x, keff.y, keff.z};
-    const float norm = 1.0f / (float)(n.x * n.y * n.z);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float tr = re[c] - ke[c] * kfr, ti = im[c] - ke[c] * kfi;
-      v[c] = make_float2(norm * (tr * cs[c] - ti * sn[c]), norm * (ti * cs[c] + tr * sn[c]));  // centres -> faces, FFT normalisation
-    }
-  }
-  g[id] = v[0];
-  g[planeCplx + id] = v[1];
-  g[2 * planeCplx + id] = v[2];
-}
-
 static int fib_make_plans(FIB *f) {
   if (int e = rocfft_setup_once()) return e;
   const size_t nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1;
@@ -284,14 +187,15 @@ int uammd_fib_forward(uammd_fib *h, float *d_pos, const float *d_force, int N, v
   const float invh = 1.0f / f->hKernel;
   const dim3 gp((N + 3) / 4), bp(256);
   if (d_force)
-    hipLaunchKernelGGL(k_fib_spread, gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, g, f->planeReal, f->nxpad, N, f->grid, invh);
+    hipLaunchKernelGGL(k_fib_spread, gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, g, f->planeReal, f->nxpad, N, f->grid, invh,
+                       1.0f);
   UH_ROCFFT(rocfft_execution_info_set_stream(f->info, (void *)st));
   void *bufs[1] = {g};
   UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
   const uint total = (uint)f->planeCplx;
-  hipLaunchKernelGGL(k_fib_stokes, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, f->planeCplx, n,
+  hipLaunchKernelGGL((k_fib_stokes<false>), dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, f->planeCplx, n,
                      real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity, make_fastdiv(n.x / 2 + 1),
-                     make_fastdiv(n.y));
+                     make_fastdiv(n.y), 0.0f, true);
   UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
   hipLaunchKernelGGL((k_fib_midpoint<0>), gp, bp, 0, st, (float4 *)d_pos, (float4 *)f->posOld.ptr, (const float *)g, f->planeReal, f->nxpad, N,
                      f->grid, invh, f->par.dt);
