@@ -68,7 +68,7 @@ int main(int argc, char *argv[]) {
     auto icm = std::make_shared<Hydro::ICM>(pd, par);
     icm->addInteractor(std::make_shared<Pull>(pd, "puller"));
     for (int i = 0; i < 50; ++i) icm->forwardTime();
-    const int3 n = icm->getNumberFluidCells();
+    const auto n = icm->getNumberFluidCells();
     const real3 *v = icm->getFluidVelocities(access::cpu);
     double vmax = 0, mom = 0;
     for (int i = 0; i < n.x * n.y * n.z; ++i) { vmax = std::max(vmax, (double)std::abs(v[i].x)); mom += v[i].x; }
