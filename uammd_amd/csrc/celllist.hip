@@ -333,7 +333,7 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   if (int e = sortHash.reserve(sizeof(uint) * (size_t)(N + 1))) return e;
   if (int e = index.reserve(sizeof(int) * (size_t)(N + 1))) return e;
   // +4: the traversal kernels read candidates in groups of four from one base address (reads past a cell are masked)
-  if (int e = sortPos.reserve(sizeof(float4) * (size_t)(N + 4))) return e;
+  if (int e = sortPos.reserve(sizeof(float4) * (size_t)(N + 8))) return e;
   numberParticlesBuilt = N;
 
   const uint maxHash = morton_hash(make_int3(grid.cellDim.x - 1, grid.cellDim.y - 1, grid.cellDim.z - 1));

@@ -71,21 +71,23 @@ template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
 UH_D void lj_scan(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, const float4 *__restrict__ P, int jb,
                   int je, const float4 &pi, const BoxT<float> &box, float rc2, const LJParams &p1,
                   const LJParams *tbl, int ntypes) {
-  for (int j = jb; j < je; j += 4) {
-    if (__any(Q.n > QCAP - 4)) {  // wave-uniform; the full minimum image is exact for every queued pair
+  for (int j = jb; j < je; j += 8) {
+    if (__any(Q.n > QCAP - 8)) {  // wave-uniform; the full minimum image is exact for every queued pair
       if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
       else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
     }
-    // four candidates from ONE address (immediate offsets); entries past the end of the cell are other particles or the
-    // padding of the array (CellList::update allocates N + 4) and are masked by j + u < je below
+    // eight candidates from ONE address (immediate offsets); entries past the end of the cell are other particles or the
+    // padding of the array (CellList::update allocates N + 8) and are masked by j + u < je below
     const float4 *__restrict__ pj = P + j;
-    const float4 c0 = pj[0], c1 = pj[1], c2 = pj[2], c3 = pj[3];
-    const float d0 = lj_dist2<PBC>(box, pi, c0), d1 = lj_dist2<PBC>(box, pi, c1);
-    const float d2 = lj_dist2<PBC>(box, pi, c2), d3 = lj_dist2<PBC>(box, pi, c3);
-    if (!(d0 >= rc2)) { Q.slot[Q.n * QSTRIDE] = (QT)j; ++Q.n; }
-    if (!(d1 >= rc2) && j + 1 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 1); ++Q.n; }
-    if (!(d2 >= rc2) && j + 2 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 2); ++Q.n; }
-    if (!(d3 >= rc2) && j + 3 < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + 3); ++Q.n; }
+    float4 c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = pj[u];
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = lj_dist2<PBC>(box, pi, c[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (!(d[u] >= rc2) && j + u < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + u); ++Q.n; }
   }
 }
 
@@ -102,7 +104,7 @@ struct ListView {
   int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
 };
 
-constexpr int kQCapGeneral = 16;  // per-lane FIFO depth of the global-memory kernels (uint entries)
+constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
 constexpr int kQCapBrick = 32;    // per-lane FIFO depth of the brick kernel (ushort LDS indices)
 
 // ---- general walk (also the in-kernel fallback of the brick kernel) ------------------------------
