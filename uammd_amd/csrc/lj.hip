@@ -45,22 +45,25 @@ template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
 UH_D void lj_drain(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, const float4 *__restrict__ P, const float4 &pi,
                    const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
   const int n = Q.n;
-  for (int t = 0; t < n; t += 2) {
-    const int ja = (int)Q.slot[t * QSTRIDE];
-    const int jc = (int)Q.slot[min(t + 1, n - 1) * QSTRIDE];
-    const float4 ca = P[ja], cb = P[jc];
-    real3f ra, rb;
-    float fa, fb, ea, eb;
-    if (NT1) {
-      lj_eval<PBC, WE>(box, p1, pi, ca, ra, fa, ea);
-      lj_eval<PBC, WE>(box, p1, pi, cb, rb, fb, eb);
-    } else {
-      lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)ca.w), pi, ca, ra, fa, ea);
-      lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)cb.w), pi, cb, rb, fb, eb);
+  for (int t = 0; t < n; t += 4) {
+    int jj[4];
+    float4 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) jj[u] = (int)Q.slot[min(t + u, n - 1) * QSTRIDE];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = P[jj[u]];
+    real3f r[4];
+    float f[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (NT1) lj_eval<PBC, WE>(box, p1, pi, c[u], r[u], f[u], e[u]);
+      else lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c[u].w), pi, c[u], r[u], f[u], e[u]);
     }
-    const bool mb = t + 1 < n;
-    lj_acc<WE, WV>(acc, ra, fa, ea);
-    lj_acc<WE, WV>(acc, rb, mb ? fb : 0.0f, mb ? eb : 0.0f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // added in FIFO order; the clamped tail repeats the last pair with weight 0
+      const bool live = t + u < n;
+      lj_acc<WE, WV>(acc, r[u], live ? f[u] : 0.0f, live ? e[u] : 0.0f);
+    }
   }
   Q.n = 0;
 }
