@@ -43,7 +43,7 @@ struct VerletList {
 // FIFO in LDS ([slot][lane], conflict free) and, when any lane's FIFO is nearly full, the wave flushes ROW BY ROW: for
 // k from the smallest pending row to the largest, the lanes that hold an entry for row k store it — every store
 // instruction writes one (partially masked) contiguous 256-byte row segment.
-constexpr int kFillQCap = 32;
+constexpr int kFillQCap = 24;
 __global__ void __launch_bounds__(128) k_verlet_fill(const float4 *__restrict__ sortPos, const uint *__restrict__ cellStart,
                                                       const int *__restrict__ cellEnd, uint validCell, int N,
                                                       GridT<float> grid, BoxT<float> box, float cutOff2,
