@@ -894,10 +894,11 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
 // stage: 0 = full pipeline; 1 = stop after spread+FFT+k-space (the Fourier grid can then be exported)
 int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
                                    float prefactor, float *d_linearVelocity, int stage, void *stream) {
-  if (!h || !d_pos || (!d_linearVelocity && stage == 0)) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
+  if (!h) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
+  if (N <= 0) return 0;  // nothing to move (an empty ParticleData has no arrays to point to)
+  if (!d_pos || (!d_linearVelocity && stage == 0)) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
   FCM *f = reinterpret_cast<FCM *>(h);
   hipStream_t st = (hipStream_t)stream;
-  if (N <= 0) return 0;
   float *g = (float *)f->gridBuf.ptr;
   const dim3 gp((N + 3) / 4), bp(256);
   const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
