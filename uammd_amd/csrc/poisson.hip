@@ -850,7 +850,9 @@ int uammd_poisson_destroy(uammd_poisson *h) {
 
 int uammd_poisson_sum(uammd_poisson *h, const float *d_pos, const float *d_charge, int N, float *d_force, float *d_energy,
                       int nearForce, int nearEnergy, void *stream) {
-  if (!h || !d_pos || !d_charge) { set_last_error("uammd_poisson_sum: null argument"); return -1; }
+  if (!h) { set_last_error("uammd_poisson_sum: null argument"); return -1; }
+  if (N <= 0) return 0;
+  if (!d_pos || !d_charge) { set_last_error("uammd_poisson_sum: null argument"); return -1; }
   if ((nearForce && !d_force) || (nearEnergy && !d_energy)) { set_last_error("uammd_poisson_sum: missing output array"); return -1; }
   if (N <= 0) return 0;
   Poisson *p = reinterpret_cast<Poisson *>(h);
@@ -868,7 +870,9 @@ int uammd_poisson_sum(uammd_poisson *h, const float *d_pos, const float *d_charg
 
 int uammd_poisson_field_potential(uammd_poisson *h, const float *d_pos, const float *d_charge, int N, float *d_fieldPotential,
                                   float *d_force, float *d_energy, void *stream) {
-  if (!h || !d_pos || !d_charge || !d_fieldPotential) { set_last_error("uammd_poisson_field_potential: null argument"); return -1; }
+  if (!h) { set_last_error("uammd_poisson_field_potential: null argument"); return -1; }
+  if (N <= 0) return 0;
+  if (!d_pos || !d_charge || !d_fieldPotential) { set_last_error("uammd_poisson_field_potential: null argument"); return -1; }
   if (N <= 0) return 0;
   Poisson *p = reinterpret_cast<Poisson *>(h);
   hipStream_t st = (hipStream_t)stream;

@@ -301,8 +301,9 @@ int uammd_bdhi2d_destroy(uammd_bdhi2d *h) {
 }
 
 int uammd_bdhi2d_velocities(uammd_bdhi2d *h, const float *d_pos, const float *d_force, int N, float *d_vel, void *stream) {
-  if (!h || !d_pos || !d_vel) { set_last_error("uammd_bdhi2d_velocities: null argument"); return -1; }
+  if (!h) { set_last_error("uammd_bdhi2d_velocities: null argument"); return -1; }
   if (N <= 0) return 0;
+  if (!d_pos || !d_vel) { set_last_error("uammd_bdhi2d_velocities: null argument"); return -1; }
   BDHI2D *q = reinterpret_cast<BDHI2D *>(h);
   hipStream_t st = (hipStream_t)stream;
   const float T = q->par.temperature;
