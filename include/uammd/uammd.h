@@ -459,6 +459,104 @@ inline shared_ptr<ParticleData> restoreParticleData(const std::string &fileName,
   return pd;
 }
 
+// ---- ParticleGroup (ParticleData/ParticleGroup.cuh:60-135 selectors, :170-379 group): a subset tracked by particle ID ------------
+namespace particle_selector {
+struct All { bool isSelected(int, shared_ptr<ParticleData> &) { return true; } };
+struct None { bool isSelected(int, shared_ptr<ParticleData> &) { return false; } };
+class IDRange {  // ids in [firstID, lastID]
+  int firstID, lastID;
+public:
+  IDRange(int first, int last) : firstID(first), lastID(last) {}
+  bool isSelected(int particleIndex, shared_ptr<ParticleData> &pd) {
+    const int id = pd->getId(access::cpu, access::read)[particleIndex];
+    return id >= firstID && id <= lastID;
+  }
+};
+class Type {  // pos.w
+  std::vector<int> typesToSelect;
+public:
+  Type(int type) : typesToSelect({type}) {}
+  Type(std::vector<int> types) : typesToSelect(std::move(types)) {}
+  bool isSelected(int particleIndex, shared_ptr<ParticleData> &pd) {
+    const int type_i = (int)pd->getPos(access::cpu, access::read)[particleIndex].w;
+    for (int t : typesToSelect) if (t == type_i) return true;
+    return false;
+  }
+};
+}  // namespace particle_selector
+
+class ParticleGroup {
+  shared_ptr<ParticleData> pd;
+  std::string name;
+  bool allParticlesInGroup = false;
+  std::vector<int> myParticlesIds;      // sorted by id (the reference keeps the members id-ordered)
+  std::vector<int> h_index;             // current ParticleData indices of the members
+  detail::DeviceArray<int> d_index;
+  bool needsIndexUpdate = true;
+  void updateIndices() {  // ParticleGroup_ns::updateGroupIndices, ParticleGroup.cuh:140-153: index = id2index[id]
+    if (!needsIndexUpdate || allParticlesInGroup) return;
+    const int N = pd->getNumParticles();
+    std::vector<int> id2index(N);
+    {
+      auto id = pd->getId(access::cpu, access::read);
+      for (int i = 0; i < N; ++i) id2index[id[i]] = i;
+    }
+    h_index.resize(myParticlesIds.size());
+    for (size_t k = 0; k < myParticlesIds.size(); ++k) h_index[k] = id2index[myParticlesIds[k]];
+    d_index.resize(h_index.size());
+    if (!h_index.empty()) detail::hipCheck(hipMemcpy(d_index.d, h_index.data(), sizeof(int) * h_index.size(), hipMemcpyHostToDevice), "hipMemcpy");
+    needsIndexUpdate = false;
+  }
+  void init() { pd->connectReorder([this]() { needsIndexUpdate = true; }); }
+public:
+  // index[i] of member i; the "All" group is the identity and raw() is null, which is what the C ABI takes for "all particles"
+  struct IndexIterator {
+    const int *ptr;
+    int operator[](int i) const { return ptr ? ptr[i] : i; }
+    const int *raw() const { return ptr; }
+  };
+  template <class T> struct PropertyIterator {  // property[index[i]] (host side)
+    T *base;
+    IndexIterator index;
+    T &operator[](int i) const { return base[index[i]]; }
+  };
+  ParticleGroup(shared_ptr<ParticleData> pd, std::string name = std::string("noName")) : pd(pd), name(std::move(name)), allParticlesInGroup(true) { init(); }
+  template <class ParticleSelector>
+  ParticleGroup(ParticleSelector selector, shared_ptr<ParticleData> pd, std::string name = std::string("noName")) : pd(pd), name(std::move(name)) {
+    const int N = pd->getNumParticles();
+    std::vector<int> ids;
+    {
+      auto id = pd->getId(access::cpu, access::read);
+      for (int i = 0; i < N; ++i) ids.push_back(id[i]);
+    }
+    for (int i = 0; i < N; ++i) if (selector.isSelected(i, pd)) myParticlesIds.push_back(ids[i]);
+    std::sort(myParticlesIds.begin(), myParticlesIds.end());
+    allParticlesInGroup = (int)myParticlesIds.size() == N;
+    init();
+  }
+  template <class InputIterator>
+  ParticleGroup(InputIterator begin, InputIterator end, shared_ptr<ParticleData> pd, std::string name = std::string("noName"))
+      : pd(pd), name(std::move(name)), myParticlesIds(begin, end) {
+    std::sort(myParticlesIds.begin(), myParticlesIds.end());
+    allParticlesInGroup = (int)myParticlesIds.size() == pd->getNumParticles();
+    init();
+  }
+  ParticleGroup(const ParticleGroup &) = delete;
+  int getNumberParticles() const { return allParticlesInGroup ? pd->getNumParticles() : (int)myParticlesIds.size(); }
+  shared_ptr<ParticleData> getParticleData() { return pd; }
+  std::string getName() const { return name; }
+  bool isAll() const { return allParticlesInGroup; }
+  IndexIterator getIndexIterator(access::location loc) {
+    updateIndices();
+    if (allParticlesInGroup) return IndexIterator{nullptr};
+    return IndexIterator{loc == access::gpu ? d_index.d : h_index.data()};
+  }
+  const int *getIndicesRawPtr(access::location loc) { return getIndexIterator(loc).raw(); }
+  template <class T> PropertyIterator<T> getPropertyIterator(const property_ptr<T> &prop) {
+    return PropertyIterator<T>{prop.raw(), getIndexIterator(prop.location())};
+  }
+};
+
 // ---- misc/ParameterUpdatable.h:72-80, Interactor, Integrator ------------------------------------------------------------------
 class ParameterUpdatable {
 public:
@@ -475,9 +573,12 @@ protected:
   shared_ptr<ParticleData> pd;
   shared_ptr<System> sys;
   std::string name;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
 public:
   struct Computables { bool force = false, energy = false, virial = false, stress = false; };
   Interactor(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  Interactor(shared_ptr<ParticleGroup> pg, std::string name = "noName")
+      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg->isAll() ? nullptr : pg) {}
   virtual ~Interactor() = default;
   virtual void sum(Computables comp, hipStream_t st = 0) = 0;
   std::string getName() { return name; }
@@ -490,8 +591,11 @@ protected:
   std::string name;
   std::vector<shared_ptr<Interactor>> interactors;
   std::vector<shared_ptr<ParameterUpdatable>> updatables;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
 public:
   Integrator(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  Integrator(shared_ptr<ParticleGroup> pg, std::string name = "noName")
+      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg->isAll() ? nullptr : pg) {}
   virtual ~Integrator() = default;
   virtual void forwardTime() = 0;
   virtual real sumEnergy() { return 0; }
@@ -503,6 +607,8 @@ public:
 // ---- CellList ----------------------------------------------------------------------------------------------------------------
 class CellList {
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;          // nullptr = all the particles
+  detail::DeviceArray<real4> groupPos;   // pg->getPropertyIterator(pos): the members' positions, gathered
   uammd_celllist *h = nullptr;
   bool force_next_update = true;
   real3 currentCutOff{0, 0, 0};
@@ -513,6 +619,11 @@ public:
     detail::check(uammd_celllist_create(&h));
     pd->connectPosWriteRequested([this]() { force_next_update = true; });  // CellList.cuh:94-98
   }
+  explicit CellList(shared_ptr<ParticleGroup> group) : CellList(group->getParticleData()) {
+    if (!group->isAll()) pg = group;
+    pd->connectReorder([this]() { force_next_update = true; });
+  }
+  const int *groupIndex() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
   CellList(const CellList &) = delete;
   ~CellList() { uammd_celllist_destroy(h); }
   void update(Box box, real cutOff, hipStream_t st = 0) { update(box, make_real3(cutOff), st); }
@@ -527,7 +638,14 @@ public:
     box.toArrays(L, per);
     detail::check(uammd_celllist_create_grid(L, per, rc, cd, Lo, po));
     auto pos = pd->getPos(access::gpu, access::read);
-    detail::check(uammd_celllist_update(h, (const float *)pos.raw(), pd->getNumParticles(), Lo, po, cd, (void *)st));
+    if (pg) {
+      const int n = pg->getNumberParticles();
+      groupPos.resize(n);
+      detail::check(uammd_gather(pos.raw(), pg->getIndicesRawPtr(access::gpu), groupPos.d, n, (int)sizeof(real4), (void *)st));
+      detail::check(uammd_celllist_update(h, (const float *)groupPos.d, n, Lo, po, cd, (void *)st));
+    } else {
+      detail::check(uammd_celllist_update(h, (const float *)pos.raw(), pd->getNumParticles(), Lo, po, cd, (void *)st));
+    }
     force_next_update = false;
   }
   CellListData getCellList() { CellListData d; detail::check(uammd_celllist_get(h, &d)); return d; }
@@ -620,38 +738,57 @@ template <class NL> class PairForces<Potential::LJ, NL> : public Interactor {
   shared_ptr<NL> nl;
   // NL::transverseList(Radial<LJFunctor>::Transverser): one fused entry point per neighbour-list type
   static int transverse(uammd_celllist *h, const uammd_lj_pair_parameters *t, int nt, const float *L, const int *per, float *f,
-                        float *e, float *v, void *st) {
-    return uammd_lj_transverse_celllist(h, t, nt, L, per, f, e, v, nullptr, UAMMD_LJ_ALGO_AUTO, st);
+                        float *e, float *v, const int *globalIndex, void *st) {
+    return uammd_lj_transverse_celllist(h, t, nt, L, per, f, e, v, globalIndex, UAMMD_LJ_ALGO_AUTO, st);
   }
   static int transverse(uammd_verletlist *h, const uammd_lj_pair_parameters *t, int nt, const float *L, const int *per, float *f,
-                        float *e, float *v, void *st) {
-    return uammd_lj_transverse_verletlist(h, t, nt, L, per, f, e, v, nullptr, st);
+                        float *e, float *v, const int *globalIndex, void *st) {
+    return uammd_lj_transverse_verletlist(h, t, nt, L, per, f, e, v, globalIndex, st);
+  }
+  template <class List> static shared_ptr<List> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, List *) {
+    if (pg) throw std::runtime_error("PairForces on a ParticleGroup needs the CellList neighbour list in this build");
+    return make_shared<List>(pd);
+  }
+  static shared_ptr<CellList> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, CellList *) {
+    return pg ? make_shared<CellList>(pg) : make_shared<CellList>(pd);
   }
 public:
   struct Parameters { Box box; shared_ptr<NL> nl = nullptr; };
   PairForces(shared_ptr<ParticleData> pd, Parameters par, shared_ptr<Potential::LJ> pot = make_shared<Potential::LJ>())
       : Interactor(pd, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
+  // PairForces(pg, par, pot): forces among the members of the group only (PairForces.cuh:103-107)
+  PairForces(shared_ptr<ParticleGroup> pg, Parameters par, shared_ptr<Potential::LJ> pot = make_shared<Potential::LJ>())
+      : Interactor(pg, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
   void updateBox(Box b) override { box = b; }
   void sum(Computables comp, hipStream_t st = 0) override {  // PairForces.cu:43-78
     float L[3]; int per[3];
     box.toArrays(L, per);
     const real rcut = pot->getCutOff();
-    const int N = pd->getNumParticles();
+    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
     const bool useNL = !(box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut);
     if (useNL) {
-      if (!nl) nl = make_shared<NL>(pd);
+      if (!nl) nl = makeList(pd, pg, (NL *)nullptr);
       nl->update(box, rcut, st);
     }
+    const int *globalIndex = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;
     auto force = comp.force ? pd->getForce(access::gpu, access::readwrite) : property_ptr<real4>();
     auto energy = comp.energy ? pd->getEnergy(access::gpu, access::readwrite) : property_ptr<real>();
     auto virial = comp.virial ? pd->getVirial(access::gpu, access::readwrite) : property_ptr<real>();
     if (useNL) {
       detail::check(transverse(nl->handle(), pot->deviceTable(), pot->getNumberTypes(), L, per, (float *)force.raw(),
-                               energy.raw(), virial.raw(), (void *)st));
+                               energy.raw(), virial.raw(), globalIndex, (void *)st));
     } else {
       auto pos = pd->getPos(access::gpu, access::read);
-      detail::check(uammd_lj_transverse_nbody((const float *)pos.raw(), N, pot->deviceTable(), pot->getNumberTypes(), L,
-                                              per, (float *)force.raw(), energy.raw(), virial.raw(), nullptr, (void *)st));
+      const real4 *p = pos.raw();
+      detail::DeviceArray<real4> gathered;
+      if (pg) {  // the all-pairs fallback runs on the members' positions
+        gathered.resize(N);
+        detail::check(uammd_gather(pos.raw(), globalIndex, gathered.d, N, (int)sizeof(real4), (void *)st));
+        p = gathered.d;
+      }
+      detail::check(uammd_lj_transverse_nbody((const float *)p, N, pot->deviceTable(), pot->getNumberTypes(), L,
+                                              per, (float *)force.raw(), energy.raw(), virial.raw(), globalIndex, (void *)st));
+      if (pg) detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
   }
 };
@@ -669,22 +806,26 @@ protected:
   hipStream_t stream = 0;
   virtual int kernelKind() const { return 0; }
   void callIntegrate(int step) {
-    const int N = pd->getNumParticles();
+    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    const int *index = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;  // pg->getIndexIterator(access::gpu)
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto vel = pd->getVel(access::gpu, access::readwrite);
     auto force = pd->getForce(access::gpu, access::readwrite);
     auto mass = defaultMass > 0 ? property_ptr<real>() : pd->getMassIfAllocated(access::gpu, access::read);
     auto fn = kernelKind() == 1 ? uammd_verletnvt_gj : uammd_verletnvt_basic;
-    detail::check(fn(step, (float *)pos.raw(), (float *)vel.raw(), (float *)force.raw(), mass.raw(), defaultMass, nullptr, N, dt,
+    detail::check(fn(step, (float *)pos.raw(), (float *)vel.raw(), (float *)force.raw(), mass.raw(), defaultMass, index, N, dt,
                      friction, is2D, noiseAmplitude, (uint)steps, seed, (void *)stream));
   }
-  void resetForces() {
+  void resetForces() {  // the members' forces only (Basic.cu:108-115)
     auto force = pd->getForce(access::gpu, access::write);
-    detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
+    if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), pg->getIndicesRawPtr(access::gpu), pg->getNumberParticles(), (int)sizeof(real4), (void *)stream));
+    else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
   }
 public:
   Basic(shared_ptr<ParticleData> pd, Parameters par, std::string name = "VerletNVT::Basic")
-      : Integrator(pd, name), dt(par.dt), temperature(par.temperature), friction(par.friction), is2D(par.is2D) {
+      : Basic(make_shared<ParticleGroup>(pd, "All"), par, name) {}
+  Basic(shared_ptr<ParticleGroup> group, Parameters par, std::string name = "VerletNVT::Basic")
+      : Integrator(group, name), dt(par.dt), temperature(par.temperature), friction(par.friction), is2D(par.is2D) {
     sys->rng().next32();  // Basic.cu:36-38
     sys->rng().next32();
     seed = sys->rng().next32();
@@ -693,8 +834,9 @@ public:
     if (!pd->isMassAllocated() && defaultMass < 0) defaultMass = 1.0;
     if (par.initVelocities) {
       auto vel = pd->getVel(access::gpu, access::write);
-      detail::check(uammd_verletnvt_initial_velocities((float *)vel.raw(), nullptr, (real)std::sqrt(3.0 * temperature), is2D,
-                                                       pd->getNumParticles(), sys->rng().next32(), nullptr));
+      detail::check(uammd_verletnvt_initial_velocities((float *)vel.raw(), pg ? pg->getIndicesRawPtr(access::gpu) : nullptr,
+                                                       (real)std::sqrt(3.0 * temperature), is2D,
+                                                       pg ? pg->getNumberParticles() : pd->getNumParticles(), sys->rng().next32(), nullptr));
     }
   }
   void forwardTime() override {  // Basic.cu:148-171, GronbechJensen.cu:88-115
@@ -716,6 +858,7 @@ class GronbechJensen final : public Basic {
 public:
   using Parameters = Basic::Parameters;
   GronbechJensen(shared_ptr<ParticleData> pd, Parameters par) : Basic(pd, par, "VerletNVT::GronbechJensen") {}
+  GronbechJensen(shared_ptr<ParticleGroup> pg, Parameters par) : Basic(pg, par, "VerletNVT::GronbechJensen") {}
 };
 }  // namespace VerletNVT
 

@@ -176,6 +176,8 @@ int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_li
 int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_MF, const float *d_BdW, const float K[9],
                               int numberParticles, float sqrt2Tdt, float dt, int is2D, void *stream);
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream);
+/* thrust::fill(pg->getPropertyIterator(prop), ..., T()) — zero element index[i] (elem_bytes each, a multiple of 4) for i < n */
+int uammd_fill_zero_indexed(void *d_ptr, const int *d_index, int n, int elem_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Path B — Immersed Boundary spreading / interpolation on a regular grid.  Replaces

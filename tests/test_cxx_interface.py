@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "custom_transverser"]
+PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "particle_group", "custom_transverser"]
 
 
 def _make():
@@ -38,7 +38,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
-                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []),
+                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []),
                                        ("custom_transverser", [])])
 def test_examples_run(prog, args):
     _make()

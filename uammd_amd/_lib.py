@@ -108,6 +108,7 @@ SIGNATURES = {
     "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "uammd_bdhi_euler_maruyama": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _f, _f, _i, _vp]),
     "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
+    "uammd_fill_zero_indexed": (_i, [_vp, _vp, _i, _i, _vp]),
     "uammd_fcm_gaussian_kernel": (_i, [_f, _f, C.POINTER(IBMKernel), C.POINTER(_f)]),
     "uammd_fcm_advise_grid_size": (_f, [_f, _f]),
     "uammd_ibm_barnett_magland_kernel": (_i, [_f, _f, _i, _f, C.POINTER(IBMKernel)]),

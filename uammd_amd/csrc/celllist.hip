@@ -277,6 +277,13 @@ __global__ void __launch_bounds__(kBlock) k_iota(int *__restrict__ v, int n) {
 }
 
 template <int BYTES> struct Elem { char b[BYTES]; };
+// thrust::fill over pg->getPropertyIterator(property): zero the members' elements only
+__global__ void __launch_bounds__(kBlock) k_zero_indexed(uint *__restrict__ v, const int *__restrict__ index, int n, int words) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * words) return;
+  v[(size_t)index[t / words] * words + t % words] = 0u;
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_gather(const T *__restrict__ in, const int *__restrict__ index,
                                                    T *__restrict__ out, int n) {
@@ -542,6 +549,15 @@ int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int e
 
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream) {
   UH_CHECK(hipMemsetAsync(d_ptr, 0, bytes, (hipStream_t)stream));
+  return 0;
+}
+
+int uammd_fill_zero_indexed(void *d_ptr, const int *d_index, int n, int elem_bytes, void *stream) {
+  if (n <= 0) return 0;
+  if (!d_ptr || !d_index || elem_bytes % 4 != 0 || elem_bytes <= 0) { set_last_error("uammd_fill_zero_indexed: bad arguments"); return -1; }
+  const int words = elem_bytes / 4;
+  hipLaunchKernelGGL(k_zero_indexed, dim3(nblocks(n * words)), dim3(kBlock), 0, (hipStream_t)stream, (uint *)d_ptr, d_index, n, words);
+  UH_CHECK(hipGetLastError());
   return 0;
 }
 

@@ -617,7 +617,12 @@ class _VerletNVTBasic(Integrator):
             it.updateSimulationTime(self.steps * self.dt)
         self.steps += 1
         if self.steps == 1:
-            self.pd.getForce("write").zero_()
+            if self.pg is not None and self.pg.getIndexIterator() is not None:   # resetForces on the group only (Basic.cu:108-115)
+                f = self.pd.getForce("write")
+                check(self.lib.uammd_fill_zero_indexed(_ptr(f), _ptr(self.pg.getIndexIterator()), self.pg.getNumberParticles(), 16,
+                                                       current_stream()))
+            else:
+                self.pd.getForce("write").zero_()
             for it in self.interactors:
                 it.updateTemperature(self.temperature)
                 it.updateTimeStep(self.dt)
