@@ -14,7 +14,7 @@ from util import lattice_positions
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"general": 1, "brick": 2, "quad": 3}
+ALGOS = {"general": 1, "brick": 2, "quad": 3, "staged": 5, "ring": 6, "ringh": 7}
 
 
 def _setup(hip, o32, n, L, rc, periodic=(1, 1, 1), ntypes=1, seed=1234, jitter=0.12, outside=False):
@@ -78,7 +78,7 @@ def test_lj_force_brick_sizes(hip, o32, brick_bits):
     assert _check_force(got, ref, f"brick k={brick_bits}") == 0
 
 
-@pytest.mark.parametrize("algo", ["general", "brick", "quad"])
+@pytest.mark.parametrize("algo", ["general", "brick", "quad", "staged", "ring", "ringh"])
 @pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7-partial-bricks", "noncubic"])
 def test_lj_force_parity(hip, o32, algo, L):
     rc = 2.5
@@ -97,7 +97,7 @@ def test_lj_force_parity(hip, o32, algo, L):
     assert err64 <= 1e-4
 
 
-@pytest.mark.parametrize("algo", ["general", "brick", "quad"])
+@pytest.mark.parametrize("algo", ["general", "brick", "quad", "staged", "ring", "ringh"])
 def test_lj_energy_virial_multitype(hip, o32, algo):
     n, L, rc = 12000, 25.0, 2.5
     pos, box, pot = _setup(hip, o32, n, L, rc, ntypes=3, seed=99)
@@ -198,8 +198,13 @@ def test_lj_full_size_properties(hip):
     fb, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=5)
     fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
     fq, _, _ = _run(hip, pos, box, pot, rc, ALGOS["quad"])
+    fs, _, _ = _run(hip, pos, box, pot, rc, ALGOS["staged"])
+    for a in ("ring", "ringh"):
+        fr, _, _ = _run(hip, pos, box, pot, rc, ALGOS[a])
+        assert np.array_equal(fr.view(np.uint32), fg.view(np.uint32)), a
     assert np.array_equal(fb.view(np.uint32), fg.view(np.uint32))
     assert np.array_equal(fq.view(np.uint32), fg.view(np.uint32))
+    assert np.array_equal(fs.view(np.uint32), fg.view(np.uint32))
     tot = fb[:, :3].astype(np.float64).sum(axis=0)
     assert np.abs(tot).max() <= 1e-4 * np.abs(fb[:, :3]).max() * np.sqrt(n)
     assert np.isfinite(fb).all()

@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__
                                                         const unsigned char *__restrict__ keyOutside, int3 cellDim,
                                                         uint validCell, uint *__restrict__ cellStart,
                                                         int *__restrict__ cellEnd,
-                                                        unsigned char *__restrict__ cellOutside) {
+                                                        unsigned char *__restrict__ cellOutside,
+                                                        uint2 *__restrict__ cellRange) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
   const int ncells = cellDim.x * cellDim.y * cellDim.z;
   if (c >= ncells) return;
@@ -223,6 +224,11 @@ __global__ void __launch_bounds__(kBlock) k_cell_tables(const uint *__restrict__
     cellEnd[c] = (int)e;
   }
   if (cellOutside) cellOutside[c] = keyOutside[h];
+  // the traversals' fused view of a cell: {first, last | outside << 31}, {0, 0} when empty; entry ncells = "no such cell"
+  if (cellRange) {
+    cellRange[c] = (e > s) ? make_uint2(s, e | (keyOutside[h] ? 0x80000000u : 0u)) : make_uint2(0u, 0u);
+    if (c == ncells - 1) cellRange[ncells] = make_uint2(0u, 0u);
+  }
 }
 
 // Radix path: K3 + K4 fused.  One thread per sorted slot; the previous particle's cell comes from a
@@ -313,6 +319,46 @@ int CellList::next_valid_cell(int numberParticles, bool *needsClear) {
   return 0;
 }
 
+// Half-precision copy of the sorted positions for the traversals' prefilter (lj.hip, k_lj_ringh): entry i holds particles
+// i and i + 1 as three half2 (x_i, x_i+1), (y_i, y_i+1), (z_i, z_i+1), relative to the centre of particle i's cell and in
+// units of the largest cell edge (|value| <= 0.5 for a particle of that cell).  A lane that walks a cell reads entries
+// first, first + 2, ... : two candidates per 12 bytes, both relative to the same centre; the second half of the last entry
+// of a cell may belong to the next cell and is masked by the range test.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(kBlock) k_pack_half(const float4 *__restrict__ sortPos, int N, GridT<float> grid,
+                                                      float scale, uint3 *__restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N + 8) return;
+  uint3 w = make_uint3(0u, 0u, 0u);
+  if (i < N) {
+    const float4 p0 = sortPos[i];
+    const float4 p1 = sortPos[i + 1 < N ? i + 1 : i];
+    const int3 c = grid.getCell(real3f{p0.x, p0.y, p0.z});
+    const real3f a = grid.distanceToCellCenter(real3f{p0.x, p0.y, p0.z}, c);
+    const real3f b = grid.distanceToCellCenter(real3f{p1.x, p1.y, p1.z}, c);
+    const half2_t hx = {(_Float16)(a.x * scale), (_Float16)(b.x * scale)};
+    const half2_t hy = {(_Float16)(a.y * scale), (_Float16)(b.y * scale)};
+    const half2_t hz = {(_Float16)(a.z * scale), (_Float16)(b.z * scale)};
+    w = make_uint3(__builtin_bit_cast(uint, hx), __builtin_bit_cast(uint, hy), __builtin_bit_cast(uint, hz));
+  }
+  out[i] = w;
+}
+
+int CellList::ensure_pack(hipStream_t st) {
+  const float hmax = fmaxf(grid.cellSize.x, fmaxf(grid.cellSize.y, grid.cellSize.z));
+  const float hmin = fminf(grid.cellSize.x, fminf(grid.cellSize.y, grid.cellSize.z));
+  if (!(hmin > 0.f) || !(hmax < 3.0e38f)) return 1;  // 2D / degenerate grids keep the full-precision scan
+  if (packValid) return 0;
+  const int N = numberParticlesBuilt;
+  if (int e = packHalf.reserve(sizeof(uint3) * ((size_t)N + 8))) return e;
+  packScale = 1.0f / hmax;
+  hipLaunchKernelGGL(k_pack_half, dim3(nblocks(N + 8)), dim3(kBlock), 0, st, (const float4 *)sortPos.ptr, N, grid, packScale,
+                     (uint3 *)packHalf.ptr);
+  UH_CHECK(hipGetLastError());
+  packValid = true;
+  return 0;
+}
+
 int CellList::update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3],
                      const int cellDim_[3], hipStream_t st) {
   if (numberParticles < 0 || cellDim_[0] <= 0 || cellDim_[1] <= 0 || cellDim_[2] < 0) {
@@ -342,6 +388,7 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   // +4: the traversal kernels read candidates in groups of four from one base address (reads past a cell are masked)
   if (int e = sortPos.reserve(sizeof(float4) * (size_t)(N + 8))) return e;
   numberParticlesBuilt = N;
+  packValid = false;
 
   const uint maxHash = morton_hash(make_int3(grid.cellDim.x - 1, grid.cellDim.y - 1, grid.cellDim.z - 1));
   endBit = sort_end_bit(maxHash);
@@ -385,9 +432,10 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
                        (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
                        (int *)index.ptr, (float4 *)sortPos.ptr);
     if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
+    if (int e = cellRange.reserve(sizeof(uint2) * ((size_t)ncells + 1))) return e;
     hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
                        (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
-                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr);
+                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
     haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
@@ -414,9 +462,10 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
                          (const uint *)sortHash.ptr, N, nKeys, (uint *)keyStart.ptr);
       haveKeyStart = true;
       if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
+      if (int e = cellRange.reserve(sizeof(uint2) * ((size_t)ncells + 1))) return e;
       hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
                          (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)nullptr,
-                         (int *)nullptr, (unsigned char *)cellOutside.ptr);
+                         (int *)nullptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
       haveCellOutside = true;
     } else {
       haveKeyStart = false;

@@ -23,7 +23,10 @@ struct CellList {
   // outputs (device)
   DeviceBuffer hash, sortHash, index, indexAlt, sortPos, cellStart, cellEnd, errorFlag;
   // counting-sort build state
-  DeviceBuffer keyCount, keyStart, provRank, members, scratch, keyOutside, cellOutside;
+  DeviceBuffer keyCount, keyStart, provRank, members, scratch, keyOutside, cellOutside, cellRange;
+  DeviceBuffer packHalf;  // half-precision copy of sortPos for the traversals' prefilter, built on demand (ensure_pack)
+  bool packValid = false;
+  float packScale = 0.f;
   DeviceBuffer zeroBlock;  // errorFlag | keyOutside | keyCount live here: ONE memset per build instead of three
   GridT<float> grid{};
   float boxL[3] = {0, 0, 0};
@@ -45,6 +48,7 @@ struct CellList {
   int next_valid_cell(int numberParticles, bool *needsClear);
   int update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3], const int cellDim[3],
              hipStream_t st);
+  int ensure_pack(hipStream_t st);  // 0 = packHalf is valid for the current list; 1 = this grid has no packed copy
 };
 
 extern thread_local char g_last_error[1024];

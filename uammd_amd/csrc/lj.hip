@@ -25,6 +25,7 @@
 #include "celllist.hpp"
 #include "lj_common.hpp"
 
+#include <cstdlib>
 #include <string>
 
 namespace uammd_hip {
@@ -74,24 +75,88 @@ template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
 UH_D void lj_scan(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, const float4 *__restrict__ P, int jb,
                   int je, const float4 &pi, const BoxT<float> &box, float rc2, const LJParams &p1,
                   const LJParams *tbl, int ntypes) {
+  // The FIFO state of this loop is ONE 32-bit LDS address per lane (the next free entry): an append is a masked
+  // ds_write + one add, with no per-candidate branch.
+  using LdsQT = __attribute__((address_space(3))) QT;
+  constexpr uint kStep = QSTRIDE * sizeof(QT);
+  const uint q0 = (uint)(uintptr_t)(LdsQT *)Q.slot;
+  uint qa = q0 + (uint)Q.n * kStep;
   for (int j = jb; j < je; j += 8) {
-    if (__any(Q.n > QCAP - 8)) {  // wave-uniform; the full minimum image is exact for every queued pair
+    if (__any(qa > q0 + (QCAP - 8) * kStep)) {  // wave-uniform; the full minimum image is exact for every queued pair
+      Q.n = (int)((qa - q0) / kStep);
       if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
       else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+      qa = q0;
     }
     // eight candidates from ONE address (immediate offsets); entries past the end of the cell are other particles or the
-    // padding of the array (CellList::update allocates N + 8) and are masked by j + u < je below
+    // padding of the array (CellList::update allocates N + 8) and are masked by u < rem below
     const float4 *__restrict__ pj = P + j;
     float4 c[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) c[u] = pj[u];
     float d[8];
 #pragma unroll
+#ifdef UAMMD_EXP_LOADONLY
+    for (int u = 0; u < 8; ++u) d[u] = fabsf(c[u].x) + fabsf(c[u].y) + fabsf(c[u].z) + 7.0f;
+#else
     for (int u = 0; u < 8; ++u) d[u] = lj_dist2<PBC>(box, pi, c[u]);
+#endif
+    const int rem = je - j;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (!(d[u] >= rc2) && j + u < je) { Q.slot[Q.n * QSTRIDE] = (QT)(j + u); ++Q.n; }
+    for (int u = 0; u < 8; ++u) {
+      const bool hit = !(d[u] >= rc2) & (u < rem);
+      if (hit) { *(LdsQT *)(uintptr_t)qa = (QT)(j + u); qa += kStep; }
+    }
   }
+  Q.n = (int)((qa - q0) / kStep);
+}
+
+// 16-byte LDS accesses through 32-bit LDS addresses (HIP's float4 is a class and cannot live behind an address-space pointer)
+typedef float f4v __attribute__((ext_vector_type(4)));
+using LdsV4 = __attribute__((address_space(3))) f4v;
+UH_D float4 lds_load4(uint addr) {
+  const f4v v = *(const LdsV4 *)(uintptr_t)addr;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+UH_D void lds_store4(uint addr, const float4 &v) {
+  const f4v t = {v.x, v.y, v.z, v.w};
+  *(LdsV4 *)(uintptr_t)addr = t;
+}
+
+// The same scan over candidates a wave has staged in LDS (k_lj_staged): the lane's candidates are `cnt` consecutive float4
+// starting at LDS byte address `sa`; candidate t is particle `first + t` of the sorted array (what the FIFO records and the
+// drain re-reads from global memory).  A 64-lane ds_read_b128 costs 7.4 clocks of the CU's LDS against 16.5 clocks of its
+// texture addresser for ANY global load wider than a dword, whatever the lanes' addresses (tools/vmem_ubench.hip).
+template <bool PBC, bool NT1, bool WE, bool WV, class QT, int QCAP, int QSTRIDE>
+UH_D void lj_scan_lds(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, const float4 *__restrict__ P, uint sa,
+                      int first, int cnt, const float4 &pi, const BoxT<float> &box, float rc2, const LJParams &p1,
+                      const LJParams *tbl, int ntypes) {
+  using LdsQT = __attribute__((address_space(3))) QT;
+  constexpr uint kStep = QSTRIDE * sizeof(QT);
+  const uint q0 = (uint)(uintptr_t)(LdsQT *)Q.slot;
+  uint qa = q0 + (uint)Q.n * kStep;
+  for (int j = 0; j < cnt; j += 8) {
+    if (__any(qa > q0 + (QCAP - 8) * kStep)) {
+      Q.n = (int)((qa - q0) / kStep);
+      if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+      else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+      qa = q0;
+    }
+    const uint pj = sa + (uint)j * 16u;
+    float4 c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = lds_load4(pj + 16u * u);
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = lj_dist2<PBC>(box, pi, c[u]);
+    const int rem = cnt - j;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool hit = !(d[u] >= rc2) & (u < rem);
+      if (hit) { *(LdsQT *)(uintptr_t)qa = (QT)(first + j + u); qa += kStep; }
+    }
+  }
+  Q.n = (int)((qa - q0) / kStep);
 }
 
 struct ListView {
@@ -102,6 +167,9 @@ struct ListView {
   const uint *sortHash;
   const uint *keyStart;
   const unsigned char *cellOutside;  // per linear cell: some particle stored outside the primary box (nullable)
+  const uint2 *cellRange;            // per linear cell {first, last | outside << 31}, entry ncells = {0, 0} (nullable, with cellOutside)
+  const uint3 *packHalf;  // half-precision pairs of candidates (celllist.hip k_pack_half), null when not available
+  float packScale;        // 1 / largest cell edge
   uint validCell;
   int N;
   int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
@@ -130,6 +198,45 @@ UH_D void walk_global(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, const ListView 
   const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
   const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
   bool drainPBC = false;
+  if (cl.cellRange) {
+    // One 8-byte load per neighbour cell instead of the dependent cellStart -> cellEnd -> cellOutside chain, issued one cell
+    // ahead of the scan that needs it.  A neighbour outside a non periodic box reads the {0, 0} entry past the last cell.
+    const int ncells = n.x * n.y * n.z;
+    auto fetch = [&](int cc, uint2 &rg, bool &wrapped) {
+      int3 cellj = celli;
+      if (npx > 1) cellj.x += cc % 3 - 1;
+      if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+      if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+      const int3 raw = cellj;
+      cellj.x = grid.pbc_x(cellj.x);
+      cellj.y = grid.pbc_y(cellj.y);
+      cellj.z = grid.pbc_z(cellj.z);
+      const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+      wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
+      rg = cl.cellRange[exists ? grid.getCellIndex(cellj) : ncells];
+    };
+    uint2 rg;
+    bool wrapped;
+    fetch(0, rg, wrapped);
+    for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+      uint2 rgNext = make_uint2(0u, 0u);
+      bool wrappedNext = false;
+      if (cc + 1 < numberNeighbourCells) fetch(cc + 1, rgNext, wrappedNext);
+      const int first = (int)rg.x, last = (int)(rg.y & 0x7fffffffu);
+      const bool needPBC = first < last && (smallGrid || iOut || wrapped || (rg.y >> 31) != 0u);
+      if (__any(needPBC)) {
+        drainPBC = true;
+        lj_scan<true, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
+      } else {
+        lj_scan<false, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
+      }
+      rg = rgNext;
+      wrapped = wrappedNext;
+    }
+    if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, cl.sortPos, pi, box, p1, tbl, ntypes);
+    else lj_drain<false, NT1, WE, WV>(acc, Q, cl.sortPos, pi, box, p1, tbl, ntypes);
+    return;
+  }
   for (int cc = 0; cc < numberNeighbourCells; ++cc) {
     int3 cellj = celli;
     if (npx > 1) cellj.x += cc % 3 - 1;
@@ -180,6 +287,406 @@ __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> gr
   Acc acc;
   walk_global<NT1, WE, WV>(acc, Q, cl, grid, box, tbl, ntypes, p1, rc2, pi);
   write_out(out, ori, acc);
+}
+
+// ---- ring FIFO: drain a few pairs from EVERY lane instead of everything from the fullest -------------------------------
+// With the linear FIFO above a drain empties every lane as soon as ONE lane is nearly full.  The hits arrive in bursts (a
+// lane's own cell is all hits, a corner cell none), so at that moment the typical lane holds ~6 pairs while the loop runs
+// to the fullest lane's ~20: measured at C3, a wave spends 200 pair evaluations per lane-slot for 52 useful ones and the
+// drain is 44 % of the kernel's VALU instructions.  Here the FIFO is a ring of kRingCap entries per lane and a drain takes
+// at most kRingTake pairs from each lane: lanes that fill slowly keep their pairs until they have a full batch, and the
+// number of drain iterations follows the busiest lane's TOTAL instead of the sum of the per-drain maxima.  The order in
+// which a lane evaluates its pairs is unchanged, so the results are bit-identical to the linear FIFO.
+constexpr int kRingCap = 32;   // entries per lane (power of two; at most kRingCap - 1 are ever queued)
+constexpr int kRingTake = 8;   // pairs a partial drain takes from each lane
+constexpr uint kRingStep = 128u * 4u;                 // byte stride between consecutive entries of a lane (128 lanes x uint)
+constexpr uint kRingMask = kRingCap * kRingStep - 1;  // the ring array is aligned to its size: wrap = mask
+using LdsU32 = __attribute__((address_space(3))) uint;
+
+struct RingQ {
+  uint base;  // LDS address of the ring array (multiple of its size)
+  uint head;  // LDS address of the lane's oldest entry
+  uint tail;  // LDS address of the lane's next free entry
+  UH_D uint bytes() const { return (tail - head) & kRingMask; }  // queued entries x kRingStep
+  UH_D uint wrap(uint a) const { return base | (a & kRingMask); }
+};
+
+template <bool PBC, bool NT1, bool WE, bool WV>
+UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__ P, const float4 &pi,
+                        const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
+  const int n = min((int)(Q.bytes() / kRingStep), take);
+  for (int t = 0; t < n; t += 4) {
+    int jj[4];
+    float4 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) jj[u] = (int)*(const LdsU32 *)(uintptr_t)Q.wrap(Q.head + (uint)min(t + u, n - 1) * kRingStep);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = P[jj[u]];
+    real3f r[4];
+    float f[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (NT1) lj_eval<PBC, WE>(box, p1, pi, c[u], r[u], f[u], e[u]);
+      else lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c[u].w), pi, c[u], r[u], f[u], e[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // added in FIFO order; the clamped tail repeats the last pair with weight 0
+      const bool live = t + u < n;
+      lj_acc<WE, WV>(acc, r[u], live ? f[u] : 0.0f, live ? e[u] : 0.0f);
+    }
+  }
+  Q.head = Q.wrap(Q.head + (uint)n * kRingStep);
+}
+
+template <bool PBC, bool NT1, bool WE, bool WV>
+UH_D void lj_scan_ring(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restrict__ P, int jb, int je, const float4 &pi,
+                       const BoxT<float> &box, float rc2, const LJParams &p1, const LJParams *tbl, int ntypes) {
+  for (int j = jb; j < je; j += 8) {
+    if (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {  // wave-uniform: some lane could not take 8 more
+      if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
+      else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
+    }
+    const float4 *__restrict__ pj = P + j;
+    float4 c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = pj[u];
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = lj_dist2<PBC>(box, pi, c[u]);
+    const int rem = je - j;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool hit = !(d[u] >= rc2) & (u < rem);
+      if (hit) { *(LdsU32 *)(uintptr_t)Q.tail = (uint)(j + u); Q.tail = Q.wrap(Q.tail + kRingStep); }
+    }
+  }
+}
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(128) k_lj_ring(ListView cl, GridT<float> grid, BoxT<float> box,
+                                                  const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
+  __shared__ __attribute__((aligned(kRingCap * 512))) uint ring[kRingCap * 128];
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  if (id >= cl.N) return;
+  const int gi = cl.groupIndex[id];
+  if (gi >= cl.numOwned) return;
+  const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
+  const float4 pi = cl.sortPos[id];
+  LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  RingQ Q;
+  Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
+  Q.head = Q.tail = Q.base + threadIdx.x * 4u;
+  Acc acc;
+
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int ncells = n.x * n.y * n.z;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  const bool sameBox = box.boxSize.x == grid.box.boxSize.x && box.boxSize.y == grid.box.boxSize.y &&
+                       box.boxSize.z == grid.box.boxSize.z && box.px() == grid.box.px() &&
+                       box.py() == grid.box.py() && box.pz() == grid.box.pz();
+  const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5 || !sameBox;
+  const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
+  const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
+  auto fetch = [&](int cc, uint2 &rg, bool &wrapped) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += cc % 3 - 1;
+    if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+    if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    const int3 raw = cellj;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+    wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
+    rg = cl.cellRange[exists ? grid.getCellIndex(cellj) : ncells];
+  };
+  uint2 rg;
+  bool wrapped;
+  fetch(0, rg, wrapped);
+  bool drainPBC = false;
+  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+    uint2 rgNext = make_uint2(0u, 0u);
+    bool wrappedNext = false;
+    if (cc + 1 < numberNeighbourCells) fetch(cc + 1, rgNext, wrappedNext);
+    const int first = (int)rg.x, last = (int)(rg.y & 0x7fffffffu);
+    const bool needPBC = first < last && (smallGrid || iOut || wrapped || (rg.y >> 31) != 0u);
+    if (__any(needPBC)) {
+      drainPBC = true;
+      lj_scan_ring<true, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
+    } else {
+      lj_scan_ring<false, NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, first, last, pi, box, rc2, p1, tbl, ntypes);
+    }
+    rg = rgNext;
+    wrapped = wrappedNext;
+  }
+  if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
+  else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
+  write_out(out, ori, acc);
+}
+
+// ---- half-precision prefilter: two candidates per load --------------------------------------------------------------
+// After the ring FIFO the walk is bound by the texture addresser again: a 64-lane global load of 8..16 bytes costs ~16.5
+// clocks of the CU's single addresser whatever its width and whatever the lanes' addresses (tools/vmem_ubench.hip), and the
+// scan issues one per candidate.  Here the scan reads the packed copy of the cell list (two candidates per 12-byte load,
+// half precision, relative to the candidates' cell centre) and tests |r|^2 < rc^2 + margin with three packed-half
+// instructions per candidate.  The test is a strict SUPERSET of the exact one (margin derived below), the ring entries are
+// the same particle indices in the same order, and the drain re-tests every pair in full precision: a false hit adds
+// fma(0, r, acc) == acc, so the forces stay bit-identical to k_lj_general.
+//   error budget, in units of the largest cell edge (rc <= 1, |candidate| <= 0.5, |particle relative to the neighbour
+//   centre| <= 1.5): candidate rounding 2^-13, particle rounding 2^-11, subtraction rounding 2^-11 -> |d_err| <= 1.1e-3 per
+//   component; near the threshold (r <= 1) that is 2 sqrt(3) r d_err = 3.8e-3 in r^2, plus three half-precision roundings of
+//   the squares and sums (<= 1.2e-3): 5e-3.  kHalfMargin is more than twice that.
+// The displacement uses the RAW neighbour offset (no minimum image): on a grid with >= 3 cells along every periodic
+// direction the image of j within the cut-off of i, if any, is the one in the raw-adjacent cell (cells are >= rc wide).
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+constexpr float kHalfMargin = 0.012f;
+
+template <bool NT1, bool WE, bool WV>
+UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restrict__ P, const uint3 *__restrict__ PK, int jb,
+                        int je, half2_t px, half2_t py, half2_t pz, _Float16 thr, const float4 &pi, const BoxT<float> &box,
+                        const LJParams &p1, const LJParams *tbl, int ntypes) {
+  for (int j = jb; j < je; j += 8) {
+    if (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {
+      if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
+      else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
+    }
+    const uint3 *__restrict__ pk = PK + j;
+    uint3 w[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w[m] = pk[2 * m];
+    half2_t r2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const half2_t dx = __builtin_bit_cast(half2_t, w[m].x) - px;
+      const half2_t dy = __builtin_bit_cast(half2_t, w[m].y) - py;
+      const half2_t dz = __builtin_bit_cast(half2_t, w[m].z) - pz;
+      half2_t t = dx * dx;
+      t = __builtin_elementwise_fma(dy, dy, t);
+      r2[m] = __builtin_elementwise_fma(dz, dz, t);
+    }
+    const int rem = je - j;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const _Float16 d = (u & 1) ? r2[u >> 1].y : r2[u >> 1].x;
+      const bool hit = !(d >= thr) & (u < rem);  // keeps NaN, like the exact scan
+      if (hit) { *(LdsU32 *)(uintptr_t)Q.tail = (uint)(j + u); Q.tail = Q.wrap(Q.tail + kRingStep); }
+    }
+  }
+}
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid, BoxT<float> box,
+                                                   const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
+  __shared__ __attribute__((aligned(kRingCap * 512))) uint ring[kRingCap * 128];
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  if (id >= cl.N) return;
+  const int gi = cl.groupIndex[id];
+  if (gi >= cl.numOwned) return;
+  const int ori = out.globalIndex ? out.globalIndex[gi] : gi;
+  const float4 pi = cl.sortPos[id];
+  LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  RingQ Q;
+  Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
+  Q.head = Q.tail = Q.base + threadIdx.x * 4u;
+  Acc acc;
+
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int ncells = n.x * n.y * n.z;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5;  // the launcher guarantees that box is the grid's box
+  const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
+  const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
+  // the particle relative to its own cell centre, and the threshold, in units of the largest cell edge
+  const float s = cl.packScale;
+  const real3f own = grid.distanceToCellCenter(real3f{pi.x, pi.y, pi.z}, celli);
+  const float ox = own.x * s, oy = own.y * s, oz = own.z * s;
+  const float sx = grid.cellSize.x * s, sy = grid.cellSize.y * s, sz = grid.cellSize.z * s;
+  const _Float16 thr = (_Float16)((rc2 * s * s + kHalfMargin) * 1.002f);
+  auto fetch = [&](int cc, uint2 &rg, bool &wrapped, int3 &off) {
+    int3 cellj = celli;
+    off = make_int3(0, 0, 0);
+    if (npx > 1) off.x = cc % 3 - 1;
+    if (npy > 1) off.y = (cc / npx) % 3 - 1;
+    if (npz > 1) off.z = cc / (npx * npy) - 1;
+    cellj.x += off.x; cellj.y += off.y; cellj.z += off.z;
+    const int3 raw = cellj;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+    wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
+    rg = cl.cellRange[exists ? grid.getCellIndex(cellj) : ncells];
+  };
+  uint2 rg;
+  bool wrapped;
+  int3 off;
+  fetch(0, rg, wrapped, off);
+  bool drainPBC = false;
+  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+    uint2 rgNext = make_uint2(0u, 0u);
+    bool wrappedNext = false;
+    int3 offNext = make_int3(0, 0, 0);
+    if (cc + 1 < numberNeighbourCells) fetch(cc + 1, rgNext, wrappedNext, offNext);
+    const int first = (int)rg.x, last = (int)(rg.y & 0x7fffffffu);
+    const bool needPBC = first < last && (smallGrid || iOut || wrapped || (rg.y >> 31) != 0u);
+    if (__any(needPBC)) drainPBC = true;
+    // the particle relative to the neighbour cell's centre (raw offset)
+    const _Float16 qx = (_Float16)fmaf(-(float)off.x, sx, ox), qy = (_Float16)fmaf(-(float)off.y, sy, oy),
+                   qz = (_Float16)fmaf(-(float)off.z, sz, oz);
+    lj_scan_ringh<NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, cl.packHalf, first, last, half2_t{qx, qx}, half2_t{qy, qy},
+                               half2_t{qz, qz}, thr, pi, box, p1, tbl, ntypes);
+    rg = rgNext;
+    wrapped = wrappedNext;
+    off = offNext;
+  }
+  if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
+  else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
+  write_out(out, ori, acc);
+}
+
+// ---- wave-staged walk: the candidates of a neighbour offset go through LDS ONCE per wave -------------------------------
+// k_lj_general is bound by the texture addresser, not by the VALU: every lane issues its own global load per candidate and
+// a 64-lane load of >= 8 bytes costs ~16.5 clocks of the CU's one addresser even when the lanes of a cell all read the
+// same address (0.27 ms of the 0.365 ms at C3; with the distance arithmetic removed the kernel still takes 0.29 ms).
+// Here the 64 sorted particles of a wave are runs of lanes that share a cell ("groups", ~5 per wave); for one neighbour
+// offset each group needs ONE range of the sorted array, and the wave copies the concatenation of its groups' ranges
+// (~75 particles) into LDS with at most two loads per lane (element k and k + 64 of the concatenation), issued one
+// neighbour offset ahead of the scan that reads them.  Every lane then scans ITS range from LDS (broadcast reads) in the
+// same order as k_lj_general, so the FIFO contents, the drain and the accumulated floats are bit-identical to it.
+// A neighbour offset whose ranges exceed the staging buffer (very crowded cells) takes the global-memory scan instead.
+constexpr int kStageCap = 128;  // staged candidates per wave and neighbour offset (two per lane)
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(128) k_lj_staged(ListView cl, GridT<float> grid, BoxT<float> box,
+                                                    const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
+  __shared__ uint gq[kQCapGeneral * 128];
+  __shared__ float4 stageBuf[2][kStageCap + 8];
+  const int lane = threadIdx.x & 63;
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  const bool inRange = id < cl.N;
+  const int gi = inRange ? cl.groupIndex[id] : 0;
+  const bool owned = inRange && gi < cl.numOwned;
+  if (!__any(owned)) return;  // ghost cells are whole waves at the slab faces
+  const float4 pi = inRange ? cl.sortPos[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  LJParams p1 = tbl[0];
+  const float rc2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  PairQueue<uint, kQCapGeneral, 128> Q{gq + threadIdx.x, 0};
+  Acc acc;
+
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int ncells = n.x * n.y * n.z;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  const bool sameBox = box.boxSize.x == grid.box.boxSize.x && box.boxSize.y == grid.box.boxSize.y &&
+                       box.boxSize.z == grid.box.boxSize.z && box.px() == grid.box.px() &&
+                       box.py() == grid.box.py() && box.pz() == grid.box.pz();
+  const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5 || !sameBox;
+  const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
+  const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
+
+  // groups: runs of lanes with the same cell (the array is sorted by cell); the same for all neighbour offsets
+  const int myCell = inRange ? grid.getCellIndex(celli) : -1 - lane;
+  const int prevCell = __shfl_up(myCell, 1, 64);
+  const unsigned long long leaderMask = __ballot(lane == 0 || myCell != prevCell);
+
+  auto fetch = [&](int cc, uint2 &rg, bool &wrapped) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += cc % 3 - 1;
+    if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+    if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+    const int3 raw = cellj;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    const bool exists = inRange && !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
+    wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
+    rg = cl.cellRange[exists ? grid.getCellIndex(cellj) : ncells];
+  };
+  // element k of the concatenated ranges -> index in the sorted array (src0: k = lane, src1: k = lane + 64; -1: none), and
+  // the lane's own offset into the concatenation; returns the total
+  auto plan = [&](int first, int cnt, int &src0, int &src1, int &myOff) {
+    unsigned long long m = leaderMask & __ballot(cnt > 0);
+    int sOff = 0;
+    src0 = -1; src1 = -1; myOff = 0;
+    while (m) {
+      const int L = __builtin_ctzll(m);
+      m &= m - 1;
+      const int sFirst = __builtin_amdgcn_readlane(first, L);
+      const int sCnt = __builtin_amdgcn_readlane(cnt, L);
+      const uint d0 = (uint)(lane - sOff), d1 = d0 + 64u;
+      if (d0 < (uint)sCnt) src0 = sFirst + (int)d0;
+      if (d1 < (uint)sCnt) src1 = sFirst + (int)d1;
+      if (lane >= L) myOff = sOff;
+      sOff += sCnt;
+    }
+    return sOff;
+  };
+  const uint stage0 = (uint)(uintptr_t)(__attribute__((address_space(3))) char *)(char *)&stageBuf[threadIdx.x >> 6][0];
+  const float4 *__restrict__ P = cl.sortPos;
+
+  uint2 rg, rgNext = make_uint2(0u, 0u);
+  bool wrapped, wrappedNext = false;
+  fetch(0, rg, wrapped);
+  if (numberNeighbourCells > 1) fetch(1, rgNext, wrappedNext);
+  int first = (int)rg.x, cnt = (int)(rg.y & 0x7fffffffu) - first;
+  int src0, src1, myOff;
+  int total = plan(first, cnt, src0, src1, myOff);
+  if (total <= kStageCap) {
+    if (src0 >= 0) lds_store4(stage0 + (uint)lane * 16u, P[src0]);
+    if (src1 >= 0) lds_store4(stage0 + (uint)(lane + 64) * 16u, P[src1]);
+  }
+  bool drainPBC = false;
+  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
+    // plan and load the next offset's candidates, fetch the range of the one after
+    const bool more = cc + 1 < numberNeighbourCells;
+    const int firstN = (int)rgNext.x, cntN = (int)(rgNext.y & 0x7fffffffu) - firstN;
+    const bool outsideN = (rgNext.y >> 31) != 0u, wrapN = wrappedNext;
+    int src0N = -1, src1N = -1, myOffN = 0, totalN = 0;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (more) {
+      totalN = plan(firstN, cntN, src0N, src1N, myOffN);
+      if (totalN <= kStageCap) {
+        if (src0N >= 0) v0 = P[src0N];
+        if (src1N >= 0) v1 = P[src1N];
+      }
+      rgNext = make_uint2(0u, 0u);
+      wrappedNext = false;
+      if (cc + 2 < numberNeighbourCells) fetch(cc + 2, rgNext, wrappedNext);
+    }
+    // scan the current offset
+    const int myCnt = owned ? cnt : 0;
+    const bool needPBC = myCnt > 0 && (smallGrid || iOut || wrapped || (rg.y >> 31) != 0u);
+    const bool anyPBC = __any(needPBC);
+    if (anyPBC) drainPBC = true;
+    if (total <= kStageCap) {
+      const uint sa = stage0 + (uint)myOff * 16u;
+      if (anyPBC) lj_scan_lds<true, NT1, WE, WV>(acc, Q, drainPBC, P, sa, first, myCnt, pi, box, rc2, p1, tbl, ntypes);
+      else lj_scan_lds<false, NT1, WE, WV>(acc, Q, drainPBC, P, sa, first, myCnt, pi, box, rc2, p1, tbl, ntypes);
+    } else {
+      if (anyPBC) lj_scan<true, NT1, WE, WV>(acc, Q, drainPBC, P, first, first + myCnt, pi, box, rc2, p1, tbl, ntypes);
+      else lj_scan<false, NT1, WE, WV>(acc, Q, drainPBC, P, first, first + myCnt, pi, box, rc2, p1, tbl, ntypes);
+    }
+    // the scan above has finished reading the buffer: stage the next offset
+    __builtin_amdgcn_wave_barrier();
+    if (more && totalN <= kStageCap) {
+      if (src0N >= 0) lds_store4(stage0 + (uint)lane * 16u, v0);
+      if (src1N >= 0) lds_store4(stage0 + (uint)(lane + 64) * 16u, v1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    rg.y = outsideN ? 0x80000000u : 0u;  // only the flag of rg is read below
+    wrapped = wrapN;
+    first = firstN; cnt = cntN; myOff = myOffN; total = totalN;
+  }
+  if (drainPBC) lj_drain<true, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+  else lj_drain<false, NT1, WE, WV>(acc, Q, P, pi, box, p1, tbl, ntypes);
+  if (owned) write_out(out, out.globalIndex ? out.globalIndex[gi] : gi, acc);
 }
 
 // ---- cell-per-wave kernel (tolerance-level: same pairs, different summation order) -------------------------------
@@ -743,10 +1250,14 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
   cl.sortHash = (const uint *)h->sortHash.ptr;
   cl.keyStart = (const uint *)h->keyStart.ptr;
   cl.cellOutside = h->haveCellOutside ? (const unsigned char *)h->cellOutside.ptr : nullptr;
+  cl.cellRange = h->haveCellOutside ? (const uint2 *)h->cellRange.ptr : nullptr;
+  cl.packHalf = nullptr;
+  cl.packScale = 0.f;
   cl.validCell = h->validCell;
   cl.N = h->numberParticlesBuilt;
   cl.numOwned = h->numOwned;
-  if (h->numOwned != 0x7fffffff && algo != UAMMD_LJ_ALGO_AUTO && algo != UAMMD_LJ_ALGO_GENERAL) {
+  if (h->numOwned != 0x7fffffff && algo != UAMMD_LJ_ALGO_AUTO && algo != UAMMD_LJ_ALGO_GENERAL && algo != UAMMD_LJ_ALGO_STAGED &&
+      algo != UAMMD_LJ_ALGO_RING && algo != UAMMD_LJ_ALGO_RING_HALF) {
     set_last_error("uammd_lj_transverse_celllist: the num_owned option is implemented by the general kernel only");
     return -3;
   }
@@ -788,7 +1299,47 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
     hipLaunchKernelGGL((k_lj_cellwave<NT1, WE, WV>), dim3((ncells + 3) / 4), dim3(256), 0, st, cl, g, box, tbl, ntypes, out);
     return 0;
   }
-  hipLaunchKernelGGL((k_lj_general<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+  if (algo == UAMMD_LJ_ALGO_STAGED && !cl.cellRange) {
+    set_last_error("uammd_lj_transverse_celllist: the wave-staged kernel needs the per-cell range table (a tabulated key space)");
+    return -3;
+  }
+  const bool staged = cl.cellRange && algo == UAMMD_LJ_ALGO_STAGED;
+  if (cl.cellRange && (algo == UAMMD_LJ_ALGO_AUTO || algo == UAMMD_LJ_ALGO_RING || algo == UAMMD_LJ_ALGO_RING_HALF)) {
+    // the half-precision prefilter needs the grid's own box, >= 3 cells along every periodic direction with more than one
+    // cell, and a 3D grid (ensure_pack); otherwise the full-precision ring walk
+    const bool sameBoxAny = box.boxSize.x == g.box.boxSize.x && box.boxSize.y == g.box.boxSize.y &&
+                            box.boxSize.z == g.box.boxSize.z && box.px() == g.box.px() && box.py() == g.box.py() &&
+                            box.pz() == g.box.pz();
+    const bool dimsOK = (g.cellDim.x >= 3 || !g.box.px()) && (g.cellDim.y >= 3 || !g.box.py()) && (g.cellDim.z >= 3 || !g.box.pz());
+    bool half = algo != UAMMD_LJ_ALGO_RING && sameBoxAny && dimsOK && !(algo == UAMMD_LJ_ALGO_AUTO && getenv("UAMMD_AB"));
+    if (half) {
+      const int e = h->ensure_pack(st);
+      if (e < 0) return e;
+      half = e == 0;
+    }
+    if (algo == UAMMD_LJ_ALGO_RING_HALF && !half) {
+      set_last_error("uammd_lj_transverse_celllist: the half-precision prefilter needs a 3D grid built on the potential's box "
+                     "with >= 3 cells along every periodic direction");
+      return -3;
+    }
+    cl.packHalf = half ? (const uint3 *)h->packHalf.ptr : nullptr;
+    cl.packScale = h->packScale;
+    if (half)
+      hipLaunchKernelGGL((k_lj_ringh<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+    else
+      hipLaunchKernelGGL((k_lj_ring<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+    return 0;
+  }
+  if ((algo == UAMMD_LJ_ALGO_RING || algo == UAMMD_LJ_ALGO_RING_HALF) && !cl.cellRange) {
+    set_last_error("uammd_lj_transverse_celllist: the ring kernels need the per-cell range table (a tabulated key space)");
+    return -3;
+  }
+  if (false)
+    ;
+  else if (staged)
+    hipLaunchKernelGGL((k_lj_staged<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+  else
+    hipLaunchKernelGGL((k_lj_general<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
   return 0;
 }
 
