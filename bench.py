@@ -475,7 +475,7 @@ def main():
                        "particles_per_gpu": n, "box": [L1, L1, L1 * world],
                        "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange"},
             "pair_interactions_per_s": 52.36 * value,
-            "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal, owned + ghost particles)",
+            "roofline": {"bound": "mfma", "kernel": "k_lj_ringh + k_pack_half (LJ traversal, owned + ghost particles)",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
         if args.workload == "both":
@@ -538,7 +538,7 @@ def main():
                    "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
                    "parallelism": "1 process per GPU, independent replica boxes" if world > 1 else "single GPU"},
         "pair_interactions_per_s": 52.36 * value,
-        "roofline": {"bound": "mfma", "kernel": "k_lj_general (LJ traversal)" if args.nl == "cell" else "k_lj_verlet (list traversal; the flop model is the CellList walk's, so this is an effective rate)", "achieved": achieved_tflops,
+        "roofline": {"bound": "mfma", "kernel": "k_lj_ringh + k_pack_half (LJ traversal: 27-cell walk, ring FIFO, half-precision prefilter)" if args.nl == "cell" else "k_lj_verlet (list traversal; the flop model is the CellList walk's, so this is an effective rate)", "achieved": achieved_tflops,
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
                      "traffic": traffic, "kernel_ms": k_ms,
                      "note": "f32 VALU-bound kernel; peak = f32 vector (= f32 MFMA) peak; model 1.0e4 flop/particle",

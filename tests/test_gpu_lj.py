@@ -271,3 +271,45 @@ def test_lj_cellwave_dense_cells_and_full_size(hip, o32):
     fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
     fc, _, _ = _run(hip, pos, box, pot, rc, 4)
     assert np.abs(fc - fg).max() <= 1e-5 * np.abs(fg).max()
+
+
+@pytest.mark.parametrize("case", ["nonperiodic", "cutoff-larger-than-cell", "random-gas", "four-cells", "nan-and-far"])
+def test_lj_ring_kernels_bitwise_equal_general(hip, o32, case):
+    """The ring FIFO (partial drains) and the half-precision prefilter reorder nothing and only pre-select candidates: their
+    forces, energies and virials are the general kernel's bit for bit — on non periodic boxes, when the potential's cut-off
+    exceeds the cell edge (the prefilter must then accept everything), on an uncorrelated gas with crowded cells, on the
+    smallest periodic grid the cell list produces (4 cells per direction) and with NaN / far-away coordinates."""
+    rng = np.random.default_rng(7)
+    rc_list = rc_pot = 2.5
+    periodic = (1, 1, 1)
+    L = 24.0
+    if case == "nonperiodic":
+        periodic = (1, 0, 1)
+    if case == "cutoff-larger-than-cell":
+        rc_list, rc_pot = 2.0, 2.9
+    if case == "four-cells":
+        L = 10.2  # create_update_grid collapses <= 3 cells to one, so four is the smallest periodic grid
+    n = int(0.8 * L ** 3)
+    if case == "random-gas":
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+        # keep the LJ core finite: no pair closer than 0.5 by rejection on a coarse grid is overkill here; clip the force scale instead
+        box = hip.Box(L, periodic)
+        pot = hip.Potential.LJ()
+        pot.setPotParameters(0, 0, pot.InputPairParameters(rc_pot, 0.3, 1.0, True))
+    else:
+        pos, box, pot = _setup(hip, o32, n, L, rc_pot, periodic=periodic, outside=(case != "nonperiodic"))
+    if case == "nonperiodic":
+        pos[:, 1] = np.clip(pos[:, 1], -L / 2 + 0.01, L / 2 - 0.01)
+    if case == "nan-and-far":
+        pos[5, 0] = np.nan
+        pos[77, 1] += 40 * L
+        pos[78, 2] -= 1000 * L
+    fev = (True, True, True)
+    ref = _run(hip, pos, box, pot, rc_list, ALGOS["general"], fev)
+    for a in ("ring", "ringh", "staged"):
+        got = _run(hip, pos, box, pot, rc_list, ALGOS[a], fev)
+        for g, r, what in zip(got, ref, "FEV"):
+            same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+            assert same.all(), f"{a} {case} {what}: {int((~same).sum())} words differ"
+    assert np.isfinite(ref[0]).any()

@@ -323,7 +323,7 @@ int CellList::next_valid_cell(int numberParticles, bool *needsClear) {
 // i and i + 1 as three half2 (x_i, x_i+1), (y_i, y_i+1), (z_i, z_i+1), relative to the centre of particle i's cell and in
 // units of the largest cell edge (|value| <= 0.5 for a particle of that cell).  A lane that walks a cell reads entries
 // first, first + 2, ... : two candidates per 12 bytes, both relative to the same centre; the second half of the last entry
-// of a cell may belong to the next cell and is masked by the range test.
+// of a cell is +inf when particle i + 1 belongs to another cell, so it fails every distance test.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(kBlock) k_pack_half(const float4 *__restrict__ sortPos, int N, GridT<float> grid,
                                                       float scale, uint3 *__restrict__ out) {
@@ -335,7 +335,11 @@ __global__ void __launch_bounds__(kBlock) k_pack_half(const float4 *__restrict__
     const float4 p1 = sortPos[i + 1 < N ? i + 1 : i];
     const int3 c = grid.getCell(real3f{p0.x, p0.y, p0.z});
     const real3f a = grid.distanceToCellCenter(real3f{p0.x, p0.y, p0.z}, c);
-    const real3f b = grid.distanceToCellCenter(real3f{p1.x, p1.y, p1.z}, c);
+    real3f b = grid.distanceToCellCenter(real3f{p1.x, p1.y, p1.z}, c);
+    // the second half of a cell's last entry is not a candidate of that cell: +inf fails every distance test (NaN stays NaN
+    // only for a real candidate), so the scan needs no per-candidate range test
+    const int3 c1 = grid.getCell(real3f{p1.x, p1.y, p1.z});
+    if (i + 1 >= N || c1.x != c.x || c1.y != c.y || c1.z != c.z) b = real3f{__builtin_inff(), 0.f, 0.f};
     const half2_t hx = {(_Float16)(a.x * scale), (_Float16)(b.x * scale)};
     const half2_t hy = {(_Float16)(a.y * scale), (_Float16)(b.y * scale)};
     const half2_t hz = {(_Float16)(a.z * scale), (_Float16)(b.z * scale)};

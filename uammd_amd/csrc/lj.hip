@@ -297,8 +297,14 @@ __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> gr
 // at most kRingTake pairs from each lane: lanes that fill slowly keep their pairs until they have a full batch, and the
 // number of drain iterations follows the busiest lane's TOTAL instead of the sum of the per-drain maxima.  The order in
 // which a lane evaluates its pairs is unchanged, so the results are bit-identical to the linear FIFO.
-constexpr int kRingCap = 32;   // entries per lane (power of two; at most kRingCap - 1 are ever queued)
-constexpr int kRingTake = 8;   // pairs a partial drain takes from each lane
+#ifndef RING_CAP
+#define RING_CAP 16
+#endif
+#ifndef RING_TAKE
+#define RING_TAKE 4
+#endif
+constexpr int kRingCap = RING_CAP;   // entries per lane (power of two; at most kRingCap - 1 are ever queued)
+constexpr int kRingTake = RING_TAKE;   // pairs a partial drain takes from each lane
 constexpr uint kRingStep = 128u * 4u;                 // byte stride between consecutive entries of a lane (128 lanes x uint)
 constexpr uint kRingMask = kRingCap * kRingStep - 1;  // the ring array is aligned to its size: wrap = mask
 using LdsU32 = __attribute__((address_space(3))) uint;
@@ -342,7 +348,7 @@ template <bool PBC, bool NT1, bool WE, bool WV>
 UH_D void lj_scan_ring(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restrict__ P, int jb, int je, const float4 &pi,
                        const BoxT<float> &box, float rc2, const LJParams &p1, const LJParams *tbl, int ntypes) {
   for (int j = jb; j < je; j += 8) {
-    if (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {  // wave-uniform: some lane could not take 8 more
+    while (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {  // wave-uniform: some lane could not take 8 more
       if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
       else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
     }
@@ -449,7 +455,7 @@ UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restr
                         int je, half2_t px, half2_t py, half2_t pz, _Float16 thr, const float4 &pi, const BoxT<float> &box,
                         const LJParams &p1, const LJParams *tbl, int ntypes) {
   for (int j = jb; j < je; j += 8) {
-    if (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {
+    while (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {
       if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
       else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
     }
@@ -467,11 +473,12 @@ UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restr
       t = __builtin_elementwise_fma(dy, dy, t);
       r2[m] = __builtin_elementwise_fma(dz, dz, t);
     }
+    // range test per ENTRY (pair): the odd candidate past the end of a cell is +inf in the packed copy
     const int rem = je - j;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const _Float16 d = (u & 1) ? r2[u >> 1].y : r2[u >> 1].x;
-      const bool hit = !(d >= thr) & (u < rem);  // keeps NaN, like the exact scan
+      const bool hit = !(d >= thr) & ((u & ~1) < rem);  // keeps NaN, like the exact scan
       if (hit) { *(LdsU32 *)(uintptr_t)Q.tail = (uint)(j + u); Q.tail = Q.wrap(Q.tail + kRingStep); }
     }
   }
@@ -507,7 +514,9 @@ __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid
   const real3f own = grid.distanceToCellCenter(real3f{pi.x, pi.y, pi.z}, celli);
   const float ox = own.x * s, oy = own.y * s, oz = own.z * s;
   const float sx = grid.cellSize.x * s, sy = grid.cellSize.y * s, sz = grid.cellSize.z * s;
-  const _Float16 thr = (_Float16)((rc2 * s * s + kHalfMargin) * 1.002f);
+  // a cut-off larger than a cell edge breaks the one-image argument above: accept everything, the drain decides
+  const float hmin = fminf(grid.cellSize.x, fminf(grid.cellSize.y, grid.cellSize.z));
+  const _Float16 thr = rc2 <= hmin * hmin * 1.0001f ? (_Float16)((rc2 * s * s + kHalfMargin) * 1.002f) : (_Float16)__builtin_inff();
   auto fetch = [&](int cc, uint2 &rg, bool &wrapped, int3 &off) {
     int3 cellj = celli;
     off = make_int3(0, 0, 0);
