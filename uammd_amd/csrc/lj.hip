@@ -503,12 +503,13 @@ __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid
 
   const int3 n = grid.cellDim;
   const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
-  const int numberNeighbourCells = npx * npy * npz;
+  const int numberRows = npy * npz;
   const int ncells = n.x * n.y * n.z;
   const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
   const bool smallGrid = n.x < 5 || n.y < 5 || n.z < 5;  // the launcher guarantees that box is the grid's box
   const float hx = 0.5f * box.boxSize.x, hy = 0.5f * box.boxSize.y, hz = 0.5f * box.boxSize.z;
   const bool iOut = !(pi.x >= -hx && pi.x < hx && pi.y >= -hy && pi.y < hy && pi.z >= -hz && pi.z < hz);
+  const bool alwaysPBC = smallGrid || iOut;
   // the particle relative to its own cell centre, and the threshold, in units of the largest cell edge
   const float s = cl.packScale;
   const real3f own = grid.distanceToCellCenter(real3f{pi.x, pi.y, pi.z}, celli);
@@ -517,42 +518,67 @@ __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid
   // a cut-off larger than a cell edge breaks the one-image argument above: accept everything, the drain decides
   const float hmin = fminf(grid.cellSize.x, fminf(grid.cellSize.y, grid.cellSize.z));
   const _Float16 thr = rc2 <= hmin * hmin * 1.0001f ? (_Float16)((rc2 * s * s + kHalfMargin) * 1.002f) : (_Float16)__builtin_inff();
-  auto fetch = [&](int cc, uint2 &rg, bool &wrapped, int3 &off) {
-    int3 cellj = celli;
-    off = make_int3(0, 0, 0);
-    if (npx > 1) off.x = cc % 3 - 1;
-    if (npy > 1) off.y = (cc / npx) % 3 - 1;
-    if (npz > 1) off.z = cc / (npx * npy) - 1;
-    cellj.x += off.x; cellj.y += off.y; cellj.z += off.z;
-    const int3 raw = cellj;
-    cellj.x = grid.pbc_x(cellj.x);
-    cellj.y = grid.pbc_y(cellj.y);
-    cellj.z = grid.pbc_z(cellj.z);
-    const bool exists = !(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z);
-    wrapped = raw.x != cellj.x || raw.y != cellj.y || raw.z != cellj.z;
-    rg = cl.cellRange[exists ? grid.getCellIndex(cellj) : ncells];
+
+  // The walk is the reference's (x fastest, then y, then z) as 9 rows of 3 cells.  What depends on the x offset only is
+  // computed once per particle: the wrapped x index (or "no such cell"), whether it wrapped, and the particle's packed x
+  // relative to that column.  A row adds its base index (wrapped y, z), its flags and the packed y, z.  The three ranges of a
+  // row are loaded while the previous row is scanned.
+  constexpr int kNoCell = -(1 << 30);
+  int xIdx[3];
+  bool xWrap[3];
+  half2_t qx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int raw = celli.x + (k - 1), w = grid.pbc_x(raw);
+    xIdx[k] = (w < 0 || w >= n.x) ? kNoCell : w;
+    xWrap[k] = w != raw;
+    const _Float16 q = (_Float16)fmaf(-(float)(k - 1), sx, ox);
+    qx[k] = half2_t{q, q};
+  }
+  auto row_base = [&](int row, int &base, bool &wrapped, int &offy, int &offz) {
+    offy = npy > 1 ? row % 3 - 1 : 0;
+    offz = npz > 1 ? row / npy - 1 : 0;
+    const int rawy = celli.y + offy, rawz = celli.z + offz;
+    const int wy = grid.pbc_y(rawy), wz = grid.pbc_z(rawz);
+    const bool exists = !(wy < 0 || wy >= n.y || wz < 0 || wz >= n.z);
+    base = exists ? (wz * n.y + wy) * n.x : kNoCell;
+    wrapped = wy != rawy || wz != rawz;
   };
-  uint2 rg;
-  bool wrapped;
-  int3 off;
-  fetch(0, rg, wrapped, off);
+  auto fetch_row = [&](int base, uint2 (&rg)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = base + xIdx[k];  // negative when the row or the column does not exist
+      rg[k] = (npx > 1 || k == 1) ? cl.cellRange[idx < 0 ? ncells : idx] : make_uint2(0u, 0u);
+    }
+  };
+  int base, offy, offz;
+  bool rowWrapped;
+  uint2 rg[3];
+  row_base(0, base, rowWrapped, offy, offz);
+  fetch_row(base, rg);
   bool drainPBC = false;
-  for (int cc = 0; cc < numberNeighbourCells; ++cc) {
-    uint2 rgNext = make_uint2(0u, 0u);
-    bool wrappedNext = false;
-    int3 offNext = make_int3(0, 0, 0);
-    if (cc + 1 < numberNeighbourCells) fetch(cc + 1, rgNext, wrappedNext, offNext);
-    const int first = (int)rg.x, last = (int)(rg.y & 0x7fffffffu);
-    const bool needPBC = first < last && (smallGrid || iOut || wrapped || (rg.y >> 31) != 0u);
-    if (__any(needPBC)) drainPBC = true;
-    // the particle relative to the neighbour cell's centre (raw offset)
-    const _Float16 qx = (_Float16)fmaf(-(float)off.x, sx, ox), qy = (_Float16)fmaf(-(float)off.y, sy, oy),
-                   qz = (_Float16)fmaf(-(float)off.z, sz, oz);
-    lj_scan_ringh<NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, cl.packHalf, first, last, half2_t{qx, qx}, half2_t{qy, qy},
-                               half2_t{qz, qz}, thr, pi, box, p1, tbl, ntypes);
-    rg = rgNext;
-    wrapped = wrappedNext;
-    off = offNext;
+  for (int row = 0; row < numberRows; ++row) {
+    int baseN, offyN, offzN;
+    bool rowWrappedN;
+    uint2 rgN[3];
+    row_base(row + 1 < numberRows ? row + 1 : row, baseN, rowWrappedN, offyN, offzN);
+    fetch_row(baseN, rgN);
+    const _Float16 qyh = (_Float16)fmaf(-(float)offy, sy, oy), qzh = (_Float16)fmaf(-(float)offz, sz, oz);
+    const half2_t qy = {qyh, qyh}, qz = {qzh, qzh};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (npx == 1 && k != 1) continue;
+      const int first = (int)rg[k].x, last = (int)(rg[k].y & 0x7fffffffu);
+      const bool needPBC = first < last && (alwaysPBC || rowWrapped || xWrap[k] || (rg[k].y >> 31) != 0u);
+      if (__any(needPBC)) drainPBC = true;
+      lj_scan_ringh<NT1, WE, WV>(acc, Q, drainPBC, cl.sortPos, cl.packHalf, first, last, qx[k], qy, qz, thr, pi, box, p1, tbl,
+                                 ntypes);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rg[k] = rgN[k];
+    rowWrapped = rowWrappedN;
+    offy = offyN;
+    offz = offzN;
   }
   if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
   else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingCap, cl.sortPos, pi, box, p1, tbl, ntypes);
