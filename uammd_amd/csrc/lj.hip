@@ -479,7 +479,14 @@ UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restr
     for (int u = 0; u < 8; ++u) {
       const _Float16 d = (u & 1) ? r2[u >> 1].y : r2[u >> 1].x;
       const bool hit = !(d >= thr) & ((u & ~1) < rem);  // keeps NaN, like the exact scan
-      if (hit) { *(LdsU32 *)(uintptr_t)Q.tail = (uint)(j + u); Q.tail = Q.wrap(Q.tail + kRingStep); }
+      if (hit) {
+        // store + advance + wrap in place (the compiler's version keeps the old address alive through a copy)
+        const uint val = (uint)(j + u);
+        asm volatile("ds_write_b32 %0, %1\n\tv_add_u32 %0, %2, %0\n\tv_and_or_b32 %0, %0, %3, %4"
+                     : "+v"(Q.tail)
+                     : "v"(val), "s"(kRingStep), "s"(kRingMask), "v"(Q.base)
+                     : "memory");
+      }
     }
   }
 }
