@@ -492,6 +492,8 @@ UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restr
 }
 
 template <bool NT1, bool WE, bool WV>
+// 7 waves per SIMD (<= 72 VGPRs): measured 0.321 / 0.296 / 0.281 / 0.274 / 0.280 ms at 4 / 5 / 6 (the compiler's choice) / 7 / 8
+__attribute__((amdgpu_waves_per_eu(7, 7)))
 __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid, BoxT<float> box,
                                                    const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
   __shared__ __attribute__((aligned(kRingCap * 512))) uint ring[kRingCap * 128];
