@@ -321,6 +321,7 @@ template <bool PBC, bool NT1, bool WE, bool WV>
 UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__ P, const float4 &pi,
                         const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
   const int n = min((int)(Q.bytes() / kRingStep), take);
+  const bool fastDivOK = NT1 && p1.sigma2 >= kDivLo && p1.sigma2 <= kDivHi && p1.cutOff2 <= kDivHi;  // uniform
   for (int t = 0; t < n; t += 4) {
     int jj[4];
     float4 c[4];
@@ -330,10 +331,29 @@ UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__
     for (int u = 0; u < 4; ++u) c[u] = P[jj[u]];
     real3f r[4];
     float f[4], e[4];
+    if (NT1) {
+      // one type: sigma2 / r2 without the scaling and fix-up instructions of the general division when the wave's operands
+      // allow it (div_in_range); pairs beyond the cut-off are masked whatever their quotient
+      float r2[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (NT1) lj_eval<PBC, WE>(box, p1, pi, c[u], r[u], f[u], e[u]);
-      else lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c[u].w), pi, c[u], r[u], f[u], e[u]);
+      for (int u = 0; u < 4; ++u) {
+        r[u] = real3f{c[u].x - pi.x, c[u].y - pi.y, c[u].z - pi.z};
+        if (PBC) r[u] = box.apply_pbc(r[u]);
+        r2[u] = dot3(r[u], r[u]);
+      }
+      const float r2min = fminf(fminf(r2[0], r2[1]), fminf(r2[2], r2[3]));
+      const bool plain = fastDivOK && !__any(r2min < kDivLo);
+      if (plain) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lj_eval_r2_fastdiv<WE>(p1, r2[u], f[u], e[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lj_eval<PBC, WE>(box, p1, pi, c[u], r[u], f[u], e[u]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        lj_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c[u].w), pi, c[u], r[u], f[u], e[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {  // added in FIFO order; the clamped tail repeats the last pair with weight 0

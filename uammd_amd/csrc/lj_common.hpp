@@ -51,6 +51,37 @@ UH_D void lj_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, c
     e = 0.0f;
 }
 
+// sigma2 / r2 exactly as the compiler's IEEE division computes it (v_div_scale x2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup:
+// SIISelLowering LowerFDIV32) when neither operand needs scaling and no special case applies — then v_div_scale returns its
+// operand, v_div_fmas is a plain fma and v_div_fixup returns its first operand.  Preconditions (checked by the caller): both
+// operands finite, positive and in [2^-40, 2^40].  Bit-identical to a / b there (tests compare the words over 1e6 particles).
+UH_D float div_in_range(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, r, 1.0f);
+  const float r1 = fmaf(e, r, r);
+  const float q = a * r1;
+  const float e2 = fmaf(-b, q, a);
+  const float q1 = fmaf(e2, r1, q);
+  const float e3 = fmaf(-b, q1, a);
+  return fmaf(e3, r1, q1);
+}
+constexpr float kDivLo = 9.094947017729282e-13f;  // 2^-40
+constexpr float kDivHi = 1.099511627776e12f;      // 2^40
+
+// lj_eval with the division above; r12 and r2 are computed by the caller
+template <bool WE> UH_D void lj_eval_r2_fastdiv(const LJParams &p, float r2, float &fm, float &e) {
+  const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
+  const float invr2 = div_in_range(p.sigma2, r2);
+  const float invr6 = invr2 * invr2 * invr2;
+  const float f = p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
+  fm = in ? f : 0.0f;
+  if (WE) {
+    const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
+    e = in ? 0.5f * E : 0.0f;
+  } else
+    e = 0.0f;
+}
+
 template <bool WE, bool WV>
 UH_D void lj_acc(Acc &a, const real3f &r12, float fm, float e) {
   if (WE) a.e += e;
