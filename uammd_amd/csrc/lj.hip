@@ -24,6 +24,7 @@
 //   k_lj_nbody    all pairs with LDS tiles (small boxes; PairForces.cu:49-53).
 #include "celllist.hpp"
 #include "lj_common.hpp"
+#include "ring_scan.hpp"
 
 #include <cstdlib>
 #include <string>
@@ -297,26 +298,6 @@ __global__ void __launch_bounds__(128) k_lj_general(ListView cl, GridT<float> gr
 // at most kRingTake pairs from each lane: lanes that fill slowly keep their pairs until they have a full batch, and the
 // number of drain iterations follows the busiest lane's TOTAL instead of the sum of the per-drain maxima.  The order in
 // which a lane evaluates its pairs is unchanged, so the results are bit-identical to the linear FIFO.
-#ifndef RING_CAP
-#define RING_CAP 16
-#endif
-#ifndef RING_TAKE
-#define RING_TAKE 4
-#endif
-constexpr int kRingCap = RING_CAP;   // entries per lane (power of two; at most kRingCap - 1 are ever queued)
-constexpr int kRingTake = RING_TAKE;   // pairs a partial drain takes from each lane
-constexpr uint kRingStep = 128u * 4u;                 // byte stride between consecutive entries of a lane (128 lanes x uint)
-constexpr uint kRingMask = kRingCap * kRingStep - 1;  // the ring array is aligned to its size: wrap = mask
-using LdsU32 = __attribute__((address_space(3))) uint;
-
-struct RingQ {
-  uint base;  // LDS address of the ring array (multiple of its size)
-  uint head;  // LDS address of the lane's oldest entry
-  uint tail;  // LDS address of the lane's next free entry
-  UH_D uint bytes() const { return (tail - head) & kRingMask; }  // queued entries x kRingStep
-  UH_D uint wrap(uint a) const { return base | (a & kRingMask); }
-};
-
 template <bool PBC, bool NT1, bool WE, bool WV>
 UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__ P, const float4 &pi,
                         const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
@@ -467,48 +448,16 @@ __global__ void __launch_bounds__(128) k_lj_ring(ListView cl, GridT<float> grid,
 //   the squares and sums (<= 1.2e-3): 5e-3.  kHalfMargin is more than twice that.
 // The displacement uses the RAW neighbour offset (no minimum image): on a grid with >= 3 cells along every periodic
 // direction the image of j within the cut-off of i, if any, is the one in the raw-adjacent cell (cells are >= rc wide).
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-constexpr float kHalfMargin = 0.012f;
-
 template <bool NT1, bool WE, bool WV>
 UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restrict__ P, const uint3 *__restrict__ PK, int jb,
                         int je, half2_t px, half2_t py, half2_t pz, _Float16 thr, const float4 &pi, const BoxT<float> &box,
                         const LJParams &p1, const LJParams *tbl, int ntypes) {
-  for (int j = jb; j < je; j += 8) {
-    while (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {
+  half_scan(Q, PK, jb, je, px, py, pz, thr, [&]() {
+    while (__any(Q.bytes() > (kRingCap - 9) * kRingStep)) {  // wave-uniform: some lane could not take 8 more
       if (drainPBC) lj_drain_ring<true, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
       else lj_drain_ring<false, NT1, WE, WV>(acc, Q, kRingTake, P, pi, box, p1, tbl, ntypes);
     }
-    const uint3 *__restrict__ pk = PK + j;
-    uint3 w[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) w[m] = pk[2 * m];
-    half2_t r2[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const half2_t dx = __builtin_bit_cast(half2_t, w[m].x) - px;
-      const half2_t dy = __builtin_bit_cast(half2_t, w[m].y) - py;
-      const half2_t dz = __builtin_bit_cast(half2_t, w[m].z) - pz;
-      half2_t t = dx * dx;
-      t = __builtin_elementwise_fma(dy, dy, t);
-      r2[m] = __builtin_elementwise_fma(dz, dz, t);
-    }
-    // range test per ENTRY (pair): the odd candidate past the end of a cell is +inf in the packed copy
-    const int rem = je - j;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const _Float16 d = (u & 1) ? r2[u >> 1].y : r2[u >> 1].x;
-      const bool hit = !(d >= thr) & ((u & ~1) < rem);  // keeps NaN, like the exact scan
-      if (hit) {
-        // store + advance + wrap in place (the compiler's version keeps the old address alive through a copy)
-        const uint val = (uint)(j + u);
-        asm volatile("ds_write_b32 %0, %1\n\tv_add_u32 %0, %2, %0\n\tv_and_or_b32 %0, %0, %3, %4"
-                     : "+v"(Q.tail)
-                     : "v"(val), "s"(kRingStep), "s"(kRingMask), "v"(Q.base)
-                     : "memory");
-      }
-    }
-  }
+  });
 }
 
 template <bool NT1, bool WE, bool WV>
