@@ -71,36 +71,76 @@ def lj_setup(hip, n, L, seed, T=1.0, dt=0.005, nl="cell"):
     return pd, box, pot, verlet, pf, pos
 
 
+class EventRing:
+    """HIP event pairs around one launch per step, on the launch's stream.  A fixed ring of pairs is reused (a pair is read
+    back RING steps after it was recorded, waiting for it if the host has run that far ahead): creating two events per step made the runtime stall
+    for ~25 ms once a few hundred were alive."""
+    RING = 64
+
+    def __init__(self):
+        self.ring, self.pos, self.live = [], 0, 0
+        self.total_ms, self.count = 0.0, 0
+
+    def _collect(self, pair):
+        pair[1].synchronize()  # the host may run more than RING steps ahead of the device
+        self.total_ms += pair[0].elapsed_time(pair[1])
+        self.count += 1
+
+    def start(self):
+        if len(self.ring) < self.RING:
+            self.ring.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        else:
+            self._collect(self.ring[self.pos])
+            self.live -= 1
+        self.cur = self.ring[self.pos]
+        self.pos = (self.pos + 1) % self.RING
+        self.cur[0].record()
+
+    def stop(self):
+        self.cur[1].record()
+        self.live += 1
+
+    def clear(self):
+        self.live, self.total_ms, self.count = 0, 0.0, 0
+
+    def mean_ms(self):
+        """Call after a device synchronize: also collects the pairs still in the ring."""
+        for i in range(self.live):
+            self._collect(self.ring[(self.pos - 1 - i) % len(self.ring)])
+        self.live = 0
+        return self.total_ms / self.count if self.count else float("nan")
+
+
 class TimedPairForces:
-    """Wraps PairForces.sum with a HIP event pair around the traversal launch (same stream)."""
+    """Wraps PairForces.sum with an event pair around the traversal launch (same stream)."""
+
+    SAMPLE = 8
 
     def __init__(self, pf):
         self.pf = pf
-        self.events = []
+        self.ev = EventRing()
         self.enabled = False
-        self._orig = pf.nl.transverse_lj if pf.nl is not None else None
+        self.calls = 0
 
     def install(self):
         nl = self.pf.nl
         orig = nl.transverse_lj
 
         def timed(*a, **k):
-            if not self.enabled:
+            self.calls += 1
+            # every SAMPLE-th launch of the timed region is bracketed: an event pair around EVERY launch cost the run
+            # 0.03-0.05 ms per step plus a ~25 ms stall of the runtime after a few hundred recorded events (measured)
+            if not self.enabled or self.calls % self.SAMPLE or os.environ.get("UAMMD_BENCH_NOTIMER") == "1":
                 return orig(*a, **k)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+            self.ev.start()
             r = orig(*a, **k)
-            e1.record()
-            self.events.append((e0, e1))
+            self.ev.stop()
             return r
 
         nl.transverse_lj = timed
 
     def mean_ms(self):
-        if not self.events:
-            return float("nan")
-        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+        return self.ev.mean_ms()
 
 
 def cpu_baseline_lj(n, L, seed, sample_steps):
@@ -329,7 +369,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
     pot = hip.Potential.LJ()
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
     cl = hip.CellList()
-    trav_events = []
+    trav_events = EventRing()
+    calls = [0]
 
     def forces_fn(allpos, box_L, periodic):
         box = hip.Box(box_L, periodic)
@@ -337,11 +378,13 @@ def run_lj_distributed(hip, args, world, rank, dist):
         cl.update_grid(allpos.contiguous(), ubox, cd)
         cl.set_option("num_owned", sim.n_owned)
         f = torch.zeros((allpos.shape[0], 4), dtype=torch.float32, device=allpos.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        calls[0] += 1
+        sampled = calls[0] % TimedPairForces.SAMPLE == 0   # see TimedPairForces: an event pair per launch distorts the run
+        if sampled:
+            trav_events.start()
         cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, args.algo)
-        e1.record()
-        trav_events.append((e0, e1))
+        if sampled:
+            trav_events.stop()
         return f
 
     def integrate_fn(step, p, v, f, step_num):
@@ -396,7 +439,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
     assert torch.isfinite(pos).all()
     assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
     sim.check_skin()
-    k_ms = sum(a.elapsed_time(b) for a, b in trav_events) / max(1, len(trav_events))
+    k_ms = trav_events.mean_ms()
     return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
 
 
@@ -415,6 +458,7 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
     ap.add_argument("--brick-bits", type=int, default=None)
     ap.add_argument("--algo", type=int, default=0)
+    ap.add_argument("--sort-every", type=int, default=500, help="ParticleData::sortParticles period of the LJ run (benchmark.cu: 500)")
     ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
                     help="neighbour list of PairForces: CellList (BASELINE configs[2], default) or VerletList (the "
                          "reference's examples/misc/benchmark.cu default)")
@@ -495,8 +539,8 @@ def main():
 
     def run(k, timed):
         for j in range(k):
-            if timed and j % 500 == 0:
-                pd.sortParticles()  # examples/misc/benchmark.cu:154-156
+            if timed and j % args.sort_every == 0:
+                pd.sortParticles()  # examples/misc/benchmark.cu:154-156 (every 500 steps there)
             verlet.forwardTime()
 
     run(args.warmup, False)

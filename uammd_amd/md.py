@@ -167,7 +167,9 @@ class ParticleData:
         cd = [int(np.float32(l) / np.float32(c)) for l, c in zip(box.boxSize, rc)]
         if cd[2] == 0:
             cd[2] = 1
-        cl = CellList()
+        cl = getattr(self, "_sorter", None)   # kept: a fresh cell list per call costs ~10 ms of hipMalloc / hipFree
+        if cl is None:
+            cl = self._sorter = CellList()
         cl.update_grid(pos, box, cd)
         idx = cl.group_index()
         for name, t in list(self._props.items()):
