@@ -304,10 +304,12 @@ UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__
   const int n = min((int)(Q.bytes() / kRingStep), take);
   const bool fastDivOK = NT1 && p1.sigma2 >= kDivLo && p1.sigma2 <= kDivHi && p1.cutOff2 <= kDivHi;  // uniform
   for (int t = 0; t < n; t += 4) {
-    int jj[4];
+    // slots past the lane's n-th entry read whatever the ring holds there — a neighbour queued earlier or the lane's own
+    // particle (the kernels initialise the ring with it): a valid address and no foreign NaN — and are masked below (weight 0)
+    uint jj[4];
     float4 c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) jj[u] = (int)*(const LdsU32 *)(uintptr_t)Q.wrap(Q.head + (uint)min(t + u, n - 1) * kRingStep);
+    for (int u = 0; u < 4; ++u) jj[u] = *(const LdsU32 *)(uintptr_t)Q.wrap(Q.head + (uint)(t + u) * kRingStep);
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = P[jj[u]];
     real3f r[4];
@@ -384,6 +386,8 @@ __global__ void __launch_bounds__(128) k_lj_ring(ListView cl, GridT<float> grid,
   RingQ Q;
   Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
   Q.head = Q.tail = Q.base + threadIdx.x * 4u;
+#pragma unroll
+  for (int t = 0; t < kRingCap; ++t) ring[t * 128 + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
   Acc acc;
 
   const int3 n = grid.cellDim;
@@ -477,6 +481,8 @@ __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid
   RingQ Q;
   Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
   Q.head = Q.tail = Q.base + threadIdx.x * 4u;
+#pragma unroll
+  for (int t = 0; t < kRingCap; ++t) ring[t * 128 + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
   Acc acc;
 
   const int3 n = grid.cellDim;
