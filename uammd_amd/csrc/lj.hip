@@ -26,7 +26,6 @@
 #include "lj_common.hpp"
 #include "ring_scan.hpp"
 
-#include <cstdlib>
 #include <string>
 
 namespace uammd_hip {
@@ -1330,7 +1329,7 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
                             box.boxSize.z == g.box.boxSize.z && box.px() == g.box.px() && box.py() == g.box.py() &&
                             box.pz() == g.box.pz();
     const bool dimsOK = (g.cellDim.x >= 3 || !g.box.px()) && (g.cellDim.y >= 3 || !g.box.py()) && (g.cellDim.z >= 3 || !g.box.pz());
-    bool half = algo != UAMMD_LJ_ALGO_RING && sameBoxAny && dimsOK && !(algo == UAMMD_LJ_ALGO_AUTO && getenv("UAMMD_AB"));
+    bool half = algo != UAMMD_LJ_ALGO_RING && sameBoxAny && dimsOK;
     if (half) {
       const int e = h->ensure_pack(st);
       if (e < 0) return e;
