@@ -529,8 +529,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    # Multi-GPU: the LJ path shards by spatial domain; this round each rank integrates an independent
-    # replica box of the same size (weak scaling, no data-path collective) — see DESIGN.md §multi-GPU.
+    # Single GPU from here on (world > 1 took the z-slab domain decomposition above — DESIGN.md §7).
     pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank, nl=args.nl)
     pf.algo = args.algo
     verlet.forwardTime()  # creates the neighbour list
@@ -580,7 +579,7 @@ def main():
                                 f"VerletList (1.08 rc, {getattr(pf.nl, 'rebuilds', 0)} rebuilds in {args.warmup + args.steps + 1} steps), ") +
                                "VerletNVT::GronbechJensen T=1 dt=0.005 (BASELINE configs[2])",
                    "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
-                   "parallelism": "1 process per GPU, independent replica boxes" if world > 1 else "single GPU"},
+                   "parallelism": "single GPU"},
         "pair_interactions_per_s": 52.36 * value,
         "roofline": {"bound": "mfma", "kernel": "k_lj_ringh + k_pack_half (LJ traversal: 27-cell walk, ring FIFO, half-precision prefilter)" if args.nl == "cell" else "k_lj_verlet (list traversal; the flop model is the CellList walk's, so this is an effective rate)", "achieved": achieved_tflops,
                      "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
