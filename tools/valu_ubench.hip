@@ -63,6 +63,20 @@ template <int OP> __global__ void __launch_bounds__(256) k(float *out, float a, 
                    "v_cmp_lt_f32 s[20:21], %4, %8\n v_cmp_lt_f32 s[22:23], %5, %8\n v_cmp_lt_f32 s[24:25], %6, %8\n v_cmp_lt_f32 s[26:27], %7, %8\n"
                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a)
                    : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    } else if (OP == 13) {  // v_pk_fma_f16 / v_pk_add_f16 / v_pk_mul_f16 (the half-precision prefilter's arithmetic)
+      asm volatile("v_pk_fma_f16 %0, %0, %4, %4\n v_pk_add_f16 %1, %1, %4\n v_pk_mul_f16 %2, %2, %4\n v_pk_fma_f16 %3, %3, %4, %4\n"
+                   "v_pk_fma_f16 %0, %0, %4, %4\n v_pk_add_f16 %1, %1, %4\n v_pk_mul_f16 %2, %2, %4\n v_pk_fma_f16 %3, %3, %4, %4\n"
+                   : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(ia));
+    } else if (OP == 14) {  // v_cmp_nge_f16 to an SGPR pair, low and high half (SDWA)
+      asm volatile("v_cmp_nge_f16 s[20:21], %0, %4\n v_cmp_nge_f16_sdwa s[22:23], %1, %4 src0_sel:WORD_1 src1_sel:DWORD\n"
+                   "v_cmp_nge_f16 s[24:25], %2, %4\n v_cmp_nge_f16_sdwa s[26:27], %3, %4 src0_sel:WORD_1 src1_sel:DWORD\n"
+                   "v_cmp_nge_f16 s[20:21], %0, %4\n v_cmp_nge_f16_sdwa s[22:23], %1, %4 src0_sel:WORD_1 src1_sel:DWORD\n"
+                   "v_cmp_nge_f16 s[24:25], %2, %4\n v_cmp_nge_f16_sdwa s[26:27], %3, %4 src0_sel:WORD_1 src1_sel:DWORD\n"
+                   : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(ia) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    } else if (OP == 15) {  // v_and_or_b32 / v_add_u32 (the ring append)
+      asm volatile("v_and_or_b32 %0, %0, %4, %4\n v_add_u32 %1, %1, %4\n v_and_or_b32 %2, %2, %4, %4\n v_add_u32 %3, %3, %4\n"
+                   "v_and_or_b32 %0, %0, %4, %4\n v_add_u32 %1, %1, %4\n v_and_or_b32 %2, %2, %4, %4\n v_add_u32 %3, %3, %4\n"
+                   : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(ia));
     } else if (OP == 12) {  // v_lshl_add_u32 / v_min_i32
       asm volatile("v_lshl_add_u32 %0, %0, 4, %4\n v_min_i32 %1, %1, %4\n v_lshl_add_u32 %2, %2, 4, %4\n v_min_i32 %3, %3, %4\n"
                    "v_lshl_add_u32 %0, %0, 4, %4\n v_min_i32 %1, %1, %4\n v_lshl_add_u32 %2, %2, 4, %4\n v_min_i32 %3, %3, %4\n"
@@ -89,13 +103,13 @@ template <int OP> double run(float *d, int wavesPerSimd) {
 
 int main() {
   float *d; hipMalloc(&d, 256 * 256 * 16 * 4);
-  const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_u32", "v_rcp_f32", "v_cmp+v_cndmask(avg)", "v_div_scale/fmas/fixup(avg)", "v_sub_f32", "v_pk_add/mul_f32", "v_floor_f32", "v_mov_b32", "v_cmp->sgpr", "v_lshl_add/v_min_i32"};
+  const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_f32", "v_add_u32", "v_rcp_f32", "v_cmp+v_cndmask(avg)", "v_div_scale/fmas/fixup(avg)", "v_sub_f32", "v_pk_add/mul_f32", "v_floor_f32", "v_mov_b32", "v_cmp->sgpr", "v_lshl_add/v_min_i32", "v_pk_fma/add/mul_f16", "v_cmp_f16 lo / hi(sdwa)", "v_and_or_b32/v_add_u32"};
   for (int w : {1, 4}) {
     printf("waves/SIMD=%d  (ns per wave64 instruction per SIMD; x clock GHz = cycles)\n", w);
-    double t[13];
+    double t[16];
     t[0] = run<0>(d, w); t[1] = run<1>(d, w); t[2] = run<2>(d, w); t[3] = run<3>(d, w); t[4] = run<4>(d, w); t[5] = run<5>(d, w);
-    t[6] = run<6>(d, w); t[7] = run<7>(d, w); t[8] = run<8>(d, w); t[9] = run<9>(d, w); t[10] = run<10>(d, w); t[11] = run<11>(d, w); t[12] = run<12>(d, w);
-    for (int i = 0; i < 13; ++i) printf("  %-28s %.3f ns  (~%.2f cyc @2.4GHz)\n", names[i], t[i], t[i] * 2.4);
+    t[6] = run<6>(d, w); t[7] = run<7>(d, w); t[8] = run<8>(d, w); t[9] = run<9>(d, w); t[10] = run<10>(d, w); t[11] = run<11>(d, w); t[12] = run<12>(d, w); t[13] = run<13>(d, w); t[14] = run<14>(d, w); t[15] = run<15>(d, w);
+    for (int i = 0; i < 16; ++i) printf("  %-28s %.3f ns  (~%.2f cyc @2.4GHz)\n", names[i], t[i], t[i] * 2.4);
   }
   return 0;
 }
