@@ -371,10 +371,10 @@ UH_D void lj_scan_ring(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restri
 }
 
 template <bool NT1, bool WE, bool WV>
-__global__ void __launch_bounds__(128) k_lj_ring(ListView cl, GridT<float> grid, BoxT<float> box,
+__global__ void __launch_bounds__(kRingLanes) k_lj_ring(ListView cl, GridT<float> grid, BoxT<float> box,
                                                   const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
-  __shared__ __attribute__((aligned(kRingCap * 512))) uint ring[kRingCap * 128];
-  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  __shared__ __attribute__((aligned(kRingCap * kRingLanes * 4))) uint ring[kRingCap * kRingLanes];
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kRingLanes + threadIdx.x;
   if (id >= cl.N) return;
   const int gi = cl.groupIndex[id];
   if (gi >= cl.numOwned) return;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(128) k_lj_ring(ListView cl, GridT<float> grid,
   Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
   Q.head = Q.tail = Q.base + threadIdx.x * 4u;
 #pragma unroll
-  for (int t = 0; t < kRingCap; ++t) ring[t * 128 + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
+  for (int t = 0; t < kRingCap; ++t) ring[t * kRingLanes + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
   Acc acc;
 
   const int3 n = grid.cellDim;
@@ -466,10 +466,10 @@ UH_D void lj_scan_ringh(Acc &acc, RingQ &Q, bool drainPBC, const float4 *__restr
 template <bool NT1, bool WE, bool WV>
 // 7 waves per SIMD (<= 72 VGPRs): measured 0.321 / 0.296 / 0.281 / 0.274 / 0.280 ms at 4 / 5 / 6 (the compiler's choice) / 7 / 8
 __attribute__((amdgpu_waves_per_eu(7, 7)))
-__global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid, BoxT<float> box,
+__global__ void __launch_bounds__(kRingLanes) k_lj_ringh(ListView cl, GridT<float> grid, BoxT<float> box,
                                                    const LJParams *__restrict__ tbl, int ntypes, Outputs out) {
-  __shared__ __attribute__((aligned(kRingCap * 512))) uint ring[kRingCap * 128];
-  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 128 + threadIdx.x;
+  __shared__ __attribute__((aligned(kRingCap * kRingLanes * 4))) uint ring[kRingCap * kRingLanes];
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kRingLanes + threadIdx.x;
   if (id >= cl.N) return;
   const int gi = cl.groupIndex[id];
   if (gi >= cl.numOwned) return;
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(128) k_lj_ringh(ListView cl, GridT<float> grid
   Q.base = (uint)(uintptr_t)(LdsU32 *)ring;
   Q.head = Q.tail = Q.base + threadIdx.x * 4u;
 #pragma unroll
-  for (int t = 0; t < kRingCap; ++t) ring[t * 128 + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
+  for (int t = 0; t < kRingCap; ++t) ring[t * kRingLanes + threadIdx.x] = (uint)id;  // every entry is a valid index from the start: the particle itself
   Acc acc;
 
   const int3 n = grid.cellDim;
@@ -1343,9 +1343,9 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
     cl.packHalf = half ? (const uint3 *)h->packHalf.ptr : nullptr;
     cl.packScale = h->packScale;
     if (half)
-      hipLaunchKernelGGL((k_lj_ringh<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+      hipLaunchKernelGGL((k_lj_ringh<NT1, WE, WV>), dim3((cl.N + kRingLanes - 1) / kRingLanes), dim3(kRingLanes), 0, st, cl, g, box, tbl, ntypes, out);
     else
-      hipLaunchKernelGGL((k_lj_ring<NT1, WE, WV>), dim3((cl.N + 127) / 128), dim3(128), 0, st, cl, g, box, tbl, ntypes, out);
+      hipLaunchKernelGGL((k_lj_ring<NT1, WE, WV>), dim3((cl.N + kRingLanes - 1) / kRingLanes), dim3(kRingLanes), 0, st, cl, g, box, tbl, ntypes, out);
     return 0;
   }
   if ((algo == UAMMD_LJ_ALGO_RING || algo == UAMMD_LJ_ALGO_RING_HALF) && !cl.cellRange) {

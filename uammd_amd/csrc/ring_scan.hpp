@@ -13,7 +13,11 @@ namespace uammd_hip {
 #endif
 constexpr int kRingCap = RING_CAP;   // entries per lane (power of two; at most kRingCap - 1 are ever queued)
 constexpr int kRingTake = RING_TAKE;   // pairs a partial drain takes from each lane
-constexpr uint kRingStep = 128u * 4u;                 // byte stride between consecutive entries of a lane (128 lanes x uint)
+#ifndef RING_LANES
+#define RING_LANES 128
+#endif
+constexpr int kRingLanes = RING_LANES;                // threads per workgroup of the ring kernels
+constexpr uint kRingStep = kRingLanes * 4u;           // byte stride between consecutive entries of a lane (lanes x uint)
 constexpr uint kRingMask = kRingCap * kRingStep - 1;  // the ring array is aligned to its size: wrap = mask
 using LdsU32 = __attribute__((address_space(3))) uint;
 
