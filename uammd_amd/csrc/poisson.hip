@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
                                                         float *__restrict__ energy, float4 *__restrict__ fieldPotential, int N,
                                                         GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx,
                                                         FastDiv dsxy) {
+  kern.kind = kKernelGaussian;  // Poisson's only window; a constant kind folds phi_axis' switch (else every window is evaluated)
   const int lane = threadIdx.x & 63;
   const int sid = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (sid >= N) return;
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
 __global__ void __launch_bounds__(256) k_poisson_spread(const float4 *__restrict__ packed, float *__restrict__ gridQ, int N,
                                                         GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx,
                                                         FastDiv dsxy) {
+  kern.kind = kKernelGaussian;  // Poisson's only window; a constant kind folds phi_axis' switch (else every window is evaluated)
   const int lane = threadIdx.x & 63;
   const int sid = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (sid >= N) return;
@@ -363,6 +365,7 @@ template <int S>
 __global__ void __launch_bounds__(256) k_poisson_spread_tile(const float4 *__restrict__ tilePos, const int *__restrict__ start,
                                                              float *__restrict__ gridQ, GridT<float> grid, int nxStride,
                                                              IBMKernelDev kern, TileGeom tg) {
+  kern.kind = kKernelGaussian;  // see k_poisson_gather
   extern __shared__ float acc[];  // one private copy of the halo-extended tile per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int s = S ? S : kern.support.x;  // cubic support (Poisson_ns::Gaussian has one)

@@ -148,10 +148,12 @@ __global__ void __launch_bounds__(256) k_q2d_kspace(float2 *__restrict__ gx, flo
 
 // IBM::spread / gather on the two planes, one wave per particle (misc/IBM.cu:83-147, :164-235; 2D branch of IBM.cuh:182-194).
 // SPREAD: value = force.xy of the particle, or the constant (cx, cy) when force == nullptr (thermal drift).
-template <bool SPREAD>
+// KIND (the window) is a template parameter: with a run-time kind the compiler evaluates EVERY window of phi_axis per weight.
+template <bool SPREAD, int KIND>
 __global__ void __launch_bounds__(256) k_q2d_ibm(const float4 *__restrict__ pos, const float4 *__restrict__ force, float cx, float cy,
                                                  float *__restrict__ g0, size_t plane, float2 *__restrict__ vel, int N, GridT<float> grid,
                                                  int nxStride, IBMKernelDev kern, FastDiv dsx) {
+  kern.kind = KIND;
   const int lane = threadIdx.x & 63;
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= N) return;
@@ -318,13 +320,13 @@ int uammd_bdhi2d_velocities(uammd_bdhi2d *h, const float *d_pos, const float *d_
   if (deterministic) {
     UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 2 * q->planeReal, st));
     if (drift) {  // spreadThermalDrift, .cu:234-257
-      hipLaunchKernelGGL((k_q2d_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, -T, 0.0f, g, q->planeReal,
+      hipLaunchKernelGGL((k_q2d_ibm<true, kKernelGauss2DDriftX>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, -T, 0.0f, g, q->planeReal,
                          (float2 *)nullptr, N, q->grid, q->nxpad, q->kernDriftX, dsx);
-      hipLaunchKernelGGL((k_q2d_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, 0.0f, -T, g, q->planeReal,
+      hipLaunchKernelGGL((k_q2d_ibm<true, kKernelGauss2DDriftY>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, 0.0f, -T, g, q->planeReal,
                          (float2 *)nullptr, N, q->grid, q->nxpad, q->kernDriftY, dsx);
     }
     if (d_force)  // spreadParticleForces, .cu:268-283
-      hipLaunchKernelGGL((k_q2d_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, 0.0f, 0.0f, g, q->planeReal,
+      hipLaunchKernelGGL((k_q2d_ibm<true, kKernelGauss2D>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force, 0.0f, 0.0f, g, q->planeReal,
                          (float2 *)nullptr, N, q->grid, q->nxpad, q->kern, dsx);
     UH_ROCFFT(rocfft_execute(q->fwd, bufs, nullptr, q->info));
   }
@@ -342,7 +344,7 @@ int uammd_bdhi2d_velocities(uammd_bdhi2d *h, const float *d_pos, const float *d_
                      q->par.boxSize[0], q->par.boxSize[1], q->par.kernel, q->par.hydrodynamicRadius, q->par.viscosity, deterministic,
                      noisePrefactor, q->par.seed, q->counter);
   UH_ROCFFT(rocfft_execute(q->inv, bufs, nullptr, q->info));
-  hipLaunchKernelGGL((k_q2d_ibm<false>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, 0.0f, 0.0f, g, q->planeReal,
+  hipLaunchKernelGGL((k_q2d_ibm<false, kKernelGauss2D>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)nullptr, 0.0f, 0.0f, g, q->planeReal,
                      (float2 *)d_vel, N, q->grid, q->nxpad, q->kern, dsx);
   UH_CHECK(hipGetLastError());
   return 0;
