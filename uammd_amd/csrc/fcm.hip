@@ -169,27 +169,31 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
 }
 
 __global__ void __launch_bounds__(1024) k_fcm_tile_scan(const int *__restrict__ count, int ntiles, int *__restrict__ start) {
-  __shared__ int sh[1024];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < ntiles ? count[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < ntiles) start[i] = carry + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += sh[1023];
-    __syncthreads();
+  // exclusive scan of the tile populations by one workgroup: each thread owns a run of consecutive tiles (serial), the runs'
+  // totals are scanned with wave shuffles + one 16-entry LDS pass (the Hillis-Steele loop this replaces needed 20 barriers
+  // per 1024 tiles: 8.3 us for the 4096 tiles of C4)
+  __shared__ int waveTotal[16];
+  const int per = (ntiles + 1023) / 1024;
+  const int lo = min((int)threadIdx.x * per, ntiles), hi = min(lo + per, ntiles);
+  int mine = 0;
+  for (int i = lo; i < hi; ++i) mine += count[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
-  if (threadIdx.x == 0) start[ntiles] = carry;
+  if (lane == 63) waveTotal[wave] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += waveTotal[w];
+  int run = before + incl - mine;
+  for (int i = lo; i < hi; ++i) {
+    start[i] = run;
+    run += count[i];
+  }
+  if (threadIdx.x == 1023) start[ntiles] = before + incl;
 }
 
 // Stencil origin + the 3*support 1-D weights of every particle, written at the particle's tile-sorted slot.
