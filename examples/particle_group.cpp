@@ -5,14 +5,17 @@
 #include "Interactor/PairForces.cuh"
 #include "Integrator/VerletNVT.cuh"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 using namespace uammd;
 
 int main(int argc, char *argv[]) {
   auto sys = std::make_shared<System>(argc, argv);
-  const int N = 20000;
-  const real L = 32;
+  // optional arguments: N L.  "600 7" puts the box below 3 rc in every direction, so PairForces takes its all-pairs branch
+  // (PairForces.cu:49-53) on the group — the branch that must read pos[globalIndex[.]] from the UN-gathered array.
+  const int N = argc > 1 ? std::atoi(argv[1]) : 20000;
+  const real L = argc > 2 ? std::atof(argv[2]) : 32;
   auto pd = std::make_shared<ParticleData>(N, sys);
   std::vector<real4> members;
   {

@@ -782,17 +782,11 @@ public:
       detail::check(transverse(nl->handle(), pot->deviceTable(), pot->getNumberTypes(), L, per, (float *)force.raw(),
                                energy.raw(), virial.raw(), globalIndex, (void *)st));
     } else {
+      // all pairs among the members: the kernel reads pos[globalIndex[t]] and writes force[globalIndex[t]]
+      // (NBody over pg->getPropertyIterator(pos), PairForces.cu:49-53), so the UN-gathered array goes in.
       auto pos = pd->getPos(access::gpu, access::read);
-      const real4 *p = pos.raw();
-      detail::DeviceArray<real4> gathered;
-      if (pg) {  // the all-pairs fallback runs on the members' positions
-        gathered.resize(N);
-        detail::check(uammd_gather(pos.raw(), globalIndex, gathered.d, N, (int)sizeof(real4), (void *)st));
-        p = gathered.d;
-      }
-      detail::check(uammd_lj_transverse_nbody((const float *)p, N, pot->deviceTable(), pot->getNumberTypes(), L,
+      detail::check(uammd_lj_transverse_nbody((const float *)pos.raw(), N, pot->deviceTable(), pot->getNumberTypes(), L,
                                               per, (float *)force.raw(), energy.raw(), virial.raw(), globalIndex, (void *)st));
-      if (pg) detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
   }
 };
@@ -855,6 +849,15 @@ public:
     callIntegrate(1);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
     callIntegrate(2);
+  }
+  real sumEnergy() override {  // sumKineticEnergy, Basic.cu:186-207: energy[i] += m v^2 / 2, returns 0
+    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    auto vel = pd->getVel(access::gpu, access::read);
+    auto energy = pd->getEnergy(access::gpu, access::readwrite);
+    auto mass = defaultMass > 0 ? property_ptr<real>() : pd->getMassIfAllocated(access::gpu, access::read);
+    detail::check(uammd_sum_kinetic_energy((const float *)vel.raw(), energy.raw(), mass.raw(), defaultMass,
+                                           pg ? pg->getIndicesRawPtr(access::gpu) : nullptr, N, (void *)stream));
+    return 0;
   }
 };
 class GronbechJensen final : public Basic {

@@ -69,6 +69,13 @@ int uammd_celllist_create_grid(const float L[3], const int periodic[3], const fl
 int uammd_celllist_update(uammd_celllist *h, const float *d_pos, int numberParticles, const float L[3],
                           const int periodic[3], const int cellDim[3], void *stream);
 int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out);
+/* NaN positions or particles outside a non-periodic box: the reference raises a device flag (CellListBase.cuh:82-85) and, in
+ * UAMMD_DEBUG builds only, synchronises and throws overflow_error("CellList encountered NaN positions") inside every update
+ * (:258-264); its release builds carry on silently.  Here the build kernels raise a flag in host-mapped memory and the NEXT
+ * uammd_celllist_update / _get on the handle fails with that message (no per-step synchronisation).
+ * uammd_celllist_check_errors synchronises `stream` and reports at once; option "strict_errors" = 1 makes every update do so
+ * (the reference's debug behaviour); option "report_errors" = 0 gives the reference's release behaviour. */
+int uammd_celllist_check_errors(uammd_celllist *h, void *stream);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
  * particles with input index >= n as ghosts of a domain decomposition: they are neighbours of the others but the LJ
  * traversal computes nothing for them (n < 0 turns it off) */
@@ -169,6 +176,9 @@ int uammd_verletnvt_basic(int step, float *d_pos, float *d_vel, float *d_force, 
                           int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);
 int uammd_verletnvt_initial_velocities(float *d_vel, const int *d_index, float velAmplitude, int is2D,
                                        int numberParticles, unsigned int seed, void *stream);
+/* VerletNVT::Basic::sumKineticEnergy (VerletNVT/Basic.cu:173-207): energy[i] += 0.5 m |v|^2 (Integrator::sumEnergy) */
+int uammd_sum_kinetic_energy(const float *d_vel, float *d_energy, const float *d_mass, float defaultMass,
+                             const int *d_index, int numberParticles, void *stream);
 int uammd_bd_euler_maruyama(float *d_pos, const int *d_index, const float *d_force, const float K[9],
                             float selfMobility, const float *d_radius, float dt, int is2D, float temperature,
                             int numberParticles, unsigned int stepNum, unsigned int seed, void *stream);

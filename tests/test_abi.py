@@ -61,3 +61,17 @@ def test_product_does_not_import_oracle():
         p = os.path.join(ROOT, "include", f)
         if os.path.isfile(p):
             assert "oracle" not in open(p).read().lower()
+
+
+def test_xorshift_seed_wraps_like_uint64():
+    """Xorshift128plus::setSeed (utils/utils.h:110-113): s[1] = (s0 + K) % RANDOM_MAX in uint64 arithmetic — the sum wraps at
+    2^64 BEFORE the modulo.  The default System seed overflows, so the Python mirror must wrap too."""
+    import numpy as np
+    from uammd_amd.md import Xorshift128plus
+    K = 15438657923749336752
+    for s0 in (0xf31337Bada55D00d, 1234, 2**64 - 1, 2**64 - K, 2**64 - K - 1):
+        r = Xorshift128plus()
+        r.set_seed(s0)
+        with np.errstate(over="ignore"):
+            want = int((np.uint64(s0) + np.uint64(K)) % np.uint64(0xFFFFFFFFFFFFFFFF))
+        assert r.s == [s0, want], hex(s0)

@@ -38,7 +38,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
-                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []),
+                                       ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []), ("particle_group", ["600", "7"]),
                                        ("custom_transverser", [])])
 def test_examples_run(prog, args):
     _make()

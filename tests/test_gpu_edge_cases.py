@@ -56,16 +56,53 @@ def test_faces_far_images_and_one_crowded_cell(hip, o32):
     assert np.abs(got[fin] - ref[fin]).max() <= 1e-5 * scale
 
 
-def test_non_finite_position_is_contained(hip):
+def test_non_finite_position_is_contained_and_reported(hip):
     """A NaN position poisons the pairs it takes part in (as in the reference, whose cut-off test keeps NaN pairs) and nothing else
-    crashes: the build succeeds, far-away particles keep finite forces."""
+    crashes: far-away particles keep finite forces.  The reference raises a device flag for such a particle and throws in
+    UAMMD_DEBUG builds (CellListBase.cuh:82-85,258-264); here the flag lives in host-mapped memory: the next call on the list
+    fails (lazy, no per-step sync), at once with strict_errors, never with report_errors = 0 (the reference's release build)."""
+    from uammd_amd._lib import UammdHipError
     L = 30.0
     rng = np.random.default_rng(6)
     pos = np.zeros((2000, 4), np.float32)
     pos[:, :3] = rng.uniform(-L / 2, L / 2, (2000, 3))
     pos[7, 0] = np.nan
-    f = _forces(hip, pos, L)
-    assert np.isfinite(f).all(axis=1).sum() >= 1900
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+    cd, ubox = hip.CellList.create_update_grid(box, 2.5)
+    dp = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cl.set_option("report_errors", 0)
+    cl.update_grid(dp, ubox, cd)
+    f = torch.zeros((2000, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(pot.device_table(), 1, box, f)
+    torch.cuda.synchronize()
+    cl.update_grid(dp, ubox, cd)                       # silent, like a release build of the reference
+    assert np.isfinite(f.cpu().numpy()).all(axis=1).sum() >= 1900
+    cl = hip.CellList()
+    cl.update_grid(dp, ubox, cd)                       # lazy: this call returns before the flag can be seen
+    torch.cuda.synchronize()
+    with pytest.raises(UammdHipError, match="NaN positions"):
+        cl.update_grid(dp, ubox, cd)
+    good = dp.clone()
+    good[7, 0] = 0.0
+    cl.update_grid(good, ubox, cd)                     # the flag was consumed; a clean build passes
+    torch.cuda.synchronize()
+    cl.update_grid(good, ubox, cd)
+    cl = hip.CellList()
+    cl.set_option("strict_errors", 1)
+    with pytest.raises(UammdHipError, match="NaN positions"):
+        cl.update_grid(dp, ubox, cd)
+    # a particle outside a NON-periodic box has no cell either
+    pbox = hip.Box(L, (True, True, False))
+    cd2, ubox2 = hip.CellList.create_update_grid(pbox, 2.5)
+    out = good.clone()
+    out[3, 2] = L
+    cl = hip.CellList()
+    cl.set_option("strict_errors", 1)
+    with pytest.raises(UammdHipError, match="non-periodic"):
+        cl.update_grid(out, ubox2, cd2)
 
 
 def test_fcm_and_ibm_with_no_particles(hip):

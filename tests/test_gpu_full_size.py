@@ -1,0 +1,116 @@
+"""GPU parity AT BASELINE.json's FULL SIZES against the oracle (not property tests).
+
+C2 (1e5 LJ, L = 50 -> 20^3 cells), C3 (1e6 LJ, L = 107.7217345 -> 43^3 cells): sort order, Morton keys, sorted
+positions and cell tables word-for-word; forces |dF| <= 1e-5 max|F| per particle for every traversal the
+library selects or offers.  C4 (FCM 1e5 particles, 128^3) and C5 (FCM 2e5 particles, 256^3): velocities <= 1e-5 relative
+L2, deterministic and with the Fourier-space noise (same Saru keys -> same field).  The oracle needs ~1 s per LJ
+configuration and ~0.3 / ~3 s per FCM solve.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import canon_cell_tables, lattice_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _lj_config(hip, n, L):
+    pos = lattice_positions(n, L, seed=1234, jitter=0.1)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+    return pos, box, pot
+
+
+@pytest.mark.parametrize("n,L,cells", [(100_000, 50.0, 20), (1_000_000, 107.7217345, 43)], ids=["C2", "C3"])
+def test_lj_full_size_vs_oracle(hip, o32, n, L, cells):
+    rc = 2.5
+    pos, box, pot = _lj_config(hip, n, L)
+    cd, ubox = hip.CellList.create_update_grid(box, rc)
+    assert list(cd) == [cells] * 3
+    ocd, oL, oper = o32.celllist_create_grid(box.boxSize, [1, 1, 1], rc)
+    ref_cl = o32.celllist_build(pos, oL, oper, ocd)
+    ref_f, ref_e, ref_v = o32.lj_transverse_celllist(ref_cl, box.boxSize, [1, 1, 1], pot.table, 1, n, True, True, True)
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cl.update_grid(d_pos, ubox, cd)
+    got = cl.to_host()
+    assert np.array_equal(got["hash"], ref_cl["hash"])
+    assert np.array_equal(got["index"], ref_cl["index"])
+    assert np.array_equal(got["sortPos"].view(np.uint32), ref_cl["sortPos"].view(np.uint32))
+    gs, ge = canon_cell_tables(got)
+    rs, re = canon_cell_tables(ref_cl)
+    assert np.array_equal(gs, rs) and np.array_equal(ge, re)
+    fmax = np.abs(ref_f[:, :3]).max(axis=1) + 1e-30
+    from test_gpu_lj import ALGOS
+    for name, algo in [("auto", 0)] + sorted(ALGOS.items()):
+        f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        e = torch.zeros(n, dtype=torch.float32, device="cuda")
+        v = torch.zeros(n, dtype=torch.float32, device="cuda")
+        cl.transverse_lj(pot.device_table(), 1, box, f, e, v, None, algo)
+        torch.cuda.synchronize()
+        gf = f.cpu().numpy()
+        err = (np.abs(gf[:, :3] - ref_f[:, :3]).max(axis=1) / fmax).max()
+        nbits = int((gf[:, :3].view(np.uint32) != ref_f[:, :3].view(np.uint32)).sum())
+        eerr = np.abs(e.cpu().numpy() - ref_e).max() / np.abs(ref_e).max()
+        verr = np.abs(v.cpu().numpy() - ref_v).max() / np.abs(ref_v).max()
+        print(f"[{n} particles, {name}] force err {err:.2e} ({nbits} words differ), energy {eerr:.2e}, virial {verr:.2e}")
+        assert err <= 1e-5 and eerr <= 1e-5 and verr <= 1e-5, name
+        assert np.all(gf[:, 3] == 0)
+
+
+def _fcm_config(n, L, seed=1234):
+    rng = np.random.default_rng(seed)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = np.random.default_rng(4321).normal(0, 1, (n, 3))
+    return pos, force
+
+
+@pytest.mark.parametrize("n,ncell", [(100_000, 128), (200_000, 256)], ids=["C4", "C5"])
+def test_fcm_full_size_vs_oracle(hip, o32, n, ncell):
+    from oracle.fcm import FCMOracle
+    L, cells = float(ncell), [ncell] * 3
+    pos, force = _fcm_config(n, L)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    assert k.support[0] == 6 and abs(a_eff - 1.46674) < 1e-4
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 1.0, 1234, a_eff)
+    ofcm = FCMOracle(o32, L, cells, tolerance=1e-3, viscosity=1.0, seed=1234)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    vref = ofcm.displacements(pos, force)
+    err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+    print(f"[FCM {ncell}^3, {n} particles] T=0 rel L2 err vs oracle {err:.2e}")
+    assert err <= 1e-5
+    T, dt = 1.0, 0.01
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n, T, 1 / math.sqrt(dt)).cpu().numpy()
+    vref = ofcm.displacements(pos, force, temperature=T, prefactor=1 / math.sqrt(dt))
+    err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+    print(f"[FCM {ncell}^3, {n} particles] T=1 rel L2 err vs oracle {err:.2e}")
+    assert err <= 2e-5
+
+
+def test_fcm_c5_eight_slabs_equal_single_gpu(hip):
+    """C5 decomposed as BASELINE.json names it (256^3 grid, 8 z-slabs of 32 planes, all-to-all transposes) with all 8
+    ranks run in this process on one MI355X (exchanges = tensor copies) against the single-GPU solver."""
+    from test_gpu_fcm_slab import _assemble, _scatter, _slab_solver
+    n, ncell, P = 200_000, 256, 8
+    L, cells = float(ncell), [ncell] * 3
+    pos, force = _fcm_config(n, L)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 1.0, 1234, a_eff)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    geom, slabs, decs = _slab_solver(hip, cells, [L] * 3, P, k, 1.0, 1234)
+    pl, fl, idx = _scatter(decs, dp, df)
+    assert sum(p.shape[0] for p in pl) == n
+    for T in (0.0, 1.0):                     # seed2 advances in lock step on both solvers
+        pf = 1 / math.sqrt(0.01) if T > 0 else 0.0
+        vref = fcm.computeHydrodynamicDisplacements(dp, df, n, T, pf)
+        v = _assemble(slabs.displacements(pl, fl, T, pf), idx, n)
+        err = ((v - vref).norm() / vref.norm()).item()
+        print(f"[FCM C5, 8 slabs in process, T={T}] rel L2 err vs single GPU {err:.2e}")
+        assert err <= 1e-5

@@ -87,6 +87,7 @@ SIGNATURES = {
     "uammd_celllist_create_grid": (_i, [_f3, _i3, _f3, _i3, _f3, _i3]),
     "uammd_celllist_update": (_i, [_vp, _vp, _i, _f3, _i3, _i3, _vp]),
     "uammd_celllist_get": (_i, [_vp, C.POINTER(CellListData)]),
+    "uammd_celllist_check_errors": (_i, [_vp, _vp]),
     "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_sort_pairs": (_i, [_vp, _vp, _i, _i, _vp]),
     "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "uammd_verletnvt_gj": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_basic": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_initial_velocities": (_i, [_vp, _vp, _f, _i, _i, _u, _vp]),
+    "uammd_sum_kinetic_energy": (_i, [_vp, _vp, _vp, _f, _vp, _i, _vp]),
     "uammd_bd_euler_maruyama": (_i, [_vp, _vp, _vp, C.POINTER(_f), _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
     "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "uammd_bdhi_euler_maruyama": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _f, _f, _i, _vp]),

@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
   int3 c = grid.getCell(real3f{p.x, p.y, p.z});
   // A particle outside a non periodic box (or a NaN) has no cell: flag it (the reference raises the
   // same flag in fillCellList, CellListBase.cuh:82-85) and clamp so that no table is overrun.
-  if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z) {
+  if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z ||
+      !(p.x == p.x && p.y == p.y && p.z == p.z)) {  // (int)NaN is a valid-looking cell 0: test it by name
     errorFlag[0] = 1;
     c.x = min(max(c.x, 0), grid.cellDim.x - 1);
     c.y = min(max(c.y, 0), grid.cellDim.y - 1);
@@ -133,7 +134,8 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
     if (i < N) {
       const float4 p = pos[i];
       int3 c = grid.getCell(real3f{p.x, p.y, p.z});
-      if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z) {
+      if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z ||
+      !(p.x == p.x && p.y == p.y && p.z == p.z)) {  // (int)NaN is a valid-looking cell 0: test it by name
         errorFlag[0] = 1;
         c.x = min(max(c.x, 0), grid.cellDim.x - 1);
         c.y = min(max(c.y, 0), grid.cellDim.y - 1);
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(kBlock) k_reorder_fill(const float4 *__restric
       icell2 = 0;
   }
   const uint ncells = (uint)grid.getNumberCells();
+  if (!(p.x == p.x && p.y == p.y && p.z == p.z)) errorFlag[0] = 1;
   if (icell >= ncells || icell2 >= ncells) {
     errorFlag[0] = 1;
     return;
@@ -363,6 +366,21 @@ int CellList::ensure_pack(hipStream_t st) {
   return 0;
 }
 
+CellList::~CellList() {
+  if (hostErr) (void)hipHostFree(hostErr);
+}
+
+int CellList::check_errors(hipStream_t st, bool sync) {
+  if (!hostErr || !reportErrors) return 0;
+  if (sync) UH_CHECK(hipStreamSynchronize(st));
+  if (__atomic_load_n(hostErr, __ATOMIC_ACQUIRE)) {
+    __atomic_store_n(hostErr, 0, __ATOMIC_RELEASE);
+    set_last_error("CellList encountered NaN positions or particles outside a non-periodic box");  // CellListBase.cuh:262
+    return -4;
+  }
+  return 0;
+}
+
 int CellList::update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3],
                      const int cellDim_[3], hipStream_t st) {
   if (numberParticles < 0 || cellDim_[0] <= 0 || cellDim_[1] <= 0 || cellDim_[2] < 0) {
@@ -370,6 +388,12 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
                    cellDim_[0], cellDim_[1], cellDim_[2]);
     return -2;
   }
+  if (!hostErr) {
+    UH_CHECK(hipHostMalloc((void **)&hostErr, 64, hipHostMallocMapped));
+    hostErr[0] = 0;
+    UH_CHECK(hipHostGetDevicePointer((void **)&devErr, hostErr, 0));
+  }
+  if (int e = check_errors(st, false)) return e;  // raised by an earlier build
   const BoxT<float> box = make_box<float>(L, periodic);
   grid = make_grid<float>(box, make_int3(cellDim_[0], cellDim_[1], cellDim_[2]));
   for (int k = 0; k < 3; ++k) { boxL[k] = L[k]; boxPeriodic[k] = periodic[k] != 0; }
@@ -418,11 +442,11 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
     if (aggregateHash)
       hipLaunchKernelGGL(k_hash_agg, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st, d_pos,
-                         N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr,
+                         N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
                          (unsigned char *)keyOutside.ptr);
     else
       hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
-                         (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, (int *)errorFlag.ptr,
+                         (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
                          (unsigned char *)keyOutside.ptr);
     size_t tmpBytes = 0;
     UH_CHECK(rocprim::exclusive_scan(nullptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
@@ -444,7 +468,7 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
     hipLaunchKernelGGL(k_hash<false>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
-                       (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, (int *)errorFlag.ptr,
+                       (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, devErr,
                        tabulated ? (unsigned char *)keyOutside.ptr : (unsigned char *)nullptr);
     if (endBit > 0) {
       size_t tmpBytes = 0;
@@ -459,7 +483,7 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     }
     hipLaunchKernelGGL(k_reorder_fill, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const int *)index.ptr, N, grid,
                        validCell, (float4 *)sortPos.ptr, (uint *)cellStart.ptr, (int *)cellEnd.ptr,
-                       (int *)errorFlag.ptr);
+                       devErr);
     if (tabulated) {
       if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
       hipLaunchKernelGGL(k_key_start_from_sorted, dim3(nblocks(N + 1)), dim3(kBlock), 0, st,
@@ -478,6 +502,7 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   }
   if (counting) haveKeyStart = true;
   UH_CHECK(hipGetLastError());
+  if (strictErrors) return check_errors(st, true);
   return 0;
 }
 
@@ -540,6 +565,8 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
   CellList *cl = reinterpret_cast<CellList *>(h);
   if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
   if (std::string(name) == "aggregate_hash") { cl->aggregateHash = value != 0; return 0; }
+  if (std::string(name) == "strict_errors") { cl->strictErrors = value != 0; return 0; }
+  if (std::string(name) == "report_errors") { cl->reportErrors = value != 0; return 0; }
   if (std::string(name) == "num_owned") { cl->numOwned = value < 0 ? 0x7fffffff : value; return 0; }
   set_last_error("uammd_celllist_set_option: unknown option %s", name);
   return -1;
@@ -548,6 +575,7 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
 int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out) {
   if (!h || !out) { set_last_error("uammd_celllist_get: null argument"); return -1; }
   CellList *cl = reinterpret_cast<CellList *>(h);
+  if (int e = cl->check_errors(nullptr, false)) return e;
   out->d_cellStart = (const unsigned int *)cl->cellStart.ptr;
   out->d_cellEnd = (const int *)cl->cellEnd.ptr;
   out->d_sortPos = (const float *)cl->sortPos.ptr;
@@ -558,6 +586,11 @@ int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out) {
   out->VALID_CELL = cl->validCell;
   out->numberParticles = cl->numberParticlesBuilt;
   return 0;
+}
+
+int uammd_celllist_check_errors(uammd_celllist *h, void *stream) {
+  if (!h) { set_last_error("uammd_celllist_check_errors: null handle"); return -1; }
+  return reinterpret_cast<CellList *>(h)->check_errors((hipStream_t)stream, true);
 }
 
 int uammd_sort_pairs(unsigned int *d_keys, int *d_values, int n, int end_bit, void *stream) {

@@ -43,6 +43,14 @@ struct CellList {
   bool usedCounting = false;
   bool forceRadix = false;  // test hook: always take the rocPRIM radix path
   bool aggregateHash = true;  // k_hash_agg (LDS-aggregated histogram) instead of one global atomic per particle
+  // NaN positions / particles outside a non-periodic box (CellListBase.cuh:82-85 raises a flag; :258-264 synchronises and throws
+  // in UAMMD_DEBUG builds only, release builds carry on with those particles missing from the tables).
+  // The kernels raise the flag in HOST-mapped memory (written only in the error case, so it costs nothing per step); the host
+  // looks at it at the start of the next update / get / traversal and fails that call, or at once with strictErrors (sync).
+  int *hostErr = nullptr, *devErr = nullptr;
+  bool strictErrors = false, reportErrors = true;
+  int check_errors(hipStream_t st, bool sync);
+  ~CellList();
   int numOwned = 0x7fffffff;  // traversal option: particles with input index >= numOwned are ghosts (neighbours only, no output)
 
   int next_valid_cell(int numberParticles, bool *needsClear);

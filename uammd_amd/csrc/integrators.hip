@@ -118,6 +118,19 @@ __global__ void __launch_bounds__(kIB) k_initial_velocities(float *__restrict__ 
   vel[3 * idx] = (float)nx; vel[3 * idx + 1] = (float)ny; vel[3 * idx + 2] = (float)nz;
 }
 
+// VerletNVT::Basic::sumKineticEnergy (VerletNVT/Basic.cu:173-207): energy[i] += 0.5 |v|^2 m
+__global__ void __launch_bounds__(kIB) k_sum_kinetic_energy(const float *__restrict__ vel, float *__restrict__ energy,
+                                                            const float *__restrict__ mass, float defaultMass,
+                                                            const int *__restrict__ index, int N) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  const float vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+  const float m = (defaultMass > 0.f || !mass) ? defaultMass : mass[i];
+  const float v2 = __fmaf_rn(vz, vz, __fmaf_rn(vy, vy, vx * vx));
+  energy[i] += 0.5f * v2 * m;
+}
+
 struct Shear { float3 Kx, Ky, Kz; };
 
 __global__ void __launch_bounds__(kIB) k_bd_euler_maruyama(float4 *__restrict__ pos, const int *__restrict__ index,
@@ -270,6 +283,15 @@ int uammd_verletnvt_initial_velocities(float *d_vel, const int *d_index, float v
   if (N <= 0) return 0;
   hipLaunchKernelGGL(k_initial_velocities, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, d_vel, d_index,
                      velAmplitude, is2D, N, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_sum_kinetic_energy(const float *d_vel, float *d_energy, const float *d_mass, float defaultMass,
+                             const int *d_index, int N, void *stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_sum_kinetic_energy, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, d_vel, d_energy, d_mass,
+                     defaultMass, d_index, N);
   UH_CHECK(hipGetLastError());
   return 0;
 }

@@ -39,7 +39,7 @@ class Xorshift128plus:
 
     def set_seed(self, s0):
         m = 0xFFFFFFFFFFFFFFFF
-        self.s = [s0 & m, ((s0 + 15438657923749336752) & ((1 << 65) - 1)) % m]
+        self.s = [s0 & m, ((s0 + 15438657923749336752) & m) % m]      # uint64 wrap first (utils/utils.h:110-113)
 
     def next(self):
         m = 0xFFFFFFFFFFFFFFFF
@@ -568,6 +568,9 @@ class Integrator:
     def forwardTime(self):
         raise NotImplementedError
 
+    def sumEnergy(self):                      # Integrator.cuh:81
+        return 0.0
+
 
 class _VerletNVTBasic(Integrator):
     kind = "basic"
@@ -634,6 +637,15 @@ class _VerletNVTBasic(Integrator):
         for it in self.interactors:
             it.sum(force=True)
         self._integrate(2)
+
+    def sumEnergy(self):
+        """sumKineticEnergy (VerletNVT/Basic.cu:186-207): energy[i] += m |v|^2 / 2; returns 0 like the reference."""
+        pd = self.pd
+        idx = self.pg.getIndexIterator() if self.pg is not None else None
+        n = self.pg.getNumberParticles() if self.pg is not None else pd.N
+        check(self.lib.uammd_sum_kinetic_energy(_ptr(pd.getVel("read")), _ptr(pd.getEnergy("readwrite")), _ptr(self._mass()),
+                                                self.defaultMass, _ptr(idx), n, current_stream()))
+        return 0.0
 
 
 class _VerletNVTGJ(_VerletNVTBasic):
