@@ -102,7 +102,14 @@ typedef struct { float cutOff2, sigma2, epsilonDivSigma2, shift; } uammd_lj_pair
 int uammd_lj_process_pair_parameters(float cutOff, float sigma, float epsilon, int shift, uammd_lj_pair_parameters *out);
 
 /* flags for `algo` */
-#define UAMMD_LJ_ALGO_AUTO 0    /* the kernel measured fastest for the grid (RING_HALF where the grid allows it, else RING, else GENERAL) */
+#define UAMMD_LJ_ALGO_AUTO 0    /* the kernel measured fastest for the grid: TILE where the grid allows it (forces to rounding level, the
+                                   north star's stated tolerance), else EXACT */
+#define UAMMD_LJ_ALGO_TILE 8    /* wave per pair of x-adjacent cells, 32 x 32 distance tiles on the matrix pipe (f32 MFMA), hits re-evaluated
+                                   with the reference's arithmetic: same pairs, sums in another order (rounding-level differences) */
+#define UAMMD_LJ_ALGO_TILE1 10  /* TILE with one wave per pair of cells and a private 4 x 3 x 3-cell halo (TILE = a workgroup of four waves per
+                                   2 x 2 x 2 brick of cells sharing one staged halo); same results as TILE up to summation order */
+#define UAMMD_LJ_ALGO_EXACT 9   /* the fastest kernel that keeps the reference's summation order, bit-identical to GENERAL
+                                   (RING_HALF where the grid allows it, else RING, else GENERAL) */
 #define UAMMD_LJ_ALGO_GENERAL 1 /* thread-per-particle walk of the 27 cells (any grid) */
 #define UAMMD_LJ_ALGO_BRICK 2   /* force the LDS-tiled kernel (error if the grid does not allow it) */
 #define UAMMD_LJ_ALGO_QUAD 3    /* force the uniform-j (scalar-streamed neighbours) kernel */

@@ -159,21 +159,6 @@ UH_D void lj_scan_lds(Acc &acc, PairQueue<QT, QCAP, QSTRIDE> &Q, bool drainPBC, 
   Q.n = (int)((qa - q0) / kStep);
 }
 
-struct ListView {
-  const uint *cellStart;
-  const int *cellEnd;
-  const float4 *sortPos;
-  const int *groupIndex;
-  const uint *sortHash;
-  const uint *keyStart;
-  const unsigned char *cellOutside;  // per linear cell: some particle stored outside the primary box (nullable)
-  const uint2 *cellRange;            // per linear cell {first, last | outside << 31}, entry ncells = {0, 0} (nullable, with cellOutside)
-  const uint3 *packHalf;  // half-precision pairs of candidates (celllist.hip k_pack_half), null when not available
-  float packScale;        // 1 / largest cell edge
-  uint validCell;
-  int N;
-  int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
-};
 
 constexpr int kQCapGeneral = 24;  // per-lane FIFO depth of the global-memory kernels (uint entries)
 constexpr int kQCapBrick = 32;    // per-lane FIFO depth of the brick kernel (ushort LDS indices)
@@ -1257,6 +1242,12 @@ static int launch_brick(const ListView &cl, const GridT<float> &grid, const BoxT
   return 0;
 }
 
+// lj_tile.hip: cell-pair tiles, distance test on the matrix pipe (same pairs, another summation order)
+bool lj_tile_supported(const CellList *h, const BoxT<float> &box);
+template <bool NT1, bool WE, bool WV>
+int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, const LJParams *tbl, int ntypes, const Outputs &out,
+                   int shape, hipStream_t st);
+
 template <bool NT1, bool WE, bool WV>
 static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<float> &box, const LJParams *tbl,
                              int ntypes, const Outputs &out, hipStream_t st) {
@@ -1275,10 +1266,18 @@ static int dispatch_celllist(CellList *h, int algo, int brickBits, const BoxT<fl
   cl.N = h->numberParticlesBuilt;
   cl.numOwned = h->numOwned;
   if (h->numOwned != 0x7fffffff && algo != UAMMD_LJ_ALGO_AUTO && algo != UAMMD_LJ_ALGO_GENERAL && algo != UAMMD_LJ_ALGO_STAGED &&
-      algo != UAMMD_LJ_ALGO_RING && algo != UAMMD_LJ_ALGO_RING_HALF) {
+      algo != UAMMD_LJ_ALGO_RING && algo != UAMMD_LJ_ALGO_RING_HALF && algo != UAMMD_LJ_ALGO_TILE && algo != UAMMD_LJ_ALGO_TILE1 && algo != UAMMD_LJ_ALGO_EXACT) {
     set_last_error("uammd_lj_transverse_celllist: the num_owned option is implemented by the general kernel only");
     return -3;
   }
+  if ((algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1) && !lj_tile_supported(h, box)) {
+    set_last_error("uammd_lj_transverse_celllist: the tile kernel needs a tabulated list built on the potential's box with 1 or >= 3 "
+                   "cells per dimension (>= 4 along a periodic x)");
+    return -3;
+  }
+  if (algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1 || (algo == UAMMD_LJ_ALGO_AUTO && lj_tile_supported(h, box)))
+    return launch_lj_tile<NT1, WE, WV>(h, cl, box, tbl, ntypes, out, algo == UAMMD_LJ_ALGO_TILE1 ? 1 : 4, st);
+  if (algo == UAMMD_LJ_ALGO_EXACT) algo = UAMMD_LJ_ALGO_AUTO;  // from here on AUTO = the fastest bit-exact kernel for the grid
   const GridT<float> &g = h->grid;
   const bool brickOK = h->haveKeyStart && g.box.px() && g.box.py() && g.box.pz() && g.cellDim.x >= 4 &&
                        g.cellDim.y >= 4 && g.cellDim.z >= 4 && (NT1 || ntypes <= kMaxTypesLds);

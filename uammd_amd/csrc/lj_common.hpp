@@ -103,6 +103,24 @@ UH_D float lj_max_cutoff2(const LJParams *tbl, int ntypes) {
   return m;
 }
 
+// POD view of a built cell list handed to the traversal kernels (CellListBase::CellListData, CellListBase.cuh:145-160, plus the
+// tables the counting-sort build leaves behind)
+struct ListView {
+  const uint *cellStart;
+  const int *cellEnd;
+  const float4 *sortPos;
+  const int *groupIndex;
+  const uint *sortHash;
+  const uint *keyStart;
+  const unsigned char *cellOutside;  // per linear cell: some particle stored outside the primary box (nullable)
+  const uint2 *cellRange;            // per linear cell {first, last | outside << 31}, entry ncells = {0, 0} (nullable, with cellOutside)
+  const uint3 *packHalf;  // half-precision pairs of candidates (celllist.hip k_pack_half), null when not available
+  float packScale;        // 1 / largest cell edge
+  uint validCell;
+  int N;
+  int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
+};
+
 struct Outputs {
   float4 *force;
   float *energy;

@@ -1,0 +1,582 @@
+// Lennard-Jones traversal of the cell list, MI355X fast path: cell-pair tiles with the distance test on the matrix pipe.
+//
+// Replaces (same pairs, same per-pair arithmetic, another summation order -> rounding-level differences, SURVEY 8d tolerance):
+//   transverseWithNeighbourContainer            Interactor/NeighbourList/common.cuh:10-34
+//   CellList_ns::NeighbourContainer (27 cells)  Interactor/NeighbourList/CellList/NeighbourContainer.cuh:95-130
+//   Radial<LJ>::Transverser::compute / set      Interactor/Potential/RadialPotential.cuh:107-127
+//
+// Why another kernel.  The thread-per-particle walks (lj.hip) sit on the VALU issue limit: a lane tests ~340 candidates at
+// ~10 instructions each to find its ~52 neighbours, and every candidate costs the CU's one texture addresser a 64-lane load.
+// Here one WAVE owns the particles of two x-adjacent cells (x0 even: one contiguous range of the Morton-sorted array, ~25
+// particles at liquid density) and
+//   1. the candidates — the cells around the pair, a few dozen contiguous ranges of the sorted array — are staged into LDS by
+//      LDS-DMA loads (global_load_lds: no registers, nothing waits inside the loop), in the reference's visiting order;
+//   2. the 32 x 32 squared distances between 32 owners and 32 candidates come from three v_mfma_f32_32x32x2_f32
+//      (|a|^2 + |b|^2 - 2 a.b - rc^2 over K = 5, coordinates relative to the tile centre; exact-f32 products, f32 accumulation): the
+//      matrix pipe is otherwise idle and issues beside the VALU.  Each lane then holds 16 values of ITS owner (owner = lane & 31,
+//      the two half-waves take the even and the odd candidates) whose SIGN BIT says "inside the cut-off (+ a margin covering the
+//      expansion's rounding)";
+//   3. one v_alignbit_b32 per value shifts the sign bits into a per-lane 32-bit hit word (two matrix steps per word), stored in LDS;
+//   4. the drain walks each lane's hit words (find-first-bit, two pairs per iteration): the ~11 % of the tile's pairs that are hits
+//      are re-evaluated EXACTLY as the reference does (r12 = rj - ri, minimum image where the tile touches a box face,
+//      r2 >= rc2 -> 0, r2 == 0 -> 0, the same polynomial; the division is rcp + one Newton step) from the full-precision positions
+//      in LDS.  The prefilter is a superset, so no pair is lost and none is added.
+// Owners of the two half-waves are summed at the end; forces go to force[groupIndex[i]] as Transverser::set does.
+//
+// Two launch shapes share the scan / drain code:
+//   k_lj_tile4  (AUTO) a 256-thread workgroup owns a 2 x 2 x 2 Morton brick of cells = four x-pairs; its 4 x 4 x 4-cell halo is
+//               staged ONCE for the four waves (805 instead of 4 x 453 candidates at liquid density, and a quarter of the LDS per
+//               wave: 5 workgroups = 20 waves per CU).  Measured on the single-wave shape: staging was 70 us of a 250 us launch
+//               at C3 and the waves' phases (load latency, matrix chain, drain) did not overlap at ~3 waves per SIMD.
+//   k_lj_tile   one wave per x-pair, 4 x 3 x 3-cell halo, candidates in chunks of 512: any density; also the in-kernel fallback of
+//               a brick whose halo does not fit.
+#include "celllist.hpp"
+#include "lj_common.hpp"
+
+namespace uammd_hip {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float f4t __attribute__((ext_vector_type(4)));
+typedef _Float16 h8t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2t __attribute__((ext_vector_type(2)));
+typedef uint u4t __attribute__((ext_vector_type(4)));
+using LdsF4 = __attribute__((address_space(3))) f4t;
+using LdsU = __attribute__((address_space(3))) uint;
+using GlobV = __attribute__((address_space(1))) void;
+using LdsV = __attribute__((address_space(3))) void;
+
+constexpr int kMaxW = 12;                  // hit words (of 64 candidates) one wave can hold per pass
+constexpr int kSoloCap = 512;              // candidate slots of the single-wave kernel (8 words per chunk)
+constexpr int kBrickCap = 1024;            // candidate slots of the four-wave kernel
+constexpr int kTabWords = (kMaxW + 1) * 64 + 2 * (kMaxW + 2);  // per wave: hit words [kMaxW + 1][64] | word base [kMaxW + 2] | word count [kMaxW + 2]
+
+// count of leading zeros; 0xFFFFFFFF for 0 (v_ffbh_u32)
+UH_D int __builtin_clz_or_neg1(uint v) { return v ? __builtin_clz(v) : -1; }
+
+UH_D uint rdlane(uint v, int l) { return (uint)__builtin_amdgcn_readlane((int)v, l); }
+
+UH_D void wrap_cell(int &c, int n, bool periodic, bool &ok, bool &wr) {
+  if (n == 1) {
+    ok = ok && c == 0;
+  } else if (c < 0) {
+    if (periodic) { c += n; wr = true; } else ok = false;
+  } else if (c >= n) {
+    if (periodic) { c -= n; wr = true; } else ok = false;
+  }
+}
+
+UH_D float min_image(float d, float L, float mInvL) { return mInvL != 0.0f ? fmaf(floorf(fmaf(d, mInvL, 0.5f)), L, d) : d; }
+
+// one pair in the drain: the reference's arithmetic up to the division, which is rcp + one Newton step (<= 1 ulp) here
+template <bool PBC, bool WE>
+UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, const f4t &rj, real3f &r12, float &fm, float &e) {
+  r12 = real3f{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
+  if (PBC) r12 = box.apply_pbc(r12);
+  const float r2 = dot3(r12, r12);
+  const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
+  float r = __builtin_amdgcn_rcpf(r2);
+  r = fmaf(fmaf(-r2, r, 1.0f), r, r);
+  const float invr2 = p.sigma2 * r;
+  const float invr6 = invr2 * invr2 * invr2;
+  const float f = p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
+  fm = in ? f : 0.0f;
+  if (WE) {
+    const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
+    e = in ? 0.5f * E : 0.0f;
+  } else
+    e = 0.0f;
+}
+
+// Candidate <-> matrix row.  The 64 candidates of a word (64 consecutive LDS slots in the reference's visiting order) are assigned to
+// the rows of the word's two matrix steps so that the 32 values a lane sees (half-wave h, step parity sp, accumulator a: hardware
+// row (a & 3) + 8 (a >> 2) + 4 h) are the slots 2 (16 sp + a) + h: the two lanes of an owner take the even and the odd candidates
+// (with blocks of 32 per half the busiest lane of a model liquid holds 41 instead of 34 hits of a mean 26).  Row i of step sp holds
+// slot 32 sp + 2 ((i & 3) + 4 (i >> 3)) + ((i >> 2) & 1); bit j (from the top) of a lane's hit word is slot 2 j + h: one shift-add.
+UH_D uint row_slot(int i) { return 2u * ((uint)(i & 3) + 4u * (uint)(i >> 3)) + (uint)((i >> 2) & 1); }
+
+// |cand - owner|^2 - (rc^2 + margin) for 32 candidates (rows) x 32 owners (columns) from ONE v_mfma_f32_32x32x16_f16 (32 cycles of the
+// matrix pipe; the exact-f32 form, three chained v_mfma_f32_32x32x2_f32 = 192 cycles per step, made the waves of a SIMD queue for the
+// pipe, and a queued wave cannot issue its vector work either).  Coordinates are relative to the tile centre in units of the largest
+// cell edge (|.| <= 2.5) and rounded to half precision (toward zero: v_cvt_pkrtz); the squares are formed from the ROUNDED values and
+// carried as hi + lo halves, so the matrix returns |a^ - b^|^2 - rc2m to f32 accuracy and the only error is the coordinate rounding,
+// covered by the margin (tile_margin).  K slots (candidate side A | owner side B):
+//   k0 b^x | -2 a^x   k1 b^y | -2 a^y   k2 b^z | -2 a^z   k3 0 | 0   k4 |b^|^2 hi | 1   k5 |b^|^2 lo | 1   k6 1 | c hi   k7 1 | c lo
+// with c = |a^|^2 - rc2m; k8..15 belong to the upper half-wave, whose owner side is zero.  The SIGN BIT of a result is the hit flag.
+UH_D uint pk_rtz(float a, float b) { return __builtin_bit_cast(uint, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+UH_D float sq3_h(uint pxy, uint pz0) {  // x^2 + y^2 + z^2 of packed halves, in f32
+  const h2t hxy = __builtin_bit_cast(h2t, pxy), hz0 = __builtin_bit_cast(h2t, pz0);
+  return __builtin_amdgcn_fdot2(hz0, hz0, __builtin_amdgcn_fdot2(hxy, hxy, 0.0f, false), false);
+}
+UH_D uint split_h(float v) {  // (hi, lo) halves with hi + lo = v to ~2^-21
+  const float hi = (float)__builtin_bit_cast(h2t, pk_rtz(v, 0.0f)).x;
+  return pk_rtz(v, v - hi);
+}
+
+struct TileFrame {  // tile centre and scale of the half-precision coordinates; the scaled box for tiles that touch a face
+  float s, nox, noy, noz;     // b' = fma(c, s, no), no = -origin * s
+  float Lx, Ly, Lz, mx, my, mz;  // box size * s and -1 / (box size * s) (0 when not periodic)
+};
+
+template <bool PBC> UH_D void tile_centre(const TileFrame &fr, float x, float y, float z, float &bx, float &by, float &bz) {
+  bx = fmaf(x, fr.s, fr.nox);
+  by = fmaf(y, fr.s, fr.noy);
+  bz = fmaf(z, fr.s, fr.noz);
+  if (PBC) {
+    bx = min_image(bx, fr.Lx, fr.mx);
+    by = min_image(by, fr.Ly, fr.my);
+    bz = min_image(bz, fr.Lz, fr.mz);
+  }
+}
+
+template <bool PBC> UH_D v16f tile_distances(uint candAddr, const TileFrame &fr, const h8t &B) {
+  const f4t c = *(const LdsF4 *)(uintptr_t)candAddr;
+  float bx, by, bz;
+  tile_centre<PBC>(fr, c.x, c.y, c.z, bx, by, bz);
+  const uint pxy = pk_rtz(bx, by), pz0 = pk_rtz(bz, 0.0f);
+  const u4t a = {pxy, pz0, split_h(sq3_h(pxy, pz0)), 0x3c003c00u};
+  const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8t, a), B, z, 0, 0, 0);
+}
+
+// 16 values -> 16 bits of the lane's hit word, one v_alignbit_b32 each: m = (m << 1) | sign(d)
+// (two independent chains of 8: a dependent VALU instruction cannot issue back to back)
+UH_D uint tile_bits16(const v16f &d) {
+  uint m0 = 0, m1 = 0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(d[a]), 31);
+    m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(d[a + 8]), 31);
+  }
+  return (m0 << 8) | m1;
+}
+
+// The wave's 32 owners against nW words of staged candidates.  Word w = 64 consecutive LDS slots starting at byte candBase +
+// wbase[w], of which the first wcnt[w] are this wave's candidates (the rest is staged data of other rows, or padding: their bits
+// are cleared).  tab = this wave's table in LDS: hit words [kMaxW + 1][64] | wbase [kMaxW + 2] | wcnt [kMaxW + 2].
+template <bool PBC, bool NT1, bool WE, bool WV>
+UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const TileFrame &fr, const h8t &B, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
+  const int hi = lane >> 5;
+  const uint rowAddr = candBase + 16u * row_slot(lane & 31);  // the candidate this lane feeds to the matrix: + wbase[w] + 512 sp
+  const uint myMask = tab + 4u * (uint)lane;                  // hit word w of this lane at + 256 w
+  const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
+  // ---- scan: two matrix steps per word; the values of the next step are on the matrix pipe while this one is turned into bits ----
+  uint wb = *(const LdsU *)(uintptr_t)wbaseTab;
+  v16f dA = tile_distances<PBC>(rowAddr + wb, fr, B);
+  for (uint w = 0; w < nW; ++w) {
+    const v16f dB = tile_distances<PBC>(rowAddr + wb + 512u, fr, B);
+    const uint cnt = *(const LdsU *)(uintptr_t)(wcntTab + 4u * w);
+    const uint mA = tile_bits16(dA);
+    if (w + 1 < nW) {
+      wb = *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1));
+      dA = tile_distances<PBC>(rowAddr + wb, fr, B);
+    }
+    uint m = (mA << 16) | tile_bits16(dB);
+    if (__builtin_amdgcn_readfirstlane(cnt) < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
+      const uint mine = (cnt + 1u - (uint)hi) >> 1;
+      m &= mine >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> mine);
+    }
+    *(LdsU *)(uintptr_t)(myMask + 256u * w) = m;
+  }
+  // ---- drain: every lane walks its own hit words (bit j from the top of word w = slot 2 j + h of the word) ----
+  // cw / cb = the word being consumed and its LDS base, nw / nb = the next one; word nW of every lane is zero and a lane never moves
+  // past word nW - 1.  A lane without a set bit in cw takes a dead slot: ffbh(0) = -1 addresses slot -2 of the word — staged data of
+  // another row or the two guard slots in front of the buffer, finite either way — with weight 0.
+  *(LdsU *)(uintptr_t)(myMask + 256u * nW) = 0u;
+  const uint candHalf = candBase + 16u * (uint)hi;
+  uint cw = *(const LdsU *)(uintptr_t)myMask;
+  uint nw = *(const LdsU *)(uintptr_t)(myMask + 256u);
+  uint cb = candHalf + *(const LdsU *)(uintptr_t)wbaseTab;
+  uint nb = candHalf + *(const LdsU *)(uintptr_t)(wbaseTab + 4u);
+  uint wi = 0;  // index of cw, <= nW - 1
+  // Two pairs per iteration (instruction-level parallelism for the rcp / polynomial chains, two LDS reads in flight): advance to the
+  // next word when this one is used up, then take the TWO highest set bits; a word with an odd number of hits leaves one dead slot:
+  // 19 iterations per tile against 35 with one pair per iteration on a model liquid.
+  auto pop2 = [&](bool &live0, bool &live1, uint &a0, uint &a1) {
+    const uint wn = min(wi + 2u, nW);
+    const uint tw = *(const LdsU *)(uintptr_t)(myMask + 256u * wn);
+    const uint tb = candHalf + *(const LdsU *)(uintptr_t)(wbaseTab + 4u * wn);
+    const bool adv = cw == 0 && wi + 1u < nW;
+    cw = adv ? nw : cw;
+    cb = adv ? nb : cb;
+    nw = adv ? tw : nw;
+    nb = adv ? tb : nb;
+    wi += adv ? 1u : 0u;
+    live0 = cw != 0;
+    const uint k0 = (uint)__builtin_clz_or_neg1(cw);
+    cw &= ~(0x80000000u >> (k0 & 31u));
+    live1 = cw != 0;
+    const uint k1 = (uint)__builtin_clz_or_neg1(cw);
+    cw &= ~(0x80000000u >> (k1 & 31u));
+    a0 = cb + (k0 << 5);
+    a1 = cb + (k1 << 5);
+  };
+  bool lN0, lN1;
+  uint a0, a1;
+  pop2(lN0, lN1, a0, a1);
+  f4t cN0 = *(const LdsF4 *)(uintptr_t)a0, cN1 = *(const LdsF4 *)(uintptr_t)a1;
+  while (__any(lN0 || wi + 1u < nW)) {  // some lane still holds a pair or has words left (empty trailing words are walked through)
+    const f4t c0 = cN0, c1 = cN1;
+    const bool l0 = lN0, l1 = lN1;
+    pop2(lN0, lN1, a0, a1);  // the candidates of the next two pairs are on their way from LDS while these two are evaluated
+    cN0 = *(const LdsF4 *)(uintptr_t)a0;
+    cN1 = *(const LdsF4 *)(uintptr_t)a1;
+    real3f r0, r1;
+    float f0, f1, e0, e1;
+    if (NT1) {
+      tile_eval<PBC, WE>(box, p1, pi, c0, r0, f0, e0);
+      tile_eval<PBC, WE>(box, p1, pi, c1, r1, f1, e1);
+    } else {
+      tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c0.w), pi, c0, r0, f0, e0);
+      tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c1.w), pi, c1, r1, f1, e1);
+    }
+    lj_acc<WE, WV>(acc, r0, l0 ? f0 : 0.0f, l0 ? e0 : 0.0f);
+    lj_acc<WE, WV>(acc, r1, l1 ? f1 : 0.0f, l1 ? e1 : 0.0f);
+  }
+}
+
+// owners' side of the matrix products for the 32 owners [o0, o0 + 32) of a wave, and the lane's owner position
+struct OwnerSide { float4 pi; h8t B; bool valid; };
+UH_D OwnerSide tile_owner(const float4 *__restrict__ P, uint ownFirst, int nOwn, int o0, int lane, bool pbc, const TileFrame &fr, float ox,
+                          float oy, float oz, float rc2ms) {
+  OwnerSide o;
+  const int my = o0 + (lane & 31), hi = lane >> 5;
+  o.valid = my < nOwn;
+  o.pi = o.valid ? P[ownFirst + (uint)my] : make_float4(ox, oy, oz, 0.0f);
+  float ax, ay, az;
+  if (pbc) tile_centre<true>(fr, o.pi.x, o.pi.y, o.pi.z, ax, ay, az);
+  else tile_centre<false>(fr, o.pi.x, o.pi.y, o.pi.z, ax, ay, az);
+  const uint pxy = pk_rtz(ax, ay), pz0 = pk_rtz(az, 0.0f);
+  // a row without an owner never hits (|b^|^2 + 6e4 > 0); the upper half-wave holds k = 8..15: zero
+  const float c = o.valid ? sq3_h(pxy, pz0) - rc2ms : 6.0e4f;
+  const uint m2xy = pk_rtz(-2.0f * (float)__builtin_bit_cast(h2t, pxy).x, -2.0f * (float)__builtin_bit_cast(h2t, pxy).y);
+  const uint m2z0 = pk_rtz(-2.0f * (float)__builtin_bit_cast(h2t, pz0).x, 0.0f);
+  u4t b = {m2xy, m2z0, 0x3c003c00u, split_h(c)};
+  if (hi) b = u4t{0u, 0u, 0u, 0u};
+  o.B = __builtin_bit_cast(h8t, b);
+  return o;
+}
+
+UH_D TileFrame tile_frame(const GridT<float> &grid, const BoxT<float> &box, float ox, float oy, float oz) {
+  TileFrame fr;
+  const float e = fmaxf(grid.cellSize.x, fmaxf(grid.cellDim.y > 1 ? grid.cellSize.y : 0.f, grid.cellDim.z > 1 ? grid.cellSize.z : 0.f));
+  fr.s = 1.0f / e;
+  fr.nox = -ox * fr.s; fr.noy = -oy * fr.s; fr.noz = -oz * fr.s;
+  fr.Lx = box.boxSize.x * fr.s; fr.Ly = box.boxSize.y * fr.s; fr.Lz = box.boxSize.z * fr.s;
+  fr.mx = box.px() ? -1.0f / fr.Lx : 0.0f;
+  fr.my = box.py() ? -1.0f / fr.Ly : 0.0f;
+  fr.mz = box.pz() ? -1.0f / fr.Lz : 0.0f;
+  return fr;
+}
+
+template <bool WE, bool WV>
+UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint ownFirst, int o0, int lane, bool valid) {
+  acc.fx += __shfl_xor(acc.fx, 32);
+  acc.fy += __shfl_xor(acc.fy, 32);
+  acc.fz += __shfl_xor(acc.fz, 32);
+  if (WE) acc.e += __shfl_xor(acc.e, 32);
+  if (WV) acc.v += __shfl_xor(acc.v, 32);
+  if ((lane >> 5) == 0 && valid) {
+    const int gi = cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
+    if (gi < cl.numOwned) write_out(out, out.globalIndex ? out.globalIndex[gi] : gi, acc);
+  }
+}
+
+// ---- one wave, one x-pair of cells, its 4 x 3 x 3-cell halo in chunks of `cap` candidates (cap = 64 * words, <= 64 kMaxW) ----------
+// candBase: cap + 64 slots of LDS private to the wave; tab: its table.  Uses only wave-level synchronisation.
+template <bool NT1, bool WE, bool WV>
+UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<float> &box, const LJParams *__restrict__ tbl, int ntypes,
+                    const Outputs &out, float margin, int x0, int ty, int tz, uint candBase, uint cap, uint tab, int lane) {
+  const int cx = grid.cellDim.x, cy = grid.cellDim.y, cz = grid.cellDim.z;
+  // the 4 x 3 x 3 candidate cells: lane = 4 * row + col, row = (dy + 1) + 3 (dz + 1), col -> x0 - 1 .. x0 + 2
+  uint first = 0, len = 0;
+  bool special = false;  // the range is a periodic image or holds particles stored outside the primary box
+  if (lane < 36) {
+    const int col = lane & 3, row = lane >> 2;
+    int x = x0 - 1 + col, y = ty + (row % 3) - 1, z = tz + (row / 3) - 1;
+    bool ok = true, wr = false;
+    wrap_cell(x, cx, box.px(), ok, wr);
+    wrap_cell(y, cy, box.py(), ok, wr);
+    wrap_cell(z, cz, box.pz(), ok, wr);
+    if (col == 3 && x0 + 1 >= cx) ok = false;  // x0 + 2 only neighbours the (missing) second owner cell
+    if (ok) {
+      const uint2 cr = cl.cellRange[x + cx * (y + cy * z)];
+      first = cr.x;
+      len = (cr.y & 0x7fffffffu) - cr.x;
+      special = len != 0 && (wr || (cr.y >> 31) != 0);
+    }
+  }
+  const bool pbcTile = __any(special);
+  const bool own2 = x0 + 1 < cx;  // lane 17 = cell x0, lane 18 = cell x0 + 1 of the centre row (a periodic image when !own2)
+  const uint len17 = rdlane(len, 17), len18 = own2 ? rdlane(len, 18) : 0u;
+  const int nOwn = (int)(len17 + len18);
+  if (nOwn == 0) return;
+  const uint ownFirst = len17 ? rdlane(first, 17) : rdlane(first, 18);
+  {  // x0 and x0 + 1 are neighbours in Morton order: one contiguous range whenever both hold particles
+    const uint nf = __shfl_down(first, 1), nl = __shfl_down(len, 1);
+    const bool mrg = lane < 36 && (lane & 3) == 1 && len != 0 && nl != 0 && nf == first + len;
+    if (mrg) len += nl;
+    if (__shfl_up((int)mrg, 1)) len = 0;
+  }
+  uint C = len;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) C += __shfl_xor(C, d);
+  C = rdlane(C, 0);
+  const unsigned long long ranges = __ballot(len != 0);
+  const float ox = fmaf((float)(x0 + 1), grid.cellSize.x, -0.5f * box.boxSize.x);
+  const float oy = fmaf((float)ty + 0.5f, grid.cellSize.y, -0.5f * box.boxSize.y);
+  const float oz = fmaf((float)tz + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
+  const float4 *__restrict__ P = cl.sortPos;
+  const LJParams p1 = tbl[0];
+  const TileFrame fr = tile_frame(grid, box, ox, oy, oz);
+  const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
+  const f4t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};  // padding behind the last candidate: finite; the word counts clear its bits
+  LdsF4 *cand = (LdsF4 *)(uintptr_t)candBase;
+  const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
+  if (lane < kMaxW + 2) *(LdsU *)(uintptr_t)(wbaseTab + 4u * (uint)lane) = 1024u * (uint)lane;  // words = consecutive blocks of 64 slots
+  for (int o0 = 0; o0 < nOwn; o0 += 32) {
+    const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcTile, fr, ox, oy, oz, rc2ms);
+    Acc acc;
+    for (uint c0 = 0; c0 < C; c0 += cap) {
+      const uint nC = min(C - c0, cap);
+      if (o0 == 0 || C > cap) {
+        __builtin_amdgcn_wave_barrier();
+        // global -> LDS without registers (LDS DMA: lane i lands at the wave-uniform destination + 16 i): nothing waits in the loop
+        unsigned long long m = ranges;
+        uint sO = 0;  // flat index of the range's first candidate (the reference's visiting order)
+        while (m) {
+          const int r = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint sF = rdlane(first, r), sL = rdlane(len, r);
+          const uint lo = max(sO, c0), hiE = min(sO + sL, c0 + cap);
+          for (uint k = lo; k < hiE; k += 64u) {
+            const float4 *src = P + (sF + (k - sO));  // wave-uniform
+            if ((uint)lane < hiE - k) __builtin_amdgcn_global_load_lds((const GlobV *)(src + lane), (LdsV *)(cand + (k - c0)), 16, 0, 0);
+          }
+          sO += sL;
+        }
+        for (uint k = nC + (uint)lane; k < ((nC + 63u) & ~63u); k += 64u) cand[k] = zero4;
+        if (lane < kMaxW + 2) *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)lane) = nC > 64u * (uint)lane ? min(nC - 64u * (uint)lane, 64u) : 0u;
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): the DMA and table writes have landed
+        __builtin_amdgcn_wave_barrier();
+      }
+      const uint nW = (nC + 63u) >> 6;
+      if (pbcTile)
+        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+      else
+        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+    }
+    tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
+  }
+}
+
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_lj_tile(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, Outputs out, float margin,
+          int npx, uint nTiles) {
+  __shared__ f4t candg[2 + kSoloCap + 64];  // two guard slots in front (dead slots of the drain read slot -2)
+  __shared__ uint tab[kTabWords];
+  if (threadIdx.x < 2) candg[threadIdx.x] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
+  LdsF4 *cand = (LdsF4 *)candg + 2;
+  const uint t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (t >= nTiles) return;
+  const int cy = grid.cellDim.y;
+  const int px = (int)(t % (uint)npx), ty = (int)((t / (uint)npx) % (uint)cy), tz = (int)(t / (uint)(npx * cy));
+  tile_solo<NT1, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, 2 * px, ty, tz, (uint)(uintptr_t)cand, (uint)kSoloCap,
+                         (uint)(uintptr_t)(LdsU *)tab, (int)threadIdx.x);
+}
+
+// ---- four waves, one 2 x 2 x 2 brick of cells (four x-pairs), its 4 x 4 x 4-cell halo staged once ------------------------------------
+// Halo rows: r = ry + 4 rz (ry, rz = 0..3 <-> y0 - 1 + ry, z0 - 1 + rz), three ranges per row (x0 - 1 | x0, x0 + 1 | x0 + 2), flat
+// order (rz, ry, x) = the reference's visiting order restricted to any wave's 3 x 3 rows.  Wave k = wy + 2 wz owns the pair in row
+// (1 + wy, 1 + wz); its candidates are the rows ry in [wy, wy + 2], rz in [wz, wz + 2]: three contiguous runs of the flat array.
+template <bool NT1, bool WE, bool WV>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, Outputs out, float margin,
+           int nbx, int nby, uint nBricks) {
+  __shared__ f4t candg[2 + kBrickCap + 64];  // two guard slots in front (dead slots of the drain read slot -2)
+  __shared__ uint tabs[4 * kTabWords];
+  if (threadIdx.x < 2) candg[threadIdx.x] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
+  LdsF4 *cand = (LdsF4 *)candg + 2;
+  // (dense-brick fallback: wave k works in slots [272 k, 272 k + 256); the 16 slots in front of the next wave's region are its guard)
+  if (threadIdx.x < 64) cand[272u * (threadIdx.x >> 4) + 256u + (threadIdx.x & 15u)] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
+  __shared__ uint4 rangeTab[48];  // {first, len, flat offset, special}
+  __shared__ uint total[2];       // {number of candidates, some wave needs more than kMaxW words}
+  const uint t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  if (t >= nBricks) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave & 1, wz = wave >> 1;
+  const int cx = grid.cellDim.x, cy = grid.cellDim.y, cz = grid.cellDim.z;
+  const int bx = (int)(t % (uint)nbx), by = (int)((t / (uint)nbx) % (uint)nby), bz = (int)(t / (uint)(nbx * nby));
+  const int x0 = 2 * bx, y0 = 2 * by, z0 = 2 * bz;
+  const uint candBase = (uint)(uintptr_t)cand;
+  const uint tab = (uint)(uintptr_t)(LdsU *)tabs + 4u * (uint)(wave * kTabWords);
+  const float4 *__restrict__ P = cl.sortPos;
+  // ---- wave 0: the 48 ranges and their flat offsets ----
+  if (wave == 0) {
+    uint first = 0, len = 0, special = 0;
+    if (lane < 48) {
+      const int row = lane / 3, c = lane - 3 * row, ry = row & 3, rz = row >> 2;
+      int y = y0 - 1 + ry, z = z0 - 1 + rz;
+      bool ok = true, wr = false;  // a collapsed direction has one cell: rows other than its own do not exist
+      wrap_cell(y, cy, box.py(), ok, wr);
+      wrap_cell(z, cz, box.pz(), ok, wr);
+      const bool pairEndsGrid = x0 + 1 >= cx;  // odd grid: the last pair is the single cell x0
+      // c = 0: x0 - 1;  c = 1: x0 (+ x0 + 1, contiguous in Morton order);  c = 2: x0 + 2, or the periodic image of x0 + 1 when the
+      // grid ends at x0 (that image neighbours x0; x0 + 2 would only neighbour the missing second cell)
+      int xa = c == 0 ? x0 - 1 : (c == 1 ? x0 : (pairEndsGrid ? x0 + 1 : x0 + 2));
+      wrap_cell(xa, cx, box.px(), ok, wr);
+      if (ok) {
+        const int rowIdx = cx * (y + cy * z);
+        const uint2 cr = cl.cellRange[xa + rowIdx];
+        first = cr.x;
+        len = (cr.y & 0x7fffffffu) - cr.x;
+        uint outside = len ? (cr.y >> 31) : 0u;
+        if (c == 1 && !pairEndsGrid) {
+          const uint2 cb = cl.cellRange[x0 + 1 + rowIdx];
+          const uint lb = (cb.y & 0x7fffffffu) - cb.x;
+          if (len == 0) first = cb.x;
+          len += lb;
+          outside |= lb ? (cb.y >> 31) : 0u;
+        }
+        special = (len != 0 && (wr || outside != 0)) ? 1u : 0u;
+      }
+    }
+    uint incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    if (lane < 48) rangeTab[lane] = make_uint4(first, len, incl - len, special);
+    if (lane == 63) { total[0] = incl; total[1] = 0u; }
+  }
+  __syncthreads();
+  const uint C = total[0];
+  // every lane of every wave holds the range of its index (lanes >= 48: empty)
+  uint4 rg = make_uint4(0u, 0u, 0u, 0u);
+  if (lane < 48) rg = rangeTab[lane];
+  // this wave's pair, runs and words
+  const int ownRange = 3 * ((1 + wy) + 4 * (1 + wz)) + 1;
+  const int nOwn = (y0 + wy < cy && z0 + wz < cz) ? (int)rdlane(rg.y, ownRange) : 0;
+  const uint ownFirst = rdlane(rg.x, ownRange);
+  uint runStart[3], runLen[3], nW = 0;
+  bool pbcWave = false;
+  const unsigned long long sp = __ballot(rg.w != 0);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const int ra = 3 * (wy + 4 * (wz + p)), rb = ra + 8;  // first and last range of the run: rows wy .. wy + 2 of plane wz + p
+    runStart[p] = rdlane(rg.z, ra);
+    runLen[p] = rdlane(rg.z, rb) + rdlane(rg.y, rb) - runStart[p];
+    nW += (runLen[p] + 63u) >> 6;
+    pbcWave = pbcWave || ((sp >> ra) & 0x1FFull) != 0;
+  }
+  if (nOwn != 0 && nW > (uint)kMaxW && lane == 0) total[1] = 1u;  // (benign race: every writer stores 1)
+  const bool fits = C <= (uint)kBrickCap;
+  // ---- staging: the 48 ranges dealt to the four waves ----
+  if (fits) {
+    for (int r = wave; r < 48; r += 4) {
+      const uint sF = rdlane(rg.x, r), sL = rdlane(rg.y, r), sO = rdlane(rg.z, r);
+      for (uint k = 0; k < sL; k += 64u) {
+        const float4 *src = P + (sF + k);  // wave-uniform
+        if ((uint)lane < sL - k) __builtin_amdgcn_global_load_lds((const GlobV *)(src + lane), (LdsV *)(cand + (sO + k)), 16, 0, 0);
+      }
+    }
+    if (wave == 3) {  // 64 slots behind the last candidate: the last word of the last run reads them (finite; their bits are cleared)
+      const f4t far = {0.0f, 0.0f, 0.0f, 0.0f};
+      cand[C + (uint)lane] = far;
+    }
+    // this wave's words: run p contributes ceil(runLen / 64) words starting at its first slot
+    const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
+    const uint w0 = (runLen[0] + 63u) >> 6, w1 = w0 + ((runLen[1] + 63u) >> 6);
+    if (lane < kMaxW + 2) {
+      const uint w = (uint)lane;
+      const int p = (w >= w0) + (w >= w1);
+      const uint k = w - (p == 0 ? 0u : (p == 1 ? w0 : w1));
+      const uint rs = p == 0 ? runStart[0] : (p == 1 ? runStart[1] : runStart[2]);
+      const uint rl = p == 0 ? runLen[0] : (p == 1 ? runLen[1] : runLen[2]);
+      const uint left = rl > 64u * k ? rl - 64u * k : 0u;
+      *(LdsU *)(uintptr_t)(wbaseTab + 4u * w) = w < nW ? 16u * (rs + 64u * k) : 0u;
+      *(LdsU *)(uintptr_t)(wcntTab + 4u * w) = w < nW ? min(left, 64u) : 0u;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (!fits || total[1] != 0u) {
+    // a dense brick: every wave runs the chunked single-pair algorithm on its quarter of the candidate buffer
+    if (y0 + wy < cy && z0 + wz < cz)
+      tile_solo<NT1, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, x0, y0 + wy, z0 + wz,
+                             candBase + 16u * (uint)(wave * ((kBrickCap + 64) / 4)), 192u, tab, lane);
+    return;
+  }
+  if (nOwn == 0) return;
+  const float ox = fmaf((float)(x0 + 1), grid.cellSize.x, -0.5f * box.boxSize.x);
+  const float oy = fmaf((float)(y0 + wy) + 0.5f, grid.cellSize.y, -0.5f * box.boxSize.y);
+  const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
+  const LJParams p1 = tbl[0];
+  const TileFrame fr = tile_frame(grid, box, ox, oy, oz);
+  const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
+  for (int o0 = 0; o0 < nOwn; o0 += 32) {
+    const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
+    Acc acc;
+    if (pbcWave)
+      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+    else
+      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+    tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
+  }
+}
+
+// host side: can this list / box take the tile kernel, and with what margin
+bool lj_tile_supported(const CellList *h, const BoxT<float> &box) {
+  const GridT<float> &g = h->grid;
+  if (!h->haveCellOutside || !h->cellRange.ptr) return false;
+  const bool sameBox = box.boxSize.x == g.box.boxSize.x && box.boxSize.y == g.box.boxSize.y && box.boxSize.z == g.box.boxSize.z &&
+                       box.px() == g.box.px() && box.py() == g.box.py() && box.pz() == g.box.pz();
+  if (!sameBox) return false;
+  const int n[3] = {g.cellDim.x, g.cellDim.y, g.cellDim.z};
+  const bool per[3] = {g.box.px(), g.box.py(), g.box.pz()};
+  for (int k = 0; k < 3; ++k) {
+    // one cell along a periodic direction: the nearest image of a pair is not a function of the two centred coordinates, which is
+    // what the matrix prefilter multiplies (thin periodic slabs take the thread-per-particle kernels)
+    if (n[k] == 1 && per[k]) return false;
+    if (n[k] == 1) continue;
+    if (n[k] < 3) return false;
+    if (k == 0 && per[k] && n[k] < 4) return false;  // x0 - 1 and x0 + 2 must be different cells
+  }
+  return true;
+}
+
+static float tile_margin(const GridT<float> &) {
+  // In units of the largest cell edge e: owners lie within (1, 0.5, 0.5) and candidates within (2.5, 1.5, 1.5) of the tile centre.
+  // Rounding toward zero to half precision moves a coordinate by < 2^-10 of its magnitude, so the difference vector of a pair moves
+  // by |d| < 2^-10 |(3.5, 2, 2)| = 4.4e-3 and, for a pair inside the cut-off (r <= rc <= e, i.e. r' <= 1), the matrix result
+  // |a^ - b^|^2 <= r'^2 + 2 r' |d| + |d|^2 < r'^2 + 8.9e-3.  The hi + lo halves of the squares lose < 2^-20 of values <= 9 and the f32
+  // accumulation ~1e-6: the margin is 9.5e-3 (in e^2).  With e ~ rc that is a shell of 0.5 % of the cut-off: +1.4 % candidates reach
+  // the drain, which re-tests every pair exactly as the reference does.
+  return 9.5e-3f;
+}
+
+// shape 1 = one wave per x-pair (k_lj_tile), 4 = one workgroup of four waves per 2 x 2 x 2 brick (k_lj_tile4)
+template <bool NT1, bool WE, bool WV>
+int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, const LJParams *tbl, int ntypes, const Outputs &out,
+                   int shape, hipStream_t st) {
+  const GridT<float> &g = h->grid;
+  const float margin = tile_margin(g);
+  const int npx = (g.cellDim.x + 1) / 2;
+  if (shape == 1) {
+    const uint nTiles = (uint)npx * (uint)g.cellDim.y * (uint)g.cellDim.z;
+    hipLaunchKernelGGL((k_lj_tile<NT1, WE, WV>), dim3(nTiles), dim3(64), 0, st, cl, g, box, tbl, ntypes, out, margin, npx, nTiles);
+  } else {
+    const int nby = (g.cellDim.y + 1) / 2, nbz = (g.cellDim.z + 1) / 2;
+    const uint nBricks = (uint)npx * (uint)nby * (uint)nbz;
+    hipLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks);
+  }
+  return 0;
+}
+
+template int launch_lj_tile<true, false, false>(CellList *, const ListView &, const BoxT<float> &, const LJParams *, int, const Outputs &, int, hipStream_t);
+template int launch_lj_tile<true, true, true>(CellList *, const ListView &, const BoxT<float> &, const LJParams *, int, const Outputs &, int, hipStream_t);
+template int launch_lj_tile<false, false, false>(CellList *, const ListView &, const BoxT<float> &, const LJParams *, int, const Outputs &, int, hipStream_t);
+template int launch_lj_tile<false, true, true>(CellList *, const ListView &, const BoxT<float> &, const LJParams *, int, const Outputs &, int, hipStream_t);
+
+}  // namespace uammd_hip
