@@ -33,7 +33,6 @@ import torch  # noqa: E402
 # SURVEY §8(d) per-unit figures for the traversal kernel (stated in DESIGN.md §roofline)
 FLOP_PER_PARTICLE = 1.0e4            # 27*12.58 ~ 340 candidate pairs x ~30 flop
 BYTES_COMPULSORY_PER_PARTICLE = 52.6  # sortPos_i + groupIndex + force RMW + tables
-BYTES_STREAMED_PER_PARTICLE = 5650.0  # 27 cells x 12.58 x 16 B + tables: what a thread-per-particle walk issues
 PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
@@ -69,78 +68,6 @@ def lj_setup(hip, n, L, seed, T=1.0, dt=0.005, nl="cell"):
         # in (the reference's VerletList gives the same hint with cutOff/2, VerletList.cuh:116)
         pd.hintSortByHash(box, [2.5] * 3)
     return pd, box, pot, verlet, pf, pos
-
-
-class EventRing:
-    """HIP event pairs around one launch per step, on the launch's stream.  A fixed ring of pairs is reused (a pair is read
-    back RING steps after it was recorded, waiting for it if the host has run that far ahead): creating two events per step made the runtime stall
-    for ~25 ms once a few hundred were alive."""
-    RING = 64
-
-    def __init__(self):
-        self.ring, self.pos, self.live = [], 0, 0
-        self.total_ms, self.count = 0.0, 0
-
-    def _collect(self, pair):
-        pair[1].synchronize()  # the host may run more than RING steps ahead of the device
-        self.total_ms += pair[0].elapsed_time(pair[1])
-        self.count += 1
-
-    def start(self):
-        if len(self.ring) < self.RING:
-            self.ring.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-        else:
-            self._collect(self.ring[self.pos])
-            self.live -= 1
-        self.cur = self.ring[self.pos]
-        self.pos = (self.pos + 1) % self.RING
-        self.cur[0].record()
-
-    def stop(self):
-        self.cur[1].record()
-        self.live += 1
-
-    def clear(self):
-        self.live, self.total_ms, self.count = 0, 0.0, 0
-
-    def mean_ms(self):
-        """Call after a device synchronize: also collects the pairs still in the ring."""
-        for i in range(self.live):
-            self._collect(self.ring[(self.pos - 1 - i) % len(self.ring)])
-        self.live = 0
-        return self.total_ms / self.count if self.count else float("nan")
-
-
-class TimedPairForces:
-    """Wraps PairForces.sum with an event pair around the traversal launch (same stream)."""
-
-    SAMPLE = 8
-
-    def __init__(self, pf):
-        self.pf = pf
-        self.ev = EventRing()
-        self.enabled = False
-        self.calls = 0
-
-    def install(self):
-        nl = self.pf.nl
-        orig = nl.transverse_lj
-
-        def timed(*a, **k):
-            self.calls += 1
-            # every SAMPLE-th launch of the timed region is bracketed: an event pair around EVERY launch cost the run
-            # 0.03-0.05 ms per step plus a ~25 ms stall of the runtime after a few hundred recorded events (measured)
-            if not self.enabled or self.calls % self.SAMPLE or os.environ.get("UAMMD_BENCH_NOTIMER") == "1":
-                return orig(*a, **k)
-            self.ev.start()
-            r = orig(*a, **k)
-            self.ev.stop()
-            return r
-
-        nl.transverse_lj = timed
-
-    def mean_ms(self):
-        return self.ev.mean_ms()
 
 
 def cpu_baseline_lj(n, L, seed, sample_steps):
@@ -369,8 +296,6 @@ def run_lj_distributed(hip, args, world, rank, dist):
     pot = hip.Potential.LJ()
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
     cl = hip.CellList()
-    trav_events = EventRing()
-    calls = [0]
 
     def forces_fn(allpos, box_L, periodic):
         box = hip.Box(box_L, periodic)
@@ -378,13 +303,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
         cl.update_grid(allpos.contiguous(), ubox, cd)
         cl.set_option("num_owned", sim.n_owned)
         f = torch.zeros((allpos.shape[0], 4), dtype=torch.float32, device=allpos.device)
-        calls[0] += 1
-        sampled = calls[0] % TimedPairForces.SAMPLE == 0   # see TimedPairForces: an event pair per launch distorts the run
-        if sampled:
-            trav_events.start()
         cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, args.algo)
-        if sampled:
-            trav_events.stop()
         return f
 
     def integrate_fn(step, p, v, f, step_num):
@@ -416,7 +335,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    trav_events.clear()
+    cl.profile_enable(True)
     t0 = time.perf_counter()
     for j in range(args.steps):
         if j > 0 and j % 500 == 0:
@@ -439,7 +358,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
     assert torch.isfinite(pos).all()
     assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
     sim.check_skin()
-    k_ms = trav_events.mean_ms()
+    tot, cnt = cl.profile_read()
+    k_ms = tot / max(cnt, 1)
     return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
 
 
@@ -447,7 +367,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--equilibrate", type=int, default=300, help="untimed steps that melt the lattice before warm-up (part of the synthetic input)")
     ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both"])
     ap.add_argument("--fcm-steps", type=int, default=200)
     ap.add_argument("--fcm-warmup", type=int, default=20)
@@ -519,7 +440,7 @@ def main():
                        "particles_per_gpu": n, "box": [L1, L1, L1 * world],
                        "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange"},
             "pair_interactions_per_s": 52.36 * value,
-            "roofline": {"bound": "mfma", "kernel": "k_lj_ringh + k_pack_half (LJ traversal, owned + ghost particles)",
+            "roofline": {"bound": "valu", "kernel": "LJ traversal (k_lj_tile4), owned + ghost particles",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
         if args.workload == "both":
@@ -532,43 +453,48 @@ def main():
     # Single GPU from here on (world > 1 took the z-slab domain decomposition above — DESIGN.md §7).
     pd, box, pot, verlet, pf, _ = lj_setup(hip, n, L, seed=1234 + rank, nl=args.nl)
     pf.algo = args.algo
-    verlet.forwardTime()  # creates the neighbour list
-    timer = TimedPairForces(pf)
-    timer.install()
-
-    def run(k, timed):
-        for j in range(k):
-            if timed and j % args.sort_every == 0:
-                pd.sortParticles()  # examples/misc/benchmark.cu:154-156 (every 500 steps there)
-            verlet.forwardTime()
-
-    run(args.warmup, False)
-    pd.sortParticles()
+    # Synthetic input = an LJ LIQUID: the jittered lattice is melted for --equilibrate steps (untimed, part of building the input;
+    # the reference's benchmark relaxes 2000 steps) so that the driver's short --warmup still times the steady state.
+    for _ in range(args.equilibrate):
+        verlet.forwardTime()
+    for _ in range(args.warmup):
+        verlet.forwardTime()
+    pd.sortParticles()  # examples/misc/benchmark.cu:154-156 sorts every 500 steps: the timed region starts from a sorted state ...
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    profiled = args.nl == "cell" and os.environ.get("UAMMD_BENCH_NOTIMER") != "1"
+    if profiled:
+        pf.nl.profile_enable(True)   # start / stop events on the traversal kernel's own dispatch, every launch of the timed region
     t0 = time.perf_counter()
-    run(args.steps, True)
+    for j in range(args.steps):
+        verlet.forwardTime()
+        if (j + 1) % args.sort_every == 0:
+            pd.sortParticles()  # ... and sorts again, INSIDE the timed region, after every 500th timed step (a sort is ~1.5 ms: charging
+                                # one to a 20-step run would overstate its amortised cost of 0.003 ms per step 25-fold)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    timer.enabled = False
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    k_ms, k_launches = float("nan"), 0
+    if profiled:
+        tot, k_launches = pf.nl.profile_read()
+        pf.nl.profile_enable(False)
+        k_ms = tot / max(k_launches, 1)
 
     pos = pd.getPos().cpu().numpy()
     assert np.isfinite(pos).all(), "non finite positions after the run"
     ms_per_step = el / args.steps * 1e3
     value = n * world * args.steps / el
-    k_ms = timer.mean_ms()
     achieved_tflops = FLOP_PER_PARTICLE * n / (k_ms * 1e-3) / 1e12
     traffic = read_traffic("traffic_lj_traversal.json")
+    kern = {0: "k_lj_tile4", 8: "k_lj_tile4", 10: "k_lj_tile", 9: "k_lj_ringh + k_pack_half", 7: "k_lj_ringh + k_pack_half"}.get(args.algo, f"algo {args.algo}")
     out = {
         "metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -576,22 +502,24 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, " +
                                ("CellList rebuilt every step, sortParticles every 500 steps with hintSortByHash(box, rc), " if args.nl == "cell" else
-                                f"VerletList (1.08 rc, {getattr(pf.nl, 'rebuilds', 0)} rebuilds in {args.warmup + args.steps + 1} steps), ") +
-                               "VerletNVT::GronbechJensen T=1 dt=0.005 (BASELINE configs[2])",
+                                f"VerletList (1.08 rc, {getattr(pf.nl, 'rebuilds', 0)} rebuilds in {args.equilibrate + args.warmup + args.steps + 1} steps), ") +
+                               f"VerletNVT::GronbechJensen T=1 dt=0.005 (BASELINE configs[2]); input = jittered lattice melted for "
+                               f"{args.equilibrate} untimed steps, then {args.warmup} warm-up and {args.steps} timed steps",
                    "particles_per_gpu": n, "box": L, "cellDim": 43 if n == 1_000_000 else None,
                    "parallelism": "single GPU"},
         "pair_interactions_per_s": 52.36 * value,
-        "roofline": {"bound": "mfma", "kernel": "k_lj_ringh + k_pack_half (LJ traversal: 27-cell walk, ring FIFO, half-precision prefilter)" if args.nl == "cell" else "k_lj_verlet (list traversal; the flop model is the CellList walk's, so this is an effective rate)", "achieved": achieved_tflops,
-                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
-                     "traffic": traffic, "kernel_ms": k_ms,
-                     "note": "f32 VALU-bound kernel; peak = f32 vector (= f32 MFMA) peak; model 1.0e4 flop/particle",
-                     "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                     "hbm_frac_streamed_neighbour_model": BYTES_STREAMED_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        "roofline": {"bound": "valu",
+                     "kernel": (kern + " (LJ traversal: cell-pair tiles, f16-MFMA distance prefilter, exact f32 evaluation of the hits)") if args.nl == "cell" else "k_lj_verlet (list traversal)",
+                     "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
+                     "traffic": traffic, "kernel_ms": k_ms, "kernel_launches_timed": k_launches,
+                     "note": "the kernel is bound by f32 vector-instruction issue, not HBM; achieved = the reference walk's 1.0e4 flop/particle "
+                             "(340 candidates x ~30 flop, SURVEY 8d) / mean kernel time of every launch of the timed region; peak = f32 vector peak",
+                     "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
     }
     if args.workload == "both" and args.nl == "cell" and world == 1:
         # the same box with the reference benchmark's neighbour list (examples/misc/benchmark.cu:82-84): extra information,
         # `value` above stays the CellList configuration BASELINE.json names
-        del pd, verlet, pf, timer
+        del pd, verlet, pf
         pd2, _, _, verlet2, pf2, _ = lj_setup(hip, n, L, seed=1234, nl="verlet")
         for _ in range(150):
             verlet2.forwardTime()

@@ -76,6 +76,12 @@ int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out);
  * uammd_celllist_check_errors synchronises `stream` and reports at once; option "strict_errors" = 1 makes every update do so
  * (the reference's debug behaviour); option "report_errors" = 0 gives the reference's release behaviour. */
 int uammd_celllist_check_errors(uammd_celllist *h, void *stream);
+/* Measurement hook (no reference counterpart): while enabled, every LJ traversal of this list that runs as ONE kernel (the TILE
+ * kernels) is launched through hipExtLaunchKernel with a start / stop event pair attached to its own dispatch, and
+ * uammd_lj_profile_read returns the summed kernel time (ms) and the number of launches since the enable.  bench.py derives
+ * roofline.achieved from it: every launch of the timed region, no events between kernels. */
+int uammd_lj_profile_enable(uammd_celllist *h, int enable);
+int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
  * particles with input index >= n as ghosts of a domain decomposition: they are neighbours of the others but the LJ
  * traversal computes nothing for them (n < 0 turns it off) */

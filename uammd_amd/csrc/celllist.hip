@@ -366,6 +366,35 @@ int CellList::ensure_pack(hipStream_t st) {
   return 0;
 }
 
+int CellList::Profile::next(hipEvent_t *start, hipEvent_t *stop) {
+  if (live == kRing) { if (int e = collect(kRing - 1)) return e; }
+  const int slot = head % kRing;
+  for (int k = 0; k < 2; ++k)
+    if (!ev[slot][k]) UH_CHECK(hipEventCreate(&ev[slot][k]));
+  *start = ev[slot][0];
+  *stop = ev[slot][1];
+  head++;
+  live++;
+  return 0;
+}
+int CellList::Profile::collect(int upTo) {
+  while (live > upTo) {
+    const int slot = (head - live) % kRing;
+    UH_CHECK(hipEventSynchronize(ev[slot][1]));
+    float ms = 0.f;
+    UH_CHECK(hipEventElapsedTime(&ms, ev[slot][0], ev[slot][1]));
+    totalMs += ms;
+    launches++;
+    live--;
+  }
+  return 0;
+}
+CellList::Profile::~Profile() {
+  for (auto &p : ev)
+    for (auto &e : p)
+      if (e) (void)hipEventDestroy(e);
+}
+
 CellList::~CellList() {
   if (hostErr) (void)hipHostFree(hostErr);
 }
@@ -585,6 +614,24 @@ int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out) {
   for (int k = 0; k < 3; ++k) { out->boxSize[k] = cl->boxL[k]; out->periodic[k] = cl->boxPeriodic[k]; }
   out->VALID_CELL = cl->validCell;
   out->numberParticles = cl->numberParticlesBuilt;
+  return 0;
+}
+
+int uammd_lj_profile_enable(uammd_celllist *h, int enable) {
+  if (!h) { set_last_error("uammd_lj_profile_enable: null handle"); return -1; }
+  CellList *cl = reinterpret_cast<CellList *>(h);
+  if (int e = cl->prof.collect(0)) return e;
+  cl->prof.enabled = enable != 0;
+  cl->prof.totalMs = 0.0;
+  cl->prof.launches = 0;
+  return 0;
+}
+int uammd_lj_profile_read(uammd_celllist *h, double *totalMs, long long *launches) {
+  if (!h || !totalMs || !launches) { set_last_error("uammd_lj_profile_read: null argument"); return -1; }
+  CellList *cl = reinterpret_cast<CellList *>(h);
+  if (int e = cl->prof.collect(0)) return e;  // waits for the launches still in flight
+  *totalMs = cl->prof.totalMs;
+  *launches = cl->prof.launches;
   return 0;
 }
 

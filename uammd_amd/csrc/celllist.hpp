@@ -51,6 +51,20 @@ struct CellList {
   bool strictErrors = false, reportErrors = true;
   int check_errors(hipStream_t st, bool sync);
   ~CellList();
+  // Traversal-kernel timing for bench.py's roofline line: when enabled the LJ traversal is launched with hipExtLaunchKernel and a
+  // start / stop event pair from a ring (the events ride on the kernel's own dispatch packet: no extra barrier packets in the
+  // stream, unlike an hipEventRecord on either side of every launch).  Completed pairs are summed lazily.
+  struct Profile {
+    static constexpr int kRing = 128;
+    bool enabled = false;
+    hipEvent_t ev[kRing][2] = {};
+    int head = 0, live = 0;   // live pairs are [head - live, head)
+    double totalMs = 0.0;
+    long long launches = 0;
+    int next(hipEvent_t *start, hipEvent_t *stop);  // a pair for the next launch (collects the oldest one when the ring is full)
+    int collect(int upTo);                           // sum and retire all but the newest `upTo` live pairs
+    ~Profile();
+  } prof;
   int numOwned = 0x7fffffff;  // traversal option: particles with input index >= numOwned are ghosts (neighbours only, no output)
 
   int next_valid_cell(int numberParticles, bool *needsClear);

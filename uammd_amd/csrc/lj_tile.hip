@@ -32,6 +32,7 @@
 //               a brick whose halo does not fit.
 #include "celllist.hpp"
 #include "lj_common.hpp"
+#include <hip/hip_ext.h>
 
 namespace uammd_hip {
 
@@ -563,13 +564,15 @@ int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, cons
   const GridT<float> &g = h->grid;
   const float margin = tile_margin(g);
   const int npx = (g.cellDim.x + 1) / 2;
+  hipEvent_t e0 = nullptr, e1 = nullptr;  // null: a plain launch
+  if (h->prof.enabled) { if (int e = h->prof.next(&e0, &e1)) return e; }
   if (shape == 1) {
     const uint nTiles = (uint)npx * (uint)g.cellDim.y * (uint)g.cellDim.z;
-    hipLaunchKernelGGL((k_lj_tile<NT1, WE, WV>), dim3(nTiles), dim3(64), 0, st, cl, g, box, tbl, ntypes, out, margin, npx, nTiles);
+    hipExtLaunchKernelGGL((k_lj_tile<NT1, WE, WV>), dim3(nTiles), dim3(64), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nTiles);
   } else {
     const int nby = (g.cellDim.y + 1) / 2, nbz = (g.cellDim.z + 1) / 2;
     const uint nBricks = (uint)npx * (uint)nby * (uint)nbz;
-    hipLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks);
+    hipExtLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks);
   }
   return 0;
 }

@@ -345,6 +345,16 @@ class CellList:
             L=np.array(list(d.boxSize), np.float32), periodic=np.array(list(d.periodic), np.int32))
         return out
 
+    def profile_enable(self, on=True):
+        """Measurement hook: per-launch kernel time of the LJ traversal (uammd_lj_profile_enable, include/uammd_hip.h)."""
+        check(self.lib.uammd_lj_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """(summed kernel ms, launches) since profile_enable; waits for launches in flight."""
+        ms, n = C.c_double(0.0), C.c_longlong(0)
+        check(self.lib.uammd_lj_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def transverse_lj(self, param_table, ntypes, box, force=None, energy=None, virial=None, global_index=None,
                       algo=0):
         check(self.lib.uammd_lj_transverse_celllist(self.h, _ptr(param_table), int(ntypes), f3(box.boxSize),
