@@ -57,6 +57,8 @@ struct FCM {
   bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
   bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
+  int zTileLog2 = 0;               // test / tuning hook: log2 of the fused z pass's node tile (0 = default)
+  bool customFFT = true;           // power-of-two grids: the five-pass LDS FFT pipeline of fcm_fft.hpp instead of rocFFT + k_fcm_kspace
   PseGreens pse{0.f, 0.f, 0.f, 0.f, false};  // PSE far field: Hasimoto-split RPY greens function instead of 1/(eta k^2)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
@@ -517,7 +519,7 @@ UH_D bool noise_skipped(int id, int3 c, int3 n) {  // FCM_impl.cuh:456-463: node
 UH_D C3 draw_noise(float prefactor, uint id, uint seed1, uint seed2, bool nyquist) {  // FCM/utils.cuh:117-131 + :466-476
   Saru rng(id, seed1, seed2);
   const float sc = 0.707106781186547f * prefactor;
-  const float2 a = rng.gf(0.0f, sc), b = rng.gf(0.0f, sc), c = rng.gf(0.0f, sc);
+  const float2 a = rng.gf_fast(0.0f, sc), b = rng.gf_fast(0.0f, sc), c = rng.gf_fast(0.0f, sc);
   C3 n{a.x, a.y, b.x, b.y, c.x, c.y};
   if (nyquist) {
     const float q = 1.41421356237310f;
@@ -557,20 +559,11 @@ UH_D C3 pse_project(real3f k, const C3 &f) {  // FarField.cuh:53-73
             fmaf(-k.z, kfi, f.zi)};
 }
 
-__global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLayout lay, int3 nk, real3f L,
-                                                     float viscosity, bool haveForce, float noisePrefactor,
-                                                     uint seed1, uint seed2, PseGreens pse) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int nkx = nk.x / 2 + 1;
-  const int total = nk.z * lay.nyl * nkx;
-  if (t >= total) return;
-  // (kx, yl, z) of this thread: three integer divisions by run-time constants would cost ~100 VALU slots; multiply-high instead
-  const uint tq = lay.divNkx.div((uint)t);          // t / nkx
-  const uint tz = lay.divNyl.div(tq);               // t / (nkx * nyl)
-  const int3 cell = make_int3(t - (int)tq * nkx, lay.y0 + (int)(tq - tz * (uint)lay.nyl), (int)tz);
-  const int id = cell.x + nkx * (cell.y + nk.y * cell.z);  // the reference's linear node index (it seeds the noise)
-  const size_t a0 = (size_t)cell.x + (size_t)nkx * (size_t)(cell.y - lay.y0) + lay.zStride * (size_t)cell.z;
-  float2 *g1 = g0 + lay.compStride, *g2 = g0 + 2 * lay.compStride;
+// The Fourier-space operator on ONE node: forceFourier2Vel (FCM_impl.cuh:375-397) + fourierBrownianNoise (:437-512) in gather form,
+// or their PSE far-field counterparts (FarField.cuh:137-158, :235-308).  `in` = the transformed spread forces at the node (ignored
+// unless haveForce), `id` = the reference's linear node index cell.x + nkx (cell.y + ny cell.z): it seeds the noise.
+UH_D C3 fcm_kspace_node(int3 cell, int id, int3 nk, int nkx, real3f L, float viscosity, bool haveForce, float noisePrefactor, uint seed1,
+                        uint seed2, const PseGreens &pse, const C3 &in) {
   C3 v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // indexToWaveNumber (FCM/utils.cuh:27-35) from the cell coordinates it would recompute by division
   const int3 ik = make_int3(cell.x - nk.x * (cell.x >= nkx), cell.y - nk.y * (cell.y >= nk.y / 2 + 1),
@@ -583,7 +576,7 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
       const float B = pse_greens(k, pse, viscosity, nk);
       const real3f ks = pse_shear(k, pse.shear);
       if (haveForce) {  // forceFourier2Vel, FarField.cuh:137-158: project(B * f)
-        const float2 a = g0[a0], b = g1[a0], c = g2[a0];
+        const float2 a = make_float2(in.xr, in.xi), b = make_float2(in.yr, in.yi), c = make_float2(in.zr, in.zi);
         v = pse_project(ks, C3{a.x * B, a.y * B, b.x * B, b.y * B, c.x * B, c.y * B});
       }
       if (noisePrefactor != 0.0f) {  // fourierBrownianNoise, FarField.cuh:235-308, in gather form
@@ -611,13 +604,10 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
         v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
       }
     }
-    g0[a0] = make_float2(v.xr, v.xi);
-    g1[a0] = make_float2(v.yr, v.yi);
-    g2[a0] = make_float2(v.zr, v.zi);
-    return;
+    return v;
   }
   if (haveForce && id != 0) {  // forceFourier2Vel, FCM_impl.cuh:375-397
-    const float2 a = g0[a0], b = g1[a0], c = g2[a0];
+    const float2 a = make_float2(in.xr, in.xi), b = make_float2(in.yr, in.yi), c = make_float2(in.zr, in.zi);
     const float B = 1.0f / (viscosity * k2);
     const float sc = B / (float)(nk.x * nk.y * nk.z);
     const C3 pr = project(k2, dk, C3{a.x, a.y, b.x, b.y, c.x, c.y});
@@ -649,9 +639,82 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
     v.xr += first.xr; v.xi += first.xi; v.yr += first.yr; v.yi += first.yi; v.zr += first.zr; v.zi += first.zi;
     v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
   }
+  return v;
+}
+
+
+__global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLayout lay, int3 nk, real3f L,
+                                                     float viscosity, bool haveForce, float noisePrefactor,
+                                                     uint seed1, uint seed2, PseGreens pse) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nkx = nk.x / 2 + 1;
+  const int total = nk.z * lay.nyl * nkx;
+  if (t >= total) return;
+  // (kx, yl, z) of this thread: three integer divisions by run-time constants would cost ~100 VALU slots; multiply-high instead
+  const uint tq = lay.divNkx.div((uint)t);          // t / nkx
+  const uint tz = lay.divNyl.div(tq);               // t / (nkx * nyl)
+  const int3 cell = make_int3(t - (int)tq * nkx, lay.y0 + (int)(tq - tz * (uint)lay.nyl), (int)tz);
+  const int id = cell.x + nkx * (cell.y + nk.y * cell.z);  // the reference's linear node index (it seeds the noise)
+  const size_t a0 = (size_t)cell.x + (size_t)nkx * (size_t)(cell.y - lay.y0) + lay.zStride * (size_t)cell.z;
+  float2 *g1 = g0 + lay.compStride, *g2 = g0 + 2 * lay.compStride;
+  C3 in{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (haveForce && id != 0) {
+    const float2 a = g0[a0], b = g1[a0], c = g2[a0];
+    in = C3{a.x, a.y, b.x, b.y, c.x, c.y};
+  }
+  const C3 v = fcm_kspace_node(cell, id, nk, nkx, L, viscosity, haveForce, noisePrefactor, seed1, seed2, pse, in);
   g0[a0] = make_float2(v.xr, v.xi);
   g1[a0] = make_float2(v.yr, v.yi);
   g2[a0] = make_float2(v.zr, v.zi);
+}
+
+#include "fcm_fft.hpp"
+
+// ---- z lines + Fourier-space operator, fused -------------------------------------------------------------------------------------------
+// One workgroup holds the three components of `tl` consecutive (ky, kx) nodes (flat index q = ky nkx + kx, contiguous in memory) over
+// all nz planes in LDS: forward z transform (skipped when there are no forces: the grid is then all noise), the Stokes / noise
+// operator node by node, inverse z transform, store.  Replaces two strided rocFFT passes and k_fcm_kspace (three trips of the
+// 25.6 MB grid through memory at C4) by one.
+template <int LOG2TL, int NT>
+__global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size_t planeC, int log2nz, int3 nk, real3f L,
+                                                             float viscosity, bool haveForce, float noisePrefactor, uint seed1,
+                                                             uint seed2, PseGreens pse) {
+  extern __shared__ float2 lds[];
+  constexpr int TL = 1 << LOG2TL, JG = NT >> LOG2TL, MAXB = 6 * 256 / NT;
+  const int nz = 1 << log2nz, LS = nz + 1, nkx = nk.x / 2 + 1;
+  float2 *tw = lds, *buf = lds + nz;
+  const int tid = threadIdx.x, l = tid & (TL - 1), jg = tid >> LOG2TL;
+  const size_t slab = (size_t)nk.y * nkx;  // complex per z plane
+  const int q0 = blockIdx.x * TL, nl = min(TL, (int)slab - q0);
+  float2 *base = g + q0 + l;
+  fft_twiddles<NT>(tw, nz, tid);
+  if (haveForce) {
+    if (l < nl)
+      for (int c = 0; c < 3; ++c)
+        for (int j = jg; j < nz; j += JG) buf[(c * nl + l) * LS + j] = base[(size_t)c * planeC + (size_t)j * slab];
+    __syncthreads();
+    fft_lds<-1, MAXB, NT>(buf, LS, log2nz, 3 * nl, tw, 1, tid);
+  } else
+    __syncthreads();
+  if (l < nl) {
+    const int q = q0 + l, ky = q / nkx, kx = q - ky * nkx;
+    for (int j = jg; j < nz; j += JG) {
+      const int3 cell = make_int3(kx, ky, j);
+      const int id = kx + nkx * (ky + nk.y * j);
+      C3 in{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float2 *px = buf + l * LS + j, *py = buf + (nl + l) * LS + j, *pz = buf + (2 * nl + l) * LS + j;
+      if (haveForce) in = C3{px->x, px->y, py->x, py->y, pz->x, pz->y};
+      const C3 v = fcm_kspace_node(cell, id, nk, nkx, L, viscosity, haveForce, noisePrefactor, seed1, seed2, pse, in);
+      *px = make_float2(v.xr, v.xi);
+      *py = make_float2(v.yr, v.yi);
+      *pz = make_float2(v.zr, v.zi);
+    }
+  }
+  __syncthreads();
+  fft_lds<1, MAXB, NT>(buf, LS, log2nz, 3 * nl, tw, 1, tid);
+  if (l < nl)
+    for (int c = 0; c < 3; ++c)
+      for (int j = jg; j < nz; j += JG) base[(size_t)c * planeC + (size_t)j * slab] = buf[(c * nl + l) * LS + j];
 }
 
 // half * (i dk) x g on the planar complex grids: addTorqueCurl (ACC: out += ...) and computeVelocityCurlFourier (out = ...),
@@ -688,6 +751,72 @@ __global__ void k_fcm_export(const float2 *__restrict__ g0, size_t planeC, int t
   out6[6 * (size_t)id + 0] = a.x; out6[6 * (size_t)id + 1] = a.y;
   out6[6 * (size_t)id + 2] = b.x; out6[6 * (size_t)id + 3] = b.y;
   out6[6 * (size_t)id + 4] = c.x; out6[6 * (size_t)id + 5] = c.y;
+}
+
+
+// ---- the LDS FFT pipeline (fcm_fft.hpp) ---------------------------------------------------------------------------------------------------
+static int ilog2_exact(int n) {  // log2 of a power of two in [16, 512], else -1
+  for (int l = 4; l <= kFftMaxLog2; ++l)
+    if (n == (1 << l)) return l;
+  return -1;
+}
+// the y transform of `groups` planes of (2^log2n x nkx) complex: 16 lines of n points per workgroup = n / 64 butterflies per thread
+template <int SIGN> static void fft_launch_lines(float2 *g, int log2n, int nkx, int groups, hipStream_t st) {
+  const int n = 1 << log2n, tiles = (nkx + 15) / 16;
+  const dim3 gr(groups * tiles);
+  const size_t ldsz = sizeof(float2) * (size_t)(n + 16 * (n + 1));
+  // (512 threads per workgroup were measured slower here: 25 vs 22 us at C4; the fused z pass gains from them)
+  if (n <= 128) hipLaunchKernelGGL((k_fft_lines<SIGN, 2, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
+  else if (n == 256) hipLaunchKernelGGL((k_fft_lines<SIGN, 4, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
+  else hipLaunchKernelGGL((k_fft_lines<SIGN, 8, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
+}
+static bool fcm_custom_fft_usable(const FCM *f) {
+  return f->customFFT && ilog2_exact(f->grid.cellDim.x) >= 5 && ilog2_exact(f->grid.cellDim.y) > 0 && ilog2_exact(f->grid.cellDim.z) > 0 &&
+         f->planeReal == (size_t)f->nxpad * f->grid.cellDim.y * f->grid.cellDim.z;
+}
+// forward x and y transforms of the three real component grids, in place
+static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
+  const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1, nh = nx / 2;
+  const int lx = ilog2_exact(nx), ly = ilog2_exact(ny);
+  const int rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * nz;
+  hipLaunchKernelGGL(k_fft_x_r2c, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
+                     lx, nrows, rows);
+  const int tiles = (nkx + 15) / 16;
+  fft_launch_lines<-1>((float2 *)g, ly, nkx, 3 * nz, st);
+  (void)tiles;
+  return 0;
+}
+// z transform + Fourier-space operator + inverse z transform, then the inverse y transform
+static int fcm_fft_z_operator_y(FCM *f, float *g, bool haveForce, float noisePrefactor, hipStream_t st) {
+  const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1;
+  const int ly = ilog2_exact(ny), lz = ilog2_exact(nz);
+  const int slab = ny * nkx;
+  const real3f L{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]};
+  // tile of (ky, kx) nodes per workgroup: 3 tl nz complex in LDS and <= 6 radix-4 butterflies per thread and pass
+  const int ltl = nz <= 128 ? (f->zTileLog2 > 0 ? f->zTileLog2 : 3) : (nz == 256 ? 3 : 2), tlz = 1 << ltl;  // measured at C4: 8 nodes x 512 threads
+  const size_t ldsz = sizeof(float2) * (size_t)(nz + 3 * tlz * (nz + 1));
+  const int nt = 512;
+  const dim3 gz((slab + tlz - 1) / tlz), bz(nt);
+#define UH_ZFUSED(LT) if (nt == 512) hipLaunchKernelGGL((k_fft_z_fused<LT, 512>), gz, bz, ldsz, st, (float2 *)g, f->planeCplx, lz, f->grid.cellDim, L, f->par.viscosity, \
+                                         haveForce, noisePrefactor, f->par.seed, f->seed2, f->pse); \
+  else hipLaunchKernelGGL((k_fft_z_fused<LT, 256>), gz, bz, ldsz, st, (float2 *)g, f->planeCplx, lz, f->grid.cellDim, L, f->par.viscosity, \
+                                         haveForce, noisePrefactor, f->par.seed, f->seed2, f->pse)
+  if (ltl == 4) UH_ZFUSED(4);
+  else if (ltl == 3) UH_ZFUSED(3);
+  else UH_ZFUSED(2);
+#undef UH_ZFUSED
+  const int tiles = (nkx + 15) / 16;
+  fft_launch_lines<1>((float2 *)g, ly, nkx, 3 * nz, st);
+  (void)tiles;
+  return 0;
+}
+// inverse x transform of the three components: into the planar real grids in place, or into the gather's interleaved float4 grid
+static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st) {
+  const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nh = nx / 2;
+  const int rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * nz;
+  hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
+                     g, f->planeReal, ilog2_exact(nx), nrows, rows, inter);
+  return 0;
 }
 
 static int fcm_make_plans(FCM *f) {
@@ -924,6 +1053,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   void *bufs[1] = {g};
   const size_t zs = (size_t)f->nxpad * f->grid.cellDim.y;  // planar component grids: z stride = one xy plane
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
+  const bool custom = stage == 0 && fcm_custom_fft_usable(f);  // (stage 1 exports the Fourier grid, which the fused z pass never stores)
   FcmPrep pr{};
   if (tiles) {
     if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr)) return e;
@@ -938,7 +1068,8 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
                          (float *)nullptr, g, N, f->grid, f->nxpad, f->planeReal, zs, f->kern, dsx, dsxy, false);
     }
-    UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+    if (custom) { if (int e = fcm_fft_forward_xy(f, g, st)) return e; }
+    else UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
   }
   float noisePrefactor = 0.0f;
   if (temperature > 0.0f) {  // addBrownianNoise, FCM_impl.cuh:514-542
@@ -952,11 +1083,17 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   const int total = (int)f->planeCplx;
   const KLayout lay{f->grid.cellDim.y, 0, f->planeCplx, (size_t)(f->grid.cellDim.x / 2 + 1) * f->grid.cellDim.y,
                     make_fastdiv(f->grid.cellDim.x / 2 + 1), make_fastdiv(f->grid.cellDim.y)};
-  hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, lay,
-                     f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
-                     d_force != nullptr, noisePrefactor, f->par.seed, f->seed2, f->pse);
-  if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
-  UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
+  if (custom) {
+    if (int e = fcm_fft_z_operator_y(f, g, d_force != nullptr, noisePrefactor, st)) return e;
+  } else {
+    hipLaunchKernelGGL(k_fcm_kspace, dim3((total + 255) / 256), dim3(256), 0, st, (float2 *)g, lay,
+                       f->grid.cellDim, real3f{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]}, f->par.viscosity,
+                       d_force != nullptr, noisePrefactor, f->par.seed, f->seed2, f->pse);
+    if (stage == 1) { UH_CHECK(hipGetLastError()); return 0; }
+    UH_ROCFFT(rocfft_execute(f->inv, bufs, nullptr, f->info));
+  }
+  const bool interPath = tiles && f->interGather && !(tiles && (f->kern.support.x <= 6 && f->kern.support.y <= 6 && f->kern.support.z <= 6) && f->tileGather);
+  if (custom && !interPath) { if (int e = fcm_fft_inverse_x(f, g, nullptr, st)) return e; }
   const bool smallSupport = f->kern.support.x <= 6 && f->kern.support.y <= 6 && f->kern.support.z <= 6;
   if (tiles && smallSupport && f->tileGather)
     hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), bp, 0, st, d_linearVelocity,
@@ -965,8 +1102,11 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   else if (tiles && f->interGather) {
     const size_t nodes = (size_t)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z;
     if (int e = f->interBuf.reserve(sizeof(float4) * nodes)) return e;
-    hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
-                       f->planeReal, zs, (float4 *)f->interBuf.ptr);
+    if (custom) {  // the inverse x transform writes the interleaved grid itself
+      if (int e = fcm_fft_inverse_x(f, g, (float4 *)f->interBuf.ptr, st)) return e;
+    } else
+      hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
+                         f->planeReal, zs, (float4 *)f->interBuf.ptr);
     hipLaunchKernelGGL(k_fcm_gather_inter, gp, bp, 0, st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim,
                        f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
   } else if (tiles)
@@ -984,6 +1124,8 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
   if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
+  if (std::string(name) == "z_tile_log2" && (value == 0 || value == 3 || value == 4)) { reinterpret_cast<FCM *>(h)->zTileLog2 = value; return 0; }
+  if (std::string(name) == "custom_fft") { reinterpret_cast<FCM *>(h)->customFFT = value != 0; return 0; }
   set_last_error("uammd_fcm_set_option: unknown option %s", name);
   return -1;
 }

@@ -1,0 +1,216 @@
+// Batched 3-D real FFT for the FCM solver on power-of-two grids, written for gfx950: five passes over the grid instead of the eight
+// of rocFFT (three per transform) + the Fourier-space kernel + the interleaving copy, with the z transform, the Stokes / noise
+// operator and the inverse z transform fused into one kernel that holds a tile of z-lines in LDS.
+//
+// Replaces, for nx, ny, nz in {16 ... 512} powers of two (anything else keeps rocFFT):
+//   cufftExecR2C / cufftExecC2R (batched 3-D)                      Integrator/BDHI/FCM/FCM_impl.cuh:399-411, :544-581
+//   forceFourier2Vel + fourierBrownianNoise between them           FCM_impl.cuh:375-397, :437-512
+// Conventions are cuFFT's: forward exp(-i...), inverse exp(+i...), both unnormalised (1/N lives in the Stokes operator), the
+// imaginary parts of the kx = 0 and kx = nx/2 self-conjugate inputs of the C2R are ignored.
+//
+//   k_fft_x_r2c        rows: nx reals -> nx/2 + 1 complex in place (one complex FFT of nx/2 points + untangling), 16 rows per workgroup
+//   k_fft_lines        y: strided lines of a z-plane, a tile of <= 16 consecutive kx per workgroup (contiguous 8 tl-byte segments)
+//   k_fft_z_fused      z: a tile of consecutive (ky, kx) nodes x all nz x the three components in LDS: forward, operator, inverse
+//   k_fft_x_c2r        rows back: three components of 16 rows -> the planar real grids or the gather's interleaved float4 grid
+// All FFTs are Stockham autosort (radix 4, one radix-2 pass for odd log2) on LDS lines; a pass stages its butterflies in registers
+// (read all, barrier, write all, barrier), twiddles from a table in LDS.
+#pragma once
+// (included by fcm.hip INSIDE namespace uammd_hip, after the Fourier-space operator it fuses)
+
+constexpr int kFftThreads = 256;
+constexpr int kFftMaxLog2 = 9;  // 512
+
+UH_D float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+UH_D float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * w (SIGN < 0) or a * conj(w) (SIGN > 0), w = exp(-2 pi i k / N) from the table
+template <int SIGN> UH_D float2 ctw(float2 a, float2 w) {
+  if (SIGN < 0) return make_float2(fmaf(a.x, w.x, -(a.y * w.y)), fmaf(a.x, w.y, a.y * w.x));
+  return make_float2(fmaf(a.x, w.x, a.y * w.y), fmaf(a.y, w.x, -(a.x * w.y)));
+}
+
+// exp(-2 pi i k / n), k < n, into LDS (n <= 512: sincospif is exact enough and runs once per workgroup)
+template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int tid) {
+  for (int k = tid; k < n; k += NT) {
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)n, &s, &c);
+    tw[k] = make_float2(c, s);
+  }
+}
+
+// One Stockham pass of radix R over `nlines` lines of N = 2^LOG2N points at buf[line * LS + j]; the sub-transforms entering the pass
+// have 2^LOG2NS points.  tw holds exp(-2 pi i k / NT) for k < NT, NT = N << LOG2TWSHIFT... (twStride = NT / N).
+template <int R, int SIGN, int MAXB, int NT>
+UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
+  constexpr int LR = R == 4 ? 2 : 1;
+  const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
+  float2 v[MAXB][R];
+  int dst[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = tid + q * NT;
+    dst[q] = -1;
+    if (b < total) {
+      const int line = b >> (log2N - LR), j = b & (per - 1), k = j & (Ns - 1);
+      const float2 *p = buf + line * LS + j;
+      const int t1 = (k << (log2N - log2Ns - LR)) * twStride;  // index of exp(-2 pi i k / (Ns R)) in the table
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[q][r] = p[r * per];
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[q][r] = ctw<SIGN>(v[q][r], tw[t1 * r]);
+      if (R == 2) {
+        const float2 a = v[q][0], c = v[q][1];
+        v[q][0] = cadd(a, c);
+        v[q][1] = csub(a, c);
+      } else {
+        const float2 a0 = cadd(v[q][0], v[q][2]), a1 = csub(v[q][0], v[q][2]), a2 = cadd(v[q][1], v[q][3]);
+        const float2 d = csub(v[q][1], v[q][3]);
+        const float2 a3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);  // -i d (forward), +i d (inverse)
+        v[q][0] = cadd(a0, a2);
+        v[q][1] = cadd(a1, a3);
+        v[q][2] = csub(a0, a2);
+        v[q][3] = csub(a1, a3);
+      }
+      dst[q] = line * LS + ((j - k) << LR) + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q)
+    if (dst[q] >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[dst[q] + r * Ns] = v[q][r];
+    }
+  __syncthreads();
+}
+
+// N-point FFTs of `nlines` LDS lines (N = 2^log2N <= 512, nlines * N / 4 <= MAXB * 256).  The caller has synchronised its writes.
+template <int SIGN, int MAXB, int NT = kFftThreads>
+UH_D void fft_lds(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
+  int s = 0;
+  if (log2N & 1) {  // the radix-2 pass first (its twiddles are all 1): twice the butterflies of a radix-4 pass
+    fft_pass<2, SIGN, 2 * MAXB, NT>(buf, LS, log2N, 0, nlines, tw, twStride, tid);
+    s = 1;
+  }
+  for (; s < log2N; s += 2) fft_pass<4, SIGN, MAXB, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
+}
+
+// ---- rows: R2C in place -------------------------------------------------------------------------------------------------------------
+// g: rows of nxpad = nx + 2 floats, `nrows` of them back to back (the three planar component grids are contiguous).
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g, int log2nx, int nrows, int rowsPerBlock) {
+  extern __shared__ float2 lds[];
+  const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  float2 *tw = lds, *buf = lds + nx;
+  const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);
+  fft_twiddles(tw, nx, tid);
+  for (int i = tid; i < nr * nh; i += kFftThreads) {
+    const int r = i >> (log2nx - 1), j = i & (nh - 1);
+    buf[r * LS + j] = *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
+  }
+  __syncthreads();
+  fft_lds<-1, 2>(buf, LS, log2nx - 1, nr, tw, 2, tid);
+  // untangle: X_k = E_k + W^k O_k, E_k = (Z_k + conj Z_{nh-k}) / 2, O_k = (Z_k - conj Z_{nh-k}) / (2i), k = 0 .. nh (Z_nh = Z_0)
+  // (k runs over 0 .. nh/2: nh/2 values through the bit mask + the middle one, k = nh/2, done by the threads that draw k = 0)
+  for (int i = tid; i < nr * (nh / 2); i += kFftThreads) {
+    const int r = i >> (log2nx - 2), k = i & (nh / 2 - 1);
+    float2 *row = buf + r * LS;
+    if (k == 0) {
+      const float2 m = row[nh / 2];
+      row[nh / 2] = make_float2(m.x, -m.y);  // X_{nh/2} = conj Z_{nh/2}
+      const float2 z = row[0];
+      row[0] = make_float2(z.x + z.y, 0.0f);
+      row[nh] = make_float2(z.x - z.y, 0.0f);
+    } else {
+      const float2 a = row[k], b = row[nh - k];
+      const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // E_k
+      const float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));  // O_k = (a - conj b) / (2i)
+      const float2 wo = ctw<-1>(o, tw[k]);
+      row[k] = cadd(e, wo);
+      // X_{nh-k} = conj(E_k - W^k O_k)
+      row[nh - k] = make_float2(e.x - wo.x, -(e.y - wo.y));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nr * nh; i += kFftThreads) {
+    const int r = i >> (log2nx - 1), k = i & (nh - 1);
+    *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * k) = buf[r * LS + k];
+    if (k == 0) *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * nh) = buf[r * LS + nh];
+  }
+}
+
+// ---- strided lines (the y transform) ---------------------------------------------------------------------------------------------------
+// group = one (component, z) plane of ny x nkx complex; tile = 16 consecutive kx (the last tile of a plane is narrower); element j of
+// line l at group * ny * nkx + j * nkx + kx0 + l.  Thread (l = tid & 15, jg = tid >> 4) moves elements j = jg + 16 it of line l: 128-byte
+// segments, no integer division.
+template <int SIGN, int MAXB, int NT>
+__global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int log2n, int nkx, int tilesPerGroup) {
+  extern __shared__ float2 lds[];
+  const int n = 1 << log2n, LS = n + 1;
+  float2 *tw = lds, *buf = lds + n;
+  const int tid = threadIdx.x, group = blockIdx.x / tilesPerGroup, tile = blockIdx.x - group * tilesPerGroup;
+  const int kx0 = tile * 16, nl = min(16, nkx - kx0), l = tid & 15, jg = tid >> 4;
+  float2 *base = g + (size_t)group * n * nkx + kx0 + l;
+  fft_twiddles<NT>(tw, n, tid);
+  if (l < nl)
+    for (int j = jg; j < n; j += NT / 16) buf[l * LS + j] = base[(size_t)j * nkx];
+  __syncthreads();
+  fft_lds<SIGN, MAXB, NT>(buf, LS, log2n, nl, tw, 1, tid);
+  if (l < nl)
+    for (int j = jg; j < n; j += NT / 16) base[(size_t)j * nkx] = buf[l * LS + j];
+}
+
+// ---- rows back: C2R of the three components ---------------------------------------------------------------------------------------------
+// gc: planar complex grids (component stride planeC); output either the planar real grids in place (inter == nullptr) or the gather's
+// interleaved float4 grid inter[(z ny + y) nx + x] = (vx, vy, vz, 0).
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t planeReal, int log2nx, int nrows,
+                                                           int rowsPerBlock, float4 *__restrict__ inter) {
+  extern __shared__ float2 lds[];
+  const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  float2 *tw = lds, *buf = lds + nx;
+  const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);  // rows x 3 components
+  fft_twiddles(tw, nx, tid);
+  for (int c = 0; c < 3; ++c)
+    for (int i = tid; i < nr * nh; i += kFftThreads) {
+      const int r = i >> (log2nx - 1), k = i & (nh - 1);
+      const float *row = g + (size_t)c * planeReal + (size_t)(r0 + r) * nxpad;
+      buf[(c * nr + r) * LS + k] = *(const float2 *)(row + 2 * k);
+      if (k == 0) buf[(c * nr + r) * LS + nh] = *(const float2 *)(row + 2 * nh);
+    }
+  __syncthreads();
+  // Z_k = (X_k + conj X_{nh-k}) + i W^{-k} (X_k - conj X_{nh-k}), k = 0 .. nh - 1
+  for (int i = tid; i < 3 * nr * (nh / 2); i += kFftThreads) {
+    const int line = i >> (log2nx - 2), k = i & (nh / 2 - 1);
+    float2 *row = buf + line * LS;
+    if (k == 0) {
+      const float a = row[0].x, b = row[nh].x;
+      row[0] = make_float2(a + b, a - b);
+      const float2 m = row[nh / 2];
+      row[nh / 2] = make_float2(2.0f * m.x, -2.0f * m.y);  // Z_{nh/2} = 2 conj X_{nh/2}
+    } else {
+      const float2 a = row[k], b = row[nh - k];
+      const float2 s = make_float2(a.x + b.x, a.y - b.y);   // X_k + conj X_{nh-k}
+      const float2 d = make_float2(a.x - b.x, a.y + b.y);   // X_k - conj X_{nh-k}
+      const float2 wd = ctw<1>(d, tw[k]);                   // W^{-k} d
+      const float2 iwd = make_float2(-wd.y, wd.x);
+      row[k] = cadd(s, iwd);
+      row[nh - k] = make_float2(s.x - iwd.x, -(s.y - iwd.y));  // Z_{nh-k} = conj(s) + i W^{k} conj(d)
+    }
+  }
+  __syncthreads();
+  fft_lds<1, 2>(buf, LS, log2nx - 1, 3 * nr, tw, 2, tid);
+  if (inter) {
+    for (int i = tid; i < nr * nh; i += kFftThreads) {
+      const int r = i >> (log2nx - 1), j = i & (nh - 1);
+      const float2 vx = buf[r * LS + j], vy = buf[(nr + r) * LS + j], vz = buf[(2 * nr + r) * LS + j];
+      float4 *o = inter + (size_t)(r0 + r) * nx + 2 * j;
+      o[0] = make_float4(vx.x, vy.x, vz.x, 0.0f);
+      o[1] = make_float4(vx.y, vy.y, vz.y, 0.0f);
+    }
+  } else {
+    for (int c = 0; c < 3; ++c)
+      for (int i = tid; i < nr * nh; i += kFftThreads) {
+        const int r = i >> (log2nx - 1), j = i & (nh - 1);
+        *(float2 *)(g + (size_t)c * planeReal + (size_t)(r0 + r) * nxpad + 2 * j) = buf[(c * nr + r) * LS + j];
+      }
+  }
+}
+
