@@ -80,6 +80,10 @@ int uammd_celllist_check_errors(uammd_celllist *h, void *stream);
  * kernels) is launched through hipExtLaunchKernel with a start / stop event pair attached to its own dispatch, and
  * uammd_lj_profile_read returns the summed kernel time (ms) and the number of launches since the enable.  bench.py derives
  * roofline.achieved from it: every launch of the timed region, no events between kernels. */
+/* Slab decomposition (new design, the reference is single GPU): the positions a rank sends to its two z neighbours —
+ * d_outUp[k] = pos[idxUp[k]] + (0, 0, dzUp), d_outDown[k] = pos[idxDown[k]] + (0, 0, dzDown) — in one launch. */
+int uammd_halo_pack(const float *d_pos, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown,
+                    float *d_outUp, float *d_outDown, void *stream);
 int uammd_lj_profile_enable(uammd_celllist *h, int enable);
 int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the

@@ -64,7 +64,7 @@ def _single_domain():
     return f0, p, v
 
 
-def _worker(rank, world, port, out_dir, skin=0.0, every=1):
+def _worker(rank, world, port, out_dir, skin=0.0, every=1, persistent=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,7 +85,10 @@ def _worker(rank, world, port, out_dir, skin=0.0, every=1):
             pn, vn, fn = p.numpy(), v.numpy(), f.numpy()
             o.verletnvt_gj(step, pn, vn, fn, DT, 0.0, 0.0, step_num, 1)
 
-        sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=every)
+        def forces_into(allpos, box_L, periodic, fall):   # persistent-buffer mode: accumulate into the step's own force buffer
+            fall += forces_fn(allpos, box_L, periodic)
+
+        sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=every, forces_into=forces_into if persistent else None)
         f0 = sim.compute_forces(lpos).clone()
         ids0 = ids.clone()
         nmig = 0
@@ -104,12 +107,13 @@ def _worker(rank, world, port, out_dir, skin=0.0, every=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,skin,every", [(2, 0.0, 1), (3, 0.0, 1), (2, 0.1, 3), (3, 0.1, 2)])
-def test_slab_decomposition_matches_single_domain(world, skin, every, tmp_path):
+@pytest.mark.parametrize("world,skin,every,persistent", [(2, 0.0, 1, False), (3, 0.0, 1, False), (2, 0.15, 3, False), (3, 0.15, 2, False),
+                                                         (2, 0.15, 3, True), (3, 0.15, 2, True), (2, 0.0, 1, True)])
+def test_slab_decomposition_matches_single_domain(world, skin, every, persistent, tmp_path):
     """skin > 0: ownership and halo membership refreshed every `every` steps, cached lists in between (no size messages)."""
     f0_ref, p_ref, v_ref = _single_domain()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), skin, every), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), skin, every, persistent), nprocs=world, join=True)
     seen0, seen, nmig = [], [], 0
     fmax = np.abs(f0_ref).max()
     Lz = L[2]

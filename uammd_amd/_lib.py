@@ -88,6 +88,7 @@ SIGNATURES = {
     "uammd_celllist_update": (_i, [_vp, _vp, _i, _f3, _i3, _i3, _vp]),
     "uammd_celllist_get": (_i, [_vp, C.POINTER(CellListData)]),
     "uammd_celllist_check_errors": (_i, [_vp, _vp]),
+    "uammd_halo_pack": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "uammd_lj_profile_enable": (_i, [_vp, _i]),
     "uammd_lj_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),

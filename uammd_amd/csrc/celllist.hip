@@ -680,6 +680,34 @@ int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int e
   return 0;
 }
 
+// ---- slab decomposition: halo packing -------------------------------------------------------------------------------------
+// out[k] = pos[idx[k]] with z shifted into the receiver's frame, both faces in one launch (new design, SURVEY 8e: the reference
+// is single GPU).  Replaces two index_select + two in-place adds of the Python glue.
+__global__ void __launch_bounds__(kBlock) k_halo_pack(const float4 *__restrict__ pos, const int *__restrict__ idxUp, int nUp,
+                                                      const int *__restrict__ idxDown, int nDown, float dzUp, float dzDown,
+                                                      float4 *__restrict__ outUp, float4 *__restrict__ outDown) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < nUp) {
+    float4 p = pos[idxUp[t]];
+    p.z += dzUp;
+    outUp[t] = p;
+  } else if (t < nUp + nDown) {
+    float4 p = pos[idxDown[t - nUp]];
+    p.z += dzDown;
+    outDown[t - nUp] = p;
+  }
+}
+
+int uammd_halo_pack(const float *d_pos, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown,
+                    float *d_outUp, float *d_outDown, void *stream) {
+  if (nUp < 0 || nDown < 0) { set_last_error("uammd_halo_pack: negative count"); return -1; }
+  if (nUp + nDown == 0) return 0;
+  hipLaunchKernelGGL(k_halo_pack, dim3(nblocks(nUp + nDown)), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)d_pos, d_idxUp, nUp,
+                     d_idxDown, nDown, dzUp, dzDown, (float4 *)d_outUp, (float4 *)d_outDown);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream) {
   UH_CHECK(hipMemsetAsync(d_ptr, 0, bytes, (hipStream_t)stream));
   return 0;

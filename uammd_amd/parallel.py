@@ -160,6 +160,80 @@ class SlabDecomposition:
         from_down, from_up = self._exchange(send_up, send_down, n_from_down, n_from_up)
         return torch.cat([pos_local, from_down, from_up], dim=0), n_from_down + n_from_up
 
+    def halo_refresh_into(self, allpos, n_owned):
+        """Refresh of the membership lists on a persistent buffer: rows [0, n_owned) of `allpos` are the owned particles; the
+        ghosts are written behind them.  Returns the number of ghosts.  One host read (the four message sizes)."""
+        half = 0.5 * self.width
+        reach = self.rc + 3.0 * self.skin
+        z = allpos[:n_owned, 2]
+        up_mask = z >= half - reach
+        down_mask = z < -half + reach
+        n_up, n_down, n_from_down, n_from_up = self._counts(up_mask, down_mask)
+        assert n_owned + n_from_down + n_from_up <= allpos.shape[0], "the halo overflows the position buffer"
+        self._halo_cache = (self._index(up_mask, n_up), self._index(down_mask, n_down), n_from_down, n_from_up)
+        self._idx32 = None
+        self.halo_refill(allpos, n_owned)
+        return n_from_down + n_from_up
+
+    def halo_refill(self, allpos, n_owned):
+        """Between refreshes: rows [0, n_owned) of `allpos` are the owned particles (integrated in place), rows [n_owned, ...)
+        the ghosts of the last refresh in the order (from below, from above).  Re-sends the current positions of the listed
+        particles and lets the ghosts land in the tail of `allpos` itself: no concatenation, no allocation, nothing
+        synchronises.  On the GPU the two gathers + frame shifts are one kernel (uammd_halo_pack)."""
+        idx_up, idx_down, n_from_down, n_from_up = self._halo_cache
+        n_up, n_down = idx_up.shape[0], idx_down.shape[0]
+        pos = allpos[:n_owned]
+        tail_down = allpos[n_owned:n_owned + n_from_down]
+        tail_up = allpos[n_owned + n_from_down:n_owned + n_from_down + n_from_up]
+        loop = self.world == 1          # the only rank is its own neighbour: what goes up arrives from below
+        if allpos.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            if loop:
+                out_up, out_down = tail_down, tail_up
+            else:
+                if getattr(self, "_send", None) is None or self._send[0].shape[0] < n_up or self._send[1].shape[0] < n_down:
+                    self._send = (torch.empty((max(n_up, 1), 4), dtype=torch.float32, device=allpos.device),
+                                  torch.empty((max(n_down, 1), 4), dtype=torch.float32, device=allpos.device))
+                out_up, out_down = self._send[0][:n_up], self._send[1][:n_down]
+            if getattr(self, "_idx32", None) is None or self._idx32[2] is not idx_up:  # (int32 copies of the lists, once per refresh)
+                self._idx32 = (idx_up.to(torch.int32), idx_down.to(torch.int32), idx_up)
+            _lib.check(lib.uammd_halo_pack(pos.data_ptr(), self._idx32[0].data_ptr(), n_up, self._idx32[1].data_ptr(), n_down,
+                                           -self.width, self.width, out_up.data_ptr(), out_down.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+            if loop:
+                return
+            send_up, send_down = out_up, out_down
+        else:
+            send_up = pos.index_select(0, idx_up)
+            send_down = pos.index_select(0, idx_down)
+            send_up[:, 2] -= self.width
+            send_down[:, 2] += self.width
+            if loop:
+                tail_down.copy_(send_up)
+                tail_up.copy_(send_down)
+                return
+        send_up, send_down = self._wire(send_up), self._wire(send_down)
+        staged = send_up.device != allpos.device      # gloo with device tensors (debugging aid): receive on the host, copy back
+        rdown = torch.empty((n_from_down, 4), dtype=torch.float32, device=send_up.device) if staged else tail_down
+        rup = torch.empty((n_from_up, 4), dtype=torch.float32, device=send_up.device) if staged else tail_up
+        t1, t2 = (1, 2) if self.world == 2 else (0, 0)
+        ops = []
+        if n_up > 0:
+            ops.append(dist.P2POp(dist.isend, send_up.contiguous(), self.up, self.group, tag=t1))
+        if n_from_down > 0:
+            ops.append(dist.P2POp(dist.irecv, rdown, self.down, self.group, tag=t1))
+        if n_down > 0:
+            ops.append(dist.P2POp(dist.isend, send_down.contiguous(), self.down, self.group, tag=t2))
+        if n_from_up > 0:
+            ops.append(dist.P2POp(dist.irecv, rup, self.up, self.group, tag=t2))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            tail_down.copy_(rdown)
+            tail_up.copy_(rup)
+
     # ---- migration ------------------------------------------------------------------------------------------
     def migrate(self, pos_local, *others):
         """Moves the particles that left the slab (|z'| > width/2 after integration) to the neighbour ranks together
@@ -192,6 +266,60 @@ class SlabDecomposition:
             out.append(block.reshape((new.shape[0],) + tuple(ref.shape[1:])).contiguous())
         return tuple(out)
 
+    def migrate_inplace(self, bufs, n):
+        """The same migration on persistent buffers, touching only the rows that change.  `bufs` = per-particle arrays with spare
+        capacity (rows beyond n are scratch: the ghost tail of the position buffer, ...), the first one the positions in the
+        local frame.  Leavers are packed and sent; arrivals fill the holes they leave; if more left than arrived the remaining
+        holes are filled from the tail, if more arrived they are appended.  Returns the new number of owned rows.  The order of
+        the owned particles changes (ids travel with them).  One host read (the four message sizes); everything else is
+        asynchronous work on index lists of a few thousand rows instead of gathers of the whole arrays."""
+        pos = bufs[0]
+        z = pos[:n, 2]
+        half = 0.5 * self.width
+        go_up = z >= half
+        go_down = z < -half
+        n_up, n_down, n_from_down, n_from_up = self._counts(go_up, go_down)
+        self._halo_cache = None
+        n_leave, n_arrive = n_up + n_down, n_from_down + n_from_up
+        if n_leave == 0 and n_arrive == 0:
+            return n
+        idx_up, idx_down = self._index(go_up, n_up), self._index(go_down, n_down)
+        cols = [(b.to(torch.int32).view(torch.float32) if b.dtype != torch.float32 else b) for b in bufs]
+        widths = [c.reshape(c.shape[0], -1).shape[1] for c in cols]
+        up_rows = torch.cat([c.reshape(c.shape[0], -1).index_select(0, idx_up) for c in cols], dim=1)
+        down_rows = torch.cat([c.reshape(c.shape[0], -1).index_select(0, idx_down) for c in cols], dim=1)
+        up_rows[:, 2] -= self.width
+        down_rows[:, 2] += self.width
+        from_down, from_up = self._exchange(up_rows, down_rows, n_from_down, n_from_up)
+        arrivals = torch.cat([from_down, from_up], dim=0)
+        holes = torch.cat([idx_up, idx_down]).sort().values          # ascending
+        new_n = n - n_leave + n_arrive
+        assert new_n <= min(b.shape[0] for b in bufs), "migration overflows the particle buffers"
+        if n_arrive >= n_leave:
+            dest = torch.cat([holes, torch.arange(n, new_n, device=pos.device, dtype=holes.dtype)])
+            src_rows = arrivals
+        else:
+            k = n_leave - n_arrive
+            dest_a = holes[:n_arrive]
+            rest = holes[n_arrive:]                                   # k holes still open
+            # pair the open holes below new_n with the rows of the tail [new_n, n) that stay: both lists have the same (host-unknown)
+            # length m <= k; sorted so that they come first, the other k - m pairs copy dropped rows onto dropped rows
+            leaving = go_up | go_down
+            tail = torch.arange(new_n, n, device=pos.device, dtype=holes.dtype)
+            tail = tail[torch.argsort(leaving[new_n:n].to(torch.int8), stable=True)]
+            rest = rest[torch.argsort((rest >= new_n).to(torch.int8), stable=True)]
+            packed_tail = torch.cat([c.reshape(c.shape[0], -1).index_select(0, tail) for c in cols], dim=1)
+            dest = torch.cat([dest_a, rest])
+            src_rows = torch.cat([arrivals, packed_tail], dim=0)
+        c0 = 0
+        for b, c, w in zip(bufs, cols, widths):
+            block = src_rows[:, c0:c0 + w].contiguous()
+            c0 += w
+            if b.dtype != torch.float32:
+                block = block.view(torch.int32).to(b.dtype)
+            b.reshape(b.shape[0], -1).index_copy_(0, dest, block.reshape(block.shape[0], -1))
+        return new_n
+
     # ---- distribution of an initial configuration ------------------------------------------------------------
     def scatter_initial(self, pos_global):
         """Every rank passes the same global configuration; returns the owned subset in the local frame + global ids."""
@@ -203,42 +331,129 @@ class SlabDecomposition:
 class DistributedLJ:
     """VerletNVT::GronbechJensen + PairForces<LJ> on a z-slab decomposition.  `forces_fn(pos_all, box_L, box_periodic)`
     returns real4 forces for every row of pos_all (owned + ghosts); `integrate_fn(step, pos, vel, force, step_num)` is
-    the GJ kernel on the owned particles."""
+    the GJ kernel on the owned particles.
 
-    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1):
-        self.d, self.forces_fn, self.integrate_fn = decomp, forces_fn, integrate_fn
+    With `forces_into(pos_all, box_L, box_periodic, force_all)` (accumulates into the given buffer) the step works on
+    PERSISTENT buffers with spare capacity: the owned positions are integrated in place at the head of one buffer whose tail
+    receives the ghosts, forces accumulate into the rows GJ step 1 has just zeroed (GronbechJensen.cu:55-57), a refresh moves
+    only the particles that change rank (SlabDecomposition.migrate_inplace).  Nothing is allocated or concatenated per step;
+    a refresh costs two host reads of message sizes."""
+
+    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25):
+        self.d, self.forces_fn, self.integrate_fn, self.forces_into = decomp, forces_fn, integrate_fn, forces_into
         self.steps = 0
         self.exchange_every = int(exchange_every) if decomp.skin > 0 else 1
-        self.max_drift = None   # device scalar: largest excursion outside the slab seen at a refresh (skin check)
+        self.capacity_factor = capacity_factor
+        self.max_drift = None   # device scalar: largest displacement of an owned particle between two refreshes (skin check)
+        self._allpos = None     # owned + ghost positions of the current membership lists
+        self._fall = None       # forces for the same rows
+        self._ref = None        # owned positions at the last refresh
+        self._bufs = None       # persistent mode: [pos (owned + ghosts), vel, ids, force] with spare rows
+        self._nall = 0
 
+    # ---- generic mode (any backend, allocates per step) ---------------------------------------------------------------------
     def compute_forces(self, pos_local, refresh=True):
-        allpos, nghost = self.d.halo_exchange(pos_local, refresh)
         L, per = self.d.local_box()
-        self.n_owned = pos_local.shape[0]  # rows [n_owned, ...) of allpos are ghosts: forces_fn may skip their forces
-        f = self.forces_fn(allpos, L, per)
-        return f[:pos_local.shape[0]]
+        n = pos_local.shape[0]
+        self.n_owned = n  # rows [n_owned, ...) are ghosts: the force callbacks may skip their forces
+        if refresh or self._allpos is None:
+            self._allpos, _ = self.d.halo_exchange(pos_local, True)
+        else:
+            self.d.halo_refill(self._allpos, n)
+        return self.forces_fn(self._allpos, L, per)[:n]
+
+    def _track_drift(self, pos):
+        if self.d.skin > 0 and self._ref is not None and self._ref.shape[0] == pos.shape[0]:
+            # the cached exchange is exact while NO particle has moved more than the skin since the membership lists were made
+            # (an in-slab particle that crosses the skin towards a face is missing from the lists just as well)
+            moved = (pos[:, :3] - self._ref[:, :3]).norm(dim=1).max()
+            self.max_drift = moved if self.max_drift is None else torch.maximum(self.max_drift, moved)
 
     def forward_time(self, pos, vel, force, ids):
-        """One step; returns the (possibly re-sized) owned arrays."""
+        """One step; returns the (possibly re-sized) owned arrays (views of the step's own buffers in persistent mode: pass
+        back what the previous call returned)."""
+        if self.forces_into is not None:
+            return self._forward_persistent(pos, vel, force, ids)
         self.steps += 1
         if self.steps == 1:
             force = self.compute_forces(pos)
+            pos = self._allpos[:pos.shape[0]]
+            if self.d.skin > 0:
+                self._ref = pos.clone()
         self.integrate_fn(1, pos, vel, force, self.steps)
-        refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
+        refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None or self._allpos is None
         if refresh:
-            if self.d.skin > 0:  # how far outside its slab did the worst particle get since the last refresh?
-                self.max_drift = (pos[:, 2].abs().max() - 0.5 * self.d.width).clamp(min=0.0)
+            self._track_drift(pos)
             pos, vel, ids = self.d.migrate(pos, vel, ids)
         force = self.compute_forces(pos, refresh)
+        if refresh:
+            pos = self._allpos[:pos.shape[0]]     # from here on the owned particles live at the head of the exchange buffer
+            if self.d.skin > 0:
+                self._ref = pos.clone()
         self.integrate_fn(2, pos, vel, force, self.steps)
         return pos, vel, force, ids
+
+    # ---- persistent mode ----------------------------------------------------------------------------------------------------------
+    def _adopt(self, pos, vel, ids):
+        """(Re)builds the persistent buffers from plain arrays (first step, after a sort of the owned particles)."""
+        n = pos.shape[0]
+        reach = self.d.rc + 3.0 * self.d.skin
+        ghosts = int(2.2 * n * reach / self.d.width) + 4096                      # both halos of a uniform density, with slack
+        cap = int(self.capacity_factor * n) + ghosts
+        dev = pos.device
+        bp = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
+        bv = torch.zeros((cap,) + tuple(vel.shape[1:]), dtype=vel.dtype, device=dev)
+        bi = torch.zeros((cap,) + tuple(ids.shape[1:]), dtype=ids.dtype, device=dev)
+        bf = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
+        bp[:n], bv[:n], bi[:n] = pos, vel, ids
+        self._bufs = [bp, bv, bi, bf]
+        self._ref = None
+        return n
+
+    def _refresh_persistent(self, n):
+        bp, bv, bi, bf = self._bufs
+        self._track_drift(bp[:n])
+        n = self.d.migrate_inplace([bp, bv, bi], n)
+        bf[:n].zero_()                                # arrivals and moved rows: GJ step 1 zeroed the forces of the old layout
+        g = self.d.halo_refresh_into(bp, n)
+        self._nall = n + g
+        if self.d.skin > 0:
+            self._ref = bp[:n].clone()
+        return n
+
+    def _forces_persistent(self, n):
+        bp, bv, bi, bf = self._bufs
+        L, per = self.d.local_box()
+        self.n_owned = n
+        self.forces_into(bp[:self._nall], L, per, bf[:self._nall])
+
+    def _forward_persistent(self, pos, vel, force, ids):
+        self.steps += 1
+        n = pos.shape[0]
+        if self._bufs is None or pos.data_ptr() != self._bufs[0].data_ptr():   # plain arrays handed in: first step, or after a sort
+            n = self._adopt(pos, vel, ids)
+            n = self._refresh_persistent(n)
+            self._forces_persistent(n)
+        bp, bv, bi, bf = self._bufs
+        self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
+        refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
+        if refresh:
+            n = self._refresh_persistent(n)
+        else:
+            self.d.halo_refill(bp, n)
+        self._forces_persistent(n)
+        self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
+        return bp[:n], bv[:n], bf[:n], bi[:n]
 
     def reordered(self):
         """Call after permuting the owned arrays (a sort): the cached membership lists index the old order."""
         self.d._halo_cache = None
+        self._allpos = None
+        self._ref = None
+        self._bufs = None
 
     def check_skin(self):
         """Host check (synchronises): the cached exchange is exact only if nobody out-ran the skin."""
         if self.max_drift is not None and float(self.max_drift) > self.d.skin:
-            raise RuntimeError(f"a particle moved {float(self.max_drift):.3f} outside its slab between refreshes, more than the "
-                               f"skin {self.d.skin}: lower exchange_every or raise the skin")
+            raise RuntimeError(f"a particle moved {float(self.max_drift):.3f} between refreshes of the halo membership lists, more "
+                               f"than the skin {self.d.skin}: lower exchange_every or raise the skin")
