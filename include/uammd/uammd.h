@@ -1621,5 +1621,43 @@ inline std::vector<real4> initLatticeSC(real3 L, uint N) {
   return pos;
 }
 
+// ---- multi-GPU (new: the reference is single GPU) -----------------------------------------------------------------------------------------
+// One process per GPU.  Rank 0 makes the 128-byte id (Comm::uniqueId) and hands it to the other processes by whatever the program
+// uses to start them (MPI_Bcast, a file, a socket); every process then constructs its Comm after selecting its device.  The ranks form
+// a periodic ring along z.  Thin RAII over uammd_comm_* (include/uammd_hip.h, RCCL over xGMI inside).
+class Comm {
+  uammd_comm *h = nullptr;
+public:
+  static std::vector<char> uniqueId() {
+    std::vector<char> id(128);
+    detail::check(uammd_comm_unique_id(id.data()));
+    return id;
+  }
+  Comm(int rank, int world, const std::vector<char> &id) {
+    if (id.size() != 128) throw std::runtime_error("Comm: the unique id has 128 bytes");
+    detail::check(uammd_comm_init(&h, rank, world, id.data()));
+  }
+  Comm(const Comm &) = delete;
+  ~Comm() { uammd_comm_destroy(h); }
+  int rank() const { return uammd_comm_rank(h); }
+  int world() const { return uammd_comm_world(h); }
+  uammd_comm *handle() { return h; }
+  // rows of `floatsPerRow` floats to rank + 1 / rank - 1, rows from rank - 1 / rank + 1 (asynchronous on st)
+  void haloExchange(const real *sendUp, int nUp, const real *sendDown, int nDown, real *recvFromDown, int nFromDown, real *recvFromUp,
+                    int nFromUp, int floatsPerRow, hipStream_t st = 0) {
+    detail::check(uammd_comm_halo_exchange(h, sendUp, nUp, sendDown, nDown, recvFromDown, nFromDown, recvFromUp, nFromUp, floatsPerRow, (void *)st));
+  }
+  // the two message sizes of a refresh (synchronises st)
+  void exchangeCounts(int toUp, int toDown, int &fromDown, int &fromUp, hipStream_t st = 0) {
+    const int to[2] = {toUp, toDown};
+    int from[2] = {0, 0};
+    detail::check(uammd_comm_exchange_counts(h, to, from, (void *)st));
+    fromDown = from[0];
+    fromUp = from[1];
+  }
+  void allToAll(const void *send, void *recv, size_t bytesPerPeer, hipStream_t st = 0) { detail::check(uammd_comm_alltoall(h, send, recv, bytesPerPeer, (void *)st)); }
+  void allReduceSum(real *buf, int n, hipStream_t st = 0) { detail::check(uammd_comm_allreduce_sum(h, buf, n, (void *)st)); }
+};
+
 }  // namespace uammd
 #endif

@@ -88,6 +88,15 @@ SIGNATURES = {
     "uammd_celllist_update": (_i, [_vp, _vp, _i, _f3, _i3, _i3, _vp]),
     "uammd_celllist_get": (_i, [_vp, C.POINTER(CellListData)]),
     "uammd_celllist_check_errors": (_i, [_vp, _vp]),
+    "uammd_comm_unique_id": (_i, [C.c_char_p]),
+    "uammd_comm_init": (_i, [C.POINTER(C.c_void_p), _i, _i, C.c_char_p]),
+    "uammd_comm_destroy": (_i, [_vp]),
+    "uammd_comm_rank": (_i, [_vp]),
+    "uammd_comm_world": (_i, [_vp]),
+    "uammd_comm_halo_exchange": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "uammd_comm_exchange_counts": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+    "uammd_comm_alltoall": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "uammd_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp]),
     "uammd_halo_pack": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "uammd_lj_profile_enable": (_i, [_vp, _i]),
     "uammd_lj_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
