@@ -249,6 +249,69 @@ def run_fcm_distributed(hip, args, world, rank, dist):
                          "algorithmic_bytes_per_step": nbytes}}
 
 
+def run_fcm_c5(hip, args, world, rank, dist):
+    """BASELINE configs[4] as it is named: BDHI::FCM, 2e5 particles, 256^3 grid, STRONG scaling — the same grid and particle count
+    at every N, cut into N z-slabs (256 / N planes + 8 halo planes each; all-to-all transposes of the 3-D FFT).  N = 1 is the
+    single-GPU solver on the whole grid."""
+    n_total, nc, T, dt = 200_000, 256, 1.0, 0.01
+    L, cells = float(nc), [nc] * 3
+    steps, warm = max(10, args.fcm_steps // 4), max(3, args.fcm_warmup // 4)
+    if world == 1 and not args.force_distributed:
+        pd, integ, _, _ = fcm_setup(hip, n_total, cells, L, seed=1234)
+        step = integ.forwardTime
+        nloc = n_total
+    else:
+        from uammd_amd.parallel_fcm import (DistributedFCM, DistributedFCMIntegrator, HipSlabBackend, SlabGeometry,
+                                            make_decomposition)
+        if nc % world:
+            return {"skipped": f"256 planes do not split into {world} slabs"}
+        kernel, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+        geom = SlabGeometry(cells, [L] * 3, world, kernel.support[2])
+        back = HipSlabBackend(geom, rank, kernel, 1.0, 1234)
+        d = make_decomposition(geom, rank)
+        nloc = n_total // world
+        rng = np.random.default_rng(1234 + rank)
+        pos = np.zeros((nloc, 4), np.float32)
+        pos[:, :2] = rng.uniform(-L / 2, L / 2, (nloc, 2))
+        pos[:, 2] = rng.uniform(-L / (2 * world), L / (2 * world), nloc)       # window frame: z relative to the slab centre
+        force = np.zeros((nloc, 4), np.float32)
+        force[:, :3] = np.random.default_rng(4321 + rank).normal(0, 1, (nloc, 3))
+        state = [torch.from_numpy(pos).cuda(), torch.arange(nloc, dtype=torch.int32, device="cuda") + rank * nloc,
+                 torch.from_numpy(force).cuda()]
+        integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, T, dt, lambda p, i, f: f, migrate_every=20)
+
+        def step():
+            state[0], state[1], state[2] = integ.forward_time(state[0], state[1], state[2])
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = el / steps * 1e3
+    nbytes = fcm_bytes_per_step(n_total, cells)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"metric": "FCM-BDHI steps/s @256^3 (2e5 particles, tol 1e-3, T=1), the whole job", "value": steps / el, "unit": "steps/s",
+            "ms_per_step": ms, "steps": steps, "warmup": warm, "scaling": "strong", "n_gpus": world,
+            "config": {"workload": f"BDHI::FCMIntegrator, grid 256^3, {n_total} particles, Gaussian support 6, fixed forces + Fourier-space "
+                                   f"noise (BASELINE configs[4]); " + ("single GPU" if world == 1 and not args.force_distributed else
+                                   f"{world} z-slabs of {nc // world} planes, halo planes by send/recv, 2 all-to-all transposes per step (RCCL)")},
+            "roofline": {"bound": "hbm", "kernel": "whole FCM step, all GPUs", "achieved": gbs, "peak": PEAK_HBM_GBS * world, "unit": "GB/s",
+                         "frac": gbs / (PEAK_HBM_GBS * world), "traffic": None, "algorithmic_bytes_per_step": nbytes}}
+
+
 def cpu_baseline_fcm(sample_steps):
     import oracle
     from oracle.fcm import FCMOracle
@@ -428,6 +491,7 @@ def main():
         out = (run_fcm_distributed if (world > 1 or args.force_distributed) else run_fcm)(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
+        out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
         out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic"})
         if rank == 0:
@@ -456,6 +520,7 @@ def main():
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
         if args.workload == "both":
             out["fcm"] = run_fcm_distributed(hip, args, world, rank, dist)
+            out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:
@@ -573,6 +638,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             fcm["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
         out["fcm"] = fcm
+        out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:

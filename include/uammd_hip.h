@@ -471,6 +471,10 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int number
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream); /* in place on the owned planes */
 int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
 int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream);
+/* the three calls above (forward z, operator, inverse z) in one pass over d_cplxZ when nz is a power of two; returns 1 (and does
+ * nothing) when the grid does not allow it */
+int uammd_fcm_slab_z_fused(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor, unsigned int seed2,
+                           void *stream);
 int uammd_fcm_slab_kspace(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor,
                           unsigned int seed2, void *stream);
 

@@ -177,6 +177,7 @@ SIGNATURES = {
     "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_slab_fft_z": (_i, [_vp, _vp, _i, _vp]),
     "uammd_fcm_slab_kspace": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),
+    "uammd_fcm_slab_z_fused": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),
     "uammd_pse_near_create": (_i, [_f3, _f, _f, _f, _f, _f, _u, C.POINTER(_vp), C.POINTER(_f), C.POINTER(_i)]),
     "uammd_pse_near_destroy": (_i, [_vp]),
     "uammd_pse_near_set_shear_strain": (_i, [_vp, _f]),

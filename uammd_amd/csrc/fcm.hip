@@ -676,16 +676,18 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
 // operator node by node, inverse z transform, store.  Replaces two strided rocFFT passes and k_fcm_kspace (three trips of the
 // 25.6 MB grid through memory at C4) by one.
 template <int LOG2TL, int NT>
-__global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size_t planeC, int log2nz, int3 nk, real3f L,
-                                                             float viscosity, bool haveForce, float noisePrefactor, uint seed1,
-                                                             uint seed2, PseGreens pse) {
+__global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size_t planeC, size_t zStride, int nyl, int y0, int log2nz,
+                                                    int3 nk, real3f L, float viscosity, bool haveForce, float noisePrefactor,
+                                                    uint seed1, uint seed2, PseGreens pse) {
   extern __shared__ float2 lds[];
   constexpr int TL = 1 << LOG2TL, JG = NT >> LOG2TL, MAXB = 6 * 256 / NT;
   const int nz = 1 << log2nz, LS = nz + 1, nkx = nk.x / 2 + 1;
   float2 *tw = lds, *buf = lds + nz;
   const int tid = threadIdx.x, l = tid & (TL - 1), jg = tid >> LOG2TL;
-  const size_t slab = (size_t)nk.y * nkx;  // complex per z plane
-  const int q0 = blockIdx.x * TL, nl = min(TL, (int)slab - q0);
+  // element (component c, plane j, line q) at c planeC + j zStride + q; q = yl nkx + kx runs over this rank's y rows [y0, y0 + nyl)
+  // (single GPU: the whole grid, zStride = ny nkx; slab decomposition: the y-pencil layout [z][c][yl][kx], zStride = 3 nyl nkx)
+  const size_t slab = zStride;
+  const int q0 = blockIdx.x * TL, nl = min(TL, nyl * nkx - q0);
   float2 *base = g + q0 + l;
   fft_twiddles<NT>(tw, nz, tid);
   if (haveForce) {
@@ -697,7 +699,7 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
   } else
     __syncthreads();
   if (l < nl) {
-    const int q = q0 + l, ky = q / nkx, kx = q - ky * nkx;
+    const int q = q0 + l, yl = q / nkx, kx = q - yl * nkx, ky = y0 + yl;
     for (int j = jg; j < nz; j += JG) {
       const int3 cell = make_int3(kx, ky, j);
       const int id = kx + nkx * (ky + nk.y * j);
@@ -786,28 +788,27 @@ static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   (void)tiles;
   return 0;
 }
-// z transform + Fourier-space operator + inverse z transform, then the inverse y transform
-static int fcm_fft_z_operator_y(FCM *f, float *g, bool haveForce, float noisePrefactor, hipStream_t st) {
-  const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1;
-  const int ly = ilog2_exact(ny), lz = ilog2_exact(nz);
-  const int slab = ny * nkx;
-  const real3f L{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]};
+// z transform + Fourier-space operator + inverse z transform on lines of the layout (planeC, zStride, nyl, y0) — see k_fft_z_fused
+static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStride, int nyl, int y0, int3 cells, real3f L, bool haveForce,
+                                  float noisePrefactor, uint seed2, hipStream_t st) {
+  const int nz = cells.z, nkx = cells.x / 2 + 1, lz = ilog2_exact(nz), lines = nyl * nkx;
   // tile of (ky, kx) nodes per workgroup: 3 tl nz complex in LDS and <= 6 radix-4 butterflies per thread and pass
   const int ltl = nz <= 128 ? (f->zTileLog2 > 0 ? f->zTileLog2 : 3) : (nz == 256 ? 3 : 2), tlz = 1 << ltl;  // measured at C4: 8 nodes x 512 threads
   const size_t ldsz = sizeof(float2) * (size_t)(nz + 3 * tlz * (nz + 1));
-  const int nt = 512;
-  const dim3 gz((slab + tlz - 1) / tlz), bz(nt);
-#define UH_ZFUSED(LT) if (nt == 512) hipLaunchKernelGGL((k_fft_z_fused<LT, 512>), gz, bz, ldsz, st, (float2 *)g, f->planeCplx, lz, f->grid.cellDim, L, f->par.viscosity, \
-                                         haveForce, noisePrefactor, f->par.seed, f->seed2, f->pse); \
-  else hipLaunchKernelGGL((k_fft_z_fused<LT, 256>), gz, bz, ldsz, st, (float2 *)g, f->planeCplx, lz, f->grid.cellDim, L, f->par.viscosity, \
-                                         haveForce, noisePrefactor, f->par.seed, f->seed2, f->pse)
+  const dim3 gz((lines + tlz - 1) / tlz), bz(512);
+#define UH_ZFUSED(LT) hipLaunchKernelGGL((k_fft_z_fused<LT, 512>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, lz, cells, L, f->par.viscosity, \
+                                         haveForce, noisePrefactor, f->par.seed, seed2, f->pse)
   if (ltl == 4) UH_ZFUSED(4);
   else if (ltl == 3) UH_ZFUSED(3);
   else UH_ZFUSED(2);
 #undef UH_ZFUSED
-  const int tiles = (nkx + 15) / 16;
-  fft_launch_lines<1>((float2 *)g, ly, nkx, 3 * nz, st);
-  (void)tiles;
+  return 0;
+}
+static int fcm_fft_z_operator_y(FCM *f, float *g, bool haveForce, float noisePrefactor, hipStream_t st) {
+  const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1;
+  const real3f L{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]};
+  if (int e = fcm_fft_z_fused_launch(f, (float2 *)g, f->planeCplx, (size_t)ny * nkx, ny, 0, f->grid.cellDim, L, haveForce, noisePrefactor, f->seed2, st)) return e;
+  fft_launch_lines<1>((float2 *)g, ilog2_exact(ny), nkx, 3 * nz, st);
   return 0;
 }
 // inverse x transform of the three components: into the planar real grids in place, or into the gather's interleaved float4 grid
@@ -815,7 +816,7 @@ static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nh = nx / 2;
   const int rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * nz;
   hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
-                     g, f->planeReal, ilog2_exact(nx), nrows, rows, inter);
+                     g, f->planeReal, (size_t)ny * f->nxpad, ilog2_exact(ny), ilog2_exact(nx), nrows, rows, inter);
   return 0;
 }
 
@@ -915,6 +916,9 @@ struct FCMSlab {
   }
 };
 
+static bool fcm_slab_custom_fft(const FCMSlab *s) {
+  return s->loc.customFFT && ilog2_exact(s->cells.x) >= 5 && ilog2_exact(s->cells.y) > 0;
+}
 static int fcm_slab_make_plans(FCMSlab *s) {
   std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
   FCM *f = &s->loc;
@@ -1269,8 +1273,17 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   if (!h || !d_grid) { set_last_error("uammd_fcm_slab_forward_xy: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;  // window layout [z][component][y][x]: the owned planes are one block
+  if (fcm_slab_custom_fft(s)) {
+    const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
+    hipLaunchKernelGGL(k_fft_x_r2c, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                       (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows);
+    fft_launch_lines<-1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+    UH_CHECK(hipGetLastError());
+    return 0;
+  }
   UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
-  void *io[1] = {(void *)(d_grid + (size_t)s->halo * 3 * s->loc.planeReal)};
+  void *io[1] = {(void *)owned};
   UH_ROCFFT(rocfft_execute(s->fwdXY, io, nullptr, s->loc.info));
   return 0;
 }
@@ -1279,8 +1292,19 @@ int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
 int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   if (!h || !d_grid) { set_last_error("uammd_fcm_slab_inverse_xy: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
+  if (fcm_slab_custom_fft(s)) {
+    const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * s->nzl;
+    fft_launch_lines<1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+    // rows (z, y) of the three components: component stride = one (ny x nxpad) plane, z stride = three of them
+    hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                       (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
+                       nrows, rows, (float4 *)nullptr);
+    UH_CHECK(hipGetLastError());
+    return 0;
+  }
   UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
-  void *io[1] = {(void *)(d_grid + (size_t)s->halo * 3 * s->loc.planeReal)};
+  void *io[1] = {(void *)owned};
   UH_ROCFFT(rocfft_execute(s->invXY, io, nullptr, s->loc.info));
   return 0;
 }
@@ -1292,6 +1316,29 @@ int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *s
   UH_ROCFFT(rocfft_execution_info_set_stream(s->loc.info, stream));
   void *io[1] = {d_cplxZ};
   UH_ROCFFT(rocfft_execute(inverse ? s->invZ : s->fwdZ, io, nullptr, s->loc.info));
+  return 0;
+}
+
+// z transform + Fourier-space operator + inverse z transform of d_cplxZ [z][c][yl][kx] in one pass (power-of-two nz; returns 1 when
+// the grid does not allow it: the caller then takes uammd_fcm_slab_fft_z / _kspace / _fft_z).  haveForce = 0: the buffer's content is
+// ignored (noise only).
+int uammd_fcm_slab_z_fused(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, float temperature, float prefactor, unsigned int seed2,
+                           void *stream) {
+  if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_z_fused: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  if (!s->loc.customFFT || ilog2_exact(s->cells.z) < 0) return 1;
+  float noisePrefactor = 0.0f;
+  if (temperature > 0.0f) {
+    const float gL[3] = {s->L.x, s->L.y, s->L.z};
+    const int per[3] = {1, 1, 1};
+    const GridT<float> g = make_grid<float>(make_box<float>(gL, per), s->cells);
+    const float fourierNormalization = (float)(1.0 / ((double)s->cells.x * s->cells.y * s->cells.z));
+    noisePrefactor = prefactor * sqrtf(fourierNormalization * 2 * temperature / g.cellVolume);
+  }
+  const size_t comp = (size_t)s->nyl * s->nkx;
+  if (int e = fcm_fft_z_fused_launch(&s->loc, (float2 *)d_cplxZ, comp, 3 * comp, s->nyl, s->y0, s->cells, s->L, haveForce != 0, noisePrefactor,
+                                     seed2, (hipStream_t)stream)) return e;
+  UH_CHECK(hipGetLastError());
   return 0;
 }
 

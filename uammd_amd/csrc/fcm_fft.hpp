@@ -161,8 +161,10 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
 // ---- rows back: C2R of the three components ---------------------------------------------------------------------------------------------
 // gc: planar complex grids (component stride planeC); output either the planar real grids in place (inter == nullptr) or the gather's
 // interleaved float4 grid inter[(z ny + y) nx + x] = (vx, vy, vz, 0).
-__global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t planeReal, int log2nx, int nrows,
-                                                           int rowsPerBlock, float4 *__restrict__ inter) {
+// Row r = (z, y) of component c starts at c compStride + z zStride + y nxpad floats (single GPU: compStride = one component grid,
+// zStride = ny nxpad; slab window [z][c][y][x]: compStride = ny nxpad, zStride = 3 ny nxpad).
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t compStride, size_t zStride, int log2ny, int log2nx,
+                                                           int nrows, int rowsPerBlock, float4 *__restrict__ inter) {
   extern __shared__ float2 lds[];
   const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
   float2 *tw = lds, *buf = lds + nx;
@@ -171,7 +173,8 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
   for (int c = 0; c < 3; ++c)
     for (int i = tid; i < nr * nh; i += kFftThreads) {
       const int r = i >> (log2nx - 1), k = i & (nh - 1);
-      const float *row = g + (size_t)c * planeReal + (size_t)(r0 + r) * nxpad;
+      const int gr = r0 + r;
+      const float *row = g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad;
       buf[(c * nr + r) * LS + k] = *(const float2 *)(row + 2 * k);
       if (k == 0) buf[(c * nr + r) * LS + nh] = *(const float2 *)(row + 2 * nh);
     }
@@ -209,7 +212,9 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
     for (int c = 0; c < 3; ++c)
       for (int i = tid; i < nr * nh; i += kFftThreads) {
         const int r = i >> (log2nx - 1), j = i & (nh - 1);
-        *(float2 *)(g + (size_t)c * planeReal + (size_t)(r0 + r) * nxpad + 2 * j) = buf[(c * nr + r) * LS + j];
+        const int gr = r0 + r;
+        *(float2 *)(g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad + 2 * j) =
+            buf[(c * nr + r) * LS + j];
       }
   }
 }

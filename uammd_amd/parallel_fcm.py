@@ -122,6 +122,15 @@ class HipSlabBackend:
         self._check(self.lib.uammd_fcm_slab_kspace(self.h, self._p(buf), int(have_force), float(temperature), float(prefactor),
                                                    int(seed2) & 0xFFFFFFFF, self._st()))
 
+    def z_fused(self, buf, have_force, temperature, prefactor, seed2):
+        """forward z + operator + inverse z in one pass; False when the grid does not allow it (the caller takes the three calls)."""
+        rc = self.lib.uammd_fcm_slab_z_fused(self.h, self._p(buf), int(have_force), float(temperature), float(prefactor),
+                                             int(seed2) & 0xFFFFFFFF, self._st())
+        if rc == 1:
+            return False
+        self._check(rc)
+        return True
+
     def inverse_xy(self, grid):
         self._check(self.lib.uammd_fcm_slab_inverse_xy(self.h, self._p(grid), self._st()))
 
@@ -207,15 +216,18 @@ class DistributedFCM:
             send = [a.view(nzl, 3, P, nyl, g.nkx, 2).permute(2, 0, 1, 3, 4, 5).contiguous() for a in xy]
             recv = self.x.all_to_all(send)      # [src][zl][c][yl][kx] == [z][c][yl][kx]
             for i in range(n):
-                zb = recv[i].reshape(g.cells[2], 3, nyl, g.nkx, 2)
-                self.b[i].fft_z(zb, False)
-                zbufs.append(zb)
+                zbufs.append(recv[i].reshape(g.cells[2], 3, nyl, g.nkx, 2))
         else:
             for i in range(n):
                 if self._z[i] is None:
                     self._z[i] = self.b[i].new_zbuffer()
                 zbufs.append(self._z[i])
         for i in range(n):
+            fused = getattr(self.b[i], "z_fused", None)
+            if fused is not None and fused(zbufs[i], have_force, temperature, prefactor, self.seed2):
+                continue
+            if have_force:
+                self.b[i].fft_z(zbufs[i], False)
             self.b[i].kspace(zbufs[i], have_force, temperature, prefactor, self.seed2)
             self.b[i].fft_z(zbufs[i], True)
         back = self.x.all_to_all([zb.view(P, nzl, 3, nyl, g.nkx, 2) for zb in zbufs])   # [src(y block)][zl][c][yl][kx]
