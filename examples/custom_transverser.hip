@@ -47,6 +47,33 @@ struct UserLJ {  // Radial<LJFunctor>::Transverser (RadialPotential.cuh:107-127)
   __device__ void set(int i, Cur t) { float4 f = force[i]; f.x += t.x; f.y += t.y; f.z += t.z; f.w += 0.0f; force[i] = f; }
 };
 
+// A functor using every optional member of the concept (docs/Transverser.rst:25-54): per-particle Info (a "charge"), prepare() on
+// the host before each launch, and dynamic LDS it asks for with getSharedMemorySize() (here a 4-entry table every thread fills
+// with the same values in zero(), as the reference's own transversers fill theirs).
+struct WeightedCounter {
+  float *out;
+  const float *charge;
+  float rc2, scale;
+  float3 L;
+  using Info = float;
+  void prepare(float newScale) { scale = newScale; }
+  size_t getSharedMemorySize() { return 4 * sizeof(float); }
+  __device__ Info getInfo(int i) { return charge[i]; }
+  __device__ float zero() {
+    extern __shared__ float table[];
+    for (int k = 0; k < 4; ++k) table[k] = scale * (float)(k + 1);
+    return 0.0f;
+  }
+  __device__ float compute(const real4 &pi, const real4 &pj, Info qi, Info qj) {
+    extern __shared__ float table[];
+    float3 r = make_float3(pj.x - pi.x, pj.y - pi.y, pj.z - pi.z);
+    r.x -= floorf(r.x / L.x + 0.5f) * L.x; r.y -= floorf(r.y / L.y + 0.5f) * L.y; r.z -= floorf(r.z / L.z + 0.5f) * L.z;
+    const float r2 = r.x * r.x + r.y * r.y + r.z * r.z;
+    return (r2 < rc2 && r2 > 0.0f) ? table[0] * qi * qj : 0.0f;   // table[0] = scale
+  }
+  __device__ void set(int i, float total) { out[i] = total; }
+};
+
 #define CK(x) do { if ((x) != 0) { std::fprintf(stderr, "failed: %s (%s)\n", #x, uammd_hip_last_error()); return 2; } } while (0)
 
 int main() {
@@ -83,7 +110,7 @@ int main() {
   CK(uammd_lj_process_pair_parameters(rc, 1.0f, 1.0f, 0, &p));
   hipMalloc(&d_p, sizeof(p));
   hipMemcpy(d_p, &p, sizeof(p), hipMemcpyHostToDevice);
-  CK(uammd_lj_transverse_celllist(cl, d_p, 1, L, per, (float *)d_f2, nullptr, nullptr, nullptr, UAMMD_LJ_ALGO_AUTO, nullptr));
+  CK(uammd_lj_transverse_celllist(cl, d_p, 1, L, per, (float *)d_f2, nullptr, nullptr, nullptr, UAMMD_LJ_ALGO_EXACT, nullptr));  // EXACT: the reference's summation order (AUTO sums in tile order)
   hipDeviceSynchronize();
   std::vector<int> count(n);
   std::vector<float4> f1(n), f2(n);
@@ -114,6 +141,42 @@ int main() {
   }
   std::printf("mean neighbours %.3f, %d of 200 counts differ from the host loop; user LJ vs fused LJ: %d differing words of %d, max |dF| %.3e of %.3e\n",
               mean, countMismatch, differing, 3 * n, maxerr, maxf);
+  // 3. the same counter through the Verlet list's NeighbourContainer and through the all-pairs transverse: identical counts
+  int *d_count2, *d_count3;
+  hipMalloc(&d_count2, sizeof(int) * n); hipMalloc(&d_count3, sizeof(int) * n);
+  uammd_verletlist *vl;
+  CK(uammd_verletlist_create(&vl));
+  CK(uammd_verletlist_update(vl, (const float *)d_pos, n, L, per, rc, nullptr, nullptr));
+  NeighbourCounter ncv{d_count2, rc * rc, make_float3(Lb, Lb, Lb)}, ncn{d_count3, rc * rc, make_float3(Lb, Lb, Lb)};
+  CK(transverseList(vl, ncv));
+  CK(transverseNBody(d_pos, nullptr, ncn, n));
+  // 4. every optional member at once: Info + prepare + dynamic LDS, on the cell list and on all pairs
+  float *d_q, *d_w1, *d_w2;
+  hipMalloc(&d_q, sizeof(float) * n); hipMalloc(&d_w1, sizeof(float) * n); hipMalloc(&d_w2, sizeof(float) * n);
+  std::vector<float> q(n);
+  for (int i = 0; i < n; ++i) q[i] = 1.0f + (i % 3);
+  hipMemcpy(d_q, q.data(), sizeof(float) * n, hipMemcpyHostToDevice);
+  WeightedCounter w1{d_w1, d_q, rc * rc, 0.0f, make_float3(Lb, Lb, Lb)}, w2{d_w2, d_q, rc * rc, 0.0f, make_float3(Lb, Lb, Lb)};
+  CK(transverseList(cl, w1, nullptr, nullptr, 0.5f));            // prepare(0.5f)
+  CK(transverseNBody(d_pos, nullptr, w2, n, nullptr, 0.5f));
+  hipDeviceSynchronize();
+  std::vector<int> count2(n), count3(n);
+  std::vector<float> wa(n), wb(n);
+  hipMemcpy(count2.data(), d_count2, sizeof(int) * n, hipMemcpyDeviceToHost);
+  hipMemcpy(count3.data(), d_count3, sizeof(int) * n, hipMemcpyDeviceToHost);
+  hipMemcpy(wa.data(), d_w1, sizeof(float) * n, hipMemcpyDeviceToHost);
+  hipMemcpy(wb.data(), d_w2, sizeof(float) * n, hipMemcpyDeviceToHost);
+  int verletDiff = 0, nbodyDiff = 0, weightedDiff = 0;
+  double wsum = 0;
+  for (int i = 0; i < n; ++i) {
+    verletDiff += count2[i] != count[i];
+    nbodyDiff += count3[i] != count[i];
+    weightedDiff += wa[i] != wb[i];            // sums of small multiples of 0.5: exact in any order
+    wsum += wa[i];
+  }
+  std::printf("Verlet container: %d counts differ; all-pairs transverse: %d differ; Info + prepare + LDS functor: %d differ (sum %.1f)\n",
+              verletDiff, nbodyDiff, weightedDiff, wsum);
+  uammd_verletlist_destroy(vl);
   uammd_celllist_destroy(cl);
-  return (countMismatch <= 1 && maxerr <= 1e-5 * maxf) ? 0 : 1;  // one count may differ: pairs within an ulp of the cut-off (fma vs mul)
+  return (countMismatch <= 1 && maxerr <= 1e-5 * maxf && verletDiff == 0 && nbodyDiff == 0 && weightedDiff == 0 && wsum > 0) ? 0 : 1;  // one count may differ: pairs within an ulp of the cut-off (fma vs mul)
 }

@@ -69,6 +69,16 @@ int main(int argc, char *argv[]) {
   const double M0 = fcm->getFCM_impl()->getSelfMobility();
   std::printf("self mobility %.6f expected %.6f (a = %.5f)\n", M, M0, fcm->getFCM_impl()->getHydrodynamicRadius());
   int bad = std::abs(M / M0 - 1) < 2e-3 ? 0 : 1;
+  {  // library-mode use of FCM_impl with the reference's own signature (FCM_impl.cuh:126-129): owning containers by value
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto force = pd->getForce(access::gpu, access::read);
+    auto disp = fcm->getFCM_impl()->computeHydrodynamicDisplacements(const_cast<real4 *>(pos.raw()), const_cast<real4 *>(force.raw()), nullptr,
+                                                                      pd->getNumParticles(), 0, 0, 0);
+    real3 v0;
+    detail::hipCheck(hipMemcpy(&v0, disp.first.data(), sizeof(real3), hipMemcpyDeviceToHost), "hipMemcpy");
+    std::printf("by-value displacements: %zu linear, %zu angular entries, v0.x = %.6f\n", disp.first.size(), disp.second.size(), v0.x);
+    bad += disp.first.size() != (size_t)pd->getNumParticles() || !disp.second.empty() || std::abs(v0.x / M0 - 1) > 2e-3;
+  }
   bad += rotation<BDHI::FCMIntegrator>(sys, "Gaussian", 0.02);
   bad += rotation<BDHI::FCMIntegratorT<BDHI::FCM_ns::Kernels::GaussianFlexible::sixPoint>>(sys, "sixPoint", 0.15);
   sys->finish();

@@ -20,9 +20,16 @@ int main(int argc, char *argv[]) {
   std::vector<real4> members;
   {
     auto pos = pd->getPos(access::cpu, access::write);
+    // a jittered simple-cubic lattice (uniformly random positions overlap: forces ~1e12 would throw the members out of any box
+    // within the five integration steps below, which the cell list now reports — CellListBase.cuh:82-85)
+    int m = 1;
+    while (m * m * m < N) ++m;
     for (int i = 0; i < N; ++i) {
       const int type = (i % 3 == 0) ? 1 : 0;  // a third of the particles are type 1
-      pos[i] = make_real4(sys->rng().uniform(-0.5, 0.5) * L, sys->rng().uniform(-0.5, 0.5) * L, sys->rng().uniform(-0.5, 0.5) * L, type);
+      const int ix = i % m, iy = (i / m) % m, iz = i / (m * m);
+      const real a = L / m;
+      pos[i] = make_real4((ix + 0.5 + sys->rng().uniform(-0.1, 0.1)) * a - L / 2, (iy + 0.5 + sys->rng().uniform(-0.1, 0.1)) * a - L / 2,
+                          (iz + 0.5 + sys->rng().uniform(-0.1, 0.1)) * a - L / 2, type);
       if (type == 1) members.push_back(pos[i]);
     }
   }

@@ -97,7 +97,15 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
   explicit DeviceArray(size_t n_) { resize(n_); }
   DeviceArray(const DeviceArray &) = delete;
   DeviceArray &operator=(const DeviceArray &) = delete;
+  DeviceArray(DeviceArray &&o) noexcept : d(o.d), n(o.n) { o.d = nullptr; o.n = 0; }
+  DeviceArray &operator=(DeviceArray &&o) noexcept { swap(o); return *this; }
   ~DeviceArray() { if (d) (void)hipFree(d); }
+  T *data() { return d; }
+  const T *data() const { return d; }
+  T *begin() { return d; }
+  T *end() { return d + n; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
   void resize(size_t m) {
     if (m == n) return;
     if (d) (void)hipFree(d);
@@ -111,6 +119,8 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
   void swap(DeviceArray &o) { std::swap(d, o.d); std::swap(n, o.n); }
 };
 }  // namespace detail
+// owning device container returned by value where the reference returns cached_vector (utils/container.h); movable, not copyable
+template <class T> using cached_vector = detail::DeviceArray<T>;
 
 // ---- utils/utils.h:38-115 ----------------------------------------------------------------------------------------
 class Xorshift128plus {
@@ -1011,6 +1021,14 @@ public:
                                         real prefactor, hipStream_t st) {
     detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
                                           (float *)d_linearVelocity, (void *)st));
+  }
+  // The reference's own signature (FCM_impl.cuh:126-129): owning containers returned by value, the second one empty without torques
+  std::pair<cached_vector<real3>, cached_vector<real3>> computeHydrodynamicDisplacements(real4 *pos, real4 *force, real4 *torque,
+                                                                                         int numberParticles, real temperature,
+                                                                                         real prefactor, hipStream_t st) {
+    cached_vector<real3> linear((size_t)numberParticles), angular(torque ? (size_t)numberParticles : 0);
+    computeHydrodynamicDisplacements(pos, force, torque, linear.data(), angular.data(), numberParticles, temperature, prefactor, st);
+    return std::make_pair(std::move(linear), std::move(angular));
   }
   // with torques (FCM_impl.cuh:306-358): linear and angular velocities; torque == nullptr falls back to the call above
   void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, const real4 *torque, real3 *d_linearVelocity,

@@ -105,6 +105,36 @@ def test_ibm_spread_gather_vs_oracle(hip, o32, kind, ncomp):
     assert np.abs(out.cpu().numpy().reshape(n, ncomp) - rout).max() <= 1e-5 * np.abs(rout).max()
 
 
+@pytest.mark.parametrize("support", [22, 33, 41])
+def test_ibm_large_supports_vs_oracle(hip, o32, support):
+    """Supports above 21 nodes per axis — the reference's Poisson quadrupole test uses 41 — keep their 3 * support 1-D weights in two
+    registers of the particle's wave (stencil_weight, csrc/ibm.hpp).  Gaussian-like (Barnett-Magland) and constant windows."""
+    rng = np.random.default_rng(41)
+    cd, L = [96, 88, 104], np.array([96.0, 88.0, 104.0], np.float32)
+    n = 40
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.7, 0.7, (n, 3)) * L
+    v = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    for k in (hip.Kernels.BarnettMagland(0.5 * support, 2.3 * support, support, lengthUnit=1.0), hip.Kernels.Constant(support)):
+        ok = _okernel(o32, k)
+        nxs = cd[0] + 2
+        ibm = hip.IBM(k, hip.Box(L), cd, nxStride=nxs)
+        g = torch.zeros((cd[2], cd[1], nxs, 3), dtype=torch.float32, device="cuda")
+        dp, dv = torch.from_numpy(pos).cuda(), torch.from_numpy(v).cuda()
+        ibm.spread(dp, dv, g)
+        torch.cuda.synchronize()
+        ref = o32.ibm_spread(pos, v, L, 1, cd, ok, nx_stride=nxs)
+        got = g.cpu().numpy()
+        assert np.array_equal(got != 0, ref != 0)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+        field = rng.normal(0, 1, got.shape).astype(np.float32)
+        out = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        ibm.gather(dp, out, torch.from_numpy(field).cuda())
+        torch.cuda.synchronize()
+        rout = o32.ibm_gather(pos, field, L, 1, cd, ok, nx_stride=nxs)
+        assert np.abs(out.cpu().numpy() - rout).max() <= 2e-5 * np.abs(rout).max()
+
+
 def test_ibm_2d_adjoint_reference_test(hip):
     """test_ibm_regular.cu:186-214: 2D (n.z = 1, L.z = 0) spread then gather of a unit quantity / integral(phi^2) = 1."""
     n, L = 8, 16.0

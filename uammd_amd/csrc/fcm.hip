@@ -104,9 +104,9 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
     const uint rem = iu - kk * (uint)(sx * sy);
     const uint jj = dsx.div(rem);
     const uint ii = rem - jj * (uint)sx;
-    const float wx = __shfl(s.w, (int)ii, 64);
-    const float wy = __shfl(s.w, sx + (int)jj, 64);
-    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    const float wx = stencil_weight(s, (int)ii);
+    const float wy = stencil_weight(s, sx + (int)jj);
+    const float wz = stencil_weight(s, sx + sy + (int)kk);
     if (!in) continue;
     // triply periodic: a single wrap is enough because support < cellDim (checked at create)
     int cx = s.celli.x + (int)ii - s.P.x, cy = s.celli.y + (int)jj - s.P.y, cz = s.celli.z + (int)kk - s.P.z;

@@ -63,9 +63,9 @@ __global__ void __launch_bounds__(256) k_ibm(const float *__restrict__ pos, int 
     const uint rem = iu - kk * (uint)(sx * sy);
     const uint jj = nw.dsx.div(rem);
     const uint ii = rem - jj * (uint)sx;
-    const float wx = __shfl(s.w, (int)ii, 64);
-    const float wy = __shfl(s.w, sx + (int)jj, 64);
-    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    const float wx = stencil_weight(s, (int)ii);
+    const float wy = stencil_weight(s, sx + (int)jj);
+    const float wz = stencil_weight(s, sx + sy + (int)kk);
     if (!in) continue;
     const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
     const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);

@@ -15,7 +15,7 @@ namespace uammd_hip {
 
 enum { kKernelGaussian = 0, kKernelPeskin3 = 1, kKernelPeskin4 = 2, kKernelConstant = 3, kKernelBarnettMagland = 4,
        kKernelSixPoint = 5, kKernelGauss2D = 6, kKernelGauss2DDriftX = 7, kKernelGauss2DDriftY = 8 };
-constexpr int kMaxSupport = 21;  // 3*support weights must fit in one wave
+constexpr int kMaxSupport = 42;  // the 3*support 1-D weights live in two registers of one wave (<= 128; the reference's largest test: 41)
 
 struct IBMKernelDev {
   int kind;
@@ -100,8 +100,18 @@ UH_D float phi_axis(const IBMKernelDev &k, int axis, float r) {
 // Per-particle stencil, identical in every lane of the wave except `w` (lane l < 3*support holds one weight).
 struct Stencil {
   int3 celli, P, support;
-  float w;  // lanes [0,sx): x weights, [sx,sx+sy): y weights, [sx+sy, sx+sy+sz): z weights
+  float w;   // weight t = lane:  [0,sx) x weights, [sx,sx+sy) y weights, [sx+sy, sx+sy+sz) z weights
+  float w2;  // weight t = lane + 64 (supports above 21 nodes per axis)
 };
+// weight t of the stencil (t < 128); the second register is only consulted when the stencil has more than 64 weights (wave uniform)
+UH_D float stencil_weight(const Stencil &s, int t) {
+  float a = __shfl(s.w, t & 63, 64);
+  if (s.support.x + s.support.y + s.support.z > 64) {
+    const float b = __shfl(s.w2, t & 63, 64);
+    a = t >= 64 ? b : a;
+  }
+  return a;
+}
 
 UH_D int3 compute_support_shift(const GridT<float> &g, real3f pos, int3 celli, int3 support) {  // IBM.cu:10-31
   int3 P = make_int3(support.x / 2, support.y / 2, support.z / 2);
@@ -119,20 +129,25 @@ UH_D Stencil make_stencil(const GridT<float> &g, const IBMKernelDev &k, real3f p
   s.support = k.support;
   s.P = compute_support_shift(g, pi, s.celli, s.support);
   if (is2D) { s.P.z = 0; s.support.z = 1; }
-  s.w = 0.0f;
   const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
-  if (lane < sx) {
-    const int cx = g.pbc_x(s.celli.x + lane - s.P.x);
-    if (cx >= 0) s.w = phi_axis(k, 0, g.distanceToCellCenter(pi, make_int3(cx, s.celli.y, s.celli.z)).x);
-  } else if (lane < sx + sy) {
-    const int cy = g.pbc_y(s.celli.y + (lane - sx) - s.P.y);
-    if (cy >= 0) s.w = phi_axis(k, 1, g.distanceToCellCenter(pi, make_int3(s.celli.x, cy, s.celli.z)).y);
-  } else if (lane < sx + sy + sz) {
-    const int cz = g.pbc_z(s.celli.z + (lane - sx - sy) - s.P.z);
-    if (cz >= 0) s.w = phi_axis(k, 2, g.distanceToCellCenter(pi, make_int3(s.celli.x, s.celli.y, cz)).z);
-    // 2D: the Peskin windows of the reference tests return phiZ = 1 (test/misc/ibm/test_ibm_regular.cu:83-85)
-    if (is2D && (k.kind == kKernelPeskin3 || k.kind == kKernelPeskin4 || k.kind >= kKernelGauss2D)) s.w = 1.0f;
-  }
+  auto weight = [&](int t) -> float {
+    float w = 0.0f;
+    if (t < sx) {
+      const int cx = g.pbc_x(s.celli.x + t - s.P.x);
+      if (cx >= 0) w = phi_axis(k, 0, g.distanceToCellCenter(pi, make_int3(cx, s.celli.y, s.celli.z)).x);
+    } else if (t < sx + sy) {
+      const int cy = g.pbc_y(s.celli.y + (t - sx) - s.P.y);
+      if (cy >= 0) w = phi_axis(k, 1, g.distanceToCellCenter(pi, make_int3(s.celli.x, cy, s.celli.z)).y);
+    } else if (t < sx + sy + sz) {
+      const int cz = g.pbc_z(s.celli.z + (t - sx - sy) - s.P.z);
+      if (cz >= 0) w = phi_axis(k, 2, g.distanceToCellCenter(pi, make_int3(s.celli.x, s.celli.y, cz)).z);
+      // 2D: the Peskin windows of the reference tests return phiZ = 1 (test/misc/ibm/test_ibm_regular.cu:83-85)
+      if (is2D && (k.kind == kKernelPeskin3 || k.kind == kKernelPeskin4 || k.kind >= kKernelGauss2D)) w = 1.0f;
+    }
+    return w;
+  };
+  s.w = weight(lane);
+  s.w2 = sx + sy + sz > 64 ? weight(lane + 64) : 0.0f;
   return s;
 }
 

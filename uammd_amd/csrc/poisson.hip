@@ -206,9 +206,9 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
     const uint rem = iu - kk * (uint)(sx * sy);
     const uint jj = dsx.div(rem);
     const uint ii = rem - jj * (uint)sx;
-    const float wx = __shfl(s.w, (int)ii, 64);
-    const float wy = __shfl(s.w, sx + (int)jj, 64);
-    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    const float wx = stencil_weight(s, (int)ii);
+    const float wy = stencil_weight(s, sx + (int)jj);
+    const float wz = stencil_weight(s, sx + sy + (int)kk);
     if (!in) continue;
     const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
     const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
@@ -263,9 +263,9 @@ __global__ void __launch_bounds__(256) k_poisson_spread(const float4 *__restrict
     const uint rem = iu - kk * (uint)(sx * sy);
     const uint jj = dsx.div(rem);
     const uint ii = rem - jj * (uint)sx;
-    const float wx = __shfl(s.w, (int)ii, 64);
-    const float wy = __shfl(s.w, sx + (int)jj, 64);
-    const float wz = __shfl(s.w, sx + sy + (int)kk, 64);
+    const float wx = stencil_weight(s, (int)ii);
+    const float wy = stencil_weight(s, sx + (int)jj);
+    const float wz = stencil_weight(s, sx + sy + (int)kk);
     if (!in) continue;
     const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
     const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
@@ -744,7 +744,7 @@ int uammd_poisson_create(const uammd_poisson_parameters *par, uammd_poisson **ou
   support = std::min(support, p->cells[0] / 2 - 2);
   if (support > kMaxSupport) {
     set_last_error("uammd_poisson_create: window support %d exceeds the %d nodes per axis one wave evaluates (single precision "
-                   "tolerances below ~1e-7 are not meaningful anyway)", support, kMaxSupport);
+                   "tolerances below ~1e-7 are not meaningful anyway: the reference's support-41 quadrupole test runs in double)", support, kMaxSupport);
     delete p;
     return -2;
   }
