@@ -451,7 +451,6 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
-    ap.add_argument("--brick-bits", type=int, default=None)
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--sort-every", type=int, default=500, help="ParticleData::sortParticles period of the LJ run (benchmark.cu: 500)")
     ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
@@ -484,8 +483,6 @@ def main():
 
     import uammd_amd as hip
     from uammd_amd._lib import check, load
-    if args.brick_bits is not None:
-        check(load().uammd_hip_set_tunable(b"lj_brick_bits", args.brick_bits))
 
     if args.workload == "fcm":
         out = (run_fcm_distributed if (world > 1 or args.force_distributed) else run_fcm)(hip, args, world, rank, dist)

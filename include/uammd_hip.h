@@ -121,12 +121,8 @@ int uammd_lj_process_pair_parameters(float cutOff, float sigma, float epsilon, i
 #define UAMMD_LJ_ALGO_EXACT 9   /* the fastest kernel that keeps the reference's summation order, bit-identical to GENERAL
                                    (RING_HALF where the grid allows it, else RING, else GENERAL) */
 #define UAMMD_LJ_ALGO_GENERAL 1 /* thread-per-particle walk of the 27 cells (any grid) */
-#define UAMMD_LJ_ALGO_BRICK 2   /* force the LDS-tiled kernel (error if the grid does not allow it) */
-#define UAMMD_LJ_ALGO_QUAD 3    /* force the uniform-j (scalar-streamed neighbours) kernel */
-#define UAMMD_LJ_ALGO_STAGED 5  /* thread-per-particle walk whose candidates a wave stages through LDS once per neighbour offset (bit-identical to GENERAL) */
 #define UAMMD_LJ_ALGO_RING 6    /* GENERAL with a ring FIFO: a drain takes a few pairs from every lane (bit-identical to GENERAL) */
 #define UAMMD_LJ_ALGO_RING_HALF 7 /* RING + half-precision superset prefilter, two candidates per load (bit-identical to GENERAL) */
-#define UAMMD_LJ_ALGO_CELLWAVE 4 /* wave per cell, hits compacted across the wave: same pairs, sums in another order (rounding-level differences) */
 
 /* d_paramTable: ntypes*ntypes PairParameters indexed [ti + ntypes*tj] (ParameterHandler.cuh:17-37);
  * d_force real4[·], d_energy/d_virial real[·] are nullable and ACCUMULATED into at the particle's

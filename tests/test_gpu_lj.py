@@ -14,7 +14,7 @@ from util import lattice_positions
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"general": 1, "brick": 2, "quad": 3, "staged": 5, "ring": 6, "ringh": 7}
+ALGOS = {"general": 1, "ring": 6, "ringh": 7, "exact": 9}   # the kernels that keep the reference's summation order (TILE: test_gpu_lj_tile.py)
 
 
 def _setup(hip, o32, n, L, rc, periodic=(1, 1, 1), ntypes=1, seed=1234, jitter=0.12, outside=False):
@@ -41,11 +41,7 @@ def _oracle(o32, pos, box, pot, rc, fev=(True, False, False)):
                                       len(pos), *fev), cd
 
 
-def _run(hip, pos, box, pot, rc, algo, fev=(True, False, False), brick_bits=None):
-    import ctypes as C
-    from uammd_amd._lib import check, load
-    if brick_bits is not None:
-        check(load().uammd_hip_set_tunable(b"lj_brick_bits", brick_bits))
+def _run(hip, pos, box, pot, rc, algo, fev=(True, False, False)):
     n = len(pos)
     d_pos = torch.from_numpy(pos).cuda()
     cl = hip.CellList()
@@ -59,8 +55,14 @@ def _run(hip, pos, box, pot, rc, algo, fev=(True, False, False), brick_bits=None
     return tuple(None if t is None else t.cpu().numpy() for t in (f, e, v))
 
 
-def _check_force(got, ref, label):
+def _check_force(got, ref, label, reordered=False):
+    """|dF_i| <= 1e-5 * the particle's own largest force component (kernels that keep the reference's summation order; they are
+    expected bit-identical).  reordered=True (the tile kernels: same pairs and per-pair arithmetic, another summation order): the
+    rounding of a reordered sum scales with the MAGNITUDES of the ~52 pair forces, not with their net, so a particle whose pair
+    forces cancel is held to the system's typical force instead: 1e-5 * max(its own largest component, the median of those)."""
     fmax = np.abs(ref[:, :3]).max(axis=1) + 1e-30
+    if reordered:
+        fmax = np.maximum(fmax, np.median(fmax))
     err = np.abs(got[:, :3] - ref[:, :3]).max(axis=1) / fmax
     nbits = int((got[:, :3].view(np.uint32) != ref[:, :3].view(np.uint32)).sum())
     print(f"[{label}] max rel err vs float oracle {err.max():.3e}; words differing bitwise: {nbits} / {got[:, :3].size}")
@@ -69,24 +71,15 @@ def _check_force(got, ref, label):
     return nbits
 
 
-@pytest.mark.parametrize("brick_bits", [3, 4, 5, 6])
-def test_lj_force_brick_sizes(hip, o32, brick_bits):
-    n, L, rc = 20000, 30.0, 2.5   # 12 cells per dimension: partial bricks for 4-wide bricks? 12 % 4 == 0
-    pos, box, pot = _setup(hip, o32, n, L, rc)
-    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=brick_bits)
-    assert _check_force(got, ref, f"brick k={brick_bits}") == 0
-
-
-@pytest.mark.parametrize("algo", ["general", "brick", "quad", "staged", "ring", "ringh"])
-@pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7-partial-bricks", "noncubic"])
+@pytest.mark.parametrize("algo", ["general", "ring", "ringh", "exact"])
+@pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7", "noncubic"])
 def test_lj_force_parity(hip, o32, algo, L):
     rc = 2.5
     vol = float(np.prod(np.broadcast_to(L, (3,))))
     n = int(0.8 * vol)
     pos, box, pot = _setup(hip, o32, n, L, rc, outside=True)
     (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS[algo], brick_bits=5)
+    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS[algo])
     assert _check_force(got, ref, f"{algo} cellDim={list(cd)}") == 0
     # float64 all-pairs yardstick (same float32 inputs, double arithmetic).  The float path — the reference's
     # too — forms rj-ri in float: with |x| up to ~2L the cancellation error is ~eps*|x|/r per pair, amplified 13x
@@ -97,12 +90,12 @@ def test_lj_force_parity(hip, o32, algo, L):
     assert err64 <= 1e-4
 
 
-@pytest.mark.parametrize("algo", ["general", "brick", "quad", "staged", "ring", "ringh"])
+@pytest.mark.parametrize("algo", ["general", "ring", "ringh", "exact"])
 def test_lj_energy_virial_multitype(hip, o32, algo):
     n, L, rc = 12000, 25.0, 2.5
     pos, box, pot = _setup(hip, o32, n, L, rc, ntypes=3, seed=99)
     (rf, re, rv), cd = _oracle(o32, pos, box, pot, pot.getCutOff(), (True, True, True))
-    gf, ge, gv = _run(hip, pos, box, pot, pot.getCutOff(), ALGOS[algo], (True, True, True), brick_bits=4)
+    gf, ge, gv = _run(hip, pos, box, pot, pot.getCutOff(), ALGOS[algo], (True, True, True))
     _check_force(gf, rf, f"{algo} multitype F")
     assert np.abs(ge - re).max() <= 1e-5 * np.abs(re).max()
     assert np.abs(gv - rv).max() <= 1e-5 * np.abs(rv).max()
@@ -111,8 +104,8 @@ def test_lj_energy_virial_multitype(hip, o32, algo):
 @pytest.mark.parametrize("case", [((30.0, 30.0, 9.0), (1, 1, 1)), ((40.0, 40.0, 40.0), (1, 0, 1)),
                                   ((9.0, 30.0, 30.0), (1, 1, 0))], ids=["z-collapsed", "nonperiodic-y", "x-collapsed-npz"])
 def test_lj_general_odd_grids(hip, o32, case):
-    """Collapsed dimensions (cellDim<=3 -> 1) and non periodic boxes go through the general kernel; AUTO must
-    pick it and BRICK must refuse."""
+    """Collapsed dimensions (cellDim<=3 -> 1) and non periodic boxes: AUTO (the tile kernel where the grid allows it, else the exact
+    walk) and EXACT agree with the oracle; algorithm ids of the removed round-1 kernels are refused."""
     L, periodic = case
     rc = 2.5
     n = int(0.5 * np.prod(L))
@@ -123,11 +116,12 @@ def test_lj_general_odd_grids(hip, o32, case):
             pos[:, k] = np.clip(pos[:, k], -L3[k] / 2 + 0.01, L3[k] / 2 - 0.01)
     (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
     got, _, _ = _run(hip, pos, box, pot, rc, 0)
-    _check_force(got, ref, f"auto cellDim={list(cd)} periodic={periodic}")
-    with pytest.raises(hip.UammdHipError):
-        _run(hip, pos, box, pot, rc, ALGOS["brick"])
-    with pytest.raises(hip.UammdHipError):
-        _run(hip, pos, box, pot, rc, ALGOS["quad"])
+    _check_force(got, ref, f"auto cellDim={list(cd)} periodic={periodic}", reordered=True)
+    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["exact"])
+    assert _check_force(got, ref, f"exact cellDim={list(cd)} periodic={periodic}") == 0
+    for removed in (2, 3, 4, 5):
+        with pytest.raises(hip.UammdHipError):
+            _run(hip, pos, box, pot, rc, removed)
 
 
 def test_lj_contact_force_and_nbody(hip, o32):
@@ -159,26 +153,24 @@ def test_lj_contact_force_and_nbody(hip, o32):
     _check_force(pd.getForce().cpu().numpy(), ref, "nbody")
 
 
-def test_lj_accumulates_and_dense_fallback(hip, o32):
-    """Transverser::set does force[i] += total; and a brick whose halo does not fit in LDS (clustered
-    particles) silently takes the in-kernel global walk with identical results."""
-    n, L, rc = 30000, 20.0, 2.5      # rho = 3.75: ~59 particles per cell, 4x4x2 brick halo ~ 8.5k particles > LDS
+def test_lj_accumulates_and_dense_cells(hip, o32):
+    """Transverser::set does force[i] += total; crowded cells (59 particles per cell) on the exact kernels."""
+    n, L, rc = 30000, 20.0, 2.5      # rho = 3.75
     pos = lattice_positions(n, L, seed=11, jitter=0.02)
     box = hip.Box(L)
     pot = hip.Potential.LJ()
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 0.5, 1.0, False))
     (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=5)
-    _check_force(got, ref, "dense fallback")
-    got, _, _ = _run(hip, pos, box, pot, rc, ALGOS["quad"])
-    assert _check_force(got, ref, "dense quad (several 64-lane chunks per quad)") == 0
+    for a in ("general", "ringh"):
+        got, _, _ = _run(hip, pos, box, pot, rc, ALGOS[a])
+        assert _check_force(got, ref, f"dense {a}") == 0
     # accumulate on top of existing forces
     d_pos = torch.from_numpy(pos).cuda()
     cl = hip.CellList()
     cdd, ubox = hip.CellList.create_update_grid(box, rc)
     cl.update_grid(d_pos, ubox, cdd)
     f = torch.ones((n, 4), dtype=torch.float32, device="cuda")
-    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, ALGOS["exact"])
     torch.cuda.synchronize()
     exp = ref.copy()
     exp[:, :3] = np.float32(1.0) + ref[:, :3]
@@ -186,8 +178,9 @@ def test_lj_accumulates_and_dense_fallback(hip, o32):
 
 
 def test_lj_full_size_properties(hip):
-    """C3-sized run (1e6 particles, L=107.7217345 -> 43^3 cells): size-independent properties —
-    Newton's third law (sum of forces ~ 0), brick == general bitwise, invariance under a global shift by L."""
+    """C3-sized run (1e6 particles, L=107.7217345 -> 43^3 cells): size-independent properties — Newton's third law (sum of
+    forces ~ 0), the exact kernels bitwise equal, the tile kernel within tolerance of them.  (The comparison with the oracle at
+    this size is tests/test_gpu_full_size.py.)"""
     n, L, rc = 1_000_000, 107.7217345, 2.5
     pos = lattice_positions(n, L, seed=1234, jitter=0.1)
     box = hip.Box(L)
@@ -195,82 +188,15 @@ def test_lj_full_size_properties(hip):
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
     cd, _ = hip.CellList.create_update_grid(box, rc)
     assert cd == [43, 43, 43]
-    fb, _, _ = _run(hip, pos, box, pot, rc, ALGOS["brick"], brick_bits=5)
     fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
-    fq, _, _ = _run(hip, pos, box, pot, rc, ALGOS["quad"])
-    fs, _, _ = _run(hip, pos, box, pot, rc, ALGOS["staged"])
-    for a in ("ring", "ringh"):
+    for a in ("ring", "ringh", "exact"):
         fr, _, _ = _run(hip, pos, box, pot, rc, ALGOS[a])
         assert np.array_equal(fr.view(np.uint32), fg.view(np.uint32)), a
-    assert np.array_equal(fb.view(np.uint32), fg.view(np.uint32))
-    assert np.array_equal(fq.view(np.uint32), fg.view(np.uint32))
-    assert np.array_equal(fs.view(np.uint32), fg.view(np.uint32))
-    tot = fb[:, :3].astype(np.float64).sum(axis=0)
-    assert np.abs(tot).max() <= 1e-4 * np.abs(fb[:, :3]).max() * np.sqrt(n)
-    assert np.isfinite(fb).all()
-
-
-# ---- cell-per-wave kernel: same pairs, another summation order -> tolerance, not bits ----------------------------------
-@pytest.mark.parametrize("L", [16.0, 27.7, (33.0, 22.0, 45.5)], ids=["L16", "L27.7", "noncubic"])
-def test_lj_cellwave_force_parity(hip, o32, L):
-    rc = 2.5
-    vol = float(np.prod(np.broadcast_to(L, (3,))))
-    n = int(0.8 * vol)
-    pos, box, pot = _setup(hip, o32, n, L, rc, outside=True)
-    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-    got, _, _ = _run(hip, pos, box, pot, rc, 4)
-    fmax = np.abs(ref[:, :3]).max()
-    err = np.abs(got[:, :3] - ref[:, :3]).max() / fmax
-    print(f"[cellwave cellDim={list(cd)}] max |dF| / max|F| = {err:.3e}")
-    assert err <= 1e-5 and np.all(got[:, 3] == 0)                       # 1e-5 of max|F|
-
-
-def test_lj_cellwave_energy_virial_multitype_and_odd_grids(hip, o32):
-    n, L, rc = 12000, 25.0, 2.5
-    pos, box, pot = _setup(hip, o32, n, L, rc, ntypes=3, seed=99)
-    (rf, re, rv), cd = _oracle(o32, pos, box, pot, pot.getCutOff(), (True, True, True))
-    gf, ge, gv = _run(hip, pos, box, pot, pot.getCutOff(), 4, (True, True, True))
-    assert np.abs(gf[:, :3] - rf[:, :3]).max() <= 1e-5 * np.abs(rf[:, :3]).max()
-    assert np.abs(ge - re).max() <= 1e-5 * np.abs(re).max()
-    assert np.abs(gv - rv).max() <= 1e-5 * np.abs(rv).max()
-    for Lc, periodic in [((30.0, 30.0, 9.0), (1, 1, 1)), ((40.0, 40.0, 40.0), (1, 0, 1)), ((9.0, 30.0, 30.0), (1, 1, 0))]:
-        n = int(0.5 * np.prod(Lc))
-        pos, box, pot = _setup(hip, o32, n, Lc, rc, periodic=periodic)
-        L3 = np.asarray(Lc, np.float32)
-        for k in range(3):
-            if not periodic[k]:
-                pos[:, k] = np.clip(pos[:, k], -L3[k] / 2 + 0.01, L3[k] / 2 - 0.01)
-        (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-        got, _, _ = _run(hip, pos, box, pot, rc, 4)
-        assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max(), (Lc, periodic)
-
-
-def test_lj_cellwave_dense_cells_and_full_size(hip, o32):
-    """> 512 candidates per cell (several chunks), > 64 particles per cell (several i blocks), and the C3 box."""
-    n, L, rc = 30000, 20.0, 2.5      # rho = 3.75: ~59 particles per cell -> ~1600 candidates
-    pos = lattice_positions(n, L, seed=11, jitter=0.02)
-    box = hip.Box(L)
-    pot = hip.Potential.LJ()
-    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 0.5, 1.0, False))
-    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
-    got, _, _ = _run(hip, pos, box, pot, rc, 4)
-    assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max()
-    n, L = 9000, 12.0                # rho = 5.2 with rc 2.9 -> 4 cells of 3.0: ~140 particles per cell
-    pos = lattice_positions(n, L, seed=12, jitter=0.02)
-    box = hip.Box(L)
-    pot = hip.Potential.LJ()
-    pot.setPotParameters(0, 0, pot.InputPairParameters(2.9, 0.4, 1.0, False))
-    (ref, _, _), cd = _oracle(o32, pos, box, pot, 2.9)
-    got, _, _ = _run(hip, pos, box, pot, 2.9, 4)
-    assert np.abs(got[:, :3] - ref[:, :3]).max() <= 1e-5 * np.abs(ref[:, :3]).max()
-    n, L, rc = 1_000_000, 107.7217345, 2.5
-    pos = lattice_positions(n, L, seed=1234, jitter=0.1)
-    box = hip.Box(L)
-    pot = hip.Potential.LJ()
-    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
-    fg, _, _ = _run(hip, pos, box, pot, rc, ALGOS["general"])
-    fc, _, _ = _run(hip, pos, box, pot, rc, 4)
-    assert np.abs(fc - fg).max() <= 1e-5 * np.abs(fg).max()
+    ft, _, _ = _run(hip, pos, box, pot, rc, 0)
+    assert np.abs(ft[:, :3] - fg[:, :3]).max() <= 1e-5 * np.abs(fg[:, :3]).max()
+    tot = fg[:, :3].astype(np.float64).sum(axis=0)
+    assert np.abs(tot).max() <= 1e-4 * np.abs(fg[:, :3]).max() * np.sqrt(n)
+    assert np.isfinite(fg).all()
 
 
 @pytest.mark.parametrize("case", ["nonperiodic", "cutoff-larger-than-cell", "random-gas", "four-cells", "nan-and-far"])
@@ -307,7 +233,7 @@ def test_lj_ring_kernels_bitwise_equal_general(hip, o32, case):
         pos[78, 2] -= 1000 * L
     fev = (True, True, True)
     ref = _run(hip, pos, box, pot, rc_list, ALGOS["general"], fev)
-    for a in ("ring", "ringh", "staged"):
+    for a in ("ring", "ringh", "exact"):
         got = _run(hip, pos, box, pot, rc_list, ALGOS[a], fev)
         for g, r, what in zip(got, ref, "FEV"):
             same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))

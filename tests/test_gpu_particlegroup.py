@@ -22,10 +22,14 @@ def test_group_pairforces_and_integrator(hip, o32):
     assert pgA.getNumberParticles() == len(members)
     assert np.array_equal(pgA.getIndexIterator().cpu().numpy(), members)
     # forces among the members only, written at the members' indices
-    pf = hip.PairForces(pgA, box, pot)
+    pf = hip.PairForces(pgA, box, pot, algo=9)      # EXACT: the reference's summation order (bitwise against the oracle)
     pd.getForce("write").zero_()
     pf.sum(force=True)
     got = pd.getForce().cpu().numpy()
+    pd.getForce("write").zero_()
+    hip.PairForces(pgA, box, pot).sum(force=True)   # AUTO: the tile kernel, rounding-level differences
+    auto = pd.getForce().cpu().numpy()
+    assert np.abs(auto - got).max() <= 1e-5 * np.abs(got).max() and np.all(auto[np.setdiff1d(np.arange(n), np.nonzero(pos[:, 3] == 1)[0])] == 0)
     sub = np.ascontiguousarray(pos[members])
     cd, oL, oper = o32.celllist_create_grid(L, 1, rc)
     cl = o32.celllist_build(sub, oL, oper, cd)
