@@ -1,12 +1,13 @@
 #!/bin/bash
-# the round's GPU evidence in one call: parity tests, default bench, kernel stats, HBM traffic
+# the round's GPU evidence in one call: parity tests, default bench, driver-like bench, kernel stats, HBM traffic
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
 T0=$(date +%s); timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
 cat gpurun_out/bench_default.json
-timeout 300 tools/prof_stats.sh lj --workload lj --steps 500 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_driverlike.json 2>/dev/null
+timeout 300 tools/prof_stats.sh lj --workload lj --steps 500 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 tools/prof_stats.sh fcm --workload fcm --fcm-steps 50 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 tools/pmc_traffic.sh lj_traversal k_lj_ringh,k_pack_half --workload lj --steps 20 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 tools/pmc_traffic.sh fcm_step k_fcm_kspace,k_fcm_spread,k_fcm_gather,k_fcm_prep,k_fcm_bin,k_fcm_tile,k_fcm_euler,fft_rtc --workload fcm --fcm-steps 20 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 tools/pmc_traffic.sh calib_fill fillBufferAligned --workload lj --steps 20 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 tools/pmc_traffic.sh lj_traversal k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 tools/pmc_traffic.sh fcm_step k_fcm_spread,k_fcm_gather,k_fcm_prep,k_fcm_bin,k_fcm_tile,k_fcm_euler,k_fft_ --workload fcm --fcm-steps 20 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 tools/pmc_any.sh lj_tile k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
 ls gpurun_out
