@@ -114,17 +114,24 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
 // of a workgroup fall into ~100 distinct fine keys: they are counted in an LDS hash table first (LDS atomics run per CU) and
 // each distinct key then costs ONE global atomic that reserves the whole group's range of provisional ranks.  Unsorted input
 // degrades gracefully to one global atomic per particle.
-constexpr int kAggPerThread = 4;
-constexpr int kAggSlots = 2048;  // >= 2 x particles per workgroup: the probe sequences stay short
+template <int kAggPerThread>
 __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ pos, int N, GridT<float> grid,
                                                      uint *__restrict__ hash, uint *__restrict__ keyCount,
                                                      uint *__restrict__ provRank, int *__restrict__ errorFlag,
                                                      unsigned char *__restrict__ keyOutside) {
+  constexpr int kAggSlots = 2 * kBlock * kAggPerThread;  // 2 x particles per workgroup: the probe sequences stay short
+  constexpr int kSlotShift = 32 - (kAggPerThread == 4 ? 11 : kAggPerThread == 2 ? 10 : 9);
   __shared__ uint tKey[kAggSlots], tCnt[kAggSlots];
   for (int s = threadIdx.x; s < kAggSlots; s += kBlock) { tKey[s] = 0xffffffffu; tCnt[s] = 0u; }
   __syncthreads();
   const int base = blockIdx.x * (kBlock * kAggPerThread);
   uint myKey[kAggPerThread], mySlot[kAggPerThread], myRank[kAggPerThread];
+  float4 p[kAggPerThread];
+#pragma unroll
+  for (int u = 0; u < kAggPerThread; ++u) {  // all loads first: four independent requests in flight per thread
+    const int i = base + u * kBlock + threadIdx.x;
+    p[u] = (i < N) ? pos[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int u = 0; u < kAggPerThread; ++u) {
     const int i = base + u * kBlock + threadIdx.x;
@@ -132,10 +139,9 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
     mySlot[u] = 0;
     myRank[u] = 0;
     if (i < N) {
-      const float4 p = pos[i];
-      int3 c = grid.getCell(real3f{p.x, p.y, p.z});
+      int3 c = grid.getCell(real3f{p[u].x, p[u].y, p[u].z});
       if (c.x < 0 || c.x >= grid.cellDim.x || c.y < 0 || c.y >= grid.cellDim.y || c.z < 0 || c.z >= grid.cellDim.z ||
-      !(p.x == p.x && p.y == p.y && p.z == p.z)) {  // (int)NaN is a valid-looking cell 0: test it by name
+          !(p[u].x == p[u].x && p[u].y == p[u].y && p[u].z == p[u].z)) {  // (int)NaN is a valid-looking cell 0: test it by name
         errorFlag[0] = 1;
         c.x = min(max(c.x, 0), grid.cellDim.x - 1);
         c.y = min(max(c.y, 0), grid.cellDim.y - 1);
@@ -145,12 +151,21 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
       hash[i] = h;
       if (keyOutside) {
         const float hx = 0.5f * grid.box.boxSize.x, hy = 0.5f * grid.box.boxSize.y, hz = 0.5f * grid.box.boxSize.z;
-        if (!(p.x >= -hx && p.x < hx && p.y >= -hy && p.y < hy && p.z >= -hz && p.z < hz)) keyOutside[h] = 1;
+        if (!(p[u].x >= -hx && p[u].x < hx && p[u].y >= -hy && p[u].y < hy && p[u].z >= -hz && p[u].z < hz)) keyOutside[h] = 1;
       }
       myKey[u] = h;
-      uint s = (h * 2654435761u) >> 21;  // multiplicative hash -> 11 bits
+    }
+  }
+  bool first[kAggPerThread];
+#pragma unroll
+  for (int u = 0; u < kAggPerThread; ++u) {
+    first[u] = false;
+    if (myKey[u] != 0xffffffffu) {
+      const uint h = myKey[u];
+      uint s = (h * 2654435761u) >> kSlotShift;  // multiplicative hash -> log2(kAggSlots) bits
       for (;;) {
         const uint old = atomicCAS(&tKey[s], 0xffffffffu, h);
+        if (old == 0xffffffffu) first[u] = true;  // this thread opened the slot: it makes the slot's global reservation below
         if (old == 0xffffffffu || old == h) break;
         s = (s + 1) & (kAggSlots - 1);
       }
@@ -159,11 +174,15 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
     }
   }
   __syncthreads();
-  // one global atomic per distinct key of the workgroup: tCnt[s] becomes the first provisional rank of the group
-  for (int s = threadIdx.x; s < kAggSlots; s += kBlock) {
-    const uint k = tKey[s];
-    if (k != 0xffffffffu) tCnt[s] = atomicAdd(&keyCount[k], tCnt[s]);
-  }
+  // One global atomic per distinct key of the workgroup reserves the whole group's range of provisional ranks.  The thread that
+  // opened the slot issues it, so a thread's (up to kAggPerThread) returning atomics are all in flight together; walking the
+  // table instead costs every wave kAggSlots / kBlock serialised round trips (measured: 12 of the kernel's 29 us at C3).
+  uint grp[kAggPerThread];
+#pragma unroll
+  for (int u = 0; u < kAggPerThread; ++u) grp[u] = first[u] ? atomicAdd(&keyCount[myKey[u]], tCnt[mySlot[u]]) : 0u;
+#pragma unroll
+  for (int u = 0; u < kAggPerThread; ++u)
+    if (first[u]) tCnt[mySlot[u]] = grp[u];  // (only the opener has read this slot's count since the barrier)
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kAggPerThread; ++u) {
@@ -175,10 +194,13 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
 // Writes the provisional member list: members[keyStart[h] + provRank[i]] = i
 __global__ void __launch_bounds__(kBlock) k_members(const uint *__restrict__ hash, const uint *__restrict__ provRank,
                                                     const uint *__restrict__ keyStart, int N,
-                                                    int *__restrict__ members) {
+                                                    int *__restrict__ members, uint *__restrict__ sortHash) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
-  members[keyStart[hash[i]] + provRank[i]] = i;
+  const uint h = hash[i];
+  const uint dst = keyStart[h] + provRank[i];
+  members[dst] = i;
+  if (sortHash) sortHash[dst] = h;  // already FINAL: all members of a cell's slot range share the key, whatever their order
 }
 
 // Stable rank + scatter (K2+K3 fused): sorted slot = keyStart[h] + #{members of h with index < i}.
@@ -202,6 +224,54 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter(const float4 *__restric
   sortHash[dst] = h;
   index[dst] = i;
   sortPos[dst] = pos[i];
+}
+
+// ---- counting build, second half -----------------------------------------------------------------------------------
+// Stable placement, one thread per PROVISIONAL slot: the slot's cell is known from sortHash (coalesced), its members are the
+// neighbouring slots (cache hits), the only gather left is pos[i].  Final slot = first slot of the cell + #{members with a smaller
+// index}: the order utils/ParticleSorter.cuh:156-164,303-321 (stable radix sort of the hashes) produces.  Blocks past the
+// particle range write the per-cell tables (k_cell_tables' job) so that the build ends with this launch.
+__global__ void __launch_bounds__(kBlock) k_rank_scatter2(const float4 *__restrict__ pos, const uint *__restrict__ sortHash,
+                                                          const uint *__restrict__ keyStart, const int *__restrict__ members,
+                                                          int N, int particleBlocks, int *__restrict__ index,
+                                                          float4 *__restrict__ sortPos,
+                                                          const unsigned char *__restrict__ keyOutside, int3 cellDim,
+                                                          uint validCell, uint *__restrict__ cellStart, int *__restrict__ cellEnd,
+                                                          unsigned char *__restrict__ cellOutside, uint2 *__restrict__ cellRange) {
+  if ((int)blockIdx.x >= particleBlocks) {
+    const int c = (blockIdx.x - particleBlocks) * kBlock + threadIdx.x;
+    const int ncells = cellDim.x * cellDim.y * cellDim.z;
+    if (c >= ncells) return;
+    int3 cc;
+    cc.x = c % cellDim.x;
+    cc.y = (c / cellDim.x) % cellDim.y;
+    cc.z = c / (cellDim.x * cellDim.y);
+    const uint h = morton_hash(cc);
+    const uint s = keyStart[h], e = keyStart[h + 1];
+    const bool out = keyOutside[h] != 0;
+    cellStart[c] = (e > s) ? s + validCell : 0u;
+    cellEnd[c] = (int)e;
+    cellOutside[c] = out;
+    cellRange[c] = (e > s) ? make_uint2(s, e | (out ? 0x80000000u : 0u)) : make_uint2(0u, 0u);
+    if (c == ncells - 1) cellRange[ncells] = make_uint2(0u, 0u);
+    return;
+  }
+  const int m = blockIdx.x * kBlock + threadIdx.x;
+  if (m >= N) return;
+  const uint h = sortHash[m];
+  const int i = members[m];
+  const float4 p = pos[i];
+  const uint s = keyStart[h], e = keyStart[h + 1];
+  uint rank = 0;
+  uint q = s;
+  for (; q + 4 <= e; q += 4) {
+    const int a = members[q], b = members[q + 1], c = members[q + 2], d = members[q + 3];
+    rank += (a < i) + (b < i) + (c < i) + (d < i);
+  }
+  for (; q < e; ++q) rank += (members[q] < i) ? 1u : 0u;
+  const uint dst = s + rank;
+  index[dst] = i;
+  sortPos[dst] = p;
 }
 
 // Cell tables from keyStart: one thread per cell (linear index).  Non-empty: start + VALID_CELL;
@@ -274,10 +344,25 @@ __global__ void __launch_bounds__(kBlock) k_reorder_fill(const float4 *__restric
 __global__ void __launch_bounds__(kBlock) k_key_start_from_sorted(const uint *__restrict__ sortHash, int N, uint nkeys,
                                                                   uint *__restrict__ keyStart) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i > N) return;
-  const uint lo = (i == 0) ? 0u : sortHash[i - 1] + 1u;
-  const uint hi = (i == N) ? nkeys : sortHash[i];  // inclusive upper key that starts at i
-  for (uint h = lo; h <= hi && h <= nkeys; ++h) keyStart[h] = (uint)i;
+  uint lo = 1u, hi = 0u;  // empty range for the lanes past N
+  if (i <= N) {
+    lo = (i == 0) ? 0u : sortHash[i - 1] + 1u;
+    hi = min((i == N) ? nkeys : sortHash[i], nkeys);  // inclusive upper key that starts at i
+  }
+  // Morton keys of a non power-of-two grid leave gaps of thousands of unused keys: a short run is written by its own lane,
+  // a long one by the whole wave (one lane walking a 2^15-key gap alone cost 400 us at C3).
+  constexpr uint kShort = 4;
+  for (uint h = lo; h <= hi && h < lo + kShort; ++h) keyStart[h] = (uint)i;
+  const bool isLong = hi >= lo && hi - lo >= kShort;
+  unsigned long long pending = __ballot(isLong);
+  const int lane = threadIdx.x & 63;
+  while (pending) {
+    const int src = __ffsll((long long)pending) - 1;
+    pending &= pending - 1;
+    const uint l = __shfl(lo, src, 64) + kShort, hh = __shfl(hi, src, 64);
+    const uint v = (uint)__shfl(i, src, 64);
+    for (uint h = l + lane; h <= hh; h += 64) keyStart[h] = v;
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_iota(int *__restrict__ v, int n) {
@@ -469,30 +554,47 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
     if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
-    if (aggregateHash)
-      hipLaunchKernelGGL(k_hash_agg, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st, d_pos,
-                         N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
-                         (unsigned char *)keyOutside.ptr);
+    if (aggregateHash) {
+      auto launch = [&](auto tag) {
+        constexpr int A = decltype(tag)::value;
+        hipLaunchKernelGGL(k_hash_agg<A>, dim3((N + kBlock * A - 1) / (kBlock * A)), dim3(kBlock), 0, st, d_pos, N, grid,
+                           (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                           (unsigned char *)keyOutside.ptr);
+      };
+      if (aggPerThread == 1) launch(std::integral_constant<int, 1>());
+      else if (aggPerThread == 2) launch(std::integral_constant<int, 2>());
+      else launch(std::integral_constant<int, 4>());
+    }
     else
       hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                          (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
                          (unsigned char *)keyOutside.ptr);
+    if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
+    if (int e = cellRange.reserve(sizeof(uint2) * ((size_t)ncells + 1))) return e;
     size_t tmpBytes = 0;
     UH_CHECK(rocprim::exclusive_scan(nullptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
                                      (size_t)nKeys + 1, rocprim::plus<uint>(), st));
     if (int e = scratch.reserve(tmpBytes)) return e;
     UH_CHECK(rocprim::exclusive_scan(scratch.ptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
                                      (size_t)nKeys + 1, rocprim::plus<uint>(), st));
-    hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
-                       (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr);
-    hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const uint *)hash.ptr,
-                       (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
-                       (int *)index.ptr, (float4 *)sortPos.ptr);
-    if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
-    if (int e = cellRange.reserve(sizeof(uint2) * ((size_t)ncells + 1))) return e;
-    hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
-                       (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
-                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
+    if (!legacyCounting) {
+      hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
+                         (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)sortHash.ptr);
+      const int pb = nblocks(N);
+      hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
+                         (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr,
+                         (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
+                         (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
+    } else {
+      hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
+                         (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)nullptr);
+      hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const uint *)hash.ptr,
+                         (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
+                         (int *)index.ptr, (float4 *)sortPos.ptr);
+      hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
+                         (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
+                         (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
+    }
     haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
@@ -593,7 +695,9 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_celllist_set_option: null argument"); return -1; }
   CellList *cl = reinterpret_cast<CellList *>(h);
   if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
+  if (std::string(name) == "legacy_counting") { cl->legacyCounting = value != 0; return 0; }
   if (std::string(name) == "aggregate_hash") { cl->aggregateHash = value != 0; return 0; }
+  if (std::string(name) == "agg_per_thread") { cl->aggPerThread = value; return 0; }
   if (std::string(name) == "strict_errors") { cl->strictErrors = value != 0; return 0; }
   if (std::string(name) == "report_errors") { cl->reportErrors = value != 0; return 0; }
   if (std::string(name) == "num_owned") { cl->numOwned = value < 0 ? 0x7fffffff : value; return 0; }

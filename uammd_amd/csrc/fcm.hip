@@ -223,26 +223,56 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   for (int i = 0; i < sz; ++i) w[sx + sy + i] = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(celli.x, celli.y, grid.pbc_z(oz + i))).z);
 }
 
-// One workgroup (4 waves) per tile.  The 27 surrounding tiles' particle ranges are dealt to the waves; for each
-// range the lanes test one particle each (does its stencil reach this tile?) and the wave then spreads the
-// accepted particles one at a time, the lanes covering the nodes of the stencil-tile intersection.
-__global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride,
-                                                          int3 support, int3 ntiles, FcmPrep pr) {
-  // LDS float atomics retire ~1 lane per clock on gfx950 (measured: ds_add_f32 kept the LDS pipe 90 % busy and the
-  // kernel at 400 us).  Instead every wave owns a PRIVATE copy of the tile and updates it with plain
-  // read-modify-write (the lanes of one particle touch distinct nodes, a wave's LDS ops retire in order);
-  // the four copies are summed when the tile is stored.
+// One workgroup (4 waves) per tile, three phases per chunk of candidates so that a tile costs TWO global round trips instead
+// of one per particle (round 1 pulled each particle's weights inside the spreading loop: 26 dependent ~0.7 us loads per wave,
+// 104 us per call at C4):
+//   A  all 256 threads test the particles of the 27 surrounding tiles (one candidate each per round, every origin load in
+//      flight together) and the accepted ones are appended IN CANDIDATE ORDER to a list in LDS (ballot + wave offsets: the
+//      summation order, hence the result, is the same on every run);
+//   B  the listed particles' 1-D weights are copied to LDS, all loads in flight together;
+//   C  the waves take listed particles round-robin and spread them into their PRIVATE copy of the tile, held in registers.
+//      (LDS float atomics retire ~1 lane per clock on gfx950: a shared LDS tile kept the LDS pipe 90 % busy and the kernel at
+//      400 us; private LDS copies with read-modify-write were VALU-issue bound at 100 us.)  The four private copies are summed
+//      through LDS when the tile is stored.
+constexpr int kSpWeightWords = 8192;  // LDS budget of phase B: 256 listed particles at support 6 (32 words each), 146 at support 14
+constexpr int kSpZPad = kTile - 1;    // zeros either side of a particle's z weights: any tile plane reads SOME word, no branch
+constexpr int kSpPerThread = 3;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
+struct SpEntry {
+  int o;  // stencil origin in the tile's frame (may be negative), biased by 64 and packed: ox | oy << 8 | oz << 16
+  int slot;
+  float fx, fy, fz;
+};
+struct SpShared {
+  float wts[kSpWeightWords + 32];  // (+32: out-of-stencil lanes read up to 15 words past a particle's weights)
+  SpEntry list[257];               // (+1: phase C reads 8 words per 5-word entry)
+};
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
+                  FcmPrep pr) {
   constexpr int T3 = kTile * kTile * kTile;
-  __shared__ float acc[4 * 3 * T3];
+  // the list + weights of phases A-C and the four private tiles of the final sum are never live together: one LDS block
+  constexpr int kBytes = sizeof(SpShared) > sizeof(float) * 4 * 3 * T3 ? sizeof(SpShared) : sizeof(float) * 4 * 3 * T3;
+  __shared__ __attribute__((aligned(16))) char smem[kBytes];
+  SpShared &sh = *reinterpret_cast<SpShared *>(smem);
+  float *acc = reinterpret_cast<float *>(smem);
+  __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
+  __shared__ int waveCnt[4 * kSpPerThread];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 4 * 3 * T3; i += 256) acc[i] = 0.0f;
-  __syncthreads();
-  float *mine = acc + wave * 3 * T3;
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 acc0 = {0.f}, acc1 = {0.f};  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
+  const int half = lane >> 5, l32 = lane & 31;
+  const int aKz = l32 / 3, aC = l32 - 3 * (l32 / 3);  // A operand row n = l32 = 3 kz + c
+  const bool aValid = l32 < 3 * kTile;
+  const int bX = l32 & 7, bY = l32 >> 3;              // B operand column xy = l32 (+ 32 for the second MFMA: y + 4)
   const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
   const int x0 = tx * kTile, y0 = ty * kTile, z0 = tz * kTile;
   const int sx = support.x, sy = support.y, sz = support.z;
-  for (int nb = wave; nb < 27; nb += 4) {
+  const int wstride = pr.wstride;
+  const int wpad = wstride + 2 * kSpZPad;  // LDS words per listed particle
+  const int capEntries = min(256, kSpWeightWords / wpad);
+  if (threadIdx.x < 27) {
+    const int nb = threadIdx.x;
     int ux = tx + nb % 3 - 1, uy = ty + (nb / 3) % 3 - 1, uz = tz + nb / 9 - 1;
     int shx = -x0, shy = -y0, shz = -z0;  // image shift (in nodes) + change to this tile's frame
     if (ux < 0) { ux += ntiles.x; shx -= n.x; } else if (ux >= ntiles.x) { ux -= ntiles.x; shx += n.x; }
@@ -250,53 +280,132 @@ __global__ void __launch_bounds__(256) k_fcm_spread_tile(float *__restrict__ g0,
     if (uz < 0) { uz += ntiles.z; shz -= n.z; } else if (uz >= ntiles.z) { uz -= ntiles.z; shz += n.z; }
     const int t = ux + ntiles.x * (uy + ntiles.y * uz);
     const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
-    for (int base = s; base < e; base += 64) {
-      const int k = base + lane;
-      int ox = 0, oy = 0, oz = 0;
-      bool accept = false;
-      if (k < e) {
-        const int4 o = pr.origin[k];
-        ox = o.x + shx; oy = o.y + shy; oz = o.z + shz;
-        accept = ox < kTile && ox + sx > 0 && oy < kTile && oy + sy > 0 && oz < kTile && oz + sz > 0;
+    rStart[nb] = s;
+    rShift[3 * nb] = shx; rShift[3 * nb + 1] = shy; rShift[3 * nb + 2] = shz;
+    // inclusive scan of the 27 range lengths inside wave 0
+    int incl = e - s;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (nb >= o) incl += v;
+    }
+    rPrefix[nb + 1] = incl;
+    if (nb == 0) rPrefix[0] = 0;
+  }
+  __syncthreads();
+  const int total = rPrefix[27];
+  int listCount = 0;  // uniform over the workgroup
+
+  auto spread_list = [&](int count) {
+    // phase B
+    const int words = count * wpad;
+    const float rws = 1.0f / (float)wpad;
+    for (int e = threadIdx.x; e < words; e += 256) {
+      const int pp = (int)(((float)e + 0.5f) * rws);  // exact: e < 2^14
+      int k = e - pp * wpad;
+      bool pad = false;
+      if (k >= sx + sy) {  // z weights sit between two runs of kSpZPad zeros
+        k -= kSpZPad;
+        pad = k < sx + sy || k >= wstride;
       }
-      // Per-particle set-up is done by the particle's own lane (all candidates of the batch in parallel); the spreading
-      // loop then pulls it with v_readlane (the lane index j is wave-uniform), so those values live in SGPRs and the loop
-      // spends its VALU slots on the nodes only.  (The kernel is VALU-issue bound: 5.5e7 wave-instructions per call.)
-      const int ax = max(ox, 0), ay = max(oy, 0), az = max(oz, 0);
-      const int nx = min(ox + sx, kTile) - ax, ny = min(oy + sy, kTile) - ay, nz = min(oz + sz, kTile) - az;
-      const int nxy = nx * ny, cnt = nxy * nz;
-      // extents are in [1, 8]: exact small-integer division by an approximate reciprocal (+0.5 keeps it away from the edges)
-      const float rxy = __builtin_amdgcn_rcpf((float)max(nxy, 1)), rx = __builtin_amdgcn_rcpf((float)max(nx, 1));
-      unsigned long long todo = __ballot(accept);
-      while (todo) {
-        const int j = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int kp = base + j;
-        const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * kp + lane] : 0.0f;
-        const float4 f = pr.force[kp];
-        const int sAx = __builtin_amdgcn_readlane(ax, j), sAy = __builtin_amdgcn_readlane(ay, j), sAz = __builtin_amdgcn_readlane(az, j);
-        const int sDx = sAx - __builtin_amdgcn_readlane(ox, j), sDy = sx + sAy - __builtin_amdgcn_readlane(oy, j),
-                  sDz = sx + sy + sAz - __builtin_amdgcn_readlane(oz, j);
-        const int sNx = __builtin_amdgcn_readlane(nx, j), sNxy = __builtin_amdgcn_readlane(nxy, j), sCnt = __builtin_amdgcn_readlane(cnt, j);
-        const float sRxy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rxy), j));
-        const float sRx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), j));
-        for (int i0 = 0; i0 < sCnt; i0 += 64) {  // wave-uniform trip count (shuffles inside)
-          const int i = i0 + lane;
-          const bool in = i < sCnt;
-          const int iu = in ? i : 0;
-          const int kk = (int)(((float)iu + 0.5f) * sRxy);
-          const int r = iu - kk * sNxy;
-          const int jj = (int)(((float)r + 0.5f) * sRx);
-          const int ii = r - jj * sNx;
-          const float wx = __shfl(wl, sDx + ii, 64), wy = __shfl(wl, sDy + jj, 64), wz = __shfl(wl, sDz + kk, 64);
-          if (!in) continue;
-          const float wt = wx * wy * wz;
-          const int node = (sAx + ii) + kTile * ((sAy + jj) + kTile * (sAz + kk));
-          mine[node] += f.x * wt;
-          mine[T3 + node] += f.y * wt;
-          mine[2 * T3 + node] += f.z * wt;
-        }
+      sh.wts[e] = pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp].slot + k];
+    }
+    __syncthreads();
+    // phase C on the matrix pipe.  For one tile the spreading is a product: G[n][xy] += sum_p A[n][p] B[p][xy] with
+    // n = 3 kz + c (8 planes x 3 components = 24 of 32 rows), xy the 64 columns of the tile, A[n][p] = wz_p[kz] f_p[c] and
+    // B[p][xy] = wx_p[x] wy_p[y]: two v_mfma_f32_32x32x2_f32 (columns 0..31 and 32..63) take two particles per step, lanes 0..31
+    // building the operands of one particle and lanes 32..63 those of the other.  fp32 in, fp32 accumulate.
+    // (History: lanes over the nodes of the stencil-tile intersection with LDS read-modify-write, 104 us per call at C4; lane =
+    // column with 24 register accumulators on the VALU, 83 us of which this phase was 41 — measured by switching the phases
+    // off one at a time: A 19, B 12, C 41, prologue + reduction + store 12; with the MFMA form C is ~22 and the call 65 us.)
+    const int mineCount = (count - wave + 3) >> 2;  // entries wave, wave + 4, ... of the list
+    for (int j = 0; j < mineCount; j += 2) {
+      const int idx = j + half;
+      const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
+      const int e = wave + 4 * (real ? idx : 0);
+      const int po = sh.list[e].o;
+      const float fc = (real && aValid) ? reinterpret_cast<const float *>(&sh.list[e].fx)[aC] : 0.0f;
+      const int ox = (po & 255) - 64, oy = ((po >> 8) & 255) - 64, oz = (po >> 16) - 64;
+      const float *wp = sh.wts + e * wpad;
+      const float av = wp[sx + sy + kSpZPad - oz + aKz] * fc;  // zero-padded run: any plane reads SOME word
+      const int ii = bX - ox, j0 = bY - oy, j1 = j0 + 4;
+      const float wx = wp[ii & 15], wy0 = wp[sx + (j0 & 15)], wy1 = wp[sx + (j1 & 15)];
+      const bool inx = (unsigned)ii < (unsigned)sx;
+      const float b0 = (inx && (unsigned)j0 < (unsigned)sy) ? wx * wy0 : 0.0f;
+      const float b1 = (inx && (unsigned)j1 < (unsigned)sy) ? wx * wy1 : 0.0f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  };
+
+  const int perRound = min(capEntries, 256) * kSpPerThread;
+  for (int c0 = 0; c0 < total; c0 += perRound) {
+    // phase A: kSpPerThread candidates per thread, their origins AND forces in flight together
+    int4 org[kSpPerThread];
+    float4 frc[kSpPerThread];
+    int nbOf[kSpPerThread], kOf[kSpPerThread];
+    bool live[kSpPerThread];
+#pragma unroll
+    for (int u = 0; u < kSpPerThread; ++u) {
+      const int c = c0 + u * capEntries + (int)threadIdx.x;
+      live[u] = (int)threadIdx.x < capEntries && c < total && c < c0 + perRound;
+      int nb = 0;  // the range that holds candidate c: rPrefix[nb] <= c < rPrefix[nb + 1]
+      if (live[u]) {
+#pragma unroll
+        for (int stp = 16; stp > 0; stp >>= 1)
+          if (nb + stp <= 26 && rPrefix[nb + stp] <= c) nb += stp;
       }
+      nbOf[u] = nb;
+      kOf[u] = live[u] ? rStart[nb] + (c - rPrefix[nb]) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kSpPerThread; ++u) {
+      org[u] = live[u] ? pr.origin[kOf[u]] : make_int4(0, 0, 0, 0);
+      frc[u] = live[u] ? pr.force[kOf[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool accept[kSpPerThread];
+    unsigned long long m[kSpPerThread];
+#pragma unroll
+    for (int u = 0; u < kSpPerThread; ++u) {
+      const int nb = nbOf[u];
+      org[u].x += rShift[3 * nb]; org[u].y += rShift[3 * nb + 1]; org[u].z += rShift[3 * nb + 2];
+      accept[u] = live[u] && org[u].x < kTile && org[u].x + sx > 0 && org[u].y < kTile && org[u].y + sy > 0 &&
+                  org[u].z < kTile && org[u].z + sz > 0;
+      m[u] = __ballot(accept[u]);
+      if (lane == 0) waveCnt[4 * u + wave] = __popcll(m[u]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSpPerThread; ++u) {  // sub-rounds in candidate order (the list order is the summation order)
+      const int c0w = waveCnt[4 * u], c1w = waveCnt[4 * u + 1], c2w = waveCnt[4 * u + 2], c3w = waveCnt[4 * u + 3];
+      const int roundCount = c0w + c1w + c2w + c3w;
+      if (listCount + roundCount > capEntries) {  // uniform: spread what is listed, then start a new list
+        spread_list(listCount);
+        listCount = 0;
+      }
+      if (accept[u]) {
+        const int before = (wave > 0 ? c0w : 0) + (wave > 1 ? c1w : 0) + (wave > 2 ? c2w : 0);
+        SpEntry en;
+        en.o = (org[u].x + 64) | (org[u].y + 64) << 8 | (org[u].z + 64) << 16;
+        en.slot = kOf[u];
+        en.fx = frc[u].x; en.fy = frc[u].y; en.fz = frc[u].z;
+        sh.list[listCount + before + __popcll(m[u] & ((1ull << lane) - 1ull))] = en;
+      }
+      listCount += roundCount;
+    }
+    __syncthreads();
+  }
+  if (listCount > 0) spread_list(listCount);
+  {
+    // accumulator v of lane l is row n = 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32; rows 24..31 (v >= 12) are unused
+    float *mine = acc + wave * 3 * T3;  // node (x, y, z) of the tile = xy + 64 z
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {
+      const int nrow = 8 * (v / 4) + 4 * half + (v % 4);
+      const int kz = nrow / 3, c = nrow - 3 * kz;
+      mine[c * T3 + 64 * kz + l32] = acc0[v];
+      mine[c * T3 + 64 * kz + 32 + l32] = acc1[v];
     }
   }
   __syncthreads();
