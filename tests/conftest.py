@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running pin of the oracle against a reference test configuration")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`slow` tests (minutes each: the oracle pinned at the reference's own test sizes) run with UAMMD_RUN_SLOW=1; the default
+    CPU suite keeps their reduced-size twins and finishes in a few minutes."""
+    if os.environ.get("UAMMD_RUN_SLOW", "0") not in ("", "0"):
+        return
+    skip = pytest.mark.skip(reason="slow pin of the oracle: set UAMMD_RUN_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def o32():
     import oracle

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libuammd_hip.so")
+LIB_PATH = os.environ.get("UAMMD_HIP_LIB") or os.path.join(_HERE, "lib", "libuammd_hip.so")  # (override: A/B timing of two builds)
 
 
 class UammdHipError(RuntimeError):

@@ -215,7 +215,14 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
   const int slot = pr.tileStart[pr.tileOf[id]] + pr.rank[id];
   pr.origin[slot] = make_int4(ox, oy, oz, id);
-  pr.force[slot] = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // the spreading kernel's record: the force and, in .w, the stencil origin relative to the particle's OWN tile (each in
+  // [-16, 7], biased by 16, five bits per axis): one 16-byte load per candidate, no image arithmetic (a neighbour tile's frame is
+  // +-kTile away whatever the wrap)
+  float4 fr = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int rel = (ox - (celli.x / kTile) * kTile + 16) | (oy - (celli.y / kTile) * kTile + 16) << 5 |
+                  (oz - (celli.z / kTile) * kTile + 16) << 10;
+  fr.w = __int_as_float(rel);
+  pr.force[slot] = fr;
   float *w = pr.weights + (size_t)pr.wstride * slot;
   const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
   for (int i = 0; i < sx; ++i) w[i] = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + i), celli.y, celli.z)).x);
@@ -257,6 +264,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   float *acc = reinterpret_cast<float *>(smem);
   __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
   __shared__ int waveCnt[4 * kSpPerThread];
+  __shared__ unsigned char owner[256 * kSpPerThread];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   f32x16 acc0 = {0.f}, acc1 = {0.f};  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
@@ -273,15 +281,16 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int capEntries = min(256, kSpWeightWords / wpad);
   if (threadIdx.x < 27) {
     const int nb = threadIdx.x;
-    int ux = tx + nb % 3 - 1, uy = ty + (nb / 3) % 3 - 1, uz = tz + nb / 9 - 1;
-    int shx = -x0, shy = -y0, shz = -z0;  // image shift (in nodes) + change to this tile's frame
-    if (ux < 0) { ux += ntiles.x; shx -= n.x; } else if (ux >= ntiles.x) { ux -= ntiles.x; shx += n.x; }
-    if (uy < 0) { uy += ntiles.y; shy -= n.y; } else if (uy >= ntiles.y) { uy -= ntiles.y; shy += n.y; }
-    if (uz < 0) { uz += ntiles.z; shz -= n.z; } else if (uz >= ntiles.z) { uz -= ntiles.z; shz += n.z; }
+    const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
+    int ux = tx + dx, uy = ty + dy, uz = tz + dz;
+    if (ux < 0) ux += ntiles.x; else if (ux >= ntiles.x) ux -= ntiles.x;
+    if (uy < 0) uy += ntiles.y; else if (uy >= ntiles.y) uy -= ntiles.y;
+    if (uz < 0) uz += ntiles.z; else if (uz >= ntiles.z) uz -= ntiles.z;
     const int t = ux + ntiles.x * (uy + ntiles.y * uz);
     const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
     rStart[nb] = s;
-    rShift[3 * nb] = shx; rShift[3 * nb + 1] = shy; rShift[3 * nb + 2] = shz;
+    // a record's origin is relative to its own tile: in this tile's frame that is + kTile per tile step (and - the bias)
+    rShift[3 * nb] = kTile * dx - 16; rShift[3 * nb + 1] = kTile * dy - 16; rShift[3 * nb + 2] = kTile * dz - 16;
     // inclusive scan of the 27 range lengths inside wave 0
     int incl = e - s;
 #pragma unroll
@@ -341,35 +350,36 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
 
   const int perRound = min(capEntries, 256) * kSpPerThread;
   for (int c0 = 0; c0 < total; c0 += perRound) {
-    // phase A: kSpPerThread candidates per thread, their origins AND forces in flight together
-    int4 org[kSpPerThread];
+    // phase A: kSpPerThread candidates per thread, their 16-byte records in flight together.  owner[] maps a candidate of this
+    // round to its range (written by eight threads per range) instead of a binary search per candidate.
+    {
+      const int nb = threadIdx.x >> 3;
+      if (nb < 27) {
+        const int lo = max(rPrefix[nb], c0), hi = min(rPrefix[nb + 1], c0 + perRound);
+        for (int c = lo + (int)(threadIdx.x & 7); c < hi; c += 8) owner[c - c0] = (unsigned char)nb;
+      }
+    }
+    __syncthreads();
     float4 frc[kSpPerThread];
-    int nbOf[kSpPerThread], kOf[kSpPerThread];
+    int3 org[kSpPerThread];
+    int kOf[kSpPerThread];
     bool live[kSpPerThread];
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
       const int c = c0 + u * capEntries + (int)threadIdx.x;
-      live[u] = (int)threadIdx.x < capEntries && c < total && c < c0 + perRound;
-      int nb = 0;  // the range that holds candidate c: rPrefix[nb] <= c < rPrefix[nb + 1]
-      if (live[u]) {
-#pragma unroll
-        for (int stp = 16; stp > 0; stp >>= 1)
-          if (nb + stp <= 26 && rPrefix[nb + stp] <= c) nb += stp;
-      }
-      nbOf[u] = nb;
+      live[u] = (int)threadIdx.x < capEntries && c < total;
+      const int nb = live[u] ? owner[c - c0] : 0;
       kOf[u] = live[u] ? rStart[nb] + (c - rPrefix[nb]) : 0;
+      org[u] = make_int3(rShift[3 * nb], rShift[3 * nb + 1], rShift[3 * nb + 2]);
     }
 #pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u) {
-      org[u] = live[u] ? pr.origin[kOf[u]] : make_int4(0, 0, 0, 0);
-      frc[u] = live[u] ? pr.force[kOf[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int u = 0; u < kSpPerThread; ++u) frc[u] = live[u] ? pr.force[kOf[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
     bool accept[kSpPerThread];
     unsigned long long m[kSpPerThread];
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
-      const int nb = nbOf[u];
-      org[u].x += rShift[3 * nb]; org[u].y += rShift[3 * nb + 1]; org[u].z += rShift[3 * nb + 2];
+      const int rel = __float_as_int(frc[u].w);
+      org[u].x += rel & 31; org[u].y += (rel >> 5) & 31; org[u].z += (rel >> 10) & 31;
       accept[u] = live[u] && org[u].x < kTile && org[u].x + sx > 0 && org[u].y < kTile && org[u].y + sy > 0 &&
                   org[u].z < kTile && org[u].z + sz > 0;
       m[u] = __ballot(accept[u]);
