@@ -70,10 +70,19 @@ def lj_setup(hip, n, L, seed, T=1.0, dt=0.005, nl="cell"):
     return pd, box, pot, verlet, pf, pos
 
 
+def _pin_threads():
+    """One thread per core, close binding; must be in the environment before libgomp starts."""
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
+
 def cpu_baseline_lj(n, L, seed, sample_steps):
-    """Oracle ("port" of the reference algorithm, oracle/src/*.c, OpenMP over particles) on the host cores."""
+    """Oracle ("port" of the reference algorithm, oracle/src/*.c) on ALL host cores: OpenMP over particles in the traversal and
+    the integrator, chunked stable radix sort + parallel hash / reorder / cell tables in the build."""
+    _pin_threads()
     import oracle
     o = oracle.get("f32")
+    o.set_parallel(True)
     pos = lattice(n, L, seed)
     vel = np.zeros((n, 3), np.float32)
     force = np.zeros((n, 4), np.float32)
@@ -100,8 +109,8 @@ def cpu_baseline_lj(n, L, seed, sample_steps):
     except Exception:
         pass
     return {"value": n * sample_steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_steps} full NVT steps of the same 1e6-particle LJ box (oracle: cell list single "
-                      f"thread, traversal OpenMP over {cores} threads), {el:.1f} s"}
+            "sample": f"{sample_steps} full NVT steps of the same 1e6-particle LJ box (oracle: cell-list build, traversal and "
+                      f"integrator all OpenMP over {cores} pinned threads), {el:.1f} s"}
 
 
 
@@ -313,9 +322,11 @@ def run_fcm_c5(hip, args, world, rank, dist):
 
 
 def cpu_baseline_fcm(sample_steps):
+    _pin_threads()
     import oracle
     from oracle.fcm import FCMOracle
     o = oracle.get("f32")
+    o.set_parallel(True)
     n, cells, L = 100_000, [128, 128, 128], 128.0
     rng = np.random.default_rng(1234)
     pos = np.zeros((n, 4), np.float32)
@@ -334,8 +345,8 @@ def cpu_baseline_fcm(sample_steps):
     except Exception:
         pass
     return {"value": sample_steps / el, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_steps} FCM steps at 128^3 / 1e5 particles (oracle: C spread single thread, gather and "
-                      f"scipy pocketfft FFTs on {cores} threads, k-space single thread), {el:.1f} s"}
+            "sample": f"{sample_steps} FCM steps at 128^3 / 1e5 particles (oracle: spread with atomic adds, gather, k-space and "
+                      f"scipy pocketfft FFTs all on {cores} pinned threads), {el:.1f} s"}
 
 
 
@@ -350,7 +361,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
     L1 = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
     rc, dt, T = 2.5, 0.005, 1.0
     noise = math.sqrt(2 * dt * 1.0 * T)
-    # cached exchange: skin 0.4 sigma, ownership + halo lists refreshed every 10 steps (|v_z| dt * 10 < 0.3 at T = 1)
+    # cached exchange: skin 0.6 sigma, ownership + halo lists refreshed every 20 steps; DistributedLJ.check_skin() verifies after the
+    # run that no particle out-ran the skin between two refreshes
     d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=args.skin)
     pos = torch.from_numpy(lattice(n, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
     vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
@@ -464,8 +476,9 @@ def main():
     ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
                     help="neighbour list of PairForces: CellList (BASELINE configs[2], default) or VerletList (the "
                          "reference's examples/misc/benchmark.cu default)")
-    ap.add_argument("--skin", type=float, default=0.4, help="slab decomposition: skin of the cached halo exchange (0 = exchange sizes every step)")
-    ap.add_argument("--exchange-every", type=int, default=10, help="slab decomposition: steps between ownership / halo-list refreshes")
+    ap.add_argument("--skin", type=float, default=0.6, help="slab decomposition: skin of the cached halo exchange (0 = exchange sizes every step)")
+    ap.add_argument("--exchange-every", type=int, default=20, help="slab decomposition: steps between ownership / halo-list refreshes "
+                                                                      "(measured at world = 1: 10 / 0.4 -> 0.335 ms per step, 20 / 0.6 -> 0.315)")
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
 

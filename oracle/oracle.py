@@ -85,6 +85,10 @@ class Oracle:
         self.lib.oracle_cell_of(_p(pos4), len(pos4), _p(L), _p(per), _p(cd), _p(out))
         return out
 
+    def set_parallel(self, on):
+        """All-cores mode of the cell-list build and the IBM spreading (bench.py's cpu_baseline)."""
+        self.lib.oracle_set_parallel(int(bool(on)))
+
     def celllist_build(self, pos4, L, periodic, cell_dim, valid_cell=None, cell_start=None, cell_end=None):
         pos4 = self.r(pos4)
         n = len(pos4)

@@ -14,6 +14,9 @@
  *   CellList_ns::fillCellList (K4)          .../CellList/CellListBase.cuh:68-94
  */
 #include "common.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <limits.h>
 #include <float.h>
 
@@ -100,10 +103,70 @@ ORACLE_API uint oracle_celllist_next_valid_cell(int numberParticles, long long *
   return currentValidCell;
 }
 
+/* bench.py's cpu_baseline runs the oracle on all host cores: with this flag the build below (hash, sort,
+ * reorder, cell tables) and the IBM spreading use OpenMP.  The build's results are identical either way (the sort stays stable);
+ * the spreading then adds with atomics in thread order (rounding-level differences), so tests leave the flag off. */
+static int g_oracle_parallel = 0;
+ORACLE_API void oracle_set_parallel(int on) { g_oracle_parallel = on; }
+ORACLE_API int oracle_get_parallel(void) { return g_oracle_parallel; }
+
+/* the same stable sort with every pass split over T contiguous chunks of the input: per-chunk digit histograms, one exclusive scan
+ * over (digit, chunk) and a scatter in which a chunk's elements keep their order: bit-identical output */
+static void stable_sort_pairs_parallel(uint *keys, int *vals, int N, int end_bit) {
+  int T = 1;
+#ifdef _OPENMP
+  T = omp_get_max_threads();
+#endif
+  if (T > 64) T = 64;
+  uint *k2 = (uint *)malloc(sizeof(uint) * (size_t)N);
+  int *v2 = (int *)malloc(sizeof(int) * (size_t)N);
+  size_t *hist = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)T);
+  uint *ka = keys, *kb = k2;
+  int *va = vals, *vb = v2;
+  for (int shift = 0; shift < end_bit; shift += 8) {
+    int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    uint mask = (1u << bits) - 1u;
+    memset(hist, 0, sizeof(size_t) * 256 * (size_t)T);
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int t = 0; t < T; t++) {
+      const size_t lo = (size_t)N * (size_t)t / (size_t)T, hi = (size_t)N * (size_t)(t + 1) / (size_t)T;
+      size_t *h = hist + 256 * (size_t)t;
+      for (size_t i = lo; i < hi; i++) h[(ka[i] >> shift) & mask]++;
+    }
+    size_t run = 0;
+    for (int d = 0; d < 256; d++)
+      for (int t = 0; t < T; t++) {
+        const size_t c = hist[256 * (size_t)t + d];
+        hist[256 * (size_t)t + d] = run;
+        run += c;
+      }
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int t = 0; t < T; t++) {
+      const size_t lo = (size_t)N * (size_t)t / (size_t)T, hi = (size_t)N * (size_t)(t + 1) / (size_t)T;
+      size_t *h = hist + 256 * (size_t)t;
+      for (size_t i = lo; i < hi; i++) {
+        const size_t dst = h[(ka[i] >> shift) & mask]++;
+        kb[dst] = ka[i];
+        vb[dst] = va[i];
+      }
+    }
+    uint *tk = ka; ka = kb; kb = tk;
+    int *tv = va; va = vb; vb = tv;
+  }
+  if (ka != keys) {
+    memcpy(keys, ka, sizeof(uint) * (size_t)N);
+    memcpy(vals, va, sizeof(int) * (size_t)N);
+  }
+  free(k2);
+  free(v2);
+  free(hist);
+}
+
 /* Stable LSD radix sort of (key,value) on key bits [0,end_bit) — the contract of
  * cub::DeviceRadixSort::SortPairs(…, begin_bit=0, end_bit) used at ParticleSorter.cuh:316-320. */
 ORACLE_API void oracle_stable_sort_pairs(uint *keys, int *vals, int N, int end_bit) {
   if (end_bit <= 0 || N <= 1) return;
+  if (g_oracle_parallel) { stable_sort_pairs_parallel(keys, vals, N, end_bit); return; }
   uint *k2 = (uint *)malloc(sizeof(uint) * (size_t)N);
   int *v2 = (int *)malloc(sizeof(int) * (size_t)N);
   uint *ka = keys, *kb = k2;
@@ -136,6 +199,7 @@ ORACLE_API void oracle_assign_hash(const real4 *pos, int N, const real *L, const
                                    uint *hash, int *index) {
   Box box = box_from(L, periodic);
   Grid grid = grid_make(box, mki3(cellDim[0], cellDim[1], cellDim[2]));
+#pragma omp parallel for schedule(static) if (g_oracle_parallel)
   for (int i = 0; i < N; i++) {
     int3 c = grid_get_cell(&grid, mk3(pos[i].x, pos[i].y, pos[i].z));
     hash[i] = mortonHash(c);
@@ -162,10 +226,12 @@ ORACLE_API int oracle_celllist_build(const real4 *pos, int N, const real *L, con
   oracle_assign_hash(pos, N, L, periodic, cellDim, hash, index);
   uint maxHash = mortonHash(mki3(cellDim[0] - 1, cellDim[1] - 1, cellDim[2] - 1)); /* :161 */
   oracle_stable_sort_pairs(hash, index, N, oracle_sort_end_bit(maxHash));
+#pragma omp parallel for schedule(static) if (g_oracle_parallel)
   for (int i = 0; i < N; i++) sortPos[i] = pos[index[i]]; /* K3 */
   /* K4: fillCellList, CellListBase.cuh:68-94 (one "thread" per id; writes never collide) */
   int errorFlag = 0;
   const int ncells = grid_ncells(&grid);
+#pragma omp parallel for schedule(static) reduction(| : errorFlag) if (g_oracle_parallel)
   for (int id = 0; id < N; id++) {
     uint icell, icell2;
     icell = (uint)grid_cell_index(&grid, grid_get_cell(&grid, mk3(sortPos[id].x, sortPos[id].y, sortPos[id].z)));

@@ -175,4 +175,7 @@ static inline real3 grid_distance_to_cell_center(const Grid *g, real3 pos, int3 
 }
 
 #define ORACLE_API __attribute__((visibility("default")))
+/* celllist.c: all-cores mode of the build and the IBM spreading for bench.py's cpu_baseline (results: see there) */
+ORACLE_API void oracle_set_parallel(int on);
+ORACLE_API int oracle_get_parallel(void);
 #endif

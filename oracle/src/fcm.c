@@ -70,6 +70,7 @@ ORACLE_API void oracle_fcm_force_fourier_to_vel(real *grid6, real vis, const rea
   const int nk = n.z * n.y * (n.x / 2 + 1);
   memset(&g[0], 0, sizeof(complex3));
   const real norm = (real)(n.x * n.y * n.z);
+#pragma omp parallel for schedule(static) if (oracle_get_parallel())
   for (int id = 1; id < nk; id++) {
     const int3 wn = indexToWaveNumber(id, n);
     const real3 k = waveNumberToWaveVector(wn, L);
@@ -105,6 +106,9 @@ ORACLE_API void oracle_fcm_fourier_brownian_noise(real *grid6, const real *L3, c
   const int3 nk = mki3(cellDim[0], cellDim[1], cellDim[2]);
   const real3 L = mk3(L3[0], L3[1], L3[2]);
   const int N = nk.z * nk.y * (nk.x / 2 + 1);
+  /* (a node writes itself and, on the kx = 0 / Nyquist planes, its conjugate partner, which is one of the skipped nodes: no two
+   * iterations touch the same node) */
+#pragma omp parallel for schedule(static) if (oracle_get_parallel())
   for (int id = 0; id < N; id++) {
     const int3 cell = mki3(id % (nk.x / 2 + 1), (id / (nk.x / 2 + 1)) % nk.y, id / ((nk.x / 2 + 1) * nk.y));
     if (id == 0 || (cell.x == 0 && cell.y == 0 && 2 * cell.z >= nk.z + 1) || (cell.x == 0 && 2 * cell.y >= nk.y + 1)) continue;

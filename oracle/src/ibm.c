@@ -182,6 +182,28 @@ ORACLE_API void oracle_ibm_spread(const real *pos, int posStride, const real *v,
   Box box = box_from(L, periodic);
   Grid g = grid_make(box, mki3(cellDim[0], cellDim[1], cellDim[2]));
   const int is2D = g.cellDim.z == 1; /* IBM.cuh:189-194 */
+  if (oracle_get_parallel()) { /* cpu_baseline only: particles over the cores, atomic adds as the reference's atomicAdd (IBM.cu:143) */
+#pragma omp parallel for schedule(static)
+    for (int id = 0; id < N; id++) {
+      Stencil s;
+      real3 pi = mk3(pos[posStride * id], pos[posStride * id + 1], pos[posStride * id + 2]);
+      make_stencil(&s, &g, k, pi, is2D);
+      int nn = s.support.x * s.support.y * (is2D ? 1 : s.support.z);
+      for (int i = 0; i < nn; i++) {
+        const int ii = i % s.support.x, jj = (i / s.support.x) % s.support.y, kk = is2D ? 0 : (i / (s.support.x * s.support.y));
+        const int3 cj = grid_pbc_cell(&g, mki3(s.celli.x + ii - s.P.x, s.celli.y + jj - s.P.y, is2D ? 0 : (s.celli.z + kk - s.P.z)));
+        if (cj.x < 0 || cj.y < 0 || cj.z < 0) continue;
+        if (cj.x >= g.cellDim.x || cj.y >= g.cellDim.y || cj.z >= g.cellDim.z) continue;
+        const size_t jcell = (size_t)cj.x + (size_t)nxStride * ((size_t)cj.y + (size_t)g.cellDim.y * (size_t)cj.z);
+        for (int c = 0; c < ncomp; c++) {
+          const real add = v[ncomp * id + c] * s.wx[ii] * s.wy[jj] * s.wz[kk];
+#pragma omp atomic
+          gridData[ncomp * jcell + c] += add;
+        }
+      }
+    }
+    return;
+  }
   Stencil s;
   for (int id = 0; id < N; id++) {
     real3 pi = mk3(pos[posStride * id], pos[posStride * id + 1], pos[posStride * id + 2]);
