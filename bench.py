@@ -70,16 +70,42 @@ def lj_setup(hip, n, L, seed, T=1.0, dt=0.005, nl="cell"):
     return pd, box, pot, verlet, pf, pos
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, cut by the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota).
+    The GPU boxes show 256 hardware threads and grant 16 CPUs of time: threads beyond the quota only add throttling."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, q // per))
+        except Exception:
+            pass
+    return cores
+
+
 def _pin_threads():
-    """One thread per core, close binding; must be in the environment before libgomp starts."""
+    """One thread per usable core, close binding; must be in the environment before libgomp starts.
+    Returns the number of threads (taken BEFORE OpenMP binds the calling thread to its place)."""
+    cores = host_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
+    return int(os.environ["OMP_NUM_THREADS"])
 
 
 def cpu_baseline_lj(n, L, seed, sample_steps):
     """Oracle ("port" of the reference algorithm, oracle/src/*.c) on ALL host cores: OpenMP over particles in the traversal and
     the integrator, chunked stable radix sort + parallel hash / reorder / cell tables in the build."""
-    _pin_threads()
+    cores = _pin_threads()
     import oracle
     o = oracle.get("f32")
     o.set_parallel(True)
@@ -103,14 +129,9 @@ def cpu_baseline_lj(n, L, seed, sample_steps):
         force = forces(pos)
         o.verletnvt_gj(2, pos, vel, force, dt, 1.0, noise, s, 1234)
     el = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     return {"value": n * sample_steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} full NVT steps of the same 1e6-particle LJ box (oracle: cell-list build, traversal and "
-                      f"integrator all OpenMP over {cores} pinned threads), {el:.1f} s"}
+                      f"integrator all OpenMP over {cores} pinned threads = the CPUs the container grants of {os.cpu_count()} hardware threads), {el:.1f} s"}
 
 
 
@@ -322,7 +343,7 @@ def run_fcm_c5(hip, args, world, rank, dist):
 
 
 def cpu_baseline_fcm(sample_steps):
-    _pin_threads()
+    cores = _pin_threads()
     import oracle
     from oracle.fcm import FCMOracle
     o = oracle.get("f32")
@@ -339,11 +360,6 @@ def cpu_baseline_fcm(sample_steps):
         v = f.displacements(pos, force, temperature=1.0, prefactor=10.0)
         o.fcm_euler_maruyama(pos, v, 0.01)
     el = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     return {"value": sample_steps / el, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} FCM steps at 128^3 / 1e5 particles (oracle: spread with atomic adds, gather, k-space and "
                       f"scipy pocketfft FFTs all on {cores} pinned threads), {el:.1f} s"}

@@ -6,11 +6,14 @@ gather.  The FFT is scipy/numpy pocketfft (the reference calls cuFFT, a third-pa
 /root/reference; a DFT has one answer up to rounding).  Data layouts follow the reference exactly: real grid
 real3[nz][ny][2(nx/2+1)] (padded, FCM_impl.cuh:253), Fourier grid complex3[nz][ny][nx/2+1].
 """
+import os
+
 import numpy as np
 
 try:
     import scipy.fft as _fft
-    _kw = dict(workers=-1)
+    # as many FFT workers as OpenMP threads (bench.py sets OMP_NUM_THREADS to the CPUs the container grants)
+    _kw = dict(workers=int(os.environ.get("OMP_NUM_THREADS", "-1")))
 except Exception:  # pragma: no cover
     import numpy.fft as _fft
     _kw = {}

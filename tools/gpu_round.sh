@@ -7,6 +7,8 @@ cat gpurun_out/bench_default.json
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_driverlike.json 2>/dev/null
 timeout 300 tools/prof_stats.sh lj --workload lj --steps 500 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 tools/prof_stats.sh fcm --workload fcm --fcm-steps 50 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 tools/prof_any.sh fcm_c4 tools/time_fcm.py > /dev/null 2>&1
+MELT=100 timeout 300 tools/prof_any.sh build tools/time_build.py > gpurun_out/time_build.log 2>&1
 timeout 400 tools/pmc_traffic.sh lj_traversal k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
 timeout 400 tools/pmc_traffic.sh fcm_step k_fcm_spread,k_fcm_gather,k_fcm_prep,k_fcm_bin,k_fcm_tile,k_fcm_euler,k_fft_ --workload fcm --fcm-steps 20 --no-cpu-baseline > /dev/null 2>&1
 timeout 400 tools/pmc_any.sh lj_tile k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
