@@ -84,13 +84,29 @@ int uammd_celllist_check_errors(uammd_celllist *h, void *stream);
  * d_outUp[k] = pos[idxUp[k]] + (0, 0, dzUp), d_outDown[k] = pos[idxDown[k]] + (0, 0, dzDown) — in one launch. */
 int uammd_halo_pack(const float *d_pos, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown,
                     float *d_outUp, float *d_outDown, void *stream);
+/* The bookkeeping of a membership refresh of the slab decomposition (uammd_amd/csrc/slab.hip):
+ *   uammd_slab_select: ASCENDING indices of the rows with z >= zUp (d_idxUp) and with z < zDown (d_idxDown), their numbers in
+ *     d_counts[0..1] (device memory; the caller reads them to size its messages); d_workspace: uammd_slab_select_workspace(n) bytes;
+ *   uammd_slab_pack_rows: the listed rows as 8 floats {x, y, z + dz, w, vx, vy, vz, id} for the neighbour above / below;
+ *   uammd_slab_unpack_rows: arrivals (8-float rows, those from below first) into the holes the leavers make, arrivals in excess
+ *     appended at row n, and when fewer arrive than leave the staying rows of the tail moved into the open holes: afterwards the
+ *     first n - nUp - nDown + nArrive rows are the owned particles.  d_holes: nUp + nDown ints of scratch;
+ *   uammd_slab_max_displacement: atomicMax of |pos - ref| over the rows into *d_max (a float the caller zeroes). */
+int uammd_slab_select_workspace(int n, size_t *bytes);
+int uammd_slab_select(const float *d_pos, int n, float zUp, float zDown, int *d_idxUp, int *d_idxDown, int *d_counts, void *d_workspace,
+                      void *stream);
+int uammd_slab_pack_rows(const float *d_pos, const float *d_vel, const int *d_ids, const int *d_idxUp, int nUp, const int *d_idxDown,
+                         int nDown, float dzUp, float dzDown, float *d_outUp, float *d_outDown, void *stream);
+int uammd_slab_unpack_rows(float *d_pos, float *d_vel, int *d_ids, int n, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown,
+                           const float *d_arrivals, int nArrive, int *d_holes, void *stream);
+int uammd_slab_max_displacement(const float *d_pos, const float *d_ref, int n, float *d_max, void *stream);
 int uammd_lj_profile_enable(uammd_celllist *h, int enable);
 int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
  * particles with input index >= n as ghosts of a domain decomposition: they are neighbours of the others but the LJ
  * traversal computes nothing for them (n < 0 turns it off) */
 int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value);
-/* library-wide tunables: "lj_brick_bits" in 3..6 (cells per LDS brick = 2^k) */
+/* library-wide tunables (none at present; the call is kept for ABI stability and returns an error for unknown names) */
 int uammd_hip_set_tunable(const char *name, int value);
 
 /* ParticleSorter::updateOrderWithCustomHash + applyCurrentOrder building blocks

@@ -1,0 +1,112 @@
+"""Path A's slab decomposition on the GPU at world = 1 (the rank is its own neighbour through the periodic z faces):
+the persistent-buffer step with the library's slab kernels (uammd_slab_select / pack_rows / unpack_rows / max_displacement,
+uammd_halo_pack) against (a) the same step with the generic torch refresh — the two must produce the same rows in the same order,
+hence bit-identical trajectories — and (b) the single-domain integrator through the same C ABI (same particles by id, forces to the
+tile kernel's tolerance).  The multi-rank exchange itself is covered under gloo in test_distributed_cpu.py."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import lattice_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0):
+    from uammd_amd._lib import check, load
+    from uammd_amd.parallel import DistributedLJ, SlabDecomposition
+    lib = load()
+    rc, dt = 2.5, 0.005
+    noise = math.sqrt(2 * dt * T)
+    d = SlabDecomposition([L, L, L], rc, 0, 1, skin=skin)
+    pos = torch.from_numpy(lattice_positions(n, L, seed=11, jitter=0.1)).cuda()
+    vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, 1.0, 0, n, 77, None))
+    ids = torch.arange(n, dtype=torch.int32, device="cuda")
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    cl = hip.CellList()
+    cache = {}
+
+    def forces_into(allpos, box_L, periodic, fall):
+        key = (tuple(box_L), tuple(periodic))
+        if key not in cache:
+            box = hip.Box(box_L, periodic)
+            cache[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        box, cd, ubox = cache[key]
+        cl.update_grid(allpos, ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj(pot.device_table(), 1, box, fall, None, None, None, algo)
+
+    def integrate_fn(step, p, v, f, step_num):
+        check(lib.uammd_verletnvt_gj(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
+                                     1.0, None, p.shape[0], dt, 1.0, 0, noise, step_num, 4242,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    sim = DistributedLJ(d, None, integrate_fn, exchange_every=exchange_every, forces_into=forces_into)
+    if not fused:
+        sim._refresh_fused = None   # _refresh_persistent falls through to the generic path
+        orig = sim._refresh_persistent
+
+        def generic(nn):
+            bp, bv, bi, bf = sim._bufs
+            sim._track_drift(bp[:nn])
+            nn = sim.d.migrate_inplace([bp, bv, bi], nn)
+            bf[:nn].zero_()
+            g = sim.d.halo_refresh_into(bp, nn)
+            sim._nall = nn + g
+            if sim.d.skin > 0:
+                sim._ref = bp[:nn].clone()
+            return nn
+        sim._refresh_persistent = generic
+    force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    for _ in range(steps):
+        pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
+    torch.cuda.synchronize()
+    sim.check_skin()
+    return pos.cpu().numpy().copy(), vel.cpu().numpy().copy(), ids.cpu().numpy().copy(), float(sim.max_drift) if sim.max_drift is not None else 0.0
+
+
+def test_fused_refresh_equals_generic_refresh(hip):
+    n, L = 30000, 33.5          # rho = 0.8: particles cross the periodic z faces within a few steps
+    a = _run(hip, n, L, 40, fused=True, algo=9)
+    b = _run(hip, n, L, 40, fused=False, algo=9)
+    assert np.array_equal(a[2], b[2]), "owned rows in another order"
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert sorted(a[2].tolist()) == list(range(n))                       # nobody lost or duplicated
+    assert (np.abs(a[0][:, 2]) <= L / 2 + 0.3 + 1e-4).all()                # owners sit within the skin of their slab
+    assert abs(a[3] - b[3]) <= 1e-6 and 0.0 < a[3] <= 0.3                   # the skin check saw the same displacement
+
+
+def test_slab_world1_matches_single_domain(hip):
+    """Same box integrated by PairForces + VerletNVT::GronbechJensen without decomposition (T = 0: the noise stream is keyed by the row
+    index, which the migration permutes): particle by particle (ids), positions after 10 steps agree to the accumulated rounding of two
+    summation orders (the trajectories are chaotic: short run, loose bar)."""
+    n, L = 30000, 33.5
+    pos0 = lattice_positions(n, L, seed=11, jitter=0.1)
+    p, v, ids, _ = _run(hip, n, L, 10, fused=True, T=0.0)
+    from uammd_amd._lib import check, load
+    lib = load()
+    pd = hip.ParticleData(n, seed=1)
+    pd.setPos(pos0)
+    vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, 1.0, 0, n, 77, None))
+    pd.getVel("write").copy_(vel)
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+    par = hip.VerletNVT.GronbechJensen.Parameters(temperature=0.0, dt=0.005, friction=1.0, initVelocities=False)
+    integ = hip.VerletNVT.GronbechJensen(pd, par)
+    integ.addInteractor(hip.PairForces(pd, box, pot))
+    for _ in range(10):
+        integ.forwardTime()
+    ref = pd.getPos("read").cpu().numpy()
+    got = np.empty_like(ref)
+    got[ids] = p
+    dz = got[:, :3] - ref[:, :3]
+    dz -= np.round(dz / L) * L          # the slab keeps z folded into its frame, the single domain does not fold
+    assert np.abs(dz).max() <= 2e-4

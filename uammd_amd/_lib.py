@@ -111,6 +111,11 @@ SIGNATURES = {
     "uammd_verletlist_update": (_i, [_vp, _vp, _i, _f3, _i3, _f, _vp, C.POINTER(_i)]),
     "uammd_verletlist_force_next_update": (_i, [_vp]),
     "uammd_verletlist_set_cutoff_multiplier": (_i, [_vp, _f]),
+    "uammd_slab_select_workspace": (_i, [_i, C.POINTER(C.c_size_t)]),
+    "uammd_slab_select": (_i, [_vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_slab_pack_rows": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "uammd_slab_unpack_rows": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "uammd_slab_max_displacement": (_i, [_vp, _vp, _i, _vp, _vp]),
     "uammd_verletlist_get_steps_since_last_update": (_i, [_vp, C.POINTER(_i)]),
     "uammd_verletlist_get": (_i, [_vp, C.POINTER(VerletListData)]),
     "uammd_lj_transverse_verletlist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,8 @@ the CPU tests.
 Local frame: rank r works in coordinates z' = z - zc_r (zc_r = slab centre, periodic images chosen next to the
 slab), with a local box (Lx, Ly, slab + 2 rc) that is periodic in x, y and NOT periodic in z.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -70,7 +72,10 @@ class SlabDecomposition:
     # rows are then selected with nonzero_static (static size, no sync).
     def _counts(self, mask_up, mask_down):
         """-> (n_to_up, n_to_down, n_from_down, n_from_up) as host ints, one device->host sync."""
-        mine = torch.stack([mask_up.sum(), mask_down.sum()])
+        return self._exchange_counts(torch.stack([mask_up.sum(), mask_down.sum()]))
+
+    def _exchange_counts(self, mine):
+        """`mine` = tensor [n_to_up, n_to_down] (any device).  -> the same two numbers and what the neighbours send, as host ints."""
         if self.world == 1:  # the only rank is its own neighbour on both sides (periodic images through the loop-back)
             a, b = mine.tolist()
             return a, b, a, b
@@ -408,10 +413,14 @@ class DistributedLJ:
         bp[:n], bv[:n], bi[:n] = pos, vel, ids
         self._bufs = [bp, bv, bi, bf]
         self._ref = None
+        if getattr(self, "_slab_ws", None) is not None:
+            self._slab_ws["ref_n"] = -1      # the order changed: the stored reference positions are another permutation
         return n
 
     def _refresh_persistent(self, n):
         bp, bv, bi, bf = self._bufs
+        if bp.is_cuda and bv.dtype == torch.float32 and bv.dim() == 2 and bv.shape[1] == 3 and bi.dtype == torch.int32 and bi.dim() == 1:
+            return self._refresh_fused(n)
         self._track_drift(bp[:n])
         n = self.d.migrate_inplace([bp, bv, bi], n)
         bf[:n].zero_()                                # arrivals and moved rows: GJ step 1 zeroed the forces of the old layout
@@ -419,6 +428,69 @@ class DistributedLJ:
         self._nall = n + g
         if self.d.skin > 0:
             self._ref = bp[:n].clone()
+        return n
+
+    def _refresh_fused(self, n):
+        """The same refresh on the GPU through the library's slab kernels (csrc/slab.hip): ordered selection of leavers and of
+        halo members, packed migration rows, arrivals into the holes, the skin check's displacement — a dozen launches and two
+        host reads (the message sizes) instead of ~60 element-wise / compaction / concatenation launches.  Lists are ascending
+        as torch.nonzero's, so owned rows and ghosts come out in the same order as from the generic path."""
+        from . import _lib
+        lib = _lib.load()
+        d = self.d
+        bp, bv, bi, bf = self._bufs
+        cap, dev = bp.shape[0], bp.device
+        st = torch.cuda.current_stream().cuda_stream
+        ws = getattr(self, "_slab_ws", None)
+        if ws is None or ws["cap"] != cap:
+            nbytes = C.c_size_t(0)
+            _lib.check(lib.uammd_slab_select_workspace(cap, C.byref(nbytes)))
+            ws = dict(cap=cap, idx=torch.empty((4, cap), dtype=torch.int32, device=dev), holes=torch.empty(cap, dtype=torch.int32, device=dev),
+                      counts=torch.zeros(4, dtype=torch.int32, device=dev), tiles=torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev),
+                      rows=torch.empty((cap, 8), dtype=torch.float32, device=dev), ref=torch.empty((cap, 4), dtype=torch.float32, device=dev),
+                      maxd=torch.zeros(1, dtype=torch.float32, device=dev), ref_n=-1)
+            self._slab_ws = ws
+        idx, counts = ws["idx"], ws["counts"]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        if d.skin > 0 and ws["ref_n"] == n:
+            _lib.check(lib.uammd_slab_max_displacement(p(bp), p(ws["ref"]), n, p(ws["maxd"]), st))
+            self.max_drift = ws["maxd"][0]
+        half = 0.5 * d.width
+        # ---- who leaves ----
+        _lib.check(lib.uammd_slab_select(p(bp), n, half, -half, p(idx[0]), p(idx[1]), p(counts), p(ws["tiles"]), st))
+        n_up, n_down, n_from_down, n_from_up = d._exchange_counts(counts[:2])
+        d._halo_cache = None
+        n_leave, n_arrive = n_up + n_down, n_from_down + n_from_up
+        if n_leave or n_arrive:
+            rows = ws["rows"]
+            assert n_leave <= cap and n_arrive <= cap, "migration overflows the exchange buffer"
+            send_up, send_down = rows[:n_up], rows[n_up:n_leave]
+            _lib.check(lib.uammd_slab_pack_rows(p(bp), p(bv), p(bi), p(idx[0]), n_up, p(idx[1]), n_down, -d.width, d.width,
+                                                p(send_up) if n_up else None, p(send_down) if n_down else None, st))
+            if d.world == 1:
+                arrivals = rows            # what goes up arrives from below: [from_down | from_up] = [send_up | send_down]
+            else:
+                from_down, from_up = d._exchange(send_up, send_down, n_from_down, n_from_up)
+                arrivals = torch.cat([from_down, from_up], dim=0).contiguous()
+            new_n = n - n_leave + n_arrive
+            assert new_n <= cap, "migration overflows the particle buffers"
+            _lib.check(lib.uammd_slab_unpack_rows(p(bp), p(bv), p(bi), n, p(idx[0]), n_up, p(idx[1]), n_down, p(arrivals), n_arrive,
+                                                  p(ws["holes"]), st))
+            n = new_n
+        bf[:n].zero_()                                # arrivals and moved rows: GJ step 1 zeroed the forces of the old layout
+        # ---- who is in the halo ----
+        reach = d.rc + 3.0 * d.skin
+        _lib.check(lib.uammd_slab_select(p(bp), n, half - reach, -half + reach, p(idx[2]), p(idx[3]), p(counts[2:]), p(ws["tiles"]), st))
+        h_up, h_down, g_from_down, g_from_up = d._exchange_counts(counts[2:])
+        assert n + g_from_down + g_from_up <= cap, "the halo overflows the position buffer"
+        iu, idn = idx[2][:h_up], idx[3][:h_down]
+        d._halo_cache = (iu, idn, g_from_down, g_from_up)
+        d._idx32 = (iu, idn, iu)
+        d.halo_refill(bp, n)
+        self._nall = n + g_from_down + g_from_up
+        if d.skin > 0:
+            ws["ref"][:n].copy_(bp[:n])
+            ws["ref_n"] = n
         return n
 
     def _forces_persistent(self, n):
