@@ -390,8 +390,11 @@ k_lj_tile(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__res
 // Halo rows: r = ry + 4 rz (ry, rz = 0..3 <-> y0 - 1 + ry, z0 - 1 + rz), three ranges per row (x0 - 1 | x0, x0 + 1 | x0 + 2), flat
 // order (rz, ry, x) = the reference's visiting order restricted to any wave's 3 x 3 rows.  Wave k = wy + 2 wz owns the pair in row
 // (1 + wy, 1 + wz); its candidates are the rows ry in [wy, wy + 2], rz in [wz, wz + 2]: three contiguous runs of the flat array.
+// (five waves per SIMD: 96 VGPRs and 36 bytes of scratch; measured 0.2116 / 0.2003 / 0.2085 ms at 4 / 5 / 6 — six needs 80 VGPRs,
+// 100 bytes of scratch and an LDS diet, kMaxW 10 / kBrickCap 896 / the range table inside the hit-word rows, that sends more bricks
+// to the fallback)
 template <bool NT1, bool WE, bool WV>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, Outputs out, float margin,
            int nbx, int nby, uint nBricks) {
   __shared__ f4t candg[2 + kBrickCap + 64];  // two guard slots in front (dead slots of the drain read slot -2)
