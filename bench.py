@@ -601,6 +601,8 @@ def main():
     pos = pd.getPos().cpu().numpy()
     assert np.isfinite(pos).all(), "non finite positions after the run"
     ms_per_step = el / args.steps * 1e3
+    if os.environ.get("UAMMD_BENCH_DEBUG") == "1":
+        print(f"[debug] LJ timed loop: {el:.4f} s for {args.steps} steps", file=sys.stderr, flush=True)
     value = n * world * args.steps / el
     achieved_tflops = FLOP_PER_PARTICLE * n / (k_ms * 1e-3) / 1e12
     traffic = read_traffic("traffic_lj_traversal.json")

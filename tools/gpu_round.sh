@@ -2,7 +2,7 @@
 # the round's GPU evidence in one call: parity tests, default bench, driver-like bench, kernel stats, HBM traffic
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
-T0=$(date +%s); timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
+T0=$(date +%s); timeout 900 python bench.py --gpus 1 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
 cat gpurun_out/bench_default.json
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_driverlike.json 2>/dev/null
 timeout 300 tools/prof_stats.sh lj --workload lj --steps 500 --no-cpu-baseline > /dev/null 2>&1
