@@ -27,8 +27,7 @@ for _ in range(100):   # the bench's steady state: up to 500 steps since the las
 pos = pd.getPos("read")
 cd, ubox = hip.CellList.create_update_grid(box, [2.5] * 3)
 outs = {}
-for name, opts in (("legacy", {"legacy_counting": 1}), ("new", {}), ("new_agg2", {"agg_per_thread": 2}), ("new_agg1", {"agg_per_thread": 1}),
-                   ("radix", {"force_radix": 1})):
+for name, opts in (("counting", {}), ("radix", {"force_radix": 1})):
     cl = hip.CellList()
     for k, v in opts.items():
         cl.set_option(k, v)
@@ -41,9 +40,9 @@ for name, opts in (("legacy", {"legacy_counting": 1}), ("new", {}), ("new_agg2",
         cl.update_grid(pos, ubox, cd)
     e1.record(); torch.cuda.synchronize()
     print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per build", flush=True)
-for name in ("new", "new_agg2", "new_agg1", "radix"):
-    a, b = outs["legacy"], outs[name]
+for name in ("radix",):
+    a, b = outs["counting"], outs[name]
     same = all(np.array_equal(a[k], b[k]) for k in ("index", "hash", "sortPos", "cellEnd"))
     va, vb = a["cellStart"] >= a["validCell"], b["cellStart"] >= b["validCell"]
     same = same and np.array_equal(va, vb) and np.array_equal((a["cellStart"] - a["validCell"])[va], (b["cellStart"] - b["validCell"])[vb])
-    print(f"legacy vs {name}: {'identical' if same else 'DIFFERENT'}")
+    print(f"counting vs {name}: {'identical' if same else 'DIFFERENT'}")

@@ -114,13 +114,14 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
 // of a workgroup fall into ~100 distinct fine keys: they are counted in an LDS hash table first (LDS atomics run per CU) and
 // each distinct key then costs ONE global atomic that reserves the whole group's range of provisional ranks.  Unsorted input
 // degrades gracefully to one global atomic per particle.
-template <int kAggPerThread>
+constexpr int kAggPerThread = 4;  // (256 or 512 particles per workgroup instead of 1024: same wall time, measured)
 __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ pos, int N, GridT<float> grid,
                                                      uint *__restrict__ hash, uint *__restrict__ keyCount,
                                                      uint *__restrict__ provRank, int *__restrict__ errorFlag,
                                                      unsigned char *__restrict__ keyOutside) {
   constexpr int kAggSlots = 2 * kBlock * kAggPerThread;  // 2 x particles per workgroup: the probe sequences stay short
-  constexpr int kSlotShift = 32 - (kAggPerThread == 4 ? 11 : kAggPerThread == 2 ? 10 : 9);
+  constexpr int kSlotShift = 32 - 11;
+  static_assert(kAggSlots == 2048, "kSlotShift is log2 of the table size");
   __shared__ uint tKey[kAggSlots], tCnt[kAggSlots];
   for (int s = threadIdx.x; s < kAggSlots; s += kBlock) { tKey[s] = 0xffffffffu; tCnt[s] = 0u; }
   __syncthreads();
@@ -201,29 +202,6 @@ __global__ void __launch_bounds__(kBlock) k_members(const uint *__restrict__ has
   const uint dst = keyStart[h] + provRank[i];
   members[dst] = i;
   if (sortHash) sortHash[dst] = h;  // already FINAL: all members of a cell's slot range share the key, whatever their order
-}
-
-// Stable rank + scatter (K2+K3 fused): sorted slot = keyStart[h] + #{members of h with index < i}.
-__global__ void __launch_bounds__(kBlock) k_rank_scatter(const float4 *__restrict__ pos, const uint *__restrict__ hash,
-                                                         const uint *__restrict__ keyStart,
-                                                         const int *__restrict__ members, int N,
-                                                         uint *__restrict__ sortHash, int *__restrict__ index,
-                                                         float4 *__restrict__ sortPos) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  const uint h = hash[i];
-  const uint s = keyStart[h], e = keyStart[h + 1];
-  uint rank = 0;
-  uint m = s;
-  for (; m + 4 <= e; m += 4) {  // 4 loads in flight
-    const int a = members[m], b = members[m + 1], c = members[m + 2], d = members[m + 3];
-    rank += (a < i) + (b < i) + (c < i) + (d < i);
-  }
-  for (; m < e; ++m) rank += (members[m] < i) ? 1u : 0u;
-  const uint dst = s + rank;
-  sortHash[dst] = h;
-  index[dst] = i;
-  sortPos[dst] = pos[i];
 }
 
 // ---- counting build, second half -----------------------------------------------------------------------------------
@@ -554,17 +532,10 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
     if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
-    if (aggregateHash) {
-      auto launch = [&](auto tag) {
-        constexpr int A = decltype(tag)::value;
-        hipLaunchKernelGGL(k_hash_agg<A>, dim3((N + kBlock * A - 1) / (kBlock * A)), dim3(kBlock), 0, st, d_pos, N, grid,
-                           (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
-                           (unsigned char *)keyOutside.ptr);
-      };
-      if (aggPerThread == 1) launch(std::integral_constant<int, 1>());
-      else if (aggPerThread == 2) launch(std::integral_constant<int, 2>());
-      else launch(std::integral_constant<int, 4>());
-    }
+    if (aggregateHash)
+      hipLaunchKernelGGL(k_hash_agg, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st, d_pos, N,
+                         grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                         (unsigned char *)keyOutside.ptr);
     else
       hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                          (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
@@ -577,24 +548,13 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = scratch.reserve(tmpBytes)) return e;
     UH_CHECK(rocprim::exclusive_scan(scratch.ptr, tmpBytes, (uint *)keyCount.ptr, (uint *)keyStart.ptr, 0u,
                                      (size_t)nKeys + 1, rocprim::plus<uint>(), st));
-    if (!legacyCounting) {
-      hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
-                         (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)sortHash.ptr);
-      const int pb = nblocks(N);
-      hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
-                         (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr,
-                         (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
-                         (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
-    } else {
-      hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr,
-                         (const uint *)provRank.ptr, (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)nullptr);
-      hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, (const uint *)hash.ptr,
-                         (const uint *)keyStart.ptr, (const int *)members.ptr, N, (uint *)sortHash.ptr,
-                         (int *)index.ptr, (float4 *)sortPos.ptr);
-      hipLaunchKernelGGL(k_cell_tables, dim3(nblocks(ncells)), dim3(kBlock), 0, st, (const uint *)keyStart.ptr,
-                         (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
-                         (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
-    }
+    hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr, (const uint *)provRank.ptr,
+                       (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)sortHash.ptr);
+    const int pb = nblocks(N);
+    hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
+                       (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr,
+                       (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr, (int *)cellEnd.ptr,
+                       (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
     haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
@@ -695,9 +655,7 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_celllist_set_option: null argument"); return -1; }
   CellList *cl = reinterpret_cast<CellList *>(h);
   if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
-  if (std::string(name) == "legacy_counting") { cl->legacyCounting = value != 0; return 0; }
   if (std::string(name) == "aggregate_hash") { cl->aggregateHash = value != 0; return 0; }
-  if (std::string(name) == "agg_per_thread") { cl->aggPerThread = value; return 0; }
   if (std::string(name) == "strict_errors") { cl->strictErrors = value != 0; return 0; }
   if (std::string(name) == "report_errors") { cl->reportErrors = value != 0; return 0; }
   if (std::string(name) == "num_owned") { cl->numOwned = value < 0 ? 0x7fffffff : value; return 0; }

@@ -42,8 +42,6 @@ struct CellList {
   bool haveCellOutside = false;
   bool usedCounting = false;
   bool forceRadix = false;  // test hook: always take the rocPRIM radix path
-  bool legacyCounting = false;  // test hook: round-1 counting build (rocPRIM scan + per-particle stable rank)
-  int aggPerThread = 4;
   bool aggregateHash = true;  // k_hash_agg (LDS-aggregated histogram) instead of one global atomic per particle
   // NaN positions / particles outside a non-periodic box (CellListBase.cuh:82-85 raises a flag; :258-264 synchronises and throws
   // in UAMMD_DEBUG builds only, release builds carry on with those particles missing from the tables).
