@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter2(const float4 *__restri
                                                           const uint *__restrict__ keyStart, const int *__restrict__ members,
                                                           int N, int particleBlocks, int *__restrict__ index,
                                                           float4 *__restrict__ sortPos,
-                                                          const unsigned char *__restrict__ keyOutside, int3 cellDim,
-                                                          uint validCell, uint *__restrict__ cellStart, int *__restrict__ cellEnd,
-                                                          unsigned char *__restrict__ cellOutside, uint2 *__restrict__ cellRange) {
+                                                          unsigned char *__restrict__ keyOutside, uint *__restrict__ keyCount,
+                                                          int3 cellDim, uint validCell, uint *__restrict__ cellStart,
+                                                          int *__restrict__ cellEnd, unsigned char *__restrict__ cellOutside,
+                                                          uint2 *__restrict__ cellRange) {
   if ((int)blockIdx.x >= particleBlocks) {
     const int c = (blockIdx.x - particleBlocks) * kBlock + threadIdx.x;
     const int ncells = cellDim.x * cellDim.y * cellDim.z;
@@ -227,6 +228,10 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter2(const float4 *__restri
     const uint h = morton_hash(cc);
     const uint s = keyStart[h], e = keyStart[h + 1];
     const bool out = keyOutside[h] != 0;
+    // this key's counter and flag have done their job: left at zero, the next build of the same grid needs no memset launch (every
+    // key that was touched belongs to a cell; the scan's input beyond the last key was never written)
+    if (e > s) keyCount[h] = 0u;
+    if (out) keyOutside[h] = 0;
     cellStart[c] = (e > s) ? s + validCell : 0u;
     cellEnd[c] = (int)e;
     cellOutside[c] = out;
@@ -525,8 +530,15 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     errorFlag.alias(base, errB);
     keyOutside.alias(tabulated ? base + errB : nullptr, koB);
     keyCount.alias(counting ? base + errB + koB : nullptr, kcB);
-    if (N == 0) { UH_CHECK(hipMemsetAsync(base, 0, errB, st)); return 0; }
-    UH_CHECK(hipMemsetAsync(base, 0, errB + koB + kcB, st));
+    if (N == 0) { UH_CHECK(hipMemsetAsync(base, 0, errB, st)); zeroBlockClean = false; return 0; }
+    // the counting build hands the block back zeroed (k_rank_scatter2); anything else — first use, another layout, a radix build, a
+    // build cut short by an error — clears it here
+    const bool clean = zeroBlockClean && base == zeroBase && zeroLayout[0] == koB && zeroLayout[1] == kcB && counting;
+    if (!clean) UH_CHECK(hipMemsetAsync(base, 0, errB + koB + kcB, st));
+    zeroBlockClean = false;
+    zeroBase = base;
+    zeroLayout[0] = koB;
+    zeroLayout[1] = kcB;
   }
   if (counting) {
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
@@ -553,8 +565,9 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     const int pb = nblocks(N);
     hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
                        (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr,
-                       (const unsigned char *)keyOutside.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr, (int *)cellEnd.ptr,
-                       (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
+                       (unsigned char *)keyOutside.ptr, (uint *)keyCount.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
+                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
+    zeroBlockClean = true;
     haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;

@@ -27,7 +27,11 @@ struct CellList {
   DeviceBuffer packHalf;  // half-precision copy of sortPos for the traversals' prefilter, built on demand (ensure_pack)
   bool packValid = false;
   float packScale = 0.f;
-  DeviceBuffer zeroBlock;  // errorFlag | keyOutside | keyCount live here: ONE memset per build instead of three
+  DeviceBuffer zeroBlock;  // errorFlag | keyOutside | keyCount live here: ONE memset per build instead of three — and none when the
+                           // previous counting build of the same grid left it zeroed (zeroBlockClean)
+  bool zeroBlockClean = false;
+  char *zeroBase = nullptr;
+  size_t zeroLayout[2] = {0, 0};
   GridT<float> grid{};
   float boxL[3] = {0, 0, 0};
   int boxPeriodic[3] = {0, 0, 0};

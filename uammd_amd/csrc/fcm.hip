@@ -53,6 +53,7 @@ struct FCM {
   bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
+  bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
   bool forceAtomicSpread = false;  // test hook
   bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
@@ -170,7 +171,8 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
   pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
 }
 
-__global__ void __launch_bounds__(1024) k_fcm_tile_scan(const int *__restrict__ count, int ntiles, int *__restrict__ start) {
+__global__ void __launch_bounds__(1024) k_fcm_tile_scan(int *__restrict__ count, int ntiles, int *__restrict__ start) {
+  // (the counters are left at ZERO for the next step's binning: no memset launch per step)
   // exclusive scan of the tile populations by one workgroup, 4096 consecutive tiles per round: a thread takes four consecutive tiles
   // (one 16-byte load and store, coalesced), the threads' sums are scanned with wave shuffles + one 16-entry LDS pass, the rounds are
   // chained by a running carry.  (History: a Hillis-Steele loop needed 20 barriers per 1024 tiles, 8.3 us for the 4096 tiles of C4;
@@ -182,11 +184,13 @@ __global__ void __launch_bounds__(1024) k_fcm_tile_scan(const int *__restrict__ 
   for (int base = 0; base < ntiles; base += 4096, buf ^= 1) {
     const int i = base + 4 * (int)threadIdx.x;
     int4 c = make_int4(0, 0, 0, 0);
-    if (i + 3 < ntiles) c = *reinterpret_cast<const int4 *>(count + i);
-    else {
-      if (i < ntiles) c.x = count[i];
-      if (i + 1 < ntiles) c.y = count[i + 1];
-      if (i + 2 < ntiles) c.z = count[i + 2];
+    if (i + 3 < ntiles) {
+      c = *reinterpret_cast<const int4 *>(count + i);
+      *reinterpret_cast<int4 *>(count + i) = make_int4(0, 0, 0, 0);
+    } else {
+      if (i < ntiles) { c.x = count[i]; count[i] = 0; }
+      if (i + 1 < ntiles) { c.y = count[i + 1]; count[i + 1] = 0; }
+      if (i + 2 < ntiles) { c.z = count[i + 2]; count[i + 2] = 0; }
     }
     const int v = c.x + c.y + c.z + c.w;
     int incl = v;
@@ -1002,16 +1006,20 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
     if (int e = f->prepTileOf.reserve(sizeof(int) * (size_t)N)) return e;
     if (int e = f->prepRank.reserve(sizeof(int) * (size_t)N)) return e;
     if (int e = f->prepTileCount.reserve(sizeof(int) * (size_t)nt)) return e;
+    f->tileCountZero = false;
     if (int e = f->prepTileStart.reserve(sizeof(int) * ((size_t)nt + 1))) return e;
     f->prepCapN = N;
   }
   FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
              (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
              (int *)f->prepTileStart.ptr, wstride};
-  UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
+  if (!f->tileCountZero) {  // first use of the buffer; afterwards k_fcm_tile_scan hands the counters back zeroed
+    UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
+    f->tileCountZero = true;
+  }
   hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
                      f->ntiles, pr);
-  hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, (const int *)pr.tileCount, nt, pr.tileStart);
+  hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, pr.tileCount, nt, pr.tileStart);
 #define UH_PREPARE(K)                                                                                          \
   case K:                                                                                                      \
     hipLaunchKernelGGL(k_fcm_prepare<K>, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,       \
