@@ -486,6 +486,7 @@ def main():
     ap.add_argument("--fcm-sort", type=float, default=0.0, help="sort particles on a grid of this cell size first")
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra FCM C5 (256^3) line: profiling runs that must see C4 kernels only")
     ap.add_argument("--cpu-sample-steps", type=int, default=20)
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--sort-every", type=int, default=500, help="ParticleData::sortParticles period of the LJ run (benchmark.cu: 500)")
@@ -525,7 +526,8 @@ def main():
         out = (run_fcm_distributed if (world > 1 or args.force_distributed) else run_fcm)(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
-        out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
+        if not args.no_c5:
+            out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
         out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic"})
         if rank == 0:
@@ -674,7 +676,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             fcm["cpu_baseline"] = cpu_baseline_fcm(args.cpu_fcm_steps)
         out["fcm"] = fcm
-        out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
+        if not args.no_c5:
+            out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:

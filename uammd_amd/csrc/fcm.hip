@@ -829,7 +829,8 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
   // element (component c, plane j, line q) at c planeC + j zStride + q; q = yl nkx + kx runs over this rank's y rows [y0, y0 + nyl)
   // (single GPU: the whole grid, zStride = ny nkx; slab decomposition: the y-pencil layout [z][c][yl][kx], zStride = 3 nyl nkx)
   const size_t slab = zStride;
-  const int q0 = blockIdx.x * TL, nl = min(TL, nyl * nkx - q0);
+  // (adjacent tiles share 128-byte lines — a tile of 8 nodes is 64 bytes of every z plane: same XCD, same L2)
+  const int q0 = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * TL, nl = min(TL, nyl * nkx - q0);
   float2 *base = g + q0 + l;
   fft_twiddles<NT>(tw, nz, tid);
   if (haveForce) {

@@ -146,7 +146,10 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
   extern __shared__ float2 lds[];
   const int n = 1 << log2n, LS = n + 1;
   float2 *tw = lds, *buf = lds + n;
-  const int tid = threadIdx.x, group = blockIdx.x / tilesPerGroup, tile = blockIdx.x - group * tilesPerGroup;
+  // neighbouring tiles of a plane share the 128-byte lines their 16-complex segments straddle (a row is 8 (nx / 2 + 1) bytes: never a
+  // multiple of 128): dealt round-robin to the XCDs every such line was fetched from HBM twice (55 MB per pass of a 25.6 MB grid at C4)
+  const int blk = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, group = blk / tilesPerGroup, tile = blk - group * tilesPerGroup;
   const int kx0 = tile * 16, nl = min(16, nkx - kx0), l = tid & 15, jg = tid >> 4;
   float2 *base = g + (size_t)group * n * nkx + kx0 + l;
   fft_twiddles<NT>(tw, n, tid);
