@@ -178,10 +178,10 @@ class _Exchange:
     def all_to_all(self, blocks):
         """blocks[i]: tensor [P, ...], slice d goes to rank d.  Returns tensors [P, ...] with slice s received from rank s."""
         P = self.world
+        if P == 1:
+            return [blocks[0]]          # the only rank keeps its block: nothing moves, nothing is copied
         if self.in_process:
             return [torch.stack([blocks[s][r] for s in range(P)], dim=0) for r in range(P)]
-        if P == 1:
-            return [blocks[0]]
         out = torch.empty_like(blocks[0])
         dist.all_to_all_single(out, blocks[0].contiguous(), group=self.group)
         return [out]
@@ -234,7 +234,9 @@ class DistributedFCM:
         out = []
         for i in range(n):
             # [src][zl][c][yl][kx] -> [zl][c][y = (src, yl)][kx], written straight into the owned planes of the window
-            self.b[i].spectrum_view(grids[i]).view(nzl, 3, P, nyl, g.nkx, 2).copy_(back[i].permute(1, 2, 0, 3, 4, 5))
+            dst = self.b[i].spectrum_view(grids[i]).view(nzl, 3, P, nyl, g.nkx, 2)
+            if not (P == 1 and back[i].data_ptr() == dst.data_ptr()):   # (one rank: the z pass ran in place on the window's own spectrum)
+                dst.copy_(back[i].permute(1, 2, 0, 3, 4, 5))
             self.b[i].inverse_xy(grids[i])
         fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in grids], [gr[H:H + He] for gr in grids])
         for i, gr in enumerate(grids):
