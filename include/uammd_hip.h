@@ -482,6 +482,10 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int number
                           float *d_linearVelocity, void *stream);
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream); /* in place on the owned planes */
 int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
+/* the inverse writing the owned planes of a float4 window d_inter[z][y][x] = (vx, vy, vz, 0) (returns 1 and does nothing when the grid
+ * does not take the library's own FFT), and the gather that reads that window once the caller has exchanged its halo planes */
+int uammd_fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, void *stream);
+int uammd_fcm_slab_gather_inter(uammd_fcm_slab *h, const float *d_posLocal, int N, const float *d_inter, float *d_vel, void *stream);
 int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream);
 /* the three calls above (forward z, operator, inverse z) in one pass over d_cplxZ when nz is a power of two; returns 1 (and does
  * nothing) when the grid does not allow it */

@@ -180,6 +180,8 @@ SIGNATURES = {
     "uammd_fcm_slab_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "uammd_fcm_slab_forward_xy": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_slab_inverse_xy_inter": (_i, [_vp, _vp, _vp, _vp]),
+    "uammd_fcm_slab_gather_inter": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "uammd_fcm_slab_fft_z": (_i, [_vp, _vp, _i, _vp]),
     "uammd_fcm_slab_kspace": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),
     "uammd_fcm_slab_z_fused": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),

@@ -1456,6 +1456,45 @@ int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   return 0;
 }
 
+// The same inverse writing the OWNED planes of the gather's float4 window d_inter [z][y][x] = (vx, vy, vz, 0) (nz window planes of
+// ny x nx nodes) instead of the planar real rows: the single-GPU path's fusion of the inverse row pass with the interleaving copy.
+// The caller exchanges the halo planes of d_inter and hands it to uammd_fcm_slab_gather_inter.  Returns 1 (nothing done) when the
+// grid does not take the custom FFT: the caller then uses uammd_fcm_slab_inverse_xy + uammd_fcm_slab_gather.
+int uammd_fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, void *stream) {
+  if (!h || !d_grid || !d_inter) { set_last_error("uammd_fcm_slab_inverse_xy_inter: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  if (!fcm_slab_custom_fft(s) || !(s->loc.useTiles && !s->loc.forceAtomicSpread)) return 1;  // (the float4 gather reads tile-prepared stencils)
+  float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
+  const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * s->nzl;
+  fft_launch_lines<1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                     (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
+                     nrows, rows, (float4 *)d_inter + (size_t)s->halo * ny * nx);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// gather from the float4 window filled by uammd_fcm_slab_inverse_xy_inter (+ the caller's halo exchange); needs the stencils prepared
+// by uammd_fcm_slab_spread with the same positions
+int uammd_fcm_slab_gather_inter(uammd_fcm_slab *h, const float *d_posLocal, int N, const float *d_inter, float *d_vel, void *stream) {
+  if (!h || !d_inter || (N > 0 && (!d_posLocal || !d_vel))) { set_last_error("uammd_fcm_slab_gather_inter: null argument"); return -1; }
+  if (N <= 0) return 0;
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  FCM *f = &s->loc;
+  if (!(f->useTiles && !f->forceAtomicSpread) || f->prepCapN < N) {
+    set_last_error("uammd_fcm_slab_gather_inter: needs the tile-prepared stencils of uammd_fcm_slab_spread");
+    return -3;
+  }
+  const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+  FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr, (int *)f->prepTileOf.ptr,
+             (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr, (int *)f->prepTileStart.ptr,
+             f->kern.support.x + f->kern.support.y + f->kern.support.z};
+  hipLaunchKernelGGL(k_fcm_gather_inter, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_vel, (const float4 *)d_inter, N,
+                     f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 // 1-D complex FFT along z of d_cplxZ [z][c][yl][kx], in place
 int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream) {
   if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_fft_z: null argument"); return -1; }

@@ -134,6 +134,27 @@ class HipSlabBackend:
     def inverse_xy(self, grid):
         self._check(self.lib.uammd_fcm_slab_inverse_xy(self.h, self._p(grid), self._st()))
 
+    def inverse_xy_inter(self):
+        """The inverse writing the owned planes of the gather's float4 window (self.inter) directly; None when the grid does not take the
+        library's own FFT or the spread is not the tile-owned one (the caller then uses inverse_xy + gather)."""
+        if getattr(self, "_no_inter", False):
+            return None
+        g = self.g
+        if getattr(self, "inter", None) is None:
+            self.inter = torch.zeros((self.grid.shape[0], g.cells[1], g.cells[0], 4), dtype=torch.float32, device=self.device)
+        rc = self.lib.uammd_fcm_slab_inverse_xy_inter(self.h, self._p(self.grid), self._p(self.inter), self._st())
+        if rc == 1:
+            self._no_inter = True
+            return None
+        self._check(rc)
+        return self.inter
+
+    def gather_inter(self, pos_local, inter):
+        out = torch.empty((pos_local.shape[0], 3), dtype=torch.float32, device=self.device)
+        self._check(self.lib.uammd_fcm_slab_gather_inter(self.h, self._p(pos_local), pos_local.shape[0], self._p(inter), self._p(out),
+                                                         self._st()))
+        return out
+
     def gather(self, pos_local, grid):
         out = torch.empty((pos_local.shape[0], 3), dtype=torch.float32, device=self.device)
         self._check(self.lib.uammd_fcm_slab_gather(self.h, self._p(pos_local), pos_local.shape[0], self._p(grid), self._p(out),
@@ -231,18 +252,27 @@ class DistributedFCM:
             self.b[i].kspace(zbufs[i], have_force, temperature, prefactor, self.seed2)
             self.b[i].fft_z(zbufs[i], True)
         back = self.x.all_to_all([zb.view(P, nzl, 3, nyl, g.nkx, 2) for zb in zbufs])   # [src(y block)][zl][c][yl][kx]
-        out = []
+        out, fields = [], []
         for i in range(n):
             # [src][zl][c][yl][kx] -> [zl][c][y = (src, yl)][kx], written straight into the owned planes of the window
             dst = self.b[i].spectrum_view(grids[i]).view(nzl, 3, P, nyl, g.nkx, 2)
             if not (P == 1 and back[i].data_ptr() == dst.data_ptr()):   # (one rank: the z pass ran in place on the window's own spectrum)
                 dst.copy_(back[i].permute(1, 2, 0, 3, 4, 5))
-            self.b[i].inverse_xy(grids[i])
-        fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in grids], [gr[H:H + He] for gr in grids])
-        for i, gr in enumerate(grids):
+            inv = getattr(self.b[i], "inverse_xy_inter", None)
+            it = inv() if inv is not None else None     # (a property of the grid and the library: every rank decides alike)
+            if it is None:
+                self.b[i].inverse_xy(grids[i])
+            fields.append(it)
+        if any(f is None for f in fields):            # (all ranks decide alike: same grid, same library)
+            for i, f in enumerate(fields):
+                if f is not None:
+                    raise RuntimeError("ranks disagree on the gather layout")
+            fields = grids
+        fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in fields], [gr[H:H + He] for gr in fields])
+        for i, gr in enumerate(fields):
             gr[H - He:H] = fd[i]
             gr[H + nzl:H + nzl + He] = fu[i]
-            out.append(self.b[i].gather(pos_locals[i], gr))
+            out.append(self.b[i].gather(pos_locals[i], gr) if fields is grids else self.b[i].gather_inter(pos_locals[i], gr))
         return out
 
 
