@@ -191,7 +191,16 @@ __global__ void __launch_bounds__(kSlabBlock) k_slab_max_disp(const float4 *__re
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) d = fmaxf(d, __shfl_xor(d, o, 64));
-  if ((threadIdx.x & 63) == 0 && d > 0.0f) atomicMax(maxBits, __float_as_uint(d));  // non-negative floats order as their bits
+  __shared__ float wmax[kSlabBlock / 64];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kSlabBlock / 64; ++w) d = fmaxf(d, wmax[w]);
+    // one atomic per workgroup, and only from those that can raise the maximum (16 k waves hammering one address serialised into
+    // 180 us per call); non-negative floats order as their bits
+    const uint bits = __float_as_uint(d);
+    if (bits > __hip_atomic_load(maxBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxBits, bits);
+  }
 }
 
 }  // namespace uammd_hip
