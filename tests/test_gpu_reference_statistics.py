@@ -1,0 +1,106 @@
+"""The reference's statistical acceptance tests on the product (the deterministic ones are in test_gpu_ibm_fcm.py and
+test_gpu_fcm_pair_mobility.py):
+
+  * test/BDHI/FCM/FCM.cu:489-548 noiseVariance_test: one particle, dt = 1, the variance of its displacement per step is
+    2 T M0 in every direction, M0 = getSelfMobility() of the periodic box, for boxes from 4 to 128 radii;
+  * test/BDHI/FCM/FCM.cu:396-453 + test.bash:130-166 selfDiffusionCubicBox: 4096 non-interacting particles, dt = 0.001,
+    mean square displacement 2 D0 t per direction with D0 = T M0 (the hydrodynamic coupling between the particles does not
+    change a particle's own diffusion);
+  * test/BD/test.bash:14-70: BD::EulerMaruyama, 16384 particles, no potential, L = 32, dt = 1, T = 1, eta = 1/(6 pi):
+    msd slope over the first five lags = 2 D0, D0 = 1.
+The reference prints the deviations and leaves the judgement to plots; the bars here are 3.5 standard errors of the estimators
+(stated at each test) — runs are shortened where the statistics allow."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fcm_integrator(hip, n, L, T, dt, tol=1e-3, a=1.0, eta=1.0, seed=0x33dbff9f):
+    from uammd_amd import bdhi
+    pd = hip.ParticleData(n, seed=seed)
+    par = bdhi.FCMIntegrator.Parameters(temperature=T, viscosity=eta, hydrodynamicRadius=a, tolerance=tol, dt=dt, box=hip.Box(float(L)))
+    integ = bdhi.FCMIntegrator(pd, par)
+    return pd, integ
+
+
+# of FCM.cu:531-536's ten boxes between 4 and 128 radii (a 4-radius box does not hold the 6-point Gaussian: "Kernel support is too
+# big", as in the reference)
+@pytest.mark.parametrize("L", [8.0, 17.8, 45.3, 72.9])
+def test_fcm_noise_variance(hip, L):
+    T, nsteps = 1.3, 4000
+    pd, integ = _fcm_integrator(hip, 1, L, T, 1.0)
+    rng = np.random.default_rng(1234791)
+    p0 = np.zeros((1, 4), np.float32)
+    p0[0, :3] = rng.uniform(-0.5, 0.5, 3) * L
+    pd.setPos(p0)
+    hist = torch.empty((nsteps + 1, 3), dtype=torch.float32, device="cuda")
+    hist[0] = pd.getPos("read")[0, :3]
+    for i in range(nsteps):
+        integ.forwardTime()
+        hist[i + 1] = pd.getPos("read")[0, :3]
+    h = hist.cpu().numpy().astype(np.float64)
+    noise = np.diff(h, axis=0)
+    var = noise.var(axis=0)
+    m0 = integ.fcm.getSelfMobility()
+    ratio = var / (2 * T * m0)
+    # a variance estimated from n Gaussian samples has relative standard error sqrt(2 / n) = 2.2 %
+    assert np.all(np.abs(ratio - 1.0) <= 3.5 * math.sqrt(2.0 / nsteps)), (L, ratio)
+    assert np.all(np.abs(noise.mean(axis=0)) <= 4.0 * np.sqrt(var / nsteps)), "the noise has a drift"
+
+
+@pytest.mark.parametrize("L", [8.0, 54.0])                    # FCM.cu:441-452: L between 8 and 100 radii
+def test_fcm_self_diffusion(hip, L):
+    T, dt, n, nsteps = 1.0, 0.001, 4096, 600
+    pd, integ = _fcm_integrator(hip, n, L, T, dt)
+    rng = np.random.default_rng(0x33dbff)
+    p0 = np.zeros((n, 4), np.float32)
+    p0[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    pd.setPos(p0)
+    # The script fits msd(t) = 2 a D0 t with weights 1 / t^4 (test.bash:147-152): the short lags decide.  The particles share the
+    # fluid's long-wavelength modes, so averaging over them does not give 4096 independent samples of a long displacement (at
+    # L = 8 radii one 600-step displacement per particle scatters by 15 %); the steps ARE independent, so the estimator here is
+    # the unit-lag msd accumulated over every step.
+    prev = pd.getPos("read")[:, :3].clone()
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for i in range(nsteps):
+        integ.forwardTime()
+        cur = pd.getPos("read")[:, :3]
+        d = (cur - prev).double()
+        acc += (d * d).mean(dim=0)
+        prev.copy_(cur)
+    d0 = T * integ.fcm.getSelfMobility()
+    a = (acc / nsteps).cpu().numpy() / (2 * d0 * dt)
+    # nsteps independent draws of a field with at least a few dozen independent modes: bar 5 %
+    assert np.all(np.abs(a - 1.0) <= 0.05), (L, a)
+
+
+def test_bd_euler_maruyama_msd(hip):
+    """test/BD/test.bash: D0 = T / (6 pi eta a) = 1 with eta = 1 / (6 pi); slope of the msd over the first five lags."""
+    n, L, dt, T, nsteps = 16384, 32.0, 1.0, 1.0, 200
+    pd = hip.ParticleData(n, seed=0xBD)
+    rng = np.random.default_rng(5)
+    p0 = np.zeros((n, 4), np.float32)
+    p0[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    pd.setPos(p0)
+    par = hip.BD.EulerMaruyama.Parameters(temperature=T, viscosity=1.0 / (6.0 * math.pi), hydrodynamicRadius=1.0, dt=dt)
+    integ = hip.BD.EulerMaruyama(pd, par)
+    traj = torch.empty((nsteps + 1, n, 3), dtype=torch.float32, device="cuda")
+    traj[0] = pd.getPos("read")[:, :3]
+    for i in range(nsteps):
+        integ.forwardTime()
+        traj[i + 1] = pd.getPos("read")[:, :3]
+    tr = traj.double()
+    lag_t, lag_msd = [], []
+    for lag in range(1, 6):                                    # `msd | head -5`: lags 0..4 in the script; lag 0 carries no information
+        d = tr[lag:] - tr[:-lag]
+        lag_t.append(lag * dt)
+        lag_msd.append((d * d).mean(dim=(0, 1)).cpu().numpy())
+    t, m = np.array(lag_t), np.array(lag_msd)
+    slope = ((len(t) * (t[:, None] * m).sum(axis=0) - m.sum(axis=0) * t.sum()) / (len(t) * (t ** 2).sum() - t.sum() ** 2))
+    dev = 1.0 - slope / (2 * dt * 1.0)
+    # ~ 200 x 16384 independent unit-lag increments per direction: standard error of the slope well under 0.2 %
+    assert np.all(np.abs(dev) <= 1e-2), dev
