@@ -104,3 +104,31 @@ def test_bd_euler_maruyama_msd(hip):
     dev = 1.0 - slope / (2 * dt * 1.0)
     # ~ 200 x 16384 independent unit-lag increments per direction: standard error of the slope well under 0.2 %
     assert np.all(np.abs(dev) <= 1e-2), dev
+
+
+def test_fcm_hydrodynamic_radius_variance(hip):
+    """test/BDHI/FCM/FCM.cu:166-195 hydrodynamicRadiusVariance_test: the self mobility of a particle pulled along x as its position
+    sweeps one grid cell (L = 64 cells of size 1, Gaussian chosen by the tolerance alone) — the window's translational-invariance
+    error.  The reference prints mean and (max - min) / 2 of M_xx / M0 for the reader; here: the mean within the tolerance of 1, the
+    spread within a few tolerances, the off-diagonal response within the tolerance of zero."""
+    from uammd_amd import bdhi
+    tol, eta, n = 1e-3, 1.0, 64
+    par = bdhi.FCM.Parameters(viscosity=eta, tolerance=tol, box=hip.Box(float(n)), cells=[n] * 3, seed=1)
+    box, cells, kernel, a_eff = bdhi._initialize(par, None)
+    fcm = hip.BDHI.FCM_impl(box, cells, kernel, eta, 1, a_eff)
+    m0 = fcm.getSelfMobility()
+    rng = np.random.default_rng(11)
+    pos = torch.zeros((1, 4), dtype=torch.float32, device="cuda")
+    frc = torch.zeros((1, 4), dtype=torch.float32, device="cuda")
+    frc[0, 0] = 1.0
+    out = []
+    for _ in range(400):
+        p = np.zeros((1, 4), np.float32)
+        p[0, 0], p[0, 1] = -n / 2 + rng.uniform(0, 1), -n / 2 + rng.uniform(0, 1)     # FCM.cu:181-184: x, y inside one cell, z = 0
+        pos.copy_(torch.from_numpy(p))
+        out.append(fcm.computeHydrodynamicDisplacements(pos, frc, 1, 0.0, 0.0).cpu().numpy()[0] / m0)
+    out = np.array(out, np.float64)
+    mean, half_range = out[:, 0].mean(), 0.5 * (out[:, 0].max() - out[:, 0].min())
+    assert abs(mean - 1.0) <= 2 * tol, mean
+    assert half_range <= 3 * tol, half_range
+    assert np.abs(out[:, 1:]).max() <= tol
