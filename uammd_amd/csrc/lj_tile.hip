@@ -48,8 +48,11 @@ using LdsV = __attribute__((address_space(3))) void;
 
 constexpr int kMaxW = 12;                  // hit words (of 64 candidates) one wave can hold per pass
 constexpr int kSoloCap = 512;              // candidate slots of the single-wave kernel (8 words per chunk)
-constexpr int kBrickCap = 1024;            // candidate slots of the four-wave kernel
-constexpr int kTabWords = (kMaxW + 1) * 64 + 2 * (kMaxW + 2);  // per wave: hit words [kMaxW + 1][64] | word base [kMaxW + 2] | word count [kMaxW + 2]
+constexpr int kBrickCap = 992;             // candidate slots of the four-wave kernel (a C3 brick stages 805 +- 30; with the tables: 31.2 KB, five workgroups per CU)
+constexpr int kFallbackRegion = (kBrickCap + 64) / 4;  // slots per wave of the dense-brick fallback: 256 of work + guard
+static_assert(kFallbackRegion >= 256 + 2 && kFallbackRegion - 256 <= 16, "fallback guard slots");
+// per wave: hit words [kMaxW + 1][64] | word base [kMaxW + 2] | word count [kMaxW + 2] | absolute word base of either half-wave [2][kMaxW + 2]
+constexpr int kTabWords = (kMaxW + 1) * 64 + 4 * (kMaxW + 2);
 
 // count of leading zeros; 0xFFFFFFFF for 0 (v_ffbh_u32)
 UH_D int __builtin_clz_or_neg1(uint v) { return v ? __builtin_clz(v) : -1; }
@@ -129,12 +132,12 @@ template <bool PBC> UH_D void tile_centre(const TileFrame &fr, float x, float y,
   }
 }
 
-template <bool PBC> UH_D v16f tile_distances(uint candAddr, const TileFrame &fr, const h8t &B) {
+template <bool PBC> UH_D v16f tile_distances(uint candAddr, const TileFrame &fr, const h8t &B, uint ones) {
   const f4t c = *(const LdsF4 *)(uintptr_t)candAddr;
   float bx, by, bz;
   tile_centre<PBC>(fr, c.x, c.y, c.z, bx, by, bz);
   const uint pxy = pk_rtz(bx, by), pz0 = pk_rtz(bz, 0.0f);
-  const u4t a = {pxy, pz0, split_h(sq3_h(pxy, pz0)), 0x3c003c00u};
+  const u4t a = {pxy, pz0, split_h(sq3_h(pxy, pz0)), ones};
   const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8t, a), B, z, 0, 0, 0);
 }
@@ -161,16 +164,20 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
   const uint myMask = tab + 4u * (uint)lane;                  // hit word w of this lane at + 256 w
   const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
   // ---- scan: two matrix steps per word; the values of the next step are on the matrix pipe while this one is turned into bits ----
+  // (the two 1.0 halves of the candidate operand, hidden from constant folding: as a literal the compiler assembles the operand from a
+  // constant vector, five register moves per matrix step)
+  uint ones = 0x3c003c00u;
+  asm volatile("" : "+v"(ones));
   uint wb = *(const LdsU *)(uintptr_t)wbaseTab;
-  v16f dA = tile_distances<PBC>(rowAddr + wb, fr, B);
+  v16f dA = tile_distances<PBC>(rowAddr + wb, fr, B, ones);
   for (uint w = 0; w < nW; ++w) {
-    const v16f dB = tile_distances<PBC>(rowAddr + wb + 512u, fr, B);
+    const v16f dB = tile_distances<PBC>(rowAddr + wb + 512u, fr, B, ones);
     const uint cnt = *(const LdsU *)(uintptr_t)(wcntTab + 4u * w);
     const uint mA = tile_bits16(dA);
-    if (w + 1 < nW) {
-      wb = *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1));
-      dA = tile_distances<PBC>(rowAddr + wb, fr, B);
-    }
+    // (unconditional: behind the last word this is entry nW of the table = slot 0, a wasted step — a conditional one makes the
+    // compiler keep two register sets for dA and copy 16 registers per word)
+    wb = *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1));
+    dA = tile_distances<PBC>(rowAddr + wb, fr, B, ones);
     uint m = (mA << 16) | tile_bits16(dB);
     if (__builtin_amdgcn_readfirstlane(cnt) < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
       const uint mine = (cnt + 1u - (uint)hi) >> 1;
@@ -179,29 +186,36 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
     *(LdsU *)(uintptr_t)(myMask + 256u * w) = m;
   }
   // ---- drain: every lane walks its own hit words (bit j from the top of word w = slot 2 j + h of the word) ----
-  // cw / cb = the word being consumed and its LDS base, nw / nb = the next one; word nW of every lane is zero and a lane never moves
-  // past word nW - 1.  A lane without a set bit in cw takes a dead slot: ffbh(0) = -1 addresses slot -2 of the word — staged data of
-  // another row or the two guard slots in front of the buffer, finite either way — with weight 0.
+  // cw / cb = the word being consumed and the LDS address of its slot h, nw / nb = the next one; word nW of every lane is zero and a
+  // lane never moves past word nW - 1 (the look-ahead reads words nW and nW + 1: rows of the table that exist, never consumed).  A lane
+  // without a set bit in cw takes a dead slot: ffbh(0) = -1 addresses slot -2 of the word — staged data of another row or the two
+  // guard slots in front of the buffer, finite either way — with weight 0.
   *(LdsU *)(uintptr_t)(myMask + 256u * nW) = 0u;
-  const uint candHalf = candBase + 16u * (uint)hi;
+  const uint wabsTab = wcntTab + 4u * (uint)((kMaxW + 2) * (1 + hi));  // candBase + 16 hi + wbase[w]
   uint cw = *(const LdsU *)(uintptr_t)myMask;
   uint nw = *(const LdsU *)(uintptr_t)(myMask + 256u);
-  uint cb = candHalf + *(const LdsU *)(uintptr_t)wbaseTab;
-  uint nb = candHalf + *(const LdsU *)(uintptr_t)(wbaseTab + 4u);
-  uint wi = 0;  // index of cw, <= nW - 1
+  uint cb = *(const LdsU *)(uintptr_t)wabsTab;
+  uint nb = *(const LdsU *)(uintptr_t)(wabsTab + 4u);
+  uint wi1 = 1;  // 1 + index of cw, <= nW
+  unsigned long long more;  // lanes with wi1 < nW
+  asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(more) : "v"(wi1), "s"(nW));
   // Two pairs per iteration (instruction-level parallelism for the rcp / polynomial chains, two LDS reads in flight): advance to the
   // next word when this one is used up, then take the TWO highest set bits; a word with an odd number of hits leaves one dead slot:
   // 19 iterations per tile against 35 with one pair per iteration on a model liquid.
   auto pop2 = [&](bool &live0, bool &live1, uint &a0, uint &a1) {
-    const uint wn = min(wi + 2u, nW);
-    const uint tw = *(const LdsU *)(uintptr_t)(myMask + 256u * wn);
-    const uint tb = candHalf + *(const LdsU *)(uintptr_t)(wbaseTab + 4u * wn);
-    const bool adv = cw == 0 && wi + 1u < nW;
-    cw = adv ? nw : cw;
-    cb = adv ? nb : cb;
-    nw = adv ? tw : nw;
-    nb = adv ? tb : nb;
-    wi += adv ? 1u : 0u;
+    const uint tw = *(const LdsU *)(uintptr_t)(myMask + 256u * wi1 + 256u);
+    const uint tb = *(const LdsU *)(uintptr_t)(wabsTab + 4u * wi1 + 4u);
+    // advance: cw == 0 and words left.  (Lane masks by hand: from `wi1 += adv` the compiler makes a select and an add, from a ballot
+    // of adv a select and a compare; the mask of the compare is the carry-in of one v_addc.)
+    unsigned long long adv, co;
+    asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(adv) : "v"(cw));
+    adv &= more;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cw) : "v"(cw), "v"(nw), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cb) : "v"(cb), "v"(nb), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nw) : "v"(nw), "v"(tw), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nb) : "v"(nb), "v"(tb), "s"(adv));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(wi1), "=s"(co) : "v"(wi1), "s"(adv));
+    asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(more) : "v"(wi1), "s"(nW));
     live0 = cw != 0;
     const uint k0 = (uint)__builtin_clz_or_neg1(cw);
     cw &= ~(0x80000000u >> (k0 & 31u));
@@ -215,7 +229,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
   uint a0, a1;
   pop2(lN0, lN1, a0, a1);
   f4t cN0 = *(const LdsF4 *)(uintptr_t)a0, cN1 = *(const LdsF4 *)(uintptr_t)a1;
-  while (__any(lN0 || wi + 1u < nW)) {  // some lane still holds a pair or has words left (empty trailing words are walked through)
+  while (__any(lN0) || more != 0) {  // some lane still holds a pair or has words left (empty trailing words are walked through)
     const f4t c0 = cN0, c1 = cN1;
     const bool l0 = lN0, l1 = lN1;
     pop2(lN0, lN1, a0, a1);  // the candidates of the next two pairs are on their way from LDS while these two are evaluated
@@ -257,16 +271,27 @@ UH_D OwnerSide tile_owner(const float4 *__restrict__ P, uint ownFirst, int nOwn,
   return o;
 }
 
-UH_D TileFrame tile_frame(const GridT<float> &grid, const BoxT<float> &box, float ox, float oy, float oz) {
+// the part of the frame that depends on the grid and the box only: k_lj_tile4 takes it from the host as a kernel argument (four IEEE
+// divisions = ~48 vector instructions per wave otherwise; host and device round a division the same way, so the values are the same)
+inline __host__ __device__ TileFrame tile_scale(const GridT<float> &grid, const BoxT<float> &box) {
   TileFrame fr;
-  const float e = fmaxf(grid.cellSize.x, fmaxf(grid.cellDim.y > 1 ? grid.cellSize.y : 0.f, grid.cellDim.z > 1 ? grid.cellSize.z : 0.f));
+  const float ey = grid.cellDim.y > 1 ? grid.cellSize.y : 0.f, ez = grid.cellDim.z > 1 ? grid.cellSize.z : 0.f;
+  const float eyz = ey > ez ? ey : ez;
+  const float e = grid.cellSize.x > eyz ? grid.cellSize.x : eyz;
   fr.s = 1.0f / e;
-  fr.nox = -ox * fr.s; fr.noy = -oy * fr.s; fr.noz = -oz * fr.s;
+  fr.nox = fr.noy = fr.noz = 0.0f;
   fr.Lx = box.boxSize.x * fr.s; fr.Ly = box.boxSize.y * fr.s; fr.Lz = box.boxSize.z * fr.s;
   fr.mx = box.px() ? -1.0f / fr.Lx : 0.0f;
   fr.my = box.py() ? -1.0f / fr.Ly : 0.0f;
   fr.mz = box.pz() ? -1.0f / fr.Lz : 0.0f;
   return fr;
+}
+UH_D TileFrame tile_centred(TileFrame fr, float ox, float oy, float oz) {
+  fr.nox = -ox * fr.s; fr.noy = -oy * fr.s; fr.noz = -oz * fr.s;
+  return fr;
+}
+UH_D TileFrame tile_frame(const GridT<float> &grid, const BoxT<float> &box, float ox, float oy, float oz) {
+  return tile_centred(tile_scale(grid, box), ox, oy, oz);
 }
 
 template <bool WE, bool WV>
@@ -333,7 +358,11 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
   const f4t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};  // padding behind the last candidate: finite; the word counts clear its bits
   LdsF4 *cand = (LdsF4 *)(uintptr_t)candBase;
   const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
-  if (lane < kMaxW + 2) *(LdsU *)(uintptr_t)(wbaseTab + 4u * (uint)lane) = 1024u * (uint)lane;  // words = consecutive blocks of 64 slots
+  if (lane < kMaxW + 2) {  // words = consecutive blocks of 64 slots
+    *(LdsU *)(uintptr_t)(wbaseTab + 4u * (uint)lane) = 1024u * (uint)lane;
+    *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)(kMaxW + 2 + lane)) = candBase + 1024u * (uint)lane;
+    *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)(2 * (kMaxW + 2) + lane)) = candBase + 16u + 1024u * (uint)lane;
+  }
   for (int o0 = 0; o0 < nOwn; o0 += 32) {
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcTile, fr, ox, oy, oz, rc2ms);
     Acc acc;
@@ -396,15 +425,24 @@ k_lj_tile(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__res
 template <bool NT1, bool WE, bool WV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, Outputs out, float margin,
-           int nbx, int nby, uint nBricks) {
-  __shared__ f4t candg[2 + kBrickCap + 64];  // two guard slots in front (dead slots of the drain read slot -2)
-  __shared__ uint tabs[4 * kTabWords];
+           int nbx, int nby, uint nBricks, TileFrame scale) {
+  // (one struct: the order matters — the drain's look-ahead of the last wave reads up to 32 bytes past its hit words, into rangeTab)
+  __shared__ struct {
+    f4t candg[2 + kBrickCap + 64];  // two guard slots in front (dead slots of the drain read slot -2)
+    uint tabs[4 * kTabWords];
+    uint4 rangeTab[48];             // {first, len, flat offset, special}
+    uint total[2];                  // {number of candidates, some wave needs more than kMaxW words}
+  } sh;
+  f4t *candg = sh.candg;
+  uint *tabs = sh.tabs;
+  uint4 *rangeTab = sh.rangeTab;
+  uint *total = sh.total;
   if (threadIdx.x < 2) candg[threadIdx.x] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
   LdsF4 *cand = (LdsF4 *)candg + 2;
-  // (dense-brick fallback: wave k works in slots [272 k, 272 k + 256); the 16 slots in front of the next wave's region are its guard)
-  if (threadIdx.x < 64) cand[272u * (threadIdx.x >> 4) + 256u + (threadIdx.x & 15u)] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
-  __shared__ uint4 rangeTab[48];  // {first, len, flat offset, special}
-  __shared__ uint total[2];       // {number of candidates, some wave needs more than kMaxW words}
+  // (dense-brick fallback: wave k works in slots [R k, R k + 256), R = kFallbackRegion; the slots in front of the next wave's region are
+  // its guard)
+  if (threadIdx.x < 64 && (threadIdx.x & 15u) < (uint)(kFallbackRegion - 256))
+    cand[(uint)kFallbackRegion * (threadIdx.x >> 4) + 256u + (threadIdx.x & 15u)] = f4t{0.0f, 0.0f, 0.0f, 0.0f};
   const uint t = xcd_contiguous_block(blockIdx.x, gridDim.x);
   if (t >= nBricks) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -499,7 +537,10 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
       const uint rs = p == 0 ? runStart[0] : (p == 1 ? runStart[1] : runStart[2]);
       const uint rl = p == 0 ? runLen[0] : (p == 1 ? runLen[1] : runLen[2]);
       const uint left = rl > 64u * k ? rl - 64u * k : 0u;
-      *(LdsU *)(uintptr_t)(wbaseTab + 4u * w) = w < nW ? 16u * (rs + 64u * k) : 0u;
+      const uint wbyte = w < nW ? 16u * (rs + 64u * k) : 0u;
+      *(LdsU *)(uintptr_t)(wbaseTab + 4u * w) = wbyte;
+      *(LdsU *)(uintptr_t)(wcntTab + 4u * ((uint)(kMaxW + 2) + w)) = candBase + wbyte;
+      *(LdsU *)(uintptr_t)(wcntTab + 4u * ((uint)(2 * (kMaxW + 2)) + w)) = candBase + 16u + wbyte;
       *(LdsU *)(uintptr_t)(wcntTab + 4u * w) = w < nW ? min(left, 64u) : 0u;
     }
   }
@@ -509,7 +550,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     // a dense brick: every wave runs the chunked single-pair algorithm on its quarter of the candidate buffer
     if (y0 + wy < cy && z0 + wz < cz)
       tile_solo<NT1, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, x0, y0 + wy, z0 + wz,
-                             candBase + 16u * (uint)(wave * ((kBrickCap + 64) / 4)), 192u, tab, lane);
+                             candBase + 16u * (uint)(wave * kFallbackRegion), 192u, tab, lane);
     return;
   }
   if (nOwn == 0) return;
@@ -517,7 +558,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const float oy = fmaf((float)(y0 + wy) + 0.5f, grid.cellSize.y, -0.5f * box.boxSize.y);
   const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
   const LJParams p1 = tbl[0];
-  const TileFrame fr = tile_frame(grid, box, ox, oy, oz);
+  const TileFrame fr = tile_centred(scale, ox, oy, oz);
   const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
   for (int o0 = 0; o0 < nOwn; o0 += 32) {
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
@@ -575,7 +616,7 @@ int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, cons
   } else {
     const int nby = (g.cellDim.y + 1) / 2, nbz = (g.cellDim.z + 1) / 2;
     const uint nBricks = (uint)npx * (uint)nby * (uint)nbz;
-    hipExtLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks);
+    hipExtLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks, tile_scale(g, box));
   }
   return 0;
 }
