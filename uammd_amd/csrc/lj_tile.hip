@@ -105,7 +105,8 @@ UH_D uint row_slot(int i) { return 2u * ((uint)(i & 3) + 4u * (uint)(i >> 3)) + 
 // carried as hi + lo halves, so the matrix returns |a^ - b^|^2 - rc2m to f32 accuracy and the only error is the coordinate rounding,
 // covered by the margin (tile_margin).  K slots (candidate side A | owner side B):
 //   k0 b^x | -2 a^x   k1 b^y | -2 a^y   k2 b^z | -2 a^z   k3 0 | 0   k4 |b^|^2 hi | 1   k5 |b^|^2 lo | 1   k6 1 | c hi   k7 1 | c lo
-// with c = |a^|^2 - rc2m; k8..15 belong to the upper half-wave, whose owner side is zero.  The SIGN BIT of a result is the hit flag.
+// with c = |a^|^2 - rc2m.  K 8..15 belong to the upper half-wave and hold the SAME eight entries for another candidate: the owner side
+// is zero in one half-wave or the other (B0 / B1), which selects the candidates a product sees.  The SIGN BIT of a result is the hit flag.
 UH_D uint pk_rtz(float a, float b) { return __builtin_bit_cast(uint, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 UH_D float sq3_h(uint pxy, uint pz0) {  // x^2 + y^2 + z^2 of packed halves, in f32
   const h2t hxy = __builtin_bit_cast(h2t, pxy), hz0 = __builtin_bit_cast(h2t, pz0);
@@ -132,14 +133,18 @@ template <bool PBC> UH_D void tile_centre(const TileFrame &fr, float x, float y,
   }
 }
 
-template <bool PBC> UH_D v16f tile_distances(uint candAddr, const TileFrame &fr, const h8t &B, uint ones) {
+// candidate side of the matrix product for the slot at candAddr
+template <bool PBC> UH_D h8t tile_operand(uint candAddr, const TileFrame &fr, uint ones) {
   const f4t c = *(const LdsF4 *)(uintptr_t)candAddr;
   float bx, by, bz;
   tile_centre<PBC>(fr, c.x, c.y, c.z, bx, by, bz);
   const uint pxy = pk_rtz(bx, by), pz0 = pk_rtz(bz, 0.0f);
   const u4t a = {pxy, pz0, split_h(sq3_h(pxy, pz0)), ones};
+  return __builtin_bit_cast(h8t, a);
+}
+UH_D v16f tile_product(const h8t &A, const h8t &B) {
   const v16f z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8t, a), B, z, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, z, 0, 0, 0);
 }
 
 // 16 values -> 16 bits of the lane's hit word, one v_alignbit_b32 each: m = (m << 1) | sign(d)
@@ -158,27 +163,32 @@ UH_D uint tile_bits16(const v16f &d) {
 // wbase[w], of which the first wcnt[w] are this wave's candidates (the rest is staged data of other rows, or padding: their bits
 // are cleared).  tab = this wave's table in LDS: hit words [kMaxW + 1][64] | wbase [kMaxW + 2] | wcnt [kMaxW + 2].
 template <bool PBC, bool NT1, bool WE, bool WV>
-UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const TileFrame &fr, const h8t &B, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
+UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const TileFrame &fr, const h8t &B0, const h8t &B1, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
   const int hi = lane >> 5;
-  const uint rowAddr = candBase + 16u * row_slot(lane & 31);  // the candidate this lane feeds to the matrix: + wbase[w] + 512 sp
+  // the candidate this lane feeds to the matrix: slot row_slot(lane & 31) + 32 hi of the word at + wbase[w]
+  const uint rowAddr = candBase + 16u * row_slot(lane & 31) + 512u * (uint)hi;
   const uint myMask = tab + 4u * (uint)lane;                  // hit word w of this lane at + 256 w
   const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
-  // ---- scan: two matrix steps per word; the values of the next step are on the matrix pipe while this one is turned into bits ----
+  // ---- scan: ONE operand per lane and word — the lower half-wave holds the 32 candidates of the word's first matrix step in K slots
+  // 0..7, the upper half-wave those of the second step in K slots 8..15 — and two products: B0 carries the owners in K 0..7 and zeros
+  // in K 8..15, B1 the reverse, so each product sees one half-wave's candidates.  (Operands are finite whatever a padding slot holds:
+  // the conversions round toward zero and saturate.)  The next word's operand is built and its products are on the matrix pipe while
+  // this word's values are turned into bits.
   // (the two 1.0 halves of the candidate operand, hidden from constant folding: as a literal the compiler assembles the operand from a
   // constant vector, five register moves per matrix step)
   uint ones = 0x3c003c00u;
   asm volatile("" : "+v"(ones));
-  uint wb = *(const LdsU *)(uintptr_t)wbaseTab;
-  v16f dA = tile_distances<PBC>(rowAddr + wb, fr, B, ones);
+  h8t A = tile_operand<PBC>(rowAddr + *(const LdsU *)(uintptr_t)wbaseTab, fr, ones);
+  v16f dA = tile_product(A, B0), dB = tile_product(A, B1);
   for (uint w = 0; w < nW; ++w) {
-    const v16f dB = tile_distances<PBC>(rowAddr + wb + 512u, fr, B, ones);
     const uint cnt = *(const LdsU *)(uintptr_t)(wcntTab + 4u * w);
-    const uint mA = tile_bits16(dA);
     // (unconditional: behind the last word this is entry nW of the table = slot 0, a wasted step — a conditional one makes the
-    // compiler keep two register sets for dA and copy 16 registers per word)
-    wb = *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1));
-    dA = tile_distances<PBC>(rowAddr + wb, fr, B, ones);
+    // compiler keep two register sets for the products and copy them every word)
+    A = tile_operand<PBC>(rowAddr + *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1)), fr, ones);
+    const uint mA = tile_bits16(dA);
+    dA = tile_product(A, B0);
     uint m = (mA << 16) | tile_bits16(dB);
+    dB = tile_product(A, B1);
     if (__builtin_amdgcn_readfirstlane(cnt) < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
       const uint mine = (cnt + 1u - (uint)hi) >> 1;
       m &= mine >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> mine);
@@ -250,7 +260,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
 }
 
 // owners' side of the matrix products for the 32 owners [o0, o0 + 32) of a wave, and the lane's owner position
-struct OwnerSide { float4 pi; h8t B; bool valid; };
+struct OwnerSide { float4 pi; h8t B0, B1; bool valid; };
 UH_D OwnerSide tile_owner(const float4 *__restrict__ P, uint ownFirst, int nOwn, int o0, int lane, bool pbc, const TileFrame &fr, float ox,
                           float oy, float oz, float rc2ms) {
   OwnerSide o;
@@ -265,9 +275,10 @@ UH_D OwnerSide tile_owner(const float4 *__restrict__ P, uint ownFirst, int nOwn,
   const float c = o.valid ? sq3_h(pxy, pz0) - rc2ms : 6.0e4f;
   const uint m2xy = pk_rtz(-2.0f * (float)__builtin_bit_cast(h2t, pxy).x, -2.0f * (float)__builtin_bit_cast(h2t, pxy).y);
   const uint m2z0 = pk_rtz(-2.0f * (float)__builtin_bit_cast(h2t, pz0).x, 0.0f);
-  u4t b = {m2xy, m2z0, 0x3c003c00u, split_h(c)};
-  if (hi) b = u4t{0u, 0u, 0u, 0u};
-  o.B = __builtin_bit_cast(h8t, b);
+  // B0: the owners in the lower half-wave (K 0..7), zeros in the upper (K 8..15); B1 the reverse
+  const u4t b = {m2xy, m2z0, 0x3c003c00u, split_h(c)}, zero = {0u, 0u, 0u, 0u};
+  o.B0 = __builtin_bit_cast(h8t, hi ? zero : b);
+  o.B1 = __builtin_bit_cast(h8t, hi ? b : zero);
   return o;
 }
 
@@ -391,9 +402,9 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
       }
       const uint nW = (nC + 63u) >> 6;
       if (pbcTile)
-        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
       else
-        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     }
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
@@ -564,9 +575,9 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
     Acc acc;
     if (pbcWave)
-      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     else
-      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B, ow.pi, box, p1, tbl, ntypes);
+      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
 }
