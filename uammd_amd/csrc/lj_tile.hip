@@ -524,6 +524,13 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     pbcWave = pbcWave || ((sp >> ra) & 0x1FFull) != 0;
   }
   if (nOwn != 0 && nW > (uint)kMaxW && lane == 0) total[1] = 1u;  // (benign race: every writer stores 1)
+  // a list with ghosts (slab decomposition: particles with input index >= numOwned are neighbours only): a pair of cells that holds
+  // ghosts alone — the halo planes — has nothing to compute.  The load is in flight during the staging.
+  bool anyOwned = true;
+  if (cl.numOwned != 0x7fffffff && nOwn <= 64) {
+    const int gi = lane < nOwn ? cl.groupIndex[ownFirst + (uint)lane] : 0x7fffffff;
+    anyOwned = __any(gi < cl.numOwned);
+  }
   const bool fits = C <= (uint)kBrickCap;
   // ---- staging: the 48 ranges dealt to the four waves ----
   if (fits) {
@@ -564,7 +571,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
                              candBase + 16u * (uint)(wave * kFallbackRegion), 192u, tab, lane);
     return;
   }
-  if (nOwn == 0) return;
+  if (nOwn == 0 || !anyOwned) return;
   const float ox = fmaf((float)(x0 + 1), grid.cellSize.x, -0.5f * box.boxSize.x);
   const float oy = fmaf((float)(y0 + wy) + 0.5f, grid.cellSize.y, -0.5f * box.boxSize.y);
   const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
