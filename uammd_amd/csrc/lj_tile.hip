@@ -48,11 +48,11 @@ using LdsV = __attribute__((address_space(3))) void;
 
 constexpr int kMaxW = 12;                  // hit words (of 64 candidates) one wave can hold per pass
 constexpr int kSoloCap = 512;              // candidate slots of the single-wave kernel (8 words per chunk)
-constexpr int kBrickCap = 992;             // candidate slots of the four-wave kernel (a C3 brick stages 805 +- 30; with the tables: 31.2 KB, five workgroups per CU)
+constexpr int kBrickCap = 1024;            // candidate slots of the four-wave kernel (a C3 brick stages 805 +- 30; with the tables: 31.2 KB, five workgroups per CU)
 constexpr int kFallbackRegion = (kBrickCap + 64) / 4;  // slots per wave of the dense-brick fallback: 256 of work + guard
 static_assert(kFallbackRegion >= 256 + 2 && kFallbackRegion - 256 <= 16, "fallback guard slots");
-// per wave: hit words [kMaxW + 1][64] | word base [kMaxW + 2] | word count [kMaxW + 2] | absolute word base of either half-wave [2][kMaxW + 2]
-constexpr int kTabWords = (kMaxW + 1) * 64 + 4 * (kMaxW + 2);
+// per wave: hit words [kMaxW + 1][64] | LDS address of slot h of every word, for either half-wave h [2][kMaxW + 2]
+constexpr int kTabWords = (kMaxW + 1) * 64 + 2 * (kMaxW + 2);
 
 // count of leading zeros; 0xFFFFFFFF for 0 (v_ffbh_u32)
 UH_D int __builtin_clz_or_neg1(uint v) { return v ? __builtin_clz(v) : -1; }
@@ -109,6 +109,8 @@ UH_D uint row_slot(int i) { return 2u * ((uint)(i & 3) + 4u * (uint)(i >> 3)) + 
 // is zero in one half-wave or the other (B0 / B1), which selects the candidates a product sees.  The SIGN BIT of a result is the hit flag.
 UH_D uint pk_rtz(float a, float b) { return __builtin_bit_cast(uint, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 UH_D float sq3_h(uint pxy, uint pz0) {  // x^2 + y^2 + z^2 of packed halves, in f32
+  // (through the builtin, not inline asm: a dot instruction's result needs wait states before another kind of instruction reads it, and
+  // the compiler's hazard recognizer does not look inside asm — tried, wrong distances)
   const h2t hxy = __builtin_bit_cast(h2t, pxy), hz0 = __builtin_bit_cast(h2t, pz0);
   return __builtin_amdgcn_fdot2(hz0, hz0, __builtin_amdgcn_fdot2(hxy, hxy, 0.0f, false), false);
 }
@@ -161,14 +163,14 @@ UH_D uint tile_bits16(const v16f &d) {
 
 // The wave's 32 owners against nW words of staged candidates.  Word w = 64 consecutive LDS slots starting at byte candBase +
 // wbase[w], of which the first wcnt[w] are this wave's candidates (the rest is staged data of other rows, or padding: their bits
-// are cleared).  tab = this wave's table in LDS: hit words [kMaxW + 1][64] | wbase [kMaxW + 2] | wcnt [kMaxW + 2].
+// are cleared).  wbase / wcnt arrive in registers — lane w holds word w's, entries >= nW are zero or any staged slot — and the scan
+// reads them with v_readlane; tab = this wave's table in LDS: hit words [kMaxW + 1][64] | slot address per half-wave [2][kMaxW + 2].
 template <bool PBC, bool NT1, bool WE, bool WV>
-UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const TileFrame &fr, const h8t &B0, const h8t &B1, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
+UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, uint wcntV, int lane, const TileFrame &fr, const h8t &B0, const h8t &B1, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
   const int hi = lane >> 5;
   // the candidate this lane feeds to the matrix: slot row_slot(lane & 31) + 32 hi of the word at + wbase[w]
   const uint rowAddr = candBase + 16u * row_slot(lane & 31) + 512u * (uint)hi;
   const uint myMask = tab + 4u * (uint)lane;                  // hit word w of this lane at + 256 w
-  const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
   // ---- scan: ONE operand per lane and word — the lower half-wave holds the 32 candidates of the word's first matrix step in K slots
   // 0..7, the upper half-wave those of the second step in K slots 8..15 — and two products: B0 carries the owners in K 0..7 and zeros
   // in K 8..15, B1 the reverse, so each product sees one half-wave's candidates.  (Operands are finite whatever a padding slot holds:
@@ -178,18 +180,18 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
   // constant vector, five register moves per matrix step)
   uint ones = 0x3c003c00u;
   asm volatile("" : "+v"(ones));
-  h8t A = tile_operand<PBC>(rowAddr + *(const LdsU *)(uintptr_t)wbaseTab, fr, ones);
+  h8t A = tile_operand<PBC>(rowAddr + rdlane(wbaseV, 0), fr, ones);
   v16f dA = tile_product(A, B0), dB = tile_product(A, B1);
   for (uint w = 0; w < nW; ++w) {
-    const uint cnt = *(const LdsU *)(uintptr_t)(wcntTab + 4u * w);
+    const uint cnt = rdlane(wcntV, (int)w);
     // (unconditional: behind the last word this is entry nW of the table = slot 0, a wasted step — a conditional one makes the
     // compiler keep two register sets for the products and copy them every word)
-    A = tile_operand<PBC>(rowAddr + *(const LdsU *)(uintptr_t)(wbaseTab + 4u * (w + 1)), fr, ones);
+    A = tile_operand<PBC>(rowAddr + rdlane(wbaseV, (int)w + 1), fr, ones);
     const uint mA = tile_bits16(dA);
     dA = tile_product(A, B0);
     uint m = (mA << 16) | tile_bits16(dB);
     dB = tile_product(A, B1);
-    if (__builtin_amdgcn_readfirstlane(cnt) < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
+    if (cnt < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
       const uint mine = (cnt + 1u - (uint)hi) >> 1;
       m &= mine >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> mine);
     }
@@ -201,7 +203,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, int lane, const
   // without a set bit in cw takes a dead slot: ffbh(0) = -1 addresses slot -2 of the word — staged data of another row or the two
   // guard slots in front of the buffer, finite either way — with weight 0.
   *(LdsU *)(uintptr_t)(myMask + 256u * nW) = 0u;
-  const uint wabsTab = wcntTab + 4u * (uint)((kMaxW + 2) * (1 + hi));  // candBase + 16 hi + wbase[w]
+  const uint wabsTab = tab + 4u * (uint)((kMaxW + 1) * 64 + (kMaxW + 2) * hi);  // candBase + 16 hi + wbase[w]
   uint cw = *(const LdsU *)(uintptr_t)myMask;
   uint nw = *(const LdsU *)(uintptr_t)(myMask + 256u);
   uint cb = *(const LdsU *)(uintptr_t)wabsTab;
@@ -368,11 +370,11 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
   const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
   const f4t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};  // padding behind the last candidate: finite; the word counts clear its bits
   LdsF4 *cand = (LdsF4 *)(uintptr_t)candBase;
-  const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
-  if (lane < kMaxW + 2) {  // words = consecutive blocks of 64 slots
-    *(LdsU *)(uintptr_t)(wbaseTab + 4u * (uint)lane) = 1024u * (uint)lane;
-    *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)(kMaxW + 2 + lane)) = candBase + 1024u * (uint)lane;
-    *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)(2 * (kMaxW + 2) + lane)) = candBase + 16u + 1024u * (uint)lane;
+  const uint wabsTab = tab + 4u * (uint)((kMaxW + 1) * 64);
+  const uint wbaseV = lane < kMaxW + 2 ? 1024u * (uint)lane : 0u;  // words = consecutive blocks of 64 slots
+  if (lane < kMaxW + 2) {
+    *(LdsU *)(uintptr_t)(wabsTab + 4u * (uint)lane) = candBase + wbaseV;
+    *(LdsU *)(uintptr_t)(wabsTab + 4u * (uint)(kMaxW + 2 + lane)) = candBase + 16u + wbaseV;
   }
   for (int o0 = 0; o0 < nOwn; o0 += 32) {
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcTile, fr, ox, oy, oz, rc2ms);
@@ -396,15 +398,15 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
           sO += sL;
         }
         for (uint k = nC + (uint)lane; k < ((nC + 63u) & ~63u); k += 64u) cand[k] = zero4;
-        if (lane < kMaxW + 2) *(LdsU *)(uintptr_t)(wcntTab + 4u * (uint)lane) = nC > 64u * (uint)lane ? min(nC - 64u * (uint)lane, 64u) : 0u;
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): the DMA and table writes have landed
         __builtin_amdgcn_wave_barrier();
       }
       const uint nW = (nC + 63u) >> 6;
+      const uint wcntV = nC > 64u * (uint)lane ? min(nC - 64u * (uint)lane, 64u) : 0u;
       if (pbcTile)
-        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
       else
-        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     }
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
@@ -545,21 +547,24 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
       const f4t far = {0.0f, 0.0f, 0.0f, 0.0f};
       cand[C + (uint)lane] = far;
     }
-    // this wave's words: run p contributes ceil(runLen / 64) words starting at its first slot
-    const uint wbaseTab = tab + 4u * (uint)((kMaxW + 1) * 64), wcntTab = wbaseTab + 4u * (uint)(kMaxW + 2);
+  }
+  // this wave's words: run p contributes ceil(runLen / 64) words starting at its first slot.  Lane w keeps word w's byte offset and
+  // count (the scan reads them with v_readlane) and writes the slot addresses the drain looks up
+  uint wbaseV = 0, wcntV = 0;
+  if (fits) {
     const uint w0 = (runLen[0] + 63u) >> 6, w1 = w0 + ((runLen[1] + 63u) >> 6);
+    const uint w = (uint)lane;
+    const int p = (w >= w0) + (w >= w1);
+    const uint k = w - (p == 0 ? 0u : (p == 1 ? w0 : w1));
+    const uint rs = p == 0 ? runStart[0] : (p == 1 ? runStart[1] : runStart[2]);
+    const uint rl = p == 0 ? runLen[0] : (p == 1 ? runLen[1] : runLen[2]);
+    const uint left = rl > 64u * k ? rl - 64u * k : 0u;
+    wbaseV = w < nW ? 16u * (rs + 64u * k) : 0u;
+    wcntV = w < nW ? min(left, 64u) : 0u;
     if (lane < kMaxW + 2) {
-      const uint w = (uint)lane;
-      const int p = (w >= w0) + (w >= w1);
-      const uint k = w - (p == 0 ? 0u : (p == 1 ? w0 : w1));
-      const uint rs = p == 0 ? runStart[0] : (p == 1 ? runStart[1] : runStart[2]);
-      const uint rl = p == 0 ? runLen[0] : (p == 1 ? runLen[1] : runLen[2]);
-      const uint left = rl > 64u * k ? rl - 64u * k : 0u;
-      const uint wbyte = w < nW ? 16u * (rs + 64u * k) : 0u;
-      *(LdsU *)(uintptr_t)(wbaseTab + 4u * w) = wbyte;
-      *(LdsU *)(uintptr_t)(wcntTab + 4u * ((uint)(kMaxW + 2) + w)) = candBase + wbyte;
-      *(LdsU *)(uintptr_t)(wcntTab + 4u * ((uint)(2 * (kMaxW + 2)) + w)) = candBase + 16u + wbyte;
-      *(LdsU *)(uintptr_t)(wcntTab + 4u * w) = w < nW ? min(left, 64u) : 0u;
+      const uint wabsTab = tab + 4u * (uint)((kMaxW + 1) * 64);
+      *(LdsU *)(uintptr_t)(wabsTab + 4u * w) = candBase + wbaseV;
+      *(LdsU *)(uintptr_t)(wabsTab + 4u * ((uint)(kMaxW + 2) + w)) = candBase + 16u + wbaseV;
     }
   }
   __builtin_amdgcn_s_waitcnt(0);
@@ -582,9 +587,9 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
     Acc acc;
     if (pbcWave)
-      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     else
-      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
 }
