@@ -578,35 +578,52 @@ __global__ void __launch_bounds__(256) k_fcm_interleave(const float *__restrict_
   out[t] = make_float4(g0[node], g0[plane + node], g0[2 * plane + node], 0.0f);
 }
 
+// R = rounds of 64 stencil nodes whose loads are in flight together.  The first form of this kernel looped over the rounds with the
+// load and its use in the same iteration: the compiler put s_waitcnt vmcnt(0) between them, and a wave's origin record, its weights
+// and its four rounds were SIX dependent round trips — 48 us at C4, which is 12 rounds of waves x 6 x ~0.65 us and had been read as
+// an L2 request limit.  Here the record and the weights are requested together, then every node of a chunk of R rounds, then the
+// arithmetic: two round trips per wave.  The sums run in the same order as before (round by round, then the xor reduction).
+template <int R>
 __global__ void __launch_bounds__(256) k_fcm_gather_inter(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
                                                            int3 support, float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr,
                                                            bool accumulate) {
   const int lane = threadIdx.x & 63;
   const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (slot >= N) return;
-  const int4 o = pr.origin[slot];
   const int sx = support.x, sy = support.y, sz = support.z;
-  const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * slot + lane] : 0.0f;
+  const int4 o = pr.origin[slot];
+  const float wl = pr.weights[(size_t)pr.wstride * slot + min(lane, sx + sy + sz - 1)];  // (unconditional: no branch between the two loads)
   const int nn = sx * sy * sz;
   float ax = 0.f, ay = 0.f, az = 0.f;
-  for (int i0 = 0; i0 < nn; i0 += 64) {
-    const int i = i0 + lane;
-    const bool in = i < nn;
-    const uint iu = in ? (uint)i : 0u;
-    const uint kk = dsxy.div(iu);
-    const uint rem = iu - kk * (uint)(sx * sy);
-    const uint jj = dsx.div(rem);
-    const uint ii = rem - jj * (uint)sx;
-    const float wx = __shfl(wl, (int)ii, 64), wy = __shfl(wl, sx + (int)jj, 64), wz = __shfl(wl, sx + sy + (int)kk, 64);
-    if (!in) continue;
-    int cx = o.x + (int)ii, cy = o.y + (int)jj, cz = o.z + (int)kk;
-    cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
-    cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
-    cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
-    const float4 v = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];
-    ax = fmaf(dV, v.x * wx * wy * wz, ax);
-    ay = fmaf(dV, v.y * wx * wy * wz, ay);
-    az = fmaf(dV, v.z * wx * wy * wz, az);
+  for (int base = 0; base < nn; base += 64 * R) {
+    float4 v[R];
+    int wsel[R];  // ii | jj << 8 | kk << 16, or -1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base + 64 * r + lane;
+      const bool in = i < nn;
+      const uint iu = in ? (uint)i : 0u;
+      const uint kk = dsxy.div(iu);
+      const uint rem = iu - kk * (uint)(sx * sy);
+      const uint jj = dsx.div(rem);
+      const uint ii = rem - jj * (uint)sx;
+      int cx = o.x + (int)ii, cy = o.y + (int)jj, cz = o.z + (int)kk;
+      cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
+      cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
+      cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
+      v[r] = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];  // (a lane past the stencil re-reads node 0 of it)
+      wsel[r] = in ? (int)(ii | jj << 8 | kk << 16) : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ws = wsel[r] < 0 ? 0 : wsel[r];
+      const float wx = __shfl(wl, ws & 255, 64), wy = __shfl(wl, sx + ((ws >> 8) & 255), 64), wz = __shfl(wl, sx + sy + (ws >> 16), 64);
+      if (wsel[r] >= 0) {
+        ax = fmaf(dV, v[r].x * wx * wy * wz, ax);
+        ay = fmaf(dV, v[r].y * wx * wy * wz, ay);
+        az = fmaf(dV, v[r].z * wx * wy * wz, az);
+      }
+    }
   }
 #pragma unroll
   for (int o2 = 32; o2 > 0; o2 >>= 1) {
@@ -618,6 +635,15 @@ __global__ void __launch_bounds__(256) k_fcm_gather_inter(float *__restrict__ vo
     float *out = vout + 3 * (size_t)o.w;
     if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
   }
+}
+static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, int N, int3 n, int3 support, float dV, FastDiv dsx,
+                                FastDiv dsxy, const FcmPrep &pr, bool accumulate) {
+  const dim3 g((N + 3) / 4), b(256);
+  const int rounds = (support.x * support.y * support.z + 63) / 64;
+  if (rounds <= 1) hipLaunchKernelGGL(k_fcm_gather_inter<1>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
+  else if (rounds <= 2) hipLaunchKernelGGL(k_fcm_gather_inter<2>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
+  else if (rounds <= 4) hipLaunchKernelGGL(k_fcm_gather_inter<4>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
+  else hipLaunchKernelGGL(k_fcm_gather_inter<8>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
 }
 
 // ---- Fourier space ---------------------------------------------------------------------------------------
@@ -1258,8 +1284,8 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     } else
       hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, (float4 *)f->interBuf.ptr);
-    hipLaunchKernelGGL(k_fcm_gather_inter, gp, bp, 0, st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim,
-                       f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+    launch_gather_inter(st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume,
+                        dsx, dsxy, pr, f->accumulate);
   } else if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
                        f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
@@ -1402,8 +1428,8 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
       if (int e = f->interBuf.reserve(sizeof(float4) * nodes)) return e;
       hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, st, d_grid, f->grid.cellDim,
                          f->nxpad, f->planeReal, zs, (float4 *)f->interBuf.ptr);
-      hipLaunchKernelGGL(k_fcm_gather_inter, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, (const float4 *)f->interBuf.ptr, N,
-                         f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+      launch_gather_inter(st, d_vel, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy,
+                          pr, f->accumulate);
     } else
       hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
@@ -1489,8 +1515,8 @@ int uammd_fcm_slab_gather_inter(uammd_fcm_slab *h, const float *d_posLocal, int 
   FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr, (int *)f->prepTileOf.ptr,
              (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr, (int *)f->prepTileStart.ptr,
              f->kern.support.x + f->kern.support.y + f->kern.support.z};
-  hipLaunchKernelGGL(k_fcm_gather_inter, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_vel, (const float4 *)d_inter, N,
-                     f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
+  launch_gather_inter((hipStream_t)stream, d_vel, (const float4 *)d_inter, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx,
+                      dsxy, pr, f->accumulate);
   UH_CHECK(hipGetLastError());
   return 0;
 }
