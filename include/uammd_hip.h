@@ -100,6 +100,11 @@ int uammd_slab_pack_rows(const float *d_pos, const float *d_vel, const int *d_id
 int uammd_slab_unpack_rows(float *d_pos, float *d_vel, int *d_ids, int n, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown,
                            const float *d_arrivals, int nArrive, int *d_holes, void *stream);
 int uammd_slab_max_displacement(const float *d_pos, const float *d_ref, int n, float *d_max, void *stream);
+/* two segments of `count` floats in one launch: dst0 += src0, dst1 += src1 (the halo planes of the spread grid folded into the owned
+ * planes, FCM slab decomposition) and dst0 = src0, dst1 = src1 (the planes received before the gather); a segment's dst and src
+ * must not overlap */
+int uammd_slab_add2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream);
+int uammd_slab_copy2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream);
 int uammd_lj_profile_enable(uammd_celllist *h, int enable);
 int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
@@ -480,11 +485,18 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
                           float *d_grid, void *stream);
 int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int numberParticles, const float *d_grid,
                           float *d_linearVelocity, void *stream);
-int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream); /* in place on the owned planes */
+int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
+/* the same with the halo fold on the way: d_fromDown / d_fromUp (`planes` planes each, laid out like the window) are added to the first /
+ * last `planes` owned planes as the x pass loads them (one launch less than adding them first).  Returns 1 when the solver's own FFT
+ * does not serve this grid: add the planes and call uammd_fcm_slab_forward_xy */
+int uammd_fcm_slab_forward_xy_fold(uammd_fcm_slab *h, float *d_grid, const float *d_fromDown, const float *d_fromUp, int planes, void *stream); /* in place on the owned planes */
 int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
 /* the inverse writing the owned planes of a float4 window d_inter[z][y][x] = (vx, vy, vz, 0) (returns 1 and does nothing when the grid
  * does not take the library's own FFT), and the gather that reads that window once the caller has exchanged its halo planes */
 int uammd_fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, void *stream);
+/* world size 1 (the rank is its own neighbour through the periodic z faces): the same, and the first / last `wrapPlanes` owned planes are
+ * also stored into the halo planes above / below the owned block — the window is ready for the gather without a halo exchange */
+int uammd_fcm_slab_inverse_xy_inter_wrap(uammd_fcm_slab *h, float *d_grid, float *d_inter, int wrapPlanes, void *stream);
 int uammd_fcm_slab_gather_inter(uammd_fcm_slab *h, const float *d_posLocal, int N, const float *d_inter, float *d_vel, void *stream);
 int uammd_fcm_slab_fft_z(uammd_fcm_slab *h, float *d_cplxZ, int inverse, void *stream);
 /* the three calls above (forward z, operator, inverse z) in one pass over d_cplxZ when nz is a power of two; returns 1 (and does

@@ -121,3 +121,21 @@ def test_max_displacement(hip):
     d = (b[:, :3].astype(np.float64) - a[:, :3]).astype(np.float32)
     exp = np.sqrt((d.astype(np.float64) ** 2).sum(axis=1)).max()
     assert abs(float(out.item()) - exp) <= 2e-6 * exp
+
+
+@pytest.mark.parametrize("count,offset", [(0, 0), (1, 0), (1023, 0), (4096, 0), (4096, 1), (3 * 128 * 130 * 5, 0)])
+def test_pair_add_and_copy(hip, count, offset):
+    """uammd_slab_add2 / uammd_slab_copy2 against torch: two segments per launch, the 16-byte path (aligned, count % 4 == 0) and the
+    scalar one (odd count or an offset view); bit-exact (one addition per element)."""
+    from uammd_amd._lib import check, load
+    lib = load()
+    g = torch.Generator(device="cuda").manual_seed(count + offset)
+    big = [torch.randn(count + 8, generator=g, device="cuda") for _ in range(4)]
+    d0, s0, d1, s1 = (t[offset:offset + count] for t in big)
+    want_add = (d0 + s0, d1 + s1)
+    check(lib.uammd_slab_add2(_p(d0), _p(s0), _p(d1), _p(s1), count, None) if count else 0)
+    assert torch.equal(d0, want_add[0]) and torch.equal(d1, want_add[1])
+    check(lib.uammd_slab_copy2(_p(d0), _p(s0), _p(d1), _p(s1), count, None) if count else 0)
+    assert torch.equal(d0, s0) and torch.equal(d1, s1)
+    for t in big:  # nothing outside the segments moved
+        assert torch.isfinite(t).all()

@@ -116,6 +116,8 @@ SIGNATURES = {
     "uammd_slab_pack_rows": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "uammd_slab_unpack_rows": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "uammd_slab_max_displacement": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "uammd_slab_add2": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "uammd_slab_copy2": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "uammd_verletlist_get_steps_since_last_update": (_i, [_vp, C.POINTER(_i)]),
     "uammd_verletlist_get": (_i, [_vp, C.POINTER(VerletListData)]),
     "uammd_lj_transverse_verletlist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
@@ -179,8 +181,10 @@ SIGNATURES = {
     "uammd_fcm_slab_spread": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_fcm_slab_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "uammd_fcm_slab_forward_xy": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_slab_forward_xy_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_slab_inverse_xy_inter": (_i, [_vp, _vp, _vp, _vp]),
+    "uammd_fcm_slab_inverse_xy_inter_wrap": (_i, [_vp, _vp, _vp, _i, _vp]),
     "uammd_fcm_slab_gather_inter": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "uammd_fcm_slab_fft_z": (_i, [_vp, _vp, _i, _vp]),
     "uammd_fcm_slab_kspace": (_i, [_vp, _vp, _i, _f, _f, _u, _vp]),

@@ -951,8 +951,8 @@ static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1, nh = nx / 2;
   const int lx = ilog2_exact(nx), ly = ilog2_exact(ny);
   const int rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * nz;
-  hipLaunchKernelGGL(k_fft_x_r2c, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
-                     lx, nrows, rows);
+  hipLaunchKernelGGL(k_fft_x_r2c<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
+                     lx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
   const int tiles = (nkx + 15) / 16;
   fft_launch_lines<-1>((float2 *)g, ly, nkx, 3 * nz, st);
   (void)tiles;
@@ -986,7 +986,7 @@ static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nh = nx / 2;
   const int rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * nz;
   hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
-                     g, f->planeReal, (size_t)ny * f->nxpad, ilog2_exact(ny), ilog2_exact(nx), nrows, rows, inter);
+                     g, f->planeReal, (size_t)ny * f->nxpad, ilog2_exact(ny), ilog2_exact(nx), nrows, rows, inter, 0, (size_t)0);
   return 0;
 }
 
@@ -1444,14 +1444,31 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
 
 // batched 2-D R2C of the nzLocal OWNED planes of the window, IN PLACE: afterwards the owned part of the window holds
 // float2 [zl][c][y][kx] (a padded real row and its half spectrum occupy the same 2*(nx/2+1) floats)
+// the same with the neighbours' halo contributions folded in on the way: d_fromDown / d_fromUp = `planes` planes each ([z][c][y][x] like
+// the window) that are ADDED to the first / last `planes` owned planes while the x pass loads them.  Returns 1 when the solver's own
+// FFT does not serve this grid (the caller adds the planes itself and calls uammd_fcm_slab_forward_xy).
+int uammd_fcm_slab_forward_xy_fold(uammd_fcm_slab *h, float *d_grid, const float *d_fromDown, const float *d_fromUp, int planes, void *stream) {
+  if (!h || !d_grid || !d_fromDown || !d_fromUp) { set_last_error("uammd_fcm_slab_forward_xy_fold: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  if (planes < 0 || 2 * planes > s->nzl) { set_last_error("uammd_fcm_slab_forward_xy_fold: the folded planes overlap"); return -1; }
+  if (!fcm_slab_custom_fft(s)) return 1;
+  float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
+  const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
+  hipLaunchKernelGGL(k_fft_x_r2c<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                     (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows, d_fromDown, d_fromUp, 3 * ny * planes);
+  fft_launch_lines<-1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   if (!h || !d_grid) { set_last_error("uammd_fcm_slab_forward_xy: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;  // window layout [z][component][y][x]: the owned planes are one block
   if (fcm_slab_custom_fft(s)) {
     const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
-    hipLaunchKernelGGL(k_fft_x_r2c, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
-                       (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows);
+    hipLaunchKernelGGL(k_fft_x_r2c<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                       (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
     fft_launch_lines<-1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
     UH_CHECK(hipGetLastError());
     return 0;
@@ -1473,7 +1490,7 @@ int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
     // rows (z, y) of the three components: component stride = one (ny x nxpad) plane, z stride = three of them
     hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
                        (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
-                       nrows, rows, (float4 *)nullptr);
+                       nrows, rows, (float4 *)nullptr, 0, (size_t)0);
     UH_CHECK(hipGetLastError());
     return 0;
   }
@@ -1487,16 +1504,26 @@ int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
 // ny x nx nodes) instead of the planar real rows: the single-GPU path's fusion of the inverse row pass with the interleaving copy.
 // The caller exchanges the halo planes of d_inter and hands it to uammd_fcm_slab_gather_inter.  Returns 1 (nothing done) when the
 // grid does not take the custom FFT: the caller then uses uammd_fcm_slab_inverse_xy + uammd_fcm_slab_gather.
+static int fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, int wrapPlanes, void *stream);
 int uammd_fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, void *stream) {
+  return fcm_slab_inverse_xy_inter(h, d_grid, d_inter, 0, stream);
+}
+// world size 1 (the rank is its own neighbour through the periodic z faces): the x pass also stores the first / last `wrapPlanes` owned
+// planes into the halo planes above / below the owned block, so the window is ready for the gather without a halo exchange
+int uammd_fcm_slab_inverse_xy_inter_wrap(uammd_fcm_slab *h, float *d_grid, float *d_inter, int wrapPlanes, void *stream) {
+  return fcm_slab_inverse_xy_inter(h, d_grid, d_inter, wrapPlanes, stream);
+}
+static int fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_inter, int wrapPlanes, void *stream) {
   if (!h || !d_grid || !d_inter) { set_last_error("uammd_fcm_slab_inverse_xy_inter: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  if (wrapPlanes < 0 || wrapPlanes > s->halo || wrapPlanes > s->nzl) { set_last_error("uammd_fcm_slab_inverse_xy_inter_wrap: more planes than the halo holds"); return -1; }
   if (!fcm_slab_custom_fft(s) || !(s->loc.useTiles && !s->loc.forceAtomicSpread)) return 1;  // (the float4 gather reads tile-prepared stencils)
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
   const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * s->nzl;
   fft_launch_lines<1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
   hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
                      (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
-                     nrows, rows, (float4 *)d_inter + (size_t)s->halo * ny * nx);
+                     nrows, rows, (float4 *)d_inter + (size_t)s->halo * ny * nx, wrapPlanes * ny, (size_t)s->nzl * ny * nx);
   UH_CHECK(hipGetLastError());
   return 0;
 }

@@ -96,7 +96,11 @@ UH_D void fft_lds(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, 
 
 // ---- rows: R2C in place -------------------------------------------------------------------------------------------------------------
 // g: rows of nxpad = nx + 2 floats, `nrows` of them back to back (the three planar component grids are contiguous).
-__global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g, int log2nx, int nrows, int rowsPerBlock) {
+// FOLD (slab decomposition): the first and the last `foldRows` rows also take what the neighbours spread into their halo planes,
+// addLo / addHi (foldRows rows each, same row layout), added while the row is loaded — grid + halo, as the separate pass did.
+template <bool FOLD>
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g, int log2nx, int nrows, int rowsPerBlock,
+                                                           const float *__restrict__ addLo, const float *__restrict__ addHi, int foldRows) {
   extern __shared__ float2 lds[];
   const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
   float2 *tw = lds, *buf = lds + nx;
@@ -104,7 +108,18 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
   fft_twiddles(tw, nx, tid);
   for (int i = tid; i < nr * nh; i += kFftThreads) {
     const int r = i >> (log2nx - 1), j = i & (nh - 1);
-    buf[r * LS + j] = *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
+    float2 v = *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
+    if (FOLD) {
+      const int row = r0 + r;
+      if (row < foldRows) {
+        const float2 a = *(const float2 *)(addLo + (size_t)row * nxpad + 2 * j);
+        v = make_float2(v.x + a.x, v.y + a.y);
+      } else if (row >= nrows - foldRows) {
+        const float2 a = *(const float2 *)(addHi + (size_t)(row - (nrows - foldRows)) * nxpad + 2 * j);
+        v = make_float2(v.x + a.x, v.y + a.y);
+      }
+    }
+    buf[r * LS + j] = v;
   }
   __syncthreads();
   fft_lds<-1, 2>(buf, LS, log2nx - 1, nr, tw, 2, tid);
@@ -166,8 +181,11 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
 // interleaved float4 grid inter[(z ny + y) nx + x] = (vx, vy, vz, 0).
 // Row r = (z, y) of component c starts at c compStride + z zStride + y nxpad floats (single GPU: compStride = one component grid,
 // zStride = ny nxpad; slab window [z][c][y][x]: compStride = ny nxpad, zStride = 3 ny nxpad).
+// wrapRows > 0 (slab window of a rank that is its own neighbour, world size 1): the first wrapRows rows are also stored wrapShift float4
+// further on and the last wrapRows rows wrapShift earlier — the halo planes the gather reads, which with neighbours arrive by message.
 __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t compStride, size_t zStride, int log2ny, int log2nx,
-                                                           int nrows, int rowsPerBlock, float4 *__restrict__ inter) {
+                                                           int nrows, int rowsPerBlock, float4 *__restrict__ inter, int wrapRows,
+                                                           size_t wrapShift) {
   extern __shared__ float2 lds[];
   const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
   float2 *tw = lds, *buf = lds + nx;
@@ -208,8 +226,11 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
       const int r = i >> (log2nx - 1), j = i & (nh - 1);
       const float2 vx = buf[r * LS + j], vy = buf[(nr + r) * LS + j], vz = buf[(2 * nr + r) * LS + j];
       float4 *o = inter + (size_t)(r0 + r) * nx + 2 * j;
-      o[0] = make_float4(vx.x, vy.x, vz.x, 0.0f);
-      o[1] = make_float4(vx.y, vy.y, vz.y, 0.0f);
+      const float4 a = make_float4(vx.x, vy.x, vz.x, 0.0f), b = make_float4(vx.y, vy.y, vz.y, 0.0f);
+      o[0] = a;
+      o[1] = b;
+      if (r0 + r < wrapRows) { o[wrapShift] = a; o[wrapShift + 1] = b; }
+      if (r0 + r >= nrows - wrapRows) { (o - wrapShift)[0] = a; (o - wrapShift)[1] = b; }
     }
   } else {
     for (int c = 0; c < 3; ++c)

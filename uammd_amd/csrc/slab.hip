@@ -207,6 +207,39 @@ __global__ void __launch_bounds__(kSlabBlock) k_slab_max_disp(const float4 *__re
 
 using namespace uammd_hip;
 
+// Two segments in one launch (blockIdx.y picks the segment): the halo planes a slab folds into its owned planes after the spreading
+// (ADD) and the planes it receives before the gather (copy).  As torch expressions these were four launches per FCM step.
+template <bool ADD>
+__global__ void __launch_bounds__(kSlabBlock) k_slab_pair(float *__restrict__ d0, const float *__restrict__ s0, float *__restrict__ d1,
+                                                          const float *__restrict__ s1, size_t count, int vec) {
+  float *d = blockIdx.y ? d1 : d0;
+  const float *s = blockIdx.y ? s1 : s0;
+  const size_t i = (size_t)blockIdx.x * kSlabBlock + threadIdx.x;
+  if (vec) {
+    if (4 * i >= count) return;
+    float4 v = reinterpret_cast<const float4 *>(s)[i];
+    if (ADD) {
+      const float4 o = reinterpret_cast<const float4 *>(d)[i];
+      v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+    }
+    reinterpret_cast<float4 *>(d)[i] = v;
+  } else {
+    if (i >= count) return;
+    d[i] = ADD ? d[i] + s[i] : s[i];
+  }
+}
+static int slab_pair(bool add, float *d0, const float *s0, float *d1, const float *s1, size_t count, void *stream) {
+  if (!d0 || !s0 || !d1 || !s1) { set_last_error("uammd_slab_add2 / copy2: null pointer"); return -1; }
+  if (count == 0) return 0;
+  const bool vec = count % 4 == 0 && (((uintptr_t)d0 | (uintptr_t)s0 | (uintptr_t)d1 | (uintptr_t)s1) & 15u) == 0;
+  const size_t threads = vec ? count / 4 : count;
+  const dim3 grid((unsigned)((threads + kSlabBlock - 1) / kSlabBlock), 2);
+  if (add) hipLaunchKernelGGL(k_slab_pair<true>, grid, dim3(kSlabBlock), 0, (hipStream_t)stream, d0, s0, d1, s1, count, vec ? 1 : 0);
+  else hipLaunchKernelGGL(k_slab_pair<false>, grid, dim3(kSlabBlock), 0, (hipStream_t)stream, d0, s0, d1, s1, count, vec ? 1 : 0);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 int uammd_slab_select_workspace(int n, size_t *bytes) {
@@ -269,6 +302,13 @@ int uammd_slab_max_displacement(const float *d_pos, const float *d_ref, int n, f
                      (const float4 *)d_ref, n, (uint *)d_max);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+
+int uammd_slab_add2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream) {
+  return slab_pair(true, d_dst0, d_src0, d_dst1, d_src1, count, stream);
+}
+int uammd_slab_copy2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream) {
+  return slab_pair(false, d_dst0, d_src0, d_dst1, d_src1, count, stream);
 }
 
 }  // extern "C"

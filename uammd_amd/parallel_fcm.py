@@ -111,6 +111,19 @@ class HipSlabBackend:
         self._check(self.lib.uammd_fcm_slab_forward_xy(self.h, self._p(grid), self._st()))
         return grid[g.halo:g.halo + g.nzl].view(g.nzl, 3, g.cells[1], g.nkx, 2)
 
+    def forward_xy_fold(self, grid, from_down, from_up):
+        """forward_xy with the neighbours' halo planes added to the first / last owned planes on the way (one launch less); None if
+        the library's own FFT does not serve this grid or the planes do not qualify (the caller folds them itself)."""
+        g = self.g
+        ts = (from_down, from_up)
+        if g.he == 0 or not all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape == (g.he,) + tuple(grid.shape[1:]) for t in ts):
+            return None
+        rc = self.lib.uammd_fcm_slab_forward_xy_fold(self.h, self._p(grid), self._p(from_down), self._p(from_up), g.he, self._st())
+        if rc == 1:
+            return None
+        self._check(rc)
+        return grid[g.halo:g.halo + g.nzl].view(g.nzl, 3, g.cells[1], g.nkx, 2)
+
     def spectrum_view(self, grid):
         g = self.g
         return grid[g.halo:g.halo + g.nzl].view(g.nzl, 3, g.cells[1], g.nkx, 2)
@@ -134,15 +147,19 @@ class HipSlabBackend:
     def inverse_xy(self, grid):
         self._check(self.lib.uammd_fcm_slab_inverse_xy(self.h, self._p(grid), self._st()))
 
-    def inverse_xy_inter(self):
+    def inverse_xy_inter(self, wrap=False):
         """The inverse writing the owned planes of the gather's float4 window (self.inter) directly; None when the grid does not take the
-        library's own FFT or the spread is not the tile-owned one (the caller then uses inverse_xy + gather)."""
+        library's own FFT or the spread is not the tile-owned one (the caller then uses inverse_xy + gather).  wrap (world size 1, the
+        rank is its own neighbour): the halo planes are written by the same pass, no exchange is needed afterwards."""
         if getattr(self, "_no_inter", False):
             return None
         g = self.g
         if getattr(self, "inter", None) is None:
             self.inter = torch.zeros((self.grid.shape[0], g.cells[1], g.cells[0], 4), dtype=torch.float32, device=self.device)
-        rc = self.lib.uammd_fcm_slab_inverse_xy_inter(self.h, self._p(self.grid), self._p(self.inter), self._st())
+        if wrap:
+            rc = self.lib.uammd_fcm_slab_inverse_xy_inter_wrap(self.h, self._p(self.grid), self._p(self.inter), g.he, self._st())
+        else:
+            rc = self.lib.uammd_fcm_slab_inverse_xy_inter(self.h, self._p(self.grid), self._p(self.inter), self._st())
         if rc == 1:
             self._no_inter = True
             return None
@@ -160,6 +177,22 @@ class HipSlabBackend:
         self._check(self.lib.uammd_fcm_slab_gather(self.h, self._p(pos_local), pos_local.shape[0], self._p(grid), self._p(out),
                                                    self._st()))
         return out
+
+    def pair(self, add, dst0, src0, dst1, src1):
+        """dst0 (+)= src0 and dst1 (+)= src1 in one launch (uammd_slab_add2 / uammd_slab_copy2); False if the views do not qualify."""
+        ts = (dst0, src0, dst1, src1)
+        if not all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in ts) or len({t.numel() for t in ts}) != 1:
+            return False
+        fn = self.lib.uammd_slab_add2 if add else self.lib.uammd_slab_copy2
+        self._check(fn(self._p(dst0), self._p(src0), self._p(dst1), self._p(src1), dst0.numel(), self._st()))
+        return True
+
+    def euler_maruyama(self, pos_local, v, dt):
+        """pos += v dt (uammd_fcm_euler_maruyama); False if the arrays do not qualify."""
+        if not (pos_local.is_cuda and pos_local.is_contiguous() and v.is_contiguous() and pos_local.dtype == torch.float32):
+            return False
+        self._check(self.lib.uammd_fcm_euler_maruyama(self._p(pos_local), None, self._p(v), pos_local.shape[0], float(dt), self._st()))
+        return True
 
     def new_zbuffer(self):
         g = self.g
@@ -230,10 +263,17 @@ class DistributedFCM:
         zbufs = []
         if have_force:
             fd, fu = self.x.neighbours([gr[H + nzl:H + nzl + He] for gr in grids], [gr[H - He:H] for gr in grids])
+            xy = []
             for i, gr in enumerate(grids):
-                gr[H:H + He] += fd[i]
-                gr[H + nzl - He:H + nzl] += fu[i]
-            xy = [self.b[i].forward_xy(grids[i]) for i in range(n)]
+                fold = getattr(self.b[i], "forward_xy_fold", None)
+                done = fold(gr, fd[i], fu[i]) if fold is not None else None
+                if done is None:
+                    pair = getattr(self.b[i], "pair", None)
+                    if pair is None or not pair(True, gr[H:H + He], fd[i], gr[H + nzl - He:H + nzl], fu[i]):
+                        gr[H:H + He] += fd[i]
+                        gr[H + nzl - He:H + nzl] += fu[i]
+                    done = self.b[i].forward_xy(gr)
+                xy.append(done)
             send = [a.view(nzl, 3, P, nyl, g.nkx, 2).permute(2, 0, 1, 3, 4, 5).contiguous() for a in xy]
             recv = self.x.all_to_all(send)      # [src][zl][c][yl][kx] == [z][c][yl][kx]
             for i in range(n):
@@ -259,7 +299,7 @@ class DistributedFCM:
             if not (P == 1 and back[i].data_ptr() == dst.data_ptr()):   # (one rank: the z pass ran in place on the window's own spectrum)
                 dst.copy_(back[i].permute(1, 2, 0, 3, 4, 5))
             inv = getattr(self.b[i], "inverse_xy_inter", None)
-            it = inv() if inv is not None else None     # (a property of the grid and the library: every rank decides alike)
+            it = inv(wrap=(P == 1)) if inv is not None else None     # (a property of the grid and the library: every rank decides alike)
             if it is None:
                 self.b[i].inverse_xy(grids[i])
             fields.append(it)
@@ -268,10 +308,15 @@ class DistributedFCM:
                 if f is not None:
                     raise RuntimeError("ranks disagree on the gather layout")
             fields = grids
-        fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in fields], [gr[H:H + He] for gr in fields])
+        wrapped = P == 1 and fields is not grids     # (one rank: the inverse x pass has stored the halo planes of the float4 window itself)
+        if not wrapped:
+            fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in fields], [gr[H:H + He] for gr in fields])
         for i, gr in enumerate(fields):
-            gr[H - He:H] = fd[i]
-            gr[H + nzl:H + nzl + He] = fu[i]
+            if not wrapped:
+                pair = getattr(self.b[i], "pair", None)
+                if pair is None or not pair(False, gr[H - He:H], fd[i], gr[H + nzl:H + nzl + He], fu[i]):
+                    gr[H - He:H] = fd[i]
+                    gr[H + nzl:H + nzl + He] = fu[i]
             out.append(self.b[i].gather(pos_locals[i], gr) if fields is grids else self.b[i].gather_inter(pos_locals[i], gr))
         return out
 
@@ -294,7 +339,9 @@ class DistributedFCMIntegrator:
         self.steps += 1
         force = self.forces_fn(pos_local, *carried)
         v = self.fcm.displacements([pos_local], [force], self.temperature, 1.0 / self.dt ** 0.5)[0]
-        pos_local[:, :3] += v * self.dt                      # integrateEulerMaruyamaD, BDHI_FCM.cu:67-92
+        em = getattr(self.fcm.b[0], "euler_maruyama", None)  # integrateEulerMaruyamaD, BDHI_FCM.cu:67-92
+        if em is None or not em(pos_local, v, self.dt):
+            pos_local[:, :3] += v * self.dt
         if self.steps % self.migrate_every == 0:
             if self.migrate_every > 1:
                 self.max_drift = (pos_local[:, 2].abs().max() - 0.5 * self.d.width).clamp(min=0.0)
