@@ -209,8 +209,10 @@ class _Exchange:
         if not self.in_process and len(self.local) != 1:
             raise ValueError("hold either one rank (torch.distributed) or all of them (in-process)")
 
-    def neighbours(self, to_up, to_down):
-        """to_up[i] goes to rank+1, to_down[i] to rank-1 (periodic).  Returns (from_down, from_up) lists."""
+    def neighbours(self, to_up, to_down, into_down=None, into_up=None):
+        """to_up[i] goes to rank+1, to_down[i] to rank-1 (periodic).  Returns (from_down, from_up) lists.  into_down / into_up: where the
+        caller wants the messages (contiguous tensors of the messages' shape): under torch.distributed they are received there and
+        returned, so the caller has nothing to copy; the in-process and single-rank forms return the senders' tensors as before."""
         P = self.world
         if self.in_process:
             return [to_up[(r - 1) % P] for r in range(P)], [to_down[(r + 1) % P] for r in range(P)]
@@ -218,7 +220,11 @@ class _Exchange:
         up, down = (r + 1) % P, (r - 1) % P
         if P == 1:
             return [to_up[0]], [to_down[0]]
-        from_down, from_up = torch.empty_like(to_up[0]), torch.empty_like(to_down[0])
+
+        def landing(into, like):
+            ok = into is not None and into[0].is_contiguous() and into[0].shape == like.shape and into[0].dtype == like.dtype
+            return into[0] if ok else torch.empty_like(like)
+        from_down, from_up = landing(into_down, to_up[0]), landing(into_up, to_down[0])
         # with 2 ranks both neighbours are the same peer: the messages are told apart by tag (gloo) / issue order (RCCL)
         t1, t2 = (1, 2) if P == 2 else (0, 0)
         ops = [dist.P2POp(dist.isend, to_up[0].contiguous(), up, self.group, tag=t1),
@@ -310,9 +316,11 @@ class DistributedFCM:
             fields = grids
         wrapped = P == 1 and fields is not grids     # (one rank: the inverse x pass has stored the halo planes of the float4 window itself)
         if not wrapped:
-            fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in fields], [gr[H:H + He] for gr in fields])
+            fd, fu = self.x.neighbours([gr[H + nzl - He:H + nzl] for gr in fields], [gr[H:H + He] for gr in fields],
+                                       into_down=[gr[H - He:H] for gr in fields], into_up=[gr[H + nzl:H + nzl + He] for gr in fields])
         for i, gr in enumerate(fields):
-            if not wrapped:
+            landed = not wrapped and fd[i].data_ptr() == gr[H - He:H].data_ptr() and fu[i].data_ptr() == gr[H + nzl:H + nzl + He].data_ptr()
+            if not wrapped and not landed:   # (under torch.distributed the planes were received in place)
                 pair = getattr(self.b[i], "pair", None)
                 if pair is None or not pair(False, gr[H - He:H], fd[i], gr[H + nzl:H + nzl + He], fu[i]):
                     gr[H - He:H] = fd[i]
