@@ -264,7 +264,11 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
 //      (LDS float atomics retire ~1 lane per clock on gfx950: a shared LDS tile kept the LDS pipe 90 % busy and the kernel at
 //      400 us; private LDS copies with read-modify-write were VALU-issue bound at 100 us.)  The four private copies are summed
 //      through LDS when the tile is stored.
-constexpr int kSpWeightWords = 8192;  // LDS budget of phase B: 256 listed particles at support 6 (32 words each), 146 at support 14
+// LDS budget of phase B in words, chosen per call (spread_weight_words): 8192 = 256 listed particles at support 6 (32 words each) and
+// four workgroups per CU — a C4 tile lists ~105 particles and its 4096 tiles are exactly four rounds of 1024; 4096 = 128 listed
+// particles, the LDS floor of the final tile sum (24.6 KB), five workgroups per CU — a C5 tile lists ~26 and the call is bound by how
+// many tiles are in flight (210 -> 181 us at C5; at C4 the smaller budget costs 2 us: 3.2 rounds of 1280).
+constexpr int kSpWeightWordsMax = 8192;
 constexpr int kSpZPad = kTile - 1;    // zeros either side of a particle's z weights: any tile plane reads SOME word, no branch
 constexpr int kSpPerThread = 3;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
 struct SpEntry {
@@ -272,18 +276,24 @@ struct SpEntry {
   int slot;
   float fx, fy, fz;
 };
-struct SpShared {
-  float wts[kSpWeightWords + 32];  // (+32: out-of-stencil lanes read up to 15 words past a particle's weights)
-  SpEntry list[257];               // (+1: phase C reads 8 words per 5-word entry)
-};
+// dynamic LDS: float wts[weightWords + 32] (+32: out-of-stencil lanes read up to 15 words past a particle's weights) | SpEntry list[257]
+// (+1: phase C reads 8 words per 5-word entry); the four private tiles of the final sum alias the same block
+static size_t spread_lds_bytes(int weightWords) {
+  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * 4 * 3 * kTile * kTile * kTile;
+  return a > b ? a : b;
+}
+static int spread_weight_words(int N, int3 ntiles, int3 support) {
+  const double perTile = (double)N / ((double)ntiles.x * ntiles.y * ntiles.z);
+  const double listed = perTile * (1.0 + (support.x - 1) / (double)kTile) * (1.0 + (support.y - 1) / (double)kTile) * (1.0 + (support.z - 1) / (double)kTile);
+  return listed > 64.0 ? kSpWeightWordsMax : kSpWeightWordsMax / 2;
+}
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
-                  FcmPrep pr) {
+                  FcmPrep pr, int weightWords) {
   constexpr int T3 = kTile * kTile * kTile;
   // the list + weights of phases A-C and the four private tiles of the final sum are never live together: one LDS block
-  constexpr int kBytes = sizeof(SpShared) > sizeof(float) * 4 * 3 * T3 ? sizeof(SpShared) : sizeof(float) * 4 * 3 * T3;
-  __shared__ __attribute__((aligned(16))) char smem[kBytes];
-  SpShared &sh = *reinterpret_cast<SpShared *>(smem);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
   float *acc = reinterpret_cast<float *>(smem);
   __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
   __shared__ int waveCnt[4 * kSpPerThread];
@@ -301,7 +311,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
   const int wpad = wstride + 2 * kSpZPad;  // LDS words per listed particle
-  const int capEntries = min(256, kSpWeightWords / wpad);
+  const int capEntries = min(256, weightWords / wpad);
   if (threadIdx.x < 27) {
     const int nb = threadIdx.x;
     const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
@@ -1239,8 +1249,9 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   if (d_force) {
     if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), 0, st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                         zs, f->kern.support, f->ntiles, pr);
+      const int ww = spread_weight_words(N, f->ntiles, f->kern.support);
+      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+                         zs, f->kern.support, f->ntiles, pr, ww);
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
@@ -1390,8 +1401,9 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
     if (int e = fcm_prepare_tiles(f, d_posLocal, d_force, N, st, &pr)) return e;
     if (d_force) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), 0, st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
-                         f->kern.support, f->ntiles, pr);
+      const int ww = spread_weight_words(N, f->ntiles, f->kern.support);
+      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
+                         f->kern.support, f->ntiles, pr, ww);
     }
   } else if (d_force) {
     const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
