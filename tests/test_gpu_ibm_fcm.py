@@ -331,6 +331,29 @@ def test_fcm_tile_spread_edge_cases(hip, o32):
     assert np.abs(gk - rk).max() <= 2e-5 * np.abs(rk).max()
 
 
+@pytest.mark.parametrize("n_total,n_cluster", [(1500, 1200), (40000, 2000)])
+def test_fcm_tile_spread_list_overflow(hip, o32, n_total, n_cluster):
+    """A tile whose candidate list outgrows the LDS budget of the spreading kernel's weight stage is spread in several chunks
+    (csrc/fcm.hip, k_fcm_spread_tile: 'spread what is listed, then start a new list').  The budget follows the mean population
+    (spread_weight_words): 1500 particles on a 64^3 grid take the small one (128 listed particles per chunk), 40000 the large one
+    (256); either way a cluster of n_cluster particles inside one tile overflows it.  Against the oracle."""
+    from oracle.fcm import FCMOracle
+    cells, L = [64, 64, 64], np.array([64.0, 64.0, 64.0], np.float32)
+    rng = np.random.default_rng(n_total)
+    pos = np.zeros((n_total, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n_total, 3)) * L
+    pos[:n_cluster, :3] = np.array([3.5, -12.5, 20.5], np.float32) + rng.uniform(-3.0, 3.0, (n_cluster, 3))   # inside one 8^3 tile
+    force = np.zeros((n_total, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n_total, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 1.0, 5, a_eff)
+    ofcm = FCMOracle(o32, L, cells, tolerance=1e-3, viscosity=1.0, seed=5)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n_total, 0.0, 0.0).cpu().numpy()
+    vref = ofcm.displacements(pos, force)
+    assert np.linalg.norm(v - vref) <= 1e-5 * np.linalg.norm(vref)
+
+
 @pytest.mark.parametrize("name,rtol", [("Gaussian", 2e-3), ("BarnettMagland", None), ("Peskin3pt", 6e-2),
                                         ("Peskin4pt", 3e-2), ("GaussianFlexible6pt", 1e-2)])
 def test_fcm_alternative_kernels_self_mobility(hip, o32, name, rtol):
