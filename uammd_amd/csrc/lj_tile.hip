@@ -11,12 +11,12 @@
 // particles at liquid density) and
 //   1. the candidates — the cells around the pair, a few dozen contiguous ranges of the sorted array — are staged into LDS by
 //      LDS-DMA loads (global_load_lds: no registers, nothing waits inside the loop), in the reference's visiting order;
-//   2. the 32 x 32 squared distances between 32 owners and 32 candidates come from three v_mfma_f32_32x32x2_f32
-//      (|a|^2 + |b|^2 - 2 a.b - rc^2 over K = 5, coordinates relative to the tile centre; exact-f32 products, f32 accumulation): the
-//      matrix pipe is otherwise idle and issues beside the VALU.  Each lane then holds 16 values of ITS owner (owner = lane & 31,
-//      the two half-waves take the even and the odd candidates) whose SIGN BIT says "inside the cut-off (+ a margin covering the
-//      expansion's rounding)";
-//   3. one v_alignbit_b32 per value shifts the sign bits into a per-lane 32-bit hit word (two matrix steps per word), stored in LDS;
+//   2. the squared distances minus rc^2 between the wave's 32 owners and the 64 candidates of a "word" come from two
+//      v_mfma_f32_32x32x16_f16 sharing ONE candidate operand (half-precision coordinates relative to the tile centre, |.|^2 carried as
+//      hi + lo halves: the error is the coordinate rounding alone, covered by a margin — tile_margin): the matrix pipe is otherwise
+//      idle and issues beside the VALU.  Each lane then holds 32 values of ITS owner (owner = lane & 31, the two half-waves take the
+//      even and the odd candidates) whose SIGN BIT says "inside the cut-off + margin";
+//   3. one v_alignbit_b32 per value shifts the sign bits into a per-lane 32-bit hit word, stored in LDS;
 //   4. the drain walks each lane's hit words (find-first-bit, two pairs per iteration): the ~11 % of the tile's pairs that are hits
 //      are re-evaluated EXACTLY as the reference does (r12 = rj - ri, minimum image where the tile touches a box face,
 //      r2 >= rc2 -> 0, r2 == 0 -> 0, the same polynomial; the division is rcp + one Newton step) from the full-precision positions
