@@ -298,6 +298,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
   __shared__ int waveCnt[4 * kSpPerThread];
   __shared__ unsigned char owner[256 * kSpPerThread];
+  __builtin_amdgcn_s_setprio(3);  // phases that load go ahead of the phase that computes (five workgroups share a CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   f32x16 acc0 = {0.f}, acc1 = {0.f};  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
@@ -361,6 +362,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // column with 24 register accumulators on the VALU, 83 us of which this phase was 41 — measured by switching the phases
     // off one at a time: A 19, B 12, C 41, prologue + reduction + store 12; with the MFMA form C is ~22 and the call 65 us.)
     const int mineCount = (count - wave + 3) >> 2;  // entries wave, wave + 4, ... of the list
+    __builtin_amdgcn_s_setprio(0);  // (the arithmetic phase yields to the workgroups that are issuing loads: see the kernel's top)
     for (int j = 0; j < mineCount; j += 2) {
       const int idx = j + half;
       const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
@@ -378,6 +380,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(3);
     __syncthreads();
   };
 
