@@ -228,6 +228,7 @@ UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__
                         const BoxT<float> &box, const LJParams &p1, const LJParams *tbl, int ntypes) {
   const int n = min((int)(Q.bytes() / kRingStep), take);
   const bool fastDivOK = NT1 && p1.sigma2 >= kDivLo && p1.sigma2 <= kDivHi && p1.cutOff2 <= kDivHi;  // uniform
+  __builtin_amdgcn_s_setprio(0);  // the drain yields to waves that are scanning (their loads start earlier): 0.281 -> 0.274 ms at C3
   for (int t = 0; t < n; t += 4) {
     // slots past the lane's n-th entry read whatever the ring holds there — a neighbour queued earlier or the lane's own
     // particle (the kernels initialise the ring with it): a valid address and no foreign NaN — and are masked below (weight 0)
@@ -269,6 +270,7 @@ UH_D void lj_drain_ring(Acc &acc, RingQ &Q, int take, const float4 *__restrict__
       lj_acc<WE, WV>(acc, r[u], live ? f[u] : 0.0f, live ? e[u] : 0.0f);
     }
   }
+  __builtin_amdgcn_s_setprio(1);
   Q.head = Q.wrap(Q.head + (uint)n * kRingStep);
 }
 
