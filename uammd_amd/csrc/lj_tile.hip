@@ -69,13 +69,30 @@ UH_D void wrap_cell(int &c, int n, bool periodic, bool &ok, bool &wr) {
   }
 }
 
-UH_D float min_image(float d, float L, float mInvL) { return mInvL != 0.0f ? fmaf(floorf(fmaf(d, mInvL, 0.5f)), L, d) : d; }
+// (a direction that is not periodic has mInvL = 0 AND L = 0 here — tile_scale, tile_eval's box copy —: floor(0.5) = 0 and fma(0, 0, d)
+// = d, no select)
+UH_D float min_image(float d, float L, float mInvL) { return fmaf(floorf(fmaf(d, mInvL, 0.5f)), L, d); }
+
+// the box with L = 0 along the directions that are not periodic (what tile_eval's minimum image takes)
+UH_D BoxT<float> pbc_box(BoxT<float> b) {
+  if (!b.px()) b.boxSize.x = 0.0f;
+  if (!b.py()) b.boxSize.y = 0.0f;
+  if (!b.pz()) b.boxSize.z = 0.0f;
+  return b;
+}
 
 // one pair in the drain: the reference's arithmetic up to the division, which is rcp + one Newton step (<= 1 ulp) here
 template <bool PBC, bool WE>
 UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, const f4t &rj, real3f &r12, float &fm, float &e) {
   r12 = real3f{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
-  if (PBC) r12 = box.apply_pbc(r12);
+  if (PBC) {
+    // Box::apply_pbc (utils/Box.cuh:51-58) without its three selects: `box` is the caller's copy with L = 0 where not periodic, so
+    // the image count floor(0.5) = 0 adds 0 there.  Product and sum stay two roundings as in the reference (positions stored several
+    // boxes away make counts whose product with L is not exact: an fma differs there, tests/test_gpu_lj_tile.py 'outside').
+    r12.x = r12.x + floorf(fmaf(r12.x, box.minusInvBoxSize.x, 0.5f)) * box.boxSize.x;
+    r12.y = r12.y + floorf(fmaf(r12.y, box.minusInvBoxSize.y, 0.5f)) * box.boxSize.y;
+    r12.z = r12.z + floorf(fmaf(r12.z, box.minusInvBoxSize.z, 0.5f)) * box.boxSize.z;
+  }
   const float r2 = dot3(r12, r12);
   const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
   float r = __builtin_amdgcn_rcpf(r2);
@@ -298,6 +315,9 @@ inline __host__ __device__ TileFrame tile_scale(const GridT<float> &grid, const 
   fr.mx = box.px() ? -1.0f / fr.Lx : 0.0f;
   fr.my = box.py() ? -1.0f / fr.Ly : 0.0f;
   fr.mz = box.pz() ? -1.0f / fr.Lz : 0.0f;
+  if (!box.px()) fr.Lx = 0.0f;  // (min_image without a select: see there)
+  if (!box.py()) fr.Ly = 0.0f;
+  if (!box.pz()) fr.Lz = 0.0f;
   return fr;
 }
 UH_D TileFrame tile_centred(TileFrame fr, float ox, float oy, float oz) {
@@ -405,7 +425,7 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
       const uint nW = (nC + 63u) >> 6;
       const uint wcntV = nC > 64u * (uint)lane ? min(nC - 64u * (uint)lane, 64u) : 0u;
       if (pbcTile)
-        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
       else
         tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     }
@@ -594,7 +614,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
     Acc acc;
     if (pbcWave)
-      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
     else
       tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
