@@ -25,6 +25,11 @@ for _ in range(int(os.environ.get("MELT", "300"))):
 pd.sortParticles()
 integ.forwardTime()
 cl = pf.nl
+if os.environ.get("OUTSIDE"):   # every particle stored in a random periodic image (what unwrapped trajectories become): all tiles take the
+    g = torch.Generator(device="cuda").manual_seed(3)   # minimum-image variant
+    pos = pd.getPos("readwrite")
+    pos[:, :3] += L * torch.randint(-1, 2, (n, 3), generator=g, device="cuda").float()
+    integ.forwardTime()
 f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
 ref = None
 for algo in algos:
