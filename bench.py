@@ -37,6 +37,13 @@ PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 M
 PEAK_HBM_GBS = 8000.0
 
 
+def _allreduce(dist, values, op):
+    """floats reduced over the ranks (host tensors under gloo, device tensors under RCCL)."""
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+    return t.tolist()
+
+
 def read_traffic(name):
     """HBM bytes per launch from the committed PMC summary (tools/pmc_traffic.sh -> profiles/), or None."""
     tp = os.path.join(ROOT, "profiles", name)
@@ -203,9 +210,7 @@ def run_fcm(hip, args, world, rank, dist):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = _allreduce(dist, [el], "MAX")[0]
     assert np.isfinite(pd.getPos().cpu().numpy()).all()
     ms = el / args.fcm_steps * 1e3
     gbs = fcm_bytes_per_step(n, cells) / (ms * 1e-3) / 1e9
@@ -254,14 +259,12 @@ def run_fcm_distributed(hip, args, world, rank, dist):
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    cnt = torch.tensor([float(pos.shape[0])], dtype=torch.float64, device="cuda")
+    cnt = float(pos.shape[0])
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        el = float(t.item())
+        el = _allreduce(dist, [el], "MAX")[0]
+        cnt = _allreduce(dist, [cnt], "SUM")[0]
     assert torch.isfinite(pos).all()
-    assert abs(float(cnt.item()) - n * world) < 0.5, "particles were lost or duplicated in migration"
+    assert abs(cnt - n * world) < 0.5, "particles were lost or duplicated in migration"
     integ.check_drift()
     ms = el / args.fcm_steps * 1e3
     nbytes = fcm_bytes_per_step(n * world, cells)
@@ -327,9 +330,7 @@ def run_fcm_c5(hip, args, world, rank, dist):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = _allreduce(dist, [el], "MAX")[0]
     ms = el / steps * 1e3
     nbytes = fcm_bytes_per_step(n_total, cells)
     gbs = nbytes / (ms * 1e-3) / 1e9
@@ -456,15 +457,10 @@ def run_lj_distributed(hip, args, world, rank, dist):
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    nloc = torch.tensor([float(pos.shape[0]), el], dtype=torch.float64, device="cuda")
+    total = float(pos.shape[0])
     if dist is not None:
-        tmax = nloc[1:].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        ntot = nloc[:1].clone()
-        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
-        el, total = float(tmax.item()), float(ntot.item())
-    else:
-        total = float(pos.shape[0])
+        el = _allreduce(dist, [el], "MAX")[0]
+        total = _allreduce(dist, [total], "SUM")[0]
     assert torch.isfinite(pos).all()
     assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
     sim.check_skin()
@@ -478,6 +474,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0, help="how many times the timed --steps block is run (0 = 10 for blocks of <= 100 steps); "
+                                                           "value / ms_per_step are the median block, the spread is reported")
     ap.add_argument("--equilibrate", type=int, default=300, help="untimed steps that melt the lattice before warm-up (part of the synthetic input)")
     ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both"])
     ap.add_argument("--fcm-steps", type=int, default=200)
@@ -499,23 +497,61 @@ def main():
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
 
+    same_device = os.environ.get("UAMMD_BENCH_SAME_DEVICE") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, RCCL), exactly what the driver's
+        # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` does.  Never a silent single-rank run.
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not same_device:
+            print(f"bench.py: --gpus {args.gpus} asked for but this machine shows {ndev} GPU(s): refusing to run fewer ranks than asked.  "
+                  "(Single-GPU debugging of the N > 1 code path: UAMMD_BENCH_SAME_DEVICE=1 UAMMD_BENCH_BACKEND=gloo puts all ranks on "
+                  "cuda:0 and stages the messages through the host.)", file=sys.stderr)
+            sys.exit(2)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: the two must agree", file=sys.stderr)
+        sys.exit(2)
     dist = None
+    comm_info = {"backend": None, "rccl_version": None, "devices": [torch.cuda.get_device_name(0) + " (cuda:0)"] if torch.cuda.is_available() else []}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # debugging hooks (single-GPU box): UAMMD_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and UAMMD_BENCH_BACKEND=gloo
         # replaces RCCL (which refuses two ranks on one device), so that the N > 1 code path can be exercised on one GPU
-        if os.environ.get("UAMMD_BENCH_SAME_DEVICE") == "1":
+        if same_device:
             local_rank = 0
+        elif local_rank >= torch.cuda.device_count():
+            print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+            sys.exit(2)
         backend = os.environ.get("UAMMD_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        mine = f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}, pid {os.getpid()})"
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        comm_info = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (host-staged; all ranks on one device)" if same_device else ""),
+                     "rccl_version": rccl, "devices": devs}
     else:
         torch.cuda.set_device(0)
 
@@ -531,6 +567,7 @@ def main():
         out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                     "data": "synthetic"})
         if rank == 0:
+            out["comm"] = comm_info
             print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
@@ -558,6 +595,7 @@ def main():
             out["fcm"] = run_fcm_distributed(hip, args, world, rank, dist)
             out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
         if rank == 0:
+            out["comm"] = comm_info
             print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
@@ -579,21 +617,26 @@ def main():
     profiled = args.nl == "cell" and os.environ.get("UAMMD_BENCH_NOTIMER") != "1"
     if profiled:
         pf.nl.profile_enable(True)   # start / stop events on the traversal kernel's own dispatch, every launch of the timed region
-    t0 = time.perf_counter()
-    for j in range(args.steps):
-        verlet.forwardTime()
-        if (j + 1) % args.sort_every == 0:
-            pd.sortParticles()  # ... and sorts again, INSIDE the timed region, after every 500th timed step (a sort is ~1.5 ms: charging
-                                # one to a 20-step run would overstate its amortised cost of 0.003 ms per step 25-fold)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    # The timed region is EXACTLY --steps steps between barrier + synchronize on both sides.  A 20-step block is 4 ms of GPU time, so the
+    # block is repeated (each repeat bracketed the same way) and the line reports the MEDIAN block with the spread next to it.
+    blocks, done = [], 0
+    for _ in range(args.repeats if args.repeats > 0 else (10 if args.steps <= 100 else max(1, 1000 // args.steps))):
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            verlet.forwardTime()
+            done += 1
+            if done % args.sort_every == 0:
+                pd.sortParticles()  # ... and sorts again, INSIDE the timed region, after every 500th timed step (a sort is ~1.5 ms: charging
+                                    # one to a 20-step run would overstate its amortised cost of 0.003 ms per step 25-fold)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            el = _allreduce(dist, [el], "MAX")[0]
+        blocks.append(el)
+    el = float(np.median(blocks))
     k_ms, k_launches = float("nan"), 0
     if profiled:
         tot, k_launches = pf.nl.profile_read()
@@ -614,6 +657,8 @@ def main():
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "timed_blocks": {"repeats": len(blocks), "steps_each": args.steps, "ms_per_step_median": ms_per_step,
+                         "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3},
         "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, " +
                                ("CellList rebuilt every step, sortParticles every 500 steps with hintSortByHash(box, rc), " if args.nl == "cell" else
                                 f"VerletList (1.08 rc, {getattr(pf.nl, 'rebuilds', 0)} rebuilds in {args.equilibrate + args.warmup + args.steps + 1} steps), ") +
@@ -681,6 +726,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:
+        out["comm"] = comm_info
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -21,7 +21,28 @@ from oracle.fcm import FCMOracle  # noqa: E402
 from util import lattice_positions  # noqa: E402
 
 
+def lanczos_dense():
+    """lanczos_dense: the size-64 dense SPD case of test/misc/lanczos/test_lanczos.cu:196-209,236-269 — M from
+    std::mt19937{29374238} + uniform_real_distribution{0,1}, symmetrised + 5 size I; operator M M^T, vector from
+    std::mt19937{1234567} in [-10, 10]; answer sqrt(M M^T) v = M v.  Bv and iteration count of the oracle in both precisions."""
+    from oracle.lanczos import LanczosOracle, std_mt19937_uniform_real
+    size = 64
+    A = std_mt19937_uniform_real(29374238, size * size, 0.0, 1.0).reshape(size, size)
+    M = 0.5 * (A + A.T) + 5 * size * np.eye(size)
+    M2 = M @ M.T
+    v = std_mt19937_uniform_real(1234567, size, -10.0, 10.0)
+    Bv64, it64 = LanczosOracle(np.float64).run(lambda x: M2 @ x, v, 1e-7, return_all=True)
+    M2f = M2.astype(np.float32)
+    Bv32, it32 = LanczosOracle(np.float32).run(lambda x: M2f @ x, v.astype(np.float32), 1e-6, return_all=True)
+    assert np.abs((Bv64 - M @ v) / (M @ v)).max() <= 1e-7          # the reference's own assertion (test_lanczos.cu:262-266)
+    np.savez_compressed(os.path.join(HERE, "lanczos_dense.npz"), size=size, M=M, M2=M2, v=v, theory=M @ v, Bv_f64=Bv64, iterations_f64=it64,
+                        tolerance_f64=1e-7, Bv_f32=Bv32, iterations_f32=it32, tolerance_f32=1e-6, seed_matrix=29374238, seed_vector=1234567)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "lanczos_dense":
+        return lanczos_dense()
+    lanczos_dense()
     o32, o64 = oracle.get("f32"), oracle.get("f64")
     # saru_u32: first 16 outputs for 8 seed triples (exact)
     seeds = [(0, 0, 0), (1, 2, 3), (1234, 0, 0), (0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF), (7, 8, 9), (12345, 678, 9),

@@ -93,7 +93,7 @@ def test_fcm_full_size_vs_oracle(hip, o32, n, ncell):
     vref = ofcm.displacements(pos, force, temperature=T, prefactor=1 / math.sqrt(dt))
     err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
     print(f"[FCM {ncell}^3, {n} particles] T=1 rel L2 err vs oracle {err:.2e}")
-    assert err <= 2e-5
+    assert err <= 1e-5   # measured 2.9e-7 at C4 and C5 (the noise draw uses gf_fast, 2 ulp from libm: far inside the bar)
 
 
 def test_fcm_c5_eight_slabs_equal_single_gpu(hip):

@@ -135,3 +135,119 @@ def test_tile_accumulates_into_existing_forces_and_auto_selects_it(hip, o32):
     cl.transverse_lj(pot.device_table(), 1, box, f3, None, None, None, 9)           # EXACT: the reference's summation order
     torch.cuda.synchronize()
     assert np.array_equal(f3.cpu().numpy()[:, :3].view(np.uint32), ref[:, :3].view(np.uint32))
+
+
+def test_cutoff_longer_than_a_cell_edge_takes_the_exact_walk(hip, o32):
+    """uammd_celllist_update accepts any cellDim.  With a cell edge SHORTER than the cut-off the 27 cells no longer hold every pair
+    inside rc, the reference visits exactly those 27 cells all the same — and the tile kernel's 4-cell x halo would add pairs the
+    reference never sees while its prefilter margin (derived for rc <= edge) could drop others.  TILE must refuse, AUTO must give
+    the reference's (27-cell) answer bit for bit through the exact walk."""
+    from uammd_amd._lib import UammdHipError
+    n, L, rc = 6400, 20.0, 2.5
+    pos, box, pot = _setup(hip, o32, n, L, rc)
+    cd = [10, 10, 10]                                   # edge 2.0 < rc
+    ref_cl = o32.celllist_build(pos, [L] * 3, [1, 1, 1], cd)
+    ref, _, _ = o32.lj_transverse_celllist(ref_cl, box.boxSize, [1, 1, 1], pot.table, 1, n, True, False, False)
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cl.update_grid(d_pos, box, cd)
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)               # AUTO
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy()[:, :3].view(np.uint32), ref[:, :3].view(np.uint32))
+    for algo in (TILE, TILE1):
+        with pytest.raises(UammdHipError, match="cut-off"):
+            cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, algo)
+    # the same list with a table whose cut-off fits the edge: the tile kernel again
+    pot2 = hip.Potential.LJ()
+    pot2.setPotParameters(0, 0, pot2.InputPairParameters(1.9, 1.0, 1.0, False))
+    ref2, _, _ = o32.lj_transverse_celllist(ref_cl, box.boxSize, [1, 1, 1], pot2.table, 1, n, True, False, False)
+    f2 = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(pot2.device_table(), 1, box, f2, None, None, None, TILE)
+    torch.cuda.synchronize()
+    _check_force(f2.cpu().numpy(), ref2, "tile, rc 1.9 on 2.0 cells", reordered=True)
+
+
+def test_stale_parameter_table_is_reported_not_computed(hip, o32):
+    """The host remembers a device table's largest cut-off by pointer.  A caller that REWRITES the table in place with a longer
+    cut-off gets an error from the list (the kernel raises the host-mapped flag and computes nothing), never a wrong force."""
+    from uammd_amd._lib import UammdHipError
+    n, L = 6400, 20.0
+    pos, box, pot = _setup(hip, o32, n, L, 1.9)
+    pot.setPotParameters(0, 0, pot.InputPairParameters(1.9, 1.0, 1.0, False))
+    cd = [10, 10, 10]
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cl.update_grid(d_pos, box, cd)
+    tbl = pot.device_table()
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    before = f.clone()
+    big = hip.Potential.LJ()
+    big.setPotParameters(0, 0, big.InputPairParameters(2.5, 1.0, 1.0, False))
+    tbl.copy_(big.device_table())                      # same pointer, longer cut-off
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(f, before)                      # nothing was accumulated
+    with pytest.raises(UammdHipError, match="rewritten in place"):
+        cl.update_grid(d_pos, box, cd)
+    cl.update_grid(d_pos, box, cd)                     # the flag is consumed; the next traversal re-reads the table -> exact walk
+    ref_cl = o32.celllist_build(pos, [L] * 3, [1, 1, 1], cd)
+    ref, _, _ = o32.lj_transverse_celllist(ref_cl, box.boxSize, [1, 1, 1], big.table, 1, n, True, False, False)
+    f.zero_()
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy()[:, :3].view(np.uint32), ref[:, :3].view(np.uint32))
+
+
+@SHAPES
+@pytest.mark.parametrize("ratio", [4.0, 4.13, 4.37, 4.5, 4.77, 4.999])
+def test_prefilter_margin_adversarial_pairs_at_the_cutoff(hip, o32, ratio, TILE):
+    """The f16 matrix prefilter must be a SUPERSET of r < rc.  Its margin (lj_tile.hip tile_margin) is a hand-derived bound for
+    r <= rc <= cell edge; this sweeps L / rc over [4, 5): 4 cells per side, cell edge from 1.0 rc up to 1.25 rc (where the relative
+    margin is thinnest), and plants pairs at r = rc (1 - 1e-6) — inside the cut-off by less than any half-precision rounding —
+    in random directions, at random places of the cells including faces, edges, corners and across the periodic boundary.  Every
+    such pair carries a force of 0.0389 that a dropped hit would remove: compared against the oracle's cell-list walk."""
+    rc = 2.5
+    L = ratio * rc
+    rng = np.random.default_rng(int(ratio * 1000) + TILE)
+    npairs = 250
+    edge = L / 4
+    pts = np.zeros((0, 3))
+    while len(pts) < 2 * npairs:
+        a = rng.uniform(-L / 2, L / 2, 3)
+        # a third of the first partners sit on cell faces / edges / corners (multiples of the cell edge), within one float ulp
+        for k in range(int(rng.integers(0, 4))):
+            a[k % 3] = np.round(a[k % 3] / edge) * edge + rng.choice([-1e-6, 0.0, 1e-6])
+        d = rng.normal(size=3)
+        b = a + d / np.linalg.norm(d) * (rc * (1 - 1e-6))
+        both = np.stack([a, b])
+        both -= np.round(both / L) * L                           # fold (f64), stored as f32 below
+        if len(pts):                                             # no overlaps: every other pair force stays O(1)
+            dd = both[:, None, :] - pts[None, :, :]
+            dd -= np.round(dd / L) * L
+            if (np.linalg.norm(dd, axis=2) < 0.97).any():
+                continue
+        pts = np.concatenate([pts, both])
+    pos = np.zeros((2 * npairs, 4), np.float32)
+    pos[:, :3] = pts
+    box = hip.Box(L)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    (ref, _, _), cd = _oracle(o32, pos, box, pot, rc)
+    assert list(cd) == [4, 4, 4]
+    got, _, _ = _run(hip, pos, box, pot, rc, TILE)
+    # which planted pairs are inside the cut-off IN FLOAT (the reference's own test: r2 >= rc2 -> 0, Potential.cuh:37-50)?
+    p32 = pos[:, :3]
+    r = p32[1::2] - p32[0::2]
+    r = r - np.floor(r / np.float32(L) + np.float32(0.5)) * np.float32(L)
+    inside = (r.astype(np.float32) ** 2).sum(axis=1) < np.float32(rc * rc)
+    assert inside.sum() > npairs // 3                           # the construction does put pairs on both sides of the float test
+    fmax = np.abs(ref[:, :3]).max()
+    err = np.abs(got[:, :3] - ref[:, :3]).max()
+    print(f"[margin L/rc={ratio}] {int(inside.sum())} planted pairs inside rc; max |dF| = {err:.3e} (pair force at rc: 3.9e-2, max|F| {fmax:.3e})")
+    # a dropped pair at r ~ rc changes a force by |F(rc)| = 24 (2/rc^13 - 1/rc^7) ~ 0.039: two orders above this bar (no two
+    # particles are closer than 0.97, so every force is O(10)).
+    assert fmax < 100.0 and err <= 2e-4
+    _check_force(got, ref, f"tile margin sweep L/rc={ratio}", reordered=True)

@@ -23,6 +23,7 @@
 // keyStart[] is kept: the LDS-tiled traversal (lj.hip) uses it to find the particle range of an
 // aligned 4x4x4 brick of cells in O(1) (64 consecutive Morton keys).
 #include "celllist.hpp"
+#include <vector>
 
 #include <cstring>
 #include <string>
@@ -470,11 +471,30 @@ CellList::~CellList() {
 int CellList::check_errors(hipStream_t st, bool sync) {
   if (!hostErr || !reportErrors) return 0;
   if (sync) UH_CHECK(hipStreamSynchronize(st));
-  if (__atomic_load_n(hostErr, __ATOMIC_ACQUIRE)) {
+  if (const int code = __atomic_load_n(hostErr, __ATOMIC_ACQUIRE)) {
     __atomic_store_n(hostErr, 0, __ATOMIC_RELEASE);
+    if (code == 2) {
+      ljTable = nullptr;  // the cached cut-off was stale: the next traversal reads the table again
+      set_last_error("PairForces: the LJ parameter table was rewritten in place with a cut-off larger than the list's cell edge; the last "
+                     "traversal did not compute forces (pass a new table pointer, or rebuild the list for the new cut-off)");
+      return -4;
+    }
     set_last_error("CellList encountered NaN positions or particles outside a non-periodic box");  // CellListBase.cuh:262
     return -4;
   }
+  return 0;
+}
+
+int CellList::lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, float *out) {
+  if (d_table != ljTable || ntypes != ljTableTypes) {
+    std::vector<uammd_lj_pair_parameters> host((size_t)ntypes * (size_t)ntypes);
+    UH_CHECK(hipMemcpyAsync(host.data(), d_table, host.size() * sizeof(host[0]), hipMemcpyDeviceToHost, st));
+    UH_CHECK(hipStreamSynchronize(st));
+    float m = 0.f;
+    for (const auto &p : host) m = p.cutOff2 > m ? p.cutOff2 : m;
+    ljTable = d_table; ljTableTypes = ntypes; ljTableMaxCut2 = m;
+  }
+  *out = ljTableMaxCut2;
   return 0;
 }
 
@@ -491,6 +511,12 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     UH_CHECK(hipHostGetDevicePointer((void **)&devErr, hostErr, 0));
   }
   if (int e = check_errors(st, false)) return e;  // raised by an earlier build
+  if (buildStreamSet && buildStream != st) {  // a list's buffers are ordered by the stream it is used on: changing it drains the old one
+    UH_CHECK(hipStreamSynchronize(buildStream));
+    zeroBlockClean = false;
+  }
+  buildStream = st;
+  buildStreamSet = true;
   const BoxT<float> box = make_box<float>(L, periodic);
   grid = make_grid<float>(box, make_int3(cellDim_[0], cellDim_[1], cellDim_[2]));
   for (int k = 0; k < 3; ++k) { boxL[k] = L[k]; boxPeriodic[k] = periodic[k] != 0; }

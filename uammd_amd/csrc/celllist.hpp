@@ -30,6 +30,8 @@ struct CellList {
   DeviceBuffer zeroBlock;  // errorFlag | keyOutside | keyCount live here: ONE memset per build instead of three — and none when the
                            // previous counting build of the same grid left it zeroed (zeroBlockClean)
   bool zeroBlockClean = false;
+  hipStream_t buildStream = nullptr;  // stream of the last build: its tail zeroes the block, which orders nothing for ANOTHER stream
+  bool buildStreamSet = false;
   char *zeroBase = nullptr;
   size_t zeroLayout[2] = {0, 0};
   GridT<float> grid{};
@@ -54,6 +56,11 @@ struct CellList {
   int *hostErr = nullptr, *devErr = nullptr;
   bool strictErrors = false, reportErrors = true;
   int check_errors(hipStream_t st, bool sync);
+  // largest cutOff2 of an LJ parameter table in device memory, read back once per (pointer, ntypes) (lj.hip: is the tile kernel allowed?)
+  const void *ljTable = nullptr;
+  int ljTableTypes = 0;
+  float ljTableMaxCut2 = 0.f;
+  int lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, float *out);
   ~CellList();
   // Traversal-kernel timing for bench.py's roofline line: when enabled the LJ traversal is launched with hipExtLaunchKernel and a
   // start / stop event pair from a ring (the events ride on the kernel's own dispatch packet: no extra barrier packets in the

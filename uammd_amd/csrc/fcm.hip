@@ -54,6 +54,8 @@ struct FCM {
   int3 ntiles{0, 0, 0};
   int prepCapN = 0;
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
+  hipStream_t prepStream = nullptr;  // ... an ordering that only holds within one stream: a call on another stream waits for this one first
+  bool prepStreamSet = false;
   bool forceAtomicSpread = false;  // test hook
   bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
@@ -340,6 +342,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   int listCount = 0;  // uniform over the workgroup
 
   auto spread_list = [&](int count) {
+    // (every call site is workgroup-uniform.)  The list was appended to by all four waves, possibly in an earlier sub-round of the
+    // loop below with no barrier since: phase B reads every entry's slot, so the writes must have landed first.
+    __syncthreads();
     // phase B
     const int words = count * wpad;
     const float rws = 1.0f / (float)wpad;
@@ -955,8 +960,12 @@ template <int SIGN> static void fft_launch_lines(float2 *g, int log2n, int nkx, 
   else if (n == 256) hipLaunchKernelGGL((k_fft_lines<SIGN, 4, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
   else hipLaunchKernelGGL((k_fft_lines<SIGN, 8, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
 }
+// Sizes the LDS passes serve without asking for more than the 64 KB of dynamic LDS a launch gets by default: the y pass holds 16 lines
+// (8 (n + 16 (n + 1)) bytes: 35 KB at 256, 69.8 KB at 512), the fused z pass 12 lines of nz (53 KB at 512), the row passes <= 25 KB up
+// to 1024.  Anything else takes rocFFT + k_fcm_kspace.
+static bool fft_axis_ok(int n, int lo, int hi) { const int l = ilog2_exact(n); return l >= lo && n <= hi; }
 static bool fcm_custom_fft_usable(const FCM *f) {
-  return f->customFFT && ilog2_exact(f->grid.cellDim.x) >= 5 && ilog2_exact(f->grid.cellDim.y) > 0 && ilog2_exact(f->grid.cellDim.z) > 0 &&
+  return f->customFFT && fft_axis_ok(f->grid.cellDim.x, 5, 512) && fft_axis_ok(f->grid.cellDim.y, 1, 256) && fft_axis_ok(f->grid.cellDim.z, 1, 512) &&
          f->planeReal == (size_t)f->nxpad * f->grid.cellDim.y * f->grid.cellDim.z;
 }
 // forward x and y transforms of the three real component grids, in place
@@ -1054,6 +1063,12 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
              (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
              (int *)f->prepTileStart.ptr, wstride};
+  if (f->prepStreamSet && f->prepStream != st) {  // the handle's buffers (and the zeroed counters) are ordered by the stream of the last call
+    UH_CHECK(hipStreamSynchronize(f->prepStream));
+    f->tileCountZero = false;
+  }
+  f->prepStream = st;
+  f->prepStreamSet = true;
   if (!f->tileCountZero) {  // first use of the buffer; afterwards k_fcm_tile_scan hands the counters back zeroed
     UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
     f->tileCountZero = true;
@@ -1104,7 +1119,7 @@ struct FCMSlab {
 };
 
 static bool fcm_slab_custom_fft(const FCMSlab *s) {
-  return s->loc.customFFT && ilog2_exact(s->cells.x) >= 5 && ilog2_exact(s->cells.y) > 0;
+  return s->loc.customFFT && fft_axis_ok(s->cells.x, 5, 512) && fft_axis_ok(s->cells.y, 1, 256);
 }
 static int fcm_slab_make_plans(FCMSlab *s) {
   std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
@@ -1465,7 +1480,8 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
 int uammd_fcm_slab_forward_xy_fold(uammd_fcm_slab *h, float *d_grid, const float *d_fromDown, const float *d_fromUp, int planes, void *stream) {
   if (!h || !d_grid || !d_fromDown || !d_fromUp) { set_last_error("uammd_fcm_slab_forward_xy_fold: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
-  if (planes < 0 || 2 * planes > s->nzl) { set_last_error("uammd_fcm_slab_forward_xy_fold: the folded planes overlap"); return -1; }
+  if (planes < 0) { set_last_error("uammd_fcm_slab_forward_xy_fold: negative plane count"); return -1; }
+  if (2 * planes > s->nzl) return 1;  // thin slab, the two folds overlap: not served (the caller adds the planes itself, in order)
   if (!fcm_slab_custom_fft(s)) return 1;
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
   const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
@@ -1581,7 +1597,7 @@ int uammd_fcm_slab_z_fused(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, flo
                            void *stream) {
   if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_z_fused: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
-  if (!s->loc.customFFT || ilog2_exact(s->cells.z) < 0) return 1;
+  if (!s->loc.customFFT || !fft_axis_ok(s->cells.z, 1, 512)) return 1;
   float noisePrefactor = 0.0f;
   if (temperature > 0.0f) {
     const float gL[3] = {s->L.x, s->L.y, s->L.z};

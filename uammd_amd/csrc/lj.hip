@@ -527,10 +527,8 @@ __global__ void __launch_bounds__(128) k_lj_nbody(const float4 *__restrict__ pos
 
 // ---- dispatch --------------------------------------------------------------------------------------
 // lj_tile.hip: cell-pair tiles, distance test on the matrix pipe (same pairs, another summation order)
-bool lj_tile_supported(const CellList *h, const BoxT<float> &box);
-template <bool NT1, bool WE, bool WV>
-// lj_tile.hip: cell-pair tiles, distance test on the matrix pipe (same pairs, another summation order)
-bool lj_tile_supported(const CellList *h, const BoxT<float> &box);
+bool lj_tile_supported(const CellList *h, const BoxT<float> &box, float maxCutOff2);
+float lj_tile_max_cutoff2(const GridT<float> &g);
 template <bool NT1, bool WE, bool WV>
 int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, const LJParams *tbl, int ntypes, const Outputs &out,
                    int shape, hipStream_t st);
@@ -552,6 +550,8 @@ static int dispatch_celllist(CellList *h, int algo, const BoxT<float> &box, cons
   cl.validCell = h->validCell;
   cl.N = h->numberParticlesBuilt;
   cl.numOwned = h->numOwned;
+  cl.maxCut2Allowed = lj_tile_max_cutoff2(h->grid);
+  cl.errFlag = h->devErr;
   switch (algo) {
     case UAMMD_LJ_ALGO_AUTO: case UAMMD_LJ_ALGO_GENERAL: case UAMMD_LJ_ALGO_RING: case UAMMD_LJ_ALGO_RING_HALF: case UAMMD_LJ_ALGO_TILE:
     case UAMMD_LJ_ALGO_TILE1: case UAMMD_LJ_ALGO_EXACT: break;
@@ -560,12 +560,19 @@ static int dispatch_celllist(CellList *h, int algo, const BoxT<float> &box, cons
                      "were removed: TILE replaces them)", algo);
       return -3;
   }
-  if ((algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1) && !lj_tile_supported(h, box)) {
+  bool tileOK = false;
+  if (algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1 || algo == UAMMD_LJ_ALGO_AUTO) {
+    // the table lives in device memory: its largest cut-off is read back once per (pointer, size) and remembered with the list
+    float maxCut2 = 0.f;
+    if (int e = h->lj_max_cutoff2(tbl, ntypes, st, &maxCut2)) return e;
+    tileOK = lj_tile_supported(h, box, maxCut2);
+  }
+  if ((algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1) && !tileOK) {
     set_last_error("uammd_lj_transverse_celllist: the tile kernel needs a tabulated list built on the potential's box with 1 (non "
-                   "periodic) or >= 3 cells per dimension (>= 4 along a periodic x)");
+                   "periodic) or >= 3 cells per dimension (>= 4 along a periodic x) and no cell edge shorter than the largest cut-off");
     return -3;
   }
-  if (algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1 || (algo == UAMMD_LJ_ALGO_AUTO && lj_tile_supported(h, box)))
+  if (algo == UAMMD_LJ_ALGO_TILE || algo == UAMMD_LJ_ALGO_TILE1 || (algo == UAMMD_LJ_ALGO_AUTO && tileOK))
     return launch_lj_tile<NT1, WE, WV>(h, cl, box, tbl, ntypes, out, algo == UAMMD_LJ_ALGO_TILE1 ? 1 : 4, st);
   if (algo == UAMMD_LJ_ALGO_EXACT) algo = UAMMD_LJ_ALGO_AUTO;  // from here on AUTO = the fastest bit-exact kernel for the grid
   const GridT<float> &g = h->grid;

@@ -119,6 +119,11 @@ struct ListView {
   uint validCell;
   int N;
   int numOwned;  // particles whose input index is >= numOwned only act as neighbours (domain-decomposition ghosts)
+  // tile kernels only: they need cut-off <= every multi-cell edge (27-cell reach of the 4-cell x halo, prefilter margin).  The host
+  // routes other tables to the exact kernels from a cached copy of the table's largest cut-off; a launch that arrives here with a
+  // larger one anyway (the caller rewrote its table in place) raises the list's host-mapped error flag instead of computing.
+  float maxCut2Allowed;
+  int *errFlag;
 };
 
 struct Outputs {

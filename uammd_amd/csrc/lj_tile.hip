@@ -388,7 +388,12 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
   const float4 *__restrict__ P = cl.sortPos;
   const LJParams p1 = tbl[0];
   const TileFrame fr = tile_frame(grid, box, ox, oy, oz);
-  const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
+  const float maxCut2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  if (maxCut2 > cl.maxCut2Allowed) {  // wave-uniform; see ListView::maxCut2Allowed
+    if (lane == 0 && cl.errFlag) cl.errFlag[0] = 2;
+    return;
+  }
+  const float rc2ms = maxCut2 * fr.s * fr.s + margin;  // scaled units
   const f4t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};  // padding behind the last candidate: finite; the word counts clear its bits
   LdsF4 *cand = (LdsF4 *)(uintptr_t)candBase;
   const uint wabsTab = tab + 4u * (uint)((kMaxW + 1) * 64);
@@ -609,7 +614,12 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
   const LJParams p1 = tbl[0];
   const TileFrame fr = tile_centred(scale, ox, oy, oz);
-  const float rc2ms = (NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes)) * fr.s * fr.s + margin;  // scaled units
+  const float maxCut2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  if (maxCut2 > cl.maxCut2Allowed) {  // wave-uniform; see ListView::maxCut2Allowed
+    if (lane == 0 && cl.errFlag) cl.errFlag[0] = 2;
+    return;
+  }
+  const float rc2ms = maxCut2 * fr.s * fr.s + margin;  // scaled units
   for (int o0 = 0; o0 < nOwn; o0 += 32) {
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
     Acc acc;
@@ -622,8 +632,20 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
 }
 
 // host side: can this list / box take the tile kernel, and with what margin
-bool lj_tile_supported(const CellList *h, const BoxT<float> &box) {
+float lj_tile_max_cutoff2(const GridT<float> &g) {
+  float e2 = 3.0e38f;
+  const int n[3] = {g.cellDim.x, g.cellDim.y, g.cellDim.z};
+  const float c[3] = {g.cellSize.x, g.cellSize.y, g.cellSize.z};
+  for (int k = 0; k < 3; ++k)
+    if (n[k] > 1 && c[k] * c[k] < e2) e2 = c[k] * c[k];
+  return e2 * 1.0001f;  // (CellList::createUpdateGrid floors L / rc: the edge is >= rc up to the rounding of that division)
+}
+
+bool lj_tile_supported(const CellList *h, const BoxT<float> &box, float maxCutOff2) {
   const GridT<float> &g = h->grid;
+  // every cell edge must hold the largest cut-off: the matrix prefilter's margin is derived for r <= rc <= e, and the 4-cell x halo
+  // would otherwise pair owners with candidates two cells away, outside the reference's 27 cells
+  if (!(maxCutOff2 <= lj_tile_max_cutoff2(g))) return false;
   if (!h->haveCellOutside || !h->cellRange.ptr) return false;
   const bool sameBox = box.boxSize.x == g.box.boxSize.x && box.boxSize.y == g.box.boxSize.y && box.boxSize.z == g.box.boxSize.z &&
                        box.px() == g.box.px() && box.py() == g.box.py() && box.pz() == g.box.pz();

@@ -227,13 +227,26 @@ class _Exchange:
         from_down, from_up = landing(into_down, to_up[0]), landing(into_up, to_down[0])
         # with 2 ranks both neighbours are the same peer: the messages are told apart by tag (gloo) / issue order (RCCL)
         t1, t2 = (1, 2) if P == 2 else (0, 0)
-        ops = [dist.P2POp(dist.isend, to_up[0].contiguous(), up, self.group, tag=t1),
-               dist.P2POp(dist.irecv, from_down, down, self.group, tag=t1),
-               dist.P2POp(dist.isend, to_down[0].contiguous(), down, self.group, tag=t2),
-               dist.P2POp(dist.irecv, from_up, up, self.group, tag=t2)]
+        su, sd = to_up[0].contiguous(), to_down[0].contiguous()
+        staged = self._staged(su)
+        if staged:      # gloo moves host memory only (several ranks on ONE GPU: tests/test_gpu_world2.py, bench.py UAMMD_BENCH_BACKEND=gloo)
+            su, sd = su.cpu(), sd.cpu()
+            rd, ru = torch.empty(from_down.shape, dtype=from_down.dtype), torch.empty(from_up.shape, dtype=from_up.dtype)
+        else:
+            rd, ru = from_down, from_up
+        ops = [dist.P2POp(dist.isend, su, up, self.group, tag=t1),
+               dist.P2POp(dist.irecv, rd, down, self.group, tag=t1),
+               dist.P2POp(dist.isend, sd, down, self.group, tag=t2),
+               dist.P2POp(dist.irecv, ru, up, self.group, tag=t2)]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if staged:
+            from_down.copy_(rd)
+            from_up.copy_(ru)
         return [from_down], [from_up]
+
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def all_to_all(self, blocks):
         """blocks[i]: tensor [P, ...], slice d goes to rank d.  Returns tensors [P, ...] with slice s received from rank s."""
@@ -243,6 +256,18 @@ class _Exchange:
         if self.in_process:
             return [torch.stack([blocks[s][r] for s in range(P)], dim=0) for r in range(P)]
         out = torch.empty_like(blocks[0])
+        if self._staged(out):   # gloo has no all-to-all on device memory: P - 1 host-staged point-to-point pairs + the own block
+            src, r = blocks[0].contiguous().cpu(), self.local[0]
+            host = torch.empty(src.shape, dtype=src.dtype)
+            host[r] = src[r]
+            ops = []
+            for k in range(1, P):
+                to, frm = (r + k) % P, (r - k) % P
+                ops += [dist.P2POp(dist.isend, src[to], to, self.group, tag=k), dist.P2POp(dist.irecv, host[frm], frm, self.group, tag=k)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            out.copy_(host)
+            return [out]
         dist.all_to_all_single(out, blocks[0].contiguous(), group=self.group)
         return [out]
 
