@@ -367,6 +367,115 @@ def cpu_baseline_fcm(sample_steps):
 
 
 
+# ---- PSE + Lanczos (SURVEY 8d "PSE+Lanczos variant": the spectral-Ewald half of the north star) -----------------------------------------
+PSE_N, PSE_L, PSE_PSI, PSE_TOL = 100_000, 128.0, 0.5, 1e-3
+
+
+def _pse_inputs():
+    rng = np.random.default_rng(1234)
+    pos = np.zeros((PSE_N, 4), np.float32)
+    pos[:, :3] = rng.uniform(-PSE_L / 2, PSE_L / 2, (PSE_N, 3))
+    force = np.zeros((PSE_N, 4), np.float32)
+    force[:, :3] = np.random.default_rng(4321).normal(0, 1, (PSE_N, 3))
+    return pos, force
+
+
+def _timed(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def run_pse(hip, args):
+    """BDHI::EulerMaruyama<BDHI::PSE>: N = 1e5, L = 128, a = 1, psi = 0.5 (PSE/utils.cuh:17-24 default), tolerance 1e-3, T = 1, dt = 0.01,
+    fixed N(0,1) forces.  One step = far field (spread, FFT, sheared Hasimoto-split operator + noise, FFT, gather) + near-field M F (one
+    sparse product over the cell list, rc = sqrt(-ln tol) / psi = 5.26) + near-field noise by Lanczos (k products + the recurrence)
+    + Euler update.  Parts are timed on their own as well; roofline per part."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    lib = load()
+    pos, force = _pse_inputs()
+    pd = hip.ParticleData(PSE_N, seed=1234)
+    pd.setPos(pos)
+    par = hip.BDHI.PSE.Parameters(temperature=1.0, viscosity=1.0, hydrodynamicRadius=1.0, tolerance=PSE_TOL, dt=0.01, box=hip.Box(PSE_L),
+                                  psi=PSE_PSI)
+    integ = hip.BDHI.EulerMaruyama(pd, par, Method=hip.BDHI.PSE)
+    integ.addInteractor(FixedForce(pd, torch.from_numpy(force).cuda()))
+    pse = integ.bdhi
+    steps, warm = args.pse_steps, 5
+    for _ in range(warm):
+        integ.forwardTime()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = []
+    for _ in range(steps):
+        integ.forwardTime()
+        its.append(pse.lastLanczosIterations)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert np.isfinite(pd.getPos().cpu().numpy()).all()
+    # the parts, each on its own (same state)
+    MF = torch.zeros((PSE_N, 3), dtype=torch.float32, device="cuda")
+    dforce = torch.from_numpy(force).cuda()
+    dpos = pd.getPos("read")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t_far = _timed(lambda: pse._far(dforce, MF, 1.0, 10.0), 50)
+    t_mdot = _timed(lambda: check(lib.uammd_pse_near_mdot(pse.near, p(dpos), p(dforce), PSE_N, p(MF), st())), 50)
+    v3 = torch.randn((PSE_N, 3), dtype=torch.float32, device="cuda")
+    t_dot = _timed(lambda: check(lib.uammd_pse_near_dot(pse.near, p(dpos), p(v3), PSE_N, p(MF), st())), 50)
+    t_stoch = _timed(lambda: pse._near_stochastic(MF, 1.0, 1.0), 20)
+    k = float(np.mean(its))
+    # near-field product: candidates per particle = 27 cells x particles per cell; ~30 flop per candidate test (sheared minimum image with
+    # three roundf, dot, compare) + ~45 per pair inside rc (sqrt, two table interpolations, division, 3 x 3 product)
+    ncell = int(PSE_L / pse.rcut)
+    cand = 27.0 * PSE_N / ncell ** 3
+    hits = 4.0 / 3.0 * math.pi * pse.rcut ** 3 * PSE_N / PSE_L ** 3
+    flop_dot = PSE_N * (cand * 30.0 + hits * 45.0)
+    G = 12 * 2 * (pse.cells[0] // 2 + 1) * pse.cells[1] * pse.cells[2]
+    far_bytes = 10 * G + 60 * PSE_N
+    # one Lanczos iteration besides the product (LanczosAlgorithm.cu:114-157): w -= beta v_{i-1}; alpha = w.v; w -= alpha v; beta = |w|;
+    # v_{i+1} = w / beta  ->  ~8 passes over 3N floats; a convergence check adds the 3N x m gemv
+    lanczos_bytes_iter = 8 * 12 * PSE_N
+    return {"metric": "BDHI::PSE steps/s (1e5 particles, L=128, a=1, psi=0.5, tol 1e-3, T=1)", "value": 1e3 / ms, "unit": "steps/s",
+            "ms_per_step": ms, "steps": steps, "lanczos_iterations_mean": k, "lanczos_iterations_minmax": [int(min(its)), int(max(its))],
+            "config": {"workload": f"BDHI::EulerMaruyama<PSE>: near-field cut-off {pse.rcut:.3f} ({ncell}^3 cells, {cand:.0f} candidates and "
+                                   f"{hits:.1f} neighbours per particle), RPY table {pse.nPointsTable} points, far-field grid "
+                                   f"{list(pse.cells)}, Gaussian support {pse.support}; fixed forces"},
+            "parts_ms": {"far_field": t_far, "near_MF (cell list + 1 product)": t_mdot, "near_product (cell list + memset + 1 product)": t_dot,
+                         "near_noise (cell list + Saru vector + Lanczos)": t_stoch},
+            "roofline_near_product": {"bound": "valu", "achieved": flop_dot / (t_dot * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": flop_dot / (t_dot * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                      "note": "time includes the per-call cell-list build; flops = N (27 Nppc x 30 + neighbours x 45)"},
+            "roofline_lanczos": {"bound": "valu", "products": k + 1, "ms_per_iteration": t_stoch / (k + 1),
+                                 "note": "near_noise / (iterations + 1): one product + ~8 vector passes (%.1f MB) + scalar recurrences per iteration" % (lanczos_bytes_iter / 1e6)},
+            "roofline_far_field": {"bound": "hbm", "achieved": far_bytes / (t_far * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": far_bytes / (t_far * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": far_bytes}}
+
+
+def cpu_baseline_pse(sample_steps):
+    cores = _pin_threads()
+    import oracle
+    from oracle.pse import PSEOracle
+    o = oracle.get("f32")
+    o.set_parallel(True)
+    pos, force = _pse_inputs()
+    ps = PSEOracle(o, PSE_L, 1.0, 1.0, PSE_TOL, PSE_PSI)
+    t0 = time.perf_counter()
+    for s in range(sample_steps):
+        v = ps.computeHydrodynamicDisplacements(pos, force, 1.0, 10.0, seed2_near=s + 1, seed2_far=s + 1)
+        pos[:, :3] += v * np.float32(0.01)
+    el = time.perf_counter() - t0
+    return {"value": sample_steps / el, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_steps} PSE steps (oracle: near product + Lanczos in numpy around the C product, far field with scipy FFTs) "
+                      f"on {cores} threads, {el:.1f} s"}
+
+
 def run_lj_distributed(hip, args, world, rank, dist):
     """N > 1 (or --force-distributed): z-slab domain decomposition, one slab of `--particles` particles per rank
     (weak scaling: the global box grows along z), halo exchange + migration over torch.distributed P2P."""
@@ -477,7 +586,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="how many times the timed --steps block is run (0 = 10 for blocks of <= 100 steps); "
                                                            "value / ms_per_step are the median block, the spread is reported")
     ap.add_argument("--equilibrate", type=int, default=300, help="untimed steps that melt the lattice before warm-up (part of the synthetic input)")
-    ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both"])
+    ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both", "pse"])
+    ap.add_argument("--pse-steps", type=int, default=50)
+    ap.add_argument("--cpu-pse-steps", type=int, default=5)
     ap.add_argument("--fcm-steps", type=int, default=200)
     ap.add_argument("--fcm-warmup", type=int, default=20)
     ap.add_argument("--cpu-fcm-steps", type=int, default=40)
@@ -558,6 +669,16 @@ def main():
     import uammd_amd as hip
     from uammd_amd._lib import check, load
 
+    if args.workload == "pse":
+        if world > 1:
+            print("bench.py: the PSE line is single-GPU (the near field shards like path A, the far field like path B)", file=sys.stderr)
+            sys.exit(2)
+        out = run_pse(hip, args)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_pse(args.cpu_pse_steps)
+        out.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
+        print(json.dumps(out))
+        return
     if args.workload == "fcm":
         out = (run_fcm_distributed if (world > 1 or args.force_distributed) else run_fcm)(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -723,6 +844,10 @@ def main():
         out["fcm"] = fcm
         if not args.no_c5:
             out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
+    if args.workload == "both" and world == 1:
+        out["pse"] = run_pse(hip, args)
+        if not args.no_cpu_baseline:
+            out["pse"]["cpu_baseline"] = cpu_baseline_pse(args.cpu_pse_steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:

@@ -1138,6 +1138,7 @@ class PSE {
   shared_ptr<ParticleData> pd;
   uammd_pse_near *nearField = nullptr;
   uammd_fcm *farField = nullptr;
+  shared_ptr<bool> alive;  // the ParticleData callbacks outlive this object: they look at this flag first
   real hydrodynamicRadius, M0, temperature, dt;
   void far(const real4 *force, real3 *MF, real T, real prefactor, hipStream_t st) {
     const uint seed2 = T > 0 ? pd->getSystem()->rng().next32() : 0u;  // FarField.cuh:499
@@ -1165,6 +1166,14 @@ public:
     const uint seedNear = rng.next32();  // NearField ctor first, then FarField (initialization.cu:57-59)
     detail::check(uammd_pse_near_create(L, par.viscosity, par.hydrodynamicRadius, par.tolerance, par.psi, par.shearStrain, seedNear,
                                         &nearField, nullptr, nullptr));
+    // CellList::update rebuilds only after a position write or a reorder (CellList.cuh:94-98,134-136)
+    detail::check(uammd_pse_near_set_option(nearField, "lazy_list", 1));
+    alive = std::make_shared<bool>(true);
+    std::weak_ptr<bool> w = alive;
+    uammd_pse_near *nf = nearField;
+    auto changed = [w, nf]() { if (!w.expired()) uammd_pse_near_positions_changed(nf); };
+    pd->connectPosWriteRequested(changed);
+    pd->connectReorder(changed);
     const uint seedFar = rng.next32();
     int c[3];
     detail::check(uammd_pse_far_raw_cells(L, par.psi, par.tolerance, c));

@@ -524,6 +524,13 @@ int uammd_pse_near_create(const float boxSize[3], float viscosity, float hydrody
                           int *nPointsTable_out);
 int uammd_pse_near_destroy(uammd_pse_near *h);
 int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain);
+/* "exact_order" (default 0): 1 = thread-per-particle product in the reference's summation order (NearField.cuh:154-185 over
+ * NeighbourList/common.cuh:10-34), bit for bit; 0 = eight lanes per particle, same pairs and per-pair arithmetic, another order.
+ * "lazy_list" (default 0): 1 = the near-field cell list is rebuilt only after uammd_pse_near_positions_changed() (the host layers wire
+ * it to ParticleData's position write signal) or when the position array / N of a call changes — CellList::update's needsRebuild
+ * (NeighbourList/CellList.cuh:134-136,192-204); 0 = every mdot / stochastic / dot call rebuilds. */
+int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value);
+int uammd_pse_near_positions_changed(uammd_pse_near *h);
 /* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int numberParticles, float *d_MF,
                         void *stream);

@@ -396,3 +396,42 @@ def test_fcm_alternative_kernels_self_mobility(hip, o32, name, rtol):
     vref = ofcm.displacements(pos, force)
     v = fcm.computeHydrodynamicDisplacements(torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda(), npart, 0.0, 0.0)
     assert np.linalg.norm(v.cpu().numpy() - vref) <= 2e-5 * np.linalg.norm(vref)
+
+
+@pytest.mark.parametrize("cells,tol", [([108, 100, 84], 1e-3), ([40, 30, 35], 1e-4), ([54, 54, 54], 1e-3), ([20, 24, 28], 1e-2)],
+                         ids=["T=6,5,7-P6", "T=8,6,7-P8", "T=6-P6", "T=5,8,7-P5"])
+def test_fcm_tile_edges_other_than_eight(hip, o32, cells, tol):
+    """The tile-owned spread / prepared gather with tile edges of 4..8 nodes per axis (fcm_tiles_usable: the largest divisor of the axis
+    that holds the stencil's reach): the grids the reference's nextFFTWiseSize3D hands out are 2^a 3^b 5^c 7^d 11^e, e.g. the 108^3 far
+    field of PSE at psi = 0.5.  Random particles + clusters on tile corners + unwrapped coordinates, against the atomic spread and
+    the oracle."""
+    from oracle.fcm import FCMOracle
+    L = np.asarray(cells, np.float32)
+    rng = np.random.default_rng(sum(cells))
+    n = 3000
+    pos = np.zeros((n, 4), np.float32)
+    pos[:1500, :3] = rng.uniform(-0.5, 0.5, (1500, 3)) * L
+    step = np.array([6, 5, 7], np.float32)
+    pos[1500:2500, :3] = (rng.integers(0, 4, (1000, 3)) * step).astype(np.float32) - L / 2 + rng.normal(0, 0.4, (1000, 3))
+    pos[2500:, :3] = rng.uniform(-1.5, 1.5, (500, 3)) * L
+    pos[0, :3] = -L / 2
+    pos[1, :3] = L / 2 - np.float32(1e-3)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, tol)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    fa = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    fa.set_option("atomic_spread", 1)
+    ofcm = FCMOracle(o32, L, cells, tolerance=tol, viscosity=0.9, seed=5)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    va = fa.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    vref = ofcm.displacements(pos, force)
+    assert np.linalg.norm(v - va) <= 1e-5 * np.linalg.norm(va)
+    assert np.linalg.norm(v - vref) <= 1e-5 * np.linalg.norm(vref)
+    gk = fcm.fourier_grid(dp, df, n, 0.0, 0.0).cpu().numpy()
+    ga = fa.fourier_grid(dp, df, n, 0.0, 0.0).cpu().numpy()
+    assert np.abs(gk - ga).max() <= 2e-5 * np.abs(ga).max()
+    v2 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()      # with noise (same seeds, same seed2 sequence)
+    va2 = fa.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()
+    assert np.linalg.norm(v2 - va2) <= 1e-5 * np.linalg.norm(va2)

@@ -54,8 +54,16 @@ def test_setup_and_near_dot(hip, o32, psi, tol, shear):
     cl = ref._near_list(pos)
     ref._near_dot(cl, v, 3, expect)
     got = out.cpu().numpy()
+    # default product: eight lanes per particle (same pairs, same per-pair arithmetic, another summation order)
     assert np.abs(got - expect).max() <= 1e-6 * np.abs(expect).max()
-    print("differing words:", np.count_nonzero(got.view(np.uint32) != expect.view(np.uint32)), "of", got.size)
+    print("8-lane product, differing words:", np.count_nonzero(got.view(np.uint32) != expect.view(np.uint32)), "of", got.size)
+    # "exact_order": the reference's summation order, bit for bit
+    check(pse.lib.uammd_pse_near_set_option(pse.near, b"exact_order", 1))
+    out.fill_(7.0)
+    check(pse.lib.uammd_pse_near_dot(pse.near, _ptr(pd.getPos()), _ptr(d_v), n, _ptr(out), current_stream()))
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
+    check(pse.lib.uammd_pse_near_set_option(pse.near, b"exact_order", 0))
     # Mdot with real4 forces ACCUMULATES into MF
     f4 = np.zeros((n, 4), np.float32)
     f4[:, :3] = v
@@ -102,6 +110,15 @@ def test_near_noise_and_lanczos(hip, o32):
     got = BdW.cpu().numpy()
     assert 1 <= it.value <= 30
     assert np.linalg.norm(got - exp) <= 5 * tol * np.linalg.norm(exp)
+    # the default path iterates on vectors in cell order; "exact_order" keeps the caller's order: same Krylov space, same iteration
+    # count, results equal to rounding
+    check(pse.lib.uammd_pse_near_set_option(pse.near, b"exact_order", 1))
+    B2 = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    it2 = C.c_int(0)
+    check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, 0.8, 1.1, 555, _ptr(B2), current_stream(), C.byref(it2)))
+    check(pse.lib.uammd_pse_near_set_option(pse.near, b"exact_order", 0))
+    assert it2.value == it.value
+    assert np.linalg.norm(B2.cpu().numpy() - got) <= 1e-5 * np.linalg.norm(got)
     # M^(1/2) property: |B dW|^2 / |dW|^2 is a Rayleigh quotient of M_near -> between its extreme eigenvalues (all > 0)
     assert 0 < np.linalg.norm(got) < np.linalg.norm(ref.near_noise(n, 1.1 * math.sqrt(2 * 0.8), 555))
 
@@ -200,3 +217,31 @@ def test_euler_maruyama_pse_step_matches_oracle(hip, o32):
     Kf = np.asarray(K, np.float32).reshape(-1)
     o32.lib.oracle_bdhi_euler_maruyama(_p(p), None, _p(MF), None, _p(Kf), n, C.c_float(0.0), C.c_float(dt), 0)
     assert np.abs(got - p).max() <= 1e-5 * np.abs(p - pos).max() + 1e-6
+
+
+def test_lazy_list_follows_position_writes(hip, o32):
+    """CellList::update rebuilds only after a position write (CellList.cuh:94-98,134-136): the PSE class wires ParticleData's write
+    signal to uammd_pse_near_positions_changed.  Moving the particles through the ParticleData interface must be seen by the next
+    product; a second product without a write reuses the list and gives the same bits."""
+    L, n, tol, psi = 20.0, 3000, 1e-3, 0.6
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    rng = np.random.default_rng(12)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+
+    def product():
+        MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+        return MF.cpu().numpy()
+    a = product()
+    assert np.array_equal(product(), a)
+    pos2 = pos.copy()
+    pos2[:, :3] = np.random.default_rng(99).uniform(-L / 2, L / 2, (n, 3))
+    pd.getPos("write").copy_(torch.from_numpy(pos2).cuda())              # same array, new contents: the signal invalidates the list
+    b = product()
+    expect = np.zeros((n, 3), np.float32)
+    ref.near_mdot(pos2, f4, expect)
+    assert np.abs(b - expect).max() <= 1e-6 * np.abs(expect).max() and not np.allclose(a, b)

@@ -404,6 +404,11 @@ class PSE:
                                              float(par.psi), float(par.shearStrain), seed_near, C.byref(h), C.byref(rc),
                                              C.byref(npts)))
         self.near, self.rcut, self.nPointsTable = h, float(rc.value), int(npts.value)
+        # CellList::update rebuilds only after a position write or a reorder (CellList.cuh:94-98,134-136): one build per step, not one
+        # per near-field call
+        check(self.lib.uammd_pse_near_set_option(self.near, b"lazy_list", 1))
+        pd.connectPosWrite(self._positions_changed)
+        pd.connectReorder(self._positions_changed)
         seed_far = pd.rng.next32()
         raw = i3(0)
         check(self.lib.uammd_pse_far_raw_cells(f3(L), float(par.psi), float(par.tolerance), raw))
@@ -425,6 +430,10 @@ class PSE:
                 self.far = None
         except Exception:
             pass
+
+    def _positions_changed(self, *a):
+        if getattr(self, "near", None):
+            self.lib.uammd_pse_near_positions_changed(self.near)
 
     def setup_step(self):
         pass

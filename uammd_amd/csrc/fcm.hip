@@ -52,6 +52,7 @@ struct FCM {
   DeviceBuffer gridBuf, gridBufT, interBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
   bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
   int3 ntiles{0, 0, 0};
+  int3 tdim{8, 8, 8};      // tile edge per axis, 4..8 nodes: the largest divisor of the axis that holds the stencil's reach (fcm_tiles_usable)
   int prepCapN = 0;
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
   hipStream_t prepStream = nullptr;  // ... an ordering that only holds within one stream: a call on another stream waits for this one first
@@ -160,6 +161,7 @@ struct FcmPrep {
   int *tileCount;   // int[ntiles]
   int *tileStart;   // int[ntiles+1]
   int wstride;
+  int3 tdim;        // tile edge per axis (<= kTile: the kernels' layouts are sized for kTile, shorter tiles leave rows / columns unused)
 };
 
 __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict__ pos, int N, GridT<float> grid,
@@ -168,7 +170,7 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
   if (id >= N) return;
   const float4 p4 = pos[id];
   const int3 celli = grid.getCell(real3f{p4.x, p4.y, p4.z});
-  const int t = (celli.x / kTile) + ntiles.x * ((celli.y / kTile) + ntiles.y * (celli.z / kTile));
+  const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
   pr.tileOf[id] = t;
   pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
 }
@@ -244,8 +246,8 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   // [-16, 7], biased by 16, five bits per axis): one 16-byte load per candidate, no image arithmetic (a neighbour tile's frame is
   // +-kTile away whatever the wrap)
   float4 fr = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int rel = (ox - (celli.x / kTile) * kTile + 16) | (oy - (celli.y / kTile) * kTile + 16) << 5 |
-                  (oz - (celli.z / kTile) * kTile + 16) << 10;
+  const int rel = (ox - (celli.x / pr.tdim.x) * pr.tdim.x + 16) | (oy - (celli.y / pr.tdim.y) * pr.tdim.y + 16) << 5 |
+                  (oz - (celli.z / pr.tdim.z) * pr.tdim.z + 16) << 10;
   fr.w = __int_as_float(rel);
   pr.force[slot] = fr;
   float *w = pr.weights + (size_t)pr.wstride * slot;
@@ -284,9 +286,9 @@ static size_t spread_lds_bytes(int weightWords) {
   const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * 4 * 3 * kTile * kTile * kTile;
   return a > b ? a : b;
 }
-static int spread_weight_words(int N, int3 ntiles, int3 support) {
+static int spread_weight_words(int N, int3 ntiles, int3 support, int3 tdim) {
   const double perTile = (double)N / ((double)ntiles.x * ntiles.y * ntiles.z);
-  const double listed = perTile * (1.0 + (support.x - 1) / (double)kTile) * (1.0 + (support.y - 1) / (double)kTile) * (1.0 + (support.z - 1) / (double)kTile);
+  const double listed = perTile * (1.0 + (support.x - 1) / (double)tdim.x) * (1.0 + (support.y - 1) / (double)tdim.y) * (1.0 + (support.z - 1) / (double)tdim.z);
   return listed > 64.0 ? kSpWeightWordsMax : kSpWeightWordsMax / 2;
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
@@ -310,7 +312,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int bX = l32 & 7, bY = l32 >> 3;              // B operand column xy = l32 (+ 32 for the second MFMA: y + 4)
   const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
-  const int x0 = tx * kTile, y0 = ty * kTile, z0 = tz * kTile;
+  const int3 td = pr.tdim;
+  const int x0 = tx * td.x, y0 = ty * td.y, z0 = tz * td.z;
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
   const int wpad = wstride + 2 * kSpZPad;  // LDS words per listed particle
@@ -325,8 +328,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     const int t = ux + ntiles.x * (uy + ntiles.y * uz);
     const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
     rStart[nb] = s;
-    // a record's origin is relative to its own tile: in this tile's frame that is + kTile per tile step (and - the bias)
-    rShift[3 * nb] = kTile * dx - 16; rShift[3 * nb + 1] = kTile * dy - 16; rShift[3 * nb + 2] = kTile * dz - 16;
+    // a record's origin is relative to its own tile: in this tile's frame that is + one tile edge per tile step (and - the bias)
+    rShift[3 * nb] = td.x * dx - 16; rShift[3 * nb + 1] = td.y * dy - 16; rShift[3 * nb + 2] = td.z * dz - 16;
     // inclusive scan of the 27 range lengths inside wave 0
     int incl = e - s;
 #pragma unroll
@@ -421,8 +424,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     for (int u = 0; u < kSpPerThread; ++u) {
       const int rel = __float_as_int(frc[u].w);
       org[u].x += rel & 31; org[u].y += (rel >> 5) & 31; org[u].z += (rel >> 10) & 31;
-      accept[u] = live[u] && org[u].x < kTile && org[u].x + sx > 0 && org[u].y < kTile && org[u].y + sy > 0 &&
-                  org[u].z < kTile && org[u].z + sz > 0;
+      accept[u] = live[u] && org[u].x < td.x && org[u].x + sx > 0 && org[u].y < td.y && org[u].y + sy > 0 &&
+                  org[u].z < td.z && org[u].z + sz > 0;
       m[u] = __ballot(accept[u]);
       if (lane == 0) waveCnt[4 * u + wave] = __popcll(m[u]);
     }
@@ -462,6 +465,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   __syncthreads();
   for (int i = threadIdx.x; i < T3; i += 256) {
     const int lx = i % kTile, ly = (i / kTile) % kTile, lz = i / (kTile * kTile);
+    if (lx >= td.x || ly >= td.y || lz >= td.z) continue;  // (a tile edge shorter than the layout's 8: those rows belong to a neighbour)
     const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * (size_t)(y0 + ly) + zstride * (size_t)(z0 + lz);
     g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
     g0[plane + node] = (acc[T3 + i] + acc[4 * T3 + i]) + (acc[7 * T3 + i] + acc[10 * T3 + i]);
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(256) k_fcm_gather_tile(float *__restrict__ vou
   const int first = pr.tileStart[tile], last = pr.tileStart[tile + 1];
   if (first == last) return;  // the whole workgroup leaves: no particle interpolates from this window
   const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
-  const int wx0 = tx * kTile - 4, wy0 = ty * kTile - 4, wz0 = tz * kTile - 4;  // window origin, unwrapped
+  const int wx0 = tx * pr.tdim.x - 4, wy0 = ty * pr.tdim.y - 4, wz0 = tz * pr.tdim.z - 4;  // window origin, unwrapped
   for (int e = threadIdx.x; e < 3 * kGW * kGW * (kGW / 2); e += 256) {
     const int q = e & 7, row = e >> 3;
     const int y = row & 15, z = (row >> 4) & 15, c = row >> 8;
@@ -1062,7 +1066,7 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   }
   FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
              (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
-             (int *)f->prepTileStart.ptr, wstride};
+             (int *)f->prepTileStart.ptr, wstride, f->tdim};
   if (f->prepStreamSet && f->prepStream != st) {  // the handle's buffers (and the zeroed counters) are ordered by the stream of the last call
     UH_CHECK(hipStreamSynchronize(f->prepStream));
     f->tileCountZero = false;
@@ -1093,9 +1097,19 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
 
 // tile-owned spreading is possible when the grid is a whole number (>= 3) of tiles per axis and a stencil only
 // reaches the adjacent tiles
-static bool fcm_tiles_usable(const int cells[3], const int support[3]) {
-  for (int a = 0; a < 3; ++a)
-    if (cells[a] % kTile != 0 || cells[a] / kTile < 3 || support[a] > 2 * (kTile - 1)) return false;
+// (a particle is binned by ITS cell and its stencil reaches support / 2 (+ 1 with the shift of even supports) nodes either way: it stays
+// within the adjacent tiles when support <= 2 (T - 1)).  The tile edge T is chosen per axis: the largest divisor of the axis in 4..8
+// that satisfies this — 8 for power-of-two grids, 6 for the 108^3 grid of the PSE far field at psi = 0.5, 5 for 100, 7 for 84.  The
+// kernels' LDS / matrix layouts are sized for 8; a shorter tile leaves rows and columns unused (and unwritten).
+static bool fcm_tiles_usable(const int cells[3], const int support[3], int3 *tdim, bool only8 = false) {
+  int T[3];
+  for (int a = 0; a < 3; ++a) {
+    T[a] = 0;
+    for (int t = kTile; t >= (only8 ? kTile : 4); --t)
+      if (cells[a] % t == 0 && cells[a] / t >= 3 && support[a] <= 2 * (t - 1)) { T[a] = t; break; }
+    if (!T[a]) return false;
+  }
+  *tdim = make_int3(T[0], T[1], T[2]);
   return true;
 }
 
@@ -1211,8 +1225,8 @@ int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
   f->planeReal = (size_t)f->nxpad * par->cells[1] * par->cells[2];
   f->planeCplx = f->planeReal / 2;
   if (int e = f->gridBuf.reserve(sizeof(float) * 3 * f->planeReal)) { delete f; return e; }
-  f->useTiles = fcm_tiles_usable(par->cells, par->kernel.support);
-  f->ntiles = make_int3(par->cells[0] / kTile, par->cells[1] / kTile, par->cells[2] / kTile);
+  f->useTiles = fcm_tiles_usable(par->cells, par->kernel.support, &f->tdim);
+  f->ntiles = make_int3(par->cells[0] / f->tdim.x, par->cells[1] / f->tdim.y, par->cells[2] / f->tdim.z);
   if (int e = fcm_make_plans(f)) { delete f; return e; }
   *out = reinterpret_cast<uammd_fcm *>(f);
   return 0;
@@ -1267,7 +1281,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   if (d_force) {
     if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      const int ww = spread_weight_words(N, f->ntiles, f->kern.support);
+      const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
       hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
                          zs, f->kern.support, f->ntiles, pr, ww);
     } else {
@@ -1381,8 +1395,8 @@ int uammd_fcm_slab_create(const uammd_fcm_parameters *par, int nzLocal, int z0, 
   f->kern = to_dev(par->kernel);
   f->nxpad = 2 * s->nkx;
   f->planeReal = (size_t)f->nxpad * lc[1];  // component stride of the interleaved-plane layout
-  f->useTiles = fcm_tiles_usable(lc, par->kernel.support);
-  f->ntiles = make_int3(lc[0] / kTile, lc[1] / kTile, lc[2] / kTile);
+  f->useTiles = fcm_tiles_usable(lc, par->kernel.support, &f->tdim, true);  // (the slab window's halo is a whole number of 8-node tiles)
+  f->ntiles = make_int3(lc[0] / f->tdim.x, lc[1] / f->tdim.y, lc[2] / f->tdim.z);
   if (int e = fcm_slab_make_plans(s)) { delete s; return e; }
   *out = reinterpret_cast<uammd_fcm_slab *>(s);
   return 0;
@@ -1419,7 +1433,7 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
     if (int e = fcm_prepare_tiles(f, d_posLocal, d_force, N, st, &pr)) return e;
     if (d_force) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      const int ww = spread_weight_words(N, f->ntiles, f->kern.support);
+      const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
       hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
                          f->kern.support, f->ntiles, pr, ww);
     }
@@ -1449,7 +1463,7 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
     if (f->prepCapN < N) { set_last_error("uammd_fcm_slab_gather: call uammd_fcm_slab_spread with these positions first"); return -3; }
     FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr,
                (int *)f->prepTileOf.ptr, (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr,
-               (int *)f->prepTileStart.ptr, f->kern.support.x + f->kern.support.y + f->kern.support.z};
+               (int *)f->prepTileStart.ptr, f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim};
     if (f->kern.support.x <= 6 && f->kern.support.y <= 6 && f->kern.support.z <= 6 && f->tileGather)
       hipLaunchKernelGGL(k_fcm_gather_tile, dim3(f->ntiles.x * f->ntiles.y * f->ntiles.z), dim3(256), 0, st, d_vel, d_grid,
                          f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, f->grid.cellVolume, dsx, dsxy,
@@ -1573,7 +1587,7 @@ int uammd_fcm_slab_gather_inter(uammd_fcm_slab *h, const float *d_posLocal, int 
   const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
   FcmPrep pr{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, (float4 *)f->prepSorted.ptr, (int *)f->prepTileOf.ptr,
              (int *)f->prepRank.ptr, (int *)f->prepTileCount.ptr, (int *)f->prepTileStart.ptr,
-             f->kern.support.x + f->kern.support.y + f->kern.support.z};
+             f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim};
   launch_gather_inter((hipStream_t)stream, d_vel, (const float4 *)d_inter, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx,
                       dsxy, pr, f->accumulate);
   UH_CHECK(hipGetLastError());

@@ -29,6 +29,12 @@ struct PSENear {
   unsigned int seed = 0;
   int N = 0;
   hipStream_t cbStream = 0;
+  bool exactOrder = false;  // option "exact_order": the thread-per-particle walk (the reference's summation order, bit for bit)
+  // option "lazy_list": like CellList::update (CellList.cuh:134-136,192-204) the list is rebuilt only after the positions were
+  // written (uammd_pse_near_positions_changed, wired to ParticleData's write signal by the host layer) or when the array / N changes
+  bool lazyList = false, listValid = false;
+  const void *listPos = nullptr;
+  DeviceBuffer sortedOut;   // Lanczos result in cell order
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
   }
@@ -177,6 +183,145 @@ __global__ void __launch_bounds__(128) k_pse_near(const float4 *__restrict__ sor
   o[0] += tx; o[1] += ty; o[2] += tz;
 }
 
+// ---- AUTO: eight lanes per sorted particle --------------------------------------------------------------------------------------
+// The thread-per-particle walk above is one dependent chain of ~200 candidates (load, sheared image, compare, and for a hit a square
+// root, two dependent table reads and a 3 x 3 product) on 1.5 waves per SIMD at N = 1e5: 201 us per product, latency from end to end.
+// Here a group of 8 lanes shares a particle.  Scan: the 27 (first, last) ranges are fetched up front (lane q of the group takes cells
+// q, q + 8, ...), then the group tests 8 candidates per step with a cheap SUPERSET test (reciprocal multiplications instead of the
+// reference's divisions, 1e-5 of slack) and appends the hits, in the reference's visiting order, to the group's list in LDS (wave ballot,
+// the group's byte of the mask).  Drain: lane k evaluates hits k, k + 8, ... exactly as the reference does (sheared_distance with its
+// divisions and roundf, `r2 >= rcut2 -> nothing`, the same table arithmetic), so the SAME pairs contribute the SAME terms; the eight
+// partial sums meet in a 3-step butterfly.  Another summation order: results agree with the walk to rounding (tests: 1e-6 of max|Mv|).
+constexpr int kNearGroup = 8, kNearBlock = 256, kNearCap = 96;  // hits a group can hold before it drains (12 KB of LDS per workgroup)
+
+template <bool SHEAR>
+UH_D float scan_distance2(const float4 &pi, const float4 &pj, real3f L, real3f invL, float shear) {
+  float x = pj.x - pi.x, y = pj.y - pi.y, z = pj.z - pi.z;
+  if (SHEAR) x = fmaf(shear, y, x);
+  const float s1 = __builtin_rintf(y * invL.y);
+  if (SHEAR) x = fmaf(-(shear * L.y), s1, x);
+  y = fmaf(-L.y, s1, y);
+  z = fmaf(-L.z, __builtin_rintf(z * invL.z), z);
+  x = fmaf(-L.x, __builtin_rintf(x * invL.x), x);
+  return fmaf(z, z, fmaf(y, y, x * x));
+}
+
+template <int VSTRIDE, bool INDIRECT, bool ACCUM, bool SHEAR>
+__global__ void __launch_bounds__(kNearBlock) k_pse_near8(const float4 *__restrict__ sortPos, const float *__restrict__ v,
+                                                           const int *__restrict__ groupIndex, const uint *__restrict__ cellStart,
+                                                           const int *__restrict__ cellEnd, uint validCell, int N, GridT<float> grid,
+                                                           real3f L, float shear, float rcut2, TableView tab, float *__restrict__ Mv) {
+  __shared__ int hitList[kNearBlock / kNearGroup][kNearCap];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & (kNearGroup - 1), gbase = lane & ~(kNearGroup - 1);
+  const int grp = threadIdx.x / kNearGroup;
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * (kNearBlock / kNearGroup) + grp;
+  const bool active = id < N;
+  const float4 pi = sortPos[active ? id : 0];
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  const real3f invL{1.0f / L.x, 1.0f / L.y, 1.0f / L.z};
+  const float rcut2s = rcut2 * 1.00001f + 1e-30f;
+  // ranges of the neighbour cells, four per lane
+  int first4[4], last4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = sub + kNearGroup * q;
+    first4[q] = 0; last4[q] = 0;
+    if (active && cc < numberNeighbourCells) {
+      int3 cellj = celli;
+      if (npx > 1) cellj.x += cc % 3 - 1;
+      if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+      if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+      cellj.x = grid.pbc_x(cellj.x);
+      cellj.y = grid.pbc_y(cellj.y);
+      cellj.z = grid.pbc_z(cellj.z);
+      if (!(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z)) {
+        const int icellj = grid.getCellIndex(cellj);
+        const uint cs = cellStart[icellj];
+        if (cs >= validCell) { first4[q] = (int)(cs - validCell); last4[q] = cellEnd[icellj]; }
+      }
+    }
+  }
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  int cnt = 0;  // hits in this group's list (the same number in its eight lanes)
+  auto drain = [&]() {
+    for (int k = sub; k < cnt; k += kNearGroup) {
+      const int j = hitList[grp][k];
+      const real3f rij = sheared_distance(pi, sortPos[j], L, shear);
+      const float r2 = dot3(rij, rij);
+      if (r2 >= rcut2) continue;  // (the scan's test is a superset)
+      const float *vp = v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j);
+      const float vx = vp[0], vy = vp[1], vz = vp[2];
+      const float2 fg = table_get(tab, sqrtf(r2));
+      const float f = fg.x, g = fg.y;
+      float rx, ry, rz;
+      if (r2 == 0.0f) {
+        rx = f * vx; ry = f * vy; rz = f * vz;
+      } else {
+        const float invr2 = 1.0f / r2;
+        const float gmfv = (g - f) * dot3(rij, real3f{vx, vy, vz}) * invr2;
+        rx = fmaf(gmfv, rij.x, f * vx);
+        ry = fmaf(gmfv, rij.y, f * vy);
+        rz = fmaf(gmfv, rij.z, f * vz);
+      }
+      tx += rx; ty += ry; tz += rz;
+    }
+    cnt = 0;
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int r = 0; r < kNearGroup; ++r) {
+      if (kNearGroup * q + r >= numberNeighbourCells) break;  // (uniform over the grid)
+      const int first = __shfl(first4[q], gbase + r, 64), last = __shfl(last4[q], gbase + r, 64);
+      for (int j0 = first; __any(j0 < last); j0 += kNearGroup) {
+        if (__any(cnt > kNearCap - kNearGroup)) drain();  // (wave-uniform; lists that still have room are drained early, harmless)
+        const int j = j0 + sub;
+        bool hit = false;
+        if (j < last) hit = scan_distance2<SHEAR>(pi, sortPos[j], L, invL, shear) < rcut2s;
+        const unsigned long long m = __ballot(hit);
+        const uint mine = (uint)(m >> gbase) & 0xffu;
+        if (hit) hitList[grp][cnt + __popc(mine & ((1u << sub) - 1u))] = j;
+        cnt += __popc(mine);
+      }
+    }
+  }
+  drain();
+#pragma unroll
+  for (int o = 1; o < kNearGroup; o <<= 1) {
+    tx += __shfl_xor(tx, o, 64);
+    ty += __shfl_xor(ty, o, 64);
+    tz += __shfl_xor(tz, o, 64);
+  }
+  if (active && sub == 0) {
+    float *o = Mv + 3 * (size_t)(INDIRECT ? groupIndex[id] : id);
+    if (ACCUM) { o[0] += tx; o[1] += ty; o[2] += tz; }
+    else { o[0] = tx; o[1] = ty; o[2] = tz; }
+  }
+}
+
+// the Lanczos iteration runs in CELL order (dot products and norms do not care; the product then reads v_j next to pos_j and needs
+// neither a gather of v nor a memset of Mv): noise of particle index[k] at slot k, and the result scattered back at the end
+__global__ void __launch_bounds__(256) k_pse_noise_sorted(float *__restrict__ out3, const int *__restrict__ groupIndex, int N,
+                                                           float variance, uint seed1, uint seed2) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  Saru rng((uint)groupIndex[k], seed1, seed2);
+  const float2 a = rng.gf(0.0f, 1.0f);
+  const float2 b = rng.gf(0.0f, 1.0f);
+  out3[3 * (size_t)k] = a.x * variance;
+  out3[3 * (size_t)k + 1] = a.y * variance;
+  out3[3 * (size_t)k + 2] = b.x * variance;
+}
+__global__ void __launch_bounds__(256) k_pse_unsort3(const float *__restrict__ in3, const int *__restrict__ groupIndex, int N,
+                                                      float *__restrict__ out3) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  float *o = out3 + 3 * (size_t)groupIndex[k];
+  o[0] = in3[3 * (size_t)k]; o[1] = in3[3 * (size_t)k + 1]; o[2] = in3[3 * (size_t)k + 2];
+}
+
 // SaruTransform (NearField.cuh:218-228): make_real3(gf(0,1), gf(0,1).x) * variance
 __global__ void __launch_bounds__(256) k_pse_noise(float *__restrict__ out3, int N, float variance, uint seed1, uint seed2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -201,6 +346,9 @@ static TableView make_view(const PSENear *p) {
 
 // cl->update(box, rcut * safetyFactor) (NearField.cuh:231-237)
 static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st) {
+  if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N) return 0;
+  p->listValid = true;
+  p->listPos = d_pos;
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
   const float rc = p->rcut * safety;
@@ -213,26 +361,54 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   return p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st);
 }
 
-template <int VSTRIDE>
+#define UH_NEAR8(VS, IND, ACC)                                                                                                       \
+  do {                                                                                                                               \
+    const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));                                                    \
+    if (p->shear != 0.0f)                                                                                                            \
+      hipLaunchKernelGGL((k_pse_near8<VS, IND, ACC, true>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr, d_v,     \
+                         (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr,            \
+                         p->cl.validCell, N, p->cl.grid, Lb, p->shear, p->rcut * p->rcut, make_view(p), d_Mv);                       \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((k_pse_near8<VS, IND, ACC, false>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr, d_v,    \
+                         (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr,            \
+                         p->cl.validCell, N, p->cl.grid, Lb, p->shear, p->rcut * p->rcut, make_view(p), d_Mv);                       \
+  } while (0)
+
+// d_Mv (+)= M_near v with v and Mv in the caller's particle order (stride VSTRIDE / 3)
+template <int VSTRIDE, bool ACCUM>
 static int pse_dot(PSENear *p, const float *d_v, float *d_Mv, hipStream_t st) {
   const int N = p->N;
+  const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
+  if (!p->exactOrder) {
+    UH_NEAR8(VSTRIDE, true, ACCUM);
+    UH_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (!ACCUM) UH_CHECK(hipMemsetAsync(d_Mv, 0, sizeof(float) * 3 * (size_t)N, st));
   if (int e = p->sortV.reserve(sizeof(float4) * (size_t)N)) return e;
   hipLaunchKernelGGL((k_pse_gather_v<VSTRIDE>), dim3((N + 255) / 256), dim3(256), 0, st, d_v, (const int *)p->cl.index.ptr,
                      (float4 *)p->sortV.ptr, N);
   hipLaunchKernelGGL(k_pse_near, dim3((N + 127) / 128), dim3(128), 0, st, (const float4 *)p->cl.sortPos.ptr,
                      (const float4 *)p->sortV.ptr, (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr,
-                     (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, real3f{p->boxL[0], p->boxL[1], p->boxL[2]},
-                     p->shear, p->rcut * p->rcut, make_view(p), d_Mv);
+                     (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb, p->shear, p->rcut * p->rcut, make_view(p), d_Mv);
   UH_CHECK(hipGetLastError());
   return 0;
 }
 
-// pse_ns::Dotctor (NearField.cuh:201-216): Mv = 0; cl->transverseList(Mv_tr)
+// pse_ns::Dotctor (NearField.cuh:201-216): Mv = 0; cl->transverseList(Mv_tr) — caller's particle order
 static int pse_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) {
+  (void)n;
+  return pse_dot<3, false>(static_cast<PSENear *>(ctx), d_v, d_Mv, (hipStream_t)stream);
+}
+// the same product on vectors held in CELL order (the default path of computeStochasticDisplacements)
+static int pse_lanczos_dot_sorted(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) {
+  (void)n;
   PSENear *p = static_cast<PSENear *>(ctx);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(d_Mv, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return -1;
-  return pse_dot<3>(p, d_v, d_Mv, st);
+  const int N = p->N;
+  const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
+  UH_NEAR8(3, false, false);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ---- BDHI::Lanczos: dense open-boundary RPY mobility, matrix free (Integrator/BDHI/BDHI_Lanczos.cu:56-118, BDHI.cuh:27-96) ----
@@ -369,6 +545,24 @@ int uammd_pse_near_destroy(uammd_pse_near *h) {
 int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain) {
   if (!h) { set_last_error("uammd_pse_near_set_shear_strain: null handle"); return -1; }
   reinterpret_cast<PSENear *>(h)->shear = shearStrain;
+  reinterpret_cast<PSENear *>(h)->listValid = false;  // (the list's cut-off carries the shear's safety factor)
+  return 0;
+}
+
+// "exact_order" (0): 1 = the thread-per-particle walk in the reference's summation order instead of the eight-lanes-per-particle kernel.
+// "lazy_list" (0): 1 = rebuild the cell list only after uammd_pse_near_positions_changed (CellList::update's needsRebuild,
+// NeighbourList/CellList.cuh:134-136,192-204) or when the position array / particle count of the call changes.
+int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_pse_near_set_option: null argument"); return -1; }
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
+  if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
+  set_last_error("uammd_pse_near_set_option: unknown option %s", name);
+  return -1;
+}
+int uammd_pse_near_positions_changed(uammd_pse_near *h) {
+  if (!h) { set_last_error("uammd_pse_near_positions_changed: null handle"); return -1; }
+  reinterpret_cast<PSENear *>(h)->listValid = false;
   return 0;
 }
 
@@ -378,7 +572,7 @@ int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_fo
   if (!d_force || N <= 0) return 0;
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (int e = pse_update_list(p, d_pos, N, (hipStream_t)stream)) return e;
-  return pse_dot<4>(p, d_force, d_MF, (hipStream_t)stream);
+  return pse_dot<4, true>(p, d_force, d_MF, (hipStream_t)stream);
 }
 
 // NearField::computeStochasticDisplacements (NearField.cuh:252-285): d_BdW real3[N] = prefactor sqrt(2 T) M_near^(1/2) dW
@@ -393,14 +587,28 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   if (int e = pse_update_list(p, d_pos, N, st)) return e;
   if (int e = p->noise.reserve(sizeof(float) * 3 * (size_t)N)) return e;
   const float noise_prefactor = prefactor * sqrtf(2 * temperature);
-  hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
-                     seed2);
-  UH_CHECK(hipGetLastError());
   int it = 0;
-  const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot, p, d_BdW, (const float *)p->noise.ptr, p->tolerance, 3 * N,
-                                   stream, &it);
+  if (p->exactOrder) {
+    hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
+                       seed2);
+    UH_CHECK(hipGetLastError());
+    const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot, p, d_BdW, (const float *)p->noise.ptr, p->tolerance, 3 * N,
+                                     stream, &it);
+    if (iterations) *iterations = it;
+    return rc;
+  }
+  if (int e = p->sortedOut.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+  hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
+                     noise_prefactor, p->seed, seed2);
+  UH_CHECK(hipGetLastError());
+  const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
+                                   p->tolerance, 3 * N, stream, &it);
   if (iterations) *iterations = it;
-  return rc;
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pse_unsort3, dim3((N + 255) / 256), dim3(256), 0, st, (const float *)p->sortedOut.ptr, (const int *)p->cl.index.ptr, N,
+                     d_BdW);
+  UH_CHECK(hipGetLastError());
+  return 0;
 }
 
 // test hook: the Saru noise vector of computeStochasticDisplacements (real3[N])
