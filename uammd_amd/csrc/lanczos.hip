@@ -18,13 +18,17 @@
 // V_m y is a bandwidth-bound streaming kernel (N x m floats read once) — MFMA would buy nothing for one RHS.
 #include "celllist.hpp"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace uammd_hip {
 
 constexpr int kLB = 256;       // threads per block
 constexpr int kLParts = 256;   // reduction partials (one per block)
+constexpr int kLDevM = 32;     // Krylov sizes whose convergence check goes through the host-mapped block (k_l_publish)
 
 struct Lanczos {
   DeviceBuffer V, w, Bold, parts, scal, ycoef;
@@ -36,6 +40,12 @@ struct Lanczos {
   uammd_allreduce_fn reduce = nullptr;
   void *reduceCtx = nullptr;
   bool ownsFirstElement = true;  // the rank that holds global element 0 (the breakdown fallback w = e1)
+  // convergence checks without stream synchronisation: the check kernels leave {sequence number, error} in host-mapped memory and the
+  // host spins on the sequence number (a hipStreamSynchronize + two small copies cost ~25 us each, four checks per run at the PSE size)
+  volatile float *hostStat = nullptr;
+  float *devStat = nullptr;
+  unsigned seq = 0;
+  ~Lanczos() { if (hostStat) (void)hipHostFree((void *)hostStat); }
 };
 
 UH_D float block_sum(float x, float *sh) {
@@ -156,6 +166,45 @@ __global__ void __launch_bounds__(kLB) k_l_estimate(const float *__restrict__ V,
   if (threadIdx.x == 0) parts[blockIdx.x] = ta;
   const float tb = block_sum(b, sh);
   if (threadIdx.x == 0) parts[kLParts + blockIdx.x] = tb;
+}
+
+// Convergence checks without a stream synchronisation.  hdiag / hsup are a few floats: k_l_publish copies them into host-mapped memory
+// behind a sequence number; the host (spinning on that number) solves the m x m tridiagonal problem in double — microseconds there, 30-60 us
+// for one GPU thread (a QL step is ~100 dependent double operations with a square root and two divisions) — and writes the m coefficients
+// of H^(1/2) e1 back into mapped memory behind a second sequence number, which an ALREADY QUEUED one-thread relay kernel polls before the estimate
+// reads them: the GPU never waits for a launch.  (The poll is bounded: a host that never answers makes the kernel give up with an error flag.)
+// mapped block (floats): [0] seqA (scalars published)  [1] seqB (error published)  [2] err  [3] status  [4] seqY (host: y ready)
+//                        [8 .. 8+32) y   [64 .. 64+32) hdiag   [96 .. 96+32) hsup
+__global__ void k_l_publish(const float *__restrict__ hdiag, const float *__restrict__ hsup, int m, volatile float *__restrict__ stat, float seq) {
+  const int k = threadIdx.x;
+  if (k < m) { stat[64 + k] = hdiag[k]; stat[96 + k] = hsup[k]; }
+  __threadfence_system();
+  __syncthreads();
+  if (k == 0) stat[0] = seq;
+}
+// ONE thread waits for the host's coefficients and hands them to device memory (256 workgroups polling host memory over the bus at once
+// delayed the very write they were waiting for: 146 us per check)
+__global__ void k_l_relay(volatile float *__restrict__ stat, int m, float seq, float *__restrict__ ycoef) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    while (stat[4] != seq && ++spins < 20000000L) __builtin_amdgcn_s_sleep(8);
+    ok = stat[4] == seq;
+    if (!ok) stat[3] = -1.0f;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m) ycoef[threadIdx.x] = ok ? stat[8 + threadIdx.x] : 0.0f;
+}
+// err = |Bz - Bold| / |Bold| from the estimate's partials, left with a sequence number where the host can see it
+__global__ void __launch_bounds__(kLB) k_l_error(const float *__restrict__ parts, int nparts, float *__restrict__ stat, float seq) {
+  __shared__ float sh[16];
+  const float a = sum_parts(parts, nparts, sh);
+  const float b = sum_parts(parts + kLParts, nparts, sh);
+  if (threadIdx.x == 0) {
+    stat[2] = fabsf(sqrtf(b) / sqrtf(a));
+    __threadfence_system();
+    stat[1] = seq;
+  }
 }
 
 // Symmetric tridiagonal eigenproblem by implicit QL with eigenvector accumulation; d (diag, size m) returns the
@@ -291,7 +340,73 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
     if (int rc = complete(parts + kLParts)) return rc;
     hipLaunchKernelGGL(k_l_c, dim3(g), dim3(kLB), 0, st, (const float *)w, n, (const float *)(parts + kLParts), np,
                        (const float *)(hdiag + i), (const float *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
-    if (i >= checkConvergenceSteps) {
+    if (i >= checkConvergenceSteps && !L->reduce && i + 1 <= kLDevM) {
+      const int m = i + 1;
+      if (!L->hostStat) {
+        UH_CHECK(hipHostMalloc((void **)&L->hostStat, 1024, hipHostMallocMapped | hipHostMallocCoherent));
+        for (int k = 0; k < 256; ++k) L->hostStat[k] = 0.f;
+        UH_CHECK(hipHostGetDevicePointer((void **)&L->devStat, (void *)L->hostStat, 0));
+      }
+      L->seq = (L->seq % 1000000u) + 1u;
+      const float seq = (float)L->seq;
+      volatile float *hs = L->hostStat;
+      hs[3] = 0.f;
+      hipLaunchKernelGGL(k_l_publish, dim3(1), dim3(64), 0, st, (const float *)hdiag, (const float *)hsup, m, L->devStat, seq);
+      hipLaunchKernelGGL(k_l_relay, dim3(1), dim3(64), 0, st, L->devStat, m, seq, ycoef);
+      hipLaunchKernelGGL(k_l_estimate, dim3(g), dim3(kLB), 0, st, (const float *)V, n, m, (const float *)ycoef,
+                         (const float *)scal, d_Bv, Bold, parts);
+      hipLaunchKernelGGL(k_l_error, dim3(1), dim3(kLB), 0, st, (const float *)parts, g, L->devStat, seq);
+      auto wait = [&](int slot) -> int {
+        long spins = 0;
+        while (hs[slot] != seq)
+          if (++spins > 400000000L) { set_last_error("[Lanczos] the convergence check never reported"); return -23; }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return 0;
+      };
+      const auto tA = std::chrono::steady_clock::now();
+      if (int e = wait(0)) return e;
+      const auto tB = std::chrono::steady_clock::now();
+      dd.assign(m, 0.0);
+      ee.assign(m, 0.0);
+      zz.assign((size_t)m * m, 0.0);
+      for (int k = 0; k < m; ++k) { dd[k] = hs[64 + k]; zz[(size_t)k * m + k] = 1.0; }
+      for (int k = 0; k + 1 < m; ++k) ee[k] = hs[96 + k];
+      const int info = tridiag_ql(dd, ee, zz, m);
+      for (int r = 0; r < m; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < m; ++j) acc += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
+        hs[8 + r] = (float)acc;
+      }
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      hs[4] = seq;   // the queued estimate kernel goes ahead (also after a failed diagonalisation: it must not be left waiting)
+      const auto tC = std::chrono::steady_clock::now();
+      if (int e = wait(1)) return e;
+      if (getenv("UAMMD_LANCZOS_DEBUG")) {
+        const auto tD = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[lanczos] i=%d wait scalars %.1f us, host QL %.1f us, wait error %.1f us\n", i, us(tA, tB), us(tB, tC), us(tC, tD));
+      }
+      if (info) {
+        set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
+        return -20;
+      }
+      if (hs[3] != 0.f) { set_last_error("[Lanczos] the estimate kernel gave up waiting for the host's coefficients"); return -23; }
+      if (i > 0) {
+        const float err = hs[2];
+        if (std::isnan(err)) {
+          set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
+          return -21;
+        }
+        if (err <= tolerance) {
+          L->lastRunRequiredSteps = i;
+          if (i - 2 > L->check_convergence_steps) L->check_convergence_steps += 1;
+          else L->check_convergence_steps = std::max(1, L->check_convergence_steps - 2);
+          if (iterations) *iterations = i;
+          UH_CHECK(hipGetLastError());
+          return 0;
+        }
+      }
+    } else if (i >= checkConvergenceSteps) {
       const int m = i + 1;
       UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(float) * (2 * cap + 1), hipMemcpyDeviceToHost, st));
       UH_CHECK(hipStreamSynchronize(st));

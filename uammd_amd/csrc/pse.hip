@@ -22,7 +22,9 @@ namespace uammd_hip {
 struct PSENear {
   CellList cl;
   uammd_lanczos *lanczos = nullptr;
-  DeviceBuffer table, sortV, noise;
+  DeviceBuffer table, table4, sortV, noise;
+  int nearKernel = 1;  // option "near_kernel": 1 = eight lanes per particle (k_pse_near8, default: 55 us at the bench size), 0 = wave per cell with
+                       // LDS-staged candidates (k_pse_near_cell: 73 us there — fewer loads, but latency bound at 3 waves per SIMD)
   int nPointsTable = 0;
   float rcut = 0.f, shear = 0.f, tolerance = 0.f;
   float boxL[3] = {0, 0, 0};
@@ -301,6 +303,153 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near8(const float4 *__restri
   }
 }
 
+// ---- AUTO where the table has its packed copy: one WAVE per cell, candidates staged in LDS ------------------------------------------------
+// k_pse_near8 still issues ~150 global load instructions per wave (a candidate load per scan step, position + v + two table reads per
+// hit) and every 64-lane load costs the CU's one address unit ~16 clocks whatever it fetches: 59 us at N = 1e5.  All particles of a cell
+// see the SAME 27 cells, so here a wave owns a cell: it fetches the 27 ranges (lanes 0..26), builds their prefix sum with shuffles,
+// stages the ~200 candidates' positions and v ONCE (four 16-byte requests per lane: flat candidate index -> cell by binary search in
+// the LDS prefix table) and then works from LDS — groups of 8 lanes take one owner each (passes of 8 owners), scan with the cheap
+// superset test, compact the hits per group (ballot), and evaluate them exactly as the reference does; the only global reads of the
+// drain are the table's, one 16-byte request per hit from a copy that holds {F_i, G_i, F_i+1, G_i+1} per entry.  Chunks of kCellCap
+// candidates for crowded neighbourhoods.  Same pairs, same per-pair arithmetic, another summation order.
+constexpr int kCellCap = 256;   // candidates staged per chunk (a hit is stored as one byte)
+struct CellWaveLds {
+  float4 pos[kCellCap];
+  float vel[3 * kCellCap];
+  unsigned char hits[kNearGroup][kCellCap];
+  int pre[28], first[28];
+};
+
+template <int VSTRIDE, bool INDIRECT, bool ACCUM, bool SHEAR>
+__global__ void __launch_bounds__(256) k_pse_near_cell(const float4 *__restrict__ sortPos, const float *__restrict__ v,
+                                                        const int *__restrict__ groupIndex, const uint *__restrict__ cellStart,
+                                                        const int *__restrict__ cellEnd, uint validCell, int ncells, GridT<float> grid,
+                                                        real3f L, float shear, float rcut2, TableView tab, const float4 *__restrict__ table4,
+                                                        float *__restrict__ Mv, int ablate) {
+  __shared__ CellWaveLds lds[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (kNearGroup - 1), grp = lane / kNearGroup, gbase = lane & ~(kNearGroup - 1);
+  CellWaveLds &sh = lds[wave];
+  const int c = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wave;
+  if (c >= ncells) return;  // (waves of a workgroup are independent: no workgroup barrier anywhere)
+  const uint cs0 = cellStart[c];
+  if (cs0 < validCell) return;
+  const int o0 = (int)(cs0 - validCell), o1 = cellEnd[c];
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int3 celli = make_int3(c % n.x, (c / n.x) % n.y, c / (n.x * n.y));
+  // the 27 ranges in the reference's visiting order (x fastest) and their prefix sum
+  int first = 0, count = 0;
+  if (lane < numberNeighbourCells) {
+    int3 cellj = celli;
+    if (npx > 1) cellj.x += lane % 3 - 1;
+    if (npy > 1) cellj.y += (lane / npx) % 3 - 1;
+    if (npz > 1) cellj.z += lane / (npx * npy) - 1;
+    cellj.x = grid.pbc_x(cellj.x);
+    cellj.y = grid.pbc_y(cellj.y);
+    cellj.z = grid.pbc_z(cellj.z);
+    if (!(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z)) {
+      const int icellj = grid.getCellIndex(cellj);
+      const uint cs = cellStart[icellj];
+      if (cs >= validCell) { first = (int)(cs - validCell); count = cellEnd[icellj] - first; }
+    }
+  }
+  int incl = count;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane < 28) { sh.pre[lane] = incl - count; sh.first[lane] = first; }  // (lanes >= the cell count hold the total)
+  const int total = __shfl(incl, 27, 64);
+  const real3f invL{1.0f / L.x, 1.0f / L.y, 1.0f / L.z};
+  const float rcut2s = rcut2 * 1.00001f + 1e-30f;
+  for (int base = 0; base < total; base += kCellCap) {
+    const int chunk = min(kCellCap, total - base);
+    // ---- stage: flat candidate index -> (cell, particle) ----
+#pragma unroll
+    for (int k = 0; k < kCellCap / 64; ++k) {
+      const int t = base + lane + 64 * k;
+      if (t < base + chunk) {
+        int lo = 0;  // largest cell index with pre[cell] <= t (pre is non decreasing, 28 entries)
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+          if (lo + step < 28 && sh.pre[lo + step] <= t) lo += step;
+        const int j = sh.first[lo] + (t - sh.pre[lo]);
+        float4 pj = sortPos[j];
+        pj.w = __int_as_float(j);
+        const float *vp = v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j);
+        sh.pos[t - base] = pj;
+        sh.vel[3 * (t - base)] = vp[0]; sh.vel[3 * (t - base) + 1] = vp[1]; sh.vel[3 * (t - base) + 2] = vp[2];
+      }
+    }
+    // ---- passes of eight owners ----
+    if (ablate & 1) continue;
+    for (int ob = o0; ob < o1; ob += kNearGroup) {
+      const int id = ob + grp;
+      const bool active = id < o1;
+      const float4 pi = sortPos[active ? id : o0];
+      int cnt = 0;
+      for (int t0 = 0; t0 < chunk; t0 += kNearGroup) {
+        const int t = t0 + sub;
+        const float4 pj = sh.pos[t < chunk ? t : 0];
+        const bool hit = active && t < chunk && scan_distance2<SHEAR>(pi, pj, L, invL, shear) < rcut2s;
+        const unsigned long long m = __ballot(hit);
+        const uint mine = (uint)(m >> gbase) & 0xffu;
+        if (hit) sh.hits[grp][cnt + __popc(mine & ((1u << sub) - 1u))] = (unsigned char)t;
+        cnt += __popc(mine);
+      }
+      float tx = 0.f, ty = 0.f, tz = 0.f;
+      if (ablate & 2) cnt = 0;
+      for (int k = sub; k < cnt; k += kNearGroup) {
+        const int t = sh.hits[grp][k];
+        const float4 pj = sh.pos[t];
+        const real3f vj{sh.vel[3 * t], sh.vel[3 * t + 1], sh.vel[3 * t + 2]};
+        const real3f rij = sheared_distance(pi, pj, L, shear);
+        const float r2 = dot3(rij, rij);
+        if (r2 >= rcut2) continue;  // (the scan's test is a superset)
+        // TabulatedFunction::operator() as table_get above, both samples in one request
+        const float rs = sqrtf(r2);
+        float f = 0.f, g = 0.f;
+        if (!(rs >= tab.rmax)) {
+          const float r = rs * tab.interval;
+          const int i = r <= 0.0f ? 0 : (int)(r * (float)tab.Ntable);
+          const float4 q = table4[i];
+          if (r <= 0.0f) { f = q.x; g = q.y; }
+          else {
+            const float w = (r - (float)i * tab.dr) * (float)tab.Ntable;
+            f = fmaf(w, q.z, fmaf(-w, q.x, q.x));
+            g = fmaf(w, q.w, fmaf(-w, q.y, q.y));
+          }
+        }
+        float rx, ry, rz;
+        if (r2 == 0.0f) {
+          rx = f * vj.x; ry = f * vj.y; rz = f * vj.z;
+        } else {
+          const float invr2 = 1.0f / r2;
+          const float gmfv = (g - f) * dot3(rij, real3f{vj.x, vj.y, vj.z}) * invr2;
+          rx = fmaf(gmfv, rij.x, f * vj.x);
+          ry = fmaf(gmfv, rij.y, f * vj.y);
+          rz = fmaf(gmfv, rij.z, f * vj.z);
+        }
+        tx += rx; ty += ry; tz += rz;
+      }
+#pragma unroll
+      for (int o = 1; o < kNearGroup; o <<= 1) {
+        tx += __shfl_xor(tx, o, 64);
+        ty += __shfl_xor(ty, o, 64);
+        tz += __shfl_xor(tz, o, 64);
+      }
+      if (active && sub == 0) {
+        float *o = Mv + 3 * (size_t)(INDIRECT ? groupIndex[id] : id);
+        if (ACCUM || base > 0) { o[0] += tx; o[1] += ty; o[2] += tz; }  // (later chunks add to what the first one stored)
+        else { o[0] = tx; o[1] = ty; o[2] = tz; }
+      }
+    }
+  }
+}
+
 // the Lanczos iteration runs in CELL order (dot products and norms do not care; the product then reads v_j next to pos_j and needs
 // neither a gather of v nor a memset of Mv): noise of particle index[k] at slot k, and the result scattered back at the end
 __global__ void __launch_bounds__(256) k_pse_noise_sorted(float *__restrict__ out3, const int *__restrict__ groupIndex, int N,
@@ -361,8 +510,24 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   return p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st);
 }
 
+static int g_ablate = getenv("UAMMD_PSE_ABLATE") ? atoi(getenv("UAMMD_PSE_ABLATE")) : 0;
 #define UH_NEAR8(VS, IND, ACC)                                                                                                       \
   do {                                                                                                                               \
+    if (p->nearKernel == 0) {                                                                                                        \
+      const int ncells = p->cl.grid.cellDim.x * p->cl.grid.cellDim.y * p->cl.grid.cellDim.z;                                         \
+      const dim3 gc((ncells + 3) / 4);                                                                                               \
+      if (p->shear != 0.0f)                                                                                                          \
+        hipLaunchKernelGGL((k_pse_near_cell<VS, IND, ACC, true>), gc, dim3(256), 0, st, (const float4 *)p->cl.sortPos.ptr, d_v,      \
+                           (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr,          \
+                           p->cl.validCell, ncells, p->cl.grid, Lb, p->shear, p->rcut * p->rcut, make_view(p),                       \
+                           (const float4 *)p->table4.ptr, d_Mv, g_ablate);                                                                     \
+      else                                                                                                                           \
+        hipLaunchKernelGGL((k_pse_near_cell<VS, IND, ACC, false>), gc, dim3(256), 0, st, (const float4 *)p->cl.sortPos.ptr, d_v,     \
+                           (const int *)p->cl.index.ptr, (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr,          \
+                           p->cl.validCell, ncells, p->cl.grid, Lb, p->shear, p->rcut * p->rcut, make_view(p),                       \
+                           (const float4 *)p->table4.ptr, d_Mv, g_ablate);                                                                     \
+      break;                                                                                                                         \
+    }                                                                                                                                \
     const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));                                                    \
     if (p->shear != 0.0f)                                                                                                            \
       hipLaunchKernelGGL((k_pse_near8<VS, IND, ACC, true>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr, d_v,     \
@@ -530,6 +695,19 @@ int uammd_pse_near_create(const float boxSize[3], float viscosity, float hydrody
     set_last_error("uammd_pse_near_create: could not upload the RPY table");
     return -3;
   }
+  {  // the same samples, two per entry: {F_i, G_i, F_i+1, G_i+1} (one 16-byte request per interpolation)
+    std::vector<float4> h4((size_t)Ntable + 1);
+    for (int i = 0; i <= Ntable; ++i) {
+      const float2 a = host[i], b = host[i < Ntable ? i + 1 : i];
+      h4[i] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    if (p->table4.reserve(sizeof(float4) * h4.size()) ||
+        hipMemcpy(p->table4.ptr, h4.data(), sizeof(float4) * h4.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      delete p;
+      set_last_error("uammd_pse_near_create: could not upload the RPY table");
+      return -3;
+    }
+  }
   if (int e = uammd_lanczos_create(&p->lanczos)) { delete p; return e; }
   *out = reinterpret_cast<uammd_pse_near *>(p);
   if (rcut_out) *rcut_out = rcut;
@@ -557,6 +735,7 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
   if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
+  if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
   return -1;
 }
