@@ -596,6 +596,14 @@ public:
   virtual ~Interactor() = default;
   virtual void sum(Computables comp, hipStream_t st = 0) = 0;
   std::string getName() { return name; }
+  // Not part of UAMMD's interface: an Interactor that IS PairForces<Potential::LJ, CellList> on every particle lets
+  // VerletNVT::GronbechJensen run its whole step through one fused library call (uammd_verletnvt_gj_lj_step, bit-identical to the
+  // three-call sequence).  Everything else answers false and the integrator does what the reference does.
+  struct FusedGronbechJensen {
+    float *pos, *vel, *force; const float *mass; float defaultMass; int N; float dt, friction; bool is2D; float noiseAmplitude;
+    uint stepNum, seed; hipStream_t st;
+  };
+  virtual bool fusedGronbechJensenStep(const FusedGronbechJensen &) { return false; }
 };
 
 class Integrator {
@@ -664,6 +672,9 @@ public:
   }
   CellListData getCellList() { CellListData d; detail::check(uammd_celllist_get(h, &d)); return d; }
   uammd_celllist *handle() { return h; }
+  bool isAllParticles() const { return !pg; }
+  // the fused MD step built the list as update(box, cutOff) would have: the lazy-update bookkeeping follows
+  void fusedBuilt(Box box, real3 cutOff) { currentBox = box; currentCutOff = cutOff; force_next_update = false; }
 };
 
 // ---- VerletList (Interactor/NeighbourList/VerletList.cuh:83-201) ------------------------------------------------------------------
@@ -774,6 +785,30 @@ public:
   PairForces(shared_ptr<ParticleGroup> pg, Parameters par, shared_ptr<Potential::LJ> pot = make_shared<Potential::LJ>())
       : Interactor(pg, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
   void updateBox(Box b) override { box = b; }
+private:
+  static bool fusedStep(shared_ptr<CellList> &list, shared_ptr<ParticleData> pd, shared_ptr<Potential::LJ> pot, Box box,
+                        const FusedGronbechJensen &a) {
+    if (!list) list = make_shared<CellList>(pd);
+    if (!list->isAllParticles()) return false;
+    float L[3], Lo[3]; int per[3], cd[3], po[3];
+    box.toArrays(L, per);
+    const real rcut = pot->getCutOff();
+    const float rc[3] = {rcut, rcut, rcut};
+    detail::check(uammd_celllist_create_grid(L, per, rc, cd, Lo, po));
+    detail::check(uammd_verletnvt_gj_lj_step(list->handle(), a.pos, a.vel, a.force, a.mass, a.defaultMass, a.N, L, per, Lo, po, cd,
+                                             pot->deviceTable(), pot->getNumberTypes(), a.dt, a.friction, a.is2D, a.noiseAmplitude,
+                                             a.stepNum, a.seed, UAMMD_LJ_ALGO_AUTO, (void *)a.st));
+    list->fusedBuilt(box, make_real3(rcut));
+    return true;
+  }
+  template <class List> static bool fusedStep(shared_ptr<List> &, shared_ptr<ParticleData>, shared_ptr<Potential::LJ>, Box,
+                                              const FusedGronbechJensen &) { return false; }  // (only the CellList is fused)
+public:
+  bool fusedGronbechJensenStep(const FusedGronbechJensen &a) override {
+    const real rcut = pot->getCutOff();
+    if (pg || (box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut)) return false;
+    return fusedStep(nl, pd, pot, box, a);
+  }
   void sum(Computables comp, hipStream_t st = 0) override {  // PairForces.cu:43-78
     float L[3]; int per[3];
     box.toArrays(L, per);
@@ -855,6 +890,15 @@ public:
       for (auto &u : updatables) { u->updateTemperature(temperature); u->updateTimeStep(dt); }
       for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
       detail::hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    if (kernelKind() == 1 && !pg && interactors.size() == 1) {  // GronbechJensen + one interactor: try the fused step
+      auto pos = pd->getPos(access::gpu, access::readwrite);
+      auto vel = pd->getVel(access::gpu, access::readwrite);
+      auto force = pd->getForce(access::gpu, access::readwrite);
+      auto mass = defaultMass > 0 ? property_ptr<real>() : pd->getMassIfAllocated(access::gpu, access::read);
+      const Interactor::FusedGronbechJensen a{(float *)pos.raw(), (float *)vel.raw(), (float *)force.raw(), mass.raw(), defaultMass,
+                                              pd->getNumParticles(), dt, friction, is2D, noiseAmplitude, (uint)steps, seed, stream};
+      if (interactors[0]->fusedGronbechJensenStep(a)) return;
     }
     callIntegrate(1);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }

@@ -205,6 +205,19 @@ int uammd_lj_transverse_verletlist(uammd_verletlist *h, const uammd_lj_pair_para
 int uammd_verletnvt_gj(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
                        const int *d_index, int numberParticles, float dt, float friction, int is2D,
                        float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);
+/* One whole VerletNVT::GronbechJensen::forwardTime (Integrator/VerletNVT/GronbechJensen.cu:88-115) whose only interactor is
+ * PairForces<Potential::LJ, CellList> on every particle (Interactor/PairForces.cu:43-78), fused into five launches: the first half step
+ * rides in the cell list's hash kernel, the second in the traversal's store.  Bit-identical to the sequence
+ *   uammd_verletnvt_gj(1) -> uammd_celllist_update(updateL, updatePeriodic, cellDim) -> uammd_lj_transverse_celllist(algo) -> uammd_verletnvt_gj(2)
+ * which is also what runs where the list does not take the aggregated counting build or the tile kernel.  d_force holds f(t) on entry
+ * (the integrator's first step computes it the plain way) and f(t + dt) on return; updateL / updatePeriodic / cellDim as
+ * uammd_celllist_create_grid returns them for (boxL, boxPeriodic, cut-off). */
+int uammd_verletnvt_gj_lj_step(uammd_celllist *h, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                               int numberParticles, const float boxL[3], const int boxPeriodic[3], const float updateL[3],
+                               const int updatePeriodic[3], const int cellDim[3], const uammd_lj_pair_parameters *d_paramTable,
+                               int ntypes, float dt, float friction, int is2D, float noiseAmplitude, unsigned int stepNum,
+                               unsigned int seed, int algo, void *stream);
+
 int uammd_verletnvt_basic(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass,
                           float defaultMass, const int *d_index, int numberParticles, float dt, float friction,
                           int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);

@@ -1,0 +1,96 @@
+"""The fused MD step (uammd_verletnvt_gj_lj_step: GronbechJensen's first half step inside the cell list's hash kernel, the second inside
+the tile traversal's store) against the plain sequence uammd_verletnvt_gj(1) -> CellList::update -> PairForces::sum -> uammd_verletnvt_gj(2)
+it replaces (GronbechJensen.cu:88-115): positions, velocities and forces must be the SAME BITS after every step, with noise, on grids that
+take the fused kernels and on grids that fall back (radix build, exact traversal, all-pairs box)."""
+import numpy as np
+import pytest
+import torch
+
+from util import lattice_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(hip, n, L, fuse, T=1.0, algo=0, ntypes=1, mass=None, is2D=False, periodic=(1, 1, 1), force_radix=False):
+    pd = hip.ParticleData(n, seed=77)
+    pos = lattice_positions(n, L, seed=5, jitter=0.1, ntypes=ntypes)
+    if is2D:   # a square lattice in the plane z = 0
+        m = int(round(n ** 0.5))
+        g = np.stack(np.meshgrid(np.arange(m), np.arange(m), indexing="ij"), -1).reshape(-1, 2)
+        rng = np.random.default_rng(5)
+        pos[:, :2] = (g + 0.5) / m * np.asarray(L[:2]) - np.asarray(L[:2]) / 2 + rng.uniform(-0.1, 0.1, (n, 2))
+        pos[:, 2] = 0.0
+    pd.setPos(pos)
+    if mass is not None:
+        pd.getMass("write").copy_(torch.from_numpy(mass).cuda())
+    box = hip.Box(L, periodic)
+    pot = hip.Potential.LJ()
+    for a in range(ntypes):
+        for b in range(a, ntypes):
+            pot.setPotParameters(a, b, pot.InputPairParameters(2.5 - 0.2 * a, 1.0 + 0.05 * b, 1.0 + 0.1 * (a + b), (a + b) % 2 == 1))
+    par = hip.VerletNVT.GronbechJensen.Parameters(temperature=T, dt=0.004, friction=1.0, initVelocities=True, is2D=is2D)
+    integ = hip.VerletNVT.GronbechJensen(pd, par)
+    integ.fuse = fuse
+    pf = hip.PairForces(pd, box, pot, algo=algo)
+    if force_radix:
+        pf.nl = hip.CellList(pd)
+        pf.nl.set_option("force_radix", 1)
+    integ.addInteractor(pf)
+    return pd, integ
+
+
+def _same(a, b):
+    return np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["cubic", "noncubic-multitype", "mass-array", "exact-algo", "radix-build", "small-box-nbody", "2D"])
+def test_fused_step_is_bit_identical(hip, case):
+    kw, n, L = {}, 20000, 29.3
+    if case == "noncubic-multitype":
+        kw, n, L = dict(ntypes=3), 24000, (33.0, 27.5, 35.2)
+    elif case == "mass-array":
+        kw = dict(mass=np.random.default_rng(1).uniform(0.5, 2.0, n).astype(np.float32))
+    elif case == "exact-algo":
+        kw = dict(algo=9)
+    elif case == "radix-build":
+        kw = dict(force_radix=True)
+    elif case == "small-box-nbody":
+        n, L = 300, 7.2
+    elif case == "2D":
+        n, L, kw = 2500, (56.0, 56.0, 10.0), dict(is2D=True, periodic=(1, 1, 0))
+    pa, ia = _sim(hip, n, L, True, **kw)
+    pb, ib = _sim(hip, n, L, False, **kw)
+    for step in range(25):
+        ia.forwardTime()
+        ib.forwardTime()
+        if step in (0, 1, 9, 24):
+            assert _same(pa.getPos("read"), pb.getPos("read")), (case, step)
+            assert _same(pa.getVel("read"), pb.getVel("read")), (case, step)
+            fa, fb = pa.getForce("read").cpu().numpy(), pb.getForce("read").cpu().numpy()
+            assert np.array_equal(fa, fb), (case, step)          # (== : +0 and -0 compare equal)
+    assert np.isfinite(pa.getPos("read").cpu().numpy()).all()
+    # a later plain call on the fused simulation's list sees a valid, current list
+    pf = ia.interactors[0]
+    pa.getForce("write").zero_()
+    pf.sum(force=True)
+    assert np.allclose(pa.getForce("read").cpu().numpy(), fa, rtol=0, atol=0) or case == "small-box-nbody"
+
+
+def test_fused_step_sort_and_restart(hip):
+    """sortParticles between fused steps (the reorder signal) and switching the fusion off and on mid-run keep the two runs identical."""
+    n, L = 20000, 29.3
+    pa, ia = _sim(hip, n, L, True)
+    pb, ib = _sim(hip, n, L, False)
+    for step in range(30):
+        if step == 10:
+            pa.sortParticles()
+            pb.sortParticles()
+        if step == 20:
+            ia.fuse = False
+        if step == 25:
+            ia.fuse = True
+        ia.forwardTime()
+        ib.forwardTime()
+    ida, idb = pa.id.cpu().numpy(), pb.id.cpu().numpy()
+    assert np.array_equal(ida, idb)
+    assert _same(pa.getPos("read"), pb.getPos("read")) and _same(pa.getVel("read"), pb.getVel("read"))

@@ -23,6 +23,7 @@
 // keyStart[] is kept: the LDS-tiled traversal (lj.hip) uses it to find the particle range of an
 // aligned 4x4x4 brick of cells in O(1) (64 consecutive Morton keys).
 #include "celllist.hpp"
+#include "gj_step.hpp"
 #include <vector>
 
 #include <cstring>
@@ -116,10 +117,14 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
 // each distinct key then costs ONE global atomic that reserves the whole group's range of provisional ranks.  Unsorted input
 // degrades gracefully to one global atomic per particle.
 constexpr int kAggPerThread = 4;  // (256 or 512 particles per workgroup instead of 1024: same wall time, measured)
-__global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ pos, int N, GridT<float> grid,
+// GJ1: the fused MD step (uammd_verletnvt_gj_lj_step) — VerletNVT::GronbechJensen's first half step (GronbechJensen.cu:28-57) is applied
+// to each particle as it is loaded, the new position is stored and hashed: one pass over pos / vel / force instead of the integrator's
+// own launch followed by this kernel re-reading the positions.
+template <bool GJ1>
+__global__ void __launch_bounds__(kBlock) k_hash_agg(float4 *__restrict__ pos, int N, GridT<float> grid,
                                                      uint *__restrict__ hash, uint *__restrict__ keyCount,
                                                      uint *__restrict__ provRank, int *__restrict__ errorFlag,
-                                                     unsigned char *__restrict__ keyOutside) {
+                                                     unsigned char *__restrict__ keyOutside, GJFuse gj) {
   constexpr int kAggSlots = 2 * kBlock * kAggPerThread;  // 2 x particles per workgroup: the probe sequences stay short
   constexpr int kSlotShift = 32 - 11;
   static_assert(kAggSlots == 2048, "kSlotShift is log2 of the table size");
@@ -133,6 +138,27 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(const float4 *__restrict__ 
   for (int u = 0; u < kAggPerThread; ++u) {  // all loads first: four independent requests in flight per thread
     const int i = base + u * kBlock + threadIdx.x;
     p[u] = (i < N) ? pos[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (GJ1) {
+    float3 v[kAggPerThread];
+    float4 f4[kAggPerThread];
+#pragma unroll
+    for (int u = 0; u < kAggPerThread; ++u) {
+      const int i = min(base + u * kBlock + (int)threadIdx.x, N - 1);
+      v[u] = make_float3(gj.vel[3 * (size_t)i], gj.vel[3 * (size_t)i + 1], gj.vel[3 * (size_t)i + 2]);
+      f4[u] = gj.force[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kAggPerThread; ++u) {
+      const int i = base + u * kBlock + threadIdx.x;
+      if (i < N) {
+        const float invMass = 1.0f / (gj.defaultMass > 0 ? gj.defaultMass : gj.mass[i]);
+        gj_step1(p[u], v[u], f4[u], invMass, gj.dt, gj.friction, gj.noiseAmplitude, gj.is2D, (uint)i, gj.stepNum, gj.seed);
+        pos[i] = p[u];
+        gj.vel[3 * (size_t)i] = v[u].x; gj.vel[3 * (size_t)i + 1] = v[u].y; gj.vel[3 * (size_t)i + 2] = v[u].z;
+        gj.force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   }
 #pragma unroll
   for (int u = 0; u < kAggPerThread; ++u) {
@@ -498,8 +524,11 @@ int CellList::lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, fl
   return 0;
 }
 
+// gj (nullable): the fused MD step asks for GronbechJensen's first half step to be applied BEFORE the list is built — inside the hash
+// kernel where the build takes the aggregated counting path, by the integrator's own kernel otherwise (gjDone says which happened).
 int CellList::update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3],
-                     const int cellDim_[3], hipStream_t st) {
+                     const int cellDim_[3], hipStream_t st, const GJFuse *gj) {
+  gjDone = false;
   if (numberParticles < 0 || cellDim_[0] <= 0 || cellDim_[1] <= 0 || cellDim_[2] < 0) {
     set_last_error("CellList encountered an invalid grid and/or cutoff (N=%d cellDim=%d %d %d)", numberParticles,
                    cellDim_[0], cellDim_[1], cellDim_[2]);
@@ -548,6 +577,14 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   // Counting-sort build when the key table is comparable to the particle count.
   const bool counting = forceRadix ? false : (nKeys != 0 && (unsigned long long)nKeys <= 8ull * (unsigned long long)N + 4096ull);
   usedCounting = counting;
+  if (gj && !(counting && aggregateHash && N > 0)) {  // only the aggregated counting build carries the half step inside its hash kernel
+    if (N > 0)
+      if (int e = uammd_verletnvt_gj(1, (float *)const_cast<float4 *>(d_pos), gj->vel, (float *)gj->force, gj->mass, gj->defaultMass, nullptr,
+                                     N, gj->dt, gj->friction, gj->is2D, gj->noiseAmplitude, gj->stepNum, gj->seed, (void *)st))
+        return e;
+    gjDone = true;
+    gj = nullptr;
+  }
   {  // everything that must start at zero sits in one block: error flag, per-key "outside" flags, per-key counters
     const size_t errB = 16, koB = tabulated ? (((size_t)nKeys + 16 + 15) & ~(size_t)15) : 0,
                  kcB = counting ? sizeof(uint) * ((size_t)nKeys + 4) : 0;
@@ -570,10 +607,15 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
     if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
     if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
-    if (aggregateHash)
-      hipLaunchKernelGGL(k_hash_agg, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st, d_pos, N,
-                         grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
-                         (unsigned char *)keyOutside.ptr);
+    if (aggregateHash && gj) {
+      hipLaunchKernelGGL(k_hash_agg<true>, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st,
+                         const_cast<float4 *>(d_pos), N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                         (unsigned char *)keyOutside.ptr, *gj);
+      gjDone = true;
+    } else if (aggregateHash)
+      hipLaunchKernelGGL(k_hash_agg<false>, dim3((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread)), dim3(kBlock), 0, st,
+                         const_cast<float4 *>(d_pos), N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                         (unsigned char *)keyOutside.ptr, GJFuse{});
     else
       hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                          (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,

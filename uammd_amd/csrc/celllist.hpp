@@ -80,7 +80,8 @@ struct CellList {
 
   int next_valid_cell(int numberParticles, bool *needsClear);
   int update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3], const int cellDim[3],
-             hipStream_t st);
+             hipStream_t st, const struct GJFuse *gj = nullptr);
+  bool gjDone = false;  // the last update applied the fused half step (see update)
   int ensure_pack(hipStream_t st);  // 0 = packHalf is valid for the current list; 1 = this grid has no packed copy
 };
 

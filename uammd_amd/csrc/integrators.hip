@@ -10,6 +10,7 @@
 // Noise streams are keyed exactly as in the reference: Saru(thread index in group, step, seed).
 #include "celllist.hpp"
 #include "saru.hpp"
+#include "gj_step.hpp"
 
 namespace uammd_hip {
 
@@ -28,33 +29,12 @@ __global__ void __launch_bounds__(kIB) k_verletnvt_gj(float4 *__restrict__ pos, 
   float3 v = make_float3(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]);
   const float4 f4 = force[i];
   if (STEP == 1) {
-    Saru rng((uint)id, stepNum, seed);
-    noiseAmplitude *= 1.0f / sqrtf(invMass);
-    const float2 n01 = rng.gf(0.0f, noiseAmplitude);
-    float nz = 0.0f;
-    if (!is2D) nz = rng.gf(0.0f, noiseAmplitude).x;
-    const float gdthalfinvMass = friction * dt * 0.5f;
-    const float b = 1.0f / (1.0f + gdthalfinvMass);
-    const float a = (1.0f - gdthalfinvMass) * b;
     float4 p = pos[i];
-    const float bdt = b * dt;
-    const float c = 0.5f * invMass * dt * b;
-    p.x = fmaf(c, fmaf(dt, f4.x, n01.x), fmaf(bdt, v.x, p.x));
-    p.y = fmaf(c, fmaf(dt, f4.y, n01.y), fmaf(bdt, v.y, p.y));
-    p.z = fmaf(c, fmaf(dt, f4.z, nz), fmaf(bdt, v.z, p.z));
+    gj_step1(p, v, f4, invMass, dt, friction, noiseAmplitude, is2D, (uint)id, stepNum, seed);
     pos[i] = p;
-    const float d = dt * 0.5f * invMass * a;
-    const float e = b * invMass;
-    v.x = fmaf(e, n01.x, fmaf(d, f4.x, a * v.x));
-    v.y = fmaf(e, n01.y, fmaf(d, f4.y, a * v.y));
-    v.z = fmaf(e, nz, fmaf(d, f4.z, a * v.z));
     force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-    const float d = dt * 0.5f * invMass;
-    v.x = fmaf(d, f4.x, v.x);
-    v.y = fmaf(d, f4.y, v.y);
-    v.z = fmaf(d, f4.z, v.z);
-  }
+  } else
+    gj_step2(v, f4.x, f4.y, f4.z, invMass, dt, is2D);
   if (is2D) v.z = 0.0f;
   vel[3 * i] = v.x; vel[3 * i + 1] = v.y; vel[3 * i + 2] = v.z;
 }

@@ -18,6 +18,7 @@
 // measured slower than k_lj_ringh — DESIGN.md 5.2 keeps the numbers — and were removed when the tile kernels replaced them.)
 #include "celllist.hpp"
 #include "lj_common.hpp"
+#include "gj_step.hpp"
 #include "ring_scan.hpp"
 
 #include <string>
@@ -667,6 +668,47 @@ int uammd_lj_transverse_celllist(uammd_celllist *hh, const uammd_lj_pair_paramet
   UH_DISPATCH_FEV(dispatch_celllist, h, algo, box, tbl, ntypes, out, (hipStream_t)stream);
   if (rc) return rc;
   UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// One VerletNVT::GronbechJensen::forwardTime (GronbechJensen.cu:88-115) whose only interactor is PairForces<Potential::LJ, CellList> on the
+// whole system (PairForces.cu:43-78), in five launches instead of seven: the first half step rides in the cell list's hash kernel (the new
+// position is stored and hashed in one pass), the second in the traversal's store (the force is still in registers).  Same arithmetic as
+// uammd_verletnvt_gj(1) -> uammd_celllist_update -> uammd_lj_transverse_celllist -> uammd_verletnvt_gj(2), bit for bit; where the list
+// does not take the aggregated counting build or the tile kernel, exactly that sequence runs instead.  d_force must hold f(t) on entry
+// (the integrator's first step computes it the plain way) and holds f(t + dt) on return.
+int uammd_verletnvt_gj_lj_step(uammd_celllist *hh, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                               int N, const float boxL[3], const int boxPeriodic[3], const float updateL[3], const int updatePeriodic[3],
+                               const int cellDim[3], const uammd_lj_pair_parameters *d_paramTable, int ntypes, float dt, float friction,
+                               int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed, int algo, void *stream) {
+  if (!hh || !d_pos || !d_vel || !d_force || !d_paramTable || ntypes < 1 || N < 0) { set_last_error("uammd_verletnvt_gj_lj_step: bad arguments"); return -1; }
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_verletnvt_gj_lj_step: no mass array and defaultMass <= 0"); return -1; }
+  if (N == 0) return 0;
+  CellList *h = reinterpret_cast<CellList *>(hh);
+  hipStream_t st = (hipStream_t)stream;
+  const GJFuse gj{d_vel, reinterpret_cast<float4 *>(d_force), d_mass, defaultMass, dt, friction, noiseAmplitude, is2D, stepNum, seed};
+  if (int e = h->update(reinterpret_cast<const float4 *>(d_pos), N, updateL, updatePeriodic, cellDim, st, &gj)) {
+    if (!h->gjDone) {
+      // (the build refused — a flag raised by an earlier build, a bad grid — before the half step: nothing was changed)
+    }
+    return e;
+  }
+  const BoxT<float> box = make_box<float>(boxL, boxPeriodic);
+  const LJParams *tbl = reinterpret_cast<const LJParams *>(d_paramTable);
+  float maxCut2 = 0.f;
+  if (int e = h->lj_max_cutoff2(tbl, ntypes, st, &maxCut2)) return e;
+  const bool tile = (algo == UAMMD_LJ_ALGO_AUTO || algo == UAMMD_LJ_ALGO_TILE) && h->numOwned == 0x7fffffff && lj_tile_supported(h, box, maxCut2);
+  Outputs out{reinterpret_cast<float4 *>(d_force), nullptr, nullptr, nullptr};
+  if (tile) {
+    out.vel = d_vel; out.mass = d_mass; out.defaultMass = defaultMass; out.dt = dt; out.is2D = is2D;
+  }
+  int rc = 0;
+  if (ntypes == 1) rc = dispatch_celllist<true, false, false>(h, algo, box, tbl, ntypes, out, st);
+  else rc = dispatch_celllist<false, false, false>(h, algo, box, tbl, ntypes, out, st);
+  if (rc) return rc;
+  UH_CHECK(hipGetLastError());
+  if (!tile)
+    return uammd_verletnvt_gj(2, d_pos, d_vel, d_force, d_mass, defaultMass, nullptr, N, dt, friction, is2D, noiseAmplitude, stepNum, seed, stream);
   return 0;
 }
 

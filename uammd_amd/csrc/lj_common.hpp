@@ -131,6 +131,12 @@ struct Outputs {
   float *energy;
   float *virial;
   const int *globalIndex;
+  // fused MD step (uammd_verletnvt_gj_lj_step), tile kernels only: vel != null -> the store is GronbechJensen's second half step
+  // (GronbechJensen.cu:58-61) on the spot, v += dt / (2 m) f, and force = f (the first half step left the force array at zero)
+  float *vel = nullptr;
+  const float *mass = nullptr;
+  float defaultMass = 0.f, dt = 0.f;
+  int is2D = 0;
 };
 
 UH_D void write_out(const Outputs &o, int ori, const Acc &a) {

@@ -32,6 +32,7 @@
 //               a brick whose halo does not fit.
 #include "celllist.hpp"
 #include "lj_common.hpp"
+#include "gj_step.hpp"
 #include <hip/hip_ext.h>
 
 namespace uammd_hip {
@@ -337,7 +338,14 @@ UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint own
   if (WV) acc.v += __shfl_xor(acc.v, 32);
   if ((lane >> 5) == 0 && valid) {
     const int gi = cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
-    if (gi < cl.numOwned) write_out(out, out.globalIndex ? out.globalIndex[gi] : gi, acc);
+    if (out.vel) {  // the fused step: half kick with the force that is still in registers (every particle is owned, no group)
+      const float invMass = 1.0f / (out.defaultMass > 0 ? out.defaultMass : out.mass[gi]);
+      float3 v = make_float3(out.vel[3 * (size_t)gi], out.vel[3 * (size_t)gi + 1], out.vel[3 * (size_t)gi + 2]);
+      const float fx = 0.0f + acc.fx, fy = 0.0f + acc.fy, fz = 0.0f + acc.fz;  // what `force += f` leaves in a zeroed array
+      gj_step2(v, fx, fy, fz, invMass, out.dt, out.is2D);
+      out.vel[3 * (size_t)gi] = v.x; out.vel[3 * (size_t)gi + 1] = v.y; out.vel[3 * (size_t)gi + 2] = v.z;
+      out.force[gi] = make_float4(fx, fy, fz, 0.0f);
+    } else if (gi < cl.numOwned) write_out(out, out.globalIndex ? out.globalIndex[gi] : gi, acc);
   }
 }
 

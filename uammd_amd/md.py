@@ -300,6 +300,14 @@ class CellList:
             self.update_grid(pos, ubox, cd)
             self.force_next_update = False
 
+    def fused_built(self, box, cutoff, pos):
+        """The fused MD step built this list on `pos` as update(box, cutoff) would have: the lazy-update bookkeeping follows."""
+        self.currentBox = box
+        self.currentCutOff = np.broadcast_to(np.asarray(cutoff, dtype=np.float32), (3,)).copy()
+        self.N = pos.shape[0]
+        self._pos_ref = pos
+        self.force_next_update = False
+
     def update_grid(self, pos, box, cellDim):
         """CellListBase::update(pos, N, grid, st) (CellListBase.cuh:124-140)."""
         assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 4
@@ -519,6 +527,22 @@ class PairForces(Interactor):
             pg, pd = pd, pd.getParticleData()
         self.pd, self.box, self.pot, self.nl, self.algo, self.pg = pd, box, pot, nl, algo, pg
 
+    def fused_gj_arguments(self):
+        """What uammd_verletnvt_gj_lj_step needs from this interactor, or None when it is not the plain PairForces<LJ, CellList> on all
+        particles with a neighbour list (group, Verlet list, all-pairs box: the integrator then runs the plain sequence)."""
+        if self.pg is not None or not isinstance(self.pot, _LJ):
+            return None
+        rc = np.float32(self.pot.getCutOff())
+        L = self.box.boxSize
+        if L[0] <= 3 * rc and L[1] <= 3 * rc and L[2] <= 3 * rc:
+            return None
+        if self.nl is None:
+            self.nl = CellList(self.pd)
+        if type(self.nl) is not CellList:
+            return None
+        cd, ubox = CellList.create_update_grid(self.box, rc)
+        return self.nl, self.box, ubox, cd, self.pot.device_table(), self.pot.ntypes, self.algo
+
     def sum(self, force=True, energy=False, virial=False):
         pd = self.pd
         f = pd.getForce("readwrite") if force else None
@@ -643,10 +667,33 @@ class _VerletNVTBasic(Integrator):
                 it.updateTimeStep(self.dt)
             for it in self.interactors:
                 it.sum(force=True)
+        if self._fused_step():
+            return
         self._integrate(1)
         for it in self.interactors:
             it.sum(force=True)
         self._integrate(2)
+
+    fuse = True   # GronbechJensen + one PairForces<LJ, CellList> on every particle: uammd_verletnvt_gj_lj_step (bit-identical, five launches)
+
+    def _fused_step(self):
+        if not (self.fuse and self.kind == "gj" and self.pg is None and len(self.interactors) == 1):
+            return False
+        it = self.interactors[0]
+        args = getattr(it, "fused_gj_arguments", None)
+        args = args() if args is not None else None
+        if args is None:
+            return False
+        nl, box, ubox, cd, tbl, ntypes, algo = args
+        pd = self.pd
+        pos = pd.getPos("readwrite")          # (signals the position write: every list on this ParticleData rebuilds next time)
+        check(self.lib.uammd_verletnvt_gj_lj_step(nl.h, _ptr(pos), _ptr(pd.getVel("readwrite")), _ptr(pd.getForce("readwrite")),
+                                                  _ptr(self._mass()), self.defaultMass, pd.N, f3(box.boxSize),
+                                                  i3([int(p) for p in box.periodic]), f3(ubox.boxSize), i3([int(p) for p in ubox.periodic]),
+                                                  i3(cd), _ptr(tbl), ntypes, self.dt, self.friction, int(self.is2D), self.noiseAmplitude,
+                                                  self.steps, self.seed, algo, current_stream()))
+        nl.fused_built(box, it.pot.getCutOff(), pos)
+        return True
 
     def sumEnergy(self):
         """sumKineticEnergy (VerletNVT/Basic.cu:186-207): energy[i] += m |v|^2 / 2; returns 0 like the reference."""
