@@ -621,6 +621,62 @@ int uammd_comm_exchange_counts(uammd_comm *h, const int toUpDown[2], int fromDow
 int uammd_comm_alltoall(uammd_comm *h, const void *d_send, void *d_recv, size_t bytesPerPeer, void *stream);
 int uammd_comm_allreduce_sum(uammd_comm *h, float *d_buf, int n, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DOUBLE_PRECISION build of path B (global/defines.h:9-11,33-44 makes `real` a build switch; every accuracy assertion the
+ * reference ships is compiled with it: test/CMakeLists.txt:9, test/BDHI/FCM/Makefile:9).  The `_f64` entry points below are
+ * that build of the layout-generic kernels: IBM spread / gather, FCM_impl (deterministic part), PSE near / far field and
+ * lanczos::Solver with real = double, so that the reference's own known answers run on the GPU at their own tolerances:
+ *   test/BDHI/FCM/fcm_test.cu:85-144 (Hasimoto, 1e-8)        test/misc/ibm/test_ibm_regular.cu:113-136,240-274 (1e-10)
+ *   test/misc/lanczos/test_lanczos.cu:236-269 (1e-7)          test/BDHI/PSE/pse_test.cu:64-117
+ * Positions / forces are real4 = double[4], velocities real3 = double[3].  The tuned hot path (tile-owned MFMA spreading,
+ * the in-LDS FFT, the pair prefilter) is single precision by construction: UAMMD's default `real`, and what bench.py measures.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int kind;        /* UAMMD_IBM_KERNEL_GAUSSIAN, _PESKIN3, _PESKIN4 or _CONSTANT */
+  int support[3];
+  double prefactor, tau, rmax;
+  double invh[3];
+} uammd_ibm_kernel_f64;
+typedef struct {
+  double boxSize[3];
+  int cells[3];
+  double viscosity;
+  uammd_ibm_kernel_f64 kernel;
+} uammd_fcm_parameters_f64;
+typedef struct uammd_fcm_f64 uammd_fcm_f64;
+typedef struct uammd_pse_near_f64 uammd_pse_near_f64;
+typedef struct uammd_lanczos_f64 uammd_lanczos_f64;
+int uammd_fcm_gaussian_kernel_f64(double h, double tolerance, uammd_ibm_kernel_f64 *out, double *a_eff);
+double uammd_fcm_advise_grid_size_f64(double hydrodynamicRadius, double tolerance);
+int uammd_ibm_spread_f64(const double *d_pos, int posStride, const double *d_quantity, int ncomp, int numberParticles,
+                         const double boxSize[3], const int periodic[3], const int cellDim[3], int nxStride,
+                         const uammd_ibm_kernel_f64 *kernel, double *d_grid, void *stream);
+int uammd_ibm_gather_f64(const double *d_pos, int posStride, double *d_out, int ncomp, int numberParticles, const double boxSize[3],
+                         const int periodic[3], const int cellDim[3], int nxStride, const uammd_ibm_kernel_f64 *kernel,
+                         const double *d_grid, void *stream);
+int uammd_fcm_create_f64(const uammd_fcm_parameters_f64 *par, uammd_fcm_f64 **out);
+int uammd_fcm_destroy_f64(uammd_fcm_f64 *h);
+/* d_velocity real3[N] = M F (overwritten; a PSE far-field handle ADDS, as FarField.cuh:563-566) */
+int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int numberParticles,
+                                double *d_velocity, void *stream);
+int uammd_pse_far_raw_cells_f64(const double boxSize[3], double psi, double tolerance, int cells_out[3]);
+int uammd_pse_far_create_f64(const double boxSize[3], const int cells[3], double viscosity, double hydrodynamicRadius,
+                             double tolerance, double psi, double shearStrain, uammd_fcm_f64 **out, int *support_out,
+                             double *eta_out);
+int uammd_pse_near_create_f64(const double boxSize[3], double viscosity, double hydrodynamicRadius, double tolerance, double psi,
+                              uammd_pse_near_f64 **out, double *rcut_out, int *nPointsTable_out);
+int uammd_pse_near_destroy_f64(uammd_pse_near_f64 *h);
+/* d_MF real3[N] += M_near v, v = d_v with stride 4 (real4 forces) or 3 */
+int uammd_pse_near_mdot_f64(uammd_pse_near_f64 *h, const double *d_pos, const double *d_v, int vstride, int numberParticles,
+                            double *d_MF, void *stream);
+typedef int (*uammd_matvec_fn_f64)(void *ctx, const double *d_v, double *d_Mv, int n, void *stream);
+int uammd_lanczos_create_f64(uammd_lanczos_f64 **out);
+int uammd_lanczos_destroy_f64(uammd_lanczos_f64 *h);
+int uammd_lanczos_run_f64(uammd_lanczos_f64 *h, uammd_matvec_fn_f64 dot, void *ctx, double *d_Bv, const double *d_v,
+                          double tolerance, int n, void *stream, int *iterations);
+int uammd_lanczos_set_iteration_hard_limit_f64(uammd_lanczos_f64 *h, int limit);
+int uammd_lanczos_get_last_run_required_steps_f64(uammd_lanczos_f64 *h, int *steps);
+
 #ifdef __cplusplus
 }
 #endif

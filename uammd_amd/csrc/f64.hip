@@ -1,0 +1,555 @@
+// DOUBLE_PRECISION build of path B — the reference makes `real` a build switch (global/defines.h:9-11,33-44) and compiles every accuracy
+// assertion it ships with it (test/CMakeLists.txt:9, test/BDHI/FCM/Makefile:9): Hasimoto self mobility to 1e-8 (test/BDHI/FCM/fcm_test.cu:
+// 85-144), Peskin spreading / random-field interpolation to 1e-10 (test/misc/ibm/test_ibm_regular.cu:113-136,240-274), dense SPD Lanczos
+// to 1e-7 (test/misc/lanczos/test_lanczos.cu:236-269), PSE self mobility (test/BDHI/PSE/pse_test.cu:64-117).  This file is that build for
+// gfx950: the `_f64` entry points of include/uammd_hip.h, so that those known answers run ON THE GPU at the reference's own tolerances
+// (tests/test_gpu_f64.py).
+//
+// What is in it (same algorithms as the single-precision library's layout-generic kernels, `real` = double; MI355X runs f64 vector
+// arithmetic at half the f32 rate and has hardware f64 atomics in L2):
+//   IBM spread / gather      misc/IBM.cu:10-65 (stencil, support shift, weights), :83-147 (particles2GridD), :164-235 (grid2ParticlesDTPP)
+//                            one wave per particle, the 3 x support weights in LDS, global_atomic_add_f64 / shuffle reduction
+//   FCM_impl                 Integrator/BDHI/FCM/FCM_impl.cuh:293-304,375-397,399-411,544-581,652-693 (spread, rocFFT R2C in double,
+//                            forceFourier2Vel, C2R, gather); deterministic part (every double-precision test of the reference is T = 0 or
+//                            statistical)
+//   PSE far field            Integrator/BDHI/PSE/FarField.cuh:85-158,605-654 (window, sinc^2 Hasimoto-split greens function, projection)
+//   PSE near field           Integrator/BDHI/PSE/NearField.cuh:65-99,120-196 over all pairs (minimum image; rcut <= L/2 is the reference's own
+//                            precondition, NearField.cuh:69-78): the double-precision tests hold one particle or a handful
+//   lanczos::Solver          lanczos.hip is a template over `real` (uammd_lanczos_*_f64 live there)
+// The tuned single-precision hot path (tile-owned MFMA spreading, the in-LDS FFT with the fused operator, the f16-MFMA pair prefilter) is
+// single precision by construction and stays that way: `real` = float is UAMMD's default and the benchmarked configuration.
+#include "celllist.hpp"
+#include "ibm.hpp"
+
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace uammd_hip {
+
+int rocfft_setup_once();  // fcm.hip
+
+struct Kern64 {
+  int kind;
+  int3 support;
+  double prefactor, tau, rmax, invhx, invhy, invhz;
+};
+
+UH_D double phi64_peskin3(double invh, double rr) {  // misc/IBM_kernels.cuh:120-136
+  const double r = fabs(rr) * invh;
+  if (r < 0.5) return invh * (1 / 3.0) * (1.0 + sqrt(fma(-3.0 * r, r, 1.0)));
+  if (r < 1.5) {
+    const double omr = 1.0 - r;
+    return invh * (1 / 6.0) * (fma(-3.0, r, 5.0) - sqrt(fma(-3.0 * omr, omr, 1.0)));
+  }
+  return 0.0;
+}
+UH_D double phi64_peskin4(double invh, double rr) {  // misc/IBM_kernels.cuh:145-158
+  const double r = fabs(rr) * invh;
+  if (r < 1.0) return invh * 0.125 * (fma(-2.0, r, 3.0) + sqrt(fma(4.0 * r, (1.0 - r), 1.0)));
+  if (r < 2.0) return invh * 0.125 * (fma(-2.0, r, 5.0) - sqrt(fma(-(4.0 * r), r, fma(12.0, r, -7.0))));
+  return 0.0;
+}
+UH_D double phi64_axis(const Kern64 &k, int axis, double r) {
+  switch (k.kind) {
+    case kKernelGaussian: return (r >= k.rmax) ? 0.0 : k.prefactor * exp(k.tau * r * r);  // FCM_kernels.cuh:55-57
+    case kKernelPeskin3: return phi64_peskin3(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    case kKernelPeskin4: return phi64_peskin4(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    default: return 1.0;  // the constant window of the reference's test (test_ibm_regular.cu:11-14)
+  }
+}
+
+UH_D int3 support_shift64(const GridT<double> &g, real3d pos, int3 celli, int3 support) {  // IBM.cu:10-31
+  int3 P = make_int3(support.x / 2, support.y / 2, support.z / 2);
+  real3d d = g.distanceToCellCenter(pos, make_int3(celli.x - P.x, celli.y - P.y, celli.z - P.z));
+  d.x = fabs(d.x); d.y = fabs(d.y); d.z = fabs(d.z);
+  if (g.cellSize.x > 0 && d.x > (double)support.x * g.cellSize.x / 2.0) P.x -= 1;
+  if (g.cellSize.y > 0 && d.y > (double)support.y * g.cellSize.y / 2.0) P.y -= 1;
+  if (g.cellSize.z > 0 && d.z > (double)support.z * g.cellSize.z / 2.0) P.z -= 1;
+  return P;
+}
+
+// One wave per particle (four per workgroup).  The 3 x support 1-D weights are evaluated by the first lanes and kept in LDS
+// (fillSharedWeights, IBM.cu:33-65); lanes then walk the support^3 nodes, x fastest.  Component c of node n lives at
+// grid[n * nodeStride + c * compStride]: interleaved user grids (nodeStride = NCOMP, compStride = 1, the reference's real3 grid) or the
+// solver's planar grids (nodeStride = 1, compStride = one component grid).  Spread ADDS into the grid, gather ADDS into qout unless
+// `overwrite`.
+constexpr int kW64 = 3 * kMaxSupport;
+template <int NCOMP, bool SPREAD>
+__global__ void __launch_bounds__(256) k_ibm64(const double *__restrict__ pos, int posStride, const double *__restrict__ qin, int qStride,
+                                                double *__restrict__ qout, double *__restrict__ grid, int N, GridT<double> g, int nxStride,
+                                                size_t nodeStride, size_t compStride, Kern64 kern, FastDiv dsx, FastDiv dsxy, bool is2D,
+                                                bool overwrite) {
+  __shared__ double wsh[4][kW64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int id = blockIdx.x * 4 + wave;
+  if (id >= N) return;  // whole wave (no workgroup barrier below)
+  double *w = wsh[wave];
+  const real3d pi{pos[(size_t)posStride * id], pos[(size_t)posStride * id + 1], pos[(size_t)posStride * id + 2]};
+  const int3 celli = g.getCell(pi);
+  int3 support = kern.support;
+  int3 P = support_shift64(g, pi, celli, support);
+  if (is2D) { P.z = 0; support.z = 1; }
+  const int sx = support.x, sy = support.y, sz = support.z;
+  for (int t = lane; t < sx + sy + sz; t += 64) {
+    double v = 0.0;
+    if (t < sx) {
+      const int cx = g.pbc_x(celli.x + t - P.x);
+      if (cx >= 0) v = phi64_axis(kern, 0, g.distanceToCellCenter(pi, make_int3(cx, celli.y, celli.z)).x);
+    } else if (t < sx + sy) {
+      const int cy = g.pbc_y(celli.y + (t - sx) - P.y);
+      if (cy >= 0) v = phi64_axis(kern, 1, g.distanceToCellCenter(pi, make_int3(celli.x, cy, celli.z)).y);
+    } else {
+      const int cz = g.pbc_z(celli.z + (t - sx - sy) - P.z);
+      if (cz >= 0) v = phi64_axis(kern, 2, g.distanceToCellCenter(pi, make_int3(celli.x, celli.y, cz)).z);
+      if (is2D && (kern.kind == kKernelPeskin3 || kern.kind == kKernelPeskin4)) v = 1.0;  // test_ibm_regular.cu:83-85
+    }
+    w[t] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  double v[NCOMP], acc[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    v[c] = SPREAD ? qin[(size_t)qStride * id + c] : 0.0;
+    acc[c] = 0.0;
+  }
+  const double dV = g.cellVolume;
+  const int nn = sx * sy * sz;
+  for (int i = lane; i < nn; i += 64) {
+    const uint kk = dsxy.div((uint)i);
+    const uint rem = (uint)i - kk * (uint)(sx * sy);
+    const uint jj = dsx.div(rem);
+    const uint ii = rem - jj * (uint)sx;
+    const int cx = g.pbc_x(celli.x + (int)ii - P.x);
+    const int cy = g.pbc_y(celli.y + (int)jj - P.y);
+    const int cz = is2D ? 0 : g.pbc_z(celli.z + (int)kk - P.z);
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= g.cellDim.x || cy >= g.cellDim.y || cz >= g.cellDim.z) continue;
+    const size_t node = (size_t)cx + (size_t)nxStride * ((size_t)cy + (size_t)g.cellDim.y * (size_t)cz);
+    if (SPREAD) {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) unsafeAtomicAdd(&grid[node * nodeStride + (size_t)c * compStride], v[c] * w[ii] * w[sx + jj] * w[sx + sy + kk]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c] = fma(dV, grid[node * nodeStride + (size_t)c * compStride] * w[ii] * w[sx + jj] * w[sx + sy + kk], acc[c]);
+    }
+  }
+  if (!SPREAD) {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      double t = acc[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0) {
+        if (overwrite) qout[(size_t)NCOMP * id + c] = t;
+        else qout[(size_t)NCOMP * id + c] += t;
+      }
+    }
+  }
+}
+
+static Kern64 to_dev64(const uammd_ibm_kernel_f64 &k) {
+  return Kern64{k.kind, make_int3(k.support[0], k.support[1], k.support[2]), k.prefactor, k.tau, k.rmax, k.invh[0], k.invh[1], k.invh[2]};
+}
+static int check_kernel64(const char *fn, const uammd_ibm_kernel_f64 *k) {
+  if (!k) { set_last_error("%s: null kernel", fn); return -1; }
+  for (int a = 0; a < 3; ++a)
+    if (k->support[a] < 1 || k->support[a] > kMaxSupport) { set_last_error("%s: kernel support %d outside [1, %d]", fn, k->support[a], kMaxSupport); return -1; }
+  if (k->kind != kKernelGaussian && k->kind != kKernelPeskin3 && k->kind != kKernelPeskin4 && k->kind != kKernelConstant) {
+    set_last_error("%s: the double-precision build has the Gaussian, Peskin 3 / 4 point and constant windows (kind %d asked)", fn, k->kind);
+    return -1;
+  }
+  return 0;
+}
+
+// ---- Fourier space, FCM (FCM/utils.cuh:27-74, FCM_impl.cuh:375-397) and PSE far field (FarField.cuh:53-158) ------------------------------
+struct Pse64 { double rh, split, eta, shear; bool on; };
+
+__global__ void __launch_bounds__(256) k_kspace64(double2 *__restrict__ g0, size_t planeC, int3 nk, real3d L, double viscosity, Pse64 pse) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nkx = nk.x / 2 + 1;
+  const size_t total = (size_t)nk.z * nk.y * nkx;
+  if (t >= total) return;
+  int3 ik = make_int3((int)(t % nkx), (int)((t / nkx) % nk.y), (int)(t / ((size_t)nkx * nk.y)));  // indexToWaveNumber
+  ik.x -= nk.x * (ik.x >= nkx);
+  ik.y -= nk.y * (ik.y >= (nk.y / 2 + 1));
+  ik.z -= nk.z * (ik.z >= (nk.z / 2 + 1));
+  double2 *g1 = g0 + planeC, *g2 = g0 + 2 * planeC;
+  const double2 zero = make_double2(0.0, 0.0);
+  if (t == 0) { g0[0] = zero; g1[0] = zero; g2[0] = zero; return; }
+  const double twopi = 2.0 * 3.14159265358979323846;
+  const real3d k{(twopi / L.x) * (double)ik.x, (twopi / L.y) * (double)ik.y, (twopi / L.z) * (double)ik.z};
+  const double2 fx = g0[t], fy = g1[t], fz = g2[t];
+  if (pse.on) {  // forceFourier2Vel of the far field: project(B f) with the sheared wave vector, no Nyquist zeroing
+    const double k2 = dot3(k, k);
+    real3d kE = k;
+    kE.y = fma(-pse.shear, k.x, k.y);
+    const double kE2 = dot3(kE, kE);
+    const double kmod = sqrt(kE2), invk2 = 1.0 / kE2;
+    const double sink = sin(kmod * pse.rh);
+    const double kEw = kE2 / (4.0 * pse.split * pse.split), kNU = k2 / (4.0 * pse.split * pse.split);
+    const double tau = fma(pse.eta, kNU, -kEw);
+    const double hashimoto = (1.0 + kEw) * exp(tau) / kE2;
+    double B = sink * sink * invk2 * hashimoto / (viscosity * pse.rh * pse.rh);
+    B /= (double)nk.x * (double)nk.y * (double)nk.z;
+    const real3d re{fx.x * B, fy.x * B, fz.x * B}, im{fx.y * B, fy.y * B, fz.y * B};
+    const double kfr = dot3(kE, re) * invk2, kfi = dot3(kE, im) * invk2;
+    g0[t] = make_double2(fma(-kE.x, kfr, re.x), fma(-kE.x, kfi, im.x));
+    g1[t] = make_double2(fma(-kE.y, kfr, re.y), fma(-kE.y, kfi, im.y));
+    g2[t] = make_double2(fma(-kE.z, kfr, re.z), fma(-kE.z, kfi, im.z));
+    return;
+  }
+  const double k2 = dot3(k, k);
+  // getGradientFourier: unpaired (Nyquist) components are zero in the projector (FCM/utils.cuh:41-51)
+  const real3d dk{ik.x == (nk.x - ik.x) ? 0.0 : k.x, ik.y == (nk.y - ik.y) ? 0.0 : k.y, ik.z == (nk.z - ik.z) ? 0.0 : k.z};
+  const double invk2 = 1.0 / k2;
+  const real3d dki{dk.x * invk2, dk.y * invk2, dk.z * invk2};
+  const double sr = dot3(real3d{fx.x, fy.x, fz.x}, dki), si = dot3(real3d{fx.y, fy.y, fz.y}, dki);
+  const double B = 1.0 / (viscosity * k2);
+  const double sc = B / ((double)nk.x * (double)nk.y * (double)nk.z);  // the FFT normalisation lives here (FCM_impl.cuh:392)
+  g0[t] = make_double2(fma(-dk.x, sr, fx.x) * sc, fma(-dk.x, si, fx.y) * sc);
+  g1[t] = make_double2(fma(-dk.y, sr, fy.x) * sc, fma(-dk.y, si, fy.y) * sc);
+  g2[t] = make_double2(fma(-dk.z, sr, fz.x) * sc, fma(-dk.z, si, fz.y) * sc);
+}
+
+struct FCM64 {
+  GridT<double> grid;
+  Kern64 kern;
+  double L[3], viscosity;
+  int nxpad = 0;
+  size_t planeReal = 0, planeCplx = 0;
+  DeviceBuffer gridBuf, work;
+  Pse64 pse{0, 0, 0, 0, false};
+  bool accumulate = false;
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  ~FCM64() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+
+#define UH_ROCFFT64(expr)                                                                      \
+  do {                                                                                         \
+    const rocfft_status s_ = (expr);                                                           \
+    if (s_ != rocfft_status_success) {                                                         \
+      set_last_error("%s failed with rocfft status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+      return -10;                                                                              \
+    }                                                                                          \
+  } while (0)
+
+static int fcm64_plans(FCM64 *f) {
+  rocfft_setup_once();
+  const size_t nx = (size_t)f->grid.cellDim.x, ny = (size_t)f->grid.cellDim.y, nz = (size_t)f->grid.cellDim.z, nkx = nx / 2 + 1;
+  const size_t lengths[3] = {nx, ny, nz};
+  const size_t rstr[3] = {1, (size_t)f->nxpad, (size_t)f->nxpad * ny}, cstr[3] = {1, nkx, nkx * ny};
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 3,
+                                                      rstr, f->planeReal, 3, cstr, f->planeCplx));
+  UH_ROCFFT64(rocfft_plan_create(&f->fwd, rocfft_placement_inplace, rocfft_transform_type_real_forward, rocfft_precision_double, 3, lengths, 3, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr, 3,
+                                                      cstr, f->planeCplx, 3, rstr, f->planeReal));
+  UH_ROCFFT64(rocfft_plan_create(&f->inv, rocfft_placement_inplace, rocfft_transform_type_real_inverse, rocfft_precision_double, 3, lengths, 3, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  size_t wf = 0, wi = 0;
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(f->fwd, &wf));
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(f->inv, &wi));
+  const size_t wb = std::max(wf, wi);
+  UH_ROCFFT64(rocfft_execution_info_create(&f->info));
+  if (wb) {
+    if (int e = f->work.reserve(wb)) return e;
+    UH_ROCFFT64(rocfft_execution_info_set_work_buffer(f->info, f->work.ptr, wb));
+  }
+  return 0;
+}
+
+// RPYPSE_near::FandG (pse.hip, host, double)
+void rpy_near_FandG(double r, double rh, double psi, double rcut, double *F, double *G);
+
+// NearField Mdot over all pairs with the minimum image (NearField.cuh:134-185): Mv[i] (+)= sum_j F(r) v_j + (G - F) (r.v_j) r / r^2,
+// F and G by linear interpolation of the tabulated closed form (TabulatedFunction.cuh:63-75,148-157)
+__global__ void __launch_bounds__(128) k_pse_near64(const double *__restrict__ pos, const double *__restrict__ v, int vstride, int N, real3d L,
+                                                     double rcut, const double2 *__restrict__ table, int Ntable, double *__restrict__ Mv,
+                                                     bool overwrite) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  const real3d pi{pos[4 * (size_t)i], pos[4 * (size_t)i + 1], pos[4 * (size_t)i + 2]};
+  const double interval = 1.0 / rcut, dr = 1.0 / (double)Ntable, rcut2 = rcut * rcut;
+  double tx = 0, ty = 0, tz = 0;
+  for (int j = 0; j < N; ++j) {
+    real3d rij{pos[4 * (size_t)j] - pi.x, pos[4 * (size_t)j + 1] - pi.y, pos[4 * (size_t)j + 2] - pi.z};
+    rij.y = fma(-L.y, round(rij.y / L.y), rij.y);
+    rij.z = fma(-L.z, round(rij.z / L.z), rij.z);
+    rij.x = fma(-L.x, round(rij.x / L.x), rij.x);
+    const double r2 = dot3(rij, rij);
+    if (r2 >= rcut2) continue;
+    const double rs = sqrt(r2);
+    double f = 0, g = 0;
+    if (!(rs >= rcut)) {
+      const double r = rs * interval;
+      if (r <= 0.0) { f = table[0].x; g = table[0].y; }
+      else {
+        const int t = (int)(r * (double)Ntable);
+        const double r0 = (double)t * dr;
+        const double2 v0 = table[t], v1 = table[t + 1];
+        const double w = (r - r0) * (double)Ntable;
+        f = fma(w, v1.x, fma(-w, v0.x, v0.x));
+        g = fma(w, v1.y, fma(-w, v0.y, v0.y));
+      }
+    }
+    const double vx = v[(size_t)vstride * j], vy = v[(size_t)vstride * j + 1], vz = v[(size_t)vstride * j + 2];
+    if (r2 == 0.0) { tx += f * vx; ty += f * vy; tz += f * vz; }
+    else {
+      const double gmfv = (g - f) * dot3(rij, real3d{vx, vy, vz}) * (1.0 / r2);
+      tx += fma(gmfv, rij.x, f * vx);
+      ty += fma(gmfv, rij.y, f * vy);
+      tz += fma(gmfv, rij.z, f * vz);
+    }
+  }
+  double *o = Mv + 3 * (size_t)i;
+  if (overwrite) { o[0] = tx; o[1] = ty; o[2] = tz; } else { o[0] += tx; o[1] += ty; o[2] += tz; }
+}
+
+struct PSENear64 {
+  DeviceBuffer table;
+  int nPointsTable = 0;
+  double rcut = 0, L[3] = {0, 0, 0};
+};
+
+static double fcm_upsampling64(double tolerance) {  // FCM_kernels.cuh:24-30
+  const double amin = 0.55, amax = 1.65;
+  const double x = -std::log10(3 * tolerance) / 10.0;
+  const double factor = amin + x * (amax - amin);
+  return factor < amax ? factor : amax;
+}
+
+}  // namespace uammd_hip
+
+using namespace uammd_hip;
+
+extern "C" {
+
+// FCM_ns::Kernels::Gaussian(h, tolerance), BDHI/FCM/FCM_kernels.cuh:22-58 over IBM_kernels::Gaussian (misc/IBM_kernels.cuh:28-40)
+int uammd_fcm_gaussian_kernel_f64(double h, double tolerance, uammd_ibm_kernel_f64 *out, double *a_eff) {
+  if (!out || !(h > 0) || !(tolerance > 0)) { set_last_error("uammd_fcm_gaussian_kernel_f64: bad arguments"); return -1; }
+  const double ups = fcm_upsampling64(tolerance), width = h * ups;
+  const double prefactor = std::pow(2.0 * M_PI * width * width, -0.5), tau = -0.5 / (width * width);
+  const double dr = 0.5 * h;
+  double r = dr;
+  while (prefactor * std::exp(tau * r * r) > tolerance) r += dr;
+  int support = (int)(2 * r / h + 0.5);
+  if (support < 3) support = 3;
+  out->kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+  out->support[0] = out->support[1] = out->support[2] = support;
+  out->prefactor = prefactor;
+  out->tau = tau;
+  out->rmax = (double)support * h;
+  out->invh[0] = out->invh[1] = out->invh[2] = 0.0;
+  if (a_eff) *a_eff = (h * ups) * std::sqrt(M_PI);
+  return 0;
+}
+double uammd_fcm_advise_grid_size_f64(double hydrodynamicRadius, double tolerance) {  // FCM_kernels.cuh:47-50
+  return hydrodynamicRadius / (std::sqrt(M_PI) * fcm_upsampling64(tolerance));
+}
+
+// IBM::spread / IBM::gather (misc/IBM.cuh:99-203) on a user-owned grid with interleaved components, LinearIndex3D(nxStride, ny, nz)
+int uammd_ibm_spread_f64(const double *d_pos, int posStride, const double *d_quantity, int ncomp, int N, const double L[3],
+                         const int periodic[3], const int cellDim[3], int nxStride, const uammd_ibm_kernel_f64 *kernel, double *d_grid,
+                         void *stream) {
+  if (int e = check_kernel64("uammd_ibm_spread_f64", kernel)) return e;
+  if (posStride < 3 || (ncomp != 1 && ncomp != 3) || nxStride < cellDim[0]) { set_last_error("uammd_ibm_spread_f64: bad arguments"); return -1; }
+  if (N <= 0) return 0;
+  const GridT<double> g = make_grid<double>(make_box<double>(L, periodic), make_int3(cellDim[0], cellDim[1], cellDim[2]));
+  const bool is2D = g.cellDim.z == 1;  // IBM.cuh:189-194
+  const Kern64 k = to_dev64(*kernel);
+  const FastDiv dsx = make_fastdiv(k.support.x), dsxy = make_fastdiv(k.support.x * k.support.y);
+  const dim3 gr((N + 3) / 4), b(256);
+  if (ncomp == 1)
+    hipLaunchKernelGGL((k_ibm64<1, true>), gr, b, 0, (hipStream_t)stream, d_pos, posStride, d_quantity, 1, (double *)nullptr, d_grid, N, g,
+                       nxStride, (size_t)1, (size_t)1, k, dsx, dsxy, is2D, false);
+  else
+    hipLaunchKernelGGL((k_ibm64<3, true>), gr, b, 0, (hipStream_t)stream, d_pos, posStride, d_quantity, 3, (double *)nullptr, d_grid, N, g,
+                       nxStride, (size_t)3, (size_t)1, k, dsx, dsxy, is2D, false);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+int uammd_ibm_gather_f64(const double *d_pos, int posStride, double *d_out, int ncomp, int N, const double L[3], const int periodic[3],
+                         const int cellDim[3], int nxStride, const uammd_ibm_kernel_f64 *kernel, const double *d_grid, void *stream) {
+  if (int e = check_kernel64("uammd_ibm_gather_f64", kernel)) return e;
+  if (posStride < 3 || (ncomp != 1 && ncomp != 3) || nxStride < cellDim[0]) { set_last_error("uammd_ibm_gather_f64: bad arguments"); return -1; }
+  if (N <= 0) return 0;
+  const GridT<double> g = make_grid<double>(make_box<double>(L, periodic), make_int3(cellDim[0], cellDim[1], cellDim[2]));
+  const bool is2D = g.cellDim.z == 1;
+  const Kern64 k = to_dev64(*kernel);
+  const FastDiv dsx = make_fastdiv(k.support.x), dsxy = make_fastdiv(k.support.x * k.support.y);
+  const dim3 gr((N + 3) / 4), b(256);
+  if (ncomp == 1)
+    hipLaunchKernelGGL((k_ibm64<1, false>), gr, b, 0, (hipStream_t)stream, d_pos, posStride, (const double *)nullptr, 1, d_out,
+                       const_cast<double *>(d_grid), N, g, nxStride, (size_t)1, (size_t)1, k, dsx, dsxy, is2D, false);
+  else
+    hipLaunchKernelGGL((k_ibm64<3, false>), gr, b, 0, (hipStream_t)stream, d_pos, posStride, (const double *)nullptr, 3, d_out,
+                       const_cast<double *>(d_grid), N, g, nxStride, (size_t)3, (size_t)1, k, dsx, dsxy, is2D, false);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// FCM_impl (Integrator/BDHI/FCM/FCM_impl.cuh:56-119): triply periodic, three planar padded grids transformed in place by rocFFT (double)
+int uammd_fcm_create_f64(const uammd_fcm_parameters_f64 *par, uammd_fcm_f64 **out) {
+  if (!par || !out) { set_last_error("uammd_fcm_create_f64: null argument"); return -1; }
+  if (int e = check_kernel64("uammd_fcm_create_f64", &par->kernel)) return e;
+  for (int a = 0; a < 3; ++a)
+    if (par->cells[a] < 2 || par->kernel.support[a] > par->cells[a] || !(par->boxSize[a] > 0)) {
+      set_last_error("uammd_fcm_create_f64: bad grid (cells %d %d %d, support %d)", par->cells[0], par->cells[1], par->cells[2], par->kernel.support[0]);
+      return -2;
+    }
+  FCM64 *f = new FCM64();
+  const int periodic[3] = {1, 1, 1};
+  f->grid = make_grid<double>(make_box<double>(par->boxSize, periodic), make_int3(par->cells[0], par->cells[1], par->cells[2]));
+  f->kern = to_dev64(par->kernel);
+  for (int a = 0; a < 3; ++a) f->L[a] = par->boxSize[a];
+  f->viscosity = par->viscosity;
+  f->nxpad = 2 * (par->cells[0] / 2 + 1);
+  f->planeReal = (size_t)f->nxpad * par->cells[1] * par->cells[2];
+  f->planeCplx = f->planeReal / 2;
+  if (int e = f->gridBuf.reserve(sizeof(double) * 3 * f->planeReal)) { delete f; return e; }
+  if (int e = fcm64_plans(f)) { delete f; return e; }
+  *out = reinterpret_cast<uammd_fcm_f64 *>(f);
+  return 0;
+}
+int uammd_fcm_destroy_f64(uammd_fcm_f64 *h) {
+  delete reinterpret_cast<FCM64 *>(h);
+  return 0;
+}
+// FCM_impl::computeHydrodynamicDisplacements (FCM_impl.cuh:652-693) at T = 0: d_velocity real3[N] = M F (overwritten; a PSE far-field
+// handle ADDS, as FarField does).  d_pos / d_force real4[N].
+int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int N, double *d_velocity, void *stream) {
+  if (!h || (N > 0 && (!d_pos || !d_force || !d_velocity))) { set_last_error("uammd_fcm_displacements_f64: null argument"); return -1; }
+  if (N <= 0) return 0;
+  FCM64 *f = reinterpret_cast<FCM64 *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  double *g = (double *)f->gridBuf.ptr;
+  const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
+  const dim3 gp((N + 3) / 4), bp(256);
+  UH_CHECK(hipMemsetAsync(g, 0, sizeof(double) * 3 * f->planeReal, st));
+  hipLaunchKernelGGL((k_ibm64<3, true>), gp, bp, 0, st, d_pos, 4, d_force, 4, (double *)nullptr, g, N, f->grid, f->nxpad, (size_t)1, f->planeReal,
+                     f->kern, dsx, dsxy, false, false);
+  UH_ROCFFT64(rocfft_execution_info_set_stream(f->info, st));
+  void *bufs[1] = {g};
+  UH_ROCFFT64(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+  const size_t total = f->planeCplx;
+  hipLaunchKernelGGL(k_kspace64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (double2 *)g, f->planeCplx, f->grid.cellDim,
+                     real3d{f->L[0], f->L[1], f->L[2]}, f->viscosity, f->pse);
+  UH_ROCFFT64(rocfft_execute(f->inv, bufs, nullptr, f->info));
+  hipLaunchKernelGGL((k_ibm64<3, false>), gp, bp, 0, st, d_pos, 4, (const double *)nullptr, 3, d_velocity, g, N, f->grid, f->nxpad, (size_t)1,
+                     f->planeReal, f->kern, dsx, dsxy, false, !f->accumulate);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- PSE (Integrator/BDHI/PSE) ------------------------------------------------------------------------------------------------------------
+int uammd_pse_far_raw_cells_f64(const double boxSize[3], double psi, double tolerance, int cells_out[3]) {  // FarField.cuh:646-654
+  if (!boxSize || !cells_out) { set_last_error("uammd_pse_far_raw_cells_f64: null argument"); return -1; }
+  const double kcut = 2 * psi * std::sqrt(-std::log(tolerance));
+  const double hgrid = 2 * M_PI / kcut;
+  for (int k = 0; k < 3; ++k) cells_out[k] = (int)(2 * boxSize[k] / hgrid) + 1;
+  return 0;
+}
+// FarField ctor + initializeKernel (FarField.cuh:318-342,605-644)
+int uammd_pse_far_create_f64(const double boxSize[3], const int cells[3], double viscosity, double hydrodynamicRadius, double tolerance, double psi,
+                             double shearStrain, uammd_fcm_f64 **out, int *support_out, double *eta_out) {
+  if (!boxSize || !cells || !out) { set_last_error("uammd_pse_far_create_f64: null argument"); return -1; }
+  const double C = 0.976;
+  double m = 1;
+  while (std::erfc(m / std::sqrt(2.0)) > 0.1 * tolerance) m += 0.01;
+  int support;
+  while ((support = int(std::pow(m / C, 2) / M_PI + 0.5) + 1) % 2 == 0) m += tolerance;
+  int P = support / 2;
+  const int minCellDim = std::min(cells[0], std::min(cells[1], cells[2]));
+  if (support > minCellDim) {
+    support = minCellDim;
+    if (support % 2 == 0) support--;
+    P = support / 2;
+    m = C * std::sqrt(M_PI * support);
+  }
+  const double pw = 2 * P + 1;
+  const double cs[3] = {boxSize[0] / cells[0], boxSize[1] / cells[1], boxSize[2] / cells[2]};
+  const double hh = std::min(cs[0], std::min(cs[1], cs[2]));
+  const double w = pw * hh / 2.0;
+  const double eta = std::pow(2.0 * psi * w / m, 2);
+  const double width = std::sqrt(eta) / (2.0 * psi);  // pse_ns::Kernel(P, width), FarField.cuh:25-41
+  if (2 * P + 1 > kMaxSupport) { set_last_error("uammd_pse_far_create_f64: support %d above %d", 2 * P + 1, kMaxSupport); return -2; }
+  uammd_fcm_parameters_f64 p{};
+  for (int k = 0; k < 3; ++k) { p.boxSize[k] = boxSize[k]; p.cells[k] = cells[k]; }
+  p.viscosity = viscosity;
+  p.kernel.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+  p.kernel.support[0] = p.kernel.support[1] = p.kernel.support[2] = 2 * P + 1;
+  p.kernel.prefactor = std::cbrt(1.0 / (width * width * width * std::pow(2.0 * M_PI, 1.5)));
+  p.kernel.tau = -0.5 / (width * width);
+  p.kernel.rmax = INFINITY;  // this window is not cut (FarField.cuh:37-39)
+  if (int e = uammd_fcm_create_f64(&p, out)) return e;
+  FCM64 *f = reinterpret_cast<FCM64 *>(*out);
+  f->pse = Pse64{hydrodynamicRadius, psi, eta, shearStrain, true};
+  f->accumulate = true;  // ibm.gather adds into MF (FarField.cuh:563-566)
+  if (support_out) *support_out = 2 * P + 1;
+  if (eta_out) *eta_out = eta;
+  return 0;
+}
+
+// NearField::initializeDeterministicPart (NearField.cuh:65-99) + TabulatedFunction<real2>
+int uammd_pse_near_create_f64(const double boxSize[3], double viscosity, double hydrodynamicRadius, double tolerance, double psi,
+                              uammd_pse_near_f64 **out, double *rcut_out, int *nPointsTable_out) {
+  if (!boxSize || !out) { set_last_error("uammd_pse_near_create_f64: null argument"); return -1; }
+  const double rcut = std::sqrt(-std::log(tolerance)) / psi;
+  if (0.5 * boxSize[0] < rcut) { set_last_error("[BDHI::PSE] Cut off is too large, try increasing psi"); return -2; }
+  const double textureTolerance = hydrodynamicRadius * tolerance;
+  double np = rcut / textureTolerance + 0.5;
+  if (np > 2e30) np = 2e30;
+  unsigned nPointsTable = np >= 4294967295.0 ? 4294967295u : (unsigned)np;
+  nPointsTable = std::min(1u << 22, std::max(1u << 14, nPointsTable));
+  const int Ntable = (int)nPointsTable - 1;
+  const double normalization = 6 * M_PI * hydrodynamicRadius * viscosity;
+  std::vector<double2> host((size_t)Ntable + 1);
+  for (int i = 0; i <= Ntable; ++i) {
+    const double x = (i / (double)Ntable) * rcut;
+    double F, G;
+    rpy_near_FandG(x, hydrodynamicRadius, psi, rcut, &F, &G);
+    host[i] = make_double2(F / normalization, G / normalization);
+  }
+  PSENear64 *p = new PSENear64();
+  for (int k = 0; k < 3; ++k) p->L[k] = boxSize[k];
+  p->rcut = rcut;
+  p->nPointsTable = (int)nPointsTable;
+  if (p->table.reserve(sizeof(double2) * host.size()) ||
+      hipMemcpy(p->table.ptr, host.data(), sizeof(double2) * host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    delete p;
+    set_last_error("uammd_pse_near_create_f64: could not upload the RPY table");
+    return -3;
+  }
+  *out = reinterpret_cast<uammd_pse_near_f64 *>(p);
+  if (rcut_out) *rcut_out = rcut;
+  if (nPointsTable_out) *nPointsTable_out = (int)nPointsTable;
+  return 0;
+}
+int uammd_pse_near_destroy_f64(uammd_pse_near_f64 *h) {
+  delete reinterpret_cast<PSENear64 *>(h);
+  return 0;
+}
+// NearField::Mdot (NearField.cuh:239-250): d_MF real3[N] += M_near F with d_force real4[N] (vstride 4), or a real3 vector (vstride 3)
+int uammd_pse_near_mdot_f64(uammd_pse_near_f64 *h, const double *d_pos, const double *d_v, int vstride, int N, double *d_MF, void *stream) {
+  if (!h || (N > 0 && (!d_pos || !d_v || !d_MF)) || (vstride != 3 && vstride != 4)) { set_last_error("uammd_pse_near_mdot_f64: bad arguments"); return -1; }
+  if (N <= 0) return 0;
+  PSENear64 *p = reinterpret_cast<PSENear64 *>(h);
+  hipLaunchKernelGGL(k_pse_near64, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_pos, d_v, vstride, N,
+                     real3d{p->L[0], p->L[1], p->L[2]}, p->rcut, (const double2 *)p->table.ptr, p->nPointsTable - 1, d_MF, false);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

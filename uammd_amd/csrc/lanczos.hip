@@ -30,43 +30,43 @@ constexpr int kLB = 256;       // threads per block
 constexpr int kLParts = 256;   // reduction partials (one per block)
 constexpr int kLDevM = 32;     // Krylov sizes whose convergence check goes through the host-mapped block (k_l_publish)
 
-struct Lanczos {
+template <class T> struct LanczosT {
   DeviceBuffer V, w, Bold, parts, scal, ycoef;
   int capCols = 0, capN = 0;
   int check_convergence_steps = 3;  // Solver::Solver(), LanczosAlgorithm.cu:175
   int iterationHardLimit = 200;
   int lastRunRequiredSteps = 0;
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
-  uammd_allreduce_fn reduce = nullptr;
+  uammd_allreduce_fn reduce = nullptr;   // (single precision only)
   void *reduceCtx = nullptr;
   bool ownsFirstElement = true;  // the rank that holds global element 0 (the breakdown fallback w = e1)
   // convergence checks without stream synchronisation: the check kernels leave {sequence number, error} in host-mapped memory and the
   // host spins on the sequence number (a hipStreamSynchronize + two small copies cost ~25 us each, four checks per run at the PSE size)
-  volatile float *hostStat = nullptr;
-  float *devStat = nullptr;
+  volatile double *hostStat = nullptr;
+  double *devStat = nullptr;
   unsigned seq = 0;
-  ~Lanczos() { if (hostStat) (void)hipHostFree((void *)hostStat); }
+  ~LanczosT() { if (hostStat) (void)hipHostFree((void *)hostStat); }
 };
 
-UH_D float block_sum(float x, float *sh) {
+template <class T> UH_D T block_sum(T x, T *sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) sh[wv] = x;
   __syncthreads();
-  float t = 0.f;
+  T t = 0;
   if (threadIdx.x < 64) {
-    t = (threadIdx.x < kLB / 64) ? sh[threadIdx.x] : 0.f;
+    t = (threadIdx.x < kLB / 64) ? sh[threadIdx.x] : T(0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   }
   __syncthreads();
   return t;  // valid in wave 0
 }
-UH_D float sum_parts(const float *__restrict__ parts, int nparts, float *sh) {  // every block: same order, same result
-  float x = 0.f;
+template <class T> UH_D T sum_parts(const T *__restrict__ parts, int nparts, T *sh) {  // every block: same order, same result
+  T x = 0;
   for (int k = threadIdx.x; k < nparts; k += kLB) x += parts[k];
-  float t = block_sum(x, sh);
+  T t = block_sum(x, sh);
   if (threadIdx.x == 0) sh[8] = t;
   __syncthreads();
   t = sh[8];
@@ -76,95 +76,102 @@ UH_D float sum_parts(const float *__restrict__ parts, int nparts, float *sh) {  
 
 // scal layout (device floats): [0] = |z|, [1..] hdiag[i] at 1+i, hsup[i] at 1+cap+i
 // parts <- partial sums of x[i]^2
-__global__ void __launch_bounds__(kLB) k_l_norm2(const float *__restrict__ x, int n, float *__restrict__ parts) {
-  __shared__ float sh[16];
-  float a = 0.f;
-  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) a = fmaf(x[i], x[i], a);
-  const float t = block_sum(a, sh);
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_norm2(const T *__restrict__ x, int n, T *__restrict__ parts) {
+  __shared__ T sh[16];
+  T a = T(0);
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) a = fma_(x[i], x[i], a);
+  const T t = block_sum(a, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = t;
 }
 // v0 = z / |z| ; scal[0] = |z|
-__global__ void __launch_bounds__(kLB) k_l_first(const float *__restrict__ z, int n, const float *__restrict__ parts,
-                                                 int nparts, float *__restrict__ v0, float *__restrict__ scal) {
-  __shared__ float sh[16];
-  const float normz = sqrtf(sum_parts(parts, nparts, sh));
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_first(const T *__restrict__ z, int n, const T *__restrict__ parts,
+                                                 int nparts, T *__restrict__ v0, T *__restrict__ scal) {
+  __shared__ T sh[16];
+  const T normz = sqrt_(sum_parts(parts, nparts, sh));
   if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = normz;
-  const float inv = 1.0f / normz;
+  const T inv = T(1) / normz;
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) v0[i] = z[i] * inv;
 }
 // w -= hsup[i-1] * v_(i-1) (if i > 0); parts <- partial w . v_i
-__global__ void __launch_bounds__(kLB) k_l_a(float *__restrict__ w, const float *__restrict__ vprev,
-                                             const float *__restrict__ vi, int n, const float *__restrict__ hsupPrev,
-                                             float *__restrict__ parts) {
-  __shared__ float sh[16];
-  const float hp = hsupPrev ? *hsupPrev : 0.f;
-  float a = 0.f;
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_a(T *__restrict__ w, const T *__restrict__ vprev,
+                                             const T *__restrict__ vi, int n, const T *__restrict__ hsupPrev,
+                                             T *__restrict__ parts) {
+  __shared__ T sh[16];
+  const T hp = hsupPrev ? *hsupPrev : T(0);
+  T a = T(0);
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
-    float x = w[i];
-    if (vprev) { x = fmaf(-hp, vprev[i], x); w[i] = x; }
-    a = fmaf(x, vi[i], a);
+    T x = w[i];
+    if (vprev) { x = fma_(-hp, vprev[i], x); w[i] = x; }
+    a = fma_(x, vi[i], a);
   }
-  const float t = block_sum(a, sh);
+  const T t = block_sum(a, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = t;
 }
 // sharded vectors: parts[0] <- sum of the g partials of this rank (then all-reduced by the caller's callback)
-__global__ void __launch_bounds__(kLB) k_l_collapse(float *__restrict__ parts, int nparts) {
-  __shared__ float sh[16];
-  const float t = sum_parts(parts, nparts, sh);
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_collapse(T *__restrict__ parts, int nparts) {
+  __shared__ T sh[16];
+  const T t = sum_parts(parts, nparts, sh);
   if (threadIdx.x == 0) parts[0] = t;
 }
 // hdiag_i = sum(partsA); w -= hdiag_i * v_i; partsB <- partial |w|^2
-__global__ void __launch_bounds__(kLB) k_l_b(float *__restrict__ w, const float *__restrict__ vi, int n,
-                                             const float *__restrict__ partsA, int nparts, float *__restrict__ hdiag_i,
-                                             float *__restrict__ partsB) {
-  __shared__ float sh[16];
-  const float h = sum_parts(partsA, nparts, sh);
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_b(T *__restrict__ w, const T *__restrict__ vi, int n,
+                                             const T *__restrict__ partsA, int nparts, T *__restrict__ hdiag_i,
+                                             T *__restrict__ partsB) {
+  __shared__ T sh[16];
+  const T h = sum_parts(partsA, nparts, sh);
   if (blockIdx.x == 0 && threadIdx.x == 0) *hdiag_i = h;
-  float a = 0.f;
+  T a = T(0);
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
-    const float x = fmaf(-h, vi[i], w[i]);
+    const T x = fma_(-h, vi[i], w[i]);
     w[i] = x;
-    a = fmaf(x, x, a);
+    a = fma_(x, x, a);
   }
-  const float t = block_sum(a, sh);
+  const T t = block_sum(a, sh);
   if (threadIdx.x == 0) partsB[blockIdx.x] = t;
 }
 // hsup_i = |w| with the breakdown guard; v_(i+1) = w / hsup_i  (or e1)
-__global__ void __launch_bounds__(kLB) k_l_c(const float *__restrict__ w, int n, const float *__restrict__ partsB,
-                                             int nparts, const float *__restrict__ hdiag_i,
-                                             const float *__restrict__ normz, float *__restrict__ hsup_i,
-                                             float *__restrict__ vnext, bool ownsFirstElement) {
-  __shared__ float sh[16];
-  float hs = sqrtf(sum_parts(partsB, nparts, sh));
-  const float tol = 1e-3f * (*hdiag_i) / (*normz);
-  if (hs < tol) hs = 0.0f;
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_c(const T *__restrict__ w, int n, const T *__restrict__ partsB,
+                                             int nparts, const T *__restrict__ hdiag_i,
+                                             const T *__restrict__ normz, T *__restrict__ hsup_i,
+                                             T *__restrict__ vnext, bool ownsFirstElement) {
+  __shared__ T sh[16];
+  T hs = sqrt_(sum_parts(partsB, nparts, sh));
+  const T tol = T(1e-3) * (*hdiag_i) / (*normz);
+  if (hs < tol) hs = T(0);
   if (blockIdx.x == 0 && threadIdx.x == 0) *hsup_i = hs;
-  const float inv = hs > 0.0f ? 1.0f / hs : 0.0f;
+  const T inv = hs > T(0) ? T(1) / hs : T(0);
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB)
-    vnext[i] = hs > 0.0f ? w[i] * inv : ((i == 0 && ownsFirstElement) ? 1.0f : 0.0f);
+    vnext[i] = hs > T(0) ? w[i] * inv : ((i == 0 && ownsFirstElement) ? T(1) : T(0));
 }
 // Bz = |z| * V[:, :m] * y ; partials of |Bold|^2 and |Bz - Bold|^2 ; then Bold <- Bz
-__global__ void __launch_bounds__(kLB) k_l_estimate(const float *__restrict__ V, int n, int m,
-                                                    const float *__restrict__ y, const float *__restrict__ normz,
-                                                    float *__restrict__ Bz, float *__restrict__ Bold,
-                                                    float *__restrict__ parts) {
-  __shared__ float sh[16];
-  const float nz = *normz;
-  float a = 0.f, b = 0.f;
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_estimate(const T *__restrict__ V, int n, int m,
+                                                    const T *__restrict__ y, const T *__restrict__ normz,
+                                                    T *__restrict__ Bz, T *__restrict__ Bold,
+                                                    T *__restrict__ parts) {
+  __shared__ T sh[16];
+  const T nz = *normz;
+  T a = T(0), b = T(0);
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
-    float s = 0.f;
-    for (int c = 0; c < m; ++c) s = fmaf(V[(size_t)c * n + i], y[c], s);
+    T s = T(0);
+    for (int c = 0; c < m; ++c) s = fma_(V[(size_t)c * n + i], y[c], s);
     s *= nz;
-    const float o = Bold[i];
-    a = fmaf(o, o, a);
-    const float d = s - o;
-    b = fmaf(d, d, b);
+    const T o = Bold[i];
+    a = fma_(o, o, a);
+    const T d = s - o;
+    b = fma_(d, d, b);
     Bz[i] = s;
     Bold[i] = s;
   }
-  const float ta = block_sum(a, sh);
+  const T ta = block_sum(a, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = ta;
-  const float tb = block_sum(b, sh);
+  const T tb = block_sum(b, sh);
   if (threadIdx.x == 0) parts[kLParts + blockIdx.x] = tb;
 }
 
@@ -175,7 +182,8 @@ __global__ void __launch_bounds__(kLB) k_l_estimate(const float *__restrict__ V,
 // reads them: the GPU never waits for a launch.  (The poll is bounded: a host that never answers makes the kernel give up with an error flag.)
 // mapped block (floats): [0] seqA (scalars published)  [1] seqB (error published)  [2] err  [3] status  [4] seqY (host: y ready)
 //                        [8 .. 8+32) y   [64 .. 64+32) hdiag   [96 .. 96+32) hsup
-__global__ void k_l_publish(const float *__restrict__ hdiag, const float *__restrict__ hsup, int m, volatile float *__restrict__ stat, float seq) {
+template <class T>
+__global__ void k_l_publish(const T *__restrict__ hdiag, const T *__restrict__ hsup, int m, volatile double *__restrict__ stat, double seq) {
   const int k = threadIdx.x;
   if (k < m) { stat[64 + k] = hdiag[k]; stat[96 + k] = hsup[k]; }
   __threadfence_system();
@@ -184,24 +192,26 @@ __global__ void k_l_publish(const float *__restrict__ hdiag, const float *__rest
 }
 // ONE thread waits for the host's coefficients and hands them to device memory (256 workgroups polling host memory over the bus at once
 // delayed the very write they were waiting for: 146 us per check)
-__global__ void k_l_relay(volatile float *__restrict__ stat, int m, float seq, float *__restrict__ ycoef) {
+template <class T>
+__global__ void k_l_relay(volatile double *__restrict__ stat, int m, double seq, T *__restrict__ ycoef) {
   __shared__ int ok;
   if (threadIdx.x == 0) {
     long spins = 0;
     while (stat[4] != seq && ++spins < 20000000L) __builtin_amdgcn_s_sleep(8);
     ok = stat[4] == seq;
-    if (!ok) stat[3] = -1.0f;
+    if (!ok) stat[3] = -1.0;
   }
   __syncthreads();
-  if ((int)threadIdx.x < m) ycoef[threadIdx.x] = ok ? stat[8 + threadIdx.x] : 0.0f;
+  if ((int)threadIdx.x < m) ycoef[threadIdx.x] = ok ? (T)stat[8 + threadIdx.x] : T(0);
 }
 // err = |Bz - Bold| / |Bold| from the estimate's partials, left with a sequence number where the host can see it
-__global__ void __launch_bounds__(kLB) k_l_error(const float *__restrict__ parts, int nparts, float *__restrict__ stat, float seq) {
-  __shared__ float sh[16];
-  const float a = sum_parts(parts, nparts, sh);
-  const float b = sum_parts(parts + kLParts, nparts, sh);
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_error(const T *__restrict__ parts, int nparts, double *__restrict__ stat, double seq) {
+  __shared__ T sh[16];
+  const T a = sum_parts(parts, nparts, sh);
+  const T b = sum_parts(parts + kLParts, nparts, sh);
   if (threadIdx.x == 0) {
-    stat[2] = fabsf(sqrtf(b) / sqrtf(a));
+    stat[2] = fabs(sqrt_(b) / sqrt_(a));
     __threadfence_system();
     stat[1] = seq;
   }
@@ -252,6 +262,7 @@ static int tridiag_ql(std::vector<double> &d, std::vector<double> &e, std::vecto
   return 0;
 }
 
+using Lanczos = LanczosT<float>;
 static inline int lgrid(int n) { return std::min(kLParts, (n + kLB - 1) / kLB); }
 
 }  // namespace uammd_hip
@@ -289,73 +300,74 @@ int uammd_lanczos_set_allreduce(uammd_lanczos *h, uammd_allreduce_fn reduce, voi
   return 0;
 }
 
-int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance,
-                      int n, void *stream, int *iterations) {
-  if (!hh || !dot || !d_Bv || !d_v || n < 1) { set_last_error("uammd_lanczos_run: bad arguments"); return -1; }
-  Lanczos *L = reinterpret_cast<Lanczos *>(hh);
+}  // extern "C"
+
+template <class T, class MatVec>
+static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *d_v, T tolerance, int n, void *stream, int *iterations) {
+  if (!L || !dot || !d_Bv || !d_v || n < 1) { set_last_error("uammd_lanczos_run: bad arguments"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   const int cap = L->iterationHardLimit + 2;
   if (L->capCols < cap || L->capN < n) {
     UH_CHECK(hipStreamSynchronize(st));
-    if (int e = L->V.reserve(sizeof(float) * (size_t)n * cap)) return e;
-    if (int e = L->w.reserve(sizeof(float) * (size_t)n)) return e;
-    if (int e = L->Bold.reserve(sizeof(float) * (size_t)n)) return e;
-    if (int e = L->parts.reserve(sizeof(float) * 2 * kLParts)) return e;
-    if (int e = L->scal.reserve(sizeof(float) * (2 * cap + 2))) return e;
-    if (int e = L->ycoef.reserve(sizeof(float) * cap)) return e;
+    if (int e = L->V.reserve(sizeof(T) * (size_t)n * cap)) return e;
+    if (int e = L->w.reserve(sizeof(T) * (size_t)n)) return e;
+    if (int e = L->Bold.reserve(sizeof(T) * (size_t)n)) return e;
+    if (int e = L->parts.reserve(sizeof(T) * 2 * kLParts)) return e;
+    if (int e = L->scal.reserve(sizeof(T) * (2 * cap + 2))) return e;
+    if (int e = L->ycoef.reserve(sizeof(T) * cap)) return e;
     L->capCols = cap;
     L->capN = n;
   }
-  float *V = (float *)L->V.ptr, *w = (float *)L->w.ptr, *Bold = (float *)L->Bold.ptr, *parts = (float *)L->parts.ptr;
-  float *scal = (float *)L->scal.ptr, *ycoef = (float *)L->ycoef.ptr;
-  float *hdiag = scal + 1, *hsup = scal + 1 + cap;
+  T *V = (T *)L->V.ptr, *w = (T *)L->w.ptr, *Bold = (T *)L->Bold.ptr, *parts = (T *)L->parts.ptr;
+  T *scal = (T *)L->scal.ptr, *ycoef = (T *)L->ycoef.ptr;
+  T *hdiag = scal + 1, *hsup = scal + 1 + cap;
   const int g = lgrid(n);
   // with sharded vectors a finished set of partials is collapsed to one number and summed over the ranks; the consumers
   // then "re-sum" a single partial
   const int np = L->reduce ? 1 : g;
-  auto complete = [&](float *p) -> int {
+  auto complete = [&](T *p) -> int {
     if (!L->reduce) return 0;
-    hipLaunchKernelGGL(k_l_collapse, dim3(1), dim3(kLB), 0, st, p, g);
-    return L->reduce(L->reduceCtx, p, 1, stream);
+    hipLaunchKernelGGL(k_l_collapse<T>, dim3(1), dim3(kLB), 0, st, p, g);
+    return L->reduce(L->reduceCtx, (float *)p, 1, stream);   // (reduce is only ever set on the float solver)
   };
-  UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(float) * (size_t)n, st));   // oldBz = 0, :205-206
-  hipLaunchKernelGGL(k_l_norm2, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
+  UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(T) * (size_t)n, st));   // oldBz = 0, :205-206
+  hipLaunchKernelGGL(k_l_norm2<T>, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
   if (int rc = complete(parts)) return rc;
-  hipLaunchKernelGGL(k_l_first, dim3(g), dim3(kLB), 0, st, d_v, n, (const float *)parts, np, V, scal);
+  hipLaunchKernelGGL(k_l_first<T>, dim3(g), dim3(kLB), 0, st, d_v, n, (const T *)parts, np, V, scal);
   const int checkConvergenceSteps = std::min(L->check_convergence_steps, L->iterationHardLimit - 2);
-  std::vector<float> hbuf(2 * cap + 2);
+  std::vector<T> hbuf(2 * cap + 2);
   std::vector<double> dd, ee, zz;
-  std::vector<float> yy;
+  std::vector<T> yy;
   for (int i = 0; i < L->iterationHardLimit; ++i) {
-    float *vi = V + (size_t)i * n;
+    T *vi = V + (size_t)i * n;
     if (int rc = dot(ctx, vi, w, n, stream)) {
       if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the matrix-vector callback failed (%d)", rc);
       return rc;
     }
-    hipLaunchKernelGGL(k_l_a, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const float *)(V + (size_t)(i - 1) * n) : nullptr,
-                       (const float *)vi, n, i > 0 ? (const float *)(hsup + i - 1) : nullptr, parts);
+    hipLaunchKernelGGL(k_l_a<T>, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const T *)(V + (size_t)(i - 1) * n) : nullptr,
+                       (const T *)vi, n, i > 0 ? (const T *)(hsup + i - 1) : nullptr, parts);
     if (int rc = complete(parts)) return rc;
-    hipLaunchKernelGGL(k_l_b, dim3(g), dim3(kLB), 0, st, w, (const float *)vi, n, (const float *)parts, np, hdiag + i,
+    hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, w, (const T *)vi, n, (const T *)parts, np, hdiag + i,
                        parts + kLParts);
     if (int rc = complete(parts + kLParts)) return rc;
-    hipLaunchKernelGGL(k_l_c, dim3(g), dim3(kLB), 0, st, (const float *)w, n, (const float *)(parts + kLParts), np,
-                       (const float *)(hdiag + i), (const float *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
+    hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)w, n, (const T *)(parts + kLParts), np,
+                       (const T *)(hdiag + i), (const T *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
     if (i >= checkConvergenceSteps && !L->reduce && i + 1 <= kLDevM) {
       const int m = i + 1;
       if (!L->hostStat) {
         UH_CHECK(hipHostMalloc((void **)&L->hostStat, 1024, hipHostMallocMapped | hipHostMallocCoherent));
-        for (int k = 0; k < 256; ++k) L->hostStat[k] = 0.f;
+        for (int k = 0; k < 128; ++k) L->hostStat[k] = 0.0;
         UH_CHECK(hipHostGetDevicePointer((void **)&L->devStat, (void *)L->hostStat, 0));
       }
       L->seq = (L->seq % 1000000u) + 1u;
-      const float seq = (float)L->seq;
-      volatile float *hs = L->hostStat;
-      hs[3] = 0.f;
-      hipLaunchKernelGGL(k_l_publish, dim3(1), dim3(64), 0, st, (const float *)hdiag, (const float *)hsup, m, L->devStat, seq);
-      hipLaunchKernelGGL(k_l_relay, dim3(1), dim3(64), 0, st, L->devStat, m, seq, ycoef);
-      hipLaunchKernelGGL(k_l_estimate, dim3(g), dim3(kLB), 0, st, (const float *)V, n, m, (const float *)ycoef,
-                         (const float *)scal, d_Bv, Bold, parts);
-      hipLaunchKernelGGL(k_l_error, dim3(1), dim3(kLB), 0, st, (const float *)parts, g, L->devStat, seq);
+      const double seq = (double)L->seq;
+      volatile double *hs = L->hostStat;
+      hs[3] = 0.0;
+      hipLaunchKernelGGL(k_l_publish<T>, dim3(1), dim3(64), 0, st, (const T *)hdiag, (const T *)hsup, m, L->devStat, seq);
+      hipLaunchKernelGGL(k_l_relay<T>, dim3(1), dim3(64), 0, st, L->devStat, m, seq, ycoef);
+      hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef,
+                         (const T *)scal, d_Bv, Bold, parts);
+      hipLaunchKernelGGL(k_l_error<T>, dim3(1), dim3(kLB), 0, st, (const T *)parts, g, L->devStat, seq);
       auto wait = [&](int slot) -> int {
         long spins = 0;
         while (hs[slot] != seq)
@@ -375,7 +387,7 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
       for (int r = 0; r < m; ++r) {
         double acc = 0.0;
         for (int j = 0; j < m; ++j) acc += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
-        hs[8 + r] = (float)acc;
+        hs[8 + r] = (double)(T)acc;
       }
       __atomic_thread_fence(__ATOMIC_RELEASE);
       hs[4] = seq;   // the queued estimate kernel goes ahead (also after a failed diagonalisation: it must not be left waiting)
@@ -390,9 +402,9 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
         set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
         return -20;
       }
-      if (hs[3] != 0.f) { set_last_error("[Lanczos] the estimate kernel gave up waiting for the host's coefficients"); return -23; }
+      if (hs[3] != 0.0) { set_last_error("[Lanczos] the estimate kernel gave up waiting for the host's coefficients"); return -23; }
       if (i > 0) {
-        const float err = hs[2];
+        const T err = (T)hs[2];
         if (std::isnan(err)) {
           set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
           return -21;
@@ -408,7 +420,7 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
       }
     } else if (i >= checkConvergenceSteps) {
       const int m = i + 1;
-      UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(float) * (2 * cap + 1), hipMemcpyDeviceToHost, st));
+      UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(T) * (2 * cap + 1), hipMemcpyDeviceToHost, st));
       UH_CHECK(hipStreamSynchronize(st));
       dd.assign(m, 0.0);
       ee.assign(m, 0.0);
@@ -419,25 +431,25 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
         set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
         return -20;
       }
-      yy.assign(m, 0.f);
+      yy.assign(m, T(0));
       // H^(1/2) e1 = P * (sqrt(lambda_j) * P[0][j])   (:64-82); a negative eigenvalue gives NaN as in the reference
       for (int r = 0; r < m; ++r) {
         double s = 0.0;
         for (int j = 0; j < m; ++j) s += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
-        yy[r] = (float)s;
+        yy[r] = (T)s;
       }
-      UH_CHECK(hipMemcpyAsync(ycoef, yy.data(), sizeof(float) * m, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_l_estimate, dim3(g), dim3(kLB), 0, st, (const float *)V, n, m, (const float *)ycoef,
-                         (const float *)scal, d_Bv, Bold, parts);
+      UH_CHECK(hipMemcpyAsync(ycoef, yy.data(), sizeof(T) * m, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef,
+                         (const T *)scal, d_Bv, Bold, parts);
       if (i > 0) {
         if (int rc = complete(parts)) return rc;
         if (int rc = complete(parts + kLParts)) return rc;
-        float hp[2 * kLParts];
-        UH_CHECK(hipMemcpyAsync(hp, parts, sizeof(float) * 2 * kLParts, hipMemcpyDeviceToHost, st));
+        T hp[2 * kLParts];
+        UH_CHECK(hipMemcpyAsync(hp, parts, sizeof(T) * 2 * kLParts, hipMemcpyDeviceToHost, st));
         UH_CHECK(hipStreamSynchronize(st));
         double a = 0.0, b = 0.0;
         for (int k = 0; k < np; ++k) { a += hp[k]; b += hp[kLParts + k]; }
-        const float err = std::fabs((float)(std::sqrt(b) / std::sqrt(a)));
+        const T err = (T)std::fabs(std::sqrt(b) / std::sqrt(a));
         if (std::isnan(err)) {
           set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
           return -21;
@@ -457,6 +469,40 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
   UH_CHECK(hipGetLastError());
   set_last_error("[Lanczos] Could not converge");
   return -22;
+}
+
+
+extern "C" {
+
+int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance, int n, void *stream,
+                      int *iterations) {
+  return lanczos_run<float>(reinterpret_cast<Lanczos *>(hh), dot, ctx, d_Bv, d_v, tolerance, n, stream, iterations);
+}
+
+// ---- DOUBLE_PRECISION build (global/defines.h:9-11): lanczos::Solver with real = double, e.g. the reference's own test
+// (test/misc/lanczos/test_lanczos.cu, tolerance 1e-7) on the GPU ----
+int uammd_lanczos_create_f64(uammd_lanczos_f64 **out) {
+  if (!out) { set_last_error("uammd_lanczos_create_f64: null output"); return -1; }
+  *out = reinterpret_cast<uammd_lanczos_f64 *>(new LanczosT<double>());
+  return 0;
+}
+int uammd_lanczos_destroy_f64(uammd_lanczos_f64 *h) {
+  delete reinterpret_cast<LanczosT<double> *>(h);
+  return 0;
+}
+int uammd_lanczos_set_iteration_hard_limit_f64(uammd_lanczos_f64 *h, int limit) {
+  if (!h || limit < 1) { set_last_error("uammd_lanczos_set_iteration_hard_limit_f64: bad arguments"); return -1; }
+  reinterpret_cast<LanczosT<double> *>(h)->iterationHardLimit = limit;
+  return 0;
+}
+int uammd_lanczos_get_last_run_required_steps_f64(uammd_lanczos_f64 *h, int *steps) {
+  if (!h || !steps) { set_last_error("uammd_lanczos_get_last_run_required_steps_f64: null argument"); return -1; }
+  *steps = reinterpret_cast<LanczosT<double> *>(h)->lastRunRequiredSteps;
+  return 0;
+}
+int uammd_lanczos_run_f64(uammd_lanczos_f64 *hh, uammd_matvec_fn_f64 dot, void *ctx, double *d_Bv, const double *d_v, double tolerance, int n,
+                          void *stream, int *iterations) {
+  return lanczos_run<double>(reinterpret_cast<LanczosT<double> *>(hh), dot, ctx, d_Bv, d_v, tolerance, n, stream, iterations);
 }
 
 }  // extern "C"

@@ -43,7 +43,7 @@ struct PSENear {
 };
 
 // the closed form of eq. A3-A4 of Fiore et al. 2017 as the reference evaluates it (coefficient sets f0..f7, g0..g7)
-static void rpy_near_FandG(double r, double rh, double psi, double rcut, double *F, double *G) {
+void rpy_near_FandG(double r, double rh, double psi, double rcut, double *F, double *G) {  // (also used by the double-precision build, f64.hip)
   *F = *G = 0.0;
   if (r >= rcut) return;
   const double spi = std::sqrt(M_PI);
