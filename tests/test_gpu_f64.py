@@ -1,0 +1,237 @@
+"""The reference's double-precision known answers ON THE GPU, at the reference's own tolerances, through the DOUBLE_PRECISION build of the
+library (the `_f64` entry points of include/uammd_hip.h; global/defines.h:9-11 makes `real` a build switch and test/CMakeLists.txt:9 /
+test/BDHI/FCM/Makefile:9 compile the reference's tests with it):
+
+  test/misc/ibm/test_ibm_regular.cu:16-64     constant window: 27 / 27 / 8 nodes                                  exact
+  test/misc/ibm/test_ibm_regular.cu:113-136   Peskin spreading against the brute-force weights                    1e-10
+  test/misc/ibm/test_ibm_regular.cu:240-274   interpolation of a random field, 128 particles, 32^3                1e-10
+  test/BDHI/FCM/fcm_test.cu:85-144            Hasimoto self mobility, tolerance 1e-8, L = 96 h ceil(a/h) = 288^3   1e-8
+  test/misc/lanczos/test_lanczos.cu:34-93,236-269   identity, 2 I in <= 5 steps, dense SPD operator M^2 -> M v     1e-7
+  test/BDHI/PSE/pse_test.cu:64-117            PSE self mobility = Hasimoto, tolerance 1e-8, L = 128 a, psi = 1      1e-8
+
+plus the same kernels against the double-precision oracle on random inputs (1e-12: same arithmetic, another summation order)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def f64(hip):
+    from uammd_amd import f64 as m
+    return m
+
+
+def _peskin3(h):
+    def phi(rr):
+        r = abs(rr) / h
+        if r < 0.5:
+            return (1 + math.sqrt(1 - 3 * r * r)) / (3 * h)
+        if r < 1.5:
+            return (5 - 3 * r - math.sqrt(1 - 3 * (1 - r) ** 2)) / (6 * h)
+        return 0.0
+    return phi
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def test_constant_kernel_counts(f64):
+    """test_ibm_regular.cu:16-64."""
+    k = f64.Kernels.Constant(3)
+    for L, pos, per, expect in [(1.0, (0, 0, 0), 1, 27), (3.0, (-1, -1, -1), 1, 27), (3.0, (-1, -1, -1), 0, 8)]:
+        ibm = f64.IBM(k, L, per, [3, 3, 3])
+        g = torch.zeros((3, 3, 3), dtype=torch.float64, device="cuda")
+        ibm.spread(_dev([pos]), _dev([1.0]), g)
+        assert float(g.sum()) == expect
+
+
+def test_peskin_spread_bruteforce(f64):
+    """test_ibm_regular.cu:113-136, tolerance 1e-10."""
+    n, L = 8, 16.0
+    h = L / n
+    ibm = f64.IBM(f64.Kernels.Peskin3pt(h), L, 1, [n] * 3)
+    g = torch.zeros((n, n, n), dtype=torch.float64, device="cuda")
+    ibm.spread(_dev(np.zeros((1, 3))), _dev([1.0]), g)
+    phi = _peskin3(h)
+    w = np.array([phi(-L / 2 + (i + 0.5) * h) for i in range(n)])
+    assert np.abs(g.cpu().numpy() - w[:, None, None] * w[None, :, None] * w[None, None, :]).max() <= 1e-10
+
+
+def test_interpolation_random_field(f64):
+    """test_ibm_regular.cu:240-274: 128 particles kept 2 h from the faces, 32^3, random field, against brute force, 1e-10."""
+    n, L, N = 32, 16.0, 128
+    h = L / n
+    rng = np.random.default_rng(123)
+    pos = rng.uniform(-L / 2 + 2 * h, L / 2 - 2 * h, (N, 3))
+    field = rng.uniform(-L / 2 + 2 * h, L / 2 - 2 * h, (n, n, n))
+    ibm = f64.IBM(f64.Kernels.Peskin3pt(h), L, 1, [n] * 3)
+    out = torch.zeros(N, dtype=torch.float64, device="cuda")
+    ibm.gather(_dev(pos), out, _dev(field))
+    out = out.cpu().numpy()
+    phi = _peskin3(h)
+    c = -L / 2 + (np.arange(n) + 0.5) * h
+    for i in range(N):
+        wx = np.array([phi(x - pos[i, 0]) for x in c]); wy = np.array([phi(y - pos[i, 1]) for y in c])
+        wz = np.array([phi(z - pos[i, 2]) for z in c])
+        exp = np.einsum("k,j,i,kji->", wz, wy, wx, field) * h ** 3
+        assert abs(out[i] - exp) <= 1e-10
+
+
+@pytest.mark.parametrize("kind", ["gaussian-tol1e-8", "peskin4", "gaussian-3comp-nonperiodic"])
+def test_ibm_against_the_double_oracle(f64, o64, kind):
+    rng = np.random.default_rng(5)
+    cells, L, per = [24, 20, 28], np.array([12.0, 10.0, 14.0]), 1
+    N, ncomp = 300, 1
+    if kind == "gaussian-tol1e-8":
+        kg, _ = f64.Kernels.Gaussian(0.5, 1e-8)
+        ko = o64.fcm_gaussian(0.5, 1e-8)["kernel"]
+    elif kind == "peskin4":
+        kg = f64.Kernels.Peskin4pt(L / np.asarray(cells))
+        ko = o64.ibm_kernel("peskin4", 4, invh=list(np.asarray(cells) / L))
+    else:
+        kg, _ = f64.Kernels.Gaussian(0.5, 1e-4)
+        ko = o64.fcm_gaussian(0.5, 1e-4)["kernel"]
+        per, ncomp = [1, 0, 1], 3
+    pos = rng.uniform(-0.5, 0.5, (N, 3)) * L * 1.2        # some outside the primary box
+    if kind == "gaussian-3comp-nonperiodic":
+        pos[:, 1] = rng.uniform(-0.5, 0.5, N) * L[1] * 0.99
+    q = rng.normal(0, 1, (N, ncomp))
+    shape = (cells[2], cells[1], cells[0], ncomp)
+    ibm = f64.IBM(kg, L, per, cells)
+    g = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    ibm.spread(_dev(pos), _dev(q if ncomp > 1 else q[:, 0]), g)
+    ref = o64.ibm_spread(pos, q, L, per, cells, ko)
+    assert np.abs(g.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    field = rng.normal(0, 1, shape)
+    out = torch.zeros((N, ncomp) if ncomp > 1 else (N,), dtype=torch.float64, device="cuda")
+    ibm.gather(_dev(pos), out, _dev(field))
+    refg = o64.ibm_gather(pos, field, L, per, cells, ko)
+    assert np.abs(out.cpu().numpy().reshape(N, ncomp) - refg).max() <= 1e-12 * np.abs(refg).max()
+
+
+def _mobility_error(f64, o64, mult, positions):
+    """fcm_test.cu:85-144: a = 1.012312, eta = 1.12321, tolerance 1e-8, h from adviseGridSize, L = mult h ceil(a / h), positions from
+    Saru(1234).f(-0.5, 0.5) L, unit force along each axis, the pulled particle must move with the Hasimoto mobility."""
+    a, eta, tol = 1.012312, 1.12321, 1e-8
+    h = f64.Kernels.adviseGridSize(a, tol)
+    L = mult * h * math.ceil(a / h)
+    cells = int(L / h)
+    k, a_eff = f64.Kernels.Gaussian(L / cells, tol)
+    assert abs(a_eff - a) < 1e-12 and k.support[0] == 17
+    fcm = f64.FCM_impl(L, [cells] * 3, k, eta, a_eff)
+    m0 = fcm.getSelfMobility()
+    u = o64.saru_f_range(1234, -0.5, 0.5, 3 * positions).reshape(positions, 3)       # the reference's own random positions
+    worst = 0.0
+    for j in range(positions):
+        for d in range(3):
+            f = np.zeros((1, 4)); f[0, d] = 1.0
+            v = fcm.computeHydrodynamicDisplacements(_dev([[u[j, 0] * L, u[j, 1] * L, u[j, 2] * L, 0.0]]), _dev(f)).cpu().numpy()[0]
+            exp = np.zeros(3); exp[d] = m0
+            worst = max(worst, np.abs(v - exp).max())
+    return worst, cells
+
+
+def test_fcm_hasimoto_self_mobility_reference_configuration(f64, o64):
+    """EXACTLY fcm_test.cu:85-144: 288^3 grid (3 x 288^3 doubles = 573 MB), support 17, error <= 1e-8, the reference's ten positions."""
+    worst, cells = _mobility_error(f64, o64, 96, 10)
+    print(f"[f64 FCM Hasimoto, {cells}^3] max |M - M0| = {worst:.2e}")
+    assert cells == 288 and worst <= 1e-8
+
+
+def test_fcm_against_the_double_oracle(f64, o64):
+    from oracle.fcm import FCMOracle
+    cells, L, n, tol, eta = [40, 36, 48], np.array([20.0, 18.0, 24.0]), 500, 1e-6, 0.9
+    rng = np.random.default_rng(9)
+    pos = np.zeros((n, 4)); pos[:, :3] = rng.uniform(-0.7, 0.7, (n, 3)) * L
+    force = np.zeros((n, 4)); force[:, :3] = rng.normal(0, 1, (n, 3))
+    h = float(min(L / np.asarray(cells)))
+    k, a_eff = f64.Kernels.Gaussian(h, tol)
+    fcm = f64.FCM_impl(L, cells, k, eta, a_eff)
+    v = fcm.computeHydrodynamicDisplacements(_dev(pos), _dev(force)).cpu().numpy()
+    ref = FCMOracle(o64, L, cells, tolerance=tol, viscosity=eta).displacements(pos, force)
+    assert np.linalg.norm(v - ref) <= 1e-11 * np.linalg.norm(ref)
+
+
+def _dense_case(size):
+    from oracle.lanczos import std_mt19937_uniform_real
+    A = std_mt19937_uniform_real(29374238, size * size, 0.0, 1.0).reshape(size, size)
+    M = 0.5 * (A + A.T) + 5 * size * np.eye(size)
+    return M, M @ M.T, std_mt19937_uniform_real(1234567, size, -10.0, 10.0)
+
+
+def test_lanczos_reference_tests(f64):
+    """test_lanczos.cu: identity and 2 I for every size up to 128 (2 I in <= 5 steps), random diagonal matrices, and the dense SPD
+    operator M M^T whose square root applied to v is M v — all to the reference's 1e-7, with the reference's mt19937 inputs."""
+    from oracle.lanczos import std_mt19937_uniform_real
+    solver = f64.LanczosSolver()
+    for scale, expect in ((1.0, 1.0), (2.0, math.sqrt(2.0))):
+        for size in list(range(1, 40)) + [64, 127, 128]:
+            v, Bv = _dev(np.ones(size)), torch.zeros(size, dtype=torch.float64, device="cuda")
+            it = solver.run(lambda x, y: y.copy_(scale * x), Bv, v, 1e-7)
+            assert np.abs(Bv.cpu().numpy() - expect).max() <= 1e-7, (scale, size)
+            if scale == 2.0:
+                assert it <= 5 and solver.getLastRunRequiredSteps() <= 5          # test_lanczos.cu:78-93
+    m = std_mt19937_uniform_real(29374238, 128, 1.0, 2.0)
+    for size in (1, 2, 3, 17, 64, 100, 127):
+        d, v = _dev(m[:size]), std_mt19937_uniform_real(1234567, size, -10.0, 10.0)
+        Bv = torch.zeros(size, dtype=torch.float64, device="cuda")
+        solver.run(lambda x, y: torch.mul(d, x, out=y), Bv, _dev(v), 1e-7)
+        theory = np.sqrt(m[:size]) * v
+        assert np.abs((Bv.cpu().numpy() - theory) / theory).max() <= 1e-7, size
+    for size in (1, 2, 5, 31, 64, 65, 128, 200, 255, 256, 300, 511):                     # test_lanczos.cu:236-269
+        M, M2, v = _dense_case(size)
+        dM2, Bv = _dev(M2), torch.zeros(size, dtype=torch.float64, device="cuda")
+        solver.run(lambda x, y: torch.mv(dM2, x, out=y), Bv, _dev(v), 1e-7)
+        theory = M @ v
+        assert np.abs((Bv.cpu().numpy() - theory) / theory).max() <= 1e-7, size
+
+
+def test_lanczos_golden_vector(f64):
+    """tests/golden/lanczos_dense.npz: Bv and the iteration count of the double-precision solve."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lanczos_dense.npz"))
+    dM2, Bv = _dev(g["M2"]), torch.zeros(int(g["size"]), dtype=torch.float64, device="cuda")
+    it = f64.LanczosSolver().run(lambda x, y: torch.mv(dM2, x, out=y), Bv, _dev(g["v"]), float(g["tolerance_f64"]))
+    assert it == int(g["iterations_f64"])
+    assert np.abs(Bv.cpu().numpy() - g["Bv_f64"]).max() <= 1e-11 * np.abs(g["Bv_f64"]).max()
+
+
+RH, VISC = 1.012312, 1.12321
+
+
+def test_pse_self_mobility_reference_configuration(f64, o64):
+    """pse_test.cu:64-117: tolerance 1e-8, L = 128 a, psi = 1 (360^3 far-field grid, support 13: 1.1 GB of doubles), one particle at
+    the reference's Saru(1234) position pulled along x, y and z: M F = Hasimoto's mobility within the tolerance."""
+    L = 128 * RH
+    p = f64.PSE(L, VISC, RH, 1e-8, 1.0)
+    m0 = p.getSelfMobility()
+    u = o64.saru_f_range(1234, -0.5, 0.5, 3)
+    pos = np.zeros((1, 4)); pos[0, :3] = u * L
+    worst = 0.0
+    for d in range(3):
+        f = np.zeros((1, 4)); f[0, d] = 1.0
+        MF = p.computeMF(_dev(pos), _dev(f)).cpu().numpy()[0]
+        exp = np.zeros(3); exp[d] = m0
+        worst = max(worst, np.abs(MF - exp).max())
+    print(f"[f64 PSE self mobility, grid {p.cells}, support {p.support}] max |M - M0| = {worst:.2e}")
+    assert list(p.cells) == [360, 360, 360] and worst <= 1e-8
+
+
+def test_pse_against_the_double_oracle(f64, o64):
+    from oracle.pse import PSEOracle
+    L, n, tol, psi = 24.0, 60, 1e-6, 0.8
+    rng = np.random.default_rng(3)
+    pos = np.zeros((n, 4)); pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    f = np.zeros((n, 4)); f[:, :3] = rng.normal(0, 1, (n, 3))
+    p = f64.PSE(L, VISC, RH, tol, psi)
+    ref = PSEOracle(o64, [L] * 3, RH, VISC, tol, psi)
+    assert p.nPointsTable == ref.nPointsTable and abs(p.rcut - float(ref.rcut)) <= 1e-15 and list(p.cells) == list(ref.cells)
+    assert p.support == ref.support and abs(p.eta - float(ref.eta)) <= 1e-14 * float(ref.eta)
+    MF = p.computeMF(_dev(pos), _dev(f)).cpu().numpy()
+    exp = ref.computeHydrodynamicDisplacements(pos, f, 0.0, 0.0)
+    assert np.abs(MF - exp).max() <= 1e-11 * np.abs(exp).max()

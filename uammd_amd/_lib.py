@@ -67,6 +67,15 @@ class PoissonInfo(C.Structure):
                 ("h", C.c_float)]
 
 
+class IBMKernel64(C.Structure):
+    _fields_ = [("kind", C.c_int), ("support", C.c_int * 3), ("prefactor", C.c_double), ("tau", C.c_double), ("rmax", C.c_double),
+                ("invh", C.c_double * 3)]
+
+
+class FCMParameters64(C.Structure):
+    _fields_ = [("boxSize", C.c_double * 3), ("cells", C.c_int * 3), ("viscosity", C.c_double), ("kernel", IBMKernel64)]
+
+
 _f3 = C.c_float * 3
 _i3 = C.c_int * 3
 _vp = C.c_void_p
@@ -76,8 +85,30 @@ _u = C.c_uint
 
 # name -> (restype, argtypes).  Every symbol include/uammd_hip.h declares must be listed here:
 # tests/test_abi.py checks header, library and this table against each other.
+_d = C.c_double
+_d3 = C.c_double * 3
+MATVEC64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
 SIGNATURES = {
     "uammd_hip_abi_version": (_i, []),
+    # DOUBLE_PRECISION build (f64.hip, lanczos.hip)
+    "uammd_fcm_gaussian_kernel_f64": (_i, [_d, _d, C.POINTER(IBMKernel64), C.POINTER(_d)]),
+    "uammd_fcm_advise_grid_size_f64": (_d, [_d, _d]),
+    "uammd_ibm_spread_f64": (_i, [_vp, _i, _vp, _i, _i, _d3, _i3, _i3, _i, C.POINTER(IBMKernel64), _vp, _vp]),
+    "uammd_ibm_gather_f64": (_i, [_vp, _i, _vp, _i, _i, _d3, _i3, _i3, _i, C.POINTER(IBMKernel64), _vp, _vp]),
+    "uammd_fcm_create_f64": (_i, [C.POINTER(FCMParameters64), C.POINTER(_vp)]),
+    "uammd_fcm_destroy_f64": (_i, [_vp]),
+    "uammd_fcm_displacements_f64": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_pse_far_raw_cells_f64": (_i, [_d3, _d, _d, _i3]),
+    "uammd_pse_far_create_f64": (_i, [_d3, _i3, _d, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_d)]),
+    "uammd_pse_near_create_f64": (_i, [_d3, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_d), C.POINTER(_i)]),
+    "uammd_pse_near_destroy_f64": (_i, [_vp]),
+    "uammd_pse_near_mdot_f64": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "uammd_lanczos_create_f64": (_i, [C.POINTER(_vp)]),
+    "uammd_lanczos_destroy_f64": (_i, [_vp]),
+    "uammd_lanczos_run_f64": (_i, [_vp, MATVEC64, _vp, _vp, _vp, _d, _i, _vp, C.POINTER(_i)]),
+    "uammd_lanczos_set_iteration_hard_limit_f64": (_i, [_vp, _i]),
+    "uammd_lanczos_get_last_run_required_steps_f64": (_i, [_vp, C.POINTER(_i)]),
     "uammd_hip_last_error": (C.c_char_p, []),
     "uammd_hip_device_count": (_i, [C.POINTER(_i)]),
     "uammd_hip_set_device": (_i, [_i]),
