@@ -499,6 +499,11 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
 int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int numberParticles, const float *d_grid,
                           float *d_linearVelocity, void *stream);
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream);
+/* device side of the all-to-all transposes (uammd_comm_alltoall moves block p of the send buffer to rank p): pack the owned planes'
+ * spectrum [zl][c][y][kx] into [p][zl][c][yl][kx]; what arrives is the z buffer as it stands; on the way back unpack
+ * [src][zl][c][yl][kx] into the spectrum of the window.  Buffers: 3 nzLocal ny (nx/2+1) float2 each. */
+int uammd_fcm_slab_transpose_pack(uammd_fcm_slab *h, const float *d_grid, float *d_send, void *stream);
+int uammd_fcm_slab_transpose_unpack(uammd_fcm_slab *h, const float *d_recv, float *d_grid, void *stream);
 /* the same with the halo fold on the way: d_fromDown / d_fromUp (`planes` planes each, laid out like the window) are added to the first /
  * last `planes` owned planes as the x pass loads them (one launch less than adding them first).  Returns 1 when the solver's own FFT
  * does not serve this grid: add the planes and call uammd_fcm_slab_forward_xy */

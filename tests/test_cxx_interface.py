@@ -45,3 +45,17 @@ def test_examples_run(prog, args):
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,args", [("lj_slab", ["32768", "40"]), ("fcm_slab", ["64", "20000"]), ("fcm_slab", ["36", "4000"])])
+def test_slab_drivers_world1(prog, args, tmp_path):
+    """The C++14 multi-GPU drivers (include/uammd/Distributed.h over uammd::Comm = RCCL behind the C ABI) as ONE rank that is its own
+    neighbour through the periodic z faces — every message of the N-rank schedule is sent and received, through RCCL, on the one GPU a
+    test box has — compared inside the program with the single-domain classes of uammd.h.  (RCCL refuses two ranks on one device: runs
+    with N > 1 processes need N GPUs; the process-level N > 1 runs of the same library kernels are tests/test_gpu_world2.py.)"""
+    _make()
+    r = subprocess.run([os.path.join(EX, "_build", prog), "0", "1", str(tmp_path / "comm.id")] + args, capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "world 1:" in r.stdout

@@ -213,6 +213,8 @@ SIGNATURES = {
     "uammd_fcm_slab_spread": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_fcm_slab_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "uammd_fcm_slab_forward_xy": (_i, [_vp, _vp, _vp]),
+    "uammd_fcm_slab_transpose_pack": (_i, [_vp, _vp, _vp, _vp]),
+    "uammd_fcm_slab_transpose_unpack": (_i, [_vp, _vp, _vp, _vp]),
     "uammd_fcm_slab_forward_xy_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "uammd_fcm_slab_inverse_xy": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_slab_inverse_xy_inter": (_i, [_vp, _vp, _vp, _vp]),

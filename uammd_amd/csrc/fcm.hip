@@ -1506,6 +1506,48 @@ int uammd_fcm_slab_forward_xy_fold(uammd_fcm_slab *h, float *d_grid, const float
   return 0;
 }
 
+// The transposes of the slab FFT, device side of the all-to-all (uammd_comm_alltoall moves equal blocks, block p <-> rank p):
+//   pack:   the owned planes' xy spectrum float2 [zl][c][y = (p, yl)][kx]  ->  send float2 [p][zl][c][yl][kx]      (block p: rank p's y rows)
+//   (what arrives, recv [src][zl][c][yl][kx], IS the z buffer [z = (src, zl)][c][yl][kx]: no unpack on the way there)
+//   unpack: what comes back, float2 [src (y block)][zl][c][yl][kx]          ->  the spectrum [zl][c][y = (src, yl)][kx]
+__global__ void __launch_bounds__(256) k_slab_transpose(const float2 *__restrict__ in, float2 *__restrict__ out, int nzl, int P, int nyl, int nkx,
+                                                         bool pack) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)nzl * 3 * P * nyl * nkx;
+  if (t >= total) return;
+  // t enumerates the SPECTRUM layout [zl][c][p][yl][kx]
+  const int kx = (int)(t % nkx);
+  size_t q = t / nkx;
+  const int yl = (int)(q % nyl); q /= nyl;
+  const int p = (int)(q % P); q /= P;
+  const int c = (int)(q % 3);
+  const int zl = (int)(q / 3);
+  const size_t blk = ((((size_t)p * nzl + zl) * 3 + c) * nyl + yl) * nkx + kx;
+  if (pack) out[blk] = in[t]; else out[t] = in[blk];
+}
+int uammd_fcm_slab_transpose_pack(uammd_fcm_slab *h, const float *d_grid, float *d_send, void *stream) {
+  if (!h || !d_grid || !d_send) { set_last_error("uammd_fcm_slab_transpose_pack: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  const float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
+  const int P = s->cells.y / s->nyl;
+  const size_t total = (size_t)s->nzl * 3 * s->cells.y * s->nkx;
+  hipLaunchKernelGGL(k_slab_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2 *)owned,
+                     (float2 *)d_send, s->nzl, P, s->nyl, s->nkx, true);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+int uammd_fcm_slab_transpose_unpack(uammd_fcm_slab *h, const float *d_recv, float *d_grid, void *stream) {
+  if (!h || !d_grid || !d_recv) { set_last_error("uammd_fcm_slab_transpose_unpack: null argument"); return -1; }
+  FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
+  float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
+  const int P = s->cells.y / s->nyl;
+  const size_t total = (size_t)s->nzl * 3 * s->cells.y * s->nkx;
+  hipLaunchKernelGGL(k_slab_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2 *)d_recv,
+                     (float2 *)owned, s->nzl, P, s->nyl, s->nkx, false);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   if (!h || !d_grid) { set_last_error("uammd_fcm_slab_forward_xy: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
