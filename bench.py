@@ -837,6 +837,22 @@ def main():
                                       "ms_per_step": t2 / 500 * 1e3, "list_rebuilds": pf3.nl.rebuilds - r0,
                                       "published": "~90 steps/s on a GTX 980 (benchmark.cu:8), other hardware: orientation only"}
         del pd3, verlet3, pf3
+        # the same configuration with PairForces<LJ, CellList> (the list this library is fastest with: the fused step of DESIGN 5.3)
+        pd4, _, _, verlet4, pf4, _ = lj_setup(hip, nb, Lb, seed=1234, dt=0.01, nl="cell")
+        pd4.sortParticles()
+        for _ in range(500):
+            verlet4.forwardTime()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for j in range(500):
+            verlet4.forwardTime()
+            if j % 500 == 0:
+                pd4.sortParticles()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter() - t3
+        out["reference_benchmark"]["with_celllist"] = {"steps_per_s": 500 / t3, "ms_per_step": t3 / 500 * 1e3,
+                                                       "note": "same box, potential, integrator and sort period with PairForces<LJ, CellList>"}
+        del pd4, verlet4, pf4
     if args.workload == "both":
         fcm = run_fcm(hip, args, world, rank, dist)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

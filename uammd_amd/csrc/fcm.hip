@@ -972,10 +972,34 @@ static bool fcm_custom_fft_usable(const FCM *f) {
   return f->customFFT && fft_axis_ok(f->grid.cellDim.x, 5, 512) && fft_axis_ok(f->grid.cellDim.y, 1, 256) && fft_axis_ok(f->grid.cellDim.z, 1, 512) &&
          f->planeReal == (size_t)f->nxpad * f->grid.cellDim.y * f->grid.cellDim.z;
 }
+// the plane kernel's LDS: twiddles + ny rows of nx / 2 + 1 complex; its butterfly budget: rows ny nh / 4 <= 2 x 1024, columns
+// (nh + 1) ny / 4 <= 3 x 1024
+static size_t fcm_plane_fft_lds(int nx, int ny) { return sizeof(float2) * ((size_t)std::max(nx, ny) + (size_t)ny * (nx / 2 + 1)); }
+static bool fcm_plane_fft_usable(int nx, int ny) {
+  static int ldsLimit = -1;
+  if (ldsLimit < 0) {
+    int dev = 0, v = 0;
+    ldsLimit = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) ? v : 0;
+    if (getenv("UAMMD_FCM_NO_PLANE_FFT")) ldsLimit = 0;
+  }
+  const int nh = nx / 2;
+  return nx >= 32 && ny >= 16 && (size_t)ny * nh / 4 <= 2 * 1024 && (size_t)(nh + 1) * ny / 4 <= 3 * 1024 &&
+         fcm_plane_fft_lds(nx, ny) <= (size_t)std::min(ldsLimit, 96 * 1024);
+}
 // forward x and y transforms of the three real component grids, in place
 static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1, nh = nx / 2;
   const int lx = ilog2_exact(nx), ly = ilog2_exact(ny);
+  if (fcm_plane_fft_usable(nx, ny)) {  // one pass: a whole plane per workgroup
+    const size_t lds = fcm_plane_fft_lds(nx, ny);
+    static bool attrSet = false;
+    if (!attrSet) {
+      UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attrSet = true;
+    }
+    hipLaunchKernelGGL(k_fft_xy_r2c_plane, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, lx, ly);
+    return 0;
+  }
   const int rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * nz;
   hipLaunchKernelGGL(k_fft_x_r2c<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
                      lx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
@@ -989,7 +1013,9 @@ static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStri
                                   float noisePrefactor, uint seed2, hipStream_t st) {
   const int nz = cells.z, nkx = cells.x / 2 + 1, lz = ilog2_exact(nz), lines = nyl * nkx;
   // tile of (ky, kx) nodes per workgroup: 3 tl nz complex in LDS and <= 6 radix-4 butterflies per thread and pass
-  const int ltl = nz <= 128 ? (f->zTileLog2 > 0 ? f->zTileLog2 : 3) : (nz == 256 ? 3 : 2), tlz = 1 << ltl;  // measured at C4: 8 nodes x 512 threads
+  int ltl = nz <= 128 ? 3 : (nz == 256 ? 3 : 2);  // measured at C4: 8 nodes x 512 threads
+  if (f->zTileLog2 > 0 && sizeof(float2) * (size_t)(nz + 3 * (1 << f->zTileLog2) * (nz + 1)) <= 64 * 1024) ltl = f->zTileLog2;  // (tuning option)
+  const int tlz = 1 << ltl;
   const size_t ldsz = sizeof(float2) * (size_t)(nz + 3 * tlz * (nz + 1));
   const dim3 gz((lines + tlz - 1) / tlz), bz(512);
 #define UH_ZFUSED(LT) hipLaunchKernelGGL((k_fft_z_fused<LT, 512>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, lz, cells, L, f->par.viscosity, \
@@ -1345,7 +1371,7 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
   if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
-  if (std::string(name) == "z_tile_log2" && (value == 0 || value == 3 || value == 4)) { reinterpret_cast<FCM *>(h)->zTileLog2 = value; return 0; }
+  if (std::string(name) == "z_tile_log2" && (value == 0 || value == 2 || value == 3 || value == 4)) { reinterpret_cast<FCM *>(h)->zTileLog2 = value; return 0; }
   if (std::string(name) == "custom_fft") { reinterpret_cast<FCM *>(h)->customFFT = value != 0; return 0; }
   set_last_error("uammd_fcm_set_option: unknown option %s", name);
   return -1;

@@ -83,6 +83,62 @@ UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const
   __syncthreads();
 }
 
+// the same pass over lines whose ELEMENTS are `ES` apart and whose first elements are `LS` apart (columns of a row-major plane in LDS:
+// LS = 1, ES = the row stride)
+template <int R, int SIGN, int MAXB, int NT>
+UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
+  constexpr int LR = R == 4 ? 2 : 1;
+  const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
+  float2 v[MAXB][R];
+  int dst[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    // consecutive threads take consecutive LINES (neighbouring LDS words), not consecutive butterflies of a line
+    const int b = tid + q * NT;
+    dst[q] = -1;
+    if (b < total) {
+      const int line = b % nlines, j = b / nlines, k = j & (Ns - 1);
+      const float2 *p = buf + line * LS + j * ES;
+      const int t1 = (k << (log2N - log2Ns - LR)) * twStride;
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[q][r] = p[r * per * ES];
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[q][r] = ctw<SIGN>(v[q][r], tw[t1 * r]);
+      if (R == 2) {
+        const float2 a = v[q][0], c = v[q][1];
+        v[q][0] = cadd(a, c);
+        v[q][1] = csub(a, c);
+      } else {
+        const float2 a0 = cadd(v[q][0], v[q][2]), a1 = csub(v[q][0], v[q][2]), a2 = cadd(v[q][1], v[q][3]);
+        const float2 d = csub(v[q][1], v[q][3]);
+        const float2 a3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+        v[q][0] = cadd(a0, a2);
+        v[q][1] = cadd(a1, a3);
+        v[q][2] = csub(a0, a2);
+        v[q][3] = csub(a1, a3);
+      }
+      dst[q] = line * LS + (((j - k) << LR) + k) * ES;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q)
+    if (dst[q] >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[dst[q] + r * Ns * ES] = v[q][r];
+    }
+  __syncthreads();
+}
+template <int SIGN, int MAXB, int NT>
+UH_D void fft_lds_strided(float2 *buf, int LS, int ES, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
+  int s = 0;
+  if (log2N & 1) {
+    fft_pass_strided<2, SIGN, 2 * MAXB, NT>(buf, LS, ES, log2N, 0, nlines, tw, twStride, tid);
+    s = 1;
+  }
+  for (; s < log2N; s += 2) fft_pass_strided<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
+}
+
 // N-point FFTs of `nlines` LDS lines (N = 2^log2N <= 512, nlines * N / 4 <= MAXB * 256).  The caller has synchronised its writes.
 template <int SIGN, int MAXB, int NT = kFftThreads>
 UH_D void fft_lds(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
@@ -149,6 +205,55 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
     const int r = i >> (log2nx - 1), k = i & (nh - 1);
     *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * k) = buf[r * LS + k];
     if (k == 0) *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * nh) = buf[r * LS + nh];
+  }
+}
+
+// ---- a whole (component, z) plane: x then y, one pass over the grid instead of two -----------------------------------------------------------
+// The rows' R2C and the columns' transform of one plane both fit a workgroup's LDS when ny (nx / 2 + 1) complex do (66.5 KB at 128 x 128 of
+// gfx950's 160 KB per CU): rows in, ny FFTs of nx / 2 points + untangling, nx / 2 + 1 FFTs of ny points down the columns of the same array
+// (element stride = the row stride), rows out.  3 nz workgroups of 1024 threads; a launch asks for its dynamic LDS beyond 64 KB through
+// hipFuncSetAttribute.  Replaces k_fft_x_r2c + k_fft_lines<-1> where the plane fits (fcm_plane_fft_usable).
+constexpr int kPlaneThreads = 1024;
+__global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__restrict__ g, int log2nx, int log2ny) {
+  extern __shared__ float2 lds[];
+  const int nx = 1 << log2nx, ny = 1 << log2ny, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  const int ntw = nx > ny ? nx : ny;           // one table exp(-2 pi i k / ntw) serves both transforms (both sizes divide it)
+  float2 *tw = lds, *buf = lds + ntw;
+  const int tid = threadIdx.x;
+  float *plane = g + (size_t)blockIdx.x * ny * nxpad;   // (the three planar component grids are contiguous: plane index = c nz + z)
+  fft_twiddles<kPlaneThreads>(tw, ntw, tid);
+  for (int i = tid; i < ny * nh; i += kPlaneThreads) {
+    const int r = i >> (log2nx - 1), j = i & (nh - 1);
+    buf[r * LS + j] = *(const float2 *)(plane + (size_t)r * nxpad + 2 * j);
+  }
+  __syncthreads();
+  // rows: ny complex FFTs of nh points (table stride: exp(-2 pi i k / nh) = tw[k ntw / nh])
+  fft_lds<-1, 2, kPlaneThreads>(buf, LS, log2nx - 1, ny, tw, ntw / nh, tid);
+  const int twx = ntw / nx;
+  for (int i = tid; i < ny * (nh / 2); i += kPlaneThreads) {   // untangle (as k_fft_x_r2c)
+    const int r = i >> (log2nx - 2), k = i & (nh / 2 - 1);
+    float2 *row = buf + r * LS;
+    if (k == 0) {
+      const float2 m = row[nh / 2];
+      row[nh / 2] = make_float2(m.x, -m.y);
+      const float2 z = row[0];
+      row[0] = make_float2(z.x + z.y, 0.0f);
+      row[nh] = make_float2(z.x - z.y, 0.0f);
+    } else {
+      const float2 a = row[k], b = row[nh - k];
+      const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+      const float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+      const float2 wo = ctw<-1>(o, tw[k * twx]);
+      row[k] = cadd(e, wo);
+      row[nh - k] = make_float2(e.x - wo.x, -(e.y - wo.y));
+    }
+  }
+  __syncthreads();
+  // columns: nh + 1 FFTs of ny points, element stride LS
+  fft_lds_strided<-1, 3, kPlaneThreads>(buf, 1, LS, log2ny, nh + 1, tw, ntw / ny, tid);
+  for (int i = tid; i < ny * LS; i += kPlaneThreads) {
+    const int r = i / LS, k = i - r * LS;
+    *(float2 *)(plane + (size_t)r * nxpad + 2 * k) = buf[r * LS + k];
   }
 }
 
