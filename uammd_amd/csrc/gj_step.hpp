@@ -15,6 +15,7 @@ struct GJFuse {
   float defaultMass, dt, friction, noiseAmplitude;
   int is2D;
   uint stepNum, seed;
+  int keepForce;  // the hash kernel's fused half step leaves the force array alone (the caller's traversal overwrites every entry)
 };
 
 // step 1 for particle i, noise stream id: p, v updated in place; the caller stores them (and zeroes the force)

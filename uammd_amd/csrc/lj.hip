@@ -686,7 +686,10 @@ int uammd_verletnvt_gj_lj_step(uammd_celllist *hh, float *d_pos, float *d_vel, f
   if (N == 0) return 0;
   CellList *h = reinterpret_cast<CellList *>(hh);
   hipStream_t st = (hipStream_t)stream;
-  const GJFuse gj{d_vel, reinterpret_cast<float4 *>(d_force), d_mass, defaultMass, dt, friction, noiseAmplitude, is2D, stepNum, seed};
+  // keepForce: when the previous fused step on this list ended in the tile traversal, this one will too unless the grid changes — the
+  // traversal's store overwrites every force, so the half step does not have to zero them (fixed up below if the guess was wrong)
+  const GJFuse gj{d_vel, reinterpret_cast<float4 *>(d_force), d_mass, defaultMass, dt, friction, noiseAmplitude, is2D, stepNum, seed,
+                  h->lastFusedTile ? 1 : 0};
   if (int e = h->update(reinterpret_cast<const float4 *>(d_pos), N, updateL, updatePeriodic, cellDim, st, &gj)) {
     if (!h->gjDone) {
       // (the build refused — a flag raised by an earlier build, a bad grid — before the half step: nothing was changed)
@@ -702,6 +705,8 @@ int uammd_verletnvt_gj_lj_step(uammd_celllist *hh, float *d_pos, float *d_vel, f
   if (tile) {
     out.vel = d_vel; out.mass = d_mass; out.defaultMass = defaultMass; out.dt = dt; out.is2D = is2D;
   }
+  if (!tile && gj.keepForce && h->gjInHash) UH_CHECK(hipMemsetAsync(d_force, 0, sizeof(float4) * (size_t)N, st));
+  h->lastFusedTile = tile;
   int rc = 0;
   if (ntypes == 1) rc = dispatch_celllist<true, false, false>(h, algo, box, tbl, ntypes, out, st);
   else rc = dispatch_celllist<false, false, false>(h, algo, box, tbl, ntypes, out, st);
