@@ -109,12 +109,8 @@ int uammd_lj_profile_enable(uammd_celllist *h, int enable);
 int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the
  * particles with input index >= n as ghosts of a domain decomposition: they are neighbours of the others but the LJ
- * traversal computes nothing for them (n < 0 turns it off); "slotted_build" = 0 / 1 / 2: the counting build that writes the
- * provisional member lists from its hash kernel into fixed-capacity rows (one pass fewer) is never used / used once the largest
- * cell of an earlier build of the same grid is known to leave a margin (default) / always used (test hook) */
+ * traversal computes nothing for them (n < 0 turns it off) */
 int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value);
-/* what the last update did: "used_counting", "used_slotted" (0 / 1) */
-int uammd_celllist_get_option(uammd_celllist *h, const char *name, int *value);
 /* library-wide tunables (none at present; the call is kept for ABI stability and returns an error for unknown names) */
 int uammd_hip_set_tunable(const char *name, int value);
 

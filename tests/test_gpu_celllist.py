@@ -124,90 +124,3 @@ def test_sort_pairs_stable_and_end_bit(hip, o32):
         torch.cuda.synchronize()
         assert np.array_equal(dv.cpu().numpy(), rv)
         assert np.array_equal(dk.cpu().numpy().view(np.uint32), rk)
-
-
-# ---- slotted counting build (celllist.hip, BuildAux): same list, one pass fewer ----------------------------------------------
-def _tables(cl):
-    got = cl.to_host()
-    s, e = canon_cell_tables(got)
-    return got["hash"], got["index"], got["sortPos"].view(np.uint32), s, e
-
-
-@pytest.mark.parametrize("case", CASES, ids=[c[4] for c in CASES])
-def test_slotted_build_equals_general_build(hip, case):
-    """slotted_build = 2 forces the fixed-capacity rows on every build: the list is the general build's, bit for bit, including the
-    second and third build on the same handle (the counters are handed back at zero by the build itself)."""
-    n, L, rc, periodic, _ = case
-    pos = lattice_positions(n, L, seed=99, jitter=0.3)
-    box = hip.Box(L, periodic)
-    cd, ubox = hip.CellList.create_update_grid(box, rc)
-    ref_cl = hip.CellList()
-    ref_cl.set_option("slotted_build", 0)
-    cl = hip.CellList()
-    cl.set_option("slotted_build", 2)
-    rng = np.random.default_rng(5)
-    for it in range(3):
-        d_pos = torch.from_numpy(pos).cuda()
-        ref_cl.update_grid(d_pos, ubox, cd)
-        cl.update_grid(d_pos, ubox, cd)
-        for a, b in zip(_tables(ref_cl), _tables(cl)):
-            assert np.array_equal(a, b), it
-        pos = (pos + rng.normal(0, 0.2, pos.shape).astype(np.float32)).astype(np.float32)
-        L3 = np.broadcast_to(np.asarray(L, dtype=np.float32), (3,))
-        for k in range(3):
-            if not periodic[k]:
-                pos[:, k] = np.clip(pos[:, k], -L3[k] / 2 + 0.01, L3[k] / 2 - 0.01)
-
-
-def test_slotted_build_overflowing_cells(hip):
-    """Cells that outgrow their 32-entry row keep their members in the overflow list: a cluster of 500 particles in one cell and 70 in
-    another, the rest dilute; the forced slotted build still equals the general build."""
-    n, L, rc = 6000, 40.0, 2.5
-    pos = lattice_positions(n, L, seed=3, jitter=0.3)
-    rng = np.random.default_rng(8)
-    pos[100:600, :3] = (np.array([5.1, -3.2, 7.7]) + rng.uniform(-0.5, 0.5, (500, 3))).astype(np.float32)
-    pos[900:970, :3] = (np.array([-11.0, 2.0, 0.3]) + rng.uniform(-0.4, 0.4, (70, 3))).astype(np.float32)
-    box = hip.Box(L)
-    cd, ubox = hip.CellList.create_update_grid(box, rc)
-    d_pos = torch.from_numpy(pos).cuda()
-    ref_cl = hip.CellList()
-    ref_cl.set_option("slotted_build", 0)
-    cl = hip.CellList()
-    cl.set_option("slotted_build", 2)
-    for it in range(3):  # (the overflow counters alternate between builds)
-        ref_cl.update_grid(d_pos, ubox, cd)
-        cl.update_grid(d_pos, ubox, cd)
-        for a, b in zip(_tables(ref_cl), _tables(cl)):
-            assert np.array_equal(a, b), it
-
-
-def test_slotted_build_is_taken_once_the_occupancy_is_known(hip):
-    """Default policy: the first builds of a grid take the general path; once the largest cell of an earlier build has reached the host
-    (mapped memory, no synchronisation) and leaves a margin below the row length, the slotted build takes over — and a handle whose
-    cells are too full never switches."""
-    n, L, rc = 20000, 40.0, 2.5  # 16^3 cells, ~5 per cell
-    pos = lattice_positions(n, L, seed=11, jitter=0.3)
-    box = hip.Box(L)
-    cd, ubox = hip.CellList.create_update_grid(box, rc)
-    d_pos = torch.from_numpy(pos).cuda()
-    cl = hip.CellList()
-    ref_cl = hip.CellList()
-    ref_cl.set_option("slotted_build", 0)
-    ref_cl.update_grid(d_pos, ubox, cd)
-    ref = _tables(ref_cl)
-    used = []
-    for it in range(6):
-        cl.update_grid(d_pos, ubox, cd)
-        torch.cuda.synchronize()
-        used.append(cl.get_option("used_slotted"))
-        for a, b in zip(ref, _tables(cl)):
-            assert np.array_equal(a, b), it
-    assert used[0] == 0 and used[-1] == 1, used
-    dense = lattice_positions(60000, 20.0, seed=12, jitter=0.3)  # 8^3 cells, ~117 per cell
-    cd2, ubox2 = hip.CellList.create_update_grid(hip.Box(20.0), rc)
-    d2 = torch.from_numpy(dense).cuda()
-    cl2 = hip.CellList()
-    for it in range(5):
-        cl2.update_grid(d2, ubox2, cd2)
-        torch.cuda.synchronize()
-        assert cl2.get_option("used_slotted") == 0

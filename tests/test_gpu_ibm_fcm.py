@@ -435,3 +435,35 @@ def test_fcm_tile_edges_other_than_eight(hip, o32, cells, tol):
     v2 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()      # with noise (same seeds, same seed2 sequence)
     va2 = fa.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()
     assert np.linalg.norm(v2 - va2) <= 1e-5 * np.linalg.norm(va2)
+
+
+@pytest.mark.parametrize("cells,tol,n", [((64, 64, 64), 1e-3, 40000), ((40, 56, 48), 1e-3, 20000), ((36, 60, 42), 1e-4, 20001),
+                                         ((128, 128, 128), 1e-3, 100003)])
+def test_fcm_gather_particles_per_wave(hip, cells, tol, n):
+    """k_fcm_gather_inter with 1, 2 and 4 particles per wave sums the same nodes in the same order (particle counts that are not multiples
+    of the group, stencils that wrap around the box, T = 0 and T > 0).  Two solves are not the same bits — the order in which the
+    binning pass hands out the slots of a tile, hence the spread's summation order, is an atomic's (the reference's spread is an
+    atomicAdd per node) — so the bar is rounding level, 2e-6 of the largest displacement."""
+    L = np.asarray(cells, np.float32)
+    rng = np.random.default_rng(sum(cells) + n)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    pos[: n // 10, :3] = (np.array([3.3, -7.1, 9.9]) + rng.normal(0, 1.0, (n // 10, 3))).astype(np.float32)   # a dense cluster
+    pos[n // 10: n // 5, :3] = rng.uniform(-1.5, 1.5, (n // 5 - n // 10, 3)) * L                           # unwrapped coordinates
+    pos[0, :3] = -L / 2
+    pos[1, :3] = L / 2 - np.float32(1e-3)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, tol)
+    out = {}
+    for mode in (1, 2, 4):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        fcm.set_option("gather_per_wave", mode)
+        dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+        v0 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+        v1 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()
+        out[mode] = (v0, v1)
+    assert np.isfinite(out[2][0]).all() and np.abs(out[2][0]).max() > 0
+    for mode in (2, 4):
+        for a, b in zip(out[1], out[mode]):
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()

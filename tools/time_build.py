@@ -27,7 +27,7 @@ for _ in range(100):   # the bench's steady state: up to 500 steps since the las
 pos = pd.getPos("read")
 cd, ubox = hip.CellList.create_update_grid(box, [2.5] * 3)
 outs = {}
-for name, opts in (("counting", {"slotted_build": 0}), ("slotted", {"slotted_build": 2}), ("default", {}), ("radix", {"force_radix": 1})):
+for name, opts in (("counting", {}), ("radix", {"force_radix": 1})):
     cl = hip.CellList()
     for k, v in opts.items():
         cl.set_option(k, v)
@@ -39,8 +39,8 @@ for name, opts in (("counting", {"slotted_build": 0}), ("slotted", {"slotted_bui
     for _ in range(reps):
         cl.update_grid(pos, ubox, cd)
     e1.record(); torch.cuda.synchronize()
-    print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per build (slotted: {cl.get_option('used_slotted')})", flush=True)
-for name in ("radix", "slotted", "default"):
+    print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per build", flush=True)
+for name in ("radix",):
     a, b = outs["counting"], outs[name]
     same = all(np.array_equal(a[k], b[k]) for k in ("index", "hash", "sortPos", "cellEnd"))
     va, vb = a["cellStart"] >= a["validCell"], b["cellStart"] >= b["validCell"]

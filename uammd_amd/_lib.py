@@ -132,7 +132,6 @@ SIGNATURES = {
     "uammd_lj_profile_enable": (_i, [_vp, _i]),
     "uammd_lj_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),
-    "uammd_celllist_get_option": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
     "uammd_sort_pairs": (_i, [_vp, _vp, _i, _i, _vp]),
     "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),

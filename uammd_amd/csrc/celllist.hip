@@ -72,41 +72,12 @@ static int sort_end_bit(uint maxHash) {
 // ---- kernels -------------------------------------------------------------------------------------
 constexpr int kBlock = 256;
 
-// What the counting build's hash kernels carry besides the histogram: the slotted build — the provisional member list is written by
-// the hash kernel itself into fixed-capacity rows, one row per key, so that the separate pass that wrote it after the scan
-// (k_members) disappears.
-constexpr int kScanChunks = 256;     // workgroups of the key scan (k_key_scan)
-constexpr int kSlotCap = 32;         // row length of the slotted build; members beyond it go to the overflow list
-constexpr uint kOvfCap = 1u << 16;   // overflow list entries; more than that is reported (check_errors code 3)
-struct BuildAux {
-  int *slots;      // [nKeys][kSlotCap] particle indices in arrival order (null: provisional ranks go to provRank)
-  uint2 *ovf;      // {key, particle} of the members that did not fit their row
-  uint *ovfCount;  // this build's counter (two alternate: the rank kernel of build n clears the one build n + 1 will use)
-  const uint *wgMax;  // largest cell seen by each of the nWgMax cell workgroups of the PREVIOUS build, relayed to the host by block 0 ...
-  int nWgMax;
-  int *hostStat;   // ... through mapped memory: the host picks the slotted build only while cells stay well below kSlotCap
-  uint statTag;    // ... tagged with the grid generation of that build (<< 8): the host ignores what another grid left behind
-};
-// (all threads of workgroup 0, before any of them exits)
-UH_D void relay_max_count(const BuildAux &aux) {
-  __shared__ uint relayMax;
-  if (threadIdx.x == 0) relayMax = 0u;
-  __syncthreads();
-  uint m = 0;
-  for (int w = threadIdx.x; w < aux.nWgMax; w += kBlock) m = max(m, aux.wgMax[w]);
-  if (m) atomicMax(&relayMax, m);
-  __syncthreads();
-  if (threadIdx.x == 0 && aux.hostStat) aux.hostStat[1] = (int)(aux.statTag | min(relayMax, 255u));
-}
-
 // K1 (+ histogram): one thread per particle.
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos, int N, GridT<float> grid,
                                                  uint *__restrict__ hash, int *__restrict__ index,
                                                  uint *__restrict__ keyCount, uint *__restrict__ provRank,
-                                                 int *__restrict__ errorFlag, unsigned char *__restrict__ keyOutside,
-                                                 BuildAux aux) {
-  if (COUNT && blockIdx.x == 0) relay_max_count(aux);
+                                                 int *__restrict__ errorFlag, unsigned char *__restrict__ keyOutside) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;  // exited lanes drop out of the ballots below
   const float4 p = pos[i];
@@ -145,21 +116,22 @@ __global__ void __launch_bounds__(kBlock) k_hash(const float4 *__restrict__ pos,
 // of a workgroup fall into ~100 distinct fine keys: they are counted in an LDS hash table first (LDS atomics run per CU) and
 // each distinct key then costs ONE global atomic that reserves the whole group's range of provisional ranks.  Unsorted input
 // degrades gracefully to one global atomic per particle.
-constexpr int kAggPerThread = 4;  // (256 or 512 particles per workgroup instead of 1024: same wall time, measured)
+// kAggPerThread particles per thread: 4 for the plain build (256 or 512 particles per workgroup instead of 1024: same wall time,
+// measured), 1 with the fused half step, whose workgroups otherwise all stream, all compute and all wait for their atomics at the
+// same time (35.3 -> 30.5 us at C3 with four times the workgroups; the launch is 3.8 workgroups per CU at 4).
 // GJ1: the fused MD step (uammd_verletnvt_gj_lj_step) — VerletNVT::GronbechJensen's first half step (GronbechJensen.cu:28-57) is applied
 // to each particle as it is loaded, the new position is stored and hashed: one pass over pos / vel / force instead of the integrator's
 // own launch followed by this kernel re-reading the positions.
-template <bool GJ1, bool SLOT>
+template <bool GJ1, int kAggPerThread>
 __global__ void __launch_bounds__(kBlock) k_hash_agg(float4 *__restrict__ pos, int N, GridT<float> grid,
                                                      uint *__restrict__ hash, uint *__restrict__ keyCount,
                                                      uint *__restrict__ provRank, int *__restrict__ errorFlag,
-                                                     unsigned char *__restrict__ keyOutside, GJFuse gj, BuildAux aux) {
+                                                     unsigned char *__restrict__ keyOutside, GJFuse gj) {
   constexpr int kAggSlots = 2 * kBlock * kAggPerThread;  // 2 x particles per workgroup: the probe sequences stay short
-  constexpr int kSlotShift = 32 - 11;
-  static_assert(kAggSlots == 2048, "kSlotShift is log2 of the table size");
+  constexpr int kSlotShift = 32 - (kAggPerThread == 4 ? 11 : kAggPerThread == 2 ? 10 : 9);
+  static_assert(kAggSlots == (1 << (32 - kSlotShift)), "kSlotShift is log2 of the table size");
   __shared__ uint tKey[kAggSlots], tCnt[kAggSlots];
   for (int s = threadIdx.x; s < kAggSlots; s += kBlock) { tKey[s] = 0xffffffffu; tCnt[s] = 0u; }
-  if (blockIdx.x == 0) relay_max_count(aux);
   __syncthreads();
   const int base = blockIdx.x * (kBlock * kAggPerThread);
   uint myKey[kAggPerThread], mySlot[kAggPerThread], myRank[kAggPerThread];
@@ -245,21 +217,11 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(float4 *__restrict__ pos, i
 #pragma unroll
   for (int u = 0; u < kAggPerThread; ++u) {
     const int i = base + u * kBlock + threadIdx.x;
-    if (i < N) {
-      const uint r = tCnt[mySlot[u]] + myRank[u];
-      if (!SLOT) {
-        provRank[i] = r;
-      } else if (r < (uint)kSlotCap) {
-        aux.slots[(size_t)myKey[u] * kSlotCap + r] = i;
-      } else {
-        const uint o = atomicAdd(aux.ovfCount, 1u);
-        if (o < kOvfCap) aux.ovf[o] = make_uint2(myKey[u], (uint)i);
-        else errorFlag[0] = 3;
-      }
-    }
+    if (i < N) provRank[i] = tCnt[mySlot[u]] + myRank[u];
   }
 }
 
+constexpr int kScanChunks = 256;     // workgroups of the key scan (k_key_scan)
 // Exclusive scan of the key counters in ONE launch (rocPRIM's look-back scan is two: state initialisation + scan).  Workgroup b owns
 // the keys [b, b + 1) << chunkShift, at most kScanChunks workgroups: each publishes the total of its chunk tagged with the build's
 // generation (nothing to reset between builds), then thread t < b waits for workgroup t's total — a direct sum over the predecessors,
@@ -362,60 +324,38 @@ __global__ void __launch_bounds__(kBlock) k_members(const uint *__restrict__ has
 // neighbouring slots (cache hits), the only gather left is pos[i].  Final slot = first slot of the cell + #{members with a smaller
 // index}: the order utils/ParticleSorter.cuh:156-164,303-321 (stable radix sort of the hashes) produces.  Blocks past the
 // particle range write the per-cell tables (k_cell_tables' job) so that the build ends with this launch.
-struct CellTablesArgs {
-  const uint *keyStart;
-  unsigned char *keyOutside;
-  uint *keyCount;
-  int3 cellDim;
-  uint validCell;
-  uint *cellStart;
-  int *cellEnd;
-  unsigned char *cellOutside;
-  uint2 *cellRange;
-  uint *ovfCountNext;  // the overflow counter the NEXT build will use
-  uint *wgMax;         // largest cell seen by each workgroup (relay_max_count reduces them in the next build)
-};
-// The blocks past the particle range of the rank kernels: per-cell tables from keyStart (k_cell_tables' job), and the build's
-// counters handed back at zero so that the next build of the same grid needs no memset launch.
-UH_D void cell_tables_block(const CellTablesArgs &a, int c) {
-  const int ncells = a.cellDim.x * a.cellDim.y * a.cellDim.z;
-  uint count = 0;
-  if (c < ncells) {
-    int3 cc;
-    cc.x = c % a.cellDim.x;
-    cc.y = (c / a.cellDim.x) % a.cellDim.y;
-    cc.z = c / (a.cellDim.x * a.cellDim.y);
-    const uint h = morton_hash(cc);
-    const uint s = a.keyStart[h], e = a.keyStart[h + 1];
-    const bool out = a.keyOutside[h] != 0;
-    // this key's counter and flag have done their job: left at zero (every key that was touched belongs to a cell; the scan's input
-    // beyond the last key was never written)
-    if (e > s) a.keyCount[h] = 0u;
-    if (out) a.keyOutside[h] = 0;
-    a.cellStart[c] = (e > s) ? s + a.validCell : 0u;
-    a.cellEnd[c] = (int)e;
-    a.cellOutside[c] = out;
-    a.cellRange[c] = (e > s) ? make_uint2(s, e | (out ? 0x80000000u : 0u)) : make_uint2(0u, 0u);
-    if (c == ncells - 1) a.cellRange[ncells] = make_uint2(0u, 0u);
-    count = e - s;
-  }
-  if (c == 0) a.ovfCountNext[0] = 0u;
-  __shared__ uint blockMax;
-  if (threadIdx.x == 0) blockMax = 0u;
-  __syncthreads();
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) count = max(count, (uint)__shfl_xor((int)count, d, 64));
-  if ((threadIdx.x & 63) == 0 && count) atomicMax(&blockMax, count);
-  __syncthreads();
-  if (threadIdx.x == 0) a.wgMax[c / kBlock] = blockMax;  // (see k_rank_scatter_rows)
-}
-
+// (Round 3 tried to do without k_members: the hash kernel wrote the members into fixed-capacity rows, one per key, and half a wave per
+// cell ranked its row through lane shuffles and scattered — lists identical, the C3 step the same to 0.2 % (0.19358 against 0.19391 ms:
+// the hash kernel's scattered row stores cost what k_members saved), a plain build 5 us slower; a particle-major form of it lost 6 us
+// to 16-byte scattered stores, and an atomicMax of every workgroup on one word cost 19 us.  Removed.)
 __global__ void __launch_bounds__(kBlock) k_rank_scatter2(const float4 *__restrict__ pos, const uint *__restrict__ sortHash,
                                                           const uint *__restrict__ keyStart, const int *__restrict__ members,
                                                           int N, int particleBlocks, int *__restrict__ index,
-                                                          float4 *__restrict__ sortPos, CellTablesArgs tables) {
+                                                          float4 *__restrict__ sortPos,
+                                                          unsigned char *__restrict__ keyOutside, uint *__restrict__ keyCount,
+                                                          int3 cellDim, uint validCell, uint *__restrict__ cellStart,
+                                                          int *__restrict__ cellEnd, unsigned char *__restrict__ cellOutside,
+                                                          uint2 *__restrict__ cellRange) {
   if ((int)blockIdx.x >= particleBlocks) {
-    cell_tables_block(tables, (blockIdx.x - particleBlocks) * kBlock + threadIdx.x);
+    const int c = (blockIdx.x - particleBlocks) * kBlock + threadIdx.x;
+    const int ncells = cellDim.x * cellDim.y * cellDim.z;
+    if (c >= ncells) return;
+    int3 cc;
+    cc.x = c % cellDim.x;
+    cc.y = (c / cellDim.x) % cellDim.y;
+    cc.z = c / (cellDim.x * cellDim.y);
+    const uint h = morton_hash(cc);
+    const uint s = keyStart[h], e = keyStart[h + 1];
+    const bool out = keyOutside[h] != 0;
+    // this key's counter and flag have done their job: left at zero, the next build of the same grid needs no memset launch (every
+    // key that was touched belongs to a cell; the scan's input beyond the last key was never written)
+    if (e > s) keyCount[h] = 0u;
+    if (out) keyOutside[h] = 0;
+    cellStart[c] = (e > s) ? s + validCell : 0u;
+    cellEnd[c] = (int)e;
+    cellOutside[c] = out;
+    cellRange[c] = (e > s) ? make_uint2(s, e | (out ? 0x80000000u : 0u)) : make_uint2(0u, 0u);
+    if (c == ncells - 1) cellRange[ncells] = make_uint2(0u, 0u);
     return;
   }
   const int m = blockIdx.x * kBlock + threadIdx.x;
@@ -434,88 +374,6 @@ __global__ void __launch_bounds__(kBlock) k_rank_scatter2(const float4 *__restri
   const uint dst = s + rank;
   index[dst] = i;
   sortPos[dst] = p;
-}
-
-// The slotted build's rank kernel: HALF A WAVE PER CELL.  The cell's provisional members are its key's row (one coalesced 128-byte
-// load); every lane holds one member and counts the smaller indices among the others through lane shuffles — the stable rank — then
-// gathers its position and stores into the cell's contiguous range (the stores of one cell are one or two full lines; a particle-major
-// variant that scattered 16-byte stores instead took 35 us, twice the general pair of kernels).  Lane 0 writes the cell's tables and
-// hands the key's counter and flag back at zero, so this launch ends the build.  A cell that outgrew its row (rare: the host only
-// picks this build while the largest cell of the previous builds stayed below the row length) finds its other members in the
-// overflow list.
-__global__ void __launch_bounds__(kBlock) k_rank_scatter_rows(const float4 *__restrict__ pos, const uint *__restrict__ keyStart,
-                                                              const int *__restrict__ slots, const uint2 *__restrict__ ovf,
-                                                              const uint *__restrict__ ovfCount, int *__restrict__ index,
-                                                              float4 *__restrict__ sortPos, CellTablesArgs a) {
-  const int ncells = a.cellDim.x * a.cellDim.y * a.cellDim.z;
-  const int c = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
-  const int q = threadIdx.x & 31, halfBase = threadIdx.x & 32;
-  uint s = 0, count = 0, h = 0;
-  if (c < ncells) {
-    int3 cc;
-    cc.x = c % a.cellDim.x;
-    cc.y = (c / a.cellDim.x) % a.cellDim.y;
-    cc.z = c / (a.cellDim.x * a.cellDim.y);
-    h = morton_hash(cc);
-    s = a.keyStart[h];
-    const uint e = a.keyStart[h + 1];
-    count = e - s;
-    if (q == 0) {
-      const bool out = a.keyOutside[h] != 0;
-      if (count) a.keyCount[h] = 0u;
-      if (out) a.keyOutside[h] = 0;
-      a.cellStart[c] = count ? s + a.validCell : 0u;
-      a.cellEnd[c] = (int)e;
-      a.cellOutside[c] = out;
-      a.cellRange[c] = count ? make_uint2(s, e | (out ? 0x80000000u : 0u)) : make_uint2(0u, 0u);
-      if (c == ncells - 1) a.cellRange[ncells] = make_uint2(0u, 0u);
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ovfCountNext[0] = 0u;
-  const uint n = min(count, (uint)kSlotCap);
-  const int *row = slots + (size_t)h * kSlotCap;
-  const int i = ((uint)q < n) ? row[q] : 0x7fffffff;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((uint)q < n) p = pos[i];  // (in flight while the rank is counted)
-  const uint nWave = max(n, (uint)__shfl_xor((int)n, 32, 64));
-  uint rank = 0;
-  for (uint j = 0; j < nWave; ++j) {
-    const int v = __shfl(i, halfBase + (int)j, 64);  // (the padding lanes hold INT_MAX: they are never smaller)
-    rank += (v < i) ? 1u : 0u;
-  }
-  if (count > (uint)kSlotCap) {  // rare: the rest of this cell's members sit in the overflow list, in arrival order
-    const uint no = min(ovfCount[0], kOvfCap);
-    for (uint o = 0; o < no; ++o) {
-      const uint2 v = ovf[o];
-      rank += (v.x == h && (int)v.y < i) ? 1u : 0u;
-    }
-    for (uint o = q; o < no; o += 32) {
-      const uint2 v = ovf[o];
-      if (v.x != h) continue;
-      const int io = (int)v.y;
-      uint r = 0;
-      for (int j = 0; j < kSlotCap; ++j) r += (row[j] < io) ? 1u : 0u;
-      for (uint o2 = 0; o2 < no; ++o2) {
-        const uint2 w = ovf[o2];
-        r += (w.x == h && (int)w.y < io) ? 1u : 0u;
-      }
-      index[s + r] = io;
-      sortPos[s + r] = pos[io];
-    }
-  }
-  if ((uint)q < n) {
-    index[s + rank] = i;
-    sortPos[s + rank] = p;
-  }
-  // the largest cell of this workgroup, for the host's choice of build (relay_max_count): a plain store per workgroup — an atomic
-  // maximum on one word from ~1e4 workgroups serialises in L2 (19 us, measured; the other XCDs' copies of the word stay stale, so
-  // testing it first does not help)
-  __shared__ uint blockMax;
-  if (threadIdx.x == 0) blockMax = 0u;
-  __syncthreads();
-  if (q == 0 && count) atomicMax(&blockMax, count);
-  __syncthreads();
-  if (threadIdx.x == 0) a.wgMax[blockIdx.x] = blockMax;
 }
 
 // Cell tables from keyStart: one thread per cell (linear index).  Non-empty: start + VALID_CELL;
@@ -743,25 +601,9 @@ int CellList::check_errors(hipStream_t st, bool sync) {
       set_last_error("CellList: the key scan gave up waiting for a preceding workgroup; the last list is incomplete");
       return -4;
     }
-    if (code == 3) {
-      hostErr[1] = 0;  // (forget the occupancy seen so far: the next builds take the general path until it is known again)
-      set_last_error("CellList: the number of particles per cell jumped between two consecutive builds (more than %u particles beyond %d per "
-                     "cell); the last list is incomplete — rebuild it", kOvfCap, kSlotCap);
-      return -4;
-    }
     set_last_error("CellList encountered NaN positions or particles outside a non-periodic box");  // CellListBase.cuh:262
     return -4;
   }
-  return 0;
-}
-
-int CellList::ensure_sort_hash() {
-  if (sortHashValid || numberParticlesBuilt <= 0) return 0;
-  const int N = numberParticlesBuilt;
-  hipLaunchKernelGGL(k_gather<uint>, dim3(nblocks(N)), dim3(kBlock), 0, buildStream, (const uint *)hash.ptr, (const int *)index.ptr,
-                     (uint *)sortHash.ptr, N);
-  UH_CHECK(hipGetLastError());
-  sortHashValid = true;
   return 0;
 }
 
@@ -783,6 +625,7 @@ int CellList::lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, fl
 int CellList::update(const float4 *d_pos, int numberParticles, const float L[3], const int periodic[3],
                      const int cellDim_[3], hipStream_t st, const GJFuse *gj) {
   gjDone = false;
+  gjInHash = false;
   if (numberParticles < 0 || cellDim_[0] <= 0 || cellDim_[1] <= 0 || cellDim_[2] < 0) {
     set_last_error("CellList encountered an invalid grid and/or cutoff (N=%d cellDim=%d %d %d)", numberParticles,
                    cellDim_[0], cellDim_[1], cellDim_[2]);
@@ -791,7 +634,6 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   if (!hostErr) {
     UH_CHECK(hipHostMalloc((void **)&hostErr, 64, hipHostMallocMapped));
     hostErr[0] = 0;
-    hostErr[1] = 0;
     UH_CHECK(hipHostGetDevicePointer((void **)&devErr, hostErr, 0));
   }
   if (int e = check_errors(st, false)) return e;  // raised by an earlier build
@@ -845,12 +687,12 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
                  kcB = counting ? sizeof(uint) * ((size_t)nKeys + 4) : 0;
     if (int e = zeroBlock.reserve(errB + koB + kcB)) return e;
     char *base = (char *)zeroBlock.ptr;
-    errorFlag.alias(base, errB);  // four words of build state: [1], [2] the overflow counters of alternate builds, [3] the largest cell
+    errorFlag.alias(base, errB);
     keyOutside.alias(tabulated ? base + errB : nullptr, koB);
     keyCount.alias(counting ? base + errB + koB : nullptr, kcB);
     if (N == 0) { UH_CHECK(hipMemsetAsync(base, 0, errB, st)); zeroBlockClean = false; return 0; }
-    // the counting build hands the block back zeroed (the rank kernels' cell blocks); anything else — first use, another layout, a
-    // radix build, a build cut short by an error — clears it here
+    // the counting build hands the block back zeroed (k_rank_scatter2); anything else — first use, another layout, a radix build, a
+    // build cut short by an error — clears it here
     const bool clean = zeroBlockClean && base == zeroBase && zeroLayout[0] == koB && zeroLayout[1] == kcB && counting;
     if (!clean) UH_CHECK(hipMemsetAsync(base, 0, errB + koB + kcB, st));
     zeroBlockClean = false;
@@ -860,99 +702,50 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   }
   if (counting) {
     if (int e = keyStart.reserve(sizeof(uint) * ((size_t)nKeys + 2))) return e;
-    uint *stat = (uint *)errorFlag.ptr;
-    BuildAux aux{};
-    const int chunkShift = endBit > 18 ? endBit - 8 : 10;  // <= kScanChunks chunks of >= 1024 keys
-    const int nChunks = (int)((nKeys + (1u << chunkShift) - 1) >> chunkShift);
-    if (!scanFlags.ptr) {
-      if (int e = scanFlags.reserve(sizeof(unsigned long long) * kScanChunks)) return e;
-      UH_CHECK(hipMemsetAsync(scanFlags.ptr, 0, sizeof(unsigned long long) * kScanChunks, st));
-      scanGeneration = 0;
-    }
-    if (++scanGeneration == 0u) scanGeneration = 1u;  // (0 is the cleared state)
-    buildParity ^= 1;
-    aux.ovfCount = stat + 1 + buildParity;
-    aux.wgMax = (const uint *)wgMax.ptr;
-    aux.nWgMax = nWgMax;  // (what the previous counting build on this handle wrote; 0 the first time)
-    aux.hostStat = devErr;
-    // The slotted build needs the cells to stay inside their rows: the largest cell of an earlier build of THIS grid (a few builds old
-    // by the time the host reads it) must leave a margin.  Anything unknown — first builds, a new grid — takes the general build.
-    if (gridSeen[0] != grid.cellDim.x || gridSeen[1] != grid.cellDim.y || gridSeen[2] != grid.cellDim.z || gridSeenN != N) {
-      gridSeen[0] = grid.cellDim.x; gridSeen[1] = grid.cellDim.y; gridSeen[2] = grid.cellDim.z; gridSeenN = N;
-      gridGen = (gridGen + 1u) & 0x7fffffu;
-      if (!gridGen) gridGen = 1u;  // (0 is "nothing relayed yet")
-    }
-    aux.statTag = lastBuildGen << 8;
-    lastBuildGen = gridGen;
-    const uint relayed = (uint)__atomic_load_n(&hostErr[1], __ATOMIC_RELAXED);
-    const int seenMax = (relayed >> 8) == gridGen ? (int)(relayed & 255u) : 0;
-    const bool slotted = slottedBuild && aggregateHash && (slottedBuild == 2 || (seenMax > 0 && seenMax <= kSlotCap - 8)) &&
-                         (size_t)nKeys * kSlotCap * sizeof(int) <= ((size_t)1 << 28);
-    usedSlotted = slotted;
-    {  // one word per cell workgroup of the rank kernel this build will launch (the hash kernel has read the previous build's by then)
-      const int n = slotted ? (int)((ncells + kBlock / 32 - 1) / (kBlock / 32)) : nblocks(ncells);
-      if (sizeof(uint) * (size_t)n > wgMax.cap) {
-        if (int e = wgMax.reserve(sizeof(uint) * (size_t)n)) return e;
-        aux.wgMax = (const uint *)wgMax.ptr;
-        aux.nWgMax = 0;  // (the old words went with the old buffer)
-      }
-      nWgMax = n;
-    }
-    if (slotted) {
-      if (int e = slots.reserve(sizeof(int) * (size_t)nKeys * kSlotCap)) return e;
-      if (int e = overflow.reserve(sizeof(uint2) * (size_t)kOvfCap)) return e;
-      aux.slots = (int *)slots.ptr;
-      aux.ovf = (uint2 *)overflow.ptr;
-    } else {
-      if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
-      if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
-    }
-    const dim3 aggGrid((N + kBlock * kAggPerThread - 1) / (kBlock * kAggPerThread));
-    float4 *posw = const_cast<float4 *>(d_pos);
-    gjInHash = false;
-    if (aggregateHash) {
-      const GJFuse g = gj ? *gj : GJFuse{};
-#define UH_HASH_AGG(GJ1, SLOT)                                                                                                   \
-  hipLaunchKernelGGL((k_hash_agg<GJ1, SLOT>), aggGrid, dim3(kBlock), 0, st, posw, N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, \
-                     (uint *)provRank.ptr, devErr, (unsigned char *)keyOutside.ptr, g, aux)
-      if (gj && slotted) UH_HASH_AGG(true, true);
-      else if (gj) UH_HASH_AGG(true, false);
-      else if (slotted) UH_HASH_AGG(false, true);
-      else UH_HASH_AGG(false, false);
-#undef UH_HASH_AGG
-      if (gj) { gjDone = true; gjInHash = true; }
-    } else
+    if (int e = provRank.reserve(sizeof(uint) * (size_t)N)) return e;
+    if (int e = members.reserve(sizeof(int) * (size_t)N)) return e;
+    if (aggregateHash && gj) {
+      hipLaunchKernelGGL((k_hash_agg<true, 1>), dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                         const_cast<float4 *>(d_pos), N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                         (unsigned char *)keyOutside.ptr, *gj);
+      gjDone = true;
+      gjInHash = true;
+    } else if (aggregateHash)
+      hipLaunchKernelGGL((k_hash_agg<false, 4>), dim3((N + kBlock * 4 - 1) / (kBlock * 4)), dim3(kBlock), 0, st,
+                         const_cast<float4 *>(d_pos), N, grid, (uint *)hash.ptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
+                         (unsigned char *)keyOutside.ptr, GJFuse{});
+    else
       hipLaunchKernelGGL(k_hash<true>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                          (int *)nullptr, (uint *)keyCount.ptr, (uint *)provRank.ptr, devErr,
-                         (unsigned char *)keyOutside.ptr, aux);
+                         (unsigned char *)keyOutside.ptr);
     if (int e = cellOutside.reserve((size_t)ncells + 16)) return e;
     if (int e = cellRange.reserve(sizeof(uint2) * ((size_t)ncells + 1))) return e;
-    hipLaunchKernelGGL(k_key_scan, dim3(nChunks), dim3(kBlock), 0, st, (const uint *)keyCount.ptr, nKeys, chunkShift,
-                       (unsigned long long *)scanFlags.ptr, scanGeneration, (uint *)keyStart.ptr, devErr);
-    const CellTablesArgs tables{(const uint *)keyStart.ptr, (unsigned char *)keyOutside.ptr, (uint *)keyCount.ptr, grid.cellDim, validCell,
-                                (uint *)cellStart.ptr, (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr,
-                                stat + 1 + (buildParity ^ 1), (uint *)wgMax.ptr};
-    const int pb = nblocks(N);
-    if (slotted) {
-      hipLaunchKernelGGL(k_rank_scatter_rows, dim3((unsigned)((ncells + kBlock / 32 - 1) / (kBlock / 32))), dim3(kBlock), 0, st, d_pos,
-                         (const uint *)keyStart.ptr, (const int *)slots.ptr, (const uint2 *)overflow.ptr, (const uint *)aux.ovfCount,
-                         (int *)index.ptr, (float4 *)sortPos.ptr, tables);
-    } else {
-      hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr, (const uint *)provRank.ptr,
-                         (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)sortHash.ptr);
-      hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
-                         (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr, tables);
+    {
+      const int chunkShift = endBit > 18 ? endBit - 8 : 10;  // <= kScanChunks chunks of >= 1024 keys
+      const int nChunks = (int)((nKeys + (1u << chunkShift) - 1) >> chunkShift);
+      if (!scanFlags.ptr) {
+        if (int e = scanFlags.reserve(sizeof(unsigned long long) * kScanChunks)) return e;
+        UH_CHECK(hipMemsetAsync(scanFlags.ptr, 0, sizeof(unsigned long long) * kScanChunks, st));
+        scanGeneration = 0;
+      }
+      if (++scanGeneration == 0u) scanGeneration = 1u;  // (0 is the cleared state)
+      hipLaunchKernelGGL(k_key_scan, dim3(nChunks), dim3(kBlock), 0, st, (const uint *)keyCount.ptr, nKeys, chunkShift,
+                         (unsigned long long *)scanFlags.ptr, scanGeneration, (uint *)keyStart.ptr, devErr);
     }
-    sortHashValid = !slotted;
+    hipLaunchKernelGGL(k_members, dim3(nblocks(N)), dim3(kBlock), 0, st, (const uint *)hash.ptr, (const uint *)provRank.ptr,
+                       (const uint *)keyStart.ptr, N, (int *)members.ptr, (uint *)sortHash.ptr);
+    const int pb = nblocks(N);
+    hipLaunchKernelGGL(k_rank_scatter2, dim3(pb + nblocks(ncells)), dim3(kBlock), 0, st, d_pos, (const uint *)sortHash.ptr,
+                       (const uint *)keyStart.ptr, (const int *)members.ptr, N, pb, (int *)index.ptr, (float4 *)sortPos.ptr,
+                       (unsigned char *)keyOutside.ptr, (uint *)keyCount.ptr, grid.cellDim, validCell, (uint *)cellStart.ptr,
+                       (int *)cellEnd.ptr, (unsigned char *)cellOutside.ptr, (uint2 *)cellRange.ptr);
     zeroBlockClean = true;
     haveCellOutside = true;
   } else {
     if (int e = indexAlt.reserve(sizeof(int) * (size_t)N)) return e;
-    sortHashValid = true;
-    usedSlotted = false;
     hipLaunchKernelGGL(k_hash<false>, dim3(nblocks(N)), dim3(kBlock), 0, st, d_pos, N, grid, (uint *)hash.ptr,
                        (int *)indexAlt.ptr, (uint *)nullptr, (uint *)nullptr, devErr,
-                       tabulated ? (unsigned char *)keyOutside.ptr : (unsigned char *)nullptr, BuildAux{});
+                       tabulated ? (unsigned char *)keyOutside.ptr : (unsigned char *)nullptr);
     if (endBit > 0) {
       size_t tmpBytes = 0;
       UH_CHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, (uint *)hash.ptr, (uint *)sortHash.ptr,
@@ -1048,20 +841,10 @@ int uammd_celllist_set_option(uammd_celllist *h, const char *name, int value) {
   CellList *cl = reinterpret_cast<CellList *>(h);
   if (std::string(name) == "force_radix") { cl->forceRadix = value != 0; return 0; }
   if (std::string(name) == "aggregate_hash") { cl->aggregateHash = value != 0; return 0; }
-  if (std::string(name) == "slotted_build") { cl->slottedBuild = value; return 0; }  // 0 never, 1 when the cells are known to fit, 2 always
   if (std::string(name) == "strict_errors") { cl->strictErrors = value != 0; return 0; }
   if (std::string(name) == "report_errors") { cl->reportErrors = value != 0; return 0; }
   if (std::string(name) == "num_owned") { cl->numOwned = value < 0 ? 0x7fffffff : value; return 0; }
   set_last_error("uammd_celllist_set_option: unknown option %s", name);
-  return -1;
-}
-
-int uammd_celllist_get_option(uammd_celllist *h, const char *name, int *value) {
-  if (!h || !name || !value) { set_last_error("uammd_celllist_get_option: null argument"); return -1; }
-  CellList *cl = reinterpret_cast<CellList *>(h);
-  if (std::string(name) == "used_counting") { *value = cl->usedCounting; return 0; }
-  if (std::string(name) == "used_slotted") { *value = cl->usedSlotted; return 0; }
-  set_last_error("uammd_celllist_get_option: unknown option %s", name);
   return -1;
 }
 
@@ -1073,7 +856,6 @@ int uammd_celllist_get(uammd_celllist *h, uammd_celllist_data *out) {
   out->d_cellEnd = (const int *)cl->cellEnd.ptr;
   out->d_sortPos = (const float *)cl->sortPos.ptr;
   out->d_groupIndex = (const int *)cl->index.ptr;
-  if (int e = cl->ensure_sort_hash()) return e;
   out->d_sortHash = (const unsigned int *)cl->sortHash.ptr;
   out->cellDim[0] = cl->grid.cellDim.x; out->cellDim[1] = cl->grid.cellDim.y; out->cellDim[2] = cl->grid.cellDim.z;
   for (int k = 0; k < 3; ++k) { out->boxSize[k] = cl->boxL[k]; out->periodic[k] = cl->boxPeriodic[k]; }

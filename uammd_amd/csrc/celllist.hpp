@@ -26,16 +26,6 @@ struct CellList {
   DeviceBuffer keyCount, keyStart, provRank, members, scratch, keyOutside, cellOutside, cellRange;
   DeviceBuffer scanFlags;        // k_key_scan's per-workgroup totals, tagged with scanGeneration
   uint scanGeneration = 0;
-  DeviceBuffer wgMax;            // largest cell per workgroup of the last rank kernel (relay_max_count)
-  int nWgMax = 0;
-  DeviceBuffer slots, overflow;  // slotted counting build (celllist.hip, BuildAux)
-  int slottedBuild = 1;          // option "slotted_build": 0 never, 1 when the cells are known to fit their rows, 2 always
-  bool usedSlotted = false;      // which build the last update took
-  bool sortHashValid = true;     // the slotted build does not write sortHash: uammd_celllist_get fills it on demand
-  int ensure_sort_hash();
-  int buildParity = 0;
-  int gridSeen[3] = {0, 0, 0}, gridSeenN = -1;
-  uint gridGen = 0, lastBuildGen = 0;
   bool lastFusedTile = false;  // uammd_verletnvt_gj_lj_step: the previous fused step ended in the tile traversal
   bool gjInHash = false;  // the last update applied the half step inside its hash kernel (gjDone: applied at all)
   DeviceBuffer packHalf;  // half-precision copy of sortPos for the traversals' prefilter, built on demand (ensure_pack)

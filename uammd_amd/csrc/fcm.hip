@@ -59,6 +59,7 @@ struct FCM {
   bool prepStreamSet = false;
   bool forceAtomicSpread = false;  // test hook
   bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
+  int gatherPerWave = 2;           // particles per wave of k_fcm_gather_inter (1, 2, 4)
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
   bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
   int zTileLog2 = 0;               // test / tuning hook: log2 of the fused z pass's node tile (0 = default)
@@ -606,20 +607,30 @@ __global__ void __launch_bounds__(256) k_fcm_interleave(const float *__restrict_
 // an L2 request limit.  Here the record and the weights are requested together, then every node of a chunk of R rounds, then the
 // arithmetic: two round trips per wave.  The sums run in the same order as before (round by round, then the xor reduction).
 constexpr int kGatherWaves = 4;  // (16 waves = 16 consecutive tile-sorted particles per workgroup, to share their lines in the CU's L1: 48.7 against 47.1 us)
-template <int R>
+// P = particles per wave: the kernel is bound by wave lifetimes (two round trips + the reduction, ~3.8 us, at 32 waves per CU), not by
+// bytes; a wave that carries P particles keeps P R loads in flight for the same two round trips.
+template <int R, int P>
 __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
                                                            int3 support, float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr,
                                                            bool accumulate) {
   const int lane = threadIdx.x & 63;
-  const int slot = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6);
-  if (slot >= N) return;
+  const int slot0 = ((int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6)) * P;
+  if (slot0 >= N) return;
   const int sx = support.x, sy = support.y, sz = support.z;
-  const int4 o = pr.origin[slot];
-  const float wl = pr.weights[(size_t)pr.wstride * slot + min(lane, sx + sy + sz - 1)];  // (unconditional: no branch between the two loads)
+  int4 o[P];
+  float wl[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const int slot = min(slot0 + q, N - 1);
+    o[q] = pr.origin[slot];
+    wl[q] = pr.weights[(size_t)pr.wstride * slot + min(lane, sx + sy + sz - 1)];  // (unconditional: no branch between the two loads)
+  }
   const int nn = sx * sy * sz;
-  float ax = 0.f, ay = 0.f, az = 0.f;
+  float ax[P], ay[P], az[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) ax[q] = ay[q] = az[q] = 0.f;
   for (int base = 0; base < nn; base += 64 * R) {
-    float4 v[R];
+    float4 v[P][R];
     int wsel[R];  // ii | jj << 8 | kk << 16, or -1
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -630,43 +641,64 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *_
       const uint rem = iu - kk * (uint)(sx * sy);
       const uint jj = dsx.div(rem);
       const uint ii = rem - jj * (uint)sx;
-      int cx = o.x + (int)ii, cy = o.y + (int)jj, cz = o.z + (int)kk;
-      cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
-      cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
-      cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
-      v[r] = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];  // (a lane past the stencil re-reads node 0 of it)
       wsel[r] = in ? (int)(ii | jj << 8 | kk << 16) : -1;
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        int cx = o[q].x + (int)ii, cy = o[q].y + (int)jj, cz = o[q].z + (int)kk;
+        cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
+        cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
+        cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
+        v[q][r] = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];  // (a lane past the stencil re-reads node 0 of it)
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ws = wsel[r] < 0 ? 0 : wsel[r];
-      const float wx = __shfl(wl, ws & 255, 64), wy = __shfl(wl, sx + ((ws >> 8) & 255), 64), wz = __shfl(wl, sx + sy + (ws >> 16), 64);
-      if (wsel[r] >= 0) {
-        ax = fmaf(dV, v[r].x * wx * wy * wz, ax);
-        ay = fmaf(dV, v[r].y * wx * wy * wz, ay);
-        az = fmaf(dV, v[r].z * wx * wy * wz, az);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const float wx = __shfl(wl[q], ws & 255, 64), wy = __shfl(wl[q], sx + ((ws >> 8) & 255), 64), wz = __shfl(wl[q], sx + sy + (ws >> 16), 64);
+        if (wsel[r] >= 0) {
+          ax[q] = fmaf(dV, v[q][r].x * wx * wy * wz, ax[q]);
+          ay[q] = fmaf(dV, v[q][r].y * wx * wy * wz, ay[q]);
+          az[q] = fmaf(dV, v[q][r].z * wx * wy * wz, az[q]);
+        }
       }
     }
   }
 #pragma unroll
   for (int o2 = 32; o2 > 0; o2 >>= 1) {
-    ax += __shfl_xor(ax, o2, 64);
-    ay += __shfl_xor(ay, o2, 64);
-    az += __shfl_xor(az, o2, 64);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      ax[q] += __shfl_xor(ax[q], o2, 64);
+      ay[q] += __shfl_xor(ay[q], o2, 64);
+      az[q] += __shfl_xor(az[q], o2, 64);
+    }
   }
   if (lane == 0) {
-    float *out = vout + 3 * (size_t)o.w;
-    if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      if (slot0 + q >= N) break;
+      float *out = vout + 3 * (size_t)o[q].w;
+      if (accumulate) { out[0] += ax[q]; out[1] += ay[q]; out[2] += az[q]; } else { out[0] = ax[q]; out[1] = ay[q]; out[2] = az[q]; }
+    }
   }
 }
+// (A window gather — a workgroup per tile stages the tile-edge + support window of the interleaved grid in LDS, 44 KB at C4, and its
+// four waves interpolate the tile's ~24 particles from LDS — was written twice: round 1 on the planar grids, 112 us, and round 3 on the
+// float4 grid with every load of a thread in flight together, 72 us against 47 us for the kernel above: three workgroups per CU do not
+// hide the window's round trip and the per-particle shuffle chains.  Not kept.)
 static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, int N, int3 n, int3 support, float dV, FastDiv dsx,
-                                FastDiv dsxy, const FcmPrep &pr, bool accumulate) {
-  const dim3 g((N + kGatherWaves - 1) / kGatherWaves), b(64 * kGatherWaves);
+                                FastDiv dsxy, const FcmPrep &pr, bool accumulate, int perWave = 2) {
   const int rounds = (support.x * support.y * support.z + 63) / 64;
-  if (rounds <= 1) hipLaunchKernelGGL(k_fcm_gather_inter<1>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
-  else if (rounds <= 2) hipLaunchKernelGGL(k_fcm_gather_inter<2>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
-  else if (rounds <= 4) hipLaunchKernelGGL(k_fcm_gather_inter<4>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
-  else hipLaunchKernelGGL(k_fcm_gather_inter<8>, g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate);
+  // (measured at C4, support 6: 47.3 / 40.2 / 40.8 us with 1 / 2 / 4 particles per wave)
+  const int P = (rounds <= 4 && perWave >= 2) ? (perWave >= 4 ? 4 : 2) : 1;
+  const dim3 g((N + kGatherWaves * P - 1) / (kGatherWaves * P)), b(64 * kGatherWaves);
+#define UH_GI(RR, PP) hipLaunchKernelGGL((k_fcm_gather_inter<RR, PP>), g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate)
+  if (rounds <= 1) { if (P == 4) UH_GI(1, 4); else if (P == 2) UH_GI(1, 2); else UH_GI(1, 1); }
+  else if (rounds <= 2) { if (P == 4) UH_GI(2, 4); else if (P == 2) UH_GI(2, 2); else UH_GI(2, 1); }
+  else if (rounds <= 4) { if (P == 4) UH_GI(4, 4); else if (P == 2) UH_GI(4, 2); else UH_GI(4, 1); }
+  else UH_GI(8, 1);
+#undef UH_GI
 }
 
 // ---- Fourier space ---------------------------------------------------------------------------------------
@@ -1355,7 +1387,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
       hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, (float4 *)f->interBuf.ptr);
     launch_gather_inter(st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume,
-                        dsx, dsxy, pr, f->accumulate);
+                        dsx, dsxy, pr, f->accumulate, f->gatherPerWave);
   } else if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
                        f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);
@@ -1369,6 +1401,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
+  if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
   if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
   if (std::string(name) == "z_tile_log2" && (value == 0 || value == 2 || value == 3 || value == 4)) { reinterpret_cast<FCM *>(h)->zTileLog2 = value; return 0; }
@@ -1500,7 +1533,7 @@ int uammd_fcm_slab_gather(uammd_fcm_slab *h, const float *d_posLocal, int N, con
       hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, st, d_grid, f->grid.cellDim,
                          f->nxpad, f->planeReal, zs, (float4 *)f->interBuf.ptr);
       launch_gather_inter(st, d_vel, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume, dsx, dsxy,
-                          pr, f->accumulate);
+                          pr, f->accumulate, f->gatherPerWave);
     } else
       hipLaunchKernelGGL(k_fcm_gather_prep, dim3((N + 3) / 4), dim3(256), 0, st, d_vel, d_grid, N, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);

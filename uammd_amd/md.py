@@ -275,11 +275,6 @@ class CellList:
     def set_option(self, name, value):
         check(self.lib.uammd_celllist_set_option(self.h, name.encode(), int(value)))
 
-    def get_option(self, name):
-        v = C.c_int(0)
-        check(self.lib.uammd_celllist_get_option(self.h, name.encode(), C.byref(v)))
-        return v.value
-
     @staticmethod
     def create_update_grid(box, cutoff):
         lib = _lib.load()
