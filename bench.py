@@ -793,7 +793,11 @@ def main():
                      "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS,
                      "traffic": traffic, "kernel_ms": k_ms, "kernel_launches_timed": k_launches,
                      "note": "the kernel is bound by f32 vector-instruction issue, not HBM; achieved = the reference walk's 1.0e4 flop/particle "
-                             "(340 candidates x ~30 flop, SURVEY 8d) / mean kernel time of every launch of the timed region; peak = f32 vector peak",
+                             "(340 candidates x ~30 flop, SURVEY 8d) / mean kernel time of every launch of the timed region; peak = f32 vector peak, which is "
+                             "quoted on the packed v_pk_*_f32 instructions: they issue at half rate here (the drain rewritten on them: 144 -> 166 us, "
+                             "DESIGN 5.2), single-issue f32 peaks at 78.6 TFLOP/s, and the kernel's issue port is busy for its whole duration "
+                             "(SQ_ACTIVE_INST_VALU x 4 = 3.9e5 cycles per SIMD against 3.5e5 cycles of run time, profiles/r03_pmc_lj_tile4.txt)",
+                     "frac_of_single_issue_peak": achieved_tflops / (PEAK_FP32_TFLOPS / 2),
                      "hbm_frac_compulsory": BYTES_COMPULSORY_PER_PARTICLE * n / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
     }
     if args.workload == "both" and args.nl == "cell" and world == 1:
