@@ -124,3 +124,30 @@ def test_sort_pairs_stable_and_end_bit(hip, o32):
         torch.cuda.synchronize()
         assert np.array_equal(dv.cpu().numpy(), rv)
         assert np.array_equal(dk.cpu().numpy().view(np.uint32), rk)
+
+
+@pytest.mark.parametrize("n,L,note", [(300000, 250.0, "2^21 keys: 256 scan workgroups of 8192 keys"),
+                                       (40000, (20.0, 20.0, 640.0), "256 cells along z only: a 2^24-key envelope falls back to the radix build"),
+                                       (70000, (45.0, 40.0, 160.0), "2^18 keys, most of them not cells")])
+def test_counting_build_key_scan_sizes(hip, n, L, note):
+    """k_key_scan (the counting build's one-launch scan of the key counters) over key spaces of other sizes than the bench's: the
+    tables equal the radix build's, build after build on the same handle (the per-workgroup totals are tagged with a generation, never
+    reset)."""
+    pos = lattice_positions(n, L, seed=21, jitter=0.4)
+    box = hip.Box(L)
+    cd, ubox = hip.CellList.create_update_grid(box, 2.5)
+    cl, ref_cl = hip.CellList(), hip.CellList()
+    ref_cl.set_option("force_radix", 1)
+    rng = np.random.default_rng(9)
+    for it in range(3):
+        d_pos = torch.from_numpy(pos).cuda()
+        cl.update_grid(d_pos, ubox, cd)
+        ref_cl.update_grid(d_pos, ubox, cd)
+        a, b = cl.to_host(), ref_cl.to_host()
+        for k in ("hash", "index"):
+            assert np.array_equal(a[k], b[k]), (it, k)
+        assert np.array_equal(a["sortPos"].view(np.uint32), b["sortPos"].view(np.uint32))
+        sa, ea = canon_cell_tables(a)
+        sb, eb = canon_cell_tables(b)
+        assert np.array_equal(sa, sb) and np.array_equal(ea, eb)
+        pos = (pos + rng.normal(0, 0.3, pos.shape).astype(np.float32)).astype(np.float32)

@@ -467,3 +467,26 @@ def test_fcm_gather_particles_per_wave(hip, cells, tol, n):
     for mode in (2, 4):
         for a, b in zip(out[1], out[mode]):
             assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+
+
+def test_fcm_spread_two_waves_per_tile(hip, o32):
+    """k_fcm_spread_tile<2> (two waves per tile, the choice for sparse tiles) against the four-wave form and the atomic spread: a dilute
+    case where it is the default and a dense one where it is forced (lists longer than its 128-entry rounds)."""
+    for cells, n, tol in (((64, 64, 64), 3000, 1e-3), ((48, 48, 48), 60000, 1e-3), ((40, 56, 48), 20000, 1e-4)):
+        L = np.asarray(cells, np.float32)
+        rng = np.random.default_rng(n)
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, :3] = rng.uniform(-1.0, 1.0, (n, 3)) * L
+        force = np.zeros((n, 4), np.float32)
+        force[:, :3] = rng.normal(0, 1, (n, 3))
+        k, a_eff = hip.Kernels.Gaussian(1.0, tol)
+        dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+        out = {}
+        for mode, opt in (("w4", ("spread_waves", 4)), ("w2", ("spread_waves", 2)), ("atomic", ("atomic_spread", 1))):
+            fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+            fcm.set_option(*opt)
+            out[mode] = fcm.fourier_grid(dp, df, n, 0.0, 0.0).cpu().numpy()
+        scale = np.abs(out["atomic"]).max()
+        assert scale > 0
+        assert np.abs(out["w2"] - out["atomic"]).max() <= 2e-5 * scale
+        assert np.abs(out["w2"] - out["w4"]).max() <= 2e-5 * scale

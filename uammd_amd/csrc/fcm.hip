@@ -60,6 +60,7 @@ struct FCM {
   bool forceAtomicSpread = false;  // test hook
   bool interGather = true;         // gather from an interleaved float4 copy of the velocity grids (k_fcm_interleave)
   int gatherPerWave = 2;           // particles per wave of k_fcm_gather_inter (1, 2, 4)
+  int spreadWaves = 0;             // waves per tile of k_fcm_spread_tile: 0 = by the tiles' population (spread_waves), 2, 4
   bool tileGather = false;         // LDS-staged gather (k_fcm_gather_tile): measured SLOWER than the global gather, off
   bool accumulate = false;         // gather adds into the output (IBM::gather semantics; PSE far field)
   int zTileLog2 = 0;               // test / tuning hook: log2 of the fused z pass's node tile (0 = default)
@@ -283,16 +284,27 @@ struct SpEntry {
 };
 // dynamic LDS: float wts[weightWords + 32] (+32: out-of-stencil lanes read up to 15 words past a particle's weights) | SpEntry list[257]
 // (+1: phase C reads 8 words per 5-word entry); the four private tiles of the final sum alias the same block
-static size_t spread_lds_bytes(int weightWords) {
-  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * 4 * 3 * kTile * kTile * kTile;
+static size_t spread_lds_bytes(int weightWords, int waves = 4) {
+  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * waves * 3 * kTile * kTile * kTile;
   return a > b ? a : b;
+}
+// two waves per tile where a tile lists few particles (measured at C5, ~26 listed: see DESIGN 5.4), four otherwise
+static int spread_waves(int N, int3 ntiles, int3 support, int3 tdim, int option) {
+  if (option == 2 || option == 4) return option;
+  const double perTile = (double)N / ((double)ntiles.x * ntiles.y * ntiles.z);
+  const double listed = perTile * (1.0 + (support.x - 1) / (double)tdim.x) * (1.0 + (support.y - 1) / (double)tdim.y) * (1.0 + (support.z - 1) / (double)tdim.z);
+  return listed > 48.0 ? 4 : 2;
 }
 static int spread_weight_words(int N, int3 ntiles, int3 support, int3 tdim) {
   const double perTile = (double)N / ((double)ntiles.x * ntiles.y * ntiles.z);
   const double listed = perTile * (1.0 + (support.x - 1) / (double)tdim.x) * (1.0 + (support.y - 1) / (double)tdim.y) * (1.0 + (support.z - 1) / (double)tdim.z);
   return listed > 64.0 ? kSpWeightWordsMax : kSpWeightWordsMax / 2;
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+// W = waves per workgroup: 4, or 2 where the tiles are sparse (spread_waves) — a tile then costs the same chain of round trips for a
+// few matrix steps: twice the tiles in flight for the same waves.  Measured at C5 (256^3, 6 particles per tile, ~26 listed): 179 / 168 /
+// 224 us with 4 / 2 / 1 waves per tile; at C4 (24 per tile, ~105 listed) 62 / 98 with 4 / 2.
+template <int W>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
                   FcmPrep pr, int weightWords) {
   constexpr int T3 = kTile * kTile * kTile;
@@ -301,8 +313,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
   float *acc = reinterpret_cast<float *>(smem);
   __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
+  constexpr int kThreads = 64 * W;
   __shared__ int waveCnt[4 * kSpPerThread];
-  __shared__ unsigned char owner[256 * kSpPerThread];
+  __shared__ unsigned char owner[kThreads * kSpPerThread];
   __builtin_amdgcn_s_setprio(3);  // phases that load go ahead of the phase that computes (five workgroups share a CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -318,7 +331,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
   const int wpad = wstride + 2 * kSpZPad;  // LDS words per listed particle
-  const int capEntries = min(256, weightWords / wpad);
+  const int capEntries = min(kThreads, weightWords / wpad);
   if (threadIdx.x < 27) {
     const int nb = threadIdx.x;
     const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
@@ -352,7 +365,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // phase B
     const int words = count * wpad;
     const float rws = 1.0f / (float)wpad;
-    for (int e = threadIdx.x; e < words; e += 256) {
+    for (int e = threadIdx.x; e < words; e += kThreads) {
       const int pp = (int)(((float)e + 0.5f) * rws);  // exact: e < 2^14
       int k = e - pp * wpad;
       bool pad = false;
@@ -370,12 +383,12 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // (History: lanes over the nodes of the stencil-tile intersection with LDS read-modify-write, 104 us per call at C4; lane =
     // column with 24 register accumulators on the VALU, 83 us of which this phase was 41 — measured by switching the phases
     // off one at a time: A 19, B 12, C 41, prologue + reduction + store 12; with the MFMA form C is ~22 and the call 65 us.)
-    const int mineCount = (count - wave + 3) >> 2;  // entries wave, wave + 4, ... of the list
+    const int mineCount = (count - wave + W - 1) / W;  // entries wave, wave + W, ... of the list
     __builtin_amdgcn_s_setprio(0);  // (the arithmetic phase yields to the workgroups that are issuing loads: see the kernel's top)
     for (int j = 0; j < mineCount; j += 2) {
       const int idx = j + half;
       const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
-      const int e = wave + 4 * (real ? idx : 0);
+      const int e = wave + W * (real ? idx : 0);
       const int po = sh.list[e].o;
       const float fc = (real && aValid) ? reinterpret_cast<const float *>(&sh.list[e].fx)[aC] : 0.0f;
       const int ox = (po & 255) - 64, oy = ((po >> 8) & 255) - 64, oz = (po >> 16) - 64;
@@ -393,15 +406,16 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     __syncthreads();
   };
 
-  const int perRound = min(capEntries, 256) * kSpPerThread;
+  const int perRound = min(capEntries, kThreads) * kSpPerThread;
   for (int c0 = 0; c0 < total; c0 += perRound) {
     // phase A: kSpPerThread candidates per thread, their 16-byte records in flight together.  owner[] maps a candidate of this
     // round to its range (written by eight threads per range) instead of a binary search per candidate.
     {
-      const int nb = threadIdx.x >> 3;
+      constexpr int kPerRange = W == 4 ? 8 : 4;  // threads that fill one range's part of owner[]
+      const int nb = threadIdx.x / kPerRange;
       if (nb < 27) {
         const int lo = max(rPrefix[nb], c0), hi = min(rPrefix[nb + 1], c0 + perRound);
-        for (int c = lo + (int)(threadIdx.x & 7); c < hi; c += 8) owner[c - c0] = (unsigned char)nb;
+        for (int c = lo + (int)(threadIdx.x % kPerRange); c < hi; c += kPerRange) owner[c - c0] = (unsigned char)nb;
       }
     }
     __syncthreads();
@@ -433,7 +447,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {  // sub-rounds in candidate order (the list order is the summation order)
-      const int c0w = waveCnt[4 * u], c1w = waveCnt[4 * u + 1], c2w = waveCnt[4 * u + 2], c3w = waveCnt[4 * u + 3];
+      const int c0w = waveCnt[4 * u], c1w = W > 1 ? waveCnt[4 * u + 1] : 0, c2w = W > 2 ? waveCnt[4 * u + 2] : 0, c3w = W > 2 ? waveCnt[4 * u + 3] : 0;
       const int roundCount = c0w + c1w + c2w + c3w;
       if (listCount + roundCount > capEntries) {  // uniform: spread what is listed, then start a new list
         spread_list(listCount);
@@ -464,13 +478,19 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < T3; i += 256) {
+  for (int i = threadIdx.x; i < T3; i += kThreads) {
     const int lx = i % kTile, ly = (i / kTile) % kTile, lz = i / (kTile * kTile);
     if (lx >= td.x || ly >= td.y || lz >= td.z) continue;  // (a tile edge shorter than the layout's 8: those rows belong to a neighbour)
     const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * (size_t)(y0 + ly) + zstride * (size_t)(z0 + lz);
-    g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
-    g0[plane + node] = (acc[T3 + i] + acc[4 * T3 + i]) + (acc[7 * T3 + i] + acc[10 * T3 + i]);
-    g0[2 * plane + node] = (acc[2 * T3 + i] + acc[5 * T3 + i]) + (acc[8 * T3 + i] + acc[11 * T3 + i]);
+    if (W == 4) {
+      g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
+      g0[plane + node] = (acc[T3 + i] + acc[4 * T3 + i]) + (acc[7 * T3 + i] + acc[10 * T3 + i]);
+      g0[2 * plane + node] = (acc[2 * T3 + i] + acc[5 * T3 + i]) + (acc[8 * T3 + i] + acc[11 * T3 + i]);
+    } else {
+      g0[node] = acc[i] + acc[3 * T3 + i];
+      g0[plane + node] = acc[T3 + i] + acc[4 * T3 + i];
+      g0[2 * plane + node] = acc[2 * T3 + i] + acc[5 * T3 + i];
+    }
   }
 }
 
@@ -1340,7 +1360,12 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
     if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
-      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+      const int sw = spread_waves(N, f->ntiles, f->kern.support, f->tdim, f->spreadWaves);
+      if (sw == 2)
+        hipLaunchKernelGGL(k_fcm_spread_tile<2>, dim3(nt), dim3(128), spread_lds_bytes(ww, 2), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+                           zs, f->kern.support, f->ntiles, pr, ww);
+      else
+      hipLaunchKernelGGL(k_fcm_spread_tile<4>, dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
                          zs, f->kern.support, f->ntiles, pr, ww);
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
@@ -1401,6 +1426,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
+  if (std::string(name) == "spread_waves") { reinterpret_cast<FCM *>(h)->spreadWaves = value; return 0; }
   if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
   if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
@@ -1493,7 +1519,7 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
     if (d_force) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
-      hipLaunchKernelGGL(k_fcm_spread_tile, dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
+      hipLaunchKernelGGL(k_fcm_spread_tile<4>, dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
                          f->kern.support, f->ntiles, pr, ww);
     }
   } else if (d_force) {
