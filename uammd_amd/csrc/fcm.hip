@@ -935,9 +935,18 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
   float2 *base = g + q0 + l;
   fft_twiddles<NT>(tw, nz, tid);
   if (haveForce) {
-    if (l < nl)
-      for (int c = 0; c < 3; ++c)
-        for (int j = jg; j < nz; j += JG) buf[(c * nl + l) * LS + j] = base[(size_t)c * planeC + (size_t)j * slab];
+    if (l < nl) {  // element e = c (nz / JG) + j / JG of this thread's 3 nz / JG
+      const int perC = (nz + JG - 1) / JG;
+      staged_copy<12, float2>(0, 3 * perC, 1,
+          [&](int e) {
+            const int c = e / perC, j = jg + (e - c * perC) * JG;
+            return j < nz ? base[(size_t)c * planeC + (size_t)j * slab] : make_float2(0.f, 0.f);
+          },
+          [&](int e, float2 v) {
+            const int c = e / perC, j = jg + (e - c * perC) * JG;
+            if (j < nz) buf[(c * nl + l) * LS + j] = v;
+          });
+    }
     __syncthreads();
     fft_lds<-1, MAXB, NT>(buf, LS, log2nz, 3 * nl, tw, 1, tid);
   } else

@@ -28,6 +28,25 @@ template <int SIGN> UH_D float2 ctw(float2 a, float2 w) {
   return make_float2(fmaf(a.x, w.x, a.y * w.y), fmaf(a.y, w.x, -(a.x * w.y)));
 }
 
+// Global -> LDS copies go through registers U at a time: written as `buf[f(i)] = g[h(i)]` in a loop of run-time length the compiler
+// emits load, s_waitcnt vmcnt(0), ds_write per iteration — every element one dependent round trip (8 to 16 of them per workgroup in
+// each of these kernels).  Here the U loads of a round are all issued before the first is used.
+template <int U, class T, class LD, class ST> UH_D void staged_copy(int begin, int end, int step, LD ld, ST st) {
+  for (int i0 = begin; i0 < end; i0 += step * U) {
+    T t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * step;
+      if (i < end) t[u] = ld(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * step;
+      if (i < end) st(i, t[u]);
+    }
+  }
+}
+
 // exp(-2 pi i k / n), k < n, into LDS (n <= 512: sincospif is exact enough and runs once per workgroup)
 template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int tid) {
   for (int k = tid; k < n; k += NT) {
@@ -162,20 +181,26 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
   float2 *tw = lds, *buf = lds + nx;
   const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);
   fft_twiddles(tw, nx, tid);
-  for (int i = tid; i < nr * nh; i += kFftThreads) {
-    const int r = i >> (log2nx - 1), j = i & (nh - 1);
-    float2 v = *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
-    if (FOLD) {
-      const int row = r0 + r;
-      if (row < foldRows) {
-        const float2 a = *(const float2 *)(addLo + (size_t)row * nxpad + 2 * j);
-        v = make_float2(v.x + a.x, v.y + a.y);
-      } else if (row >= nrows - foldRows) {
-        const float2 a = *(const float2 *)(addHi + (size_t)(row - (nrows - foldRows)) * nxpad + 2 * j);
-        v = make_float2(v.x + a.x, v.y + a.y);
-      }
-    }
-    buf[r * LS + j] = v;
+  staged_copy<8, float2>(tid, nr * nh, kFftThreads,
+      [&](int i) {
+        const int r = i >> (log2nx - 1), j = i & (nh - 1);
+        return *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
+      },
+      [&](int i, float2 v) { buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))] = v; });
+  if (FOLD) {  // (the rows that take a neighbour's halo plane: a second pass over those rows only)
+    __syncthreads();
+    staged_copy<8, float2>(tid, nr * nh, kFftThreads,
+        [&](int i) {
+          const int r = i >> (log2nx - 1), j = i & (nh - 1), row = r0 + r;
+          float2 a = make_float2(0.f, 0.f);
+          if (row < foldRows) a = *(const float2 *)(addLo + (size_t)row * nxpad + 2 * j);
+          else if (row >= nrows - foldRows) a = *(const float2 *)(addHi + (size_t)(row - (nrows - foldRows)) * nxpad + 2 * j);
+          return a;
+        },
+        [&](int i, float2 a) {
+          float2 &v = buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))];
+          v = make_float2(v.x + a.x, v.y + a.y);
+        });
   }
   __syncthreads();
   fft_lds<-1, 2>(buf, LS, log2nx - 1, nr, tw, 2, tid);
@@ -222,10 +247,9 @@ __global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__res
   const int tid = threadIdx.x;
   float *plane = g + (size_t)blockIdx.x * ny * nxpad;   // (the three planar component grids are contiguous: plane index = c nz + z)
   fft_twiddles<kPlaneThreads>(tw, ntw, tid);
-  for (int i = tid; i < ny * nh; i += kPlaneThreads) {
-    const int r = i >> (log2nx - 1), j = i & (nh - 1);
-    buf[r * LS + j] = *(const float2 *)(plane + (size_t)r * nxpad + 2 * j);
-  }
+  staged_copy<8, float2>(tid, ny * nh, kPlaneThreads,
+      [&](int i) { return *(const float2 *)(plane + (size_t)(i >> (log2nx - 1)) * nxpad + 2 * (i & (nh - 1))); },
+      [&](int i, float2 v) { buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))] = v; });
   __syncthreads();
   // rows: ny complex FFTs of nh points (table stride: exp(-2 pi i k / nh) = tw[k ntw / nh])
   fft_lds<-1, 2, kPlaneThreads>(buf, LS, log2nx - 1, ny, tw, ntw / nh, tid);
@@ -274,7 +298,7 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
   float2 *base = g + (size_t)group * n * nkx + kx0 + l;
   fft_twiddles<NT>(tw, n, tid);
   if (l < nl)
-    for (int j = jg; j < n; j += NT / 16) buf[l * LS + j] = base[(size_t)j * nkx];
+    staged_copy<16, float2>(jg, n, NT / 16, [&](int j) { return base[(size_t)j * nkx]; }, [&](int j, float2 v) { buf[l * LS + j] = v; });
   __syncthreads();
   fft_lds<SIGN, MAXB, NT>(buf, LS, log2n, nl, tw, 1, tid);
   if (l < nl)
@@ -296,14 +320,26 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
   float2 *tw = lds, *buf = lds + nx;
   const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);  // rows x 3 components
   fft_twiddles(tw, nx, tid);
-  for (int c = 0; c < 3; ++c)
-    for (int i = tid; i < nr * nh; i += kFftThreads) {
-      const int r = i >> (log2nx - 1), k = i & (nh - 1);
+  {  // element e = c (nr nh) + r nh + k of the 3 nr rows; the rows' last (Nyquist) entries in a second, short round
+    const int per = nr * nh;
+    auto rowOf = [&](int c, int r) {
       const int gr = r0 + r;
-      const float *row = g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad;
-      buf[(c * nr + r) * LS + k] = *(const float2 *)(row + 2 * k);
-      if (k == 0) buf[(c * nr + r) * LS + nh] = *(const float2 *)(row + 2 * nh);
+      return g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad;
+    };
+    staged_copy<12, float2>(tid, 3 * per, kFftThreads,
+        [&](int e) {
+          const int c = e / per, i = e - c * per;
+          return *(const float2 *)(rowOf(c, i >> (log2nx - 1)) + 2 * (i & (nh - 1)));
+        },
+        [&](int e, float2 v) {
+          const int c = e / per, i = e - c * per;
+          buf[(c * nr + (i >> (log2nx - 1))) * LS + (i & (nh - 1))] = v;
+        });
+    if (tid < 3 * nr) {
+      const int c = tid / nr, r = tid - c * nr;
+      buf[(c * nr + r) * LS + nh] = *(const float2 *)(rowOf(c, r) + 2 * nh);
     }
+  }
   __syncthreads();
   // Z_k = (X_k + conj X_{nh-k}) + i W^{-k} (X_k - conj X_{nh-k}), k = 0 .. nh - 1
   for (int i = tid; i < 3 * nr * (nh / 2); i += kFftThreads) {
