@@ -133,6 +133,25 @@ UH_D uint xcd_contiguous_block(uint b, uint nb) {
 }
 UH_HD uint morton_hash(int3 c) { return spread10((uint)c.x) | (spread10((uint)c.y) << 1) | (spread10((uint)c.z) << 2); }
 
+// Global -> LDS copies go through registers U at a time: written as `buf[f(i)] = g[h(i)]` in a loop of run-time length the compiler
+// emits load, s_waitcnt vmcnt(0), ds_write per iteration — every element one dependent round trip (8 to 16 of them per workgroup in
+// each of these kernels).  Here the U loads of a round are all issued before the first is used.
+template <int U, class T, class LD, class ST> UH_D void staged_copy(int begin, int end, int step, LD ld, ST st) {
+  for (int i0 = begin; i0 < end; i0 += step * U) {
+    T t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * step;
+      if (i < end) t[u] = ld(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * step;
+      if (i < end) st(i, t[u]);
+    }
+  }
+}
+
 // ---- error plumbing ------------------------------------------------------------------------------
 void set_last_error(const char *fmt, ...);
 #define UH_CHECK(expr)                                                                         \

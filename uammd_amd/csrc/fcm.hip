@@ -365,16 +365,19 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // phase B
     const int words = count * wpad;
     const float rws = 1.0f / (float)wpad;
-    for (int e = threadIdx.x; e < words; e += kThreads) {
-      const int pp = (int)(((float)e + 0.5f) * rws);  // exact: e < 2^14
-      int k = e - pp * wpad;
-      bool pad = false;
-      if (k >= sx + sy) {  // z weights sit between two runs of kSpZPad zeros
-        k -= kSpZPad;
-        pad = k < sx + sy || k >= wstride;
-      }
-      sh.wts[e] = pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp].slot + k];
-    }
+    // (staged: as a plain loop the compiler waits for every load before it issues the next, ~13 round trips per tile at C4)
+    staged_copy<8, float>(threadIdx.x, words, kThreads,
+        [&](int e) {
+          const int pp = (int)(((float)e + 0.5f) * rws);  // exact: e < 2^14
+          int k = e - pp * wpad;
+          bool pad = false;
+          if (k >= sx + sy) {  // z weights sit between two runs of kSpZPad zeros
+            k -= kSpZPad;
+            pad = k < sx + sy || k >= wstride;
+          }
+          return pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp].slot + k];
+        },
+        [&](int e, float v) { sh.wts[e] = v; });
     __syncthreads();
     // phase C on the matrix pipe.  For one tile the spreading is a product: G[n][xy] += sum_p A[n][p] B[p][xy] with
     // n = 3 kz + c (8 planes x 3 components = 24 of 32 rows), xy the 64 columns of the tile, A[n][p] = wz_p[kz] f_p[c] and

@@ -28,25 +28,6 @@ template <int SIGN> UH_D float2 ctw(float2 a, float2 w) {
   return make_float2(fmaf(a.x, w.x, a.y * w.y), fmaf(a.y, w.x, -(a.x * w.y)));
 }
 
-// Global -> LDS copies go through registers U at a time: written as `buf[f(i)] = g[h(i)]` in a loop of run-time length the compiler
-// emits load, s_waitcnt vmcnt(0), ds_write per iteration — every element one dependent round trip (8 to 16 of them per workgroup in
-// each of these kernels).  Here the U loads of a round are all issued before the first is used.
-template <int U, class T, class LD, class ST> UH_D void staged_copy(int begin, int end, int step, LD ld, ST st) {
-  for (int i0 = begin; i0 < end; i0 += step * U) {
-    T t[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * step;
-      if (i < end) t[u] = ld(i);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * step;
-      if (i < end) st(i, t[u]);
-    }
-  }
-}
-
 // exp(-2 pi i k / n), k < n, into LDS (n <= 512: sincospif is exact enough and runs once per workgroup)
 template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int tid) {
   for (int k = tid; k < n; k += NT) {
