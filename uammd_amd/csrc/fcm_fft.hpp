@@ -37,11 +37,45 @@ template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int ti
   }
 }
 
+// the R-point DFT of v (SIGN < 0: forward, exp(-2 pi i r m / R)), in place, natural order out
+template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
+  auto mul_mi = [](float2 d) { return SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x); };  // -i d (forward), +i d (inverse)
+  if (R == 2) {
+    const float2 a = v[0], c = v[1];
+    v[0] = cadd(a, c);
+    v[1] = csub(a, c);
+  } else if (R == 4) {
+    const float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = mul_mi(csub(v[1], v[3]));
+    v[0] = cadd(a0, a2);
+    v[1] = cadd(a1, a3);
+    v[2] = csub(a0, a2);
+    v[3] = csub(a1, a3);
+  } else {  // 8 = 2 x 4: sums and differences four apart, the differences turned by W8^r, then a 4-point DFT of either half
+    float2 e[4], o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e[r] = cadd(v[r], v[r + 4]); o[r] = csub(v[r], v[r + 4]); }
+    const float h = 0.70710678118654752440f;
+    // W8 = exp(-i pi / 4) forward: (x + i y)(h - i h) = h (x + y) + i h (y - x); inverse the conjugate
+    o[1] = SIGN < 0 ? make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)) : make_float2(h * (o[1].x - o[1].y), h * (o[1].y + o[1].x));
+    o[2] = mul_mi(o[2]);
+    // W8^3 = exp(-3 i pi / 4) forward: (x + i y)(-h - i h) = h (y - x) - i h (x + y)
+    o[3] = SIGN < 0 ? make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)) : make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y));
+    {
+      const float2 a0 = cadd(e[0], e[2]), a1 = csub(e[0], e[2]), a2 = cadd(e[1], e[3]), a3 = mul_mi(csub(e[1], e[3]));
+      v[0] = cadd(a0, a2); v[2] = cadd(a1, a3); v[4] = csub(a0, a2); v[6] = csub(a1, a3);
+    }
+    {
+      const float2 a0 = cadd(o[0], o[2]), a1 = csub(o[0], o[2]), a2 = cadd(o[1], o[3]), a3 = mul_mi(csub(o[1], o[3]));
+      v[1] = cadd(a0, a2); v[3] = cadd(a1, a3); v[5] = csub(a0, a2); v[7] = csub(a1, a3);
+    }
+  }
+}
+
 // One Stockham pass of radix R over `nlines` lines of N = 2^LOG2N points at buf[line * LS + j]; the sub-transforms entering the pass
 // have 2^LOG2NS points.  tw holds exp(-2 pi i k / NT) for k < NT, NT = N << LOG2TWSHIFT... (twStride = NT / N).
 template <int R, int SIGN, int MAXB, int NT>
 UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
-  constexpr int LR = R == 4 ? 2 : 1;
+  constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
   const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
   float2 v[MAXB][R];
   int dst[MAXB];
@@ -57,19 +91,7 @@ UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const
       for (int r = 0; r < R; ++r) v[q][r] = p[r * per];
 #pragma unroll
       for (int r = 1; r < R; ++r) v[q][r] = ctw<SIGN>(v[q][r], tw[t1 * r]);
-      if (R == 2) {
-        const float2 a = v[q][0], c = v[q][1];
-        v[q][0] = cadd(a, c);
-        v[q][1] = csub(a, c);
-      } else {
-        const float2 a0 = cadd(v[q][0], v[q][2]), a1 = csub(v[q][0], v[q][2]), a2 = cadd(v[q][1], v[q][3]);
-        const float2 d = csub(v[q][1], v[q][3]);
-        const float2 a3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);  // -i d (forward), +i d (inverse)
-        v[q][0] = cadd(a0, a2);
-        v[q][1] = cadd(a1, a3);
-        v[q][2] = csub(a0, a2);
-        v[q][3] = csub(a1, a3);
-      }
+      fft_butterfly<R, SIGN>(v[q]);
       dst[q] = line * LS + ((j - k) << LR) + k;
     }
   }
@@ -87,7 +109,7 @@ UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const
 // LS = 1, ES = the row stride)
 template <int R, int SIGN, int MAXB, int NT>
 UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
-  constexpr int LR = R == 4 ? 2 : 1;
+  constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
   const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
   float2 v[MAXB][R];
   int dst[MAXB];
@@ -104,19 +126,7 @@ UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, i
       for (int r = 0; r < R; ++r) v[q][r] = p[r * per * ES];
 #pragma unroll
       for (int r = 1; r < R; ++r) v[q][r] = ctw<SIGN>(v[q][r], tw[t1 * r]);
-      if (R == 2) {
-        const float2 a = v[q][0], c = v[q][1];
-        v[q][0] = cadd(a, c);
-        v[q][1] = csub(a, c);
-      } else {
-        const float2 a0 = cadd(v[q][0], v[q][2]), a1 = csub(v[q][0], v[q][2]), a2 = cadd(v[q][1], v[q][3]);
-        const float2 d = csub(v[q][1], v[q][3]);
-        const float2 a3 = SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-        v[q][0] = cadd(a0, a2);
-        v[q][1] = cadd(a1, a3);
-        v[q][2] = csub(a0, a2);
-        v[q][3] = csub(a1, a3);
-      }
+      fft_butterfly<R, SIGN>(v[q]);
       dst[q] = line * LS + (((j - k) << LR) + k) * ES;
     }
   }
@@ -129,25 +139,24 @@ UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, i
     }
   __syncthreads();
 }
+// Pass plan: radix 8 where it fits (a pass is two workgroup barriers and a trip of every point through LDS whatever its radix: 64 points
+// are two passes instead of three, 128 and 256 three instead of four): log2 N = 3 a + 2 b with b <= 2, the radix-4 passes first.
+// MAXB = radix-4 butterflies per thread; a radix-8 pass has half as many.
 template <int SIGN, int MAXB, int NT>
 UH_D void fft_lds_strided(float2 *buf, int LS, int ES, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
+  const int n4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);  // 4 = 2 + 2, 5 = 2 + 3, 7 = 2 + 2 + 3, 8 = 2 + 3 + 3
   int s = 0;
-  if (log2N & 1) {
-    fft_pass_strided<2, SIGN, 2 * MAXB, NT>(buf, LS, ES, log2N, 0, nlines, tw, twStride, tid);
-    s = 1;
-  }
-  for (; s < log2N; s += 2) fft_pass_strided<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
+  for (int a = 0; a < n4; ++a, s += 2) fft_pass_strided<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
+  for (; s < log2N; s += 3) fft_pass_strided<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
 }
 
 // N-point FFTs of `nlines` LDS lines (N = 2^log2N <= 512, nlines * N / 4 <= MAXB * 256).  The caller has synchronised its writes.
 template <int SIGN, int MAXB, int NT = kFftThreads>
 UH_D void fft_lds(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
+  const int n4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);
   int s = 0;
-  if (log2N & 1) {  // the radix-2 pass first (its twiddles are all 1): twice the butterflies of a radix-4 pass
-    fft_pass<2, SIGN, 2 * MAXB, NT>(buf, LS, log2N, 0, nlines, tw, twStride, tid);
-    s = 1;
-  }
-  for (; s < log2N; s += 2) fft_pass<4, SIGN, MAXB, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
+  for (int a = 0; a < n4; ++a, s += 2) fft_pass<4, SIGN, MAXB, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
+  for (; s < log2N; s += 3) fft_pass<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
 }
 
 // ---- rows: R2C in place -------------------------------------------------------------------------------------------------------------
