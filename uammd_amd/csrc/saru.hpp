@@ -65,17 +65,18 @@ struct Saru {
     return make_float2(fmaf(r * sinf(theta), std, mean), fmaf(r * cosf(theta), std, mean));
   }
   // The same pair from the same two uniforms with the hardware transcendentals: log2 and sqrt to ~1 ulp (v_log_f32, v_sqrt_f32) and
-  // sin / cos of 2 pi u1 by sincospi (exact argument reduction, no 2 pi rounding).  Differs from gf() by a few 1e-7 of the
-  // standard deviation — the same size as gf()'s own distance from the host libm — at a fifth of the instructions; used where
-  // the draw is the hot loop (the 6 normals per Fourier node of the FCM noise, FCM_impl.cuh:466-476).
+  // sin / cos of 2 pi u1 from v_sin_f32 / v_cos_f32, whose argument is in revolutions (no 2 pi rounding, one instruction each; the
+  // library's sincospif was a third of the FCM node operator: C4 solve 0.212 -> 0.205 ms, the T = 1 error against the oracle unchanged
+  // at 3.2e-7).  Differs from gf() by a few 1e-7 of the standard deviation — the same size as gf()'s own distance from the host
+  // libm; used where the draw is the hot loop (the 6 normals per Fourier node of the FCM noise, FCM_impl.cuh:466-476).
   UH_HD float2 gf_fast(float mean, float std) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float u0;
     do { u0 = f(); } while (u0 <= 1.17549435e-38f);
     const float u1 = f();
     const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));  // sqrt(-2 ln u0), ln = log2 * ln 2
-    float sn, cs;
-    sincospif(2.0f * u1, &sn, &cs);
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2 pi u1) is one instruction (the library's sincospif is ~50)
+    const float sn = __builtin_amdgcn_sinf(u1), cs = __builtin_amdgcn_cosf(u1);
     return make_float2(fmaf(r * sn, std, mean), fmaf(r * cs, std, mean));
 #else
     return gf(mean, std);  // (host pass of the compiler only)
