@@ -440,8 +440,9 @@ def test_fcm_tile_edges_other_than_eight(hip, o32, cells, tol):
 @pytest.mark.parametrize("cells,tol,n", [((64, 64, 64), 1e-3, 40000), ((40, 56, 48), 1e-3, 20000), ((36, 60, 42), 1e-4, 20001),
                                          ((128, 128, 128), 1e-3, 100003)])
 def test_fcm_gather_particles_per_wave(hip, cells, tol, n):
-    """k_fcm_gather_inter with 1, 2 and 4 particles per wave sums the same nodes in the same order (particle counts that are not multiples
-    of the group, stencils that wrap around the box, T = 0 and T > 0).  Two solves are not the same bits — the order in which the
+    """k_fcm_gather_inter with 1, 2 and 4 particles per wave (option values -1, -2, -4) and the column form k_fcm_gather_col (2, the
+    default for supports <= 8) sum the same terms (particle counts that are not multiples of the group, stencils that wrap around the
+    box, T = 0 and T > 0).  Two solves are not the same bits — the order in which the
     binning pass hands out the slots of a tile, hence the spread's summation order, is an atomic's (the reference's spread is an
     atomicAdd per node) — so the bar is rounding level, 2e-6 of the largest displacement."""
     L = np.asarray(cells, np.float32)
@@ -456,7 +457,7 @@ def test_fcm_gather_particles_per_wave(hip, cells, tol, n):
     force[:, :3] = rng.normal(0, 1, (n, 3))
     k, a_eff = hip.Kernels.Gaussian(1.0, tol)
     out = {}
-    for mode in (1, 2, 4):
+    for mode in (-1, -2, -4, 2):
         fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
         fcm.set_option("gather_per_wave", mode)
         dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
@@ -464,8 +465,8 @@ def test_fcm_gather_particles_per_wave(hip, cells, tol, n):
         v1 = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.7, 2.0).cpu().numpy()
         out[mode] = (v0, v1)
     assert np.isfinite(out[2][0]).all() and np.abs(out[2][0]).max() > 0
-    for mode in (2, 4):
-        for a, b in zip(out[1], out[mode]):
+    for mode in (-2, -4, 2):
+        for a, b in zip(out[-1], out[mode]):
             assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
 
 

@@ -706,12 +706,101 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *_
     }
   }
 }
+// Column form of the same gather for supports <= 8: lane = one (ii, jj) column of the stencil (lane & 7, lane >> 3), a loop over the
+// stencil's z planes.  With two particles per wave k_fcm_gather_inter is bound by its own instruction stream (~225 vector + LDS-pipe
+// instructions per particle: three lane shuffles and a multiply-high division pair per node round, three wraps per node), not by
+// memory; here the x / y wraps, the column's address and the product wx wy are computed once per particle, a plane costs an add, a load
+// and four multiply-adds, and wz comes from a scalar lane read.  The terms are the same as k_fcm_gather_inter's (dV (g w), w = (wx wy)
+// wz), summed in another order.
+template <int P, int SZMAX>
+__global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
+                                                                      int3 support, float dV, FcmPrep pr, bool accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int slot0 = ((int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6)) * P;
+  if (slot0 >= N) return;
+  const int sx = support.x, sy = support.y, sz = support.z;
+  const int ii = lane & 7, jj = lane >> 3;
+  const bool col = ii < sx && jj < sy;
+  int4 o[P];
+  float wl[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const int slot = min(slot0 + q, N - 1);
+    o[q] = pr.origin[slot];
+    wl[q] = pr.weights[(size_t)pr.wstride * slot + min(lane, sx + sy + sz - 1)];
+  }
+  float4 g[P][SZMAX];
+  float wxy[P];
+  const uint planeNodes = (uint)n.x * (uint)n.y;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    int cx = o[q].x + ii, cy = o[q].y + jj;
+    cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
+    cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
+    const uint base = col ? (uint)cx + (uint)n.x * (uint)cy : 0u;  // (a lane outside the stencil re-reads node 0 of the plane)
+    const int oz = __builtin_amdgcn_readfirstlane(o[q].z);
+#pragma unroll
+    for (int kk = 0; kk < SZMAX; ++kk) {
+      if (kk < sz) {
+        int cz = oz + kk;
+        cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
+        g[q][kk] = gi[(size_t)(base + planeNodes * (uint)cz)];
+      }
+    }
+    wxy[q] = __shfl(wl[q], ii, 64) * __shfl(wl[q], sx + jj, 64);
+  }
+  float ax[P], ay[P], az[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    ax[q] = ay[q] = az[q] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < SZMAX; ++kk) {
+      if (kk < sz) {
+        const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl[q]), sx + sy + kk));
+        const float w = wxy[q] * wz;
+        if (col) {
+          ax[q] = fmaf(dV, g[q][kk].x * w, ax[q]);
+          ay[q] = fmaf(dV, g[q][kk].y * w, ay[q]);
+          az[q] = fmaf(dV, g[q][kk].z * w, az[q]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      ax[q] += __shfl_xor(ax[q], o2, 64);
+      ay[q] += __shfl_xor(ay[q], o2, 64);
+      az[q] += __shfl_xor(az[q], o2, 64);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      if (slot0 + q >= N) break;
+      float *out = vout + 3 * (size_t)o[q].w;
+      if (accumulate) { out[0] += ax[q]; out[1] += ay[q]; out[2] += az[q]; } else { out[0] = ax[q]; out[1] = ay[q]; out[2] = az[q]; }
+    }
+  }
+}
 // (A window gather — a workgroup per tile stages the tile-edge + support window of the interleaved grid in LDS, 44 KB at C4, and its
 // four waves interpolate the tile's ~24 particles from LDS — was written twice: round 1 on the planar grids, 112 us, and round 3 on the
 // float4 grid with every load of a thread in flight together, 72 us against 47 us for the kernel above: three workgroups per CU do not
 // hide the window's round trip and the per-particle shuffle chains.  Not kept.)
 static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, int N, int3 n, int3 support, float dV, FastDiv dsx,
                                 FastDiv dsxy, const FcmPrep &pr, bool accumulate, int perWave = 2) {
+  // the column form where the float4 grid stays in the 256 MB Infinity Cache (C4: 39.5 -> 32.9 us; at C5, a 268 MB grid read from HBM,
+  // its six partly filled loads per particle lose to the four full ones: 126 against 112 us)
+  const size_t nodes = (size_t)n.x * n.y * n.z;
+  if (perWave >= 0 && support.x <= 8 && support.y <= 8 && support.z <= 8 && nodes * sizeof(float4) <= ((size_t)128 << 20)) {
+    constexpr int P = 2;  // (32.9 / 33.5 / 36.4 us with 2 / 3 / 4 particles per wave at C4)
+    const dim3 g((N + kGatherWaves * P - 1) / (kGatherWaves * P)), b(64 * kGatherWaves);
+    if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_col<2, 6>), g, b, 0, st, vout, gi, N, n, support, dV, pr, accumulate);
+    else hipLaunchKernelGGL((k_fcm_gather_col<2, 8>), g, b, 0, st, vout, gi, N, n, support, dV, pr, accumulate);
+    return;
+  }
+  if (perWave < 0) perWave = -perWave;  // (test hook: a negative value asks for k_fcm_gather_inter with that many particles per wave)
   const int rounds = (support.x * support.y * support.z + 63) / 64;
   // (measured at C4, support 6: 47.3 / 40.2 / 40.8 us with 1 / 2 / 4 particles per wave)
   const int P = (rounds <= 4 && perWave >= 2) ? (perWave >= 4 ? 4 : 2) : 1;
