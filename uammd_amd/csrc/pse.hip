@@ -196,8 +196,12 @@ __global__ void __launch_bounds__(128) k_pse_near(const float4 *__restrict__ sor
 // partial sums meet in a 3-step butterfly.  Another summation order: results agree with the walk to rounding (tests: 1e-6 of max|Mv|).
 constexpr int kNearGroup = 8, kNearBlock = 256, kNearCap = 96;  // hits a group can hold before it drains (12 KB of LDS per workgroup)
 
+// The sheared minimum image with the image counts from a reciprocal multiplication and round-to-even instead of the reference's
+// division and roundf.  The distance vector depends on the COUNTS only (rij - L * count, one fma per component, as in
+// sheared_distance): it is the reference's, bit for bit, whenever the counts agree — and they can only differ for a component within an
+// ulp of half a box length, i.e. for pairs far outside any near-field cut-off (cut-off <= cell edge <= L / 3).
 template <bool SHEAR>
-UH_D float scan_distance2(const float4 &pi, const float4 &pj, real3f L, real3f invL, float shear) {
+UH_D real3f scan_rij(const float4 &pi, const float4 &pj, real3f L, real3f invL, float shear) {
   float x = pj.x - pi.x, y = pj.y - pi.y, z = pj.z - pi.z;
   if (SHEAR) x = fmaf(shear, y, x);
   const float s1 = __builtin_rintf(y * invL.y);
@@ -205,7 +209,12 @@ UH_D float scan_distance2(const float4 &pi, const float4 &pj, real3f L, real3f i
   y = fmaf(-L.y, s1, y);
   z = fmaf(-L.z, __builtin_rintf(z * invL.z), z);
   x = fmaf(-L.x, __builtin_rintf(x * invL.x), x);
-  return fmaf(z, z, fmaf(y, y, x * x));
+  return real3f{x, y, z};
+}
+template <bool SHEAR>
+UH_D float scan_distance2(const float4 &pi, const float4 &pj, real3f L, real3f invL, float shear) {
+  const real3f r = scan_rij<SHEAR>(pi, pj, L, invL, shear);
+  return fmaf(r.z, r.z, fmaf(r.y, r.y, r.x * r.x));
 }
 
 template <int VSTRIDE, bool INDIRECT, bool ACCUM, bool SHEAR>
@@ -252,7 +261,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near8(const float4 *__restri
   auto drain = [&]() {
     for (int k = sub; k < cnt; k += kNearGroup) {
       const int j = hitList[grp][k];
-      const real3f rij = sheared_distance(pi, sortPos[j], L, shear);
+      const real3f rij = scan_rij<SHEAR>(pi, sortPos[j], L, invL, shear);  // (= sheared_distance for every pair that can pass the next line)
       const float r2 = dot3(rij, rij);
       if (r2 >= rcut2) continue;  // (the scan's test is a superset)
       const float *vp = v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j);
