@@ -212,11 +212,30 @@ __global__ void __launch_bounds__(128) k_lj_verlet(const float4 *__restrict__ so
   const int nn = numberNeighbours[id];
   const int *mine = neighbourList + id;
   Acc acc;
+  // Software pipeline, two stages deep: the list entries of iteration k + 2 and the positions of iteration k + 1 are requested before
+  // the pairs of iteration k are evaluated (written as load - gather - evaluate per iteration the loop was two dependent round trips
+  // per four neighbours, ~16 times per particle).  Entries past the particle's own count re-read its last one and carry no weight.
+  const int l1 = max(nn - 1, 0);
+  auto entries = [&](int k, int (&j)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = mine[(size_t)min(k + u, l1) * N];
+  };
+  int jb[4], jc[4];
+  float4 cb[4];
+  entries(0, jb);
+  entries(4, jc);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cb[u] = sortPos[jb[u]];
   for (int k = 0; k < nn; k += 4) {
-    const int l1 = nn - 1;
-    const int j0 = mine[(size_t)k * N], j1 = mine[(size_t)min(k + 1, l1) * N], j2 = mine[(size_t)min(k + 2, l1) * N],
-              j3 = mine[(size_t)min(k + 3, l1) * N];
-    const float4 c[4] = {sortPos[j0], sortPos[j1], sortPos[j2], sortPos[j3]};
+    float4 c[4];
+    int jd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = cb[u];
+    entries(k + 8, jd);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cb[u] = sortPos[jc[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) jc[u] = jd[u];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       real3f r12;
