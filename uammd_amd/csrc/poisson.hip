@@ -198,26 +198,124 @@ __global__ void __launch_bounds__(256) k_poisson_gather(const float4 *__restrict
   const int nn = sx * sy * sz;
   const float dV = grid.cellVolume;
   float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-  for (int i0 = 0; i0 < nn; i0 += 64) {
-    const int i = i0 + lane;
-    const bool in = i < nn;
-    const uint iu = in ? (uint)i : 0u;
-    const uint kk = dsxy.div(iu);
-    const uint rem = iu - kk * (uint)(sx * sy);
-    const uint jj = dsx.div(rem);
-    const uint ii = rem - jj * (uint)sx;
-    const float wx = stencil_weight(s, (int)ii);
-    const float wy = stencil_weight(s, sx + (int)jj);
-    const float wz = stencil_weight(s, sx + sy + (int)kk);
-    if (!in) continue;
+  // kR rounds of 64 nodes with all their loads in flight before the first is used (round by round — load, use, next load — a support-9
+  // stencil was twelve dependent round trips per particle: 1.37 ms per call at 1e6 charges); same nodes, same order of the sums
+  constexpr int kR = 6;
+  for (int base = 0; base < nn; base += 64 * kR) {
+    float4 g[kR];
+    int sel[kR];  // ii | jj << 8 | kk << 16, or -1
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int i = base + 64 * r + lane;
+      const bool in = i < nn;
+      const uint iu = in ? (uint)i : 0u;
+      const uint kk = dsxy.div(iu);
+      const uint rem = iu - kk * (uint)(sx * sy);
+      const uint jj = dsx.div(rem);
+      const uint ii = rem - jj * (uint)sx;
+      sel[r] = in ? (int)(ii | jj << 8 | kk << 16) : -1;
+      const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
+      const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
+      const int cz = grid.pbc_z(s.celli.z + (int)kk - s.P.z);
+      g[r] = grid4[(size_t)cx + (size_t)nxStride * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz)];  // (a lane past the stencil re-reads its node 0)
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int w = sel[r] < 0 ? 0 : sel[r];
+      const float wx = stencil_weight(s, w & 255);
+      const float wy = stencil_weight(s, sx + ((w >> 8) & 255));
+      const float wz = stencil_weight(s, sx + sy + (w >> 16));
+      if (sel[r] >= 0) {
+        ax = fmaf(dV, g[r].x * wx * wy * wz, ax);
+        ay = fmaf(dV, g[r].y * wx * wy * wz, ay);
+        az = fmaf(dV, g[r].z * wx * wy * wz, az);
+        aw = fmaf(dV, g[r].w * wx * wy * wz, aw);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ax += __shfl_xor(ax, o, 64);
+    ay += __shfl_xor(ay, o, 64);
+    az += __shfl_xor(az, o, 64);
+    aw += __shfl_xor(aw, o, 64);
+  }
+  if (lane != 0) return;
+  const float q = p.w;
+  const int id = groupIndex[sid];
+  if (force) {
+    float4 f = force[id];
+    f.x += q * ax; f.y += q * ay; f.z += q * az; f.w += q * 0.0f;
+    force[id] = f;
+  }
+  if (energy) energy[id] += q * aw;
+  if (fieldPotential) {
+    float4 f = fieldPotential[id];
+    f.x += ax; f.y += ay; f.z += az; f.w += aw;
+    fieldPotential[id] = f;
+  }
+}
+
+// Column form of the same gather (fcm.hip k_fcm_gather_col): lane = one (ii, jj) column of the stencil, G = ceil(sx sy / 64) columns per
+// lane, a loop over the stencil's z planes.  The node-by-node form above is bound by its own instruction stream — two multiply-high
+// divisions, three wraps, three lane shuffles and the address arithmetic per node, ~55 instructions x 729 nodes per particle at support 9:
+// 1.37 ms per call at 1e6 charges — here the wraps, the column's address and wx wy are per column, a plane costs an add, a load and five
+// multiply-adds, wz is a scalar lane read.  Same terms (dV (g w), w = (wx wy) wz), another order of the sums.
+template <int G>
+__global__ void __launch_bounds__(256) k_poisson_gather_col(const float4 *__restrict__ packed, const int *__restrict__ groupIndex,
+                                                            const float4 *__restrict__ grid4, float4 *__restrict__ force,
+                                                            float *__restrict__ energy, float4 *__restrict__ fieldPotential, int N,
+                                                            GridT<float> grid, int nxStride, IBMKernelDev kern, FastDiv dsx) {
+  kern.kind = kKernelGaussian;
+  const int lane = threadIdx.x & 63;
+  const int sid = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (sid >= N) return;
+  const float4 p = packed[sid];
+  const Stencil s = make_stencil(grid, kern, real3f{p.x, p.y, p.z}, false, lane);
+  const int sx = s.support.x, sy = s.support.y, sz = s.support.z;
+  const float dV = grid.cellVolume;
+  uint base[G];
+  float wxy[G];
+  bool col[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const uint c = (uint)(lane + 64 * g);
+    col[g] = c < (uint)(sx * sy);
+    const uint cc = col[g] ? c : 0u;
+    const uint jj = dsx.div(cc), ii = cc - jj * (uint)sx;
     const int cx = grid.pbc_x(s.celli.x + (int)ii - s.P.x);
     const int cy = grid.pbc_y(s.celli.y + (int)jj - s.P.y);
-    const int cz = grid.pbc_z(s.celli.z + (int)kk - s.P.z);
-    const float4 g = grid4[(size_t)cx + (size_t)nxStride * ((size_t)cy + (size_t)grid.cellDim.y * (size_t)cz)];
-    ax = fmaf(dV, g.x * wx * wy * wz, ax);
-    ay = fmaf(dV, g.y * wx * wy * wz, ay);
-    az = fmaf(dV, g.z * wx * wy * wz, az);
-    aw = fmaf(dV, g.w * wx * wy * wz, aw);
+    base[g] = (uint)cx + (uint)nxStride * (uint)cy;
+    wxy[g] = stencil_weight(s, (int)ii) * stencil_weight(s, sx + (int)jj);
+  }
+  const uint planeNodes = (uint)nxStride * (uint)grid.cellDim.y;
+  const int z0 = __builtin_amdgcn_readfirstlane(s.celli.z - s.P.z);
+  float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+  constexpr int kPlanes = 3;  // planes whose loads are in flight together
+  for (int k0 = 0; k0 < sz; k0 += kPlanes) {
+    float4 v[kPlanes][G];
+#pragma unroll
+    for (int u = 0; u < kPlanes; ++u) {
+      const int cz = grid.pbc_z(z0 + min(k0 + u, sz - 1));
+#pragma unroll
+      for (int g = 0; g < G; ++g) v[u][g] = grid4[(size_t)(base[g] + planeNodes * (uint)cz)];  // (idle columns re-read column 0)
+    }
+#pragma unroll
+    for (int u = 0; u < kPlanes; ++u) {
+      if (k0 + u < sz) {
+        const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.w), sx + sy + k0 + u));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (col[g]) {
+            const float w = wxy[g] * wz;
+            ax = fmaf(dV, v[u][g].x * w, ax);
+            ay = fmaf(dV, v[u][g].y * w, ay);
+            az = fmaf(dV, v[u][g].z * w, az);
+            aw = fmaf(dV, v[u][g].w * w, aw);
+          }
+        }
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -302,12 +400,30 @@ __global__ void __launch_bounds__(256) k_poisson_tile_count(const float4 *__rest
                                                             IBMKernelDev kern, TileGeom tg, FastDiv dx, FastDiv dy, FastDiv dz,
                                                             int *__restrict__ count, int *__restrict__ rank) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const float4 p = packed[i];
-  const int3 o = stencil_origin(grid, kern, real3f{p.x, p.y, p.z});
-  const int t = (int)dx.div((uint)o.x) + tg.nt.x * ((int)dy.div((uint)o.y) + tg.nt.y * (int)dz.div((uint)o.z));
-  rank[i] = atomicAdd(&count[t], 1);  // rank within the tile (order of arrival)
-  rank[N + i] = t;
+  const bool active = i < N;
+  int t = -1 - (int)(threadIdx.x & 63);  // (idle lanes: distinct negative keys, never equal to a neighbour's)
+  if (active) {
+    const float4 p = packed[i];
+    const int3 o = stencil_origin(grid, kern, real3f{p.x, p.y, p.z});
+    t = (int)dx.div((uint)o.x) + tg.nt.x * ((int)dy.div((uint)o.y) + tg.nt.y * (int)dz.div((uint)o.z));
+  }
+  // The particles arrive Morton-sorted: a wave is a handful of RUNS of lanes with the same tile.  One atomic per run (its first lane
+  // reserves the run's ranks) instead of one per particle: 1e6 atomics on 4096 counters serialise in L2 — 220 us per call.
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(t, 1, 64);
+  const bool head = lane == 0 || prev != t;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int h = 63 - __builtin_clzll(below);                         // first lane of this lane's run
+  const unsigned long long after = heads & ~((2ull << h) - 1ull);    // (h < 63 whenever a later head exists)
+  const int end = (h == 63 || after == 0ull) ? 64 : __builtin_ctzll(after);
+  int base = 0;
+  if (head && active) base = atomicAdd(&count[t], end - h);  // (a run of active lanes is all active: idle lanes have their own keys)
+  base = __shfl(base, h, 64);
+  if (active) {
+    rank[i] = base + (lane - h);  // rank within the tile (order of arrival of the runs)
+    rank[N + i] = t;
+  }
 }
 
 // exclusive scan of the tile counts by ONE workgroup (the tile table is small)
@@ -558,6 +674,10 @@ __global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__
   }
 }
 
+// (Round 3 measured two restructurings of this walk at 1e6 charges, 1.76 ms per call: eight lanes per particle with a flat candidate
+// sequence and compacted hits — the scheme of pse.hip k_pse_near8 — 1.68 ms; one lane per particle testing four candidates per step into
+// a per-lane FIFO in LDS with the listed pairs evaluated wave-wide, 1.98 ms.  At this size the walk is bound by its instruction
+// throughput, not by latency or by the divergence of the hit branch; neither was kept.)
 static Table1 view(const DeviceBuffer &b, int ntable, float rmax) {
   Table1 t;
   t.table = (const float *)b.ptr;
@@ -663,9 +783,16 @@ static int poisson_far(Poisson *p, int N, float *d_force, float *d_energy, float
   hipLaunchKernelGGL(k_poisson_interleave, dim3((nreal + 255) / 256), dim3(256), 0, st, (const float *)p->planes.ptr, p->planeReal,
                      (float4 *)p->inter.ptr, nreal);
   {
-    hipLaunchKernelGGL(k_poisson_gather, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)p->packed.ptr,
-                       (const int *)p->cl.index.ptr, (const float4 *)p->inter.ptr, (float4 *)d_force, d_energy,
-                       (float4 *)d_fieldPotential, N, p->grid, p->nxpad, p->kern, dsx, dsxy);
+    const int cols = p->kern.support.x * p->kern.support.y, wts = p->kern.support.x + p->kern.support.y + p->kern.support.z;
+    const bool colForm = !getenv("UAMMD_POISSON_FLAT_GATHER") && cols <= 128 && wts <= 64 &&
+                         (size_t)p->nxpad * p->grid.cellDim.y * p->grid.cellDim.z < ((size_t)1 << 31);
+#define UH_PGATHER(K, ...) hipLaunchKernelGGL(K, dim3((N + 3) / 4), dim3(256), 0, st, (const float4 *)p->packed.ptr, (const int *)p->cl.index.ptr, \
+                                              (const float4 *)p->inter.ptr, (float4 *)d_force, d_energy, (float4 *)d_fieldPotential, N, p->grid,  \
+                                              p->nxpad, p->kern, __VA_ARGS__)
+    if (colForm && cols <= 64) UH_PGATHER(k_poisson_gather_col<1>, dsx);
+    else if (colForm) UH_PGATHER(k_poisson_gather_col<2>, dsx);
+    else UH_PGATHER(k_poisson_gather, dsx, dsxy);
+#undef UH_PGATHER
   }
   UH_CHECK(hipGetLastError());
   return 0;
