@@ -617,6 +617,10 @@ __global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__
   const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
   const int numberNeighbourCells = npx * npy * npz;
   const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  // every pair the exact tests keep has r2 below this: r2 < rc^2 for the potential table, sqrt(r2) < rc for the field (a square root
+  // correctly rounded cannot report < rc for r2 >= rc^2 (1 + 1e-5))
+  const float rcAny = MODE == 1 ? sqrtf(tabP.rmax) : (MODE == 0 ? tabF.rmax : fmaxf(tabF.rmax, sqrtf(tabP.rmax)));
+  const float r2skip = rcAny * rcAny * 1.00001f + 1e-30f;
   float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f;
   for (int cc = 0; cc < numberNeighbourCells; ++cc) {
     int3 cellj = celli;
@@ -631,13 +635,21 @@ __global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__
     const uint cs = cellStart[icellj];
     if (cs < validCell) continue;
     const int first = (int)(cs - validCell), last = cellEnd[icellj];
-    for (int j = first; j < last; ++j) {
-      const float4 pj = packed[j];
+    // (four candidates per trip with their loads in flight together; evaluated one after the other, in the walk's order)
+    for (int j0 = first; j0 < last; j0 += 4) {
+     float4 c4[4];
+#pragma unroll
+     for (int u = 0; u < 4; ++u) c4[u] = packed[min(j0 + u, last - 1)];
+#pragma unroll
+     for (int u = 0; u < 4; ++u) {
+      if (j0 + u >= last) break;
+      const float4 pj = c4[u];
       const real3f rij = box.apply_pbc(real3f{pj.x - pi.x, pj.y - pi.y, pj.z - pi.z});
       const float r2 = dot3(rij, rij);
       // both tables return 0 at and beyond the cut-off (TabulatedFunction.cuh:150-151): such pairs add exactly zero, so
       // skipping them (85 % of the 27-cell candidates) changes no bit of the result
       // (each mode tests the table(s) it reads: r2 against rc^2 for G, sqrt(r2) against rc for the field)
+      if (r2 >= r2skip) continue;  // (clearly outside: the exact tests below, with their square root, only see the rest)
       if (MODE == 1 && r2 >= tabP.rmax) continue;
       if (MODE == 0 && sqrtf(r2) >= tabF.rmax) continue;
       if (MODE == 2 && r2 >= tabP.rmax && sqrtf(r2) >= tabF.rmax) continue;
@@ -661,6 +673,7 @@ __global__ void __launch_bounds__(128) k_poisson_near(const float4 *__restrict__
         }
         tx += ex; ty += ey; tz += ez; tw += phi;
       }
+     }
     }
   }
   const int ori = groupIndex[id];
