@@ -129,6 +129,7 @@ SIGNATURES = {
     "uammd_comm_alltoall": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "uammd_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp]),
     "uammd_halo_pack": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "uammd_lj_tile_stats": (_i, [_vp, _i, C.POINTER(C.c_uint), _vp]),
     "uammd_lj_profile_enable": (_i, [_vp, _i]),
     "uammd_lj_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),

@@ -593,8 +593,9 @@ int CellList::check_errors(hipStream_t st, bool sync) {
     __atomic_store_n(hostErr, 0, __ATOMIC_RELEASE);
     if (code == 2) {
       ljTable = nullptr;  // the cached cut-off was stale: the next traversal reads the table again
-      set_last_error("PairForces: the LJ parameter table was rewritten in place with a cut-off larger than the list's cell edge; the last "
-                     "traversal did not compute forces (pass a new table pointer, or rebuild the list for the new cut-off)");
+      set_last_error("PairForces: the LJ parameter table was rewritten in place behind the list's cached copy (a cut-off larger than the "
+                     "cell edge, or sigma / epsilon no longer 1 where the reduced-units kernel was chosen); the last traversal did not "
+                     "compute forces — the table is read again on the next call (rebuild the list if the cut-off grew)");
       return -4;
     }
     if (code == 4) {
@@ -615,6 +616,7 @@ int CellList::lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, fl
     float m = 0.f;
     for (const auto &p : host) m = p.cutOff2 > m ? p.cutOff2 : m;
     ljTable = d_table; ljTableTypes = ntypes; ljTableMaxCut2 = m;
+    ljTableUnit = ntypes == 1 && host[0].sigma2 == 1.0f && host[0].epsilonDivSigma2 == 1.0f;
   }
   *out = ljTableMaxCut2;
   return 0;
@@ -879,6 +881,25 @@ int uammd_lj_profile_read(uammd_celllist *h, double *totalMs, long long *launche
   if (int e = cl->prof.collect(0)) return e;  // waits for the launches still in flight
   *totalMs = cl->prof.totalMs;
   *launches = cl->prof.launches;
+  return 0;
+}
+
+int uammd_lj_tile_stats(uammd_celllist *h, int enable, unsigned int out[4], void *stream) {
+  if (!h) { set_last_error("uammd_lj_tile_stats: null handle"); return -1; }
+  CellList *cl = reinterpret_cast<CellList *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (out) {
+    out[0] = out[1] = out[2] = out[3] = 0u;
+    if (cl->tileStatsOn) {
+      UH_CHECK(hipMemcpyAsync(out, cl->tileStats.ptr, 4 * sizeof(uint), hipMemcpyDeviceToHost, st));
+      UH_CHECK(hipStreamSynchronize(st));
+    }
+  }
+  if (enable) {
+    if (int e = cl->tileStats.reserve(4 * sizeof(uint))) return e;
+    UH_CHECK(hipMemsetAsync(cl->tileStats.ptr, 0, 4 * sizeof(uint), st));
+  }
+  cl->tileStatsOn = enable != 0;
   return 0;
 }
 

@@ -64,6 +64,7 @@ struct CellList {
   const void *ljTable = nullptr;
   int ljTableTypes = 0;
   float ljTableMaxCut2 = 0.f;
+  bool ljTableUnit = false;  // one type with sigma^2 = epsilon / sigma^2 = 1 (the tile kernel's reduced-units instantiation)
   int lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, float *out);
   ~CellList();
   // Traversal-kernel timing for bench.py's roofline line: when enabled the LJ traversal is launched with hipExtLaunchKernel and a
@@ -80,6 +81,8 @@ struct CellList {
     int collect(int upTo);                           // sum and retire all but the newest `upTo` live pairs
     ~Profile();
   } prof;
+  DeviceBuffer tileStats;  // uammd_lj_tile_stats: counters the tile kernel bumps while enabled
+  bool tileStatsOn = false;
   int numOwned = 0x7fffffff;  // traversal option: particles with input index >= numOwned are ghosts (neighbours only, no output)
 
   int next_valid_cell(int numberParticles, bool *needsClear);

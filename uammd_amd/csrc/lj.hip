@@ -553,6 +553,7 @@ static int dispatch_celllist(CellList *h, int algo, const BoxT<float> &box, cons
   cl.numOwned = h->numOwned;
   cl.maxCut2Allowed = lj_tile_max_cutoff2(h->grid);
   cl.errFlag = h->devErr;
+  cl.tileStats = h->tileStatsOn ? (uint *)h->tileStats.ptr : nullptr;
   switch (algo) {
     case UAMMD_LJ_ALGO_AUTO: case UAMMD_LJ_ALGO_GENERAL: case UAMMD_LJ_ALGO_RING: case UAMMD_LJ_ALGO_RING_HALF: case UAMMD_LJ_ALGO_TILE:
     case UAMMD_LJ_ALGO_TILE1: case UAMMD_LJ_ALGO_EXACT: break;

@@ -124,6 +124,8 @@ struct ListView {
   // larger one anyway (the caller rewrote its table in place) raises the list's host-mapped error flag instead of computing.
   float maxCut2Allowed;
   int *errFlag;
+  // measurement hook (uammd_lj_tile_stats, null unless enabled): [0] bricks that took the dense-brick fallback, [1] bricks launched
+  uint *tileStats;
 };
 
 struct Outputs {

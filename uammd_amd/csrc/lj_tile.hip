@@ -34,6 +34,8 @@
 #include "lj_common.hpp"
 #include "gj_step.hpp"
 #include <hip/hip_ext.h>
+#include <vector>
+#include <algorithm>
 
 namespace uammd_hip {
 
@@ -82,8 +84,11 @@ UH_D BoxT<float> pbc_box(BoxT<float> b) {
   return b;
 }
 
-// one pair in the drain: the reference's arithmetic up to the division, which is rcp + one Newton step (<= 1 ulp) here
-template <bool PBC, bool WE>
+// one pair in the drain: the reference's arithmetic up to the division, which is rcp + one Newton step (<= 1 ulp) here.
+// UNIT: the (single) pair type has sigma^2 = 1 and epsilon / sigma^2 = 1 exactly — reduced units, what the reference's benchmark and
+// test programs run — and the two products by 1.0f are left out: the same bits (x * 1.0f == x), two instructions per pair fewer.  The
+// kernel is instantiated on it (a wave-uniform branch between two copies of the drain loop was measured 7 % SLOWER in round 2: code size).
+template <bool PBC, bool WE, bool UNIT = false>
 UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri, const f4t &rj, real3f &r12, float &fm, float &e) {
   r12 = real3f{rj.x - ri.x, rj.y - ri.y, rj.z - ri.z};
   if (PBC) {
@@ -98,9 +103,9 @@ UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri,
   const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
   float r = __builtin_amdgcn_rcpf(r2);
   r = fmaf(fmaf(-r2, r, 1.0f), r, r);
-  const float invr2 = p.sigma2 * r;
+  const float invr2 = UNIT ? r : p.sigma2 * r;
   const float invr6 = invr2 * invr2 * invr2;
-  const float f = p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
+  const float f = UNIT ? fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2 : p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
   fm = in ? f : 0.0f;
   if (WE) {
     const float E = fmaf(p.epsilonDivSigma2 * p.sigma2 * 4.0f * invr6, (invr6 - 1.0f), -p.shift);
@@ -109,12 +114,25 @@ UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri,
     e = 0.0f;
 }
 
-// Candidate <-> matrix row.  The 64 candidates of a word (64 consecutive LDS slots in the reference's visiting order) are assigned to
-// the rows of the word's two matrix steps so that the 32 values a lane sees (half-wave h, step parity sp, accumulator a: hardware
-// row (a & 3) + 8 (a >> 2) + 4 h) are the slots 2 (16 sp + a) + h: the two lanes of an owner take the even and the odd candidates
-// (with blocks of 32 per half the busiest lane of a model liquid holds 41 instead of 34 hits of a mean 26).  Row i of step sp holds
-// slot 32 sp + 2 ((i & 3) + 4 (i >> 3)) + ((i >> 2) & 1); bit j (from the top) of a lane's hit word is slot 2 j + h: one shift-add.
-UH_D uint row_slot(int i) { return 2u * ((uint)(i & 3) + 4u * (uint)(i >> 3)) + (uint)((i >> 2) & 1); }
+// Candidate <-> matrix row.  The 64 candidates of a word (64 consecutive LDS slots in the reference's visiting order) are fed to the
+// word's two matrix steps so that the two lanes of an owner take the even and the odd candidates (with blocks of 32 per half the busiest
+// lane of a model liquid holds 41 instead of 34 hits of a mean 26) and bit j FROM THE TOP of a lane's hit word is slot 2 j + h: the
+// drain's address is one shift-add.  A lane of half-wave h holds, of step sp (0: the lower half-wave's candidates, 1: the upper's) and
+// accumulator a, the value of hardware row (a & 3) + 8 (a >> 2) + 4 h; which BIT that value becomes is the sign collector's business
+// (tile_bits32: value index v = 2 a + sp lands on bit tile_bit_of(v)), so feeding lane (row i, step sp) reads slot
+// 2 (31 - tile_bit_of(2 a + sp)) + h with a = (i & 3) + 4 (i >> 3), h = (i >> 2) & 1.
+#ifndef UAMMD_TILE_ALIGNBIT
+// fp6 collector: value v sits at bits 6 v .. 6 v + 5 of the 192-bit result, its sign at 6 v + 5; the six dwords are merged without
+// moving a bit except the upper three by one place (see tile_bits32): v < 16 -> (6 v + 5) mod 32 (the odd places), v >= 16 -> one below
+UH_HD uint tile_bit_of(uint v) { return ((6u * (v & 15u) + 5u) & 31u) - (v >> 4); }
+#else
+// v_alignbit chains (round 2): step 0's accumulators fill bits 31..16 and step 1's bits 15..0, each in accumulator order
+UH_HD uint tile_bit_of(uint v) { return 31u - (16u * (v & 1u) + (v >> 1)); }
+#endif
+UH_D uint row_slot(int i, int sp) {
+  const uint a = (uint)(i & 3) + 4u * (uint)(i >> 3), h = (uint)((i >> 2) & 1);
+  return 2u * (31u - tile_bit_of(2u * a + (uint)sp)) + h;
+}
 
 // |cand - owner|^2 - (rc^2 + margin) for 32 candidates (rows) x 32 owners (columns) from ONE v_mfma_f32_32x32x16_f16 (32 cycles of the
 // matrix pipe; the exact-f32 form, three chained v_mfma_f32_32x32x2_f32 = 192 cycles per step, made the waves of a SIMD queue for the
@@ -167,8 +185,31 @@ UH_D v16f tile_product(const h8t &A, const h8t &B) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, z, 0, 0, 0);
 }
 
-// 16 values -> 16 bits of the lane's hit word, one v_alignbit_b32 each: m = (m << 1) | sign(d)
-// (two independent chains of 8: a dependent VALU instruction cannot issue back to back)
+// 2 x 16 values -> the lane's 32-bit hit word (bit tile_bit_of(2 a + sp) = sign of step sp's accumulator a).
+#ifndef UAMMD_TILE_ALIGNBIT
+// ONE v_cvt_scalef32_2xpk16_fp6_f32 packs the 32 values into 32 six-bit floats (a[n] -> value 2 n, b[n] -> value 2 n + 1; the sign is
+// kept for zeros, denormals, huge and infinite inputs: tools/cvt_probe.hip), whose sign bits sit 6 apart: dwords 0, 1, 2 hold them at
+// bits {5, 11, 17, 23, 29}, {3, 9, 15, 21, 27}, {1, 7, 13, 19, 25, 31} — together the 16 odd places — and dwords 3, 4, 5 the same for
+// values 16..31.  Five bit selects and one shift merge them.  Measured (tools/cvt_probe.hip, 4 waves per SIMD): the conversion 28.3 ns
+// per wave against 32 v_alignbit_b32 at 1.88 = 60 ns; 28.3 + 6 x 1.9 = 40 ns for the word.
+typedef uint v6u __attribute__((ext_vector_type(6)));
+// (a & mask) | (b & ~mask) as ONE v_bfi_b32, the mask in a scalar register: written in C the compiler, knowing the masks, turns the five
+// selects into six ANDs, two three-way ORs and an AND-OR
+UH_D uint bit_select(uint mask, uint a, uint b) {
+  uint d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+  return d;
+}
+UH_D uint tile_bits32(const v16f &dA, const v16f &dB) {
+  const v6u r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(dA, dB, 1.0f);
+  constexpr uint M0 = 0x20820820u, M01 = M0 | 0x08208208u;  // bits {5, 11, 17, 23, 29} and {3, 9, 15, 21, 27}
+  const uint lo = bit_select(M01, bit_select(M0, r[0], r[1]), r[2]);
+  const uint hi = bit_select(M01, bit_select(M0, r[3], r[4]), r[5]);
+  return bit_select(0xAAAAAAAAu, lo, hi >> 1);
+}
+#else
+// one v_alignbit_b32 per value: m = (m << 1) | sign(d) (two independent chains of 8 per step: a dependent VALU instruction cannot issue
+// back to back)
 UH_D uint tile_bits16(const v16f &d) {
   uint m0 = 0, m1 = 0;
 #pragma unroll
@@ -178,16 +219,19 @@ UH_D uint tile_bits16(const v16f &d) {
   }
   return (m0 << 8) | m1;
 }
+UH_D uint tile_bits32(const v16f &dA, const v16f &dB) { return (tile_bits16(dA) << 16) | tile_bits16(dB); }
+#endif
 
 // The wave's 32 owners against nW words of staged candidates.  Word w = 64 consecutive LDS slots starting at byte candBase +
 // wbase[w], of which the first wcnt[w] are this wave's candidates (the rest is staged data of other rows, or padding: their bits
 // are cleared).  wbase / wcnt arrive in registers — lane w holds word w's, entries >= nW are zero or any staged slot — and the scan
 // reads them with v_readlane; tab = this wave's table in LDS: hit words [kMaxW + 1][64] | slot address per half-wave [2][kMaxW + 2].
-template <bool PBC, bool NT1, bool WE, bool WV>
+// NT: 0 = several types (a parameter lookup per pair), 1 = one type, 2 = one type in reduced units (tile_eval's UNIT)
+template <bool PBC, int NT, bool WE, bool WV>
 UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, uint wcntV, int lane, const TileFrame &fr, const h8t &B0, const h8t &B1, const float4 &pi, const BoxT<float> &box, const LJParams &p1, const LJParams *__restrict__ tbl, int ntypes) {
   const int hi = lane >> 5;
   // the candidate this lane feeds to the matrix: slot row_slot(lane & 31) + 32 hi of the word at + wbase[w]
-  const uint rowAddr = candBase + 16u * row_slot(lane & 31) + 512u * (uint)hi;
+  const uint rowAddr = candBase + 16u * row_slot(lane & 31, hi);
   const uint myMask = tab + 4u * (uint)lane;                  // hit word w of this lane at + 256 w
   // ---- scan: ONE operand per lane and word — the lower half-wave holds the 32 candidates of the word's first matrix step in K slots
   // 0..7, the upper half-wave those of the second step in K slots 8..15 — and two products: B0 carries the owners in K 0..7 and zeros
@@ -205,13 +249,13 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     // (unconditional: behind the last word this is entry nW of the table = slot 0, a wasted step — a conditional one makes the
     // compiler keep two register sets for the products and copy them every word)
     A = tile_operand<PBC>(rowAddr + rdlane(wbaseV, (int)w + 1), fr, ones);
-    const uint mA = tile_bits16(dA);
+    uint m = tile_bits32(dA, dB);
     dA = tile_product(A, B0);
-    uint m = (mA << 16) | tile_bits16(dB);
     dB = tile_product(A, B1);
-    if (cnt < 64u) {  // the word runs past the wave's candidates: slots 2 j + h >= cnt are not its own
-      const uint mine = (cnt + 1u - (uint)hi) >> 1;
-      m &= mine >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> mine);
+    if (cnt < 64u) {  // the word runs past the wave's candidates (the last word of a run): slots 2 j + h >= cnt are not its own
+      asm volatile("");  // (keeps the wave-uniform branch: if-converted, these instructions run for every word)
+      const uint mine = (cnt + 1u - (uint)hi) >> 1;  // <= 32
+      m &= (uint)(0xFFFFFFFF00000000ull >> mine);
     }
     *(LdsU *)(uintptr_t)(myMask + 256u * w) = m;
   }
@@ -268,9 +312,9 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     cN1 = *(const LdsF4 *)(uintptr_t)a1;
     real3f r0, r1;
     float f0, f1, e0, e1;
-    if (NT1) {
-      tile_eval<PBC, WE>(box, p1, pi, c0, r0, f0, e0);
-      tile_eval<PBC, WE>(box, p1, pi, c1, r1, f1, e1);
+    if (NT != 0) {
+      tile_eval<PBC, WE, NT == 2>(box, p1, pi, c0, r0, f0, e0);
+      tile_eval<PBC, WE, NT == 2>(box, p1, pi, c1, r1, f1, e1);
     } else {
       tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c0.w), pi, c0, r0, f0, e0);
       tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c1.w), pi, c1, r1, f1, e1);
@@ -438,9 +482,9 @@ UH_D void tile_solo(const ListView &cl, const GridT<float> &grid, const BoxT<flo
       const uint nW = (nC + 63u) >> 6;
       const uint wcntV = nC > 64u * (uint)lane ? min(nC - 64u * (uint)lane, 64u) : 0u;
       if (pbcTile)
-        tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
+        tile_words<true, NT1 ? 1 : 0, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
       else
-        tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+        tile_words<false, NT1 ? 1 : 0, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     }
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
@@ -469,7 +513,7 @@ k_lj_tile(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__res
 // (five waves per SIMD: 96 VGPRs and 36 bytes of scratch; measured 0.2116 / 0.2003 / 0.2085 ms at 4 / 5 / 6 — six needs 80 VGPRs,
 // 100 bytes of scratch and an LDS diet, kMaxW 10 / kBrickCap 896 / the range table inside the hit-word rows, that sends more bricks
 // to the fallback)
-template <bool NT1, bool WE, bool WV>
+template <int NT, bool WE, bool WV>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__restrict__ tbl, int ntypes, Outputs out, float margin,
            int nbx, int nby, uint nBricks, TileFrame scale) {
@@ -495,8 +539,14 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   // memory latency starts late.  Letting the phases that WAIT go first took the launch from 0.1815 to 0.1626 ms (tools/time_lj.py; the
   // prologue alone: 0.170; scan at 1 or 2: the same; the final store raised as well: 0.166).
   __builtin_amdgcn_s_setprio(3);
+  // (every XCD gets one contiguous eighth of the bricks, by COUNT.  Cutting by work instead — on an odd grid the last brick layer along y
+  // and z holds one cell layer instead of two, and at C3 the XCD that owns the light z layer runs out of work early — was measured 5 %
+  // slower with light bricks weighted 0.6 of a full one: a light brick holds its workgroup slot for as long as its two working waves run,
+  // ~0.8 of a full brick; and a look-up table of brick indices in any order costs one more dependent memory round trip at the head of
+  // every workgroup: 4 % — tools/variants_tile.sh, DESIGN 5.2 "Round 4")
   const uint t = xcd_contiguous_block(blockIdx.x, gridDim.x);
   if (t >= nBricks) return;
+  if (cl.tileStats && threadIdx.x == 0) atomicAdd(&cl.tileStats[1], 1u);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave & 1, wz = wave >> 1;
   const int cx = grid.cellDim.x, cy = grid.cellDim.y, cz = grid.cellDim.z;
@@ -611,9 +661,10 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   __builtin_amdgcn_s_setprio(2);
   if (!fits || total[1] != 0u) {
     // a dense brick: every wave runs the chunked single-pair algorithm on its quarter of the candidate buffer
+    if (cl.tileStats && tid == 0) atomicAdd(&cl.tileStats[0], 1u);
     if (y0 + wy < cy && z0 + wz < cz)
-      tile_solo<NT1, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, x0, y0 + wy, z0 + wz,
-                             candBase + 16u * (uint)(wave * kFallbackRegion), 192u, tab, lane);
+      tile_solo<NT != 0, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, x0, y0 + wy, z0 + wz,
+                                 candBase + 16u * (uint)(wave * kFallbackRegion), 192u, tab, lane);
     return;
   }
   if (nOwn == 0 || !anyOwned) return;
@@ -622,8 +673,10 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
   const LJParams p1 = tbl[0];
   const TileFrame fr = tile_centred(scale, ox, oy, oz);
-  const float maxCut2 = NT1 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
-  if (maxCut2 > cl.maxCut2Allowed) {  // wave-uniform; see ListView::maxCut2Allowed
+  const float maxCut2 = NT != 0 ? p1.cutOff2 : lj_max_cutoff2(tbl, ntypes);
+  // (wave-uniform; see ListView::maxCut2Allowed.  The host picks the reduced-units instantiation from its cached copy of the table:
+  // a table rewritten in place behind that cache is caught here, not evaluated with the wrong units)
+  if (maxCut2 > cl.maxCut2Allowed || (NT == 2 && !(p1.sigma2 == 1.0f && p1.epsilonDivSigma2 == 1.0f))) {
     if (lane == 0 && cl.errFlag) cl.errFlag[0] = 2;
     return;
   }
@@ -632,9 +685,9 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
     Acc acc;
     if (pbcWave)
-      tile_words<true, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
+      tile_words<true, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
     else
-      tile_words<false, NT1, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+      tile_words<false, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
   }
 }
@@ -689,14 +742,25 @@ int launch_lj_tile(CellList *h, const ListView &cl, const BoxT<float> &box, cons
   const float margin = tile_margin(g);
   const int npx = (g.cellDim.x + 1) / 2;
   hipEvent_t e0 = nullptr, e1 = nullptr;  // null: a plain launch
-  if (h->prof.enabled) { if (int e = h->prof.next(&e0, &e1)) return e; }
   if (shape == 1) {
+    if (h->prof.enabled) { if (int e = h->prof.next(&e0, &e1)) return e; }
     const uint nTiles = (uint)npx * (uint)g.cellDim.y * (uint)g.cellDim.z;
     hipExtLaunchKernelGGL((k_lj_tile<NT1, WE, WV>), dim3(nTiles), dim3(64), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nTiles);
   } else {
     const int nby = (g.cellDim.y + 1) / 2, nbz = (g.cellDim.z + 1) / 2;
     const uint nBricks = (uint)npx * (uint)nby * (uint)nbz;
-    hipExtLaunchKernelGGL((k_lj_tile4<NT1, WE, WV>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks, tile_scale(g, box));
+    if (h->prof.enabled) { if (int e = h->prof.next(&e0, &e1)) return e; }
+    // (the reduced-units instantiation: one type, forces only, sigma^2 = epsilon / sigma^2 = 1 in the list's cached copy of the table;
+    // the kernel checks the table it is given)
+#ifdef UAMMD_TILE_NOUNIT  // (A/B timing)
+    const bool unit = false;
+#else
+    const bool unit = NT1 && !WE && !WV && h->ljTable == (const void *)tbl && h->ljTableUnit;
+#endif
+    if (unit)
+      hipExtLaunchKernelGGL((k_lj_tile4<2, false, false>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks, tile_scale(g, box));
+    else
+      hipExtLaunchKernelGGL((k_lj_tile4<NT1 ? 1 : 0, WE, WV>), dim3(nBricks), dim3(256), 0, st, e0, e1, 0, cl, g, box, tbl, ntypes, out, margin, npx, nby, nBricks, tile_scale(g, box));
   }
   return 0;
 }

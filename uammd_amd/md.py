@@ -357,6 +357,12 @@ class CellList:
         """Measurement hook: per-launch kernel time of the LJ traversal (uammd_lj_profile_enable, include/uammd_hip.h)."""
         check(self.lib.uammd_lj_profile_enable(self.h, int(bool(on))))
 
+    def tile_stats(self, enable=True):
+        """Measurement hook (uammd_lj_tile_stats): {'fallback_bricks', 'bricks'} counted since the last call; then on / off."""
+        out = (C.c_uint * 4)()
+        check(self.lib.uammd_lj_tile_stats(self.h, int(bool(enable)), out, current_stream()))
+        return {"fallback_bricks": int(out[0]), "bricks": int(out[1])}
+
     def profile_read(self):
         """(summed kernel ms, launches) since profile_enable; waits for launches in flight."""
         ms, n = C.c_double(0.0), C.c_longlong(0)
@@ -675,6 +681,7 @@ class _VerletNVTBasic(Integrator):
         self._integrate(2)
 
     fuse = True   # GronbechJensen + one PairForces<LJ, CellList> on every particle: uammd_verletnvt_gj_lj_step (bit-identical, five launches)
+    fused_steps = 0   # how many forwardTime() calls went through it
 
     def _fused_step(self):
         if not (self.fuse and self.kind == "gj" and self.pg is None and len(self.interactors) == 1):
@@ -693,6 +700,7 @@ class _VerletNVTBasic(Integrator):
                                                   i3(cd), _ptr(tbl), ntypes, self.dt, self.friction, int(self.is2D), self.noiseAmplitude,
                                                   self.steps, self.seed, algo, current_stream()))
         nl.fused_built(box, it.pot.getCutOff(), pos)
+        self.fused_steps += 1
         return True
 
     def sumEnergy(self):
