@@ -107,9 +107,10 @@ int uammd_slab_add2(float *d_dst0, const float *d_src0, float *d_dst1, const flo
 int uammd_slab_copy2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream);
 /* Measurement hook (no reference counterpart): counters of the tile traversal (AUTO / TILE) of this list.  The call first copies the
  * counters accumulated so far into out (nullable; zeros when the hook was off) — out[0] = workgroups (2 x 2 x 2-cell bricks) that took
- * the in-kernel dense-brick fallback, out[1] = bricks launched, out[2..3] reserved —, then zeroes them and turns the hook on
- * (enable != 0) or off.  tests/test_gpu_bench_state.py asserts with it that the melted state bench.py times runs on the main path. */
-int uammd_lj_tile_stats(uammd_celllist *h, int enable, unsigned int out[4], void *stream);
+ * the in-kernel dense-brick fallback, out[1] = bricks launched, out[2..3] reserved, out[4..15] = phase times of diagnostic builds
+ * (-DUAMMD_TILE_TIMELINE, tools/variants_tile.sh; zeros otherwise) —, then zeroes them and turns the hook on (enable != 0) or off.
+ * tests/test_gpu_bench_state.py asserts with it that the melted state bench.py times runs on the main path. */
+int uammd_lj_tile_stats(uammd_celllist *h, int enable, unsigned int out[16], void *stream);
 int uammd_lj_profile_enable(uammd_celllist *h, int enable);
 int uammd_lj_profile_read(uammd_celllist *h, double *total_ms, long long *launches);
 /* options: "force_radix" = 1 makes the build use the stable radix sort path (test hook); "num_owned" = n marks the

@@ -32,6 +32,15 @@ if os.environ.get("OUTSIDE"):   # every particle stored in a random periodic ima
     integ.forwardTime()
 f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
 ref = None
+if os.environ.get("TIMELINE"):   # a -DUAMMD_TILE_TIMELINE build (tools/variants_tile.sh): where a workgroup's lifetime goes
+    cl.tile_stats(True)
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 8)
+    torch.cuda.synchronize()
+    st = cl.tile_stats(False)
+    t, nb = st["timeline"], st["bricks"]
+    nw = max(t[4], 1)
+    print(f"timeline (us, 100 MHz ticks / 100): bricks {nb}, waves with owners {t[4]}; per wave of a brick: ranges known {t[0] / (4 * nb) / 100:.2f}, "
+          f"staging landed {t[1] / (4 * nb) / 100:.2f}, halo staged (barrier) {t[2] / (4 * nb) / 100:.2f}, wave done {t[3] / nw / 100:.2f}", flush=True)
 for algo in algos:
     f.zero_()
     cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, algo)

@@ -884,20 +884,20 @@ int uammd_lj_profile_read(uammd_celllist *h, double *totalMs, long long *launche
   return 0;
 }
 
-int uammd_lj_tile_stats(uammd_celllist *h, int enable, unsigned int out[4], void *stream) {
+int uammd_lj_tile_stats(uammd_celllist *h, int enable, unsigned int out[16], void *stream) {
   if (!h) { set_last_error("uammd_lj_tile_stats: null handle"); return -1; }
   CellList *cl = reinterpret_cast<CellList *>(h);
   hipStream_t st = (hipStream_t)stream;
   if (out) {
-    out[0] = out[1] = out[2] = out[3] = 0u;
+    for (int k = 0; k < 16; ++k) out[k] = 0u;
     if (cl->tileStatsOn) {
-      UH_CHECK(hipMemcpyAsync(out, cl->tileStats.ptr, 4 * sizeof(uint), hipMemcpyDeviceToHost, st));
+      UH_CHECK(hipMemcpyAsync(out, cl->tileStats.ptr, 16 * sizeof(uint), hipMemcpyDeviceToHost, st));
       UH_CHECK(hipStreamSynchronize(st));
     }
   }
   if (enable) {
-    if (int e = cl->tileStats.reserve(4 * sizeof(uint))) return e;
-    UH_CHECK(hipMemsetAsync(cl->tileStats.ptr, 0, 4 * sizeof(uint), st));
+    if (int e = cl->tileStats.reserve(16 * sizeof(uint))) return e;
+    UH_CHECK(hipMemsetAsync(cl->tileStats.ptr, 0, 16 * sizeof(uint), st));
   }
   cl->tileStatsOn = enable != 0;
   return 0;

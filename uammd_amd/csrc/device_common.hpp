@@ -131,6 +131,18 @@ UH_D uint xcd_contiguous_block(uint b, uint nb) {
   if (b >= (per << 3)) return b;  // tail of an incomplete round keeps its place
   return (b & 7u) * per + (b >> 3);
 }
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (no LDS round trips: a __shfl_up ladder is six ds_bpermute, each
+// with its address arithmetic and ~100 cycles of latency): Hillis-Steele inside each row of 16 lanes, then the rows' totals carried across
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+UH_D uint wave_inclusive_scan(uint x) {
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return x;
+}
 UH_HD uint morton_hash(int3 c) { return spread10((uint)c.x) | (spread10((uint)c.y) << 1) | (spread10((uint)c.z) << 2); }
 
 // Global -> LDS copies go through registers U at a time: written as `buf[f(i)] = g[h(i)]` in a loop of run-time length the compiler

@@ -326,12 +326,18 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
 
 // owners' side of the matrix products for the 32 owners [o0, o0 + 32) of a wave, and the lane's owner position
 struct OwnerSide { float4 pi; h8t B0, B1; bool valid; };
+// (ownLds != 0: the LDS byte address of the owners' first staged slot — the brick kernel's halo holds its owners, and a global load here
+// would be one more memory round trip between the staging barrier and the first matrix step)
 UH_D OwnerSide tile_owner(const float4 *__restrict__ P, uint ownFirst, int nOwn, int o0, int lane, bool pbc, const TileFrame &fr, float ox,
-                          float oy, float oz, float rc2ms) {
+                          float oy, float oz, float rc2ms, uint ownLds = 0u) {
   OwnerSide o;
   const int my = o0 + (lane & 31), hi = lane >> 5;
   o.valid = my < nOwn;
-  o.pi = o.valid ? P[ownFirst + (uint)my] : make_float4(ox, oy, oz, 0.0f);
+  if (ownLds) {
+    const f4t q = *(const LdsF4 *)(uintptr_t)(ownLds + 16u * (uint)(o.valid ? my : 0));
+    o.pi = o.valid ? make_float4(q.x, q.y, q.z, q.w) : make_float4(ox, oy, oz, 0.0f);
+  } else
+    o.pi = o.valid ? P[ownFirst + (uint)my] : make_float4(ox, oy, oz, 0.0f);
   float ax, ay, az;
   if (pbc) tile_centre<true>(fr, o.pi.x, o.pi.y, o.pi.z, ax, ay, az);
   else tile_centre<false>(fr, o.pi.x, o.pi.y, o.pi.z, ax, ay, az);
@@ -373,15 +379,17 @@ UH_D TileFrame tile_frame(const GridT<float> &grid, const BoxT<float> &box, floa
   return tile_centred(tile_scale(grid, box), ox, oy, oz);
 }
 
+// (giPre >= 0: the owner's input index, loaded by the caller BEFORE the scan and drain — at the end of a wave's life the index load and
+// the velocity loads that depend on it are two exposed memory round trips that keep the workgroup's slot)
 template <bool WE, bool WV>
-UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint ownFirst, int o0, int lane, bool valid) {
+UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint ownFirst, int o0, int lane, bool valid, int giPre = -1) {
   acc.fx += __shfl_xor(acc.fx, 32);
   acc.fy += __shfl_xor(acc.fy, 32);
   acc.fz += __shfl_xor(acc.fz, 32);
   if (WE) acc.e += __shfl_xor(acc.e, 32);
   if (WV) acc.v += __shfl_xor(acc.v, 32);
   if ((lane >> 5) == 0 && valid) {
-    const int gi = cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
+    const int gi = giPre >= 0 ? giPre : cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
     if (out.vel) {  // the fused step: half kick with the force that is still in registers (every particle is owned, no group)
       const float invMass = 1.0f / (out.defaultMass > 0 ? out.defaultMass : out.mass[gi]);
       float3 v = make_float3(out.vel[3 * (size_t)gi], out.vel[3 * (size_t)gi + 1], out.vel[3 * (size_t)gi + 2]);
@@ -547,6 +555,12 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const uint t = xcd_contiguous_block(blockIdx.x, gridDim.x);
   if (t >= nBricks) return;
   if (cl.tileStats && threadIdx.x == 0) atomicAdd(&cl.tileStats[1], 1u);
+#ifdef UAMMD_TILE_TIMELINE  // diagnostic build: where a workgroup's lifetime goes (100 MHz clock ticks summed over the launch's waves)
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#define TL_STAMP(k) do { if (cl.tileStats && (threadIdx.x & 63) == 0) atomicAdd(&cl.tileStats[k], (uint)(__builtin_amdgcn_s_memrealtime() - tl0)); } while (0)
+#else
+#define TL_STAMP(k) do {} while (0)
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave & 1, wz = wave >> 1;
   const int cx = grid.cellDim.x, cy = grid.cellDim.y, cz = grid.cellDim.z;
@@ -585,16 +599,12 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
         special = (len != 0 && (wr || outside != 0)) ? 1u : 0u;
       }
     }
-    uint incl = len;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint v = __shfl_up(incl, d);
-      if (lane >= d) incl += v;
-    }
+    const uint incl = wave_inclusive_scan(len);
     if (lane < 48) rangeTab[lane] = make_uint4(first, len, incl - len, special);
     if (lane == 63) { total[0] = incl; total[1] = 0u; }
   }
   __syncthreads();
+  TL_STAMP(4);  // ranges known
   const uint C = total[0];
   // every lane of every wave holds the range of its index (lanes >= 48: empty)
   uint4 rg = make_uint4(0u, 0u, 0u, 0u);
@@ -603,6 +613,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   const int ownRange = 3 * ((1 + wy) + 4 * (1 + wz)) + 1;
   const int nOwn = (y0 + wy < cy && z0 + wz < cz) ? (int)rdlane(rg.y, ownRange) : 0;
   const uint ownFirst = rdlane(rg.x, ownRange);
+  const uint ownLds = candBase + 16u * rdlane(rg.z, ownRange);
   uint runStart[3], runLen[3], nW = 0;
   bool pbcWave = false;
   const unsigned long long sp = __ballot(rg.w != 0);
@@ -657,7 +668,9 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     }
   }
   __builtin_amdgcn_s_waitcnt(0);
+  TL_STAMP(5);  // this wave's staging loads landed
   __syncthreads();
+  TL_STAMP(6);  // halo staged
   __builtin_amdgcn_s_setprio(2);
   if (!fits || total[1] != 0u) {
     // a dense brick: every wave runs the chunked single-pair algorithm on its quarter of the candidate buffer
@@ -682,14 +695,19 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   }
   const float rc2ms = maxCut2 * fr.s * fr.s + margin;  // scaled units
   for (int o0 = 0; o0 < nOwn; o0 += 32) {
-    const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms);
+    const OwnerSide ow = tile_owner(P, ownFirst, nOwn, o0, lane, pbcWave, fr, ox, oy, oz, rc2ms, ownLds);
+    const int giPre = ow.valid ? cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))] : 0;
     Acc acc;
     if (pbcWave)
       tile_words<true, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
     else
       tile_words<false, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
-    tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid);
+    tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid, giPre);
   }
+  TL_STAMP(7);  // wave done
+#ifdef UAMMD_TILE_TIMELINE
+  if (cl.tileStats && (threadIdx.x & 63) == 0) atomicAdd(&cl.tileStats[8], 1u);  // waves that reached the end with owners
+#endif
 }
 
 // host side: can this list / box take the tile kernel, and with what margin

@@ -359,9 +359,9 @@ class CellList:
 
     def tile_stats(self, enable=True):
         """Measurement hook (uammd_lj_tile_stats): {'fallback_bricks', 'bricks'} counted since the last call; then on / off."""
-        out = (C.c_uint * 4)()
+        out = (C.c_uint * 16)()
         check(self.lib.uammd_lj_tile_stats(self.h, int(bool(enable)), out, current_stream()))
-        return {"fallback_bricks": int(out[0]), "bricks": int(out[1])}
+        return {"fallback_bricks": int(out[0]), "bricks": int(out[1]), "timeline": [int(x) for x in out[4:]]}
 
     def profile_read(self):
         """(summed kernel ms, launches) since profile_enable; waits for launches in flight."""
