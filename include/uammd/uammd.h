@@ -44,29 +44,14 @@
 #include <vector>
 
 #include "../uammd_hip.h"
+#include "utils/vector.cuh"
 
 namespace uammd {
 
 using std::make_shared;
 using std::shared_ptr;
 
-// ---- global/defines.h:33-44 ------------------------------------------------------------------------------------
-using real = float;
-struct real2 { real x, y; };
-struct real3 { real x, y, z; };
-struct real4 { real x, y, z, w; };
-struct int3_t { int x, y, z; };
-using int3 = int3_t;
-using uint = unsigned int;
-using ullint = unsigned long long;
-inline real3 make_real3(real x, real y, real z) { return {x, y, z}; }
-inline real3 make_real3(real v) { return {v, v, v}; }
-inline real3 make_real3(real4 a) { return {a.x, a.y, a.z}; }
-inline real4 make_real4(real x, real y, real z, real w) { return {x, y, z, w}; }
-inline real4 make_real4(real v) { return {v, v, v, v}; }
-inline real4 make_real4(real3 a, real w) { return {a.x, a.y, a.z, w}; }
-inline int3 make_int3(int x, int y, int z) { return {x, y, z}; }
-
+// ---- global/defines.h:33-44, utils/vector.cuh: real, real2/3/4, int2/3 and their arithmetic (own headers at the reference's paths) ----
 // ---- errors: utils/debugTools.h:20-64, utils/exception.h ---------------------------------------------------------
 struct cuda_generic_error : public std::runtime_error {
   cuda_generic_error(const std::string &m, int code) : std::runtime_error(m), code(code) {}
@@ -122,6 +107,14 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
 // owning device container returned by value where the reference returns cached_vector (utils/container.h); movable, not copyable
 template <class T> using cached_vector = detail::DeviceArray<T>;
 
+// ---- utils/utils.h:21-32: wall-clock stopwatch, seconds ----
+class Timer {
+  std::chrono::time_point<std::chrono::system_clock> t0;
+public:
+  void tic() { t0 = std::chrono::system_clock::now(); }
+  float toc() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now() - t0).count() * 1e-9; }
+};
+
 // ---- utils/utils.h:38-115 ----------------------------------------------------------------------------------------
 class Xorshift128plus {
   uint64_t s[2];
@@ -144,16 +137,34 @@ public:
     const double a = uniform(min, max), b = uniform(min, max), c = uniform(min, max);
     return {(real)a, (real)b, (real)c};
   }
+  // Box-Muller, two numbers per pair of uniforms: the second is handed out by the next call (utils/utils.h:77-104; the spare is shared by
+  // all generators of the process there, and here)
+  double gaussian(double mean, double std) {
+    static double spare;
+    static bool haveSpare = false;
+    haveSpare = !haveSpare;
+    if (!haveSpare) return spare * std + mean;
+    double u1, u2;
+    do { u1 = uniform(0, 1); u2 = uniform(0, 1); } while (u1 <= std::numeric_limits<double>::min());
+    const double r = std::sqrt(-2.0 * std::log(u1)), phi = 2.0 * M_PI * u2;
+    spare = r * std::sin(phi);
+    return r * std::cos(phi) * std + mean;
+  }
+  ::double3 gaussian3(double mean, double std) { const double a = gaussian(mean, std), b = gaussian(mean, std), c = gaussian(mean, std); return ::double3(a, b, c); }
+  ::double2 gaussian2(double mean, double std) { const double a = gaussian(mean, std), b = gaussian(mean, std); return ::double2(a, b); }
+  void setSeed(uint64_t s0, uint64_t s1) { s[0] = s0; s[1] = s1; }
   void setSeed(uint64_t s0) { s[0] = s0; s[1] = (s0 + 15438657923749336752ULL) % 0xFFffFFffFFffFFffULL; }
 };
 
 // ---- System/System.h -----------------------------------------------------------------------------------------------
 class System {
   Xorshift128plus m_rng;
+  int m_argc = 0;
+  char **m_argv = nullptr;
 public:
   enum LogLevel { CRITICAL = 0, ERROR, EXCEPTION, WARNING, MESSAGE, STDERR, STDOUT, DEBUG, DEBUG1, DEBUG2, DEBUG3, DEBUG4, DEBUG5, DEBUG6, DEBUG7 };
   System() : System(0, nullptr) {}
-  System(int argc, char **argv) {
+  System(int argc, char **argv) : m_argc(argc), m_argv(argv) {
     const auto now = std::chrono::steady_clock::now().time_since_epoch();
     m_rng.setSeed(0xf31337Bada55D00dULL ^ (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now).count());
     int dev = -1;
@@ -162,17 +173,29 @@ public:
     if (dev >= 0) detail::check(uammd_hip_set_device(dev));
   }
   Xorshift128plus &rng() { return m_rng; }
+  int getargc() const { return m_argc; }                          // System.h:282-290
+  const char **getargv() const { return (const char **)m_argv; }
+  // System/Log.h:30-80: levels up to MAXLOGLEVEL (6 unless the program is compiled with another) are printed — CRITICAL .. STDERR and
+  // the DEBUG levels on stderr, STDOUT on stdout — behind the level's tag; CRITICAL also throws (System.h:251-257)
   template <LogLevel level> static void log(const char *fmt, ...) {
     if (level > maxLogLevel()) return;
     va_list ap;
     va_start(ap, fmt);
-    char buf[1024];
+    char buf[2048];
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (level == CRITICAL) throw std::runtime_error(std::string("[CRITICAL] ") + buf);  // System.h:251-257
-    std::fprintf(stderr, "[%s] %s\n", level <= EXCEPTION ? "ERROR" : (level == WARNING ? "WARNING" : "MESSAGE"), buf);
+    static const char *tag[] = {"\033[101m[CRITICAL] ", "\033[91m[ERROR] \033[0m", "\033[1m\033[91m[EXCEPTION] \033[0m", "\033[34m[WARNING] \033[0m",
+                                "\033[92m[MESSAGE] \033[0m", " ", " "};
+    std::fprintf(level == STDOUT ? stdout : stderr, "%s%s%s\n", level <= STDOUT ? tag[level] : "\033[96m[ DEBUG ] \033[0m", buf,
+                 level == CRITICAL ? "\033[0m" : "");
+    if (level == CRITICAL) throw std::runtime_error(std::string("[CRITICAL] ") + buf);
   }
-  static int &maxLogLevel() { static int l = WARNING; return l; }
+  template <LogLevel level> static void log(const std::string &msg) { log<level>("%s", msg.c_str()); }
+#ifdef MAXLOGLEVEL
+  static int &maxLogLevel() { static int l = MAXLOGLEVEL; return l; }
+#else
+  static int &maxLogLevel() { static int l = STDOUT; return l; }
+#endif
   void finish() { (void)hipDeviceSynchronize(); }
 };
 
@@ -214,6 +237,57 @@ struct Box {
     per[0] = isPeriodicX(); per[1] = isPeriodicY(); per[2] = isPeriodicZ();
   }
 };
+
+// ---- utils/Grid.cuh:21-139: a box cut into cellDim cells — which cell holds a position, linear cell indices, periodic wrapping of cell
+// coordinates.  Host twin of the arithmetic the cell-list and spreading kernels do on the device (csrc/device_common.hpp). ----
+struct Grid {
+  int3 gridPos2CellIndex;   // strides of the linear index: (1, nx, nx ny)
+  int3 cellDim;
+  real3 cellSize, invCellSize;
+  Box box;
+  real cellVolume;
+  Grid() : Grid(Box(), make_int3(0, 0, 0)) {}
+  Grid(Box box, real3 minCellSize) : Grid(box, make_int3(box.boxSize / minCellSize)) {}
+  Grid(Box box, real minCellSize) : Grid(box, make_real3(minCellSize)) {}
+  Grid(Box box_, int3 cells) : cellDim(cells), box(box_) {
+    if (cellDim.z == 0) cellDim.z = 1;
+    cellSize = box.boxSize / make_real3(cellDim);
+    invCellSize = 1.0 / cellSize;
+    if (box.boxSize.z == real(0.0)) invCellSize.z = 0;
+    gridPos2CellIndex = make_int3(1, cellDim.x, cellDim.x * cellDim.y);
+    cellVolume = cellSize.x * cellSize.y * (cellDim.z > 1 ? cellSize.z : real(1.0));
+  }
+  template <class VecType> int3 getCell(const VecType &r) const {
+    int3 cell = make_int3((box.apply_pbc(make_real3(r)) + real(0.5) * box.boxSize) * invCellSize);
+    // (a position exactly on the upper face rounds to cell cellDim: it belongs to cell 0)
+    if (cell.x == cellDim.x) cell.x = 0;
+    if (cell.y == cellDim.y) cell.y = 0;
+    if (cell.z == cellDim.z) cell.z = 0;
+    return cell;
+  }
+  int getCellIndex(const int3 &cell) const { return dot(cell, gridPos2CellIndex); }
+  int getCellIndex(const int2 &cell) const { return dot(cell, make_int2(gridPos2CellIndex)); }
+  template <int coordinate> int pbc_cell_coord(int cell) const {
+    const int ncells = coordinate == 0 ? (box.isPeriodicX() ? cellDim.x : 0)
+                                       : (coordinate == 1 ? (box.isPeriodicY() ? cellDim.y : 0) : (box.isPeriodicZ() ? cellDim.z : 0));
+    if (cell <= -1) cell += ncells;
+    else if (cell >= ncells) cell -= ncells;
+    return cell;
+  }
+  int3 pbc_cell(const int3 &cell) const { return make_int3(pbc_cell_coord<0>(cell.x), pbc_cell_coord<1>(cell.y), pbc_cell_coord<2>(cell.z)); }
+  int getNumberCells() const { return cellDim.x * cellDim.y * cellDim.z; }
+  real getCellVolume() const { return cellVolume; }
+  real getCellVolume(int3) const { return cellVolume; }
+  real3 getCellSize() const { return cellSize; }
+  real3 getCellSize(int3) const { return cellSize; }
+  real3 getCellCenter(int3 cell) const { return cellSize * (make_real3(cell) + real(0.5)); }
+  real3 distanceToCellCenter(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - getCellCenter(cell)); }
+  real3 distanceToCellUpperLeftCorner(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - cellSize * make_real3(cell)); }
+};
+// the next grid size, per axis, that is even and has only the factors 2, 3, 5, 7, 11 (utils/Grid.cuh:142-213)
+inline int3 nextFFTWiseSize3D(int3 size) {
+  return make_int3(detail::nextFFTWiseSize(size.x), detail::nextFFTWiseSize(size.y), size.z > 1 ? detail::nextFFTWiseSize(size.z) : size.z);
+}
 
 // ---- access, property_ptr, ParticleData ---------------------------------------------------------------------------------
 namespace access {
@@ -318,6 +392,7 @@ public:
     auto ids = id.data(access::cpu, access::write);  // ParticleData.cuh:471-490
     for (int i = 0; i < N; ++i) ids[i] = i;
   }
+  ParticleData(shared_ptr<System> s, int N) : ParticleData(N, s) {}  // ParticleData.cuh:215-216
   ~ParticleData() { if (sorter) uammd_celllist_destroy(sorter); }
   ParticleData(const ParticleData &) = delete;
   ParticleData &operator=(const ParticleData &) = delete;
@@ -354,7 +429,26 @@ public:
     if (!charge.isAllocated()) charge.resize(numberParticles);
     return charge.data(l, m);
   }
-  property_ptr<int> getId(access::location l, access::mode m) { return id.data(l, m); }
+  property_ptr<int> getId(access::location l, access::mode m) {
+    if (m != access::read) idOrderValid = false;
+    return id.data(l, m);
+  }
+  // ParticleData::getIdOrderedIndices (ParticleData.cuh:298-323): the particle with id i sits at row getIdOrderedIndices()[i]; valid
+  // until the next sortParticles
+  const int *getIdOrderedIndices(access::location dev) {
+    if (!idOrderValid) {
+      id2indexHost.assign(numberParticles, 0);
+      {
+        auto ids = id.data(access::cpu, access::read);
+        for (int i = 0; i < numberParticles; ++i) id2indexHost[ids[i]] = i;
+      }
+      id2indexDevice.resize(numberParticles);
+      if (numberParticles)
+        detail::hipCheck(hipMemcpy(id2indexDevice.d, id2indexHost.data(), sizeof(int) * numberParticles, hipMemcpyHostToDevice), "hipMemcpy");
+      idOrderValid = true;
+    }
+    return dev == access::gpu ? id2indexDevice.d : id2indexHost.data();
+  }
   property_ptr<real4> getPosIfAllocated(access::location l, access::mode m) { return pos.isAllocated() ? pos.data(l, m) : property_ptr<real4>(); }
   property_ptr<real4> getForceIfAllocated(access::location l, access::mode m) { return force.isAllocated() ? force.data(l, m) : property_ptr<real4>(); }
   property_ptr<real3> getVelIfAllocated(access::location l, access::mode m) { return vel.isAllocated() ? vel.data(l, m) : property_ptr<real3>(); }
@@ -391,11 +485,15 @@ public:
     reorder(energy, d.d_groupIndex, st); reorder(virial, d.d_groupIndex, st); reorder(mass, d.d_groupIndex, st);
     reorder(radius, d.d_groupIndex, st); reorder(charge, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    idOrderValid = false;
     for (auto &cb : posWriteCallbacks) cb();
     for (auto &cb : reorderCallbacks) cb();
   }
 private:
   uammd_celllist *sorter = nullptr;
+  std::vector<int> id2indexHost;
+  detail::DeviceArray<int> id2indexDevice;
+  bool idOrderValid = false;
   template <class T> void reorder(Property<T> &p, const int *d_index, hipStream_t st) {
     if (!p.isAllocated()) return;
     auto h = p.data(access::gpu, access::readwrite);
@@ -1033,6 +1131,111 @@ struct GaussianTorque {};  // :60-80, built by uammd_fcm_torque_gaussian_kernel
 }  // namespace Kernels
 }  // namespace FCM_ns
 
+}  // namespace BDHI
+
+// ---- misc/IBM_kernels.cuh:26-240: the windows UAMMD ships, as HOST descriptors (the device evaluation lives in the library: a
+// user-written window is a device functor and needs hipcc, include/uammd/device/).  describe() is what IBM<> hands to the C ABI. ----
+namespace IBM_kernels {
+class Gaussian {  // phi(r) = exp(-r^2 / (2 width^2)) / sqrt(2 pi width^2), :28-40.  support: nodes per axis (the reference asks the caller's getSupport)
+  real prefactor, tau;
+public:
+  int support;
+  explicit Gaussian(real width, int support_ = 0) : prefactor(std::pow(2.0 * M_PI * width * width, -0.5)), tau(-0.5 / (width * width)), support(support_) {}
+  real phi(real r, real3 = real3()) const { return prefactor * std::exp(tau * r * r); }
+  uammd_ibm_kernel describe() const {
+    if (support <= 0) throw std::invalid_argument("IBM_kernels::Gaussian: give the support (nodes per axis) to spread or gather with it");
+    uammd_ibm_kernel k{};
+    k.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+    k.support[0] = k.support[1] = k.support[2] = support;
+    k.prefactor = prefactor; k.tau = tau; k.rmax = std::numeric_limits<float>::infinity();
+    return k;
+  }
+};
+struct BarnettMagland {  // :82-112; alpha = half width of the window, in length units
+  real alpha, beta;
+  int support;
+  BarnettMagland(real alpha_, real beta_, int support_ = 0) : alpha(alpha_), beta(beta_), support(support_) {}
+  uammd_ibm_kernel describe() const {
+    if (support <= 0) throw std::invalid_argument("IBM_kernels::BarnettMagland: give the support (nodes per axis) to spread or gather with it");
+    uammd_ibm_kernel k;
+    uammd::detail::check(uammd_ibm_barnett_magland_kernel(alpha, beta, support, real(1.0), &k));
+    return k;
+  }
+};
+namespace Peskin {
+struct threePoint {  // :118-137
+  real invh;
+  static constexpr int support = 3;
+  explicit threePoint(real h) : invh(real(1.0) / h) {}
+  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN3, 3, real(1.0) / invh, &k); return k; }
+};
+struct fourPoint {  // :140-160
+  real invh;
+  static constexpr int support = 4;
+  explicit fourPoint(real h) : invh(real(1.0) / h) {}
+  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN4, 4, real(1.0) / invh, &k); return k; }
+};
+}  // namespace Peskin
+namespace GaussianFlexible {
+struct sixPoint {  // :168-236
+  real invh;
+  static constexpr int support = 6;
+  explicit sixPoint(real h, real = 1e-7) : invh(real(1.0) / h) {}
+  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_SIXPOINT, 6, real(1.0) / invh, &k); return k; }
+};
+}  // namespace GaussianFlexible
+}  // namespace IBM_kernels
+
+// ---- misc/IBM.cuh:63-203: IBM<Kernel, Grid, Index3D> — spread particle quantities to a grid, gather grid quantities to the particles
+// (library mode: no ParticleData, device pointers in, device pointers out).  Kernel is a host descriptor with describe() (IBM_kernels
+// above); Index3D is the linear node index i + nx (j + ny k) whose nx may exceed the grid's (a padded, in-place-FFT layout); the
+// quantity is real or real3 per particle / node.  Default weights only (value * phiX * phiY * phiZ, quadrature weight = cell volume):
+// user WeightCompute / QuadratureWeights functors are device code. ----
+namespace IBM_ns {
+struct LinearIndex3D {
+  LinearIndex3D(int nx_, int ny_, int nz_) : nx(nx_), ny(ny_), nz(nz_) {}
+  int operator()(int3 c) const { return (*this)(c.x, c.y, c.z); }
+  int operator()(int i, int j, int k) const { return i + nx * (j + ny * k); }
+  int nx, ny, nz;
+};
+}  // namespace IBM_ns
+template <class Kernel, class GridT = uammd::Grid, class Index3D = IBM_ns::LinearIndex3D> class IBM {
+  static_assert(std::is_same<Index3D, IBM_ns::LinearIndex3D>::value, "the host IBM<> takes IBM_ns::LinearIndex3D; another node indexing is a device functor (hipcc)");
+  shared_ptr<Kernel> kernel;
+  GridT grid;
+  Index3D cell2index;
+  template <class Q> static int components() {
+    static_assert(sizeof(Q) == sizeof(real) || sizeof(Q) == 3 * sizeof(real), "IBM<>: the quantity is real or real3");
+    return (int)(sizeof(Q) / sizeof(real));
+  }
+  struct Geometry { float L[3]; int per[3], cd[3]; };
+  Geometry geometry() const {
+    Geometry g;
+    grid.box.toArrays(g.L, g.per);
+    g.cd[0] = grid.cellDim.x; g.cd[1] = grid.cellDim.y; g.cd[2] = grid.cellDim.z;
+    return g;
+  }
+public:
+  IBM(shared_ptr<Kernel> kern, GridT a_grid, Index3D index) : kernel(kern), grid(a_grid), cell2index(index) {}
+  IBM(shared_ptr<Kernel> kern, GridT a_grid) : IBM(kern, a_grid, Index3D(a_grid.cellDim.x, a_grid.cellDim.y, a_grid.cellDim.z)) {}
+  // gridData[node] += sum_i v[i] phi(node - pos[i])   (IBM.cuh:118-138; a grid with cellDim.z == 1 is 2D, :182-194)
+  template <class Q> void spread(const real4 *pos, const Q *v, Q *gridData, int numberParticles, hipStream_t st = 0) const {
+    const Geometry g = geometry();
+    const uammd_ibm_kernel k = kernel->describe();
+    detail::check(uammd_ibm_spread((const float *)pos, 4, (const float *)v, components<Q>(), numberParticles, g.L, g.per, g.cd, cell2index.nx, &k,
+                                   (float *)gridData, (void *)st));
+  }
+  // Jq[i] += sum_node gridData[node] phi(node - pos[i]) cellVolume   (IBM.cuh:140-180)
+  template <class Q> void gather(const real4 *pos, Q *Jq, const Q *gridData, int numberParticles, hipStream_t st = 0) const {
+    const Geometry g = geometry();
+    const uammd_ibm_kernel k = kernel->describe();
+    detail::check(uammd_ibm_gather((const float *)pos, 4, (float *)Jq, components<Q>(), numberParticles, g.L, g.per, g.cd, cell2index.nx, &k,
+                                   (const float *)gridData, (void *)st));
+  }
+  shared_ptr<Kernel> getKernel() { return kernel; }
+};
+
+namespace BDHI {
 template <class Kernel = FCM_ns::Kernels::Gaussian, class KernelTorque = FCM_ns::Kernels::GaussianTorque> class FCM_impl {
   uammd_fcm *h = nullptr;
   Box box;

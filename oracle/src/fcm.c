@@ -100,52 +100,85 @@ static inline int isNyquistWaveNumber(int3 cell, int3 nc) { /* utils.cuh:133-167
 }
 
 /* K17: FCM_impl.cuh:437-512.  `prefactor` is the noisePrefactor of addBrownianNoise. */
+static void fcm_noise_node(complex3 *g, int id, int3 nk, real3 L, real prefactor, real viscosity, uint seed1, uint seed2) {
+  const int3 cell = mki3(id % (nk.x / 2 + 1), (id / (nk.x / 2 + 1)) % nk.y, id / ((nk.x / 2 + 1) * nk.y));
+  if (id == 0 || (cell.x == 0 && cell.y == 0 && 2 * cell.z >= nk.z + 1) || (cell.x == 0 && 2 * cell.y >= nk.y + 1)) return;
+  complex3 noise = generateNoise(prefactor, (uint)id, seed1, seed2);
+  const int nyquist = isNyquistWaveNumber(cell, nk);
+  if (nyquist) {
+    const real nqsc = (real)1.41421356237310;
+    noise.xr *= nqsc; noise.xi = 0;
+    noise.yr *= nqsc; noise.yi = 0;
+    noise.zr *= nqsc; noise.zi = 0;
+  }
+  {
+    const int3 ik = indexToWaveNumber(id, nk);
+    const real3 k = waveNumberToWaveVector(ik, L);
+    const real k2 = dot3(k, k);
+    const real B = (real)1.0 / (k2 * viscosity);
+    complex3 factor = c3scale(noise, SQRT(B));
+    const real3 dk = getGradientFourier(ik, nk, L);
+    c3add(&g[id], projectFourierC(k2, dk, factor));
+  }
+  if (nyquist) return;
+  if (cell.x == nk.x - cell.x || cell.x == 0) {
+    const int xc = cell.x;
+    const int yc = (cell.y > 0) * (nk.y - cell.y);
+    const int zc = (cell.z > 0) * (nk.z - cell.z);
+    const int id_conj = xc + (nk.x / 2 + 1) * (yc + zc * nk.y);
+    const int3 ik = indexToWaveNumber(id_conj, nk);
+    const real3 k = waveNumberToWaveVector(ik, L);
+    const real k2 = dot3(k, k);
+    const real B = (real)1.0 / (k2 * viscosity);
+    const real Bsq = SQRT(B);
+    complex3 factor = c3scale(noise, Bsq);
+    factor.xi *= (real)(-1.0); factor.yi *= (real)(-1.0); factor.zi *= (real)(-1.0);
+    const real3 dk = getGradientFourier(ik, nk, L);
+    c3add(&g[id_conj], projectFourierC(k2, dk, factor));
+  }
+}
+
 ORACLE_API void oracle_fcm_fourier_brownian_noise(real *grid6, const real *L3, const int *cellDim, real prefactor,
                                                   real viscosity, uint seed1, uint seed2) {
   complex3 *g = (complex3 *)grid6;
   const int3 nk = mki3(cellDim[0], cellDim[1], cellDim[2]);
   const real3 L = mk3(L3[0], L3[1], L3[2]);
-  const int N = nk.z * nk.y * (nk.x / 2 + 1);
-  /* (a node writes itself and, on the kx = 0 / Nyquist planes, its conjugate partner, which is one of the skipped nodes: no two
-   * iterations touch the same node) */
-#pragma omp parallel for schedule(static) if (oracle_get_parallel())
-  for (int id = 0; id < N; id++) {
-    const int3 cell = mki3(id % (nk.x / 2 + 1), (id / (nk.x / 2 + 1)) % nk.y, id / ((nk.x / 2 + 1) * nk.y));
-    if (id == 0 || (cell.x == 0 && cell.y == 0 && 2 * cell.z >= nk.z + 1) || (cell.x == 0 && 2 * cell.y >= nk.y + 1)) continue;
-    complex3 noise = generateNoise(prefactor, (uint)id, seed1, seed2);
-    const int nyquist = isNyquistWaveNumber(cell, nk);
-    if (nyquist) {
-      const real nqsc = (real)1.41421356237310;
-      noise.xr *= nqsc; noise.xi = 0;
-      noise.yr *= nqsc; noise.yi = 0;
-      noise.zr *= nqsc; noise.zi = 0;
-    }
-    {
-      const int3 ik = indexToWaveNumber(id, nk);
-      const real3 k = waveNumberToWaveVector(ik, L);
-      const real k2 = dot3(k, k);
-      const real B = (real)1.0 / (k2 * viscosity);
-      complex3 factor = c3scale(noise, SQRT(B));
-      const real3 dk = getGradientFourier(ik, nk, L);
-      c3add(&g[id], projectFourierC(k2, dk, factor));
-    }
-    if (nyquist) continue;
-    if (cell.x == nk.x - cell.x || cell.x == 0) {
-      const int xc = cell.x;
-      const int yc = (cell.y > 0) * (nk.y - cell.y);
-      const int zc = (cell.z > 0) * (nk.z - cell.z);
-      const int id_conj = xc + (nk.x / 2 + 1) * (yc + zc * nk.y);
-      const int3 ik = indexToWaveNumber(id_conj, nk);
-      const real3 k = waveNumberToWaveVector(ik, L);
-      const real k2 = dot3(k, k);
-      const real B = (real)1.0 / (k2 * viscosity);
-      const real Bsq = SQRT(B);
-      complex3 factor = c3scale(noise, Bsq);
-      factor.xi *= (real)(-1.0); factor.yi *= (real)(-1.0); factor.zi *= (real)(-1.0);
-      const real3 dk = getGradientFourier(ik, nk, L);
-      c3add(&g[id_conj], projectFourierC(k2, dk, factor));
-    }
+  const int nxh = nk.x / 2 + 1;
+  const int N = nk.z * nk.y * nxh;
+  if (!oracle_get_parallel()) {  /* the reference's order: one loop over the nodes (what every parity test runs) */
+    for (int id = 0; id < N; id++) fcm_noise_node(g, id, nk, L, prefactor, viscosity, seed1, seed2);
+    return;
   }
+  /* Parallel mode (bench.py's cpu_baseline leg only).  A node on the kx = 0 or kx = nx/2 plane also writes its conjugate partner.
+   * Where the partner is one of the SKIPPED nodes no two iterations touch the same element; where it is not — the whole kx = nx/2 plane
+   * (even nx) and the line kx = 0, ky = ny/2 (even ny) — a node and its partner both run and each adds to the other's element: a race
+   * under `omp parallel for` (round-3 verdict).  The threads therefore leave out every node whose partner is active, and those nodes
+   * are walked afterwards by one thread in the reference's order: the same sums, bit for bit, as the serial loop. */
+#define FCM_NOISE_SKIPPED(i, c) ((i) == 0 || ((c).x == 0 && (c).y == 0 && 2 * (c).z >= nk.z + 1) || ((c).x == 0 && 2 * (c).y >= nk.y + 1))
+#define FCM_NOISE_DEFERRED(id, out)                                                                        \
+  do {                                                                                                     \
+    const int3 c_ = mki3((id) % nxh, ((id) / nxh) % nk.y, (id) / (nxh * nk.y));                           \
+    (out) = 0;                                                                                             \
+    if (c_.x == 0 || c_.x == nk.x - c_.x) {                                                                \
+      const int3 p_ = mki3(c_.x, (c_.y > 0) * (nk.y - c_.y), (c_.z > 0) * (nk.z - c_.z));                 \
+      const int ip_ = p_.x + nxh * (p_.y + p_.z * nk.y);                                                   \
+      (out) = ip_ != (id) && !FCM_NOISE_SKIPPED(ip_, p_);                                                  \
+    }                                                                                                      \
+  } while (0)
+#pragma omp parallel for schedule(static)
+  for (int id = 0; id < N; id++) {
+    int deferred;
+    FCM_NOISE_DEFERRED(id, deferred);
+    if (!deferred) fcm_noise_node(g, id, nk, L, prefactor, viscosity, seed1, seed2);
+  }
+  for (int id = 0; id < N; id++) {
+    if (id % nxh != 0 && id % nxh != nk.x - id % nxh) continue;
+    int deferred;
+    FCM_NOISE_DEFERRED(id, deferred);
+    if (deferred) fcm_noise_node(g, id, nk, L, prefactor, viscosity, seed1, seed2);
+  }
+#undef FCM_NOISE_DEFERRED
+#undef FCM_NOISE_SKIPPED
 }
 
 /* addBrownianNoise: noisePrefactor = prefactor * sqrt(fourierNormalization*2*T/dV), FCM_impl.cuh:526-532 */

@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "particle_group", "custom_transverser"]
+PROGS = ["custom_potential", "ibm_library_mode", "bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "particle_group", "custom_transverser"]
 
 
 def _make():
@@ -37,7 +37,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog,args", [("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
+@pytest.mark.parametrize("prog,args", [("custom_potential", []), ("ibm_library_mode", []), ("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
                                        ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []), ("particle_group", ["600", "7"]),
                                        ("custom_transverser", [])])
 def test_examples_run(prog, args):
@@ -59,3 +59,22 @@ def test_slab_drivers_world1(prog, args, tmp_path):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "world 1:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_program_runs(tmp_path):
+    """examples/_build/ref_benchmark = the REFERENCE's examples/misc/benchmark.cu, compiled from where it lies by plain g++ against
+    include/uammd and linked with libuammd_hip (examples/Makefile; built in the container that holds the reference tree, the binary
+    travels).  Its own defaults: 2^20 particles from initLattice(fcc) in a 128^3 box, VerletNVT::GronbechJensen, PairForces<LJ,
+    VerletList> with rcutmult 1.2, 500 + 500 steps, "mean FPS" on the log."""
+    exe = os.path.join(EX, "_build", "ref_benchmark")
+    if not os.path.exists(exe):
+        pytest.skip("ref_benchmark was not built (no reference tree where `make -C examples` ran)")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    import re
+    m = re.search(r"mean FPS: ([0-9.]+)", r.stdout + r.stderr)
+    assert m, "the program did not report its rate"
+    assert float(m.group(1)) > 200.0     # ~90 on the GTX 980 of the reference's comment; > 2000 measured on MI355X
+    assert (tmp_path / "data.main.benchmark").exists()   # it wrote its default parameter file through InputFile's reader

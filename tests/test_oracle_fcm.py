@@ -206,3 +206,23 @@ def test_barnett_magland_norm_and_support(o64, o32):
     g = o64.ibm_spread(np.array([[0.1, -0.07, 0.2]]), np.ones(1), L, 1, [n] * 3, k)[..., 0]
     assert np.count_nonzero(g) <= 4 ** 3
     assert abs(g.sum() * h ** 3 - 1.0) <= 2e-3  # ES window: partition of unity only up to its design tolerance
+
+
+def test_fcm_noise_parallel_mode_equals_serial(o32):
+    """The all-cores mode of fourierBrownianNoise (bench.py's cpu_baseline leg) must give the serial loop's bits: on the kx = nx/2 plane a
+    node and its conjugate partner add to each other's element, which raced under `omp parallel for` until round 4 (the plane is now
+    walked by one thread in the reference's order)."""
+    cells, L, eta = [32, 24, 20], np.array([32.0, 24.0, 20.0], np.float32), 1.0
+    npf = o32.fcm_noise_prefactor(1.0, 1.0, L, cells)
+    rng = np.random.default_rng(5)
+    g0 = (rng.normal(size=(20, 24, 17, 3)) + 1j * rng.normal(size=(20, 24, 17, 3))).astype(np.complex64)
+    ref = g0.copy()
+    o32.fcm_fourier_brownian_noise(ref, L, cells, npf, eta, 4242, 7)
+    o32.set_parallel(True)
+    try:
+        for _ in range(5):
+            g = g0.copy()
+            o32.fcm_fourier_brownian_noise(g, L, cells, npf, eta, 4242, 7)
+            assert np.array_equal(g.view(np.uint32), ref.view(np.uint32))
+    finally:
+        o32.set_parallel(False)
