@@ -37,11 +37,29 @@ PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 M
 PEAK_HBM_GBS = 8000.0
 
 
+ABI_COMM = None   # uammd_amd.comm.AbiComm when the run's messages go through uammd_comm_* (the product's stack); None: torch.distributed
+TRANSPORT = "none (single domain)"   # what actually carried the messages: goes into config.workload and comm.backend
+
+
 def _allreduce(dist, values, op):
-    """floats reduced over the ranks (host tensors under gloo, device tensors under RCCL)."""
+    """floats reduced over the ranks (through uammd_comm_allreduce_sum when the C-ABI stack carries the run; else host tensors under
+    gloo, device tensors under torch's RCCL)."""
+    if ABI_COMM is not None:
+        return ABI_COMM.reduce_host(values, op)
     t = torch.tensor(values, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
     dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
     return t.tolist()
+
+
+def _barrier(dist):
+    if ABI_COMM is not None:
+        ABI_COMM.barrier()
+    elif dist is not None:
+        dist.barrier()
+
+
+def _reducing(dist):
+    return ABI_COMM is not None or dist is not None
 
 
 def read_traffic(name):
@@ -199,8 +217,7 @@ def run_fcm(hip, args, world, rank, dist):
     for _ in range(args.fcm_warmup):
         integ.forwardTime()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -209,11 +226,10 @@ def run_fcm(hip, args, world, rank, dist):
         integ.forwardTime()
     e1.record()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if dist is not None:
+    if _reducing(dist):
         el = _allreduce(dist, [el], "MAX")[0]
     assert np.isfinite(pd.getPos().cpu().numpy()).all()
     ms = el / args.fcm_steps * 1e3
@@ -239,7 +255,7 @@ def run_fcm_distributed(hip, args, world, rank, dist):
     kernel, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
     geom = SlabGeometry(cells, L, world, kernel.support[2])
     back = HipSlabBackend(geom, rank, kernel, 1.0, 1234)
-    d = make_decomposition(geom, rank)
+    d = make_decomposition(geom, rank, comm=ABI_COMM)
     rng = np.random.default_rng(1234 + rank)
     pos = np.zeros((n, 4), np.float32)
     pos[:, :3] = rng.uniform(-64.0, 64.0, (n, 3))            # window frame: z relative to the slab centre
@@ -248,23 +264,21 @@ def run_fcm_distributed(hip, args, world, rank, dist):
     pos, force = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
     ids = torch.arange(n, dtype=torch.int32, device="cuda") + rank * n
     # thermal steps are ~0.03 h: with 3 spare halo planes the particles are re-assigned to their slabs every 20 steps
-    integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, T, dt, lambda p, i, f: f, migrate_every=20)
+    integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank], comm=ABI_COMM), d, T, dt, lambda p, i, f: f, migrate_every=20)
     for _ in range(args.fcm_warmup):
         pos, ids, force = integ.forward_time(pos, ids, force)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.fcm_steps):
         pos, ids, force = integ.forward_time(pos, ids, force)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     cnt = float(pos.shape[0])
-    if dist is not None:
+    if _reducing(dist):
         el = _allreduce(dist, [el], "MAX")[0]
         cnt = _allreduce(dist, [cnt], "SUM")[0]
     assert torch.isfinite(pos).all()
@@ -279,7 +293,7 @@ def run_fcm_distributed(hip, args, world, rank, dist):
             "warmup": args.fcm_warmup,
             "config": {"workload": f"BDHI::FCMIntegrator, grid 128x128x{128 * world}, {n * world} particles, Gaussian support 6, "
                                    "fixed forces + Fourier-space noise; z-slab decomposition: halo planes by send/recv, "
-                                   "2 all-to-all transposes per step (RCCL)",
+                                   f"2 all-to-all transposes per step; messages through {TRANSPORT}",
                        "parallelism": f"slab{world}: 1 process per GPU"},
             "roofline": {"bound": "hbm", "kernel": "whole FCM step, all GPUs", "achieved": gbs, "peak": PEAK_HBM_GBS * world,
                          "unit": "GB/s", "frac": gbs / (PEAK_HBM_GBS * world), "traffic": None,
@@ -305,7 +319,7 @@ def run_fcm_c5(hip, args, world, rank, dist):
         kernel, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
         geom = SlabGeometry(cells, [L] * 3, world, kernel.support[2])
         back = HipSlabBackend(geom, rank, kernel, 1.0, 1234)
-        d = make_decomposition(geom, rank)
+        d = make_decomposition(geom, rank, comm=ABI_COMM)
         nloc = n_total // world
         rng = np.random.default_rng(1234 + rank)
         pos = np.zeros((nloc, 4), np.float32)
@@ -315,25 +329,23 @@ def run_fcm_c5(hip, args, world, rank, dist):
         force[:, :3] = np.random.default_rng(4321 + rank).normal(0, 1, (nloc, 3))
         state = [torch.from_numpy(pos).cuda(), torch.arange(nloc, dtype=torch.int32, device="cuda") + rank * nloc,
                  torch.from_numpy(force).cuda()]
-        integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank]), d, T, dt, lambda p, i, f: f, migrate_every=20)
+        integ = DistributedFCMIntegrator(DistributedFCM(geom, [back], [rank], comm=ABI_COMM), d, T, dt, lambda p, i, f: f, migrate_every=20)
 
         def step():
             state[0], state[1], state[2] = integ.forward_time(state[0], state[1], state[2])
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if dist is not None:
+    if _reducing(dist):
         el = _allreduce(dist, [el], "MAX")[0]
     ms = el / steps * 1e3
     nbytes = fcm_bytes_per_step(n_total, cells)
@@ -493,7 +505,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
     noise = math.sqrt(2 * dt * 1.0 * T)
     # cached exchange: skin 0.6 sigma, ownership + halo lists refreshed every 20 steps; DistributedLJ.check_skin() verifies after the
     # run that no particle out-ran the skin between two refreshes
-    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=args.skin)
+    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=args.skin, comm=ABI_COMM)
     pos = torch.from_numpy(lattice(n, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
     vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, math.sqrt(3 * T), 0, n, 77 + rank, None))
@@ -521,9 +533,11 @@ def run_lj_distributed(hip, args, world, rank, dist):
         return f
 
     def integrate_fn(step, p, v, f, step_num):
-        check(lib.uammd_verletnvt_gj(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
-                                     1.0, None, p.shape[0], dt, 1.0, 0, noise, step_num, 4242 + rank,
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        # the thermostat's stream keyed by the GLOBAL particle id, one seed for all ranks: kicks do not depend on the decomposition
+        key = sim.current_ids
+        check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
+                                           1.0, None, C.c_void_p(key.data_ptr()), p.shape[0], dt, 1.0, 0, noise, step_num, 4242,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into)
     force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
@@ -554,8 +568,7 @@ def run_lj_distributed(hip, args, world, rank, dist):
         pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
     pos, vel, force, ids = sort_owned(pos, vel, force, ids)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     sim.max_drift = None  # the skin check below covers the timed region (the reference's initial velocities are sqrt(3) too hot,
                           # Basic.cu:12-29: the first steps of the warm-up out-run a skin sized for the equilibrated liquid)
@@ -566,12 +579,11 @@ def run_lj_distributed(hip, args, world, rank, dist):
             pos, vel, force, ids = sort_owned(pos, vel, force, ids)
         pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     total = float(pos.shape[0])
-    if dist is not None:
+    if _reducing(dist):
         el = _allreduce(dist, [el], "MAX")[0]
         total = _allreduce(dist, [total], "SUM")[0]
     assert torch.isfinite(pos).all()
@@ -674,6 +686,42 @@ def main():
     import uammd_amd as hip
     from uammd_amd._lib import check, load
 
+    # ONE communication stack: every message of the slab-decomposed runs (N > 1, or --force-distributed at N = 1 where the ring closes on
+    # the rank itself) goes through uammd_comm_* — RCCL behind the C ABI, the entry points include/uammd/Distributed.h drives from C++.
+    # torch.distributed is then only the bootstrap that hands rank 0's RCCL id around.  The gloo harness (all ranks on one device, host
+    # staged) keeps torch.distributed as the transport: a test double, and the labels say so.
+    global ABI_COMM, TRANSPORT
+    if world > 1 or args.force_distributed:
+        backend = os.environ.get("UAMMD_BENCH_BACKEND", "nccl") if world > 1 else "nccl"
+        want_abi = backend == "nccl" and os.environ.get("UAMMD_BENCH_COMM", "abi") == "abi"
+        err = None
+        if want_abi:
+            from uammd_amd.comm import AbiComm
+            try:
+                ABI_COMM = AbiComm.from_torch_distributed(dist) if world > 1 else AbiComm(0, 1, AbiComm.unique_id())
+            except Exception as e:   # (a rank that cannot build the communicator must not leave the others waiting: agree below)
+                err = f"{type(e).__name__}: {e}"
+            if world > 1:
+                ok = torch.tensor([0.0 if err else 1.0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() == 0.0 and ABI_COMM is not None:
+                    ABI_COMM.close()
+                    ABI_COMM = None
+                    err = err or "another rank failed to build the communicator"
+        if ABI_COMM is not None:
+            TRANSPORT = "uammd_comm_* (RCCL behind the C ABI: csrc/comm.hip)"
+            comm_info["backend"] = TRANSPORT
+            comm_info["bootstrap"] = "torch.distributed (hands rank 0's RCCL id to the other ranks; carries no payload)" if world > 1 else "in-process"
+        elif world > 1:
+            TRANSPORT = ("torch.distributed nccl (RCCL)" if backend == "nccl" else
+                         f"torch.distributed {backend} (host-staged test double" + ("; all ranks on one device)" if same_device else ")"))
+            comm_info["backend"] = TRANSPORT
+        else:
+            TRANSPORT = "in-process loop-back (world of one, no messages)"
+            comm_info["backend"] = TRANSPORT
+        if err:
+            comm_info["abi_comm_error"] = err
+
     if args.workload == "pse":
         if world > 1:
             print("bench.py: the PSE line is single-GPU (the near field shards like path A, the far field like path B)", file=sys.stderr)
@@ -710,7 +758,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, z-slab domain decomposition (one 43-cell "
-                                   "slab per GPU, global box L x L x N*L), halo positions + migration by RCCL send/recv",
+                                   f"slab per GPU, global box L x L x N*L), halo positions + migration through {TRANSPORT}",
                        "particles_per_gpu": n, "box": [L1, L1, L1 * world],
                        "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange"},
             "pair_interactions_per_s": 52.36 * value,
@@ -737,8 +785,7 @@ def main():
         verlet.forwardTime()
     pd.sortParticles()  # examples/misc/benchmark.cu:154-156 sorts every 500 steps: the timed region starts from a sorted state ...
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    _barrier(dist)
     torch.cuda.synchronize()
     profiled = args.nl == "cell" and os.environ.get("UAMMD_BENCH_NOTIMER") != "1"
     if profiled:
@@ -759,16 +806,15 @@ def main():
                 pd.sortParticles()  # ... and sorts again, INSIDE the timed region, after every 500th timed step (a sort is ~1.5 ms: charging
                                     # one to a 20-step run would overstate its amortised cost of 0.003 ms per step 25-fold)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        _barrier(dist)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if dist is not None:
+        if _reducing(dist):
             el = _allreduce(dist, [el], "MAX")[0]
         blocks.append(el)
         if args.repeats <= 0 and len(blocks) == 1:
             nrep = int(min(5000, max(10 if args.steps <= 100 else 1, math.ceil(args.min_timed_seconds / max(el, 1e-6)))))
-            if dist is not None:
+            if _reducing(dist):
                 nrep = int(_allreduce(dist, [float(nrep)], "MAX")[0])
     el = float(np.median(blocks))
     k_ms, k_launches = float("nan"), 0

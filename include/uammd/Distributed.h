@@ -113,8 +113,10 @@ class DistributedLJ {
                                                UAMMD_LJ_ALGO_AUTO, (void *)st));
   }
   void integrate(int step) {
-    detail::check(uammd_verletnvt_gj(step, (float *)pos.d, vel.d, (float *)force.d, nullptr, real(1.0), nullptr, nOwned, dt, friction, 0,
-                                     noiseAmplitude, (uint)steps, seed, (void *)st));
+    // (the thermostat's stream is keyed by the particle's GLOBAL id, same seed on every rank: a particle draws the same kicks whichever
+    // rank and row holds it — no correlation between slabs through equal row numbers, no dependence on the decomposition)
+    detail::check(uammd_verletnvt_gj_keyed(step, (float *)pos.d, vel.d, (float *)force.d, nullptr, real(1.0), nullptr, ids.d, nOwned, dt, friction,
+                                           0, noiseAmplitude, (uint)steps, seed, (void *)st));
   }
 public:
   struct Parameters {

@@ -211,6 +211,13 @@ int uammd_lj_transverse_verletlist(uammd_verletlist *h, const uammd_lj_pair_para
 int uammd_verletnvt_gj(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
                        const int *d_index, int numberParticles, float dt, float friction, int is2D,
                        float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);
+/* The same step with the thermostat's random stream of thread t keyed by d_noiseKey[t] instead of t (nullable: then exactly
+ * uammd_verletnvt_gj).  New design for the domain-decomposed drivers (the reference is single GPU): the key is the particle's GLOBAL id,
+ * so a particle draws the same kicks whichever rank and row holds it — the trajectory of an N-rank run does not depend on the
+ * decomposition or on the order migration leaves the rows in, and slabs are not correlated through equal row numbers. */
+int uammd_verletnvt_gj_keyed(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                             const int *d_index, const int *d_noiseKey, int numberParticles, float dt, float friction, int is2D,
+                             float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);
 /* One whole VerletNVT::GronbechJensen::forwardTime (Integrator/VerletNVT/GronbechJensen.cu:88-115) whose only interactor is
  * PairForces<Potential::LJ, CellList> on every particle (Interactor/PairForces.cu:43-78), fused into five launches: the first half step
  * rides in the cell list's hash kernel, the second in the traversal's store.  Bit-identical to the sequence

@@ -136,3 +136,43 @@ def test_md_steps_lj_nvt(hip, o32):
     gp, gv = pd.getPos().cpu().numpy(), pd.getVel().cpu().numpy()
     assert np.abs(gp - rp).max() <= 1e-5
     assert np.abs(gv - rv).max() <= 1e-4
+
+
+def test_gj_noise_keyed_by_global_id(hip):
+    """uammd_verletnvt_gj_keyed (the domain-decomposed drivers' thermostat): row t draws the stream of key[t], so a particle gets the same
+    kicks whichever row (and rank) holds it — the rows of a shuffled copy, keyed by their original numbers, land exactly where the
+    unshuffled ones do; and two "ranks" holding different ids with the same seed draw different, uncorrelated kicks (with the plain entry
+    point and equal seeds their rows t would draw identical ones: ADVICE round 3)."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    lib = load()
+    n, dt, T = 4096, 0.005, 1.3
+    noise = math.sqrt(2 * dt * 1.0 * T)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    pos = torch.rand((n, 4), generator=g, device="cuda") * 10
+    vel = torch.randn((n, 3), generator=g, device="cuda")
+    force = torch.randn((n, 4), generator=g, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def step(pos, vel, force, key, seed=99):
+        pp, vv, ff = pos.clone(), vel.clone(), force.clone()
+        if key is None:
+            check(lib.uammd_verletnvt_gj(1, p(pp), p(vv), p(ff), None, 1.0, None, n, dt, 1.0, 0, noise, 7, seed, None))
+        else:
+            check(lib.uammd_verletnvt_gj_keyed(1, p(pp), p(vv), p(ff), None, 1.0, None, p(key), n, dt, 1.0, 0, noise, 7, seed, None))
+        torch.cuda.synchronize()
+        return pp, vv
+    ref_p, ref_v = step(pos, vel, force, None)
+    ident = torch.arange(n, dtype=torch.int32, device="cuda")
+    kp, kv = step(pos, vel, force, ident)
+    assert torch.equal(kp, ref_p) and torch.equal(kv, ref_v)                      # key = row number: the plain entry point
+    perm = torch.randperm(n, generator=g, device="cuda")
+    sp, sv = step(pos[perm].contiguous(), vel[perm].contiguous(), force[perm].contiguous(), perm.to(torch.int32))
+    assert torch.equal(sp, ref_p[perm]) and torch.equal(sv, ref_v[perm])          # the kicks travel with the id, not with the row
+    # two slabs, same seed, ids 0..n-1 and n..2n-1, zero forces and velocities: the velocity after step 1 IS the kick
+    zero_v, zero_f = torch.zeros_like(vel), torch.zeros_like(force)
+    _, va = step(pos, zero_v, zero_f, ident)
+    _, vb = step(pos, zero_v, zero_f, ident + n)
+    assert not torch.equal(va, vb)
+    c = torch.corrcoef(torch.stack([va.flatten(), vb.flatten()]))[0, 1].item()
+    assert abs(c) < 5.0 / math.sqrt(3 * n)

@@ -154,6 +154,7 @@ SIGNATURES = {
     "uammd_verletlist_get": (_i, [_vp, C.POINTER(VerletListData)]),
     "uammd_lj_transverse_verletlist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
     "uammd_verletnvt_gj": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
+    "uammd_verletnvt_gj_keyed": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_gj_lj_step": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _f3, _i3, _f3, _i3, _i3, _vp, _i, _f, _f, _i, _f, _u, _u, _i, _vp]),
     "uammd_verletnvt_basic": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _f, _f, _i, _f, _u, _u, _vp]),
     "uammd_verletnvt_initial_velocities": (_i, [_vp, _vp, _f, _i, _i, _u, _vp]),

@@ -16,12 +16,14 @@ namespace uammd_hip {
 
 constexpr int kIB = 256;
 
+// noiseKey (nullable): the Saru stream of thread id is keyed by noiseKey[id] instead of id — a domain-decomposed run passes the GLOBAL
+// particle ids, so that a particle draws the same kicks whichever rank and row holds it (the reference is single GPU: key = id)
 template <int STEP>
 __global__ void __launch_bounds__(kIB) k_verletnvt_gj(float4 *__restrict__ pos, float *__restrict__ vel,
                                                       float4 *__restrict__ force, const float *__restrict__ mass,
                                                       float defaultMass, const int *__restrict__ index, int N,
                                                       float dt, float friction, int is2D, float noiseAmplitude,
-                                                      uint stepNum, uint seed) {
+                                                      uint stepNum, uint seed, const int *__restrict__ noiseKey = nullptr) {
   const int id = blockIdx.x * kIB + threadIdx.x;
   if (id >= N) return;
   const int i = index ? index[id] : id;
@@ -30,7 +32,7 @@ __global__ void __launch_bounds__(kIB) k_verletnvt_gj(float4 *__restrict__ pos, 
   const float4 f4 = force[i];
   if (STEP == 1) {
     float4 p = pos[i];
-    gj_step1(p, v, f4, invMass, dt, friction, noiseAmplitude, is2D, (uint)id, stepNum, seed);
+    gj_step1(p, v, f4, invMass, dt, friction, noiseAmplitude, is2D, noiseKey ? (uint)noiseKey[id] : (uint)id, stepNum, seed);
     pos[i] = p;
     force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   } else
@@ -238,6 +240,22 @@ int uammd_verletnvt_gj(int step, float *d_pos, float *d_vel, float *d_force, con
   else
     hipLaunchKernelGGL(k_verletnvt_gj<2>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
                        d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_verletnvt_gj_keyed(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                             const int *d_index, const int *d_noiseKey, int N, float dt, float friction, int is2D, float noiseAmplitude,
+                             unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_verletnvt_gj_keyed: no mass array and defaultMass <= 0"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (step == 1)
+    hipLaunchKernelGGL(k_verletnvt_gj<1>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed, d_noiseKey);
+  else
+    hipLaunchKernelGGL(k_verletnvt_gj<2>, dim3(nb(N)), dim3(kIB), 0, st, (float4 *)d_pos, d_vel, (float4 *)d_force,
+                       d_mass, defaultMass, d_index, N, dt, friction, is2D, noiseAmplitude, stepNum, seed, d_noiseKey);
   UH_CHECK(hipGetLastError());
   return 0;
 }

@@ -19,6 +19,7 @@
 #include "celllist.hpp"
 
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -197,7 +198,7 @@ __global__ void k_l_relay(volatile double *__restrict__ stat, int m, double seq,
   __shared__ int ok;
   if (threadIdx.x == 0) {
     long spins = 0;
-    while (stat[4] != seq && ++spins < 20000000L) __builtin_amdgcn_s_sleep(8);
+    while (stat[4] != seq && ++spins < 200000000L) __builtin_amdgcn_s_sleep(8);  // (~0.25 us per poll: gives up after ~a minute, as the host does)
     ok = stat[4] == seq;
     if (!ok) stat[3] = -1.0;
   }
@@ -335,6 +336,8 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
   if (int rc = complete(parts)) return rc;
   hipLaunchKernelGGL(k_l_first<T>, dim3(g), dim3(kLB), 0, st, d_v, n, (const T *)parts, np, V, scal);
   const int checkConvergenceSteps = std::min(L->check_convergence_steps, L->iterationHardLimit - 2);
+  hipStreamCaptureStatus captureStatus = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &captureStatus) == hipSuccess && captureStatus != hipStreamCaptureStatusNone;
   std::vector<T> hbuf(2 * cap + 2);
   std::vector<double> dd, ee, zz;
   std::vector<T> yy;
@@ -352,6 +355,10 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
     if (int rc = complete(parts + kLParts)) return rc;
     hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)w, n, (const T *)(parts + kLParts), np,
                        (const T *)(hdiag + i), (const T *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
+    if (i >= checkConvergenceSteps && capturing) {
+      set_last_error("[Lanczos] the solver cannot run inside a stream capture: its convergence checks need the host between launches");
+      return -24;
+    }
     if (i >= checkConvergenceSteps && !L->reduce && i + 1 <= kLDevM) {
       const int m = i + 1;
       if (!L->hostStat) {
@@ -368,10 +375,23 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef,
                          (const T *)scal, d_Bv, Bold, parts);
       hipLaunchKernelGGL(k_l_error<T>, dim3(1), dim3(kLB), 0, st, (const T *)parts, g, L->devStat, seq);
+      // The host waits for the GPU's sequence number: a short spin (the answer is usually microseconds away), then sleeping polls — no core
+      // burnt while a long product or other work queued on the stream runs first — bounded by WALL-CLOCK time (a minute), not by a number
+      // of reads.  A wait that does expire releases the queued relay kernel and drains the stream before the error goes out, so that
+      // nothing of this run is left polling or writing into the status block when the next run resets it.
       auto wait = [&](int slot) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
-        while (hs[slot] != seq)
-          if (++spins > 400000000L) { set_last_error("[Lanczos] the convergence check never reported"); return -23; }
+        while (hs[slot] != seq) {
+          if (++spins < 20000) continue;
+          std::this_thread::sleep_for(std::chrono::microseconds(spins < 200000 ? 5 : 50));
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+            hs[4] = seq;                          // let the relay go (it hands out whatever y holds; the run is abandoned)
+            (void)hipStreamSynchronize(st);
+            set_last_error("[Lanczos] the convergence check did not report within 60 s (slot %d)", slot);
+            return -23;
+          }
+        }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         return 0;
       };

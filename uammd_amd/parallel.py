@@ -22,17 +22,22 @@ import torch.distributed as dist
 
 
 class SlabDecomposition:
-    def __init__(self, L, rc, rank=None, world=None, group=None, skin=0.0):
-        """skin = delta > 0 turns on the cached exchange: ownership and the halo membership lists are refreshed only every
+    def __init__(self, L, rc, rank=None, world=None, group=None, skin=0.0, comm=None):
+        """comm: an uammd_amd.comm.AbiComm — every message then goes through uammd_comm_* (RCCL behind the C ABI, the stack of the C++
+        drivers), also at world 1 where the ring closes on the rank itself; without it the torch.distributed test double carries them.
+        skin = delta > 0 turns on the cached exchange: ownership and the halo membership lists are refreshed only every
         few steps (DistributedLJ.exchange_every), in between a rank re-sends the CURRENT positions of the listed particles —
         no size messages, no host synchronisation.  Valid while no particle moves more than delta between refreshes: the
         lists then hold everything within rc + 3 delta of a face (owners may sit up to delta outside their slab, so may the
         particle that needs them, and a listed particle may drift delta itself), and the local box is rc + 4 delta thick."""
         self.group = group
+        self.comm = comm
         self.skin = float(skin)
         self._halo_cache = None
-        self.rank = dist.get_rank(group) if rank is None else rank
-        self.world = dist.get_world_size(group) if world is None else world
+        self.rank = (comm.rank if comm is not None else dist.get_rank(group)) if rank is None else rank
+        self.world = (comm.world if comm is not None else dist.get_world_size(group)) if world is None else world
+        if comm is not None and (comm.rank != self.rank or comm.world != self.world):
+            raise ValueError("the communicator's rank / world differ from the decomposition's")
         self.L = [float(x) for x in L]
         self.rc = float(rc)
         self.width = self.L[2] / self.world
@@ -76,6 +81,10 @@ class SlabDecomposition:
 
     def _exchange_counts(self, mine):
         """`mine` = tensor [n_to_up, n_to_down] (any device).  -> the same two numbers and what the neighbours send, as host ints."""
+        if self.comm is not None:
+            a, b = mine.tolist()
+            c, d = self.comm.exchange_counts(a, b)
+            return a, b, c, d
         if self.world == 1:  # the only rank is its own neighbour on both sides (periodic images through the loop-back)
             a, b = mine.tolist()
             return a, b, a, b
@@ -119,6 +128,11 @@ class SlabDecomposition:
         receive sizes come from _counts."""
         ncol = send_up.shape[1]
         dev = send_up.device
+        if self.comm is not None:
+            from_down = torch.empty((n_from_down, ncol), dtype=torch.float32, device=dev)
+            from_up = torch.empty((n_from_up, ncol), dtype=torch.float32, device=dev)
+            self.comm.halo_exchange(send_up.contiguous(), send_down.contiguous(), from_down, from_up)
+            return from_down, from_up
         if self.world == 1:
             return send_up, send_down
         send_up, send_down = self._wire(send_up), self._wire(send_down)
@@ -190,7 +204,7 @@ class SlabDecomposition:
         pos = allpos[:n_owned]
         tail_down = allpos[n_owned:n_owned + n_from_down]
         tail_up = allpos[n_owned + n_from_down:n_owned + n_from_down + n_from_up]
-        loop = self.world == 1          # the only rank is its own neighbour: what goes up arrives from below
+        loop = self.world == 1 and self.comm is None   # the only rank is its own neighbour: what goes up arrives from below
         if allpos.is_cuda:
             from . import _lib
             lib = _lib.load()
@@ -209,6 +223,9 @@ class SlabDecomposition:
             if loop:
                 return
             send_up, send_down = out_up, out_down
+            if self.comm is not None:   # straight into the ghost tail, on the stream: nothing is staged, nothing waits
+                self.comm.halo_exchange(send_up, send_down, tail_down, tail_up)
+                return
         else:
             send_up = pos.index_select(0, idx_up)
             send_down = pos.index_select(0, idx_down)
@@ -347,6 +364,7 @@ class DistributedLJ:
     def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25):
         self.d, self.forces_fn, self.integrate_fn, self.forces_into = decomp, forces_fn, integrate_fn, forces_into
         self.steps = 0
+        self.current_ids = None   # the owned rows' global ids, set before every integrate_fn call
         self.exchange_every = int(exchange_every) if decomp.skin > 0 else 1
         self.capacity_factor = capacity_factor
         self.max_drift = None   # device scalar: largest displacement of an owned particle between two refreshes (skin check)
@@ -385,6 +403,7 @@ class DistributedLJ:
             pos = self._allpos[:pos.shape[0]]
             if self.d.skin > 0:
                 self._ref = pos.clone()
+        self.current_ids = ids     # (for callbacks that key the thermostat's stream on the global id: uammd_verletnvt_gj_keyed)
         self.integrate_fn(1, pos, vel, force, self.steps)
         refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None or self._allpos is None
         if refresh:
@@ -395,6 +414,7 @@ class DistributedLJ:
             pos = self._allpos[:pos.shape[0]]     # from here on the owned particles live at the head of the exchange buffer
             if self.d.skin > 0:
                 self._ref = pos.clone()
+        self.current_ids = ids
         self.integrate_fn(2, pos, vel, force, self.steps)
         return pos, vel, force, ids
 
@@ -467,7 +487,7 @@ class DistributedLJ:
             send_up, send_down = rows[:n_up], rows[n_up:n_leave]
             _lib.check(lib.uammd_slab_pack_rows(p(bp), p(bv), p(bi), p(idx[0]), n_up, p(idx[1]), n_down, -d.width, d.width,
                                                 p(send_up) if n_up else None, p(send_down) if n_down else None, st))
-            if d.world == 1:
+            if d.world == 1 and d.comm is None:
                 arrivals = rows            # what goes up arrives from below: [from_down | from_up] = [send_up | send_down]
             else:
                 from_down, from_up = d._exchange(send_up, send_down, n_from_down, n_from_up)
@@ -507,6 +527,7 @@ class DistributedLJ:
             n = self._refresh_persistent(n)
             self._forces_persistent(n)
         bp, bv, bi, bf = self._bufs
+        self.current_ids = bi[:n]
         self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
         refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
         if refresh:
@@ -514,6 +535,7 @@ class DistributedLJ:
         else:
             self.d.halo_refill(bp, n)
         self._forces_persistent(n)
+        self.current_ids = bi[:n]
         self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
         return bp[:n], bv[:n], bf[:n], bi[:n]
 

@@ -203,8 +203,10 @@ class HipSlabBackend:
 class _Exchange:
     """The three communication patterns, for either ONE local rank under torch.distributed or ALL ranks in-process."""
 
-    def __init__(self, world, local_ranks, group=None):
-        self.world, self.local, self.group = world, list(local_ranks), group
+    def __init__(self, world, local_ranks, group=None, comm=None):
+        """comm: an uammd_amd.comm.AbiComm (uammd_comm_*: RCCL behind the C ABI) for the one-rank-per-process form — also at world 1,
+        where every message then makes the round trip through RCCL; without it torch.distributed (the test double) carries them."""
+        self.world, self.local, self.group, self.comm = world, list(local_ranks), group, comm
         self.in_process = len(self.local) == world
         if not self.in_process and len(self.local) != 1:
             raise ValueError("hold either one rank (torch.distributed) or all of them (in-process)")
@@ -214,6 +216,14 @@ class _Exchange:
         caller wants the messages (contiguous tensors of the messages' shape): under torch.distributed they are received there and
         returned, so the caller has nothing to copy; the in-process and single-rank forms return the senders' tensors as before."""
         P = self.world
+        if self.comm is not None and len(self.local) == 1:   # one rank per process through uammd_comm_* (also the world of one)
+            su, sd = to_up[0].contiguous(), to_down[0].contiguous()
+            ok = lambda into, like: into is not None and into[0].is_contiguous() and into[0].shape == like.shape and into[0].dtype == like.dtype
+            from_down = into_down[0] if ok(into_down, su) else torch.empty_like(su)
+            from_up = into_up[0] if ok(into_up, sd) else torch.empty_like(sd)
+            flat = lambda t: t.view(torch.float32).reshape(1, -1) if t.numel() else t.view(torch.float32).reshape(0, 1)
+            self.comm.halo_exchange(flat(su), flat(sd), flat(from_down), flat(from_up))
+            return [from_down], [from_up]
         if self.in_process:
             return [to_up[(r - 1) % P] for r in range(P)], [to_down[(r + 1) % P] for r in range(P)]
         r = self.local[0]
@@ -251,6 +261,11 @@ class _Exchange:
     def all_to_all(self, blocks):
         """blocks[i]: tensor [P, ...], slice d goes to rank d.  Returns tensors [P, ...] with slice s received from rank s."""
         P = self.world
+        if self.comm is not None and len(self.local) == 1:
+            src = blocks[0].contiguous()
+            out = torch.empty_like(src)
+            self.comm.alltoall(src, out)
+            return [out]
         if P == 1:
             return [blocks[0]]          # the only rank keeps its block: nothing moves, nothing is copied
         if self.in_process:
@@ -275,9 +290,9 @@ class _Exchange:
 class DistributedFCM:
     """FCM_impl over z-slabs.  `backends`: one per local rank (see _Exchange)."""
 
-    def __init__(self, geom, backends, local_ranks, seed2=0, group=None):
+    def __init__(self, geom, backends, local_ranks, seed2=0, group=None, comm=None):
         self.g, self.b = geom, list(backends)
-        self.x = _Exchange(geom.world, local_ranks, group)
+        self.x = _Exchange(geom.world, local_ranks, group, comm)
         self.seed2 = int(seed2)  # the reference's `static uint seed2` (FCM_impl.cuh:517)
         self._z = [None] * len(self.b)
 
@@ -390,7 +405,7 @@ class DistributedFCMIntegrator:
                                f"{allowed:.3f} the spare halo planes allow: lower migrate_every")
 
 
-def make_decomposition(geom, rank, group=None):
+def make_decomposition(geom, rank, group=None, comm=None):
     """Particle ownership that matches the grid slabs: z in [-Lz/2 + r Lz/P, ...), cut-off = the stencil reach."""
     hz = geom.L[2] / geom.cells[2]
-    return SlabDecomposition(geom.L, geom.he * hz, rank, geom.world, group)
+    return SlabDecomposition(geom.L, geom.he * hz, rank, geom.world, group, comm=comm)
