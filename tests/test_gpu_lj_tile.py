@@ -251,3 +251,60 @@ def test_prefilter_margin_adversarial_pairs_at_the_cutoff(hip, o32, ratio, TILE)
     # particles are closer than 0.97, so every force is O(10)).
     assert fmax < 100.0 and err <= 2e-4
     _check_force(got, ref, f"tile margin sweep L/rc={ratio}", reordered=True)
+
+
+@pytest.mark.parametrize("sigma,eps", [(1.0, 1.0), (0.9, 1.3), (1.0, 0.7)], ids=["reduced-units", "sigma0.9-eps1.3", "eps0.7"])
+def test_tile_unit_and_general_parameter_instantiations(hip, o32, sigma, eps):
+    """AUTO launches the brick kernel in two single-type instantiations: the general one (products by sigma^2 and epsilon / sigma^2 per
+    pair) and, for sigma = epsilon = 1, one without them (the same bits: x * 1.0f == x).  Liquid density on the kernel's main path
+    (no dense-brick fallback: checked with the stats hook), forces alone (the fused step's launch) and with energy + virial."""
+    n, L, rc = 30000, 33.5, 2.5
+    pos, box, _ = _setup(hip, o32, n, L, rc, seed=5)
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, sigma, eps, False))
+    (rf, re, rv), cd = _oracle(o32, pos, box, pot, rc, (True, True, True))
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cdd, ubox = hip.CellList.create_update_grid(box, rc)
+    cl.update_grid(d_pos, ubox, cdd)
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.tile_stats(True)
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    st = cl.tile_stats(False)
+    assert st["bricks"] > 0 and st["fallback_bricks"] == 0
+    _check_force(f.cpu().numpy(), rf, f"tile forces only, sigma {sigma} eps {eps}", reordered=True)
+    gf, ge, gv = _run(hip, pos, box, pot, rc, 0, (True, True, True))
+    _check_force(gf, rf, f"tile F + E + V, sigma {sigma} eps {eps}", reordered=True)
+    assert np.abs(ge - re).max() <= 1e-5 * np.abs(re).max() and np.abs(gv - rv).max() <= 1e-5 * np.abs(rv).max()
+
+
+def test_tile_parameter_table_rewritten_in_place_is_caught(hip, o32):
+    """The host picks the reduced-units instantiation from its cached copy of the device table (read back once per pointer).  A program
+    that rewrites the SAME device buffer with other units must not get forces in the wrong units: the kernel checks the table it is
+    given, raises the list's error flag instead of computing, and the next call reads the table again."""
+    from uammd_amd._lib import UammdHipError
+    n, L, rc = 20000, 30.0, 2.5
+    pos, box, pot = _setup(hip, o32, n, L, rc)          # sigma = epsilon = 1
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cdd, ubox = hip.CellList.create_update_grid(box, rc)
+    cl.update_grid(d_pos, ubox, cdd)
+    tbl = pot.device_table()
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # caches: unit table at this pointer
+    torch.cuda.synchronize()
+    other = hip.Potential.LJ()
+    other.setPotParameters(0, 0, other.InputPairParameters(rc, 0.8, 2.0, False))
+    tbl.copy_(other.device_table())                               # same pointer, other units
+    f.zero_()
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # launched as "unit": the kernel refuses
+    torch.cuda.synchronize()
+    assert float(f.abs().max()) == 0.0
+    with pytest.raises(UammdHipError, match="rewritten in place"):
+        cl.check_errors()                                         # (the next update / get of the list reports it as well)
+    (ref, _, _), _ = _oracle(o32, pos, box, other, rc)
+    f.zero_()
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # table read again: the general instantiation, right forces
+    torch.cuda.synchronize()
+    _check_force(f.cpu().numpy(), ref, "after the table was re-read", reordered=True)

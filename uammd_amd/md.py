@@ -275,6 +275,11 @@ class CellList:
     def set_option(self, name, value):
         check(self.lib.uammd_celllist_set_option(self.h, name.encode(), int(value)))
 
+    def check_errors(self):
+        """uammd_celllist_check_errors: synchronises the stream and raises what the list's kernels flagged (NaN positions, particles
+        outside a non-periodic box, a parameter table rewritten behind the list's cached copy) instead of waiting for the next update."""
+        check(self.lib.uammd_celllist_check_errors(self.h, current_stream()))
+
     @staticmethod
     def create_update_grid(box, cutoff):
         lib = _lib.load()
