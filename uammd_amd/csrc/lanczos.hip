@@ -150,6 +150,11 @@ __global__ void __launch_bounds__(kLB) k_l_c(const T *__restrict__ w, int n, con
   for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB)
     vnext[i] = hs > T(0) ? w[i] * inv : ((i == 0 && ownsFirstElement) ? T(1) : T(0));
 }
+// (Round 4, measured and removed: the three recurrence kernels as ONE launch — every thread keeping its elements of w in registers across
+// the two reductions, a generation-tagged counter in global memory as the barrier over the <= 256 resident blocks, partials as relaxed
+// agent-scope atomics.  Same bits as the three kernels; PSE near noise 0.547 against 0.514 ms with them (7 iterations): two trips of
+// every block to the device-coherent level per barrier — the arrival, the poll, then 256 uncached partial loads — cost more than the
+// two kernel boundaries they replace (~5 us per kernel all in on this GPU); with __threadfence() in the barrier, 1.04 ms.)
 // Bz = |z| * V[:, :m] * y ; partials of |Bold|^2 and |Bz - Bold|^2 ; then Bold <- Bz
 template <class T>
 __global__ void __launch_bounds__(kLB) k_l_estimate(const T *__restrict__ V, int n, int m,
@@ -375,17 +380,19 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef,
                          (const T *)scal, d_Bv, Bold, parts);
       hipLaunchKernelGGL(k_l_error<T>, dim3(1), dim3(kLB), 0, st, (const T *)parts, g, L->devStat, seq);
-      // The host waits for the GPU's sequence number: a short spin (the answer is usually microseconds away), then sleeping polls — no core
-      // burnt while a long product or other work queued on the stream runs first — bounded by WALL-CLOCK time (a minute), not by a number
-      // of reads.  A wait that does expire releases the queued relay kernel and drains the stream before the error goes out, so that
+      // The host waits for the GPU's sequence number: it spins for the first 5 ms (the answer is usually microseconds away, and one
+      // sleep costs more than a whole check), then polls between 100 us sleeps — no core burnt while a long product or other work
+      // queued on the stream runs first — bounded by WALL-CLOCK time (a minute), not by a number of reads.  A wait that does expire releases the queued relay kernel and drains the stream before the error goes out, so that
       // nothing of this run is left polling or writing into the status block when the next run resets it.
       auto wait = [&](int slot) -> int {
         const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
         while (hs[slot] != seq) {
-          if (++spins < 20000) continue;
-          std::this_thread::sleep_for(std::chrono::microseconds(spins < 200000 ? 5 : 50));
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+          if ((++spins & 1023) != 0) continue;                       // (the clock is read once per 1024 polls)
+          const auto waited = std::chrono::steady_clock::now() - t0;
+          if (waited < std::chrono::milliseconds(5)) continue;       // the common case: spin (a sleep is >= 50 us of timer slack per check)
+          std::this_thread::sleep_for(std::chrono::microseconds(100));
+          if (waited > std::chrono::seconds(60)) {
             hs[4] = seq;                          // let the relay go (it hands out whatever y holds; the run is abandoned)
             (void)hipStreamSynchronize(st);
             set_last_error("[Lanczos] the convergence check did not report within 60 s (slot %d)", slot);

@@ -705,6 +705,7 @@ int uammd_verletnvt_gj_lj_step(uammd_celllist *hh, float *d_pos, float *d_vel, f
   Outputs out{reinterpret_cast<float4 *>(d_force), nullptr, nullptr, nullptr};
   if (tile) {
     out.vel = d_vel; out.mass = d_mass; out.defaultMass = defaultMass; out.dt = dt; out.is2D = is2D;
+    out.invDefaultMass = defaultMass > 0 ? 1.0f / defaultMass : 0.f;
   }
   if (!tile && gj.keepForce && h->gjInHash) UH_CHECK(hipMemsetAsync(d_force, 0, sizeof(float4) * (size_t)N, st));
   h->lastFusedTile = tile;

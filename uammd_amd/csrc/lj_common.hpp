@@ -138,6 +138,7 @@ struct Outputs {
   float *vel = nullptr;
   const float *mass = nullptr;
   float defaultMass = 0.f, dt = 0.f;
+  float invDefaultMass = 0.f;  // 1 / defaultMass by the host's IEEE division (the same bits as the device's): not once per owner in the kernel
   int is2D = 0;
 };
 

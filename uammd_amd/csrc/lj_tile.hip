@@ -391,7 +391,7 @@ UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint own
   if ((lane >> 5) == 0 && valid) {
     const int gi = giPre >= 0 ? giPre : cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
     if (out.vel) {  // the fused step: half kick with the force that is still in registers (every particle is owned, no group)
-      const float invMass = 1.0f / (out.defaultMass > 0 ? out.defaultMass : out.mass[gi]);
+      const float invMass = out.defaultMass > 0 ? out.invDefaultMass : 1.0f / out.mass[gi];
       float3 v = make_float3(out.vel[3 * (size_t)gi], out.vel[3 * (size_t)gi + 1], out.vel[3 * (size_t)gi + 2]);
       const float fx = 0.0f + acc.fx, fy = 0.0f + acc.fy, fz = 0.0f + acc.fz;  // what `force += f` leaves in a zeroed array
       gj_step2(v, fx, fy, fz, invMass, out.dt, out.is2D);
