@@ -4,6 +4,7 @@
 // VerletNVT::GronbechJensen like any other Interactor.
 #include <Interactor/PairForces.cuh>   // under hipcc this brings device/PairForces.hip.hpp
 #include <Integrator/VerletNVT.cuh>
+#include <Interactor/ExternalForces.cuh>
 #include <utils/InitialConditions.cuh>
 #include <cstdio>
 #include <random>
@@ -38,6 +39,35 @@ struct Yukawa {
     if (r2 >= p.cutOff2) return 0;
     const real r = sqrtf(r2);
     return real(0.5) * p.strength * expf(-p.kappa * r) / r;
+  }
+};
+
+// the reference's examples/misc/LJ.cu:35-66 shape: a wall acting on one species, arrays chosen by the functor
+struct HarmonicWall : public ParameterUpdatable {
+  real zwall, k = 0.1;
+  real lastTime = -1;
+  explicit HarmonicWall(real zwall) : zwall(zwall) {}
+  __device__ ForceEnergyVirial sum(Interactor::Computables comp, real4 pos) {
+    const real fz = -k * (pos.z - zwall);
+    return {{0.0f, 0.0f, fz}, comp.energy ? real(0.5) * k * (pos.z - zwall) * (pos.z - zwall) : real(0), 0};
+  }
+  auto getArrays(ParticleData *pd) {
+    auto pos = pd->getPos(access::gpu, access::read);
+    return pos.begin();
+  }
+  void updateSimulationTime(real t) override { lastTime = t; }
+};
+struct DragOnIds {  // several arrays through a tuple
+  real gamma = 0.5;
+  __device__ ForceEnergyVirial sum(Interactor::Computables, real4, real3 vel, int id) {
+    const real g = (id % 2) ? gamma : real(0);
+    return {{-g * vel.x, -g * vel.y, -g * vel.z}, 0, 0};
+  }
+  auto getArrays(ParticleData *pd) {
+    auto pos = pd->getPos(access::gpu, access::read);
+    auto vel = pd->getVel(access::gpu, access::read);
+    auto id = pd->getId(access::gpu, access::read);
+    return std::make_tuple(pos.begin(), vel.begin(), id.begin());
   }
 };
 
@@ -143,6 +173,48 @@ int main() {
     }
     std::printf("two-type Yukawa, 20 NVT steps: finite %d, total force (%.2e %.2e %.2e) against max |f| %.2e\n", (int)finite, fsum[0], fsum[1], fsum[2], fabsmax);
     if (!finite || fabsmax <= 0 || std::fabs(fsum[0]) > 1e-3 * fabsmax * std::sqrt((double)N)) { ++fails; std::printf("FAIL Yukawa\n"); }  // Newton's third law
+  }
+  {  // ExternalForces<Functor> on a ParticleGroup selected by type, and with several arrays on everybody
+    const int N = 5000;
+    auto pd = std::make_shared<ParticleData>(N);
+    std::vector<real4> hpos(N);
+    std::vector<real3> hvel(N);
+    {
+      auto pos = pd->getPos(access::cpu, access::write);
+      auto vel = pd->getVel(access::cpu, access::write);
+      std::mt19937 gen(5);
+      std::uniform_real_distribution<real> u(-10, 10);
+      for (int i = 0; i < N; ++i) {
+        hpos[i] = pos[i] = make_real4(u(gen), u(gen), u(gen), real(i % 3 == 0 ? 1 : 0));
+        hvel[i] = vel[i] = make_real3(u(gen), u(gen), u(gen));
+      }
+      auto force = pd->getForce(access::cpu, access::write);
+      auto energy = pd->getEnergy(access::cpu, access::write);
+      std::fill(force.begin(), force.end(), real4());
+      std::fill(energy.begin(), energy.end(), real(0));
+    }
+    auto species1 = std::make_shared<ParticleGroup>(particle_selector::Type(1), pd, "species 1");
+    auto wall = std::make_shared<HarmonicWall>(real(2.5));
+    auto ext = std::make_shared<ExternalForces<HarmonicWall>>(species1, wall);
+    ext->updateSimulationTime(real(3.25));
+    ext->sum({.force = true, .energy = true, .virial = false});
+    auto drag = std::make_shared<ExternalForces<DragOnIds>>(pd);
+    drag->sum({.force = true, .energy = false, .virial = false});
+    auto force = pd->getForce(access::cpu, access::read);
+    auto energy = pd->getEnergy(access::cpu, access::read);
+    double worst = 0, worstE = 0;
+    for (int i = 0; i < N; ++i) {
+      const bool in = i % 3 == 0;
+      const real g = (i % 2) ? real(0.5) : real(0);
+      const real fz = (in ? real(-0.1) * (hpos[i].z - real(2.5)) : real(0)) - g * hvel[i].z;
+      worst = std::max(worst, (double)std::fabs(force[i].z - fz));
+      worst = std::max(worst, (double)std::fabs(force[i].x + g * hvel[i].x));
+      const real e = in ? real(0.5) * real(0.1) * (hpos[i].z - real(2.5)) * (hpos[i].z - real(2.5)) : real(0);
+      worstE = std::max(worstE, (double)std::fabs(energy[i] - e));
+    }
+    std::printf("ExternalForces: wall on the %d particles of type 1 + drag on odd ids: max |dF| %.2e, max |dE| %.2e, functor saw t = %.2f\n",
+                species1->getNumberParticles(), worst, worstE, wall->lastTime);
+    if (worst > 1e-5 || worstE > 1e-5 || wall->lastTime != real(3.25) || species1->getNumberParticles() != (N + 2) / 3) { ++fails; std::printf("FAIL ExternalForces\n"); }
   }
   std::printf(fails ? "FAILED\n" : "ok\n");
   return fails;

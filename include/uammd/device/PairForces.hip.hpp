@@ -29,21 +29,13 @@
 #define UAMMD_MI355X_PAIRFORCES_HIP_HPP
 
 #include "../uammd.h"
+#include "ForceEnergyVirial.hpp"
 #include "Transverser.hip.hpp"
 
 #include <algorithm>
 #include <vector>
 
 namespace uammd {
-
-// what a Transverser of a pair potential accumulates per particle (Interactor/Potential/PotentialBase.cuh)
-struct ForceEnergyVirial {
-  real3 force;
-  real energy, virial;
-};
-UAMMD_HD ForceEnergyVirial operator+(const ForceEnergyVirial &a, const ForceEnergyVirial &b) {
-  return {a.force + b.force, a.energy + b.energy, a.virial + b.virial};
-}
 
 namespace Potential {
 

@@ -78,3 +78,35 @@ def test_reference_benchmark_program_runs(tmp_path):
     assert m, "the program did not report its rate"
     assert float(m.group(1)) > 200.0     # ~90 on the GTX 980 of the reference's comment; > 2000 measured on MI355X
     assert (tmp_path / "data.main.benchmark").exists()   # it wrote its default parameter file through InputFile's reader
+
+
+@pytest.mark.gpu
+def test_reference_LJ_program_runs(tmp_path):
+    """examples/_build/ref_LJ = the REFERENCE's examples/misc/LJ.cu compiled from where it lies by hipcc against include/uammd
+    (PairForces<Potential::LJ> on the library's fused path + two ExternalForces<HarmonicWall> — a device functor of the program's own —
+    on ParticleGroups selected by type, VerletNVT::GronbechJensen, InputFile).  Run on its own parameter file format; the walls pull the
+    two species to z = -Lz/4 and +Lz/4."""
+    exe = os.path.join(EX, "_build", "ref_LJ")
+    if not os.path.exists(exe):
+        pytest.skip("ref_LJ was not built (no reference tree where `make -C examples` ran)")
+    # (a dilute mixture — the program's default density with sigma = 2 for one species is close packed and does not move in a short run)
+    n = 4096
+    (tmp_path / "data.main.lj").write_text(f"boxSize 60 60 60\nnumberParticles {n}\ndt 0.005\nnumberSteps 6000\nprintSteps 5999\n"
+                                           f"outputFile {tmp_path / 'out.dat'}\ntemperature 0.5\nfriction 1.0\n")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [l.split() for l in open(tmp_path / "out.dat") if l.strip() and not l.startswith("#")]
+    assert len(rows) >= n
+    import numpy as np
+    last = np.array(rows[-n:], dtype=float)
+    assert np.isfinite(last).all()
+    # columns: x y z radius type.  The harmonic walls (k = 0.1, ExternalForces on the ParticleGroups of type 0 and type 1) pull type 0
+    # towards z = -Lz/4 = -15 and type 1 towards + 15.  The program's cross interaction is 8 kT deep (epsilon 4 at T = 0.5), so the species
+    # stick to each other and only partly demix in 30 time units: the test asks for the right DIRECTIONS (the exact wall force on a
+    # group, and several arrays through a tuple, are checked to the bit in examples/custom_potential.hip)
+    z, kind = last[:, 2], last[:, 4]
+    z0, z1 = z[kind == 0].mean(), z[kind == 1].mean()
+    print("mean z of type 0:", z0, " of type 1:", z1)
+    assert (kind == 0).sum() > n // 4 and (kind == 1).sum() > n // 4
+    assert z0 < -1.0 and z1 > 1.0

@@ -21,7 +21,7 @@ GXX = ["basic_concepts/1-system.cu", "basic_concepts/2-hello_world.cu", "basic_c
        "basic_concepts/10-initial_configuration.cu", "basic_concepts/13-your-first-interactor.cu", "misc/benchmark.cu"]
 HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "basic_concepts/5-particle_data.cu",
          "basic_concepts/6-particle_data2.cu", "basic_concepts/7-moving_particles.cu", "basic_concepts/8-interacting_particles.cu",
-         "basic_concepts/11-measuring_things.cu", "basic_concepts/12-your-first-integrator.cu", "misc/LJMultipleTypes.cu", "misc/checkpoint.cu"]
+         "basic_concepts/11-measuring_things.cu", "basic_concepts/12-your-first-integrator.cu", "misc/LJ.cu", "misc/LJMultipleTypes.cu", "misc/checkpoint.cu"]
 
 
 def _source(rel, tmp_path, suffix):
