@@ -51,6 +51,19 @@ def _allreduce(dist, values, op):
     return t.tolist()
 
 
+_RESULT_FD = None
+
+
+def emit_result(obj):
+    """the run's one line of stdout (main() moved file descriptor 1 itself to stderr for the libraries' chatter)"""
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def _barrier(dist):
     if ABI_COMM is not None:
         ABI_COMM.barrier()
@@ -619,8 +632,10 @@ def main():
     ap.add_argument("--nl", default="cell", choices=["cell", "verlet"],
                     help="neighbour list of PairForces: CellList (BASELINE configs[2], default) or VerletList (the "
                          "reference's examples/misc/benchmark.cu default)")
-    ap.add_argument("--skin", type=float, default=0.6, help="slab decomposition: skin of the cached halo exchange (0 = exchange sizes every step)")
-    ap.add_argument("--exchange-every", type=int, default=20, help="slab decomposition: steps between ownership / halo-list refreshes "
+    # (skin 0.6 / refresh every 20 steps was marginal: the fastest of N x 1e6 thermal particles moves 0.55-0.62 sigma in 20 steps — the
+    # skin check tripped at 2e6 particles once the thermostat's stream was keyed by particle id; 0.5 / 10 leaves a factor 1.6)
+    ap.add_argument("--skin", type=float, default=0.5, help="slab decomposition: skin of the cached halo exchange (0 = exchange sizes every step)")
+    ap.add_argument("--exchange-every", type=int, default=10, help="slab decomposition: steps between ownership / halo-list refreshes "
                                                                       "(measured at world = 1: 10 / 0.4 -> 0.335 ms per step, 20 / 0.6 -> 0.315)")
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
     args = ap.parse_args()
@@ -647,6 +662,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
+    # From here on this process is a worker.  Its stdout is ONE JSON line (rank 0): whatever libraries print on file descriptor 1 — gloo's
+    # and librccl's greetings, rocFFT notes — is sent to stderr for the whole run, and the line goes out through the saved descriptor.
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -667,10 +688,12 @@ def main():
             sys.exit(2)
         backend = os.environ.get("UAMMD_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        from uammd_amd.comm import _stdout_to_stderr
+        with _stdout_to_stderr():   # (gloo and librccl greet on stdout; this program's stdout is one JSON line)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
         mine = f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}, pid {os.getpid()})"
         devs = [None] * world
         dist.all_gather_object(devs, mine)
@@ -730,7 +753,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_pse(args.cpu_pse_steps)
         out.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
-        print(json.dumps(out))
+        emit_result(out)
         return
     if args.workload == "fcm":
         out = (run_fcm_distributed if (world > 1 or args.force_distributed) else run_fcm)(hip, args, world, rank, dist)
@@ -742,7 +765,7 @@ def main():
                     "data": "synthetic"})
         if rank == 0:
             out["comm"] = comm_info
-            print(json.dumps(out))
+            emit_result(out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -770,7 +793,7 @@ def main():
             out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
         if rank == 0:
             out["comm"] = comm_info
-            print(json.dumps(out))
+            emit_result(out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -933,7 +956,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_lj(n, L, 1234, args.cpu_sample_steps)
     if rank == 0:
         out["comm"] = comm_info
-        print(json.dumps(out))
+        emit_result(out)
     if dist is not None:
         dist.destroy_process_group()
 
