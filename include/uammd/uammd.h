@@ -1269,6 +1269,13 @@ public:
     detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
                                           (float *)d_linearVelocity, (void *)st));
   }
+  // computeHydrodynamicDisplacements followed by integrateEulerMaruyamaD (BDHI_FCM.cu:67-92) in one library call: pos += v dt in place
+  // positionsKept: pos is exactly what the previous call left (UAMMD_FCM_STEP_POSITIONS_KEPT: that call's binning is used)
+  void stepEulerMaruyama(real4 *pos, const real4 *force, real3 *d_linearVelocity, int N, real temperature, real prefactor, real dt,
+                         bool positionsKept, hipStream_t st) {
+    detail::check(uammd_fcm_step_euler_maruyama(h, (float *)pos, (const float *)force, N, temperature, prefactor, dt,
+                                                (float *)d_linearVelocity, positionsKept ? UAMMD_FCM_STEP_POSITIONS_KEPT : 0, (void *)st));
+  }
   // The reference's own signature (FCM_impl.cuh:126-129): owning containers returned by value, the second one empty without torques
   std::pair<cached_vector<real3>, cached_vector<real3>> computeHydrodynamicDisplacements(real4 *pos, real4 *force, real4 *torque,
                                                                                          int numberParticles, real temperature,
@@ -1335,12 +1342,15 @@ template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : publi
   real temperature, dt;
   uint steps = 0;
   hipStream_t st = 0;
+  bool posTouched = true;
 public:
   using Parameters = BDHI::Parameters;
   FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par)
       : Integrator(pd, "BDHI::FCMIntegrator"), linearV(pd->getNumParticles()), angularV(pd->getNumParticles()),
         temperature(par.temperature), dt(par.dt) {
     fcm = make_shared<FCM_impl<Kernel>>(detail_fcm::initialize<Kernel>(par, *sys));
+    pd->connectPosWriteRequested([this]() { posTouched = true; });
+    pd->connectReorder([this]() { posTouched = true; });
   }
   shared_ptr<FCM_impl<Kernel>> getFCM_impl() { return fcm; }
   void forwardTime() override {
@@ -1357,6 +1367,14 @@ public:
     }
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
     const int N = pd->getNumParticles();
+    if (!pd->isDirAllocated() && !pd->isTorqueAllocated()) {  // no rotation: the update rides in the solver's interpolation kernel
+      const bool kept = !posTouched;  // (getPosWriteRequestedSignal: somebody may have moved the particles since our last step)
+      auto pos = pd->getPos(access::gpu, access::readwrite);
+      auto force = pd->getForce(access::gpu, access::read);
+      fcm->stepEulerMaruyama(pos.raw(), force.raw(), linearV.d, N, temperature, 1.0 / std::sqrt(dt), dt, kept, st);
+      posTouched = false;
+      return;
+    }
     {
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);

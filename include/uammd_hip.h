@@ -325,6 +325,17 @@ int uammd_fcm_destroy(uammd_fcm *h);
  * (noise only).  Every call with temperature > 0 advances the noise stream (the reference's static seed2). */
 int uammd_fcm_displacements(uammd_fcm *h, const float *d_pos, const float *d_force, int numberParticles,
                             float temperature, float prefactor, float *d_linearVelocity, void *stream);
+/* BDHI::FCMIntegrator::forwardTime without torques (Integrator/BDHI/BDHI_FCM.cu:94-119 -> computeHydrodynamicDisplacements, then
+ * integrateEulerMaruyamaD :67-92): the same velocities as uammd_fcm_displacements, then pos[i].xyz += v_i dt IN PLACE (the fma of
+ * uammd_fcm_euler_maruyama: identical positions) by a kernel that also bins the positions it writes, so that the next call can
+ * start at the tile scan.  d_linearVelocity real3[N] receives v; it may be NULL (a buffer of the handle is used).
+ * flags: UAMMD_FCM_STEP_POSITIONS_KEPT = d_pos holds exactly what the previous uammd_fcm_step_euler_maruyama call on this handle left
+ * there (same array, size and stream; nobody asked for write access in between: ParticleData::getPosWriteRequestedSignal is how the
+ * host layers know) -> that call's binning is used instead of a binning pass.  Without the flag nothing is assumed.
+ * option "bin_ahead" = 0 switches the binning ahead off. */
+#define UAMMD_FCM_STEP_POSITIONS_KEPT 1
+int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_force, int numberParticles, float temperature,
+                                  float prefactor, float dt, float *d_linearVelocity, int flags, void *stream);
 /* Hasimoto-corrected self mobility, FCM_impl::getSelfMobility (FCM_impl.cuh:102-119), host */
 double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, double Lx);
 /* noise call counter (the reference's process-global `static uint seed2`, FCM_impl.cuh:517; per handle here) */

@@ -491,3 +491,93 @@ def test_fcm_spread_two_waves_per_tile(hip, o32):
         assert scale > 0
         assert np.abs(out["w2"] - out["atomic"]).max() <= 2e-5 * scale
         assert np.abs(out["w2"] - out["w4"]).max() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("cells,n", [((64, 64, 64), 20001), ((36, 30, 28), 700), ((128, 128, 128), 100000)])
+def test_fcm_step_euler_maruyama(hip, o32, cells, n):
+    """uammd_fcm_step_euler_maruyama = computeHydrodynamicDisplacements + integrateEulerMaruyamaD (BDHI_FCM.cu:67-119): the new positions
+    are EXACTLY fma(v, dt, pos) of the velocities the same call returns (the oracle's statement of the update), w is kept, and v agrees
+    with a plain displacements call (same seeds, same noise call number) at rounding level — on the tile path and on the rocFFT /
+    generic path of the 36 x 30 x 28 grid, with and without an output array."""
+    L = np.asarray(cells, np.float32)
+    rng = np.random.default_rng(n)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.7, 0.7, (n, 3)) * L
+    pos[:, 3] = rng.integers(0, 3, n)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    T, dt = 0.6, 0.01
+    df = torch.from_numpy(force).cuda()
+    ref = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    vref = ref.computeHydrodynamicDisplacements(torch.from_numpy(pos).cuda(), df, n, T, 1 / math.sqrt(dt)).cpu().numpy()
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    dp = torch.from_numpy(pos).cuda()
+    v = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    fcm.stepEulerMaruyama(dp, df, n, T, 1 / math.sqrt(dt), dt, out=v)
+    torch.cuda.synchronize()
+    got, vv = dp.cpu().numpy(), v.cpu().numpy()
+    want = pos.copy()
+    o32.fcm_euler_maruyama(want, vv, dt)   # fmaf(v, dt, pos), the oracle's statement of BDHI_FCM.cu:67-92
+    assert np.array_equal(got, want)
+    assert np.abs(vv - vref).max() <= 2e-6 * np.abs(vref).max()
+    # without an output array the positions still move
+    fcm2 = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+    dp2 = torch.from_numpy(pos).cuda()
+    fcm2.stepEulerMaruyama(dp2, df, n, T, 1 / math.sqrt(dt), dt)
+    torch.cuda.synchronize()
+    # (another solve: the spread's summation order is an atomic's, v differs at rounding level; a position of ~L/2 has ulp(L/2))
+    assert np.abs(dp2.cpu().numpy()[:, :3] - want[:, :3]).max() <= 4e-6 * np.abs(vref).max() * dt + 2 * np.spacing(np.float32(L.max()))
+
+
+@pytest.mark.parametrize("cells,n", [((64, 64, 64), 20001), ((128, 128, 128), 100000)])
+def test_fcm_step_bins_ahead(hip, o32, cells, n):
+    """The update kernel also bins the positions it writes (k_fcm_update_bin), and a following step that is told the array is untouched
+    (UAMMD_FCM_STEP_POSITIONS_KEPT) starts at the tile scan.  Ten steps three ways — binning ahead used, binning ahead ignored (no flag: the
+    pending counters are dropped), binning ahead off — give the same trajectory at rounding level; a step after the particles were moved by hand
+    (no flag) and a plain displacements call between two steps are handled; with T = 0 and one particle per tile (no summation order to
+    differ) the three trajectories are bit-identical."""
+    L = np.asarray(cells, np.float32)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    dt = 0.01
+
+    def run(pos0, force, T, mode, steps=10):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        if mode == "unfused":
+            fcm.set_option("bin_ahead", 0)
+        nn = pos0.shape[0]
+        dp, df = torch.from_numpy(pos0.copy()).cuda(), torch.from_numpy(force).cuda()
+        for s in range(steps):
+            if s == 4:   # somebody moves the particles: this step must not use the previous step's binning
+                dp[:, :3] += 0.37
+                kept = False
+            else:
+                kept = mode == "ahead" and s > 0
+            if s == 7:   # a plain solve in between (it must drop the pending counters, and the next step may not claim them)
+                fcm.computeHydrodynamicDisplacements(dp, df, nn, 0.0, 0.0)
+                kept = False
+            fcm.stepEulerMaruyama(dp, df, nn, T, 1 / math.sqrt(dt), dt, positions_kept=kept)
+        torch.cuda.synchronize()
+        return dp.cpu().numpy()
+
+    rng = np.random.default_rng(n)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.7, 0.7, (n, 3)) * L
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    out = {m: run(pos, force, 0.6, m) for m in ("ahead", "noflag", "unfused")}
+    assert np.isfinite(out["ahead"]).all()
+    moved = np.abs(out["ahead"][:, :3] - pos[:, :3] - 0.37).max()
+    assert moved > 0.05
+    for m in ("noflag", "unfused"):
+        assert np.abs(out[m][:, :3] - out["ahead"][:, :3]).max() <= 1e-5 * moved + 4 * np.spacing(np.float32(L.max()))
+    # one particle per tile, T = 0 (the noise stream advances per solve; the plain solve at step 7 is noise free either way): same bits
+    nt = [c // 8 for c in cells]
+    gx, gy, gz = np.meshgrid(np.arange(nt[0]), np.arange(nt[1]), np.arange(nt[2]), indexing="ij")
+    centres = (np.stack([gx, gy, gz], -1).reshape(-1, 3) * 8 + 4.0).astype(np.float32) - L / 2
+    p1 = np.zeros((centres.shape[0], 4), np.float32)
+    p1[:, :3] = centres + rng.uniform(-1.0, 1.0, centres.shape).astype(np.float32)
+    f1 = np.zeros_like(p1)
+    f1[:, :3] = 0.2 * rng.normal(0, 1, centres.shape)
+    ex = {m: run(p1, f1, 0.0, m, steps=9) for m in ("ahead", "noflag", "unfused")}
+    assert np.array_equal(ex["ahead"], ex["noflag"]) and np.array_equal(ex["ahead"], ex["unfused"])

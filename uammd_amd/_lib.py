@@ -200,6 +200,7 @@ SIGNATURES = {
     "uammd_fcm_destroy": (_i, [_vp]),
     "uammd_fcm_displacements": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "uammd_fcm_displacements_staged": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _i, _vp]),
+    "uammd_fcm_step_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _i, _vp]),
     "uammd_fcm_export_fourier": (_i, [_vp, _vp, _vp]),
     "uammd_fcm_self_mobility": (C.c_double, [C.c_double, C.c_double, C.c_double]),
     "uammd_fcm_get_seed2": (_i, [_vp, C.POINTER(_u)]),

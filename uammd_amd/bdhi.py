@@ -235,6 +235,16 @@ class FCM_impl:
                                                float(prefactor), _ptr(out), current_stream()))
         return out
 
+    def stepEulerMaruyama(self, pos, force, numberParticles, temperature, prefactor, dt, out=None, positions_kept=False):
+        """computeHydrodynamicDisplacements followed by integrateEulerMaruyamaD (BDHI_FCM.cu:67-92) in one library call
+        (uammd_fcm_step_euler_maruyama): pos += v dt in place, inside the interpolation kernel where the solver's gather takes it.
+        `out` (real3[N], optional) receives the velocities.  positions_kept: `pos` is exactly what the previous call left (nobody
+        asked for write access since): the binning that call did on the way is used (UAMMD_FCM_STEP_POSITIONS_KEPT)."""
+        check(self.lib.uammd_fcm_step_euler_maruyama(self.h, _ptr(pos), _ptr(force), int(numberParticles), float(temperature),
+                                                     float(prefactor), float(dt), _ptr(out) if out is not None else None,
+                                                     1 if positions_kept else 0, current_stream()))
+        return out
+
     def setTorqueKernel(self, kernelTorque=None, tolerance=1e-3):
         """FCM_impl::Parameters::kernelTorque; default = detail::initializeKernelTorque (BDHI_FCM.cuh:69-80)."""
         if kernelTorque is None:
@@ -337,6 +347,12 @@ class FCMIntegrator(Integrator):
         self.fcm = FCM_impl(box, cd, kernel, par.viscosity, par.seed, a_eff)
         self.fcm.setTorqueKernel(getattr(par, "kernelTorque", None), par.tolerance)  # detail::initializeKernelTorque
         self._v = torch.empty((pd.N, 3), dtype=torch.float32, device=pd.device)
+        self._pos_touched = True
+        pd.connectPosWrite(self._on_pos_write)
+        pd.connectReorder(self._on_pos_write)
+
+    def _on_pos_write(self):
+        self._pos_touched = True
 
     def getFCM_impl(self):
         return self.fcm
@@ -359,6 +375,13 @@ class FCMIntegrator(Integrator):
         torque = pd.getTorqueIfAllocated("read")
         dirs = pd.getDirIfAllocated("readwrite")
         w = None
+        if torque is None and dirs is None:   # no rotation: the update rides in the solver's interpolation kernel
+            kept = not self._pos_touched      # (getPosWriteRequestedSignal: somebody may have moved the particles since our last step)
+            pos = pd.getPos("readwrite")
+            self.fcm.stepEulerMaruyama(pos, pd.getForce("read"), pd.N, self.temperature, 1.0 / math.sqrt(self.dt), self.dt,
+                                       out=self._v, positions_kept=kept)
+            self._pos_touched = False
+            return
         if torque is not None:
             v, w = self.fcm.computeHydrodynamicDisplacementsTorque(pd.getPos("read"), pd.getForce("read"), torque, pd.N,
                                                                    self.temperature, 1.0 / math.sqrt(self.dt))

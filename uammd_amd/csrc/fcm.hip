@@ -50,6 +50,12 @@ struct FCM {
   size_t planeReal = 0;    // floats per component plane
   size_t planeCplx = 0;    // complex per component plane
   DeviceBuffer gridBuf, gridBufT, interBuf, work, prepOrigin, prepWeights, prepTileOf, prepRank, prepTileCount, prepTileStart, prepSorted;
+  int emVelN = 0;
+  DeviceBuffer emVel;              // velocities of uammd_fcm_step_euler_maruyama when the caller keeps none
+  bool emBin = true;               // uammd_fcm_step_euler_maruyama: the update kernel also bins the positions it writes for the next call
+  bool binnedPending = false;      // tileCount / tileOf / rank hold the binning of binnedPos (written by k_fcm_update_bin)
+  const void *binnedPos = nullptr;
+  int binnedN = 0;
   bool useTiles = false;   // grid divisible by the tile and >= 3 tiles per dimension
   int3 ntiles{0, 0, 0};
   int3 tdim{8, 8, 8};      // tile edge per axis, 4..8 nodes: the largest divisor of the axis that holds the stencil's reach (fcm_tiles_usable)
@@ -175,6 +181,29 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
   const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
   pr.tileOf[id] = t;
   pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
+}
+
+// integrateEulerMaruyamaD (BDHI_FCM.cu:67-92), pos += v dt, and k_fcm_bin_count for the position just written, in one launch: the two
+// are a load -> store and a load -> atomic chain of the same length, each 5-9 us of latency as a kernel of its own
+// (uammd_fcm_step_euler_maruyama: 4.7 + 8.9 -> 9.4 us, C4 step 0.2035 -> 0.2010 ms).
+// (Measured and not kept: the update inside the interpolation kernel — one lane per wave loading, storing and taking its rank: 50 000
+// single-lane memory instructions instead of 1 600 full ones — took the gather from 32 to 34 us with the update alone and to 127 us with
+// the atomics.)
+__global__ void __launch_bounds__(256) k_fcm_update_bin(float4 *__restrict__ pos, const float *__restrict__ linearV, int N, float dt,
+                                                         GridT<float> grid, int3 ntiles, FcmPrep pr, bool bin) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  float4 p = pos[id];
+  p.x = fmaf(linearV[3 * id], dt, p.x);
+  p.y = fmaf(linearV[3 * id + 1], dt, p.y);
+  p.z = fmaf(linearV[3 * id + 2], dt, p.z);
+  pos[id] = p;
+  if (bin) {
+    const int3 celli = grid.getCell(real3f{p.x, p.y, p.z});
+    const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
+    pr.tileOf[id] = t;
+    pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
+  }
 }
 
 __global__ void __launch_bounds__(1024) k_fcm_tile_scan(int *__restrict__ count, int ntiles, int *__restrict__ start) {
@@ -1228,7 +1257,7 @@ static int fcm_make_plans(FCM *f) {
 }
 
 // bins the particles by tile and fills the tile-sorted stencil origins / weights / forces (reused by spread and gather)
-static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, int N, hipStream_t st, FcmPrep *out) {
+static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, int N, hipStream_t st, FcmPrep *out, bool positionsKept = false) {
   const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
   const int wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
   if (f->prepCapN < N) {
@@ -1250,14 +1279,20 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
     UH_CHECK(hipStreamSynchronize(f->prepStream));
     f->tileCountZero = false;
   }
+  // the previous uammd_fcm_step_euler_maruyama binned the positions it wrote (k_fcm_update_bin): its counts are in tileCount, the tiles
+  // and ranks in tileOf / rank.  Used when the caller vouches that the array is untouched and it is the same array; dropped otherwise.
+  const bool binned = f->binnedPending && positionsKept && f->binnedPos == (const void *)d_pos && f->binnedN == N && f->prepStream == st;
+  if (f->binnedPending && !binned) f->tileCountZero = false;
+  f->binnedPending = false;
   f->prepStream = st;
   f->prepStreamSet = true;
   if (!f->tileCountZero) {  // first use of the buffer; afterwards k_fcm_tile_scan hands the counters back zeroed
     UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)nt, st));
     f->tileCountZero = true;
   }
-  hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
-                     f->ntiles, pr);
+  if (!binned)
+    hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
+                       f->ntiles, pr);
   hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, pr.tileCount, nt, pr.tileStart);
 #define UH_PREPARE(K)                                                                                          \
   case K:                                                                                                      \
@@ -1438,8 +1473,8 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
 }
 
 // stage: 0 = full pipeline; 1 = stop after spread+FFT+k-space (the Fourier grid can then be exported)
-int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
-                                   float prefactor, float *d_linearVelocity, int stage, void *stream) {
+static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
+                                  float prefactor, float *d_linearVelocity, int stage, void *stream, bool positionsKept) {
   if (!h) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
   if (N <= 0) return 0;  // nothing to move (an empty ParticleData has no arrays to point to)
   if (!d_pos || (!d_linearVelocity && stage == 0)) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
@@ -1455,7 +1490,7 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   const bool custom = stage == 0 && fcm_custom_fft_usable(f);  // (stage 1 exports the Fourier grid, which the fused z pass never stores)
   FcmPrep pr{};
   if (tiles) {
-    if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr)) return e;
+    if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
   }
   if (d_force) {
     if (tiles) {
@@ -1524,9 +1559,49 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   return 0;
 }
 
+int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
+                                   float prefactor, float *d_linearVelocity, int stage, void *stream) {
+  return fcm_displacements_impl(h, d_pos, d_force, N, temperature, prefactor, d_linearVelocity, stage, stream, false);
+}
+
+// BDHI::FCMIntegrator::forwardTime without torques (BDHI_FCM.cu:67-119): v = M F + sqrt(2 T / dt) dW as uammd_fcm_displacements, then
+// integrateEulerMaruyamaD's pos += v dt — by a kernel that also bins the positions it writes, so that the next call (told that the array
+// is untouched) starts at the tile scan: one launch per step less.  d_linearVelocity may be NULL; positions move in place.
+int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_force, int N, float temperature, float prefactor,
+                                  float dt, float *d_linearVelocity, int flags, void *stream) {
+  if (!h || (N > 0 && !d_pos)) { set_last_error("uammd_fcm_step_euler_maruyama: null argument"); return -1; }
+  if (N <= 0) return 0;
+  FCM *f = reinterpret_cast<FCM *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  float *v = d_linearVelocity;
+  if (!v) {
+    if (f->emVelN < N) {
+      UH_CHECK(hipStreamSynchronize(st));
+      if (int e = f->emVel.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+      f->emVelN = N;
+    }
+    v = (float *)f->emVel.ptr;
+  }
+  if (int e = fcm_displacements_impl(h, d_pos, d_force, N, temperature, prefactor, v, 0, stream, (flags & UAMMD_FCM_STEP_POSITIONS_KEPT) != 0))
+    return e;
+  const bool tiles = f->useTiles && !f->forceAtomicSpread;
+  const bool bin = tiles && f->emBin && f->prepCapN >= N;  // (the tile scan of the solve above left the counters at zero)
+  FcmPrep pr{};
+  if (bin) {
+    pr.tileOf = (int *)f->prepTileOf.ptr; pr.rank = (int *)f->prepRank.ptr; pr.tileCount = (int *)f->prepTileCount.ptr;
+    pr.tdim = f->tdim;
+  }
+  hipLaunchKernelGGL(k_fcm_update_bin, dim3((N + 255) / 256), dim3(256), 0, st, (float4 *)d_pos, (const float *)v, N, dt, f->grid, f->ntiles,
+                     pr, bin);
+  UH_CHECK(hipGetLastError());
+  if (bin) { f->binnedPending = true; f->binnedPos = (const void *)d_pos; f->binnedN = N; }
+  return 0;
+}
+
 int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
+  if (std::string(name) == "bin_ahead") { reinterpret_cast<FCM *>(h)->emBin = value != 0; return 0; }
   if (std::string(name) == "spread_waves") { reinterpret_cast<FCM *>(h)->spreadWaves = value; return 0; }
   if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
