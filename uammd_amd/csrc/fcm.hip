@@ -1158,12 +1158,18 @@ static bool fcm_custom_fft_usable(const FCM *f) {
 // (nh + 1) ny / 4 <= 3 x 1024
 static size_t fcm_plane_fft_lds(int nx, int ny) { return sizeof(float2) * ((size_t)std::max(nx, ny) + (size_t)ny * (nx / 2 + 1)); }
 static bool fcm_plane_fft_usable(int nx, int ny) {
-  static int ldsLimit = -1;
-  if (ldsLimit < 0) {
-    int dev = 0, v = 0;
-    ldsLimit = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) ? v : 0;
-    if (getenv("UAMMD_FCM_NO_PLANE_FFT")) ldsLimit = 0;
+  // (per device: a process may run solvers on several GPUs)
+  static int ldsLimits[64];
+  static bool ldsKnown[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!ldsKnown[dev]) {
+    int v = 0;
+    ldsLimits[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess ? v : 0;
+    if (getenv("UAMMD_FCM_NO_PLANE_FFT")) ldsLimits[dev] = 0;
+    ldsKnown[dev] = true;
   }
+  const int ldsLimit = ldsLimits[dev];
   const int nh = nx / 2;
   return nx >= 32 && ny >= 16 && (size_t)ny * nh / 4 <= 2 * 1024 && (size_t)(nh + 1) * ny / 4 <= 3 * 1024 &&
          fcm_plane_fft_lds(nx, ny) <= (size_t)std::min(ldsLimit, 96 * 1024);
@@ -1174,10 +1180,12 @@ static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   const int lx = ilog2_exact(nx), ly = ilog2_exact(ny);
   if (fcm_plane_fft_usable(nx, ny)) {  // one pass: a whole plane per workgroup
     const size_t lds = fcm_plane_fft_lds(nx, ny);
-    static bool attrSet = false;
-    if (!attrSet) {
+    static bool attrSet[64] = {false};  // (a function attribute belongs to the device's copy of the kernel)
+    int dev = 0;
+    UH_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attrSet[dev]) {
       UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attrSet = true;
+      if (dev >= 0 && dev < 64) attrSet[dev] = true;
     }
     hipLaunchKernelGGL(k_fft_xy_r2c_plane, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, lx, ly);
     return 0;

@@ -36,6 +36,7 @@ struct PSENear {
   // written (uammd_pse_near_positions_changed, wired to ParticleData's write signal by the host layer) or when the array / N changes
   bool lazyList = false, listValid = false;
   const void *listPos = nullptr;
+  hipStream_t listStream = nullptr;
   DeviceBuffer sortedOut;   // Lanczos result in cell order
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
@@ -538,9 +539,8 @@ static TableView make_view(const PSENear *p) {
 
 // cl->update(box, rcut * safetyFactor) (NearField.cuh:231-237)
 static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st) {
-  if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N) return 0;
-  p->listValid = true;
-  p->listPos = d_pos;
+  if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N && p->listStream == st) return 0;
+  p->listValid = false;  // (valid again only when the build below went through: a failed build must not be reused)
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
   const float rc = p->rcut * safety;
@@ -550,7 +550,11 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   float gL[3];
   if (int e = uammd_celllist_create_grid(p->boxL, per, rc3, cd, gL, gper)) return e;
   p->N = N;
-  return p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st);
+  if (int e = p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st)) return e;
+  p->listValid = true;
+  p->listPos = d_pos;
+  p->listStream = st;  // (the list is ordered after the build on THIS stream only)
+  return 0;
 }
 
 static int g_ablate = getenv("UAMMD_PSE_ABLATE") ? atoi(getenv("UAMMD_PSE_ABLATE")) : 0;

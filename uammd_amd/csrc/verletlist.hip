@@ -216,9 +216,11 @@ __global__ void __launch_bounds__(128) k_lj_verlet(const float4 *__restrict__ so
   // the pairs of iteration k are evaluated (written as load - gather - evaluate per iteration the loop was two dependent round trips
   // per four neighbours, ~16 times per particle).  Entries past the particle's own count re-read its last one and carry no weight.
   const int l1 = max(nn - 1, 0);
+  // (a particle without a single neighbour — a NaN position fails even its own r2 <= rc2 test — has no row 0: its prologue reads
+  // nothing and gathers its own position)
   auto entries = [&](int k, int (&j)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) j[u] = mine[(size_t)min(k + u, l1) * N];
+    for (int u = 0; u < 4; ++u) j[u] = nn > 0 ? mine[(size_t)min(k + u, l1) * N] : id;
   };
   int jb[4], jc[4];
   float4 cb[4];
