@@ -1039,13 +1039,14 @@ __global__ void __launch_bounds__(256) k_fcm_kspace(float2 *__restrict__ g0, KLa
 // all nz planes in LDS: forward z transform (skipped when there are no forces: the grid is then all noise), the Stokes / noise
 // operator node by node, inverse z transform, store.  Replaces two strided rocFFT passes and k_fcm_kspace (three trips of the
 // 25.6 MB grid through memory at C4) by one.
-template <int LOG2TL, int NT>
-__global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size_t planeC, size_t zStride, int nyl, int y0, int log2nz,
+template <int LOG2TL, int NT, bool P2>
+__global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size_t planeC, size_t zStride, int nyl, int y0, int nzArg,
                                                     int3 nk, real3f L, float viscosity, bool haveForce, float noisePrefactor,
                                                     uint seed1, uint seed2, PseGreens pse) {
   extern __shared__ float2 lds[];
   constexpr int TL = 1 << LOG2TL, JG = NT >> LOG2TL, MAXB = 6 * 256 / NT;
-  const int nz = 1 << log2nz, LS = nz + 1, nkx = nk.x / 2 + 1;
+  const int nz = fft_len<P2>(nzArg);
+  const int LS = nz + 1, nkx = nk.x / 2 + 1;
   float2 *tw = lds, *buf = lds + nz;
   const int tid = threadIdx.x, l = tid & (TL - 1), jg = tid >> LOG2TL;
   // element (component c, plane j, line q) at c planeC + j zStride + q; q = yl nkx + kx runs over this rank's y rows [y0, y0 + nyl)
@@ -1069,7 +1070,7 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
           });
     }
     __syncthreads();
-    fft_lds<-1, MAXB, NT>(buf, LS, log2nz, 3 * nl, tw, 1, tid);
+    fft_lds<-1, MAXB, NT, P2>(buf, LS, nz, 3 * nl, tw, 1, tid);
   } else
     __syncthreads();
   if (l < nl) {
@@ -1087,7 +1088,7 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
     }
   }
   __syncthreads();
-  fft_lds<1, MAXB, NT>(buf, LS, log2nz, 3 * nl, tw, 1, tid);
+  fft_lds<1, MAXB, NT, P2>(buf, LS, nz, 3 * nl, tw, 1, tid);
   if (l < nl)
     for (int c = 0; c < 3; ++c)
       for (int j = jg; j < nz; j += JG) base[(size_t)c * planeC + (size_t)j * slab] = buf[(c * nl + l) * LS + j];
@@ -1131,32 +1132,31 @@ __global__ void k_fcm_export(const float2 *__restrict__ g0, size_t planeC, int t
 
 
 // ---- the LDS FFT pipeline (fcm_fft.hpp) ---------------------------------------------------------------------------------------------------
-static int ilog2_exact(int n) {  // log2 of a power of two in [16, 512], else -1
-  for (int l = 4; l <= kFftMaxLog2; ++l)
-    if (n == (1 << l)) return l;
-  return -1;
-}
-// the y transform of `groups` planes of (2^log2n x nkx) complex: 16 lines of n points per workgroup = n / 64 butterflies per thread
-template <int SIGN> static void fft_launch_lines(float2 *g, int log2n, int nkx, int groups, hipStream_t st) {
-  const int n = 1 << log2n, tiles = (nkx + 15) / 16;
+// the y transform of `groups` planes of (n x nkx) complex: 16 lines of n points per workgroup = n / 64 radix-4 butterflies per thread
+// (the shift-and-mask instantiations: powers of two from 4 up; a two-point axis takes the general passes)
+static bool is_pow2(int n) { return n >= 4 && (n & (n - 1)) == 0; }
+template <int SIGN> static void fft_launch_lines(float2 *g, int n, int nkx, int groups, hipStream_t st) {
+  const int tiles = (nkx + 15) / 16;
   const dim3 gr(groups * tiles);
   const size_t ldsz = sizeof(float2) * (size_t)(n + 16 * (n + 1));
   // (512 threads per workgroup were measured slower here: 25 vs 22 us at C4; the fused z pass gains from them)
-  if (n <= 128) hipLaunchKernelGGL((k_fft_lines<SIGN, 2, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
-  else if (n == 256) hipLaunchKernelGGL((k_fft_lines<SIGN, 4, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
-  else hipLaunchKernelGGL((k_fft_lines<SIGN, 8, 256>), gr, dim3(256), ldsz, st, g, log2n, nkx, tiles);
+#define UH_LINES(MB, P) hipLaunchKernelGGL((k_fft_lines<SIGN, MB, 256, P>), gr, dim3(256), ldsz, st, g, n, nkx, tiles)
+  if (is_pow2(n)) { if (n <= 128) UH_LINES(2, true); else if (n <= 256) UH_LINES(4, true); else UH_LINES(8, true); }
+  else { if (n <= 128) UH_LINES(2, false); else if (n <= 256) UH_LINES(4, false); else UH_LINES(8, false); }
+#undef UH_LINES
 }
 // Sizes the LDS passes serve without asking for more than the 64 KB of dynamic LDS a launch gets by default: the y pass holds 16 lines
 // (8 (n + 16 (n + 1)) bytes: 35 KB at 256, 69.8 KB at 512), the fused z pass 12 lines of nz (53 KB at 512), the row passes <= 25 KB up
 // to 1024.  Anything else takes rocFFT + k_fcm_kspace.
-static bool fft_axis_ok(int n, int lo, int hi) { const int l = ilog2_exact(n); return l >= lo && n <= hi; }
+// (an axis the mixed-radix passes serve: 2^a 3^b 5^c within [lo, hi])
+static bool fft_axis_ok(int n, int lo, int hi) { int e2, e3, e5; return n >= lo && n <= hi && fft_factors(n, e2, e3, e5); }
 static bool fcm_custom_fft_usable(const FCM *f) {
-  return f->customFFT && fft_axis_ok(f->grid.cellDim.x, 5, 512) && fft_axis_ok(f->grid.cellDim.y, 1, 256) && fft_axis_ok(f->grid.cellDim.z, 1, 512) &&
+  return f->customFFT && f->grid.cellDim.x % 2 == 0 && fft_axis_ok(f->grid.cellDim.x, 16, 512) && fft_axis_ok(f->grid.cellDim.y, 2, 256) && fft_axis_ok(f->grid.cellDim.z, 2, 512) &&
          f->planeReal == (size_t)f->nxpad * f->grid.cellDim.y * f->grid.cellDim.z;
 }
 // the plane kernel's LDS: twiddles + ny rows of nx / 2 + 1 complex; its butterfly budget: rows ny nh / 4 <= 2 x 1024, columns
 // (nh + 1) ny / 4 <= 3 x 1024
-static size_t fcm_plane_fft_lds(int nx, int ny) { return sizeof(float2) * ((size_t)std::max(nx, ny) + (size_t)ny * (nx / 2 + 1)); }
+static size_t fcm_plane_fft_lds(int nx, int ny) { return sizeof(float2) * ((size_t)nx + (size_t)ny + (size_t)ny * (nx / 2 + 1)); }
 static bool fcm_plane_fft_usable(int nx, int ny) {
   // (per device: a process may run solvers on several GPUs)
   static int ldsLimits[64];
@@ -1177,42 +1177,46 @@ static bool fcm_plane_fft_usable(int nx, int ny) {
 // forward x and y transforms of the three real component grids, in place
 static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1, nh = nx / 2;
-  const int lx = ilog2_exact(nx), ly = ilog2_exact(ny);
   if (fcm_plane_fft_usable(nx, ny)) {  // one pass: a whole plane per workgroup
     const size_t lds = fcm_plane_fft_lds(nx, ny);
     static bool attrSet[64] = {false};  // (a function attribute belongs to the device's copy of the kernel)
     int dev = 0;
     UH_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attrSet[dev]) {
-      UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       if (dev >= 0 && dev < 64) attrSet[dev] = true;
     }
-    hipLaunchKernelGGL(k_fft_xy_r2c_plane, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, lx, ly);
+    if (is_pow2(nx) && is_pow2(ny)) hipLaunchKernelGGL(k_fft_xy_r2c_plane<true>, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, nx, ny);
+    else hipLaunchKernelGGL(k_fft_xy_r2c_plane<false>, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, nx, ny);
     return 0;
   }
   const int rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * nz;
-  hipLaunchKernelGGL(k_fft_x_r2c<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
-                     lx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
+  if (is_pow2(nx))
+    hipLaunchKernelGGL((k_fft_x_r2c<false, true>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
+                       nx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
+  else
+    hipLaunchKernelGGL((k_fft_x_r2c<false, false>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)), st, g,
+                       nx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
   const int tiles = (nkx + 15) / 16;
-  fft_launch_lines<-1>((float2 *)g, ly, nkx, 3 * nz, st);
+  fft_launch_lines<-1>((float2 *)g, ny, nkx, 3 * nz, st);
   (void)tiles;
   return 0;
 }
 // z transform + Fourier-space operator + inverse z transform on lines of the layout (planeC, zStride, nyl, y0) — see k_fft_z_fused
 static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStride, int nyl, int y0, int3 cells, real3f L, bool haveForce,
                                   float noisePrefactor, uint seed2, hipStream_t st) {
-  const int nz = cells.z, nkx = cells.x / 2 + 1, lz = ilog2_exact(nz), lines = nyl * nkx;
+  const int nz = cells.z, nkx = cells.x / 2 + 1, lines = nyl * nkx;
   // tile of (ky, kx) nodes per workgroup: 3 tl nz complex in LDS and <= 6 radix-4 butterflies per thread and pass
-  int ltl = nz <= 128 ? 3 : (nz == 256 ? 3 : 2);  // measured at C4: 8 nodes x 512 threads
+  int ltl = nz <= 256 ? 3 : 2;  // measured at C4: 8 nodes x 512 threads
   if (f->zTileLog2 > 0 && sizeof(float2) * (size_t)(nz + 3 * (1 << f->zTileLog2) * (nz + 1)) <= 64 * 1024) ltl = f->zTileLog2;  // (tuning option)
   const int tlz = 1 << ltl;
   const size_t ldsz = sizeof(float2) * (size_t)(nz + 3 * tlz * (nz + 1));
   const dim3 gz((lines + tlz - 1) / tlz), bz(512);
-#define UH_ZFUSED(LT) hipLaunchKernelGGL((k_fft_z_fused<LT, 512>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, lz, cells, L, f->par.viscosity, \
+#define UH_ZFUSED(LT, P) hipLaunchKernelGGL((k_fft_z_fused<LT, 512, P>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, nz, cells, L, f->par.viscosity, \
                                          haveForce, noisePrefactor, f->par.seed, seed2, f->pse)
-  if (ltl == 4) UH_ZFUSED(4);
-  else if (ltl == 3) UH_ZFUSED(3);
-  else UH_ZFUSED(2);
+  if (is_pow2(nz)) { if (ltl == 4) UH_ZFUSED(4, true); else if (ltl == 3) UH_ZFUSED(3, true); else UH_ZFUSED(2, true); }
+  else { if (ltl == 4) UH_ZFUSED(4, false); else if (ltl == 3) UH_ZFUSED(3, false); else UH_ZFUSED(2, false); }
 #undef UH_ZFUSED
   return 0;
 }
@@ -1220,15 +1224,19 @@ static int fcm_fft_z_operator_y(FCM *f, float *g, bool haveForce, float noisePre
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nkx = nx / 2 + 1;
   const real3f L{f->par.boxSize[0], f->par.boxSize[1], f->par.boxSize[2]};
   if (int e = fcm_fft_z_fused_launch(f, (float2 *)g, f->planeCplx, (size_t)ny * nkx, ny, 0, f->grid.cellDim, L, haveForce, noisePrefactor, f->seed2, st)) return e;
-  fft_launch_lines<1>((float2 *)g, ilog2_exact(ny), nkx, 3 * nz, st);
+  fft_launch_lines<1>((float2 *)g, ny, nkx, 3 * nz, st);
   return 0;
 }
 // inverse x transform of the three components: into the planar real grids in place, or into the gather's interleaved float4 grid
 static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nh = nx / 2;
   const int rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * nz;
-  hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
-                     g, f->planeReal, (size_t)ny * f->nxpad, ilog2_exact(ny), ilog2_exact(nx), nrows, rows, inter, 0, (size_t)0);
+  if (is_pow2(nx) && is_pow2(ny))
+    hipLaunchKernelGGL(k_fft_x_c2r<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
+                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, 0, (size_t)0);
+  else
+    hipLaunchKernelGGL(k_fft_x_c2r<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
+                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, 0, (size_t)0);
   return 0;
 }
 
@@ -1355,7 +1363,7 @@ struct FCMSlab {
 };
 
 static bool fcm_slab_custom_fft(const FCMSlab *s) {
-  return s->loc.customFFT && fft_axis_ok(s->cells.x, 5, 512) && fft_axis_ok(s->cells.y, 1, 256);
+  return s->loc.customFFT && s->cells.x % 2 == 0 && fft_axis_ok(s->cells.x, 16, 512) && fft_axis_ok(s->cells.y, 2, 256);
 }
 static int fcm_slab_make_plans(FCMSlab *s) {
   std::call_once(g_rocfft_once, []() { (void)rocfft_setup(); });
@@ -1768,9 +1776,14 @@ int uammd_fcm_slab_forward_xy_fold(uammd_fcm_slab *h, float *d_grid, const float
   if (!fcm_slab_custom_fft(s)) return 1;
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
   const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
-  hipLaunchKernelGGL(k_fft_x_r2c<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
-                     (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows, d_fromDown, d_fromUp, 3 * ny * planes);
-  fft_launch_lines<-1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+  if (is_pow2(nx)) {
+  hipLaunchKernelGGL((k_fft_x_r2c<true, true>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                     (hipStream_t)stream, owned, nx, nrows, rows, d_fromDown, d_fromUp, 3 * ny * planes);
+  } else {
+  hipLaunchKernelGGL((k_fft_x_r2c<true, false>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                     (hipStream_t)stream, owned, nx, nrows, rows, d_fromDown, d_fromUp, 3 * ny * planes);
+  }
+  fft_launch_lines<-1>((float2 *)owned, ny, s->nkx, 3 * s->nzl, (hipStream_t)stream);
   UH_CHECK(hipGetLastError());
   return 0;
 }
@@ -1823,9 +1836,14 @@ int uammd_fcm_slab_forward_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;  // window layout [z][component][y][x]: the owned planes are one block
   if (fcm_slab_custom_fft(s)) {
     const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(16, 2048 / nh)), nrows = 3 * ny * s->nzl;
-    hipLaunchKernelGGL(k_fft_x_r2c<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
-                       (hipStream_t)stream, owned, ilog2_exact(nx), nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
-    fft_launch_lines<-1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+    if (is_pow2(nx)) {
+    hipLaunchKernelGGL((k_fft_x_r2c<false, true>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                       (hipStream_t)stream, owned, nx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
+    } else {
+    hipLaunchKernelGGL((k_fft_x_r2c<false, false>), dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + rows * (nh + 1)),
+                       (hipStream_t)stream, owned, nx, nrows, rows, (const float *)nullptr, (const float *)nullptr, 0);
+    }
+    fft_launch_lines<-1>((float2 *)owned, ny, s->nkx, 3 * s->nzl, (hipStream_t)stream);
     UH_CHECK(hipGetLastError());
     return 0;
   }
@@ -1842,11 +1860,17 @@ int uammd_fcm_slab_inverse_xy(uammd_fcm_slab *h, float *d_grid, void *stream) {
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
   if (fcm_slab_custom_fft(s)) {
     const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * s->nzl;
-    fft_launch_lines<1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
+    fft_launch_lines<1>((float2 *)owned, ny, s->nkx, 3 * s->nzl, (hipStream_t)stream);
     // rows (z, y) of the three components: component stride = one (ny x nxpad) plane, z stride = three of them
-    hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
-                       (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
+    if (is_pow2(nx) && is_pow2(ny)) {
+    hipLaunchKernelGGL(k_fft_x_c2r<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                       (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ny, nx,
                        nrows, rows, (float4 *)nullptr, 0, (size_t)0);
+    } else {
+    hipLaunchKernelGGL(k_fft_x_c2r<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                       (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ny, nx,
+                       nrows, rows, (float4 *)nullptr, 0, (size_t)0);
+    }
     UH_CHECK(hipGetLastError());
     return 0;
   }
@@ -1876,10 +1900,16 @@ static int fcm_slab_inverse_xy_inter(uammd_fcm_slab *h, float *d_grid, float *d_
   if (!fcm_slab_custom_fft(s) || !(s->loc.useTiles && !s->loc.forceAtomicSpread)) return 1;  // (the float4 gather reads tile-prepared stencils)
   float *owned = d_grid + (size_t)s->halo * 3 * s->loc.planeReal;
   const int nx = s->cells.x, ny = s->cells.y, nh = nx / 2, rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * s->nzl;
-  fft_launch_lines<1>((float2 *)owned, ilog2_exact(ny), s->nkx, 3 * s->nzl, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_fft_x_c2r, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
-                     (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ilog2_exact(ny), ilog2_exact(nx),
+  fft_launch_lines<1>((float2 *)owned, ny, s->nkx, 3 * s->nzl, (hipStream_t)stream);
+  if (is_pow2(nx) && is_pow2(ny)) {
+  hipLaunchKernelGGL(k_fft_x_c2r<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                     (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ny, nx,
                      nrows, rows, (float4 *)d_inter + (size_t)s->halo * ny * nx, wrapPlanes * ny, (size_t)s->nzl * ny * nx);
+  } else {
+  hipLaunchKernelGGL(k_fft_x_c2r<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)),
+                     (hipStream_t)stream, owned, (size_t)ny * s->loc.nxpad, 3 * (size_t)ny * s->loc.nxpad, ny, nx,
+                     nrows, rows, (float4 *)d_inter + (size_t)s->halo * ny * nx, wrapPlanes * ny, (size_t)s->nzl * ny * nx);
+  }
   UH_CHECK(hipGetLastError());
   return 0;
 }
@@ -1922,7 +1952,7 @@ int uammd_fcm_slab_z_fused(uammd_fcm_slab *h, float *d_cplxZ, int haveForce, flo
                            void *stream) {
   if (!h || !d_cplxZ) { set_last_error("uammd_fcm_slab_z_fused: null argument"); return -1; }
   FCMSlab *s = reinterpret_cast<FCMSlab *>(h);
-  if (!s->loc.customFFT || !fft_axis_ok(s->cells.z, 1, 512)) return 1;
+  if (!s->loc.customFFT || !fft_axis_ok(s->cells.z, 2, 512)) return 1;
   float noisePrefactor = 0.0f;
   if (temperature > 0.0f) {
     const float gL[3] = {s->L.x, s->L.y, s->L.z};

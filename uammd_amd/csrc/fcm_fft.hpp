@@ -1,24 +1,44 @@
-// Batched 3-D real FFT for the FCM solver on power-of-two grids, written for gfx950: five passes over the grid instead of the eight
-// of rocFFT (three per transform) + the Fourier-space kernel + the interleaving copy, with the z transform, the Stokes / noise
-// operator and the inverse z transform fused into one kernel that holds a tile of z-lines in LDS.
+// Batched 3-D real FFT for the FCM solver, written for gfx950: five passes over the grid instead of the eight of rocFFT (three per
+// transform) + the Fourier-space kernel + the interleaving copy, with the z transform, the Stokes / noise operator and the inverse z
+// transform fused into one kernel that holds a tile of z-lines in LDS.
 //
-// Replaces, for nx, ny, nz in {16 ... 512} powers of two (anything else keeps rocFFT):
+// Replaces, for axis lengths 2^a 3^b 5^c (x even, x and z <= 512, y <= 256) — the sizes Grid's nextFFTWiseSize3D hands out, up to its
+// factors 7 and 11 (anything else keeps rocFFT):
 //   cufftExecR2C / cufftExecC2R (batched 3-D)                      Integrator/BDHI/FCM/FCM_impl.cuh:399-411, :544-581
 //   forceFourier2Vel + fourierBrownianNoise between them           FCM_impl.cuh:375-397, :437-512
 // Conventions are cuFFT's: forward exp(-i...), inverse exp(+i...), both unnormalised (1/N lives in the Stokes operator), the
 // imaginary parts of the kx = 0 and kx = nx/2 self-conjugate inputs of the C2R are ignored.
 //
 //   k_fft_x_r2c        rows: nx reals -> nx/2 + 1 complex in place (one complex FFT of nx/2 points + untangling), 16 rows per workgroup
+//   k_fft_xy_r2c_plane a whole (component, z) plane: rows, then columns, where the plane fits the LDS
 //   k_fft_lines        y: strided lines of a z-plane, a tile of <= 16 consecutive kx per workgroup (contiguous 8 tl-byte segments)
 //   k_fft_z_fused      z: a tile of consecutive (ky, kx) nodes x all nz x the three components in LDS: forward, operator, inverse
 //   k_fft_x_c2r        rows back: three components of 16 rows -> the planar real grids or the gather's interleaved float4 grid
-// All FFTs are Stockham autosort (radix 4, one radix-2 pass for odd log2) on LDS lines; a pass stages its butterflies in registers
-// (read all, barrier, write all, barrier), twiddles from a table in LDS.
+// All FFTs are Stockham autosort on LDS lines, mixed radix: the factor 2^a as radix-8 passes with one or two radix-4 (or one radix-2)
+// passes in front, then radix-3 and radix-5 passes; a pass stages its butterflies in registers (read all, barrier, write all, barrier),
+// twiddles from a table in LDS.  Index arithmetic is shifts for power-of-two lengths and an exact float reciprocal otherwise (IDiv).
 #pragma once
 // (included by fcm.hip INSIDE namespace uammd_hip, after the Fourier-space operator it fuses)
 
 constexpr int kFftThreads = 256;
-constexpr int kFftMaxLog2 = 9;  // 512
+constexpr int kFftMax = 512;
+
+// i / d and i % d for 0 <= i < 2^21 and a wave-uniform d: a shift and a mask when d is a power of two, otherwise
+// (int)((i + 0.5) * (1 / d)) — exact: the product is off by less than i 2^-22 / d < 0.5 / d from (i + 0.5) / d
+// P2: the caller knows d is a power of two (the kernels are instantiated for all-power-of-two grids and for the rest: with the choice at
+// run time the power-of-two launches of C4 were 7 % slower)
+template <bool P2> struct IDivT {
+  int d, sh;
+  float rcp;
+  UH_D explicit IDivT(int dd) : d(dd), sh(31 - __builtin_clz((unsigned)dd)), rcp(1.0f / (float)dd) {}
+  UH_D int div(int i) const { return P2 ? (i >> sh) : (int)(((float)i + 0.5f) * rcp); }
+  UH_D int mod(int i) const { return P2 ? (i & (d - 1)) : i - __mul24(div(i), d); }
+  UH_D int rem(int i, int q) const { return P2 ? (i & (d - 1)) : i - __mul24(q, d); }  // i % d given q = i / d
+};
+
+// a length the power-of-two instantiations can treat as one: written as a shift, so that the divisions and remainders of the copy loops
+// compile to shifts and masks (with the plain kernel argument the fused z pass was 3 us slower at C4)
+template <bool P2> UH_D int fft_len(int n) { return P2 ? (1 << (31 - __builtin_clz((unsigned)n))) : n; }
 
 UH_D float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 UH_D float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -40,16 +60,38 @@ template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int ti
 // the R-point DFT of v (SIGN < 0: forward, exp(-2 pi i r m / R)), in place, natural order out
 template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
   auto mul_mi = [](float2 d) { return SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x); };  // -i d (forward), +i d (inverse)
-  if (R == 2) {
+  if constexpr (R == 2) {
     const float2 a = v[0], c = v[1];
     v[0] = cadd(a, c);
     v[1] = csub(a, c);
-  } else if (R == 4) {
+  } else if constexpr (R == 3) {
+    // y0 = a + (b + c), y1,2 = a - (b + c) / 2 -+ i (sqrt(3) / 2) (b - c)  (forward; the inverse swaps y1 and y2)
+    const float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(fmaf(-0.5f, s.x, v[0].x), fmaf(-0.5f, s.y, v[0].y));
+    const float2 q = mul_mi(make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y));
+    v[0] = cadd(v[0], s);
+    v[1] = cadd(m, q);
+    v[2] = csub(m, q);
+  } else if constexpr (R == 4) {
     const float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = mul_mi(csub(v[1], v[3]));
     v[0] = cadd(a0, a2);
     v[1] = cadd(a1, a3);
     v[2] = csub(a0, a2);
     v[3] = csub(a1, a3);
+  } else if constexpr (R == 5) {
+    // with s1 = v1 + v4, d1 = v1 - v4, s2 = v2 + v3, d2 = v2 - v3, c1 = cos(2 pi / 5), c2 = cos(4 pi / 5), n1 = sin(2 pi / 5), n2 = sin(4 pi / 5):
+    //   y0 = v0 + s1 + s2;  y1,4 = (v0 + c1 s1 + c2 s2) -+ i (n1 d1 + n2 d2);  y2,3 = (v0 + c2 s1 + c1 s2) -+ i (n2 d1 - n1 d2)   (forward)
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, n1 = 0.95105651629515357212f, n2 = 0.58778525229247312917f;
+    const float2 s1 = cadd(v[1], v[4]), d1 = csub(v[1], v[4]), s2 = cadd(v[2], v[3]), d2 = csub(v[2], v[3]);
+    const float2 a1 = make_float2(fmaf(c1, s1.x, fmaf(c2, s2.x, v[0].x)), fmaf(c1, s1.y, fmaf(c2, s2.y, v[0].y)));
+    const float2 a2 = make_float2(fmaf(c2, s1.x, fmaf(c1, s2.x, v[0].x)), fmaf(c2, s1.y, fmaf(c1, s2.y, v[0].y)));
+    const float2 b1 = mul_mi(make_float2(fmaf(n1, d1.x, n2 * d2.x), fmaf(n1, d1.y, n2 * d2.y)));
+    const float2 b2 = mul_mi(make_float2(fmaf(n2, d1.x, -(n1 * d2.x)), fmaf(n2, d1.y, -(n1 * d2.y))));
+    v[0] = cadd(v[0], cadd(s1, s2));
+    v[1] = cadd(a1, b1);
+    v[4] = csub(a1, b1);
+    v[2] = cadd(a2, b2);
+    v[3] = csub(a2, b2);
   } else {  // 8 = 2 x 4: sums and differences four apart, the differences turned by W8^r, then a 4-point DFT of either half
     float2 e[4], o[4];
 #pragma unroll
@@ -71,10 +113,55 @@ template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
   }
 }
 
+// One Stockham pass of radix R over `nlines` lines of N points; the sub-transforms entering the pass have Ns points (the product of the
+// radices already done).  Butterfly j < N / R of a line: inputs at j + r N / R, turned by exp(-2 pi i k r / (Ns R)) with k = j mod Ns,
+// outputs at (j - k) R + k + r Ns.  tw holds exp(-2 pi i t / (N twStride)) for t < N twStride.
+// STRIDED = false: line l at buf[l * LS + j], consecutive threads take consecutive butterflies of a line;
+// STRIDED = true:  element j of line l at buf[l * LS + j * ES] (columns of a row-major plane in LDS: LS = 1, ES = the row stride),
+//                  consecutive threads take consecutive LINES (neighbouring LDS words).
+template <int R, int SIGN, int MAXB, int NT, bool STRIDED, bool P2>
+UH_D void fft_pass(float2 *buf, int LS, int ES, int N, int Ns, int nlines, const float2 *tw, int twStride, int tid) {
+  const int per = N / R, total = nlines * per;
+  const IDivT<P2> dPer(per), dNs(Ns);
+  const IDivT<false> dLines(nlines);
+  const int es = STRIDED ? ES : 1, pes = per * es, nes = Ns * es;  // (a compile-time 1 for contiguous lines)
+  const int twk = (per / Ns) * twStride;  // index step of exp(-2 pi i k / (Ns R)) in the table: N / (Ns R) entries of the N-point table
+  float2 v[MAXB][R];
+  int dst[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = tid + q * NT;
+    dst[q] = -1;
+    if (b < total) {
+      int line, j;
+      if (STRIDED) { j = dLines.div(b); line = dLines.rem(b, j); }
+      else { line = dPer.div(b); j = dPer.rem(b, line); }
+      const int k = dNs.mod(j);
+      const float2 *p = buf + __mul24(line, LS) + __mul24(j, es);
+      const int t1 = __mul24(k, twk);
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[q][r] = p[r * pes];
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[q][r] = ctw<SIGN>(v[q][r], tw[t1 * r]);
+      fft_butterfly<R, SIGN>(v[q]);
+      dst[q] = __mul24(line, LS) + __mul24((j - k) * R + k, es);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q)
+    if (dst[q] >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[dst[q] + r * nes] = v[q][r];
+    }
+  __syncthreads();
+}
+
+// ---- power-of-two lengths: the passes with shifts and masks (the all-power-of-two grids of C4 / C5 run these) ----
 // One Stockham pass of radix R over `nlines` lines of N = 2^LOG2N points at buf[line * LS + j]; the sub-transforms entering the pass
 // have 2^LOG2NS points.  tw holds exp(-2 pi i k / NT) for k < NT, NT = N << LOG2TWSHIFT... (twStride = NT / N).
 template <int R, int SIGN, int MAXB, int NT>
-UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
+UH_D void fft_pass_p2(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
   constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
   const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
   float2 v[MAXB][R];
@@ -108,7 +195,7 @@ UH_D void fft_pass(float2 *buf, int LS, int log2N, int log2Ns, int nlines, const
 // the same pass over lines whose ELEMENTS are `ES` apart and whose first elements are `LS` apart (columns of a row-major plane in LDS:
 // LS = 1, ES = the row stride)
 template <int R, int SIGN, int MAXB, int NT>
-UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
+UH_D void fft_pass_strided_p2(float2 *buf, int LS, int ES, int log2N, int log2Ns, int nlines, const float2 *tw, int twStride, int tid) {
   constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
   const int N = 1 << log2N, per = N >> LR, Ns = 1 << log2Ns, total = nlines << (log2N - LR);
   float2 v[MAXB][R];
@@ -139,69 +226,75 @@ UH_D void fft_pass_strided(float2 *buf, int LS, int ES, int log2N, int log2Ns, i
     }
   __syncthreads();
 }
-// Pass plan: radix 8 where it fits (a pass is two workgroup barriers and a trip of every point through LDS whatever its radix: 64 points
-// are two passes instead of three, 128 and 256 three instead of four): log2 N = 3 a + 2 b with b <= 2, the radix-4 passes first.
-// MAXB = radix-4 butterflies per thread; a radix-8 pass has half as many.
-template <int SIGN, int MAXB, int NT>
-UH_D void fft_lds_strided(float2 *buf, int LS, int ES, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
-  const int n4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);  // 4 = 2 + 2, 5 = 2 + 3, 7 = 2 + 2 + 3, 8 = 2 + 3 + 3
-  int s = 0;
-  for (int a = 0; a < n4; ++a, s += 2) fft_pass_strided<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
-  for (; s < log2N; s += 3) fft_pass_strided<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, ES, log2N, s, nlines, tw, twStride, tid);
+
+// N = 2^a 3^b 5^c?  (host and device)
+inline __host__ __device__ bool fft_factors(int n, int &e2, int &e3, int &e5) {
+  e2 = e3 = e5 = 0;
+  if (n < 1) return false;
+  while (n % 2 == 0) { n /= 2; ++e2; }
+  while (n % 3 == 0) { n /= 3; ++e3; }
+  while (n % 5 == 0) { n /= 5; ++e5; }
+  return n == 1;
 }
 
-// N-point FFTs of `nlines` LDS lines (N = 2^log2N <= 512, nlines * N / 4 <= MAXB * 256).  The caller has synchronised its writes.
-template <int SIGN, int MAXB, int NT = kFftThreads>
-UH_D void fft_lds(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid) {
-  const int n4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);
-  int s = 0;
-  for (int a = 0; a < n4; ++a, s += 2) fft_pass<4, SIGN, MAXB, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
-  for (; s < log2N; s += 3) fft_pass<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, s, nlines, tw, twStride, tid);
-}
-
-// ---- rows: R2C in place -------------------------------------------------------------------------------------------------------------
-// g: rows of nxpad = nx + 2 floats, `nrows` of them back to back (the three planar component grids are contiguous).
-// FOLD (slab decomposition): the first and the last `foldRows` rows also take what the neighbours spread into their halo planes,
-// addLo / addHi (foldRows rows each, same row layout), added while the row is loaded — grid + halo, as the separate pass did.
-template <bool FOLD>
-__global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g, int log2nx, int nrows, int rowsPerBlock,
-                                                           const float *__restrict__ addLo, const float *__restrict__ addHi, int foldRows) {
-  extern __shared__ float2 lds[];
-  const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
-  float2 *tw = lds, *buf = lds + nx;
-  const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);
-  fft_twiddles(tw, nx, tid);
-  staged_copy<8, float2>(tid, nr * nh, kFftThreads,
-      [&](int i) {
-        const int r = i >> (log2nx - 1), j = i & (nh - 1);
-        return *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
-      },
-      [&](int i, float2 v) { buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))] = v; });
-  if (FOLD) {  // (the rows that take a neighbour's halo plane: a second pass over those rows only)
-    __syncthreads();
-    staged_copy<8, float2>(tid, nr * nh, kFftThreads,
-        [&](int i) {
-          const int r = i >> (log2nx - 1), j = i & (nh - 1), row = r0 + r;
-          float2 a = make_float2(0.f, 0.f);
-          if (row < foldRows) a = *(const float2 *)(addLo + (size_t)row * nxpad + 2 * j);
-          else if (row >= nrows - foldRows) a = *(const float2 *)(addHi + (size_t)(row - (nrows - foldRows)) * nxpad + 2 * j);
-          return a;
-        },
-        [&](int i, float2 a) {
-          float2 &v = buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))];
-          v = make_float2(v.x + a.x, v.y + a.y);
-        });
+// N-point FFTs of `nlines` LDS lines.  MAXB = radix-4 butterflies per thread the caller has room for (nlines N / 4 <= MAXB NT); the
+// other radices scale from it (a radix-R pass has nlines N / R butterflies).  The caller has synchronised its writes.
+// Pass plan for 2^a: radix 8 where it fits (a pass is two workgroup barriers and a trip of every point through LDS whatever its radix),
+// a = 3 n8 + 2 n4 + n2 with the small passes first.
+template <int SIGN, int MAXB, int NT, bool STRIDED, bool P2>
+UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const float2 *tw, int twStride, int tid) {
+  int e2, e3, e5;
+  if (P2) { e2 = 31 - __builtin_clz((unsigned)N); e3 = e5 = 0; }
+  else fft_factors(N, e2, e3, e5);
+  int n8 = e2 / 3, n4 = 0, n2 = 0;
+  if (e2 % 3 == 2) n4 = 1;
+  else if (e2 % 3 == 1) { if (n8 > 0) { n8 -= 1; n4 = 2; } else n2 = 1; }
+  if constexpr (P2) {  // (N >= 4: a two-point axis takes the general instantiation.  The plan loop is written as it was when only powers
+    // of two were served — radix-4 passes until the rest is a multiple of three bits, then radix 8: counted loops over n4 and n8 compiled
+    // to a fused z pass 3 us slower at C4)
+    const int log2N = e2;
+    const int m4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);
+    int ls = 0;
+    for (int a = 0; a < m4; ++a, ls += 2) {
+      if constexpr (STRIDED) fft_pass_strided_p2<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, ls, nlines, tw, twStride, tid);
+      else fft_pass_p2<4, SIGN, MAXB, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+    }
+    for (; ls < log2N; ls += 3) {
+      if constexpr (STRIDED) fft_pass_strided_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, ES, log2N, ls, nlines, tw, twStride, tid);
+      else fft_pass_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+    }
+  } else {
+    int Ns = 1;
+    for (int a = 0; a < n2; ++a, Ns *= 2) fft_pass<2, SIGN, 2 * MAXB, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n4; ++a, Ns *= 4) fft_pass<4, SIGN, MAXB, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n8; ++a, Ns *= 8) fft_pass<8, SIGN, (MAXB + 1) / 2, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < e3; ++a, Ns *= 3) fft_pass<3, SIGN, (4 * MAXB + 2) / 3, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < e5; ++a, Ns *= 5) fft_pass<5, SIGN, (4 * MAXB + 4) / 5, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
   }
-  __syncthreads();
-  fft_lds<-1, 2>(buf, LS, log2nx - 1, nr, tw, 2, tid);
-  // untangle: X_k = E_k + W^k O_k, E_k = (Z_k + conj Z_{nh-k}) / 2, O_k = (Z_k - conj Z_{nh-k}) / (2i), k = 0 .. nh (Z_nh = Z_0)
-  // (k runs over 0 .. nh/2: nh/2 values through the bit mask + the middle one, k = nh/2, done by the threads that draw k = 0)
-  for (int i = tid; i < nr * (nh / 2); i += kFftThreads) {
-    const int r = i >> (log2nx - 2), k = i & (nh / 2 - 1);
+}
+template <int SIGN, int MAXB, int NT, bool P2>
+UH_D void fft_lds(float2 *buf, int LS, int N, int nlines, const float2 *tw, int twStride, int tid) {
+  fft_lds_any<SIGN, MAXB, NT, false, P2>(buf, LS, 1, N, nlines, tw, twStride, tid);
+}
+template <int SIGN, int MAXB, int NT, bool P2>
+UH_D void fft_lds_strided(float2 *buf, int LS, int ES, int N, int nlines, const float2 *tw, int twStride, int tid) {
+  fft_lds_any<SIGN, MAXB, NT, true, P2>(buf, LS, ES, N, nlines, tw, twStride, tid);
+}
+
+// rows of nh = nx / 2 complex Z (the FFT of the rows' even / odd samples) -> the nh + 1 entries X_0 .. X_nh of the real rows' spectra:
+// X_k = E_k + W^k O_k, E_k = (Z_k + conj Z_{nh-k}) / 2, O_k = (Z_k - conj Z_{nh-k}) / (2i), W = exp(-2 pi i / nx); the pair (k, nh - k)
+// by one thread, k = 0 (with the middle entry nh / 2 when nh is even) by another.  tw[k twx] = W^k.
+template <int NT, bool P2> UH_D void fft_untangle_r2c(float2 *buf, int LS, int nh, int nrows, const float2 *tw, int twx, int tid) {
+  const int half = (nh + 1) / 2;  // k = 0 .. half - 1: pairs (k, nh - k), k >= 1
+  const IDivT<P2> dHalf(half);
+  for (int i = tid; i < nrows * half; i += NT) {
+    const int r = dHalf.div(i), k = dHalf.rem(i, r);
     float2 *row = buf + r * LS;
     if (k == 0) {
-      const float2 m = row[nh / 2];
-      row[nh / 2] = make_float2(m.x, -m.y);  // X_{nh/2} = conj Z_{nh/2}
+      if ((nh & 1) == 0) {
+        const float2 m = row[nh / 2];
+        row[nh / 2] = make_float2(m.x, -m.y);  // X_{nh/2} = conj Z_{nh/2}
+      }
       const float2 z = row[0];
       row[0] = make_float2(z.x + z.y, 0.0f);
       row[nh] = make_float2(z.x - z.y, 0.0f);
@@ -209,15 +302,81 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
       const float2 a = row[k], b = row[nh - k];
       const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));   // E_k
       const float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));  // O_k = (a - conj b) / (2i)
-      const float2 wo = ctw<-1>(o, tw[k]);
+      const float2 wo = ctw<-1>(o, tw[k * twx]);
       row[k] = cadd(e, wo);
       // X_{nh-k} = conj(E_k - W^k O_k)
       row[nh - k] = make_float2(e.x - wo.x, -(e.y - wo.y));
     }
   }
+}
+// the reverse: X_0 .. X_nh -> Z_0 .. Z_{nh-1}, Z_k = (X_k + conj X_{nh-k}) + i W^{-k} (X_k - conj X_{nh-k}) (unnormalised: twice the above)
+template <int NT, bool P2> UH_D void fft_tangle_c2r(float2 *buf, int LS, int nh, int nlines, const float2 *tw, int twx, int tid) {
+  const int half = (nh + 1) / 2;
+  const IDivT<P2> dHalf(half);
+  for (int i = tid; i < nlines * half; i += NT) {
+    const int line = dHalf.div(i), k = dHalf.rem(i, line);
+    float2 *row = buf + line * LS;
+    if (k == 0) {
+      const float a = row[0].x, b = row[nh].x;
+      row[0] = make_float2(a + b, a - b);
+      if ((nh & 1) == 0) {
+        const float2 m = row[nh / 2];
+        row[nh / 2] = make_float2(2.0f * m.x, -2.0f * m.y);  // Z_{nh/2} = 2 conj X_{nh/2}
+      }
+    } else {
+      const float2 a = row[k], b = row[nh - k];
+      const float2 s = make_float2(a.x + b.x, a.y - b.y);   // X_k + conj X_{nh-k}
+      const float2 d = make_float2(a.x - b.x, a.y + b.y);   // X_k - conj X_{nh-k}
+      const float2 wd = ctw<1>(d, tw[k * twx]);             // W^{-k} d
+      const float2 iwd = make_float2(-wd.y, wd.x);
+      row[k] = cadd(s, iwd);
+      row[nh - k] = make_float2(s.x - iwd.x, -(s.y - iwd.y));  // Z_{nh-k} = conj(s) + i W^{k} conj(d)
+    }
+  }
+}
+
+// ---- rows: R2C in place -------------------------------------------------------------------------------------------------------------
+// g: rows of nxpad = nx + 2 floats, `nrows` of them back to back (the three planar component grids are contiguous).
+// FOLD (slab decomposition): the first and the last `foldRows` rows also take what the neighbours spread into their halo planes,
+// addLo / addHi (foldRows rows each, same row layout), added while the row is loaded — grid + halo, as the separate pass did.
+template <bool FOLD, bool P2>
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g, int nxArg, int nrows, int rowsPerBlock,
+                                                           const float *__restrict__ addLo, const float *__restrict__ addHi, int foldRows) {
+  extern __shared__ float2 lds[];
+  const int nx = fft_len<P2>(nxArg);
+  const int nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  const IDivT<P2> dNh(nh);
+  float2 *tw = lds, *buf = lds + nx;
+  const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);
+  fft_twiddles(tw, nx, tid);
+  staged_copy<8, float2>(tid, nr * nh, kFftThreads,
+      [&](int i) {
+        const int r = dNh.div(i), j = dNh.rem(i, r);
+        return *(const float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * j);
+      },
+      [&](int i, float2 v) { const int r = dNh.div(i); buf[__mul24(r, LS) + dNh.rem(i, r)] = v; });
+  if (FOLD) {  // (the rows that take a neighbour's halo plane: a second pass over those rows only)
+    __syncthreads();
+    staged_copy<8, float2>(tid, nr * nh, kFftThreads,
+        [&](int i) {
+          const int r = dNh.div(i), j = dNh.rem(i, r), row = r0 + r;
+          float2 a = make_float2(0.f, 0.f);
+          if (row < foldRows) a = *(const float2 *)(addLo + (size_t)row * nxpad + 2 * j);
+          else if (row >= nrows - foldRows) a = *(const float2 *)(addHi + (size_t)(row - (nrows - foldRows)) * nxpad + 2 * j);
+          return a;
+        },
+        [&](int i, float2 a) {
+          const int r = dNh.div(i);
+          float2 &v = buf[__mul24(r, LS) + dNh.rem(i, r)];
+          v = make_float2(v.x + a.x, v.y + a.y);
+        });
+  }
+  __syncthreads();
+  fft_lds<-1, 2, kFftThreads, P2>(buf, LS, nh, nr, tw, 2, tid);
+  fft_untangle_r2c<kFftThreads, P2>(buf, LS, nh, nr, tw, 1, tid);
   __syncthreads();
   for (int i = tid; i < nr * nh; i += kFftThreads) {
-    const int r = i >> (log2nx - 1), k = i & (nh - 1);
+    const int r = dNh.div(i), k = dNh.rem(i, r);
     *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * k) = buf[r * LS + k];
     if (k == 0) *(float2 *)(g + (size_t)(r0 + r) * nxpad + 2 * nh) = buf[r * LS + nh];
   }
@@ -228,45 +387,32 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
 // gfx950's 160 KB per CU): rows in, ny FFTs of nx / 2 points + untangling, nx / 2 + 1 FFTs of ny points down the columns of the same array
 // (element stride = the row stride), rows out.  3 nz workgroups of 1024 threads; a launch asks for its dynamic LDS beyond 64 KB through
 // hipFuncSetAttribute.  Replaces k_fft_x_r2c + k_fft_lines<-1> where the plane fits (fcm_plane_fft_usable).
+// LDS: exp(-2 pi i k / nx), k < nx | exp(-2 pi i k / ny), k < ny | the plane
 constexpr int kPlaneThreads = 1024;
-__global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__restrict__ g, int log2nx, int log2ny) {
+template <bool P2>
+__global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__restrict__ g, int nxArg, int nyArg) {
   extern __shared__ float2 lds[];
-  const int nx = 1 << log2nx, ny = 1 << log2ny, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
-  const int ntw = nx > ny ? nx : ny;           // one table exp(-2 pi i k / ntw) serves both transforms (both sizes divide it)
-  float2 *tw = lds, *buf = lds + ntw;
+  const int nx = fft_len<P2>(nxArg), ny = fft_len<P2>(nyArg);
+  const int nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  const IDivT<P2> dNh(nh);
+  const IDivT<false> dLS(LS);
+  float2 *twx = lds, *twy = lds + nx, *buf = lds + nx + ny;
   const int tid = threadIdx.x;
   float *plane = g + (size_t)blockIdx.x * ny * nxpad;   // (the three planar component grids are contiguous: plane index = c nz + z)
-  fft_twiddles<kPlaneThreads>(tw, ntw, tid);
+  fft_twiddles<kPlaneThreads>(twx, nx, tid);
+  fft_twiddles<kPlaneThreads>(twy, ny, tid);
   staged_copy<8, float2>(tid, ny * nh, kPlaneThreads,
-      [&](int i) { return *(const float2 *)(plane + (size_t)(i >> (log2nx - 1)) * nxpad + 2 * (i & (nh - 1))); },
-      [&](int i, float2 v) { buf[(i >> (log2nx - 1)) * LS + (i & (nh - 1))] = v; });
+      [&](int i) { const int r = dNh.div(i); return *(const float2 *)(plane + (size_t)r * nxpad + 2 * dNh.rem(i, r)); },
+      [&](int i, float2 v) { const int r = dNh.div(i); buf[__mul24(r, LS) + dNh.rem(i, r)] = v; });
   __syncthreads();
-  // rows: ny complex FFTs of nh points (table stride: exp(-2 pi i k / nh) = tw[k ntw / nh])
-  fft_lds<-1, 2, kPlaneThreads>(buf, LS, log2nx - 1, ny, tw, ntw / nh, tid);
-  const int twx = ntw / nx;
-  for (int i = tid; i < ny * (nh / 2); i += kPlaneThreads) {   // untangle (as k_fft_x_r2c)
-    const int r = i >> (log2nx - 2), k = i & (nh / 2 - 1);
-    float2 *row = buf + r * LS;
-    if (k == 0) {
-      const float2 m = row[nh / 2];
-      row[nh / 2] = make_float2(m.x, -m.y);
-      const float2 z = row[0];
-      row[0] = make_float2(z.x + z.y, 0.0f);
-      row[nh] = make_float2(z.x - z.y, 0.0f);
-    } else {
-      const float2 a = row[k], b = row[nh - k];
-      const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-      const float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
-      const float2 wo = ctw<-1>(o, tw[k * twx]);
-      row[k] = cadd(e, wo);
-      row[nh - k] = make_float2(e.x - wo.x, -(e.y - wo.y));
-    }
-  }
+  // rows: ny complex FFTs of nh points (exp(-2 pi i k / nh) = twx[2 k])
+  fft_lds<-1, 2, kPlaneThreads, P2>(buf, LS, nh, ny, twx, 2, tid);
+  fft_untangle_r2c<kPlaneThreads, P2>(buf, LS, nh, ny, twx, 1, tid);
   __syncthreads();
   // columns: nh + 1 FFTs of ny points, element stride LS
-  fft_lds_strided<-1, 3, kPlaneThreads>(buf, 1, LS, log2ny, nh + 1, tw, ntw / ny, tid);
+  fft_lds_strided<-1, 3, kPlaneThreads, P2>(buf, 1, LS, ny, nh + 1, twy, 1, tid);
   for (int i = tid; i < ny * LS; i += kPlaneThreads) {
-    const int r = i / LS, k = i - r * LS;
+    const int r = dLS.div(i), k = dLS.rem(i, r);
     *(float2 *)(plane + (size_t)r * nxpad + 2 * k) = buf[r * LS + k];
   }
 }
@@ -275,10 +421,11 @@ __global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__res
 // group = one (component, z) plane of ny x nkx complex; tile = 16 consecutive kx (the last tile of a plane is narrower); element j of
 // line l at group * ny * nkx + j * nkx + kx0 + l.  Thread (l = tid & 15, jg = tid >> 4) moves elements j = jg + 16 it of line l: 128-byte
 // segments, no integer division.
-template <int SIGN, int MAXB, int NT>
-__global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int log2n, int nkx, int tilesPerGroup) {
+template <int SIGN, int MAXB, int NT, bool P2>
+__global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int nArg, int nkx, int tilesPerGroup) {
   extern __shared__ float2 lds[];
-  const int n = 1 << log2n, LS = n + 1;
+  const int n = fft_len<P2>(nArg);
+  const int LS = n + 1;
   float2 *tw = lds, *buf = lds + n;
   // neighbouring tiles of a plane share the 128-byte lines their 16-complex segments straddle (a row is 8 (nx / 2 + 1) bytes: never a
   // multiple of 128): dealt round-robin to the XCDs every such line was fetched from HBM twice (55 MB per pass of a 25.6 MB grid at C4)
@@ -290,7 +437,7 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
   if (l < nl)
     staged_copy<16, float2>(jg, n, NT / 16, [&](int j) { return base[(size_t)j * nkx]; }, [&](int j, float2 v) { buf[l * LS + j] = v; });
   __syncthreads();
-  fft_lds<SIGN, MAXB, NT>(buf, LS, log2n, nl, tw, 1, tid);
+  fft_lds<SIGN, MAXB, NT, P2>(buf, LS, n, nl, tw, 1, tid);
   if (l < nl)
     for (int j = jg; j < n; j += NT / 16) base[(size_t)j * nkx] = buf[l * LS + j];
 }
@@ -302,28 +449,32 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int lo
 // zStride = ny nxpad; slab window [z][c][y][x]: compStride = ny nxpad, zStride = 3 ny nxpad).
 // wrapRows > 0 (slab window of a rank that is its own neighbour, world size 1): the first wrapRows rows are also stored wrapShift float4
 // further on and the last wrapRows rows wrapShift earlier — the halo planes the gather reads, which with neighbours arrive by message.
-__global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t compStride, size_t zStride, int log2ny, int log2nx,
+template <bool P2>
+__global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t compStride, size_t zStride, int nyArg, int nxArg,
                                                            int nrows, int rowsPerBlock, float4 *__restrict__ inter, int wrapRows,
                                                            size_t wrapShift) {
   extern __shared__ float2 lds[];
-  const int nx = 1 << log2nx, nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  const int nx = fft_len<P2>(nxArg), ny = fft_len<P2>(nyArg);
+  const int nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
+  const IDivT<P2> dNh(nh), dNy(ny);
   float2 *tw = lds, *buf = lds + nx;
   const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);  // rows x 3 components
   fft_twiddles(tw, nx, tid);
+  auto rowOf = [&](int c, int r) {
+    const int gr = r0 + r, z = dNy.div(gr);
+    return g + (size_t)c * compStride + (size_t)z * zStride + (size_t)dNy.rem(gr, z) * nxpad;
+  };
   {  // element e = c (nr nh) + r nh + k of the 3 nr rows; the rows' last (Nyquist) entries in a second, short round
     const int per = nr * nh;
-    auto rowOf = [&](int c, int r) {
-      const int gr = r0 + r;
-      return g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad;
-    };
+    const IDivT<false> dPer(per);
     staged_copy<12, float2>(tid, 3 * per, kFftThreads,
         [&](int e) {
-          const int c = e / per, i = e - c * per;
-          return *(const float2 *)(rowOf(c, i >> (log2nx - 1)) + 2 * (i & (nh - 1)));
+          const int c = dPer.div(e), i = dPer.rem(e, c), r = dNh.div(i);
+          return *(const float2 *)(rowOf(c, r) + 2 * dNh.rem(i, r));
         },
         [&](int e, float2 v) {
-          const int c = e / per, i = e - c * per;
-          buf[(c * nr + (i >> (log2nx - 1))) * LS + (i & (nh - 1))] = v;
+          const int c = dPer.div(e), i = dPer.rem(e, c), r = dNh.div(i);
+          buf[__mul24(c * nr + r, LS) + dNh.rem(i, r)] = v;
         });
     if (tid < 3 * nr) {
       const int c = tid / nr, r = tid - c * nr;
@@ -331,30 +482,12 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
     }
   }
   __syncthreads();
-  // Z_k = (X_k + conj X_{nh-k}) + i W^{-k} (X_k - conj X_{nh-k}), k = 0 .. nh - 1
-  for (int i = tid; i < 3 * nr * (nh / 2); i += kFftThreads) {
-    const int line = i >> (log2nx - 2), k = i & (nh / 2 - 1);
-    float2 *row = buf + line * LS;
-    if (k == 0) {
-      const float a = row[0].x, b = row[nh].x;
-      row[0] = make_float2(a + b, a - b);
-      const float2 m = row[nh / 2];
-      row[nh / 2] = make_float2(2.0f * m.x, -2.0f * m.y);  // Z_{nh/2} = 2 conj X_{nh/2}
-    } else {
-      const float2 a = row[k], b = row[nh - k];
-      const float2 s = make_float2(a.x + b.x, a.y - b.y);   // X_k + conj X_{nh-k}
-      const float2 d = make_float2(a.x - b.x, a.y + b.y);   // X_k - conj X_{nh-k}
-      const float2 wd = ctw<1>(d, tw[k]);                   // W^{-k} d
-      const float2 iwd = make_float2(-wd.y, wd.x);
-      row[k] = cadd(s, iwd);
-      row[nh - k] = make_float2(s.x - iwd.x, -(s.y - iwd.y));  // Z_{nh-k} = conj(s) + i W^{k} conj(d)
-    }
-  }
+  fft_tangle_c2r<kFftThreads, P2>(buf, LS, nh, 3 * nr, tw, 1, tid);
   __syncthreads();
-  fft_lds<1, 2>(buf, LS, log2nx - 1, 3 * nr, tw, 2, tid);
+  fft_lds<1, 2, kFftThreads, P2>(buf, LS, nh, 3 * nr, tw, 2, tid);
   if (inter) {
     for (int i = tid; i < nr * nh; i += kFftThreads) {
-      const int r = i >> (log2nx - 1), j = i & (nh - 1);
+      const int r = dNh.div(i), j = dNh.rem(i, r);
       const float2 vx = buf[r * LS + j], vy = buf[(nr + r) * LS + j], vz = buf[(2 * nr + r) * LS + j];
       float4 *o = inter + (size_t)(r0 + r) * nx + 2 * j;
       const float4 a = make_float4(vx.x, vy.x, vz.x, 0.0f), b = make_float4(vx.y, vy.y, vz.y, 0.0f);
@@ -366,10 +499,8 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
   } else {
     for (int c = 0; c < 3; ++c)
       for (int i = tid; i < nr * nh; i += kFftThreads) {
-        const int r = i >> (log2nx - 1), j = i & (nh - 1);
-        const int gr = r0 + r;
-        *(float2 *)(g + (size_t)c * compStride + (size_t)(gr >> log2ny) * zStride + (size_t)(gr & ((1 << log2ny) - 1)) * nxpad + 2 * j) =
-            buf[(c * nr + r) * LS + j];
+        const int r = dNh.div(i), j = dNh.rem(i, r);
+        *(float2 *)(rowOf(c, r) + 2 * j) = buf[(c * nr + r) * LS + j];
       }
   }
 }
