@@ -84,6 +84,28 @@ def read_traffic(name):
         return None
 
 
+def read_kernel_fractions(name, bytes_of):
+    """Per-kernel rooflines of a step from the committed rocprofv3 summary (tools/prof_any.sh -> profiles/<name>: lines
+    `kernel | calls | total_us | avg_us | pct`): for every kernel `bytes_of` knows (prefix -> algorithmic HBM bytes per launch) its average
+    duration, achieved GB/s and fraction of the HBM roof.  None if the file is not there."""
+    tp = os.path.join(ROOT, "profiles", name)
+    try:
+        rows = [l.split(" | ") for l in open(tp) if " | " in l and not l.startswith("#")]
+    except Exception:
+        return None
+    out = []
+    for r in rows:
+        kern = r[0].replace("void ", "").replace("uammd_hip::", "")
+        for prefix, nbytes in bytes_of.items():
+            if kern.startswith(prefix):
+                us = float(r[3])
+                gbs = nbytes / (us * 1e-6) / 1e9
+                out.append({"kernel": kern.split("(")[0], "avg_us": us, "algorithmic_bytes": nbytes, "achieved_GBs": round(gbs, 1),
+                            "frac": round(gbs / PEAK_HBM_GBS, 4)})
+                break
+    return {"source": "profiles/" + name, "kernels": out} if out else None
+
+
 def lattice(n, L, seed, jitter=0.1):
     from util import lattice_positions
     return lattice_positions(n, L, seed=seed, jitter=jitter)
@@ -255,6 +277,15 @@ def run_fcm(hip, args, world, rank, dist):
                         "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "traffic": read_traffic("traffic_fcm_step.json"),
                         "algorithmic_bytes_per_step": fcm_bytes_per_step(n, cells)}}
+    # every kernel of the step against the HBM roof on ITS OWN algorithmic bytes (G = one pass over the 3-component complex grid, 25.6 MB
+    # at C4; the gather reads the float4 grid, 16 B per node; a particle's prepared stencil is 16 + 72 B), durations from the committed
+    # rocprofv3 summary of tools/time_fcm.py
+    G = 12 * 2 * (cells[0] // 2 + 1) * cells[1] * cells[2]
+    nodes = cells[0] * cells[1] * cells[2]
+    out["kernel_rooflines"] = read_kernel_fractions("r04_kernel_stats_fcm_c4.txt", {
+        "k_fcm_spread_tile": G + 4.3 * n * (16 + 72), "k_fft_xy_r2c_plane": 2 * G, "k_fft_z_fused": 2 * G, "k_fft_lines": 2 * G,
+        "k_fft_x_c2r": G + 16 * nodes, "k_fcm_gather_col": 16 * nodes + n * (16 + 72 + 12), "k_fcm_prepare": n * (32 + 16 + 16 + 72),
+        "k_fcm_bin_count": n * 24, "k_fcm_update_bin": n * (32 + 12 + 8)})
     return out
 
 

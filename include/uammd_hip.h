@@ -570,7 +570,9 @@ int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain);
  * NeighbourList/common.cuh:10-34), bit for bit; 0 = eight lanes per particle, same pairs and per-pair arithmetic, another order.
  * "lazy_list" (default 0): 1 = the near-field cell list is rebuilt only after uammd_pse_near_positions_changed() (the host layers wire
  * it to ParticleData's position write signal) or when the position array / N of a call changes — CellList::update's needsRebuild
- * (NeighbourList/CellList.cuh:134-136,192-204); 0 = every mdot / stochastic / dot call rebuilds. */
+ * (NeighbourList/CellList.cuh:134-136,192-204); 0 = every mdot / stochastic / dot call rebuilds.
+ * "pair_list" (default 1; takes effect with "lazy_list"): the pairs inside the cut-off are evaluated once per list build into 24-byte
+ * records (F, (G - F) / r^2, r_ij, j) and the ~8 products of a step stream them; 0 = every product scans the 27 cells. */
 int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value);
 int uammd_pse_near_positions_changed(uammd_pse_near *h);
 /* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */

@@ -245,3 +245,53 @@ def test_lazy_list_follows_position_writes(hip, o32):
     expect = np.zeros((n, 3), np.float32)
     ref.near_mdot(pos2, f4, expect)
     assert np.abs(b - expect).max() <= 1e-6 * np.abs(expect).max() and not np.allclose(a, b)
+
+
+def test_pair_records_match_the_scan_product(hip, o32):
+    """The pair records (k_pse_pairs_build / k_pse_near_pairs: the default once the list is kept between products) against the product that
+    scans the cells every time (k_pse_near8, option pair_list = 0): the same pairs, (G - F) / r^2 rounded once more per pair; caller-order
+    and accumulate forms; a sheared box; after a position write the records follow the new list; and a cluster with more neighbours than a
+    hit list holds sends the handle back to the scanning product (same results)."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    for shear, cluster in ((0.0, False), (0.2, False), (0.0, True)):
+        L, n, tol, psi = 20.0, 4000, 1e-3, 0.6
+        pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n, shear=shear)
+        if cluster:
+            pos = pos.copy()
+            pos[:300, :3] = np.random.default_rng(5).normal(0, 0.3, (300, 3)).astype(np.float32)   # 300 particles within one cut-off
+            pd.setPos(pos)
+        rng = np.random.default_rng(3)
+        f4 = np.zeros((n, 4), np.float32)
+        f4[:, :3] = rng.normal(0, 1, (n, 3))
+        d_f = torch.from_numpy(f4).cuda()
+        d_v = torch.from_numpy(np.ascontiguousarray(f4[:, :3])).cuda()
+
+        def products():
+            MF = torch.ones((n, 3), dtype=torch.float32, device="cuda")
+            check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+            out = torch.full((n, 3), 7.0, dtype=torch.float32, device="cuda")
+            check(pse.lib.uammd_pse_near_dot(pse.near, _ptr(pd.getPos()), _ptr(d_v), n, _ptr(out), current_stream()))
+            return MF.cpu().numpy(), out.cpu().numpy()
+        a = products()
+        a2 = products()                                    # the records are reused: the same bits
+        assert np.array_equal(a[0], a2[0]) and np.array_equal(a[1], a2[1])
+        check(pse.lib.uammd_pse_near_set_option(pse.near, b"pair_list", 0))
+        b = products()
+        check(pse.lib.uammd_pse_near_set_option(pse.near, b"pair_list", 1))
+        expect = np.zeros((n, 3), np.float32)
+        ref.near_mdot(pos, f4, expect)
+        scale = np.abs(expect).max()
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-6 * scale
+        assert np.abs(a[1] - expect).max() <= 1e-6 * scale and np.abs(a[0] - 1.0 - expect).max() <= 2e-6 * max(1.0, scale)
+        if cluster:
+            assert np.array_equal(a[1], b[1])              # more than a hit list holds: both runs took the scanning product
+        # a position write: new list, new records
+        pos2 = pos.copy()
+        pos2[:, :3] = np.random.default_rng(99).uniform(-L / 2, L / 2, (n, 3))
+        pd.getPos("write").copy_(torch.from_numpy(pos2).cuda())
+        c = products()
+        expect2 = np.zeros((n, 3), np.float32)
+        ref.near_mdot(pos2, f4, expect2)
+        assert np.abs(c[1] - expect2).max() <= 1e-6 * np.abs(expect2).max()

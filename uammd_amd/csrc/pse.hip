@@ -38,8 +38,18 @@ struct PSENear {
   const void *listPos = nullptr;
   hipStream_t listStream = nullptr;
   DeviceBuffer sortedOut;   // Lanczos result in cell order
+  // Pair records (option "pair_list", default 1; used with "lazy_list"): the near field is applied ~8 times per step (the deterministic
+  // product + the Lanczos iterations) to positions that do not move in between, so the pairs inside the cut-off — and everything about
+  // a pair that does not depend on the vector: F, (G - F) / r^2, the distance vector — are found ONCE per list build
+  // (k_pse_pairs_build: k_pse_near8's scan, the hits written out instead of summed) and every product is a stream over 24-byte records
+  // (k_pse_near_pairs: two dependent loads per particle instead of ~17).
+  bool pairList = true, pairsValid = false, pairsUnfit = false;
+  DeviceBuffer recA, recB, pairRange, pairCursor;  // float4 (F, (G - F) / r2, rx, ry) | float2 (rz, j) per record; int2 (first, count) per particle
+  size_t pairCap = 0;        // records allocated
+  int *pairTotalHost = nullptr;  // pinned: {records used, a particle overflowed its hit list}
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
+    if (pairTotalHost) (void)hipHostFree(pairTotalHost);
   }
 };
 
@@ -347,6 +357,181 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near8(const float4 *__restri
   }
 }
 
+// ---- pair records ---------------------------------------------------------------------------------------------------------------------
+// k_pse_near8's scan (same mapping, same superset test), but a hit is EVALUATED ONCE INTO A RECORD instead of being summed: the table
+// values and the distance vector of a pair do not depend on the vector the mobility is applied to.  A workgroup reserves the records of
+// its 32 particles with one atomic (particle p's run is contiguous: first[p], count[p]); a pair that fails the exact cut-off after
+// passing the scan's keeps its slot with F = C = 0 (adds +0).  A particle with more hits than the list holds (kNearCap) raises
+// status[1]: the host then stays on k_pse_near8 for this handle.
+template <bool SHEAR>
+__global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__restrict__ sortPos, const uint *__restrict__ cellStart,
+                                                                 const int *__restrict__ cellEnd, uint validCell, int N, GridT<float> grid,
+                                                                 real3f L, float shear, float rcut2, TableView tab, float4 *__restrict__ recA,
+                                                                 float2 *__restrict__ recB, int2 *__restrict__ pairRange,
+                                                                 int *__restrict__ status, long long cap) {
+  __shared__ int hitList[kNearBlock / kNearGroup][kNearCap];
+  __shared__ int2 ranges[kNearBlock / kNearGroup][29];
+  __shared__ int groupCount[kNearBlock / kNearGroup], blockBase;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & (kNearGroup - 1), gbase = lane & ~(kNearGroup - 1);
+  const int grp = threadIdx.x / kNearGroup;
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * (kNearBlock / kNearGroup) + grp;
+  const bool active = id < N;
+  const float4 pi = sortPos[active ? id : 0];
+  const int3 n = grid.cellDim;
+  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+  const int numberNeighbourCells = npx * npy * npz;
+  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+  const real3f invL{1.0f / L.x, 1.0f / L.y, 1.0f / L.z};
+  const float rcut2s = rcut2 * 1.00001f + 1e-30f;
+  int first4[4], last4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cc = sub + kNearGroup * q;
+    first4[q] = 0; last4[q] = 0;
+    if (active && cc < numberNeighbourCells) {
+      int3 cellj = celli;
+      if (npx > 1) cellj.x += cc % 3 - 1;
+      if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+      if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+      cellj.x = grid.pbc_x(cellj.x);
+      cellj.y = grid.pbc_y(cellj.y);
+      cellj.z = grid.pbc_z(cellj.z);
+      if (!(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z)) {
+        const int icellj = grid.getCellIndex(cellj);
+        const uint cs = cellStart[icellj];
+        if (cs >= validCell) { first4[q] = (int)(cs - validCell); last4[q] = cellEnd[icellj]; }
+      }
+    }
+  }
+  int nR = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int len = last4[q] - first4[q];
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < kNearGroup; o <<= 1) {
+      const int u = __shfl_up(incl, o, kNearGroup);
+      if (sub >= o) incl += u;
+    }
+    const uint mine = (uint)(__ballot(len > 0) >> gbase) & 0xffu;
+    if (len > 0) ranges[grp][nR + __popc(mine & ((1u << sub) - 1u))] = make_int2(first4[q], total + incl - len);
+    nR += __popc(mine);
+    total += __shfl(incl, kNearGroup - 1, kNearGroup);
+  }
+  if (sub == 0) ranges[grp][nR] = make_int2(0, total);
+  int c = 0, cnt = 0;
+  bool over = false;
+  constexpr int kRows = 2;
+  for (int t0 = 0; __any(t0 < total); t0 += kRows * kNearGroup) {
+    int j[kRows];
+    float4 pj[kRows];
+    bool in[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const int t = t0 + u * kNearGroup + sub;
+      in[u] = t < total;
+      j[u] = 0;
+      pj[u] = pi;
+      if (in[u]) {
+        while (t >= ranges[grp][c + 1].y) ++c;
+        const int2 r = ranges[grp][c];
+        j[u] = r.x + (t - r.y);
+        pj[u] = sortPos[j[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      const bool hit = in[u] && scan_distance2<SHEAR>(pi, pj[u], L, invL, shear) < rcut2s;
+      const unsigned long long m = __ballot(hit);
+      const uint mine = (uint)(m >> gbase) & 0xffu;
+      const int at = cnt + __popc(mine & ((1u << sub) - 1u));
+      if (hit && at < kNearCap) hitList[grp][at] = j[u];
+      cnt += __popc(mine);
+    }
+  }
+  if (cnt > kNearCap) { over = true; cnt = kNearCap; }
+  if (!active) cnt = 0;
+  if (sub == 0) groupCount[grp] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int g = 0; g < kNearBlock / kNearGroup; ++g) tot += groupCount[g];
+    blockBase = tot ? atomicAdd(&status[0], tot) : 0;
+  }
+  if (__any(over) && lane == 0) status[1] = 1;
+  __syncthreads();
+  long long off = blockBase;
+  for (int g = 0; g < grp; ++g) off += groupCount[g];
+  if (active && sub == 0) pairRange[id] = make_int2((int)off, off + cnt <= cap ? cnt : 0);   // (past the capacity: the host grows the arrays and builds again)
+  if (off + cnt > cap) return;
+  for (int k = sub; k < cnt; k += kNearGroup) {
+    const int j = hitList[grp][k];
+    const real3f rij = scan_rij<SHEAR>(pi, sortPos[j], L, invL, shear);
+    const float r2 = dot3(rij, rij);
+    float f = 0.0f, cc = 0.0f;
+    if (r2 < rcut2) {
+      const float2 fg = table_get(tab, sqrtf(r2));
+      f = fg.x;
+      cc = r2 == 0.0f ? 0.0f : (fg.y - fg.x) * (1.0f / r2);
+    }
+    recA[off + k] = make_float4(f, cc, rij.x, rij.y);
+    recB[off + k] = make_float2(rij.z, __int_as_float(j));
+  }
+}
+
+// Mv_i (+)= sum over i's records of F v_j + C (r . v_j) r  (RPYNearTransverser::compute, NearField.cuh:154-196, with (G - F) / r^2 folded
+// into C when the record was made: one rounding per pair apart from k_pse_near8's terms).  Eight lanes per particle; a particle's records
+// are contiguous: the group's loads are one 128-byte and one 64-byte segment per eight records, all of a particle's records and then all
+// of its v_j in flight together (up to four rounds: 32 records; longer runs loop).
+template <int VSTRIDE, bool INDIRECT, bool ACCUM>
+__global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__restrict__ recA, const float2 *__restrict__ recB,
+                                                                const int2 *__restrict__ pairRange, const float *__restrict__ v,
+                                                                const int *__restrict__ groupIndex, int N, float *__restrict__ Mv) {
+  const int sub = threadIdx.x & (kNearGroup - 1);
+  const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * (kNearBlock / kNearGroup) + threadIdx.x / kNearGroup;
+  const bool active = id < N;
+  const int2 rg = active ? pairRange[id] : make_int2(0, 0);
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  constexpr int U = 4;
+  for (int k0 = sub; k0 < rg.y; k0 += U * kNearGroup) {
+    float4 a[U];
+    float2 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * kNearGroup;
+      const bool in = k < rg.y;
+      a[u] = in ? recA[(size_t)rg.x + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      b[u] = in ? recB[(size_t)rg.x + k] : make_float2(0.f, __int_as_float(id));
+    }
+    float vx[U], vy[U], vz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = __float_as_int(b[u].y);
+      const float *vp = v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j);
+      vx[u] = vp[0]; vy[u] = vp[1]; vz[u] = vp[2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const real3f rij{a[u].z, a[u].w, b[u].x};
+      const float gm = a[u].y * dot3(rij, real3f{vx[u], vy[u], vz[u]});
+      tx += fmaf(gm, rij.x, a[u].x * vx[u]);
+      ty += fmaf(gm, rij.y, a[u].x * vy[u]);
+      tz += fmaf(gm, rij.z, a[u].x * vz[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < kNearGroup; o <<= 1) {
+    tx += __shfl_xor(tx, o, 64);
+    ty += __shfl_xor(ty, o, 64);
+    tz += __shfl_xor(tz, o, 64);
+  }
+  if (active && sub == 0) {
+    float *o = Mv + 3 * (size_t)(INDIRECT ? groupIndex[id] : id);
+    if (ACCUM) { o[0] += tx; o[1] += ty; o[2] += tz; }
+    else { o[0] = tx; o[1] = ty; o[2] = tz; }
+  }
+}
+
 // ---- AUTO where the table has its packed copy: one WAVE per cell, candidates staged in LDS ------------------------------------------------
 // k_pse_near8 still issues ~150 global load instructions per wave (a candidate load per scan step, position + v + two table reads per
 // hit) and every 64-lane load costs the CU's one address unit ~16 clocks whatever it fetches: 59 us at N = 1e5.  All particles of a cell
@@ -541,6 +726,7 @@ static TableView make_view(const PSENear *p) {
 static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st) {
   if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N && p->listStream == st) return 0;
   p->listValid = false;  // (valid again only when the build below went through: a failed build must not be reused)
+  p->pairsValid = false;
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
   const float rc = p->rcut * safety;
@@ -557,9 +743,51 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   return 0;
 }
 
+static TableView make_view(const PSENear *p);
+// the pair records of the current list (see PSENear::pairList).  One host read per build: the number of records, to grow the arrays
+// when they do not fit (the build then runs again).
+static int pse_build_pairs(PSENear *p, hipStream_t st) {
+  const int N = p->N;
+  if (!p->pairTotalHost) UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, 2 * sizeof(int)));
+  if (int e = p->pairRange.reserve(sizeof(int2) * (size_t)N)) return e;
+  if (int e = p->pairCursor.reserve(2 * sizeof(int))) return e;
+  if (p->pairCap < (size_t)N) p->pairCap = (size_t)48 * (size_t)N;
+  const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
+  const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (p->pairCap > (size_t)0x7fffff00) { p->pairsUnfit = true; return 0; }   // (record indices are ints)
+    if (int e = p->recA.reserve(sizeof(float4) * p->pairCap)) return e;
+    if (int e = p->recB.reserve(sizeof(float2) * p->pairCap)) return e;
+    UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, 2 * sizeof(int), st));
+#define UH_PAIRS(SH)                                                                                                                \
+    hipLaunchKernelGGL((k_pse_pairs_build<SH>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                     \
+                       (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb,       \
+                       p->shear, p->rcut * p->rcut, make_view(p), (float4 *)p->recA.ptr, (float2 *)p->recB.ptr,                     \
+                       (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap)
+    if (p->shear != 0.0f) UH_PAIRS(true); else UH_PAIRS(false);
+#undef UH_PAIRS
+    UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    UH_CHECK(hipStreamSynchronize(st));
+    if (p->pairTotalHost[1]) { p->pairsUnfit = true; return 0; }   // a particle with more neighbours than a hit list holds: k_pse_near8 from here on
+    if ((size_t)p->pairTotalHost[0] <= p->pairCap) { p->pairsValid = true; return 0; }
+    p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
+  }
+  p->pairsUnfit = true;
+  return 0;
+}
+
 static int g_ablate = getenv("UAMMD_PSE_ABLATE") ? atoi(getenv("UAMMD_PSE_ABLATE")) : 0;
 #define UH_NEAR8(VS, IND, ACC)                                                                                                       \
   do {                                                                                                                               \
+    if (p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1) {                                        \
+      if (!p->pairsValid) { if (int e_ = pse_build_pairs(p, st)) return e_; }                                                        \
+      if (p->pairsValid) {                                                                                                           \
+        const dim3 gp((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));                                                \
+        hipLaunchKernelGGL((k_pse_near_pairs<VS, IND, ACC>), gp, dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr,               \
+                           (const float2 *)p->recB.ptr, (const int2 *)p->pairRange.ptr, d_v, (const int *)p->cl.index.ptr, N, d_Mv); \
+        break;                                                                                                                       \
+      }                                                                                                                              \
+    }                                                                                                                                \
     if (p->nearKernel == 0) {                                                                                                        \
       const int ncells = p->cl.grid.cellDim.x * p->cl.grid.cellDim.y * p->cl.grid.cellDim.z;                                         \
       const dim3 gc((ncells + 3) / 4);                                                                                               \
@@ -777,10 +1005,13 @@ int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain) {
 // "exact_order" (0): 1 = the thread-per-particle walk in the reference's summation order instead of the eight-lanes-per-particle kernel.
 // "lazy_list" (0): 1 = rebuild the cell list only after uammd_pse_near_positions_changed (CellList::update's needsRebuild,
 // NeighbourList/CellList.cuh:134-136,192-204) or when the position array / particle count of the call changes.
+// "pair_list" (1): with "lazy_list", the pairs of a list are evaluated once into records and every product streams them (PSENear::pairList);
+// 0 = every product scans the cells.  (A particle with more than 96 neighbours inside the cut-off sends the handle to the scanning product.)
 int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_pse_near_set_option: null argument"); return -1; }
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
+  if (std::string(name) == "pair_list") { p->pairList = value != 0; return 0; }
   if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
   if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
