@@ -483,6 +483,10 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
 // into C when the record was made: one rounding per pair apart from k_pse_near8's terms).  Eight lanes per particle; a particle's records
 // are contiguous: the group's loads are one 128-byte and one 64-byte segment per eight records, all of a particle's records and then all
 // of its v_j in flight together (up to four rounds: 32 records; longer runs loop).
+// (Measured and not kept: the Lanczos recurrence's k_l_c of the previous iteration and k_l_a inside this kernel — the input scaled by
+// 1 / |w| on the way, every workgroup re-summing the |w|^2 partials, the row's update and its partial of w . v_i in the epilogue: two
+// launches per iteration instead of four, product 14.2 -> 17.2 us, k_l_b 4.8 -> 7.3 us on 3125 partials, near noise 328 -> 320 us: 2.5 %
+// for an interface between the solver and the matrix.)
 template <int VSTRIDE, bool INDIRECT, bool ACCUM>
 __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__restrict__ recA, const float2 *__restrict__ recB,
                                                                 const int2 *__restrict__ pairRange, const float *__restrict__ v,
