@@ -1,5 +1,4 @@
-"""The solver's own mixed-radix FFT pipeline (csrc/fcm_fft.hpp: axis lengths 2^a 3^b 5^c — what Grid's nextFFTWiseSize3D hands out up to its
-factors 7 and 11) against rocFFT + the stand-alone Fourier-space kernel on the same handle type, and against the oracle."""
+"""The solver's own mixed-radix FFT pipeline (csrc/fcm_fft.hpp: axis lengths 2^a 3^b 5^c 7^d 11^e — what Grid's nextFFTWiseSize3D hands out) against rocFFT + the stand-alone Fourier-space kernel on the same handle type, and against the oracle."""
 import math
 
 import numpy as np
@@ -9,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GRIDS = [(54, 54, 54), (48, 40, 60), (96, 80, 50), (108, 108, 108), (30, 36, 20), (20, 12, 16), (120, 90, 150), (162, 128, 100),
-         (250, 256, 12), (64, 100, 27), (32, 16, 500), (18, 250, 8), (128, 128, 128), (36, 30, 25)]
+         (250, 256, 12), (64, 100, 27), (32, 16, 500), (18, 250, 8), (128, 128, 128), (36, 30, 25),
+         (112, 84, 98), (110, 66, 44), (28, 22, 14), (154, 126, 242), (56, 121, 49)]
 
 
 def _inputs(cells, n, seed):
@@ -43,7 +43,7 @@ def test_fcm_own_fft_matches_rocfft(hip, cells):
         assert np.linalg.norm(a - b) <= 1e-5 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("cells", [(54, 54, 54), (30, 36, 20), (48, 40, 60)], ids=["54", "30x36x20", "48x40x60"])
+@pytest.mark.parametrize("cells", [(54, 54, 54), (30, 36, 20), (48, 40, 60), (28, 22, 42)], ids=["54", "30x36x20", "48x40x60", "28x22x42"])
 def test_fcm_own_fft_vs_oracle(hip, o32, cells):
     from oracle.fcm import FCMOracle
     n = 500

@@ -1148,8 +1148,8 @@ template <int SIGN> static void fft_launch_lines(float2 *g, int n, int nkx, int 
 // Sizes the LDS passes serve without asking for more than the 64 KB of dynamic LDS a launch gets by default: the y pass holds 16 lines
 // (8 (n + 16 (n + 1)) bytes: 35 KB at 256, 69.8 KB at 512), the fused z pass 12 lines of nz (53 KB at 512), the row passes <= 25 KB up
 // to 1024.  Anything else takes rocFFT + k_fcm_kspace.
-// (an axis the mixed-radix passes serve: 2^a 3^b 5^c within [lo, hi])
-static bool fft_axis_ok(int n, int lo, int hi) { int e2, e3, e5; return n >= lo && n <= hi && fft_factors(n, e2, e3, e5); }
+// (an axis the mixed-radix passes serve: 2^a 3^b 5^c 7^d 11^e within [lo, hi])
+static bool fft_axis_ok(int n, int lo, int hi) { int e[5]; return n >= lo && n <= hi && fft_factors(n, e); }
 static bool fcm_custom_fft_usable(const FCM *f) {
   return f->customFFT && f->grid.cellDim.x % 2 == 0 && fft_axis_ok(f->grid.cellDim.x, 16, 512) && fft_axis_ok(f->grid.cellDim.y, 2, 256) && fft_axis_ok(f->grid.cellDim.z, 2, 512) &&
          f->planeReal == (size_t)f->nxpad * f->grid.cellDim.y * f->grid.cellDim.z;

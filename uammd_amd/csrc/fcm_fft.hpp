@@ -2,8 +2,8 @@
 // transform) + the Fourier-space kernel + the interleaving copy, with the z transform, the Stokes / noise operator and the inverse z
 // transform fused into one kernel that holds a tile of z-lines in LDS.
 //
-// Replaces, for axis lengths 2^a 3^b 5^c (x even, x and z <= 512, y <= 256) — the sizes Grid's nextFFTWiseSize3D hands out, up to its
-// factors 7 and 11 (anything else keeps rocFFT):
+// Replaces, for axis lengths 2^a 3^b 5^c 7^d 11^e (x even, x and z <= 512, y <= 256) — the sizes Grid's nextFFTWiseSize3D hands out
+// (anything else keeps rocFFT):
 //   cufftExecR2C / cufftExecC2R (batched 3-D)                      Integrator/BDHI/FCM/FCM_impl.cuh:399-411, :544-581
 //   forceFourier2Vel + fourierBrownianNoise between them           FCM_impl.cuh:375-397, :437-512
 // Conventions are cuFFT's: forward exp(-i...), inverse exp(+i...), both unnormalised (1/N lives in the Stokes operator), the
@@ -15,7 +15,7 @@
 //   k_fft_z_fused      z: a tile of consecutive (ky, kx) nodes x all nz x the three components in LDS: forward, operator, inverse
 //   k_fft_x_c2r        rows back: three components of 16 rows -> the planar real grids or the gather's interleaved float4 grid
 // All FFTs are Stockham autosort on LDS lines, mixed radix: the factor 2^a as radix-8 passes with one or two radix-4 (or one radix-2)
-// passes in front, then radix-3 and radix-5 passes; a pass stages its butterflies in registers (read all, barrier, write all, barrier),
+// passes in front, then radix-3, 5, 7 and 11 passes; a pass stages its butterflies in registers (read all, barrier, write all, barrier),
 // twiddles from a table in LDS.  Index arithmetic is shifts for power-of-two lengths and an exact float reciprocal otherwise (IDiv).
 #pragma once
 // (included by fcm.hip INSIDE namespace uammd_hip, after the Fourier-space operator it fuses)
@@ -92,6 +92,41 @@ template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
     v[4] = csub(a1, b1);
     v[2] = cadd(a2, b2);
     v[3] = csub(a2, b2);
+  } else if constexpr (R == 7 || R == 11) {
+    // an odd prime: with s_r = v_r + v_(R-r), d_r = v_r - v_(R-r) (r = 1 .. H = (R - 1) / 2) and k = r m mod R,
+    //   y_m, y_(R-m) = (v_0 + sum_r cos(2 pi k / R) s_r) -+ i sum_r sin(2 pi k / R) d_r   (forward; the inverse swaps the two)
+    constexpr int H = (R - 1) / 2;
+    constexpr float C7[3] = {0.62348980185873359439f, -0.22252093395631433737f, -0.90096886790241903498f};
+    constexpr float S7[3] = {0.78183148246802980363f, 0.97492791218182361934f, 0.43388373911755823142f};
+    constexpr float C11[5] = {0.84125353283118120551f, 0.41541501300188643508f, -0.14231483827328500480f, -0.65486073394528498959f,
+                              -0.95949297361449736865f};
+    constexpr float S11[5] = {0.54064081745559755543f, 0.90963199535451833011f, 0.98982144188093279524f, 0.75574957435425826890f,
+                              0.28173255684142967104f};
+    float2 s[H], d[H];
+#pragma unroll
+    for (int r = 1; r <= H; ++r) { s[r - 1] = cadd(v[r], v[R - r]); d[r - 1] = csub(v[r], v[R - r]); }
+    float2 y0 = v[0];
+#pragma unroll
+    for (int r = 0; r < H; ++r) y0 = cadd(y0, s[r]);
+    float2 out[R];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+      float2 a = v[0], b = make_float2(0.0f, 0.0f);
+#pragma unroll
+      for (int r = 1; r <= H; ++r) {
+        const int k = (r * m) % R, kk = k <= H ? k : R - k;
+        const float c = R == 7 ? C7[kk - 1] : C11[kk - 1];
+        const float sn = (R == 7 ? S7[kk - 1] : S11[kk - 1]) * (k <= H ? 1.0f : -1.0f);
+        a = make_float2(fmaf(c, s[r - 1].x, a.x), fmaf(c, s[r - 1].y, a.y));
+        b = make_float2(fmaf(sn, d[r - 1].x, b.x), fmaf(sn, d[r - 1].y, b.y));
+      }
+      const float2 q = mul_mi(b);
+      out[m] = cadd(a, q);
+      out[R - m] = csub(a, q);
+    }
+    v[0] = y0;
+#pragma unroll
+    for (int m = 1; m < R; ++m) v[m] = out[m];
   } else {  // 8 = 2 x 4: sums and differences four apart, the differences turned by W8^r, then a 4-point DFT of either half
     float2 e[4], o[4];
 #pragma unroll
@@ -227,13 +262,13 @@ UH_D void fft_pass_strided_p2(float2 *buf, int LS, int ES, int log2N, int log2Ns
   __syncthreads();
 }
 
-// N = 2^a 3^b 5^c?  (host and device)
-inline __host__ __device__ bool fft_factors(int n, int &e2, int &e3, int &e5) {
-  e2 = e3 = e5 = 0;
+// N = 2^a 3^b 5^c 7^d 11^e?  (host and device; e[] = the exponents of 2, 3, 5, 7, 11 — the factors of Grid's nextFFTWiseSize3D)
+inline __host__ __device__ bool fft_factors(int n, int (&e)[5]) {
+  const int p[5] = {2, 3, 5, 7, 11};
+  for (int k = 0; k < 5; ++k) e[k] = 0;
   if (n < 1) return false;
-  while (n % 2 == 0) { n /= 2; ++e2; }
-  while (n % 3 == 0) { n /= 3; ++e3; }
-  while (n % 5 == 0) { n /= 5; ++e5; }
+  for (int k = 0; k < 5; ++k)
+    while (n % p[k] == 0) { n /= p[k]; ++e[k]; }
   return n == 1;
 }
 
@@ -243,9 +278,10 @@ inline __host__ __device__ bool fft_factors(int n, int &e2, int &e3, int &e5) {
 // a = 3 n8 + 2 n4 + n2 with the small passes first.
 template <int SIGN, int MAXB, int NT, bool STRIDED, bool P2>
 UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const float2 *tw, int twStride, int tid) {
-  int e2, e3, e5;
-  if (P2) { e2 = 31 - __builtin_clz((unsigned)N); e3 = e5 = 0; }
-  else fft_factors(N, e2, e3, e5);
+  int e[5] = {0, 0, 0, 0, 0};
+  if (P2) e[0] = 31 - __builtin_clz((unsigned)N);
+  else fft_factors(N, e);
+  const int e2 = e[0], e3 = e[1], e5 = e[2];
   int n8 = e2 / 3, n4 = 0, n2 = 0;
   if (e2 % 3 == 2) n4 = 1;
   else if (e2 % 3 == 1) { if (n8 > 0) { n8 -= 1; n4 = 2; } else n2 = 1; }
@@ -270,6 +306,8 @@ UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const floa
     for (int a = 0; a < n8; ++a, Ns *= 8) fft_pass<8, SIGN, (MAXB + 1) / 2, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < e3; ++a, Ns *= 3) fft_pass<3, SIGN, (4 * MAXB + 2) / 3, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < e5; ++a, Ns *= 5) fft_pass<5, SIGN, (4 * MAXB + 4) / 5, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < e[3]; ++a, Ns *= 7) fft_pass<7, SIGN, (4 * MAXB + 6) / 7, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < e[4]; ++a, Ns *= 11) fft_pass<11, SIGN, (4 * MAXB + 10) / 11, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
   }
 }
 template <int SIGN, int MAXB, int NT, bool P2>

@@ -531,12 +531,19 @@ class Potential:
 class PairForces(Interactor):
     """PairForces<Potential::LJ, CellList> (PairForces.cu:43-78): neighbour list unless the box is <= 3 rc in
     every direction, then all pairs."""
+    _said_verlet = False
 
     def __init__(self, pd, box, pot, nl=None, algo=0, pg=None):
         self.lib = _lib.load()
         if isinstance(pd, ParticleGroup):          # PairForces(pg, par, pot) constructor of the reference
             pg, pd = pd, pd.getParticleData()
         self.pd, self.box, self.pot, self.nl, self.algo, self.pg = pd, box, pot, nl, algo, pg
+        if isinstance(nl, VerletList) and not PairForces._said_verlet:
+            # (as the C++ class: the cell list rebuilt every step is the faster neighbour list on this GPU, DESIGN.md 5.2b)
+            PairForces._said_verlet = True
+            import logging
+            logging.getLogger("uammd_amd").info("[PairForces] VerletList chosen: on MI355X PairForces<LJ, CellList> is ~1.9x faster per "
+                                                "step for dense liquids (DESIGN.md 5.2b)")
 
     def fused_gj_arguments(self):
         """What uammd_verletnvt_gj_lj_step needs from this interactor, or None when it is not the plain PairForces<LJ, CellList> on all
