@@ -611,6 +611,12 @@ int uammd_lanczos_destroy(uammd_lanczos *h);
 int uammd_lanczos_run(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v,
                       float tolerance, int n, void *stream, int *iterations);
 int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
+/* "defer_checks" (default 1): the reference checks convergence at every iteration from an adaptive first step on
+ * (LanczosAlgorithm.cu:218-232); here the checks of the iterations before the one the PREVIOUS run stopped at are evaluated together
+ * at that iteration — one host round trip and one pass over the Krylov basis instead of one per iteration; the run still stops at
+ * the first iteration whose error passes, with that iteration's estimate (the reference's result and iteration count).  0 = every
+ * check as its iteration completes. */
+int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value);
 /* Vectors sharded over several ranks (Lanczos row): `n` is then the LOCAL length, the matvec callback computes the
  * local rows of M v, and every dot product / norm of the recurrence is completed by `reduce`, which must sum d_values[0..count)
  * in place over all ranks on `stream` (RCCL all-reduce of 1 float, 3 per iteration + 2 per convergence check).  ownsFirstElement:

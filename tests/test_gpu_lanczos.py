@@ -80,3 +80,31 @@ def test_large_vector(hip):
     solver = hip.BDHI.LanczosSolver()
     Bv, it = _run(hip, solver, lambda x, y: torch.mul(d, x, out=y), v, 1e-5)
     assert np.abs(Bv - np.sqrt(dm) * v).max() <= 1e-4 * np.abs(v).max() and it < 30
+
+
+@pytest.mark.parametrize("size,spread", [(300, 50.0), (2000, 400.0), (64, 3.0)])
+def test_deferred_checks_stop_where_the_reference_does(hip, size, spread):
+    """Deferred convergence checks (lanczos_run: the checks before the iteration the previous run stopped at are evaluated together, one
+    host round trip and one pass over the Krylov basis) against a check after every iteration: a sequence of runs on matrices whose
+    required iteration count moves up and down — the stopping iteration, hence lastRunRequiredSteps and the adaptive first-check step,
+    and the result must be the same run by run (the same estimates from the same H and V: bit for bit)."""
+    rng = np.random.default_rng(size)
+    out = {}
+    for defer in (1, 0):
+        solver = hip.BDHI.LanczosSolver()
+        solver.setOption("defer_checks", defer)
+        res = []
+        r2 = np.random.default_rng(size + 1)
+        for run in range(12):
+            # condition number varies from run to run: easy (few iterations), hard (many), easy again
+            cond = [2.0, spread, spread, 5.0, 5.0, spread, 1.5, 1.5, spread, spread, 3.0, spread][run]
+            d = torch.from_numpy(np.linspace(1.0, cond, size).astype(np.float32)).cuda()
+            v = r2.normal(0, 1, size)
+            Bv, it = _run(hip, solver, lambda x, y: torch.mul(d, x, out=y), v, 1e-5)
+            res.append((Bv, it, solver.getLastRunRequiredSteps()))
+            theory = np.sqrt(np.linspace(1.0, cond, size)) * v
+            assert np.linalg.norm(Bv - theory) <= 2e-4 * np.linalg.norm(theory)
+        out[defer] = res
+    for a, b in zip(out[1], out[0]):
+        assert a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[0], b[0])

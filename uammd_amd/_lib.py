@@ -243,6 +243,7 @@ SIGNATURES = {
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),
     "uammd_lanczos_set_iteration_hard_limit": (_i, [_vp, _i]),
+    "uammd_lanczos_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_lanczos_set_allreduce": (_i, [_vp, _vp, _vp, _i]),
     "uammd_lanczos_get_last_run_required_steps": (_i, [_vp, C.POINTER(_i)]),
     "uammd_rpy_nbody_mdot": (_i, [_vp, _vp, _i, _vp, _f, _f, _i, _vp, _vp]),

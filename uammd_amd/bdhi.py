@@ -760,6 +760,10 @@ class LanczosSolver:
     def setIterationHardLimit(self, n):
         check(self.lib.uammd_lanczos_set_iteration_hard_limit(self.h, int(n)))
 
+    def setOption(self, name, value):
+        """"defer_checks" (1): the convergence checks before the iteration the previous run stopped at are evaluated together."""
+        check(self.lib.uammd_lanczos_set_option(self.h, name.encode(), int(value)))
+
     def setAllReduce(self, group=None, owns_first_element=None, enabled=True):
         """Sharded vectors (one slice per rank): the dot products of the recurrence are summed over `group` with
         torch.distributed.all_reduce (RCCL on the GPUs; host staging under gloo, which cannot move device memory)."""

@@ -24,19 +24,26 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 
 namespace uammd_hip {
 
 constexpr int kLB = 256;       // threads per block
 constexpr int kLParts = 256;   // reduction partials (one per block)
 constexpr int kLDevM = 32;     // Krylov sizes whose convergence check goes through the host-mapped block (k_l_publish)
+constexpr int kLBatch = 8;     // convergence checks evaluated together (see lanczos_run: deferred checks)
+// host-mapped status block (doubles): [0] seqA  [1] seqB  [3] status  [4] seqY  [16 .. 16 + kLBatch) errors  [64 .. 96) hdiag  [96 .. 128) hsup
+//                                     [128 + 32 k .. ) y of batched check k
+constexpr int kLStatDoubles = 128 + 32 * kLBatch;
 
 template <class T> struct LanczosT {
   DeviceBuffer V, w, Bold, parts, scal, ycoef;
+  DeviceBuffer estimates;   // the K results of a batched convergence check
   int capCols = 0, capN = 0;
   int check_convergence_steps = 3;  // Solver::Solver(), LanczosAlgorithm.cu:175
   int iterationHardLimit = 200;
   int lastRunRequiredSteps = 0;
+  bool deferChecks = true;   // evaluate the convergence checks of several iterations together (lanczos_run)
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
   uammd_allreduce_fn reduce = nullptr;   // (single precision only)
   void *reduceCtx = nullptr;
@@ -223,6 +230,105 @@ __global__ void __launch_bounds__(kLB) k_l_error(const T *__restrict__ parts, in
   }
 }
 
+// ---- batched checks: K consecutive estimates from one pass over V -----------------------------------------------------------------
+// estimate k (k < K) is the Krylov result of size m0 + k: Bz_k = |z| V[:, :m0 + k] y_k; the check of that iteration compares it with the
+// one before (Bz_(-1) = Bold, the last estimate of an earlier check or zero).  Every Bz_k is stored (est + k n), the last one also into
+// Bz and Bold; partials of |Bz_(k-1)|^2 and |Bz_k - Bz_(k-1)|^2 at parts[(2 k) kLParts + block] and parts[(2 k + 1) kLParts + block].
+// Column by column in ascending order, then the product by |z|: the arithmetic of k_l_estimate.
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_estimate_batch(const T *__restrict__ V, int n, int m0, int K, const T *__restrict__ y /* [K][kLDevM] */,
+                                                          const T *__restrict__ normz, T *__restrict__ est, T *__restrict__ Bz,
+                                                          T *__restrict__ Bold, T *__restrict__ parts) {
+  __shared__ T sh[16];
+  __shared__ T ys[kLBatch * kLDevM];
+  for (int k = threadIdx.x; k < K * kLDevM; k += kLB) ys[k] = y[k];
+  __syncthreads();
+  const T nz = *normz;
+  T a[kLBatch], b[kLBatch];
+#pragma unroll
+  for (int k = 0; k < kLBatch; ++k) a[k] = b[k] = T(0);
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
+    T s[kLBatch];
+#pragma unroll
+    for (int k = 0; k < kLBatch; ++k) s[k] = T(0);
+    const int mLast = m0 + K - 1;
+    for (int c = 0; c < mLast; ++c) {
+      const T v = V[(size_t)c * n + i];
+#pragma unroll
+      for (int k = 0; k < kLBatch; ++k)
+        if (k < K && c < m0 + k) s[k] = fma_(v, ys[k * kLDevM + c], s[k]);
+    }
+    T prev = Bold[i];
+#pragma unroll
+    for (int k = 0; k < kLBatch; ++k)
+      if (k < K) {
+        const T r = s[k] * nz;
+        a[k] = fma_(prev, prev, a[k]);
+        const T d = r - prev;
+        b[k] = fma_(d, d, b[k]);
+        est[(size_t)k * n + i] = r;
+        prev = r;
+      }
+    Bz[i] = prev;
+    Bold[i] = prev;
+  }
+  // the 2 K partial sums of the workgroup through ONE barrier (2 K block_sum calls were 4 K barriers: a batch of five checks spent more
+  // time in them than in its pass over V)
+  __shared__ T red[kLB / 64][2 * kLBatch];
+#pragma unroll
+  for (int k = 0; k < kLBatch; ++k)
+    if (k < K) {
+      T x = a[k], z = b[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); z += __shfl_xor(z, o, 64); }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * k] = x; red[threadIdx.x >> 6][2 * k + 1] = z; }
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * K) {
+    const int t = threadIdx.x;
+    parts[(size_t)t * kLParts + blockIdx.x] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  }
+  (void)sh;
+}
+// ONE thread waits for the host's K coefficient vectors and hands them to device memory
+template <class T>
+__global__ void k_l_relay_batch(volatile double *__restrict__ stat, int K, double seq, T *__restrict__ ycoef) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    while (stat[4] != seq && ++spins < 200000000L) __builtin_amdgcn_s_sleep(8);
+    ok = stat[4] == seq;
+    if (!ok) stat[3] = -1.0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K * kLDevM; k += blockDim.x) ycoef[k] = ok ? (T)stat[128 + k] : T(0);
+}
+// err_k = |Bz_k - Bz_(k-1)| / |Bz_(k-1)| for the K checks, left with a sequence number where the host can see them
+// (one wave per sum — 2 K waves — and one barrier)
+template <class T>
+__global__ void __launch_bounds__(64 * 2 * kLBatch) k_l_error_batch(const T *__restrict__ parts, int nparts, int K, double *__restrict__ stat, double seq) {
+  __shared__ T tot[2 * kLBatch];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wv < 2 * K) {
+    T x = T(0);
+    for (int j = lane; j < nparts; j += 64) x += parts[(size_t)wv * kLParts + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (lane == 0) tot[wv] = x;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K) stat[16 + threadIdx.x] = fabs(sqrt_(tot[2 * threadIdx.x + 1]) / sqrt_(tot[2 * threadIdx.x]));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    stat[1] = seq;
+  }
+}
+template <class T>
+__global__ void __launch_bounds__(kLB) k_l_copy(const T *__restrict__ src, int n, T *__restrict__ dst) {
+  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) dst[i] = src[i];
+}
+
 // Symmetric tridiagonal eigenproblem by implicit QL with eigenvector accumulation; d (diag, size m) returns the
 // eigenvalues, e (sub-diagonal, e[0..m-2]) is destroyed, z (m x m, row major z[i*m+j]) must be the identity on
 // entry and returns the eigenvectors in its columns.  Returns 0, or i+1 if eigenvalue i failed to converge.
@@ -291,6 +397,12 @@ int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit) {
   reinterpret_cast<Lanczos *>(h)->iterationHardLimit = limit;
   return 0;
 }
+int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value) {
+  if (!h || !name) { set_last_error("uammd_lanczos_set_option: null argument"); return -1; }
+  if (std::string(name) == "defer_checks") { reinterpret_cast<Lanczos *>(h)->deferChecks = value != 0; return 0; }
+  set_last_error("uammd_lanczos_set_option: unknown option %s", name);
+  return -1;
+}
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps) {
   if (!h || !steps) { set_last_error("uammd_lanczos_get_last_run_required_steps: null argument"); return -1; }
   *steps = reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps;
@@ -318,9 +430,9 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
     if (int e = L->V.reserve(sizeof(T) * (size_t)n * cap)) return e;
     if (int e = L->w.reserve(sizeof(T) * (size_t)n)) return e;
     if (int e = L->Bold.reserve(sizeof(T) * (size_t)n)) return e;
-    if (int e = L->parts.reserve(sizeof(T) * 2 * kLParts)) return e;
+    if (int e = L->parts.reserve(sizeof(T) * 2 * kLParts * kLBatch)) return e;
     if (int e = L->scal.reserve(sizeof(T) * (2 * cap + 2))) return e;
-    if (int e = L->ycoef.reserve(sizeof(T) * cap)) return e;
+    if (int e = L->ycoef.reserve(sizeof(T) * std::max(cap, kLBatch * kLDevM))) return e;
     L->capCols = cap;
     L->capN = n;
   }
@@ -346,6 +458,10 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
   std::vector<T> hbuf(2 * cap + 2);
   std::vector<double> dd, ee, zz;
   std::vector<T> yy;
+  // deferred checks (see below): iterations [checkFrom, evalAt) wait for their checks until evalAt
+  int checkFrom = checkConvergenceSteps;
+  int evalAt = std::max(checkConvergenceSteps, std::min(L->deferChecks ? L->lastRunRequiredSteps : 0, checkConvergenceSteps + kLBatch - 1));
+  evalAt = std::min(evalAt, std::min(kLDevM - 1, L->iterationHardLimit - 1));
   for (int i = 0; i < L->iterationHardLimit; ++i) {
     T *vi = V + (size_t)i * n;
     if (int rc = dot(ctx, vi, w, n, stream)) {
@@ -365,21 +481,33 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       return -24;
     }
     if (i >= checkConvergenceSteps && !L->reduce && i + 1 <= kLDevM) {
-      const int m = i + 1;
+      // Deferred checks.  The reference evaluates the estimate and its error at EVERY iteration from check_convergence_steps on
+      // (LanczosAlgorithm.cu:218-232) and stops at the first whose change is within the tolerance; a check is a host round trip and a
+      // pass over V — ~34 us here, against ~30 us for the iteration itself at the PSE size, four of them per run.  But nothing a check
+      // needs is lost by waiting: H only grows (the m x m problem of iteration i is the leading block of any later one) and V keeps its
+      // columns.  So the checks of iterations [checkFrom, i] are evaluated TOGETHER at the iteration the previous run stopped at
+      // (lastRunRequiredSteps: consecutive calls almost always need the same number): one round trip, one pass over V for all of them
+      // (k_l_estimate_batch), and the run still stops at the FIRST iteration whose error passes — with that iteration's estimate, the
+      // reference's result and iteration count.  A run that would have stopped earlier than predicted has done a few iterations for
+      // nothing; one that needs more goes on checking every iteration.
+      if (i < evalAt) continue;
+      const int K = i - checkFrom + 1, m = i + 1, m0 = checkFrom + 1;   // checks of iterations checkFrom .. i, Krylov sizes m0 .. m
       if (!L->hostStat) {
-        UH_CHECK(hipHostMalloc((void **)&L->hostStat, 1024, hipHostMallocMapped | hipHostMallocCoherent));
-        for (int k = 0; k < 128; ++k) L->hostStat[k] = 0.0;
+        UH_CHECK(hipHostMalloc((void **)&L->hostStat, sizeof(double) * kLStatDoubles, hipHostMallocMapped | hipHostMallocCoherent));
+        for (int k = 0; k < kLStatDoubles; ++k) L->hostStat[k] = 0.0;
         UH_CHECK(hipHostGetDevicePointer((void **)&L->devStat, (void *)L->hostStat, 0));
       }
+      if (int e = L->estimates.reserve(sizeof(T) * (size_t)n * kLBatch)) return e;
+      T *est = (T *)L->estimates.ptr;
       L->seq = (L->seq % 1000000u) + 1u;
       const double seq = (double)L->seq;
       volatile double *hs = L->hostStat;
       hs[3] = 0.0;
       hipLaunchKernelGGL(k_l_publish<T>, dim3(1), dim3(64), 0, st, (const T *)hdiag, (const T *)hsup, m, L->devStat, seq);
-      hipLaunchKernelGGL(k_l_relay<T>, dim3(1), dim3(64), 0, st, L->devStat, m, seq, ycoef);
-      hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef,
-                         (const T *)scal, d_Bv, Bold, parts);
-      hipLaunchKernelGGL(k_l_error<T>, dim3(1), dim3(kLB), 0, st, (const T *)parts, g, L->devStat, seq);
+      hipLaunchKernelGGL(k_l_relay_batch<T>, dim3(1), dim3(64), 0, st, L->devStat, K, seq, ycoef);
+      hipLaunchKernelGGL(k_l_estimate_batch<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m0, K, (const T *)ycoef, (const T *)scal, est,
+                         d_Bv, Bold, parts);
+      hipLaunchKernelGGL(k_l_error_batch<T>, dim3(1), dim3(64 * 2 * K), 0, st, (const T *)parts, g, K, L->devStat, seq);
       // The host waits for the GPU's sequence number: it spins for the first 5 ms (the answer is usually microseconds away, and one
       // sleep costs more than a whole check), then polls between 100 us sleeps — no core burnt while a long product or other work
       // queued on the stream runs first — bounded by WALL-CLOCK time (a minute), not by a number of reads.  A wait that does expire releases the queued relay kernel and drains the stream before the error goes out, so that
@@ -405,16 +533,22 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       const auto tA = std::chrono::steady_clock::now();
       if (int e = wait(0)) return e;
       const auto tB = std::chrono::steady_clock::now();
-      dd.assign(m, 0.0);
-      ee.assign(m, 0.0);
-      zz.assign((size_t)m * m, 0.0);
-      for (int k = 0; k < m; ++k) { dd[k] = hs[64 + k]; zz[(size_t)k * m + k] = 1.0; }
-      for (int k = 0; k + 1 < m; ++k) ee[k] = hs[96 + k];
-      const int info = tridiag_ql(dd, ee, zz, m);
-      for (int r = 0; r < m; ++r) {
-        double acc = 0.0;
-        for (int j = 0; j < m; ++j) acc += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
-        hs[8 + r] = (double)(T)acc;
+      int info = 0;
+      for (int k = 0; k < K; ++k) {   // H^(1/2) e1 of the leading mk x mk block, mk = m0 + k
+        const int mk = m0 + k;
+        dd.assign(mk, 0.0);
+        ee.assign(mk, 0.0);
+        zz.assign((size_t)mk * mk, 0.0);
+        for (int r = 0; r < mk; ++r) { dd[r] = hs[64 + r]; zz[(size_t)r * mk + r] = 1.0; }
+        for (int r = 0; r + 1 < mk; ++r) ee[r] = hs[96 + r];
+        const int inf = tridiag_ql(dd, ee, zz, mk);
+        if (inf && !info) info = inf;
+        for (int r = 0; r < kLDevM; ++r) {
+          double acc = 0.0;
+          if (r < mk)
+            for (int j = 0; j < mk; ++j) acc += zz[(size_t)r * mk + j] * std::sqrt(dd[j]) * zz[j];
+          hs[128 + kLDevM * k + r] = (double)(T)acc;
+        }
       }
       __atomic_thread_fence(__ATOMIC_RELEASE);
       hs[4] = seq;   // the queued estimate kernel goes ahead (also after a failed diagonalisation: it must not be left waiting)
@@ -423,28 +557,34 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       if (getenv("UAMMD_LANCZOS_DEBUG")) {
         const auto tD = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[lanczos] i=%d wait scalars %.1f us, host QL %.1f us, wait error %.1f us\n", i, us(tA, tB), us(tB, tC), us(tC, tD));
+        fprintf(stderr, "[lanczos] i=%d (%d checks) wait scalars %.1f us, host QL %.1f us, wait error %.1f us\n", i, K, us(tA, tB), us(tB, tC), us(tC, tD));
       }
       if (info) {
         set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
         return -20;
       }
       if (hs[3] != 0.0) { set_last_error("[Lanczos] the estimate kernel gave up waiting for the host's coefficients"); return -23; }
-      if (i > 0) {
-        const T err = (T)hs[2];
+      for (int k = 0; k < K; ++k) {
+        const int ik = checkFrom + k;   // the iteration this check belongs to
+        if (ik == 0) continue;          // (the reference computes no error at iteration 0)
+        const T err = (T)hs[16 + k];
         if (std::isnan(err)) {
-          set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", i);
+          set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", ik);
           return -21;
         }
         if (err <= tolerance) {
-          L->lastRunRequiredSteps = i;
-          if (i - 2 > L->check_convergence_steps) L->check_convergence_steps += 1;
+          if (k < K - 1)   // the run stops at an earlier iteration than the last one evaluated: that iteration's estimate is the result
+            hipLaunchKernelGGL(k_l_copy<T>, dim3(g), dim3(kLB), 0, st, (const T *)(est + (size_t)k * n), n, d_Bv);
+          L->lastRunRequiredSteps = ik;
+          if (ik - 2 > L->check_convergence_steps) L->check_convergence_steps += 1;
           else L->check_convergence_steps = std::max(1, L->check_convergence_steps - 2);
-          if (iterations) *iterations = i;
+          if (iterations) *iterations = ik;
           UH_CHECK(hipGetLastError());
           return 0;
         }
       }
+      checkFrom = i + 1;   // from here on every iteration is checked as it comes (Bold holds the last estimate)
+      evalAt = i + 1;
     } else if (i >= checkConvergenceSteps) {
       const int m = i + 1;
       UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(T) * (2 * cap + 1), hipMemcpyDeviceToHost, st));

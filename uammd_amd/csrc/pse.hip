@@ -1016,6 +1016,7 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
   if (std::string(name) == "pair_list") { p->pairList = value != 0; return 0; }
+  if (std::string(name) == "defer_checks") return uammd_lanczos_set_option(p->lanczos, "defer_checks", value);
   if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
   if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
