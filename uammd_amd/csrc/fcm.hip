@@ -303,9 +303,15 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
 // four workgroups per CU — a C4 tile lists ~105 particles and its 4096 tiles are exactly four rounds of 1024; 4096 = 128 listed
 // particles, the LDS floor of the final tile sum (24.6 KB), five workgroups per CU — a C5 tile lists ~26 and the call is bound by how
 // many tiles are in flight (210 -> 181 us at C5; at C4 the smaller budget costs 2 us: 3.2 rounds of 1280).
-constexpr int kSpWeightWordsMax = 8192;
+#ifndef UAMMD_SP_WORDS   // (A/B builds: tools/variants_fcm.sh — 6144 words / 4 candidates per thread: within 1 % of these at C4 and 108^3)
+#define UAMMD_SP_WORDS 8192
+#endif
+#ifndef UAMMD_SP_PER_THREAD
+#define UAMMD_SP_PER_THREAD 3
+#endif
+constexpr int kSpWeightWordsMax = UAMMD_SP_WORDS;
 constexpr int kSpZPad = kTile - 1;    // zeros either side of a particle's z weights: any tile plane reads SOME word, no branch
-constexpr int kSpPerThread = 3;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
+constexpr int kSpPerThread = UAMMD_SP_PER_THREAD;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
 struct SpEntry {
   int o;  // stencil origin in the tile's frame (may be negative), biased by 64 and packed: ox | oy << 8 | oz << 16
   int slot;
@@ -332,6 +338,12 @@ static int spread_weight_words(int N, int3 ntiles, int3 support, int3 tdim) {
 // W = waves per workgroup: 4, or 2 where the tiles are sparse (spread_waves) — a tile then costs the same chain of round trips for a
 // few matrix steps: twice the tiles in flight for the same waves.  Measured at C5 (256^3, 6 particles per tile, ~26 listed): 179 / 168 /
 // 224 us with 4 / 2 / 1 waves per tile; at C4 (24 per tile, ~105 listed) 62 / 98 with 4 / 2.
+#ifdef UAMMD_SPREAD_TIMELINE   // diagnostic build (tools/variants_fcm.sh, tools/spread_timeline.py): where a tile's lifetime goes, 100 MHz ticks
+__device__ unsigned long long g_spread_tl[8];
+#define SP_STAMP(k) do { if (threadIdx.x == 0) atomicAdd(&g_spread_tl[k], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tl0)); } while (0)
+#else
+#define SP_STAMP(k) do {} while (0)
+#endif
 template <int W>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
@@ -346,6 +358,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   __shared__ int waveCnt[4 * kSpPerThread];
   __shared__ unsigned char owner[kThreads * kSpPerThread];
   __builtin_amdgcn_s_setprio(3);  // phases that load go ahead of the phase that computes (five workgroups share a CU)
+#ifdef UAMMD_SPREAD_TIMELINE
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   f32x16 acc0 = {0.f}, acc1 = {0.f};  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
@@ -384,6 +399,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     if (nb == 0) rPrefix[0] = 0;
   }
   __syncthreads();
+  SP_STAMP(0);  // ranges known
   const int total = rPrefix[27];
   int listCount = 0;  // uniform over the workgroup
 
@@ -392,6 +408,10 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // loop below with no barrier since: phase B reads every entry's slot, so the writes must have landed first.
     __syncthreads();
     // phase B
+    // (Measured and not kept: the listed particles' weights COMPUTED here from their positions — one 16-byte load per listed
+    // particle instead of 13 loads per thread in two dependent rounds, which tools/spread_timeline.py shows as 35 % of a tile's
+    // lifetime; one (particle, axis) per thread, prepare's own expression, identical results: 57 -> 69 us.  The kernel is not waiting
+    // for those loads as much as it is short of issue slots: 1890 exponentials per tile cost more than the round trips they replace.)
     const int words = count * wpad;
     const float rws = 1.0f / (float)wpad;
     // (staged: as a plain loop the compiler waits for every load before it issues the next, ~13 round trips per tile at C4)
@@ -408,6 +428,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
         },
         [&](int e, float v) { sh.wts[e] = v; });
     __syncthreads();
+    SP_STAMP(2);  // weights in LDS
     // phase C on the matrix pipe.  For one tile the spreading is a product: G[n][xy] += sum_p A[n][p] B[p][xy] with
     // n = 3 kz + c (8 planes x 3 components = 24 of 32 rows), xy the 64 columns of the tile, A[n][p] = wz_p[kz] f_p[c] and
     // B[p][xy] = wx_p[x] wy_p[y]: two v_mfma_f32_32x32x2_f32 (columns 0..31 and 32..63) take two particles per step, lanes 0..31
@@ -436,6 +457,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();
+    SP_STAMP(3);  // matrix phase done
   };
 
   const int perRound = min(capEntries, kThreads) * kSpPerThread;
@@ -497,6 +519,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
     __syncthreads();
   }
+  SP_STAMP(1);  // candidates tested, list complete
   if (listCount > 0) spread_list(listCount);
   {
     // accumulator v of lane l is row n = 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32; rows 24..31 (v >= 12) are unused
@@ -524,6 +547,10 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       g0[2 * plane + node] = acc[2 * T3 + i] + acc[5 * T3 + i];
     }
   }
+  SP_STAMP(4);  // stored
+#ifdef UAMMD_SPREAD_TIMELINE
+  if (threadIdx.x == 0) atomicAdd(&g_spread_tl[7], 1ull);
+#endif
 }
 
 // Gather with the precomputed origin/weights: one wave per tile-sorted slot (neighbouring waves touch the same
@@ -2167,3 +2194,10 @@ double uammd_fcm_self_mobility(double hydrodynamicRadius, double viscosity, doub
 }
 
 }  // extern "C"
+#ifdef UAMMD_SPREAD_TIMELINE
+extern "C" int uammd_debug_spread_timeline(unsigned long long out[8]) {
+  unsigned long long zero[8] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uammd_hip::g_spread_tl), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(uammd_hip::g_spread_tl), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
