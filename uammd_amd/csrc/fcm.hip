@@ -414,6 +414,21 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // for those loads as much as it is short of issue slots: 1890 exponentials per tile cost more than the round trips they replace.)
     const int words = count * wpad;
     const float rws = 1.0f / (float)wpad;
+    if (wpad == 32) {
+      // support 6 (C4, C5): 32 words per particle, so a thread's words e = tid + kThreads j are the SAME word k = tid & 31 of particles
+      // (tid >> 5) + (kThreads / 32) j: the pad decision and the source offset once per thread instead of a division, two compares and
+      // a subtraction per word (the kernel is short of vector issue slots: profiles/r04_pmc_fcm_spread.txt)
+      int k = threadIdx.x & 31;
+      bool pad = false;
+      if (k >= sx + sy) {
+        k -= kSpZPad;
+        pad = k < sx + sy || k >= wstride;
+      }
+      const int pp0 = threadIdx.x >> 5;
+      staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
+          [&](int j) { return pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp0 + (kThreads / 32) * j].slot + k]; },
+          [&](int j, float v) { sh.wts[threadIdx.x + kThreads * j] = v; });
+    } else
     // (staged: as a plain loop the compiler waits for every load before it issues the next, ~13 round trips per tile at C4)
     staged_copy<8, float>(threadIdx.x, words, kThreads,
         [&](int e) {
