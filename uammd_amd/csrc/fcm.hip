@@ -299,25 +299,24 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
 //      (LDS float atomics retire ~1 lane per clock on gfx950: a shared LDS tile kept the LDS pipe 90 % busy and the kernel at
 //      400 us; private LDS copies with read-modify-write were VALU-issue bound at 100 us.)  The four private copies are summed
 //      through LDS when the tile is stored.
-// LDS budget of phase B in words, chosen per call (spread_weight_words): 8192 = 256 listed particles at support 6 (32 words each) and
-// four workgroups per CU — a C4 tile lists ~105 particles and its 4096 tiles are exactly four rounds of 1024; 4096 = 128 listed
-// particles, the LDS floor of the final tile sum (24.6 KB), five workgroups per CU — a C5 tile lists ~26 and the call is bound by how
-// many tiles are in flight (210 -> 181 us at C5; at C4 the smaller budget costs 2 us: 3.2 rounds of 1280).
+// LDS budget of phase B in words, chosen per call (spread_weight_words): 24 words per listed particle (kSpWT), 6144 = 256 listed
+// particles (a C4 tile lists ~105), 3072 = 128 where tiles are sparse (a C5 tile lists ~26); with the list either fits five
+// workgroups per CU beside the 24.6 KB floor of the final tile sum.
 #ifndef UAMMD_SP_WORDS   // (A/B builds: tools/variants_fcm.sh — 6144 words / 4 candidates per thread: within 1 % of these at C4 and 108^3)
-#define UAMMD_SP_WORDS 8192
+#define UAMMD_SP_WORDS 6144
 #endif
 #ifndef UAMMD_SP_PER_THREAD
 #define UAMMD_SP_PER_THREAD 3
 #endif
 constexpr int kSpWeightWordsMax = UAMMD_SP_WORDS;
-constexpr int kSpZPad = kTile - 1;    // zeros either side of a particle's z weights: any tile plane reads SOME word, no branch
+constexpr int kSpWT = 3 * kTile;      // LDS words per listed particle: its weights at the tile's 8 nodes along x, y, z
 constexpr int kSpPerThread = UAMMD_SP_PER_THREAD;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
 struct SpEntry {
   int o;  // stencil origin in the tile's frame (may be negative), biased by 64 and packed: ox | oy << 8 | oz << 16
   int slot;
   float fx, fy, fz;
 };
-// dynamic LDS: float wts[weightWords + 32] (+32: out-of-stencil lanes read up to 15 words past a particle's weights) | SpEntry list[257]
+// dynamic LDS: float wts[weightWords + 32] | SpEntry list[257]
 // (+1: phase C reads 8 words per 5-word entry); the four private tiles of the final sum alias the same block
 static size_t spread_lds_bytes(int weightWords, int waves = 4) {
   const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * waves * 3 * kTile * kTile * kTile;
@@ -374,8 +373,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int x0 = tx * td.x, y0 = ty * td.y, z0 = tz * td.z;
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
-  const int wpad = wstride + 2 * kSpZPad;  // LDS words per listed particle
-  const int capEntries = min(kThreads, weightWords / wpad);
+  const int capEntries = min(kThreads, weightWords / kSpWT);
   if (threadIdx.x < 27) {
     const int nb = threadIdx.x;
     const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
@@ -412,36 +410,25 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // particle instead of 13 loads per thread in two dependent rounds, which tools/spread_timeline.py shows as 35 % of a tile's
     // lifetime; one (particle, axis) per thread, prepare's own expression, identical results: 57 -> 69 us.  The kernel is not waiting
     // for those loads as much as it is short of issue slots: 1890 exponentials per tile cost more than the round trips they replace.)
-    const int words = count * wpad;
-    const float rws = 1.0f / (float)wpad;
-    if (wpad == 32) {
-      // support 6 (C4, C5): 32 words per particle, so a thread's words e = tid + kThreads j are the SAME word k = tid & 31 of particles
-      // (tid >> 5) + (kThreads / 32) j: the pad decision and the source offset once per thread instead of a division, two compares and
-      // a subtraction per word (the kernel is short of vector issue slots: profiles/r04_pmc_fcm_spread.txt)
-      int k = threadIdx.x & 31;
-      bool pad = false;
-      if (k >= sx + sy) {
-        k -= kSpZPad;
-        pad = k < sx + sy || k >= wstride;
-      }
+    // The weights go to LDS in the TILE's frame: 3 x 8 words per listed particle, word (axis, t) = the particle's weight at the tile's
+    // node t along that axis (w[t - o], or 0 where its stencil does not reach).  A lane of the matrix phase then reads its operand
+    // parts at CONSTANT offsets (its column's x and y, its row's plane): no origin to unpack, no index masks, range tests or selects
+    // per step — the kernel is short of vector issue slots (profiles/r04_pmc_fcm_spread.txt), and that phase was ~40 instructions
+    // per matrix step.  Thread r = tid & 31 < 24 copies word r of particles (tid >> 5) + (kThreads / 32) j: axis, t and the word's
+    // place once per thread; all of a thread's loads in flight together (staged).
+    {
+      const int r = threadIdx.x & 31, axis = r >> 3, t = r & 7;
+      const int sa = axis == 0 ? sx : (axis == 1 ? sy : sz), aoff = axis == 0 ? 0 : (axis == 1 ? sx : sx + sy);
       const int pp0 = threadIdx.x >> 5;
-      staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
-          [&](int j) { return pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp0 + (kThreads / 32) * j].slot + k]; },
-          [&](int j, float v) { sh.wts[threadIdx.x + kThreads * j] = v; });
-    } else
-    // (staged: as a plain loop the compiler waits for every load before it issues the next, ~13 round trips per tile at C4)
-    staged_copy<8, float>(threadIdx.x, words, kThreads,
-        [&](int e) {
-          const int pp = (int)(((float)e + 0.5f) * rws);  // exact: e < 2^14
-          int k = e - pp * wpad;
-          bool pad = false;
-          if (k >= sx + sy) {  // z weights sit between two runs of kSpZPad zeros
-            k -= kSpZPad;
-            pad = k < sx + sy || k >= wstride;
-          }
-          return pad ? 0.0f : pr.weights[(size_t)wstride * sh.list[pp].slot + k];
-        },
-        [&](int e, float v) { sh.wts[e] = v; });
+      if (r < kSpWT)
+        staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
+            [&](int j) {
+              const SpEntry &en = sh.list[pp0 + (kThreads / 32) * j];
+              const int i = t - (((en.o >> (8 * axis)) & 255) - 64);
+              return (unsigned)i < (unsigned)sa ? pr.weights[(size_t)wstride * en.slot + aoff + i] : 0.0f;
+            },
+            [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * kSpWT + r] = v; });
+    }
     __syncthreads();
     SP_STAMP(2);  // weights in LDS
     // phase C on the matrix pipe.  For one tile the spreading is a product: G[n][xy] += sum_p A[n][p] B[p][xy] with
@@ -453,20 +440,16 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // off one at a time: A 19, B 12, C 41, prologue + reduction + store 12; with the MFMA form C is ~22 and the call 65 us.)
     const int mineCount = (count - wave + W - 1) / W;  // entries wave, wave + W, ... of the list
     __builtin_amdgcn_s_setprio(0);  // (the arithmetic phase yields to the workgroups that are issuing loads: see the kernel's top)
+    const int zAt = 16 + (aValid ? aKz : 0);  // (rows 24..31 of the A operand carry no plane: force 0, any word)
     for (int j = 0; j < mineCount; j += 2) {
       const int idx = j + half;
       const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
       const int e = wave + W * (real ? idx : 0);
-      const int po = sh.list[e].o;
       const float fc = (real && aValid) ? reinterpret_cast<const float *>(&sh.list[e].fx)[aC] : 0.0f;
-      const int ox = (po & 255) - 64, oy = ((po >> 8) & 255) - 64, oz = (po >> 16) - 64;
-      const float *wp = sh.wts + e * wpad;
-      const float av = wp[sx + sy + kSpZPad - oz + aKz] * fc;  // zero-padded run: any plane reads SOME word
-      const int ii = bX - ox, j0 = bY - oy, j1 = j0 + 4;
-      const float wx = wp[ii & 15], wy0 = wp[sx + (j0 & 15)], wy1 = wp[sx + (j1 & 15)];
-      const bool inx = (unsigned)ii < (unsigned)sx;
-      const float b0 = (inx && (unsigned)j0 < (unsigned)sy) ? wx * wy0 : 0.0f;
-      const float b1 = (inx && (unsigned)j1 < (unsigned)sy) ? wx * wy1 : 0.0f;
+      const float *wt = sh.wts + e * kSpWT;
+      const float av = wt[zAt] * fc;
+      const float wx = wt[bX];
+      const float b0 = wx * wt[8 + bY], b1 = wx * wt[12 + bY];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
     }
