@@ -274,11 +274,11 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   const int slot = pr.tileStart[pr.tileOf[id]] + pr.rank[id];
   pr.origin[slot] = make_int4(ox, oy, oz, id);
   // the spreading kernel's record: the force and, in .w, the stencil origin relative to the particle's OWN tile (each in
-  // [-16, 7], biased by 16, five bits per axis): one 16-byte load per candidate, no image arithmetic (a neighbour tile's frame is
-  // +-kTile away whatever the wrap)
+  // [-16, 7], biased by 16, in 7-bit fields: x | y << 7 | z << 14): one 16-byte load per candidate, no image arithmetic (a neighbour
+  // tile's frame is +-kTile away whatever the wrap); the spread adds a neighbour's shift and tests the three fields at once
   float4 fr = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int rel = (ox - (celli.x / pr.tdim.x) * pr.tdim.x + 16) | (oy - (celli.y / pr.tdim.y) * pr.tdim.y + 16) << 5 |
-                  (oz - (celli.z / pr.tdim.z) * pr.tdim.z + 16) << 10;
+  const int rel = (ox - (celli.x / pr.tdim.x) * pr.tdim.x + 16) | (oy - (celli.y / pr.tdim.y) * pr.tdim.y + 16) << 7 |
+                  (oz - (celli.z / pr.tdim.z) * pr.tdim.z + 16) << 14;
   fr.w = __int_as_float(rel);
   pr.force[slot] = fr;
   float *w = pr.weights + (size_t)pr.wstride * slot;
@@ -312,7 +312,7 @@ constexpr int kSpWeightWordsMax = UAMMD_SP_WORDS;
 constexpr int kSpWT = 3 * kTile;      // LDS words per listed particle: its weights at the tile's 8 nodes along x, y, z
 constexpr int kSpPerThread = UAMMD_SP_PER_THREAD;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
 struct SpEntry {
-  int o;  // stencil origin in the tile's frame (may be negative), biased by 64 and packed: ox | oy << 8 | oz << 16
+  int o;  // stencil origin in the tile's frame (may be negative), biased by 24 and packed in 7-bit fields: ox | oy << 7 | oz << 14
   int slot;
   float fx, fy, fz;
 };
@@ -352,7 +352,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
   float *acc = reinterpret_cast<float *>(smem);
-  __shared__ int rStart[28], rPrefix[28], rShift[27 * 3];
+  __shared__ int rPrefix[28];
+  __shared__ int2 rInfo[27];   // {first slot of the range minus its offset in the flat candidate sequence, the packed shift of its tile}
   constexpr int kThreads = 64 * W;
   __shared__ int waveCnt[4 * kSpPerThread];
   __shared__ unsigned char owner[kThreads * kSpPerThread];
@@ -383,9 +384,6 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     if (uz < 0) uz += ntiles.z; else if (uz >= ntiles.z) uz -= ntiles.z;
     const int t = ux + ntiles.x * (uy + ntiles.y * uz);
     const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
-    rStart[nb] = s;
-    // a record's origin is relative to its own tile: in this tile's frame that is + one tile edge per tile step (and - the bias)
-    rShift[3 * nb] = td.x * dx - 16; rShift[3 * nb + 1] = td.y * dy - 16; rShift[3 * nb + 2] = td.z * dz - 16;
     // inclusive scan of the 27 range lengths inside wave 0
     int incl = e - s;
 #pragma unroll
@@ -395,6 +393,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
     rPrefix[nb + 1] = incl;
     if (nb == 0) rPrefix[0] = 0;
+    // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
+    // + 8 more every field of record + shift is (origin in this tile's frame) + 24, in [0, 47]: no carry between the 7-bit fields
+    rInfo[nb] = make_int2(s - (incl - (e - s)), (td.x * dx + 8) | (td.y * dy + 8) << 7 | (td.z * dz + 8) << 14);
   }
   __syncthreads();
   SP_STAMP(0);  // ranges known
@@ -424,7 +425,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
         staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
             [&](int j) {
               const SpEntry &en = sh.list[pp0 + (kThreads / 32) * j];
-              const int i = t - (((en.o >> (8 * axis)) & 255) - 64);
+              const int i = t - (((en.o >> (7 * axis)) & 127) - 24);
               return (unsigned)i < (unsigned)sa ? pr.weights[(size_t)wstride * en.slot + aoff + i] : 0.0f;
             },
             [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * kSpWT + r] = v; });
@@ -472,27 +473,30 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
     __syncthreads();
     float4 frc[kSpPerThread];
-    int3 org[kSpPerThread];
+    int org[kSpPerThread];   // record + shift: the stencil origin in this tile's frame, + 24, in 7-bit fields
     int kOf[kSpPerThread];
     bool live[kSpPerThread];
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
       const int c = c0 + u * capEntries + (int)threadIdx.x;
       live[u] = (int)threadIdx.x < capEntries && c < total;
-      const int nb = live[u] ? owner[c - c0] : 0;
-      kOf[u] = live[u] ? rStart[nb] + (c - rPrefix[nb]) : 0;
-      org[u] = make_int3(rShift[3 * nb], rShift[3 * nb + 1], rShift[3 * nb + 2]);
+      const int2 ri = rInfo[live[u] ? owner[c - c0] : 0];
+      kOf[u] = live[u] ? ri.x + c : 0;
+      org[u] = ri.y;
     }
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) frc[u] = live[u] ? pr.force[kOf[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
     bool accept[kSpPerThread];
     unsigned long long m[kSpPerThread];
+    // a stencil overlaps the tile iff -support < origin < tile edge on every axis, i.e. 25 - support <= field <= 23 + edge: the three
+    // fields tested at once through their guard bits (bit 6 of a field survives `(field | guard) - lo` iff field >= lo)
+    constexpr int kGuard = 0x40 | 0x40 << 7 | 0x40 << 14;
+    const int lo3 = (25 - sx) | (25 - sy) << 7 | (25 - sz) << 14;
+    const int hi3 = ((23 + td.x) | (23 + td.y) << 7 | (23 + td.z) << 14) | kGuard;
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
-      const int rel = __float_as_int(frc[u].w);
-      org[u].x += rel & 31; org[u].y += (rel >> 5) & 31; org[u].z += (rel >> 10) & 31;
-      accept[u] = live[u] && org[u].x < td.x && org[u].x + sx > 0 && org[u].y < td.y && org[u].y + sy > 0 &&
-                  org[u].z < td.z && org[u].z + sz > 0;
+      org[u] += __float_as_int(frc[u].w);
+      accept[u] = live[u] && ((((org[u] | kGuard) - lo3) & (hi3 - org[u])) & kGuard) == kGuard;
       m[u] = __ballot(accept[u]);
       if (lane == 0) waveCnt[4 * u + wave] = __popcll(m[u]);
     }
@@ -508,7 +512,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       if (accept[u]) {
         const int before = (wave > 0 ? c0w : 0) + (wave > 1 ? c1w : 0) + (wave > 2 ? c2w : 0);
         SpEntry en;
-        en.o = (org[u].x + 64) | (org[u].y + 64) << 8 | (org[u].z + 64) << 16;
+        en.o = org[u];
         en.slot = kOf[u];
         en.fx = frc[u].x; en.fy = frc[u].y; en.fz = frc[u].z;
         sh.list[listCount + before + __popcll(m[u] & ((1ull << lane) - 1ull))] = en;
