@@ -802,7 +802,9 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__r
       if (kk < sz) {
         int cz = oz + kk;
         cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
-        g[q][kk] = gi[(size_t)(base + planeNodes * (uint)cz)];
+        // (a 32-bit byte offset from the grid's base: the launcher takes this kernel for grids below 128 MB, and the address is one shift
+        // instead of a 64-bit multiply-add per load)
+        g[q][kk] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + ((base + planeNodes * (uint)cz) << 4));
       }
     }
     wxy[q] = __shfl(wl[q], ii, 64) * __shfl(wl[q], sx + jj, 64);
@@ -817,9 +819,11 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__r
         const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl[q]), sx + sy + kk));
         const float w = wxy[q] * wz;
         if (col) {
-          ax[q] = fmaf(dV, g[q][kk].x * w, ax[q]);
-          ay[q] = fmaf(dV, g[q][kk].y * w, ay[q]);
-          az[q] = fmaf(dV, g[q][kk].z * w, az[q]);
+          // (the quadrature weight dV multiplies the finished sum, not every term: three instructions per node fewer in a kernel that is
+          // short of issue slots; rounding-level difference from k_fcm_gather_inter's dV (g w) terms)
+          ax[q] = fmaf(g[q][kk].x, w, ax[q]);
+          ay[q] = fmaf(g[q][kk].y, w, ay[q]);
+          az[q] = fmaf(g[q][kk].z, w, az[q]);
         }
       }
     }
@@ -837,6 +841,7 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__r
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       if (slot0 + q >= N) break;
+      ax[q] *= dV; ay[q] *= dV; az[q] *= dV;
       float *out = vout + 3 * (size_t)o[q].w;
       if (accumulate) { out[0] += ax[q]; out[1] += ay[q]; out[2] += az[q]; } else { out[0] = ax[q]; out[1] = ay[q]; out[2] = az[q]; }
     }
