@@ -260,11 +260,18 @@ __global__ void __launch_bounds__(1024) k_fcm_tile_scan(int *__restrict__ count,
 // The window kind is a template parameter: with a run-time kind the compiler if-converts phi_axis' switch and evaluates
 // EVERY window (exp, three sqrt, a division) for each of the 3*support weights — 4656 VALU instructions per particle,
 // 22.9 us at C4 on 1.5 waves per SIMD.
+#ifndef UAMMD_PREP_LANES
+#define UAMMD_PREP_LANES 4
+#endif
+constexpr int kPrepLanes = UAMMD_PREP_LANES;
 template <int KIND>
 __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ pos, const float4 *__restrict__ force,
                                                       int N, GridT<float> grid, IBMKernelDev kern, FcmPrep pr) {
   kern.kind = KIND;  // constant-folds the switch
-  const int id = blockIdx.x * 256 + threadIdx.x;
+  // kPrepLanes threads per particle, each with every kPrepLanes-th weight: at 1e5 particles one thread per particle is 1.5
+  // waves per SIMD walking 18 dependent exp chains; four lanes per particle put 6 waves on a SIMD with a quarter of the chain
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int id = gid / kPrepLanes, sub = gid % kPrepLanes;
   if (id >= N) return;
   const float4 p4 = pos[id];
   const real3f pi{p4.x, p4.y, p4.z};
@@ -272,6 +279,16 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   const int3 P = compute_support_shift(grid, pi, celli, kern.support);
   const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
   const int slot = pr.tileStart[pr.tileOf[id]] + pr.rank[id];
+  float *w = pr.weights + (size_t)pr.wstride * slot;
+  const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
+  for (int k = sub; k < sx + sy + sz; k += kPrepLanes) {
+    float v;
+    if (k < sx) v = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + k), celli.y, celli.z)).x);
+    else if (k < sx + sy) v = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(celli.x, grid.pbc_y(oy + k - sx), celli.z)).y);
+    else v = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(celli.x, celli.y, grid.pbc_z(oz + k - sx - sy))).z);
+    w[k] = v;
+  }
+  if (sub) return;
   pr.origin[slot] = make_int4(ox, oy, oz, id);
   // the spreading kernel's record: the force and, in .w, the stencil origin relative to the particle's OWN tile (each in
   // [-16, 7], biased by 16, in 7-bit fields: x | y << 7 | z << 14): one 16-byte load per candidate, no image arithmetic (a neighbour
@@ -281,11 +298,6 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
                   (oz - (celli.z / pr.tdim.z) * pr.tdim.z + 16) << 14;
   fr.w = __int_as_float(rel);
   pr.force[slot] = fr;
-  float *w = pr.weights + (size_t)pr.wstride * slot;
-  const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
-  for (int i = 0; i < sx; ++i) w[i] = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + i), celli.y, celli.z)).x);
-  for (int i = 0; i < sy; ++i) w[sx + i] = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(celli.x, grid.pbc_y(oy + i), celli.z)).y);
-  for (int i = 0; i < sz; ++i) w[sx + sy + i] = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(celli.x, celli.y, grid.pbc_z(oz + i))).z);
 }
 
 // One workgroup (4 waves) per tile, three phases per chunk of candidates so that a tile costs TWO global round trips instead
@@ -1346,7 +1358,7 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, pr.tileCount, nt, pr.tileStart);
 #define UH_PREPARE(K)                                                                                          \
   case K:                                                                                                      \
-    hipLaunchKernelGGL(k_fcm_prepare<K>, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,       \
+    hipLaunchKernelGGL(k_fcm_prepare<K>, dim3((N * kPrepLanes + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,       \
                        (const float4 *)d_force, N, f->grid, f->kern, pr);                                      \
     break;
   switch (f->kern.kind) {
