@@ -511,8 +511,10 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__r
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = __float_as_int(b[u].y);
-      const float *vp = v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j);
-      vx[u] = vp[0]; vy[u] = vp[1]; vz[u] = vp[2];
+      // (one 12-byte request: global loads only need their dwords aligned)
+      struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+      const V3 vj = *(const V3 *)(v + (size_t)VSTRIDE * (INDIRECT ? groupIndex[j] : j));
+      vx[u] = vj.x; vy[u] = vj.y; vz[u] = vj.z;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
