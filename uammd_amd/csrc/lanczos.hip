@@ -241,7 +241,12 @@ __global__ void __launch_bounds__(kLB) k_l_estimate_batch(const T *__restrict__ 
                                                           T *__restrict__ Bold, T *__restrict__ parts) {
   __shared__ T sh[16];
   __shared__ T ys[kLBatch * kLDevM];
-  for (int k = threadIdx.x; k < K * kLDevM; k += kLB) ys[k] = y[k];
+  // (zero where estimate k has no term — beyond its Krylov size m0 + k, and whole rows beyond K: the sums below run without a branch and
+  // fma(v, 0, s) leaves s as it is)
+  for (int e = threadIdx.x; e < kLBatch * kLDevM; e += kLB) {
+    const int k = e / kLDevM, c = e - k * kLDevM;
+    ys[e] = (k < K && c < m0 + k) ? y[e] : T(0);
+  }
   __syncthreads();
   const T nz = *normz;
   T a[kLBatch], b[kLBatch];
@@ -252,21 +257,20 @@ __global__ void __launch_bounds__(kLB) k_l_estimate_batch(const T *__restrict__ 
 #pragma unroll
     for (int k = 0; k < kLBatch; ++k) s[k] = T(0);
     const int mLast = m0 + K - 1;
-    // four columns' loads in flight together (one at a time this pass was ~mLast dependent round trips per element: 21 us for a
-    // batch at the PSE size); the sums still take their terms in ascending column order
-    for (int c0 = 0; c0 < mLast; c0 += 4) {
-      T v[4];
+    // eight columns' loads and the previous estimate in flight together (one at a time this pass was ~mLast dependent round trips per
+    // element: 21 us for a batch at the PSE size); the sums still take their terms in ascending column order
+    T prev = Bold[i];
+    for (int c0 = 0; c0 < mLast; c0 += 8) {
+      T v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = c0 + u < mLast ? V[(size_t)(c0 + u) * n + i] : T(0);
+      for (int u = 0; u < 8; ++u) v[u] = c0 + u < mLast ? V[(size_t)(c0 + u) * n + i] : T(0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int c = c0 + u;
 #pragma unroll
-        for (int k = 0; k < kLBatch; ++k)
-          if (k < K && c < m0 + k) s[k] = fma_(v[u], ys[k * kLDevM + c], s[k]);
+        for (int k = 0; k < kLBatch; ++k) s[k] = fma_(v[u], ys[k * kLDevM + (c & (kLDevM - 1))], s[k]);
       }
     }
-    T prev = Bold[i];
 #pragma unroll
     for (int k = 0; k < kLBatch; ++k)
       if (k < K) {
@@ -280,27 +284,27 @@ __global__ void __launch_bounds__(kLB) k_l_estimate_batch(const T *__restrict__ 
     Bz[i] = prev;
     Bold[i] = prev;
   }
-  // the 2 K partial sums of the workgroup through ONE barrier (2 K block_sum calls were 4 K barriers: a batch of five checks spent more
-  // time in them than in its pass over V)
-  __shared__ T red[kLB / 64][2 * kLBatch];
+  // the 2 K partial sums of the workgroup: every thread's terms through LDS, sixteen lanes per sum (sixteen reads and four shuffles each;
+  // 2 K block_sum calls were 4 K barriers, and shuffling all sixteen values down every wave 96 dependent ds_bpermute)
+  static_assert(kLB / 16 == 2 * kLBatch, "sixteen lanes per partial sum");
+  __shared__ T red[2 * kLBatch][kLB + 1];
 #pragma unroll
-  for (int k = 0; k < kLBatch; ++k)
-    if (k < K) {
-      T x = a[k], z = b[k];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); z += __shfl_xor(z, o, 64); }
-      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * k] = x; red[threadIdx.x >> 6][2 * k + 1] = z; }
-    }
+  for (int k = 0; k < kLBatch; ++k) { red[2 * k][threadIdx.x] = a[k]; red[2 * k + 1][threadIdx.x] = b[k]; }
   __syncthreads();
-  if ((int)threadIdx.x < 2 * K) {
-    const int t = threadIdx.x;
-    parts[(size_t)t * kLParts + blockIdx.x] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  {
+    const int t = threadIdx.x >> 4, sub = threadIdx.x & 15;   // kLB / 16 = 2 kLBatch sums
+    T x = T(0);
+#pragma unroll
+    for (int j = 0; j < kLB / 16; ++j) x += red[t][sub + 16 * j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (sub == 0 && t < 2 * K) parts[(size_t)t * kLParts + blockIdx.x] = x;
   }
   (void)sh;
 }
 // ONE thread waits for the host's K coefficient vectors and hands them to device memory
 template <class T>
-__global__ void k_l_relay_batch(volatile double *__restrict__ stat, int K, double seq, T *__restrict__ ycoef) {
+__global__ void k_l_relay_batch(volatile double *__restrict__ stat, int K, int mLast, double seq, T *__restrict__ ycoef) {
   __shared__ int ok;
   if (threadIdx.x == 0) {
     long spins = 0;
@@ -309,7 +313,12 @@ __global__ void k_l_relay_batch(volatile double *__restrict__ stat, int K, doubl
     if (!ok) stat[3] = -1.0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K * kLDevM; k += blockDim.x) ycoef[k] = ok ? (T)stat[128 + k] : T(0);
+  // only the mLast coefficients per check that the estimate reads: every read here is a trip over the bus, and K * kLDevM of them
+  // were three rounds for the 64 threads (~9 us of this kernel's 25)
+  for (int e = threadIdx.x; e < K * mLast; e += blockDim.x) {
+    const int k = e / mLast, r = e - k * mLast;
+    ycoef[k * kLDevM + r] = ok ? (T)stat[128 + k * kLDevM + r] : T(0);
+  }
 }
 // err_k = |Bz_k - Bz_(k-1)| / |Bz_(k-1)| for the K checks, left with a sequence number where the host can see them
 // (one wave per sum — 2 K waves — and one barrier)
@@ -512,7 +521,7 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       volatile double *hs = L->hostStat;
       hs[3] = 0.0;
       hipLaunchKernelGGL(k_l_publish<T>, dim3(1), dim3(64), 0, st, (const T *)hdiag, (const T *)hsup, m, L->devStat, seq);
-      hipLaunchKernelGGL(k_l_relay_batch<T>, dim3(1), dim3(64), 0, st, L->devStat, K, seq, ycoef);
+      hipLaunchKernelGGL(k_l_relay_batch<T>, dim3(1), dim3(64), 0, st, L->devStat, K, m, seq, ycoef);
       hipLaunchKernelGGL(k_l_estimate_batch<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m0, K, (const T *)ycoef, (const T *)scal, est,
                          d_Bv, Bold, parts);
       hipLaunchKernelGGL(k_l_error_batch<T>, dim3(1), dim3(64 * 2 * K), 0, st, (const T *)parts, g, K, L->devStat, seq);
