@@ -57,10 +57,13 @@ template <int NT = kFftThreads> UH_D void fft_twiddles(float2 *tw, int n, int ti
   }
 }
 
+template <int R1, int R2, int SIGN> UH_D void fft_butterfly_ct(float2 (&v)[R1 * R2]);
 // the R-point DFT of v (SIGN < 0: forward, exp(-2 pi i r m / R)), in place, natural order out
 template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
   auto mul_mi = [](float2 d) { return SIGN < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x); };  // -i d (forward), +i d (inverse)
-  if constexpr (R == 2) {
+  if constexpr (R == 6 || R == 9 || R == 12) {
+    fft_butterfly_ct<R / 3, 3, SIGN>(v);
+  } else if constexpr (R == 2) {
     const float2 a = v[0], c = v[1];
     v[0] = cadd(a, c);
     v[1] = csub(a, c);
@@ -145,6 +148,46 @@ template <int R, int SIGN> UH_D void fft_butterfly(float2 (&v)[R]) {
       const float2 a0 = cadd(o[0], o[2]), a1 = csub(o[0], o[2]), a2 = cadd(o[1], o[3]), a3 = mul_mi(csub(o[1], o[3]));
       v[1] = cadd(a0, a2); v[3] = cadd(a1, a3); v[5] = csub(a0, a2); v[7] = csub(a1, a3);
     }
+  }
+}
+
+// R = R1 R2 (6 = 2 x 3, 9 = 3 x 3, 12 = 4 x 3) by one Cooley-Tukey step in registers: with n = R2 n1 + n2 and k = k1 + R1 k2,
+//   X[k1 + R1 k2] = sum_n2 W_R^(n2 k1) W_R2^(n2 k2) sum_n1 v[R2 n1 + n2] W_R1^(n1 k1)
+// — R2 DFTs of R1 points, the turn by W_R^(n2 k1), R1 DFTs of R2 points.  Half the passes of a 2^a 3^b line (108 = 12 x 9 instead of
+// 4 x 3 x 3 x 3): a pass is two workgroup barriers and a trip of every point through LDS whatever its radix.
+template <int R1, int R2, int SIGN> UH_D void fft_butterfly_ct(float2 (&v)[R1 * R2]) {
+  constexpr int R = R1 * R2;
+  // cos, sin of 2 pi m / R for the exponents m = n2 k1 in use (n2 < R2 = 3, k1 < R1)
+  constexpr float C6[3] = {1.0f, 0.5f, -0.5f}, S6[3] = {0.0f, 0.86602540378443864676f, 0.86602540378443864676f};
+  constexpr float C9[5] = {1.0f, 0.76604444311897803520f, 0.17364817766693034885f, -0.5f, -0.93969262078590838405f};
+  constexpr float S9[5] = {0.0f, 0.64278760968653932632f, 0.98480775301220805937f, 0.86602540378443864676f, 0.34202014332566873304f};
+  constexpr float C12[7] = {1.0f, 0.86602540378443864676f, 0.5f, 0.0f, -0.5f, -0.86602540378443864676f, -1.0f};
+  constexpr float S12[7] = {0.0f, 0.5f, 0.86602540378443864676f, 1.0f, 0.86602540378443864676f, 0.5f, 0.0f};
+  float2 t[R2][R1];
+#pragma unroll
+  for (int n2 = 0; n2 < R2; ++n2) {
+    float2 a[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) a[n1] = v[R2 * n1 + n2];
+    fft_butterfly<R1, SIGN>(a);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+      const int m = n2 * k1;
+      if (m == 0) t[n2][k1] = a[k1];
+      else {
+        const float c = R == 6 ? C6[m] : (R == 9 ? C9[m] : C12[m]), sn = R == 6 ? S6[m] : (R == 9 ? S9[m] : S12[m]);
+        t[n2][k1] = ctw<SIGN>(a[k1], make_float2(c, -sn));
+      }
+    }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    float2 b[R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) b[n2] = t[n2][k1];
+    fft_butterfly<R2, SIGN>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
   }
 }
 
@@ -300,11 +343,26 @@ UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const floa
       else fft_pass_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
     }
   } else {
+    // 3^b as radix-9 passes; an odd three left over joins a four (12) or a two (6) where that saves a pass of the 2^a part
+    auto passes2 = [](int a) { return (a + 2) / 3; };
+    const int n9 = e3 / 2, r3 = e3 & 1;
+    int n12 = 0, n6 = 0, n3 = r3, a2 = e2;
+    if (r3) {
+      const int plain = passes2(e2) + 1;
+      if (e2 >= 2 && passes2(e2 - 2) + 1 < plain) { n12 = 1; n3 = 0; a2 = e2 - 2; }
+      else if (e2 >= 1 && passes2(e2 - 1) + 1 < plain) { n6 = 1; n3 = 0; a2 = e2 - 1; }
+    }
+    n8 = a2 / 3; n4 = 0; n2 = 0;
+    if (a2 % 3 == 2) n4 = 1;
+    else if (a2 % 3 == 1) { if (n8 > 0) { n8 -= 1; n4 = 2; } else n2 = 1; }
     int Ns = 1;
     for (int a = 0; a < n2; ++a, Ns *= 2) fft_pass<2, SIGN, 2 * MAXB, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < n4; ++a, Ns *= 4) fft_pass<4, SIGN, MAXB, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < n8; ++a, Ns *= 8) fft_pass<8, SIGN, (MAXB + 1) / 2, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
-    for (int a = 0; a < e3; ++a, Ns *= 3) fft_pass<3, SIGN, (4 * MAXB + 2) / 3, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n6; ++a, Ns *= 6) fft_pass<6, SIGN, (4 * MAXB + 5) / 6, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n12; ++a, Ns *= 12) fft_pass<12, SIGN, (4 * MAXB + 11) / 12, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n3; ++a, Ns *= 3) fft_pass<3, SIGN, (4 * MAXB + 2) / 3, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
+    for (int a = 0; a < n9; ++a, Ns *= 9) fft_pass<9, SIGN, (4 * MAXB + 8) / 9, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < e5; ++a, Ns *= 5) fft_pass<5, SIGN, (4 * MAXB + 4) / 5, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < e[3]; ++a, Ns *= 7) fft_pass<7, SIGN, (4 * MAXB + 6) / 7, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
     for (int a = 0; a < e[4]; ++a, Ns *= 11) fft_pass<11, SIGN, (4 * MAXB + 10) / 11, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
