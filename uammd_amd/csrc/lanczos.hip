@@ -31,6 +31,7 @@ namespace uammd_hip {
 constexpr int kLB = 256;       // threads per block
 constexpr int kLParts = 256;   // reduction partials (one per block)
 constexpr int kLDevM = 32;     // Krylov sizes whose convergence check goes through the host-mapped block (k_l_publish)
+constexpr int kLPre = 6;       // elements a thread of the recurrence kernels fetches ahead (n <= kLPre x 65536)
 constexpr int kLBatch = 8;     // convergence checks evaluated together (see lanczos_run: deferred checks)
 // host-mapped status block (doubles): [0] seqA  [1] seqB  [3] status  [4] seqY  [16 .. 16 + kLBatch) errors  [64 .. 96) hdiag  [96 .. 128) hsup
 //                                     [128 + 32 k .. ) y of batched check k
@@ -110,10 +111,34 @@ __global__ void __launch_bounds__(kLB) k_l_a(T *__restrict__ w, const T *__restr
   __shared__ T sh[16];
   const T hp = hsupPrev ? *hsupPrev : T(0);
   T a = T(0);
-  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
-    T x = w[i];
-    if (vprev) { x = fma_(-hp, vprev[i], x); w[i] = x; }
-    a = fma_(x, vi[i], a);
+  const int i0 = blockIdx.x * kLB + threadIdx.x, stride = gridDim.x * kLB;
+  if ((long)n <= (long)kLPre * stride) {
+    // a thread's few elements (n / 65536 of them: 4.6 at the PSE size) all in flight together instead of one round trip per turn of
+    // the loop; the sums take their terms in the loop's order
+    T xw[kLPre], xp[kLPre], xv[kLPre];
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) {
+      const int i = i0 + u * stride;
+      const bool in = i < n;
+      xw[u] = in ? w[i] : T(0);
+      xp[u] = in && vprev ? vprev[i] : T(0);
+      xv[u] = in ? vi[i] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) {
+      const int i = i0 + u * stride;
+      if (i < n) {
+        T x = xw[u];
+        if (vprev) { x = fma_(-hp, xp[u], x); w[i] = x; }
+        a = fma_(x, xv[u], a);
+      }
+    }
+  } else {
+    for (int i = i0; i < n; i += stride) {
+      T x = w[i];
+      if (vprev) { x = fma_(-hp, vprev[i], x); w[i] = x; }
+      a = fma_(x, vi[i], a);
+    }
   }
   const T t = block_sum(a, sh);
   if (threadIdx.x == 0) parts[blockIdx.x] = t;
@@ -131,13 +156,36 @@ __global__ void __launch_bounds__(kLB) k_l_b(T *__restrict__ w, const T *__restr
                                              const T *__restrict__ partsA, int nparts, T *__restrict__ hdiag_i,
                                              T *__restrict__ partsB) {
   __shared__ T sh[16];
+  const int i0 = blockIdx.x * kLB + threadIdx.x, stride = gridDim.x * kLB;
+  const bool pre = (long)n <= (long)kLPre * stride;   // (the thread's elements are on their way while the partials are summed)
+  T xw[kLPre], xv[kLPre];
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) {
+      const int i = i0 + u * stride;
+      xw[u] = i < n ? w[i] : T(0);
+      xv[u] = i < n ? vi[i] : T(0);
+    }
+  }
   const T h = sum_parts(partsA, nparts, sh);
   if (blockIdx.x == 0 && threadIdx.x == 0) *hdiag_i = h;
   T a = T(0);
-  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
-    const T x = fma_(-h, vi[i], w[i]);
-    w[i] = x;
-    a = fma_(x, x, a);
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) {
+      const int i = i0 + u * stride;
+      if (i < n) {
+        const T x = fma_(-h, xv[u], xw[u]);
+        w[i] = x;
+        a = fma_(x, x, a);
+      }
+    }
+  } else {
+    for (int i = i0; i < n; i += stride) {
+      const T x = fma_(-h, vi[i], w[i]);
+      w[i] = x;
+      a = fma_(x, x, a);
+    }
   }
   const T t = block_sum(a, sh);
   if (threadIdx.x == 0) partsB[blockIdx.x] = t;
@@ -149,13 +197,28 @@ __global__ void __launch_bounds__(kLB) k_l_c(const T *__restrict__ w, int n, con
                                              const T *__restrict__ normz, T *__restrict__ hsup_i,
                                              T *__restrict__ vnext, bool ownsFirstElement) {
   __shared__ T sh[16];
+  const int i0 = blockIdx.x * kLB + threadIdx.x, stride = gridDim.x * kLB;
+  const bool pre = (long)n <= (long)kLPre * stride;
+  T xw[kLPre];
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) xw[u] = i0 + u * stride < n ? w[i0 + u * stride] : T(0);
+  }
   T hs = sqrt_(sum_parts(partsB, nparts, sh));
   const T tol = T(1e-3) * (*hdiag_i) / (*normz);
   if (hs < tol) hs = T(0);
   if (blockIdx.x == 0 && threadIdx.x == 0) *hsup_i = hs;
   const T inv = hs > T(0) ? T(1) / hs : T(0);
-  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB)
-    vnext[i] = hs > T(0) ? w[i] * inv : ((i == 0 && ownsFirstElement) ? T(1) : T(0));
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < kLPre; ++u) {
+      const int i = i0 + u * stride;
+      if (i < n) vnext[i] = hs > T(0) ? xw[u] * inv : ((i == 0 && ownsFirstElement) ? T(1) : T(0));
+    }
+  } else {
+    for (int i = i0; i < n; i += stride)
+      vnext[i] = hs > T(0) ? w[i] * inv : ((i == 0 && ownsFirstElement) ? T(1) : T(0));
+  }
 }
 // (Round 4, measured and removed: the three recurrence kernels as ONE launch — every thread keeping its elements of w in registers across
 // the two reductions, a generation-tagged counter in global memory as the barrier over the <= 256 resident blocks, partials as relaxed
