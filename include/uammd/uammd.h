@@ -1462,6 +1462,10 @@ public:
     const int N = pd->getNumParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
     auto force = pd->getForce(access::gpu, access::read);
+    {  // (the near field's list and pair records are queued first: their one host read then happens while the far field runs)
+      auto pos = pd->getPos(access::gpu, access::read);
+      detail::check(uammd_pse_near_prepare(nearField, (const float *)pos.raw(), N, (void *)st));
+    }
     far(force.raw(), MF, temperature, real(1.0 / std::sqrt(dt)), st);
     auto pos = pd->getPos(access::gpu, access::read);
     detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));

@@ -575,6 +575,12 @@ int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain);
  * records (F, (G - F) / r^2, r_ij, j) and the ~8 products of a step stream them; 0 = every product scans the 27 cells. */
 int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value);
 int uammd_pse_near_positions_changed(uammd_pse_near *h);
+/* The list update of the calls below (cl->update, NearField.cuh:231-237) ahead of them, nothing waited for; with "lazy_list" and
+ * "pair_list" also the launch of the pair records' build.  Optional: a caller that queues other work between this and the first
+ * product (BDHI::PSE::computeMF's far field, BDHI_PSE.cuh:92-120) hides the build's one host read behind it. */
+int uammd_pse_near_prepare(uammd_pse_near *h, const float *d_pos, int numberParticles, void *stream);
+/* diagnostics: pair records in use (0 while the products scan the cells) and allocated */
+int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long *capacity);
 /* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int numberParticles, float *d_MF,
                         void *stream);

@@ -255,7 +255,7 @@ def test_pair_records_match_the_scan_product(hip, o32):
     from uammd_amd._lib import check
     from uammd_amd.md import _ptr, current_stream
     for shear, cluster in ((0.0, False), (0.2, False), (0.0, True)):
-        L, n, tol, psi = 20.0, 4000, 1e-3, 0.6
+        L, n, tol, psi = 40.0, 4000, 1e-3, 0.6   # ~22 neighbours per particle (at L = 20 every particle has more than a hit list holds)
         pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n, shear=shear)
         if cluster:
             pos = pos.copy()
@@ -274,6 +274,10 @@ def test_pair_records_match_the_scan_product(hip, o32):
             check(pse.lib.uammd_pse_near_dot(pse.near, _ptr(pd.getPos()), _ptr(d_v), n, _ptr(out), current_stream()))
             return MF.cpu().numpy(), out.cpu().numpy()
         a = products()
+        import ctypes as C
+        used = C.c_longlong(0)
+        check(pse.lib.uammd_pse_near_pair_records(pse.near, C.byref(used), None))
+        assert (used.value == 0) if cluster else (15 * n < used.value < 40 * n)   # the records are what ran (or, for the cluster, are not)
         a2 = products()                                    # the records are reused: the same bits
         assert np.array_equal(a[0], a2[0]) and np.array_equal(a[1], a2[1])
         check(pse.lib.uammd_pse_near_set_option(pse.near, b"pair_list", 0))
@@ -283,7 +287,8 @@ def test_pair_records_match_the_scan_product(hip, o32):
         ref.near_mdot(pos, f4, expect)
         scale = np.abs(expect).max()
         for x, y in zip(a, b):
-            assert np.abs(x - y).max() <= 1e-6 * scale
+            # (the accumulate form adds to ones: an ulp of 1 on top)
+            assert np.abs(x - y).max() <= 1e-6 * scale + 2.5e-7, (shear, cluster, float(np.abs(x - y).max()), float(scale))
         assert np.abs(a[1] - expect).max() <= 1e-6 * scale and np.abs(a[0] - 1.0 - expect).max() <= 2e-6 * max(1.0, scale)
         if cluster:
             assert np.array_equal(a[1], b[1])              # more than a hit list holds: both runs took the scanning product
@@ -295,3 +300,65 @@ def test_pair_records_match_the_scan_product(hip, o32):
         expect2 = np.zeros((n, 3), np.float32)
         ref.near_mdot(pos2, f4, expect2)
         assert np.abs(c[1] - expect2).max() <= 1e-6 * np.abs(expect2).max()
+
+
+@pytest.mark.gpu
+def test_near_prepare_changes_no_result(hip, o32):
+    """uammd_pse_near_prepare queues the list and the pair records' build ahead of the products (the records' host read then overlaps whatever
+    the caller queues in between): the products give the bits they give without it; a prepare for positions that are then written again is
+    superseded by the next call's list; capacity growth still works when the first launch came from prepare."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n, tol, psi = 40.0, 4000, 1e-3, 0.6       # ~22 neighbours per particle: the records are in use
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+
+    def records():
+        used, cap = C.c_longlong(0), C.c_longlong(0)
+        check(pse.lib.uammd_pse_near_pair_records(pse.near, C.byref(used), C.byref(cap)))
+        return used.value, cap.value
+    rng = np.random.default_rng(3)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+
+    def mdot(prepare, between=None):
+        check(pse.lib.uammd_pse_near_positions_changed(pse.near))
+        if prepare:
+            check(pse.lib.uammd_pse_near_prepare(pse.near, _ptr(pd.getPos()), n, current_stream()))
+        if between is not None:
+            between()
+        MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+        return MF.cpu().numpy()
+    plain = mdot(False)
+    assert 15 * n < records()[0] < 30 * n
+    scratch = torch.zeros(1 << 20, device="cuda")
+    assert np.array_equal(mdot(True), plain)
+    assert np.array_equal(mdot(True, lambda: scratch.add_(1.0)), plain)      # other work between the two halves of the build
+    expect = np.zeros((n, 3), np.float32)
+    ref.near_mdot(pos, f4, expect)
+    assert np.abs(plain - expect).max() <= 1e-6 * np.abs(expect).max()
+    # prepared, then written: the products follow the positions they are called with
+    check(pse.lib.uammd_pse_near_prepare(pse.near, _ptr(pd.getPos()), n, current_stream()))
+    pos2 = pos.copy()
+    pos2[:, :3] = np.random.default_rng(99).uniform(-L / 2, L / 2, (n, 3))
+    pd.getPos("write").copy_(torch.from_numpy(pos2).cuda())
+    MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+    expect2 = np.zeros((n, 3), np.float32)
+    ref.near_mdot(pos2, f4, expect2)
+    assert np.abs(MF.cpu().numpy() - expect2).max() <= 1e-6 * np.abs(expect2).max()
+    # a denser configuration (~54 neighbours, at most 91) than the first allocation holds (48 records per particle): the build started by prepare is
+    # repeated with more room
+    assert records()[1] == 48 * n
+    pos3 = pos.copy()
+    pos3[:, :3] = np.random.default_rng(7).uniform(-14.0, 14.0, (n, 3))
+    pd.getPos("write").copy_(torch.from_numpy(pos3).cuda())
+    check(pse.lib.uammd_pse_near_prepare(pse.near, _ptr(pd.getPos()), n, current_stream()))
+    MF.zero_()
+    check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+    expect3 = np.zeros((n, 3), np.float32)
+    ref.near_mdot(pos3, f4, expect3)
+    assert np.abs(MF.cpu().numpy() - expect3).max() <= 2e-6 * np.abs(expect3).max()
+    assert records()[0] > 48 * n and records()[1] >= records()[0]

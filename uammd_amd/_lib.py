@@ -231,6 +231,8 @@ SIGNATURES = {
     "uammd_pse_near_set_shear_strain": (_i, [_vp, _f]),
     "uammd_pse_near_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_pse_near_positions_changed": (_i, [_vp]),
+    "uammd_pse_near_prepare": (_i, [_vp, _vp, _i, _vp]),
+    "uammd_pse_near_pair_records": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_mdot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_pse_near_stochastic": (_i, [_vp, _vp, _i, _f, _f, _u, _vp, _vp, C.POINTER(_i)]),
     "uammd_pse_near_noise": (_i, [_vp, _i, _f, _u, _vp, _vp]),

@@ -495,6 +495,8 @@ class PSE:
         pd = self.pd
         MF.zero_()
         force = pd.getForce("read")
+        # (the near field's list and pair records are queued first: their one host read then happens while the far field runs)
+        check(self.lib.uammd_pse_near_prepare(self.near, _ptr(pd.getPos("read")), pd.N, current_stream()))
         self._far(force, MF, self.temperature, 1.0 / math.sqrt(self.dt))
         check(self.lib.uammd_pse_near_mdot(self.near, _ptr(pd.getPos("read")), _ptr(force), pd.N, _ptr(MF), current_stream()))
 

@@ -47,9 +47,15 @@ struct PSENear {
   DeviceBuffer recA, recB, pairRange, pairCursor;  // float4 (F, (G - F) / r2, rx, ry) | float2 (rz, j) per record; int2 (first, count) per particle
   size_t pairCap = 0;        // records allocated
   int *pairTotalHost = nullptr;  // pinned: {records used, a particle overflowed its hit list}
+  // a build is two halves: the launch (kernel + copy of the two counters + pairsEvent) and the read of the counters.  A caller with other
+  // work for the stream queues it between the two (uammd_pse_near_prepare, then the far field, then the near products): the read then
+  // finds the event complete and the GPU busy — waited for on the spot it was a bubble of ~20 us per step
+  bool pairsPending = false;
+  hipEvent_t pairsEvent = nullptr;
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
     if (pairTotalHost) (void)hipHostFree(pairTotalHost);
+    if (pairsEvent) (void)hipEventDestroy(pairsEvent);
   }
 };
 
@@ -733,6 +739,7 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N && p->listStream == st) return 0;
   p->listValid = false;  // (valid again only when the build below went through: a failed build must not be reused)
   p->pairsValid = false;
+  p->pairsPending = false;  // (a build in flight is of the old list; the next one is ordered after it on the stream)
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
   const float rc = p->rcut * safety;
@@ -752,28 +759,39 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
 static TableView make_view(const PSENear *p);
 // the pair records of the current list (see PSENear::pairList).  One host read per build: the number of records, to grow the arrays
 // when they do not fit (the build then runs again).
-static int pse_build_pairs(PSENear *p, hipStream_t st) {
+static int pse_launch_pairs(PSENear *p, hipStream_t st) {
   const int N = p->N;
   if (!p->pairTotalHost) UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, 2 * sizeof(int)));
+  if (!p->pairsEvent) UH_CHECK(hipEventCreateWithFlags(&p->pairsEvent, hipEventDisableTiming));
   if (int e = p->pairRange.reserve(sizeof(int2) * (size_t)N)) return e;
   if (int e = p->pairCursor.reserve(2 * sizeof(int))) return e;
   if (p->pairCap < (size_t)N) p->pairCap = (size_t)48 * (size_t)N;
+  if (p->pairCap > (size_t)0x7fffff00) { p->pairsUnfit = true; return 0; }   // (record indices are ints)
+  if (int e = p->recA.reserve(sizeof(float4) * p->pairCap)) return e;
+  if (int e = p->recB.reserve(sizeof(float2) * p->pairCap)) return e;
   const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
   const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    if (p->pairCap > (size_t)0x7fffff00) { p->pairsUnfit = true; return 0; }   // (record indices are ints)
-    if (int e = p->recA.reserve(sizeof(float4) * p->pairCap)) return e;
-    if (int e = p->recB.reserve(sizeof(float2) * p->pairCap)) return e;
-    UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, 2 * sizeof(int), st));
+  UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, 2 * sizeof(int), st));
 #define UH_PAIRS(SH)                                                                                                                \
-    hipLaunchKernelGGL((k_pse_pairs_build<SH>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                     \
-                       (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb,       \
-                       p->shear, p->rcut * p->rcut, make_view(p), (float4 *)p->recA.ptr, (float2 *)p->recB.ptr,                     \
-                       (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap)
-    if (p->shear != 0.0f) UH_PAIRS(true); else UH_PAIRS(false);
+  hipLaunchKernelGGL((k_pse_pairs_build<SH>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                       \
+                     (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb,         \
+                     p->shear, p->rcut * p->rcut, make_view(p), (float4 *)p->recA.ptr, (float2 *)p->recB.ptr,                       \
+                     (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap)
+  if (p->shear != 0.0f) UH_PAIRS(true); else UH_PAIRS(false);
 #undef UH_PAIRS
-    UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    UH_CHECK(hipStreamSynchronize(st));
+  UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  UH_CHECK(hipEventRecord(p->pairsEvent, st));
+  p->pairsPending = true;
+  return 0;
+}
+static int pse_build_pairs(PSENear *p, hipStream_t st) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (!p->pairsPending) {
+      if (int e = pse_launch_pairs(p, st)) return e;
+      if (p->pairsUnfit) return 0;
+    }
+    UH_CHECK(hipEventSynchronize(p->pairsEvent));
+    p->pairsPending = false;
     if (p->pairTotalHost[1]) { p->pairsUnfit = true; return 0; }   // a particle with more neighbours than a hit list holds: k_pse_near8 from here on
     if ((size_t)p->pairTotalHost[0] <= p->pairCap) { p->pairsValid = true; return 0; }
     p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
@@ -1027,6 +1045,31 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
 int uammd_pse_near_positions_changed(uammd_pse_near *h) {
   if (!h) { set_last_error("uammd_pse_near_positions_changed: null handle"); return -1; }
   reinterpret_cast<PSENear *>(h)->listValid = false;
+  return 0;
+}
+
+// cl->update (NearField.cuh:231-237) ahead of the products, with nothing waited for: the list and — with "lazy_list" and "pair_list" —
+// the launch half of the pair records' build.  The products of the same positions on the same stream find both done; a caller
+// (BDHI::PSE::computeMF: far field, then near field, BDHI_PSE.cuh:92-120) that calls this BEFORE queueing the far field has the
+// records' counters read while the GPU works on the far field instead of draining the stream for them.
+int uammd_pse_near_prepare(uammd_pse_near *h, const float *d_pos, int N, void *stream) {
+  if (!h || (N > 0 && !d_pos)) { set_last_error("uammd_pse_near_prepare: null argument"); return -1; }
+  if (N <= 0) return 0;
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = pse_update_list(p, d_pos, N, st)) return e;
+  if (p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1 && !p->exactOrder && !p->pairsValid && !p->pairsPending)
+    return pse_launch_pairs(p, st);
+  return 0;
+}
+
+// diagnostics: the pair records the products stream (0 while there are none: before the first product, with "pair_list" off, or after a
+// particle overflowed its hit list) and the records allocated
+int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long *capacity) {
+  if (!h) { set_last_error("uammd_pse_near_pair_records: null handle"); return -1; }
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  if (records) *records = (p->pairsValid && p->pairTotalHost) ? (long long)p->pairTotalHost[0] : 0;
+  if (capacity) *capacity = (long long)p->pairCap;
   return 0;
 }
 
