@@ -1471,6 +1471,29 @@ public:
     detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
+  // computeMF and computeBdW (:92-126) as EulerMaruyama runs them when T > 0, queued so that the step's one wait for the GPU — the Lanczos
+  // solve's convergence check — has work behind it: near-field list and pair records, the solve, the FAR FIELD from inside the solve
+  // (uammd_pse_near_set_interleave: behind the check's kernels, while the host is busy with the check), then the near-field M F.  The same
+  // calls with the same arguments; the two draws of System::rng() keep the reference's order (FarField.cuh:499, then NearField.cuh:276).
+  void computeMFandBdW(real3 *MF, real3 *BdW, hipStream_t st = 0) {
+    if (temperature == real(0.0)) { computeMF(MF, st); return; }
+    const int N = pd->getNumParticles();
+    detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
+    auto force = pd->getForce(access::gpu, access::read);
+    auto pos = pd->getPos(access::gpu, access::read);
+    const uint seedFar = pd->getSystem()->rng().next32();
+    const uint seedNear = pd->getSystem()->rng().next32();
+    detail::check(uammd_pse_near_prepare(nearField, (const float *)pos.raw(), N, (void *)st));
+    struct Far { uammd_fcm *solver; const float *pos, *force; int N; float T, prefactor; uint seed; float *MF; };
+    Far far{farField, (const float *)pos.raw(), (const float *)force.raw(), N, (float)temperature, (float)(1.0 / std::sqrt(dt)), seedFar, (float *)MF};
+    uammd_interleave_fn queueFar = [](void *c, void *stream) -> int {
+      const Far *f = static_cast<const Far *>(c);
+      return uammd_pse_far_displacements(f->solver, f->pos, f->force, f->N, f->T, f->prefactor, f->seed, f->MF, stream);
+    };
+    detail::check(uammd_pse_near_set_interleave(nearField, queueFar, &far));
+    detail::check(uammd_pse_near_stochastic(nearField, (const float *)pos.raw(), N, temperature, real(1.0), seedNear, (float *)BdW, (void *)st, nullptr));
+    detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
+  }
   void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
     const int N = pd->getNumParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
@@ -1603,6 +1626,17 @@ public:
       : Integrator(pd, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(pd, par)), MF(pd->getNumParticles()),
         BdW(pd->getNumParticles() + 1) {}
   shared_ptr<Method> getMethod() { return bdhi; }
+private:
+  // computeMF then computeBdW (BDHI_EulerMaruyama.cu:140-150) — or, for a method that can interleave the two (PSE: its far field behind
+  // the Lanczos solve's one wait), its computeMFandBdW
+  template <class M> auto mobilityAndNoise(M &m, int) -> decltype(m.computeMFandBdW(MF.d, BdW.d, stream), void()) {
+    m.computeMFandBdW(MF.d, BdW.d, stream);
+  }
+  template <class M> void mobilityAndNoise(M &m, long) {
+    m.computeMF(MF.d, stream);
+    m.computeBdW(BdW.d, stream);
+  }
+public:
   void forwardTime() override {
     steps++;
     for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
@@ -1614,8 +1648,8 @@ public:
     }
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
     bdhi->setup_step(stream);
-    bdhi->computeMF(MF.d, stream);
-    if (par.temperature > 0) bdhi->computeBdW(BdW.d, stream);
+    if (par.temperature > 0) mobilityAndNoise(*bdhi, 0);
+    else bdhi->computeMF(MF.d, stream);
     const real sqrt2Tdt = std::sqrt(2 * par.dt * par.temperature);
     bdhi->finish_step(stream);
     float K[9] = {0};

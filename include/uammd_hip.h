@@ -629,6 +629,18 @@ int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value);
  * non-zero on the rank that holds global element 0.  reduce == NULL restores the single-rank behaviour. */
 typedef int (*uammd_allreduce_fn)(void *ctx, float *d_values, int count, void *stream);
 int uammd_lanczos_set_allreduce(uammd_lanczos *h, uammd_allreduce_fn reduce, void *ctx, int ownsFirstElement);
+/* {check_convergence_steps, lastRunRequiredSteps}: the adaptive schedule a run leaves behind (LanczosAlgorithm.cu:175, :245-251); a caller
+ * that repeats a run restores it first */
+int uammd_lanczos_get_schedule(uammd_lanczos *h, int state[2]);
+int uammd_lanczos_set_schedule(uammd_lanczos *h, const int state[2]);
+/* fn(ctx, stream) is called ONCE during the next uammd_lanczos_run: after the host has answered the run's first convergence check and
+ * before it waits for the outcome (or when the run ends, if it never waited).  What fn queues on the stream runs behind the check's
+ * kernels while the host is busy with the check: the one wait of a run is no longer a drained stream.  One-shot. */
+typedef int (*uammd_interleave_fn)(void *ctx, void *stream);
+int uammd_lanczos_set_interleave(uammd_lanczos *h, uammd_interleave_fn fn, void *ctx);
+/* the same for the solve inside the next uammd_pse_near_stochastic (BDHI::PSE queues its far field there); fn must not call into the
+ * near-field handle.  One-shot. */
+int uammd_pse_near_set_interleave(uammd_pse_near *h, uammd_interleave_fn fn, void *ctx);
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps);
 
 /* BDHI::Lanczos (open boundaries, dense RPY mobility, matrix free).  Replaces

@@ -362,3 +362,96 @@ def test_near_prepare_changes_no_result(hip, o32):
     ref.near_mdot(pos3, f4, expect3)
     assert np.abs(MF.cpu().numpy() - expect3).max() <= 2e-6 * np.abs(expect3).max()
     assert records()[0] > 48 * n and records()[1] >= records()[0]
+
+
+@pytest.mark.gpu
+def test_records_read_after_the_solve(hip, o32):
+    """"optimistic_records": the near-field noise streams the records of a build whose counters it reads only after the Lanczos run.  Same
+    bits and iteration counts as reading them first — also when the build did not fit (first allocation forced small: the solve is repeated
+    on the larger build from the same noise, the solver's adaptive schedule put back), over a run of calls whose schedule adapts."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n, tol, psi = 40.0, 4000, 1e-3, 0.6
+
+    def run(optimistic, capacity):
+        pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+        check(pse.lib.uammd_pse_near_set_option(pse.near, b"optimistic_records", optimistic))
+        if capacity:
+            check(pse.lib.uammd_pse_near_set_option(pse.near, b"pair_capacity", capacity))
+        outs, its = [], []
+        for call in range(6):
+            if call == 3:      # new positions: new list, new records
+                pos2 = pos.copy()
+                pos2[:, :3] = np.random.default_rng(99).uniform(-L / 2, L / 2, (n, 3))
+                pd.getPos("write").copy_(torch.from_numpy(pos2).cuda())
+            BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+            it = C.c_int(0)
+            check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, 1.0, 1.0, 1000 + call, _ptr(BdW), current_stream(),
+                                                    C.byref(it)))
+            outs.append(BdW.cpu().numpy())
+            its.append(it.value)
+        used, cap = C.c_longlong(0), C.c_longlong(0)
+        check(pse.lib.uammd_pse_near_pair_records(pse.near, C.byref(used), C.byref(cap)))
+        return outs, its, used.value, cap.value
+    base = run(0, 0)
+    assert base[2] > 15 * n and all(np.isfinite(o).all() and np.abs(o).max() > 0 for o in base[0])
+    for optimistic, capacity in ((1, 0), (1, 8 * n), (0, 8 * n)):
+        got = run(optimistic, capacity)
+        assert got[1] == base[1], (optimistic, capacity, got[1], base[1])
+        assert all(np.array_equal(a, b) for a, b in zip(got[0], base[0])), (optimistic, capacity)
+        assert got[2] == base[2] and (capacity == 0 or got[3] >= got[2] > capacity)
+
+
+@pytest.mark.gpu
+def test_far_field_interleaved_with_the_solve(hip, o32):
+    """PSE.computeMFandBdW (what EulerMaruyama runs when T > 0: the far field queued from inside the Lanczos solve, behind its convergence
+    check) against computeMF followed by computeBdW on a twin with the same seeds: the same noise bit for bit, the same M F.  The callback runs exactly once per solve,
+    and a product of the near-field handle from inside it is refused."""
+    from uammd_amd._lib import check, INTERLEAVE_FN
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n = 40.0, 4000
+
+    def twin():
+        pd = hip.ParticleData(n, seed=77)
+        rng = np.random.default_rng(7)
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+        pd.setPos(pos)
+        f4 = np.zeros((n, 4), np.float32)
+        f4[:, :3] = np.random.default_rng(3).normal(0, 1, (n, 3))
+        pd.getForce("write").copy_(torch.from_numpy(f4).cuda())
+        par = hip.BDHI.PSE.Parameters(psi=0.6, temperature=1.3, viscosity=VISC, hydrodynamicRadius=RH, tolerance=1e-3, dt=0.01,
+                                      box=hip.Box(L))
+        return pd, hip.BDHI.PSE(pd, par)
+    pd_a, a = twin()
+    pd_b, b = twin()
+    for step in range(3):
+        MFa, Ba = torch.zeros((n, 3), device="cuda"), torch.zeros((n + 1, 3), device="cuda")
+        MFb, Bb = torch.zeros((n, 3), device="cuda"), torch.zeros((n + 1, 3), device="cuda")
+        a.computeMF(MFa)
+        a.computeBdW(Ba)
+        b.computeMFandBdW(MFb, Bb)
+        assert a.lastLanczosIterations == b.lastLanczosIterations, (step, a.lastLanczosIterations, b.lastLanczosIterations)
+        assert torch.equal(Ba, Bb), (step, float((Ba - Bb).abs().max()), float(Ba.abs().max()))
+        # (the far field of this small box spreads with f32 atomics — no tile edge fits its grid — whose order varies from run to run)
+        assert float((MFa - MFb).abs().max()) <= 2e-6 * float(MFa.abs().max()), (step, float((MFa - MFb).abs().max()))
+        assert float(MFa.abs().max()) > 0 and float(Ba.abs().max()) > 0
+        for pd, pse in ((pd_a, a), (pd_b, b)):     # move on: new list, new records
+            pd.getPos("write")[:, :3] += 0.05 * torch.randn((n, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(step))
+    # the callback: once per solve; the handle refuses its own products from inside it
+    calls, refused = [], []
+
+    def inside(_ctx, _stream):
+        calls.append(1)
+        MF = torch.zeros((n, 3), device="cuda")
+        refused.append(b.lib.uammd_pse_near_mdot(b.near, _ptr(pd_b.getPos()), _ptr(pd_b.getForce()), n, _ptr(MF), current_stream()))
+        return 0
+    cb = INTERLEAVE_FN(inside)
+    check(b.lib.uammd_pse_near_positions_changed(b.near))
+    check(b.lib.uammd_pse_near_set_interleave(b.near, C.cast(cb, C.c_void_p), None))
+    out = torch.zeros((n, 3), device="cuda")
+    for _ in range(2):
+        check(b.lib.uammd_pse_near_stochastic(b.near, _ptr(pd_b.getPos()), n, 1.0, 1.0, 5, _ptr(out), current_stream(), None))
+    assert len(calls) == 1 and refused[0] != 0

@@ -232,6 +232,10 @@ SIGNATURES = {
     "uammd_pse_near_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_pse_near_positions_changed": (_i, [_vp]),
     "uammd_pse_near_prepare": (_i, [_vp, _vp, _i, _vp]),
+    "uammd_lanczos_get_schedule": (_i, [_vp, _vp]),
+    "uammd_lanczos_set_schedule": (_i, [_vp, _vp]),
+    "uammd_lanczos_set_interleave": (_i, [_vp, _vp, _vp]),
+    "uammd_pse_near_set_interleave": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_pair_records": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_mdot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_pse_near_stochastic": (_i, [_vp, _vp, _i, _f, _f, _u, _vp, _vp, C.POINTER(_i)]),
@@ -254,6 +258,7 @@ SIGNATURES = {
 
 MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+INTERLEAVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 _lib = None
 

@@ -503,6 +503,42 @@ class PSE:
     def computeBdW(self, BdW):
         self._near_stochastic(BdW, self.temperature, 1.0)       # BDHI_PSE.cuh:122-126
 
+    def computeMFandBdW(self, MF, BdW):
+        """computeMF and computeBdW (BDHI_PSE.cuh:92-126) as EulerMaruyama runs them when T > 0, queued so that the step's one wait for the
+        GPU — the Lanczos solve's convergence check — has work behind it: near-field list and pair records, the solve, and the FAR FIELD
+        from inside the solve (uammd_pse_near_set_interleave: behind the check's kernels, while the host is busy with the check), then the
+        near-field M F.  Run one after the other, the host came back from the check to an empty stream and the GPU idled through the
+        step's last launches and the next step's first (~50 us of 0.6 ms).  The same calls with the same arguments; the two draws of
+        System::rng() keep the reference's order (far field: FarField.cuh:499, then near field: NearField.cuh:276)."""
+        pd = self.pd
+        MF.zero_()
+        force = pd.getForce("read")
+        pos = pd.getPos("read")
+        st = current_stream()
+        seed_far = pd.rng.next32()
+        seed_near = pd.rng.next32()
+        check(self.lib.uammd_pse_near_prepare(self.near, _ptr(pos), pd.N, st))
+        failed = []
+
+        def far(_ctx, _stream):
+            try:
+                check(self.lib.uammd_pse_far_displacements(self.far, _ptr(pos), _ptr(force), pd.N, float(self.temperature),
+                                                           1.0 / math.sqrt(self.dt), seed_far, _ptr(MF), st))
+                return 0
+            except Exception as e:      # (an exception must not cross the C frames)
+                failed.append(e)
+                return -1
+        self._interleave_cb = _lib.INTERLEAVE_FN(far)
+        check(self.lib.uammd_pse_near_set_interleave(self.near, C.cast(self._interleave_cb, C.c_void_p), None))
+        it = C.c_int(0)
+        rc = self.lib.uammd_pse_near_stochastic(self.near, _ptr(pos), pd.N, float(self.temperature), 1.0, seed_near, _ptr(BdW), st,
+                                                C.byref(it))
+        if failed:
+            raise failed[0]
+        check(rc)
+        self.lastLanczosIterations = int(it.value)
+        check(self.lib.uammd_pse_near_mdot(self.near, _ptr(pos), _ptr(force), pd.N, _ptr(MF), st))
+
     def computeHydrodynamicDisplacements(self, force, MF, temperature, noise_prefactor):
         """BDHI_PSE.cuh:135-155, statement for statement: with forces AND T > 0 the Lanczos result overwrites the near
         deterministic term (reference behaviour, kept)."""
@@ -731,9 +767,12 @@ class EulerMaruyama(Integrator):
         for it in self.interactors:
             it.sum(force=True)
         self.bdhi.setup_step()
-        self.bdhi.computeMF(self.MF)
-        if par.temperature > 0:
-            self.bdhi.computeBdW(self.BdW)
+        if par.temperature > 0 and hasattr(self.bdhi, "computeMFandBdW"):   # (a method that interleaves the two: see PSE.computeMFandBdW)
+            self.bdhi.computeMFandBdW(self.MF, self.BdW)
+        else:
+            self.bdhi.computeMF(self.MF)
+            if par.temperature > 0:
+                self.bdhi.computeBdW(self.BdW)
         sqrt2Tdt = math.sqrt(2 * par.dt * par.temperature)
         self.bdhi.finish_step()
         check(self.lib.uammd_bdhi_euler_maruyama(_ptr(pd.getPos("readwrite")), None, _ptr(self.MF),

@@ -44,6 +44,8 @@ template <class T> struct LanczosT {
   int check_convergence_steps = 3;  // Solver::Solver(), LanczosAlgorithm.cu:175
   int iterationHardLimit = 200;
   int lastRunRequiredSteps = 0;
+  uammd_interleave_fn interleave = nullptr;   // uammd_lanczos_set_interleave (one-shot)
+  void *interleaveCtx = nullptr;
   bool deferChecks = true;   // evaluate the convergence checks of several iterations together (lanczos_run)
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
   uammd_allreduce_fn reduce = nullptr;   // (single precision only)
@@ -483,6 +485,29 @@ int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value) {
   set_last_error("uammd_lanczos_set_option: unknown option %s", name);
   return -1;
 }
+// the adaptive schedule a run leaves behind {check_convergence_steps, lastRunRequiredSteps} (LanczosAlgorithm.cu:175, :245-251): a caller
+// that has to REPEAT a run (the PSE near field, when the matrix of the first attempt turns out to have been incomplete) puts it back first
+int uammd_lanczos_get_schedule(uammd_lanczos *h, int state[2]) {
+  if (!h || !state) { set_last_error("uammd_lanczos_get_schedule: null argument"); return -1; }
+  state[0] = reinterpret_cast<Lanczos *>(h)->check_convergence_steps;
+  state[1] = reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps;
+  return 0;
+}
+int uammd_lanczos_set_schedule(uammd_lanczos *h, const int state[2]) {
+  if (!h || !state || state[0] < 1 || state[1] < 0) { set_last_error("uammd_lanczos_set_schedule: bad argument"); return -1; }
+  reinterpret_cast<Lanczos *>(h)->check_convergence_steps = state[0];
+  reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps = state[1];
+  return 0;
+}
+// fn(ctx, stream) is called ONCE during the NEXT run: after the kernels of its first convergence check are queued and before the host
+// waits for them — or when the run ends, if it never waited.  Whatever fn queues on the stream runs behind the check while the host is
+// busy with it: the one wait of a run stops being a drained stream.  One-shot: cleared when called.
+int uammd_lanczos_set_interleave(uammd_lanczos *h, uammd_interleave_fn fn, void *ctx) {
+  if (!h) { set_last_error("uammd_lanczos_set_interleave: null handle"); return -1; }
+  reinterpret_cast<Lanczos *>(h)->interleave = fn;
+  reinterpret_cast<Lanczos *>(h)->interleaveCtx = ctx;
+  return 0;
+}
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps) {
   if (!h || !steps) { set_last_error("uammd_lanczos_get_last_run_required_steps: null argument"); return -1; }
   *steps = reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps;
@@ -632,6 +657,15 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       }
       __atomic_thread_fence(__ATOMIC_RELEASE);
       hs[4] = seq;   // the queued estimate kernel goes ahead (also after a failed diagonalisation: it must not be left waiting)
+      if (L->interleave) {   // the caller's other work for this stream goes in behind the check (uammd_lanczos_set_interleave)
+        uammd_interleave_fn fn = L->interleave;
+        L->interleave = nullptr;
+        if (int rc = fn(L->interleaveCtx, stream)) {
+          (void)wait(1);   // (nothing of this run may be left writing into the status block)
+          if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the interleaved callback failed (%d)", rc);
+          return rc;
+        }
+      }
       const auto tC = std::chrono::steady_clock::now();
       if (int e = wait(1)) return e;
       if (getenv("UAMMD_LANCZOS_DEBUG")) {
@@ -723,7 +757,18 @@ extern "C" {
 
 int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance, int n, void *stream,
                       int *iterations) {
-  return lanczos_run<float>(reinterpret_cast<Lanczos *>(hh), dot, ctx, d_Bv, d_v, tolerance, n, stream, iterations);
+  Lanczos *L = reinterpret_cast<Lanczos *>(hh);
+  const int rc = lanczos_run<float>(L, dot, ctx, d_Bv, d_v, tolerance, n, stream, iterations);
+  if (L && L->interleave) {   // a run that never waited: the callback's work goes in behind it
+    uammd_interleave_fn fn = L->interleave;
+    L->interleave = nullptr;
+    const int rf = fn(L->interleaveCtx, stream);
+    if (!rc && rf) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the interleaved callback failed (%d)", rf);
+      return rf;
+    }
+  }
+  return rc;
 }
 
 // ---- DOUBLE_PRECISION build (global/defines.h:9-11): lanczos::Solver with real = double, e.g. the reference's own test

@@ -52,6 +52,14 @@ struct PSENear {
   // finds the event complete and the GPU busy — waited for on the spot it was a bubble of ~20 us per step
   bool pairsPending = false;
   hipEvent_t pairsEvent = nullptr;
+  // option "optimistic_records" (1): uammd_pse_near_stochastic streams the records of a build whose counters it has not read yet and reads
+  // them AFTER the Lanczos run (which has waited for the GPU by then): no wait at the start of the solve; a build that did not fit — the
+  // kernel then wrote no records for the particles past the capacity — is repeated larger and the solve run again from the same noise,
+  // with the solver's adaptive schedule put back.  `optimistic` is set only inside that call.
+  bool optimisticRecords = true, optimistic = false;
+  size_t pairCapFirst = 0;   // option "pair_capacity": the first allocation in records (tests: a build that has to grow); 0 = 48 per particle
+  uammd_interleave_fn interleave = nullptr;   // uammd_pse_near_set_interleave (one-shot, handed to the next solve)
+  void *interleaveCtx = nullptr;
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
     if (pairTotalHost) (void)hipHostFree(pairTotalHost);
@@ -765,7 +773,7 @@ static int pse_launch_pairs(PSENear *p, hipStream_t st) {
   if (!p->pairsEvent) UH_CHECK(hipEventCreateWithFlags(&p->pairsEvent, hipEventDisableTiming));
   if (int e = p->pairRange.reserve(sizeof(int2) * (size_t)N)) return e;
   if (int e = p->pairCursor.reserve(2 * sizeof(int))) return e;
-  if (p->pairCap < (size_t)N) p->pairCap = (size_t)48 * (size_t)N;
+  if (p->pairCap < (size_t)N) p->pairCap = p->pairCapFirst ? std::max(p->pairCapFirst, (size_t)N) : (size_t)48 * (size_t)N;
   if (p->pairCap > (size_t)0x7fffff00) { p->pairsUnfit = true; return 0; }   // (record indices are ints)
   if (int e = p->recA.reserve(sizeof(float4) * p->pairCap)) return e;
   if (int e = p->recB.reserve(sizeof(float2) * p->pairCap)) return e;
@@ -804,8 +812,9 @@ static int g_ablate = getenv("UAMMD_PSE_ABLATE") ? atoi(getenv("UAMMD_PSE_ABLATE
 #define UH_NEAR8(VS, IND, ACC)                                                                                                       \
   do {                                                                                                                               \
     if (p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1) {                                        \
-      if (!p->pairsValid) { if (int e_ = pse_build_pairs(p, st)) return e_; }                                                        \
-      if (p->pairsValid) {                                                                                                           \
+      const bool ahead_ = p->optimistic && p->pairsPending && !p->pairsValid;                                                        \
+      if (!p->pairsValid && !ahead_) { if (int e_ = pse_build_pairs(p, st)) return e_; }                                             \
+      if (p->pairsValid || ahead_) {                                                                                                 \
         const dim3 gp((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));                                                \
         hipLaunchKernelGGL((k_pse_near_pairs<VS, IND, ACC>), gp, dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr,               \
                            (const float2 *)p->recB.ptr, (const int2 *)p->pairRange.ptr, d_v, (const int *)p->cl.index.ptr, N, d_Mv); \
@@ -1036,6 +1045,8 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
   if (std::string(name) == "pair_list") { p->pairList = value != 0; return 0; }
+  if (std::string(name) == "optimistic_records") { p->optimisticRecords = value != 0; return 0; }
+  if (std::string(name) == "pair_capacity" && value >= 0) { p->pairCapFirst = (size_t)value; p->pairCap = 0; p->pairsValid = false; p->pairsPending = false; return 0; }
   if (std::string(name) == "defer_checks") return uammd_lanczos_set_option(p->lanczos, "defer_checks", value);
   if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
   if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
@@ -1073,11 +1084,23 @@ int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long
   return 0;
 }
 
+// fn(ctx, stream) is handed to the Lanczos solver of the NEXT uammd_pse_near_stochastic (uammd_lanczos_set_interleave): it is called once,
+// behind the solve's first convergence check, for the caller's other work on the stream — BDHI::PSE queues its far field there, so that the
+// one wait of a step has the far field running behind it.  fn must not call into THIS handle (the solve may be streaming pair records
+// whose counters are still unread: a product from inside fn is refused).  One-shot.
+int uammd_pse_near_set_interleave(uammd_pse_near *h, uammd_interleave_fn fn, void *ctx) {
+  if (!h) { set_last_error("uammd_pse_near_set_interleave: null handle"); return -1; }
+  reinterpret_cast<PSENear *>(h)->interleave = fn;
+  reinterpret_cast<PSENear *>(h)->interleaveCtx = ctx;
+  return 0;
+}
+
 // NearField::Mdot (NearField.cuh:239-250): d_MF real3[N] += M_near F, forces real4[N] (NULL: nothing to do)
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int N, float *d_MF, void *stream) {
   if (!h || (N > 0 && (!d_pos || !d_MF))) { set_last_error("uammd_pse_near_mdot: null argument"); return -1; }
   if (!d_force || N <= 0) return 0;
   PSENear *p = reinterpret_cast<PSENear *>(h);
+  if (p->optimistic) { set_last_error("uammd_pse_near_mdot: called from inside the handle's own solve (uammd_pse_near_set_interleave)"); return -1; }
   if (int e = pse_update_list(p, d_pos, N, (hipStream_t)stream)) return e;
   return pse_dot<4, true>(p, d_force, d_MF, (hipStream_t)stream);
 }
@@ -1096,6 +1119,10 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   const float noise_prefactor = prefactor * sqrtf(2 * temperature);
   int it = 0;
   if (p->exactOrder) {
+    if (p->interleave) {
+      if (int e = uammd_lanczos_set_interleave(p->lanczos, p->interleave, p->interleaveCtx)) return e;
+      p->interleave = nullptr;
+    }
     hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
                        seed2);
     UH_CHECK(hipGetLastError());
@@ -1105,11 +1132,37 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
     return rc;
   }
   if (int e = p->sortedOut.reserve(sizeof(float) * 3 * (size_t)N)) return e;
-  hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
-                     noise_prefactor, p->seed, seed2);
-  UH_CHECK(hipGetLastError());
-  const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
-                                   p->tolerance, 3 * N, stream, &it);
+  auto solve = [&]() -> int {
+    hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
+                       noise_prefactor, p->seed, seed2);
+    UH_CHECK(hipGetLastError());
+    return uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
+                             p->tolerance, 3 * N, stream, &it);
+  };
+  // the records' counters are read after the solve instead of before it (PSENear::optimisticRecords)
+  const bool records = p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1;
+  if (records && p->optimisticRecords && !p->pairsValid && !p->pairsPending) { if (int e = pse_launch_pairs(p, st)) return e; }
+  const bool ahead = records && p->optimisticRecords && p->pairsPending && !p->pairsValid;
+  int schedule[2] = {0, 0};
+  if (ahead) { if (int e = uammd_lanczos_get_schedule(p->lanczos, schedule)) return e; }
+  if (p->interleave) {   // (one-shot: a repeated solve below runs without it)
+    if (int e = uammd_lanczos_set_interleave(p->lanczos, p->interleave, p->interleaveCtx)) return e;
+    p->interleave = nullptr;
+  }
+  p->optimistic = ahead;
+  int rc = solve();
+  p->optimistic = false;
+  if (ahead && p->pairsPending) {
+    UH_CHECK(hipEventSynchronize(p->pairsEvent));
+    p->pairsPending = false;
+    if (!p->pairTotalHost[1] && (size_t)p->pairTotalHost[0] <= p->pairCap) p->pairsValid = true;
+    else {   // the products of this solve missed pairs: the build again (pse_build_pairs from the first product: larger, or back to the scanning product), the solve again
+      if (p->pairTotalHost[1]) p->pairsUnfit = true;
+      else p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
+      if (int e = uammd_lanczos_set_schedule(p->lanczos, schedule)) return e;
+      rc = solve();
+    }
+  }
   if (iterations) *iterations = it;
   if (rc) return rc;
   hipLaunchKernelGGL(k_pse_unsort3, dim3((N + 255) / 256), dim3(256), 0, st, (const float *)p->sortedOut.ptr, (const int *)p->cl.index.ptr, N,
