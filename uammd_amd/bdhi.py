@@ -533,6 +533,7 @@ class PSE:
         it = C.c_int(0)
         rc = self.lib.uammd_pse_near_stochastic(self.near, _ptr(pos), pd.N, float(self.temperature), 1.0, seed_near, _ptr(BdW), st,
                                                 C.byref(it))
+        self._interleave_cb = None      # (one-shot; the closure holds self)
         if failed:
             raise failed[0]
         check(rc)

@@ -95,8 +95,7 @@ class ParticleData:
 
     def getPos(self, mode="read"):
         if mode != "read":
-            for cb in self._pos_write_callbacks:  # ParticleData::getPosWriteRequestedSignal
-                cb()
+            self._emit(self._pos_write_callbacks)  # ParticleData::getPosWriteRequestedSignal
         return self._get("pos", 4)
 
     def getForce(self, mode="read"):
@@ -146,12 +145,32 @@ class ParticleData:
         p = self.getPos("write")
         p.copy_(torch.as_tensor(np.ascontiguousarray(pos4, dtype=np.float32)).to(self.device))
 
+    @staticmethod
+    def _slot(cb):
+        """A connection must not keep its receiver alive (the reference's receivers hold connection objects that disconnect with them):
+        a bound method is held weakly — ParticleData -> callback -> solver -> ParticleData would otherwise be a cycle, and the solver's
+        handle (device memory, streams, events) would live until the cyclic collector happens to run."""
+        import weakref
+        return weakref.WeakMethod(cb) if hasattr(cb, "__self__") and cb.__self__ is not None else (lambda: cb)
+
+    @staticmethod
+    def _emit(slots):
+        dead = False
+        for s in list(slots):
+            cb = s()
+            if cb is None:
+                dead = True
+            else:
+                cb()
+        if dead:
+            slots[:] = [s for s in slots if s() is not None]
+
     def connectPosWrite(self, cb):
-        self._pos_write_callbacks.append(cb)
+        self._pos_write_callbacks.append(self._slot(cb))
 
     def connectReorder(self, cb):
         """ParticleData::getReorderSignal (ParticleData.cuh:196-208)."""
-        self._reorder_callbacks.append(cb)
+        self._reorder_callbacks.append(self._slot(cb))
 
     def hintSortByHash(self, hash_box, hash_cutOff):
         """ParticleData::hintSortByHash (ParticleData.cuh:389-394)."""
@@ -180,10 +199,8 @@ class ParticleData:
         out = torch.empty_like(self.id)
         check(lib.uammd_gather(_ptr(self.id), _ptr(idx), _ptr(out), self.N, 4, current_stream()))
         self.id = out
-        for cb in self._pos_write_callbacks:
-            cb()
-        for cb in self._reorder_callbacks:
-            cb()
+        self._emit(self._pos_write_callbacks)
+        self._emit(self._reorder_callbacks)
 
 
 class ParticleGroup:
