@@ -455,3 +455,31 @@ def test_far_field_interleaved_with_the_solve(hip, o32):
     for _ in range(2):
         check(b.lib.uammd_pse_near_stochastic(b.near, _ptr(pd_b.getPos()), n, 1.0, 1.0, 5, _ptr(out), current_stream(), None))
     assert len(calls) == 1 and refused[0] != 0
+
+
+@pytest.mark.gpu
+def test_interleaved_work_is_queued_once_on_every_path(hip, o32):
+    """uammd_pse_near_set_interleave: the callback runs exactly once per uammd_pse_near_stochastic whatever the call does — a solve, nothing to
+    solve (T = 0), the exact-order solve, a refused call — and no registration is left for the call after."""
+    from uammd_amd._lib import INTERLEAVE_FN
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n = 40.0, 2000
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, 1e-3, 0.6, n)
+    calls = []
+    cb = INTERLEAVE_FN(lambda _c, _s: calls.append(1) or 0)
+    out = torch.zeros((n, 3), device="cuda")
+
+    def stochastic(T, register=True, out_ptr=None):
+        if register:
+            assert pse.lib.uammd_pse_near_set_interleave(pse.near, C.cast(cb, C.c_void_p), None) == 0
+        return pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, T, 1.0, 7, _ptr(out) if out_ptr is None else out_ptr,
+                                                 current_stream(), None)
+    assert stochastic(1.0) == 0 and len(calls) == 1
+    assert stochastic(0.0) == 0 and len(calls) == 2              # nothing to solve: queued on the way out
+    assert stochastic(1.0, register=False) == 0 and len(calls) == 2   # one-shot
+    assert stochastic(1.0, out_ptr=C.c_void_p(0)) != 0 and len(calls) == 3   # a refused call still hands the stream over
+    assert pse.lib.uammd_pse_near_set_option(pse.near, b"exact_order", 1) == 0
+    assert stochastic(1.0) == 0 and len(calls) == 4
+    assert stochastic(1.0, register=False) == 0 and len(calls) == 4
+    torch.cuda.synchronize()

@@ -1109,29 +1109,53 @@ int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_fo
 // (the Lanczos result OVERWRITES d_BdW).  seed2 = the per-call draw of System::rng().  Nothing happens when T == 0.
 int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, float temperature, float prefactor,
                               unsigned int seed2, float *d_BdW, void *stream, int *iterations) {
-  if (!h || (N > 0 && (!d_pos || !d_BdW))) { set_last_error("uammd_pse_near_stochastic: null argument"); return -1; }
+  if (!h) { set_last_error("uammd_pse_near_stochastic: null handle"); return -1; }
   if (iterations) *iterations = 0;
-  if (temperature == 0.0f || N <= 0) return 0;
   PSENear *p = reinterpret_cast<PSENear *>(h);
   hipStream_t st = (hipStream_t)stream;
-  if (int e = pse_update_list(p, d_pos, N, st)) return e;
-  if (int e = p->noise.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+  // The caller's interleaved work (uammd_pse_near_set_interleave) is queued EXACTLY once by this call, whatever path it takes: by the
+  // solver behind its first check, or here on the way out (nothing to solve, an error before the solve, a solve that never waited) —
+  // and no registration outlives the call (its context may live on the caller's stack).
+  struct Hook {
+    PSENear *p; void *stream; uammd_interleave_fn fn; void *ctx; bool fired = false; int rc = 0;
+    static int tramp(void *self, void *stream) {
+      Hook *k = static_cast<Hook *>(self);
+      k->fired = true;
+      return k->fn(k->ctx, stream);
+    }
+    ~Hook() {
+      if (!fn) return;
+      (void)uammd_lanczos_set_interleave(p->lanczos, nullptr, nullptr);
+      if (!fired) { fired = true; rc = fn(ctx, stream); }
+    }
+  } hook{p, stream, p->interleave, p->interleaveCtx};
+  p->interleave = nullptr;
+  p->interleaveCtx = nullptr;
+  auto leave = [&](int rc) -> int {   // (the hook's own failure is reported when nothing else failed)
+    if (hook.fn && !hook.fired) { hook.fired = true; hook.rc = hook.fn(hook.ctx, stream); }
+    if (!rc && hook.rc) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_pse_near_stochastic: the interleaved callback failed (%d)", hook.rc);
+      return hook.rc;
+    }
+    return rc;
+  };
+  if (N > 0 && (!d_pos || !d_BdW)) { set_last_error("uammd_pse_near_stochastic: null argument"); return leave(-1); }
+  if (temperature == 0.0f || N <= 0) return leave(0);
+  if (int e = pse_update_list(p, d_pos, N, st)) return leave(e);
+  if (int e = p->noise.reserve(sizeof(float) * 3 * (size_t)N)) return leave(e);
   const float noise_prefactor = prefactor * sqrtf(2 * temperature);
   int it = 0;
   if (p->exactOrder) {
-    if (p->interleave) {
-      if (int e = uammd_lanczos_set_interleave(p->lanczos, p->interleave, p->interleaveCtx)) return e;
-      p->interleave = nullptr;
-    }
+    if (hook.fn) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return leave(e); }
     hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
                        seed2);
-    UH_CHECK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { set_last_error("uammd_pse_near_stochastic: kernel launch failed"); return leave(-1); }
     const int rc = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot, p, d_BdW, (const float *)p->noise.ptr, p->tolerance, 3 * N,
                                      stream, &it);
     if (iterations) *iterations = it;
-    return rc;
+    return leave(rc);
   }
-  if (int e = p->sortedOut.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+  if (int e = p->sortedOut.reserve(sizeof(float) * 3 * (size_t)N)) return leave(e);
   auto solve = [&]() -> int {
     hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
                        noise_prefactor, p->seed, seed2);
@@ -1141,14 +1165,11 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   };
   // the records' counters are read after the solve instead of before it (PSENear::optimisticRecords)
   const bool records = p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1;
-  if (records && p->optimisticRecords && !p->pairsValid && !p->pairsPending) { if (int e = pse_launch_pairs(p, st)) return e; }
+  if (records && p->optimisticRecords && !p->pairsValid && !p->pairsPending) { if (int e = pse_launch_pairs(p, st)) return leave(e); }
   const bool ahead = records && p->optimisticRecords && p->pairsPending && !p->pairsValid;
   int schedule[2] = {0, 0};
-  if (ahead) { if (int e = uammd_lanczos_get_schedule(p->lanczos, schedule)) return e; }
-  if (p->interleave) {   // (one-shot: a repeated solve below runs without it)
-    if (int e = uammd_lanczos_set_interleave(p->lanczos, p->interleave, p->interleaveCtx)) return e;
-    p->interleave = nullptr;
-  }
+  if (ahead) { if (int e = uammd_lanczos_get_schedule(p->lanczos, schedule)) return leave(e); }
+  if (hook.fn) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return leave(e); }   // (one-shot: a repeated solve below runs without it)
   p->optimistic = ahead;
   int rc = solve();
   p->optimistic = false;
@@ -1159,16 +1180,16 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
     else {   // the products of this solve missed pairs: the build again (pse_build_pairs from the first product: larger, or back to the scanning product), the solve again
       if (p->pairTotalHost[1]) p->pairsUnfit = true;
       else p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
-      if (int e = uammd_lanczos_set_schedule(p->lanczos, schedule)) return e;
+      if (int e = uammd_lanczos_set_schedule(p->lanczos, schedule)) return leave(e);
       rc = solve();
     }
   }
   if (iterations) *iterations = it;
-  if (rc) return rc;
+  if (rc) return leave(rc);
   hipLaunchKernelGGL(k_pse_unsort3, dim3((N + 255) / 256), dim3(256), 0, st, (const float *)p->sortedOut.ptr, (const int *)p->cl.index.ptr, N,
                      d_BdW);
   UH_CHECK(hipGetLastError());
-  return 0;
+  return leave(0);
 }
 
 // test hook: the Saru noise vector of computeStochasticDisplacements (real3[N])

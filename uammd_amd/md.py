@@ -150,8 +150,9 @@ class ParticleData:
         """A connection must not keep its receiver alive (the reference's receivers hold connection objects that disconnect with them):
         a bound method is held weakly — ParticleData -> callback -> solver -> ParticleData would otherwise be a cycle, and the solver's
         handle (device memory, streams, events) would live until the cyclic collector happens to run."""
+        import types
         import weakref
-        return weakref.WeakMethod(cb) if hasattr(cb, "__self__") and cb.__self__ is not None else (lambda: cb)
+        return weakref.WeakMethod(cb) if isinstance(cb, types.MethodType) else (lambda: cb)
 
     @staticmethod
     def _emit(slots):
