@@ -143,6 +143,22 @@ UH_D uint wave_inclusive_scan(uint x) {
   x += (uint)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
   return x;
 }
+// the sum of x over the 64 lanes of a wave, valid in lane 63 (read it with wave_total), in six DPP additions — a __shfl_xor ladder is six
+// ds_bpermute round trips per value (~100 cycles each): pairs and quads by quad_perm, the row of 16 by the two mirrors, the rows by the
+// two broadcasts.  The order of the additions is fixed: the same bits on every run.
+template <int CTRL, int ROWS, bool BOUND> UH_D float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, BOUND));
+}
+UH_D float wave_sum_to_last(float x) {
+  x += dpp_move<0xB1, 0xf, true>(x);    // quad_perm [1, 0, 3, 2]
+  x += dpp_move<0x4E, 0xf, true>(x);    // quad_perm [2, 3, 0, 1]
+  x += dpp_move<0x141, 0xf, true>(x);   // row_half_mirror: eight lanes
+  x += dpp_move<0x140, 0xf, true>(x);   // row_mirror: the row of sixteen
+  x += dpp_move<0x142, 0xa, false>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_move<0x143, 0xc, false>(x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+UH_D float wave_total(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_to_last(x)), 63)); }
 UH_HD uint morton_hash(int3 c) { return spread10((uint)c.x) | (spread10((uint)c.y) << 1) | (spread10((uint)c.z) << 2); }
 
 // Global -> LDS copies go through registers U at a time: written as `buf[f(i)] = g[h(i)]` in a loop of run-time length the compiler
