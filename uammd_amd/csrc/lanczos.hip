@@ -59,20 +59,23 @@ template <class T> struct LanczosT {
   ~LanczosT() { if (hostStat) (void)hipHostFree((void *)hostStat); }
 };
 
-template <class T> UH_D T block_sum(T x, T *sh) {
+// the wave's sum in lane 63: six DPP additions in single precision (a __shfl_xor ladder is six ds_bpermute round trips, and these kernels
+// are nothing but latency: ~4.5 us each for 1.2 MB vectors), the ladder in double
+UH_D float wave_sum_last(float x) { return wave_sum_to_last(x); }
+UH_D double wave_sum_last(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+template <class T> UH_D T block_sum(T x, T *sh) {
+  static_assert(kLB == 256, "four waves per block");
+  x = wave_sum_last(x);
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sh[wv] = x;
+  if ((threadIdx.x & 63) == 63) sh[wv] = x;
   __syncthreads();
-  T t = 0;
-  if (threadIdx.x < 64) {
-    t = (threadIdx.x < kLB / 64) ? sh[threadIdx.x] : T(0);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-  }
+  const T t = (sh[0] + sh[2]) + (sh[1] + sh[3]);   // (the four waves' sums, every thread the same: no second ladder)
   __syncthreads();
-  return t;  // valid in wave 0
+  return t;
 }
 template <class T> UH_D T sum_parts(const T *__restrict__ parts, int nparts, T *sh) {  // every block: same order, same result
   T x = 0;

@@ -539,12 +539,17 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__r
       tz += fmaf(gm, rij.z, a[u].x * vz[u]);
     }
   }
-#pragma unroll
-  for (int o = 1; o < kNearGroup; o <<= 1) {
-    tx += __shfl_xor(tx, o, 64);
-    ty += __shfl_xor(ty, o, 64);
-    tz += __shfl_xor(tz, o, 64);
-  }
+  // the group's eight partial sums by three DPP additions each (pairs, quads, the half row) instead of three ds_bpermute round trips
+  static_assert(kNearGroup == 8, "eight lanes per particle");
+  auto group_sum = [](float x) {
+    x += dpp_move<0xB1, 0xf, true>(x);    // quad_perm [1, 0, 3, 2]
+    x += dpp_move<0x4E, 0xf, true>(x);    // quad_perm [2, 3, 0, 1]
+    x += dpp_move<0x141, 0xf, true>(x);   // row_half_mirror
+    return x;
+  };
+  tx = group_sum(tx);
+  ty = group_sum(ty);
+  tz = group_sum(tz);
   if (active && sub == 0) {
     float *o = Mv + 3 * (size_t)(INDIRECT ? groupIndex[id] : id);
     if (ACCUM) { o[0] += tx; o[1] += ty; o[2] += tz; }
