@@ -233,10 +233,9 @@ __global__ void __launch_bounds__(kBlock) k_key_scan(const uint *__restrict__ ke
   __shared__ uint waveSum[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto block_sum = [&](uint v) -> uint {  // every thread gets the workgroup's total
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    v = wave_inclusive_scan(v);   // (lane 63: the wave's total)
     __syncthreads();  // (waveSum is reused)
-    if (lane == 0) waveSum[wave] = v;
+    if (lane == 63) waveSum[wave] = v;
     __syncthreads();
     uint t = 0;
 #pragma unroll
@@ -277,12 +276,7 @@ __global__ void __launch_bounds__(kBlock) k_key_scan(const uint *__restrict__ ke
     const uint k = t + 4 * threadIdx.x;
     load4(k, c);
     const uint mine = c[0] + c[1] + c[2] + c[3];
-    uint incl = mine;  // inclusive scan inside the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint up = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += up;
-    }
+    const uint incl = wave_inclusive_scan(mine);  // inclusive scan inside the wave (six DPP additions: no ds_bpermute ladder)
     __syncthreads();
     if (lane == 63) waveSum[wave] = incl;
     __syncthreads();

@@ -228,12 +228,7 @@ __global__ void __launch_bounds__(1024) k_fcm_tile_scan(int *__restrict__ count,
       if (i + 2 < ntiles) { c.z = count[i + 2]; count[i + 2] = 0; }
     }
     const int v = c.x + c.y + c.z + c.w;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
+    const int incl = (int)wave_inclusive_scan((uint)v);   // (six DPP additions: no ds_bpermute ladder)
     if (lane == 63) waveTotal[buf][wave] = incl;
     __syncthreads();   // (two buffers: the next round's writes cannot overtake this round's reads)
     int before = 0, total = 0;
