@@ -392,12 +392,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     const int t = ux + ntiles.x * (uy + ntiles.y * uz);
     const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
     // inclusive scan of the 27 range lengths inside wave 0
-    int incl = e - s;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (nb >= o) incl += v;
-    }
+    const int incl = (int)wave_inclusive_scan((uint)(e - s));   // (DPP additions: the 27 active lanes sit in rows 0 and 1)
     rPrefix[nb + 1] = incl;
     if (nb == 0) rPrefix[0] = 0;
     // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
