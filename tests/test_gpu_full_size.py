@@ -116,3 +116,57 @@ def test_fcm_c5_eight_slabs_equal_single_gpu(hip):
         err = ((v - vref).norm() / vref.norm()).item()
         print(f"[FCM C5, 8 slabs in process, T={T}] rel L2 err vs single GPU {err:.2e}")
         assert err <= 1e-5
+
+
+def test_pse_full_size_vs_oracle(hip, o32):
+    """BDHI::PSE at the size bench.py times (1e5 particles, L = 128, psi = 0.5, tolerance 1e-3: cut-off 5.26 -> 24^3 cells and ~29
+    neighbours per particle, far field on 108^3 with support 7) against the oracle — the paths that only exist at this size: the pair
+    records (the small cases hold 22 neighbours, this one the bench's), the 6-node spreading tiles and the 12 x 9 FFT plan of the 108^3
+    far field, the Lanczos solve with deferred checks on 3e5-element vectors."""
+    import ctypes as C
+    from oracle.pse import PSEOracle
+    from uammd_amd._lib import check
+    from uammd_amd.md import Xorshift128plus, _ptr, current_stream
+    n, L, psi, tol = 100_000, 128.0, 0.5, 1e-3
+    rng = np.random.default_rng(1234)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-L / 2, L / 2, (n, 3))
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = np.random.default_rng(4321).normal(0, 1, (n, 3))
+    pd = hip.ParticleData(n, seed=1)
+    pd.setPos(pos)
+    par = hip.BDHI.PSE.Parameters(psi=psi, temperature=0.0, viscosity=1.0, hydrodynamicRadius=1.0, tolerance=tol, dt=1.0, box=hip.Box(L))
+    pse = hip.BDHI.PSE(pd, par)
+    assert list(pse.cells) == [108, 108, 108] and pse.support == 7
+    r = Xorshift128plus()
+    r.set_seed(1)
+    ref = PSEOracle(o32, [L] * 3, 1.0, 1.0, tol, psi, seed_near=r.next32(), seed_far=r.next32())
+    d_f = torch.from_numpy(f4).cuda()
+    # near field, deterministic: the records
+    MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+    used = C.c_longlong(0)
+    check(pse.lib.uammd_pse_near_pair_records(pse.near, C.byref(used), None))
+    assert 25 * n < used.value < 35 * n
+    expect = np.zeros((n, 3), np.float32)
+    ref.near_mdot(pos, f4, expect)
+    err = np.abs(MF.cpu().numpy() - expect).max() / np.abs(expect).max()
+    print(f"[PSE near M F, {used.value / n:.1f} records per particle] max err / max|MF| {err:.2e}")
+    assert err <= 2e-6
+    # far field: deterministic, then with the Fourier-space noise
+    for T, pref, seed2 in ((0.0, 0.0, 0), (1.0, 10.0, 4242)):
+        out = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(pse.lib.uammd_pse_far_displacements(pse.far, _ptr(pd.getPos()), _ptr(d_f), n, T, pref, seed2, _ptr(out), current_stream()))
+        expect = np.zeros((n, 3), np.float32)
+        ref.far(pos, f4, expect, T, pref, seed2)
+        err = np.linalg.norm(out.cpu().numpy() - expect) / np.linalg.norm(expect)
+        print(f"[PSE far field 108^3, T = {T}] rel L2 err vs oracle {err:.2e}")
+        assert err <= 1e-5
+    # near noise: the Lanczos solve (the oracle iterates the reference's schedule: check at every iteration)
+    BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    it = C.c_int(0)
+    check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, 1.0, 1.0, 555, _ptr(BdW), current_stream(), C.byref(it)))
+    exp = ref.near_stochastic(pos, 1.0, 1.0, 555)
+    err = np.linalg.norm(BdW.cpu().numpy() - exp) / np.linalg.norm(exp)
+    print(f"[PSE near noise, {it.value} Lanczos iterations] rel L2 err vs oracle {err:.2e}")
+    assert 3 <= it.value <= 12 and err <= 5 * tol
