@@ -1484,13 +1484,20 @@ public:
     const uint seedFar = pd->getSystem()->rng().next32();
     const uint seedNear = pd->getSystem()->rng().next32();
     detail::check(uammd_pse_near_prepare(nearField, (const float *)pos.raw(), N, (void *)st));
+    // the far field in two halves around the check: spreading and forward transforms while the host answers it, the rest while the host
+    // reacts to its outcome
     struct Far { uammd_fcm *solver; const float *pos, *force; int N; float T, prefactor; uint seed; float *MF; };
     Far far{farField, (const float *)pos.raw(), (const float *)force.raw(), N, (float)temperature, (float)(1.0 / std::sqrt(dt)), seedFar, (float *)MF};
-    uammd_interleave_fn queueFar = [](void *c, void *stream) -> int {
+    uammd_interleave_fn firstHalf = [](void *c, void *stream) -> int {
       const Far *f = static_cast<const Far *>(c);
-      return uammd_pse_far_displacements(f->solver, f->pos, f->force, f->N, f->T, f->prefactor, f->seed, f->MF, stream);
+      return uammd_pse_far_displacements_half(f->solver, f->pos, f->force, f->N, f->T, f->prefactor, f->seed, f->MF, 1, stream);
     };
-    detail::check(uammd_pse_near_set_interleave(nearField, queueFar, &far));
+    uammd_interleave_fn secondHalf = [](void *c, void *stream) -> int {
+      const Far *f = static_cast<const Far *>(c);
+      return uammd_pse_far_displacements_half(f->solver, f->pos, f->force, f->N, f->T, f->prefactor, f->seed, f->MF, 2, stream);
+    };
+    detail::check(uammd_pse_near_set_interleave_early(nearField, firstHalf, &far));
+    detail::check(uammd_pse_near_set_interleave(nearField, secondHalf, &far));
     detail::check(uammd_pse_near_stochastic(nearField, (const float *)pos.raw(), N, temperature, real(1.0), seedNear, (float *)BdW, (void *)st, nullptr));
     detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
   }

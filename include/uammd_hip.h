@@ -638,9 +638,17 @@ int uammd_lanczos_set_schedule(uammd_lanczos *h, const int state[2]);
  * kernels while the host is busy with the check: the one wait of a run is no longer a drained stream.  One-shot. */
 typedef int (*uammd_interleave_fn)(void *ctx, void *stream);
 int uammd_lanczos_set_interleave(uammd_lanczos *h, uammd_interleave_fn fn, void *ctx);
+/* one stage earlier: called after the first check's scalars are on their way to the host and BEFORE the kernels that wait for the host's
+ * answer; what fn queues runs while the host solves the check's small eigenproblems.  One-shot; called before the callback above. */
+int uammd_lanczos_set_interleave_early(uammd_lanczos *h, uammd_interleave_fn fn, void *ctx);
 /* the same for the solve inside the next uammd_pse_near_stochastic (BDHI::PSE queues its far field there); fn must not call into the
  * near-field handle.  One-shot. */
 int uammd_pse_near_set_interleave(uammd_pse_near *h, uammd_interleave_fn fn, void *ctx);
+int uammd_pse_near_set_interleave_early(uammd_pse_near *h, uammd_interleave_fn fn, void *ctx);
+/* uammd_pse_far_displacements queued in two halves on the same stream with the same arguments (1: binning, spreading, forward x / y
+ * transforms; 2: z transforms + operator + noise, inverse transforms, gather) — for the two callbacks above */
+int uammd_pse_far_displacements_half(uammd_fcm *h, const float *d_pos, const float *d_force, int numberParticles, float temperature,
+                                     float prefactor, unsigned int seed2, float *d_MF, int half, void *stream);
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps);
 
 /* BDHI::Lanczos (open boundaries, dense RPY mobility, matrix free).  Replaces

@@ -162,6 +162,20 @@ def test_pse_full_size_vs_oracle(hip, o32):
         err = np.linalg.norm(out.cpu().numpy() - expect) / np.linalg.norm(expect)
         print(f"[PSE far field 108^3, T = {T}] rel L2 err vs oracle {err:.2e}")
         assert err <= 1e-5
+    # the far field queued in two halves (what BDHI::PSE does around the near field's convergence check) against the whole
+    whole = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(pse.lib.uammd_pse_far_displacements(pse.far, _ptr(pd.getPos()), _ptr(d_f), n, 1.0, 10.0, 4242, _ptr(whole), current_stream()))
+    halves = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(1 << 20, device="cuda")
+    for half in (1, 2):
+        check(pse.lib.uammd_pse_far_displacements_half(pse.far, _ptr(pd.getPos()), _ptr(d_f), n, 1.0, 10.0, 4242, _ptr(halves), half,
+                                                       current_stream()))
+        scratch.add_(1.0)      # (other work between the halves)
+    # (not bit for bit: a tile's particles are ranked by an atomic counter at binning time, so the order of a node's terms — and the last bits —
+    # differ between any two solves)
+    assert float((whole - halves).abs().max()) <= 2e-6 * float(whole.abs().max())
+    assert pse.lib.uammd_pse_far_displacements_half(pse.far, _ptr(pd.getPos()), _ptr(d_f), n, 1.0, 10.0, 4242, _ptr(halves), 2,
+                                                    current_stream()) != 0      # a second half without its first is refused
     # near noise: the Lanczos solve (the oracle iterates the reference's schedule: check at every iteration)
     BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     it = C.c_int(0)

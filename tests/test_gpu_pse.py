@@ -466,13 +466,15 @@ def test_interleaved_work_is_queued_once_on_every_path(hip, o32):
     import ctypes as C
     L, n = 40.0, 2000
     pd, pse, ref, pos, _ = _pair(hip, o32, L, 1e-3, 0.6, n)
-    calls = []
-    cb = INTERLEAVE_FN(lambda _c, _s: calls.append(1) or 0)
+    calls, order = [], []
+    cb = INTERLEAVE_FN(lambda _c, _s: (calls.append(1), order.append("late")) and 0)
+    cb_early = INTERLEAVE_FN(lambda _c, _s: order.append("early") or 0)
     out = torch.zeros((n, 3), device="cuda")
 
     def stochastic(T, register=True, out_ptr=None):
         if register:
             assert pse.lib.uammd_pse_near_set_interleave(pse.near, C.cast(cb, C.c_void_p), None) == 0
+            assert pse.lib.uammd_pse_near_set_interleave_early(pse.near, C.cast(cb_early, C.c_void_p), None) == 0
         return pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, T, 1.0, 7, _ptr(out) if out_ptr is None else out_ptr,
                                                  current_stream(), None)
     assert stochastic(1.0) == 0 and len(calls) == 1
@@ -483,3 +485,4 @@ def test_interleaved_work_is_queued_once_on_every_path(hip, o32):
     assert stochastic(1.0) == 0 and len(calls) == 4
     assert stochastic(1.0, register=False) == 0 and len(calls) == 4
     torch.cuda.synchronize()
+    assert order == ["early", "late"] * 4          # the early callback before the late one on every path, each once

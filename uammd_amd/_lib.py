@@ -236,6 +236,8 @@ SIGNATURES = {
     "uammd_lanczos_set_schedule": (_i, [_vp, _vp]),
     "uammd_lanczos_set_interleave": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_set_interleave": (_i, [_vp, _vp, _vp]),
+    "uammd_pse_near_set_interleave_early": (_i, [_vp, _vp, _vp]),
+    "uammd_lanczos_set_interleave_early": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_pair_records": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_mdot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_pse_near_stochastic": (_i, [_vp, _vp, _i, _f, _f, _u, _vp, _vp, C.POINTER(_i)]),
@@ -245,6 +247,7 @@ SIGNATURES = {
     "uammd_pse_far_create": (_i, [_f3, _i3, _f, _f, _f, _f, _f, _u, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_f)]),
     "uammd_pse_far_set_shear_strain": (_i, [_vp, _f]),
     "uammd_pse_far_displacements": (_i, [_vp, _vp, _vp, _i, _f, _f, _u, _vp, _vp]),
+    "uammd_pse_far_displacements_half": (_i, [_vp, _vp, _vp, _i, _f, _f, _u, _vp, _i, _vp]),
     "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),

@@ -520,16 +520,21 @@ class PSE:
         check(self.lib.uammd_pse_near_prepare(self.near, _ptr(pos), pd.N, st))
         failed = []
 
-        def far(_ctx, _stream):
-            try:
-                check(self.lib.uammd_pse_far_displacements(self.far, _ptr(pos), _ptr(force), pd.N, float(self.temperature),
-                                                           1.0 / math.sqrt(self.dt), seed_far, _ptr(MF), st))
-                return 0
-            except Exception as e:      # (an exception must not cross the C frames)
-                failed.append(e)
-                return -1
-        self._interleave_cb = _lib.INTERLEAVE_FN(far)
-        check(self.lib.uammd_pse_near_set_interleave(self.near, C.cast(self._interleave_cb, C.c_void_p), None))
+        def far_half(half):
+            def queue(_ctx, _stream):
+                try:
+                    check(self.lib.uammd_pse_far_displacements_half(self.far, _ptr(pos), _ptr(force), pd.N, float(self.temperature),
+                                                                    1.0 / math.sqrt(self.dt), seed_far, _ptr(MF), half, st))
+                    return 0
+                except Exception as e:      # (an exception must not cross the C frames)
+                    failed.append(e)
+                    return -1
+            return _lib.INTERLEAVE_FN(queue)
+        # the far field in two halves around the check: spreading and forward transforms while the host answers it (the GPU idled in
+        # the kernel that waits for the answer), the rest while the host reacts to its outcome
+        self._interleave_cb = (far_half(1), far_half(2))
+        check(self.lib.uammd_pse_near_set_interleave_early(self.near, C.cast(self._interleave_cb[0], C.c_void_p), None))
+        check(self.lib.uammd_pse_near_set_interleave(self.near, C.cast(self._interleave_cb[1], C.c_void_p), None))
         it = C.c_int(0)
         rc = self.lib.uammd_pse_near_stochastic(self.near, _ptr(pos), pd.N, float(self.temperature), 1.0, seed_near, _ptr(BdW), st,
                                                 C.byref(it))

@@ -40,6 +40,20 @@ namespace uammd_hip {
 // PSE far field (FarField.cuh:85-119): hydrodynamic radius, Ewald splitting, kernel splitting, shear strain
 struct PseGreens { float rh, split, eta, shear; bool on; };
 
+// the tile-sorted stencil arrays of a solve (fcm_prepare_tiles)
+struct FcmPrep {
+  // all arrays below are in TILE-SORTED order (slot = tileStart[tile] + rank) except tileOf/rank
+  int4 *origin;     // int4[N]: first stencil node per axis (celli - P), unwrapped; .w = original particle index
+  float *weights;   // float[wstride*N]
+  float4 *force;    // float4[N] (xyz)
+  int *tileOf;      // int[N]   (original order)
+  int *rank;        // int[N]   (original order)
+  int *tileCount;   // int[ntiles]
+  int *tileStart;   // int[ntiles+1]
+  int wstride;
+  int3 tdim;        // tile edge per axis (<= kTile: the kernels' layouts are sized for kTile, shorter tiles leave rows / columns unused)
+};
+
 struct FCM {
   uammd_fcm_parameters par;
   GridT<float> grid;
@@ -76,6 +90,9 @@ struct FCM {
   rocfft_execution_info info = nullptr;
   size_t workBytes = 0;
   unsigned int seed2 = 0;  // the reference's `static uint seed2` (FCM_impl.cuh:517): per-handle here
+  FcmPrep halfPrep{};      // a solve queued in two halves (fcm_displacements_impl): the stencil view of the first for the second
+  int halfN = 0;
+  bool halfPending = false;
   ~FCM() {
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
@@ -159,18 +176,6 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
 // (k_fcm_prepare) and reused by every tile that the particle touches and by the gather.
 constexpr int kTile = 8;
 
-struct FcmPrep {
-  // all arrays below are in TILE-SORTED order (slot = tileStart[tile] + rank) except tileOf/rank
-  int4 *origin;     // int4[N]: first stencil node per axis (celli - P), unwrapped; .w = original particle index
-  float *weights;   // float[wstride*N]
-  float4 *force;    // float4[N] (xyz)
-  int *tileOf;      // int[N]   (original order)
-  int *rank;        // int[N]   (original order)
-  int *tileCount;   // int[ntiles]
-  int *tileStart;   // int[ntiles+1]
-  int wstride;
-  int3 tdim;        // tile edge per axis (<= kTile: the kernels' layouts are sized for kTile, shorter tiles leave rows / columns unused)
-};
 
 __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict__ pos, int N, GridT<float> grid,
                                                         int3 ntiles, FcmPrep pr) {
@@ -1523,8 +1528,11 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
 }
 
 // stage: 0 = full pipeline; 1 = stop after spread+FFT+k-space (the Fourier grid can then be exported)
+// half: 0 = the whole solve; 1 = its first half (binning, stencils, spreading, the forward x / y transforms), 2 = the second (z transform,
+// operator and noise, inverse transforms, gather) of a solve whose first half was queued on the same stream with the same arguments —
+// for a caller with other work to queue in between (uammd_pse_far_displacements_half)
 static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
-                                  float prefactor, float *d_linearVelocity, int stage, void *stream, bool positionsKept) {
+                                  float prefactor, float *d_linearVelocity, int stage, void *stream, bool positionsKept, int half = 0) {
   if (!h) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
   if (N <= 0) return 0;  // nothing to move (an empty ParticleData has no arrays to point to)
   if (!d_pos || (!d_linearVelocity && stage == 0)) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
@@ -1539,10 +1547,14 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
   const bool custom = stage == 0 && fcm_custom_fft_usable(f);  // (stage 1 exports the Fourier grid, which the fused z pass never stores)
   FcmPrep pr{};
-  if (tiles) {
+  if (half == 2) {
+    if (!f->halfPending || f->halfN != N) { set_last_error("uammd_fcm: the second half of a solve without its first"); return -1; }
+    pr = f->halfPrep;
+    f->halfPending = false;
+  } else if (tiles) {
     if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
   }
-  if (d_force) {
+  if (d_force && half != 2) {
     if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
@@ -1560,6 +1572,13 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
     }
     if (custom) { if (int e = fcm_fft_forward_xy(f, g, st)) return e; }
     else UH_ROCFFT(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+  }
+  if (half == 1) {
+    f->halfPrep = pr;
+    f->halfN = N;
+    f->halfPending = true;
+    UH_CHECK(hipGetLastError());
+    return 0;
   }
   float noisePrefactor = 0.0f;
   if (temperature > 0.0f) {  // addBrownianNoise, FCM_impl.cuh:514-542
@@ -2091,6 +2110,20 @@ int uammd_pse_far_displacements(uammd_fcm *h, const float *d_pos, const float *d
   if (!f->pse.on) { set_last_error("uammd_pse_far_displacements: not a PSE far-field handle"); return -1; }
   f->seed2 = seed2;
   return uammd_fcm_displacements_staged(h, d_pos, d_force, N, temperature, prefactor, d_MF, 0, stream);
+}
+
+// The same solve queued in two halves (1: binning, stencils, spreading, forward x / y transforms; 2: z transform + operator + noise,
+// inverse transforms, gather): BDHI::PSE queues the near field's convergence check between them (uammd_pse_near_set_interleave_early /
+// uammd_pse_near_set_interleave), so that the GPU has the first half to do while the host answers the check and the second while it
+// reacts to the outcome.  Same arguments to both calls, same stream; the result is uammd_pse_far_displacements'.
+int uammd_pse_far_displacements_half(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature, float prefactor,
+                                     unsigned int seed2, float *d_MF, int half, void *stream) {
+  if (!h) { set_last_error("uammd_pse_far_displacements_half: null handle"); return -1; }
+  if (half != 1 && half != 2) { set_last_error("uammd_pse_far_displacements_half: half must be 1 or 2"); return -1; }
+  FCM *f = reinterpret_cast<FCM *>(h);
+  if (!f->pse.on) { set_last_error("uammd_pse_far_displacements_half: not a PSE far-field handle"); return -1; }
+  f->seed2 = seed2;
+  return fcm_displacements_impl(h, d_pos, d_force, N, temperature, prefactor, d_MF, 0, stream, false, half);
 }
 
 // ---- torques / rotation -------------------------------------------------------------------------------------

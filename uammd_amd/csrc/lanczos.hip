@@ -46,6 +46,8 @@ template <class T> struct LanczosT {
   int lastRunRequiredSteps = 0;
   uammd_interleave_fn interleave = nullptr;   // uammd_lanczos_set_interleave (one-shot)
   void *interleaveCtx = nullptr;
+  uammd_interleave_fn interleaveEarly = nullptr;   // uammd_lanczos_set_interleave_early (one-shot)
+  void *interleaveEarlyCtx = nullptr;
   bool deferChecks = true;   // evaluate the convergence checks of several iterations together (lanczos_run)
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
   uammd_allreduce_fn reduce = nullptr;   // (single precision only)
@@ -511,6 +513,14 @@ int uammd_lanczos_set_interleave(uammd_lanczos *h, uammd_interleave_fn fn, void 
   reinterpret_cast<Lanczos *>(h)->interleaveCtx = ctx;
   return 0;
 }
+// the same, one stage earlier: fn is called after the first check's scalars have been queued for the host and BEFORE the kernels that
+// wait for the host's answer — what it queues runs while the host solves the check's tridiagonal problems (the GPU idled ~20 us there)
+int uammd_lanczos_set_interleave_early(uammd_lanczos *h, uammd_interleave_fn fn, void *ctx) {
+  if (!h) { set_last_error("uammd_lanczos_set_interleave_early: null handle"); return -1; }
+  reinterpret_cast<Lanczos *>(h)->interleaveEarly = fn;
+  reinterpret_cast<Lanczos *>(h)->interleaveEarlyCtx = ctx;
+  return 0;
+}
 int uammd_lanczos_get_last_run_required_steps(uammd_lanczos *h, int *steps) {
   if (!h || !steps) { set_last_error("uammd_lanczos_get_last_run_required_steps: null argument"); return -1; }
   *steps = reinterpret_cast<Lanczos *>(h)->lastRunRequiredSteps;
@@ -612,6 +622,15 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       volatile double *hs = L->hostStat;
       hs[3] = 0.0;
       hipLaunchKernelGGL(k_l_publish<T>, dim3(1), dim3(64), 0, st, (const T *)hdiag, (const T *)hsup, m, L->devStat, seq);
+      if (L->interleaveEarly) {   // the caller's work for the time the host needs to answer (uammd_lanczos_set_interleave_early)
+        uammd_interleave_fn fn = L->interleaveEarly;
+        L->interleaveEarly = nullptr;
+        if (int rc = fn(L->interleaveEarlyCtx, stream)) {
+          (void)hipStreamSynchronize(st);
+          if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the interleaved callback failed (%d)", rc);
+          return rc;
+        }
+      }
       hipLaunchKernelGGL(k_l_relay_batch<T>, dim3(1), dim3(64), 0, st, L->devStat, K, m, seq, ycoef);
       hipLaunchKernelGGL(k_l_estimate_batch<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m0, K, (const T *)ycoef, (const T *)scal, est,
                          d_Bv, Bold, parts);
@@ -762,7 +781,17 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
                       int *iterations) {
   Lanczos *L = reinterpret_cast<Lanczos *>(hh);
   const int rc = lanczos_run<float>(L, dot, ctx, d_Bv, d_v, tolerance, n, stream, iterations);
-  if (L && L->interleave) {   // a run that never waited: the callback's work goes in behind it
+  if (L && L->interleaveEarly) {   // a run that never waited: the callbacks' work goes in behind it, in their order
+    uammd_interleave_fn fn = L->interleaveEarly;
+    L->interleaveEarly = nullptr;
+    const int rf = fn(L->interleaveEarlyCtx, stream);
+    if (!rc && rf) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the interleaved callback failed (%d)", rf);
+      L->interleave = nullptr;
+      return rf;
+    }
+  }
+  if (L && L->interleave) {
     uammd_interleave_fn fn = L->interleave;
     L->interleave = nullptr;
     const int rf = fn(L->interleaveCtx, stream);

@@ -60,6 +60,8 @@ struct PSENear {
   size_t pairCapFirst = 0;   // option "pair_capacity": the first allocation in records (tests: a build that has to grow); 0 = 48 per particle
   uammd_interleave_fn interleave = nullptr;   // uammd_pse_near_set_interleave (one-shot, handed to the next solve)
   void *interleaveCtx = nullptr;
+  uammd_interleave_fn interleaveEarly = nullptr;   // uammd_pse_near_set_interleave_early
+  void *interleaveEarlyCtx = nullptr;
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
     if (pairTotalHost) (void)hipHostFree(pairTotalHost);
@@ -1100,6 +1102,14 @@ int uammd_pse_near_set_interleave(uammd_pse_near *h, uammd_interleave_fn fn, voi
   return 0;
 }
 
+// one stage earlier (uammd_lanczos_set_interleave_early): before the kernels that wait for the host's answer to the check
+int uammd_pse_near_set_interleave_early(uammd_pse_near *h, uammd_interleave_fn fn, void *ctx) {
+  if (!h) { set_last_error("uammd_pse_near_set_interleave_early: null handle"); return -1; }
+  reinterpret_cast<PSENear *>(h)->interleaveEarly = fn;
+  reinterpret_cast<PSENear *>(h)->interleaveEarlyCtx = ctx;
+  return 0;
+}
+
 // NearField::Mdot (NearField.cuh:239-250): d_MF real3[N] += M_near F, forces real4[N] (NULL: nothing to do)
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int N, float *d_MF, void *stream) {
   if (!h || (N > 0 && (!d_pos || !d_MF))) { set_last_error("uammd_pse_near_mdot: null argument"); return -1; }
@@ -1122,25 +1132,38 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   // solver behind its first check, or here on the way out (nothing to solve, an error before the solve, a solve that never waited) —
   // and no registration outlives the call (its context may live on the caller's stack).
   struct Hook {
-    PSENear *p; void *stream; uammd_interleave_fn fn; void *ctx; bool fired = false; int rc = 0;
+    uammd_interleave_fn fn; void *ctx; bool fired = false; int rc = 0;
     static int tramp(void *self, void *stream) {
       Hook *k = static_cast<Hook *>(self);
       k->fired = true;
-      return k->fn(k->ctx, stream);
+      return k->rc = k->fn(k->ctx, stream);
     }
-    ~Hook() {
-      if (!fn) return;
-      (void)uammd_lanczos_set_interleave(p->lanczos, nullptr, nullptr);
-      if (!fired) { fired = true; rc = fn(ctx, stream); }
+    void flush(void *stream) { if (fn && !fired) { fired = true; rc = fn(ctx, stream); } }
+  };
+  struct Hooks {   // (the early one first, whatever the path)
+    PSENear *p; void *stream; Hook early, late;
+    ~Hooks() {
+      if (early.fn) (void)uammd_lanczos_set_interleave_early(p->lanczos, nullptr, nullptr);
+      if (late.fn) (void)uammd_lanczos_set_interleave(p->lanczos, nullptr, nullptr);
+      early.flush(stream);
+      late.flush(stream);
     }
-  } hook{p, stream, p->interleave, p->interleaveCtx};
-  p->interleave = nullptr;
-  p->interleaveCtx = nullptr;
-  auto leave = [&](int rc) -> int {   // (the hook's own failure is reported when nothing else failed)
-    if (hook.fn && !hook.fired) { hook.fired = true; hook.rc = hook.fn(hook.ctx, stream); }
-    if (!rc && hook.rc) {
-      if (!uammd_hip_last_error()[0]) set_last_error("uammd_pse_near_stochastic: the interleaved callback failed (%d)", hook.rc);
-      return hook.rc;
+  } hooks{p, stream, {p->interleaveEarly, p->interleaveEarlyCtx}, {p->interleave, p->interleaveCtx}};
+  Hook &hook = hooks.late;
+  p->interleave = p->interleaveEarly = nullptr;
+  p->interleaveCtx = p->interleaveEarlyCtx = nullptr;
+  auto arm = [&]() -> int {   // hand both to the solver of the coming run
+    if (hooks.early.fn && !hooks.early.fired) { if (int e = uammd_lanczos_set_interleave_early(p->lanczos, &Hook::tramp, &hooks.early)) return e; }
+    if (hook.fn && !hook.fired) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return e; }
+    return 0;
+  };
+  auto leave = [&](int rc) -> int {   // (a hook's own failure is reported when nothing else failed)
+    hooks.early.flush(stream);
+    hook.flush(stream);
+    const int hrc = hooks.early.rc ? hooks.early.rc : hook.rc;
+    if (!rc && hrc) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_pse_near_stochastic: the interleaved callback failed (%d)", hrc);
+      return hrc;
     }
     return rc;
   };
@@ -1151,7 +1174,7 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   const float noise_prefactor = prefactor * sqrtf(2 * temperature);
   int it = 0;
   if (p->exactOrder) {
-    if (hook.fn) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return leave(e); }
+    if (int e = arm()) return leave(e);
     hipLaunchKernelGGL(k_pse_noise, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, N, noise_prefactor, p->seed,
                        seed2);
     if (hipGetLastError() != hipSuccess) { set_last_error("uammd_pse_near_stochastic: kernel launch failed"); return leave(-1); }
@@ -1174,7 +1197,7 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   const bool ahead = records && p->optimisticRecords && p->pairsPending && !p->pairsValid;
   int schedule[2] = {0, 0};
   if (ahead) { if (int e = uammd_lanczos_get_schedule(p->lanczos, schedule)) return leave(e); }
-  if (hook.fn) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return leave(e); }   // (one-shot: a repeated solve below runs without it)
+  if (int e = arm()) return leave(e);   // (one-shot: a repeated solve below runs without them)
   p->optimistic = ahead;
   int rc = solve();
   p->optimistic = false;
