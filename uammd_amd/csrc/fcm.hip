@@ -1547,6 +1547,7 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
   const bool custom = stage == 0 && fcm_custom_fft_usable(f);  // (stage 1 exports the Fourier grid, which the fused z pass never stores)
   FcmPrep pr{};
+  if (half != 2) f->halfPending = false;   // (a first half whose second never came is forgotten by the next solve)
   if (half == 2) {
     if (!f->halfPending || f->halfN != N) { set_last_error("uammd_fcm: the second half of a solve without its first"); return -1; }
     pr = f->halfPrep;
