@@ -495,6 +495,8 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
   }
 }
 
+// (Measured and not kept in k_pse_pairs_build: skipping the neighbour cells whose nearest point is beyond the cut-off — half of the corner
+// cells, a quarter of the edge cells, 26 % of the candidates — 63.6 -> 62.9 us: the build is not its scan.)
 // Mv_i (+)= sum over i's records of F v_j + C (r . v_j) r  (RPYNearTransverser::compute, NearField.cuh:154-196, with (G - F) / r^2 folded
 // into C when the record was made: one rounding per pair apart from k_pse_near8's terms).  Eight lanes per particle; a particle's records
 // are contiguous: the group's loads are one 128-byte and one 64-byte segment per eight records, all of a particle's records and then all
