@@ -1095,7 +1095,40 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
   const int q0 = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * TL, nl = min(TL, nyl * nkx - q0);
   float2 *base = g + q0 + l;
   fft_twiddles<NT>(tw, nz, tid);
-  if (haveForce) {
+  // Power-of-two lines whose plan starts with a radix-4 pass and ends with a radix-8 one (128, 256, 32): the first forward pass is done on
+  // the values as they arrive from memory and the last inverse pass on the values as they leave — two trips of the tile through LDS and
+  // two barriers fewer of the kernel's eight.  Same butterflies on the same values: the same bits.
+  constexpr int NLINES = 3 * TL, QF = 3, QL = 2;
+  const int log2N = 31 - __builtin_clz((unsigned)nz);
+  const bool edges = P2 && haveForce && nl == TL && log2N % 3 != 0 && log2N >= 5 && NLINES * (nz >> 2) <= QF * NT &&
+                     NLINES * (nz >> 3) <= QL * NT;
+  if (edges) {
+    const int per = nz >> 2, total = NLINES * per;
+    float2 v[QF][4];
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int b = tid + q * NT;
+      if (b < total) {
+        const int j = b / NLINES, line = b - j * NLINES, c = line >> LOG2TL, ll = line & (TL - 1);
+        const float2 *src = g + q0 + ll + (size_t)c * planeC + (size_t)j * slab;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = src[(size_t)(r * per) * slab];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QF; ++q) {
+      const int b = tid + q * NT;
+      if (b < total) {
+        const int j = b / NLINES, line = b - j * NLINES;
+        fft_butterfly<4, -1>(v[q]);
+        float2 *dst = buf + line * LS + 4 * j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = v[q][r];
+      }
+    }
+    __syncthreads();
+    fft_lds_p2_inner<-1, MAXB, NT>(buf, LS, log2N, NLINES, tw, 1, tid, true, false);
+  } else if (haveForce) {
     if (l < nl) {  // element e = c (nz / JG) + j / JG of this thread's 3 nz / JG
       const int perC = (nz + JG - 1) / JG;
       staged_copy<12, float2>(0, 3 * perC, 1,
@@ -1127,6 +1160,28 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
     }
   }
   __syncthreads();
+  if (edges) {
+    fft_lds_p2_inner<1, MAXB, NT>(buf, LS, log2N, NLINES, tw, 1, tid, false, true);
+    const int per = nz >> 3, total = NLINES * per;   // the last pass: radix 8, sub-transforms of nz / 8 points, outputs at j + r nz / 8
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const int b = tid + q * NT;
+      if (b < total) {
+        const int j = b / NLINES, line = b - j * NLINES, c = line >> LOG2TL, ll = line & (TL - 1);
+        const float2 *p = buf + line * LS + j;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = p[r * per];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = ctw<1>(v[r], tw[j * r]);
+        fft_butterfly<8, 1>(v);
+        float2 *dst = g + q0 + ll + (size_t)c * planeC + (size_t)j * slab;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[(size_t)(r * per) * slab] = v[r];
+      }
+    }
+    return;
+  }
   fft_lds<1, MAXB, NT, P2>(buf, LS, nz, 3 * nl, tw, 1, tid);
   if (l < nl)
     for (int c = 0; c < 3; ++c)

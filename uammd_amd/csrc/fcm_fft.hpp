@@ -368,6 +368,17 @@ UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const floa
     for (int a = 0; a < e[4]; ++a, Ns *= 11) fft_pass<11, SIGN, (4 * MAXB + 10) / 11, NT, STRIDED, false>(buf, LS, ES, N, Ns, nlines, tw, twStride, tid);
   }
 }
+// the power-of-two plan of fft_lds_any (radix-4 passes until the rest is a multiple of three bits, then radix 8) without its first and / or
+// its last pass: a caller that has the lines in registers on the way in (or wants them there on the way out) does that pass itself —
+// k_fft_z_fused's first forward pass on the values it loads, its last inverse pass into the values it stores
+template <int SIGN, int MAXB, int NT>
+UH_D void fft_lds_p2_inner(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid, bool skipFirst, bool skipLast) {
+  const int m4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);
+  int ls = 0;
+  for (int a = 0; a < m4; ++a, ls += 2)
+    if (!(skipFirst && a == 0)) fft_pass_p2<4, SIGN, MAXB, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+  for (; ls + (skipLast ? 3 : 0) < log2N; ls += 3) fft_pass_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+}
 template <int SIGN, int MAXB, int NT, bool P2>
 UH_D void fft_lds(float2 *buf, int LS, int N, int nlines, const float2 *tw, int twStride, int tid) {
   fft_lds_any<SIGN, MAXB, NT, false, P2>(buf, LS, 1, N, nlines, tw, twStride, tid);
