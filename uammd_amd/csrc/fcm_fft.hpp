@@ -541,6 +541,58 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int nA
   const int kx0 = tile * 16, nl = min(16, nkx - kx0), l = tid & 15, jg = tid >> 4;
   float2 *base = g + (size_t)group * n * nkx + kx0 + l;
   fft_twiddles<NT>(tw, n, tid);
+  // full tiles of power-of-two lines whose plan is 4 .. 8 (128, 256, 32): the first pass on the values as they arrive from memory, the last
+  // on the values as they leave (see k_fft_z_fused: two trips through LDS and two barriers fewer, the same bits)
+  constexpr int QF = MAXB, QL = (MAXB + 1) / 2;   // (MAXB = radix-4 butterflies per thread the launch has room for)
+  const int log2N = 31 - __builtin_clz((unsigned)n);
+  const bool edges = P2 && nl == 16 && log2N % 3 != 0 && log2N >= 5 && 16 * (n >> 2) <= QF * NT && 16 * (n >> 3) <= QL * NT;
+  if (edges) {
+    float2 *tile = g + (size_t)group * n * nkx + kx0;
+    {
+      const int per = n >> 2, total = 16 * per;
+      float2 v[QF][4];
+#pragma unroll
+      for (int q = 0; q < QF; ++q) {
+        const int b = tid + q * NT;
+        if (b < total) {
+          const float2 *src = tile + (b & 15) + (size_t)(b >> 4) * nkx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[q][r] = src[(size_t)(r * per) * nkx];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < QF; ++q) {
+        const int b = tid + q * NT;
+        if (b < total) {
+          fft_butterfly<4, SIGN>(v[q]);
+          float2 *dst = buf + (b & 15) * LS + 4 * (b >> 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[r] = v[q][r];
+        }
+      }
+    }
+    __syncthreads();
+    fft_lds_p2_inner<SIGN, MAXB, NT>(buf, LS, log2N, 16, tw, 1, tid, true, true);
+    const int per = n >> 3, total = 16 * per;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const int b = tid + q * NT;
+      if (b < total) {
+        const int line = b & 15, j = b >> 4;
+        const float2 *p = buf + line * LS + j;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = p[r * per];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = ctw<SIGN>(v[r], tw[j * r]);
+        fft_butterfly<8, SIGN>(v);
+        float2 *dst = tile + line + (size_t)j * nkx;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[(size_t)(r * per) * nkx] = v[r];
+      }
+    }
+    return;
+  }
   if (l < nl)
     staged_copy<16, float2>(jg, n, NT / 16, [&](int j) { return base[(size_t)j * nkx]; }, [&](int j, float2 v) { buf[l * LS + j] = v; });
   __syncthreads();
