@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 GRIDS = [(54, 54, 54), (48, 40, 60), (96, 80, 50), (108, 108, 108), (30, 36, 20), (20, 12, 16), (120, 90, 150), (162, 128, 100),
          (250, 256, 12), (64, 100, 27), (32, 16, 500), (18, 250, 8), (128, 128, 128), (36, 30, 25),
-         (112, 84, 98), (110, 66, 44), (28, 22, 14), (154, 126, 242), (56, 121, 49)]
+         (112, 84, 98), (110, 66, 44), (28, 22, 14), (154, 126, 242), (56, 121, 49),
+         # the passes fused with the loads / stores: rows starting with radix 4 and radix 8, columns of one pass, z lines of 32 and 256
+         (32, 32, 32), (16, 8, 64), (64, 64, 256), (256, 32, 128)]
 
 
 def _inputs(cells, n, seed):

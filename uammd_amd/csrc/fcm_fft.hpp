@@ -371,13 +371,26 @@ UH_D void fft_lds_any(float2 *buf, int LS, int ES, int N, int nlines, const floa
 // the power-of-two plan of fft_lds_any (radix-4 passes until the rest is a multiple of three bits, then radix 8) without its first and / or
 // its last pass: a caller that has the lines in registers on the way in (or wants them there on the way out) does that pass itself —
 // k_fft_z_fused's first forward pass on the values it loads, its last inverse pass into the values it stores
-template <int SIGN, int MAXB, int NT>
-UH_D void fft_lds_p2_inner(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid, bool skipFirst, bool skipLast) {
+template <int SIGN, int MAXB, int NT, bool STRIDED = false>
+UH_D void fft_lds_p2_inner(float2 *buf, int LS, int log2N, int nlines, const float2 *tw, int twStride, int tid, bool skipFirst, bool skipLast,
+                           int ES = 1) {
   const int m4 = (log2N % 3 == 0) ? 0 : (log2N % 3 == 2 ? 1 : 2);
   int ls = 0;
-  for (int a = 0; a < m4; ++a, ls += 2)
-    if (!(skipFirst && a == 0)) fft_pass_p2<4, SIGN, MAXB, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
-  for (; ls + (skipLast ? 3 : 0) < log2N; ls += 3) fft_pass_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+  bool skip = skipFirst;
+  for (int a = 0; a < m4; ++a, ls += 2) {
+    if (!skip) {
+      if constexpr (STRIDED) fft_pass_strided_p2<4, SIGN, MAXB, NT>(buf, LS, ES, log2N, ls, nlines, tw, twStride, tid);
+      else fft_pass_p2<4, SIGN, MAXB, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+    }
+    skip = false;
+  }
+  for (; ls + (skipLast ? 3 : 0) < log2N; ls += 3) {
+    if (!skip) {
+      if constexpr (STRIDED) fft_pass_strided_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, ES, log2N, ls, nlines, tw, twStride, tid);
+      else fft_pass_p2<8, SIGN, (MAXB + 1) / 2, NT>(buf, LS, log2N, ls, nlines, tw, twStride, tid);
+    }
+    skip = false;
+  }
 }
 template <int SIGN, int MAXB, int NT, bool P2>
 UH_D void fft_lds(float2 *buf, int LS, int N, int nlines, const float2 *tw, int twStride, int tid) {
@@ -508,6 +521,76 @@ __global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__res
   float *plane = g + (size_t)blockIdx.x * ny * nxpad;   // (the three planar component grids are contiguous: plane index = c nz + z)
   fft_twiddles<kPlaneThreads>(twx, nx, tid);
   fft_twiddles<kPlaneThreads>(twy, ny, tid);
+  // power-of-two planes: the rows' first pass on the values as they arrive from memory, the columns' last pass (radix 8) on the values as
+  // they leave (see k_fft_z_fused): two trips of the plane through LDS and two barriers fewer, the same bits
+  const int log2H = 31 - __builtin_clz((unsigned)nh), log2Y = 31 - __builtin_clz((unsigned)ny);
+  // (the columns' plan must END with a radix-8 pass: every power of two from 8 up except 16 = 4 x 4)
+  const bool edges = P2 && log2H >= 3 && log2Y >= 3 && log2Y != 4 && (ny >> 3) * LS <= 2 * kPlaneThreads &&
+                     ny * (nh >> (log2H % 3 == 0 ? 3 : 2)) <= (log2H % 3 == 0 ? 1 : 2) * kPlaneThreads;
+  if (edges) {
+    if (log2H % 3 == 0) {   // the rows' plan starts with a radix-8 pass: one butterfly per thread
+      const int per = nh >> 3, b = tid;
+      if (b < ny * per) {
+        const int j = b & (per - 1), r = b >> (log2H - 3);
+        const float2 *src = (const float2 *)(plane + (size_t)r * nxpad) + j;
+        float2 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = src[m * per];
+        fft_butterfly<8, -1>(v);
+        float2 *dst = buf + __mul24(r, LS) + 8 * j;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst[m] = v[m];
+      }
+    } else {                // with a radix-4 pass: up to two butterflies per thread
+      const int per = nh >> 2;
+      float2 v[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int b = tid + q * kPlaneThreads;
+        if (b < ny * per) {
+          const int j = b & (per - 1), r = b >> (log2H - 2);
+          const float2 *src = (const float2 *)(plane + (size_t)r * nxpad) + j;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v[q][m] = src[m * per];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int b = tid + q * kPlaneThreads;
+        if (b < ny * per) {
+          const int j = b & (per - 1), r = b >> (log2H - 2);
+          fft_butterfly<4, -1>(v[q]);
+          float2 *dst = buf + __mul24(r, LS) + 4 * j;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) dst[m] = v[q][m];
+        }
+      }
+    }
+    __syncthreads();
+    fft_lds_p2_inner<-1, 2, kPlaneThreads>(buf, LS, log2H, ny, twx, 2, tid, true, false);
+    fft_untangle_r2c<kPlaneThreads, P2>(buf, LS, nh, ny, twx, 1, tid);
+    __syncthreads();
+    fft_lds_p2_inner<-1, 3, kPlaneThreads, true>(buf, 1, log2Y, LS, twy, 1, tid, false, true, LS);
+    const int per = ny >> 3, total = per * LS;   // the columns' last pass: sub-transforms of ny / 8 points, outputs at rows j + m ny / 8
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int b = tid + q * kPlaneThreads;
+      if (b < total) {
+        const int j = dLS.div(b), k = dLS.rem(b, j);
+        const float2 *p = buf + k + __mul24(j, LS);
+        float2 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = p[__mul24(m * per, LS)];
+#pragma unroll
+        for (int m = 1; m < 8; ++m) v[m] = ctw<-1>(v[m], twy[j * m]);
+        fft_butterfly<8, -1>(v);
+        float2 *dst = (float2 *)(plane + (size_t)j * nxpad) + k;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *(float2 *)((float *)dst + (size_t)(m * per) * nxpad) = v[m];
+      }
+    }
+    return;
+  }
   staged_copy<8, float2>(tid, ny * nh, kPlaneThreads,
       [&](int i) { const int r = dNh.div(i); return *(const float2 *)(plane + (size_t)r * nxpad + 2 * dNh.rem(i, r)); },
       [&](int i, float2 v) { const int r = dNh.div(i); buf[__mul24(r, LS) + dNh.rem(i, r)] = v; });
