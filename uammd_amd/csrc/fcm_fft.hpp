@@ -469,6 +469,50 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
   float2 *tw = lds, *buf = lds + nx;
   const int tid = threadIdx.x, r0 = blockIdx.x * rowsPerBlock, nr = min(rowsPerBlock, nrows - r0);
   fft_twiddles(tw, nx, tid);
+  // power-of-two rows without a halo to fold in: the first pass on the values as they arrive from memory (see k_fft_xy_r2c_plane)
+  const int log2H = 31 - __builtin_clz((unsigned)nh);
+  const bool first8 = log2H % 3 == 0;
+  const bool edge = P2 && !FOLD && log2H >= 3 && nr * (nh >> (first8 ? 3 : 2)) <= (first8 ? 1 : 2) * kFftThreads;
+  if (edge) {
+    if (first8) {
+      const int per = nh >> 3;
+      if (tid < nr * per) {
+        const int j = tid & (per - 1), r = tid >> (log2H - 3);
+        const float2 *src = (const float2 *)(g + (size_t)(r0 + r) * nxpad) + j;
+        float2 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = src[m * per];
+        fft_butterfly<8, -1>(v);
+        float2 *dst = buf + __mul24(r, LS) + 8 * j;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst[m] = v[m];
+      }
+    } else {
+      const int per = nh >> 2;
+      float2 v[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int b = tid + q * kFftThreads;
+        if (b < nr * per) {
+          const float2 *src = (const float2 *)(g + (size_t)(r0 + (b >> (log2H - 2))) * nxpad) + (b & (per - 1));
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v[q][m] = src[m * per];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int b = tid + q * kFftThreads;
+        if (b < nr * per) {
+          fft_butterfly<4, -1>(v[q]);
+          float2 *dst = buf + __mul24(b >> (log2H - 2), LS) + 4 * (b & (per - 1));
+#pragma unroll
+          for (int m = 0; m < 4; ++m) dst[m] = v[q][m];
+        }
+      }
+    }
+    __syncthreads();
+    fft_lds_p2_inner<-1, 2, kFftThreads>(buf, LS, log2H, nr, tw, 2, tid, true, false);
+  } else {
   staged_copy<8, float2>(tid, nr * nh, kFftThreads,
       [&](int i) {
         const int r = dNh.div(i), j = dNh.rem(i, r);
@@ -493,6 +537,7 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
   }
   __syncthreads();
   fft_lds<-1, 2, kFftThreads, P2>(buf, LS, nh, nr, tw, 2, tid);
+  }
   fft_untangle_r2c<kFftThreads, P2>(buf, LS, nh, nr, tw, 1, tid);
   __syncthreads();
   for (int i = tid; i < nr * nh; i += kFftThreads) {
