@@ -737,7 +737,8 @@ __global__ void __launch_bounds__(NT) k_fft_lines(float2 *__restrict__ g, int nA
 // wrapRows > 0 (slab window of a rank that is its own neighbour, world size 1): the first wrapRows rows are also stored wrapShift float4
 // further on and the last wrapRows rows wrapShift earlier — the halo planes the gather reads, which with neighbours arrive by message.
 // (Measured and not kept: the tangling on the values as they arrive from memory — a pair's two entries loaded together, tangled in registers,
-// stored once, one trip through LDS and one barrier fewer: 14.8 -> 14.1 us at C4, 88 -> 96 us at C5, where the rows come from HBM.)
+// stored once, one trip through LDS and one barrier fewer: 14.8 -> 14.1 us at C4, 96.4 against 96.5 us at C5: 0.4 % of the C4 step for
+// a second copy of the tangling arithmetic.)
 template <bool P2>
 __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g, size_t compStride, size_t zStride, int nyArg, int nxArg,
                                                            int nrows, int rowsPerBlock, float4 *__restrict__ inter, int wrapRows,
