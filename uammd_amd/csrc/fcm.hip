@@ -264,14 +264,15 @@ __global__ void __launch_bounds__(1024) k_fcm_tile_scan(int *__restrict__ count,
 #define UAMMD_PREP_LANES 4
 #endif
 constexpr int kPrepLanes = UAMMD_PREP_LANES;
-template <int KIND>
+constexpr int kPrepLanesUpTo = 150000;   // (at 2e5 particles the chip is full with one lane each: 19.7 against 23.0 us with four)
+template <int KIND, int LANES>
 __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ pos, const float4 *__restrict__ force,
                                                       int N, GridT<float> grid, IBMKernelDev kern, FcmPrep pr) {
   kern.kind = KIND;  // constant-folds the switch
-  // kPrepLanes threads per particle, each with every kPrepLanes-th weight: at 1e5 particles one thread per particle is 1.5
+  // LANES threads per particle, each with every LANES-th weight: at 1e5 particles one thread per particle is 1.5
   // waves per SIMD walking 18 dependent exp chains; four lanes per particle put 6 waves on a SIMD with a quarter of the chain
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int id = gid / kPrepLanes, sub = gid % kPrepLanes;
+  const int id = gid / LANES, sub = gid % LANES;
   if (id >= N) return;
   const float4 p4 = pos[id];
   const real3f pi{p4.x, p4.y, p4.z};
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   const int slot = pr.tileStart[pr.tileOf[id]] + pr.rank[id];
   float *w = pr.weights + (size_t)pr.wstride * slot;
   const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
-  for (int k = sub; k < sx + sy + sz; k += kPrepLanes) {
+  for (int k = sub; k < sx + sy + sz; k += LANES) {
     float v;
     if (k < sx) v = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + k), celli.y, celli.z)).x);
     else if (k < sx + sy) v = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(celli.x, grid.pbc_y(oy + k - sx), celli.z)).y);
@@ -1406,8 +1407,12 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, pr.tileCount, nt, pr.tileStart);
 #define UH_PREPARE(K)                                                                                          \
   case K:                                                                                                      \
-    hipLaunchKernelGGL(k_fcm_prepare<K>, dim3((N * kPrepLanes + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos,       \
-                       (const float4 *)d_force, N, f->grid, f->kern, pr);                                      \
+    if (N <= kPrepLanesUpTo)                                                                                   \
+      hipLaunchKernelGGL((k_fcm_prepare<K, kPrepLanes>), dim3((N * kPrepLanes + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, \
+                         (const float4 *)d_force, N, f->grid, f->kern, pr);                                    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_fcm_prepare<K, 1>), dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, \
+                         (const float4 *)d_force, N, f->grid, f->kern, pr);                                    \
     break;
   switch (f->kern.kind) {
     UH_PREPARE(kKernelGaussian) UH_PREPARE(kKernelPeskin3) UH_PREPARE(kKernelPeskin4) UH_PREPARE(kKernelConstant)
