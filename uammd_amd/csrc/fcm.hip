@@ -1299,6 +1299,9 @@ static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
   return 0;
 }
 // z transform + Fourier-space operator + inverse z transform on lines of the layout (planeC, zStride, nyl, y0) — see k_fft_z_fused
+#ifndef UAMMD_ZG_THREADS
+#define UAMMD_ZG_THREADS 256
+#endif
 static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStride, int nyl, int y0, int3 cells, real3f L, bool haveForce,
                                   float noisePrefactor, uint seed2, hipStream_t st) {
   const int nz = cells.z, nkx = cells.x / 2 + 1, lines = nyl * nkx;
@@ -1311,7 +1314,14 @@ static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStri
 #define UH_ZFUSED(LT, P) hipLaunchKernelGGL((k_fft_z_fused<LT, 512, P>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, nz, cells, L, f->par.viscosity, \
                                          haveForce, noisePrefactor, f->par.seed, seed2, f->pse)
   if (is_pow2(nz)) { if (ltl == 4) UH_ZFUSED(4, true); else if (ltl == 3) UH_ZFUSED(3, true); else UH_ZFUSED(2, true); }
-  else { if (ltl == 4) UH_ZFUSED(4, false); else if (ltl == 3) UH_ZFUSED(3, false); else UH_ZFUSED(2, false); }
+  else {
+    // (mixed-radix lines: a radix-12 or radix-9 pass has 3 tl nz / 12 .. / 9 butterflies — 216 and 288 at 108 — for 512 threads; with 256
+    // threads per workgroup the passes fill their waves and the LDS, not the thread count, sets how many tiles a CU holds)
+#define UH_ZFUSED_G(LT) hipLaunchKernelGGL((k_fft_z_fused<LT, UAMMD_ZG_THREADS, false>), gz, dim3(UAMMD_ZG_THREADS), ldsz, st, g, planeC, zStride, nyl, y0, nz, \
+                                           cells, L, f->par.viscosity, haveForce, noisePrefactor, f->par.seed, seed2, f->pse)
+    if (ltl == 4) UH_ZFUSED_G(4); else if (ltl == 3) UH_ZFUSED_G(3); else UH_ZFUSED_G(2);
+#undef UH_ZFUSED_G
+  }
 #undef UH_ZFUSED
   return 0;
 }
