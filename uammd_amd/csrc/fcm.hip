@@ -1099,7 +1099,7 @@ __global__ void __launch_bounds__(NT) k_fft_z_fused(float2 *__restrict__ g, size
   // Power-of-two lines whose plan starts with a radix-4 pass and ends with a radix-8 one (128, 256, 32): the first forward pass is done on
   // the values as they arrive from memory and the last inverse pass on the values as they leave — two trips of the tile through LDS and
   // two barriers fewer of the kernel's eight.  Same butterflies on the same values: the same bits.
-  constexpr int NLINES = 3 * TL, QF = 3, QL = 2;
+  constexpr int NLINES = 3 * TL, QF = 3 * 512 / NT, QL = 2 * 512 / NT;
   const int log2N = 31 - __builtin_clz((unsigned)nz);
   const bool edges = P2 && haveForce && nl == TL && log2N % 3 != 0 && log2N >= 5 && NLINES * (nz >> 2) <= QF * NT &&
                      NLINES * (nz >> 3) <= QL * NT;
@@ -1311,7 +1311,10 @@ static int fcm_fft_z_fused_launch(FCM *f, float2 *g, size_t planeC, size_t zStri
   const int tlz = 1 << ltl;
   const size_t ldsz = sizeof(float2) * (size_t)(nz + 3 * tlz * (nz + 1));
   const dim3 gz((lines + tlz - 1) / tlz), bz(512);
-#define UH_ZFUSED(LT, P) hipLaunchKernelGGL((k_fft_z_fused<LT, 512, P>), gz, bz, ldsz, st, g, planeC, zStride, nyl, y0, nz, cells, L, f->par.viscosity, \
+#ifndef UAMMD_ZP_THREADS
+#define UAMMD_ZP_THREADS 512
+#endif
+#define UH_ZFUSED(LT, P) hipLaunchKernelGGL((k_fft_z_fused<LT, UAMMD_ZP_THREADS, P>), gz, dim3(UAMMD_ZP_THREADS), ldsz, st, g, planeC, zStride, nyl, y0, nz, cells, L, f->par.viscosity, \
                                          haveForce, noisePrefactor, f->par.seed, seed2, f->pse)
   if (is_pow2(nz)) { if (ltl == 4) UH_ZFUSED(4, true); else if (ltl == 3) UH_ZFUSED(3, true); else UH_ZFUSED(2, true); }
   else {
