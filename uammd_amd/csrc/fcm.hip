@@ -75,6 +75,7 @@ struct FCM {
   int3 tdim{8, 8, 8};      // tile edge per axis, 4..8 nodes: the largest divisor of the axis that holds the stencil's reach (fcm_tiles_usable)
   int prepCapN = 0;
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
+  bool binBySlot = true;            // option "bin_by_slot": the step's update + binning pass walks the particles in the solve's tile order (k_fcm_update_bin)
   hipStream_t prepStream = nullptr;  // ... an ordering that only holds within one stream: a call on another stream waits for this one first
   bool prepStreamSet = false;
   bool forceAtomicSpread = false;  // test hook
@@ -197,10 +198,14 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
 // (Measured and not kept: the update inside the interpolation kernel — one lane per wave loading, storing and taking its rank: 50 000
 // single-lane memory instructions instead of 1 600 full ones — took the gather from 32 to 34 us with the update alone and to 127 us with
 // the atomics.)
+// bySlot: thread s takes the particle of slot s of the solve that has just run (pr.origin[s].w): neighbours in a wave are then particles of
+// the same tile — still, after one step — and the wave counts them itself: one atomic per tile and wave (three or four) instead of 64.
+// The binning pass is bound by the memory side's atomic rate (1e5 of them: ~9 us), not by its round trip.
 __global__ void __launch_bounds__(256) k_fcm_update_bin(float4 *__restrict__ pos, const float *__restrict__ linearV, int N, float dt,
-                                                         GridT<float> grid, int3 ntiles, FcmPrep pr, bool bin) {
-  const int id = blockIdx.x * 256 + threadIdx.x;
-  if (id >= N) return;
+                                                         GridT<float> grid, int3 ntiles, FcmPrep pr, bool bin, bool bySlot) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= N) return;
+  const int id = bySlot ? pr.origin[s].w : s;
   float4 p = pos[id];
   p.x = fmaf(linearV[3 * id], dt, p.x);
   p.y = fmaf(linearV[3 * id + 1], dt, p.y);
@@ -210,7 +215,26 @@ __global__ void __launch_bounds__(256) k_fcm_update_bin(float4 *__restrict__ pos
     const int3 celli = grid.getCell(real3f{p.x, p.y, p.z});
     const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
     pr.tileOf[id] = t;
-    pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
+    if (!bySlot) { pr.rank[id] = atomicAdd(&pr.tileCount[t], 1); return; }
+    // up to eight tiles per wave are counted by the wave (the lanes of a tile: their number, a lane's place among them, the lowest
+    // as the leader); what is left after eight rounds — a wave of strangers — takes its ranks one by one
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(1);
+    int cnt = 1, before = 0, lead = lane;
+    for (int round = 0; round < 8 && rem; ++round) {
+      const int l = __ffsll((unsigned long long)rem) - 1;
+      const int t0 = __builtin_amdgcn_readlane(t, l);
+      const unsigned long long m = __ballot(t == t0) & rem;
+      if (t == t0 && ((rem >> lane) & 1ull)) {
+        cnt = __popcll(m);
+        before = __popcll(m & ((1ull << lane) - 1ull));
+        lead = l;
+      }
+      rem &= ~m;
+    }
+    int got = 0;
+    if (lane == lead) got = atomicAdd(&pr.tileCount[t], cnt);
+    pr.rank[id] = __shfl(got, lead, 64) + before;
   }
 }
 
@@ -1735,10 +1759,11 @@ int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_for
   FcmPrep pr{};
   if (bin) {
     pr.tileOf = (int *)f->prepTileOf.ptr; pr.rank = (int *)f->prepRank.ptr; pr.tileCount = (int *)f->prepTileCount.ptr;
+    pr.origin = (int4 *)f->prepOrigin.ptr;   // (the stencils of the solve above: slot -> particle)
     pr.tdim = f->tdim;
   }
   hipLaunchKernelGGL(k_fcm_update_bin, dim3((N + 255) / 256), dim3(256), 0, st, (float4 *)d_pos, (const float *)v, N, dt, f->grid, f->ntiles,
-                     pr, bin);
+                     pr, bin, bin && f->binBySlot);
   UH_CHECK(hipGetLastError());
   if (bin) { f->binnedPending = true; f->binnedPos = (const void *)d_pos; f->binnedN = N; }
   return 0;
@@ -1748,6 +1773,7 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
   if (std::string(name) == "bin_ahead") { reinterpret_cast<FCM *>(h)->emBin = value != 0; return 0; }
+  if (std::string(name) == "bin_by_slot") { reinterpret_cast<FCM *>(h)->binBySlot = value != 0; return 0; }
   if (std::string(name) == "spread_waves") { reinterpret_cast<FCM *>(h)->spreadWaves = value; return 0; }
   if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
   if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
