@@ -63,11 +63,7 @@ class DistributedLJ {
 
   int *idxRow(int k) { return idx.d + (size_t)k * cap; }
   void hostCounts(const int *dev2, int &toUp, int &toDown, int &fromDown, int &fromUp) {
-    int h[2];
-    detail::hipCheck(hipMemcpyAsync(h, dev2, 2 * sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
-    detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
-    toUp = h[0]; toDown = h[1];
-    comm->exchangeCounts(toUp, toDown, fromDown, fromUp, st);
+    comm->exchangeCountsDevice(dev2, toUp, toDown, fromDown, fromUp, st);  // (one synchronisation: the sizes travel from device memory)
   }
   void refill() {  // the listed particles' current positions to the neighbours, straight into the ghost tail
     detail::check(uammd_halo_pack((const float *)pos.d, idxRow(2), nUpH, idxRow(3), nDownH, -width, width, sendUp.d, sendDown.d, (void *)st));

@@ -2000,6 +2000,12 @@ public:
     fromDown = from[0];
     fromUp = from[1];
   }
+  // the same with the two sizes still in device memory (uammd_slab_select's counts): one synchronisation returns all four
+  void exchangeCountsDevice(const int *d_toUpDown, int &toUp, int &toDown, int &fromDown, int &fromUp, hipStream_t st = 0) {
+    int all4[4] = {0, 0, 0, 0};
+    detail::check(uammd_comm_exchange_counts_device(h, d_toUpDown, all4, (void *)st));
+    toUp = all4[0]; toDown = all4[1]; fromDown = all4[2]; fromUp = all4[3];
+  }
   void allToAll(const void *send, void *recv, size_t bytesPerPeer, hipStream_t st = 0) { detail::check(uammd_comm_alltoall(h, send, recv, bytesPerPeer, (void *)st)); }
   void allReduceSum(real *buf, int n, hipStream_t st = 0) { detail::check(uammd_comm_allreduce_sum(h, buf, n, (void *)st)); }
 };

@@ -667,7 +667,8 @@ int uammd_rpy_lanczos_bdw(uammd_lanczos *solver, const float *d_pos, const float
  * Multi-GPU (new design: the reference is single GPU).  One process per GPU, RCCL over xGMI, loaded on first use.
  * Set-up: rank 0 calls uammd_comm_unique_id and hands the 128 bytes to the other processes by any means (MPI, a file, a TCP
  * store: outside this library); every process then calls uammd_comm_init on ITS device.  All calls are asynchronous on `stream`
- * except uammd_comm_exchange_counts.  The ranks form a periodic ring along z: "up" = rank + 1, "down" = rank - 1.
+ * except uammd_comm_exchange_counts and uammd_comm_exchange_counts_device (the latter takes the two sizes from device memory and
+ * returns {toUp, toDown, fromDown, fromUp} with one synchronisation).  The ranks form a periodic ring along z: "up" = rank + 1, "down" = rank - 1.
  *   path A  uammd_halo_pack -> uammd_comm_halo_exchange (4 floats per row), receive straight into the tail of the position array
  *   path B  uammd_fcm_slab_* + uammd_comm_halo_exchange (grid planes) + uammd_comm_alltoall (FFT transposes)
  *   Lanczos uammd_lanczos_set_allreduce with a callback that calls uammd_comm_allreduce_sum
@@ -681,6 +682,7 @@ int uammd_comm_world(const uammd_comm *h);
 int uammd_comm_halo_exchange(uammd_comm *h, const float *d_sendUp, int nUp, const float *d_sendDown, int nDown, float *d_recvFromDown,
                              int nFromDown, float *d_recvFromUp, int nFromUp, int floatsPerRow, void *stream);
 int uammd_comm_exchange_counts(uammd_comm *h, const int toUpDown[2], int fromDownUp[2], void *stream);
+int uammd_comm_exchange_counts_device(uammd_comm *h, const int *d_toUpDown, int all4[4], void *stream);
 int uammd_comm_alltoall(uammd_comm *h, const void *d_send, void *d_recv, size_t bytesPerPeer, void *stream);
 int uammd_comm_allreduce_sum(uammd_comm *h, float *d_buf, int n, void *stream);
 

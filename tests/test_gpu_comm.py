@@ -26,6 +26,11 @@ def test_comm_world_of_one(hip):
         frm = (C.c_int * 2)(0, 0)
         check(lib.uammd_comm_exchange_counts(comm, to, frm, st))
         assert list(frm) == [37, 5]
+        # the same with the sizes in device memory: all four numbers from one read
+        dev2 = torch.tensor([41, 9], dtype=torch.int32, device="cuda")
+        all4 = (C.c_int * 4)(0, 0, 0, 0)
+        check(lib.uammd_comm_exchange_counts_device(comm, C.c_void_p(dev2.data_ptr()), all4, st))
+        assert list(all4) == [41, 9, 41, 9]
         # halo: pack two index lists with the frame shift, exchange, land in the tail of the position array
         n = 1000
         pos = torch.rand((n + 42, 4), dtype=torch.float32, device="cuda")

@@ -126,6 +126,7 @@ SIGNATURES = {
     "uammd_comm_world": (_i, [_vp]),
     "uammd_comm_halo_exchange": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "uammd_comm_exchange_counts": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+    "uammd_comm_exchange_counts_device": (_i, [_vp, _vp, C.POINTER(C.c_int), _vp]),
     "uammd_comm_alltoall": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "uammd_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp]),
     "uammd_halo_pack": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _vp]),

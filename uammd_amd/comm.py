@@ -94,6 +94,14 @@ class AbiComm:
         _lib.check(self.lib.uammd_comm_exchange_counts(self.h, to, frm, self._st()))
         return int(frm[0]), int(frm[1])
 
+    def exchange_counts_device(self, mine):
+        """`mine` = int32 device tensor [to_up, to_down] (as uammd_slab_select leaves it); returns (to_up, to_down, from_down, from_up) as host
+        ints with ONE stream synchronisation (the sizes travel from device memory; the host reads all four together)."""
+        assert mine.is_cuda and mine.dtype == torch.int32 and mine.numel() == 2 and mine.is_contiguous()
+        out = (C.c_int * 4)(0, 0, 0, 0)
+        _lib.check(self.lib.uammd_comm_exchange_counts_device(self.h, self._p(mine), out, self._st()))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def halo_exchange(self, send_up, send_down, from_down, from_up):
         """float32 rows: send_up -> rank + 1, send_down -> rank - 1; from_down / from_up are the landing tensors (their row counts are the
         message sizes).  Asynchronous on the current stream."""

@@ -75,6 +75,7 @@ struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   int *d_counts = nullptr;   // 4 ints of device scratch for uammd_comm_exchange_counts
+  int *h_counts = nullptr;   // 4 ints of pinned host memory: the landing place of uammd_comm_exchange_counts_device's one read
 };
 
 }  // namespace uammd_hip
@@ -106,7 +107,13 @@ int uammd_comm_init(uammd_comm **out, int rank, int world, const char id[128]) {
     delete c;
     return -20 - (int)r;
   }
-  if (hipMalloc((void **)&c->d_counts, 4 * sizeof(int)) != hipSuccess) { set_last_error("uammd_comm_init: hipMalloc failed"); delete c; return -2; }
+  if (hipMalloc((void **)&c->d_counts, 4 * sizeof(int)) != hipSuccess || hipHostMalloc((void **)&c->h_counts, 4 * sizeof(int)) != hipSuccess) {
+    set_last_error("uammd_comm_init: hipMalloc failed");
+    (void)g_rccl.CommDestroy(c->comm);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    delete c;
+    return -2;
+  }
   *out = reinterpret_cast<uammd_comm *>(c);
   return 0;
 }
@@ -116,6 +123,7 @@ int uammd_comm_destroy(uammd_comm *h) {
   Comm *c = reinterpret_cast<Comm *>(h);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
   delete c;
   return 0;
 }
@@ -157,6 +165,27 @@ int uammd_comm_exchange_counts(uammd_comm *h, const int toUpDown[2], int fromDow
   UH_NCCL(g_rccl.GroupEnd());
   UH_CHECK(hipMemcpyAsync(fromDownUp, c->d_counts + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   UH_CHECK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// The same exchange with the two sizes still on the device (where the selection kernel left them: uammd_slab_select's counts): they go to
+// the neighbours from there, and ONE read returns all four numbers {toUp, toDown, fromDown, fromUp} — one stream synchronisation per
+// phase of a refresh instead of two (the read of the own sizes, then the exchange's).
+int uammd_comm_exchange_counts_device(uammd_comm *h, const int *d_toUpDown, int all4[4], void *stream) {
+  if (!h || !d_toUpDown || !all4) { set_last_error("uammd_comm_exchange_counts_device: null argument"); return -1; }
+  Comm *c = reinterpret_cast<Comm *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  const int up = (c->rank + 1) % c->world, down = (c->rank + c->world - 1) % c->world;
+  UH_NCCL(g_rccl.GroupStart());
+  UH_NCCL(g_rccl.Send(d_toUpDown, 1, ncclInt32, up, c->comm, st));
+  UH_NCCL(g_rccl.Recv(c->d_counts + 2, 1, ncclInt32, down, c->comm, st));
+  UH_NCCL(g_rccl.Send(d_toUpDown + 1, 1, ncclInt32, down, c->comm, st));
+  UH_NCCL(g_rccl.Recv(c->d_counts + 3, 1, ncclInt32, up, c->comm, st));
+  UH_NCCL(g_rccl.GroupEnd());
+  UH_CHECK(hipMemcpyAsync(c->d_counts, d_toUpDown, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));
+  UH_CHECK(hipMemcpyAsync(c->h_counts, c->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  UH_CHECK(hipStreamSynchronize(st));
+  for (int k = 0; k < 4; ++k) all4[k] = c->h_counts[k];
   return 0;
 }
 

@@ -82,6 +82,8 @@ class SlabDecomposition:
     def _exchange_counts(self, mine):
         """`mine` = tensor [n_to_up, n_to_down] (any device).  -> the same two numbers and what the neighbours send, as host ints."""
         if self.comm is not None:
+            if mine.is_cuda and mine.dtype == torch.int32 and mine.is_contiguous():
+                return self.comm.exchange_counts_device(mine)      # sizes straight from device memory: one host read for all four
             a, b = mine.tolist()
             c, d = self.comm.exchange_counts(a, b)
             return a, b, c, d
