@@ -589,6 +589,17 @@ def run_lj_distributed(hip, args, world, rank, dist):
         cl.set_option("num_owned", sim.n_owned)
         cl.transverse_lj(pot.device_table(), 1, box, fall, None, None, None, args.algo)
 
+    def forces_step2_into(allpos, box_L, periodic, fall, v):
+        """the same with GronbechJensen's second half step of the owned rows in the traversal's store (uammd_lj_transverse_celllist_gj2)"""
+        key = (tuple(box_L), tuple(periodic))
+        if key not in grid_cache:
+            box = hip.Box(box_L, periodic)
+            grid_cache[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        box, cd, ubox = grid_cache[key]
+        cl.update_grid(allpos, ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, args.algo)
+
     def forces_fn(allpos, box_L, periodic):
         f = torch.zeros((allpos.shape[0], 4), dtype=torch.float32, device=allpos.device)
         forces_into(allpos.contiguous(), box_L, periodic, f)
@@ -601,7 +612,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
                                            1.0, None, C.c_void_p(key.data_ptr()), p.shape[0], dt, 1.0, 0, noise, step_num, 4242,
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into)
+    sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into,
+                        forces_step2_into=None if os.environ.get("UAMMD_BENCH_NO_GJ2") == "1" else forces_step2_into)
     force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
     sorter = hip.CellList()
 

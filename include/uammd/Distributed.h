@@ -108,6 +108,12 @@ class DistributedLJ {
     detail::check(uammd_lj_transverse_celllist(cl, pot.deviceTable(), pot.getNumberTypes(), boxL, boxPer, (float *)force.d, nullptr, nullptr, nullptr,
                                                UAMMD_LJ_ALGO_AUTO, (void *)st));
   }
+  void forcesAndSecondHalfStep() {  // the same, GronbechJensen's second half step of the owned rows riding in the traversal's store
+    detail::check(uammd_celllist_update(cl, (const float *)pos.d, nAll, updL, updPer, cellDim, (void *)st));
+    detail::check(uammd_celllist_set_option(cl, "num_owned", nOwned));
+    detail::check(uammd_lj_transverse_celllist_gj2(cl, pot.deviceTable(), pot.getNumberTypes(), boxL, boxPer, (float *)force.d, vel.d, nullptr, real(1.0),
+                                                   dt, 0, UAMMD_LJ_ALGO_AUTO, (void *)st));
+  }
   void integrate(int step) {
     // (the thermostat's stream is keyed by the particle's GLOBAL id, same seed on every rank: a particle draws the same kicks whichever
     // rank and row holds it — no correlation between slabs through equal row numbers, no dependence on the decomposition)
@@ -161,8 +167,7 @@ public:
     if (steps == 1) { refresh(); forces(); }
     integrate(1);
     if ((steps - 1) % exchangeEvery == 0) refresh(); else refill();
-    forces();
-    integrate(2);
+    forcesAndSecondHalfStep();
   }
   int numberOwned() const { return nOwned; }
   int numberGhosts() const { return nAll - nOwned; }

@@ -231,6 +231,14 @@ int uammd_verletnvt_gj_lj_step(uammd_celllist *h, float *d_pos, float *d_vel, fl
                                int ntypes, float dt, float friction, int is2D, float noiseAmplitude, unsigned int stepNum,
                                unsigned int seed, int algo, void *stream);
 
+/* The second half of that fusion alone, for lists with ghosts (the domain-decomposed drivers exchange the halo between the first half
+ * step and the list build, so only the traversal's store can carry a half step): PairForces<Potential::LJ, CellList>::sum on the owned
+ * rows (option num_owned of the list) with GronbechJensen's second half step (GronbechJensen.cu:28-62) applied to them in the store.
+ * d_force must be zero on the owned rows on entry.  Same bits as uammd_lj_transverse_celllist -> uammd_verletnvt_gj(2) on the owned rows. */
+int uammd_lj_transverse_celllist_gj2(uammd_celllist *h, const uammd_lj_pair_parameters *d_paramTable, int ntypes, const float boxL[3],
+                                     const int boxPeriodic[3], float *d_force, float *d_vel, const float *d_mass, float defaultMass,
+                                     float dt, int is2D, int algo, void *stream);
+
 int uammd_verletnvt_basic(int step, float *d_pos, float *d_vel, float *d_force, const float *d_mass,
                           float defaultMass, const int *d_index, int numberParticles, float dt, float friction,
                           int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);

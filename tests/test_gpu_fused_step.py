@@ -94,3 +94,56 @@ def test_fused_step_sort_and_restart(hip):
     ida, idb = pa.id.cpu().numpy(), pb.id.cpu().numpy()
     assert np.array_equal(ida, idb)
     assert _same(pa.getPos("read"), pb.getPos("read")) and _same(pa.getVel("read"), pb.getVel("read"))
+
+
+@pytest.mark.parametrize("case", ["tile", "tile-mass-array", "exact-fallback", "multitype", "no-ghosts"])
+def test_traversal_with_second_half_step_on_a_list_with_ghosts(hip, case):
+    """uammd_lj_transverse_celllist_gj2 (the slab drivers' step: the list holds ghosts, the traversal's store applies GronbechJensen's second
+    half step, GronbechJensen.cu:28-62, to the owned rows) against uammd_lj_transverse_celllist -> uammd_verletnvt_gj(2) on the owned rows:
+    forces and velocities the same bits, ghost rows of the force array and every row beyond the owned velocities untouched."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    lib = load()
+    n, L, ntypes = 30000, (31.0, 31.0, 36.0), 1
+    if case == "multitype":
+        ntypes = 2
+    pos = torch.from_numpy(lattice_positions(n, L, seed=11, jitter=0.1, ntypes=ntypes)).cuda()
+    # a slab: non-periodic z, the rows with |z| beyond 14 are ghosts and sit at the END of the array (as the halo tail does)
+    ghost = pos[:, 2].abs() > 14.0
+    order = torch.argsort(ghost.to(torch.int8), stable=True)
+    pos = pos[order].contiguous()
+    n_owned = n if case == "no-ghosts" else int((~ghost).sum())
+    assert case == "no-ghosts" or 0 < n_owned < n
+    box = hip.Box(L, (1, 1, 0))
+    pot = hip.Potential.LJ()
+    for a in range(ntypes):
+        for b in range(a, ntypes):
+            pot.setPotParameters(a, b, pot.InputPairParameters(2.5 - 0.2 * a, 1.0 + 0.05 * b, 1.0 + 0.1 * (a + b), False))
+    cd, ubox = hip.CellList.create_update_grid(box, 2.5)
+    algo = 9 if case == "exact-fallback" else 0
+    mass = torch.from_numpy(np.random.default_rng(3).uniform(0.5, 2.0, n).astype(np.float32)).cuda() if case == "tile-mass-array" else None
+    dt = 0.004
+    vel0 = torch.randn((n_owned + 7, 3), dtype=torch.float32, device="cuda")   # 7 spare rows that nobody may touch
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+
+    def run(fused):
+        cl = hip.CellList()
+        cl.update_grid(pos, ubox, cd)
+        cl.set_option("num_owned", -1 if case == "no-ghosts" else n_owned)
+        f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        f[n_owned:] = 123.0                       # ghost rows: must come back as they went in
+        v = vel0.clone()
+        if fused:
+            cl.transverse_lj_gj2(pot.device_table(), ntypes, box, f, v, dt, mass, 1.0, False, algo)
+        else:
+            cl.transverse_lj(pot.device_table(), ntypes, box, f, None, None, None, algo)
+            check(lib.uammd_verletnvt_gj(2, None, p(v), p(f), p(mass), 0.0 if mass is not None else 1.0, None, n_owned, dt, 1.0, 0, 0.0, 0, 0, st))
+        torch.cuda.synchronize()
+        return f, v
+
+    f0, v0 = run(False)
+    f1, v1 = run(True)
+    assert float(f0[:n_owned, :3].abs().max()) > 1.0 and not _same(v0[:n_owned], vel0[:n_owned])
+    assert _same(f0, f1) and _same(v0, v1)
+    assert _same(v1[n_owned:], vel0[n_owned:]) and bool((f1[n_owned:] == 123.0).all())

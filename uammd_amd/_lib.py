@@ -138,6 +138,7 @@ SIGNATURES = {
     "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),
     "uammd_lj_transverse_celllist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _i, _vp]),
+    "uammd_lj_transverse_celllist_gj2": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _f, _f, _i, _i, _vp]),
     "uammd_lj_transverse_nbody": (_i, [_vp, _i, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _vp]),
     "uammd_verletlist_create": (_i, [C.POINTER(_vp)]),
     "uammd_verletlist_destroy": (_i, [_vp]),

@@ -719,6 +719,41 @@ int uammd_verletnvt_gj_lj_step(uammd_celllist *hh, float *d_pos, float *d_vel, f
   return 0;
 }
 
+// The second half of that fusion on its own, for the domain-decomposed drivers: between the first half step and the list build they
+// exchange the halo, so the build cannot carry the first half step — but the traversal's store can still carry the second one.  The
+// list may hold ghosts (option num_owned): they act as neighbours only.  d_force must be zero on the owned rows (GronbechJensen's
+// first half step leaves it so) and holds f(t + dt) on return.  Same bits as uammd_lj_transverse_celllist followed by
+// uammd_verletnvt_gj(2) on the owned rows, which is what runs where the tile kernel does not take the list.
+int uammd_lj_transverse_celllist_gj2(uammd_celllist *hh, const uammd_lj_pair_parameters *d_paramTable, int ntypes, const float boxL[3],
+                                     const int boxPeriodic[3], float *d_force, float *d_vel, const float *d_mass, float defaultMass, float dt,
+                                     int is2D, int algo, void *stream) {
+  if (!hh || !d_paramTable || ntypes < 1 || !d_force || !d_vel) { set_last_error("uammd_lj_transverse_celllist_gj2: bad arguments"); return -1; }
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_lj_transverse_celllist_gj2: no mass array and defaultMass <= 0"); return -1; }
+  CellList *h = reinterpret_cast<CellList *>(hh);
+  if (h->numberParticlesBuilt == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const BoxT<float> box = make_box<float>(boxL, boxPeriodic);
+  const LJParams *tbl = reinterpret_cast<const LJParams *>(d_paramTable);
+  float maxCut2 = 0.f;
+  if (int e = h->lj_max_cutoff2(tbl, ntypes, st, &maxCut2)) return e;
+  const bool tile = (algo == UAMMD_LJ_ALGO_AUTO || algo == UAMMD_LJ_ALGO_TILE) && lj_tile_supported(h, box, maxCut2);
+  Outputs out{reinterpret_cast<float4 *>(d_force), nullptr, nullptr, nullptr};
+  if (tile) {
+    out.vel = d_vel; out.mass = d_mass; out.defaultMass = defaultMass; out.dt = dt; out.is2D = is2D;
+    out.invDefaultMass = defaultMass > 0 ? 1.0f / defaultMass : 0.f;
+  }
+  int rc = 0;
+  if (ntypes == 1) rc = dispatch_celllist<true, false, false>(h, algo, box, tbl, ntypes, out, st);
+  else rc = dispatch_celllist<false, false, false>(h, algo, box, tbl, ntypes, out, st);
+  if (rc) return rc;
+  UH_CHECK(hipGetLastError());
+  if (!tile) {
+    const int nOwned = h->numOwned < h->numberParticlesBuilt ? h->numOwned : h->numberParticlesBuilt;
+    return uammd_verletnvt_gj(2, nullptr, d_vel, d_force, d_mass, defaultMass, nullptr, nOwned, dt, 0.f, is2D, 0.f, 0u, 0u, stream);
+  }
+  return 0;
+}
+
 int uammd_lj_transverse_nbody(const float *d_pos, int numberParticles, const uammd_lj_pair_parameters *d_paramTable,
                               int ntypes, const float boxL[3], const int boxPeriodic[3], float *d_force,
                               float *d_energy, float *d_virial, const int *d_globalIndex, void *stream) {

@@ -390,7 +390,8 @@ UH_D void tile_finish(Acc &acc, const ListView &cl, const Outputs &out, uint own
   if (WV) acc.v += __shfl_xor(acc.v, 32);
   if ((lane >> 5) == 0 && valid) {
     const int gi = giPre >= 0 ? giPre : cl.groupIndex[ownFirst + (uint)(o0 + (lane & 31))];
-    if (out.vel) {  // the fused step: half kick with the force that is still in registers (every particle is owned, no group)
+    if (out.vel) {  // the fused step: half kick with the force that is still in registers (no group; ghosts of a slab's list are skipped)
+      if (gi >= cl.numOwned) return;
       const float invMass = out.defaultMass > 0 ? out.invDefaultMass : 1.0f / out.mass[gi];
       float3 v = make_float3(out.vel[3 * (size_t)gi], out.vel[3 * (size_t)gi + 1], out.vel[3 * (size_t)gi + 2]);
       const float fx = 0.0f + acc.fx, fy = 0.0f + acc.fy, fz = 0.0f + acc.fz;  // what `force += f` leaves in a zeroed array

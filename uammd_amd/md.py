@@ -399,6 +399,15 @@ class CellList:
                                                     _ptr(virial), _ptr(global_index), int(algo), current_stream()))
 
 
+    def transverse_lj_gj2(self, param_table, ntypes, box, force, vel, dt, mass=None, default_mass=1.0, is2D=False, algo=0):
+        """The LJ forces of the owned rows (option num_owned) with VerletNVT::GronbechJensen's second half step applied in the traversal's
+        store (uammd_lj_transverse_celllist_gj2): `force` must be zero on the owned rows on entry."""
+        check(self.lib.uammd_lj_transverse_celllist_gj2(self.h, _ptr(param_table), int(ntypes), f3(box.boxSize),
+                                                        i3([int(p) for p in box.periodic]), _ptr(force), _ptr(vel), _ptr(mass),
+                                                        float(0.0 if mass is not None else default_mass), float(dt), int(bool(is2D)), int(algo),
+                                                        current_stream()))
+
+
 class VerletList:
     """VerletList (Interactor/NeighbourList/VerletList.cuh:83-201): the NeighbourList concept on an explicit list that is
     only rebuilt when a particle has drifted (1.08 rc - rc)/2 from where it was at the last build."""

@@ -363,8 +363,11 @@ class DistributedLJ:
     only the particles that change rank (SlabDecomposition.migrate_inplace).  Nothing is allocated or concatenated per step;
     a refresh costs two host reads of message sizes."""
 
-    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25):
+    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25, forces_step2_into=None):
         self.d, self.forces_fn, self.integrate_fn, self.forces_into = decomp, forces_fn, integrate_fn, forces_into
+        # optional: forces_step2_into(allpos, box_L, periodic, fall, vel) = the forces AND the integrator's second half step of the owned
+        # rows in one call (uammd_lj_transverse_celllist_gj2: the half step rides in the traversal's store); persistent mode only
+        self.forces_step2_into = forces_step2_into
         self.steps = 0
         self.current_ids = None   # the owned rows' global ids, set before every integrate_fn call
         self.exchange_every = int(exchange_every) if decomp.skin > 0 else 1
@@ -536,9 +539,14 @@ class DistributedLJ:
             n = self._refresh_persistent(n)
         else:
             self.d.halo_refill(bp, n)
-        self._forces_persistent(n)
         self.current_ids = bi[:n]
-        self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
+        if self.forces_step2_into is not None:
+            L, per = self.d.local_box()
+            self.n_owned = n
+            self.forces_step2_into(bp[:self._nall], L, per, bf[:self._nall], bv[:n])
+        else:
+            self._forces_persistent(n)
+            self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
         return bp[:n], bv[:n], bf[:n], bi[:n]
 
     def reordered(self):
