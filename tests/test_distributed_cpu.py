@@ -88,7 +88,13 @@ def _worker(rank, world, port, out_dir, skin=0.0, every=1, persistent=False):
         def forces_into(allpos, box_L, periodic, fall):   # persistent-buffer mode: accumulate into the step's own force buffer
             fall += forces_fn(allpos, box_L, periodic)
 
-        sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=every, forces_into=forces_into if persistent else None)
+        def forces_step2_into(allpos, box_L, periodic, fall, v):   # what uammd_lj_transverse_celllist_gj2 does in one launch on the GPU
+            n_own = v.shape[0]
+            fall[:n_own] += forces_fn(allpos, box_L, periodic)[:n_own]
+            integrate_fn(2, allpos[:n_own], v, fall[:n_own], 0)
+
+        sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=every, forces_into=forces_into if persistent else None,
+                            forces_step2_into=forces_step2_into if persistent == "step2" else None)
         f0 = sim.compute_forces(lpos).clone()
         ids0 = ids.clone()
         nmig = 0
@@ -108,7 +114,8 @@ def _worker(rank, world, port, out_dir, skin=0.0, every=1, persistent=False):
 
 
 @pytest.mark.parametrize("world,skin,every,persistent", [(2, 0.0, 1, False), (3, 0.0, 1, False), (2, 0.15, 3, False), (3, 0.15, 2, False),
-                                                         (2, 0.15, 3, True), (3, 0.15, 2, True), (2, 0.0, 1, True)])
+                                                         (2, 0.15, 3, True), (3, 0.15, 2, True), (2, 0.0, 1, True), (2, 0.15, 3, "step2"),
+                                                         (3, 0.0, 1, "step2")])
 def test_slab_decomposition_matches_single_domain(world, skin, every, persistent, tmp_path):
     """skin > 0: ownership and halo membership refreshed every `every` steps, cached lists in between (no size messages)."""
     f0_ref, p_ref, v_ref = _single_domain()
