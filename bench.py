@@ -612,8 +612,17 @@ def run_lj_distributed(hip, args, world, rank, dist):
                                            1.0, None, C.c_void_p(key.data_ptr()), p.shape[0], dt, 1.0, 0, noise, step_num, 4242,
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def integrate_rows_fn(step, p, v, f, rows, keys, step_num):
+        check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
+                                           1.0, C.c_void_p(rows.data_ptr()), C.c_void_p(keys.data_ptr()), rows.shape[0], dt, 1.0, 0, noise,
+                                           step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
     sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into,
-                        forces_step2_into=None if os.environ.get("UAMMD_BENCH_NO_GJ2") == "1" else forces_step2_into)
+                        forces_step2_into=None if os.environ.get("UAMMD_BENCH_NO_GJ2") == "1" else forces_step2_into,
+                        integrate_rows_fn=integrate_rows_fn if os.environ.get("UAMMD_BENCH_OVERLAP") == "1" else None)
+    # (UAMMD_BENCH_OVERLAP=1: the halo exchange on a side stream behind the half step of the unlisted particles.  Bit-identical
+    # (tests/test_gpu_slab_lj.py) and, at a world of one, SLOWER — 0.289 against 0.255 ms: the half step fills the chip, so only RCCL's
+    # 12 us kernel can hide, and the two cross-stream waits cost 6 + 15 us; DESIGN 7.  Off by default.)
     force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
     sorter = hip.CellList()
 

@@ -13,15 +13,16 @@ import torch
 from util import lattice_positions
 
 pytestmark = pytest.mark.gpu
+sim_box = []   # the last simulation _run built (for assertions on which path it took)
 
 
-def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0):
+def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, comm=None, overlap=False, step2=False):
     from uammd_amd._lib import check, load
     from uammd_amd.parallel import DistributedLJ, SlabDecomposition
     lib = load()
     rc, dt = 2.5, 0.005
     noise = math.sqrt(2 * dt * T)
-    d = SlabDecomposition([L, L, L], rc, 0, 1, skin=skin)
+    d = SlabDecomposition([L, L, L], rc, 0, 1, skin=skin, comm=comm)
     pos = torch.from_numpy(lattice_positions(n, L, seed=11, jitter=0.1)).cuda()
     vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, 1.0, 0, n, 77, None))
@@ -46,7 +47,28 @@ def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0):
                                      1.0, None, p.shape[0], dt, 1.0, 0, noise, step_num, 4242,
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    sim = DistributedLJ(d, None, integrate_fn, exchange_every=exchange_every, forces_into=forces_into)
+    def keyed(step, p, v, f, rows, keys, count, step_num):
+        check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None, 1.0,
+                                           None if rows is None else C.c_void_p(rows.data_ptr()), C.c_void_p(keys.data_ptr()), count, dt, 1.0, 0,
+                                           noise, step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def forces_step2_into(allpos, box_L, periodic, fall, v):
+        key = (tuple(box_L), tuple(periodic))
+        if key not in cache:
+            box = hip.Box(box_L, periodic)
+            cache[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        box, cd, ubox = cache[key]
+        cl.update_grid(allpos, ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, algo)
+
+    if comm is not None:   # the bench's configuration: thermostat keyed by the global id, every message through uammd_comm_*
+        integrate_fn = lambda step, p, v, f, step_num: keyed(step, p, v, f, None, sim.current_ids, p.shape[0], step_num)
+    sim = DistributedLJ(d, None, integrate_fn, exchange_every=exchange_every, forces_into=forces_into,
+                        forces_step2_into=forces_step2_into if step2 else None,
+                        integrate_rows_fn=(lambda step, p, v, f, rows, keys, step_num: keyed(step, p, v, f, rows, keys, rows.shape[0], step_num))
+                        if overlap else None)
+    sim_box.append(sim)
     if not fused:
         sim._refresh_fused = None   # _refresh_persistent falls through to the generic path
         orig = sim._refresh_persistent
@@ -68,6 +90,25 @@ def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0):
     torch.cuda.synchronize()
     sim.check_skin()
     return pos.cpu().numpy().copy(), vel.cpu().numpy().copy(), ids.cpu().numpy().copy(), float(sim.max_drift) if sim.max_drift is not None else 0.0
+
+
+def test_overlapped_exchange_and_fused_half_step_are_bit_identical(hip):
+    """The bench's slab step — halo exchange through uammd_comm_* (RCCL, the ring closing on the rank itself) on a side stream while the
+    main stream integrates the particles nobody else needs, second half step in the traversal's store — against the plain sequence
+    (half step, exchange, build, traversal, half step) on one stream: same rows, same bits, with noise, across refreshes."""
+    from uammd_amd.comm import AbiComm
+    n, L = 30000, 33.5
+    comm = AbiComm(0, 1, AbiComm.unique_id())
+    try:
+        a = _run(hip, n, L, 23, fused=True, comm=comm, overlap=False, step2=False)
+        b = _run(hip, n, L, 23, fused=True, comm=comm, overlap=True, step2=True)
+        assert sim_box[-1]._side is not None, "the overlapped path did not run"
+    finally:
+        comm.close()
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert sorted(a[2].tolist()) == list(range(n))
 
 
 def test_fused_refresh_equals_generic_refresh(hip):

@@ -363,11 +363,20 @@ class DistributedLJ:
     only the particles that change rank (SlabDecomposition.migrate_inplace).  Nothing is allocated or concatenated per step;
     a refresh costs two host reads of message sizes."""
 
-    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25, forces_step2_into=None):
+    def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25, forces_step2_into=None,
+                 integrate_rows_fn=None):
         self.d, self.forces_fn, self.integrate_fn, self.forces_into = decomp, forces_fn, integrate_fn, forces_into
         # optional: forces_step2_into(allpos, box_L, periodic, fall, vel) = the forces AND the integrator's second half step of the owned
         # rows in one call (uammd_lj_transverse_celllist_gj2: the half step rides in the traversal's store); persistent mode only
         self.forces_step2_into = forces_step2_into
+        # optional: integrate_rows_fn(step, pos, vel, force, rows, keys, step_num) = the integrator's half step on the rows `rows` (int32) with
+        # the thermostat keyed by `keys` (their global ids).  With it (persistent mode, GPU, a communicator, cached lists) the halo exchange
+        # of a step between refreshes OVERLAPS the first half step: the listed particles (the ones the neighbours need) are integrated
+        # first, their positions packed and sent on a side stream while the main stream integrates everybody else; the list build waits
+        # for the ghosts.  Same arithmetic per particle: same bits as the unsplit step.
+        self.integrate_rows_fn = integrate_rows_fn
+        self._split = None      # (listed rows, their keys, the other rows, their keys) of the current membership lists
+        self._side = None       # side stream + events of the overlapped exchange
         self.steps = 0
         self.current_ids = None   # the owned rows' global ids, set before every integrate_fn call
         self.exchange_every = int(exchange_every) if decomp.skin > 0 else 1
@@ -444,6 +453,7 @@ class DistributedLJ:
 
     def _refresh_persistent(self, n):
         bp, bv, bi, bf = self._bufs
+        self._split = None
         if bp.is_cuda and bv.dtype == torch.float32 and bv.dim() == 2 and bv.shape[1] == 3 and bi.dtype == torch.int32 and bi.dim() == 1:
             return self._refresh_fused(n)
         self._track_drift(bp[:n])
@@ -513,6 +523,14 @@ class DistributedLJ:
         d._idx32 = (iu, idn, iu)
         d.halo_refill(bp, n)
         self._nall = n + g_from_down + g_from_up
+        self._split = None
+        if self.integrate_rows_fn is not None and d.comm is not None and d.width > 2.0 * reach and 0 < h_up + h_down < n:
+            # (up and down lists are disjoint when the slab is wider than two reaches: their concatenation lists every row once)
+            listed = torch.cat([iu, idn])
+            mask = torch.ones(n, dtype=torch.bool, device=dev)
+            mask[listed.long()] = False
+            rest = torch.nonzero_static(mask, size=n - (h_up + h_down)).flatten().to(torch.int32)
+            self._split = (listed, bi.index_select(0, listed.long()), rest, bi.index_select(0, rest.long()))
         if d.skin > 0:
             ws["ref"][:n].copy_(bp[:n])
             ws["ref_n"] = n
@@ -533,12 +551,27 @@ class DistributedLJ:
             self._forces_persistent(n)
         bp, bv, bi, bf = self._bufs
         self.current_ids = bi[:n]
-        self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
         refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
-        if refresh:
-            n = self._refresh_persistent(n)
+        if not refresh and self._split is not None:
+            listed, lkeys, rest, rkeys = self._split
+            if self._side is None:
+                self._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            side, ev_listed, ev_ghosts = self._side
+            main = torch.cuda.current_stream()
+            self.integrate_rows_fn(1, bp, bv, bf, listed, lkeys, self.steps)
+            ev_listed.record(main)
+            self.integrate_rows_fn(1, bp, bv, bf, rest, rkeys, self.steps)   # everybody else takes the half step, while ...
+            with torch.cuda.stream(side):
+                side.wait_event(ev_listed)
+                self.d.halo_refill(bp, n)          # ... the listed positions are packed, sent, and the ghosts land in the tail
+                ev_ghosts.record(side)
+            main.wait_event(ev_ghosts)
         else:
-            self.d.halo_refill(bp, n)
+            self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
+            if refresh:
+                n = self._refresh_persistent(n)
+            else:
+                self.d.halo_refill(bp, n)
         self.current_ids = bi[:n]
         if self.forces_step2_into is not None:
             L, per = self.d.local_box()
@@ -555,6 +588,7 @@ class DistributedLJ:
         self._allpos = None
         self._ref = None
         self._bufs = None
+        self._split = None
 
     def check_skin(self):
         """Host check (synchronises): the cached exchange is exact only if nobody out-ran the skin."""
