@@ -37,6 +37,7 @@ PEAK_FP32_TFLOPS = 157.3             # MI355X_MICROARCH.md: FP32 vector = FP32 M
 PEAK_HBM_GBS = 8000.0
 
 
+SLAB_STEP = None   # what the slab-decomposed LJ step was made of (set by run_lj_distributed, reported in config)
 ABI_COMM = None   # uammd_amd.comm.AbiComm when the run's messages go through uammd_comm_* (the product's stack); None: torch.distributed
 TRANSPORT = "none (single domain)"   # what actually carried the messages: goes into config.workload and comm.backend
 
@@ -656,6 +657,12 @@ def run_lj_distributed(hip, args, world, rank, dist):
     sim.max_drift = None  # the skin check below covers the timed region (the reference's initial velocities are sqrt(3) too hot,
                           # Basic.cu:12-29: the first steps of the warm-up out-run a skin sized for the equilibrated liquid)
     cl.profile_enable(True)
+    global SLAB_STEP
+    SLAB_STEP = {"second_half_step": "in the traversal's store (uammd_lj_transverse_celllist_gj2)" if sim.forces_step2_into is not None
+                 else "own kernel (uammd_verletnvt_gj_keyed)",
+                 "halo_exchange": "on a side stream behind the half step of the unlisted particles" if sim.integrate_rows_fn is not None
+                 else "on the step's stream, between the first half step and the list build",
+                 "skin": args.skin, "membership_refresh_every": args.exchange_every}
     t0 = time.perf_counter()
     for j in range(args.steps):
         if j > 0 and j % 500 == 0:
@@ -854,7 +861,7 @@ def main():
             "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, z-slab domain decomposition (one 43-cell "
                                    f"slab per GPU, global box L x L x N*L), halo positions + migration through {TRANSPORT}",
                        "particles_per_gpu": n, "box": [L1, L1, L1 * world],
-                       "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange"},
+                       "parallelism": f"slab{world}: 1 process per GPU, P2P halo exchange", "slab_step": SLAB_STEP},
             "pair_interactions_per_s": 52.36 * value,
             "roofline": {"bound": "valu", "kernel": "LJ traversal (k_lj_tile4), owned + ghost particles",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
