@@ -136,11 +136,7 @@ public:
 
 namespace pairforces_detail {
 template <class List> shared_ptr<List> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, List *) {
-  if (pg) throw std::runtime_error("PairForces on a ParticleGroup needs the CellList neighbour list in this build");
-  return make_shared<List>(pd);
-}
-inline shared_ptr<CellList> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, CellList *) {
-  return pg ? make_shared<CellList>(pg) : make_shared<CellList>(pd);
+  return pg ? make_shared<List>(pg) : make_shared<List>(pd);  // both lists take a group (CellList.cuh:132, VerletList.cuh:96)
 }
 template <class Tr> int transverseList(CellList &nl, Tr &tr, const int *globalIndex, hipStream_t st) {
   return device::transverseList(nl.handle(), tr, st, globalIndex);

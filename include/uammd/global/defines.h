@@ -10,9 +10,11 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define UAMMD_HD inline __host__ __device__
+#define UAMMD_HOSTDEV __host__ __device__
 #else
 #include <hip/hip_vector_types.h>
 #define UAMMD_HD inline
+#define UAMMD_HOSTDEV
 #endif
 
 #define UAMMD_VERSION "3.0.0"

@@ -12,10 +12,14 @@
 #include <thrust/execution_policy.h>
 #include <thrust/fill.h>
 #include <thrust/host_vector.h>
+#include <thrust/iterator/constant_iterator.h>
 #include <thrust/iterator/counting_iterator.h>
 #include <thrust/iterator/permutation_iterator.h>
 #include <thrust/iterator/transform_iterator.h>
 #include <thrust/reduce.h>
 #include <thrust/transform.h>
 #include <thrust/transform_reduce.h>
+// the reference's umbrella header also brings CUB (third_party/uammd_cub.cuh); its name on this platform is hipcub:: — programs that say
+// cub::ThreadLoad / cub::DeviceScan spell it hipcub:: (a user-side edit like cudaStream_t -> hipStream_t; not aliased here)
+#include <hipcub/hipcub.hpp>
 #endif

@@ -36,8 +36,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <deque>
 #include <functional>
 #include <limits>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -45,6 +47,17 @@
 
 #include "../uammd_hip.h"
 #include "utils/vector.cuh"
+// A TU compiled by hipcc also gets the DEVICE side of the neighbour lists (NeighbourContainer and its iterators, the list kernels): the
+// host classes below then hand out getNeighbourContainer() and take device iterators, as the reference's do under nvcc.  A plain C++
+// compiler sees the host interface alone.
+#if defined(__HIPCC__)
+#include "device/Transverser.hip.hpp"
+#include <thrust/device_malloc_allocator.h>
+#include <thrust/device_ptr.h>
+#include <thrust/execution_policy.h>
+#include <thrust/iterator/iterator_traits.h>
+#include <thrust/transform.h>
+#endif
 
 namespace uammd {
 
@@ -60,6 +73,9 @@ struct cuda_generic_error : public std::runtime_error {
 struct illegal_property_access : public std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+using exception = std::exception;  // utils/exception.h:11
+// utils/exception.h:13-27: what() of an exception and of every exception nested in it, one log line per level
+inline void backtrace_nested_exception(const uammd::exception &e, int level = 0);
 namespace detail {
 inline void check(int rc) {
   if (rc != 0) throw cuda_generic_error(std::string(uammd_hip_last_error()), rc);
@@ -75,7 +91,55 @@ inline int nextFFTWiseSize(int v) {  // utils/Grid.cuh:142-213, one dimension
     if (m == 1) return v;
   }
 }
-template <class T> struct DeviceArray {  // owning device buffer (thrust::device_vector stand-in for host code)
+// The pool of temporary device memory (System.h:65-78, misc/allocator.h: pool_memory_resource_adaptor): blocks that are given back are
+// kept, by size, and handed out again instead of going through hipFree / hipMalloc (a hipFree waits for the device).  One pool per
+// process, single host thread (the reference's assumption too); System::finish() and the end of the process return the kept blocks.
+class DevicePool {
+  std::multimap<size_t, void *> kept;  // free blocks by capacity
+  std::map<void *, size_t> live;       // blocks handed out -> capacity
+  size_t keptBytes = 0;
+  static size_t capacityFor(size_t bytes) {  // 256-byte granules up to 1 MiB, then 1/8-octave steps: bounded slack, few distinct sizes
+    if (bytes <= (size_t(1) << 20)) return (bytes + 255) & ~size_t(255);
+    size_t step = size_t(1) << 17;
+    while ((step << 4) < bytes) step <<= 1;
+    return (bytes + step - 1) / step * step;
+  }
+public:
+  static DevicePool &instance() { static DevicePool *p = new DevicePool; return *p; }  // (never destroyed: no runtime calls at exit)
+  void *allocate(size_t bytes) {
+    if (bytes == 0) return nullptr;
+    const size_t cap = capacityFor(bytes);
+    auto it = kept.find(cap);
+    void *ptr = nullptr;
+    if (it != kept.end()) { ptr = it->second; kept.erase(it); keptBytes -= cap; }
+    else {
+      hipError_t e = hipMalloc(&ptr, cap);
+      if (e != hipSuccess) {  // give the kept blocks back to the runtime and try once more
+        (void)hipGetLastError();
+        release();
+        hipCheck(hipMalloc(&ptr, cap), "hipMalloc");
+      }
+    }
+    live[ptr] = cap;
+    return ptr;
+  }
+  void deallocate(void *ptr) {
+    if (!ptr) return;
+    auto it = live.find(ptr);
+    if (it == live.end()) { (void)hipFree(ptr); return; }  // not ours
+    kept.emplace(it->second, ptr);
+    keptBytes += it->second;
+    live.erase(it);
+  }
+  void release() {
+    for (auto &b : kept) (void)hipFree(b.second);
+    kept.clear();
+    keptBytes = 0;
+  }
+  size_t bytesKept() const { return keptBytes; }
+  size_t blocksLive() const { return live.size(); }
+};
+template <class T> struct DeviceArray {  // owning device buffer (thrust::device_vector stand-in for host code), memory from the pool
   T *d = nullptr;
   size_t n = 0;
   DeviceArray() = default;
@@ -84,7 +148,7 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
   DeviceArray &operator=(const DeviceArray &) = delete;
   DeviceArray(DeviceArray &&o) noexcept : d(o.d), n(o.n) { o.d = nullptr; o.n = 0; }
   DeviceArray &operator=(DeviceArray &&o) noexcept { swap(o); return *this; }
-  ~DeviceArray() { if (d) (void)hipFree(d); }
+  ~DeviceArray() { DevicePool::instance().deallocate(d); }
   T *data() { return d; }
   const T *data() const { return d; }
   T *begin() { return d; }
@@ -93,11 +157,11 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
   bool empty() const { return n == 0; }
   void resize(size_t m) {
     if (m == n) return;
-    if (d) (void)hipFree(d);
+    DevicePool::instance().deallocate(d);
     d = nullptr;
     n = m;
     if (m) {
-      hipCheck(hipMalloc((void **)&d, sizeof(T) * m), "hipMalloc");
+      d = static_cast<T *>(DevicePool::instance().allocate(sizeof(T) * m));
       hipCheck(hipMemset(d, 0, sizeof(T) * m), "hipMemset");
     }
   }
@@ -106,6 +170,7 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
 }  // namespace detail
 // owning device container returned by value where the reference returns cached_vector (utils/container.h); movable, not copyable
 template <class T> using cached_vector = detail::DeviceArray<T>;
+template <class T> using uninitialized_cached_vector = detail::DeviceArray<T>;  // utils/container.h:128-129
 
 // ---- utils/utils.h:21-32: wall-clock stopwatch, seconds ----
 class Timer {
@@ -196,41 +261,82 @@ public:
 #else
   static int &maxLogLevel() { static int l = STDOUT; return l; }
 #endif
-  void finish() { (void)hipDeviceSynchronize(); }
+  void finish() { (void)hipDeviceSynchronize(); detail::DevicePool::instance().release(); }
+  // System.h:65-78: allocators over the pool of temporary device memory.  allocator<T> hands out raw device pointers;
+  // allocator_thrust<T> is the same pool behind thrust's allocator interface (thrust::device_vector<T, System::allocator_thrust<T>>,
+  // thrust::device(System::allocator_thrust<char>()) as an execution policy) and needs a TU compiled by hipcc, as thrust does.
+  template <class T> struct allocator {
+    using value_type = T;
+    allocator() = default;
+    template <class U> allocator(const allocator<U> &) {}
+    T *allocate(size_t n) const { return static_cast<T *>(detail::DevicePool::instance().allocate(n * sizeof(T))); }
+    void deallocate(T *p, size_t = 0) const { detail::DevicePool::instance().deallocate(p); }
+    template <class U> bool operator==(const allocator<U> &) const { return true; }
+    template <class U> bool operator!=(const allocator<U> &) const { return false; }
+  };
+  template <class T> allocator<T> getTemporaryDeviceAllocator() { return allocator<T>(); }  // System.h:292-296
+#if defined(__HIPCC__)
+  template <class T> struct allocator_thrust : thrust::device_malloc_allocator<T> {
+    using super = thrust::device_malloc_allocator<T>;
+    using pointer = typename super::pointer;
+    using size_type = typename super::size_type;
+    template <class U> struct rebind { using other = allocator_thrust<U>; };
+    __host__ allocator_thrust() {}
+    __host__ allocator_thrust(const allocator_thrust &) = default;
+    template <class U> __host__ allocator_thrust(const allocator_thrust<U> &) {}
+    __host__ pointer allocate(size_type n) { return pointer(static_cast<T *>(detail::DevicePool::instance().allocate(n * sizeof(T)))); }
+    __host__ void deallocate(pointer p, size_type = 0) { detail::DevicePool::instance().deallocate(thrust::raw_pointer_cast(p)); }
+  };
+#endif
 };
+inline void backtrace_nested_exception(const uammd::exception &e, int level) {
+  System::log<System::EXCEPTION>(std::string(level, ' ') + "level " + std::to_string(level) + " exception: " + e.what());
+  try { std::rethrow_if_nested(e); }
+  catch (const std::exception &nested) { backtrace_nested_exception(nested, level + 1); }
+  catch (...) {}
+}
 
 // ---- utils/Box.cuh ----------------------------------------------------------------------------------------------------
-struct Box {
+struct Box {  // a POD a kernel takes by value: every member is callable from device code in a TU compiled by hipcc (utils/Box.cuh:16-92)
   real3 boxSize, minusInvBoxSize;
-  Box() : Box(real(0)) {}
-  Box(real L) : Box(make_real3(L)) {}
-  Box(real3 L) : boxSize(L), minusInvBoxSize{real(-1.0) / L.x, real(-1.0) / L.y, real(-1.0) / L.z} {
-    if (boxSize.x == real(0.0) || std::isinf(boxSize.x)) minusInvBoxSize.x = real(0.0);
-    if (boxSize.y == real(0.0) || std::isinf(boxSize.y)) minusInvBoxSize.y = real(0.0);
-    if (boxSize.z == real(0.0) || std::isinf(boxSize.z)) minusInvBoxSize.z = real(0.0);
+  UAMMD_HOSTDEV Box() : Box(real(0)) {}
+  UAMMD_HOSTDEV Box(real L) : Box(make_real3(L)) {}
+  UAMMD_HOSTDEV Box(real3 L) : boxSize(L), minusInvBoxSize{real(-1.0) / L.x, real(-1.0) / L.y, real(-1.0) / L.z} {
+    if (boxSize.x == real(0.0) || __builtin_isinf(boxSize.x)) minusInvBoxSize.x = real(0.0);
+    if (boxSize.y == real(0.0) || __builtin_isinf(boxSize.y)) minusInvBoxSize.y = real(0.0);
+    if (boxSize.z == real(0.0) || __builtin_isinf(boxSize.z)) minusInvBoxSize.z = real(0.0);
   }
-  void setPeriodicity(bool x, bool y, bool z) {
+  UAMMD_HOSTDEV void setPeriodicity(bool x, bool y, bool z) {
     if (!x) minusInvBoxSize.x = 0;
     if (!y) minusInvBoxSize.y = 0;
     if (!z) minusInvBoxSize.z = 0;
   }
-  bool isPeriodicX() const { return minusInvBoxSize.x != 0; }
-  bool isPeriodicY() const { return minusInvBoxSize.y != 0; }
-  bool isPeriodicZ() const { return minusInvBoxSize.z != 0; }
-  real3 apply_pbc(real3 r) const {
-    const real ox = std::floor(r.x * minusInvBoxSize.x + real(0.5)), oy = std::floor(r.y * minusInvBoxSize.y + real(0.5)),
-               oz = std::floor(r.z * minusInvBoxSize.z + real(0.5));
-    r.x += isPeriodicX() ? ox * boxSize.x : 0;
-    r.y += isPeriodicY() ? oy * boxSize.y : 0;
-    r.z += isPeriodicZ() ? oz * boxSize.z : 0;
+  UAMMD_HOSTDEV bool isPeriodicX() const { return minusInvBoxSize.x != 0; }
+  UAMMD_HOSTDEV bool isPeriodicY() const { return minusInvBoxSize.y != 0; }
+  UAMMD_HOSTDEV bool isPeriodicZ() const { return minusInvBoxSize.z != 0; }
+  // utils/Box.cuh:51-58 under the library's floating-point contract: the offset from ONE fused multiply-add, the shift
+  // r + offset * L unfused — what the cell-list and traversal kernels compute, so a user kernel takes the same decision for a pair an
+  // ulp from the cut-off
+  UAMMD_HOSTDEV real3 apply_pbc(real3 r) const {
+    const real ox = ::floorf(::fmaf(r.x, minusInvBoxSize.x, real(0.5))), oy = ::floorf(::fmaf(r.y, minusInvBoxSize.y, real(0.5))),
+               oz = ::floorf(::fmaf(r.z, minusInvBoxSize.z, real(0.5)));
+    const real sx = ox * boxSize.x, sy = oy * boxSize.y, sz = oz * boxSize.z;
+    r.x += isPeriodicX() ? sx : 0;
+    r.y += isPeriodicY() ? sy : 0;
+    r.z += isPeriodicZ() ? sz : 0;
     return r;
   }
-  real getVolume() const { return boxSize.z != real(0.0) ? boxSize.x * boxSize.y * boxSize.z : boxSize.x * boxSize.y; }
-  bool operator==(const Box &o) const {
+  template <class VecType> UAMMD_HOSTDEV real3 apply_pbc(const VecType &r) const { return apply_pbc(make_real3(r)); }
+  UAMMD_HOSTDEV bool isInside(const real3 &r) const {  // utils/Box.cuh:60-70
+    const real3 h = boxSize * real(0.5);
+    return !(r.x <= -h.x || r.x > h.x) && !(r.y <= -h.y || r.y > h.y) && !(r.z <= -h.z || r.z > h.z);
+  }
+  UAMMD_HOSTDEV real getVolume() const { return boxSize.z != real(0.0) ? boxSize.x * boxSize.y * boxSize.z : boxSize.x * boxSize.y; }
+  UAMMD_HOSTDEV bool operator==(const Box &o) const {
     return boxSize.x == o.boxSize.x && boxSize.y == o.boxSize.y && boxSize.z == o.boxSize.z &&
            isPeriodicX() == o.isPeriodicX() && isPeriodicY() == o.isPeriodicY() && isPeriodicZ() == o.isPeriodicZ();
   }
-  bool operator!=(const Box &o) const { return !(*this == o); }
+  UAMMD_HOSTDEV bool operator!=(const Box &o) const { return !(*this == o); }
   // helpers for the C ABI
   void toArrays(float L[3], int per[3]) const {
     L[0] = boxSize.x; L[1] = boxSize.y; L[2] = boxSize.z;
@@ -246,10 +352,10 @@ struct Grid {
   real3 cellSize, invCellSize;
   Box box;
   real cellVolume;
-  Grid() : Grid(Box(), make_int3(0, 0, 0)) {}
-  Grid(Box box, real3 minCellSize) : Grid(box, make_int3(box.boxSize / minCellSize)) {}
-  Grid(Box box, real minCellSize) : Grid(box, make_real3(minCellSize)) {}
-  Grid(Box box_, int3 cells) : cellDim(cells), box(box_) {
+  UAMMD_HOSTDEV Grid() : Grid(Box(), make_int3(0, 0, 0)) {}
+  UAMMD_HOSTDEV Grid(Box box, real3 minCellSize) : Grid(box, make_int3(box.boxSize / minCellSize)) {}
+  UAMMD_HOSTDEV Grid(Box box, real minCellSize) : Grid(box, make_real3(minCellSize)) {}
+  UAMMD_HOSTDEV Grid(Box box_, int3 cells) : cellDim(cells), box(box_) {
     if (cellDim.z == 0) cellDim.z = 1;
     cellSize = box.boxSize / make_real3(cellDim);
     invCellSize = 1.0 / cellSize;
@@ -257,7 +363,7 @@ struct Grid {
     gridPos2CellIndex = make_int3(1, cellDim.x, cellDim.x * cellDim.y);
     cellVolume = cellSize.x * cellSize.y * (cellDim.z > 1 ? cellSize.z : real(1.0));
   }
-  template <class VecType> int3 getCell(const VecType &r) const {
+  template <class VecType> UAMMD_HOSTDEV int3 getCell(const VecType &r) const {
     int3 cell = make_int3((box.apply_pbc(make_real3(r)) + real(0.5) * box.boxSize) * invCellSize);
     // (a position exactly on the upper face rounds to cell cellDim: it belongs to cell 0)
     if (cell.x == cellDim.x) cell.x = 0;
@@ -265,35 +371,123 @@ struct Grid {
     if (cell.z == cellDim.z) cell.z = 0;
     return cell;
   }
-  int getCellIndex(const int3 &cell) const { return dot(cell, gridPos2CellIndex); }
-  int getCellIndex(const int2 &cell) const { return dot(cell, make_int2(gridPos2CellIndex)); }
-  template <int coordinate> int pbc_cell_coord(int cell) const {
+  UAMMD_HOSTDEV int getCellIndex(const int3 &cell) const { return dot(cell, gridPos2CellIndex); }
+  UAMMD_HOSTDEV int getCellIndex(const int2 &cell) const { return dot(cell, make_int2(gridPos2CellIndex)); }
+  template <int coordinate> UAMMD_HOSTDEV int pbc_cell_coord(int cell) const {
     const int ncells = coordinate == 0 ? (box.isPeriodicX() ? cellDim.x : 0)
                                        : (coordinate == 1 ? (box.isPeriodicY() ? cellDim.y : 0) : (box.isPeriodicZ() ? cellDim.z : 0));
     if (cell <= -1) cell += ncells;
     else if (cell >= ncells) cell -= ncells;
     return cell;
   }
-  int3 pbc_cell(const int3 &cell) const { return make_int3(pbc_cell_coord<0>(cell.x), pbc_cell_coord<1>(cell.y), pbc_cell_coord<2>(cell.z)); }
-  int getNumberCells() const { return cellDim.x * cellDim.y * cellDim.z; }
-  real getCellVolume() const { return cellVolume; }
-  real getCellVolume(int3) const { return cellVolume; }
-  real3 getCellSize() const { return cellSize; }
-  real3 getCellSize(int3) const { return cellSize; }
-  real3 getCellCenter(int3 cell) const { return cellSize * (make_real3(cell) + real(0.5)); }
-  real3 distanceToCellCenter(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - getCellCenter(cell)); }
-  real3 distanceToCellUpperLeftCorner(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - cellSize * make_real3(cell)); }
+  UAMMD_HOSTDEV int3 pbc_cell(const int3 &cell) const { return make_int3(pbc_cell_coord<0>(cell.x), pbc_cell_coord<1>(cell.y), pbc_cell_coord<2>(cell.z)); }
+  UAMMD_HOSTDEV int getNumberCells() const { return cellDim.x * cellDim.y * cellDim.z; }
+  UAMMD_HOSTDEV real getCellVolume() const { return cellVolume; }
+  UAMMD_HOSTDEV real getCellVolume(int3) const { return cellVolume; }
+  UAMMD_HOSTDEV real3 getCellSize() const { return cellSize; }
+  UAMMD_HOSTDEV real3 getCellSize(int3) const { return cellSize; }
+  UAMMD_HOSTDEV real3 getCellCenter(int3 cell) const { return cellSize * (make_real3(cell) + real(0.5)); }
+  UAMMD_HOSTDEV real3 distanceToCellCenter(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - getCellCenter(cell)); }
+  UAMMD_HOSTDEV real3 distanceToCellUpperLeftCorner(real3 pos, int3 cell) const { return box.apply_pbc(pos + box.boxSize * real(0.5) - cellSize * make_real3(cell)); }
 };
 // the next grid size, per axis, that is even and has only the factors 2, 3, 5, 7, 11 (utils/Grid.cuh:142-213)
 inline int3 nextFFTWiseSize3D(int3 size) {
   return make_int3(detail::nextFFTWiseSize(size.x), detail::nextFFTWiseSize(size.y), size.z > 1 ? detail::nextFFTWiseSize(size.z) : size.z);
 }
 
+// ---- signal / connection (ParticleData.cuh:110-125: nod::unsafe_signal / nod::connection; single host thread, as there) ------------
+// signal<void(Args...)>::connect(slot) hands out a connection; connection::disconnect() removes the slot; a connection may outlive its
+// signal (it then reports !connected()).  A slot may disconnect itself or others while the signal is being emitted.
+namespace detail {
+struct signal_state_base {
+  virtual ~signal_state_base() = default;
+  virtual void remove(size_t id) = 0;
+  virtual bool has(size_t id) const = 0;
+};
+}  // namespace detail
+class connection {
+  std::weak_ptr<detail::signal_state_base> state;
+  size_t id = 0;
+public:
+  connection() = default;
+  connection(std::weak_ptr<detail::signal_state_base> s, size_t id) : state(std::move(s)), id(id) {}
+  connection(connection &&o) noexcept : state(std::move(o.state)), id(o.id) { o.state.reset(); o.id = 0; }
+  connection &operator=(connection &&o) noexcept { state = std::move(o.state); id = o.id; o.state.reset(); o.id = 0; return *this; }
+  connection(const connection &) = delete;
+  connection &operator=(const connection &) = delete;
+  bool connected() const { auto s = state.lock(); return s && s->has(id); }
+  void disconnect() {
+    if (auto s = state.lock()) s->remove(id);
+    state.reset();
+    id = 0;
+  }
+};
+// a connection that disconnects when it goes out of scope (nod::scoped_connection): what the modules of this header hold
+class scoped_connection {
+  connection c;
+public:
+  scoped_connection() = default;
+  scoped_connection(connection &&o) : c(std::move(o)) {}
+  scoped_connection(scoped_connection &&) = default;
+  scoped_connection &operator=(connection &&o) { c.disconnect(); c = std::move(o); return *this; }
+  scoped_connection &operator=(scoped_connection &&o) { c.disconnect(); c = std::move(o.c); return *this; }
+  ~scoped_connection() { c.disconnect(); }
+  bool connected() const { return c.connected(); }
+  void disconnect() { c.disconnect(); }
+  void reset() { c.disconnect(); }
+  connection release() { return std::move(c); }
+};
+template <class Signature> class signal;
+template <class... Args> class signal<void(Args...)> {
+  struct State : detail::signal_state_base {
+    std::deque<std::pair<size_t, std::function<void(Args...)>>> slots;  // (a deque: connecting from inside a slot does not move the running one)
+    size_t next = 1;
+    int emitting = 0;
+    bool holes = false;
+    void remove(size_t id) override {
+      for (auto &s : slots)
+        if (s.first == id) { s.first = 0; holes = true; }  // (the slot itself is destroyed outside any emission: it may be the caller)
+      if (!emitting) compact();
+    }
+    bool has(size_t id) const override {
+      for (auto &s : slots) if (s.first == id && id) return true;
+      return false;
+    }
+    void compact() {
+      if (!holes) return;
+      slots.erase(std::remove_if(slots.begin(), slots.end(), [](const std::pair<size_t, std::function<void(Args...)>> &s) { return s.first == 0; }), slots.end());
+      holes = false;
+    }
+  };
+  std::shared_ptr<State> st = std::make_shared<State>();
+public:
+  signal() = default;
+  signal(const signal &) = delete;
+  signal &operator=(const signal &) = delete;
+  template <class Slot> connection connect(Slot &&slot) {
+    const size_t id = st->next++;
+    st->slots.emplace_back(id, std::function<void(Args...)>(std::forward<Slot>(slot)));
+    return connection(std::weak_ptr<detail::signal_state_base>(st), id);
+  }
+  void operator()(Args... a) const {
+    const std::shared_ptr<State> keep = st;  // (a slot may destroy the object that owns this signal)
+    State &s = *keep;
+    ++s.emitting;
+    const size_t n = s.slots.size();  // slots connected during the emission are not called by it
+    for (size_t i = 0; i < n; ++i)
+      if (s.slots[i].first) s.slots[i].second(a...);
+    if (--s.emitting == 0) s.compact();
+  }
+  int slot_count() const { int c = 0; for (auto &s : st->slots) c += s.first != 0; return c; }
+  bool empty() const { return slot_count() == 0; }
+  void disconnect_all_slots() { for (auto &s : st->slots) s.first = 0; st->holes = true; if (!st->emitting) st->compact(); }
+};
+
 // ---- access, property_ptr, ParticleData ---------------------------------------------------------------------------------
-namespace access {
-enum location { cpu, gpu, managed, nodevice };
-enum mode { read, write, readwrite, nomode };
-}  // namespace access
+struct access {  // a struct, as in the reference (ParticleData/Property.cuh:30-39): `using uammd::access;` works
+  enum location { cpu, gpu, managed, nodevice };
+  enum mode { read, write, readwrite, nomode };
+};
 
 template <class T> class Property;
 // RAII handle on a property (Property.cuh:49-147): releases the lock (and uploads host writes) when destroyed
@@ -382,7 +576,19 @@ class ParticleData {
   Property<real3> vel{"vel"};
   Property<real> energy{"energy"}, virial{"virial"}, mass{"mass"}, radius{"radius"}, charge{"charge"};
   Property<int> id{"id"};
-  std::vector<std::function<void()>> posWriteCallbacks, reorderCallbacks;
+  // one write-requested signal per property + reorder + number-of-particles (ParticleData.cuh:182-194): modules hold the connections
+  using VoidSignal = signal<void(void)>;
+  shared_ptr<VoidSignal> reorderSignal = make_shared<VoidSignal>();
+  shared_ptr<signal<void(int)>> numParticlesChangedSignal = make_shared<signal<void(int)>>();
+  shared_ptr<VoidSignal> posWriteRequestedSignal = make_shared<VoidSignal>(), forceWriteRequestedSignal = make_shared<VoidSignal>(),
+                         torqueWriteRequestedSignal = make_shared<VoidSignal>(), dirWriteRequestedSignal = make_shared<VoidSignal>(),
+                         velWriteRequestedSignal = make_shared<VoidSignal>(), energyWriteRequestedSignal = make_shared<VoidSignal>(),
+                         virialWriteRequestedSignal = make_shared<VoidSignal>(), massWriteRequestedSignal = make_shared<VoidSignal>(),
+                         radiusWriteRequestedSignal = make_shared<VoidSignal>(), chargeWriteRequestedSignal = make_shared<VoidSignal>(),
+                         idWriteRequestedSignal = make_shared<VoidSignal>();
+  static void announce(const shared_ptr<VoidSignal> &sig, access::mode m) {  // ParticleData.cuh:232-239
+    if (m == access::write || m == access::readwrite) (*sig)();
+  }
   struct Hints { Box hash_box = Box(real(128)); real3 hash_cutOff = make_real3(10.0); } hints;  // ParticleData.cuh:164-169
   template <class T> property_ptr<T> get(Property<T> &p, access::location l, access::mode m) { return p.data(l, m); }
 public:
@@ -398,15 +604,13 @@ public:
   ParticleData &operator=(const ParticleData &) = delete;
   shared_ptr<System> getSystem() { return sys; }
   int getNumParticles() const { return numberParticles; }
-  property_ptr<real4> getPos(access::location l, access::mode m) {
-    if (m != access::read) for (auto &cb : posWriteCallbacks) cb();  // getPosWriteRequestedSignal, ParticleData.cuh:182-194
-    return pos.data(l, m);
-  }
-  property_ptr<real4> getForce(access::location l, access::mode m) { return force.data(l, m); }
-  property_ptr<real3> getVel(access::location l, access::mode m) { return vel.data(l, m); }
+  property_ptr<real4> getPos(access::location l, access::mode m) { announce(posWriteRequestedSignal, m); return pos.data(l, m); }
+  property_ptr<real4> getForce(access::location l, access::mode m) { announce(forceWriteRequestedSignal, m); return force.data(l, m); }
+  property_ptr<real3> getVel(access::location l, access::mode m) { announce(velWriteRequestedSignal, m); return vel.data(l, m); }
   // torques (real4) and orientation quaternions (n, vx, vy, vz) are allocated on first request, as every UAMMD property
   property_ptr<real4> getTorque(access::location l, access::mode m) {
     if (!torque.isAllocated()) torque.resize(numberParticles);
+    announce(torqueWriteRequestedSignal, m);
     return torque.data(l, m);
   }
   property_ptr<real4> getDir(access::location l, access::mode m) {
@@ -415,22 +619,25 @@ public:
       auto d = dir.data(access::cpu, access::write);
       for (int i = 0; i < numberParticles; ++i) d[i] = make_real4(1, 0, 0, 0);
     }
+    announce(dirWriteRequestedSignal, m);
     return dir.data(l, m);
   }
-  property_ptr<real4> getTorqueIfAllocated(access::location l, access::mode m) { return torque.isAllocated() ? torque.data(l, m) : property_ptr<real4>(); }
-  property_ptr<real4> getDirIfAllocated(access::location l, access::mode m) { return dir.isAllocated() ? dir.data(l, m) : property_ptr<real4>(); }
+  property_ptr<real4> getTorqueIfAllocated(access::location l, access::mode m) { return torque.isAllocated() ? getTorque(l, m) : property_ptr<real4>(); }
+  property_ptr<real4> getDirIfAllocated(access::location l, access::mode m) { return dir.isAllocated() ? getDir(l, m) : property_ptr<real4>(); }
   bool isTorqueAllocated() const { return torque.isAllocated(); }
   bool isDirAllocated() const { return dir.isAllocated(); }
-  property_ptr<real> getEnergy(access::location l, access::mode m) { return energy.data(l, m); }
-  property_ptr<real> getVirial(access::location l, access::mode m) { return virial.data(l, m); }
-  property_ptr<real> getMass(access::location l, access::mode m) { return mass.data(l, m); }
-  property_ptr<real> getRadius(access::location l, access::mode m) { return radius.data(l, m); }
+  property_ptr<real> getEnergy(access::location l, access::mode m) { announce(energyWriteRequestedSignal, m); return energy.data(l, m); }
+  property_ptr<real> getVirial(access::location l, access::mode m) { announce(virialWriteRequestedSignal, m); return virial.data(l, m); }
+  property_ptr<real> getMass(access::location l, access::mode m) { announce(massWriteRequestedSignal, m); return mass.data(l, m); }
+  property_ptr<real> getRadius(access::location l, access::mode m) { announce(radiusWriteRequestedSignal, m); return radius.data(l, m); }
   property_ptr<real> getCharge(access::location l, access::mode m) {
     if (!charge.isAllocated()) charge.resize(numberParticles);
+    announce(chargeWriteRequestedSignal, m);
     return charge.data(l, m);
   }
   property_ptr<int> getId(access::location l, access::mode m) {
     if (m != access::read) idOrderValid = false;
+    announce(idWriteRequestedSignal, m);
     return id.data(l, m);
   }
   // ParticleData::getIdOrderedIndices (ParticleData.cuh:298-323): the particle with id i sits at row getIdOrderedIndices()[i]; valid
@@ -449,21 +656,34 @@ public:
     }
     return dev == access::gpu ? id2indexDevice.d : id2indexHost.data();
   }
-  property_ptr<real4> getPosIfAllocated(access::location l, access::mode m) { return pos.isAllocated() ? pos.data(l, m) : property_ptr<real4>(); }
-  property_ptr<real4> getForceIfAllocated(access::location l, access::mode m) { return force.isAllocated() ? force.data(l, m) : property_ptr<real4>(); }
-  property_ptr<real3> getVelIfAllocated(access::location l, access::mode m) { return vel.isAllocated() ? vel.data(l, m) : property_ptr<real3>(); }
-  property_ptr<real> getEnergyIfAllocated(access::location l, access::mode m) { return energy.isAllocated() ? energy.data(l, m) : property_ptr<real>(); }
-  property_ptr<real> getVirialIfAllocated(access::location l, access::mode m) { return virial.isAllocated() ? virial.data(l, m) : property_ptr<real>(); }
-  property_ptr<real> getChargeIfAllocated(access::location l, access::mode m) { return charge.isAllocated() ? charge.data(l, m) : property_ptr<real>(); }
-  property_ptr<real> getMassIfAllocated(access::location l, access::mode m) { return mass.isAllocated() ? mass.data(l, m) : property_ptr<real>(); }
-  property_ptr<real> getRadiusIfAllocated(access::location l, access::mode m) { return radius.isAllocated() ? radius.data(l, m) : property_ptr<real>(); }
+  // get<Name>IfAllocated (ParticleData.cuh:247-259): the getter (signal included) when the property exists, an empty handle otherwise
+  property_ptr<real4> getPosIfAllocated(access::location l, access::mode m) { return pos.isAllocated() ? getPos(l, m) : property_ptr<real4>(); }
+  property_ptr<real4> getForceIfAllocated(access::location l, access::mode m) { return force.isAllocated() ? getForce(l, m) : property_ptr<real4>(); }
+  property_ptr<real3> getVelIfAllocated(access::location l, access::mode m) { return vel.isAllocated() ? getVel(l, m) : property_ptr<real3>(); }
+  property_ptr<real> getEnergyIfAllocated(access::location l, access::mode m) { return energy.isAllocated() ? getEnergy(l, m) : property_ptr<real>(); }
+  property_ptr<real> getVirialIfAllocated(access::location l, access::mode m) { return virial.isAllocated() ? getVirial(l, m) : property_ptr<real>(); }
+  property_ptr<real> getChargeIfAllocated(access::location l, access::mode m) { return charge.isAllocated() ? getCharge(l, m) : property_ptr<real>(); }
+  property_ptr<real> getMassIfAllocated(access::location l, access::mode m) { return mass.isAllocated() ? getMass(l, m) : property_ptr<real>(); }
+  property_ptr<real> getRadiusIfAllocated(access::location l, access::mode m) { return radius.isAllocated() ? getRadius(l, m) : property_ptr<real>(); }
   bool isPosAllocated() const { return pos.isAllocated(); }
   bool isVelAllocated() const { return vel.isAllocated(); }
   bool isForceAllocated() const { return force.isAllocated(); }
   bool isMassAllocated() const { return mass.isAllocated(); }
   bool isRadiusAllocated() const { return radius.isAllocated(); }
-  void connectPosWriteRequested(std::function<void()> cb) { posWriteCallbacks.push_back(std::move(cb)); }
-  void connectReorder(std::function<void()> cb) { reorderCallbacks.push_back(std::move(cb)); }
+  // ParticleData.cuh:364-381: the signals themselves; `auto c = pd->getReorderSignal()->connect(slot); ... c.disconnect();`
+  shared_ptr<signal<void(void)>> getReorderSignal() { return reorderSignal; }
+  shared_ptr<signal<void(int)>> getNumParticlesChangedSignal() { return numParticlesChangedSignal; }
+  shared_ptr<signal<void(void)>> getPosWriteRequestedSignal() { return posWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getForceWriteRequestedSignal() { return forceWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getTorqueWriteRequestedSignal() { return torqueWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getDirWriteRequestedSignal() { return dirWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getVelWriteRequestedSignal() { return velWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getEnergyWriteRequestedSignal() { return energyWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getVirialWriteRequestedSignal() { return virialWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getMassWriteRequestedSignal() { return massWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getRadiusWriteRequestedSignal() { return radiusWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getChargeWriteRequestedSignal() { return chargeWriteRequestedSignal; }
+  shared_ptr<signal<void(void)>> getIdWriteRequestedSignal() { return idWriteRequestedSignal; }
   void hintSortByHash(Box hash_box, real3 hash_cutOff) { hints.hash_box = hash_box; hints.hash_cutOff = hash_cutOff; }
   // ParticleData::sortParticles (ParticleData.cuh:492-522): Morton order on the hint grid, every allocated property
   void sortParticles(hipStream_t st = 0) {
@@ -486,8 +706,8 @@ public:
     reorder(radius, d.d_groupIndex, st); reorder(charge, d.d_groupIndex, st); reorder(id, d.d_groupIndex, st);
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     idOrderValid = false;
-    for (auto &cb : posWriteCallbacks) cb();
-    for (auto &cb : reorderCallbacks) cb();
+    (*reorderSignal)();  // emitReorder, ParticleData.cu:519 (the positions moved in memory: every listener of this header's modules that
+                         // caches something per row listens to this signal as well as to the position writes)
   }
 private:
   uammd_celllist *sorter = nullptr;
@@ -619,7 +839,8 @@ class ParticleGroup {
     if (!h_index.empty()) detail::hipCheck(hipMemcpy(d_index.d, h_index.data(), sizeof(int) * h_index.size(), hipMemcpyHostToDevice), "hipMemcpy");
     needsIndexUpdate = false;
   }
-  void init() { pd->connectReorder([this]() { needsIndexUpdate = true; }); }
+  scoped_connection reorderConnection;  // ParticleGroup.cuh:188,212: dropped with the group
+  void init() { reorderConnection = pd->getReorderSignal()->connect([this]() { needsIndexUpdate = true; }); }
 public:
   // index[i] of member i; the "All" group is the identity and raw() is null, which is what the C ABI takes for "all particles"
   struct IndexIterator {
@@ -668,6 +889,25 @@ public:
     return PropertyIterator<T>{prop.raw(), getIndexIterator(prop.location())};
   }
 };
+
+namespace detail {
+// property rows of the members of a group as one contiguous device array, in the group's order (what pg->getPropertyIterator(prop) is to
+// a kernel of the reference): the property's own array for the group of all particles (pg == nullptr or pg->isAll()), a gathered copy in
+// `buf` otherwise.  The modules below run their solvers on these arrays and scatter through the group's index in their update kernels.
+template <class T> inline const T *groupRows(const T *all, ParticleGroup *pg, DeviceArray<T> &buf, hipStream_t st) {
+  if (!all || !pg || pg->isAll()) return all;
+  const int n = pg->getNumberParticles();
+  if (buf.size() != (size_t)n) buf.resize(n);
+  check(uammd_gather(all, pg->getIndicesRawPtr(access::gpu), buf.d, n, (int)sizeof(T), (void *)st));
+  return buf.d;
+}
+// ... and the way back for the rows a module changed in place: all[index[i]] = rows[i] (nothing to do when rows IS the property)
+template <class T> inline void scatterRows(const T *rows, T *all, ParticleGroup *pg, hipStream_t st) {
+  if (!rows || rows == all || !pg || pg->isAll()) return;
+  check(uammd_scatter(rows, pg->getIndicesRawPtr(access::gpu), all, pg->getNumberParticles(), (int)sizeof(T), (void *)st));
+}
+inline shared_ptr<ParticleGroup> subsetOrNull(const shared_ptr<ParticleGroup> &pg) { return (pg && !pg->isAll()) ? pg : nullptr; }
+}  // namespace detail
 
 // ---- misc/ParameterUpdatable.h:72-80, Interactor, Integrator ------------------------------------------------------------------
 class ParameterUpdatable {
@@ -719,10 +959,144 @@ public:
   virtual ~Integrator() = default;
   virtual void forwardTime() = 0;
   virtual real sumEnergy() { return 0; }
+protected:
+  // the particles this integrator moves: the members of its group (all of them without one)
+  int groupSize() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
+  const int *groupIndex() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
+  void resetGroupForces(hipStream_t st) {  // thrust::fill(forceGroup, forceGroup + N, real4()) of the reference's integrators
+    auto force = pd->getForce(access::gpu, access::write);
+    if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
+    else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
+  }
+public:
   void addInteractor(shared_ptr<Interactor> an_interactor) { interactors.push_back(an_interactor); addUpdatable(an_interactor); }
   std::vector<shared_ptr<Interactor>> getInteractors() { return interactors; }
   void addUpdatable(shared_ptr<ParameterUpdatable> u) { updatables.push_back(u); }
 };
+
+// ---- library mode: CellListBase / BasicNeighbourListBase (no ParticleData) ---------------------------------------------------------
+// Interactor/NeighbourList/CellList/CellListBase.cuh:97-172 and BasicList/BasicListBase.cuh:76-215, as
+// examples/uammd_as_a_library/neighbour_list.cu:159-167 uses them: positions from any iterator, a Grid (or a Box and a cut-off), a stream.
+namespace detail {
+// the positions as one real4 array on the device: a raw device pointer goes through untouched; any other iterator (thrust device
+// iterators, transform / permutation iterators over real3 or real4) is evaluated into `staged` — that needs device code: hipcc only
+inline const real4 *stagePositions(const real4 *pos, int, DeviceArray<real4> &, hipStream_t) { return pos; }
+inline const real4 *stagePositions(real4 *pos, int, DeviceArray<real4> &, hipStream_t) { return pos; }
+#if defined(__HIPCC__)
+struct ToReal4 {  // CellListBase.cuh:60-66
+  template <class V> __host__ __device__ real4 operator()(const V &v) const { return make_real4(v); }
+};
+template <class PositionIterator>
+inline const real4 *stagePositions(PositionIterator pos, int n, DeviceArray<real4> &staged, hipStream_t st) {
+  if (staged.size() != (size_t)n) staged.resize(n);
+  thrust::transform(thrust::hip::par.on(st), pos, pos + n, staged.d, ToReal4());
+  return staged.d;
+}
+#else
+template <class PositionIterator>
+inline const real4 *stagePositions(PositionIterator, int, DeviceArray<real4> &, hipStream_t) {
+  static_assert(sizeof(PositionIterator) == 0, "a position iterator other than a real4 device pointer needs device code: compile this TU with hipcc");
+  return nullptr;
+}
+#endif
+}  // namespace detail
+
+class CellListBase {
+protected:
+  uammd_celllist *h = nullptr;
+  detail::DeviceArray<real4> staged;
+  Grid grid;
+public:
+  CellListBase() { detail::check(uammd_celllist_create(&h)); }
+  CellListBase(const CellListBase &) = delete;
+  CellListBase &operator=(const CellListBase &) = delete;
+  ~CellListBase() { uammd_celllist_destroy(h); }
+  // CellListBase.cuh:124-141.  The grid is the caller's: no createUpdateGrid here (that is CellList's, CellList.cuh:100-126)
+  template <class PositionIterator> void update(PositionIterator pos, int numberParticles, Grid in_grid, hipStream_t st = 0) {
+    grid = in_grid;
+    float L[3]; int per[3];
+    grid.box.toArrays(L, per);
+    const int cd[3] = {grid.cellDim.x, grid.cellDim.y, grid.cellDim.z};
+    const real4 *p = detail::stagePositions(pos, numberParticles, staged, st);
+    detail::check(uammd_celllist_update(h, (const float *)p, numberParticles, L, per, cd, (void *)st));
+  }
+  // CellListBase.cuh:145-172: the reference's field names, on top of the C ABI's POD (what the device-side NeighbourContainer takes)
+  struct CellListData : uammd_celllist_data {
+    const uint *cellStart = nullptr;
+    const int *cellEnd = nullptr;
+    const real4 *sortPos = nullptr;
+    const int *groupIndex = nullptr;
+    Grid grid;
+    CellListData() : uammd_celllist_data() {}
+    explicit CellListData(const uammd_celllist_data &d)
+        : uammd_celllist_data(d), cellStart(d.d_cellStart), cellEnd(d.d_cellEnd), sortPos((const real4 *)d.d_sortPos), groupIndex(d.d_groupIndex) {
+      Box b(make_real3(d.boxSize[0], d.boxSize[1], d.boxSize[2]));
+      b.setPeriodicity(d.periodic[0], d.periodic[1], d.periodic[2]);
+      grid = Grid(b, make_int3(d.cellDim[0], d.cellDim[1], d.cellDim[2]));
+    }
+  };
+  CellListData getCellList() {
+    uammd_celllist_data d;
+    detail::check(uammd_celllist_get(h, &d));
+    return CellListData(d);
+  }
+  uammd_celllist *handle() { return h; }
+};
+
+class BasicNeighbourListBase {
+protected:
+  uammd_verletlist *h = nullptr;
+  detail::DeviceArray<real4> staged;
+  real currentCutOff = 0;
+  Box currentBox;
+public:
+  // the list of a BasicNeighbourListBase holds exactly the pairs within the cut-off at the time of update (no skin) and is refilled by
+  // every update: the Verlet list of the C ABI with a cut-off multiplier of one, forced
+  BasicNeighbourListBase() {
+    detail::check(uammd_verletlist_create(&h));
+    detail::check(uammd_verletlist_set_cutoff_multiplier(h, real(1.0)));
+  }
+  BasicNeighbourListBase(const BasicNeighbourListBase &) = delete;
+  BasicNeighbourListBase &operator=(const BasicNeighbourListBase &) = delete;
+  ~BasicNeighbourListBase() { uammd_verletlist_destroy(h); }
+  template <class PositionIterator> void update(PositionIterator pos, int numberParticles, Box box, real cutOff, hipStream_t st = 0) {  // :131-141
+    currentBox = box;
+    currentCutOff = cutOff;
+    float L[3]; int per[3];
+    box.toArrays(L, per);
+    const real4 *p = detail::stagePositions(pos, numberParticles, staged, st);
+    detail::check(uammd_verletlist_force_next_update(h));
+    detail::check(uammd_verletlist_update(h, (const float *)p, numberParticles, L, per, cutOff, (void *)st, nullptr));
+  }
+  // particleStride[i] is the distance between consecutive neighbours of particle i in neighbourList (BasicListBase.cuh:90-103: a
+  // constant, the number of particles): neighbour k of sorted particle i is neighbourList[particleStride[i] * k + i]
+  struct StrideIterator {
+    int stride = 0;
+    UAMMD_HOSTDEV int operator[](int) const { return stride; }
+    UAMMD_HOSTDEV int operator*() const { return stride; }
+  };
+  struct BasicNeighbourListData : uammd_verletlist_data {  // :144-152
+    const int *neighbourList = nullptr;
+    const int *numberNeighbours = nullptr;
+    const real4 *sortPos = nullptr;
+    const int *groupIndex = nullptr;
+    StrideIterator particleStride;
+    BasicNeighbourListData() : uammd_verletlist_data() {}
+    explicit BasicNeighbourListData(const uammd_verletlist_data &d)
+        : uammd_verletlist_data(d), neighbourList(d.d_neighbourList), numberNeighbours(d.d_numberNeighbours), sortPos((const real4 *)d.d_sortPos),
+          groupIndex(d.d_groupIndex) { particleStride.stride = d.particleStride; }
+  };
+  BasicNeighbourListData getBasicNeighbourList(hipStream_t = 0) {
+    uammd_verletlist_data d;
+    detail::check(uammd_verletlist_get(h, &d));
+    return BasicNeighbourListData(d);
+  }
+  uammd_verletlist *handle() { return h; }
+};
+#if defined(__HIPCC__)
+namespace CellList_ns { using NeighbourContainer = device::NeighbourContainer; }                  // CellList/NeighbourContainer.cuh:54
+namespace BasicNeighbourList_ns { using NeighbourContainer = device::VerletNeighbourContainer; }  // BasicList/NeighbourContainer.cuh:42
+#endif
 
 // ---- CellList ----------------------------------------------------------------------------------------------------------------
 class CellList {
@@ -733,19 +1107,25 @@ class CellList {
   bool force_next_update = true;
   real3 currentCutOff{0, 0, 0};
   Box currentBox;
+  scoped_connection posWriteConnection, reorderConnection;
 public:
-  using CellListData = uammd_celllist_data;
+  using CellListData = CellListBase::CellListData;
   explicit CellList(shared_ptr<ParticleData> pd) : pd(pd) {
     detail::check(uammd_celllist_create(&h));
-    pd->connectPosWriteRequested([this]() { force_next_update = true; });  // CellList.cuh:94-98
+    // CellList.cuh:88,133-143: the connection is a member and is dropped in the destructor, so a list may die before its ParticleData
+    posWriteConnection = pd->getPosWriteRequestedSignal()->connect([this]() { force_next_update = true; });  // CellList.cuh:94-98
+    reorderConnection = pd->getReorderSignal()->connect([this]() { force_next_update = true; });
   }
   explicit CellList(shared_ptr<ParticleGroup> group) : CellList(group->getParticleData()) {
     if (!group->isAll()) pg = group;
-    pd->connectReorder([this]() { force_next_update = true; });
   }
   const int *groupIndex() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
   CellList(const CellList &) = delete;
-  ~CellList() { uammd_celllist_destroy(h); }
+  ~CellList() {
+    posWriteConnection.disconnect();
+    reorderConnection.disconnect();
+    uammd_celllist_destroy(h);
+  }
   void update(Box box, real cutOff, hipStream_t st = 0) { update(box, make_real3(cutOff), st); }
   void update(Box box, real3 cutOff, hipStream_t st = 0) {
     const bool rebuild = force_next_update || cutOff.x != currentCutOff.x || cutOff.y != currentCutOff.y ||
@@ -768,7 +1148,11 @@ public:
     }
     force_next_update = false;
   }
-  CellListData getCellList() { CellListData d; detail::check(uammd_celllist_get(h, &d)); return d; }
+  CellListData getCellList() { uammd_celllist_data d; detail::check(uammd_celllist_get(h, &d)); return CellListData(d); }
+#if defined(__HIPCC__)
+  // CellList.cuh:186-189: a forward iterator over the neighbours of a particle for the caller's own kernels (hipcc TUs)
+  CellList_ns::NeighbourContainer getNeighbourContainer() { return CellList_ns::NeighbourContainer(getCellList()); }
+#endif
   uammd_celllist *handle() { return h; }
   bool isAllParticles() const { return !pg; }
   // the fused MD step built the list as update(box, cutOff) would have: the lazy-update bookkeeping follows
@@ -778,19 +1162,29 @@ public:
 // ---- VerletList (Interactor/NeighbourList/VerletList.cuh:83-201) ------------------------------------------------------------------
 class VerletList {
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;          // nullptr = all the particles
+  detail::DeviceArray<real4> groupPos;   // pg->getPropertyIterator(pos): the members' positions, gathered
   uammd_verletlist *h = nullptr;
   bool forceNextUpdate = true;
   Box currentBox;
   real currentCutOff = 0;
+  scoped_connection posWriteConnection, reorderConnection;  // :88
 public:
-  using VerletListData = uammd_verletlist_data;
+  using VerletListData = BasicNeighbourListBase::BasicNeighbourListData;  // VerletListBase.cuh:176-186
+  explicit VerletList(shared_ptr<ParticleGroup> group) : VerletList(group->getParticleData()) {  // :96-103
+    if (!group->isAll()) pg = group;
+  }
   explicit VerletList(shared_ptr<ParticleData> pd) : pd(pd) {
     detail::check(uammd_verletlist_create(&h));
-    pd->connectPosWriteRequested([this]() { forceNextUpdate = true; });                                         // :171-175
-    pd->connectReorder([this]() { forceNextUpdate = true; uammd_verletlist_force_next_update(h); });            // :177-182
+    posWriteConnection = pd->getPosWriteRequestedSignal()->connect([this]() { forceNextUpdate = true; });       // :99-100, :171-175
+    reorderConnection = pd->getReorderSignal()->connect([this]() { forceNextUpdate = true; uammd_verletlist_force_next_update(h); });  // :101-102, :177-182
   }
   VerletList(const VerletList &) = delete;
-  ~VerletList() { uammd_verletlist_destroy(h); }
+  ~VerletList() {  // :106-110
+    posWriteConnection.disconnect();
+    reorderConnection.disconnect();
+    uammd_verletlist_destroy(h);
+  }
   void update(Box box, real cutOff, hipStream_t st = 0) {  // :112-124
     const bool rebuild = forceNextUpdate || box != currentBox || cutOff != currentCutOff;
     forceNextUpdate = false;
@@ -802,16 +1196,24 @@ public:
     box.toArrays(L, per);
     // VerletList reads the positions with access::read: that does not raise the pos-write signal (Property access only)
     auto pos = pd->getPos(access::gpu, access::read);
-    detail::check(uammd_verletlist_update(h, (const float *)pos.raw(), pd->getNumParticles(), L, per, cutOff, (void *)st, nullptr));
+    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    detail::check(uammd_verletlist_update(h, (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), groupPos, st), N, L, per, cutOff,
+                                          (void *)st, nullptr));
   }
   void update(Box box, real3 cutOff, hipStream_t st = 0) {  // :130-136
     if (cutOff.x != cutOff.y || cutOff.x != cutOff.z) throw std::runtime_error("[VerletList] Invalid argument");
     update(box, cutOff.x, st);
   }
-  VerletListData getVerletList() { VerletListData d; detail::check(uammd_verletlist_get(h, &d)); return d; }
+  VerletListData getVerletList() { uammd_verletlist_data d; detail::check(uammd_verletlist_get(h, &d)); return VerletListData(d); }
+#if defined(__HIPCC__)
+  // VerletList.cuh:160-164
+  BasicNeighbourList_ns::NeighbourContainer getNeighbourContainer() { return BasicNeighbourList_ns::NeighbourContainer(getVerletList()); }
+#endif
   void setCutOffMultiplier(real newMultiplier) { forceNextUpdate = true; detail::check(uammd_verletlist_set_cutoff_multiplier(h, newMultiplier)); }
   int getNumberOfStepsSinceLastUpdate() { int s = 0; detail::check(uammd_verletlist_get_steps_since_last_update(h, &s)); return s; }
   uammd_verletlist *handle() { return h; }
+  bool isAllParticles() const { return !pg; }
+  const int *groupIndex() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
 };
 
 // ---- Potential::LJ ---------------------------------------------------------------------------------------------------------------
@@ -846,6 +1248,7 @@ public:
     if (dirty) {
       d_table.resize(table.size());
       detail::hipCheck(hipMemcpy(d_table.d, table.data(), sizeof(table[0]) * table.size(), hipMemcpyHostToDevice), "hipMemcpy");
+      detail::check(uammd_lj_table_changed());  // (the same address may now hold other parameters: the lists read it again)
       dirty = false;
     }
     return d_table.d;
@@ -869,11 +1272,7 @@ template <class NL> class PairForces<Potential::LJ, NL> : public Interactor {
     return uammd_lj_transverse_verletlist(h, t, nt, L, per, f, e, v, globalIndex, st);
   }
   template <class List> static shared_ptr<List> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, List *) {
-    if (pg) throw std::runtime_error("PairForces on a ParticleGroup needs the CellList neighbour list in this build");
-    return make_shared<List>(pd);
-  }
-  static shared_ptr<CellList> makeList(shared_ptr<ParticleData> pd, shared_ptr<ParticleGroup> pg, CellList *) {
-    return pg ? make_shared<CellList>(pg) : make_shared<CellList>(pd);
+    return pg ? make_shared<List>(pg) : make_shared<List>(pd);  // both lists take a group (CellList.cuh:132, VerletList.cuh:96)
   }
 public:
   struct Parameters { Box box; shared_ptr<NL> nl = nullptr; };
@@ -1046,19 +1445,17 @@ private:
   int steps = 0;
   hipStream_t st = 0;
 public:
-  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : Integrator(pd, "BD::EulerMaruyama"), par(par) {
+  EulerMaruyama(shared_ptr<ParticleGroup> pg, Parameters par) : Integrator(pg, "BD::EulerMaruyama"), par(par) {  // BrownianDynamics.cuh:113-121
     seed = sys->rng().next32();
     selfMobility = 1.0 / (6.0 * M_PI * par.viscosity);  // BrownianDynamics.cu:12-23
     if (par.hydrodynamicRadius != real(-1.0)) selfMobility /= par.hydrodynamicRadius;
   }
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}
   void forwardTime() override {  // BrownianDynamics.cu:146-170
     steps++;
     for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
     if (steps == 1) for (auto &u : updatables) { u->updateTemperature(par.temperature); u->updateTimeStep(par.dt); }
-    {
-      auto force = pd->getForce(access::gpu, access::write);
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
-    }
+    resetGroupForces(st);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
     float K[9] = {0};
     const bool shear = par.K.size() == 3;
@@ -1066,8 +1463,8 @@ public:
     auto radius = (par.hydrodynamicRadius == real(-1.0)) ? pd->getRadiusIfAllocated(access::gpu, access::read) : property_ptr<real>();
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto force = pd->getForce(access::gpu, access::read);
-    detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), nullptr, (const float *)force.raw(), shear ? K : nullptr, selfMobility,
-                                          radius.raw(), par.dt, par.is2D, par.temperature, pd->getNumParticles(), (uint)steps, seed,
+    detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)force.raw(), shear ? K : nullptr, selfMobility,
+                                          radius.raw(), par.dt, par.is2D, par.temperature, groupSize(), (uint)steps, seed,
                                           (void *)st));
   }
 };
@@ -1324,18 +1721,24 @@ inline BDHI::Parameters initialize(BDHI::Parameters par, System &sys) {  // BDHI
 }  // namespace detail_fcm
 class FCM {  // the Method concept of BDHI::EulerMaruyama (BDHI_FCM.cuh:84-147)
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
   shared_ptr<FCM_impl<>> fcm;
   real temperature, dt;
+  detail::DeviceArray<real4> posRows, forceRows;
 public:
   using Parameters = BDHI::Parameters;
-  FCM(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), temperature(par.temperature), dt(par.dt) {
+  FCM(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_FCM.cuh:98-110
+      : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), temperature(par.temperature), dt(par.dt) {
     fcm = make_shared<FCM_impl<>>(detail_fcm::initialize(par, *pd->getSystem()));
   }
+  FCM(shared_ptr<ParticleData> pd, Parameters par) : FCM(make_shared<ParticleGroup>(pd, "All"), par) {}
   void setup_step(hipStream_t = 0) {}
   void computeMF(real3 *MF, hipStream_t st = 0) {
     auto force = pd->getForce(access::gpu, access::read);
     auto pos = pd->getPos(access::gpu, access::read);
-    fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), MF, pd->getNumParticles(), temperature, 1.0 / std::sqrt(dt), st);
+    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    fcm->computeHydrodynamicDisplacements(detail::groupRows(pos.raw(), pg.get(), posRows, st), detail::groupRows(force.raw(), pg.get(), forceRows, st),
+                                          MF, N, temperature, 1.0 / std::sqrt(dt), st);
   }
   void computeBdW(real3 *, hipStream_t = 0) {}
   void finish_step(hipStream_t = 0) {}
@@ -1351,31 +1754,32 @@ template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : publi
   uint steps = 0;
   hipStream_t st = 0;
   bool posTouched = true;
+  scoped_connection posWriteConnection, reorderConnection;  // dropped with the integrator
+  detail::DeviceArray<real4> posRows, forceRows, torqueRows;  // the rows of a proper subgroup, gathered
 public:
   using Parameters = BDHI::Parameters;
-  FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "BDHI::FCMIntegrator"), linearV(pd->getNumParticles()), angularV(pd->getNumParticles()),
+  FCMIntegratorT(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_FCM.cuh:167-174
+      : Integrator(group, "BDHI::FCMIntegrator"), linearV(group->getNumberParticles()), angularV(group->getNumberParticles()),
         temperature(par.temperature), dt(par.dt) {
     fcm = make_shared<FCM_impl<Kernel>>(detail_fcm::initialize<Kernel>(par, *sys));
-    pd->connectPosWriteRequested([this]() { posTouched = true; });
-    pd->connectReorder([this]() { posTouched = true; });
+    posWriteConnection = pd->getPosWriteRequestedSignal()->connect([this]() { posTouched = true; });
+    reorderConnection = pd->getReorderSignal()->connect([this]() { posTouched = true; });
   }
+  FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par) : FCMIntegratorT(make_shared<ParticleGroup>(pd, "All"), par) {}
   shared_ptr<FCM_impl<Kernel>> getFCM_impl() { return fcm; }
   void forwardTime() override {
     steps++;
     for (auto &u : updatables) u->updateSimulationTime(steps * dt);
     if (steps == 1) for (auto &u : updatables) { u->updateTimeStep(dt); u->updateTemperature(temperature); u->updateBox(fcm->getBox()); }
-    {
-      auto force = pd->getForce(access::gpu, access::write);
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
-    }
+    resetGroupForces(st);
     if (pd->isDirAllocated()) {  // computeCurrentForces, BDHI_FCM.cu:50-57
       auto torque = pd->getTorque(access::gpu, access::write);
-      detail::check(uammd_fill_zero(torque.raw(), sizeof(real4) * torque.size(), (void *)st));
+      if (pg) detail::check(uammd_fill_zero_indexed(torque.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
+      else detail::check(uammd_fill_zero(torque.raw(), sizeof(real4) * torque.size(), (void *)st));
     }
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
-    const int N = pd->getNumParticles();
-    if (!pd->isDirAllocated() && !pd->isTorqueAllocated()) {  // no rotation: the update rides in the solver's interpolation kernel
+    const int N = groupSize();
+    if (!pg && !pd->isDirAllocated() && !pd->isTorqueAllocated()) {  // no rotation: the update rides in the solver's interpolation kernel
       const bool kept = !posTouched;  // (getPosWriteRequestedSignal: somebody may have moved the particles since our last step)
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::read);
@@ -1387,12 +1791,13 @@ public:
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
       auto torque = pd->getTorqueIfAllocated(access::gpu, access::read);
-      fcm->computeHydrodynamicDisplacements(pos.raw(), force.raw(), torque.raw(), linearV.d, angularV.d, N, temperature,
+      fcm->computeHydrodynamicDisplacements(detail::groupRows(pos.raw(), pg.get(), posRows, st), detail::groupRows(force.raw(), pg.get(), forceRows, st),
+                                            detail::groupRows(torque.raw(), pg.get(), torqueRows, st), linearV.d, angularV.d, N, temperature,
                                             1.0 / std::sqrt(dt), st);
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto dir = pd->getDirIfAllocated(access::gpu, access::readwrite);
-    detail::check(uammd_fcm_euler_maruyama_dir((float *)pos.raw(), (float *)dir.raw(), nullptr, (const float *)linearV.d,
+    detail::check(uammd_fcm_euler_maruyama_dir((float *)pos.raw(), (float *)dir.raw(), groupIndex(), (const float *)linearV.d,
                                                dir.raw() ? (const float *)angularV.d : nullptr, N, dt, (void *)st));
   }
 };
@@ -1409,27 +1814,34 @@ struct Parameters : BDHI::Parameters {  // PSE/utils.cuh:17-24
 }  // namespace pse_ns
 class PSE {
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_PSE.cuh:171)
+  detail::DeviceArray<real4> posRows, forceRows;
+  int numberParticles() const { return pg ? pg->getNumberParticles() : numberParticles(); }
+  // the members' positions, contiguous (the property itself without a proper subgroup)
+  const float *positions(const property_ptr<real4> &pos, hipStream_t st) { return (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st); }
   uammd_pse_near *nearField = nullptr;
   uammd_fcm *farField = nullptr;
-  shared_ptr<bool> alive;  // the ParticleData callbacks outlive this object: they look at this flag first
+  scoped_connection posWriteConnection, reorderConnection;  // dropped in the destructor, before the handles they touch
   real hydrodynamicRadius, M0, temperature, dt;
   void far(const real4 *force, real3 *MF, real T, real prefactor, hipStream_t st) {
     const uint seed2 = T > 0 ? pd->getSystem()->rng().next32() : 0u;  // FarField.cuh:499
     auto pos = pd->getPos(access::gpu, access::read);
-    detail::check(uammd_pse_far_displacements(farField, (const float *)pos.raw(), (const float *)force, pd->getNumParticles(), T,
+    detail::check(uammd_pse_far_displacements(farField, positions(pos, st), (const float *)force, numberParticles(), T,
                                               prefactor, seed2, (float *)MF, (void *)st));
   }
   void nearStochastic(real3 *BdW, real T, real prefactor, hipStream_t st) {
     if (T == real(0.0)) return;
     const uint seed2 = pd->getSystem()->rng().next32();  // NearField.cuh:276
     auto pos = pd->getPos(access::gpu, access::read);
-    detail::check(uammd_pse_near_stochastic(nearField, (const float *)pos.raw(), pd->getNumParticles(), T, prefactor, seed2,
+    detail::check(uammd_pse_near_stochastic(nearField, positions(pos, st), numberParticles(), T, prefactor, seed2,
                                             (float *)BdW, (void *)st, nullptr));
   }
 public:
   using Parameters = pse_ns::Parameters;
-  PSE(shared_ptr<ParticleData> pd, Parameters par)
-      : pd(pd), hydrodynamicRadius(par.hydrodynamicRadius), temperature(par.temperature), dt(par.dt) {
+  PSE(shared_ptr<ParticleData> pd, Parameters par) : PSE(make_shared<ParticleGroup>(pd, "All"), par) {}  // BDHI_PSE.cuh:85-86
+  PSE(shared_ptr<ParticleGroup> group, Parameters par)
+      : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), hydrodynamicRadius(par.hydrodynamicRadius), temperature(par.temperature),
+        dt(par.dt) {
     M0 = (real)uammd_fcm_self_mobility(par.hydrodynamicRadius, par.viscosity, par.box.boxSize.x);
     const real3 L3 = par.box.boxSize;
     if (L3.x == real(0.0) && L3.y == real(0.0) && L3.z == real(0.0)) throw std::invalid_argument("Box of size zero detected");
@@ -1441,12 +1853,10 @@ public:
                                         &nearField, nullptr, nullptr));
     // CellList::update rebuilds only after a position write or a reorder (CellList.cuh:94-98,134-136)
     detail::check(uammd_pse_near_set_option(nearField, "lazy_list", 1));
-    alive = std::make_shared<bool>(true);
-    std::weak_ptr<bool> w = alive;
     uammd_pse_near *nf = nearField;
-    auto changed = [w, nf]() { if (!w.expired()) uammd_pse_near_positions_changed(nf); };
-    pd->connectPosWriteRequested(changed);
-    pd->connectReorder(changed);
+    auto changed = [nf]() { uammd_pse_near_positions_changed(nf); };
+    posWriteConnection = pd->getPosWriteRequestedSignal()->connect(changed);
+    reorderConnection = pd->getReorderSignal()->connect(changed);
     const uint seedFar = rng.next32();
     int c[3];
     detail::check(uammd_pse_far_raw_cells(L, par.psi, par.tolerance, c));
@@ -1455,20 +1865,26 @@ public:
                                        &farField, nullptr, nullptr));
   }
   PSE(const PSE &) = delete;
-  ~PSE() { uammd_pse_near_destroy(nearField); uammd_fcm_destroy(farField); }
+  ~PSE() {
+    posWriteConnection.disconnect();
+    reorderConnection.disconnect();
+    uammd_pse_near_destroy(nearField);
+    uammd_fcm_destroy(farField);
+  }
   void setup_step(hipStream_t = 0) {}
   void finish_step(hipStream_t = 0) {}
   void computeMF(real3 *MF, hipStream_t st = 0) {  // :92-120
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
-    auto force = pd->getForce(access::gpu, access::read);
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    const real4 *force = detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st);
     {  // (the near field's list and pair records are queued first: their one host read then happens while the far field runs)
       auto pos = pd->getPos(access::gpu, access::read);
-      detail::check(uammd_pse_near_prepare(nearField, (const float *)pos.raw(), N, (void *)st));
+      detail::check(uammd_pse_near_prepare(nearField, positions(pos, st), N, (void *)st));
     }
-    far(force.raw(), MF, temperature, real(1.0 / std::sqrt(dt)), st);
+    far(force, MF, temperature, real(1.0 / std::sqrt(dt)), st);
     auto pos = pd->getPos(access::gpu, access::read);
-    detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
+    detail::check(uammd_pse_near_mdot(nearField, positions(pos, st), (const float *)force, N, (float *)MF, (void *)st));
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
   // computeMF and computeBdW (:92-126) as EulerMaruyama runs them when T > 0, queued so that the step's one wait for the GPU — the Lanczos
@@ -1477,17 +1893,19 @@ public:
   // calls with the same arguments; the two draws of System::rng() keep the reference's order (FarField.cuh:499, then NearField.cuh:276).
   void computeMFandBdW(real3 *MF, real3 *BdW, hipStream_t st = 0) {
     if (temperature == real(0.0)) { computeMF(MF, st); return; }
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
-    auto force = pd->getForce(access::gpu, access::read);
-    auto pos = pd->getPos(access::gpu, access::read);
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    auto posAll = pd->getPos(access::gpu, access::read);
+    const float *posRowsPtr = positions(posAll, st);
+    const real4 *force = detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st);
     const uint seedFar = pd->getSystem()->rng().next32();
     const uint seedNear = pd->getSystem()->rng().next32();
-    detail::check(uammd_pse_near_prepare(nearField, (const float *)pos.raw(), N, (void *)st));
+    detail::check(uammd_pse_near_prepare(nearField, posRowsPtr, N, (void *)st));
     // the far field in two halves around the check: spreading and forward transforms while the host answers it, the rest while the host
     // reacts to its outcome
     struct Far { uammd_fcm *solver; const float *pos, *force; int N; float T, prefactor; uint seed; float *MF; };
-    Far far{farField, (const float *)pos.raw(), (const float *)force.raw(), N, (float)temperature, (float)(1.0 / std::sqrt(dt)), seedFar, (float *)MF};
+    Far far{farField, posRowsPtr, (const float *)force, N, (float)temperature, (float)(1.0 / std::sqrt(dt)), seedFar, (float *)MF};
     uammd_interleave_fn firstHalf = [](void *c, void *stream) -> int {
       const Far *f = static_cast<const Far *>(c);
       return uammd_pse_far_displacements_half(f->solver, f->pos, f->force, f->N, f->T, f->prefactor, f->seed, f->MF, 1, stream);
@@ -1498,15 +1916,15 @@ public:
     };
     detail::check(uammd_pse_near_set_interleave_early(nearField, firstHalf, &far));
     detail::check(uammd_pse_near_set_interleave(nearField, secondHalf, &far));
-    detail::check(uammd_pse_near_stochastic(nearField, (const float *)pos.raw(), N, temperature, real(1.0), seedNear, (float *)BdW, (void *)st, nullptr));
-    detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force.raw(), N, (float *)MF, (void *)st));
+    detail::check(uammd_pse_near_stochastic(nearField, posRowsPtr, N, temperature, real(1.0), seedNear, (float *)BdW, (void *)st, nullptr));
+    detail::check(uammd_pse_near_mdot(nearField, posRowsPtr, (const float *)force, N, (float *)MF, (void *)st));
   }
   void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
     {
       auto pos = pd->getPos(access::gpu, access::read);
-      detail::check(uammd_pse_near_mdot(nearField, (const float *)pos.raw(), (const float *)force, N, (float *)MF, (void *)st));
+      detail::check(uammd_pse_near_mdot(nearField, positions(pos, st), (const float *)force, N, (float *)MF, (void *)st));
     }
     nearStochastic(MF, T, noise_prefactor, st);
     far(force, MF, T, noise_prefactor, st);
@@ -1522,13 +1940,19 @@ public:
 // BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67): open boundaries, dense RPY mobility, matrix free
 class Lanczos {
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_Lanczos.cuh:51)
+  detail::DeviceArray<real4> posRows, forceRows;
+  detail::DeviceArray<real> radiusRows;
+  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
   BDHI::Parameters par;
   uammd_lanczos *solver = nullptr;
   detail::DeviceArray<real3> noise;
   Xorshift128plus gen;  // the reference uses cuRAND here (stream unpinned): Box-Muller on the System generator family instead
 public:
   using Parameters = BDHI::Parameters;
-  Lanczos(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), par(par), noise(pd->getNumParticles()) {
+  Lanczos(shared_ptr<ParticleData> pd, Parameters par) : Lanczos(make_shared<ParticleGroup>(pd, "All"), par) {}  // :28-29
+  Lanczos(shared_ptr<ParticleGroup> group, Parameters par)
+      : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), par(par), noise(group->getNumberParticles()) {
     if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
       System::log<System::CRITICAL>("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the individual particle radius.");
     detail::check(uammd_lanczos_create(&solver));
@@ -1544,12 +1968,14 @@ public:
     auto pos = pd->getPos(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::read);
     auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_rpy_nbody_mdot((const float *)pos.raw(), (const float *)force.raw(), 4, radius.raw(), par.hydrodynamicRadius,
-                                       par.viscosity, pd->getNumParticles(), (float *)MF, (void *)st));
+    detail::check(uammd_rpy_nbody_mdot((const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
+                                       (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, st), 4,
+                                       detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st), par.hydrodynamicRadius,
+                                       par.viscosity, numberParticles(), (float *)MF, (void *)st));
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) {
     if (!(par.temperature > real(0.0))) return;
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     std::vector<real3> h(N);
     for (auto &v : h) {  // standard normals, Box-Muller
       real g[4];
@@ -1563,7 +1989,8 @@ public:
     detail::hipCheck(hipMemcpy(noise.d, h.data(), sizeof(real3) * N, hipMemcpyHostToDevice), "hipMemcpy");
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_rpy_lanczos_bdw(solver, (const float *)pos.raw(), radius.raw(), par.hydrodynamicRadius, par.viscosity, N,
+    detail::check(uammd_rpy_lanczos_bdw(solver, (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
+                                        detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st), par.hydrodynamicRadius, par.viscosity, N,
                                         (const float *)noise.d, par.tolerance, (float *)BdW, (void *)st, nullptr));
   }
 };
@@ -1572,15 +1999,19 @@ public:
 // the noise (rocSOLVER potrf + rocBLAS symv / trmv behind uammd_bdhi_cholesky_*)
 class Cholesky {
   shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_Cholesky.cuh:58); the C ABI takes the group's index
+  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
+  const int *index() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
   BDHI::Parameters par;
   uammd_bdhi_cholesky *h = nullptr;
   Xorshift128plus gen;  // cuRAND in the reference (stream unpinned): Box-Muller on the System generator family instead
 public:
   using Parameters = BDHI::Parameters;
-  Cholesky(shared_ptr<ParticleData> pd, Parameters par) : pd(pd), par(par) {
+  Cholesky(shared_ptr<ParticleData> pd, Parameters par) : Cholesky(make_shared<ParticleGroup>(pd, "All"), par) {}  // :36-37
+  Cholesky(shared_ptr<ParticleGroup> group, Parameters par) : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), par(par) {
     if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
       System::log<System::CRITICAL>("[BDHI::Cholesky] You need to provide Cholesky with either an hydrodynamic radius or via the individual particle radius.");
-    detail::check(uammd_bdhi_cholesky_create(pd->getNumParticles(), par.viscosity, par.hydrodynamicRadius, &h));
+    detail::check(uammd_bdhi_cholesky_create(numberParticles(), par.viscosity, par.hydrodynamicRadius, &h));
     gen.setSeed(pd->getSystem()->rng().next());
   }
   Cholesky(const Cholesky &) = delete;
@@ -1592,16 +2023,16 @@ public:
   void setup_step(hipStream_t st = 0) {
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_bdhi_cholesky_setup_step(h, (const float *)pos.raw(), nullptr, radius.raw(), (void *)st));
+    detail::check(uammd_bdhi_cholesky_setup_step(h, (const float *)pos.raw(), index(), radius.raw(), (void *)st));
   }
   void computeMF(real3 *MF, hipStream_t st = 0) {
     auto pos = pd->getPos(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_bdhi_cholesky_mf(h, (const float *)pos.raw(), (const float *)force.raw(), nullptr, radius.raw(), (float *)MF, (void *)st));
+    detail::check(uammd_bdhi_cholesky_mf(h, (const float *)pos.raw(), (const float *)force.raw(), index(), radius.raw(), (float *)MF, (void *)st));
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) {
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     std::vector<real3> hn(N);
     for (auto &v : hn) {  // standard normals, Box-Muller
       real g[4];
@@ -1616,7 +2047,7 @@ public:
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_bdhi_cholesky_bdw(h, (const float *)pos.raw(), nullptr, radius.raw(), (float *)BdW, (void *)st));
+    detail::check(uammd_bdhi_cholesky_bdw(h, (const float *)pos.raw(), index(), radius.raw(), (float *)BdW, (void *)st));
   }
 };
 
@@ -1629,9 +2060,13 @@ template <class Method> class EulerMaruyama : public Integrator {
   hipStream_t stream = 0;
 public:
   using Parameters = Parameters_t;
-  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(pd, par)), MF(pd->getNumParticles()),
-        BdW(pd->getNumParticles() + 1) {}
+  EulerMaruyama(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_EulerMaruyama.cuh:67, .cu:30-60
+      : Integrator(group, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(group, par)), MF(group->getNumberParticles()),
+        BdW(group->getNumberParticles() + 1) {}
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}  // :69-70
+  shared_ptr<Method> getScheme() { return bdhi; }  // :81
+  real getHydrodynamicRadius() { return bdhi->getHydrodynamicRadius(); }
+  real getSelfMobility() { return bdhi->getSelfMobility(); }
   shared_ptr<Method> getMethod() { return bdhi; }
 private:
   // computeMF then computeBdW (BDHI_EulerMaruyama.cu:140-150) — or, for a method that can interleave the two (PSE: its far field behind
@@ -1649,10 +2084,7 @@ public:
     for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
     if (steps == 1)
       for (auto &u : updatables) { u->updateTimeStep(par.dt); u->updateTemperature(par.temperature); u->updateBox(par.box); u->updateViscosity(par.viscosity); }
-    {
-      auto force = pd->getForce(access::gpu, access::write);
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
-    }
+    resetGroupForces(stream);  // .cu:115-123
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
     bdhi->setup_step(stream);
     if (par.temperature > 0) mobilityAndNoise(*bdhi, 0);
@@ -1663,8 +2095,8 @@ public:
     const bool shear = par.K.size() == 3;
     if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
     auto pos = pd->getPos(access::gpu, access::readwrite);
-    detail::check(uammd_bdhi_euler_maruyama((float *)pos.raw(), nullptr, (const float *)MF.d, par.temperature > 0 ? (const float *)BdW.d : nullptr,
-                                            shear ? K : nullptr, pd->getNumParticles(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
+    detail::check(uammd_bdhi_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)MF.d, par.temperature > 0 ? (const float *)BdW.d : nullptr,
+                                            shear ? K : nullptr, groupSize(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
   }
 };
 }  // namespace BDHI
@@ -1684,12 +2116,14 @@ template <class HydroKernel> class BDHI2D : public Integrator {
   int step = 0;
   int cellsOut[2] = {0, 0}, support = 0;
   hipStream_t st = 0;
+  detail::DeviceArray<real4> posRows, forceRows;
 public:
   struct Parameters : BDHI::Parameters {
     int2 cells = make_int2(-1, -1);
   };
-  BDHI2D(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "BDHI::BDHI2D"), particleVels(pd->getNumParticles()), box(make_real3(par.box.boxSize.x, par.box.boxSize.y, 0)),
+  BDHI2D(shared_ptr<ParticleData> pd, Parameters par) : BDHI2D(make_shared<ParticleGroup>(pd, "All"), par) {}  // BDHI_quasi2D.cuh:189-190
+  BDHI2D(shared_ptr<ParticleGroup> group, Parameters par)
+      : Integrator(group, "BDHI::BDHI2D"), particleVels(group->getNumberParticles()), box(make_real3(par.box.boxSize.x, par.box.boxSize.y, 0)),
         temperature(par.temperature), dt(par.dt), viscosity(par.viscosity) {
     uammd_bdhi2d_parameters p{};
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y;
@@ -1707,20 +2141,20 @@ public:
     for (auto &u : updatables) u->updateSimulationTime(step * dt);
     step++;
     if (step == 1) for (auto &u : updatables) { u->updateTemperature(temperature); u->updateBox(box); u->updateTimeStep(dt); }
-    {
-      auto force = pd->getForce(access::gpu, access::write);
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
-    }
+    resetGroupForces(st);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
-    const int N = pd->getNumParticles();
+    const int N = groupSize();
     {
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
-      detail::check(uammd_bdhi2d_velocities(h, (const float *)pos.raw(), interactors.empty() ? nullptr : (const float *)force.raw(), N,
-                                            (float *)particleVels.d, (void *)st));
+      detail::check(uammd_bdhi2d_velocities(h, (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
+                                            interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, st),
+                                            N, (float *)particleVels.d, (void *)st));
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
-    detail::check(uammd_bdhi2d_update_positions((float *)pos.raw(), (const float *)particleVels.d, N, dt, (void *)st));
+    real4 *rows = pg ? posRows.d : pos.raw();  // (a proper subgroup: the gathered rows above, moved, then written back through the index)
+    detail::check(uammd_bdhi2d_update_positions((float *)rows, (const float *)particleVels.d, N, dt, (void *)st));
+    detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), st);
   }
 };
 using True2D = BDHI2D<BDHI2D_ns::True2D>;
@@ -1735,6 +2169,7 @@ class FIB : public Integrator {
   real temperature, viscosity, dt, hydrodynamicRadius = 0;
   int cellsOut[3] = {0, 0, 0};
   unsigned long long step = 0;
+  detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
 public:
   enum Scheme { MIDPOINT, IMPROVED_MIDPOINT };
   struct Parameters {
@@ -1747,8 +2182,9 @@ public:
     Scheme scheme = Scheme::IMPROVED_MIDPOINT;
     real tolerance = 1e-5;
   };
-  FIB(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "BDHI::FIB"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt) {
+  FIB(shared_ptr<ParticleData> pd, Parameters par) : FIB(make_shared<ParticleGroup>(pd, "All"), par) {}  // FIB.cuh:163-164
+  FIB(shared_ptr<ParticleGroup> group, Parameters par)
+      : Integrator(group, "BDHI::FIB"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt) {
     uammd_fib_parameters p{};
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
     p.temperature = par.temperature; p.viscosity = par.viscosity; p.hydrodynamicRadius = par.hydrodynamicRadius; p.dt = par.dt;
@@ -1767,15 +2203,15 @@ public:
   void forwardTime() override {
     step++;
     if (step == 1) for (auto &u : updatables) { u->updateSimulationTime(0); u->updateTimeStep(dt); u->updateTemperature(temperature); u->updateBox(box); }
-    {
-      auto force = pd->getForce(access::gpu, access::write);
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));
-    }
+    resetGroupForces(nullptr);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, 0); }
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::read);
-      detail::check(uammd_fib_forward(h, (float *)pos.raw(), (const float *)force.raw(), pd->getNumParticles(), nullptr));
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
+      detail::check(uammd_fib_forward(h, (float *)rows, (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, nullptr),
+                                      groupSize(), nullptr));
+      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
     }
     for (auto &u : updatables) u->updateSimulationTime(step * dt);
   }
@@ -1791,6 +2227,7 @@ class ICM : public Integrator {
   int cellsOut[3] = {0, 0, 0};
   uint step = 0;
   detail::DeviceArray<real3> collocated;
+  detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
   std::vector<real3> h_collocated;
 public:
   struct Parameters {
@@ -1804,8 +2241,9 @@ public:
     bool sumThermalDrift = false;
     bool removeTotalMomentum = true;
   };
-  ICM(shared_ptr<ParticleData> pd, Parameters par)
-      : Integrator(pd, "Hydro::ICM"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt), collocated(0) {
+  ICM(shared_ptr<ParticleData> pd, Parameters par) : ICM(make_shared<ParticleGroup>(pd, "All"), par) {}  // ICM.cuh:174-175
+  ICM(shared_ptr<ParticleGroup> group, Parameters par)
+      : Integrator(group, "Hydro::ICM"), box(par.box), temperature(par.temperature), viscosity(par.viscosity), dt(par.dt), collocated(0) {
     uammd_icm_parameters p{};
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
     p.temperature = par.temperature; p.viscosity = par.viscosity; p.density = par.density; p.hydrodynamicRadius = par.hydrodynamicRadius;
@@ -1819,7 +2257,7 @@ public:
   }
   ICM(const ICM &) = delete;
   ~ICM() { uammd_icm_destroy(h); }
-  real sumEnergy() { return 0; }
+  real sumEnergy() override { return 0; }
   real getSelfMobility() { return 1.0 / (6 * M_PI * viscosity * hydrodynamicRadius) * (1 - 2.837297 * hydrodynamicRadius / box.boxSize.x); }
   real getHydrodynamicRadius() { return hydrodynamicRadius; }
   int3 getNumberFluidCells() { return make_int3(cellsOut[0], cellsOut[1], cellsOut[2]); }
@@ -1841,21 +2279,26 @@ public:
       for (auto &u : updatables) { u->updateTemperature(temperature); u->updateTimeStep(dt); u->updateBox(box); u->updateSimulationTime(0); }
       for (auto &f : interactors) f->sum(c, 0);
     }
-    const int N = pd->getNumParticles();
+    const int N = groupSize();
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
-      detail::check(uammd_icm_predictor(h, (float *)pos.raw(), N, nullptr));
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
+      detail::check(uammd_icm_predictor(h, (float *)rows, N, nullptr));
+      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
     }
     for (auto &u : updatables) u->updateSimulationTime((step - 0.5) * dt);
     if (!interactors.empty()) {
-      { auto force = pd->getForce(access::gpu, access::write); detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr)); }
+      resetGroupForces(nullptr);
       for (auto &f : interactors) f->sum(c, 0);
     }
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::readwrite);
-      detail::check(uammd_icm_fluid_and_corrector(h, (float *)pos.raw(), interactors.empty() ? nullptr : (const float *)force.raw(), N, nullptr));
-      detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));  // correctorStep, :1176-1181
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
+      detail::check(uammd_icm_fluid_and_corrector(h, (float *)rows, interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, nullptr), N, nullptr));
+      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
+      if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), N, (int)sizeof(real4), nullptr));
+      else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));  // correctorStep, :1176-1181
     }
     for (auto &u : updatables) u->updateSimulationTime(step * dt);
   }
@@ -1866,6 +2309,9 @@ public:
 class Poisson : public Interactor {
   uammd_poisson *h = nullptr;
   uammd_poisson_info info{};
+  detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
+  detail::DeviceArray<real> chargeRows, energyRows;
+  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
 public:
   struct Parameters {  // SpectralEwaldPoisson.cuh:94-103; cells and support are never read by the reference's constructor
     real upsampling = -1.0;
@@ -1877,7 +2323,8 @@ public:
     int support = -1;
     real split = -1;
   };
-  Poisson(shared_ptr<ParticleData> pd, Parameters par) : Interactor(pd, "IBM::Poisson") {
+  Poisson(shared_ptr<ParticleData> pd, Parameters par) : Poisson(make_shared<ParticleGroup>(pd, "All"), par) {}  // SpectralEwaldPoisson.cuh:103-104
+  Poisson(shared_ptr<ParticleGroup> group, Parameters par) : Interactor(group, "IBM::Poisson") {
     uammd_poisson_parameters p{};
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
     p.epsilon = par.epsilon; p.tolerance = par.tolerance; p.gw = par.gw; p.split = par.split; p.upsampling = par.upsampling;
@@ -1896,12 +2343,18 @@ public:
     auto charge = pd->getCharge(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::readwrite);
     auto energy = pd->getEnergy(access::gpu, access::readwrite);
-    detail::check(uammd_poisson_sum(h, (const float *)pos.raw(), charge.raw(), pd->getNumParticles(), (float *)force.raw(),
-                                    energy.raw(), comp.force, comp.energy, (void *)st));
+    ParticleGroup *g = pg.get();  // a proper subgroup: the members' rows gathered, the sums written back through the group's index
+    real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, st));
+    real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, st));
+    detail::check(uammd_poisson_sum(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, st),
+                                    detail::groupRows((const real *)charge.raw(), g, chargeRows, st), numberParticles(), (float *)f, e, comp.force,
+                                    comp.energy, (void *)st));
+    detail::scatterRows((const real4 *)f, force.raw(), g, st);
+    detail::scatterRows((const real *)e, energy.raw(), g, st);
   }
   // (Ex, Ey, Ez, phi) at the particles; like the reference's call, the far field also lands on the forces and energies
   std::vector<real4> computeFieldPotentialAtParticles() {
-    const int N = pd->getNumParticles();
+    const int N = numberParticles();
     detail::DeviceArray<real4> fp(N);
     detail::check(uammd_fill_zero(fp.d, sizeof(real4) * (size_t)N, nullptr));
     {
@@ -1909,8 +2362,14 @@ public:
       auto charge = pd->getCharge(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::readwrite);
       auto energy = pd->getEnergy(access::gpu, access::readwrite);
-      detail::check(uammd_poisson_field_potential(h, (const float *)pos.raw(), charge.raw(), N, (float *)fp.d, (float *)force.raw(),
-                                                  energy.raw(), nullptr));
+      ParticleGroup *g = pg.get();
+      real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, nullptr));
+      real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, nullptr));
+      detail::check(uammd_poisson_field_potential(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, nullptr),
+                                                  detail::groupRows((const real *)charge.raw(), g, chargeRows, nullptr), N, (float *)fp.d, (float *)f, e,
+                                                  nullptr));
+      detail::scatterRows((const real4 *)f, force.raw(), g, nullptr);
+      detail::scatterRows((const real *)e, energy.raw(), g, nullptr);
     }
     std::vector<real4> out(N);
     detail::hipCheck(hipMemcpy(out.data(), fp.d, sizeof(real4) * (size_t)N, hipMemcpyDeviceToHost), "hipMemcpy");
@@ -2011,4 +2470,30 @@ public:
 };
 
 }  // namespace uammd
+
+// ---- utils/debugTools.h:14-15: UAMMD's own checking macros, used by programs written against it --------------------------------------
+// CudaSafeCall(err) throws uammd::cuda_generic_error for a runtime call that did not return success; CudaCheckError() does the same for
+// the last error the runtime recorded (after a device synchronisation when UAMMD_DEBUG is defined)
+namespace uammd {
+namespace detail {
+inline void safeCall(hipError_t err, const char *file, int line) {
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    throw cuda_generic_error("CudaSafeCall() failed at " + std::string(file) + ":" + std::to_string(line) + ": " + hipGetErrorString(err) +
+                                 " - code: " + std::to_string((int)err), (int)err);
+  }
+}
+inline void checkError(const char *file, int line) {
+#ifdef UAMMD_DEBUG
+  safeCall(hipDeviceSynchronize(), file, line);
+#endif
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess)
+    throw cuda_generic_error("CudaCheckError() failed at " + std::string(file) + ":" + std::to_string(line) + ": " + hipGetErrorString(err) +
+                                 " - code: " + std::to_string((int)err), (int)err);
+}
+}  // namespace detail
+}  // namespace uammd
+#define CudaSafeCall(err) ::uammd::detail::safeCall(err, __FILE__, __LINE__)
+#define CudaCheckError() ::uammd::detail::checkError(__FILE__, __LINE__)
 #endif

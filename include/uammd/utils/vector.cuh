@@ -7,6 +7,7 @@
 
 #include "../global/defines.h"
 
+#include <algorithm>
 #include <cmath>
 #include <istream>
 #include <ostream>
@@ -73,6 +74,15 @@ UAMMD_HD real4 normalize(const real4 &v) { return v * (real(1) / length(v)); }
 using ::floorf;
 using ::sqrt;
 using ::abs;
+// uammd::max / uammd::min of two scalars (examples/advanced/customPotentials.cu:133): the runtime's in device code, the standard
+// library's on the host
+#if defined(__HIPCC__)
+using ::max;
+using ::min;
+#else
+using std::max;
+using std::min;
+#endif
 UAMMD_HD real2 floorf(const real2 &a) { return real2(std::floor(a.x), std::floor(a.y)); }
 UAMMD_HD real3 floorf(const real3 &a) { return real3(std::floor(a.x), std::floor(a.y), std::floor(a.z)); }
 UAMMD_HD real4 floorf(const real4 &a) { return real4(std::floor(a.x), std::floor(a.y), std::floor(a.z), std::floor(a.w)); }

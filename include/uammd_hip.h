@@ -125,6 +125,9 @@ int uammd_hip_set_tunable(const char *name, int value);
  * gather out[i] = in[index[i]] for 4/8/12/16-byte elements.  Used by ParticleData::sortParticles. */
 int uammd_sort_pairs(unsigned int *d_keys, int *d_values, int n, int end_bit, void *stream);
 int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream);
+/* the inverse: out[index[i]] = in[i] (distinct indices).  What assigning through pg->getPropertyIterator(prop) does in the reference
+ * (ParticleData/ParticleGroup.cuh:473-496): the modules that solve on the gathered rows of a proper subgroup write positions back with it. */
+int uammd_scatter(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Path A — traversal with the Lennard-Jones Transverser.  Replaces
@@ -137,6 +140,11 @@ int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int e
 typedef struct { float cutOff2, sigma2, epsilonDivSigma2, shift; } uammd_lj_pair_parameters;
 /* LJFunctor::processPairParameters (Potential/Potential.cuh:66-82), host */
 int uammd_lj_process_pair_parameters(float cutOff, float sigma, float epsilon, int shift, uammd_lj_pair_parameters *out);
+/* A list caches what it needs of the table (largest cut-off; whether sigma = epsilon = 1) keyed by the table's device address.  After
+ * rewriting a table in place — or uploading a new one into memory a previous table occupied — call this before the next traversal: every
+ * list reads its table again (one small device-to-host copy).  Potential::LJ::setPotParameters between steps (legal in the reference,
+ * Potential.cuh:60-82) goes through here in both host layers. */
+int uammd_lj_table_changed(void);
 
 /* flags for `algo` */
 #define UAMMD_LJ_ALGO_AUTO 0    /* the kernel measured fastest for the grid: TILE where the grid allows it (forces to rounding level, the

@@ -6,7 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "examples")
-PROGS = ["custom_potential", "ibm_library_mode", "bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "particle_group", "custom_transverser"]
+PROGS = ["custom_potential", "ibm_library_mode", "bd_readme", "lj_benchmark", "fcm_selfmobility", "pse_selfmobility", "poisson_two_charges", "checkpoint", "quasi2d_selfmobility", "particle_group", "custom_transverser", "module_lifetime"]
 
 
 def _make():
@@ -39,7 +39,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("custom_potential", []), ("ibm_library_mode", []), ("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
                                        ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []), ("particle_group", ["600", "7"]),
-                                       ("custom_transverser", [])])
+                                       ("custom_transverser", []), ("module_lifetime", [])])
 def test_examples_run(prog, args):
     _make()
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
@@ -78,6 +78,40 @@ def test_reference_benchmark_program_runs(tmp_path):
     assert m, "the program did not report its rate"
     assert float(m.group(1)) > 200.0     # ~90 on the GTX 980 of the reference's comment; > 2000 measured on MI355X
     assert (tmp_path / "data.main.benchmark").exists()   # it wrote its default parameter file through InputFile's reader
+
+
+def test_signal_semantics_host_only(tmp_path):
+    """signal / connection / scoped_connection (the reference's nod::unsafe_signal, ParticleData.cuh:110-125) under AddressSanitizer, no
+    device call: connect / emit / disconnect, a listener destroyed before the signal (round 4's use-after-free), slots that disconnect
+    themselves or connect others during an emission, a connection that outlives its signal."""
+    exe = str(tmp_path / "signal_semantics")
+    rocm = "/opt/rocm"
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include",
+                        "-I" + os.path.join(ROOT, "include", "uammd"), os.path.join(ROOT, "tests", "cxx", "signal_semantics.cpp"), "-o", exe,
+                        "-L" + os.path.join(ROOT, "uammd_amd", "lib"), "-luammd_hip", f"-L{rocm}/lib", "-lamdhip64",
+                        "-Wl,-rpath," + os.path.join(ROOT, "uammd_amd", "lib"), f"-Wl,-rpath,{rocm}/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "signal semantics ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,expect", [("ref_NeighbourListIterator", "mean FPS"), ("ref_neighbour_list", None), ("ref_signals", "No work needs to be done"),
+                                         ("ref_temporary_memory", None)])
+def test_more_reference_programs_run(prog, expect, tmp_path):
+    """The reference's examples/advanced/{NeighbourListIterator,signals,temporary_memory}.cu and uammd_as_a_library/neighbour_list.cu,
+    compiled from where they lie by hipcc against include/uammd (examples/Makefile, the documented user-side spellings replaced) and RUN:
+    a kernel of the program's own over CellList::getNeighbourContainer() driving 500 steps of VerletNVT, BasicNeighbourListBase on a
+    thrust vector with the list walked from a kernel, from thrust and downloaded, signal / connection objects, thrust vectors on
+    System::allocator_thrust."""
+    exe = os.path.join(EX, "_build", prog)
+    if not os.path.exists(exe):
+        pytest.skip(prog + " was not built (no reference tree where `make -C examples` ran)")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    if expect:
+        assert expect in r.stdout + r.stderr
 
 
 @pytest.mark.gpu

@@ -1,9 +1,10 @@
 """The programs the reference SHIPS, compiled from where they lie against include/uammd (round-3 verdict: "make the C++ side a drop-in for
 the programs the reference ships").
 
-Nothing is copied: each file is read from /root/reference/examples, the two CUDA spellings that have no HIP spelling of their own are
-replaced (`cudaStream_t` -> `hipStream_t`, `thrust::cuda::par` -> `thrust::hip::par`: one-token edits, documented in INTEGRATION.md — no
-typedef shim in the headers), and the result goes through the compiler's front end only (-fsyntax-only).  Programs that use nothing but
+Nothing is copied: each file is read from /root/reference/examples, the CUDA spellings that have no HIP spelling of their own are
+replaced (`cudaStream_t` -> `hipStream_t`, `thrust::cuda::par` -> `thrust::hip::par`, `cudaDeviceSynchronize` -> `hipDeviceSynchronize`,
+`cub::` -> `hipcub::`: one-token edits, documented in INTEGRATION.md — no typedef shim in the headers), and the result goes through the
+compiler's front end only (-fsyntax-only).  Programs that use nothing but
 the host interface go through plain `g++ -std=c++14 -x c++` (the headers' contract); the tutorials that call thrust need hipcc, as they
 need nvcc in the reference.  Skipped where /root/reference does not exist (the GPU boxes)."""
 import os
@@ -21,16 +22,27 @@ GXX = ["basic_concepts/1-system.cu", "basic_concepts/2-hello_world.cu", "basic_c
        "basic_concepts/10-initial_configuration.cu", "basic_concepts/13-your-first-interactor.cu", "misc/benchmark.cu"]
 HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "basic_concepts/5-particle_data.cu",
          "basic_concepts/6-particle_data2.cu", "basic_concepts/7-moving_particles.cu", "basic_concepts/8-interacting_particles.cu",
-         "basic_concepts/11-measuring_things.cu", "basic_concepts/12-your-first-integrator.cu", "misc/LJ.cu", "misc/LJMultipleTypes.cu", "misc/checkpoint.cu"]
+         "basic_concepts/11-measuring_things.cu", "basic_concepts/12-your-first-integrator.cu", "misc/LJ.cu", "misc/LJMultipleTypes.cu", "misc/checkpoint.cu",
+         # round 5 (the round-4 verdict's list): library-mode lists, getNeighbourContainer(), signal / connection objects, the pooled
+         # temporaries behind System::allocator_thrust, Potentials of the program's own, the ParticleGroup constructors of the BDHI modules
+         "uammd_as_a_library/neighbour_list.cu", "advanced/NeighbourListIterator.cu", "advanced/signals.cu", "advanced/temporary_memory.cu",
+         "advanced/customPotentials.cu", "advanced/error_handling.cu", "integration_schemes/others/FCM.cu", "integration_schemes/others/BDHI.cu",
+         "integration_schemes/others/q2D.cu", "interaction_modules/Poisson.cu", "interaction_modules/external.cu",
+         "uammd_as_a_library/electrostatic_forces.cu"]
+# Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
+# advanced/execution_policy.cu includes <cuda_profiler_api.h>; integration_schemes/icm.cu needs Hydro/ICM_Compressible (out of
+# scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation).
 
 
 def _source(rel, tmp_path, suffix):
     text = open(os.path.join(REF, rel)).read()
     text, n1 = re.subn(r"\bcudaStream_t\b", "hipStream_t", text)
     text, n2 = re.subn(r"thrust::cuda::par\b", "thrust::hip::par", text)
+    text, n3 = re.subn(r"\bcudaDeviceSynchronize\b", "hipDeviceSynchronize", text)
+    text, n4 = re.subn(r"\bcub::", "hipcub::", text)
     out = tmp_path / (os.path.basename(rel).replace(".cu", suffix))
     out.write_text(text)
-    return str(out), n1 + n2
+    return str(out), n1 + n2 + n3 + n4
 
 
 @pytest.mark.parametrize("rel", GXX)

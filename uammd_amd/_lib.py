@@ -136,6 +136,8 @@ SIGNATURES = {
     "uammd_celllist_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_sort_pairs": (_i, [_vp, _vp, _i, _i, _vp]),
     "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "uammd_scatter": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "uammd_lj_table_changed": (_i, []),
     "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),
     "uammd_lj_transverse_celllist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _i, _vp]),
     "uammd_lj_transverse_celllist_gj2": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _f, _f, _i, _i, _vp]),

@@ -24,6 +24,7 @@
 // aligned 4x4x4 brick of cells in O(1) (64 consecutive Morton keys).
 #include "celllist.hpp"
 #include "gj_step.hpp"
+#include <atomic>
 #include <vector>
 
 #include <cstring>
@@ -481,6 +482,13 @@ __global__ void __launch_bounds__(kBlock) k_gather(const T *__restrict__ in, con
   if (i < n) out[i] = in[index[i]];
 }
 
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_scatter(const T *__restrict__ in, const int *__restrict__ index,
+                                                    T *__restrict__ out, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[index[i]] = in[i];
+}
+
 static inline int nblocks(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 // ---- CellList ------------------------------------------------------------------------------------
@@ -602,8 +610,16 @@ int CellList::check_errors(hipStream_t st, bool sync) {
   return 0;
 }
 
+// A list keeps what it needs of the pair-parameter table (largest cut-off, reduced units or not) keyed by the table's address.  A table
+// rewritten IN PLACE (Potential::LJ::setPotParameters between steps re-uploads into the same buffer; an allocator hands a freed address
+// out again) is announced through uammd_lj_table_changed(): a process-wide count every list compares with the one it read at.
+static std::atomic<unsigned> g_ljTableEpoch{1};
+extern "C" int uammd_lj_table_changed(void) { g_ljTableEpoch.fetch_add(1); return 0; }
+
 int CellList::lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, float *out) {
-  if (d_table != ljTable || ntypes != ljTableTypes) {
+  const unsigned epoch = g_ljTableEpoch.load();
+  if (d_table != ljTable || ntypes != ljTableTypes || epoch != ljTableEpoch) {
+    ljTableEpoch = epoch;
     std::vector<uammd_lj_pair_parameters> host((size_t)ntypes * (size_t)ntypes);
     UH_CHECK(hipMemcpyAsync(host.data(), d_table, host.size() * sizeof(host[0]), hipMemcpyDeviceToHost, st));
     UH_CHECK(hipStreamSynchronize(st));
@@ -937,6 +953,21 @@ int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int e
     case 12: hipLaunchKernelGGL(k_gather<Elem<12>>, g, b, 0, st, (const Elem<12> *)d_in, d_index, (Elem<12> *)d_out, n); break;
     case 16: hipLaunchKernelGGL(k_gather<uint4>, g, b, 0, st, (const uint4 *)d_in, d_index, (uint4 *)d_out, n); break;
     default: set_last_error("uammd_gather: unsupported element size %d", elem_bytes); return -1;
+  }
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_scatter(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(nblocks(n)), b(kBlock);
+  switch (elem_bytes) {
+    case 4: hipLaunchKernelGGL(k_scatter<uint>, g, b, 0, st, (const uint *)d_in, d_index, (uint *)d_out, n); break;
+    case 8: hipLaunchKernelGGL(k_scatter<uint2>, g, b, 0, st, (const uint2 *)d_in, d_index, (uint2 *)d_out, n); break;
+    case 12: hipLaunchKernelGGL(k_scatter<Elem<12>>, g, b, 0, st, (const Elem<12> *)d_in, d_index, (Elem<12> *)d_out, n); break;
+    case 16: hipLaunchKernelGGL(k_scatter<uint4>, g, b, 0, st, (const uint4 *)d_in, d_index, (uint4 *)d_out, n); break;
+    default: set_last_error("uammd_scatter: unsupported element size %d", elem_bytes); return -1;
   }
   UH_CHECK(hipGetLastError());
   return 0;

@@ -64,6 +64,7 @@ struct CellList {
   const void *ljTable = nullptr;
   int ljTableTypes = 0;
   float ljTableMaxCut2 = 0.f;
+  unsigned ljTableEpoch = 0;  // uammd_lj_table_changed() count at the time the table was read
   bool ljTableUnit = false;  // one type with sigma^2 = epsilon / sigma^2 = 1 (the tile kernel's reduced-units instantiation)
   int lj_max_cutoff2(const void *d_table, int ntypes, hipStream_t st, float *out);
   ~CellList();

@@ -548,6 +548,7 @@ class _LJ:
     def device_table(self):
         if self._dev is None:
             self._dev = torch.from_numpy(self.table.copy()).cuda()
+            check(self.lib.uammd_lj_table_changed())  # (the allocator may hand out the address of the previous table)
         return self._dev
 
 
