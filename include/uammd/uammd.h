@@ -1816,7 +1816,7 @@ class PSE {
   shared_ptr<ParticleData> pd;
   shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_PSE.cuh:171)
   detail::DeviceArray<real4> posRows, forceRows;
-  int numberParticles() const { return pg ? pg->getNumberParticles() : numberParticles(); }
+  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
   // the members' positions, contiguous (the property itself without a proper subgroup)
   const float *positions(const property_ptr<real4> &pos, hipStream_t st) { return (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st); }
   uammd_pse_near *nearField = nullptr;

@@ -581,3 +581,48 @@ def test_fcm_step_bins_ahead(hip, o32, cells, n):
     f1[:, :3] = 0.2 * rng.normal(0, 1, centres.shape)
     ex = {m: run(p1, f1, 0.0, m, steps=9) for m in ("ahead", "noflag", "unfused")}
     assert np.array_equal(ex["ahead"], ex["noflag"]) and np.array_equal(ex["ahead"], ex["unfused"])
+
+
+@pytest.mark.parametrize("cells,n,cluster", [((64, 64, 64), 20001, 0), ((64, 64, 64), 6000, 900), ((128, 128, 128), 100000, 0), ((48, 40, 56), 9000, 300)])
+def test_fcm_step_slot_layout(hip, cells, n, cluster):
+    """Round 5: a step that is told the array is untouched finds its WHOLE preparation done by the previous step's update kernel
+    (k_fcm_step_prep: update + binning + stencils in one launch, spread records in fixed-capacity tile slots, no scan).  The same steps
+    with the slot layout off (the compact, scanned layout of rounds 2-4) give the same trajectory at rounding level — with a cluster
+    that overflows its tiles' slots (the overflow records every tile tests), across the periodic sorted solve that refreshes the entries'
+    order ("slot_refresh"), with a step without forces in between, and with tile edges other than eight (48 x 40 x 56)."""
+    L = np.asarray(cells, np.float32)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    dt = 0.01
+    rng = np.random.default_rng(n + cluster)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    if cluster:   # many particles inside one tile and its neighbour: more than any fixed capacity sized by the mean
+        pos[:cluster, :3] = rng.uniform(-3.5, 5.0, (cluster, 3)) + np.array([0.0, 4.0, -4.0], np.float32)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+
+    def run(slots, T, steps=14):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        fcm.set_option("slots", 1 if slots else 0)
+        fcm.set_option("slot_refresh", 4)
+        dp, df = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(force).cuda()
+        v = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        traj = []
+        for s in range(steps):
+            ff = None if s == 9 else df          # a step that only has noise (or nothing) to spread
+            fcm.stepEulerMaruyama(dp, ff, n, T, 1 / math.sqrt(dt), dt, out=v, positions_kept=s > 0)
+            traj.append(v.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        return dp.cpu().numpy(), traj
+
+    for T in (0.0, 0.6):
+        a, va = run(True, T)
+        b, vb = run(False, T)
+        assert np.isfinite(a).all()
+        scale = max(np.abs(x).max() for x in vb)
+        assert scale > 0
+        for x, y in zip(va, vb):
+            assert np.abs(x - y).max() <= 2e-5 * scale
+        moved = np.abs(b[:, :3] - pos[:, :3]).max()
+        assert np.abs(a[:, :3] - b[:, :3]).max() <= 2e-5 * moved + 4 * np.spacing(np.float32(L.max()))
+        assert np.array_equal(a[:, 3], pos[:, 3])

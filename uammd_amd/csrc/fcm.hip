@@ -52,6 +52,17 @@ struct FcmPrep {
   int *tileStart;   // int[ntiles+1]
   int wstride;
   int3 tdim;        // tile edge per axis (<= kTile: the kernels' layouts are sized for kTile, shorter tiles leave rows / columns unused)
+  // SLOT layout of a step that was prepared by the previous step's update kernel (k_fcm_step_prep; cap > 0): origin / weights stay in
+  // the order of the last sorted solve (entry s, .w = the particle), and the spread's candidate records live in FIXED-CAPACITY tile
+  // slots — rec[tile * cap + rank] = {s, particle, tile, origin relative to the tile (packed)} — so that no scan separates the binning
+  // from the spread.  A tile that receives more than cap particles appends the rest to the overflow records rec[ntiles * cap + k],
+  // which every tile tests (rare; counted, and reported to the host through slotFlag when it is no longer rare).
+  int4 *rec;
+  int cap;          // 0: the compact layout above
+  int *slotCount;   // int[ntiles + 1]: this solve's tile populations, [ntiles] = overflow records
+  int *slotCountNext;  // the other parity's counters: the spread hands them to the next update kernel zeroed
+  int *slotFlag;    // host-mapped: set when the overflow list is long enough to cost time
+  const float4 *forceById;  // the caller's force array (slot layout: forces are fetched for the LISTED particles only)
 };
 
 struct FCM {
@@ -75,6 +86,19 @@ struct FCM {
   int3 tdim{8, 8, 8};      // tile edge per axis, 4..8 nodes: the largest divisor of the axis that holds the stencil's reach (fcm_tiles_usable)
   int prepCapN = 0;
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
+  // slot layout (FcmPrep::cap > 0): uammd_fcm_step_euler_maruyama's update kernel prepares the NEXT solve completely (k_fcm_step_prep)
+  DeviceBuffer prepRec, prepSlotCount;
+  bool slotsEnabled = true;         // option "slots"
+  int slotCap = 0;                  // records per tile
+  int slotParity = 0;               // which half of prepSlotCount the pending preparation counted into
+  bool slotPending = false;         // origin / weights / rec / counters hold the preparation of slotPos (k_fcm_step_prep)
+  bool slotDirty = true;            // the counters may hold anything (first use, or a pending preparation was dropped)
+  const void *slotPos = nullptr;
+  int slotN = 0;
+  int slotRefresh = 128;            // a sorted (compact) solve every so many steps: the entries' order is what keeps the gather's windows local (option "slot_refresh")
+  bool lastSolveSlots = false;      // the solve that has just run read the slot layout
+  int slotSteps = 0;                // slot-layout steps since the last sorted solve (the entries' order is refreshed every kSlotRefresh)
+  int *slotFlagHost = nullptr, *slotFlagDev = nullptr;  // mapped: the spread reports an overflow list that is long enough to cost time
   bool binBySlot = true;            // option "bin_by_slot": the step's update + binning pass walks the particles in the solve's tile order (k_fcm_update_bin)
   hipStream_t prepStream = nullptr;  // ... an ordering that only holds within one stream: a call on another stream waits for this one first
   bool prepStreamSet = false;
@@ -95,6 +119,7 @@ struct FCM {
   int halfN = 0;
   bool halfPending = false;
   ~FCM() {
+    if (slotFlagHost) (void)hipHostFree(slotFlagHost);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
     if (info) rocfft_execution_info_destroy(info);
@@ -328,6 +353,80 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   pr.force[slot] = fr;
 }
 
+// ---- the whole preparation of the NEXT solve inside the step's update kernel (round 5) --------------------------------------------------
+// uammd_fcm_step_euler_maruyama used to end with k_fcm_update_bin and the next call began with k_fcm_tile_scan + k_fcm_prepare: three
+// kernels in a dependent chain, each at its latency floor (8.6 + 4.8 + 9.8 us at C4, 13 % of the step).  This kernel is all three:
+// LANES threads per particle; the particle of entry s of the last sorted solve (origin[s].w: the entries keep their order between
+// sorted solves, so neighbours in a wave are neighbours in space) is moved, its tile found, its 3 * support weights and its stencil
+// origin written at entry s (they do not depend on the rank), and its record {s, particle, tile, origin relative to its tile} goes to
+// slot rank of its tile's FIXED-CAPACITY range, the rank from one returning atomic per tile and wave (k_fcm_update_bin's ballots) —
+// the weights are computed while that atomic is in flight.  No scan: the spread reads the 27 tile populations instead of 27 range
+// bounds.  linearV == nullptr: no update (the preparation alone).
+template <int KIND, int LANES>
+__global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos, const float *__restrict__ linearV, int N, float dt,
+                                                        GridT<float> grid, IBMKernelDev kern, int3 ntiles, FcmPrep pr, int ovfCap) {
+  kern.kind = KIND;  // constant-folds phi_axis' switch
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int s = gid / LANES, sub = gid % LANES;
+  const bool live = s < N;
+  const bool head = live && sub == 0;
+  const int id = live ? pr.origin[s].w : 0;
+  float4 p = pos[id];
+  if (linearV) {
+    p.x = fmaf(linearV[3 * id], dt, p.x);
+    p.y = fmaf(linearV[3 * id + 1], dt, p.y);
+    p.z = fmaf(linearV[3 * id + 2], dt, p.z);
+    if (head) pos[id] = p;
+  }
+  const real3f pi{p.x, p.y, p.z};
+  const int3 celli = grid.getCell(pi);
+  const int tcx = celli.x / pr.tdim.x, tcy = celli.y / pr.tdim.y, tcz = celli.z / pr.tdim.z;
+  const int t = tcx + ntiles.x * (tcy + ntiles.y * tcz);
+  // the rank: the heads of a wave that share a tile are counted by the wave (up to eight tiles per wave; strangers one by one)
+  const int lane = threadIdx.x & 63;
+  unsigned long long rem = __ballot(head);
+  int cnt = 1, before = 0, lead = lane;
+  for (int round = 0; round < 8 && rem; ++round) {
+    const int l = __ffsll((unsigned long long)rem) - 1;
+    const int t0 = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(head && t == t0) & rem;
+    if (head && t == t0 && ((rem >> lane) & 1ull)) {
+      cnt = __popcll(m);
+      before = __popcll(m & ((1ull << lane) - 1ull));
+      lead = l;
+    }
+    rem &= ~m;
+  }
+  int got = 0;
+  if (head && lane == lead) got = atomicAdd(&pr.slotCount[t], cnt);
+  // ... and while it is on its way: the stencil
+  const int3 P = compute_support_shift(grid, pi, celli, kern.support);
+  const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
+  const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
+  if (live) {
+    float *w = pr.weights + (size_t)pr.wstride * s;
+    for (int k = sub; k < sx + sy + sz; k += LANES) {
+      float v;
+      if (k < sx) v = phi_axis(kern, 0, grid.distanceToCellCenter(pi, make_int3(grid.pbc_x(ox + k), celli.y, celli.z)).x);
+      else if (k < sx + sy) v = phi_axis(kern, 1, grid.distanceToCellCenter(pi, make_int3(celli.x, grid.pbc_y(oy + k - sx), celli.z)).y);
+      else v = phi_axis(kern, 2, grid.distanceToCellCenter(pi, make_int3(celli.x, celli.y, grid.pbc_z(oz + k - sx - sy))).z);
+      w[k] = v;
+    }
+  }
+  if (head) pr.origin[s] = make_int4(ox, oy, oz, id);
+  const int rank = __shfl(got, lead, 64) + before;
+  if (!head) return;
+  const int rel = (ox - tcx * pr.tdim.x + 16) | (oy - tcy * pr.tdim.y + 16) << 7 | (oz - tcz * pr.tdim.z + 16) << 14;
+  const int nt = ntiles.x * ntiles.y * ntiles.z;
+  int slot;
+  if (rank < pr.cap) slot = t * pr.cap + rank;
+  else {
+    const int k = atomicAdd(&pr.slotCount[nt], 1);  // (k < N <= ovfCap: one record per particle at most)
+    slot = nt * pr.cap + min(k, ovfCap - 1);
+  }
+  pr.rec[slot] = make_int4(s, id, t, rel);
+}
+
 // One workgroup (4 waves) per tile, three phases per chunk of candidates so that a tile costs TWO global round trips instead
 // of one per particle (round 1 pulled each particle's weights inside the spreading loop: 26 dependent ~0.7 us loads per wave,
 // 104 us per call at C4):
@@ -383,7 +482,10 @@ __device__ unsigned long long g_spread_tl[8];
 #else
 #define SP_STAMP(k) do {} while (0)
 #endif
-template <int W>
+// SLOTS: the records come from fixed-capacity tile slots written by k_fcm_step_prep (FcmPrep::cap > 0) instead of the compact,
+// scanned layout: 27 populations instead of 27 range bounds, a 28th range for the overflow records (usually empty), the forces of the
+// LISTED particles fetched by particle index in phase B, and the other parity's counters handed back zeroed.
+template <int W, bool SLOTS = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
                   FcmPrep pr, int weightWords) {
@@ -392,8 +494,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
   float *acc = reinterpret_cast<float *>(smem);
-  __shared__ int rPrefix[28];
-  __shared__ int2 rInfo[27];   // {first slot of the range minus its offset in the flat candidate sequence, the packed shift of its tile}
+  constexpr int kRanges = SLOTS ? 28 : 27;  // (slots: + the overflow records)
+  __shared__ int rPrefix[kRanges + 1];
+  __shared__ int2 rInfo[kRanges];   // {first slot of the range minus its offset in the flat candidate sequence, the packed shift of its tile}
   constexpr int kThreads = 64 * W;
   __shared__ int waveCnt[4 * kSpPerThread];
   __shared__ unsigned char owner[kThreads * kSpPerThread];
@@ -415,26 +518,42 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
   const int capEntries = min(kThreads, weightWords / kSpWT);
-  if (threadIdx.x < 27) {
+  if (threadIdx.x < kRanges) {
     const int nb = threadIdx.x;
     const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
     int ux = tx + dx, uy = ty + dy, uz = tz + dz;
     if (ux < 0) ux += ntiles.x; else if (ux >= ntiles.x) ux -= ntiles.x;
     if (uy < 0) uy += ntiles.y; else if (uy >= ntiles.y) uy -= ntiles.y;
     if (uz < 0) uz += ntiles.z; else if (uz >= ntiles.z) uz -= ntiles.z;
-    const int t = ux + ntiles.x * (uy + ntiles.y * uz);
-    const int s = pr.tileStart[t], e = pr.tileStart[t + 1];
+    const int numTiles = ntiles.x * ntiles.y * ntiles.z;
+    const int t = nb < 27 ? ux + ntiles.x * (uy + ntiles.y * uz) : numTiles;
+    int s, e;
+    if (SLOTS) {
+      const int c = pr.slotCount[t];
+      s = t * pr.cap;
+      e = s + (nb < 27 ? min(c, pr.cap) : c);  // (range 27: every overflow record, whatever its tile)
+    } else {
+      s = pr.tileStart[t];
+      e = pr.tileStart[t + 1];
+    }
     // inclusive scan of the 27 range lengths inside wave 0
     const int incl = (int)wave_inclusive_scan((uint)(e - s));   // (DPP additions: the 27 active lanes sit in rows 0 and 1)
     rPrefix[nb + 1] = incl;
     if (nb == 0) rPrefix[0] = 0;
+    if (SLOTS && nb == 27) {  // this parity's counters have been read by every tile that needs them once all tiles ran: the other parity's
+      pr.slotCountNext[tile] = 0;  // are zeroed here for the update kernel that follows this solve
+      if (tile == 0) {
+        pr.slotCountNext[numTiles] = 0;
+        if (e - s > 2048) pr.slotFlag[0] = 1;  // (tell the host: the overflow list is long enough to cost time)
+      }
+    }
     // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
     // + 8 more every field of record + shift is (origin in this tile's frame) + 24, in [0, 47]: no carry between the 7-bit fields
     rInfo[nb] = make_int2(s - (incl - (e - s)), (td.x * dx + 8) | (td.y * dy + 8) << 7 | (td.z * dz + 8) << 14);
   }
   __syncthreads();
   SP_STAMP(0);  // ranges known
-  const int total = rPrefix[27];
+  const int total = rPrefix[kRanges];
   int listCount = 0;  // uniform over the workgroup
 
   auto spread_list = [&](int count) {
@@ -452,6 +571,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // per step — the kernel is short of vector issue slots (profiles/r04_pmc_fcm_spread.txt), and that phase was ~40 instructions
     // per matrix step.  Thread r = tid & 31 < 24 copies word r of particles (tid >> 5) + (kThreads / 32) j: axis, t and the word's
     // place once per thread; all of a thread's loads in flight together (staged).
+    float4 myForce = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SLOTS && (int)threadIdx.x < count) myForce = pr.forceById[__float_as_int(sh.list[threadIdx.x].fx)];  // (in flight with the weights)
     {
       const int r = threadIdx.x & 31, axis = r >> 3, t = r & 7;
       const int sa = axis == 0 ? sx : (axis == 1 ? sy : sz), aoff = axis == 0 ? 0 : (axis == 1 ? sx : sx + sy);
@@ -465,6 +586,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
             },
             [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * kSpWT + r] = v; });
     }
+    if (SLOTS && (int)threadIdx.x < count) { SpEntry &en = sh.list[threadIdx.x]; en.fx = myForce.x; en.fy = myForce.y; en.fz = myForce.z; }
     __syncthreads();
     SP_STAMP(2);  // weights in LDS
     // phase C on the matrix pipe.  For one tile the spreading is a product: G[n][xy] += sum_p A[n][p] B[p][xy] with
@@ -501,7 +623,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     {
       constexpr int kPerRange = W == 4 ? 8 : 4;  // threads that fill one range's part of owner[]
       const int nb = threadIdx.x / kPerRange;
-      if (nb < 27) {
+      if (nb < kRanges) {
         const int lo = max(rPrefix[nb], c0), hi = min(rPrefix[nb + 1], c0 + perRound);
         for (int c = lo + (int)(threadIdx.x % kPerRange); c < hi; c += kPerRange) owner[c - c0] = (unsigned char)nb;
       }
@@ -511,16 +633,21 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     int org[kSpPerThread];   // record + shift: the stencil origin in this tile's frame, + 24, in 7-bit fields
     int kOf[kSpPerThread];
     bool live[kSpPerThread];
+    bool ovf[kSpPerThread];
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
       const int c = c0 + u * capEntries + (int)threadIdx.x;
       live[u] = (int)threadIdx.x < capEntries && c < total;
-      const int2 ri = rInfo[live[u] ? owner[c - c0] : 0];
+      const int own = live[u] ? owner[c - c0] : 0;
+      const int2 ri = rInfo[own];
+      ovf[u] = SLOTS && own == 27;
       kOf[u] = live[u] ? ri.x + c : 0;
       org[u] = ri.y;
     }
+    // (slots: the 16-byte record is {entry, particle, tile, packed origin} — the packed origin sits where the compact record has it)
 #pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u) frc[u] = live[u] ? pr.force[kOf[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < kSpPerThread; ++u)
+      frc[u] = live[u] ? (SLOTS ? __builtin_bit_cast(float4, pr.rec[kOf[u]]) : pr.force[kOf[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
     bool accept[kSpPerThread];
     unsigned long long m[kSpPerThread];
     // a stencil overlaps the tile iff -support < origin < tile edge on every axis, i.e. 25 - support <= field <= 23 + edge: the three
@@ -530,6 +657,15 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     const int hi3 = ((23 + td.x) | (23 + td.y) << 7 | (23 + td.z) << 14) | kGuard;
 #pragma unroll
     for (int u = 0; u < kSpPerThread; ++u) {
+      if (SLOTS && ovf[u]) {  // an overflow record: its tile is in the record, not implied by a range; the shift from the tiles' distance
+        const int tc = __float_as_int(frc[u].z);
+        int ddx = tc % ntiles.x - tx, ddy = (tc / ntiles.x) % ntiles.y - ty, ddz = tc / (ntiles.x * ntiles.y) - tz;
+        ddx += ddx > 1 ? -ntiles.x : (ddx < -1 ? ntiles.x : 0);
+        ddy += ddy > 1 ? -ntiles.y : (ddy < -1 ? ntiles.y : 0);
+        ddz += ddz > 1 ? -ntiles.z : (ddz < -1 ? ntiles.z : 0);
+        if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1 || ddz < -1 || ddz > 1) live[u] = false;
+        org[u] = (td.x * ddx + 8) | (td.y * ddy + 8) << 7 | (td.z * ddz + 8) << 14;
+      }
       org[u] += __float_as_int(frc[u].w);
       accept[u] = live[u] && ((((org[u] | kGuard) - lo3) & (hi3 - org[u])) & kGuard) == kGuard;
       m[u] = __ballot(accept[u]);
@@ -548,8 +684,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
         const int before = (wave > 0 ? c0w : 0) + (wave > 1 ? c1w : 0) + (wave > 2 ? c2w : 0);
         SpEntry en;
         en.o = org[u];
-        en.slot = kOf[u];
-        en.fx = frc[u].x; en.fy = frc[u].y; en.fz = frc[u].z;
+        en.slot = SLOTS ? __float_as_int(frc[u].x) : kOf[u];  // where its weights are: the entry (slots) / the compact slot
+        en.fx = SLOTS ? frc[u].y : frc[u].x; en.fy = frc[u].y; en.fz = frc[u].z;  // (slots: .fx carries the particle until phase B)
         sh.list[listCount + before + __popcll(m[u] & ((1ull << lane) - 1ull))] = en;
       }
       listCount += roundCount;
@@ -1411,6 +1547,11 @@ static int fcm_make_plans(FCM *f) {
 static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, int N, hipStream_t st, FcmPrep *out, bool positionsKept = false) {
   const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
   const int wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
+  if (f->slotPending) {  // (a slot-layout preparation that nobody claimed: this call rewrites the arrays it points into)
+    f->slotPending = false;
+    f->slotDirty = true;
+  }
+  f->slotSteps = 0;  // a sorted solve: the entries' order is fresh
   if (f->prepCapN < N) {
     UH_CHECK(hipStreamSynchronize(st));
     if (int e = f->prepOrigin.reserve(sizeof(int4) * (size_t)N)) return e;
@@ -1647,16 +1788,43 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
   const bool custom = stage == 0 && fcm_custom_fft_usable(f);  // (stage 1 exports the Fourier grid, which the fused z pass never stores)
   FcmPrep pr{};
+  bool slots = false;
   if (half != 2) f->halfPending = false;   // (a first half whose second never came is forgotten by the next solve)
   if (half == 2) {
     if (!f->halfPending || f->halfN != N) { set_last_error("uammd_fcm: the second half of a solve without its first"); return -1; }
     pr = f->halfPrep;
     f->halfPending = false;
   } else if (tiles) {
-    if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
+    // the previous step's update kernel prepared this solve (k_fcm_step_prep): usable when the caller vouches that the array is untouched
+    slots = half == 0 && f->slotPending && positionsKept && f->slotPos == (const void *)d_pos && f->slotN == N && f->prepStreamSet &&
+            f->prepStream == st;
+    if (f->slotPending && !slots) f->slotDirty = true;  // dropped: its counters are garbage now
+    f->slotPending = false;
+    if (slots) {
+      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+      int *counts = (int *)f->prepSlotCount.ptr;
+      pr = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (int4 *)f->prepRec.ptr, f->slotCap,
+                   counts + (size_t)f->slotParity * (nt + 1), counts + (size_t)(f->slotParity ^ 1) * (nt + 1), f->slotFlagDev,
+                   (const float4 *)d_force};
+      f->binnedPending = false;
+      // (no forces: no spread to hand the other parity's counters back zeroed)
+      if (!d_force) UH_CHECK(hipMemsetAsync(pr.slotCountNext, 0, sizeof(int) * (size_t)(nt + 1), st));
+    } else if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
   }
+  f->lastSolveSlots = slots;
   if (d_force && half != 2) {
-    if (tiles) {
+    if (tiles && slots) {
+      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+      const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
+      const int sw = spread_waves(N, f->ntiles, f->kern.support, f->tdim, f->spreadWaves);
+      if (sw == 2)
+        hipLaunchKernelGGL((k_fcm_spread_tile<2, true>), dim3(nt), dim3(128), spread_lds_bytes(ww, 2), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+                           zs, f->kern.support, f->ntiles, pr, ww);
+      else
+        hipLaunchKernelGGL((k_fcm_spread_tile<4, true>), dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
+                           zs, f->kern.support, f->ntiles, pr, ww);
+    } else if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
       const int sw = spread_waves(N, f->ntiles, f->kern.support, f->tdim, f->spreadWaves);
@@ -1734,6 +1902,74 @@ int uammd_fcm_displacements_staged(uammd_fcm *h, const float *d_pos, const float
   return fcm_displacements_impl(h, d_pos, d_force, N, temperature, prefactor, d_linearVelocity, stage, stream, false);
 }
 
+// The slot layout's preparation as the step's update kernel (k_fcm_step_prep).  Returns false when the slot layout is not to be used for
+// the next solve (then the caller runs the compact layout's update kernel); true with *rc set otherwise.
+static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, float dt, hipStream_t st, int *rc) {
+  *rc = 0;
+  if (f->slotFlagHost && f->slotFlagHost[0]) {  // the spread met a long overflow list: this system is too clustered for fixed capacities
+    f->slotsEnabled = false;
+    return false;
+  }
+  if (f->slotSteps >= f->slotRefresh) { f->slotSteps = 0; return false; }
+  const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+  const double mean = (double)N / nt;
+  const int cap = std::max(32, ((int)(3.0 * mean) + 16 + 7) & ~7);
+  const size_t recBytes = sizeof(int4) * ((size_t)nt * cap + (size_t)N);
+  if (recBytes > ((size_t)1 << 30)) return false;
+  auto fail = [&](int e) { *rc = e; return true; };
+  if (!f->slotFlagHost) {
+    if (hipHostMalloc((void **)&f->slotFlagHost, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
+    f->slotFlagHost[0] = 0;
+    if (hipHostGetDevicePointer((void **)&f->slotFlagDev, f->slotFlagHost, 0) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
+  }
+  if (f->prepRec.cap < recBytes || f->slotCap != cap || f->prepSlotCount.cap < sizeof(int) * 2 * ((size_t)nt + 1)) {
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-1);
+    if (int e = f->prepRec.reserve(recBytes)) return fail(e);
+    if (int e = f->prepSlotCount.reserve(sizeof(int) * 2 * ((size_t)nt + 1))) return fail(e);
+    f->slotCap = cap;
+    f->slotDirty = true;
+  }
+  int *counts = (int *)f->prepSlotCount.ptr;
+  int parity;
+  if (f->lastSolveSlots && !f->slotDirty) parity = f->slotParity ^ 1;  // (the spread of the solve above zeroed these)
+  else {
+    if (hipMemsetAsync(counts, 0, sizeof(int) * 2 * ((size_t)nt + 1), st) != hipSuccess) return fail(-1);
+    f->slotDirty = false;
+    parity = 0;
+  }
+  FcmPrep pr{};
+  pr.origin = (int4 *)f->prepOrigin.ptr;   // entry -> particle from the solve above; rewritten entry by entry
+  pr.weights = (float *)f->prepWeights.ptr;
+  pr.wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
+  pr.tdim = f->tdim;
+  pr.rec = (int4 *)f->prepRec.ptr;
+  pr.cap = cap;
+  pr.slotCount = counts + (size_t)parity * (nt + 1);
+#define UH_STEP_PREP(K)                                                                                                                        \
+  case K:                                                                                                                                      \
+    if (N <= kPrepLanesUpTo)                                                                                                                   \
+      hipLaunchKernelGGL((k_fcm_step_prep<K, kPrepLanes>), dim3((unsigned)(((size_t)N * kPrepLanes + 255) / 256)), dim3(256), 0, st, (float4 *)d_pos, v, N, \
+                         dt, f->grid, f->kern, f->ntiles, pr, N);                                                                              \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((k_fcm_step_prep<K, 1>), dim3((N + 255) / 256), dim3(256), 0, st, (float4 *)d_pos, v, N, dt, f->grid, f->kern,         \
+                         f->ntiles, pr, N);                                                                                                    \
+    break;
+  switch (f->kern.kind) {
+    UH_STEP_PREP(kKernelGaussian) UH_STEP_PREP(kKernelPeskin3) UH_STEP_PREP(kKernelPeskin4) UH_STEP_PREP(kKernelConstant)
+    UH_STEP_PREP(kKernelBarnettMagland) UH_STEP_PREP(kKernelSixPoint)
+    default: return false;
+  }
+#undef UH_STEP_PREP
+  if (hipGetLastError() != hipSuccess) return fail(-1);
+  f->slotParity = parity;
+  f->slotPending = true;
+  f->slotPos = (const void *)d_pos;
+  f->slotN = N;
+  f->slotSteps++;
+  f->binnedPending = false;
+  return true;
+}
+
 // BDHI::FCMIntegrator::forwardTime without torques (BDHI_FCM.cu:67-119): v = M F + sqrt(2 T / dt) dW as uammd_fcm_displacements, then
 // integrateEulerMaruyamaD's pos += v dt — by a kernel that also bins the positions it writes, so that the next call (told that the array
 // is untouched) starts at the tile scan: one launch per step less.  d_linearVelocity may be NULL; positions move in place.
@@ -1756,6 +1992,10 @@ int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_for
     return e;
   const bool tiles = f->useTiles && !f->forceAtomicSpread;
   const bool bin = tiles && f->emBin && f->prepCapN >= N;  // (the tile scan of the solve above left the counters at zero)
+  if (bin && f->slotsEnabled) {
+    int rc = 0;
+    if (fcm_step_prep_launch(f, d_pos, v, N, dt, st, &rc)) return rc;  // (launched, or failed: done either way)
+  }
   FcmPrep pr{};
   if (bin) {
     pr.tileOf = (int *)f->prepTileOf.ptr; pr.rank = (int *)f->prepRank.ptr; pr.tileCount = (int *)f->prepTileCount.ptr;
@@ -1773,6 +2013,8 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_fcm_set_option: null argument"); return -1; }
   if (std::string(name) == "atomic_spread") { reinterpret_cast<FCM *>(h)->forceAtomicSpread = value != 0; return 0; }
   if (std::string(name) == "bin_ahead") { reinterpret_cast<FCM *>(h)->emBin = value != 0; return 0; }
+  if (std::string(name) == "slot_refresh" && value >= 1) { reinterpret_cast<FCM *>(h)->slotRefresh = value; return 0; }
+  if (std::string(name) == "slots") { reinterpret_cast<FCM *>(h)->slotsEnabled = value != 0; return 0; }
   if (std::string(name) == "bin_by_slot") { reinterpret_cast<FCM *>(h)->binBySlot = value != 0; return 0; }
   if (std::string(name) == "spread_waves") { reinterpret_cast<FCM *>(h)->spreadWaves = value; return 0; }
   if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
