@@ -54,10 +54,11 @@ struct FcmPrep {
   int3 tdim;        // tile edge per axis (<= kTile: the kernels' layouts are sized for kTile, shorter tiles leave rows / columns unused)
   // SLOT layout of a step that was prepared by the previous step's update kernel (k_fcm_step_prep; cap > 0): origin / weights stay in
   // the order of the last sorted solve (entry s, .w = the particle), and the spread's candidate records live in FIXED-CAPACITY tile
-  // slots — rec[tile * cap + rank] = {s, particle, tile, origin relative to the tile (packed)} — so that no scan separates the binning
+  // slots — rec[tile * cap + rank] = entry | particle << 21 | origin relative to the tile (3 x 7 bits) << 42 — so that no scan separates the binning
   // from the spread.  A tile that receives more than cap particles appends the rest to the overflow records rec[ntiles * cap + k],
   // which every tile tests (rare; counted, and reported to the host through slotFlag when it is no longer rare).
-  int4 *rec;
+  unsigned long long *rec;   // entry (21 bits) | particle << 21 | packed origin << 42
+  int *ovfTile;     // int[N]: the tile of overflow record k
   int cap;          // 0: the compact layout above
   int *slotCount;   // int[ntiles + 1]: this solve's tile populations, [ntiles] = overflow records
   int *slotCountNext;  // the other parity's counters: the spread hands them to the next update kernel zeroed
@@ -87,7 +88,7 @@ struct FCM {
   int prepCapN = 0;
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
   // slot layout (FcmPrep::cap > 0): uammd_fcm_step_euler_maruyama's update kernel prepares the NEXT solve completely (k_fcm_step_prep)
-  DeviceBuffer prepRec, prepSlotCount;
+  DeviceBuffer prepRec, prepOvfTile, prepSlotCount;
   bool slotsEnabled = true;         // option "slots"
   int slotCap = 0;                  // records per tile
   int slotParity = 0;               // which half of prepSlotCount the pending preparation counted into
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
 // kernels in a dependent chain, each at its latency floor (8.6 + 4.8 + 9.8 us at C4, 13 % of the step).  This kernel is all three:
 // LANES threads per particle; the particle of entry s of the last sorted solve (origin[s].w: the entries keep their order between
 // sorted solves, so neighbours in a wave are neighbours in space) is moved, its tile found, its 3 * support weights and its stencil
-// origin written at entry s (they do not depend on the rank), and its record {s, particle, tile, origin relative to its tile} goes to
+// origin written at entry s (they do not depend on the rank), and its 64-bit record (entry, particle, origin relative to its tile) goes to
 // slot rank of its tile's FIXED-CAPACITY range, the rank from one returning atomic per tile and wave (k_fcm_update_bin's ballots) —
 // the weights are computed while that atomic is in flight.  No scan: the spread reads the 27 tile populations instead of 27 range
 // bounds.  linearV == nullptr: no update (the preparation alone).
@@ -421,10 +422,11 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
   int slot;
   if (rank < pr.cap) slot = t * pr.cap + rank;
   else {
-    const int k = atomicAdd(&pr.slotCount[nt], 1);  // (k < N <= ovfCap: one record per particle at most)
-    slot = nt * pr.cap + min(k, ovfCap - 1);
+    const int k = min(atomicAdd(&pr.slotCount[nt], 1), ovfCap - 1);  // (k < N <= ovfCap: one record per particle at most)
+    slot = nt * pr.cap + k;
+    pr.ovfTile[k] = t;
   }
-  pr.rec[slot] = make_int4(s, id, t, rel);
+  pr.rec[slot] = (unsigned long long)(uint)s | (unsigned long long)(uint)id << 21 | (unsigned long long)(uint)rel << 42;
 }
 
 // One workgroup (4 waves) per tile, three phases per chunk of candidates so that a tile costs TWO global round trips instead
@@ -495,11 +497,15 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
   float *acc = reinterpret_cast<float *>(smem);
   constexpr int kRanges = SLOTS ? 28 : 27;  // (slots: + the overflow records)
+  constexpr int kThreads = 64 * W;
+  // (Measured and not kept, round 5: a SPECULATIVE first round in the slot layout — the first 47 slots of each of the 27 tiles requested
+  // together with the tiles' populations, since the slots sit at fixed addresses: one round trip instead of two.  1269 records
+  // requested for ~660 real ones, five candidates per thread instead of three: the kernel went from 45.6 to 48.4 us at C4.)
+  constexpr int kU = kSpPerThread;
   __shared__ int rPrefix[kRanges + 1];
   __shared__ int2 rInfo[kRanges];   // {first slot of the range minus its offset in the flat candidate sequence, the packed shift of its tile}
-  constexpr int kThreads = 64 * W;
-  __shared__ int waveCnt[4 * kSpPerThread];
-  __shared__ unsigned char owner[kThreads * kSpPerThread];
+  __shared__ int waveCnt[4 * kU];
+  __shared__ unsigned char owner[kThreads * kU];
   __builtin_amdgcn_s_setprio(3);  // phases that load go ahead of the phase that computes (five workgroups share a CU)
 #ifdef UAMMD_SPREAD_TIMELINE
   const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
@@ -518,6 +524,8 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
   const int capEntries = min(kThreads, weightWords / kSpWT);
+  const int numTiles = ntiles.x * ntiles.y * ntiles.z;
+  int myTile = numTiles, myShift = 0;  // threads < kRanges: their range's tile and packed shift
   if (threadIdx.x < kRanges) {
     const int nb = threadIdx.x;
     const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
@@ -525,19 +533,21 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     if (ux < 0) ux += ntiles.x; else if (ux >= ntiles.x) ux -= ntiles.x;
     if (uy < 0) uy += ntiles.y; else if (uy >= ntiles.y) uy -= ntiles.y;
     if (uz < 0) uz += ntiles.z; else if (uz >= ntiles.z) uz -= ntiles.z;
-    const int numTiles = ntiles.x * ntiles.y * ntiles.z;
-    const int t = nb < 27 ? ux + ntiles.x * (uy + ntiles.y * uz) : numTiles;
+    if (nb < 27) myTile = ux + ntiles.x * (uy + ntiles.y * uz);
+    // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
+    // + 8 more every field of record + shift is (origin in this tile's frame) + 24, in [0, 47]: no carry between the 7-bit fields
+    myShift = (td.x * dx + 8) | (td.y * dy + 8) << 7 | (td.z * dz + 8) << 14;
     int s, e;
     if (SLOTS) {
-      const int c = pr.slotCount[t];
-      s = t * pr.cap;
+      const int c = pr.slotCount[myTile];
+      s = myTile * pr.cap;
       e = s + (nb < 27 ? min(c, pr.cap) : c);  // (range 27: every overflow record, whatever its tile)
     } else {
-      s = pr.tileStart[t];
-      e = pr.tileStart[t + 1];
+      s = pr.tileStart[myTile];
+      e = pr.tileStart[myTile + 1];
     }
-    // inclusive scan of the 27 range lengths inside wave 0
-    const int incl = (int)wave_inclusive_scan((uint)(e - s));   // (DPP additions: the 27 active lanes sit in rows 0 and 1)
+    // inclusive scan of the range lengths inside wave 0
+    const int incl = (int)wave_inclusive_scan((uint)(e - s));   // (DPP additions: the active lanes sit in rows 0 and 1)
     rPrefix[nb + 1] = incl;
     if (nb == 0) rPrefix[0] = 0;
     if (SLOTS && nb == 27) {  // this parity's counters have been read by every tile that needs them once all tiles ran: the other parity's
@@ -547,16 +557,18 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
         if (e - s > 2048) pr.slotFlag[0] = 1;  // (tell the host: the overflow list is long enough to cost time)
       }
     }
-    // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
-    // + 8 more every field of record + shift is (origin in this tile's frame) + 24, in [0, 47]: no carry between the 7-bit fields
-    rInfo[nb] = make_int2(s - (incl - (e - s)), (td.x * dx + 8) | (td.y * dy + 8) << 7 | (td.z * dz + 8) << 14);
+    rInfo[nb] = make_int2(s - (incl - (e - s)), myShift);
   }
   __syncthreads();
   SP_STAMP(0);  // ranges known
   const int total = rPrefix[kRanges];
   int listCount = 0;  // uniform over the workgroup
 
-  auto spread_list = [&](int count) {
+  // (always_inline: out of line, the lambda's captures — the accumulators, pr — live in scratch memory and the kernel is 8x slower;
+  // it was inlined by size alone until round 5 added to it;
+  // sx, sy, sz by VALUE: by reference they are three adjacent pointers of the closure, `axis == 0 ? sx : (axis == 1 ? sy : sz)` becomes a
+  // load at a variable offset into the closure, and the closure — with every captured variable behind it — stays in scratch memory)
+  auto spread_list = [&, sx, sy, sz, wstride](int count) __attribute__((always_inline)) {
     // (every call site is workgroup-uniform.)  The list was appended to by all four waves, possibly in an earlier sub-round of the
     // loop below with no barrier since: phase B reads every entry's slot, so the writes must have landed first.
     __syncthreads();
@@ -616,64 +628,27 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     SP_STAMP(3);  // matrix phase done
   };
 
-  const int perRound = min(capEntries, kThreads) * kSpPerThread;
-  for (int c0 = 0; c0 < total; c0 += perRound) {
-    // phase A: kSpPerThread candidates per thread, their 16-byte records in flight together.  owner[] maps a candidate of this
-    // round to its range (written by eight threads per range) instead of a binary search per candidate.
-    {
-      constexpr int kPerRange = W == 4 ? 8 : 4;  // threads that fill one range's part of owner[]
-      const int nb = threadIdx.x / kPerRange;
-      if (nb < kRanges) {
-        const int lo = max(rPrefix[nb], c0), hi = min(rPrefix[nb + 1], c0 + perRound);
-        for (int c = lo + (int)(threadIdx.x % kPerRange); c < hi; c += kPerRange) owner[c - c0] = (unsigned char)nb;
-      }
-    }
-    __syncthreads();
-    float4 frc[kSpPerThread];
-    int org[kSpPerThread];   // record + shift: the stencil origin in this tile's frame, + 24, in 7-bit fields
-    int kOf[kSpPerThread];
-    bool live[kSpPerThread];
-    bool ovf[kSpPerThread];
+  // a stencil overlaps the tile iff -support < origin < tile edge on every axis, i.e. 25 - support <= field <= 23 + edge: the three
+  // fields tested at once through their guard bits (bit 6 of a field survives `(field | guard) - lo` iff field >= lo)
+  constexpr int kGuard = 0x40 | 0x40 << 7 | 0x40 << 14;
+  const int lo3 = (25 - sx) | (25 - sy) << 7 | (25 - sz) << 14;
+  const int hi3 = ((23 + td.x) | (23 + td.y) << 7 | (23 + td.z) << 14) | kGuard;
+  // accept / ballot / append for one round of kU candidates per thread: org = record origin + tile shift (or garbage where !live),
+  // key = where the candidate's weights are, fx.. = its force (compact) / its particle in fx (slots).  Sub-rounds in candidate order: the
+  // list order is the summation order.
+  auto take_round = [&](const bool (&live)[kU], const int (&org)[kU], const int (&key)[kU], const float (&fx)[kU], const float (&fy)[kU],
+                        const float (&fz)[kU]) __attribute__((always_inline)) {
+    bool accept[kU];
+    unsigned long long m[kU];
 #pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u) {
-      const int c = c0 + u * capEntries + (int)threadIdx.x;
-      live[u] = (int)threadIdx.x < capEntries && c < total;
-      const int own = live[u] ? owner[c - c0] : 0;
-      const int2 ri = rInfo[own];
-      ovf[u] = SLOTS && own == 27;
-      kOf[u] = live[u] ? ri.x + c : 0;
-      org[u] = ri.y;
-    }
-    // (slots: the 16-byte record is {entry, particle, tile, packed origin} — the packed origin sits where the compact record has it)
-#pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u)
-      frc[u] = live[u] ? (SLOTS ? __builtin_bit_cast(float4, pr.rec[kOf[u]]) : pr.force[kOf[u]]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    bool accept[kSpPerThread];
-    unsigned long long m[kSpPerThread];
-    // a stencil overlaps the tile iff -support < origin < tile edge on every axis, i.e. 25 - support <= field <= 23 + edge: the three
-    // fields tested at once through their guard bits (bit 6 of a field survives `(field | guard) - lo` iff field >= lo)
-    constexpr int kGuard = 0x40 | 0x40 << 7 | 0x40 << 14;
-    const int lo3 = (25 - sx) | (25 - sy) << 7 | (25 - sz) << 14;
-    const int hi3 = ((23 + td.x) | (23 + td.y) << 7 | (23 + td.z) << 14) | kGuard;
-#pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u) {
-      if (SLOTS && ovf[u]) {  // an overflow record: its tile is in the record, not implied by a range; the shift from the tiles' distance
-        const int tc = __float_as_int(frc[u].z);
-        int ddx = tc % ntiles.x - tx, ddy = (tc / ntiles.x) % ntiles.y - ty, ddz = tc / (ntiles.x * ntiles.y) - tz;
-        ddx += ddx > 1 ? -ntiles.x : (ddx < -1 ? ntiles.x : 0);
-        ddy += ddy > 1 ? -ntiles.y : (ddy < -1 ? ntiles.y : 0);
-        ddz += ddz > 1 ? -ntiles.z : (ddz < -1 ? ntiles.z : 0);
-        if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1 || ddz < -1 || ddz > 1) live[u] = false;
-        org[u] = (td.x * ddx + 8) | (td.y * ddy + 8) << 7 | (td.z * ddz + 8) << 14;
-      }
-      org[u] += __float_as_int(frc[u].w);
+    for (int u = 0; u < kU; ++u) {
       accept[u] = live[u] && ((((org[u] | kGuard) - lo3) & (hi3 - org[u])) & kGuard) == kGuard;
       m[u] = __ballot(accept[u]);
       if (lane == 0) waveCnt[4 * u + wave] = __popcll(m[u]);
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < kSpPerThread; ++u) {  // sub-rounds in candidate order (the list order is the summation order)
+    for (int u = 0; u < kU; ++u) {
       const int c0w = waveCnt[4 * u], c1w = W > 1 ? waveCnt[4 * u + 1] : 0, c2w = W > 2 ? waveCnt[4 * u + 2] : 0, c3w = W > 2 ? waveCnt[4 * u + 3] : 0;
       const int roundCount = c0w + c1w + c2w + c3w;
       if (listCount + roundCount > capEntries) {  // uniform: spread what is listed, then start a new list
@@ -684,13 +659,83 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
         const int before = (wave > 0 ? c0w : 0) + (wave > 1 ? c1w : 0) + (wave > 2 ? c2w : 0);
         SpEntry en;
         en.o = org[u];
-        en.slot = SLOTS ? __float_as_int(frc[u].x) : kOf[u];  // where its weights are: the entry (slots) / the compact slot
-        en.fx = SLOTS ? frc[u].y : frc[u].x; en.fy = frc[u].y; en.fz = frc[u].z;  // (slots: .fx carries the particle until phase B)
+        en.slot = key[u];
+        en.fx = fx[u]; en.fy = fy[u]; en.fz = fz[u];
         sh.list[listCount + before + __popcll(m[u] & ((1ull << lane) - 1ull))] = en;
       }
       listCount += roundCount;
     }
     __syncthreads();
+  };
+  const int perRound = min(capEntries, kThreads) * kU;
+  for (int c0 = 0; c0 < total; c0 += perRound) {
+    // phase A: kU candidates per thread, their records in flight together.  owner[] maps a candidate of this round to its range
+    // (written by eight threads per range) instead of a binary search per candidate.
+    {
+      constexpr int kPerRange = W == 4 ? 8 : 4;  // threads that fill one range's part of owner[]
+      const int nb = threadIdx.x / kPerRange;
+      if (nb < kRanges) {
+        const int lo = max(rPrefix[nb], c0), hi = min(rPrefix[nb + 1], c0 + perRound);
+        for (int c = lo + (int)(threadIdx.x % kPerRange); c < hi; c += kPerRange) owner[c - c0] = (unsigned char)nb;
+      }
+    }
+    __syncthreads();
+    bool live[kU];
+    int org[kU], key[kU];   // org: record + shift = the stencil origin in this tile's frame, + 24, in 7-bit fields
+    float fx[kU], fy[kU], fz[kU];
+    if (SLOTS) {
+      unsigned long long rec[kU];
+      int tc[kU];
+      bool ovf[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int c = c0 + u * capEntries + (int)threadIdx.x;
+        live[u] = (int)threadIdx.x < capEntries && c < total;
+        const int own = live[u] ? owner[c - c0] : 0;
+        const int2 ri = rInfo[own];
+        ovf[u] = live[u] && own == 27;
+        key[u] = live[u] ? ri.x + c : 0;
+        org[u] = ri.y;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        rec[u] = live[u] ? pr.rec[key[u]] : 0ull;
+        tc[u] = ovf[u] ? pr.ovfTile[key[u] - numTiles * pr.cap] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (ovf[u]) {  // an overflow record: its tile comes with it, not with a range; the shift from the tiles' distance
+          int ddx = tc[u] % ntiles.x - tx, ddy = (tc[u] / ntiles.x) % ntiles.y - ty, ddz = tc[u] / (ntiles.x * ntiles.y) - tz;
+          ddx += ddx > 1 ? -ntiles.x : (ddx < -1 ? ntiles.x : 0);
+          ddy += ddy > 1 ? -ntiles.y : (ddy < -1 ? ntiles.y : 0);
+          ddz += ddz > 1 ? -ntiles.z : (ddz < -1 ? ntiles.z : 0);
+          if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1 || ddz < -1 || ddz > 1) live[u] = false;
+          org[u] = (td.x * ddx + 8) | (td.y * ddy + 8) << 7 | (td.z * ddz + 8) << 14;
+        }
+        org[u] += (int)(rec[u] >> 42);
+        key[u] = (int)(rec[u] & 0x1fffffull);
+        fx[u] = __int_as_float((int)((rec[u] >> 21) & 0x1fffffull));
+        fy[u] = fz[u] = 0.f;
+      }
+    } else {
+      float4 frc[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int c = c0 + u * capEntries + (int)threadIdx.x;
+        live[u] = (int)threadIdx.x < capEntries && c < total;
+        const int2 ri = rInfo[live[u] ? owner[c - c0] : 0];
+        key[u] = live[u] ? ri.x + c : 0;
+        org[u] = ri.y;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) frc[u] = live[u] ? pr.force[key[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        org[u] += __float_as_int(frc[u].w);
+        fx[u] = frc[u].x; fy[u] = frc[u].y; fz[u] = frc[u].z;
+      }
+    }
+    take_round(live, org, key, fx, fy, fz);
   }
   SP_STAMP(1);  // candidates tested, list complete
   if (listCount > 0) spread_list(listCount);
@@ -1804,7 +1849,8 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       int *counts = (int *)f->prepSlotCount.ptr;
       pr = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (int4 *)f->prepRec.ptr, f->slotCap,
+                   f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (unsigned long long *)f->prepRec.ptr,
+                   (int *)f->prepOvfTile.ptr, f->slotCap,
                    counts + (size_t)f->slotParity * (nt + 1), counts + (size_t)(f->slotParity ^ 1) * (nt + 1), f->slotFlagDev,
                    (const float4 *)d_force};
       f->binnedPending = false;
@@ -1914,17 +1960,18 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
   const double mean = (double)N / nt;
   const int cap = std::max(32, ((int)(3.0 * mean) + 16 + 7) & ~7);
-  const size_t recBytes = sizeof(int4) * ((size_t)nt * cap + (size_t)N);
-  if (recBytes > ((size_t)1 << 30)) return false;
+  const size_t recBytes = sizeof(unsigned long long) * ((size_t)nt * cap + (size_t)N);
+  if (recBytes > ((size_t)1 << 30) || N >= (1 << 21)) return false;  // (a record holds entry and particle in 21 bits each)
   auto fail = [&](int e) { *rc = e; return true; };
   if (!f->slotFlagHost) {
     if (hipHostMalloc((void **)&f->slotFlagHost, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
     f->slotFlagHost[0] = 0;
     if (hipHostGetDevicePointer((void **)&f->slotFlagDev, f->slotFlagHost, 0) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
   }
-  if (f->prepRec.cap < recBytes || f->slotCap != cap || f->prepSlotCount.cap < sizeof(int) * 2 * ((size_t)nt + 1)) {
+  if (f->prepRec.cap < recBytes || f->prepOvfTile.cap < sizeof(int) * (size_t)N || f->slotCap != cap || f->prepSlotCount.cap < sizeof(int) * 2 * ((size_t)nt + 1)) {
     if (hipStreamSynchronize(st) != hipSuccess) return fail(-1);
     if (int e = f->prepRec.reserve(recBytes)) return fail(e);
+    if (int e = f->prepOvfTile.reserve(sizeof(int) * (size_t)N)) return fail(e);
     if (int e = f->prepSlotCount.reserve(sizeof(int) * 2 * ((size_t)nt + 1))) return fail(e);
     f->slotCap = cap;
     f->slotDirty = true;
@@ -1942,7 +1989,8 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   pr.weights = (float *)f->prepWeights.ptr;
   pr.wstride = f->kern.support.x + f->kern.support.y + f->kern.support.z;
   pr.tdim = f->tdim;
-  pr.rec = (int4 *)f->prepRec.ptr;
+  pr.rec = (unsigned long long *)f->prepRec.ptr;
+  pr.ovfTile = (int *)f->prepOvfTile.ptr;
   pr.cap = cap;
   pr.slotCount = counts + (size_t)parity * (nt + 1);
 #define UH_STEP_PREP(K)                                                                                                                        \
