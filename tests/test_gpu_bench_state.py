@@ -79,6 +79,13 @@ def _compare_state(hip, o32, pd, box, pot, pf, n, rc, label, algos):
               + (f", bricks {st['bricks']} of which dense fallback {st['fallback_bricks']}" if st else ""))
         assert err <= 1e-5 and err2 <= 1e-5 and eerr <= 1e-5 and verr <= 1e-5, name
         assert nbits == 0 or tile, name      # only the tile kernels may differ from the oracle's bits
+        if tile:   # the un-floored per-particle figure (tests/test_gpu_full_size.py states the bounds)
+            from test_gpu_full_size import UNFLOORED_MAX, UNFLOORED_P999
+            raw = np.abs(gf[:, :3] - ref_f[:, :3]).max(axis=1) / fmax
+            p999, worst = np.quantile(raw, 0.999), raw.max()
+            print(f"    un-floored per-particle |dF|/max|F_i|: 99.9th percentile {p999:.2e}, max {worst:.2e} "
+                  f"(the worst particle's max|F_i| is {fmax[raw.argmax()] / np.median(fmax):.1e} of the median)")
+            assert p999 <= UNFLOORED_P999 and worst <= UNFLOORED_MAX, name
         out[name] = st
     print(f"[{label}] cell occupancy: mean {occ.mean():.2f}, max {occ.max()}, empty cells {int((rs < 0).sum())}; max|F| {fmax.max():.1f}")
     return out, occ

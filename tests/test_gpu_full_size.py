@@ -60,8 +60,22 @@ def test_lj_full_size_vs_oracle(hip, o32, n, L, cells):
         verr = np.abs(v.cpu().numpy() - ref_v).max() / np.abs(ref_v).max()
         print(f"[{n} particles, {name}] force err {err:.2e} ({nbits} words differ), energy {eerr:.2e}, virial {verr:.2e}")
         assert err <= 1e-5 and eerr <= 1e-5 and verr <= 1e-5, name
+        if algo in (0, 10):
+            # what the floor above hides: |dF_i| / max|F_i| with NO floor (a particle whose pair forces cancel has no meaningful relative
+            # error: its bar is the sum of the magnitudes it adds up, reported as the third figure)
+            raw = np.abs(gf[:, :3] - ref_f[:, :3]).max(axis=1) / fmax
+            p999, worst = np.quantile(raw, 0.999), raw.max()
+            print(f"    un-floored per-particle |dF|/max|F_i|: 99.9th percentile {p999:.2e}, max {worst:.2e} "
+                  f"(the worst particle's max|F_i| is {fmax[raw.argmax()] / np.median(fmax):.1e} of the median)")
+            assert p999 <= UNFLOORED_P999 and worst <= UNFLOORED_MAX, name
         assert nbits == 0 or algo in (0, 10), name      # only the tile kernels may differ from the oracle's bits
         assert np.all(gf[:, 3] == 0)
+
+
+# Un-floored bounds for the tile kernels (reordered f32 sums of ~55 pair forces): each |dF_i| is a few ulp of the LARGEST pair force the
+# particle adds up, so relative to its own net force the figure grows where the pair forces cancel.  Stated, measured on the three states
+# the suite holds (C2, C3 lattices + jitter, the melted C3 box): see the printed lines.
+UNFLOORED_P999, UNFLOORED_MAX = 2e-4, 5e-2
 
 
 def _fcm_config(n, L, seed=1234):
@@ -182,5 +196,42 @@ def test_pse_full_size_vs_oracle(hip, o32):
     check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, 1.0, 1.0, 555, _ptr(BdW), current_stream(), C.byref(it)))
     exp = ref.near_stochastic(pos, 1.0, 1.0, 555)
     err = np.linalg.norm(BdW.cpu().numpy() - exp) / np.linalg.norm(exp)
-    print(f"[PSE near noise, {it.value} Lanczos iterations] rel L2 err vs oracle {err:.2e}")
-    assert 3 <= it.value <= 12 and err <= 5 * tol
+    print(f"[PSE near noise, {it.value} Lanczos iterations (oracle {ref.lanczos.getLastRunRequiredSteps()})] rel L2 err vs oracle {err:.2e}")
+    # the same schedule as the reference's solver (deferred checks stop where its per-iteration checks do) and the parity bar of 8d
+    # (measured 2e-7), not the solver's own tolerance
+    assert it.value == ref.lanczos.getLastRunRequiredSteps() and err <= 1e-5
+
+
+def test_fcm_c4_through_the_comm_stack_vs_oracle(hip, o32):
+    """The slab-decomposed solver driven through uammd_comm_* (RCCL; a world of one rank that is its own neighbour through the periodic z
+    faces: every message of the N-rank schedule — halo planes folded back, both all-to-all transposes, the interpolation halo — is sent
+    and received) at C4's size, against the ORACLE (not against the single-GPU HIP path): T = 0 and T = 1."""
+    from oracle.fcm import FCMOracle
+    from uammd_amd.comm import AbiComm
+    from uammd_amd.parallel_fcm import DistributedFCM, HipSlabBackend, SlabGeometry, make_decomposition
+    n, ncell = 100_000, 128
+    L, cells = float(ncell), [ncell] * 3
+    pos, force = _fcm_config(n, L)
+    kernel, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    comm = AbiComm(0, 1, AbiComm.unique_id())
+    try:
+        geom = SlabGeometry(cells, [L] * 3, 1, kernel.support[2])
+        back = HipSlabBackend(geom, 0, kernel, 1.0, 1234)
+        d = make_decomposition(geom, 0, comm=comm)
+        fcm = DistributedFCM(geom, [back], [0], comm=comm)
+        dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+        pl = [d.to_local(dp).contiguous()]
+        ofcm = FCMOracle(o32, L, cells, tolerance=1e-3, viscosity=1.0, seed=1234)
+        v = fcm.displacements(pl, [df], 0.0, 0.0)[0].cpu().numpy()
+        vref = ofcm.displacements(pos, force)
+        err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+        print(f"[slab FCM through uammd_comm_*, world 1, 128^3, {n} particles] T=0 rel L2 err vs oracle {err:.2e}")
+        assert err <= 1e-5
+        T, dt = 1.0, 0.01
+        v = fcm.displacements(pl, [df], T, 1 / math.sqrt(dt))[0].cpu().numpy()
+        vref = ofcm.displacements(pos, force, temperature=T, prefactor=1 / math.sqrt(dt))
+        err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+        print(f"[slab FCM through uammd_comm_*, world 1] T=1 rel L2 err vs oracle {err:.2e}")
+        assert err <= 1e-5
+    finally:
+        comm.close()
