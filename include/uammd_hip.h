@@ -636,8 +636,11 @@ int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
 /* "defer_checks" (default 1): the reference checks convergence at every iteration from an adaptive first step on
  * (LanczosAlgorithm.cu:218-232); here the checks of the iterations before the one the PREVIOUS run stopped at are evaluated together
  * at that iteration — one host round trip and one pass over the Krylov basis instead of one per iteration; the run still stops at
- * the first iteration whose error passes, with that iteration's estimate (the reference's result and iteration count).  0 = every
- * check as its iteration completes. */
+ * the first iteration whose error passes, with that iteration's estimate (the reference's result and iteration count).  The checks are
+ * evaluated in the reference's order: a tridiagonal block that cannot be diagonalised fails the run (-20) only if no EARLIER check
+ * ends it.  Side effect to know about: a run that would have stopped at iteration k has by then called `dot` for the iterations up to
+ * the previous run's stopping point (at most 7 more calls than the reference makes) — a callback that counts its calls sees them.
+ * 0 = every check as its iteration completes, the reference's call count exactly. */
 int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value);
 /* Vectors sharded over several ranks (Lanczos row): `n` is then the LOCAL length, the matvec callback computes the
  * local rows of M v, and every dot product / norm of the recurrence is completed by `reduce`, which must sum d_values[0..count)

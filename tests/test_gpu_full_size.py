@@ -72,10 +72,11 @@ def test_lj_full_size_vs_oracle(hip, o32, n, L, cells):
         assert np.all(gf[:, 3] == 0)
 
 
-# Un-floored bounds for the tile kernels (reordered f32 sums of ~55 pair forces): each |dF_i| is a few ulp of the LARGEST pair force the
-# particle adds up, so relative to its own net force the figure grows where the pair forces cancel.  Stated, measured on the three states
-# the suite holds (C2, C3 lattices + jitter, the melted C3 box): see the printed lines.
-UNFLOORED_P999, UNFLOORED_MAX = 2e-4, 5e-2
+# Un-floored bounds for the tile kernels (reordered f32 sums of ~55 pair forces): |dF_i| / max|F_i| with NO floor.  Measured (round 5,
+# MI355X): 99.9th percentile 8.6e-7 .. 1.2e-6 and max 2.4e-6 .. 1.5e-5 on the three states the suite holds (C2 and C3 lattices + jitter,
+# the C3 box melted 300 steps as bench.py times it); the worst particles are those whose pair forces nearly cancel (their max|F_i| is
+# 0.3 % .. 4 % of the median).  Bars: the 8d bar for 99.9 % of the particles, ten times it for every particle.
+UNFLOORED_P999, UNFLOORED_MAX = 1e-5, 1e-4
 
 
 def _fcm_config(n, L, seed=1234):

@@ -133,7 +133,7 @@ class AbiComm:
     # ---- what a timing harness needs: barrier, host reductions (all through the all-reduce) -----------------------------------------------
     def _slots(self):
         if self._scratch is None:
-            self._scratch = torch.zeros(max(self.world, 1), dtype=torch.float32, device="cuda")
+            self._scratch = torch.zeros(2 * max(self.world, 1), dtype=torch.float32, device="cuda")
         return self._scratch
 
     def barrier(self):
@@ -143,14 +143,22 @@ class AbiComm:
         torch.cuda.current_stream().synchronize()
 
     def gather_host(self, value):
-        """Every rank's float, on every rank (one slot each, summed)."""
+        """Every rank's number, on every rank.  One pair of float32 slots per rank (only its owner writes them, the sum over the ranks is
+        a gather): the value's float32 rounding and the float32 rounding of what that left — 48 bits of it survive the float32 wire, so
+        counts above 2^24 (particle-steps, records) and millisecond timings keep their digits."""
+        import numpy as np
         s = self._slots()
         s.zero_()
-        s[self.rank] = float(value)
+        v = float(value)
+        hi = float(np.float32(v))
+        lo = float(np.float32(v - hi)) if np.isfinite(hi) else 0.0
+        s[2 * self.rank] = hi
+        s[2 * self.rank + 1] = lo
         self.allreduce_sum_(s)
-        return [float(x) for x in s.cpu().tolist()]
+        flat = s.cpu().tolist()
+        return [float(flat[2 * r]) + float(flat[2 * r + 1]) for r in range(self.world)]
 
     def reduce_host(self, values, op):
-        """values: list of floats; op: "MAX" or "SUM" over the ranks, element-wise.  (float32 on the wire.)"""
+        """values: list of floats; op: "MAX" or "SUM" over the ranks, element-wise, accumulated in double on the host (gather_host)."""
         cols = [self.gather_host(v) for v in values]
         return [max(c) if op == "MAX" else sum(c) for c in cols]

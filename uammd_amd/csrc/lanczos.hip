@@ -660,7 +660,7 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       const auto tA = std::chrono::steady_clock::now();
       if (int e = wait(0)) return e;
       const auto tB = std::chrono::steady_clock::now();
-      int info = 0;
+      int infoOf[kLDevM];   // per check: a diagonalisation that fails on a LATER, larger block must not fail a run that an earlier check ends
       for (int k = 0; k < K; ++k) {   // H^(1/2) e1 of the leading mk x mk block, mk = m0 + k
         const int mk = m0 + k;
         dd.assign(mk, 0.0);
@@ -668,8 +668,7 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
         zz.assign((size_t)mk * mk, 0.0);
         for (int r = 0; r < mk; ++r) { dd[r] = hs[64 + r]; zz[(size_t)r * mk + r] = 1.0; }
         for (int r = 0; r + 1 < mk; ++r) ee[r] = hs[96 + r];
-        const int inf = tridiag_ql(dd, ee, zz, mk);
-        if (inf && !info) info = inf;
+        infoOf[k] = tridiag_ql(dd, ee, zz, mk);
         for (int r = 0; r < kLDevM; ++r) {
           double acc = 0.0;
           if (r < mk)
@@ -695,13 +694,13 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         fprintf(stderr, "[lanczos] i=%d (%d checks) wait scalars %.1f us, host QL %.1f us, wait error %.1f us\n", i, K, us(tA, tB), us(tB, tC), us(tC, tD));
       }
-      if (info) {
-        set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
-        return -20;
-      }
       if (hs[3] != 0.0) { set_last_error("[Lanczos] the estimate kernel gave up waiting for the host's coefficients"); return -23; }
-      for (int k = 0; k < K; ++k) {
+      for (int k = 0; k < K; ++k) {   // in the reference's order: iteration ik's diagonalisation, then its error
         const int ik = checkFrom + k;   // the iteration this check belongs to
+        if (infoOf[k]) {
+          set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", infoOf[k]);
+          return -20;
+        }
         if (ik == 0) continue;          // (the reference computes no error at iteration 0)
         const T err = (T)hs[16 + k];
         if (std::isnan(err)) {
