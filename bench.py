@@ -555,6 +555,175 @@ def cpu_baseline_pse(sample_steps):
                       f"on {cores} threads, {el:.1f} s"}
 
 
+# ---- N > 1: nothing may hang, and nothing is timed before the slab path has been shown to agree with the single-domain path ----------
+STAGE = "start"            # where the run is (the watchdog's error line says it)
+_WATCHDOG = {"deadline": None, "rank": 0, "world": 1}
+
+
+def stage(name, seconds=None):
+    """Name the phase the run is entering; `seconds` (optional) is the wall-clock budget of the phase: when it runs out the watchdog
+    thread prints ONE JSON line with an `error` field through the result descriptor (rank 0) and ends the process — a collective that
+    never completes (a rank that died, a communicator that did not form) must not leave the driver waiting on a silent program."""
+    global STAGE
+    STAGE = name
+    _WATCHDOG["deadline"] = None if seconds is None else time.monotonic() + seconds
+    print(f"[bench rank {_WATCHDOG['rank']}] {name}", file=sys.stderr, flush=True)
+
+
+def _start_watchdog(rank, world, n_gpus):
+    import threading
+    _WATCHDOG["rank"], _WATCHDOG["world"] = rank, world
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            dl = _WATCHDOG["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                msg = f"rank {rank} of {world}: stage '{STAGE}' did not finish within its wall-clock budget"
+                print("bench.py: " + msg, file=sys.stderr, flush=True)
+                if rank == 0:
+                    emit_result({"metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU", "value": None,
+                                 "unit": "particle-steps/s", "n_gpus": n_gpus, "error": msg, "stage": STAGE})
+                os._exit(4)
+    threading.Thread(target=watch, daemon=True).start()
+
+
+def fail_all(dist, world, rank, n_gpus, local_error, what):
+    """Every rank calls this with its own verdict (None = fine); if ANY rank failed, rank 0 prints the JSON error line and all ranks exit 3."""
+    bad = 1.0 if local_error else 0.0
+    if _reducing(dist) and world > 1:
+        bad = _allreduce(dist, [bad], "MAX")[0]
+    if bad == 0.0:
+        return
+    if local_error:
+        print(f"bench.py: rank {rank}: {what}: {local_error}", file=sys.stderr, flush=True)
+    if rank == 0:
+        emit_result({"metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU", "value": None,
+                     "unit": "particle-steps/s", "n_gpus": n_gpus, "error": f"{what}: {local_error or 'failed on another rank (see stderr)'}",
+                     "stage": STAGE})
+    os._exit(3)
+
+
+def preflight(hip, args, world, rank, dist):
+    """Before anything is timed at N > 1 (or --force-distributed): a SMALL box of each path through the run's own communication stack,
+    compared on every rank with the single-domain classes on the same global system — the slab LJ step (halo exchange, migration,
+    thermostat keyed by the global particle id) after 12 steps, the slab FCM solve (halo fold, two all-to-all transposes, gather halo)
+    at T = 0 and T > 0.  Returns a dict for the result line; raises RuntimeError with the figure that failed."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    from uammd_amd.parallel import DistributedLJ, SlabDecomposition
+    from uammd_amd.parallel_fcm import DistributedFCM, HipSlabBackend, SlabGeometry, make_decomposition
+    lib = load()
+    report = {}
+    # ---- path A ---------------------------------------------------------------------------------------------------------------------
+    n, rc, dt, T, steps = 16384, 2.5, 0.005, 1.0, 12
+    L1 = (n / 0.8) ** (1.0 / 3.0)
+    noise = math.sqrt(2 * dt * T)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def initial(r):   # rank r's slab in ITS frame, and its velocities: the same on every rank that asks
+        p = torch.from_numpy(lattice(n, L1, 1234 + r)).cuda()
+        v = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(v.data_ptr()), None, 1.0, 0, n, 77 + r, None))
+        return p, v
+    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=0.5, comm=ABI_COMM)
+    pos, vel = initial(rank)
+    ids = torch.arange(n, dtype=torch.int32, device="cuda") + rank * n
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    cl = hip.CellList()
+    grids = {}
+
+    def grid_of(box_L, periodic):
+        key = (tuple(box_L), tuple(periodic))
+        if key not in grids:
+            box = hip.Box(box_L, periodic)
+            grids[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        return grids[key]
+
+    def forces_into(allpos, box_L, periodic, fall):
+        box, cd, ubox = grid_of(box_L, periodic)
+        cl.update_grid(allpos, ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj(pot.device_table(), 1, box, fall, None, None, None, 0)
+
+    def keyed(step, p, v, f, keys, step_num):
+        check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None, 1.0, None,
+                                           C.c_void_p(keys.data_ptr()), p.shape[0], dt, 1.0, 0, noise, step_num, 4242, st()))
+    sim = DistributedLJ(d, None, lambda step, p, v, f, k: keyed(step, p, v, f, sim.current_ids, k), exchange_every=4, forces_into=forces_into)
+    force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    for _ in range(steps):
+        pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
+    torch.cuda.synchronize()
+    sim.check_skin()
+    # the same global system, no decomposition, on THIS rank: all the slabs' initial states stacked along z
+    N = n * world
+    gp = torch.empty((N, 4), dtype=torch.float32, device="cuda")
+    gv = torch.empty((N, 3), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        p, v = initial(r)
+        p[:, 2] += (r - 0.5 * (world - 1)) * L1
+        gp[r * n:(r + 1) * n], gv[r * n:(r + 1) * n] = p, v
+    gkeys = torch.arange(N, dtype=torch.int32, device="cuda")
+    gf = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    gcl = hip.CellList()
+    gbox, gcd, gubox = grid_of([L1, L1, L1 * world], [1, 1, 1])
+
+    def gforces():
+        gcl.update_grid(gp, gubox, gcd)
+        gcl.transverse_lj(pot.device_table(), 1, gbox, gf, None, None, None, 0)
+    gforces()
+    for k in range(1, steps + 1):
+        keyed(1, gp, gv, gf, gkeys, k)
+        gforces()
+        keyed(2, gp, gv, gf, gkeys, k)
+    torch.cuda.synchronize()
+    mine = pos[:, :3].clone()
+    mine[:, 2] += (rank - 0.5 * (world - 1)) * L1       # the slab's frame -> the global frame
+    dx = mine - gp[ids.long(), :3]
+    Lg = torch.tensor([L1, L1, L1 * world], device="cuda")
+    dx -= torch.round(dx / Lg) * Lg
+    err = float(dx.abs().max())
+    report["lj"] = {"particles_per_rank": n, "steps": steps, "owned_after": int(pos.shape[0]), "max_dx_vs_single_domain": err, "bar": 2e-4}
+    if not (err <= 2e-4):
+        raise RuntimeError(f"slab LJ differs from the single-domain run: max |dx| {err:.3e} after {steps} steps (bar 2e-4)")
+    # ---- path B ---------------------------------------------------------------------------------------------------------------------
+    m, nc = 6000, 32
+    cells, Lf = [nc, nc, nc * world], [float(nc), float(nc), float(nc * world)]
+    kernel, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    geom = SlabGeometry(cells, Lf, world, kernel.support[2])
+    back = HipSlabBackend(geom, rank, kernel, 1.0, 1234)
+    dec = make_decomposition(geom, rank, comm=ABI_COMM)
+    fcm = DistributedFCM(geom, [back], [rank], comm=ABI_COMM)
+
+    def particles(r):   # window frame of slab r
+        rng = np.random.default_rng(99 + r)
+        p = np.zeros((m, 4), np.float32)
+        p[:, :3] = rng.uniform(-nc / 2, nc / 2, (m, 3))
+        f = np.zeros((m, 4), np.float32)
+        f[:, :3] = np.random.default_rng(4321 + r).normal(0, 1, (m, 3))
+        return p, f
+    p, f = particles(rank)
+    dp, df = torch.from_numpy(p).cuda(), torch.from_numpy(f).cuda()
+    allp, allf = [], []
+    for r in range(world):
+        pr_, fr_ = particles(r)
+        pr_[:, 2] += (r - 0.5 * (world - 1)) * nc
+        allp.append(pr_), allf.append(fr_)
+    gP, gF = torch.from_numpy(np.concatenate(allp)).cuda(), torch.from_numpy(np.concatenate(allf)).cuda()
+    ref = hip.BDHI.FCM_impl(hip.Box(Lf), cells, kernel, 1.0, 1234, a_eff)
+    errs = []
+    for temperature, pref in ((0.0, 0.0), (1.0, 10.0)):
+        v = fcm.displacements([dp], [df], temperature, pref)[0]
+        vref = ref.computeHydrodynamicDisplacements(gP, gF, m * world, temperature, pref)[rank * m:(rank + 1) * m]
+        torch.cuda.synchronize()
+        errs.append(float((v - vref).norm() / vref.norm()))
+    report["fcm"] = {"particles_per_rank": m, "grid": cells, "rel_l2_vs_single_domain": {"T=0": errs[0], "T=1": errs[1]}, "bar": 1e-5}
+    if not (max(errs) <= 1e-5):
+        raise RuntimeError(f"slab FCM differs from the single-GPU solver: rel L2 {errs[0]:.3e} (T = 0), {errs[1]:.3e} (T = 1), bar 1e-5")
+    return report
+
+
 def run_lj_distributed(hip, args, world, rank, dist):
     """N > 1 (or --force-distributed): z-slab domain decomposition, one slab of `--particles` particles per rank
     (weak scaling: the global box grows along z), halo exchange + migration over torch.distributed P2P."""
@@ -615,7 +784,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
 
     def integrate_rows_fn(step, p, v, f, rows, keys, step_num):
         check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None,
-                                           1.0, C.c_void_p(rows.data_ptr()), C.c_void_p(keys.data_ptr()), rows.shape[0], dt, 1.0, 0, noise,
+                                           1.0, None if rows is None else C.c_void_p(rows.data_ptr()), C.c_void_p(keys.data_ptr()),
+                                           keys.shape[0] if rows is None else rows.shape[0], dt, 1.0, 0, noise,
                                            step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into,
@@ -715,6 +885,10 @@ def main():
     ap.add_argument("--exchange-every", type=int, default=10, help="slab decomposition: steps between ownership / halo-list refreshes "
                                                                       "(measured at world = 1: 10 / 0.4 -> 0.335 ms per step, 20 / 0.6 -> 0.315)")
     ap.add_argument("--force-distributed", action="store_true", help="use the slab-decomposition code path at N=1 too")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1 / --force-distributed: skip the small slab-vs-single-domain parity runs before the timed ones")
+    ap.add_argument("--stage-seconds", type=float, default=300.0, help="N > 1: wall-clock budget of process-group set-up and of the preflight, each; "
+                    "a stage that runs out prints a JSON line with an `error` field and exits instead of hanging")
+    ap.add_argument("--max-seconds", type=float, default=1500.0, help="N > 1: wall-clock budget of the timed workloads")
     args = ap.parse_args()
 
     same_device = os.environ.get("UAMMD_BENCH_SAME_DEVICE") == "1"
@@ -753,6 +927,9 @@ def main():
         sys.exit(2)
     dist = None
     comm_info = {"backend": None, "rccl_version": None, "devices": [torch.cuda.get_device_name(0) + " (cuda:0)"] if torch.cuda.is_available() else []}
+    if world > 1 or args.force_distributed:
+        _start_watchdog(rank, world, args.gpus)
+        stage("process group + communicator", args.stage_seconds)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -767,10 +944,12 @@ def main():
         torch.cuda.set_device(local_rank)
         from uammd_amd.comm import _stdout_to_stderr
         with _stdout_to_stderr():   # (gloo and librccl greet on stdout; this program's stdout is one JSON line)
+            import datetime
+            lim = datetime.timedelta(seconds=args.stage_seconds)   # (torch's own collectives give up too, not only the watchdog)
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=lim)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, timeout=lim)
         mine = f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}, pid {os.getpid()})"
         devs = [None] * world
         dist.all_gather_object(devs, mine)
@@ -821,6 +1000,19 @@ def main():
             comm_info["backend"] = TRANSPORT
         if err:
             comm_info["abi_comm_error"] = err
+        print(f"[bench rank {rank}] {comm_info['devices'][rank] if world > 1 else comm_info['devices']}; RCCL {comm_info.get('rccl_version')}; "
+              f"messages through {TRANSPORT}", file=sys.stderr, flush=True)
+        if not args.no_preflight:
+            stage("preflight: small slab runs against the single-domain classes", args.stage_seconds)
+            perr, rep_ = None, None
+            try:
+                rep_ = preflight(hip, args, world, rank, dist)
+            except Exception as e:
+                perr = f"{type(e).__name__}: {e}"
+            fail_all(dist, world, rank, args.gpus, perr, "preflight")
+            comm_info["preflight"] = rep_
+            _settle()
+        stage("timed workloads", args.max_seconds)
 
     if args.workload == "pse":
         if world > 1:

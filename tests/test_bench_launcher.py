@@ -27,3 +27,16 @@ def test_world_size_must_match_gpus():
     r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert '"metric"' not in r.stdout
+
+
+def test_a_stage_that_never_finishes_ends_in_a_json_error_line_not_a_hang():
+    """bench.py at N > 1: every stage (process group + communicator, preflight, timed workloads) has a wall-clock budget; when one runs
+    out — a collective that never completes — rank 0 prints ONE JSON line with an `error` field and every rank exits.  Here: a stage
+    with a one-second budget that sleeps."""
+    import json
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench._start_watchdog(0, 2, 2); "
+            "bench.stage('a collective that never completes', 1.0); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4, (r.returncode, r.stderr[-500:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "did not finish" in line["error"] and line["stage"] == "a collective that never completes" and line["n_gpus"] == 2

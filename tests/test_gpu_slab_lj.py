@@ -66,7 +66,7 @@ def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, com
         integrate_fn = lambda step, p, v, f, step_num: keyed(step, p, v, f, None, sim.current_ids, p.shape[0], step_num)
     sim = DistributedLJ(d, None, integrate_fn, exchange_every=exchange_every, forces_into=forces_into,
                         forces_step2_into=forces_step2_into if step2 else None,
-                        integrate_rows_fn=(lambda step, p, v, f, rows, keys, step_num: keyed(step, p, v, f, rows, keys, rows.shape[0], step_num))
+                        integrate_rows_fn=(lambda step, p, v, f, rows, keys, step_num: keyed(step, p, v, f, rows, keys, keys.shape[0] if rows is None else rows.shape[0], step_num))
                         if overlap else None)
     sim_box.append(sim)
     if not fused:

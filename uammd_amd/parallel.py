@@ -369,8 +369,9 @@ class DistributedLJ:
         # optional: forces_step2_into(allpos, box_L, periodic, fall, vel) = the forces AND the integrator's second half step of the owned
         # rows in one call (uammd_lj_transverse_celllist_gj2: the half step rides in the traversal's store); persistent mode only
         self.forces_step2_into = forces_step2_into
-        # optional: integrate_rows_fn(step, pos, vel, force, rows, keys, step_num) = the integrator's half step on the rows `rows` (int32) with
-        # the thermostat keyed by `keys` (their global ids).  With it (persistent mode, GPU, a communicator, cached lists) the halo exchange
+        # optional: integrate_rows_fn(step, pos, vel, force, rows, keys, step_num) = the integrator's half step on the rows `rows` (int32; None =
+        # rows 0 .. len(keys) - 1) with the thermostat keyed by `keys` (their global ids).  When given it is the ONLY integrator the persistent
+        # path calls (split and unsplit steps alike).  With it (persistent mode, GPU, a communicator, cached lists) the halo exchange
         # of a step between refreshes OVERLAPS the first half step: the listed particles (the ones the neighbours need) are integrated
         # first, their positions packed and sent on a side stream while the main stream integrates everybody else; the list build waits
         # for the ghosts.  Same arithmetic per particle: same bits as the unsplit step.
@@ -567,7 +568,13 @@ class DistributedLJ:
                 ev_ghosts.record(side)
             main.wait_event(ev_ghosts)
         else:
-            self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
+            # (ONE callback defines the arithmetic of the half step when the overlapped form is armed: the unsplit steps call it too —
+            # rows None = all n owned rows, keyed by their global ids — so that a caller's integrate_fn keyed any other way cannot give the
+            # refresh steps a different noise stream than the split steps)
+            if self.integrate_rows_fn is not None:
+                self.integrate_rows_fn(1, bp[:n], bv[:n], bf[:n], None, bi[:n], self.steps)
+            else:
+                self.integrate_fn(1, bp[:n], bv[:n], bf[:n], self.steps)
             if refresh:
                 n = self._refresh_persistent(n)
             else:
@@ -579,7 +586,10 @@ class DistributedLJ:
             self.forces_step2_into(bp[:self._nall], L, per, bf[:self._nall], bv[:n])
         else:
             self._forces_persistent(n)
-            self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
+            if self.integrate_rows_fn is not None:
+                self.integrate_rows_fn(2, bp[:n], bv[:n], bf[:n], None, bi[:n], self.steps)
+            else:
+                self.integrate_fn(2, bp[:n], bv[:n], bf[:n], self.steps)
         return bp[:n], bv[:n], bf[:n], bi[:n]
 
     def reordered(self):
