@@ -98,6 +98,7 @@ struct FCM {
   int slotN = 0;
   int slotRefresh = 128;            // a sorted (compact) solve every so many steps: the entries' order is what keeps the gather's windows local (option "slot_refresh")
   bool lastSolveSlots = false;      // the solve that has just run read the slot layout
+  int orderN = 0;                   // origin[0 .. orderN).w is a permutation of the particles (entry -> particle) left by an earlier solve of orderN particles
   int slotSteps = 0;                // slot-layout steps since the last sorted solve (the entries' order is refreshed every kSlotRefresh)
   int *slotFlagHost = nullptr, *slotFlagDev = nullptr;  // mapped: the spread reports an overflow list that is long enough to cost time
   bool binBySlot = true;            // option "bin_by_slot": the step's update + binning pass walks the particles in the solve's tile order (k_fcm_update_bin)
@@ -1599,6 +1600,7 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   f->slotSteps = 0;  // a sorted solve: the entries' order is fresh
   if (f->prepCapN < N) {
     UH_CHECK(hipStreamSynchronize(st));
+    f->orderN = 0;
     if (int e = f->prepOrigin.reserve(sizeof(int4) * (size_t)N)) return e;
     if (int e = f->prepWeights.reserve(sizeof(float) * (size_t)wstride * N)) return e;
     if (int e = f->prepSorted.reserve(sizeof(float4) * (size_t)N)) return e;
@@ -1646,6 +1648,7 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
     default: set_last_error("fcm: window kind %d has no spreading kernel", f->kern.kind); return -3;
   }
 #undef UH_PREPARE
+  f->orderN = N;  // (origin[slot].w = the particle of compact slot `slot`: the entry order of the slot layout)
   *out = pr;
   return 0;
 }
@@ -1817,6 +1820,7 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
 // half: 0 = the whole solve; 1 = its first half (binning, stencils, spreading, the forward x / y transforms), 2 = the second (z transform,
 // operator and noise, inverse transforms, gather) of a solve whose first half was queued on the same stream with the same arguments —
 // for a caller with other work to queue in between (uammd_pse_far_displacements_half)
+static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, float dt, hipStream_t st, int *rc);
 static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
                                   float prefactor, float *d_linearVelocity, int stage, void *stream, bool positionsKept, int half = 0) {
   if (!h) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
@@ -1841,10 +1845,20 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
     f->halfPending = false;
   } else if (tiles) {
     // the previous step's update kernel prepared this solve (k_fcm_step_prep): usable when the caller vouches that the array is untouched
-    slots = half == 0 && f->slotPending && positionsKept && f->slotPos == (const void *)d_pos && f->slotN == N && f->prepStreamSet &&
-            f->prepStream == st;
+    slots = f->slotPending && !f->tileGather && positionsKept && f->slotPos == (const void *)d_pos && f->slotN == N && f->prepStreamSet && f->prepStream == st;
     if (f->slotPending && !slots) f->slotDirty = true;  // dropped: its counters are garbage now
     f->slotPending = false;
+    if (!slots && f->slotsEnabled && !f->tileGather && f->orderN == N && f->prepStreamSet && f->prepStream == st) {  // (k_fcm_gather_tile walks compact tile ranges)
+      // nobody prepared this solve: the same kernel without the update (binning + stencils + records in ONE launch instead of
+      // k_fcm_bin_count -> k_fcm_tile_scan -> k_fcm_prepare), in the entry order an earlier solve of these N particles left;
+      // every slotRefresh-th solve goes through the sorted layout again (the entries' order is what keeps the gather's windows local)
+      int rc = 0;
+      if (fcm_step_prep_launch(f, const_cast<float *>(d_pos), nullptr, N, 0.0f, st, &rc)) {
+        if (rc) return rc;
+        slots = true;
+        f->slotPending = false;
+      }
+    }
     if (slots) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       int *counts = (int *)f->prepSlotCount.ptr;
@@ -1858,7 +1872,7 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
       if (!d_force) UH_CHECK(hipMemsetAsync(pr.slotCountNext, 0, sizeof(int) * (size_t)(nt + 1), st));
     } else if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
   }
-  f->lastSolveSlots = slots;
+  if (half != 2) f->lastSolveSlots = slots;  // (the second half of a solve reads what the first half prepared)
   if (d_force && half != 2) {
     if (tiles && slots) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
