@@ -478,6 +478,8 @@ def run_pse(hip, args):
     integ = hip.BDHI.EulerMaruyama(pd, par, Method=hip.BDHI.PSE)
     integ.addInteractor(FixedForce(pd, torch.from_numpy(force).cuda()))
     pse = integ.bdhi
+    if os.environ.get("UAMMD_PSE_FUSE") == "0":   # (A/B: the Lanczos recurrence as four launches per iteration instead of two)
+        check(lib.uammd_pse_near_set_option(pse.near, b"fuse_recurrence", 0))
     steps, warm = args.pse_steps, 5
     for _ in range(warm):
         integ.forwardTime()

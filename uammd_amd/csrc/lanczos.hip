@@ -26,6 +26,8 @@
 #include <vector>
 #include <string>
 
+#include "lanczos_fused.hpp"
+
 namespace uammd_hip {
 
 constexpr int kLB = 256;       // threads per block
@@ -49,6 +51,11 @@ template <class T> struct LanczosT {
   uammd_interleave_fn interleaveEarly = nullptr;   // uammd_lanczos_set_interleave_early (one-shot)
   void *interleaveEarlyCtx = nullptr;
   bool deferChecks = true;   // evaluate the convergence checks of several iterations together (lanczos_run)
+  // a product that runs the recurrence's first and last kernels itself (lanczos_fused.hpp; single precision, unsharded vectors)
+  lanczos_fused_fn fused = nullptr;
+  void *fusedCtx = nullptr;
+  bool fuseRecurrence = true;   // option "fuse_recurrence"
+  DeviceBuffer w2, partsWide, partsB;   // the second w buffer, the product's partials of w . v_i, k_l_b's partials of |w|^2
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
   uammd_allreduce_fn reduce = nullptr;   // (single precision only)
   void *reduceCtx = nullptr;
@@ -463,6 +470,13 @@ static int tridiag_ql(std::vector<double> &d, std::vector<double> &e, std::vecto
 
 using Lanczos = LanczosT<float>;
 static inline int lgrid(int n) { return std::min(kLParts, (n + kLB - 1) / kLB); }
+int lanczos_set_fused(::uammd_lanczos *h, lanczos_fused_fn fn, void *ctx) {
+  if (!h) { set_last_error("lanczos_set_fused: null handle"); return -1; }
+  Lanczos *L = reinterpret_cast<Lanczos *>(h);
+  L->fused = fn;
+  L->fusedCtx = ctx;
+  return 0;
+}
 
 }  // namespace uammd_hip
 
@@ -487,6 +501,7 @@ int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit) {
 int uammd_lanczos_set_option(uammd_lanczos *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_lanczos_set_option: null argument"); return -1; }
   if (std::string(name) == "defer_checks") { reinterpret_cast<Lanczos *>(h)->deferChecks = value != 0; return 0; }
+  if (std::string(name) == "fuse_recurrence") { reinterpret_cast<Lanczos *>(h)->fuseRecurrence = value != 0; return 0; }
   set_last_error("uammd_lanczos_set_option: unknown option %s", name);
   return -1;
 }
@@ -538,6 +553,20 @@ int uammd_lanczos_set_allreduce(uammd_lanczos *h, uammd_allreduce_fn reduce, voi
 
 }  // extern "C"
 
+// the fused product is a single-precision, single-rank affair
+static bool fused_usable(LanczosT<float> *L) { return L->fused && L->fuseRecurrence && !L->reduce; }
+static bool fused_usable(LanczosT<double> *) { return false; }
+static int fused_call(LanczosT<float> *L, const float *wPrev, const float *vi, const float *partsB, int npB, const float *hdiagPrev,
+                      const float *normz, float *hsupPrev, float *viOut, const float *vPrev, float *wOut, float *partsA, int partsACap,
+                      int *npA, int n, void *stream) {
+  LanczosFusedArgs a{wPrev, vi, partsB, npB, hdiagPrev, normz, hsupPrev, viOut, L->ownsFirstElement, vPrev, wOut, partsA, partsACap, 0};
+  const int rc = L->fused(L->fusedCtx, &a, n, stream);
+  *npA = a.npA;
+  return rc;
+}
+static int fused_call(LanczosT<double> *, const double *, const double *, const double *, int, const double *, const double *, double *,
+                      double *, const double *, double *, double *, int, int *, int, void *) { return 1; }
+
 template <class T, class MatVec>
 static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *d_v, T tolerance, int n, void *stream, int *iterations) {
   if (!L || !dot || !d_Bv || !d_v || n < 1) { set_last_error("uammd_lanczos_run: bad arguments"); return -1; }
@@ -580,20 +609,57 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
   int checkFrom = checkConvergenceSteps;
   int evalAt = std::max(checkConvergenceSteps, std::min(L->deferChecks ? L->lastRunRequiredSteps : 0, checkConvergenceSteps + kLBatch - 1));
   evalAt = std::min(evalAt, std::min(kLDevM - 1, L->iterationHardLimit - 1));
+  // the fused iteration (lanczos_fused.hpp): two launches instead of four.  vNextPending: v_(i+1) and hsup_i of the iteration that has
+  // just run are still to be made (by the next fused product's prologue, or by k_l_c if that product declines)
+  // (|w|^2 partials in a buffer of their own: the fused iteration reads them in the NEXT product's prologue, after a convergence check
+  // has used `parts` as its scratch)
+  if (!L->partsB.ptr) { if (int e = L->partsB.reserve(sizeof(T) * kLParts)) return e; }
+  T *partsB = (T *)L->partsB.ptr;
+  bool vNextPending = false;
+  T *wcur = w;
   for (int i = 0; i < L->iterationHardLimit; ++i) {
     T *vi = V + (size_t)i * n;
-    if (int rc = dot(ctx, vi, w, n, stream)) {
-      if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the matrix-vector callback failed (%d)", rc);
-      return rc;
+    bool fusedDone = false;
+    if (fused_usable(L)) {
+      if (!L->w2.ptr || L->w2.cap < sizeof(T) * (size_t)n) { if (int e = L->w2.reserve(sizeof(T) * (size_t)n)) return e; }
+      const int wideCap = 1 << 16;
+      if (!L->partsWide.ptr) { if (int e = L->partsWide.reserve(sizeof(T) * (size_t)wideCap)) return e; }
+      T *wnext = wcur == w ? (T *)L->w2.ptr : w;
+      int npA = 0;
+      const int rc = fused_call(L, vNextPending ? wcur : nullptr, vi, partsB, np, i > 0 ? hdiag + i - 1 : nullptr, scal,
+                                i > 0 ? hsup + i - 1 : nullptr, vNextPending ? vi : nullptr, i > 0 ? V + (size_t)(i - 1) * n : nullptr,
+                                wnext, (T *)L->partsWide.ptr, wideCap, &npA, n, stream);
+      if (rc < 0) {
+        if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the fused matrix-vector product failed (%d)", rc);
+        return rc;
+      }
+      if (rc == 0) {
+        wcur = wnext;
+        hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, wcur, (const T *)vi, n, (const T *)L->partsWide.ptr, npA, hdiag + i,
+                           partsB);
+        vNextPending = true;
+        fusedDone = true;
+      }
     }
-    hipLaunchKernelGGL(k_l_a<T>, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const T *)(V + (size_t)(i - 1) * n) : nullptr,
-                       (const T *)vi, n, i > 0 ? (const T *)(hsup + i - 1) : nullptr, parts);
-    if (int rc = complete(parts)) return rc;
-    hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, w, (const T *)vi, n, (const T *)parts, np, hdiag + i,
-                       parts + kLParts);
-    if (int rc = complete(parts + kLParts)) return rc;
-    hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)w, n, (const T *)(parts + kLParts), np,
-                       (const T *)(hdiag + i), (const T *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
+    if (!fusedDone) {
+      if (vNextPending) {   // the previous iteration ran fused and left its last kernel to a product that now declines
+        hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)wcur, n, (const T *)(partsB), np,
+                           (const T *)(hdiag + i - 1), (const T *)scal, hsup + i - 1, vi, L->ownsFirstElement);
+        vNextPending = false;
+      }
+      if (int rc = dot(ctx, vi, wcur, n, stream)) {
+        if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the matrix-vector callback failed (%d)", rc);
+        return rc;
+      }
+      hipLaunchKernelGGL(k_l_a<T>, dim3(g), dim3(kLB), 0, st, wcur, i > 0 ? (const T *)(V + (size_t)(i - 1) * n) : nullptr,
+                         (const T *)vi, n, i > 0 ? (const T *)(hsup + i - 1) : nullptr, parts);
+      if (int rc = complete(parts)) return rc;
+      hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, wcur, (const T *)vi, n, (const T *)parts, np, hdiag + i,
+                         partsB);
+      if (int rc = complete(partsB)) return rc;
+      hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)wcur, n, (const T *)(partsB), np,
+                         (const T *)(hdiag + i), (const T *)scal, hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
+    }
     if (i >= checkConvergenceSteps && capturing) {
       set_last_error("[Lanczos] the solver cannot run inside a stream capture: its convergence checks need the host between launches");
       return -24;
@@ -608,6 +674,16 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       // (k_l_estimate_batch), and the run still stops at the FIRST iteration whose error passes — with that iteration's estimate, the
       // reference's result and iteration count.  A run that would have stopped earlier than predicted has done a few iterations for
       // nothing; one that needs more goes on checking every iteration.
+      if (getenv("UAMMD_LANCZOS_DUMP")) {
+        std::vector<T> dbg(2 * cap + 2);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(dbg.data(), scal, sizeof(T) * (2 * cap + 1), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lanczos dump] i=%d normz=%g hdiag:", i, (double)dbg[0]);
+        for (int k = 0; k <= i; ++k) fprintf(stderr, " %g", (double)dbg[1 + k]);
+        fprintf(stderr, " hsup:");
+        for (int k = 0; k <= i; ++k) fprintf(stderr, " %g", (double)dbg[1 + cap + k]);
+        fprintf(stderr, "\n");
+      }
       if (i < evalAt) continue;
       const int K = i - checkFrom + 1, m = i + 1, m0 = checkFrom + 1;   // checks of iterations checkFrom .. i, Krylov sizes m0 .. m
       if (!L->hostStat) {

@@ -9,6 +9,7 @@
 // M_near v is a sparse matrix-vector product: (M v)_i = sum_j F(r) v_j + (G(r) - F(r)) (r.v_j) r / r^2 over the 27 cells,
 // F and G read from a table of 2^14..2^22 real2 points.  The reference gathers v_j through the group index for every
 // neighbour (getInfo); here v is gathered ONCE into cell order (same values, contiguous with the positions).
+#include "lanczos_fused.hpp"
 #include "celllist.hpp"
 #include "saru.hpp"
 
@@ -561,6 +562,109 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__r
   }
 }
 
+// The same product as one iteration of the Lanczos recurrence (lanczos_fused.hpp).  v_i = wPrev / hsup_(i-1) is not formed before the
+// product: the pair sums run on wPrev as it is and the ROW's sum is scaled by 1 / hsup_(i-1) afterwards (M (w / h) = (M w) / h to
+// rounding) — so nothing in the kernel waits for the norm: the |wPrev|^2 partials are requested first and summed, in lanczos.hip's
+// order (k_l_c: the breakdown guard, e1 when the norm vanishes — then the sums are redone on e1), after the pair loop.  The rows' v_i
+// and, one workgroup, hsup_(i-1) are written on the way; then w = M v_i - hsup_(i-1) v_(i-1) for the workgroup's rows and ONE partial of
+// w . v_i per workgroup (k_l_a).  Vectors in cell order, stride 3.  (First form, measured: norm first, every v_j scaled as it is read —
+// the product waited a round trip and two barriers before its first record, 13.4 -> ~24 us, the step 0.547 -> 0.562 ms.)
+__global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const float4 *__restrict__ recA, const float2 *__restrict__ recB,
+                                                                        const int2 *__restrict__ pairRange, int N, LanczosFusedArgs a) {
+  __shared__ float sh[16];
+  const int sub = threadIdx.x & (kNearGroup - 1);
+  const int block = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int id = block * (kNearBlock / kNearGroup) + threadIdx.x / kNearGroup;
+  const bool active = id < N;
+  const bool scaled = a.wPrev != nullptr;
+  const float *vsrc = scaled ? a.wPrev : a.viDirect;
+  struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+  // everything the tail needs is requested up front: the norm's partials (npB <= 256: one per thread), the row's own vectors
+  const float pb = (scaled && (int)threadIdx.x < a.npB) ? a.partsB[threadIdx.x] : 0.f;
+  const float hsGiven = (!scaled && a.hsupPrev) ? *a.hsupPrev : 0.f;   // (v_i came from k_l_c: its hsup is in memory)
+  const float hd = scaled ? *a.hdiagPrev : 0.f, nz = scaled ? *a.normz : 1.f;
+  const int2 rg = active ? pairRange[id] : make_int2(0, 0);
+  const V3 zero3{0.f, 0.f, 0.f};
+  const V3 own = active ? *(const V3 *)(vsrc + 3 * (size_t)id) : zero3;
+  const V3 vp = (active && a.vPrev) ? *(const V3 *)(a.vPrev + 3 * (size_t)id) : zero3;
+  auto pair_sums = [&](bool e1, float &tx, float &ty, float &tz) __attribute__((always_inline)) {
+    tx = ty = tz = 0.f;
+    constexpr int U = 4;
+    for (int k0 = sub; k0 < rg.y; k0 += U * kNearGroup) {
+      float4 ra[U];
+      float2 rb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * kNearGroup;
+        const bool in = k < rg.y;
+        ra[u] = in ? recA[(size_t)rg.x + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[u] = in ? recB[(size_t)rg.x + k] : make_float2(0.f, __int_as_float(id));
+      }
+      V3 vj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = __float_as_int(rb[u].y);
+        if (e1) vj[u] = V3{(j == 0 && a.ownsFirstElement) ? 1.f : 0.f, 0.f, 0.f};
+        else vj[u] = *(const V3 *)(vsrc + 3 * (size_t)j);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const real3f rij{ra[u].z, ra[u].w, rb[u].x};
+        const float gm = ra[u].y * dot3(rij, real3f{vj[u].x, vj[u].y, vj[u].z});
+        tx += fmaf(gm, rij.x, ra[u].x * vj[u].x);
+        ty += fmaf(gm, rij.y, ra[u].x * vj[u].y);
+        tz += fmaf(gm, rij.z, ra[u].x * vj[u].z);
+      }
+    }
+    static_assert(kNearGroup == 8, "eight lanes per particle");
+    auto group_sum = [](float x) {
+      x += dpp_move<0xB1, 0xf, true>(x);    // quad_perm [1, 0, 3, 2]
+      x += dpp_move<0x4E, 0xf, true>(x);    // quad_perm [2, 3, 0, 1]
+      x += dpp_move<0x141, 0xf, true>(x);   // row_half_mirror
+      return x;
+    };
+    tx = group_sum(tx);
+    ty = group_sum(ty);
+    tz = group_sum(tz);
+  };
+  float tx, ty, tz;
+  pair_sums(false, tx, ty, tz);
+  // hsup_(i-1) (k_l_c): the partials in lanczos.hip's order — thread t holds partial t, the wave sums, (s0 + s2) + (s1 + s3)
+  float hs = hsGiven, inv = 1.f;
+  if (scaled) {
+    const float ws = wave_sum_to_last(pb);
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    hs = sqrtf((sh[0] + sh[2]) + (sh[1] + sh[3]));
+    __syncthreads();
+    if (hs < 1e-3f * hd / nz) hs = 0.f;
+    if (block == 0 && threadIdx.x == 0) *a.hsupPrev = hs;
+    inv = hs > 0.f ? 1.0f / hs : 0.f;
+  }
+  V3 vi = own;
+  if (scaled) {
+    if (hs > 0.f) { vi.x *= inv; vi.y *= inv; vi.z *= inv; tx *= inv; ty *= inv; tz *= inv; }
+    else {   // breakdown: v_i = e1 (k_l_c), the sums again on it (wave-uniform, rare)
+      vi = V3{(id == 0 && a.ownsFirstElement) ? 1.f : 0.f, 0.f, 0.f};
+      pair_sums(true, tx, ty, tz);
+    }
+  }
+  // the row's v_i (written out when this kernel made it), w = M v_i - hsup_(i-1) v_(i-1), the partial of w . v_i (k_l_a)
+  float part = 0.f;
+  if (active && sub == 0) {
+    if (scaled && a.viOut) { float *o = a.viOut + 3 * (size_t)id; o[0] = vi.x; o[1] = vi.y; o[2] = vi.z; }
+    float wx = tx, wy = ty, wz = tz;
+    if (a.vPrev) { wx = fmaf(-hs, vp.x, wx); wy = fmaf(-hs, vp.y, wy); wz = fmaf(-hs, vp.z, wz); }
+    float *o = a.wOut + 3 * (size_t)id;
+    o[0] = wx; o[1] = wy; o[2] = wz;
+    part = fmaf(wz, vi.z, fmaf(wy, vi.y, wx * vi.x));
+  }
+  part = wave_sum_to_last(part);
+  if ((threadIdx.x & 63) == 63) sh[4 + (threadIdx.x >> 6)] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partsA[block] = (sh[4] + sh[6]) + (sh[5] + sh[7]);
+}
+
 // ---- AUTO where the table has its packed copy: one WAVE per cell, candidates staged in LDS ------------------------------------------------
 // k_pse_near8 still issues ~150 global load instructions per wave (a candidate load per scan step, position + v + two table reads per
 // hit) and every 64-lane load costs the CU's one address unit ~16 clocks whatever it fetches: 59 us at N = 1e5.  All particles of a cell
@@ -893,6 +997,24 @@ static int pse_lanczos_dot_sorted(void *ctx, const float *d_v, float *d_Mv, int 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the sorted product as a fused Lanczos iteration (lanczos_fused.hpp): only on the pair-record path, declines otherwise
+static int pse_lanczos_fused(void *ctx, LanczosFusedArgs *a, int n, void *stream) {
+  (void)n;
+  PSENear *p = static_cast<PSENear *>(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  const int N = p->N;
+  if (!(p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1)) return 1;
+  const bool ahead = p->optimistic && p->pairsPending && !p->pairsValid;
+  if (!p->pairsValid && !ahead) { if (int e = pse_build_pairs(p, st)) return e; }
+  if (!(p->pairsValid || ahead)) return 1;
+  const int nb = (N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup);
+  if (nb > a->partsACap || a->npB > kNearBlock) return 1;
+  a->npA = nb;
+  hipLaunchKernelGGL(k_pse_near_pairs_lanczos, dim3(nb), dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr, (const float2 *)p->recB.ptr,
+                     (const int2 *)p->pairRange.ptr, N, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- BDHI::Lanczos: dense open-boundary RPY mobility, matrix free (Integrator/BDHI/BDHI_Lanczos.cu:56-118, BDHI.cuh:27-96) ----
 UH_D void rpy_different_sizes(float M0, float r, float ai, float aj, float &c1, float &c2) {
   const float asum = ai + aj;
@@ -1057,6 +1179,7 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   if (std::string(name) == "optimistic_records") { p->optimisticRecords = value != 0; return 0; }
   if (std::string(name) == "pair_capacity" && value >= 0) { p->pairCapFirst = (size_t)value; p->pairCap = 0; p->pairsValid = false; p->pairsPending = false; return 0; }
   if (std::string(name) == "defer_checks") return uammd_lanczos_set_option(p->lanczos, "defer_checks", value);
+  if (std::string(name) == "fuse_recurrence") return uammd_lanczos_set_option(p->lanczos, "fuse_recurrence", value);
   if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
   if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
@@ -1190,8 +1313,12 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
     hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
                        noise_prefactor, p->seed, seed2);
     UH_CHECK(hipGetLastError());
-    return uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
-                             p->tolerance, 3 * N, stream, &it);
+    // (the pair-record product also runs the recurrence's neighbours: two launches per iteration instead of four, lanczos_fused.hpp)
+    if (int e = lanczos_set_fused(p->lanczos, &pse_lanczos_fused, p)) return e;
+    const int rcRun = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
+                                        p->tolerance, 3 * N, stream, &it);
+    (void)lanczos_set_fused(p->lanczos, nullptr, nullptr);
+    return rcRun;
   };
   // the records' counters are read after the solve instead of before it (PSENear::optimisticRecords)
   const bool records = p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1;
