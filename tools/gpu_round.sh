@@ -13,6 +13,9 @@ timeout 300 tools/prof_any.sh fcm_c4 tools/time_fcm.py > /dev/null 2>&1
 N=200000 NC=256 timeout 300 tools/prof_any.sh fcm_c5 tools/time_fcm.py > /dev/null 2>&1
 MELT=100 timeout 300 tools/prof_any.sh build tools/time_build.py > gpurun_out/time_build.log 2>&1
 timeout 400 tools/pmc_traffic.sh lj_traversal k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
-timeout 400 tools/pmc_traffic.sh fcm_step k_fcm_spread,k_fcm_gather,k_fcm_prep,k_fcm_bin,k_fcm_tile,k_fcm_euler,k_fft_ --workload fcm --fcm-steps 20 --no-cpu-baseline --no-c5 > /dev/null 2>&1
+timeout 400 tools/pmc_traffic.sh fcm_step k_fcm_spread,k_fcm_gather,k_fcm_step,k_fcm_prep,k_fcm_bin,k_fcm_tile,k_fcm_update,k_fcm_euler,k_fft_ --workload fcm --fcm-steps 20 --no-cpu-baseline --no-c5 > /dev/null 2>&1
 timeout 400 tools/pmc_any.sh lj_tile k_lj_tile4 --workload lj --steps 20 --warmup 10 --equilibrate 100 --no-cpu-baseline > /dev/null 2>&1
+timeout 500 python bench.py --force-distributed --workload lj --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/bench_slab_world1_lj.json 2>/dev/null
+timeout 500 python bench.py --force-distributed --workload fcm --fcm-steps 100 --no-cpu-baseline > gpurun_out/bench_slab_world1_fcm.json 2>/dev/null
+timeout 400 tools/pmc_any.sh fcm_spread k_fcm_spread --workload fcm --fcm-steps 20 --no-cpu-baseline --no-c5 > /dev/null 2>&1
 ls gpurun_out
