@@ -186,7 +186,7 @@ def test_stale_parameter_table_is_reported_not_computed(hip, o32):
     before = f.clone()
     big = hip.Potential.LJ()
     big.setPotParameters(0, 0, big.InputPairParameters(2.5, 1.0, 1.0, False))
-    tbl.copy_(big.device_table())                      # same pointer, longer cut-off
+    tbl.copy_(torch.from_numpy(big.table.copy()).cuda())   # same pointer, longer cut-off, and nobody told the library (uammd_lj_table_changed)
     cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)
     torch.cuda.synchronize()
     assert torch.equal(f, before)                      # nothing was accumulated
@@ -296,7 +296,7 @@ def test_tile_parameter_table_rewritten_in_place_is_caught(hip, o32):
     torch.cuda.synchronize()
     other = hip.Potential.LJ()
     other.setPotParameters(0, 0, other.InputPairParameters(rc, 0.8, 2.0, False))
-    tbl.copy_(other.device_table())                               # same pointer, other units
+    tbl.copy_(torch.from_numpy(other.table.copy()).cuda())        # same pointer, other units, unannounced (no uammd_lj_table_changed)
     f.zero_()
     cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # launched as "unit": the kernel refuses
     torch.cuda.synchronize()
@@ -308,3 +308,38 @@ def test_tile_parameter_table_rewritten_in_place_is_caught(hip, o32):
     cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # table read again: the general instantiation, right forces
     torch.cuda.synchronize()
     _check_force(f.cpu().numpy(), ref, "after the table was re-read", reordered=True)
+
+
+def test_parameter_table_rewritten_in_place_and_announced_is_followed(hip, o32):
+    """Round 5 (ADVICE r04): Potential::LJ::setPotParameters between steps re-uploads into the SAME device buffer (legal in the reference,
+    Potential.cuh:60-82).  Both host layers announce it (uammd_lj_table_changed): the list then reads its cached view of the table again
+    and the traversal computes with the new parameters at once — other units (the reduced-units instantiation is dropped) and a longer
+    cut-off — with no error raised."""
+    from uammd_amd._lib import check, load
+    n, L, rc = 20000, 30.0, 2.5
+    pos, box, pot = _setup(hip, o32, n, L, rc)          # sigma = epsilon = 1
+    d_pos = torch.from_numpy(pos).cuda()
+    cl = hip.CellList()
+    cdd, ubox = hip.CellList.create_update_grid(box, rc)
+    cl.update_grid(d_pos, ubox, cdd)
+    tbl = pot.device_table()
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)        # caches: unit table at this pointer
+    other = hip.Potential.LJ()
+    other.setPotParameters(0, 0, other.InputPairParameters(rc, 0.8, 2.0, False))
+    tbl.copy_(torch.from_numpy(other.table.copy()).cuda())        # same pointer, other units ...
+    check(load().uammd_lj_table_changed())                        # ... announced
+    f.zero_()
+    cl.transverse_lj(tbl, 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    cl.check_errors()
+    (ref, _, _), _ = _oracle(o32, pos, box, other, rc)
+    _check_force(f.cpu().numpy(), ref, "after an announced rewrite", reordered=True)
+    # the host mirror's own path: the same Potential object changed between two traversals
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.1, 0.5, False))
+    f.zero_()
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    cl.check_errors()
+    (ref, _, _), _ = _oracle(o32, pos, box, pot, rc)
+    _check_force(f.cpu().numpy(), ref, "after setPotParameters between traversals", reordered=True)
