@@ -626,3 +626,39 @@ def test_fcm_step_slot_layout(hip, cells, n, cluster):
         moved = np.abs(b[:, :3] - pos[:, :3]).max()
         assert np.abs(a[:, :3] - b[:, :3]).max() <= 2e-5 * moved + 4 * np.spacing(np.float32(L.max()))
         assert np.array_equal(a[:, 3], pos[:, 3])
+
+
+def test_fcm_slot_layout_survives_a_relayout_of_the_callers_arrays(hip):
+    """The slot layout's entry order is an index permutation left by the last sorted solve.  A caller that re-lays its arrays out with
+    the same N (ParticleData::sortParticles, a compaction after migration) changes which particle an index means: the results must not
+    care (the order only decides which particles share a wave), and the library notices the scrambled order by itself (tile changes
+    along the entry sequence, reported by the spread) and goes through the sorted layout again — here only the results are checked:
+    the same solves on a handle with the slot layout off."""
+    cells, n = (64, 64, 64), 30000
+    L = np.asarray(cells, np.float32)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    rng = np.random.default_rng(3)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    perms = [np.arange(n)] + [rng.permutation(n) for _ in range(3)]
+
+    def run(slots):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        fcm.set_option("slots", 1 if slots else 0)
+        out = []
+        for rep in range(8):                       # the same particles, laid out four ways, two solves each
+            p = perms[rep // 2]
+            dp, df = torch.from_numpy(pos[p]).cuda(), torch.from_numpy(force[p]).cuda()
+            v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+            back = np.empty_like(v)
+            back[p] = v
+            out.append(back)
+        return out
+    a, b = run(True), run(False)
+    scale = np.abs(b[0]).max()
+    for x, y in zip(a, b):
+        assert np.abs(x - y).max() <= 2e-5 * scale
+    for x in a[1:]:
+        assert np.abs(x - a[0]).max() <= 2e-5 * scale   # and the layout of the caller's arrays changes nothing

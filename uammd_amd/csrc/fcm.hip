@@ -60,9 +60,9 @@ struct FcmPrep {
   unsigned long long *rec;   // entry (21 bits) | particle << 21 | packed origin << 42
   int *ovfTile;     // int[N]: the tile of overflow record k
   int cap;          // 0: the compact layout above
-  int *slotCount;   // int[ntiles + 1]: this solve's tile populations, [ntiles] = overflow records
+  int *slotCount;   // int[ntiles + 2]: this solve's tile populations, [ntiles] = overflow records, [ntiles + 1] = tile changes along the entry sequence
   int *slotCountNext;  // the other parity's counters: the spread hands them to the next update kernel zeroed
-  int *slotFlag;    // host-mapped: set when the overflow list is long enough to cost time
+  int *slotFlag;    // host-mapped: [0] set when the overflow list is long enough to cost time, [1] = the last solve's tile changes along its entries
   const float4 *forceById;  // the caller's force array (slot layout: forces are fetched for the LISTED particles only)
 };
 
@@ -89,7 +89,7 @@ struct FCM {
   bool tileCountZero = false;       // prepTileCount holds zeros (k_fcm_tile_scan leaves it so)
   // slot layout (FcmPrep::cap > 0): uammd_fcm_step_euler_maruyama's update kernel prepares the NEXT solve completely (k_fcm_step_prep)
   DeviceBuffer prepRec, prepOvfTile, prepSlotCount;
-  bool slotsEnabled = true;         // option "slots"
+  bool slotsEnabled = !(getenv("UAMMD_FCM_SLOTS") && atoi(getenv("UAMMD_FCM_SLOTS")) == 0);   // option "slots" (environment: A/B runs of programs that do not set options)
   int slotCap = 0;                  // records per tile
   int slotParity = 0;               // which half of prepSlotCount the pending preparation counted into
   bool slotPending = false;         // origin / weights / rec / counters hold the preparation of slotPos (k_fcm_step_prep)
@@ -401,6 +401,17 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
   }
   int got = 0;
   if (head && lane == lead) got = atomicAdd(&pr.slotCount[t], cnt);
+  // how well the entries' order still follows the tiles (it is only an index permutation: a caller that re-lays its arrays out — a
+  // sort, a compaction after migration — scrambles it without anybody noticing, and the gather's windows stop sharing cache lines:
+  // 31 -> 77 us at C4).  Tile changes between consecutive entries of a wave: ~ntiles for a sorted order, ~N for a scrambled one;
+  // the host compares (fcm_prepare_best) and goes through the sorted layout again when it is the latter.
+  // (SAMPLED: one wave in 64 counts — thousands of atomics on one address serialise in the L2: with every wave counting the kernel
+  // went from 13 to ~60 us — and the host scales the count back)
+  if ((blockIdx.x & 15) == 0 && threadIdx.x < 64) {
+    const int tPrev = __shfl_up(t, LANES, 64);
+    const unsigned long long changes = __ballot(head && lane >= LANES && t != tPrev);
+    if (lane == 0 && changes) atomicAdd(&pr.slotCount[ntiles.x * ntiles.y * ntiles.z + 1], (int)__popcll(changes));
+  }
   // ... and while it is on its way: the stencil
   const int3 P = compute_support_shift(grid, pi, celli, kern.support);
   const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
@@ -555,7 +566,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       pr.slotCountNext[tile] = 0;  // are zeroed here for the update kernel that follows this solve
       if (tile == 0) {
         pr.slotCountNext[numTiles] = 0;
+        pr.slotCountNext[numTiles + 1] = 0;
         if (e - s > 2048) pr.slotFlag[0] = 1;  // (tell the host: the overflow list is long enough to cost time)
+        pr.slotFlag[1] = pr.slotCount[numTiles + 1];  // ... and how scrambled the entries' order is
       }
     }
     rInfo[nb] = make_int2(s - (incl - (e - s)), myShift);
@@ -1820,7 +1833,52 @@ int uammd_fcm_export_fourier(uammd_fcm *h, float *d_out6, void *stream) {
 // half: 0 = the whole solve; 1 = its first half (binning, stencils, spreading, the forward x / y transforms), 2 = the second (z transform,
 // operator and noise, inverse transforms, gather) of a solve whose first half was queued on the same stream with the same arguments —
 // for a caller with other work to queue in between (uammd_pse_far_displacements_half)
+// The stencils of a solve, the cheapest way that applies: (1) the previous step's update kernel prepared it (k_fcm_step_prep) and the
+// caller vouches that the array is untouched; (2) nobody prepared it but an earlier solve of these N particles left an entry order:
+// the same kernel without the update, ONE launch instead of k_fcm_bin_count -> k_fcm_tile_scan -> k_fcm_prepare (every slotRefresh-th
+// solve goes through the sorted layout again: the entries' order is what keeps the gather's windows local); (3) the sorted layout.
+// *slots says which layout `pr` describes (the spread kernel's template argument).
 static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, float dt, hipStream_t st, int *rc);
+// the spread of the last slot-layout solve reported how many tile changes its entry sequence had (FcmPrep::slotFlag[1]; read without
+// a wait: a solve or two late is soon enough)
+static bool fcm_entries_scrambled(FCM *f, int N) {
+  if (!f->slotFlagHost) return false;
+  const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+  const long changes = 64L * ((volatile int *)f->slotFlagHost)[1];   // (one wave in 64 counted)
+  if (changes <= (long)std::max(4 * nt, N / 4)) return false;
+  f->slotFlagHost[1] = 0;
+  return true;
+}
+static int fcm_prepare_best(FCM *f, const float *d_pos, const float *d_force, int N, hipStream_t st, bool positionsKept, FcmPrep *out,
+                            bool *slotsOut) {
+  bool slots = f->slotPending && !f->tileGather && positionsKept && f->slotPos == (const void *)d_pos && f->slotN == N && f->prepStreamSet &&
+               f->prepStream == st;
+  // (a pending preparation is used whatever its order: it is correct, and the step's update kernel looks at the order itself)
+  const bool scrambled = !slots && fcm_entries_scrambled(f, N);
+  if (f->slotPending && !slots) f->slotDirty = true;  // dropped: its counters are garbage now
+  f->slotPending = false;
+  if (!slots && !scrambled && f->slotsEnabled && !f->tileGather && f->orderN == N && f->prepStreamSet && f->prepStream == st) {  // (k_fcm_gather_tile walks compact tile ranges)
+    int rc = 0;
+    if (fcm_step_prep_launch(f, const_cast<float *>(d_pos), nullptr, N, 0.0f, st, &rc)) {
+      if (rc) return rc;
+      slots = true;
+      f->slotPending = false;
+    }
+  }
+  *slotsOut = slots;
+  if (!slots) return fcm_prepare_tiles(f, d_pos, d_force, N, st, out, positionsKept);
+  const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
+  int *counts = (int *)f->prepSlotCount.ptr;
+  *out = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (unsigned long long *)f->prepRec.ptr,
+                 (int *)f->prepOvfTile.ptr, f->slotCap, counts + (size_t)f->slotParity * (nt + 2),
+                 counts + (size_t)(f->slotParity ^ 1) * (nt + 2), f->slotFlagDev, (const float4 *)d_force};
+  f->binnedPending = false;
+  // (no forces: no spread to hand the other parity's counters back zeroed)
+  if (!d_force) UH_CHECK(hipMemsetAsync(out->slotCountNext, 0, sizeof(int) * (size_t)(nt + 2), st));
+  return 0;
+}
+
 static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float *d_force, int N, float temperature,
                                   float prefactor, float *d_linearVelocity, int stage, void *stream, bool positionsKept, int half = 0) {
   if (!h) { set_last_error("uammd_fcm_displacements: null argument"); return -1; }
@@ -1844,33 +1902,7 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
     pr = f->halfPrep;
     f->halfPending = false;
   } else if (tiles) {
-    // the previous step's update kernel prepared this solve (k_fcm_step_prep): usable when the caller vouches that the array is untouched
-    slots = f->slotPending && !f->tileGather && positionsKept && f->slotPos == (const void *)d_pos && f->slotN == N && f->prepStreamSet && f->prepStream == st;
-    if (f->slotPending && !slots) f->slotDirty = true;  // dropped: its counters are garbage now
-    f->slotPending = false;
-    if (!slots && f->slotsEnabled && !f->tileGather && f->orderN == N && f->prepStreamSet && f->prepStream == st) {  // (k_fcm_gather_tile walks compact tile ranges)
-      // nobody prepared this solve: the same kernel without the update (binning + stencils + records in ONE launch instead of
-      // k_fcm_bin_count -> k_fcm_tile_scan -> k_fcm_prepare), in the entry order an earlier solve of these N particles left;
-      // every slotRefresh-th solve goes through the sorted layout again (the entries' order is what keeps the gather's windows local)
-      int rc = 0;
-      if (fcm_step_prep_launch(f, const_cast<float *>(d_pos), nullptr, N, 0.0f, st, &rc)) {
-        if (rc) return rc;
-        slots = true;
-        f->slotPending = false;
-      }
-    }
-    if (slots) {
-      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      int *counts = (int *)f->prepSlotCount.ptr;
-      pr = FcmPrep{(int4 *)f->prepOrigin.ptr, (float *)f->prepWeights.ptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (unsigned long long *)f->prepRec.ptr,
-                   (int *)f->prepOvfTile.ptr, f->slotCap,
-                   counts + (size_t)f->slotParity * (nt + 1), counts + (size_t)(f->slotParity ^ 1) * (nt + 1), f->slotFlagDev,
-                   (const float4 *)d_force};
-      f->binnedPending = false;
-      // (no forces: no spread to hand the other parity's counters back zeroed)
-      if (!d_force) UH_CHECK(hipMemsetAsync(pr.slotCountNext, 0, sizeof(int) * (size_t)(nt + 1), st));
-    } else if (int e = fcm_prepare_tiles(f, d_pos, d_force, N, st, &pr, positionsKept)) return e;
+    if (int e = fcm_prepare_best(f, d_pos, d_force, N, st, positionsKept, &pr, &slots)) return e;
   }
   if (half != 2) f->lastSolveSlots = slots;  // (the second half of a solve reads what the first half prepared)
   if (d_force && half != 2) {
@@ -1971,6 +2003,7 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
     return false;
   }
   if (f->slotSteps >= f->slotRefresh) { f->slotSteps = 0; return false; }
+  if (v && fcm_entries_scrambled(f, N)) return false;   // (the step's update kernel: the compact layout's, so that the next solve sorts)
   const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
   const double mean = (double)N / nt;
   const int cap = std::max(32, ((int)(3.0 * mean) + 16 + 7) & ~7);
@@ -1980,13 +2013,14 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   if (!f->slotFlagHost) {
     if (hipHostMalloc((void **)&f->slotFlagHost, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
     f->slotFlagHost[0] = 0;
+    f->slotFlagHost[1] = 0;
     if (hipHostGetDevicePointer((void **)&f->slotFlagDev, f->slotFlagHost, 0) != hipSuccess) { (void)hipGetLastError(); f->slotsEnabled = false; return false; }
   }
-  if (f->prepRec.cap < recBytes || f->prepOvfTile.cap < sizeof(int) * (size_t)N || f->slotCap != cap || f->prepSlotCount.cap < sizeof(int) * 2 * ((size_t)nt + 1)) {
+  if (f->prepRec.cap < recBytes || f->prepOvfTile.cap < sizeof(int) * (size_t)N || f->slotCap != cap || f->prepSlotCount.cap < sizeof(int) * 2 * ((size_t)nt + 2)) {
     if (hipStreamSynchronize(st) != hipSuccess) return fail(-1);
     if (int e = f->prepRec.reserve(recBytes)) return fail(e);
     if (int e = f->prepOvfTile.reserve(sizeof(int) * (size_t)N)) return fail(e);
-    if (int e = f->prepSlotCount.reserve(sizeof(int) * 2 * ((size_t)nt + 1))) return fail(e);
+    if (int e = f->prepSlotCount.reserve(sizeof(int) * 2 * ((size_t)nt + 2))) return fail(e);
     f->slotCap = cap;
     f->slotDirty = true;
   }
@@ -1994,7 +2028,7 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   int parity;
   if (f->lastSolveSlots && !f->slotDirty) parity = f->slotParity ^ 1;  // (the spread of the solve above zeroed these)
   else {
-    if (hipMemsetAsync(counts, 0, sizeof(int) * 2 * ((size_t)nt + 1), st) != hipSuccess) return fail(-1);
+    if (hipMemsetAsync(counts, 0, sizeof(int) * 2 * ((size_t)nt + 2), st) != hipSuccess) return fail(-1);
     f->slotDirty = false;
     parity = 0;
   }
@@ -2006,7 +2040,7 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   pr.rec = (unsigned long long *)f->prepRec.ptr;
   pr.ovfTile = (int *)f->prepOvfTile.ptr;
   pr.cap = cap;
-  pr.slotCount = counts + (size_t)parity * (nt + 1);
+  pr.slotCount = counts + (size_t)parity * (nt + 2);
 #define UH_STEP_PREP(K)                                                                                                                        \
   case K:                                                                                                                                      \
     if (N <= kPrepLanesUpTo)                                                                                                                   \
@@ -2167,12 +2201,18 @@ int uammd_fcm_slab_spread(uammd_fcm_slab *h, const float *d_posLocal, const floa
   if (N <= 0) return 0;
   FcmPrep pr{};
   if (tiles) {
-    if (int e = fcm_prepare_tiles(f, d_posLocal, d_force, N, st, &pr)) return e;
+    bool slots = false;
+    if (int e = fcm_prepare_best(f, d_posLocal, d_force, N, st, false, &pr, &slots)) return e;
+    f->lastSolveSlots = slots;
     if (d_force) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
-      hipLaunchKernelGGL(k_fcm_spread_tile<4>, dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad, f->planeReal, zs,
-                         f->kern.support, f->ntiles, pr, ww);
+      if (slots)
+        hipLaunchKernelGGL((k_fcm_spread_tile<4, true>), dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad,
+                           f->planeReal, zs, f->kern.support, f->ntiles, pr, ww);
+      else
+        hipLaunchKernelGGL((k_fcm_spread_tile<4, false>), dim3(nt), dim3(256), spread_lds_bytes(ww), st, d_grid, f->grid.cellDim, f->nxpad,
+                           f->planeReal, zs, f->kern.support, f->ntiles, pr, ww);
     }
   } else if (d_force) {
     const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
