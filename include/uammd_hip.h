@@ -702,6 +702,18 @@ int uammd_comm_halo_exchange(uammd_comm *h, const float *d_sendUp, int nUp, cons
                              int nFromDown, float *d_recvFromUp, int nFromUp, int floatsPerRow, void *stream);
 int uammd_comm_exchange_counts(uammd_comm *h, const int toUpDown[2], int fromDownUp[2], void *stream);
 int uammd_comm_exchange_counts_device(uammd_comm *h, const int *d_toUpDown, int all4[4], void *stream);
+/* The membership refresh of a slab step in ONE call — the sequence above as uammd_amd/parallel.py (DistributedLJ) and
+ * include/uammd/Distributed.h run it: displacement since the last refresh (when refRows == n; d_ref / d_maxDisplacement nullable),
+ * leavers selected, the sizes to and from the two neighbours (host read 1), migration rows packed, exchanged (8 floats per row) and
+ * dropped into the holes, forces of the owned rows zeroed, halo members selected with `reach` = rc + 3 skin, their sizes (host read 2),
+ * positions packed with the frame shift and received straight into rows [n, n + ghosts) of d_pos, d_ref <- d_pos.
+ * d_idx: int[4][capRows] (leavers up / down, halo up / down: rows 2 and 3 are the cached membership lists of the steps until the next
+ * refresh); d_rows, d_arrivals: float[capRows][8]; d_send: float[capRows][4]; d_counts: int[4]; d_holes: int[capRows];
+ * d_selectWorkspace: uammd_slab_select_workspace(capRows) bytes.  comm == NULL: a world of one in process.
+ * out = {owned rows, owned + ghosts, halo up, halo down, ghosts from below, from above, left up, left down, arrived from below, above}. */
+int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_ids, float *d_force, int n, int capRows, float width, float reach,
+                          int *d_idx, int *d_holes, int *d_counts, void *d_selectWorkspace, float *d_rows, float *d_arrivals, float *d_send,
+                          float *d_ref, int refRows, float *d_maxDisplacement, int out[10], void *stream);
 int uammd_comm_alltoall(uammd_comm *h, const void *d_send, void *d_recv, size_t bytesPerPeer, void *stream);
 int uammd_comm_allreduce_sum(uammd_comm *h, float *d_buf, int n, void *stream);
 

@@ -304,6 +304,72 @@ int uammd_slab_max_displacement(const float *d_pos, const float *d_ref, int n, f
   return 0;
 }
 
+// The whole membership refresh of a slab step as ONE library call (the kernels above + the communicator's entry points in the order
+// DistributedLJ runs them): who leaves, the migration rows there and back, who is in the halo, the ghosts into the tail of the position
+// array, the skin check's displacement and its new reference.  Two host reads (the message sizes: they size the launches that follow)
+// and nothing between the launches but this function — from Python the same sequence was ~270 us of host per refresh, most of it the
+// interpreter between twelve launches.  comm == NULL: a world of one in process (what goes up arrives from below).
+int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_ids, float *d_force, int n, int capRows, float width, float reach,
+                          int *d_idx, int *d_holes, int *d_counts, void *d_selectWorkspace, float *d_rows, float *d_arrivals, float *d_send,
+                          float *d_ref, int refRows, float *d_maxDisplacement, int out[10], void *stream) {
+  if (!d_pos || !d_vel || !d_ids || !d_force || !d_idx || !d_holes || !d_counts || !d_selectWorkspace || !d_rows || !d_arrivals || !d_send ||
+      !out || n < 0 || capRows < n) {
+    set_last_error("uammd_slab_refresh_lj: bad arguments");
+    return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int *idxUp = d_idx, *idxDown = d_idx + capRows, *haloUp = d_idx + 2 * (size_t)capRows, *haloDown = d_idx + 3 * (size_t)capRows;
+  const float half = 0.5f * width;
+  if (d_ref && d_maxDisplacement && refRows == n && n > 0)
+    if (int e = uammd_slab_max_displacement(d_pos, d_ref, n, d_maxDisplacement, stream)) return e;
+  // ---- who leaves ----
+  if (int e = uammd_slab_select(d_pos, n, half, -half, idxUp, idxDown, d_counts, d_selectWorkspace, stream)) return e;
+  int c4[4] = {0, 0, 0, 0};   // {to up, to down, from down, from up}
+  auto sizes = [&](const int *d_two) -> int {
+    if (comm) return uammd_comm_exchange_counts_device(comm, d_two, c4, stream);
+    UH_CHECK(hipMemcpyAsync(c4, d_two, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    UH_CHECK(hipStreamSynchronize(st));
+    c4[2] = c4[0]; c4[3] = c4[1];
+    return 0;
+  };
+  if (int e = sizes(d_counts)) return e;
+  const int nUp = c4[0], nDown = c4[1], nFromDown = c4[2], nFromUp = c4[3];
+  const int nLeave = nUp + nDown, nArrive = nFromDown + nFromUp;
+  if (nLeave > capRows || nArrive > capRows) { set_last_error("uammd_slab_refresh_lj: migration overflows the exchange buffer"); return -2; }
+  if (nLeave || nArrive) {
+    float *sendUp = d_rows, *sendDown = d_rows + 8 * (size_t)nUp;
+    if (int e = uammd_slab_pack_rows(d_pos, d_vel, d_ids, idxUp, nUp, idxDown, nDown, -width, width, nUp ? sendUp : nullptr,
+                                     nDown ? sendDown : nullptr, stream)) return e;
+    const float *arrivals = d_rows;   // in process: [from down | from up] = [send up | send down]
+    if (comm) {
+      if (int e = uammd_comm_halo_exchange(comm, sendUp, nUp, sendDown, nDown, d_arrivals, nFromDown, d_arrivals + 8 * (size_t)nFromDown, nFromUp, 8,
+                                           stream)) return e;
+      arrivals = d_arrivals;
+    }
+    if (n - nLeave + nArrive > capRows) { set_last_error("uammd_slab_refresh_lj: migration overflows the particle buffers"); return -2; }
+    if (int e = uammd_slab_unpack_rows(d_pos, d_vel, d_ids, n, idxUp, nUp, idxDown, nDown, arrivals, nArrive, d_holes, stream)) return e;
+    n = n - nLeave + nArrive;
+  }
+  if (n > 0) UH_CHECK(hipMemsetAsync(d_force, 0, sizeof(float) * 4 * (size_t)n, st));   // (arrivals and moved rows: the half step zeroed the old layout)
+  // ---- who is in the halo ----
+  if (int e = uammd_slab_select(d_pos, n, half - reach, -half + reach, haloUp, haloDown, d_counts + 2, d_selectWorkspace, stream)) return e;
+  if (int e = sizes(d_counts + 2)) return e;
+  const int hUp = c4[0], hDown = c4[1], gFromDown = c4[2], gFromUp = c4[3];
+  if (n + gFromDown + gFromUp > capRows) { set_last_error("uammd_slab_refresh_lj: the halo overflows the position buffer"); return -2; }
+  float *tailDown = d_pos + 4 * (size_t)n, *tailUp = d_pos + 4 * (size_t)(n + gFromDown);
+  if (comm) {
+    float *outUp = d_send, *outDown = d_send + 4 * (size_t)hUp;
+    if (int e = uammd_halo_pack(d_pos, haloUp, hUp, haloDown, hDown, -width, width, outUp, outDown, stream)) return e;
+    if (int e = uammd_comm_halo_exchange(comm, outUp, hUp, outDown, hDown, tailDown, gFromDown, tailUp, gFromUp, 4, stream)) return e;
+  } else {
+    if (int e = uammd_halo_pack(d_pos, haloUp, hUp, haloDown, hDown, -width, width, tailDown, tailUp, stream)) return e;
+  }
+  if (d_ref && n > 0) UH_CHECK(hipMemcpyAsync(d_ref, d_pos, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+  out[0] = n; out[1] = n + gFromDown + gFromUp; out[2] = hUp; out[3] = hDown; out[4] = gFromDown; out[5] = gFromUp;
+  out[6] = nUp; out[7] = nDown; out[8] = nFromDown; out[9] = nFromUp;
+  return 0;
+}
+
 int uammd_slab_add2(float *d_dst0, const float *d_src0, float *d_dst1, const float *d_src1, size_t count, void *stream) {
   return slab_pair(true, d_dst0, d_src0, d_dst1, d_src1, count, stream);
 }

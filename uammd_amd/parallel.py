@@ -16,6 +16,7 @@ Local frame: rank r works in coordinates z' = z - zc_r (zc_r = slab centre, peri
 slab), with a local box (Lx, Ly, slab + 2 rc) that is periodic in x, y and NOT periodic in z.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -488,6 +489,30 @@ class DistributedLJ:
             self._slab_ws = ws
         idx, counts = ws["idx"], ws["counts"]
         p = lambda t: C.c_void_p(t.data_ptr())
+        if (d.comm is not None or d.world == 1) and os.environ.get("UAMMD_SLAB_REFRESH", "c") == "c" and self.integrate_rows_fn is None:
+            # the whole refresh as ONE library call (uammd_slab_refresh_lj: the same kernels and messages in the same order, two host
+            # reads, no interpreter between the launches)
+            if "arrivals" not in ws:
+                ws["arrivals"] = torch.empty((cap, 8), dtype=torch.float32, device=dev)
+                ws["send"] = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+            out = (C.c_int * 10)()
+            use_ref = d.skin > 0
+            had_ref = use_ref and ws["ref_n"] == n
+            _lib.check(lib.uammd_slab_refresh_lj(d.comm.h if d.comm is not None else None, p(bp), p(bv), p(bi), p(bf), n, cap, d.width,
+                                                 d.rc + 3.0 * d.skin, p(idx), p(ws["holes"]), p(counts), p(ws["tiles"]), p(ws["rows"]),
+                                                 p(ws["arrivals"]), p(ws["send"]), p(ws["ref"]) if use_ref else None, ws["ref_n"],
+                                                 p(ws["maxd"]) if use_ref else None, out, st))
+            if had_ref:
+                self.max_drift = ws["maxd"][0]
+            n, nall, h_up, h_down, g_from_down, g_from_up = (int(x) for x in out[:6])
+            iu, idn = idx[2][:h_up], idx[3][:h_down]
+            d._halo_cache = (iu, idn, g_from_down, g_from_up)
+            d._idx32 = (iu, idn, iu)
+            self._nall = nall
+            self._split = None
+            if use_ref:
+                ws["ref_n"] = n
+            return n
         if d.skin > 0 and ws["ref_n"] == n:
             _lib.check(lib.uammd_slab_max_displacement(p(bp), p(ws["ref"]), n, p(ws["maxd"]), st))
             self.max_drift = ws["maxd"][0]
