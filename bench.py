@@ -790,9 +790,30 @@ def run_lj_distributed(hip, args, world, rank, dist):
                                            keys.shape[0] if rows is None else rows.shape[0], dt, 1.0, 0, noise,
                                            step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def pack_step1(p, v, f, keys, iu, nu, idn, nd, dzu, dzd, ou, od, step_num):
+        """the first half step of the listed rows on the way into the halo messages (uammd_halo_pack_gj1)"""
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.uammd_halo_pack_gj1(P(p), P(v), P(f), None, 1.0, P(keys), P(iu), nu, P(idn), nd, dzu, dzd, P(ou), P(od), dt, 1.0, 0, noise,
+                                      step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def forces_step12_into(allpos, box_L, periodic, fall, v, keys, skip, step_num):
+        """... of everybody else inside the list build (uammd_celllist_update_gj1), then the traversal with the second half step"""
+        key = (tuple(box_L), tuple(periodic))
+        if key not in grid_cache:
+            box = hip.Box(box_L, periodic)
+            grid_cache[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        box, cd, ubox = grid_cache[key]
+        cl.update_grid_gj1(allpos, ubox, cd, v, fall, keys, skip, sim.n_owned, dt, 1.0, 0, noise, step_num, 4242)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, args.algo)
+
+    no_gj2 = os.environ.get("UAMMD_BENCH_NO_GJ2") == "1"
+    overlap = os.environ.get("UAMMD_BENCH_OVERLAP") == "1"
+    fuse1 = not no_gj2 and not overlap and os.environ.get("UAMMD_BENCH_NO_GJ1") != "1"
     sim = DistributedLJ(d, forces_fn, integrate_fn, exchange_every=args.exchange_every, forces_into=forces_into,
-                        forces_step2_into=None if os.environ.get("UAMMD_BENCH_NO_GJ2") == "1" else forces_step2_into,
-                        integrate_rows_fn=integrate_rows_fn if os.environ.get("UAMMD_BENCH_OVERLAP") == "1" else None)
+                        forces_step2_into=None if no_gj2 else forces_step2_into,
+                        integrate_rows_fn=integrate_rows_fn if overlap else None,
+                        step1_fused=(pack_step1, forces_step12_into) if fuse1 else None)
     # (UAMMD_BENCH_OVERLAP=1: the halo exchange on a side stream behind the half step of the unlisted particles.  Bit-identical
     # (tests/test_gpu_slab_lj.py) and, at a world of one, SLOWER — 0.289 against 0.255 ms: the half step fills the chip, so only RCCL's
     # 12 us kernel can hide, and the two cross-stream waits cost 6 + 15 us; DESIGN 7.  Off by default.)
@@ -830,7 +851,10 @@ def run_lj_distributed(hip, args, world, rank, dist):
                           # Basic.cu:12-29: the first steps of the warm-up out-run a skin sized for the equilibrated liquid)
     cl.profile_enable(True)
     global SLAB_STEP
-    SLAB_STEP = {"second_half_step": "in the traversal's store (uammd_lj_transverse_celllist_gj2)" if sim.forces_step2_into is not None
+    SLAB_STEP = {"first_half_step": "listed rows in the halo pack (uammd_halo_pack_gj1), the others in the list build's hash kernel "
+                                    "(uammd_celllist_update_gj1); own kernel on the refresh steps" if sim.step1_fused is not None
+                 else "own kernel (uammd_verletnvt_gj_keyed)",
+                 "second_half_step": "in the traversal's store (uammd_lj_transverse_celllist_gj2)" if sim.forces_step2_into is not None
                  else "own kernel (uammd_verletnvt_gj_keyed)",
                  "halo_exchange": "on a side stream behind the half step of the unlisted particles" if sim.integrate_rows_fn is not None
                  else "on the step's stream, between the first half step and the list build",

@@ -84,6 +84,23 @@ int uammd_celllist_check_errors(uammd_celllist *h, void *stream);
  * d_outUp[k] = pos[idxUp[k]] + (0, 0, dzUp), d_outDown[k] = pos[idxDown[k]] + (0, 0, dzDown) — in one launch. */
 int uammd_halo_pack(const float *d_pos, const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown,
                     float *d_outUp, float *d_outDown, void *stream);
+/* The decomposed step with GronbechJensen's first half step (Integrator/VerletNVT/GronbechJensen.cu:86-116) folded into the two
+ * kernels that read the positions anyway, instead of a launch of its own before the exchange:
+ *   uammd_halo_pack_gj1: the half step of every LISTED row (noise keyed by d_keys[row], the global particle id; force zeroed), then
+ *     uammd_halo_pack of the new positions.  The up and down lists must be disjoint (a slab wider than two reaches): a row in both
+ *     would take the half step twice.
+ *   uammd_celllist_update_gj1: uammd_celllist_update over rows [0, numberParticles) = owned + ghosts, the half step applied, as the
+ *     rows are loaded, to the owned rows [0, numberOwned) with d_skip[row] == 0 (d_skip: one byte per owned row, the listed rows —
+ *     uammd_slab_refresh_lj writes it; NULL: nobody is skipped).  The list is built from the new positions; forces of the
+ *     integrated rows are zeroed.  Bit-identical to uammd_verletnvt_gj_keyed(1, ...) followed by the plain calls. */
+int uammd_halo_pack_gj1(float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass, const int *d_keys,
+                        const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown, float *d_outUp,
+                        float *d_outDown, float dt, float friction, int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed,
+                        void *stream);
+int uammd_celllist_update_gj1(uammd_celllist *h, float *d_pos, int numberParticles, const float L[3], const int periodic[3],
+                              const int cellDim[3], float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                              const int *d_keys, const unsigned char *d_skip, int numberOwned, float dt, float friction, int is2D,
+                              float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream);
 /* The bookkeeping of a membership refresh of the slab decomposition (uammd_amd/csrc/slab.hip):
  *   uammd_slab_select: ASCENDING indices of the rows with z >= zUp (d_idxUp) and with z < zDown (d_idxDown), their numbers in
  *     d_counts[0..1] (device memory; the caller reads them to size its messages); d_workspace: uammd_slab_select_workspace(n) bytes;
@@ -710,10 +727,11 @@ int uammd_comm_exchange_counts_device(uammd_comm *h, const int *d_toUpDown, int 
  * d_idx: int[4][capRows] (leavers up / down, halo up / down: rows 2 and 3 are the cached membership lists of the steps until the next
  * refresh); d_rows, d_arrivals: float[capRows][8]; d_send: float[capRows][4]; d_counts: int[4]; d_holes: int[capRows];
  * d_selectWorkspace: uammd_slab_select_workspace(capRows) bytes.  comm == NULL: a world of one in process.
+ * d_listedMask (nullable, capRows bytes): 1 for the owned rows that are in a halo list, 0 for the others.
  * out = {owned rows, owned + ghosts, halo up, halo down, ghosts from below, from above, left up, left down, arrived from below, above}. */
 int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_ids, float *d_force, int n, int capRows, float width, float reach,
                           int *d_idx, int *d_holes, int *d_counts, void *d_selectWorkspace, float *d_rows, float *d_arrivals, float *d_send,
-                          float *d_ref, int refRows, float *d_maxDisplacement, int out[10], void *stream);
+                          float *d_ref, int refRows, float *d_maxDisplacement, unsigned char *d_listedMask, int out[10], void *stream);
 int uammd_comm_alltoall(uammd_comm *h, const void *d_send, void *d_recv, size_t bytesPerPeer, void *stream);
 int uammd_comm_allreduce_sum(uammd_comm *h, float *d_buf, int n, void *stream);
 

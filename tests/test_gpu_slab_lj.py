@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 sim_box = []   # the last simulation _run built (for assertions on which path it took)
 
 
-def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, comm=None, overlap=False, step2=False):
+def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, comm=None, overlap=False, step2=False, fuse1=False, aggregate_hash=True, keyed_plain=False):
     from uammd_amd._lib import check, load
     from uammd_amd.parallel import DistributedLJ, SlabDecomposition
     lib = load()
@@ -30,6 +30,8 @@ def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, com
     pot = hip.Potential.LJ()
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
     cl = hip.CellList()
+    if not aggregate_hash:
+        cl.set_option("aggregate_hash", 0)
     cache = {}
 
     def forces_into(allpos, box_L, periodic, fall):
@@ -62,12 +64,30 @@ def _run(hip, n, L, steps, fused, exchange_every=5, skin=0.3, algo=0, T=1.0, com
         cl.set_option("num_owned", sim.n_owned)
         cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, algo)
 
+    def pack_step1(p, v, f, keys, iu, nu, idn, nd, dzu, dzd, ou, od, step_num):
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.uammd_halo_pack_gj1(P(p), P(v), P(f), None, 1.0, P(keys), P(iu), nu, P(idn), nd, dzu, dzd, P(ou), P(od), dt, 1.0, 0, noise,
+                                      step_num, 4242, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def forces_step12_into(allpos, box_L, periodic, fall, v, keys, skip, step_num):
+        key = (tuple(box_L), tuple(periodic))
+        if key not in cache:
+            box = hip.Box(box_L, periodic)
+            cache[key] = (box,) + tuple(hip.CellList.create_update_grid(box, rc))
+        box, cd, ubox = cache[key]
+        cl.update_grid_gj1(allpos, ubox, cd, v, fall, keys, skip, sim.n_owned, dt, 1.0, 0, noise, step_num, 4242)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, algo)
+        sim.fused1_steps = getattr(sim, "fused1_steps", 0) + 1
+
+    if (fuse1 or keyed_plain) and comm is None:   # (the noise keyed by the global id in the unfused steps too)
+        integrate_fn = lambda step, p, v, f, step_num: keyed(step, p, v, f, None, sim.current_ids, p.shape[0], step_num)
     if comm is not None:   # the bench's configuration: thermostat keyed by the global id, every message through uammd_comm_*
         integrate_fn = lambda step, p, v, f, step_num: keyed(step, p, v, f, None, sim.current_ids, p.shape[0], step_num)
     sim = DistributedLJ(d, None, integrate_fn, exchange_every=exchange_every, forces_into=forces_into,
                         forces_step2_into=forces_step2_into if step2 else None,
                         integrate_rows_fn=(lambda step, p, v, f, rows, keys, step_num: keyed(step, p, v, f, rows, keys, keys.shape[0] if rows is None else rows.shape[0], step_num))
-                        if overlap else None)
+                        if overlap else None, step1_fused=(pack_step1, forces_step12_into) if fuse1 else None)
     sim_box.append(sim)
     if not fused:
         sim._refresh_fused = None   # _refresh_persistent falls through to the generic path
@@ -109,6 +129,35 @@ def test_overlapped_exchange_and_fused_half_step_are_bit_identical(hip):
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
     assert sorted(a[2].tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("through_comm,aggregate_hash,algo", [(True, True, 0), (False, True, 0), (False, False, 0), (False, True, 9)])
+def test_first_half_step_in_the_pack_and_the_list_build_is_bit_identical(hip, through_comm, aggregate_hash, algo):
+    """The slab step with GronbechJensen's first half step folded into the halo pack (listed rows: uammd_halo_pack_gj1) and into the list
+    build's hash kernel (everybody else: uammd_celllist_update_gj1 with the listed rows masked), second half step in the traversal's
+    store — against the plain sequence of five calls: same rows, same bits, with noise, across membership refreshes.  Also where the
+    build does not carry the half step in its hash kernel (aggregate_hash off: one masked launch first) and through the exact kernel."""
+    from uammd_amd.comm import AbiComm
+    n, L = 30000, 33.5
+    comm = AbiComm(0, 1, AbiComm.unique_id()) if through_comm else None
+    try:
+        a = _run(hip, n, L, 23, fused=True, comm=comm, step2=False, fuse1=False, algo=algo)
+        if comm is None:   # the plain run's noise keyed by the global id as well
+            a = _run_keyed_plain(hip, n, L, 23, algo)
+        b = _run(hip, n, L, 23, fused=True, comm=comm, step2=True, fuse1=True, aggregate_hash=aggregate_hash, algo=algo)
+        assert getattr(sim_box[-1], "fused1_steps", 0) >= 15, "the fused first half step did not run"
+    finally:
+        if comm is not None:
+            comm.close()
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert sorted(a[2].tolist()) == list(range(n))
+
+
+def _run_keyed_plain(hip, n, L, steps, algo):
+    """_run's plain sequence with the thermostat keyed by the global id (what fuse1's unfused refresh steps use)."""
+    return _run(hip, n, L, steps, fused=True, algo=algo, keyed_plain=True)
 
 
 def test_fused_refresh_equals_generic_refresh(hip):

@@ -138,7 +138,10 @@ SIGNATURES = {
     "uammd_gather": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uammd_scatter": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uammd_lj_table_changed": (_i, []),
-    "uammd_slab_refresh_lj": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "uammd_slab_refresh_lj": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "uammd_halo_pack_gj1": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _f, _f, _i, _f, C.c_uint, C.c_uint, _vp]),
+    "uammd_celllist_update_gj1": (_i, [_vp, _vp, _i, _f3, _i3, _i3, _vp, _vp, _vp, _f, _vp, _vp, _i, _f, _f, _i, _f, C.c_uint, C.c_uint,
+                                      _vp]),
     "uammd_lj_process_pair_parameters": (_i, [_f, _f, _f, _i, C.POINTER(LJPairParameters)]),
     "uammd_lj_transverse_celllist": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _vp, _i, _vp]),
     "uammd_lj_transverse_celllist_gj2": (_i, [_vp, _vp, _i, _f3, _i3, _vp, _vp, _vp, _f, _f, _i, _i, _vp]),

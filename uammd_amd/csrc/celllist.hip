@@ -145,18 +145,20 @@ __global__ void __launch_bounds__(kBlock) k_hash_agg(float4 *__restrict__ pos, i
   if (GJ1) {
     float3 v[kAggPerThread];
     float4 f4[kAggPerThread];
+    const int nRows = gj.nRows > 0 ? min(gj.nRows, N) : N;   // (rows beyond are ghosts: hashed, not integrated)
 #pragma unroll
     for (int u = 0; u < kAggPerThread; ++u) {
-      const int i = min(base + u * kBlock + (int)threadIdx.x, N - 1);
+      const int i = min(base + u * kBlock + (int)threadIdx.x, nRows - 1);
       v[u] = make_float3(gj.vel[3 * (size_t)i], gj.vel[3 * (size_t)i + 1], gj.vel[3 * (size_t)i + 2]);
       f4[u] = gj.force[i];
     }
 #pragma unroll
     for (int u = 0; u < kAggPerThread; ++u) {
       const int i = base + u * kBlock + threadIdx.x;
-      if (i < N) {
+      if (i < nRows && !(gj.skip && gj.skip[i])) {
         const float invMass = 1.0f / (gj.defaultMass > 0 ? gj.defaultMass : gj.mass[i]);
-        gj_step1(p[u], v[u], f4[u], invMass, gj.dt, gj.friction, gj.noiseAmplitude, gj.is2D, (uint)i, gj.stepNum, gj.seed);
+        gj_step1(p[u], v[u], f4[u], invMass, gj.dt, gj.friction, gj.noiseAmplitude, gj.is2D, gj.keys ? (uint)gj.keys[i] : (uint)i, gj.stepNum,
+                 gj.seed);
         pos[i] = p[u];
         gj.vel[3 * (size_t)i] = v[u].x; gj.vel[3 * (size_t)i + 1] = v[u].y; gj.vel[3 * (size_t)i + 2] = v[u].z;
         if (!gj.keepForce) gj.force[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // (keepForce: the traversal that follows overwrites it)
@@ -491,6 +493,21 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const T *__restrict__ in, co
 
 static inline int nblocks(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
+// GronbechJensen's first half step on the rows [0, nRows) that are not marked in gj.skip, noise keyed by gj.keys[row] (the fallback of
+// uammd_celllist_update_gj1 where the build does not carry the half step in its hash kernel)
+__global__ void __launch_bounds__(kBlock) k_gj1_rows(float4 *__restrict__ pos, int nRows, GJFuse gj) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nRows || (gj.skip && gj.skip[i])) return;
+  float4 p = pos[i];
+  float3 v = make_float3(gj.vel[3 * (size_t)i], gj.vel[3 * (size_t)i + 1], gj.vel[3 * (size_t)i + 2]);
+  const float4 f4 = gj.force[i];
+  const float invMass = 1.0f / (gj.defaultMass > 0 ? gj.defaultMass : gj.mass[i]);
+  gj_step1(p, v, f4, invMass, gj.dt, gj.friction, gj.noiseAmplitude, gj.is2D, gj.keys ? (uint)gj.keys[i] : (uint)i, gj.stepNum, gj.seed);
+  pos[i] = p;
+  gj.vel[3 * (size_t)i] = v.x; gj.vel[3 * (size_t)i + 1] = v.y; gj.vel[3 * (size_t)i + 2] = v.z;
+  if (!gj.keepForce) gj.force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---- CellList ------------------------------------------------------------------------------------
 int CellList::next_valid_cell(int numberParticles, bool *needsClear) {
   // CellListBase::updateCurrentValidCell, CellListBase.cuh:210-230
@@ -686,6 +703,15 @@ int CellList::update(const float4 *d_pos, int numberParticles, const float L[3],
   // Counting-sort build when the key table is comparable to the particle count.
   const bool counting = forceRadix ? false : (nKeys != 0 && (unsigned long long)nKeys <= 8ull * (unsigned long long)N + 4096ull);
   usedCounting = counting;
+  if (gj && !(counting && aggregateHash && N > 0) && (gj->keys || gj->skip || gj->nRows > 0)) {  // the decomposed step's form of the same fallback
+    const int nRows = gj->nRows > 0 ? std::min(gj->nRows, N) : N;
+    if (nRows > 0) {
+      hipLaunchKernelGGL(k_gj1_rows, dim3(nblocks(nRows)), dim3(kBlock), 0, st, const_cast<float4 *>(d_pos), nRows, *gj);
+      UH_CHECK(hipGetLastError());
+    }
+    gjDone = true;
+    gj = nullptr;
+  }
   if (gj && !(counting && aggregateHash && N > 0)) {  // only the aggregated counting build carries the half step inside its hash kernel
     if (N > 0)
       if (int e = uammd_verletnvt_gj(1, (float *)const_cast<float4 *>(d_pos), gj->vel, (float *)gj->force, gj->mass, gj->defaultMass, nullptr,
@@ -999,6 +1025,59 @@ int uammd_halo_pack(const float *d_pos, const int *d_idxUp, int nUp, const int *
                      d_idxDown, nDown, dzUp, dzDown, (float4 *)d_outUp, (float4 *)d_outDown);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+
+// uammd_halo_pack that first applies GronbechJensen's first half step to the rows it packs (each listed row once: the caller's up and
+// down lists are disjoint — a slab wider than two reaches) — the decomposed step then needs no integrator launch of its own before the
+// exchange: the unlisted rows take their half step inside the list build's hash kernel (uammd_celllist_update_gj1 with these rows masked)
+__global__ void __launch_bounds__(kBlock) k_halo_pack_gj1(float4 *__restrict__ pos, const int *__restrict__ idxUp, int nUp,
+                                                          const int *__restrict__ idxDown, int nDown, float dzUp, float dzDown,
+                                                          float4 *__restrict__ outUp, float4 *__restrict__ outDown, GJFuse gj) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nUp + nDown) return;
+  const bool up = t < nUp;
+  const int i = up ? idxUp[t] : idxDown[t - nUp];
+  float4 p = pos[i];
+  float3 v = make_float3(gj.vel[3 * (size_t)i], gj.vel[3 * (size_t)i + 1], gj.vel[3 * (size_t)i + 2]);
+  const float4 f4 = gj.force[i];
+  const float invMass = 1.0f / (gj.defaultMass > 0 ? gj.defaultMass : gj.mass[i]);
+  gj_step1(p, v, f4, invMass, gj.dt, gj.friction, gj.noiseAmplitude, gj.is2D, gj.keys ? (uint)gj.keys[i] : (uint)i, gj.stepNum, gj.seed);
+  pos[i] = p;
+  gj.vel[3 * (size_t)i] = v.x; gj.vel[3 * (size_t)i + 1] = v.y; gj.vel[3 * (size_t)i + 2] = v.z;
+  gj.force[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  p.z += up ? dzUp : dzDown;
+  if (up) outUp[t] = p; else outDown[t - nUp] = p;
+}
+
+int uammd_halo_pack_gj1(float *d_pos, float *d_vel, float *d_force, const float *d_mass, float defaultMass, const int *d_keys,
+                        const int *d_idxUp, int nUp, const int *d_idxDown, int nDown, float dzUp, float dzDown, float *d_outUp,
+                        float *d_outDown, float dt, float friction, int is2D, float noiseAmplitude, unsigned int stepNum, unsigned int seed,
+                        void *stream) {
+  if (nUp < 0 || nDown < 0 || !d_pos || !d_vel || !d_force) { set_last_error("uammd_halo_pack_gj1: bad arguments"); return -1; }
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_halo_pack_gj1: no mass array and defaultMass <= 0"); return -1; }
+  if (nUp + nDown == 0) return 0;
+  GJFuse gj{d_vel, (float4 *)d_force, d_mass, defaultMass, dt, friction, noiseAmplitude, is2D, stepNum, seed, 0, d_keys, nullptr, 0};
+  hipLaunchKernelGGL(k_halo_pack_gj1, dim3(nblocks(nUp + nDown)), dim3(kBlock), 0, (hipStream_t)stream, (float4 *)d_pos, d_idxUp, nUp,
+                     d_idxDown, nDown, dzUp, dzDown, (float4 *)d_outUp, (float4 *)d_outDown, gj);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// uammd_celllist_update on owned + ghost rows with GronbechJensen's first half step of the owned, unmasked rows applied as they are
+// loaded (k_hash_agg<GJ1>; where the build takes another path, one plain launch first): the new positions are what is hashed.
+int uammd_celllist_update_gj1(uammd_celllist *hh, float *d_pos, int numberParticles, const float L[3], const int periodic[3],
+                              const int cellDim[3], float *d_vel, float *d_force, const float *d_mass, float defaultMass,
+                              const int *d_keys, const unsigned char *d_skip, int numberOwned, float dt, float friction, int is2D,
+                              float noiseAmplitude, unsigned int stepNum, unsigned int seed, void *stream) {
+  if (!hh || !d_pos || !d_vel || !d_force || numberOwned < 0 || numberOwned > numberParticles) {
+    set_last_error("uammd_celllist_update_gj1: bad arguments");
+    return -1;
+  }
+  if (!d_mass && !(defaultMass > 0)) { set_last_error("uammd_celllist_update_gj1: no mass array and defaultMass <= 0"); return -1; }
+  CellList *h = reinterpret_cast<CellList *>(hh);
+  if (numberOwned == 0) return h->update((const float4 *)d_pos, numberParticles, L, periodic, cellDim, (hipStream_t)stream, nullptr);
+  const GJFuse gj{d_vel, (float4 *)d_force, d_mass, defaultMass, dt, friction, noiseAmplitude, is2D, stepNum, seed, 0, d_keys, d_skip, numberOwned};
+  return h->update((const float4 *)d_pos, numberParticles, L, periodic, cellDim, (hipStream_t)stream, &gj);
 }
 
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream) {

@@ -16,6 +16,11 @@ struct GJFuse {
   int is2D;
   uint stepNum, seed;
   int keepForce;  // the hash kernel's fused half step leaves the force array alone (the caller's traversal overwrites every entry)
+  // the domain-decomposed step (uammd_celllist_update_gj1): the thermostat's stream keyed by keys[row] (the global particle id) instead of
+  // the row, rows with skip[row] != 0 left alone (the halo pack integrated them before it sent them), rows >= nRows are ghosts
+  const int *keys;             // nullable
+  const unsigned char *skip;   // nullable
+  int nRows;                   // 0: every row
 };
 
 // step 1 for particle i, noise stream id: p, v updated in place; the caller stores them (and zeroes the force)

@@ -309,9 +309,19 @@ int uammd_slab_max_displacement(const float *d_pos, const float *d_ref, int n, f
 // array, the skin check's displacement and its new reference.  Two host reads (the message sizes: they size the launches that follow)
 // and nothing between the launches but this function — from Python the same sequence was ~270 us of host per refresh, most of it the
 // interpreter between twelve launches.  comm == NULL: a world of one in process (what goes up arrives from below).
+}  // extern "C"
+
+__global__ void __launch_bounds__(256) k_mark_listed(const int *__restrict__ up, int nUp, const int *__restrict__ down, int nDown,
+                                                     unsigned char *__restrict__ mask) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nUp + nDown) mask[t < nUp ? up[t] : down[t - nUp]] = 1;
+}
+
+extern "C" {
+
 int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_ids, float *d_force, int n, int capRows, float width, float reach,
                           int *d_idx, int *d_holes, int *d_counts, void *d_selectWorkspace, float *d_rows, float *d_arrivals, float *d_send,
-                          float *d_ref, int refRows, float *d_maxDisplacement, int out[10], void *stream) {
+                          float *d_ref, int refRows, float *d_maxDisplacement, unsigned char *d_listedMask, int out[10], void *stream) {
   if (!d_pos || !d_vel || !d_ids || !d_force || !d_idx || !d_holes || !d_counts || !d_selectWorkspace || !d_rows || !d_arrivals || !d_send ||
       !out || n < 0 || capRows < n) {
     set_last_error("uammd_slab_refresh_lj: bad arguments");
@@ -365,6 +375,13 @@ int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_i
     if (int e = uammd_halo_pack(d_pos, haloUp, hUp, haloDown, hDown, -width, width, tailDown, tailUp, stream)) return e;
   }
   if (d_ref && n > 0) UH_CHECK(hipMemcpyAsync(d_ref, d_pos, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+  if (d_listedMask && n > 0) {   // one byte per owned row: is it in a membership list (uammd_halo_pack_gj1 / uammd_celllist_update_gj1's skip)
+    UH_CHECK(hipMemsetAsync(d_listedMask, 0, (size_t)n, st));
+    if (hUp + hDown > 0) {
+      hipLaunchKernelGGL(k_mark_listed, dim3((hUp + hDown + 255) / 256), dim3(256), 0, st, haloUp, hUp, haloDown, hDown, d_listedMask);
+      UH_CHECK(hipGetLastError());
+    }
+  }
   out[0] = n; out[1] = n + gFromDown + gFromUp; out[2] = hUp; out[3] = hDown; out[4] = gFromDown; out[5] = gFromUp;
   out[6] = nUp; out[7] = nDown; out[8] = nFromDown; out[9] = nFromUp;
   return 0;

@@ -339,6 +339,18 @@ class CellList:
         check(self.lib.uammd_celllist_update(self.h, _ptr(pos), self.N, f3(box.boxSize),
                                              i3([int(p) for p in box.periodic]), i3(cellDim), current_stream()))
 
+    def update_grid_gj1(self, pos, box, cellDim, vel, force, keys, skip, n_owned, dt, friction, is2D, noise, step_num, seed, mass=None,
+                        default_mass=1.0):
+        """uammd_celllist_update_gj1: update_grid over owned + ghost rows with GronbechJensen's first half step of the owned rows that
+        are not marked in `skip` folded into the build's first kernel (keys: the global ids the thermostat's stream is keyed by)."""
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 4
+        self.N = pos.shape[0]
+        self._pos_ref = pos
+        check(self.lib.uammd_celllist_update_gj1(self.h, _ptr(pos), self.N, f3(box.boxSize), i3([int(p) for p in box.periodic]),
+                                                 i3(cellDim), _ptr(vel), _ptr(force), None if mass is None else _ptr(mass),
+                                                 default_mass, _ptr(keys), None if skip is None else _ptr(skip), n_owned, dt, friction,
+                                                 int(is2D), noise, step_num, seed, current_stream()))
+
     def getCellList(self):
         d = CellListData()
         check(self.lib.uammd_celllist_get(self.h, C.byref(d)))

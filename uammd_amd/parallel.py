@@ -197,7 +197,7 @@ class SlabDecomposition:
         self.halo_refill(allpos, n_owned)
         return n_from_down + n_from_up
 
-    def halo_refill(self, allpos, n_owned):
+    def halo_refill(self, allpos, n_owned, pack=None):
         """Between refreshes: rows [0, n_owned) of `allpos` are the owned particles (integrated in place), rows [n_owned, ...)
         the ghosts of the last refresh in the order (from below, from above).  Re-sends the current positions of the listed
         particles and lets the ghosts land in the tail of `allpos` itself: no concatenation, no allocation, nothing
@@ -220,9 +220,12 @@ class SlabDecomposition:
                 out_up, out_down = self._send[0][:n_up], self._send[1][:n_down]
             if getattr(self, "_idx32", None) is None or self._idx32[2] is not idx_up:  # (int32 copies of the lists, once per refresh)
                 self._idx32 = (idx_up.to(torch.int32), idx_down.to(torch.int32), idx_up)
-            _lib.check(lib.uammd_halo_pack(pos.data_ptr(), self._idx32[0].data_ptr(), n_up, self._idx32[1].data_ptr(), n_down,
-                                           -self.width, self.width, out_up.data_ptr(), out_down.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream))
+            if pack is not None:   # the caller's pack (uammd_halo_pack_gj1: the half step of the listed rows on the way)
+                pack(self._idx32[0], n_up, self._idx32[1], n_down, -self.width, self.width, out_up, out_down)
+            else:
+                _lib.check(lib.uammd_halo_pack(pos.data_ptr(), self._idx32[0].data_ptr(), n_up, self._idx32[1].data_ptr(), n_down,
+                                               -self.width, self.width, out_up.data_ptr(), out_down.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
             if loop:
                 return
             send_up, send_down = out_up, out_down
@@ -365,7 +368,7 @@ class DistributedLJ:
     a refresh costs two host reads of message sizes."""
 
     def __init__(self, decomp, forces_fn, integrate_fn, exchange_every=1, forces_into=None, capacity_factor=1.25, forces_step2_into=None,
-                 integrate_rows_fn=None):
+                 integrate_rows_fn=None, step1_fused=None):
         self.d, self.forces_fn, self.integrate_fn, self.forces_into = decomp, forces_fn, integrate_fn, forces_into
         # optional: forces_step2_into(allpos, box_L, periodic, fall, vel) = the forces AND the integrator's second half step of the owned
         # rows in one call (uammd_lj_transverse_celllist_gj2: the half step rides in the traversal's store); persistent mode only
@@ -377,6 +380,14 @@ class DistributedLJ:
         # first, their positions packed and sent on a side stream while the main stream integrates everybody else; the list build waits
         # for the ghosts.  Same arithmetic per particle: same bits as the unsplit step.
         self.integrate_rows_fn = integrate_rows_fn
+        # optional: step1_fused = (pack_step1(pos, vel, force, keys, idx_up, n_up, idx_down, n_down, dz_up, dz_down, out_up, out_down, step_num),
+        #                         forces_step12_into(allpos, box_L, periodic, fall, vel, keys, skip, step_num)):
+        # between refreshes the first half step runs inside the halo pack (the listed rows: uammd_halo_pack_gj1) and inside the list build
+        # (everybody else: uammd_celllist_update_gj1, `skip` = the listed rows' byte mask), the second one in the traversal's store — a
+        # step is pack, exchange, build, traversal on ONE stream.  Needs a slab wider than two reaches (disjoint lists) and the library
+        # refresh (it writes the mask); otherwise the step runs unfused with integrate_fn, which must then be the same arithmetic.
+        self.step1_fused = step1_fused
+        self._listed_mask = None
         self._split = None      # (listed rows, their keys, the other rows, their keys) of the current membership lists
         self._side = None       # side stream + events of the overlapped exchange
         self.steps = 0
@@ -456,6 +467,7 @@ class DistributedLJ:
     def _refresh_persistent(self, n):
         bp, bv, bi, bf = self._bufs
         self._split = None
+        self._listed_mask = None
         if bp.is_cuda and bv.dtype == torch.float32 and bv.dim() == 2 and bv.shape[1] == 3 and bi.dtype == torch.int32 and bi.dim() == 1:
             return self._refresh_fused(n)
         self._track_drift(bp[:n])
@@ -497,11 +509,15 @@ class DistributedLJ:
                 ws["send"] = torch.empty((cap, 4), dtype=torch.float32, device=dev)
             out = (C.c_int * 10)()
             use_ref = d.skin > 0
+            want_mask = self.step1_fused is not None and d.width > 2.0 * (d.rc + 3.0 * d.skin)
+            if want_mask and "listed" not in ws:
+                ws["listed"] = torch.zeros(cap, dtype=torch.uint8, device=dev)
             had_ref = use_ref and ws["ref_n"] == n
             _lib.check(lib.uammd_slab_refresh_lj(d.comm.h if d.comm is not None else None, p(bp), p(bv), p(bi), p(bf), n, cap, d.width,
                                                  d.rc + 3.0 * d.skin, p(idx), p(ws["holes"]), p(counts), p(ws["tiles"]), p(ws["rows"]),
                                                  p(ws["arrivals"]), p(ws["send"]), p(ws["ref"]) if use_ref else None, ws["ref_n"],
-                                                 p(ws["maxd"]) if use_ref else None, out, st))
+                                                 p(ws["maxd"]) if use_ref else None, p(ws["listed"]) if want_mask else None, out, st))
+            self._listed_mask = ws["listed"] if want_mask else None
             if had_ref:
                 self.max_drift = ws["maxd"][0]
             n, nall, h_up, h_down, g_from_down, g_from_up = (int(x) for x in out[:6])
@@ -578,6 +594,15 @@ class DistributedLJ:
         bp, bv, bi, bf = self._bufs
         self.current_ids = bi[:n]
         refresh = (self.steps - 1) % self.exchange_every == 0 or self.d._halo_cache is None
+        if not refresh and self.step1_fused is not None and self._listed_mask is not None:
+            pack_step1, forces_step12_into = self.step1_fused
+            step = self.steps
+            self.d.halo_refill(bp, n, pack=lambda iu, nu, idn, nd, dzu, dzd, ou, od: pack_step1(bp, bv, bf, bi, iu, nu, idn, nd, dzu, dzd,
+                                                                                                ou, od, step))
+            L, per = self.d.local_box()
+            self.n_owned = n
+            forces_step12_into(bp[:self._nall], L, per, bf[:self._nall], bv[:n], bi[:n], self._listed_mask, step)
+            return bp[:n], bv[:n], bf[:n], bi[:n]
         if not refresh and self._split is not None:
             listed, lkeys, rest, rkeys = self._split
             if self._side is None:
@@ -624,6 +649,7 @@ class DistributedLJ:
         self._ref = None
         self._bufs = None
         self._split = None
+        self._listed_mask = None
 
     def check_skin(self):
         """Host check (synchronises): the cached exchange is exact only if nobody out-ran the skin."""
