@@ -47,6 +47,7 @@ struct PSENear {
   bool pairList = true, pairsValid = false, pairsUnfit = false;
   DeviceBuffer recA, recB, pairRange, pairCursor;  // float4 (F, (G - F) / r2, rx, ry) | float2 (rz, j) per record; int2 (first, count) per particle
   size_t pairCap = 0;        // records allocated
+  int pairRegions = 1;       // ... cut into this many regions by the last build (k_pse_pairs_build)
   int *pairTotalHost = nullptr;  // pinned: {records used, a particle overflowed its hit list}
   // a build is two halves: the launch (kernel + copy of the two counters + pairsEvent) and the read of the counters.  A caller with other
   // work for the stream queues it between the two (uammd_pse_near_prepare, then the far field, then the near products): the read then
@@ -222,6 +223,16 @@ __global__ void __launch_bounds__(128) k_pse_near(const float4 *__restrict__ sor
 // the group's byte of the mask).  Drain: lane k evaluates hits k, k + 8, ... exactly as the reference does (sheared_distance with its
 // divisions and roundf, `r2 >= rcut2 -> nothing`, the same table arithmetic), so the SAME pairs contribute the SAME terms; the eight
 // partial sums meet in a 3-step butterfly.  Another summation order: results agree with the walk to rounding (tests: 1e-6 of max|Mv|).
+// k_pse_pairs_build's record space is cut into kPairRegions equal regions, workgroup b reserving in region b % kPairRegions through that
+// region's own cursor (64 bytes apart: status[16 + 16 r]): 3125 returning atomics on ONE address are served one after the other by the
+// memory side (~20 ns each: the whole 64 us of the kernel as it was), 49 on each of 64 addresses are not.
+#ifndef UAMMD_PSE_PAIR_REGIONS
+#define UAMMD_PSE_PAIR_REGIONS 64
+#endif
+constexpr int kPairRegions = UAMMD_PSE_PAIR_REGIONS, kPairStatusInts = 16 + 16 * kPairRegions;
+#ifndef UAMMD_PSE_BUILD_ROWS
+#define UAMMD_PSE_BUILD_ROWS 2
+#endif
 constexpr int kNearGroup = 8, kNearBlock = 256, kNearCap = 96;  // hits a group can hold before it drains (12 KB of LDS per workgroup)
 
 // The sheared minimum image with the image counts from a reciprocal multiplication and round-to-even instead of the reference's
@@ -385,7 +396,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
                                                                  const int *__restrict__ cellEnd, uint validCell, int N, GridT<float> grid,
                                                                  real3f L, float shear, float rcut2, TableView tab, float4 *__restrict__ recA,
                                                                  float2 *__restrict__ recB, int2 *__restrict__ pairRange,
-                                                                 int *__restrict__ status, long long cap) {
+                                                                 int *__restrict__ status, long long cap, int nreg) {
   __shared__ int hitList[kNearBlock / kNearGroup][kNearCap];
   __shared__ int2 ranges[kNearBlock / kNearGroup][29];
   __shared__ int groupCount[kNearBlock / kNearGroup], blockBase;
@@ -438,7 +449,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
   if (sub == 0) ranges[grp][nR] = make_int2(0, total);
   int c = 0, cnt = 0;
   bool over = false;
-  constexpr int kRows = 2;
+  constexpr int kRows = UAMMD_PSE_BUILD_ROWS;
   for (int t0 = 0; __any(t0 < total); t0 += kRows * kNearGroup) {
     int j[kRows];
     float4 pj[kRows];
@@ -473,14 +484,17 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
   if (threadIdx.x == 0) {
     int tot = 0;
     for (int g = 0; g < kNearBlock / kNearGroup; ++g) tot += groupCount[g];
-    blockBase = tot ? atomicAdd(&status[0], tot) : 0;
+    blockBase = tot ? atomicAdd(&status[16 + 16 * (blockIdx.x % nreg)], tot) : 0;
   }
   if (__any(over) && lane == 0) status[1] = 1;
   __syncthreads();
-  long long off = blockBase;
-  for (int g = 0; g < grp; ++g) off += groupCount[g];
-  if (active && sub == 0) pairRange[id] = make_int2((int)off, off + cnt <= cap ? cnt : 0);   // (past the capacity: the host grows the arrays and builds again)
-  if (off + cnt > cap) return;
+  const long long regionCap = cap / nreg;
+  long long inRegion = blockBase;
+  for (int g = 0; g < grp; ++g) inRegion += groupCount[g];
+  const long long off = (long long)(blockIdx.x % nreg) * regionCap + inRegion;
+  const bool fits = inRegion + cnt <= regionCap;   // (past the region's capacity: the host grows the arrays and builds again)
+  if (active && sub == 0) pairRange[id] = make_int2((int)off, fits ? cnt : 0);
+  if (!fits) return;
   for (int k = sub; k < cnt; k += kNearGroup) {
     const int j = hitList[grp][k];
     const real3f rij = scan_rij<SHEAR>(pi, sortPos[j], L, invL, shear);
@@ -882,28 +896,48 @@ static TableView make_view(const PSENear *p);
 // when they do not fit (the build then runs again).
 static int pse_launch_pairs(PSENear *p, hipStream_t st) {
   const int N = p->N;
-  if (!p->pairTotalHost) UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, 2 * sizeof(int)));
+  if (!p->pairTotalHost) UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, kPairStatusInts * sizeof(int)));
   if (!p->pairsEvent) UH_CHECK(hipEventCreateWithFlags(&p->pairsEvent, hipEventDisableTiming));
   if (int e = p->pairRange.reserve(sizeof(int2) * (size_t)N)) return e;
-  if (int e = p->pairCursor.reserve(2 * sizeof(int))) return e;
+  if (int e = p->pairCursor.reserve(kPairStatusInts * sizeof(int))) return e;
   if (p->pairCap < (size_t)N) p->pairCap = p->pairCapFirst ? std::max(p->pairCapFirst, (size_t)N) : (size_t)48 * (size_t)N;
   if (p->pairCap > (size_t)0x7fffff00) { p->pairsUnfit = true; return 0; }   // (record indices are ints)
   if (int e = p->recA.reserve(sizeof(float4) * p->pairCap)) return e;
   if (int e = p->recB.reserve(sizeof(float2) * p->pairCap)) return e;
   const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
   const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));
-  UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, 2 * sizeof(int), st));
+  p->pairRegions = (int)std::min<long long>(kPairRegions, std::max<long long>(1, (long long)gr.x / 8));   // (a small system: fewer, larger regions)
+  UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, kPairStatusInts * sizeof(int), st));
 #define UH_PAIRS(SH)                                                                                                                \
   hipLaunchKernelGGL((k_pse_pairs_build<SH>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                       \
                      (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb,         \
                      p->shear, p->rcut * p->rcut, make_view(p), (float4 *)p->recA.ptr, (float2 *)p->recB.ptr,                       \
-                     (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap)
+                     (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap, p->pairRegions)
   if (p->shear != 0.0f) UH_PAIRS(true); else UH_PAIRS(false);
 #undef UH_PAIRS
-  UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, kPairStatusInts * sizeof(int), hipMemcpyDeviceToHost, st));
   UH_CHECK(hipEventRecord(p->pairsEvent, st));
   p->pairsPending = true;
   return 0;
+}
+// what the build's counters say once its event has completed: the records asked for, and whether every region held its share; if not,
+// the capacity that would have (the fullest region's demand for all of them, + 25 %)
+static long long pse_pairs_total(const PSENear *p) {
+  long long total = 0;
+  for (int r = 0; r < p->pairRegions; ++r) total += p->pairTotalHost[16 + 16 * r];
+  return total;
+}
+static bool pse_pairs_fit(const PSENear *p) {
+  const long long regionCap = (long long)(p->pairCap / p->pairRegions);
+  for (int r = 0; r < p->pairRegions; ++r)
+    if (p->pairTotalHost[16 + 16 * r] > regionCap) return false;
+  return true;
+}
+static void pse_pairs_grow(PSENear *p) {
+  long long worst = 0;
+  for (int r = 0; r < p->pairRegions; ++r) worst = std::max(worst, (long long)p->pairTotalHost[16 + 16 * r]);
+  const long long need = std::max(pse_pairs_total(p), worst * p->pairRegions);
+  p->pairCap = (size_t)(need + need / 4 + p->pairRegions);
 }
 static int pse_build_pairs(PSENear *p, hipStream_t st) {
   for (int attempt = 0; attempt < 4; ++attempt) {
@@ -914,8 +948,8 @@ static int pse_build_pairs(PSENear *p, hipStream_t st) {
     UH_CHECK(hipEventSynchronize(p->pairsEvent));
     p->pairsPending = false;
     if (p->pairTotalHost[1]) { p->pairsUnfit = true; return 0; }   // a particle with more neighbours than a hit list holds: k_pse_near8 from here on
-    if ((size_t)p->pairTotalHost[0] <= p->pairCap) { p->pairsValid = true; return 0; }
-    p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
+    if (pse_pairs_fit(p)) { p->pairsValid = true; return 0; }
+    pse_pairs_grow(p);
   }
   p->pairsUnfit = true;
   return 0;
@@ -1211,7 +1245,7 @@ int uammd_pse_near_prepare(uammd_pse_near *h, const float *d_pos, int N, void *s
 int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long *capacity) {
   if (!h) { set_last_error("uammd_pse_near_pair_records: null handle"); return -1; }
   PSENear *p = reinterpret_cast<PSENear *>(h);
-  if (records) *records = (p->pairsValid && p->pairTotalHost) ? (long long)p->pairTotalHost[0] : 0;
+  if (records) *records = (p->pairsValid && p->pairTotalHost) ? pse_pairs_total(p) : 0;
   if (capacity) *capacity = (long long)p->pairCap;
   return 0;
 }
@@ -1333,10 +1367,10 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   if (ahead && p->pairsPending) {
     UH_CHECK(hipEventSynchronize(p->pairsEvent));
     p->pairsPending = false;
-    if (!p->pairTotalHost[1] && (size_t)p->pairTotalHost[0] <= p->pairCap) p->pairsValid = true;
+    if (!p->pairTotalHost[1] && pse_pairs_fit(p)) p->pairsValid = true;
     else {   // the products of this solve missed pairs: the build again (pse_build_pairs from the first product: larger, or back to the scanning product), the solve again
       if (p->pairTotalHost[1]) p->pairsUnfit = true;
-      else p->pairCap = (size_t)p->pairTotalHost[0] + (size_t)p->pairTotalHost[0] / 4;
+      else pse_pairs_grow(p);
       if (int e = uammd_lanczos_set_schedule(p->lanczos, schedule)) return leave(e);
       rc = solve();
     }
