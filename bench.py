@@ -479,6 +479,8 @@ def run_pse(hip, args):
     integ = hip.BDHI.EulerMaruyama(pd, par, Method=hip.BDHI.PSE)
     integ.addInteractor(FixedForce(pd, torch.from_numpy(force).cuda()))
     pse = integ.bdhi
+    if os.environ.get("UAMMD_PSE_SKIN") is not None:   # (A/B: 0 = a list build per step)
+        check(lib.uammd_pse_near_set_option(pse.near, b"list_skin_percent", int(os.environ["UAMMD_PSE_SKIN"])))
     if os.environ.get("UAMMD_PSE_FUSE") == "0":   # (A/B: the Lanczos recurrence as four launches per iteration instead of two)
         check(lib.uammd_pse_near_set_option(pse.near, b"fuse_recurrence", 0))
     steps, warm = args.pse_steps, 5
@@ -500,6 +502,8 @@ def run_pse(hip, args):
     ms = float(np.median(block_ms))
     steps = nblocks * per_block
     assert np.isfinite(pd.getPos().cpu().numpy()).all()
+    stats = (C.c_longlong * 4)()
+    check(lib.uammd_pse_near_list_stats(pse.near, stats))
     # the parts, each on its own (same state)
     MF = torch.zeros((PSE_N, 3), dtype=torch.float32, device="cuda")
     dforce = torch.from_numpy(force).cuda()
@@ -526,6 +530,8 @@ def run_pse(hip, args):
     return {"metric": "BDHI::PSE steps/s (1e5 particles, L=128, a=1, psi=0.5, tol 1e-3, T=1)", "value": 1e3 / ms, "unit": "steps/s",
             "ms_per_step": ms, "steps": steps, "timed_blocks": {"blocks": nblocks, "steps_each": per_block, "ms_per_step_min": float(min(block_ms)),
                                                                    "ms_per_step_max": float(max(block_ms))}, "lanczos_iterations_mean": k, "lanczos_iterations_minmax": [int(min(its)), int(max(its))],
+            "near_list": {"builds_from_scratch": int(stats[0]), "record_builds_from_kept_candidates": int(stats[1]),
+                          "repeated_builds": int(stats[2]), "kept_lists_on": bool(stats[3]), "steps": warm + steps},
             "config": {"workload": f"BDHI::EulerMaruyama<PSE>: near-field cut-off {pse.rcut:.3f} ({ncell}^3 cells, {cand:.0f} candidates and "
                                    f"{hits:.1f} neighbours per particle), RPY table {pse.nPointsTable} points, far-field grid "
                                    f"{list(pse.cells)}, Gaussian support {pse.support}; fixed forces"},

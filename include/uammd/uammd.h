@@ -1901,7 +1901,8 @@ public:
     const real4 *force = detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st);
     const uint seedFar = pd->getSystem()->rng().next32();
     const uint seedNear = pd->getSystem()->rng().next32();
-    detail::check(uammd_pse_near_prepare(nearField, posRowsPtr, N, (void *)st));
+    // (no uammd_pse_near_prepare here: the solve below starts with the same list and record launches and leaves the copy of the records'
+    // counters to its own noise kernel)
     // the far field in two halves around the check: spreading and forward transforms while the host answers it, the rest while the host
     // reacts to its outcome
     struct Far { uammd_fcm *solver; const float *pos, *force; int N; float T, prefactor; uint seed; float *MF; };

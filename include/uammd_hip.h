@@ -614,6 +614,13 @@ int uammd_pse_near_positions_changed(uammd_pse_near *h);
 int uammd_pse_near_prepare(uammd_pse_near *h, const float *d_pos, int numberParticles, void *stream);
 /* diagnostics: pair records in use (0 while the products scan the cells) and allocated */
 int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long *capacity);
+/* Option "list_skin_percent" (40; with "lazy_list" and "pair_list", no shear): the particle order of a list build and every particle's
+ * candidates within rc + skin (skin = percent / 100 x rc) are KEPT over the following steps; a step then refreshes the sorted positions
+ * and makes its pair records from the candidates alone — exact while nobody has moved more than skin / 2 since the build, which is
+ * measured on the device every step and read with the records' counters (a broken bound repeats the build from scratch, and the solve
+ * that streamed the records).  Same pairs as a build per step, summed in another order.  0 = a list build per step.
+ * uammd_pse_near_list_stats: {builds from scratch, record builds from a kept list, repeated builds, 1 while the mechanism is on}. */
+int uammd_pse_near_list_stats(uammd_pse_near *h, long long out[4]);
 /* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int numberParticles, float *d_MF,
                         void *stream);

@@ -486,3 +486,75 @@ def test_interleaved_work_is_queued_once_on_every_path(hip, o32):
     assert stochastic(1.0, register=False) == 0 and len(calls) == 4
     torch.cuda.synchronize()
     assert order == ["early", "late"] * 4          # the early callback before the late one on every path, each once
+
+
+@pytest.mark.gpu
+def test_kept_candidate_lists_follow_the_particles(hip, o32):
+    """Option "list_skin_percent": the particle order and the candidates within rc + skin of a list build are kept while the particles
+    move, a step refreshes the sorted positions and makes its pair records from the candidates.  Against the ORACLE at every step of a walk
+    of small displacements (deterministic product and the Lanczos noise's iteration count against a twin that builds its list per step),
+    with the counters showing which path ran; then a jump larger than skin / 2: the bound is measured broken on the device, the build and
+    the solve that streamed its records are repeated from a fresh list — the result is the fresh handle's, bit for bit."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n, tol, psi = 40.0, 4000, 1e-3, 0.6
+
+    def stats(pse):
+        s = (C.c_longlong * 4)()
+        check(pse.lib.uammd_pse_near_list_stats(pse.near, s))
+        return [int(x) for x in s]
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+    pd2, twin, _, _, _ = _pair(hip, o32, L, tol, psi, n)
+    check(twin.lib.uammd_pse_near_set_option(twin.near, b"list_skin_percent", 0))
+    assert stats(pse)[3] == 1 and stats(twin)[3] == 0
+    rng = np.random.default_rng(3)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+    skin = 0.4 * pse.rcut
+    walk = np.random.default_rng(11)
+
+    def step(p, handle, positions, seed2):
+        p.getPos("write").copy_(torch.from_numpy(positions).cuda())
+        BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        it = C.c_int(0)
+        check(handle.lib.uammd_pse_near_stochastic(handle.near, _ptr(p.getPos()), n, 1.0, 1.0, seed2, _ptr(BdW), current_stream(), C.byref(it)))
+        MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(handle.lib.uammd_pse_near_mdot(handle.near, _ptr(p.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+        return MF.cpu().numpy(), BdW.cpu().numpy(), it.value
+    cur = pos.copy()
+    for k in range(8):
+        if k:   # every particle moves by at most 0.02 skin per axis: the bound holds for all seven steps
+            cur = cur.copy()
+            cur[:, :3] += walk.uniform(-0.02 * skin, 0.02 * skin, (n, 3)).astype(np.float32)
+        a = step(pd, pse, cur, 500 + k)
+        b = step(pd2, twin, cur, 500 + k)
+        expect = np.zeros((n, 3), np.float32)
+        ref.near_mdot(cur, f4, expect)
+        scale = np.abs(expect).max()
+        assert np.abs(a[0] - expect).max() <= 1e-6 * scale, (k, float(np.abs(a[0] - expect).max() / scale))
+        assert a[2] == b[2] and np.abs(a[1] - b[1]).max() <= 2e-6 * np.abs(b[1]).max(), (k, a[2], b[2])
+    s = stats(pse)
+    assert s[0] == 1 and s[1] == 7 and s[2] == 0, s          # one list from scratch, seven record builds from its candidates, no repeat
+    assert stats(twin)[0] == 8 and stats(twin)[1] == 0
+    # a jump: half the particles move by 0.6 skin along x
+    cur = cur.copy()
+    cur[::2, 0] += 0.6 * skin
+    a = step(pd, pse, cur, 999)
+    s = stats(pse)
+    assert s[2] == 1 and s[0] == 2, s                          # measured broken, repeated from a fresh list
+    pd3, fresh, _, _, _ = _pair(hip, o32, L, tol, psi, n)
+    c = step(pd3, fresh, cur, 999)
+    assert a[2] == c[2] and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    expect = np.zeros((n, 3), np.float32)
+    ref.near_mdot(cur, f4, expect)
+    assert np.abs(a[0] - expect).max() <= 1e-6 * np.abs(expect).max()
+    # positions far outside the primary box image are the same particles: the displacement is measured with the minimum image
+    cur2 = cur.copy()
+    cur2[:100, 1] += L
+    a = step(pd, pse, cur2, 1000)
+    assert stats(pse)[2] == 1 and stats(pse)[1] == s[1] + 1
+    expect = np.zeros((n, 3), np.float32)
+    ref.near_mdot(cur2, f4, expect)
+    assert np.abs(a[0] - expect).max() <= 1e-6 * np.abs(expect).max()

@@ -16,8 +16,9 @@ for f in glob.glob('/tmp/kt_trs/**/*.db', recursive=True):
     for b in (12, 13):
         i0, i1 = builds[b], builds[b + 1]
         # step start = the hash kernel before the build
-        while 'k_hash_agg' not in rows[i0][0]: i0 -= 1
-        while 'k_hash_agg' not in rows[i1][0]: i1 -= 1
+        first = lambda n: 'k_hash_agg' in n or 'k_pse_refresh_sorted' in n
+        while not first(rows[i0][0]): i0 -= 1
+        while not first(rows[i1][0]): i1 -= 1
         t0 = rows[i0][1]; prev_end = t0; gaps = 0.0; busy = 0.0
         print(f"# step from build {b}: {len(rows[i0:i1])} kernels, wall {(rows[i1][1]-t0)/1e3:.1f} us")
         for r in rows[i0:i1]:

@@ -517,7 +517,8 @@ class PSE:
         st = current_stream()
         seed_far = pd.rng.next32()
         seed_near = pd.rng.next32()
-        check(self.lib.uammd_pse_near_prepare(self.near, _ptr(pos), pd.N, st))
+        # (no uammd_pse_near_prepare here: the solve below starts with the same list and record launches, and leaves the copy of the records'
+        # counters to its own noise kernel)
         failed = []
 
         def far_half(half):

@@ -55,6 +55,8 @@ template <class T> struct LanczosT {
   lanczos_fused_fn fused = nullptr;
   void *fusedCtx = nullptr;
   bool fuseRecurrence = true;   // option "fuse_recurrence"
+  const T *zparts = nullptr;    // lanczos_set_znorm_parts (one-shot)
+  int znp = 0;
   DeviceBuffer w2, partsWide, partsB;   // the second w buffer, the product's partials of w . v_i, k_l_b's partials of |w|^2
   // vector sharded over several ranks: every dot product / norm is completed by the caller's all-reduce
   uammd_allreduce_fn reduce = nullptr;   // (single precision only)
@@ -168,10 +170,12 @@ __global__ void __launch_bounds__(kLB) k_l_collapse(T *__restrict__ parts, int n
 template <class T>
 __global__ void __launch_bounds__(kLB) k_l_b(T *__restrict__ w, const T *__restrict__ vi, int n,
                                              const T *__restrict__ partsA, int nparts, T *__restrict__ hdiag_i,
-                                             T *__restrict__ partsB) {
+                                             T *__restrict__ partsB, T *__restrict__ zero = nullptr) {
   __shared__ T sh[16];
   const int i0 = blockIdx.x * kLB + threadIdx.x, stride = gridDim.x * kLB;
   const bool pre = (long)n <= (long)kLPre * stride;   // (the thread's elements are on their way while the partials are summed)
+  if (zero)   // (the run's first k_l_b also clears Bold, the estimate "before the first one": no memset launch)
+    for (int i = i0; i < n; i += stride) zero[i] = T(0);
   T xw[kLPre], xv[kLPre];
   if (pre) {
 #pragma unroll
@@ -470,6 +474,13 @@ static int tridiag_ql(std::vector<double> &d, std::vector<double> &e, std::vecto
 
 using Lanczos = LanczosT<float>;
 static inline int lgrid(int n) { return std::min(kLParts, (n + kLB - 1) / kLB); }
+int lanczos_set_znorm_parts(::uammd_lanczos *h, const float *parts, int np) {
+  if (!h || np < 0 || np > kLParts) { set_last_error("lanczos_set_znorm_parts: bad arguments"); return -1; }
+  Lanczos *L = reinterpret_cast<Lanczos *>(h);
+  L->zparts = parts;
+  L->znp = parts ? np : 0;
+  return 0;
+}
 int lanczos_set_fused(::uammd_lanczos *h, lanczos_fused_fn fn, void *ctx) {
   if (!h) { set_last_error("lanczos_set_fused: null handle"); return -1; }
   Lanczos *L = reinterpret_cast<Lanczos *>(h);
@@ -558,14 +569,14 @@ static bool fused_usable(LanczosT<float> *L) { return L->fused && L->fuseRecurre
 static bool fused_usable(LanczosT<double> *) { return false; }
 static int fused_call(LanczosT<float> *L, const float *wPrev, const float *vi, const float *partsB, int npB, const float *hdiagPrev,
                       const float *normz, float *hsupPrev, float *viOut, const float *vPrev, float *wOut, float *partsA, int partsACap,
-                      int *npA, int n, void *stream) {
-  LanczosFusedArgs a{wPrev, vi, partsB, npB, hdiagPrev, normz, hsupPrev, viOut, L->ownsFirstElement, vPrev, wOut, partsA, partsACap, 0};
+                      int *npA, int n, void *stream, bool first) {
+  LanczosFusedArgs a{wPrev, vi, partsB, npB, hdiagPrev, normz, hsupPrev, viOut, L->ownsFirstElement, vPrev, wOut, partsA, partsACap, 0, first};
   const int rc = L->fused(L->fusedCtx, &a, n, stream);
   *npA = a.npA;
   return rc;
 }
 static int fused_call(LanczosT<double> *, const double *, const double *, const double *, int, const double *, const double *, double *,
-                      double *, const double *, double *, double *, int, int *, int, void *) { return 1; }
+                      double *, const double *, double *, double *, int, int *, int, void *, bool) { return 1; }
 
 template <class T, class MatVec>
 static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *d_v, T tolerance, int n, void *stream, int *iterations) {
@@ -595,10 +606,37 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
     hipLaunchKernelGGL(k_l_collapse<T>, dim3(1), dim3(kLB), 0, st, p, g);
     return L->reduce(L->reduceCtx, (float *)p, 1, stream);   // (reduce is only ever set on the float solver)
   };
-  UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(T) * (size_t)n, st));   // oldBz = 0, :205-206
-  hipLaunchKernelGGL(k_l_norm2<T>, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
-  if (int rc = complete(parts)) return rc;
-  hipLaunchKernelGGL(k_l_first<T>, dim3(g), dim3(kLB), 0, st, d_v, n, (const T *)parts, np, V, scal);
+  // With a fused product the run's first three launches go into their neighbours: the product of iteration 0 makes v_0 = z / |z| in its
+  // prologue (from the partials of |z|^2: the caller's — lanczos_set_znorm_parts — or k_l_norm2's), the first k_l_b zeroes Bold.
+  if (!L->partsB.ptr) { if (int e = L->partsB.reserve(sizeof(T) * kLParts)) return e; }
+  bool v0Pending = fused_usable(L), boldPending = v0Pending;
+  const T *zparts = L->zparts;
+  int znp = L->znp;
+  L->zparts = nullptr;
+  L->znp = 0;
+  auto plain_start = [&]() -> int {
+    if (boldPending) UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(T) * (size_t)n, st));   // oldBz = 0, :205-206
+    boldPending = false;
+    if (!zparts) {
+      hipLaunchKernelGGL(k_l_norm2<T>, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
+      if (int rc = complete(parts)) return rc;
+      zparts = parts;
+      znp = np;
+    }
+    hipLaunchKernelGGL(k_l_first<T>, dim3(g), dim3(kLB), 0, st, d_v, n, zparts, znp, V, scal);
+    v0Pending = false;
+    return 0;
+  };
+  if (v0Pending) {
+    if (!zparts) {
+      hipLaunchKernelGGL(k_l_norm2<T>, dim3(g), dim3(kLB), 0, st, d_v, n, (T *)L->partsB.ptr);
+      zparts = (const T *)L->partsB.ptr;
+      znp = g;
+    }
+  } else {
+    boldPending = true;
+    if (int rc = plain_start()) return rc;
+  }
   const int checkConvergenceSteps = std::min(L->check_convergence_steps, L->iterationHardLimit - 2);
   hipStreamCaptureStatus captureStatus = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(st, &captureStatus) == hipSuccess && captureStatus != hipStreamCaptureStatusNone;
@@ -613,7 +651,6 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
   // just run are still to be made (by the next fused product's prologue, or by k_l_c if that product declines)
   // (|w|^2 partials in a buffer of their own: the fused iteration reads them in the NEXT product's prologue, after a convergence check
   // has used `parts` as its scratch)
-  if (!L->partsB.ptr) { if (int e = L->partsB.reserve(sizeof(T) * kLParts)) return e; }
   T *partsB = (T *)L->partsB.ptr;
   bool vNextPending = false;
   T *wcur = w;
@@ -626,22 +663,27 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       if (!L->partsWide.ptr) { if (int e = L->partsWide.reserve(sizeof(T) * (size_t)wideCap)) return e; }
       T *wnext = wcur == w ? (T *)L->w2.ptr : w;
       int npA = 0;
-      const int rc = fused_call(L, vNextPending ? wcur : nullptr, vi, partsB, np, i > 0 ? hdiag + i - 1 : nullptr, scal,
-                                i > 0 ? hsup + i - 1 : nullptr, vNextPending ? vi : nullptr, i > 0 ? V + (size_t)(i - 1) * n : nullptr,
-                                wnext, (T *)L->partsWide.ptr, wideCap, &npA, n, stream);
+      const bool first = v0Pending;   // (i == 0: z is "the previous w", |z| "the previous hsup")
+      const int rc = fused_call(L, first ? d_v : (vNextPending ? wcur : nullptr), vi, first ? zparts : partsB, first ? znp : np,
+                                i > 0 ? hdiag + i - 1 : nullptr, scal, first ? scal : (i > 0 ? hsup + i - 1 : nullptr),
+                                (first || vNextPending) ? vi : nullptr, i > 0 ? V + (size_t)(i - 1) * n : nullptr, wnext,
+                                (T *)L->partsWide.ptr, wideCap, &npA, n, stream, first);
       if (rc < 0) {
         if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run: the fused matrix-vector product failed (%d)", rc);
         return rc;
       }
       if (rc == 0) {
         wcur = wnext;
+        v0Pending = false;
         hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, wcur, (const T *)vi, n, (const T *)L->partsWide.ptr, npA, hdiag + i,
-                           partsB);
+                           partsB, boldPending ? Bold : (T *)nullptr);
+        boldPending = false;
         vNextPending = true;
         fusedDone = true;
       }
     }
     if (!fusedDone) {
+      if (v0Pending) { if (int rc = plain_start()) return rc; }   // (the product declined at iteration 0)
       if (vNextPending) {   // the previous iteration ran fused and left its last kernel to a product that now declines
         hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)wcur, n, (const T *)(partsB), np,
                            (const T *)(hdiag + i - 1), (const T *)scal, hsup + i - 1, vi, L->ownsFirstElement);

@@ -48,7 +48,11 @@ struct PSENear {
   DeviceBuffer recA, recB, pairRange, pairCursor;  // float4 (F, (G - F) / r2, rx, ry) | float2 (rz, j) per record; int2 (first, count) per particle
   size_t pairCap = 0;        // records allocated
   int pairRegions = 1;       // ... cut into this many regions by the last build (k_pse_pairs_build)
-  int *pairTotalHost = nullptr;  // pinned: {records used, a particle overflowed its hit list}
+  int *pairTotalHost = nullptr;  // pinned, mapped: the build's status block {., hit list overflow, |displacement|^2 bits, candidate overflow, ..., region cursors}
+  int *pairTotalDev = nullptr;   // its device address
+  bool statusCopyDeferred = false;   // the copy of the status block is left to the solve's noise kernel (k_pse_noise_sorted_norm)
+  bool statusZeroed = false;         // k_pse_refresh_sorted has zeroed the status block for the coming build
+  DeviceBuffer zparts;               // |noise|^2 partials of k_pse_noise_sorted_norm
   // a build is two halves: the launch (kernel + copy of the two counters + pairsEvent) and the read of the counters.  A caller with other
   // work for the stream queues it between the two (uammd_pse_near_prepare, then the far field, then the near products): the read then
   // finds the event complete and the GPU busy — waited for on the spot it was a bubble of ~20 us per step
@@ -59,6 +63,26 @@ struct PSENear {
   // kernel then wrote no records for the particles past the capacity — is repeated larger and the solve run again from the same noise,
   // with the solver's adaptive schedule put back.  `optimistic` is set only inside that call.
   bool optimisticRecords = true, optimistic = false;
+  // Candidate lists kept over several steps (option "list_skin_percent", default 40; with "lazy_list" + "pair_list" and no shear).  A
+  // Brownian step moves a particle by a small fraction of the cut-off, and what the list build spends its time on is the 27-cell scan
+  // (~195 candidates per particle for ~29 neighbours at the bench's size) plus the cell list before it.  With skin = percent / 100 x rc:
+  // a full build bins on a grid of rc + skin, and its scan also writes every particle's candidates within rc + skin (k_pse_pairs_build
+  // MODE 1); the steps after it keep the particle ORDER and the candidate lists, refresh the sorted positions (k_pse_refresh_sorted)
+  // and make the records from the candidates alone (MODE 2) — exact as long as nobody has moved more than skin / 2 since the full build,
+  // which the refresh measures and the host reads with the records' counters: a broken bound repeats the build from a fresh list (and,
+  // under "optimistic_records", the solve), exactly as a build that outgrew its arrays.  The host schedules a full build BEFORE the
+  // bound is expected to break (last reading + twice the largest one-step increase seen), so a repeat is the exception.  Lists that
+  // do not survive two steps three times running turn the mechanism off for the handle.  Results: the same pairs, summed in the
+  // candidate list's order instead of the scan's (rounding-level differences).
+  int skinPercent = 40;
+  bool candEnabled = true;    // (auto-off: candShortLived)
+  bool candValid = false;     // candList / candCount / refPos belong to cl's current order
+  bool candBuild = false, candScan = false;   // what the last launched pair build was: MODE 1 / MODE 2 (neither: MODE 0)
+  DeviceBuffer candList, candCount, refPos, dispParts;
+  int candCap = 0, candGrow = 0;
+  int stepsSinceFull = 0, candShortLived = 0;
+  float skin = 0.f, lastDisp = 0.f, maxInc = 0.f;
+  long long fullBuilds = 0, candBuilds = 0, candRepeats = 0;   // diagnostics (uammd_pse_near_pair_records' sibling option reads)
   size_t pairCapFirst = 0;   // option "pair_capacity": the first allocation in records (tests: a build that has to grow); 0 = 48 per particle
   uammd_interleave_fn interleave = nullptr;   // uammd_pse_near_set_interleave (one-shot, handed to the next solve)
   void *interleaveCtx = nullptr;
@@ -230,6 +254,12 @@ __global__ void __launch_bounds__(128) k_pse_near(const float4 *__restrict__ sor
 #define UAMMD_PSE_PAIR_REGIONS 64
 #endif
 constexpr int kPairRegions = UAMMD_PSE_PAIR_REGIONS, kPairStatusInts = 16 + 16 * kPairRegions;
+#ifndef UAMMD_PSE_CAND_ROWS
+#define UAMMD_PSE_CAND_ROWS 2
+#endif
+#ifndef UAMMD_PSE_REC_ROWS
+#define UAMMD_PSE_REC_ROWS 1
+#endif
 #ifndef UAMMD_PSE_BUILD_ROWS
 #define UAMMD_PSE_BUILD_ROWS 2
 #endif
@@ -391,65 +421,100 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near8(const float4 *__restri
 // its 32 particles with one atomic (particle p's run is contiguous: first[p], count[p]); a pair that fails the exact cut-off after
 // passing the scan's keeps its slot with F = C = 0 (adds +0).  A particle with more hits than the list holds (kNearCap) raises
 // status[1]: the host then stays on k_pse_near8 for this handle.
-template <bool SHEAR>
+// MODE 0: as described.  The other two keep a particle's CANDIDATES over several steps (PSENear::skin):
+// MODE 1: the same scan on a grid whose cells are rc + skin wide; the candidates within rc + skin (a second, wider test on the distance the
+//   scan has anyway) are written to candList[id * candCap ...] (their count to candCount[id]; more than candCap: status[3]);
+// MODE 2: no cells — the candidates are the kept list, the positions the refreshed sortPos (k_pse_refresh_sorted): as long as nobody has moved
+//   more than skin / 2 since the list was made every pair inside rc is on it.  Workgroup 0 reduces k_pse_refresh_sorted's per-workgroup
+//   maxima of |displacement|^2 into status[2] (float bits): the host reads it with the counters and repeats the build from a fresh list
+//   if the bound was broken (the same path as a build that outgrew its arrays).
+struct PairCand {
+  int *list;             // [N][cap]
+  int *count;            // [N]
+  int cap;
+  float rcand2;          // (rc + skin)^2, MODE 1
+  const float *dispParts;  // MODE 2
+  int nDispParts;
+};
+template <bool SHEAR, int MODE>
 __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__restrict__ sortPos, const uint *__restrict__ cellStart,
                                                                  const int *__restrict__ cellEnd, uint validCell, int N, GridT<float> grid,
                                                                  real3f L, float shear, float rcut2, TableView tab, float4 *__restrict__ recA,
                                                                  float2 *__restrict__ recB, int2 *__restrict__ pairRange,
-                                                                 int *__restrict__ status, long long cap, int nreg) {
+                                                                 int *__restrict__ status, long long cap, int nreg, PairCand cand) {
   __shared__ int hitList[kNearBlock / kNearGroup][kNearCap];
   __shared__ int2 ranges[kNearBlock / kNearGroup][29];
   __shared__ int groupCount[kNearBlock / kNearGroup], blockBase;
+  __shared__ float dispMax[kNearBlock / 64];
   const int lane = threadIdx.x & 63, sub = threadIdx.x & (kNearGroup - 1), gbase = lane & ~(kNearGroup - 1);
   const int grp = threadIdx.x / kNearGroup;
   const int id = (int)xcd_contiguous_block(blockIdx.x, gridDim.x) * (kNearBlock / kNearGroup) + grp;
   const bool active = id < N;
   const float4 pi = sortPos[active ? id : 0];
-  const int3 n = grid.cellDim;
-  const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
-  const int numberNeighbourCells = npx * npy * npz;
-  const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
   const real3f invL{1.0f / L.x, 1.0f / L.y, 1.0f / L.z};
   const float rcut2s = rcut2 * 1.00001f + 1e-30f;
-  int first4[4], last4[4];
+  int nR = 0, total = 0;
+  if (MODE == 2) {
+    total = active ? cand.count[id] : 0;
+    if (blockIdx.x == 0) {   // (uniform branch: the barrier below is reached by the whole workgroup)
+      float m = 0.0f;
+      for (int k = threadIdx.x; k < cand.nDispParts; k += kNearBlock) m = fmaxf(m, cand.dispParts[k]);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int cc = sub + kNearGroup * q;
-    first4[q] = 0; last4[q] = 0;
-    if (active && cc < numberNeighbourCells) {
-      int3 cellj = celli;
-      if (npx > 1) cellj.x += cc % 3 - 1;
-      if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
-      if (npz > 1) cellj.z += cc / (npx * npy) - 1;
-      cellj.x = grid.pbc_x(cellj.x);
-      cellj.y = grid.pbc_y(cellj.y);
-      cellj.z = grid.pbc_z(cellj.z);
-      if (!(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z)) {
-        const int icellj = grid.getCellIndex(cellj);
-        const uint cs = cellStart[icellj];
-        if (cs >= validCell) { first4[q] = (int)(cs - validCell); last4[q] = cellEnd[icellj]; }
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (lane == 0) dispMax[threadIdx.x / 64] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < kNearBlock / 64; ++w) m = fmaxf(m, dispMax[w]);
+        status[2] = __float_as_int(m);
       }
     }
-  }
-  int nR = 0, total = 0;
+  } else {
+    const int3 n = grid.cellDim;
+    const int npx = n.x > 1 ? 3 : 1, npy = n.y > 1 ? 3 : 1, npz = n.z > 1 ? 3 : 1;
+    const int numberNeighbourCells = npx * npy * npz;
+    const int3 celli = grid.getCell(real3f{pi.x, pi.y, pi.z});
+    int first4[4], last4[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int len = last4[q] - first4[q];
-    int incl = len;
-#pragma unroll
-    for (int o = 1; o < kNearGroup; o <<= 1) {
-      const int u = __shfl_up(incl, o, kNearGroup);
-      if (sub >= o) incl += u;
+    for (int q = 0; q < 4; ++q) {
+      const int cc = sub + kNearGroup * q;
+      first4[q] = 0; last4[q] = 0;
+      if (active && cc < numberNeighbourCells) {
+        int3 cellj = celli;
+        if (npx > 1) cellj.x += cc % 3 - 1;
+        if (npy > 1) cellj.y += (cc / npx) % 3 - 1;
+        if (npz > 1) cellj.z += cc / (npx * npy) - 1;
+        cellj.x = grid.pbc_x(cellj.x);
+        cellj.y = grid.pbc_y(cellj.y);
+        cellj.z = grid.pbc_z(cellj.z);
+        if (!(cellj.x < 0 || cellj.x >= n.x || cellj.y < 0 || cellj.y >= n.y || cellj.z < 0 || cellj.z >= n.z)) {
+          const int icellj = grid.getCellIndex(cellj);
+          const uint cs = cellStart[icellj];
+          if (cs >= validCell) { first4[q] = (int)(cs - validCell); last4[q] = cellEnd[icellj]; }
+        }
+      }
     }
-    const uint mine = (uint)(__ballot(len > 0) >> gbase) & 0xffu;
-    if (len > 0) ranges[grp][nR + __popc(mine & ((1u << sub) - 1u))] = make_int2(first4[q], total + incl - len);
-    nR += __popc(mine);
-    total += __shfl(incl, kNearGroup - 1, kNearGroup);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int len = last4[q] - first4[q];
+      int incl = len;
+#pragma unroll
+      for (int o = 1; o < kNearGroup; o <<= 1) {
+        const int u = __shfl_up(incl, o, kNearGroup);
+        if (sub >= o) incl += u;
+      }
+      const uint mine = (uint)(__ballot(len > 0) >> gbase) & 0xffu;
+      if (len > 0) ranges[grp][nR + __popc(mine & ((1u << sub) - 1u))] = make_int2(first4[q], total + incl - len);
+      nR += __popc(mine);
+      total += __shfl(incl, kNearGroup - 1, kNearGroup);
+    }
+    if (sub == 0) ranges[grp][nR] = make_int2(0, total);
   }
-  if (sub == 0) ranges[grp][nR] = make_int2(0, total);
-  int c = 0, cnt = 0;
+  int c = 0, cnt = 0, ccnt = 0;
   bool over = false;
-  constexpr int kRows = UAMMD_PSE_BUILD_ROWS;
+  // (measured: 2, 3, 4 and 6 rows of the cell scan 65.8-66.6 us — it is bound by its instruction count; 8 rows of the candidate scan and
+  // 4 rounds of records at a time 46.5 against 44.1 us: neither is waiting for its dependent loads)
+  constexpr int kRows = MODE == 2 ? UAMMD_PSE_CAND_ROWS : UAMMD_PSE_BUILD_ROWS;
+  const int *myCand = cand.list + (size_t)(active ? id : 0) * cand.cap;
   for (int t0 = 0; __any(t0 < total); t0 += kRows * kNearGroup) {
     int j[kRows];
     float4 pj[kRows];
@@ -461,21 +526,36 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
       j[u] = 0;
       pj[u] = pi;
       if (in[u]) {
-        while (t >= ranges[grp][c + 1].y) ++c;
-        const int2 r = ranges[grp][c];
-        j[u] = r.x + (t - r.y);
+        if (MODE == 2) j[u] = myCand[t];
+        else {
+          while (t >= ranges[grp][c + 1].y) ++c;
+          const int2 r = ranges[grp][c];
+          j[u] = r.x + (t - r.y);
+        }
         pj[u] = sortPos[j[u]];
       }
     }
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
-      const bool hit = in[u] && scan_distance2<SHEAR>(pi, pj[u], L, invL, shear) < rcut2s;
+      const float d2 = scan_distance2<SHEAR>(pi, pj[u], L, invL, shear);
+      const bool hit = in[u] && d2 < rcut2s;
       const unsigned long long m = __ballot(hit);
       const uint mine = (uint)(m >> gbase) & 0xffu;
       const int at = cnt + __popc(mine & ((1u << sub) - 1u));
       if (hit && at < kNearCap) hitList[grp][at] = j[u];
       cnt += __popc(mine);
+      if (MODE == 1) {
+        const bool chit = in[u] && d2 < cand.rcand2;
+        const uint cmine = (uint)(__ballot(chit) >> gbase) & 0xffu;
+        const int cat = ccnt + __popc(cmine & ((1u << sub) - 1u));
+        if (chit && cat < cand.cap) cand.list[(size_t)id * cand.cap + cat] = j[u];
+        ccnt += __popc(cmine);
+      }
     }
+  }
+  if (MODE == 1) {
+    if (active && sub == 0) cand.count[id] = min(ccnt, cand.cap);
+    if (__any(active && ccnt > cand.cap) && lane == 0) status[3] = 1;
   }
   if (cnt > kNearCap) { over = true; cnt = kNearCap; }
   if (!active) cnt = 0;
@@ -495,19 +575,64 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
   const bool fits = inRegion + cnt <= regionCap;   // (past the region's capacity: the host grows the arrays and builds again)
   if (active && sub == 0) pairRange[id] = make_int2((int)off, fits ? cnt : 0);
   if (!fits) return;
-  for (int k = sub; k < cnt; k += kNearGroup) {
-    const int j = hitList[grp][k];
-    const real3f rij = scan_rij<SHEAR>(pi, sortPos[j], L, invL, shear);
-    const float r2 = dot3(rij, rij);
-    float f = 0.0f, cc = 0.0f;
-    if (r2 < rcut2) {
-      const float2 fg = table_get(tab, sqrtf(r2));
-      f = fg.x;
-      cc = r2 == 0.0f ? 0.0f : (fg.y - fg.x) * (1.0f / r2);
+  // (UAMMD_PSE_REC_ROWS rounds of eight records at a time: hit, position and the two table entries of each are four dependent reads)
+  constexpr int kRec = UAMMD_PSE_REC_ROWS;
+  for (int k0 = sub; __any(k0 < cnt); k0 += kRec * kNearGroup) {
+    int jj[kRec];
+    float4 pjj[kRec];
+#pragma unroll
+    for (int u = 0; u < kRec; ++u) {
+      const int k = k0 + u * kNearGroup;
+      jj[u] = k < cnt ? hitList[grp][k] : 0;
     }
-    recA[off + k] = make_float4(f, cc, rij.x, rij.y);
-    recB[off + k] = make_float2(rij.z, __int_as_float(j));
+#pragma unroll
+    for (int u = 0; u < kRec; ++u) pjj[u] = sortPos[jj[u]];
+    real3f rij[kRec];
+    float r2[kRec];
+    float2 fg[kRec];
+#pragma unroll
+    for (int u = 0; u < kRec; ++u) {
+      rij[u] = scan_rij<SHEAR>(pi, pjj[u], L, invL, shear);
+      r2[u] = dot3(rij[u], rij[u]);
+      fg[u] = table_get(tab, sqrtf(fminf(r2[u], rcut2)));
+    }
+#pragma unroll
+    for (int u = 0; u < kRec; ++u) {
+      const int k = k0 + u * kNearGroup;
+      float f = 0.0f, cc = 0.0f;
+      if (r2[u] < rcut2) {
+        f = fg[u].x;
+        cc = r2[u] == 0.0f ? 0.0f : (fg[u].y - fg[u].x) * (1.0f / r2[u]);
+      }
+      if (k < cnt) {
+        recA[off + k] = make_float4(f, cc, rij[u].x, rij[u].y);
+        recB[off + k] = make_float2(rij[u].z, __int_as_float(jj[u]));
+      }
+    }
   }
+}
+
+// sortPos[s] = pos[index[s]] for a list that is kept while the particles move (PSENear::skin), and what decides whether it may be: the
+// largest |displacement|^2 (minimum image) since the list was made, per workgroup (no atomics: k_pse_pairs_build<., 2> reduces them)
+__global__ void __launch_bounds__(256) k_pse_refresh_sorted(const float4 *__restrict__ pos, const int *__restrict__ index,
+                                                            const float4 *__restrict__ refPos, float4 *__restrict__ sortPos, int N, real3f L,
+                                                            float *__restrict__ dispParts, int *__restrict__ status, int nStatus) {
+  __shared__ float part[4];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (status && blockIdx.x == 0)   // (the counters of the build that follows: no memset launch)
+    for (int t = threadIdx.x; t < nStatus; t += 256) status[t] = 0;
+  float d2 = 0.0f;
+  if (s < N) {
+    const float4 p = pos[index[s]], r = refPos[s];
+    sortPos[s] = p;
+    const real3f invL{1.0f / L.x, 1.0f / L.y, 1.0f / L.z};
+    d2 = scan_distance2<false>(r, p, L, invL, 0.0f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, o, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x / 64] = d2;
+  __syncthreads();
+  if (threadIdx.x == 0) dispParts[blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
 
 // (Measured and not kept in k_pse_pairs_build: skipping the neighbour cells whose nearest point is beyond the cut-off — half of the corner
@@ -596,7 +721,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
   // everything the tail needs is requested up front: the norm's partials (npB <= 256: one per thread), the row's own vectors
   const float pb = (scaled && (int)threadIdx.x < a.npB) ? a.partsB[threadIdx.x] : 0.f;
   const float hsGiven = (!scaled && a.hsupPrev) ? *a.hsupPrev : 0.f;   // (v_i came from k_l_c: its hsup is in memory)
-  const float hd = scaled ? *a.hdiagPrev : 0.f, nz = scaled ? *a.normz : 1.f;
+  const float hd = (scaled && !a.first) ? *a.hdiagPrev : 0.f, nz = (scaled && !a.first) ? *a.normz : 1.f;   // (first: no guard, |z| >= 0 = 0)
   const int2 rg = active ? pairRange[id] : make_int2(0, 0);
   const V3 zero3{0.f, 0.f, 0.f};
   const V3 own = active ? *(const V3 *)(vsrc + 3 * (size_t)id) : zero3;
@@ -651,7 +776,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
     __syncthreads();
     hs = sqrtf((sh[0] + sh[2]) + (sh[1] + sh[3]));
     __syncthreads();
-    if (hs < 1e-3f * hd / nz) hs = 0.f;
+    if (!a.first && hs < 1e-3f * hd / nz) hs = 0.f;
     if (block == 0 && threadIdx.x == 0) *a.hsupPrev = hs;
     inv = hs > 0.f ? 1.0f / hs : 0.f;
   }
@@ -839,6 +964,31 @@ __global__ void __launch_bounds__(256) k_pse_noise_sorted(float *__restrict__ ou
   out3[3 * (size_t)k + 1] = a.y * variance;
   out3[3 * (size_t)k + 2] = b.x * variance;
 }
+// the same vector with the partials of its |.|^2 (at most 256 workgroups: the Lanczos run takes them instead of a k_l_norm2 launch,
+// lanczos_set_znorm_parts) and, workgroup 0, the pair build's counters copied to the host-mapped block the host reads after the solve
+// (instead of a copy command between the build and this kernel)
+__global__ void __launch_bounds__(256) k_pse_noise_sorted_norm(float *__restrict__ out3, const int *__restrict__ groupIndex, int N,
+                                                                float variance, uint seed1, uint seed2, float *__restrict__ parts,
+                                                                const int *__restrict__ status, int *__restrict__ statusHost, int nStatus) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < N; k += gridDim.x * 256) {
+    Saru rng((uint)groupIndex[k], seed1, seed2);
+    const float2 a = rng.gf(0.0f, 1.0f);
+    const float2 b = rng.gf(0.0f, 1.0f);
+    const float x = a.x * variance, y = a.y * variance, z = b.x * variance;
+    out3[3 * (size_t)k] = x;
+    out3[3 * (size_t)k + 1] = y;
+    out3[3 * (size_t)k + 2] = z;
+    acc = fmaf(z, z, fmaf(y, y, fmaf(x, x, acc)));
+  }
+  acc = wave_sum_to_last(acc);
+  if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = (sh[0] + sh[2]) + (sh[1] + sh[3]);
+  if (status && blockIdx.x == 0)
+    for (int t = threadIdx.x; t < nStatus; t += 256) statusHost[t] = status[t];
+}
 __global__ void __launch_bounds__(256) k_pse_unsort3(const float *__restrict__ in3, const int *__restrict__ groupIndex, int N,
                                                       float *__restrict__ out3) {
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -870,14 +1020,50 @@ static TableView make_view(const PSENear *p) {
 }
 
 // cl->update(box, rcut * safetyFactor) (NearField.cuh:231-237)
-static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st) {
-  if (p->lazyList && p->listValid && p->listPos == d_pos && p->N == N && p->listStream == st) return 0;
+static bool pse_cand_usable(const PSENear *p) {
+  return p->candEnabled && p->skinPercent > 0 && p->pairList && p->lazyList && p->nearKernel == 1 && !p->exactOrder && !p->pairsUnfit &&
+         p->shear == 0.0f;
+}
+static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st, bool full = false) {
+  if (!full && p->lazyList && p->listValid && p->listPos == d_pos && p->N == N && p->listStream == st) return 0;
+  const bool cand = pse_cand_usable(p);
+  const bool same = p->listPos == d_pos && p->N == N && p->listStream == st;
+  // the positions moved, the order and the candidate lists may stay: refresh instead of a build when the bound is expected to hold
+  if (!full && cand && p->candValid && same && !p->pairsPending && p->lastDisp + 2.0f * p->maxInc <= 0.5f * p->skin) {
+    const int nb = (N + 255) / 256;
+    if (int e = p->dispParts.reserve(sizeof(float) * (size_t)nb)) return e;
+    const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
+    if (int e = p->pairCursor.reserve(kPairStatusInts * sizeof(int))) return e;
+    hipLaunchKernelGGL(k_pse_refresh_sorted, dim3(nb), dim3(256), 0, st, (const float4 *)d_pos, (const int *)p->cl.index.ptr,
+                       (const float4 *)p->refPos.ptr, (float4 *)p->cl.sortPos.ptr, N, Lb, (float *)p->dispParts.ptr,
+                       (int *)p->pairCursor.ptr, kPairStatusInts);
+    UH_CHECK(hipGetLastError());
+    p->statusZeroed = true;
+    p->listValid = true;
+    p->pairsValid = false;
+    p->candScan = true;
+    p->candBuild = false;
+    ++p->stepsSinceFull;
+    return 0;
+  }
+  if (cand && p->candValid && same) {   // a kept list ends here: how long did it live?
+    p->candShortLived = p->stepsSinceFull < 2 ? p->candShortLived + 1 : 0;
+    if (p->candShortLived >= 3) p->candEnabled = false;
+  }
   p->listValid = false;  // (valid again only when the build below went through: a failed build must not be reused)
   p->pairsValid = false;
   p->pairsPending = false;  // (a build in flight is of the old list; the next one is ordered after it on the stream)
+  p->candValid = false;
+  p->candScan = false;
+  p->statusZeroed = false;
+  const bool keep = pse_cand_usable(p);
+  p->candBuild = keep;
+  p->skin = keep ? 0.01f * (float)p->skinPercent * p->rcut : 0.0f;
+  p->stepsSinceFull = 0;
+  p->lastDisp = 0.0f;
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
-  const float rc = p->rcut * safety;
+  const float rc = (p->rcut + p->skin) * safety;
   const float rc3[3] = {rc, rc, rc};
   const int per[3] = {1, 1, 1};
   int cd[3], gper[3];
@@ -885,6 +1071,11 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   if (int e = uammd_celllist_create_grid(p->boxL, per, rc3, cd, gL, gper)) return e;
   p->N = N;
   if (int e = p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st)) return e;
+  if (keep) {   // the positions the kept list's displacement bound is measured from
+    if (int e = p->refPos.reserve(sizeof(float4) * (size_t)N)) return e;
+    UH_CHECK(hipMemcpyAsync(p->refPos.ptr, p->cl.sortPos.ptr, sizeof(float4) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  }
+  ++p->fullBuilds;
   p->listValid = true;
   p->listPos = d_pos;
   p->listStream = st;  // (the list is ordered after the build on THIS stream only)
@@ -894,9 +1085,12 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
 static TableView make_view(const PSENear *p);
 // the pair records of the current list (see PSENear::pairList).  One host read per build: the number of records, to grow the arrays
 // when they do not fit (the build then runs again).
-static int pse_launch_pairs(PSENear *p, hipStream_t st) {
+static int pse_launch_pairs(PSENear *p, hipStream_t st, bool deferCopy = false) {
   const int N = p->N;
-  if (!p->pairTotalHost) UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, kPairStatusInts * sizeof(int)));
+  if (!p->pairTotalHost) {
+    UH_CHECK(hipHostMalloc((void **)&p->pairTotalHost, kPairStatusInts * sizeof(int), hipHostMallocMapped));
+    UH_CHECK(hipHostGetDevicePointer((void **)&p->pairTotalDev, (void *)p->pairTotalHost, 0));
+  }
   if (!p->pairsEvent) UH_CHECK(hipEventCreateWithFlags(&p->pairsEvent, hipEventDisableTiming));
   if (int e = p->pairRange.reserve(sizeof(int2) * (size_t)N)) return e;
   if (int e = p->pairCursor.reserve(kPairStatusInts * sizeof(int))) return e;
@@ -907,17 +1101,47 @@ static int pse_launch_pairs(PSENear *p, hipStream_t st) {
   const real3f Lb{p->boxL[0], p->boxL[1], p->boxL[2]};
   const dim3 gr((N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup));
   p->pairRegions = (int)std::min<long long>(kPairRegions, std::max<long long>(1, (long long)gr.x / 8));   // (a small system: fewer, larger regions)
-  UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, kPairStatusInts * sizeof(int), st));
-#define UH_PAIRS(SH)                                                                                                                \
-  hipLaunchKernelGGL((k_pse_pairs_build<SH>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                       \
+  if (!p->statusZeroed) UH_CHECK(hipMemsetAsync(p->pairCursor.ptr, 0, kPairStatusInts * sizeof(int), st));
+  p->statusZeroed = false;
+  PairCand cand{nullptr, nullptr, 0, 0.0f, nullptr, 0};
+  if (p->candBuild) {   // candidates per particle: the mean number within rc + skin with room for the density's fluctuations
+    if (p->candCap == 0) {
+      const double rcs = (double)p->rcut + p->skin, vol = (double)p->boxL[0] * p->boxL[1] * p->boxL[2];
+      const double mean = (double)N / vol * 4.18879 * rcs * rcs * rcs;
+      p->candCap = std::max(32, ((int)(1.6 * mean + 24.0) + 7) & ~7);
+    }
+    if ((size_t)N * (size_t)p->candCap > (size_t)1 << 31) { p->candBuild = false; p->candEnabled = false; }
+  }
+  if (p->candBuild || p->candScan) {
+    if (int e = p->candList.reserve(sizeof(int) * (size_t)N * (size_t)p->candCap)) return e;
+    if (int e = p->candCount.reserve(sizeof(int) * (size_t)N)) return e;
+    const float rcs = p->rcut + p->skin;
+    cand = PairCand{(int *)p->candList.ptr, (int *)p->candCount.ptr, p->candCap, rcs * rcs, (const float *)p->dispParts.ptr, (N + 255) / 256};
+  }
+#define UH_PAIRS(SH, MODE)                                                                                                          \
+  hipLaunchKernelGGL((k_pse_pairs_build<SH, MODE>), gr, dim3(kNearBlock), 0, st, (const float4 *)p->cl.sortPos.ptr,                 \
                      (const uint *)p->cl.cellStart.ptr, (const int *)p->cl.cellEnd.ptr, p->cl.validCell, N, p->cl.grid, Lb,         \
                      p->shear, p->rcut * p->rcut, make_view(p), (float4 *)p->recA.ptr, (float2 *)p->recB.ptr,                       \
-                     (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap, p->pairRegions)
-  if (p->shear != 0.0f) UH_PAIRS(true); else UH_PAIRS(false);
+                     (int2 *)p->pairRange.ptr, (int *)p->pairCursor.ptr, (long long)p->pairCap, p->pairRegions, cand)
+  if (p->candScan) { UH_PAIRS(false, 2); ++p->candBuilds; }
+  else if (p->candBuild) UH_PAIRS(false, 1);
+  else if (p->shear != 0.0f) UH_PAIRS(true, 0);
+  else UH_PAIRS(false, 0);
 #undef UH_PAIRS
+  p->statusCopyDeferred = deferCopy;   // (the caller's next kernel on the stream copies the block: pse_settle_status otherwise)
+  if (!deferCopy) {
+    UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, kPairStatusInts * sizeof(int), hipMemcpyDeviceToHost, st));
+    UH_CHECK(hipEventRecord(p->pairsEvent, st));
+  }
+  p->pairsPending = true;
+  return 0;
+}
+// a deferred copy nobody has taken: issue it now (before anything waits for pairsEvent)
+static int pse_settle_status(PSENear *p, hipStream_t st) {
+  if (!p->statusCopyDeferred) return 0;
+  p->statusCopyDeferred = false;
   UH_CHECK(hipMemcpyAsync(p->pairTotalHost, p->pairCursor.ptr, kPairStatusInts * sizeof(int), hipMemcpyDeviceToHost, st));
   UH_CHECK(hipEventRecord(p->pairsEvent, st));
-  p->pairsPending = true;
   return 0;
 }
 // what the build's counters say once its event has completed: the records asked for, and whether every region held its share; if not,
@@ -939,17 +1163,52 @@ static void pse_pairs_grow(PSENear *p) {
   const long long need = std::max(pse_pairs_total(p), worst * p->pairRegions);
   p->pairCap = (size_t)(need + need / 4 + p->pairRegions);
 }
+// The verdict on a build whose event has completed.  true: the records are what the products may stream (pairsValid).  false: something
+// was changed so that the next launch can succeed — arrays grown, the list rebuilt from scratch on the stream because the kept one's
+// displacement bound was broken (or because the products go back to scanning the cells: pairsUnfit) — and the caller launches again
+// (unless pairsUnfit).
+static int pse_pairs_verdict(PSENear *p, hipStream_t st, bool *ok) {
+  *ok = false;
+  const bool scanned = p->candScan, built = p->candBuild;
+  if (scanned) {   // how far the particles are from where the list was made
+    const float d = std::sqrt(std::max(0.0f, *reinterpret_cast<const float *>(&p->pairTotalHost[2])));
+    if (d > p->lastDisp) p->maxInc = std::max(p->maxInc, d - p->lastDisp);
+    p->lastDisp = d;
+    if (!(d <= 0.5f * p->skin)) {   // (also a NaN reading)
+      ++p->candRepeats;
+      return pse_update_list(p, (const float *)p->listPos, p->N, st, true);
+    }
+  }
+  if (p->pairTotalHost[1]) {   // a particle with more neighbours than a hit list holds: k_pse_near8 from here on — on a list of this step
+    p->pairsUnfit = true;
+    if (scanned) return pse_update_list(p, (const float *)p->listPos, p->N, st, true);
+    return 0;
+  }
+  if (built) {
+    if (p->pairTotalHost[3]) {   // a particle with more candidates than its row holds: wider rows next time (twice), then no kept lists
+      p->candCap = (p->candCap * 3 / 2 + 7) & ~7;
+      if (++p->candGrow > 2) p->candEnabled = false;
+    } else
+      p->candValid = true;
+    p->maxInc *= 0.9f;   // (an old extreme does not shorten the lists' lives for ever)
+  }
+  if (pse_pairs_fit(p)) { p->pairsValid = true; *ok = true; return 0; }
+  pse_pairs_grow(p);
+  if (scanned) p->candScan = true;   // (the same candidates again, into larger arrays)
+  return 0;
+}
 static int pse_build_pairs(PSENear *p, hipStream_t st) {
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (int attempt = 0; attempt < 5; ++attempt) {
     if (!p->pairsPending) {
       if (int e = pse_launch_pairs(p, st)) return e;
       if (p->pairsUnfit) return 0;
     }
+    if (int e = pse_settle_status(p, st)) return e;
     UH_CHECK(hipEventSynchronize(p->pairsEvent));
     p->pairsPending = false;
-    if (p->pairTotalHost[1]) { p->pairsUnfit = true; return 0; }   // a particle with more neighbours than a hit list holds: k_pse_near8 from here on
-    if (pse_pairs_fit(p)) { p->pairsValid = true; return 0; }
-    pse_pairs_grow(p);
+    bool ok = false;
+    if (int e = pse_pairs_verdict(p, st, &ok)) return e;
+    if (ok || p->pairsUnfit) return 0;
   }
   p->pairsUnfit = true;
   return 0;
@@ -1197,6 +1456,7 @@ int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain) {
   if (!h) { set_last_error("uammd_pse_near_set_shear_strain: null handle"); return -1; }
   reinterpret_cast<PSENear *>(h)->shear = shearStrain;
   reinterpret_cast<PSENear *>(h)->listValid = false;  // (the list's cut-off carries the shear's safety factor)
+  reinterpret_cast<PSENear *>(h)->candValid = false;
   return 0;
 }
 
@@ -1208,14 +1468,19 @@ int uammd_pse_near_set_shear_strain(uammd_pse_near *h, float shearStrain) {
 int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   if (!h || !name) { set_last_error("uammd_pse_near_set_option: null argument"); return -1; }
   PSENear *p = reinterpret_cast<PSENear *>(h);
-  if (std::string(name) == "exact_order") { p->exactOrder = value != 0; return 0; }
+  if (std::string(name) == "exact_order") { p->exactOrder = value != 0; p->listValid = false; p->candValid = false; return 0; }
   if (std::string(name) == "pair_list") { p->pairList = value != 0; return 0; }
   if (std::string(name) == "optimistic_records") { p->optimisticRecords = value != 0; return 0; }
   if (std::string(name) == "pair_capacity" && value >= 0) { p->pairCapFirst = (size_t)value; p->pairCap = 0; p->pairsValid = false; p->pairsPending = false; return 0; }
   if (std::string(name) == "defer_checks") return uammd_lanczos_set_option(p->lanczos, "defer_checks", value);
   if (std::string(name) == "fuse_recurrence") return uammd_lanczos_set_option(p->lanczos, "fuse_recurrence", value);
-  if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; return 0; }
-  if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; return 0; }
+  if (std::string(name) == "lazy_list") { p->lazyList = value != 0; p->listValid = false; p->candValid = false; return 0; }
+  if (std::string(name) == "near_kernel" && (value == 0 || value == 1)) { p->nearKernel = value; p->listValid = false; p->candValid = false; return 0; }
+  if (std::string(name) == "list_skin_percent" && value >= 0 && value <= 100) {
+    p->skinPercent = value; p->candEnabled = true; p->candShortLived = 0; p->candGrow = 0; p->candCap = 0; p->maxInc = 0.f;
+    p->listValid = false; p->candValid = false;
+    return 0;
+  }
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
   return -1;
 }
@@ -1247,6 +1512,15 @@ int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long
   PSENear *p = reinterpret_cast<PSENear *>(h);
   if (records) *records = (p->pairsValid && p->pairTotalHost) ? pse_pairs_total(p) : 0;
   if (capacity) *capacity = (long long)p->pairCap;
+  return 0;
+}
+
+// diagnostics of the kept candidate lists (option "list_skin_percent"): {list builds from scratch, record builds from a kept list, builds
+// repeated because the displacement bound was broken, 1 while the mechanism is on for the handle}
+int uammd_pse_near_list_stats(uammd_pse_near *h, long long out[4]) {
+  if (!h || !out) { set_last_error("uammd_pse_near_list_stats: null argument"); return -1; }
+  const PSENear *p = reinterpret_cast<const PSENear *>(h);
+  out[0] = p->fullBuilds; out[1] = p->candBuilds; out[2] = p->candRepeats; out[3] = pse_cand_usable(p) ? 1 : 0;
   return 0;
 }
 
@@ -1344,9 +1618,20 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   }
   if (int e = p->sortedOut.reserve(sizeof(float) * 3 * (size_t)N)) return leave(e);
   auto solve = [&]() -> int {
-    hipLaunchKernelGGL(k_pse_noise_sorted, dim3((N + 255) / 256), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
-                       noise_prefactor, p->seed, seed2);
+    // the noise, the partials of its norm for the solver (lanczos_set_znorm_parts) and — when a pair build has left it to this kernel —
+    // the build's status block for the host
+    const int nzb = std::min(256, (N + 255) / 256);
+    if (int e = p->zparts.reserve(sizeof(float) * 256)) return e;
+    const bool publish = p->statusCopyDeferred;
+    hipLaunchKernelGGL(k_pse_noise_sorted_norm, dim3(nzb), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
+                       noise_prefactor, p->seed, seed2, (float *)p->zparts.ptr, publish ? (const int *)p->pairCursor.ptr : nullptr,
+                       p->pairTotalDev, kPairStatusInts);
     UH_CHECK(hipGetLastError());
+    if (publish) {
+      p->statusCopyDeferred = false;
+      UH_CHECK(hipEventRecord(p->pairsEvent, st));
+    }
+    if (int e = lanczos_set_znorm_parts(p->lanczos, (const float *)p->zparts.ptr, nzb)) return e;
     // (the pair-record product also runs the recurrence's neighbours: two launches per iteration instead of four, lanczos_fused.hpp)
     if (int e = lanczos_set_fused(p->lanczos, &pse_lanczos_fused, p)) return e;
     const int rcRun = uammd_lanczos_run(p->lanczos, &pse_lanczos_dot_sorted, p, (float *)p->sortedOut.ptr, (const float *)p->noise.ptr,
@@ -1356,21 +1641,24 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   };
   // the records' counters are read after the solve instead of before it (PSENear::optimisticRecords)
   const bool records = p->pairList && p->lazyList && p->listValid && !p->pairsUnfit && p->nearKernel == 1;
-  if (records && p->optimisticRecords && !p->pairsValid && !p->pairsPending) { if (int e = pse_launch_pairs(p, st)) return leave(e); }
+  if (records && p->optimisticRecords && !p->pairsValid && !p->pairsPending) { if (int e = pse_launch_pairs(p, st, true)) return leave(e); }
   const bool ahead = records && p->optimisticRecords && p->pairsPending && !p->pairsValid;
   int schedule[2] = {0, 0};
   if (ahead) { if (int e = uammd_lanczos_get_schedule(p->lanczos, schedule)) return leave(e); }
+  // (not ahead: the records are settled BEFORE the noise is drawn — a kept list whose displacement bound turns out broken is replaced by
+  // a fresh one, in another particle order, and the solve's vectors live in the list's order)
+  if (records && !ahead && !p->pairsValid) { if (int e = pse_build_pairs(p, st)) return leave(e); }
   if (int e = arm()) return leave(e);   // (one-shot: a repeated solve below runs without them)
   p->optimistic = ahead;
   int rc = solve();
   p->optimistic = false;
   if (ahead && p->pairsPending) {
+    if (int e = pse_settle_status(p, st)) return leave(e);
     UH_CHECK(hipEventSynchronize(p->pairsEvent));
     p->pairsPending = false;
-    if (!p->pairTotalHost[1] && pse_pairs_fit(p)) p->pairsValid = true;
-    else {   // the products of this solve missed pairs: the build again (pse_build_pairs from the first product: larger, or back to the scanning product), the solve again
-      if (p->pairTotalHost[1]) p->pairsUnfit = true;
-      else pse_pairs_grow(p);
+    bool ok = false;
+    if (int e = pse_pairs_verdict(p, st, &ok)) return leave(e);
+    if (!ok) {   // the products of this solve missed pairs: the build again (pse_build_pairs from the first product: larger arrays, a fresh list, or back to the scanning product), the solve again
       if (int e = uammd_lanczos_set_schedule(p->lanczos, schedule)) return leave(e);
       rc = solve();
     }
