@@ -1190,7 +1190,7 @@ static int pse_pairs_verdict(PSENear *p, hipStream_t st, bool *ok) {
       if (++p->candGrow > 2) p->candEnabled = false;
     } else
       p->candValid = true;
-    p->maxInc *= 0.9f;   // (an old extreme does not shorten the lists' lives for ever)
+    p->maxInc *= 0.7f;   // (an old extreme does not shorten the lists' lives for ever)
   }
   if (pse_pairs_fit(p)) { p->pairsValid = true; *ok = true; return 0; }
   pse_pairs_grow(p);
