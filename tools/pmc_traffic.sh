@@ -26,8 +26,8 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
             for r in c.execute(q):
                 out["raw"].setdefault(cnt, []).append({"kernel": r[0][:80], "sum_value": r[1], "launches": r[2]})
                 s += r[1]
-                if i == 0 and launches is None:
-                    launches = r[2]
+                if i == 0:   # (every instantiation of the first pattern counts: k_fcm_spread_tile<4, true> + <4, false>)
+                    launches = (launches or 0) + r[2]
         if launches:
             tot[cnt] = s / launches
 fs, ws = tot.get("FETCH_SIZE"), tot.get("WRITE_SIZE")
