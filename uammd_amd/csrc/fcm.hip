@@ -1075,6 +1075,77 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__r
     }
   }
 }
+// Support 6 x 6 in x, y — the FCM Gaussian at tolerance 1e-3, the bench's C4 / C5 — with every lane at work: k_fcm_gather_col keeps 36 of a
+// wave's 64 lanes busy and issues sz loads per particle, and a 64-lane load costs the CU's address unit the same ~16 clocks whatever its
+// lanes fetch.  Here a HALF wave takes a particle: lane l of the half is column (ii, jj) = (l % 6, l / 6) — all 32 lanes inside the stencil,
+// rows jj = 0..4 and the first two columns of row 5 — for the loop over the z planes, and ONE more load fetches what is left of row 5
+// (columns 2..5 of every plane: 4 sz <= 32 nodes, lane -> (2 + (l & 3), l >> 2)).  sz + 1 loads per PAIR of particles instead of 2 sz.
+// Same terms as k_fcm_gather_col, summed in another order (the half wave's sum is the first five steps of wave_sum_to_last).
+template <int SZMAX>
+__global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_half(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
+                                                                       int sz, float dV, FcmPrep pr, bool accumulate) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, l = lane & 31;
+  const int slot0 = ((int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6)) * 2;
+  if (slot0 >= N) return;
+  const bool valid = slot0 + h < N;
+  const int slot = min(slot0 + h, N - 1);
+  const int4 o = pr.origin[slot];
+  const float wl = pr.weights[(size_t)pr.wstride * slot + min(l, 12 + sz - 1)];   // lanes 0..5 wx, 6..11 wy, 12.. wz of the half's particle
+  const int jj = (l * 43) >> 8, ii = l - 6 * jj;   // l / 6, l % 6 for l < 36
+  const uint planeNodes = (uint)n.x * (uint)n.y;
+  auto wrap = [](int c, int m) { return c < 0 ? c + m : (c >= m ? c - m : c); };
+  const uint base = (uint)wrap(o.x + ii, n.x) + (uint)n.x * (uint)wrap(o.y + jj, n.y);
+  float4 g[SZMAX];
+#pragma unroll
+  for (int kk = 0; kk < SZMAX; ++kk)
+    if (kk < sz)
+      g[kk] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + ((base + planeNodes * (uint)wrap(o.z + kk, n.z)) << 4));
+  // the rest of row 5
+  const int ii2 = 2 + (l & 3), kk2 = l >> 2;
+  const bool rest = kk2 < sz;
+  const uint base2 = (uint)wrap(o.x + ii2, n.x) + (uint)n.x * (uint)wrap(o.y + 5, n.y) + planeNodes * (uint)wrap(o.z + (rest ? kk2 : 0), n.z);
+  const float4 g2 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + (base2 << 4));
+  const int hb = h << 5;
+  const float wxy = __shfl(wl, hb + ii, 64) * __shfl(wl, hb + 6 + jj, 64);
+  float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < SZMAX; ++kk) {
+    if (kk < sz) {
+      const float wzA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 12 + kk));
+      const float wzB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 32 + 12 + kk));
+      const float w = wxy * (h ? wzB : wzA);
+      ax = fmaf(g[kk].x, w, ax);
+      ay = fmaf(g[kk].y, w, ay);
+      az = fmaf(g[kk].z, w, az);
+    }
+  }
+  {
+    const float w5 = h ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 32 + 11))
+                       : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 11));
+    const float w = __shfl(wl, hb + ii2, 64) * w5 * __shfl(wl, hb + 12 + (rest ? kk2 : 0), 64);
+    if (rest) {
+      ax = fmaf(g2.x, w, ax);
+      ay = fmaf(g2.y, w, ay);
+      az = fmaf(g2.z, w, az);
+    }
+  }
+  auto half_sum = [](float x) {   // lanes 31 and 63 end with their half's sum
+    x += dpp_move<0xB1, 0xf, true>(x);
+    x += dpp_move<0x4E, 0xf, true>(x);
+    x += dpp_move<0x141, 0xf, true>(x);
+    x += dpp_move<0x140, 0xf, true>(x);
+    x += dpp_move<0x142, 0xa, false>(x);
+    return x;
+  };
+  ax = half_sum(ax);
+  ay = half_sum(ay);
+  az = half_sum(az);
+  if (l == 31 && valid) {
+    ax *= dV; ay *= dV; az *= dV;
+    float *out = vout + 3 * (size_t)o.w;
+    if (accumulate) { out[0] += ax; out[1] += ay; out[2] += az; } else { out[0] = ax; out[1] = ay; out[2] = az; }
+  }
+}
 // (A window gather — a workgroup per tile stages the tile-edge + support window of the interleaved grid in LDS, 44 KB at C4, and its
 // four waves interpolate the tile's ~24 particles from LDS — was written twice: round 1 on the planar grids, 112 us, and round 3 on the
 // float4 grid with every load of a thread in flight together, 72 us against 47 us for the kernel above: three workgroups per CU do not
@@ -1084,9 +1155,21 @@ static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, i
   // the column form where the float4 grid stays in the 256 MB Infinity Cache (C4: 39.5 -> 32.9 us; at C5, a 268 MB grid read from HBM,
   // its six partly filled loads per particle lose to the four full ones: 126 against 112 us)
   const size_t nodes = (size_t)n.x * n.y * n.z;
+  static const int halfMode = getenv("UAMMD_FCM_GATHER_HALF") ? atoi(getenv("UAMMD_FCM_GATHER_HALF")) : 1;   // (A/B runs: 0 off, 2 also on grids read from HBM)
+  if (halfMode == 2 && perWave >= 0 && support.x == 6 && support.y == 6 && support.z <= 8 && nodes * sizeof(float4) < ((size_t)1 << 32)) {
+    const dim3 g((N + kGatherWaves * 2 - 1) / (kGatherWaves * 2)), b(64 * kGatherWaves);
+    if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+    else hipLaunchKernelGGL((k_fcm_gather_half<8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+    return;
+  }
   if (perWave >= 0 && support.x <= 8 && support.y <= 8 && support.z <= 8 && nodes * sizeof(float4) <= ((size_t)128 << 20)) {
     constexpr int P = 2;  // (32.9 / 33.5 / 36.4 us with 2 / 3 / 4 particles per wave at C4)
     const dim3 g((N + kGatherWaves * P - 1) / (kGatherWaves * P)), b(64 * kGatherWaves);
+    if (support.x == 6 && support.y == 6 && halfMode != 0) {
+      if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      else hipLaunchKernelGGL((k_fcm_gather_half<8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      return;
+    }
     if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_col<2, 6>), g, b, 0, st, vout, gi, N, n, support, dV, pr, accumulate);
     else hipLaunchKernelGGL((k_fcm_gather_col<2, 8>), g, b, 0, st, vout, gi, N, n, support, dV, pr, accumulate);
     return;
