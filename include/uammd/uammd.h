@@ -1917,8 +1917,9 @@ public:
     };
     detail::check(uammd_pse_near_set_interleave_early(nearField, firstHalf, &far));
     detail::check(uammd_pse_near_set_interleave(nearField, secondHalf, &far));
+    // (the near field's M F rides on the solve's first product: the pair records are streamed once for the noise vector and F)
+    detail::check(uammd_pse_near_set_mdot_rider(nearField, (const float *)force, (float *)MF));
     detail::check(uammd_pse_near_stochastic(nearField, posRowsPtr, N, temperature, real(1.0), seedNear, (float *)BdW, (void *)st, nullptr));
-    detail::check(uammd_pse_near_mdot(nearField, posRowsPtr, (const float *)force, N, (float *)MF, (void *)st));
   }
   void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
     const int N = numberParticles();

@@ -621,6 +621,11 @@ int uammd_pse_near_pair_records(uammd_pse_near *h, long long *records, long long
  * that streamed the records).  Same pairs as a build per step, summed in another order.  0 = a list build per step.
  * uammd_pse_near_list_stats: {builds from scratch, record builds from a kept list, repeated builds, 1 while the mechanism is on}. */
 int uammd_pse_near_list_stats(uammd_pse_near *h, long long out[4]);
+/* One-shot: the NEXT uammd_pse_near_stochastic on the handle also performs uammd_pse_near_mdot(h, pos, d_force, N, d_MF) with its own
+ * positions — BDHI_PSE.cuh:92-126 calls the two back to back on the same list.  Where the solve streams pair records its first product
+ * applies them to F as a second right-hand side (the records are read once for both vectors); otherwise (T = 0, scanning products) the
+ * plain product runs before the call returns.  d_force NULL disarms. */
+int uammd_pse_near_set_mdot_rider(uammd_pse_near *h, const float *d_force, float *d_MF);
 /* d_MF real3[N] += M_near F (d_force real4[N]; NULL = nothing to do) */
 int uammd_pse_near_mdot(uammd_pse_near *h, const float *d_pos, const float *d_force, int numberParticles, float *d_MF,
                         void *stream);

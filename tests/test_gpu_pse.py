@@ -564,3 +564,44 @@ def test_kept_candidate_lists_follow_the_particles(hip, o32):
     cur[:, :3] += walk.uniform(-0.02 * skin, 0.02 * skin, (n, 3)).astype(np.float32)
     step(pd, pse, cur, 1000)
     assert stats(pse)[2] == 1 and stats(pse)[0] == 3
+
+
+@pytest.mark.gpu
+def test_mdot_rides_on_the_solve(hip, o32):
+    """uammd_pse_near_set_mdot_rider: the next uammd_pse_near_stochastic also adds M_near F to MF — inside the solve's first product where
+    that streams pair records, by the plain product otherwise (T = 0; the scanning products).  Against the two separate calls on a twin:
+    the same noise bit for bit, M_near F against the oracle; one-shot (a second solve without re-arming leaves MF alone)."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n, tol, psi = 40.0, 4000, 1e-3, 0.6
+    rng = np.random.default_rng(3)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+    for records, T in ((1, 1.0), (0, 1.0), (1, 0.0)):
+        pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+        pd2, twin, _, _, _ = _pair(hip, o32, L, tol, psi, n)
+        for h in (pse, twin):
+            check(h.lib.uammd_pse_near_set_option(h.near, b"pair_list", records))
+        expect = np.zeros((n, 3), np.float32)
+        ref.near_mdot(pos, f4, expect)
+        scale = np.abs(expect).max()
+        MF = torch.full((n, 3), 0.5, dtype=torch.float32, device="cuda")
+        BdW = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        it = C.c_int(0)
+        check(pse.lib.uammd_pse_near_set_mdot_rider(pse.near, _ptr(d_f), _ptr(MF)))
+        check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, T, 1.0, 77, _ptr(BdW), current_stream(), C.byref(it)))
+        MF2 = torch.full((n, 3), 0.5, dtype=torch.float32, device="cuda")
+        BdW2 = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        it2 = C.c_int(0)
+        check(twin.lib.uammd_pse_near_stochastic(twin.near, _ptr(pd2.getPos()), n, T, 1.0, 77, _ptr(BdW2), current_stream(), C.byref(it2)))
+        check(twin.lib.uammd_pse_near_mdot(twin.near, _ptr(pd2.getPos()), _ptr(d_f), n, _ptr(MF2), current_stream()))
+        assert it.value == it2.value and np.array_equal(BdW.cpu().numpy(), BdW2.cpu().numpy()), (records, T)
+        got = MF.cpu().numpy() - 0.5
+        assert np.abs(got - expect).max() <= 1e-6 * scale + 1.5e-7, (records, T, float(np.abs(got - expect).max() / scale))
+        assert np.abs(MF.cpu().numpy() - MF2.cpu().numpy()).max() <= 1e-6 * scale + 1.5e-7
+        # one-shot
+        before = MF.clone()
+        check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, T, 1.0, 78, _ptr(BdW), current_stream(), C.byref(it)))
+        assert torch.equal(MF, before)

@@ -248,6 +248,7 @@ SIGNATURES = {
     "uammd_lanczos_set_interleave_early": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_pair_records": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_list_stats": (_i, [_vp, _vp]),
+    "uammd_pse_near_set_mdot_rider": (_i, [_vp, _vp, _vp]),
     "uammd_pse_near_mdot": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_pse_near_stochastic": (_i, [_vp, _vp, _i, _f, _f, _u, _vp, _vp, C.POINTER(_i)]),
     "uammd_pse_near_noise": (_i, [_vp, _i, _f, _u, _vp, _vp]),

@@ -537,6 +537,8 @@ class PSE:
         check(self.lib.uammd_pse_near_set_interleave_early(self.near, C.cast(self._interleave_cb[0], C.c_void_p), None))
         check(self.lib.uammd_pse_near_set_interleave(self.near, C.cast(self._interleave_cb[1], C.c_void_p), None))
         it = C.c_int(0)
+        # (the near field's M F rides on the solve's first product: the pair records are streamed once for the noise vector and F)
+        check(self.lib.uammd_pse_near_set_mdot_rider(self.near, _ptr(force), _ptr(MF)))
         rc = self.lib.uammd_pse_near_stochastic(self.near, _ptr(pos), pd.N, float(self.temperature), 1.0, seed_near, _ptr(BdW), st,
                                                 C.byref(it))
         self._interleave_cb = None      # (one-shot; the closure holds self)
@@ -544,7 +546,6 @@ class PSE:
             raise failed[0]
         check(rc)
         self.lastLanczosIterations = int(it.value)
-        check(self.lib.uammd_pse_near_mdot(self.near, _ptr(pos), _ptr(force), pd.N, _ptr(MF), st))
 
     def computeHydrodynamicDisplacements(self, force, MF, temperature, noise_prefactor):
         """BDHI_PSE.cuh:135-155, statement for statement: with forces AND T > 0 the Lanczos result overwrites the near

@@ -88,6 +88,13 @@ struct PSENear {
   void *interleaveCtx = nullptr;
   uammd_interleave_fn interleaveEarly = nullptr;   // uammd_pse_near_set_interleave_early
   void *interleaveEarlyCtx = nullptr;
+  // uammd_pse_near_set_mdot_rider (one-shot): the next uammd_pse_near_stochastic also adds M_near F to riderMF — as a second right-hand
+  // side of the solve's FIRST product (the records are streamed once for both), F gathered into the list's order by the noise kernel,
+  // the result added to riderMF by the kernel that unsorts the solve's result.  riderLaunched: the product of the current solve took it.
+  const float *riderForce = nullptr;
+  float *riderMF = nullptr;
+  bool riderArmed = false, riderLaunched = false;
+  DeviceBuffer riderFs, riderMFs;   // F and M_near F in the list's order (real3)
   ~PSENear() {
     if (lanczos) uammd_lanczos_destroy(lanczos);
     if (pairTotalHost) (void)hipHostFree(pairTotalHost);
@@ -708,8 +715,10 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs(const float4 *__r
 // and, one workgroup, hsup_(i-1) are written on the way; then w = M v_i - hsup_(i-1) v_(i-1) for the workgroup's rows and ONE partial of
 // w . v_i per workgroup (k_l_a).  Vectors in cell order, stride 3.  (First form, measured: norm first, every v_j scaled as it is read —
 // the product waited a round trip and two barriers before its first record, 13.4 -> ~24 us, the step 0.547 -> 0.562 ms.)
+template <bool RIDER>
 __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const float4 *__restrict__ recA, const float2 *__restrict__ recB,
-                                                                        const int2 *__restrict__ pairRange, int N, LanczosFusedArgs a) {
+                                                                        const int2 *__restrict__ pairRange, int N, LanczosFusedArgs a,
+                                                                        const float *__restrict__ riderFs, float *__restrict__ riderMFs) {
   __shared__ float sh[16];
   const int sub = threadIdx.x & (kNearGroup - 1);
   const int block = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -726,6 +735,7 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
   const V3 zero3{0.f, 0.f, 0.f};
   const V3 own = active ? *(const V3 *)(vsrc + 3 * (size_t)id) : zero3;
   const V3 vp = (active && a.vPrev) ? *(const V3 *)(a.vPrev + 3 * (size_t)id) : zero3;
+  float fx = 0.f, fy = 0.f, fz = 0.f;   // RIDER: the same records applied to a second vector (M_near F, NearField::Mdot)
   auto pair_sums = [&](bool e1, float &tx, float &ty, float &tz) __attribute__((always_inline)) {
     tx = ty = tz = 0.f;
     constexpr int U = 4;
@@ -739,12 +749,13 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
         ra[u] = in ? recA[(size_t)rg.x + k] : make_float4(0.f, 0.f, 0.f, 0.f);
         rb[u] = in ? recB[(size_t)rg.x + k] : make_float2(0.f, __int_as_float(id));
       }
-      V3 vj[U];
+      V3 vj[U], fj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = __float_as_int(rb[u].y);
         if (e1) vj[u] = V3{(j == 0 && a.ownsFirstElement) ? 1.f : 0.f, 0.f, 0.f};
         else vj[u] = *(const V3 *)(vsrc + 3 * (size_t)j);
+        if (RIDER && !e1) fj[u] = *(const V3 *)(riderFs + 3 * (size_t)j);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -753,6 +764,12 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
         tx += fmaf(gm, rij.x, ra[u].x * vj[u].x);
         ty += fmaf(gm, rij.y, ra[u].x * vj[u].y);
         tz += fmaf(gm, rij.z, ra[u].x * vj[u].z);
+        if (RIDER && !e1) {
+          const float gf = ra[u].y * dot3(rij, real3f{fj[u].x, fj[u].y, fj[u].z});
+          fx += fmaf(gf, rij.x, ra[u].x * fj[u].x);
+          fy += fmaf(gf, rij.y, ra[u].x * fj[u].y);
+          fz += fmaf(gf, rij.z, ra[u].x * fj[u].z);
+        }
       }
     }
     static_assert(kNearGroup == 8, "eight lanes per particle");
@@ -765,9 +782,15 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_near_pairs_lanczos(const flo
     tx = group_sum(tx);
     ty = group_sum(ty);
     tz = group_sum(tz);
+    if (RIDER && !e1) {
+      fx = group_sum(fx);
+      fy = group_sum(fy);
+      fz = group_sum(fz);
+    }
   };
   float tx, ty, tz;
   pair_sums(false, tx, ty, tz);
+  if (RIDER && active && sub == 0) { float *o = riderMFs + 3 * (size_t)id; o[0] = fx; o[1] = fy; o[2] = fz; }
   // hsup_(i-1) (k_l_c): the partials in lanczos.hip's order — thread t holds partial t, the wave sums, (s0 + s2) + (s1 + s3)
   float hs = hsGiven, inv = 1.f;
   if (scaled) {
@@ -969,11 +992,17 @@ __global__ void __launch_bounds__(256) k_pse_noise_sorted(float *__restrict__ ou
 // (instead of a copy command between the build and this kernel)
 __global__ void __launch_bounds__(256) k_pse_noise_sorted_norm(float *__restrict__ out3, const int *__restrict__ groupIndex, int N,
                                                                 float variance, uint seed1, uint seed2, float *__restrict__ parts,
-                                                                const int *__restrict__ status, int *__restrict__ statusHost, int nStatus) {
+                                                                const int *__restrict__ status, int *__restrict__ statusHost, int nStatus,
+                                                                const float4 *__restrict__ force4, float *__restrict__ forceSorted) {
   __shared__ float sh[4];
   float acc = 0.f;
   for (int k = blockIdx.x * 256 + threadIdx.x; k < N; k += gridDim.x * 256) {
-    Saru rng((uint)groupIndex[k], seed1, seed2);
+    const int idx = groupIndex[k];
+    if (force4) {   // (uammd_pse_near_set_mdot_rider: F in the list's order for the first product)
+      const float4 f = force4[idx];
+      forceSorted[3 * (size_t)k] = f.x; forceSorted[3 * (size_t)k + 1] = f.y; forceSorted[3 * (size_t)k + 2] = f.z;
+    }
+    Saru rng((uint)idx, seed1, seed2);
     const float2 a = rng.gf(0.0f, 1.0f);
     const float2 b = rng.gf(0.0f, 1.0f);
     const float x = a.x * variance, y = a.y * variance, z = b.x * variance;
@@ -989,12 +1018,19 @@ __global__ void __launch_bounds__(256) k_pse_noise_sorted_norm(float *__restrict
   if (status && blockIdx.x == 0)
     for (int t = threadIdx.x; t < nStatus; t += 256) statusHost[t] = status[t];
 }
+// (add3 / addTo: the rider's M_near F, in the list's order, added to the caller's MF on the way)
 __global__ void __launch_bounds__(256) k_pse_unsort3(const float *__restrict__ in3, const int *__restrict__ groupIndex, int N,
-                                                      float *__restrict__ out3) {
+                                                      float *__restrict__ out3, const float *__restrict__ add3 = nullptr,
+                                                      float *__restrict__ addTo = nullptr) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= N) return;
-  float *o = out3 + 3 * (size_t)groupIndex[k];
+  const size_t idx = (size_t)groupIndex[k];
+  float *o = out3 + 3 * idx;
   o[0] = in3[3 * (size_t)k]; o[1] = in3[3 * (size_t)k + 1]; o[2] = in3[3 * (size_t)k + 2];
+  if (add3) {
+    float *m = addTo + 3 * idx;
+    m[0] += add3[3 * (size_t)k]; m[1] += add3[3 * (size_t)k + 1]; m[2] += add3[3 * (size_t)k + 2];
+  }
 }
 
 // SaruTransform (NearField.cuh:218-228): make_real3(gf(0,1), gf(0,1).x) * variance
@@ -1303,8 +1339,14 @@ static int pse_lanczos_fused(void *ctx, LanczosFusedArgs *a, int n, void *stream
   const int nb = (N + kNearBlock / kNearGroup - 1) / (kNearBlock / kNearGroup);
   if (nb > a->partsACap || a->npB > kNearBlock) return 1;
   a->npA = nb;
-  hipLaunchKernelGGL(k_pse_near_pairs_lanczos, dim3(nb), dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr, (const float2 *)p->recB.ptr,
-                     (const int2 *)p->pairRange.ptr, N, *a);
+  if (p->riderArmed && !p->riderLaunched && p->riderFs.ptr && p->riderMFs.ptr) {   // the solve's first product carries M_near F along
+    hipLaunchKernelGGL(k_pse_near_pairs_lanczos<true>, dim3(nb), dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr,
+                       (const float2 *)p->recB.ptr, (const int2 *)p->pairRange.ptr, N, *a, (const float *)p->riderFs.ptr,
+                       (float *)p->riderMFs.ptr);
+    p->riderLaunched = true;
+  } else
+    hipLaunchKernelGGL(k_pse_near_pairs_lanczos<false>, dim3(nb), dim3(kNearBlock), 0, st, (const float4 *)p->recA.ptr,
+                       (const float2 *)p->recB.ptr, (const int2 *)p->pairRange.ptr, N, *a, (const float *)nullptr, (float *)nullptr);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1484,6 +1526,16 @@ int uammd_pse_near_set_option(uammd_pse_near *h, const char *name, int value) {
   set_last_error("uammd_pse_near_set_option: unknown option %s", name);
   return -1;
 }
+// One-shot: the NEXT uammd_pse_near_stochastic on this handle also does uammd_pse_near_mdot(h, its positions, d_force, N, d_MF) — as a
+// second right-hand side of the solve's first product where that product streams the pair records (they are read once for both),
+// by the plain product before it returns otherwise (also when T = 0).  d_MF += M_near F either way, after the interleaved work.
+int uammd_pse_near_set_mdot_rider(uammd_pse_near *h, const float *d_force, float *d_MF) {
+  if (!h || (d_force && !d_MF)) { set_last_error("uammd_pse_near_set_mdot_rider: null argument"); return -1; }
+  PSENear *p = reinterpret_cast<PSENear *>(h);
+  p->riderForce = d_force;
+  p->riderMF = d_force ? d_MF : nullptr;
+  return 0;
+}
 int uammd_pse_near_positions_changed(uammd_pse_near *h) {
   if (!h) { set_last_error("uammd_pse_near_positions_changed: null handle"); return -1; }
   reinterpret_cast<PSENear *>(h)->listValid = false;
@@ -1590,9 +1642,23 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
     if (hook.fn && !hook.fired) { if (int e = uammd_lanczos_set_interleave(p->lanczos, &Hook::tramp, &hook)) return e; }
     return 0;
   };
+  // the rider (uammd_pse_near_set_mdot_rider): M_near F added to riderMF by this call — inside the solve's first product, or, where no
+  // product took it (T = 0, the scanning products, an unfused solve), by the plain product on the way out
+  const float *riderF = p->riderForce;
+  float *riderMF = p->riderMF;
+  p->riderForce = nullptr;
+  p->riderMF = nullptr;
+  p->riderArmed = p->riderLaunched = false;
+  bool riderDone = riderF == nullptr;
   auto leave = [&](int rc) -> int {   // (a hook's own failure is reported when nothing else failed)
     hooks.early.flush(stream);
     hook.flush(stream);
+    p->riderArmed = false;
+    if (!rc && !riderDone && N > 0 && d_pos) {
+      riderDone = true;
+      rc = pse_update_list(p, d_pos, N, st);
+      if (!rc) rc = pse_dot<4, true>(p, riderF, riderMF, st);
+    }
     const int hrc = hooks.early.rc ? hooks.early.rc : hook.rc;
     if (!rc && hrc) {
       if (!uammd_hip_last_error()[0]) set_last_error("uammd_pse_near_stochastic: the interleaved callback failed (%d)", hrc);
@@ -1623,9 +1689,16 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
     const int nzb = std::min(256, (N + 255) / 256);
     if (int e = p->zparts.reserve(sizeof(float) * 256)) return e;
     const bool publish = p->statusCopyDeferred;
+    const bool rider = !riderDone;
+    if (rider) {
+      if (int e = p->riderFs.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+      if (int e = p->riderMFs.reserve(sizeof(float) * 3 * (size_t)N)) return e;
+    }
+    p->riderArmed = rider;
+    p->riderLaunched = false;
     hipLaunchKernelGGL(k_pse_noise_sorted_norm, dim3(nzb), dim3(256), 0, st, (float *)p->noise.ptr, (const int *)p->cl.index.ptr, N,
                        noise_prefactor, p->seed, seed2, (float *)p->zparts.ptr, publish ? (const int *)p->pairCursor.ptr : nullptr,
-                       p->pairTotalDev, kPairStatusInts);
+                       p->pairTotalDev, kPairStatusInts, rider ? (const float4 *)riderF : nullptr, rider ? (float *)p->riderFs.ptr : nullptr);
     UH_CHECK(hipGetLastError());
     if (publish) {
       p->statusCopyDeferred = false;
@@ -1665,9 +1738,11 @@ int uammd_pse_near_stochastic(uammd_pse_near *h, const float *d_pos, int N, floa
   }
   if (iterations) *iterations = it;
   if (rc) return leave(rc);
+  const bool carried = !riderDone && p->riderArmed && p->riderLaunched;   // the last solve's first product made M_near F (list order)
   hipLaunchKernelGGL(k_pse_unsort3, dim3((N + 255) / 256), dim3(256), 0, st, (const float *)p->sortedOut.ptr, (const int *)p->cl.index.ptr, N,
-                     d_BdW);
+                     d_BdW, carried ? (const float *)p->riderMFs.ptr : nullptr, carried ? riderMF : nullptr);
   UH_CHECK(hipGetLastError());
+  if (carried) riderDone = true;
   return leave(0);
 }
 
