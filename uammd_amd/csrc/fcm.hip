@@ -203,15 +203,28 @@ __global__ void __launch_bounds__(256) k_fcm_ibm(const float4 *__restrict__ pos,
 // small counting sort; the per-particle stencil origin and the 3*support 1-D weights are computed ONCE
 // (k_fcm_prepare) and reused by every tile that the particle touches and by the gather.
 constexpr int kTile = 8;
+// A particle belongs to the tile of its stencil's ORIGIN (the lowest node, wrapped into the grid): the stencil then reaches from inside
+// that tile towards + only, so a tile's candidates sit in the tiles at offsets -k .. 0 per axis, k = ceil((support - 1) / edge) —
+// eight tiles for the supports and edges of the bench's sizes, where binning by the particle's own cell needed all 27 (660 candidate
+// records per tile at C4 for ~105 accepted; now ~195).  rel: the origin relative to its tile, biased by 8, 7-bit fields.
+UH_D int stencil_tile(int ox, int oy, int oz, int3 n, int3 tdim, int3 ntiles, int *rel) {
+  const int wx = ox < 0 ? ox + n.x : ox, wy = oy < 0 ? oy + n.y : oy, wz = oz < 0 ? oz + n.z : oz;
+  const int tx = wx / tdim.x, ty = wy / tdim.y, tz = wz / tdim.z;
+  *rel = (wx - tx * tdim.x + 8) | (wy - ty * tdim.y + 8) << 7 | (wz - tz * tdim.z + 8) << 14;
+  return tx + ntiles.x * (ty + ntiles.y * tz);
+}
 
 
 __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict__ pos, int N, GridT<float> grid,
-                                                        int3 ntiles, FcmPrep pr) {
+                                                        int3 ntiles, FcmPrep pr, int3 support) {
   const int id = blockIdx.x * 256 + threadIdx.x;
   if (id >= N) return;
   const float4 p4 = pos[id];
-  const int3 celli = grid.getCell(real3f{p4.x, p4.y, p4.z});
-  const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
+  const real3f pi{p4.x, p4.y, p4.z};
+  const int3 celli = grid.getCell(pi);
+  const int3 P = compute_support_shift(grid, pi, celli, support);
+  int rel;
+  const int t = stencil_tile(celli.x - P.x, celli.y - P.y, celli.z - P.z, grid.cellDim, pr.tdim, ntiles, &rel);
   pr.tileOf[id] = t;
   pr.rank[id] = atomicAdd(&pr.tileCount[t], 1);
 }
@@ -229,7 +242,7 @@ __global__ void __launch_bounds__(256) k_fcm_bin_count(const float4 *__restrict_
 // the same tile — still, after one step — and the wave counts them itself: one atomic per tile and wave (three or four) instead of 64.
 // The binning pass is bound by the memory side's atomic rate (1e5 of them: ~9 us), not by its round trip.
 __global__ void __launch_bounds__(256) k_fcm_update_bin(float4 *__restrict__ pos, const float *__restrict__ linearV, int N, float dt,
-                                                         GridT<float> grid, int3 ntiles, FcmPrep pr, bool bin, bool bySlot) {
+                                                         GridT<float> grid, int3 ntiles, FcmPrep pr, bool bin, bool bySlot, int3 support) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= N) return;
   const int id = bySlot ? pr.origin[s].w : s;
@@ -239,8 +252,11 @@ __global__ void __launch_bounds__(256) k_fcm_update_bin(float4 *__restrict__ pos
   p.z = fmaf(linearV[3 * id + 2], dt, p.z);
   pos[id] = p;
   if (bin) {
-    const int3 celli = grid.getCell(real3f{p.x, p.y, p.z});
-    const int t = (celli.x / pr.tdim.x) + ntiles.x * ((celli.y / pr.tdim.y) + ntiles.y * (celli.z / pr.tdim.z));
+    const real3f pi{p.x, p.y, p.z};
+    const int3 celli = grid.getCell(pi);
+    const int3 P = compute_support_shift(grid, pi, celli, support);
+    int rel;
+    const int t = stencil_tile(celli.x - P.x, celli.y - P.y, celli.z - P.z, grid.cellDim, pr.tdim, ntiles, &rel);
     pr.tileOf[id] = t;
     if (!bySlot) { pr.rank[id] = atomicAdd(&pr.tileCount[t], 1); return; }
     // up to eight tiles per wave are counted by the wave (the lanes of a tile: their number, a lane's place among them, the lowest
@@ -346,11 +362,11 @@ __global__ void __launch_bounds__(256) k_fcm_prepare(const float4 *__restrict__ 
   if (sub) return;
   pr.origin[slot] = make_int4(ox, oy, oz, id);
   // the spreading kernel's record: the force and, in .w, the stencil origin relative to the particle's OWN tile (each in
-  // [-16, 7], biased by 16, in 7-bit fields: x | y << 7 | z << 14): one 16-byte load per candidate, no image arithmetic (a neighbour
+  // [0, edge), biased by 8 (stencil_tile), in 7-bit fields: x | y << 7 | z << 14): one 16-byte load per candidate, no image arithmetic (a neighbour
   // tile's frame is +-kTile away whatever the wrap); the spread adds a neighbour's shift and tests the three fields at once
   float4 fr = force ? force[id] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int rel = (ox - (celli.x / pr.tdim.x) * pr.tdim.x + 16) | (oy - (celli.y / pr.tdim.y) * pr.tdim.y + 16) << 7 |
-                  (oz - (celli.z / pr.tdim.z) * pr.tdim.z + 16) << 14;
+  int rel;
+  (void)stencil_tile(ox, oy, oz, grid.cellDim, pr.tdim, make_int3(1, 1, 1), &rel);
   fr.w = __int_as_float(rel);
   pr.force[slot] = fr;
 }
@@ -382,8 +398,10 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
   }
   const real3f pi{p.x, p.y, p.z};
   const int3 celli = grid.getCell(pi);
-  const int tcx = celli.x / pr.tdim.x, tcy = celli.y / pr.tdim.y, tcz = celli.z / pr.tdim.z;
-  const int t = tcx + ntiles.x * (tcy + ntiles.y * tcz);
+  const int3 P = compute_support_shift(grid, pi, celli, kern.support);
+  const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
+  int rel;
+  const int t = stencil_tile(ox, oy, oz, grid.cellDim, pr.tdim, ntiles, &rel);
   // the rank: the heads of a wave that share a tile are counted by the wave (up to eight tiles per wave; strangers one by one)
   const int lane = threadIdx.x & 63;
   unsigned long long rem = __ballot(head);
@@ -412,9 +430,7 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
     const unsigned long long changes = __ballot(head && lane >= LANES && t != tPrev);
     if (lane == 0 && changes) atomicAdd(&pr.slotCount[ntiles.x * ntiles.y * ntiles.z + 1], (int)__popcll(changes));
   }
-  // ... and while it is on its way: the stencil
-  const int3 P = compute_support_shift(grid, pi, celli, kern.support);
-  const int ox = celli.x - P.x, oy = celli.y - P.y, oz = celli.z - P.z;
+  // ... and while it is on its way: the stencil's weights
   const int sx = kern.support.x, sy = kern.support.y, sz = kern.support.z;
   if (live) {
     float *w = pr.weights + (size_t)pr.wstride * s;
@@ -429,7 +445,6 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
   if (head) pr.origin[s] = make_int4(ox, oy, oz, id);
   const int rank = __shfl(got, lead, 64) + before;
   if (!head) return;
-  const int rel = (ox - tcx * pr.tdim.x + 16) | (oy - tcy * pr.tdim.y + 16) << 7 | (oz - tcz * pr.tdim.z + 16) << 14;
   const int nt = ntiles.x * ntiles.y * ntiles.z;
   int slot;
   if (rank < pr.cap) slot = t * pr.cap + rank;
@@ -459,7 +474,7 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
 #define UAMMD_SP_WORDS 6144
 #endif
 #ifndef UAMMD_SP_PER_THREAD
-#define UAMMD_SP_PER_THREAD 3
+#define UAMMD_SP_PER_THREAD 2   // (round 5, ~195 candidates per C4 tile since the tiles are the stencil origins': 1 / 2 / 3 -> solve 0.1588 / 0.1595 / 0.1609 ms)
 #endif
 constexpr int kSpWeightWordsMax = UAMMD_SP_WORDS;
 constexpr int kSpWT = 3 * kTile;      // LDS words per listed particle: its weights at the tile's 8 nodes along x, y, z
@@ -540,15 +555,19 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   int myTile = numTiles, myShift = 0;  // threads < kRanges: their range's tile and packed shift
   if (threadIdx.x < kRanges) {
     const int nb = threadIdx.x;
-    const int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = nb / 9 - 1;
+    // the tiles whose particles can reach this one: offsets -k .. 0 per axis (stencil_tile)
+    const int ox1 = (sx - 2 + td.x) / td.x + 1, oy1 = (sy - 2 + td.y) / td.y + 1, oz1 = (sz - 2 + td.z) / td.z + 1;   // k + 1 each, <= 3
+    const bool used = nb < ox1 * oy1 * oz1;
+    const int dx = used ? -(nb % ox1) : 0, dy = used ? -((nb / ox1) % oy1) : 0, dz = used ? -(nb / (ox1 * oy1)) : 0;
     int ux = tx + dx, uy = ty + dy, uz = tz + dz;
     if (ux < 0) ux += ntiles.x; else if (ux >= ntiles.x) ux -= ntiles.x;
     if (uy < 0) uy += ntiles.y; else if (uy >= ntiles.y) uy -= ntiles.y;
     if (uz < 0) uz += ntiles.z; else if (uz >= ntiles.z) uz -= ntiles.z;
     if (nb < 27) myTile = ux + ntiles.x * (uy + ntiles.y * uz);
-    // a record's origin is relative to its own tile (biased by 16): in this tile's frame that is + one tile edge per tile step; with
-    // + 8 more every field of record + shift is (origin in this tile's frame) + 24, in [0, 47]: no carry between the 7-bit fields
-    myShift = (td.x * dx + 8) | (td.y * dy + 8) << 7 | (td.z * dz + 8) << 14;
+    // a record's origin is relative to its own tile (in [0, edge), biased by 8): in this tile's frame that is + one tile edge per tile
+    // step (steps 0, -1, -2); with + 16 more every field of the shift is >= 0 and every field of record + shift is (origin in this
+    // tile's frame) + 24, in [8, 31]: no carry or borrow between the 7-bit fields
+    myShift = (td.x * dx + 16) | (td.y * dy + 16) << 7 | (td.z * dz + 16) << 14;
     int s, e;
     if (SLOTS) {
       const int c = pr.slotCount[myTile];
@@ -558,6 +577,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       s = pr.tileStart[myTile];
       e = pr.tileStart[myTile + 1];
     }
+    if (nb < 27 && !used) e = s;   // (fewer than 27 source tiles)
     // inclusive scan of the range lengths inside wave 0
     const int incl = (int)wave_inclusive_scan((uint)(e - s));   // (DPP additions: the active lanes sit in rows 0 and 1)
     rPrefix[nb + 1] = incl;
@@ -720,11 +740,11 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       for (int u = 0; u < kU; ++u) {
         if (ovf[u]) {  // an overflow record: its tile comes with it, not with a range; the shift from the tiles' distance
           int ddx = tc[u] % ntiles.x - tx, ddy = (tc[u] / ntiles.x) % ntiles.y - ty, ddz = tc[u] / (ntiles.x * ntiles.y) - tz;
-          ddx += ddx > 1 ? -ntiles.x : (ddx < -1 ? ntiles.x : 0);
-          ddy += ddy > 1 ? -ntiles.y : (ddy < -1 ? ntiles.y : 0);
-          ddz += ddz > 1 ? -ntiles.z : (ddz < -1 ? ntiles.z : 0);
-          if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1 || ddz < -1 || ddz > 1) live[u] = false;
-          org[u] = (td.x * ddx + 8) | (td.y * ddy + 8) << 7 | (td.z * ddz + 8) << 14;
+          ddx -= ddx > 0 ? ntiles.x : 0;   // (a source tile sits at steps 0, -1, -2 of this one, around the box)
+          ddy -= ddy > 0 ? ntiles.y : 0;
+          ddz -= ddz > 0 ? ntiles.z : 0;
+          if (ddx < -2 || ddy < -2 || ddz < -2) { live[u] = false; ddx = ddy = ddz = 0; }
+          org[u] = (td.x * ddx + 16) | (td.y * ddy + 16) << 7 | (td.z * ddz + 16) << 14;
         }
         org[u] += (int)(rec[u] >> 42);
         key[u] = (int)(rec[u] & 0x1fffffull);
@@ -847,7 +867,7 @@ __global__ void __launch_bounds__(256) k_fcm_gather_tile(float *__restrict__ vou
   const int first = pr.tileStart[tile], last = pr.tileStart[tile + 1];
   if (first == last) return;  // the whole workgroup leaves: no particle interpolates from this window
   const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
-  const int wx0 = tx * pr.tdim.x - 4, wy0 = ty * pr.tdim.y - 4, wz0 = tz * pr.tdim.z - 4;  // window origin, unwrapped
+  const int wx0 = tx * pr.tdim.x, wy0 = ty * pr.tdim.y, wz0 = tz * pr.tdim.z;  // window origin: the tile's own (its particles' stencils start inside it)
   for (int e = threadIdx.x; e < 3 * kGW * kGW * (kGW / 2); e += 256) {
     const int q = e & 7, row = e >> 3;
     const int y = row & 15, z = (row >> 4) & 15, c = row >> 8;
@@ -868,7 +888,7 @@ __global__ void __launch_bounds__(256) k_fcm_gather_tile(float *__restrict__ vou
   for (int slot = first + wave; slot < last; slot += 4) {
     const int4 o = pr.origin[slot];
     const float wl = lane < sx + sy + sz ? pr.weights[(size_t)pr.wstride * slot + lane] : 0.0f;
-    const int lx = o.x - wx0, ly = o.y - wy0, lz = o.z - wz0;  // 1..9: the stencil stays inside the window
+    const int lx = (o.x < 0 ? o.x + n.x : o.x) - wx0, ly = (o.y < 0 ? o.y + n.y : o.y) - wy0, lz = (o.z < 0 ? o.z + n.z : o.z) - wz0;  // 0..7: the stencil stays inside the window
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int i0 = 0; i0 < nn; i0 += 64) {
       const int i = i0 + lane;
@@ -1727,7 +1747,7 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
   }
   if (!binned)
     hipLaunchKernelGGL(k_fcm_bin_count, dim3((N + 255) / 256), dim3(256), 0, st, (const float4 *)d_pos, N, f->grid,
-                       f->ntiles, pr);
+                       f->ntiles, pr, f->kern.support);
   hipLaunchKernelGGL(k_fcm_tile_scan, dim3(1), dim3(1024), 0, st, pr.tileCount, nt, pr.tileStart);
 #define UH_PREPARE(K)                                                                                          \
   case K:                                                                                                      \
@@ -2182,7 +2202,7 @@ int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_for
     pr.tdim = f->tdim;
   }
   hipLaunchKernelGGL(k_fcm_update_bin, dim3((N + 255) / 256), dim3(256), 0, st, (float4 *)d_pos, (const float *)v, N, dt, f->grid, f->ntiles,
-                     pr, bin, bin && f->binBySlot);
+                     pr, bin, bin && f->binBySlot, f->kern.support);
   UH_CHECK(hipGetLastError());
   if (bin) { f->binnedPending = true; f->binnedPos = (const void *)d_pos; f->binnedN = N; }
   return 0;
