@@ -659,7 +659,32 @@ def preflight(hip, args, world, rank, dist):
     def keyed(step, p, v, f, keys, step_num):
         check(lib.uammd_verletnvt_gj_keyed(step, C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), None, 1.0, None,
                                            C.c_void_p(keys.data_ptr()), p.shape[0], dt, 1.0, 0, noise, step_num, 4242, st()))
-    sim = DistributedLJ(d, None, lambda step, p, v, f, k: keyed(step, p, v, f, sim.current_ids, k), exchange_every=4, forces_into=forces_into)
+    # the step the timed run takes (run_lj_distributed): second half step in the traversal's store, first half step in the halo pack and
+    # the list build between refreshes — the preflight must exercise THAT path through the run's communicator
+    P = lambda t: C.c_void_p(t.data_ptr())
+
+    def forces_step2_into(allpos, box_L, periodic, fall, v):
+        box, cd, ubox = grid_of(box_L, periodic)
+        cl.update_grid(allpos, ubox, cd)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, 0)
+
+    def pack_step1(p, v, f, keys, iu, nu, idn, nd, dzu, dzd, ou, od, step_num):
+        check(lib.uammd_halo_pack_gj1(P(p), P(v), P(f), None, 1.0, P(keys), P(iu), nu, P(idn), nd, dzu, dzd, P(ou), P(od), dt, 1.0, 0, noise,
+                                      step_num, 4242, st()))
+
+    def forces_step12_into(allpos, box_L, periodic, fall, v, keys, skip, step_num):
+        box, cd, ubox = grid_of(box_L, periodic)
+        cl.update_grid_gj1(allpos, ubox, cd, v, fall, keys, skip, sim.n_owned, dt, 1.0, 0, noise, step_num, 4242)
+        cl.set_option("num_owned", sim.n_owned)
+        cl.transverse_lj_gj2(pot.device_table(), 1, box, fall, v, dt, None, 1.0, False, 0)
+        fused_steps.append(step_num)
+    fused_steps = []
+    timed_path = os.environ.get("UAMMD_BENCH_NO_GJ2") != "1" and os.environ.get("UAMMD_BENCH_OVERLAP") != "1"
+    fuse1 = timed_path and os.environ.get("UAMMD_BENCH_NO_GJ1") != "1"
+    sim = DistributedLJ(d, None, lambda step, p, v, f, k: keyed(step, p, v, f, sim.current_ids, k), exchange_every=4, forces_into=forces_into,
+                        forces_step2_into=forces_step2_into if timed_path else None,
+                        step1_fused=(pack_step1, forces_step12_into) if fuse1 else None)
     force = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
     for _ in range(steps):
         pos, vel, force, ids = sim.forward_time(pos, vel, force, ids)
@@ -693,7 +718,8 @@ def preflight(hip, args, world, rank, dist):
     Lg = torch.tensor([L1, L1, L1 * world], device="cuda")
     dx -= torch.round(dx / Lg) * Lg
     err = float(dx.abs().max())
-    report["lj"] = {"particles_per_rank": n, "steps": steps, "owned_after": int(pos.shape[0]), "max_dx_vs_single_domain": err, "bar": 2e-4}
+    report["lj"] = {"particles_per_rank": n, "steps": steps, "owned_after": int(pos.shape[0]), "max_dx_vs_single_domain": err, "bar": 2e-4,
+                    "steps_with_the_first_half_step_in_pack_and_build": len(fused_steps)}
     if not (err <= 2e-4):
         raise RuntimeError(f"slab LJ differs from the single-domain run: max |dx| {err:.3e} after {steps} steps (bar 2e-4)")
     # ---- path B ---------------------------------------------------------------------------------------------------------------------

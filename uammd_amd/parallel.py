@@ -566,6 +566,14 @@ class DistributedLJ:
         d.halo_refill(bp, n)
         self._nall = n + g_from_down + g_from_up
         self._split = None
+        if self.step1_fused is not None and d.width > 2.0 * reach:   # the listed rows' byte mask (the library refresh writes it itself)
+            if "listed" not in ws:
+                ws["listed"] = torch.zeros(cap, dtype=torch.uint8, device=dev)
+            m = ws["listed"]
+            m[:n].zero_()
+            m[iu.long()] = 1
+            m[idn.long()] = 1
+            self._listed_mask = m
         if self.integrate_rows_fn is not None and d.comm is not None and d.width > 2.0 * reach and 0 < h_up + h_down < n:
             # (up and down lists are disjoint when the slab is wider than two reaches: their concatenation lists every row once)
             listed = torch.cat([iu, idn])
