@@ -89,8 +89,25 @@ template <class T> UH_D T block_sum(T x, T *sh) {
   return t;
 }
 template <class T> UH_D T sum_parts(const T *__restrict__ parts, int nparts, T *sh) {  // every block: same order, same result
+  // (eight partials in flight at a time, added in the loop's own order: the same bits as one load per turn — the fused product leaves one
+  // partial per workgroup, 3125 at the PSE size: twelve dependent round trips per thread were most of k_l_b's 6 us)
   T x = 0;
-  for (int k = threadIdx.x; k < nparts; k += kLB) x += parts[k];
+  int k = threadIdx.x;
+  for (; k + 7 * kLB < nparts; k += 8 * kLB) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = parts[k + u * kLB];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x += v[u];
+  }
+  {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = k + u * kLB < nparts ? parts[k + u * kLB] : T(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u * kLB < nparts) x += v[u];
+  }
   T t = block_sum(x, sh);
   if (threadIdx.x == 0) sh[8] = t;
   __syncthreads();
