@@ -350,7 +350,48 @@ __global__ void __launch_bounds__(kLB) k_l_estimate_batch(const T *__restrict__ 
   T a[kLBatch], b[kLBatch];
 #pragma unroll
   for (int k = 0; k < kLBatch; ++k) a[k] = b[k] = T(0);
-  for (int i = blockIdx.x * kLB + threadIdx.x; i < n; i += gridDim.x * kLB) {
+  const int i00 = blockIdx.x * kLB + threadIdx.x, stride0 = gridDim.x * kLB;
+  const bool pre = (long)n <= (long)kLPre * stride0 && m0 + K - 1 <= 8;
+  if (pre) {
+    // a thread's few elements (n / 65536: 4.6 at the PSE size), each with its <= 8 columns and its previous estimate, ALL in flight
+    // together instead of one round trip per element; the same terms in the same order
+    T v[kLPre][8], pv[kLPre];
+    const int mLast = m0 + K - 1;
+#pragma unroll
+    for (int e = 0; e < kLPre; ++e) {
+      const int i = i00 + e * stride0;
+      pv[e] = i < n ? Bold[i] : T(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[e][u] = (i < n && u < mLast) ? V[(size_t)u * n + i] : T(0);
+    }
+#pragma unroll
+    for (int e = 0; e < kLPre; ++e) {
+      const int i = i00 + e * stride0;
+      if (i >= n) continue;
+      T s[kLBatch];
+#pragma unroll
+      for (int k = 0; k < kLBatch; ++k) s[k] = T(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int k = 0; k < kLBatch; ++k) s[k] = fma_(v[e][u], ys[k * kLDevM + u], s[k]);
+      }
+      T prev = pv[e];
+#pragma unroll
+      for (int k = 0; k < kLBatch; ++k)
+        if (k < K) {
+          const T r = s[k] * nz;
+          a[k] = fma_(prev, prev, a[k]);
+          const T d = r - prev;
+          b[k] = fma_(d, d, b[k]);
+          est[(size_t)k * n + i] = r;
+          prev = r;
+        }
+      Bz[i] = prev;
+      Bold[i] = prev;
+    }
+  }
+  for (int i = pre ? n : i00; i < n; i += stride0) {
     T s[kLBatch];
 #pragma unroll
     for (int k = 0; k < kLBatch; ++k) s[k] = T(0);
@@ -426,7 +467,13 @@ __global__ void __launch_bounds__(64 * 2 * kLBatch) k_l_error_batch(const T *__r
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < 2 * K) {
     T x = T(0);
-    for (int j = lane; j < nparts; j += 64) x += parts[(size_t)wv * kLParts + j];
+    static_assert(kLParts == 256, "four partials per lane");
+    T v[4];   // (in flight together, added in the loop's order)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = lane + 64 * u < nparts ? parts[(size_t)wv * kLParts + lane + 64 * u] : T(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (lane + 64 * u < nparts) x += v[u];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     if (lane == 0) tot[wv] = x;
