@@ -568,16 +568,19 @@ __global__ void __launch_bounds__(kNearBlock) k_pse_pairs_build(const float4 *__
   if (!active) cnt = 0;
   if (sub == 0) groupCount[grp] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int g = 0; g < kNearBlock / kNearGroup; ++g) tot += groupCount[g];
-    blockBase = tot ? atomicAdd(&status[16 + 16 * (blockIdx.x % nreg)], tot) : 0;
+  // the 32 groups' offsets inside the workgroup's reservation: one scan by the first wave (thread 0 adding 32 LDS words one after the
+  // other, then every group re-adding its predecessors', was ~3 us of a workgroup's life)
+  static_assert(kNearBlock / kNearGroup == 32, "one lane of the first wave per group");
+  if (threadIdx.x < 64) {
+    const int c = lane < 32 ? groupCount[lane] : 0;
+    const int incl = (int)wave_inclusive_scan((uint)c);
+    if (lane < 32) groupCount[lane] = incl - c;   // exclusive: the group's offset
+    if (lane == 31) blockBase = incl ? atomicAdd(&status[16 + 16 * (blockIdx.x % nreg)], incl) : 0;
   }
   if (__any(over) && lane == 0) status[1] = 1;
   __syncthreads();
   const long long regionCap = cap / nreg;
-  long long inRegion = blockBase;
-  for (int g = 0; g < grp; ++g) inRegion += groupCount[g];
+  const long long inRegion = (long long)blockBase + groupCount[grp];
   const long long off = (long long)(blockIdx.x % nreg) * regionCap + inRegion;
   const bool fits = inRegion + cnt <= regionCap;   // (past the region's capacity: the host grows the arrays and builds again)
   if (active && sub == 0) pairRange[id] = make_int2((int)off, fits ? cnt : 0);
@@ -1015,8 +1018,15 @@ __global__ void __launch_bounds__(256) k_pse_noise_sorted_norm(float *__restrict
   if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) parts[blockIdx.x] = (sh[0] + sh[2]) + (sh[1] + sh[3]);
-  if (status && blockIdx.x == 0)
-    for (int t = threadIdx.x; t < nStatus; t += 256) statusHost[t] = status[t];
+  if (status && blockIdx.x == 0) {   // (<= 5 words per thread: all read before the first is written across the bus)
+    int v[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) v[u] = (int)threadIdx.x + 256 * u < nStatus ? status[threadIdx.x + 256 * u] : 0;
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if ((int)threadIdx.x + 256 * u < nStatus) statusHost[threadIdx.x + 256 * u] = v[u];
+    for (int t = threadIdx.x + 256 * 5; t < nStatus; t += 256) statusHost[t] = status[t];
+  }
 }
 // (add3 / addTo: the rider's M_near F, in the list's order, added to the caller's MF on the way)
 __global__ void __launch_bounds__(256) k_pse_unsort3(const float *__restrict__ in3, const int *__restrict__ groupIndex, int N,
