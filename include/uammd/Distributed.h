@@ -54,6 +54,8 @@ class DistributedLJ {
   detail::DeviceArray<real> vel, rows, arrivals, sendUp, sendDown, maxd;
   detail::DeviceArray<int> ids, idx, holes, counts;
   detail::DeviceArray<char> tiles;
+  detail::DeviceArray<unsigned char> listed;   // one byte per owned row: is it in a halo list (uammd_slab_refresh_lj writes it)
+  bool fuseFirstHalfStep = false;              // a slab wider than two reaches: the up and down lists are disjoint
   uammd_celllist *cl = nullptr;
   Potential::LJ pot;
   hipStream_t st = 0;
@@ -62,45 +64,21 @@ class DistributedLJ {
   bool haveDrift = false;
 
   int *idxRow(int k) { return idx.d + (size_t)k * cap; }
-  void hostCounts(const int *dev2, int &toUp, int &toDown, int &fromDown, int &fromUp) {
-    comm->exchangeCountsDevice(dev2, toUp, toDown, fromDown, fromUp, st);  // (one synchronisation: the sizes travel from device memory)
-  }
   void refill() {  // the listed particles' current positions to the neighbours, straight into the ghost tail
     detail::check(uammd_halo_pack((const float *)pos.d, idxRow(2), nUpH, idxRow(3), nDownH, -width, width, sendUp.d, sendDown.d, (void *)st));
     comm->haloExchange(sendUp.d, nUpH, sendDown.d, nDownH, (real *)(pos.d + nOwned), gFromDown, (real *)(pos.d + nOwned + gFromDown), gFromUp, 4, st);
   }
+  // the membership refresh as ONE library call (uammd_slab_refresh_lj: displacement since the last refresh, leavers selected and migrated
+  // with their velocities and ids, halo members selected, their positions exchanged into the ghost tail; two host reads of message sizes)
   void refresh() {
-    const real half = real(0.5) * width;
-    if (skin > 0 && refN == nOwned) {
-      detail::check(uammd_slab_max_displacement((const float *)pos.d, (const float *)ref.d, nOwned, maxd.d, (void *)st));
-      haveDrift = true;
-    }
-    // who leaves
-    detail::check(uammd_slab_select((const float *)pos.d, nOwned, half, -half, idxRow(0), idxRow(1), counts.d, tiles.d, (void *)st));
-    int nUp, nDown, fromDown, fromUp;
-    hostCounts(counts.d, nUp, nDown, fromDown, fromUp);
-    const int nLeave = nUp + nDown, nArrive = fromDown + fromUp;
-    if (nLeave || nArrive) {
-      if (nLeave > cap || nArrive > cap || nOwned - nLeave + nArrive > cap) throw std::runtime_error("DistributedLJ: migration overflows the particle buffers");
-      detail::check(uammd_slab_pack_rows((const float *)pos.d, vel.d, ids.d, idxRow(0), nUp, idxRow(1), nDown, -width, width, rows.d,
-                                         rows.d + (size_t)8 * nUp, (void *)st));
-      comm->haloExchange(rows.d, nUp, rows.d + (size_t)8 * nUp, nDown, arrivals.d, fromDown, arrivals.d + (size_t)8 * fromDown, fromUp, 8, st);
-      detail::check(uammd_slab_unpack_rows((float *)pos.d, vel.d, ids.d, nOwned, idxRow(0), nUp, idxRow(1), nDown, arrivals.d, nArrive, holes.d,
-                                           (void *)st));
-      nOwned += nArrive - nLeave;
-    }
-    detail::check(uammd_fill_zero(force.d, sizeof(real4) * (size_t)nOwned, (void *)st));  // (arrivals: GJ step 1 zeroed the old layout's forces)
-    // who is in the halo
-    const real reach = rc + real(3.0) * skin;
-    detail::check(uammd_slab_select((const float *)pos.d, nOwned, half - reach, -half + reach, idxRow(2), idxRow(3), counts.d + 2, tiles.d, (void *)st));
-    hostCounts(counts.d + 2, nUpH, nDownH, gFromDown, gFromUp);
-    if (nOwned + gFromDown + gFromUp > cap) throw std::runtime_error("DistributedLJ: the halo overflows the position buffer");
-    nAll = nOwned + gFromDown + gFromUp;
-    refill();
-    if (skin > 0) {
-      detail::hipCheck(hipMemcpyAsync(ref.d, pos.d, sizeof(real4) * (size_t)nOwned, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
-      refN = nOwned;
-    }
+    int out[10];
+    const bool useRef = skin > 0;
+    if (useRef && refN == nOwned) haveDrift = true;
+    detail::check(uammd_slab_refresh_lj(comm->handle(), (float *)pos.d, vel.d, ids.d, (float *)force.d, nOwned, cap, width, rc + real(3.0) * skin,
+                                        idx.d, holes.d, counts.d, tiles.d, rows.d, arrivals.d, sendUp.d, useRef ? (float *)ref.d : nullptr, refN,
+                                        useRef ? maxd.d : nullptr, fuseFirstHalfStep ? listed.d : nullptr, out, (void *)st));
+    nOwned = out[0]; nAll = out[1]; nUpH = out[2]; nDownH = out[3]; gFromDown = out[4]; gFromUp = out[5];
+    if (useRef) refN = nOwned;
   }
   void forces() {  // owned + ghost positions -> forces of the owned rows, accumulated
     detail::check(uammd_celllist_update(cl, (const float *)pos.d, nAll, updL, updPer, cellDim, (void *)st));
@@ -110,6 +88,18 @@ class DistributedLJ {
   }
   void forcesAndSecondHalfStep() {  // the same, GronbechJensen's second half step of the owned rows riding in the traversal's store
     detail::check(uammd_celllist_update(cl, (const float *)pos.d, nAll, updL, updPer, cellDim, (void *)st));
+    detail::check(uammd_celllist_set_option(cl, "num_owned", nOwned));
+    detail::check(uammd_lj_transverse_celllist_gj2(cl, pot.deviceTable(), pot.getNumberTypes(), boxL, boxPer, (float *)force.d, vel.d, nullptr, real(1.0),
+                                                   dt, 0, UAMMD_LJ_ALGO_AUTO, (void *)st));
+  }
+  // a step between refreshes as four launches: GronbechJensen's first half step of the LISTED rows inside the halo pack, the exchange,
+  // the half step of everybody else inside the list build's hash kernel (the listed rows masked), forces + second half step
+  void fusedStep() {
+    detail::check(uammd_halo_pack_gj1((float *)pos.d, vel.d, (float *)force.d, nullptr, real(1.0), ids.d, idxRow(2), nUpH, idxRow(3), nDownH, -width,
+                                      width, sendUp.d, sendDown.d, dt, friction, 0, noiseAmplitude, (uint)steps, seed, (void *)st));
+    comm->haloExchange(sendUp.d, nUpH, sendDown.d, nDownH, (real *)(pos.d + nOwned), gFromDown, (real *)(pos.d + nOwned + gFromDown), gFromUp, 4, st);
+    detail::check(uammd_celllist_update_gj1(cl, (float *)pos.d, nAll, updL, updPer, cellDim, vel.d, (float *)force.d, nullptr, real(1.0), ids.d,
+                                            listed.d, nOwned, dt, friction, 0, noiseAmplitude, (uint)steps, seed, (void *)st));
     detail::check(uammd_celllist_set_option(cl, "num_owned", nOwned));
     detail::check(uammd_lj_transverse_celllist_gj2(cl, pot.deviceTable(), pot.getNumberTypes(), boxL, boxPer, (float *)force.d, vel.d, nullptr, real(1.0),
                                                    dt, 0, UAMMD_LJ_ALGO_AUTO, (void *)st));
@@ -148,6 +138,8 @@ public:
     size_t tb = 0;
     detail::check(uammd_slab_select_workspace(cap, &tb));
     tiles.resize(tb);
+    fuseFirstHalfStep = width > 2 * reach;
+    if (fuseFirstHalfStep) listed.resize(cap);
     detail::hipCheck(hipMemcpy(pos.d, localPos.data(), sizeof(real4) * nOwned, hipMemcpyHostToDevice), "hipMemcpy");
     detail::hipCheck(hipMemcpy(vel.d, localVel.data(), sizeof(real3) * nOwned, hipMemcpyHostToDevice), "hipMemcpy");
     detail::hipCheck(hipMemcpy(ids.d, localIds.data(), sizeof(int) * nOwned, hipMemcpyHostToDevice), "hipMemcpy");
@@ -165,8 +157,10 @@ public:
   void forwardTime() {
     steps++;
     if (steps == 1) { refresh(); forces(); }
+    const bool refreshNow = (steps - 1) % exchangeEvery == 0;
+    if (!refreshNow && fuseFirstHalfStep) { fusedStep(); return; }
     integrate(1);
-    if ((steps - 1) % exchangeEvery == 0) refresh(); else refill();
+    if (refreshNow) refresh(); else refill();
     forcesAndSecondHalfStep();
   }
   int numberOwned() const { return nOwned; }

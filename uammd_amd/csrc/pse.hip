@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -1217,7 +1218,9 @@ static int pse_pairs_verdict(PSENear *p, hipStream_t st, bool *ok) {
   *ok = false;
   const bool scanned = p->candScan, built = p->candBuild;
   if (scanned) {   // how far the particles are from where the list was made
-    const float d = std::sqrt(std::max(0.0f, *reinterpret_cast<const float *>(&p->pairTotalHost[2])));
+    float d2 = 0.0f;
+    std::memcpy(&d2, &p->pairTotalHost[2], sizeof(float));   // (float bits in the int block)
+    const float d = std::sqrt(std::max(0.0f, d2));
     if (d > p->lastDisp) p->maxInc = std::max(p->maxInc, d - p->lastDisp);
     p->lastDisp = d;
     if (!(d <= 0.5f * p->skin)) {   // (also a NaN reading)
