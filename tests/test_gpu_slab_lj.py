@@ -200,3 +200,46 @@ def test_slab_world1_matches_single_domain(hip):
     dz = got[:, :3] - ref[:, :3]
     dz -= np.round(dz / L) * L          # the slab keeps z folded into its frame, the single domain does not fold
     assert np.abs(dz).max() <= 2e-4
+
+
+def test_slab_step_through_comm_vs_oracle(hip, o32):
+    """The bench's slab step (every message through uammd_comm_* = RCCL, membership refresh by the library, first half step in the halo
+    pack and the list build, second in the traversal's store) against the ORACLE's loop — cell list, LJ traversal, GronbechJensen with the
+    same thermostat stream (keyed by the particle's global id = its row in the oracle's arrays) — particle by particle after 12 thermal
+    steps with refreshes and migration across the periodic z faces.  The chain to the oracle does not run through another HIP path."""
+    from uammd_amd._lib import check, load
+    from uammd_amd.comm import AbiComm
+    lib = load()
+    n, L, rc, dt, T, steps = 30000, 33.5, 2.5, 0.005, 1.0, 12
+    comm = AbiComm(0, 1, AbiComm.unique_id())
+    try:
+        gp, gv, gids, _ = _run(hip, n, L, steps, fused=True, comm=comm, step2=True, fuse1=True, T=T, exchange_every=5)
+        assert getattr(sim_box[-1], "fused1_steps", 0) >= 8
+    finally:
+        comm.close()
+    rp = lattice_positions(n, L, seed=11, jitter=0.1).copy()
+    vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, 1.0, 0, n, 77, None))
+    rv = vel.cpu().numpy().copy()
+    pot = hip.Potential.LJ()
+    pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
+    noise = math.sqrt(2 * dt * T)
+
+    def forces(p):
+        cd, oL, oper = o32.celllist_create_grid(L, 1, rc)
+        cl = o32.celllist_build(p, oL, oper, cd)
+        f, _, _ = o32.lj_transverse_celllist(cl, L, 1, pot.table, 1, n)
+        return f
+    rf = forces(rp)
+    for s in range(1, steps + 1):
+        o32.verletnvt_gj(1, rp, rv, rf, dt, 1.0, noise, s, 4242)
+        rf = forces(rp)
+        o32.verletnvt_gj(2, rp, rv, rf, dt, 1.0, noise, s, 4242)
+    order = np.argsort(gids)
+    assert np.array_equal(gids[order], np.arange(n))
+    dx = gp[order, :3] - rp[:, :3]
+    dx -= np.round(dx / L) * L
+    dv = np.abs(gv[order] - rv).max(axis=1)
+    print(f"[slab vs oracle, {steps} steps] max|dx| {np.abs(dx).max():.2e}; |dv| max {dv.max():.2e}, 99.9th percentile {np.quantile(dv, 0.999):.2e}")
+    assert np.abs(dx).max() <= 2e-5
+    assert np.quantile(dv, 0.999) <= 1e-4 and dv.max() <= 2e-3
