@@ -76,6 +76,8 @@ struct Comm {
   int rank = 0, world = 1;
   int *d_counts = nullptr;   // 4 ints of device scratch for uammd_comm_exchange_counts
   int *h_counts = nullptr;   // 4 ints of pinned host memory: the landing place of uammd_comm_exchange_counts_device's one read
+  // UAMMD_COMM_SELF_THROUGH_RCCL=1: the all-to-all sends the rank's own block through RCCL too (how it was until round 5: A/B runs)
+  bool selfThroughRccl = getenv("UAMMD_COMM_SELF_THROUGH_RCCL") && atoi(getenv("UAMMD_COMM_SELF_THROUGH_RCCL")) != 0;
 };
 
 }  // namespace uammd_hip
@@ -196,8 +198,15 @@ int uammd_comm_alltoall(uammd_comm *h, const void *d_send, void *d_recv, size_t 
   Comm *c = reinterpret_cast<Comm *>(h);
   hipStream_t st = (hipStream_t)stream;
   if (bytesPerPeer == 0) return 0;
+  // the rank's OWN block (1 / world of the transpose) does not go through the network layer: a send to oneself is a kernel and a staging
+  // copy there (18.7 + 5 us for 25 MB at a world of one); here it is one device-to-device copy on the same stream
+  if (!c->selfThroughRccl)
+    UH_CHECK(hipMemcpyAsync((char *)d_recv + (size_t)c->rank * bytesPerPeer, (const char *)d_send + (size_t)c->rank * bytesPerPeer, bytesPerPeer,
+                            hipMemcpyDeviceToDevice, st));
+  if (c->world == 1 && !c->selfThroughRccl) return 0;
   UH_NCCL(g_rccl.GroupStart());
   for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank && !c->selfThroughRccl) continue;
     UH_NCCL(g_rccl.Send((const char *)d_send + (size_t)p * bytesPerPeer, bytesPerPeer, ncclInt8, p, c->comm, st));
     UH_NCCL(g_rccl.Recv((char *)d_recv + (size_t)p * bytesPerPeer, bytesPerPeer, ncclInt8, p, c->comm, st));
   }
