@@ -470,6 +470,9 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
 // LDS budget of phase B in words, chosen per call (spread_weight_words): 24 words per listed particle (kSpWT), 6144 = 256 listed
 // particles (a C4 tile lists ~105), 3072 = 128 where tiles are sparse (a C5 tile lists ~26); with the list either fits five
 // workgroups per CU beside the 24.6 KB floor of the final tile sum.
+#ifndef UAMMD_SP_ABLATE   // (timing builds only, tools/variants_fcm.sh: 1 no weights copy, 2 no matrix phase, 4 no tile sum / store, 8 nothing accepted)
+#define UAMMD_SP_ABLATE 0
+#endif
 #ifndef UAMMD_SP_WORDS   // (A/B builds: tools/variants_fcm.sh — 6144 words / 4 candidates per thread: within 1 % of these at C4 and 108^3)
 #define UAMMD_SP_WORDS 6144
 #endif
@@ -623,7 +626,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       const int r = threadIdx.x & 31, axis = r >> 3, t = r & 7;
       const int sa = axis == 0 ? sx : (axis == 1 ? sy : sz), aoff = axis == 0 ? 0 : (axis == 1 ? sx : sx + sy);
       const int pp0 = threadIdx.x >> 5;
-      if (r < kSpWT)
+      if (r < kSpWT && !(UAMMD_SP_ABLATE & 1))
         staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
             [&](int j) {
               const SpEntry &en = sh.list[pp0 + (kThreads / 32) * j];
@@ -645,7 +648,12 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     const int mineCount = (count - wave + W - 1) / W;  // entries wave, wave + W, ... of the list
     __builtin_amdgcn_s_setprio(0);  // (the arithmetic phase yields to the workgroups that are issuing loads: see the kernel's top)
     const int zAt = 16 + (aValid ? aKz : 0);  // (rows 24..31 of the A operand carry no plane: force 0, any word)
-    for (int j = 0; j < mineCount; j += 2) {
+    // (Measured and not kept, round 5: the list put in the order [y < 4 only | both halves | y >= 4 only] — 8 of 13 possible y origins
+    // leave one half of the tile's columns, i.e. one of the two products, untouched — and a step issuing only the products its two
+    // particles need: 31 % fewer matrix instructions, 45.4 -> 50.7 us.  Switching the phases off one at a time (UAMMD_SP_ABLATE) prices
+    // this loop at 18.7 us, the weights' copy at 8.6, the tile sum and store at 5.3, ranges + candidate tests at 9 — but the matrix pipe
+    // itself is busy for ~14 of the 18.7 only on paper: the partition's two barriers and the branches around the products cost more.)
+    for (int j = 0; j < ((UAMMD_SP_ABLATE & 2) ? 0 : mineCount); j += 2) {
       const int idx = j + half;
       const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
       const int e = wave + W * (real ? idx : 0);
@@ -676,7 +684,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     unsigned long long m[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      accept[u] = live[u] && ((((org[u] | kGuard) - lo3) & (hi3 - org[u])) & kGuard) == kGuard;
+      accept[u] = !(UAMMD_SP_ABLATE & 8) && live[u] && ((((org[u] | kGuard) - lo3) & (hi3 - org[u])) & kGuard) == kGuard;
       m[u] = __ballot(accept[u]);
       if (lane == 0) waveCnt[4 * u + wave] = __popcll(m[u]);
     }
@@ -773,6 +781,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   }
   SP_STAMP(1);  // candidates tested, list complete
   if (listCount > 0) spread_list(listCount);
+  if (UAMMD_SP_ABLATE & 4) { if (acc0[0] + acc1[0] == 123.456f) g0[0] = 1.f; return; }
   {
     // accumulator v of lane l is row n = 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32; rows 24..31 (v >= 12) are unused
     float *mine = acc + wave * 3 * T3;  // node (x, y, z) of the tile = xy + 64 z
