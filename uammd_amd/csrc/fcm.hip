@@ -1110,17 +1110,22 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_col(float *__r
 // rows jj = 0..4 and the first two columns of row 5 — for the loop over the z planes, and ONE more load fetches what is left of row 5
 // (columns 2..5 of every plane: 4 sz <= 32 nodes, lane -> (2 + (l & 3), l >> 2)).  sz + 1 loads per PAIR of particles instead of 2 sz.
 // Same terms as k_fcm_gather_col, summed in another order (the half wave's sum is the first five steps of wave_sum_to_last).
-template <int SZMAX>
+// S = 7 (the PSE far field's support at the bench's size): the first 32 of the 49 columns in the loop, the other 17 x sz nodes in four more
+// loads — 11 per pair of particles where the column form issues 14 with 49 of 64 lanes at work.
+template <int S, int SZMAX>
 __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_half(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
                                                                        int sz, float dV, FcmPrep pr, bool accumulate) {
+  constexpr int R = S * S - 32;                          // columns the loop does not cover (row-major order: column c = (c % S, c / S))
+  constexpr int ROUNDS = (R * SZMAX + 31) / 32;
+  static_assert(R > 0 && 2 * S + SZMAX <= 32, "supports 6 and 7");
   const int lane = threadIdx.x & 63, h = lane >> 5, l = lane & 31;
   const int slot0 = ((int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6)) * 2;
   if (slot0 >= N) return;
   const bool valid = slot0 + h < N;
   const int slot = min(slot0 + h, N - 1);
   const int4 o = pr.origin[slot];
-  const float wl = pr.weights[(size_t)pr.wstride * slot + min(l, 12 + sz - 1)];   // lanes 0..5 wx, 6..11 wy, 12.. wz of the half's particle
-  const int jj = (l * 43) >> 8, ii = l - 6 * jj;   // l / 6, l % 6 for l < 36
+  const float wl = pr.weights[(size_t)pr.wstride * slot + min(l, 2 * S + sz - 1)];   // lanes 0..S-1 wx, S..2S-1 wy, 2S.. wz of the half's particle
+  const int jj = l / S, ii = l - S * jj;
   const uint planeNodes = (uint)n.x * (uint)n.y;
   auto wrap = [](int c, int m) { return c < 0 ? c + m : (c >= m ? c - m : c); };
   const uint base = (uint)wrap(o.x + ii, n.x) + (uint)n.x * (uint)wrap(o.y + jj, n.y);
@@ -1129,33 +1134,44 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_half(float *__
   for (int kk = 0; kk < SZMAX; ++kk)
     if (kk < sz)
       g[kk] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + ((base + planeNodes * (uint)wrap(o.z + kk, n.z)) << 4));
-  // the rest of row 5
-  const int ii2 = 2 + (l & 3), kk2 = l >> 2;
-  const bool rest = kk2 < sz;
-  const uint base2 = (uint)wrap(o.x + ii2, n.x) + (uint)n.x * (uint)wrap(o.y + 5, n.y) + planeNodes * (uint)wrap(o.z + (rest ? kk2 : 0), n.z);
-  const float4 g2 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + (base2 << 4));
+  // the columns beyond the first 32, plane by plane: node m = l + 32 r -> column 32 + m % R of plane m / R
+  float4 g2[ROUNDS];
+  int ii2[ROUNDS], jj2[ROUNDS], kk2[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int m = l + 32 * r;
+    kk2[r] = m / R;
+    const int col = 32 + (m - R * kk2[r]);
+    jj2[r] = col / S;
+    ii2[r] = col - S * jj2[r];
+    const bool rest = kk2[r] < sz;
+    if (!rest) kk2[r] = 0;
+    const uint b2 = (uint)wrap(o.x + ii2[r], n.x) + (uint)n.x * (uint)wrap(o.y + jj2[r], n.y) + planeNodes * (uint)wrap(o.z + kk2[r], n.z);
+    g2[r] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(gi) + (b2 << 4));
+    if (!rest) kk2[r] = -1;
+  }
   const int hb = h << 5;
-  const float wxy = __shfl(wl, hb + ii, 64) * __shfl(wl, hb + 6 + jj, 64);
+  const float wxy = __shfl(wl, hb + ii, 64) * __shfl(wl, hb + S + jj, 64);
   float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
   for (int kk = 0; kk < SZMAX; ++kk) {
     if (kk < sz) {
-      const float wzA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 12 + kk));
-      const float wzB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 32 + 12 + kk));
+      const float wzA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 2 * S + kk));
+      const float wzB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 32 + 2 * S + kk));
       const float w = wxy * (h ? wzB : wzA);
       ax = fmaf(g[kk].x, w, ax);
       ay = fmaf(g[kk].y, w, ay);
       az = fmaf(g[kk].z, w, az);
     }
   }
-  {
-    const float w5 = h ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 32 + 11))
-                       : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), 11));
-    const float w = __shfl(wl, hb + ii2, 64) * w5 * __shfl(wl, hb + 12 + (rest ? kk2 : 0), 64);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const bool rest = kk2[r] >= 0;
+    const float w = __shfl(wl, hb + ii2[r], 64) * __shfl(wl, hb + S + jj2[r], 64) * __shfl(wl, hb + 2 * S + (rest ? kk2[r] : 0), 64);
     if (rest) {
-      ax = fmaf(g2.x, w, ax);
-      ay = fmaf(g2.y, w, ay);
-      az = fmaf(g2.z, w, az);
+      ax = fmaf(g2[r].x, w, ax);
+      ay = fmaf(g2[r].y, w, ay);
+      az = fmaf(g2[r].z, w, az);
     }
   }
   auto half_sum = [](float x) {   // lanes 31 and 63 end with their half's sum
@@ -1187,16 +1203,21 @@ static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, i
   static const int halfMode = getenv("UAMMD_FCM_GATHER_HALF") ? atoi(getenv("UAMMD_FCM_GATHER_HALF")) : 1;   // (A/B runs: 0 off, 2 also on grids read from HBM)
   if (halfMode == 2 && perWave >= 0 && support.x == 6 && support.y == 6 && support.z <= 8 && nodes * sizeof(float4) < ((size_t)1 << 32)) {
     const dim3 g((N + kGatherWaves * 2 - 1) / (kGatherWaves * 2)), b(64 * kGatherWaves);
-    if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
-    else hipLaunchKernelGGL((k_fcm_gather_half<8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+    if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6, 6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+    else hipLaunchKernelGGL((k_fcm_gather_half<6, 8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
     return;
   }
   if (perWave >= 0 && support.x <= 8 && support.y <= 8 && support.z <= 8 && nodes * sizeof(float4) <= ((size_t)128 << 20)) {
     constexpr int P = 2;  // (32.9 / 33.5 / 36.4 us with 2 / 3 / 4 particles per wave at C4)
     const dim3 g((N + kGatherWaves * P - 1) / (kGatherWaves * P)), b(64 * kGatherWaves);
     if (support.x == 6 && support.y == 6 && halfMode != 0) {
-      if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
-      else hipLaunchKernelGGL((k_fcm_gather_half<8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6, 6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      else hipLaunchKernelGGL((k_fcm_gather_half<6, 8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      return;
+    }
+    if (support.x == 7 && support.y == 7 && halfMode != 0) {
+      if (support.z <= 7) hipLaunchKernelGGL((k_fcm_gather_half<7, 7>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
+      else hipLaunchKernelGGL((k_fcm_gather_half<7, 8>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
       return;
     }
     if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_col<2, 6>), g, b, 0, st, vout, gi, N, n, support, dV, pr, accumulate);
