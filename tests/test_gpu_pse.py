@@ -605,3 +605,34 @@ def test_mdot_rides_on_the_solve(hip, o32):
         before = MF.clone()
         check(pse.lib.uammd_pse_near_stochastic(pse.near, _ptr(pd.getPos()), n, T, 1.0, 78, _ptr(BdW), current_stream(), C.byref(it)))
         assert torch.equal(MF, before)
+
+
+@pytest.mark.gpu
+def test_kept_lists_step_aside_in_a_box_of_three_cells(hip, o32):
+    """A box that holds three cells of the cut-off per direction but not three of cut-off + skin: the 27-cell scan on the wider grid would
+    meet a cell twice.  The handle keeps the reference's grid and builds its list per step (the mechanism reports itself off); products
+    against the oracle before and after a move."""
+    from uammd_amd._lib import check
+    from uammd_amd.md import _ptr, current_stream
+    import ctypes as C
+    L, n, tol, psi = 16.0, 2000, 1e-3, 0.6        # rc = 4.38: 3 cells of 5.33; rc + 40 % = 6.13: 2 cells
+    pd, pse, ref, pos, _ = _pair(hip, o32, L, tol, psi, n)
+    assert int(L / pse.rcut) == 3 and int(L / (1.4 * pse.rcut)) == 2
+    rng = np.random.default_rng(3)
+    f4 = np.zeros((n, 4), np.float32)
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    d_f = torch.from_numpy(f4).cuda()
+    cur = pos.copy()
+    for k in range(3):
+        if k:
+            cur = cur.copy()
+            cur[:, :3] += rng.uniform(-0.01, 0.01, (n, 3)).astype(np.float32)
+            pd.getPos("write").copy_(torch.from_numpy(cur).cuda())
+        MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        check(pse.lib.uammd_pse_near_mdot(pse.near, _ptr(pd.getPos()), _ptr(d_f), n, _ptr(MF), current_stream()))
+        expect = np.zeros((n, 3), np.float32)
+        ref.near_mdot(cur, f4, expect)
+        assert np.abs(MF.cpu().numpy() - expect).max() <= 1e-6 * np.abs(expect).max(), k
+    s = (C.c_longlong * 4)()
+    check(pse.lib.uammd_pse_near_list_stats(pse.near, s))
+    assert s[3] == 0 and s[1] == 0 and s[0] == 3

@@ -1103,19 +1103,26 @@ static int pse_update_list(PSENear *p, const float *d_pos, int N, hipStream_t st
   p->candValid = false;
   p->candScan = false;
   p->statusZeroed = false;
-  const bool keep = pse_cand_usable(p);
-  p->candBuild = keep;
-  p->skin = keep ? 0.01f * (float)p->skinPercent * p->rcut : 0.0f;
+  bool keep = pse_cand_usable(p);
   p->stepsSinceFull = 0;
   p->lastDisp = 0.0f;
   const float g = p->shear;
   const float safety = (float)(1 + 0.5 * g * g + 0.5 * std::sqrt(g * g * (g * g + 4.0)));  // NearField.cuh:24-27
-  const float rc = (p->rcut + p->skin) * safety;
-  const float rc3[3] = {rc, rc, rc};
   const int per[3] = {1, 1, 1};
   int cd[3], gper[3];
   float gL[3];
-  if (int e = uammd_celllist_create_grid(p->boxL, per, rc3, cd, gL, gper)) return e;
+  for (;;) {
+    p->skin = keep ? 0.01f * (float)p->skinPercent * p->rcut : 0.0f;
+    const float rc = (p->rcut + p->skin) * safety;
+    const float rc3[3] = {rc, rc, rc};
+    if (int e = uammd_celllist_create_grid(p->boxL, per, rc3, cd, gL, gper)) return e;
+    // the scan visits the 27 cells around a particle's: with fewer than three cells along a periodic direction it would meet a cell twice.
+    // A box that holds three cells of the cut-off but not three of cut-off + skin keeps the reference's grid (no kept lists).
+    if (!keep || (cd[0] >= 3 && cd[1] >= 3 && cd[2] >= 3)) break;
+    keep = false;
+    p->candEnabled = false;
+  }
+  p->candBuild = keep;
   p->N = N;
   if (int e = p->cl.update((const float4 *)d_pos, N, gL, gper, cd, st)) return e;
   if (keep) {   // the positions the kept list's displacement bound is measured from
