@@ -908,6 +908,8 @@ def run_lj_distributed(hip, args, world, rank, dist):
     assert torch.isfinite(pos).all()
     assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
     sim.check_skin()
+    if sim.max_drift is not None:   # (how much of the skin the timed region used: the cached exchange is exact while this stays below it)
+        SLAB_STEP["largest_displacement_between_refreshes"] = float(sim.max_drift)
     tot, cnt = cl.profile_read()
     k_ms = tot / max(cnt, 1)
     return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
