@@ -180,7 +180,7 @@ int main(int argc, char *argv[]) {
     const real rc = 2.5;
     Xorshift128plus rng(99);
     std::vector<real4> p(N);
-    for (auto &v : p) { const real3 u = rng.uniform3(-0.5, 0.5); v = make_real4(u.x * L, u.y * L, u.z * L, 0); }
+    for (auto &v : p) { const real3 u = make_real3(rng.uniform3(-0.5, 0.5)); v = make_real4(u.x * L, u.y * L, u.z * L, 0); }
     cached_vector<real4> d_pos(N);
     CudaSafeCall(hipMemcpy(d_pos.data(), p.data(), sizeof(real4) * N, hipMemcpyHostToDevice));
     Box box(L);

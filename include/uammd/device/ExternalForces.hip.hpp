@@ -43,9 +43,9 @@ template <class Functor> class ExternalForces : public Interactor {
   ParameterUpdatable *delegate() { return ExternalForces_ns::updatable(tr.get()); }
   template <class... Ptr, size_t... I>
   void launch(Computables comp, hipStream_t st, std::tuple<Ptr...> arrays, std::index_sequence<I...>) {
-    const int n = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    const int n = subgroup ? subgroup->getNumberParticles() : pd->getNumParticles();
     if (n <= 0) return;
-    const int *groupIndex = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;
+    const int *groupIndex = subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr;
     real4 *force = comp.force ? pd->getForce(access::gpu, access::readwrite).raw() : nullptr;
     real *energy = comp.energy ? pd->getEnergy(access::gpu, access::readwrite).raw() : nullptr;
     real *virial = comp.virial ? pd->getVirial(access::gpu, access::readwrite).raw() : nullptr;

@@ -163,14 +163,14 @@ public:
   template <class Transverser> void sumTransverser(Transverser &tr, hipStream_t st) {  // PairForces.cu:43-68
     const real rcut = pot->getCutOff();
     const bool useNeighbourList = !(box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut);
-    const int *globalIndex = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;
+    const int *globalIndex = subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr;
     if (useNeighbourList) {
-      if (!nl) nl = pairforces_detail::makeList(pd, pg, (NL *)nullptr);
+      if (!nl) nl = pairforces_detail::makeList(pd, subgroup, (NL *)nullptr);
       nl->update(box, rcut, st);
       if (pairforces_detail::transverseList(*nl, tr, globalIndex, st) != 0)
         throw cuda_generic_error(std::string("PairForces: traversal failed: ") + uammd_hip_last_error(), -1);
     } else {
-      const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+      const int N = subgroup ? subgroup->getNumberParticles() : pd->getNumParticles();
       auto pos = pd->getPos(access::gpu, access::read);
       if (device::transverseNBody(pos.raw(), globalIndex, tr, N, st) != 0) throw cuda_generic_error("PairForces: all-pairs traversal failed", -1);
     }

@@ -198,10 +198,11 @@ public:
   }
   uint32_t next32() { return next() % std::numeric_limits<uint32_t>::max(); }
   double uniform(double min, double max) { return min + (next() / ((double)0xFFffFFffFFffFFffULL)) * (max - min); }
-  real3 uniform3(double min, double max) {
+  ::double3 uniform3(double min, double max) {   // (double3, as utils/utils.h:70)
     const double a = uniform(min, max), b = uniform(min, max), c = uniform(min, max);
-    return {(real)a, (real)b, (real)c};
+    return ::double3(a, b, c);
   }
+  ::double2 uniform2(double min, double max) { const double a = uniform(min, max), b = uniform(min, max); return ::double2(a, b); }
   // Box-Muller, two numbers per pair of uniforms: the second is handed out by the next call (utils/utils.h:77-104; the spare is shared by
   // all generators of the process there, and here)
   double gaussian(double mean, double std) {
@@ -925,12 +926,15 @@ protected:
   shared_ptr<ParticleData> pd;
   shared_ptr<System> sys;
   std::string name;
-  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
+  shared_ptr<ParticleGroup> pg;        // the group the module acts on — ALWAYS valid, as in the reference (Interactor.cuh:46-60: built from a
+                                       // ParticleData it is the group of all particles); user classes derived from this one say pg->...
+  shared_ptr<ParticleGroup> subgroup;  // the same group when it is a proper subset, nullptr for all the particles (what the code below branches on)
 public:
   struct Computables { bool force = false, energy = false, virial = false, stress = false; };
-  Interactor(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  Interactor(shared_ptr<ParticleData> pd, std::string name = "noName")
+      : pd(pd), sys(pd->getSystem()), name(std::move(name)), pg(std::make_shared<ParticleGroup>(pd, "All")) {}
   Interactor(shared_ptr<ParticleGroup> pg, std::string name = "noName")
-      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg->isAll() ? nullptr : pg) {}
+      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg), subgroup(pg->isAll() ? nullptr : pg) {}
   virtual ~Interactor() = default;
   virtual void sum(Computables comp, hipStream_t st = 0) = 0;
   std::string getName() { return name; }
@@ -951,21 +955,23 @@ protected:
   std::string name;
   std::vector<shared_ptr<Interactor>> interactors;
   std::vector<shared_ptr<ParameterUpdatable>> updatables;
-  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
+  shared_ptr<ParticleGroup> pg;        // ALWAYS valid (Integrator.cuh:41-55), see Interactor
+  shared_ptr<ParticleGroup> subgroup;  // nullptr = all the particles
 public:
-  Integrator(shared_ptr<ParticleData> pd, std::string name = "noName") : pd(pd), sys(pd->getSystem()), name(std::move(name)) {}
+  Integrator(shared_ptr<ParticleData> pd, std::string name = "noName")
+      : pd(pd), sys(pd->getSystem()), name(std::move(name)), pg(std::make_shared<ParticleGroup>(pd, "All")) {}
   Integrator(shared_ptr<ParticleGroup> pg, std::string name = "noName")
-      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg->isAll() ? nullptr : pg) {}
+      : pd(pg->getParticleData()), sys(pd->getSystem()), name(std::move(name)), pg(pg), subgroup(pg->isAll() ? nullptr : pg) {}
   virtual ~Integrator() = default;
   virtual void forwardTime() = 0;
   virtual real sumEnergy() { return 0; }
 protected:
   // the particles this integrator moves: the members of its group (all of them without one)
-  int groupSize() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
-  const int *groupIndex() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
+  int groupSize() const { return subgroup ? subgroup->getNumberParticles() : pd->getNumParticles(); }
+  const int *groupIndex() { return subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr; }
   void resetGroupForces(hipStream_t st) {  // thrust::fill(forceGroup, forceGroup + N, real4()) of the reference's integrators
     auto force = pd->getForce(access::gpu, access::write);
-    if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
+    if (subgroup) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
     else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)st));
   }
 public:
@@ -1311,20 +1317,20 @@ private:
 public:
   bool fusedGronbechJensenStep(const FusedGronbechJensen &a) override {
     const real rcut = pot->getCutOff();
-    if (pg || (box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut)) return false;
+    if (subgroup || (box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut)) return false;
     return fusedStep(nl, pd, pot, box, a);
   }
   void sum(Computables comp, hipStream_t st = 0) override {  // PairForces.cu:43-78
     float L[3]; int per[3];
     box.toArrays(L, per);
     const real rcut = pot->getCutOff();
-    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    const int N = subgroup ? subgroup->getNumberParticles() : pd->getNumParticles();
     const bool useNL = !(box.boxSize.x <= 3 * rcut && box.boxSize.y <= 3 * rcut && box.boxSize.z <= 3 * rcut);
     if (useNL) {
-      if (!nl) nl = makeList(pd, pg, (NL *)nullptr);
+      if (!nl) nl = makeList(pd, subgroup, (NL *)nullptr);
       nl->update(box, rcut, st);
     }
-    const int *globalIndex = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;
+    const int *globalIndex = subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr;
     auto force = comp.force ? pd->getForce(access::gpu, access::readwrite) : property_ptr<real4>();
     auto energy = comp.energy ? pd->getEnergy(access::gpu, access::readwrite) : property_ptr<real>();
     auto virial = comp.virial ? pd->getVirial(access::gpu, access::readwrite) : property_ptr<real>();
@@ -1354,8 +1360,8 @@ protected:
   hipStream_t stream = 0;
   virtual int kernelKind() const { return 0; }
   void callIntegrate(int step) {
-    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
-    const int *index = pg ? pg->getIndicesRawPtr(access::gpu) : nullptr;  // pg->getIndexIterator(access::gpu)
+    const int N = subgroup ? subgroup->getNumberParticles() : pd->getNumParticles();
+    const int *index = subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr;  // subgroup->getIndexIterator(access::gpu)
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto vel = pd->getVel(access::gpu, access::readwrite);
     auto force = pd->getForce(access::gpu, access::readwrite);
@@ -1366,7 +1372,7 @@ protected:
   }
   void resetForces() {  // the members' forces only (Basic.cu:108-115)
     auto force = pd->getForce(access::gpu, access::write);
-    if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), pg->getIndicesRawPtr(access::gpu), pg->getNumberParticles(), (int)sizeof(real4), (void *)stream));
+    if (subgroup) detail::check(uammd_fill_zero_indexed(force.raw(), subgroup->getIndicesRawPtr(access::gpu), subgroup->getNumberParticles(), (int)sizeof(real4), (void *)stream));
     else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), (void *)stream));
   }
 public:
@@ -1382,9 +1388,9 @@ public:
     if (!pd->isMassAllocated() && defaultMass < 0) defaultMass = 1.0;
     if (par.initVelocities) {
       auto vel = pd->getVel(access::gpu, access::write);
-      detail::check(uammd_verletnvt_initial_velocities((float *)vel.raw(), pg ? pg->getIndicesRawPtr(access::gpu) : nullptr,
+      detail::check(uammd_verletnvt_initial_velocities((float *)vel.raw(), subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr,
                                                        (real)std::sqrt(3.0 * temperature), is2D,
-                                                       pg ? pg->getNumberParticles() : pd->getNumParticles(), sys->rng().next32(), nullptr));
+                                                       subgroup ? subgroup->getNumberParticles() : pd->getNumParticles(), sys->rng().next32(), nullptr));
     }
   }
   void forwardTime() override {  // Basic.cu:148-171, GronbechJensen.cu:88-115
@@ -1396,7 +1402,7 @@ public:
       for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
       detail::hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
     }
-    if (kernelKind() == 1 && !pg && interactors.size() == 1) {  // GronbechJensen + one interactor: try the fused step
+    if (kernelKind() == 1 && !subgroup && interactors.size() == 1) {  // GronbechJensen + one interactor: try the fused step
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto vel = pd->getVel(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::readwrite);
@@ -1410,12 +1416,12 @@ public:
     callIntegrate(2);
   }
   real sumEnergy() override {  // sumKineticEnergy, Basic.cu:186-207: energy[i] += m v^2 / 2, returns 0
-    const int N = pg ? pg->getNumberParticles() : pd->getNumParticles();
+    const int N = subgroup ? subgroup->getNumberParticles() : pd->getNumParticles();
     auto vel = pd->getVel(access::gpu, access::read);
     auto energy = pd->getEnergy(access::gpu, access::readwrite);
     auto mass = defaultMass > 0 ? property_ptr<real>() : pd->getMassIfAllocated(access::gpu, access::read);
     detail::check(uammd_sum_kinetic_energy((const float *)vel.raw(), energy.raw(), mass.raw(), defaultMass,
-                                           pg ? pg->getIndicesRawPtr(access::gpu) : nullptr, N, (void *)stream));
+                                           subgroup ? subgroup->getIndicesRawPtr(access::gpu) : nullptr, N, (void *)stream));
     return 0;
   }
 };
@@ -2149,14 +2155,14 @@ public:
     {
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
-      detail::check(uammd_bdhi2d_velocities(h, (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
-                                            interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, st),
+      detail::check(uammd_bdhi2d_velocities(h, (const float *)detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, st),
+                                            interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), subgroup.get(), forceRows, st),
                                             N, (float *)particleVels.d, (void *)st));
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
-    real4 *rows = pg ? posRows.d : pos.raw();  // (a proper subgroup: the gathered rows above, moved, then written back through the index)
+    real4 *rows = subgroup ? posRows.d : pos.raw();  // (a proper subgroup: the gathered rows above, moved, then written back through the index)
     detail::check(uammd_bdhi2d_update_positions((float *)rows, (const float *)particleVels.d, N, dt, (void *)st));
-    detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), st);
+    detail::scatterRows((const real4 *)rows, pos.raw(), subgroup.get(), st);
   }
 };
 using True2D = BDHI2D<BDHI2D_ns::True2D>;
@@ -2210,10 +2216,10 @@ public:
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::read);
-      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
-      detail::check(uammd_fib_forward(h, (float *)rows, (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, nullptr),
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, nullptr));
+      detail::check(uammd_fib_forward(h, (float *)rows, (const float *)detail::groupRows((const real4 *)force.raw(), subgroup.get(), forceRows, nullptr),
                                       groupSize(), nullptr));
-      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
+      detail::scatterRows((const real4 *)rows, pos.raw(), subgroup.get(), nullptr);
     }
     for (auto &u : updatables) u->updateSimulationTime(step * dt);
   }
@@ -2284,9 +2290,9 @@ public:
     const int N = groupSize();
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
-      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, nullptr));
       detail::check(uammd_icm_predictor(h, (float *)rows, N, nullptr));
-      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
+      detail::scatterRows((const real4 *)rows, pos.raw(), subgroup.get(), nullptr);
     }
     for (auto &u : updatables) u->updateSimulationTime((step - 0.5) * dt);
     if (!interactors.empty()) {
@@ -2296,10 +2302,10 @@ public:
     {
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::readwrite);
-      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, nullptr));
-      detail::check(uammd_icm_fluid_and_corrector(h, (float *)rows, interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, nullptr), N, nullptr));
-      detail::scatterRows((const real4 *)rows, pos.raw(), pg.get(), nullptr);
-      if (pg) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), N, (int)sizeof(real4), nullptr));
+      real4 *rows = const_cast<real4 *>(detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, nullptr));
+      detail::check(uammd_icm_fluid_and_corrector(h, (float *)rows, interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), subgroup.get(), forceRows, nullptr), N, nullptr));
+      detail::scatterRows((const real4 *)rows, pos.raw(), subgroup.get(), nullptr);
+      if (subgroup) detail::check(uammd_fill_zero_indexed(force.raw(), groupIndex(), N, (int)sizeof(real4), nullptr));
       else detail::check(uammd_fill_zero(force.raw(), sizeof(real4) * force.size(), nullptr));  // correctorStep, :1176-1181
     }
     for (auto &u : updatables) u->updateSimulationTime(step * dt);
@@ -2313,7 +2319,7 @@ class Poisson : public Interactor {
   uammd_poisson_info info{};
   detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
   detail::DeviceArray<real> chargeRows, energyRows;
-  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
+  int numberParticles() const { return subgroup ? subgroup->getNumberParticles() : pd->getNumParticles(); }
 public:
   struct Parameters {  // SpectralEwaldPoisson.cuh:94-103; cells and support are never read by the reference's constructor
     real upsampling = -1.0;
@@ -2345,7 +2351,7 @@ public:
     auto charge = pd->getCharge(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::readwrite);
     auto energy = pd->getEnergy(access::gpu, access::readwrite);
-    ParticleGroup *g = pg.get();  // a proper subgroup: the members' rows gathered, the sums written back through the group's index
+    ParticleGroup *g = subgroup.get();  // a proper subgroup: the members' rows gathered, the sums written back through the group's index
     real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, st));
     real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, st));
     detail::check(uammd_poisson_sum(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, st),
@@ -2364,7 +2370,7 @@ public:
       auto charge = pd->getCharge(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::readwrite);
       auto energy = pd->getEnergy(access::gpu, access::readwrite);
-      ParticleGroup *g = pg.get();
+      ParticleGroup *g = subgroup.get();
       real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, nullptr));
       real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, nullptr));
       detail::check(uammd_poisson_field_potential(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, nullptr),

@@ -44,6 +44,12 @@ UAMMD_HD real4 make_real4(real4 a) { return a; }
 UAMMD_HD real4 make_real4(real3 a) { return real4(a.x, a.y, a.z, real(0)); }
 UAMMD_HD real4 make_real4(real3 a, real w) { return real4(a.x, a.y, a.z, w); }
 UAMMD_HD real4 make_real4(real2 a, real2 b) { return real4(a.x, a.y, b.x, b.y); }
+// from the double-precision vectors (System::rng().uniform3 / gaussian3 hand out double3, utils/utils.h:70,97; the reference's own test
+// programs accumulate in double3: test/BDHI/FCM/FCM.cu:88-101) — utils/vector.cuh:341,371
+UAMMD_HD real3 make_real3(::double3 a) { return real3(real(a.x), real(a.y), real(a.z)); }
+UAMMD_HD real4 make_real4(::double3 a, real w) { return real4(real(a.x), real(a.y), real(a.z), w); }
+UAMMD_HD real4 make_real4(::double4 a) { return real4(real(a.x), real(a.y), real(a.z), real(a.w)); }
+UAMMD_HD real2 make_real2(::double2 a) { return real2(real(a.x), real(a.y)); }
 // (make_int2 / make_int3 of three scalars are the runtime's; these are the conversions it does not have)
 UAMMD_HD int2 make_int2(int3 a) { return int2(a.x, a.y); }
 UAMMD_HD int2 make_int2(real2 a) { return int2(int(a.x), int(a.y)); }
@@ -90,4 +96,26 @@ UAMMD_HD real3 sqrt(const real3 &a) { return real3(std::sqrt(a.x), std::sqrt(a.y
 UAMMD_HD real3 abs(const real3 &a) { return real3(std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)); }
 
 }  // namespace uammd
+
+// ---- double3 / double4 beside the runtime's own arithmetic on them (utils/vector.cuh:410-777, at global scope as there) -------------------
+UAMMD_HD ::double3 make_double3(uammd::real3 a) { return ::double3(a.x, a.y, a.z); }
+UAMMD_HD ::double3 make_double3(uammd::real4 a) { return ::double3(a.x, a.y, a.z); }
+UAMMD_HD ::double3 make_double3(double a) { return ::double3(a, a, a); }
+UAMMD_HD ::double3 make_double3(::double3 a) { return a; }
+UAMMD_HD ::double3 make_double3(::double2 xy, double z) { return ::double3(xy.x, xy.y, z); }
+UAMMD_HD ::double3 make_double3(double x, ::double2 yz) { return ::double3(x, yz.x, yz.y); }
+UAMMD_HD ::double3 make_double3(uammd::int3 a) { return ::double3(a.x, a.y, a.z); }
+UAMMD_HD ::double3 make_double3(::double4 a) { return ::double3(a.x, a.y, a.z); }
+UAMMD_HD ::double4 make_double4(::double3 a) { return ::double4(a.x, a.y, a.z, 0.0); }
+UAMMD_HD ::double4 make_double4(::double3 a, double w) { return ::double4(a.x, a.y, a.z, w); }
+UAMMD_HD ::double4 make_double4(uammd::real4 a) { return ::double4(a.x, a.y, a.z, a.w); }
+UAMMD_HD uammd::int3 make_int3(::double3 a) { return uammd::int3(int(a.x), int(a.y), int(a.z)); }
+UAMMD_HD double dot(const ::double3 &a, const ::double3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+UAMMD_HD double dot(const ::double4 &a, const ::double4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+UAMMD_HD double length(const ::double3 &v) { return std::sqrt(dot(v, v)); }
+UAMMD_HD ::double3 normalize(const ::double3 &v) { return v * (1.0 / length(v)); }
+UAMMD_HD ::double3 cross(const ::double3 &a, const ::double3 &b) { return ::double3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+UAMMD_HD ::double3 floorf(const ::double3 &v) { return ::double3(std::floor(v.x), std::floor(v.y), std::floor(v.z)); }
+UAMMD_HD ::double3 abs(const ::double3 &a) { return ::double3(std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)); }
+inline std::ostream &operator<<(std::ostream &out, const ::double3 &f) { return out << f.x << " " << f.y << " " << f.z; }
 #endif

@@ -144,3 +144,39 @@ def test_reference_LJ_program_runs(tmp_path):
     print("mean z of type 0:", z0, " of type 1:", z1)
     assert (kind == 0).sum() > n // 4 and (kind == 1).sum() > n // 4
     assert z0 < -1.0 and z1 > 1.0
+
+
+@pytest.mark.gpu
+def test_reference_acceptance_programs_run(tmp_path):
+    """examples/_build/ref_test_{FCM,PSE} = the REFERENCE's own acceptance programs test/BDHI/FCM/FCM.cu and test/BDHI/PSE/PSE.cu (plain
+    programs; test.bash beside them drives them and plots), compiled from where they lie by hipcc against include/uammd and linked with
+    libuammd_hip.  Their user-side Interactor pulls particle 0 through `pg->getNumberParticles()` and the CPU property accessors — the
+    base class's `pg` must be the group of all particles for a module built from a ParticleData, as in the reference (it was null until
+    round 5: the programs crashed).  Self mobility in cubic boxes of 8 .. 128 hydrodynamic radii (FCM) and over psi and L (PSE): every
+    entry of |1 - M / M0| within the criterion of the reference's script, 2 / (L / rh)^6 + tolerance."""
+    tol = 1e-3
+    fcm = os.path.join(EX, "_build", "ref_test_FCM")
+    pse = os.path.join(EX, "_build", "ref_test_PSE")
+    if not (os.path.exists(fcm) and os.path.exists(pse)):
+        pytest.skip("the acceptance programs were not built (no reference tree where `make -C examples` ran)")
+    r = subprocess.run([fcm, "selfMobilityCubicBox", "0", "1", "1", str(tol)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [[float(x) for x in l.split()] for l in open(tmp_path / "selfMobilityCubicBox.test") if l.strip()]
+    assert len(rows) == 20
+    for row in rows:
+        bar = 2.0 / row[0] ** 6 + tol
+        assert max(row[1:]) <= bar, (row[0], max(row[1:]), bar)
+    print("FCM self mobility: largest |1 - M/M0| %.2e over 20 boxes" % max(max(row[1:]) for row in rows))
+    r = subprocess.run([pse, "selfMobility", "0", "1", "1", str(tol)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("selfMobility_pullForce"))
+    assert len(files) >= 3
+    worst = 0.0
+    for f in files:
+        for l in open(tmp_path / f):
+            if l.startswith("#") or not l.strip():
+                continue
+            L, dev = (float(x) for x in l.split()[:2])
+            worst = max(worst, abs(dev))
+            assert abs(dev) <= 2.0 / L ** 6 + tol, (f, L, dev)
+    print("PSE self mobility: largest deviation %.2e over %d values of psi" % (worst, len(files)))

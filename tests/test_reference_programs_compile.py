@@ -28,7 +28,11 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
          "uammd_as_a_library/neighbour_list.cu", "advanced/NeighbourListIterator.cu", "advanced/signals.cu", "advanced/temporary_memory.cu",
          "advanced/customPotentials.cu", "advanced/error_handling.cu", "integration_schemes/others/FCM.cu", "integration_schemes/others/BDHI.cu",
          "integration_schemes/others/q2D.cu", "interaction_modules/Poisson.cu", "interaction_modules/external.cu",
-         "uammd_as_a_library/electrostatic_forces.cu"]
+         "uammd_as_a_library/electrostatic_forces.cu",
+         # the reference's own ACCEPTANCE programs of path B (test/, not examples/): self / pair mobility, noise variance, Hasimoto's
+         # correction — the ones that are plain programs (the *_test.cu files beside them need gtest / gmock, which this image lacks)
+         "../test/BDHI/FCM/FCM.cu", "../test/BDHI/PSE/PSE.cu", "../test/BDHI/FIB/FIB.cu", "../test/BDHI/Lanczos_Cholesky/BDHI.cu",
+         "../test/BDHI/quasi2D/q2D.cu"]
 # Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
 # advanced/execution_policy.cu includes <cuda_profiler_api.h>; integration_schemes/icm.cu needs Hydro/ICM_Compressible (out of
 # scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation).
@@ -52,7 +56,7 @@ def _compile(job):
         cmd = ["g++", "-std=c++14", "-x", "c++", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + INC + [src]
     else:
         src, _ = _source(rel, tmp, ".hip")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fsyntax-only"] + INC + [src]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fsyntax-only", "-I", os.path.dirname(os.path.join(REF, rel))] + INC + [src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return (kind, rel), (r.returncode, r.stderr[-3000:])
 
