@@ -1780,12 +1780,12 @@ public:
     resetGroupForces(st);
     if (pd->isDirAllocated()) {  // computeCurrentForces, BDHI_FCM.cu:50-57
       auto torque = pd->getTorque(access::gpu, access::write);
-      if (pg) detail::check(uammd_fill_zero_indexed(torque.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
+      if (subgroup) detail::check(uammd_fill_zero_indexed(torque.raw(), groupIndex(), groupSize(), (int)sizeof(real4), (void *)st));
       else detail::check(uammd_fill_zero(torque.raw(), sizeof(real4) * torque.size(), (void *)st));
     }
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
     const int N = groupSize();
-    if (!pg && !pd->isDirAllocated() && !pd->isTorqueAllocated()) {  // no rotation: the update rides in the solver's interpolation kernel
+    if (!subgroup && !pd->isDirAllocated() && !pd->isTorqueAllocated()) {  // no rotation: the update rides in the solver's interpolation kernel
       const bool kept = !posTouched;  // (getPosWriteRequestedSignal: somebody may have moved the particles since our last step)
       auto pos = pd->getPos(access::gpu, access::readwrite);
       auto force = pd->getForce(access::gpu, access::read);
@@ -1797,8 +1797,8 @@ public:
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
       auto torque = pd->getTorqueIfAllocated(access::gpu, access::read);
-      fcm->computeHydrodynamicDisplacements(detail::groupRows(pos.raw(), pg.get(), posRows, st), detail::groupRows(force.raw(), pg.get(), forceRows, st),
-                                            detail::groupRows(torque.raw(), pg.get(), torqueRows, st), linearV.d, angularV.d, N, temperature,
+      fcm->computeHydrodynamicDisplacements(detail::groupRows(pos.raw(), subgroup.get(), posRows, st), detail::groupRows(force.raw(), subgroup.get(), forceRows, st),
+                                            detail::groupRows(torque.raw(), subgroup.get(), torqueRows, st), linearV.d, angularV.d, N, temperature,
                                             1.0 / std::sqrt(dt), st);
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
