@@ -1664,6 +1664,8 @@ public:
     const real hmin = std::min(hx, std::min(hy, hz));
     // initializeKernel + fixHydrodynamicRadius (BDHI_FCM.cuh:49-66, :104-106)
     hydrodynamicRadius = p.hydrodynamicRadius = Kernel::make(hmin, par.tolerance, &p.kernel);
+    if (p.kernel.support[0] >= p.cells[0] || p.kernel.support[1] >= p.cells[1] || p.kernel.support[2] >= p.cells[2])   // BDHI_FCM.cuh:58-64: said, not fatal
+      System::log<System::ERROR>("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
     detail::check(uammd_fcm_create(&p, &h));
     uammd_ibm_kernel kt;  // initializeKernelTorque, BDHI_FCM.cuh:69-80
     detail::check(uammd_fcm_torque_gaussian_kernel(hydrodynamicRadius, hmin, par.tolerance, &kt));

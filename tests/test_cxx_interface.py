@@ -180,3 +180,16 @@ def test_reference_acceptance_programs_run(tmp_path):
             worst = max(worst, abs(dev))
             assert abs(dev) <= 2.0 / L ** 6 + tol, (f, L, dev)
     print("PSE self mobility: largest deviation %.2e over %d values of psi" % (worst, len(files)))
+    # pair mobility against the open-boundary formula, boxes from 2.1 distances (the kernel's support exceeds the first grids: the reference
+    # says so and goes on, BDHI_FCM.cuh:58-64) to 100 radii: the periodic images' share shrinks with the box
+    r = subprocess.run([fcm, "pairMobilityCubicBox", "0", "1", "1", str(tol)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Kernel support is too big" in r.stderr
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("pairMobilityCubicBox.dist"))
+    assert len(files) == 3
+    for f in files:
+        rows = [[float(x) for x in l.split()] for l in open(tmp_path / f) if l.strip() and not l.startswith("#")]
+        assert len(rows) == 20 and all(np.isfinite(row).all() for row in rows)
+        # (diagonal entries: columns 1, 5, 9)
+        first, last = max(rows[0][1], rows[0][5], rows[0][9]), max(rows[-1][1], rows[-1][5], rows[-1][9])
+        assert last < 0.1 * first and last < 0.05, (f, first, last)

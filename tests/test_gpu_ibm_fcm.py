@@ -669,3 +669,21 @@ def test_fcm_slot_layout_survives_a_relayout_of_the_callers_arrays(hip):
         assert np.abs(x - y).max() <= 2e-5 * scale
     for x in a[1:]:
         assert np.abs(x - a[0]).max() <= 2e-5 * scale   # and the layout of the caller's arrays changes nothing
+
+
+@pytest.mark.parametrize("cells,L", [([6, 6, 6], 4.2), ([5, 6, 8], (3.5, 4.2, 5.6))], ids=["6cube", "5x6x8"])
+def test_fcm_support_not_smaller_than_the_grid(hip, o32, cells, L, capfd):
+    """A box so small that the kernel's support (6 at tolerance 1e-3) reaches or exceeds the grid: the reference logs an ERROR and goes on
+    (BDHI_FCM.cuh:58-64) — its own acceptance program sweeps through such boxes (test/BDHI/FCM/FCM.cu:299-331) — with stencils that wrap
+    around the box.  Followed as far as one wrap per axis reaches (what Grid::pbc_cell does): same displacements as the oracle, T = 0 and
+    with noise; a grid that does not hold half a support is refused."""
+    n, tol = 7, 1e-3
+    pos, force, fcm, ofcm = _fcm_case(hip, o32, n, cells, L, tol)
+    assert "Kernel support is too big" in capfd.readouterr().err
+    assert fcm.kernel_support()[0] >= min(cells) if hasattr(fcm, "kernel_support") else True
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    v = fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0).cpu().numpy()
+    vref = ofcm.displacements(pos, force)
+    assert np.isfinite(v).all() and np.linalg.norm(v - vref) <= 1e-5 * np.linalg.norm(vref)
+    with pytest.raises(RuntimeError, match="support is too big"):
+        hip.BDHI.FCM_impl(hip.Box(1.4), [2, 2, 2], fcm_kernel(hip, [2, 2, 2], 1.4, tol), 1.3, 1, 1.0)

@@ -205,6 +205,9 @@ class FCM_impl:
         p.viscosity, p.seed, p.kernel, p.hydrodynamicRadius = float(viscosity), int(seed) & 0xFFFFFFFF, kernel, float(hydrodynamicRadius)
         if box.boxSize[0] <= 0:
             raise RuntimeError("Invalid arguments")  # FCM_impl.cuh:74-77
+        if any(int(kernel.support[k]) >= int(cells[k]) for k in range(3)):   # BDHI_FCM.cuh:58-64: the reference says so and goes on
+            import sys
+            print("[ERROR] [BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.", file=sys.stderr)
         h = C.c_void_p()
         check(self.lib.uammd_fcm_create(C.byref(p), C.byref(h)))
         self.h, self.box, self.cells = h, box, [int(c) for c in cells]

@@ -1914,7 +1914,11 @@ int uammd_fcm_create(const uammd_fcm_parameters *par, uammd_fcm **out) {
       set_last_error("uammd_fcm_create: kernel support %d outside [1, %d]", par->kernel.support[a], kMaxSupport);
       return -2;
     }
-    if (par->kernel.support[a] >= par->cells[a]) {  // BDHI_FCM.cuh:58-64 (the reference logs an ERROR)
+    // A support that is not smaller than the grid: the reference logs an ERROR and goes on (BDHI_FCM.cuh:58-64) — its own acceptance
+    // program sweeps through such boxes (test/BDHI/FCM/FCM.cu:299-331, L from 2.1 distances) — with stencils that wrap around the box and
+    // meet nodes more than once.  Followed (the host layer prints the reference's line) as far as ONE wrap per axis reaches, which is
+    // as far as the reference's own Grid::pbc_cell goes (utils/Grid.cuh: one +- n): the grid must hold half a support.
+    if (2 * par->cells[a] < par->kernel.support[a] + 1) {
       set_last_error("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
       return -2;
     }
