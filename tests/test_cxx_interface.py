@@ -2,6 +2,8 @@
 import os
 import subprocess
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
