@@ -195,3 +195,12 @@ def test_reference_acceptance_programs_run(tmp_path):
         # (diagonal entries: columns 1, 5, 9)
         first, last = max(rows[0][1], rows[0][5], rows[0][9]), max(rows[-1][1], rows[-1][5], rows[-1][9])
         assert last < 0.1 * first and last < 0.05, (f, first, last)
+    # test/BDHI/FIB/FIB.cu, same sweep on the staggered grid: its three-point Peskin kernel is translation invariant to about a percent
+    fib = os.path.join(EX, "_build", "ref_test_FIB")
+    if os.path.exists(fib):
+        os.remove(tmp_path / "selfMobilityCubicBox.test")
+        r = subprocess.run([fib, "selfMobilityCubicBox", "0", "1", "1", str(tol)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rows = [[float(x) for x in l.split()] for l in open(tmp_path / "selfMobilityCubicBox.test") if l.strip()]
+        assert len(rows) == 20 and max(max(row[1:]) for row in rows) <= 3e-2
+        print("FIB self mobility: largest |1 - M/M0| %.2e over 20 boxes" % max(max(row[1:]) for row in rows))

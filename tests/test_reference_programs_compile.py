@@ -30,7 +30,8 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
          "integration_schemes/others/q2D.cu", "interaction_modules/Poisson.cu", "interaction_modules/external.cu",
          "uammd_as_a_library/electrostatic_forces.cu",
          # the reference's own ACCEPTANCE programs of path B (test/, not examples/): self / pair mobility, noise variance, Hasimoto's
-         # correction — the ones that are plain programs (the *_test.cu files beside them need gtest / gmock, which this image lacks)
+         # correction — the ones that are plain programs (the *_test.cu files beside them need gtest / gmock, which this image lacks); FCM.cu, PSE.cu and
+         # FIB.cu are also BUILT and RUN on the GPU (tests/test_cxx_interface.py::test_reference_acceptance_programs_run)
          "../test/BDHI/FCM/FCM.cu", "../test/BDHI/PSE/PSE.cu", "../test/BDHI/FIB/FIB.cu", "../test/BDHI/Lanczos_Cholesky/BDHI.cu",
          "../test/BDHI/quasi2D/q2D.cu"]
 # Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
