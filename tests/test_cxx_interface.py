@@ -204,3 +204,29 @@ def test_reference_acceptance_programs_run(tmp_path):
         rows = [[float(x) for x in l.split()] for l in open(tmp_path / "selfMobilityCubicBox.test") if l.strip()]
         assert len(rows) == 20 and max(max(row[1:]) for row in rows) <= 3e-2
         print("FIB self mobility: largest |1 - M/M0| %.2e over 20 boxes" % max(max(row[1:]) for row in rows))
+
+
+@pytest.mark.gpu
+def test_reference_rpy_acceptance_pipeline(tmp_path):
+    """test/BDHI/Lanczos_Cholesky of the reference, as its test.bash runs it: BDHI.cu (EulerMaruyama<BDHI::Lanczos> on 5000 spheres of two
+    radii, the big one pulled; a user Interactor writing through the CPU accessors and getIdOrderedIndices) built against include/uammd,
+    its positions piped into the checker the reference ships beside it (process.cpp, plain g++): every pair's f(r) and g(r) against the
+    Rotne-Prager-Yamakawa formulas for unequal spheres.  The script's bar (1e-7) is for its DOUBLE_PRECISION build; the headers' real is
+    float: f to 1e-5, g to 1e-2 wherever it is not about to vanish (r beyond the sum of the radii), 2e-6 in the median."""
+    prog = os.path.join(EX, "_build", "ref_test_BDHI")
+    proc = os.path.join(EX, "_build", "ref_process_bdhi")
+    if not (os.path.exists(prog) and os.path.exists(proc)):
+        pytest.skip("the acceptance program was not built (no reference tree where `make -C examples` ran)")
+    (tmp_path / "data.main").write_text("N 5000\nboxSize 4 4 4\nradius_min 0.38173\nradius_max 1.89538\noutfile /dev/stdout\ntemperature 0\n"
+                                        "viscosity 1.2131\ndt 10\ntolerance 1e-8\nnsteps 10\nprintSteps 1\nmode Lanczos\n")
+    run = subprocess.run([prog], cwd=tmp_path, capture_output=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    chk = subprocess.run([proc], cwd=tmp_path, input=run.stdout, capture_output=True, timeout=600)
+    assert chk.returncode == 0, chk.stderr[-2000:]
+    d = np.array([[float(x) for x in l.split()[:3]] for l in chk.stdout.decode().splitlines() if l.strip() and not l.startswith("#")])
+    assert d.shape[0] > 80000
+    apart = d[:, 0] > 0.38173 + 1.89538
+    print("RPY acceptance: %d pairs; f deviation max %.2e; g deviation median %.2e, max beyond contact %.2e" %
+          (d.shape[0], d[:, 1].max(), np.median(d[:, 2]), d[apart, 2].max()))
+    assert d[:, 1].max() <= 1e-5
+    assert np.median(d[:, 2]) <= 1e-4 and d[apart, 2].max() <= 1e-2
