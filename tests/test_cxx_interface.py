@@ -202,8 +202,8 @@ def test_reference_acceptance_programs_run(tmp_path):
         r = subprocess.run([fib, "selfMobilityCubicBox", "0", "1", "1", str(tol)], cwd=tmp_path, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         rows = [[float(x) for x in l.split()] for l in open(tmp_path / "selfMobilityCubicBox.test") if l.strip()]
-        assert len(rows) == 20 and max(max(row[1:]) for row in rows) <= 3e-2
-        print("FIB self mobility: largest |1 - M/M0| %.2e over 20 boxes" % max(max(row[1:]) for row in rows))
+        assert len(rows) >= 20 and max(max(row[1:]) for row in rows) <= 3e-2
+        print("FIB self mobility: largest |1 - M/M0| %.2e over %d boxes" % (max(max(row[1:]) for row in rows), len(rows)))
 
 
 @pytest.mark.gpu
