@@ -2,6 +2,7 @@
 // The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).
 #pragma once
 #include "uammd.h"
+#include "third_party/saruprng.cuh"   // (the reference's umbrella header brings Saru into user code)
 // A translation unit compiled by hipcc also gets what the reference's umbrella header brings into scope for user code: the thrust
 // algorithms and iterators its tutorials call without including them (examples/basic_concepts/8-, 11-, 12-: thrust::fill,
 // thrust::reduce, thrust::make_permutation_iterator).  rocThrust needs hipcc; a plain g++ TU gets the host interface alone.

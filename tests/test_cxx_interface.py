@@ -232,3 +232,21 @@ def test_reference_rpy_acceptance_pipeline(tmp_path):
           (d.shape[0], d[:, 1].max(), np.median(d[:, 2]), np.quantile(d[apart, 2], 0.999), d[apart, 2].max()))
     assert d[:, 1].max() <= 1e-5
     assert np.median(d[:, 2]) <= 1e-4 and np.quantile(d[apart, 2], 0.999) <= 1e-2 and d[apart, 2].max() <= 0.2
+
+
+@pytest.mark.gpu
+def test_user_side_saru_matches_the_golden_streams():
+    """third_party/saruprng.cuh in a user kernel and on the host (examples/_build/saru_user = tests/cxx/saru_user.hip): the integer streams
+    of the one-, two- and three-seed constructors against tests/golden/saru_u32.npz for every seed triple of the file, device == host, and
+    the Gaussian draws' moments."""
+    _make()
+    exe = os.path.join(EX, "_build", "saru_user")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "saru_u32.npz"))
+    for k, s in enumerate(g["seeds"]):
+        r = subprocess.run([exe] + [str(int(x)) for x in s], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.strip()}
+        for name, key in (("u32_1", "one"), ("u32_2", "two"), ("u32_3", "three")):
+            assert np.array_equal(np.array([int(x) for x in lines[name]], dtype=np.uint32), g[key][k]), (name, s)
+    mean, second = (float(x) for x in lines["moments"])
+    assert abs(mean) <= 0.06 and abs(second - 1.0) <= 0.08      # 3000 draws of N(0, 1)
