@@ -36,7 +36,9 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
          "../test/BDHI/quasi2D/q2D.cu"]
 # Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
 # advanced/execution_policy.cu includes <cuda_profiler_api.h>; integration_schemes/icm.cu needs Hydro/ICM_Compressible (out of
-# scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation).
+# scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation);
+# uammd_as_a_library/python_wrapper.cu gives its Potential only getForceTransverser, which the reference's own PairForces refuses
+# (src/Interactor/PairForces.cu:29-36 static_asserts on getTransverser): it does not build against the reference either.
 
 
 def _source(rel, tmp_path, suffix):
