@@ -20,11 +20,11 @@ for a in sys.argv[1:]:
 dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
 out = torch.empty((n, 3), dtype=torch.float32, device="cuda")
 for _ in range(10):
-    fcm.computeHydrodynamicDisplacements(dp, df, n, 1.0, 10.0, out=out)
+    fcm.computeHydrodynamicDisplacements(dp, df, n, float(os.environ.get("T", 1.0)), 10.0, out=out)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 100
 e0.record()
 for _ in range(reps):
-    fcm.computeHydrodynamicDisplacements(dp, df, n, 1.0, 10.0, out=out)
+    fcm.computeHydrodynamicDisplacements(dp, df, n, float(os.environ.get("T", 1.0)), 10.0, out=out)
 e1.record(); torch.cuda.synchronize()
 print(f"{' '.join(sys.argv[1:]) or 'default'}: {e0.elapsed_time(e1) / reps:.4f} ms per solve ({nc}^3, {n} particles)", flush=True)
