@@ -949,7 +949,10 @@ __global__ void __launch_bounds__(256) k_fcm_interleave(const float *__restrict_
 constexpr int kGatherWaves = 4;  // (16 waves = 16 consecutive tile-sorted particles per workgroup, to share their lines in the CU's L1: 48.7 against 47.1 us)
 // P = particles per wave: the kernel is bound by wave lifetimes (two round trips + the reduction, ~3.8 us, at 32 waves per CU), not by
 // bytes; a wave that carries P particles keeps P R loads in flight for the same two round trips.
-template <int R, int P>
+// PK: the grid holds 12 bytes per node (x, y, z) instead of the float4 — for grids too large for the 256 MB Infinity Cache, where the
+// kernel waits for HBM and the unused w is a quarter of what it reads (C5: 268 -> 201 MB)
+struct __attribute__((packed, aligned(4))) PackedNode { float x, y, z; };
+template <int R, int P, bool PK = false>
 __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *__restrict__ vout, const float4 *__restrict__ gi, int N, int3 n,
                                                            int3 support, float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr,
                                                            bool accumulate) {
@@ -988,7 +991,12 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *_
         cx = cx < 0 ? cx + n.x : (cx >= n.x ? cx - n.x : cx);
         cy = cy < 0 ? cy + n.y : (cy >= n.y ? cy - n.y : cy);
         cz = cz < 0 ? cz + n.z : (cz >= n.z ? cz - n.z : cz);
-        v[q][r] = gi[(size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz)];  // (a lane past the stencil re-reads node 0 of it)
+        const size_t node = (size_t)cx + (size_t)n.x * ((size_t)cy + (size_t)n.y * (size_t)cz);  // (a lane past the stencil re-reads node 0 of it)
+        if (PK) {
+          const PackedNode pn = ((const PackedNode *)gi)[node];
+          v[q][r] = make_float4(pn.x, pn.y, pn.z, 0.0f);
+        } else
+          v[q][r] = gi[node];
       }
     }
 #pragma unroll
@@ -1196,11 +1204,20 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_half(float *__
 // float4 grid with every load of a thread in flight together, 72 us against 47 us for the kernel above: three workgroups per CU do not
 // hide the window's round trip and the per-particle shuffle chains.  Not kept.)
 static void launch_gather_inter(hipStream_t st, float *vout, const float4 *gi, int N, int3 n, int3 support, float dV, FastDiv dsx,
-                                FastDiv dsxy, const FcmPrep &pr, bool accumulate, int perWave = 2) {
+                                FastDiv dsxy, const FcmPrep &pr, bool accumulate, int perWave = 2, bool packed = false) {
   // the column form where the float4 grid stays in the 256 MB Infinity Cache (C4: 39.5 -> 32.9 us; at C5, a 268 MB grid read from HBM,
   // its six partly filled loads per particle lose to the four full ones: 126 against 112 us)
   const size_t nodes = (size_t)n.x * n.y * n.z;
   static const int halfMode = getenv("UAMMD_FCM_GATHER_HALF") ? atoi(getenv("UAMMD_FCM_GATHER_HALF")) : 1;   // (A/B runs: 0 off, 2 also on grids read from HBM)
+  if (packed) {  // (fcm_inter_packed: a grid read from HBM, 12 bytes per node; the float4 forms below do not apply)
+    const int rounds = (support.x * support.y * support.z + 63) / 64;
+    const int P = rounds <= 4 ? (perWave >= 4 ? 4 : 2) : 1;
+    const dim3 g((N + kGatherWaves * P - 1) / (kGatherWaves * P)), b(64 * kGatherWaves);
+#define UH_GIP(RR, PP) hipLaunchKernelGGL((k_fcm_gather_inter<RR, PP, true>), g, b, 0, st, vout, gi, N, n, support, dV, dsx, dsxy, pr, accumulate)
+    if (rounds <= 1) UH_GIP(1, 2); else if (rounds <= 2) UH_GIP(2, 2); else if (rounds <= 4) { if (P == 4) UH_GIP(4, 4); else UH_GIP(4, 2); } else UH_GIP(8, 1);
+#undef UH_GIP
+    return;
+  }
   if (halfMode == 2 && perWave >= 0 && support.x == 6 && support.y == 6 && support.z <= 8 && nodes * sizeof(float4) < ((size_t)1 << 32)) {
     const dim3 g((N + kGatherWaves * 2 - 1) / (kGatherWaves * 2)), b(64 * kGatherWaves);
     if (support.z <= 6) hipLaunchKernelGGL((k_fcm_gather_half<6, 6>), g, b, 0, st, vout, gi, N, n, support.z, dV, pr, accumulate);
@@ -1691,15 +1708,22 @@ static int fcm_fft_z_operator_y(FCM *f, float *g, bool haveForce, float noisePre
   return 0;
 }
 // inverse x transform of the three components: into the planar real grids in place, or into the gather's interleaved float4 grid
-static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st) {
+// The gather's grid with 12 bytes per node: where the float4 grid would not stay in the Infinity Cache between the inverse x pass and the
+// gather (> 128 MB: the same bound launch_gather_inter uses for its cache-resident forms).  UAMMD_FCM_PACKED_INTER=0: float4 everywhere.
+static bool fcm_inter_packed(const FCM *f) {
+  static const bool on = !(getenv("UAMMD_FCM_PACKED_INTER") && atoi(getenv("UAMMD_FCM_PACKED_INTER")) == 0);
+  const size_t nodes = (size_t)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z;
+  return on && nodes * sizeof(float4) > ((size_t)128 << 20) && f->gatherPerWave >= 0;
+}
+static int fcm_fft_inverse_x(FCM *f, float *g, float4 *inter, hipStream_t st, bool packed = false) {
   const int nx = f->grid.cellDim.x, ny = f->grid.cellDim.y, nz = f->grid.cellDim.z, nh = nx / 2;
   const int rows = std::max(1, std::min(8, 2048 / (3 * nh))), nrows = ny * nz;
   if (is_pow2(nx) && is_pow2(ny))
     hipLaunchKernelGGL(k_fft_x_c2r<true>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
-                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, 0, (size_t)0);
+                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, packed ? -1 : 0, (size_t)0);
   else
     hipLaunchKernelGGL(k_fft_x_c2r<false>, dim3((nrows + rows - 1) / rows), dim3(kFftThreads), sizeof(float2) * (size_t)(nx + 3 * rows * (nh + 1)), st,
-                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, 0, (size_t)0);
+                       g, f->planeReal, (size_t)ny * f->nxpad, ny, nx, nrows, rows, inter, packed ? -1 : 0, (size_t)0);
   return 0;
 }
 
@@ -2109,13 +2133,14 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
   else if (tiles && f->interGather) {
     const size_t nodes = (size_t)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z;
     if (int e = f->interBuf.reserve(sizeof(float4) * nodes)) return e;
+    const bool packed = custom && fcm_inter_packed(f);
     if (custom) {  // the inverse x transform writes the interleaved grid itself
-      if (int e = fcm_fft_inverse_x(f, g, (float4 *)f->interBuf.ptr, st)) return e;
+      if (int e = fcm_fft_inverse_x(f, g, (float4 *)f->interBuf.ptr, st, packed)) return e;
     } else
       hipLaunchKernelGGL(k_fcm_interleave, dim3((unsigned)((nodes + 255) / 256)), bp, 0, st, (const float *)g, f->grid.cellDim, f->nxpad,
                          f->planeReal, zs, (float4 *)f->interBuf.ptr);
     launch_gather_inter(st, d_linearVelocity, (const float4 *)f->interBuf.ptr, N, f->grid.cellDim, f->kern.support, f->grid.cellVolume,
-                        dsx, dsxy, pr, f->accumulate, f->gatherPerWave);
+                        dsx, dsxy, pr, f->accumulate, f->gatherPerWave, packed);
   } else if (tiles)
     hipLaunchKernelGGL(k_fcm_gather_prep, gp, bp, 0, st, d_linearVelocity, (const float *)g, N, f->grid.cellDim, f->nxpad,
                        f->planeReal, zs, f->kern.support, f->grid.cellVolume, dsx, dsxy, pr, f->accumulate);

@@ -775,7 +775,15 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_c2r(float *__restrict__ g
   fft_tangle_c2r<kFftThreads, P2>(buf, LS, nh, 3 * nr, tw, 1, tid);
   __syncthreads();
   fft_lds<1, 2, kFftThreads, P2>(buf, LS, nh, 3 * nr, tw, 2, tid);
-  if (inter) {
+  if (inter && wrapRows < 0) {  // (wrapRows = -1: the gather's grid with 12 bytes per node — grids the Infinity Cache does not hold, fcm.hip)
+    for (int i = tid; i < nr * nh; i += kFftThreads) {
+      const int r = dNh.div(i), j = dNh.rem(i, r);
+      const float2 vx = buf[r * LS + j], vy = buf[(nr + r) * LS + j], vz = buf[(2 * nr + r) * LS + j];
+      PackedNode *o = (PackedNode *)inter + ((size_t)(r0 + r) * nx + 2 * j);
+      o[0] = PackedNode{vx.x, vy.x, vz.x};
+      o[1] = PackedNode{vx.y, vy.y, vz.y};
+    }
+  } else if (inter) {
     for (int i = tid; i < nr * nh; i += kFftThreads) {
       const int r = dNh.div(i), j = dNh.rem(i, r);
       const float2 vx = buf[r * LS + j], vy = buf[(nr + r) * LS + j], vz = buf[(2 * nr + r) * LS + j];
