@@ -222,6 +222,12 @@ UH_D uint tile_bits16(const v16f &d) {
 UH_D uint tile_bits32(const v16f &dA, const v16f &dB) { return (tile_bits16(dA) << 16) | tile_bits16(dB); }
 #endif
 
+// diagnostic build (tools/tile_budget.py): section marks in the assembly, no effect on a normal build
+#ifdef UAMMD_TILE_MARKERS
+#define TILE_MARK(name, k) asm volatile("; MARK " name " %0" ::"n"(k))
+#else
+#define TILE_MARK(name, k) do {} while (0)
+#endif
 // The wave's 32 owners against nW words of staged candidates.  Word w = 64 consecutive LDS slots starting at byte candBase +
 // wbase[w], of which the first wcnt[w] are this wave's candidates (the rest is staged data of other rows, or padding: their bits
 // are cleared).  wbase / wcnt arrive in registers — lane w holds word w's, entries >= nW are zero or any staged slot — and the scan
@@ -242,9 +248,11 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
   // constant vector, five register moves per matrix step)
   uint ones = 0x3c003c00u;
   asm volatile("" : "+v"(ones));
+  TILE_MARK("scan_setup", PBC);
   h8t A = tile_operand<PBC>(rowAddr + rdlane(wbaseV, 0), fr, ones);
   v16f dA = tile_product(A, B0), dB = tile_product(A, B1);
   for (uint w = 0; w < nW; ++w) {
+    TILE_MARK("scan_body", PBC);
     const uint cnt = rdlane(wcntV, (int)w);
     // (unconditional: behind the last word this is entry nW of the table = slot 0, a wasted step — a conditional one makes the
     // compiler keep two register sets for the products and copy them every word)
@@ -259,6 +267,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     }
     *(LdsU *)(uintptr_t)(myMask + 256u * w) = m;
   }
+  TILE_MARK("drain_setup", PBC);
   __builtin_amdgcn_s_setprio(0);  // (see k_lj_tile4: the drain yields to waves that are loading or scanning)
   // ---- drain: every lane walks its own hit words (bit j from the top of word w = slot 2 j + h of the word) ----
   // cw / cb = the word being consumed and the LDS address of its slot h, nw / nb = the next one; word nW of every lane is zero and a
@@ -305,6 +314,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
   pop2(lN0, lN1, a0, a1);
   f4t cN0 = *(const LdsF4 *)(uintptr_t)a0, cN1 = *(const LdsF4 *)(uintptr_t)a1;
   while (__any(lN0) || more != 0) {  // some lane still holds a pair or has words left (empty trailing words are walked through)
+    TILE_MARK("drain_body", PBC);
     const f4t c0 = cN0, c1 = cN1;
     const bool l0 = lN0, l1 = lN1;
     pop2(lN0, lN1, a0, a1);  // the candidates of the next two pairs are on their way from LDS while these two are evaluated
@@ -322,6 +332,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     lj_acc<WE, WV>(acc, r0, l0 ? f0 : 0.0f, l0 ? e0 : 0.0f);
     lj_acc<WE, WV>(acc, r1, l1 ? f1 : 0.0f, l1 ? e1 : 0.0f);
   }
+  TILE_MARK("drain_end", PBC);
 }
 
 // owners' side of the matrix products for the 32 owners [o0, o0 + 32) of a wave, and the lane's owner position
@@ -563,6 +574,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
 #define TL_STAMP(k) do {} while (0)
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  TILE_MARK("k4_ranges", 0);
   const int wy = wave & 1, wz = wave >> 1;
   const int cx = grid.cellDim.x, cy = grid.cellDim.y, cz = grid.cellDim.z;
   const int bx = (int)(t % (uint)nbx), by = (int)((t / (uint)nbx) % (uint)nby), bz = (int)(t / (uint)(nbx * nby));
@@ -605,6 +617,7 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
     if (lane == 63) { total[0] = incl; total[1] = 0u; }
   }
   __syncthreads();
+  TILE_MARK("k4_runs_staging", 0);
   TL_STAMP(4);  // ranges known
   const uint C = total[0];
   // every lane of every wave holds the range of its index (lanes >= 48: empty)
@@ -671,17 +684,20 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
   __builtin_amdgcn_s_waitcnt(0);
   TL_STAMP(5);  // this wave's staging loads landed
   __syncthreads();
+  TILE_MARK("k4_owner", 0);
   TL_STAMP(6);  // halo staged
   __builtin_amdgcn_s_setprio(2);
   if (!fits || total[1] != 0u) {
     // a dense brick: every wave runs the chunked single-pair algorithm on its quarter of the candidate buffer
     if (cl.tileStats && tid == 0) atomicAdd(&cl.tileStats[0], 1u);
+    TILE_MARK("k4_fallback_dense_brick", 0);
     if (y0 + wy < cy && z0 + wz < cz)
       tile_solo<NT != 0, WE, WV>(cl, grid, box, tbl, ntypes, out, margin, x0, y0 + wy, z0 + wz,
                                  candBase + 16u * (uint)(wave * kFallbackRegion), 192u, tab, lane);
     return;
   }
   if (nOwn == 0 || !anyOwned) return;
+  TILE_MARK("k4_frame_owner", 0);
   const float ox = fmaf((float)(x0 + 1), grid.cellSize.x, -0.5f * box.boxSize.x);
   const float oy = fmaf((float)(y0 + wy) + 0.5f, grid.cellSize.y, -0.5f * box.boxSize.y);
   const float oz = fmaf((float)(z0 + wz) + 0.5f, grid.cellSize.z, -0.5f * box.boxSize.z);
@@ -703,7 +719,9 @@ k_lj_tile4(ListView cl, GridT<float> grid, BoxT<float> box, const LJParams *__re
       tile_words<true, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, pbc_box(box), p1, tbl, ntypes);
     else
       tile_words<false, NT, WE, WV>(acc, nW, candBase, tab, wbaseV, wcntV, lane, fr, ow.B0, ow.B1, ow.pi, box, p1, tbl, ntypes);
+    TILE_MARK("k4_finish", 0);
     tile_finish<WE, WV>(acc, cl, out, ownFirst, o0, lane, ow.valid, giPre);
+    TILE_MARK("k4_finish_end", 0);
   }
   TL_STAMP(7);  // wave done
 #ifdef UAMMD_TILE_TIMELINE
