@@ -214,13 +214,15 @@ def test_reference_rpy_acceptance_pipeline(tmp_path):
     Rotne-Prager-Yamakawa formulas for unequal spheres.  The script's bar (1e-7) is for its DOUBLE_PRECISION build; the headers' real is
     float: f to 1e-5; g 2e-6 in the median and, beyond contact (where it is not about to vanish), within 1e-2 for 99.9 % of the pairs
     (the checker extracts g from the displacement's component along r: ill conditioned for the pairs that lie across the pull — the
-    positions are seeded by the clock, the worst pair of a run sits between 3e-3 and 2e-2)."""
+    worst pair of a run sits between 3e-3 and 2e-2 depending on the positions).  The program seeds its positions from the clock unless its
+    data file names a seed (BDHI.cu:16,127): the test names one, so that a run is a repeatable statement."""
+    seed = int(os.environ.get("UAMMD_RPY_ACCEPTANCE_SEED", "20260930"))
     prog = os.path.join(EX, "_build", "ref_test_BDHI")
     proc = os.path.join(EX, "_build", "ref_process_bdhi")
     if not (os.path.exists(prog) and os.path.exists(proc)):
         pytest.skip("the acceptance program was not built (no reference tree where `make -C examples` ran)")
     (tmp_path / "data.main").write_text("N 5000\nboxSize 4 4 4\nradius_min 0.38173\nradius_max 1.89538\noutfile /dev/stdout\ntemperature 0\n"
-                                        "viscosity 1.2131\ndt 10\ntolerance 1e-8\nnsteps 10\nprintSteps 1\nmode Lanczos\n")
+                                        "viscosity 1.2131\ndt 10\ntolerance 1e-8\nnsteps 10\nprintSteps 1\nmode Lanczos\nseed %d\n" % seed)
     run = subprocess.run([prog], cwd=tmp_path, capture_output=True, timeout=600)
     assert run.returncode == 0, run.stderr[-2000:]
     chk = subprocess.run([proc], cwd=tmp_path, input=run.stdout, capture_output=True, timeout=600)
