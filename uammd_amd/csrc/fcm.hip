@@ -957,7 +957,11 @@ __global__ void __launch_bounds__(64 * kGatherWaves) k_fcm_gather_inter(float *_
                                                            int3 support, float dV, FastDiv dsx, FastDiv dsxy, FcmPrep pr,
                                                            bool accumulate) {
   const int lane = threadIdx.x & 63;
-  const int slot0 = ((int)xcd_contiguous_block(blockIdx.x, gridDim.x) * kGatherWaves + (threadIdx.x >> 6)) * P;
+  // (PK = a grid read from HBM: workgroups in launch order, so that the eight XCDs sweep the same region of the grid together and what
+  // one of them brought into the Infinity Cache serves the others — C5 solve 0.697 -> 0.688 ms; a cache-resident grid keeps each XCD on
+  // its own contiguous eighth of the entries, whose lines stay in that XCD's L2)
+  const int blk = PK ? (int)blockIdx.x : (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int slot0 = (blk * kGatherWaves + (threadIdx.x >> 6)) * P;
   if (slot0 >= N) return;
   const int sx = support.x, sy = support.y, sz = support.z;
   int4 o[P];
