@@ -1051,6 +1051,7 @@ def main():
         if ABI_COMM is not None:
             TRANSPORT = "uammd_comm_* (RCCL behind the C ABI: csrc/comm.hip)"
             comm_info["backend"] = TRANSPORT
+            comm_info["rccl_version"] = AbiComm.rccl_version() or comm_info.get("rccl_version")   # (of the librccl the library loaded)
             comm_info["bootstrap"] = "torch.distributed (hands rank 0's RCCL id to the other ranks; carries no payload)" if world > 1 else "in-process"
         elif world > 1:
             TRANSPORT = ("torch.distributed nccl (RCCL)" if backend == "nccl" else

@@ -723,6 +723,8 @@ int uammd_rpy_lanczos_bdw(uammd_lanczos *solver, const float *d_pos, const float
  * ---------------------------------------------------------------------------------------------- */
 typedef struct uammd_comm uammd_comm;
 int uammd_comm_unique_id(char id[128]);
+/* the version of the librccl this library loaded (ncclGetVersion's integer: major * 10000 + minor * 100 + patch) */
+int uammd_comm_rccl_version(int *version);
 int uammd_comm_init(uammd_comm **out, int rank, int world, const char id[128]);
 int uammd_comm_destroy(uammd_comm *h);
 int uammd_comm_rank(const uammd_comm *h);

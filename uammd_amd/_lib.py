@@ -120,6 +120,7 @@ SIGNATURES = {
     "uammd_celllist_get": (_i, [_vp, C.POINTER(CellListData)]),
     "uammd_celllist_check_errors": (_i, [_vp, _vp]),
     "uammd_comm_unique_id": (_i, [C.c_char_p]),
+    "uammd_comm_rccl_version": (_i, [C.POINTER(C.c_int)]),
     "uammd_comm_init": (_i, [C.POINTER(C.c_void_p), _i, _i, C.c_char_p]),
     "uammd_comm_destroy": (_i, [_vp]),
     "uammd_comm_rank": (_i, [_vp]),

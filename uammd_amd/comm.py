@@ -55,6 +55,16 @@ class AbiComm:
             _lib.check(lib.uammd_comm_unique_id(buf))
         return bytes(buf.raw)
 
+    @staticmethod
+    def rccl_version():
+        """'major.minor.patch' of the librccl behind uammd_comm_* (None when it cannot be loaded or does not say)."""
+        lib = _lib.load()
+        v = C.c_int(0)
+        with _stdout_to_stderr():
+            if lib.uammd_comm_rccl_version(C.byref(v)) != 0:
+                return None
+        return "%d.%d.%d" % (v.value // 10000, (v.value // 100) % 100, v.value % 100)
+
     @classmethod
     def from_torch_distributed(cls, dist, group=None):
         """Bootstrap over an initialised torch.distributed process group: rank 0 makes the RCCL id, everybody gets it."""

@@ -36,6 +36,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;  // (optional)
 };
 
 static Rccl g_rccl;
@@ -58,6 +59,7 @@ static int rccl_load() {
   UH_SYM(GroupEnd, "ncclGroupEnd")
   UH_SYM(GetErrorString, "ncclGetErrorString")
 #undef UH_SYM
+  g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(lib, "ncclGetVersion"));
   g_rccl.lib = lib;
   return 0;
 }
@@ -92,6 +94,14 @@ int uammd_comm_unique_id(char id[128]) {
   ncclUniqueId u;
   UH_NCCL(g_rccl.GetUniqueId(&u));
   std::memcpy(id, u.internal, 128);
+  return 0;
+}
+
+int uammd_comm_rccl_version(int *version) {
+  if (!version) { set_last_error("uammd_comm_rccl_version: null argument"); return -1; }
+  if (int e = rccl_load()) return e;
+  if (!g_rccl.GetVersion) { set_last_error("uammd_comm_rccl_version: librccl has no ncclGetVersion"); return -1; }
+  UH_NCCL(g_rccl.GetVersion(version));
   return 0;
 }
 
