@@ -111,6 +111,28 @@ def test_fcm_full_size_vs_oracle(hip, o32, n, ncell):
     assert err <= 1e-5   # measured 2.9e-7 at C4 and C5 (the noise draw uses gf_fast, 2 ulp from libm: far inside the bar)
 
 
+@pytest.mark.parametrize("n,ncell,tol", [(150_000, 216, 1e-3), (120_000, 216, 1e-4)], ids=["216^3-tol1e-3", "216^3-tol1e-4"])
+def test_fcm_grid_beyond_the_infinity_cache_not_a_power_of_two(hip, o32, n, ncell, tol):
+    """Grids whose float4 copy would not stay in the Infinity Cache (> 128 MB) take the gather's 12-byte grid (fcm.hip fcm_inter_packed:
+    the inverse x pass writes it, k_fcm_gather_inter<R, P, true> reads it in launch order).  C5 is the power-of-two case with support 6;
+    here 216 = 2^3 3^3 (the mixed-radix passes) and a second tolerance (a wider support: more rounds of 64 stencil nodes per particle)."""
+    from oracle.fcm import FCMOracle
+    L, cells = float(ncell), [ncell] * 3
+    assert ncell ** 3 * 16 > (128 << 20)
+    pos, force = _fcm_config(n, L)
+    k, a_eff = hip.Kernels.Gaussian(1.0, tol)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 1.0, 1234, a_eff)
+    ofcm = FCMOracle(o32, L, cells, tolerance=tol, viscosity=1.0, seed=1234)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    for T in (0.0, 1.0):
+        pf = 1 / math.sqrt(0.01) if T > 0 else 0.0
+        v = fcm.computeHydrodynamicDisplacements(dp, df, n, T, pf).cpu().numpy()
+        vref = ofcm.displacements(pos, force, temperature=T, prefactor=pf) if T > 0 else ofcm.displacements(pos, force)
+        err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+        print(f"[FCM {ncell}^3, {n} particles, tolerance {tol:g}, support {k.support[0]}] T={T} rel L2 err vs oracle {err:.2e}")
+        assert err <= 1e-5
+
+
 def test_fcm_c5_eight_slabs_equal_single_gpu(hip):
     """C5 decomposed as BASELINE.json names it (256^3 grid, 8 z-slabs of 32 planes, all-to-all transposes) with all 8
     ranks run in this process on one MI355X (exchanges = tensor copies) against the single-GPU solver."""
