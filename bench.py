@@ -920,7 +920,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--min-timed-seconds", type=float, default=1.2, help="with --repeats 0: repeat the timed --steps block until the LJ headline has timed at least this much GPU work")
+    ap.add_argument("--min-timed-seconds", type=float, default=12.0, help="with --repeats 0: repeat the timed --steps block until the LJ headline has timed at least this much GPU work")
     ap.add_argument("--repeats", type=int, default=0, help="how many times the timed --steps block is run (0 = as many as --min-timed-seconds asks, at least 10 for blocks of <= 100 steps); "
                                                            "value / ms_per_step are the median block, the spread is reported")
     ap.add_argument("--equilibrate", type=int, default=300, help="untimed steps that melt the lattice before warm-up (part of the synthetic input)")
@@ -1148,7 +1148,7 @@ def main():
     # The timed region is EXACTLY --steps steps between barrier + synchronize on both sides.  A 20-step block is 4 ms of GPU time, so the
     # block is repeated (each repeat bracketed the same way) and the line reports the MEDIAN block with the spread next to it.
     # With --repeats 0 (the default) the number of blocks follows the first block's time so that the headline's timed region holds at least
-    # --min-timed-seconds (1.2 s) of GPU work whatever --steps is: the driver's --steps 20 is 4 ms per block, 39 ms in ten blocks — too short
+    # --min-timed-seconds (12 s: two periods of the sampler the driver reads gpu_busy from) of GPU work whatever --steps is: the driver's --steps 20 is 4 ms per block, 39 ms in ten blocks — too short
     # for anything that samples the GPU from outside (its gpu_busy probe read 0 % in rounds 1-3).
     blocks, done = [], 0
     nrep = args.repeats if args.repeats > 0 else 1

@@ -1,80 +1,105 @@
-// misc/TabulatedFunction.cuh (reference: src/misc/TabulatedFunction.cuh:28-162) — a function sampled on N points of [rmin, rmax) by the host
-// and read back on the device with linear interpolation: what the PSE near field reads its RPY coefficients from (NearField.cuh:65-99; the
-// library's own copy is csrc/pse.hip:table_get, the same arithmetic) offered to user code as the reference offers it.
-//   TabulatedFunction<real2> table(d_table, N, rmin, rmax, [](double r) { return real2(...); });   // d_table: device memory, N elements
-//   TabulatedFunction<real>  table(N, rmin, rmax, foo);                                             // the table allocates (and frees) its own
-//   ... in a kernel:  table(r)  /  table.get(r)      (T() beyond rmax, table[0] at or below rmin)
-// The interpolation is written with explicit fused multiply-adds (lerp as fma(t, v1, fma(-t, v0, v0)), :33-39): the same value whatever
-// the compiler's contraction setting.
+// misc/TabulatedFunction.cuh — a function of one variable sampled by the host on an even mesh over [rmin, rmax] and evaluated in device code
+// by interpolation between neighbouring samples (the user-facing counterpart of the reference's src/misc/TabulatedFunction.cuh; the
+// library's own RPY table for the PSE near field is csrc/pse.hip:table_get and evaluates a sample pair with the same arithmetic).
+//
+//   TabulatedFunction<real2> f(d_samples, N, rmin, rmax, [](double r) { return real2(...); });   // N samples into the CALLER's device memory
+//   TabulatedFunction<real>  g(N, rmin, rmax, foo);                                               // samples in pooled memory of the table's own
+//   kernel<<<...>>>(g, ...);   ...   g(r) or g.get(r) inside the kernel
+// Values: T() at and beyond rmax, the first sample at and below rmin, otherwise the chord between the two samples that bracket r.
+//
+// Design: the object IS the device-side view (samples pointer + the mesh), so it travels into a kernel by value; a table that allocated its
+// samples shares them between all of its host copies through a count of owners (the last owner returns the block to the pool of
+// temporary device memory), so copies — including the one a kernel launch makes — are ordinary values and nothing is released twice.
 #ifndef UAMMD_MI355X_MISC_TABULATEDFUNCTION_CUH
 #define UAMMD_MI355X_MISC_TABULATEDFUNCTION_CUH
 #include "../uammd.h"
-#include <iterator>
 #include <vector>
 
 namespace uammd {
-template <typename T, typename T2> UAMMD_HD T lerp(T v0, T v1, T2 t) { return ::fmaf(t, v1, ::fmaf(-t, v0, v0)); }
-template <typename T2> UAMMD_HD real2 lerp(real2 v0, real2 v1, T2 t) { return make_real2(lerp(v0.x, v1.x, t), lerp(v0.y, v1.y, t)); }
-template <typename T2> UAMMD_HD real3 lerp(real3 v0, real3 v1, T2 t) { return make_real3(lerp(v0.x, v1.x, t), lerp(v0.y, v1.y, t), lerp(v0.z, v1.z, t)); }
-template <typename T2> UAMMD_HD real4 lerp(real4 v0, real4 v1, T2 t) {
-  return make_real4(lerp(v0.x, v1.x, t), lerp(v0.y, v1.y, t), lerp(v0.z, v1.z, t), lerp(v0.w, v1.w, t));
+
+// v0 + t (v1 - v0), component by component, as two fused multiply-adds (v0 - t v0, then + t v1): exact at t = 0 and independent of the
+// compiler's contraction setting
+namespace tabulated_ns {
+UAMMD_HD float chord(float a, float b, float t) { return ::fmaf(t, b, ::fmaf(-t, a, a)); }
+UAMMD_HD double chord(double a, double b, double t) { return ::fma(t, b, ::fma(-t, a, a)); }
+}  // namespace tabulated_ns
+template <class S> UAMMD_HD float lerp(float a, float b, S t) { return tabulated_ns::chord(a, b, float(t)); }
+template <class S> UAMMD_HD double lerp(double a, double b, S t) { return tabulated_ns::chord(a, b, double(t)); }
+template <class S> UAMMD_HD real2 lerp(const real2 &a, const real2 &b, S t) { return real2(lerp(a.x, b.x, t), lerp(a.y, b.y, t)); }
+template <class S> UAMMD_HD real3 lerp(const real3 &a, const real3 &b, S t) { return real3(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
+template <class S> UAMMD_HD real4 lerp(const real4 &a, const real4 &b, S t) {
+  return real4(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t), lerp(a.w, b.w, t));
 }
 
+// The interpolation rule: samples[0 .. cells] cover the unit interval in `cells` steps of `step`; u in (0, 1) is the argument mapped onto it
 struct LinearInterpolation {
-  template <class iterator, class T = typename std::iterator_traits<iterator>::value_type>
-  UAMMD_HD T operator()(const iterator &table, int Ntable, real dr, real r) const {
-    const int i = r * Ntable;
-    const real r0 = i * dr;
-    const T v0 = table[i], v1 = table[i + 1];
-    const real t = (r - r0) * (real)Ntable;
-    return lerp(v0, v1, t);
+  template <class Samples> UAMMD_HD auto operator()(const Samples &samples, int cells, real step, real u) const -> decltype(samples[0] + samples[0]) {
+    const int k = int(u * real(cells));
+    return lerp(samples[k], samples[k + 1], (u - real(k) * step) * real(cells));
   }
 };
 
-template <class T, class Interpolation = LinearInterpolation> struct TabulatedFunction {
-  int Ntable = 0;
-  real rmin = 0, rmax = 0, interval = 0, dr = 0;
-  T *table = nullptr;
-  Interpolation interp;
-  bool freeTable = false, isCopy = false;
+template <class T, class Interpolation = LinearInterpolation> class TabulatedFunction {
+  const T *samples = nullptr;
+  int cells = 0;                 // number of intervals: samples[0 .. cells]
+  real lower = 0, upper = 0;     // the sampled range
+  real toUnit = 0, step = 0;     // 1 / (upper - lower), 1 / cells
+  Interpolation rule;
+  int *owners = nullptr;         // host counter shared by the copies of a table that allocated its samples; null: the samples are the caller's
 
-  TabulatedFunction() {}
-  // the table in memory of its own (released by the original, not by the copies a kernel launch makes)
-  template <class Functor> TabulatedFunction(int N, real rmin, real rmax, Functor foo) : TabulatedFunction(allocate(N), N, rmin, rmax, foo) { freeTable = true; }
-  // ... in the caller's device memory, N elements: sample i is foo(rmin + i (rmax - rmin) / (N - 1)), evaluated on the host in double
-  template <class Functor>
-  TabulatedFunction(T *table, int N, real rmin, real rmax, Functor foo)
-      : Ntable(N - 1), rmin(rmin), rmax(rmax), interval(real(1.0 / (rmax - rmin))), dr(real(1.0) / real(N - 1)), table(table) {
-    std::vector<T> tableCPU(Ntable + 1);
-    for (int i = 0; i <= Ntable; i++) {
-      const double x = (i / (double)(Ntable)) * (rmax - rmin) + rmin;
-      tableCPU[i] = foo(x);
+  UAMMD_HOSTDEV void share(const TabulatedFunction &o) {
+    samples = o.samples; cells = o.cells; lower = o.lower; upper = o.upper; toUnit = o.toUnit; step = o.step; rule = o.rule; owners = o.owners;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (owners) ++*owners;
+#endif
+  }
+  UAMMD_HOSTDEV void drop() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (owners && --*owners == 0) {
+      detail::DevicePool::instance().deallocate(const_cast<T *>(samples));
+      delete owners;
     }
-    detail::hipCheck(hipMemcpy(table, tableCPU.data(), (Ntable + 1) * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy");
+#endif
+    owners = nullptr;
+    samples = nullptr;
   }
-  TabulatedFunction(const TabulatedFunction &o)
-      : Ntable(o.Ntable), rmin(o.rmin), rmax(o.rmax), interval(o.interval), dr(o.dr), table(o.table), interp(o.interp), freeTable(false), isCopy(true) {}
-  void operator=(TabulatedFunction &&o) {
-    Ntable = o.Ntable; rmin = o.rmin; rmax = o.rmax; interval = o.interval; dr = o.dr; table = o.table; interp = o.interp;
-    freeTable = o.freeTable; isCopy = o.isCopy;
-    o.freeTable = false;
-    o.isCopy = true;
+  template <class Functor> void fill(T *d_samples, int N, Functor &&f) {
+    if (N < 2 || !(upper > lower)) throw std::invalid_argument("TabulatedFunction: needs at least two samples on a range rmin < rmax");
+    cells = N - 1;
+    toUnit = real(1.0 / (double(upper) - double(lower)));
+    step = real(1.0) / real(cells);
+    std::vector<T> host((size_t)N);
+    for (int k = 0; k < N; ++k) host[k] = f((double(k) / double(cells)) * (double(upper) - double(lower)) + double(lower));  // mesh point k, in double
+    detail::hipCheck(hipMemcpy(d_samples, host.data(), sizeof(T) * (size_t)N, hipMemcpyHostToDevice), "hipMemcpy");
+    samples = d_samples;
   }
-  ~TabulatedFunction() { if (freeTable && !isCopy) (void)hipFree(table); }
+public:
+  UAMMD_HOSTDEV TabulatedFunction() {}
+  // N samples of foo written to d_samples (device memory of the caller's, which outlives the table)
+  template <class Functor> TabulatedFunction(T *d_samples, int N, real rmin, real rmax, Functor foo) : lower(rmin), upper(rmax) { fill(d_samples, N, foo); }
+  // ... to memory the table takes from the pool and gives back with its last copy
+  template <class Functor> TabulatedFunction(int N, real rmin, real rmax, Functor foo) : lower(rmin), upper(rmax) {
+    T *block = static_cast<T *>(detail::DevicePool::instance().allocate(sizeof(T) * (size_t)std::max(N, 0)));
+    try { fill(block, N, foo); }
+    catch (...) { detail::DevicePool::instance().deallocate(block); throw; }
+    owners = new int(1);
+  }
+  UAMMD_HOSTDEV TabulatedFunction(const TabulatedFunction &o) { share(o); }
+  UAMMD_HOSTDEV TabulatedFunction &operator=(const TabulatedFunction &o) {
+    if (this != &o) { drop(); share(o); }
+    return *this;
+  }
+  UAMMD_HOSTDEV ~TabulatedFunction() { drop(); }
 
-  UAMMD_HD T get(real rs) const { return (*this)(rs); }
-  UAMMD_HD T operator()(real rs) const {   // (dereferences device memory: call it from device code)
-    const real r = (rs - rmin) * interval;
-    if (rs >= rmax) return T();
-    if (r <= real(0.0)) return table[0];
-    return interp(table, Ntable, dr, r);
+  UAMMD_HOSTDEV T operator()(real r) const {   // (reads device memory: for device code)
+    if (r >= upper) return T();
+    const real u = (r - lower) * toUnit;
+    if (u <= real(0.0)) return samples[0];
+    return rule(samples, cells, step, u);
   }
-private:
-  static T *allocate(int N) {
-    T *p = nullptr;
-    detail::hipCheck(hipMalloc((void **)&p, N * sizeof(T)), "hipMalloc");
-    return p;
-  }
+  UAMMD_HOSTDEV T get(real r) const { return (*this)(r); }
+  UAMMD_HOSTDEV int size() const { return cells + 1; }
+  UAMMD_HOSTDEV const T *data() const { return samples; }
 };
 }  // namespace uammd
 #endif

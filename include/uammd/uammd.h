@@ -94,6 +94,10 @@ inline int nextFFTWiseSize(int v) {  // utils/Grid.cuh:142-213, one dimension
 // The pool of temporary device memory (System.h:65-78, misc/allocator.h: pool_memory_resource_adaptor): blocks that are given back are
 // kept, by size, and handed out again instead of going through hipFree / hipMalloc (a hipFree waits for the device).  One pool per
 // process, single host thread (the reference's assumption too); System::finish() and the end of the process return the kept blocks.
+// STREAM ASSUMPTION: a block given back may be handed out again at once, and DeviceArray::resize clears it on the NULL stream.  That is
+// ordered after earlier work only for the null stream and for streams created with the default (blocking) flag, which the null stream
+// waits for — thrust's pool resource in the reference makes the same assumption.  A program that runs the modules on a stream created
+// with hipStreamNonBlocking must synchronise that stream before it destroys (or lets the library resize) a temporary the stream uses.
 class DevicePool {
   std::multimap<size_t, void *> kept;  // free blocks by capacity
   std::map<void *, size_t> live;       // blocks handed out -> capacity

@@ -55,6 +55,33 @@ int main() {
       else assert(h2[k].x == 0 && h2[k].y == 0);
     (void)hipFree(d_o2);
   }
+  {  // ownership: a copy keeps a self-allocated table's samples alive after the original is gone; assignment releases what it replaces;
+     // the pool sees the block come back exactly once, with the last owner
+    auto &pool = uammd::detail::DevicePool::instance();
+    const size_t live0 = pool.blocksLive();
+    TabulatedFunction<real> outer;
+    {
+      TabulatedFunction<real> inner(512, real(0), real(1), [](double r) { return (real)(2.0 * r); });
+      assert(pool.blocksLive() == live0 + 1);
+      outer = inner;
+      TabulatedFunction<real> third(inner);
+      third = TabulatedFunction<real>(64, real(0), real(1), [](double r) { return (real)r; });   // a second block, released with `third`
+      assert(pool.blocksLive() == live0 + 2);
+    }
+    assert(pool.blocksLive() == live0 + 1);   // `inner` and `third` are gone, `outer` still owns the first block
+    real rr = real(0.3), *d_one, *d_res, res = 0;
+    (void)hipMalloc(&d_one, sizeof(real));
+    (void)hipMalloc(&d_res, sizeof(real));
+    (void)hipMemcpy(d_one, &rr, sizeof(real), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k_eval<TabulatedFunction<real>, real>), dim3(1), dim3(64), 0, 0, outer, d_one, 1, d_res);
+    (void)hipMemcpy(&res, d_res, sizeof(real), hipMemcpyDeviceToHost);
+    assert(std::fabs(res - real(0.6)) < 1e-6);
+    assert(pool.blocksLive() == live0 + 1);   // (the launch's copy came and went)
+    outer = TabulatedFunction<real>();
+    assert(pool.blocksLive() == live0);
+    (void)hipFree(d_one);
+    (void)hipFree(d_res);
+  }
   std::printf("tabulated_function: ok (largest interpolation error %.2e)\n", worst);
   return 0;
 }

@@ -624,7 +624,7 @@ def test_fcm_step_slot_layout(hip, cells, n, cluster):
         # (rounding level for every particle — except one that sits on a cell centre to within rounding: with an even support the stencil's
         # window flips by one node there (IBM.cu:10-31), the two runs' last bits put it on different sides, and the truncated Gaussian
         # differs by its tolerance, 1e-3 — seen at 128^3: particle 16607 at y + L/2 = 107.500008 / 107.500004, |dv| 2e-4 of the scale,
-        # tools/dbg_slot_flaky.py.  At most three such particles, each within the kernel's tolerance.)
+        #  At most three such particles, each within the kernel's tolerance.)
         for x, y in zip(va, vb):
             d = np.abs(x - y).max(axis=1)
             assert (d > 2e-5 * scale).sum() <= 3 and d.max() <= 1e-3 * scale, (float(d.max() / scale), int((d > 2e-5 * scale).sum()))

@@ -207,6 +207,8 @@ constexpr int kTile = 8;
 // that tile towards + only, so a tile's candidates sit in the tiles at offsets -k .. 0 per axis, k = ceil((support - 1) / edge) —
 // eight tiles for the supports and edges of the bench's sizes, where binning by the particle's own cell needed all 27 (660 candidate
 // records per tile at C4 for ~105 accepted; now ~195).  rel: the origin relative to its tile, biased by 8, 7-bit fields.
+// INVARIANT (fcm_tiles_usable, checked where useTiles is set): support <= 2 (edge - 1) <= cells, so an origin lies in (-n, n) and ONE wrap
+// brings it into the grid; uammd_fcm_create admits support >= cells only on handles whose useTiles is false (the atomic spread).
 UH_D int stencil_tile(int ox, int oy, int oz, int3 n, int3 tdim, int3 ntiles, int *rel) {
   const int wx = ox < 0 ? ox + n.x : ox, wy = oy < 0 ? oy + n.y : oy, wz = oz < 0 ? oz + n.z : oz;
   const int tx = wx / tdim.x, ty = wy / tdim.y, tz = wz / tdim.z;
@@ -748,6 +750,9 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       for (int u = 0; u < kU; ++u) {
         if (ovf[u]) {  // an overflow record: its tile comes with it, not with a range; the shift from the tiles' distance
           int ddx = tc[u] % ntiles.x - tx, ddy = (tc[u] / ntiles.x) % ntiles.y - ty, ddz = tc[u] / (ntiles.x * ntiles.y) - tz;
+          // INVARIANT (fcm_tiles_usable): >= 3 tiles per axis, so a source tile appears at exactly ONE of the steps 0, -1, -2 and the
+          // single wrap below finds it; with <= 2 tiles per axis a tile would sit at two steps and the ranged path's enumeration would be
+          // needed — such grids never get useTiles
           ddx -= ddx > 0 ? ntiles.x : 0;   // (a source tile sits at steps 0, -1, -2 of this one, around the box)
           ddy -= ddy > 0 ? ntiles.y : 0;
           ddz -= ddz > 0 ? ntiles.z : 0;

@@ -674,8 +674,9 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
   // prologue (from the partials of |z|^2: the caller's — lanczos_set_znorm_parts — or k_l_norm2's), the first k_l_b zeroes Bold.
   if (!L->partsB.ptr) { if (int e = L->partsB.reserve(sizeof(T) * kLParts)) return e; }
   bool v0Pending = fused_usable(L), boldPending = v0Pending;
-  const T *zparts = L->zparts;
-  int znp = L->znp;
+  // (caller-supplied partials of |z|^2 are LOCAL sums: on a sharded solver the norm must go through the all-reduce, so they are dropped)
+  const T *zparts = L->reduce ? nullptr : L->zparts;
+  int znp = L->reduce ? 0 : L->znp;
   L->zparts = nullptr;
   L->znp = 0;
   auto plain_start = [&]() -> int {
@@ -780,7 +781,8 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
       // (k_l_estimate_batch), and the run still stops at the FIRST iteration whose error passes — with that iteration's estimate, the
       // reference's result and iteration count.  A run that would have stopped earlier than predicted has done a few iterations for
       // nothing; one that needs more goes on checking every iteration.
-      if (getenv("UAMMD_LANCZOS_DUMP")) {
+      static const bool dumpRecurrence = getenv("UAMMD_LANCZOS_DUMP") != nullptr;   // (read once: this is the per-iteration loop)
+      if (dumpRecurrence) {
         std::vector<T> dbg(2 * cap + 2);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(dbg.data(), scal, sizeof(T) * (2 * cap + 1), hipMemcpyDeviceToHost);

@@ -366,6 +366,8 @@ int uammd_slab_refresh_lj(uammd_comm *comm, float *d_pos, float *d_vel, int *d_i
   if (int e = sizes(d_counts + 2)) return e;
   const int hUp = c4[0], hDown = c4[1], gFromDown = c4[2], gFromUp = c4[3];
   if (n + gFromDown + gFromUp > capRows) { set_last_error("uammd_slab_refresh_lj: the halo overflows the position buffer"); return -2; }
+  // both halo lists share d_send (float[capRows][4]): a slab narrower than two reaches lists a particle twice
+  if (comm && hUp + hDown > capRows) { set_last_error("uammd_slab_refresh_lj: the halo overflows the send buffer"); return -2; }
   float *tailDown = d_pos + 4 * (size_t)n, *tailUp = d_pos + 4 * (size_t)(n + gFromDown);
   if (comm) {
     float *outUp = d_send, *outDown = d_send + 4 * (size_t)hUp;
