@@ -75,7 +75,7 @@ int main(int argc, char *argv[]) {
     auto disp = fcm->getFCM_impl()->computeHydrodynamicDisplacements(const_cast<real4 *>(pos.raw()), const_cast<real4 *>(force.raw()), nullptr,
                                                                       pd->getNumParticles(), 0, 0, 0);
     real3 v0;
-    detail::hipCheck(hipMemcpy(&v0, disp.first.data(), sizeof(real3), hipMemcpyDeviceToHost), "hipMemcpy");
+    detail::hipCheck(hipMemcpy(&v0, disp.first.data().get(), sizeof(real3), hipMemcpyDeviceToHost), "hipMemcpy");
     std::printf("by-value displacements: %zu linear, %zu angular entries, v0.x = %.6f\n", disp.first.size(), disp.second.size(), v0.x);
     bad += disp.first.size() != (size_t)pd->getNumParticles() || !disp.second.empty() || std::abs(v0.x / M0 - 1) > 2e-3;
   }

@@ -56,6 +56,11 @@ int main(int argc, char *argv[]) {
     fp.viscosity = par.viscosity;
     fp.tolerance = par.tolerance;
     fp.seed = par.seed;
+    // FCM_impl takes its two windows ready-made, as the reference's does (FCM_impl.cuh:80-84; test/BDHI/FCM/fcm_test.cu:32-44)
+    const real h = par.boxSize.x / par.cells.x;
+    fp.kernel = std::make_shared<BDHI::FCM_ns::Kernels::Gaussian>(h, fp.tolerance);
+    fp.hydrodynamicRadius = fp.kernel->fixHydrodynamicRadius(0, h);
+    fp.kernelTorque = std::make_shared<BDHI::FCM_ns::Kernels::GaussianTorque>(fp.hydrodynamicRadius / real(std::pow(6 * std::sqrt(M_PI), 1 / 3.)), h, fp.tolerance);
     BDHI::FCM_impl<> ref(fp);
     double worst = 0;
     for (int call = 0; call < 2; ++call) {

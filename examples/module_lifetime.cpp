@@ -181,11 +181,11 @@ int main(int argc, char *argv[]) {
     Xorshift128plus rng(99);
     std::vector<real4> p(N);
     for (auto &v : p) { const real3 u = make_real3(rng.uniform3(-0.5, 0.5)); v = make_real4(u.x * L, u.y * L, u.z * L, 0); }
-    cached_vector<real4> d_pos(N);
-    CudaSafeCall(hipMemcpy(d_pos.data(), p.data(), sizeof(real4) * N, hipMemcpyHostToDevice));
+    uninitialized_cached_vector<real4> d_pos(N);
+    CudaSafeCall(hipMemcpy(d_pos.data().get(), p.data(), sizeof(real4) * N, hipMemcpyHostToDevice));
     Box box(L);
     BasicNeighbourListBase nl;
-    nl.update(d_pos.data(), N, box, rc);
+    nl.update(d_pos.data().get(), N, box, rc);
     auto data = nl.getBasicNeighbourList();
     std::vector<int> nneigh(N), group(N);
     CudaSafeCall(hipMemcpy(nneigh.data(), data.numberNeighbours, sizeof(int) * N, hipMemcpyDeviceToHost));
@@ -209,7 +209,7 @@ int main(int argc, char *argv[]) {
     std::printf("BasicNeighbourListBase (library mode)  %lld pairs over %d particles, stride %d, %lld particles with a wrong list\n", pairs, N, stride, wrong);
     CHECK(wrong == 0, "library-mode neighbour list differs from all pairs");
     CellListBase cl;
-    cl.update(d_pos.data(), N, Grid(box, rc));
+    cl.update(d_pos.data().get(), N, Grid(box, rc));
     auto cld = cl.getCellList();
     const int ncells = cld.grid.getNumberCells();
     std::vector<uint> cellStart(ncells);

@@ -3,6 +3,9 @@
 // Lennard-Jones path.  A translation unit compiled by hipcc also gets the GENERIC PairForces<MyPotential, NeighbourList> and
 // Potential::Radial<Functor> (device/PairForces.hip.hpp): a user's potential is a device functor, as in the reference.
 #pragma once
+#if defined(DOUBLE_PRECISION)
+#error "PairForces.cuh: this module has a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
+#endif
 #include "../uammd.h"
 #if defined(__HIPCC__)
 #include "../device/PairForces.hip.hpp"

@@ -17,6 +17,15 @@
 //   BDHI::PSE, BDHI::EulerMaruyama<Method>   Integrator/BDHI/BDHI_PSE.cuh:79-176, BDHI_EulerMaruyama.cu:125-166
 //   lanczos::Solver, MatrixDot    misc/LanczosAlgorithm.cuh:32-83, LanczosAlgorithm/MatrixDot.h:7-25
 //
+// PRECISION.  `real` is float unless the program is compiled with -DDOUBLE_PRECISION (global/defines.h), as the reference's unit tests are
+// (test/CMakeLists.txt:9).  The library's tuned hot path — cell list, LJ traversal, integrators, the tile-owned spreading and in-LDS FFT of
+// FCM, the pair-record PSE near field — is single precision by construction; its DOUBLE_PRECISION build is the `_f64` part of the C ABI
+// (layout-generic kernels, rocFFT in double).  A DOUBLE_PRECISION program therefore gets: System, Box, Grid, ParticleData (+ sortParticles),
+// ParticleGroup, ParticleSorter, uninitialized_cached_vector, IBM<Kernel> (any kernel, device template), the FCM kernels, FCM_impl,
+// BDHI::FCM, BDHI::PSE, BDHI::EulerMaruyama<Method>, lanczos::Solver.  The classes whose backend exists in single precision only
+// (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, BDHI::Lanczos / Cholesky, BDHI2D, FIB, ICM, Poisson, Comm) are not
+// declared in that build: their forwarding headers stop the compilation with a message instead of silently computing in float.
+//
 // This header is plain host C++14: compile with any C++ compiler,
 //     g++ -std=c++14 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude main.cpp \
 //         -Luammd_amd/lib -luammd_hip -L/opt/rocm/lib -lamdhip64
@@ -47,15 +56,21 @@
 
 #include "../uammd_hip.h"
 #include "utils/vector.cuh"
+#include "third_party/saruprng.cuh"   // (uammd.cuh makes Saru visible to every program, src/uammd.cuh:14)
 // A TU compiled by hipcc also gets the DEVICE side of the neighbour lists (NeighbourContainer and its iterators, the list kernels): the
 // host classes below then hand out getNeighbourContainer() and take device iterators, as the reference's do under nvcc.  A plain C++
 // compiler sees the host interface alone.
 #if defined(__HIPCC__)
 #include "device/Transverser.hip.hpp"
 #include <thrust/device_malloc_allocator.h>
+#include <thrust/copy.h>
 #include <thrust/device_ptr.h>
+#include <thrust/device_reference.h>
 #include <thrust/execution_policy.h>
+#include <thrust/host_vector.h>
+#include <thrust/iterator/detail/normal_iterator.h>
 #include <thrust/iterator/iterator_traits.h>
+#include <thrust/iterator/reverse_iterator.h>
 #include <thrust/transform.h>
 #endif
 
@@ -171,10 +186,103 @@ template <class T> struct DeviceArray {  // owning device buffer (thrust::device
   }
   void swap(DeviceArray &o) { std::swap(d, o.d); std::swap(n, o.n); }
 };
+// ---- utils/container.h:16-117: uninitialized_cached_vector<T> — a device vector over the pool that never runs a fill kernel ----------
+// What user code does with it (test/utils/ParticleSorter.cu:26-32, test/BDHI/FCM/fcm_test.cu:105-136, test/BDHI/PSE/pse_test.cu:77-111):
+// construct with a size, copy (device to device), resize keeping the contents, v[i] = x / x = v[i] from the host, begin() / end() /
+// rbegin() / rend() into thrust algorithms, v.data().get() into kernels and C-ABI calls, conversion to a host vector.  In a TU compiled by
+// hipcc the handles are thrust's (device_ptr, device_reference, device_vector's iterator type), so thrust dispatches to the device; a
+// plain C++ TU gets handles of the same surface written on the runtime API (DevicePtr / DeviceRef below).
+#if !defined(__HIPCC__)
+template <class T> class DeviceRef {   // v[i] on the host: reads and writes one element through the runtime (thrust::device_reference's role)
+  T *p;
+public:
+  explicit DeviceRef(T *p_) : p(p_) {}
+  operator T() const { T h; hipCheck(hipMemcpy(&h, p, sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H"); return h; }
+  DeviceRef &operator=(const T &v) { hipCheck(hipMemcpy(p, &v, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D"); return *this; }
+  DeviceRef &operator=(const DeviceRef &o) { if (p != o.p) hipCheck(hipMemcpy(p, o.p, sizeof(T), hipMemcpyDeviceToDevice), "hipMemcpy D2D"); return *this; }
+  T *operator&() const { return p; }
+};
+template <class T> class DevicePtr {   // thrust::device_ptr's role: a tagged raw pointer; get() is the raw pointer
+  T *p;
+public:
+  using difference_type = std::ptrdiff_t;
+  using value_type = T;
+  explicit DevicePtr(T *p_ = nullptr) : p(p_) {}
+  T *get() const { return p; }
+  operator T *() const { return p; }   // (C-ABI calls and runtime copies take the handle as it is)
+  DeviceRef<T> operator*() const { return DeviceRef<T>(p); }
+  DeviceRef<T> operator[](std::ptrdiff_t i) const { return DeviceRef<T>(p + i); }
+  DevicePtr operator+(std::ptrdiff_t i) const { return DevicePtr(p + i); }
+  DevicePtr operator-(std::ptrdiff_t i) const { return DevicePtr(p - i); }
+  std::ptrdiff_t operator-(const DevicePtr &o) const { return p - o.p; }
+  DevicePtr &operator++() { ++p; return *this; }
+  DevicePtr &operator+=(std::ptrdiff_t i) { p += i; return *this; }
+  bool operator==(const DevicePtr &o) const { return p == o.p; }
+  bool operator!=(const DevicePtr &o) const { return p != o.p; }
+};
+#endif
+template <class T> class PooledVector {
+  T *d = nullptr;
+  size_t n = 0, cap = 0;
+  void copyFrom(const T *src, size_t count, hipMemcpyKind kind) {
+    if (count) hipCheck(hipMemcpy(d, src, sizeof(T) * count, kind), "hipMemcpy");
+  }
+public:
+  using value_type = T;
+#if defined(__HIPCC__)
+  using pointer = thrust::device_ptr<T>;
+  using reference = thrust::device_reference<T>;
+  using iterator = thrust::detail::normal_iterator<thrust::device_ptr<T>>;   // (thrust::device_vector<T>::iterator, container.h:42)
+#else
+  using pointer = DevicePtr<T>;
+  using reference = DeviceRef<T>;
+  using iterator = DevicePtr<T>;
+#endif
+  PooledVector() = default;
+  explicit PooledVector(size_t size) { resize(size); }
+  PooledVector(const std::vector<T> &host) : PooledVector(host.size()) { copyFrom(host.data(), n, hipMemcpyHostToDevice); }
+  PooledVector(const PooledVector &o) : PooledVector(o.n) { copyFrom(o.d, n, hipMemcpyDeviceToDevice); }
+  PooledVector(PooledVector &&o) noexcept : d(o.d), n(o.n), cap(o.cap) { o.d = nullptr; o.n = o.cap = 0; }
+  PooledVector &operator=(PooledVector o) noexcept { swap(o); return *this; }
+  ~PooledVector() { DevicePool::instance().deallocate(d); }
+#if defined(__HIPCC__)
+  PooledVector(const thrust::host_vector<T> &host) : PooledVector(host.size()) { copyFrom(thrust::raw_pointer_cast(host.data()), n, hipMemcpyHostToDevice); }
+  operator thrust::host_vector<T>() const {
+    thrust::host_vector<T> h(n);
+    if (n) hipCheck(hipMemcpy(thrust::raw_pointer_cast(h.data()), d, sizeof(T) * n, hipMemcpyDeviceToHost), "hipMemcpy");
+    return h;
+  }
+  thrust::reverse_iterator<iterator> rbegin() const { return thrust::make_reverse_iterator(end()); }
+  thrust::reverse_iterator<iterator> rend() const { return thrust::make_reverse_iterator(begin()); }
+#endif
+  operator std::vector<T>() const {
+    std::vector<T> h(n);
+    if (n) hipCheck(hipMemcpy(h.data(), d, sizeof(T) * n, hipMemcpyDeviceToHost), "hipMemcpy");
+    return h;
+  }
+  pointer data() const { return pointer(d); }
+  T *raw() const { return d; }                 // (not in the reference: data().get() without the handle)
+  iterator begin() const { return iterator(pointer(d)); }
+  iterator end() const { return iterator(pointer(d + n)); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  reference operator[](size_t i) const { return reference(pointer(d + i)); }
+  // growing keeps the elements and leaves the new tail as the pool hands it out; shrinking keeps the block (container.h:74-86)
+  void resize(size_t newSize) {
+    if (newSize > cap) {
+      T *grown = static_cast<T *>(DevicePool::instance().allocate(sizeof(T) * newSize));
+      if (n) hipCheck(hipMemcpy(grown, d, sizeof(T) * n, hipMemcpyDeviceToDevice), "hipMemcpy");
+      DevicePool::instance().deallocate(d);
+      d = grown;
+      cap = newSize;
+    }
+    n = newSize;
+  }
+  void clear() { DevicePool::instance().deallocate(d); d = nullptr; n = cap = 0; }
+  void swap(PooledVector &o) noexcept { std::swap(d, o.d); std::swap(n, o.n); std::swap(cap, o.cap); }
+};
 }  // namespace detail
-// owning device container returned by value where the reference returns cached_vector (utils/container.h); movable, not copyable
-template <class T> using cached_vector = detail::DeviceArray<T>;
-template <class T> using uninitialized_cached_vector = detail::DeviceArray<T>;  // utils/container.h:128-129
+template <class T> using uninitialized_cached_vector = detail::PooledVector<T>;
 
 // ---- utils/utils.h:21-32: wall-clock stopwatch, seconds ----
 class Timer {
@@ -323,8 +431,7 @@ struct Box {  // a POD a kernel takes by value: every member is callable from de
   // r + offset * L unfused — what the cell-list and traversal kernels compute, so a user kernel takes the same decision for a pair an
   // ulp from the cut-off
   UAMMD_HOSTDEV real3 apply_pbc(real3 r) const {
-    const real ox = ::floorf(::fmaf(r.x, minusInvBoxSize.x, real(0.5))), oy = ::floorf(::fmaf(r.y, minusInvBoxSize.y, real(0.5))),
-               oz = ::floorf(::fmaf(r.z, minusInvBoxSize.z, real(0.5)));
+    const real ox = imageOffset(r.x, minusInvBoxSize.x), oy = imageOffset(r.y, minusInvBoxSize.y), oz = imageOffset(r.z, minusInvBoxSize.z);
     const real sx = ox * boxSize.x, sy = oy * boxSize.y, sz = oz * boxSize.z;
     r.x += isPeriodicX() ? sx : 0;
     r.y += isPeriodicY() ? sy : 0;
@@ -342,11 +449,15 @@ struct Box {  // a POD a kernel takes by value: every member is callable from de
            isPeriodicX() == o.isPeriodicX() && isPeriodicY() == o.isPeriodicY() && isPeriodicZ() == o.isPeriodicZ();
   }
   UAMMD_HOSTDEV bool operator!=(const Box &o) const { return !(*this == o); }
-  // helpers for the C ABI
-  void toArrays(float L[3], int per[3]) const {
-    L[0] = boxSize.x; L[1] = boxSize.y; L[2] = boxSize.z;
+  // helpers for the C ABI (its single-precision entry points take float[3], the _f64 ones double[3])
+  template <class S> void toArrays(S L[3], int per[3]) const {
+    L[0] = S(boxSize.x); L[1] = S(boxSize.y); L[2] = S(boxSize.z);
     per[0] = isPeriodicX(); per[1] = isPeriodicY(); per[2] = isPeriodicZ();
   }
+private:
+  // floor(r * (-1 / L) + 1 / 2) with the product and the sum fused, in the working precision
+  UAMMD_HOSTDEV static float imageOffset(float r, float minusInvL) { return ::floorf(::fmaf(r, minusInvL, 0.5f)); }
+  UAMMD_HOSTDEV static double imageOffset(double r, double minusInvL) { return ::floor(::fma(r, minusInvL, 0.5)); }
 };
 
 // ---- utils/Grid.cuh:21-139: a box cut into cellDim cells — which cell holds a position, linear cell indices, periodic wrapping of cell
@@ -701,7 +812,15 @@ public:
     if (cd[2] == 0) cd[2] = 1;
     {
       auto p = pos.data(access::gpu, access::read);
+#if defined(DOUBLE_PRECISION)
+      // the order is a memory-locality order, not a result: the keys come from the positions rounded to single precision
+      detail::DeviceArray<float> p32(4 * (size_t)numberParticles);
+      detail::check(uammd_convert_f64_to_f32((const double *)p.raw(), p32.d, 4 * (size_t)numberParticles, (void *)st));
+      detail::check(uammd_celllist_update(cl, p32.d, numberParticles, L, per, cd, (void *)st));
+      detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");   // (p32 goes back to the pool here)
+#else
       detail::check(uammd_celllist_update(cl, (const float *)p.raw(), numberParticles, L, per, cd, (void *)st));
+#endif
     }
     uammd_celllist_data d;
     detail::check(uammd_celllist_get(cl, &d));
@@ -984,6 +1103,7 @@ public:
   void addUpdatable(shared_ptr<ParameterUpdatable> u) { updatables.push_back(u); }
 };
 
+#if !defined(DOUBLE_PRECISION)   // (single-precision backends only: see PRECISION at the top)
 // ---- library mode: CellListBase / BasicNeighbourListBase (no ParticleData) ---------------------------------------------------------
 // Interactor/NeighbourList/CellList/CellListBase.cuh:97-172 and BasicList/BasicListBase.cuh:76-215, as
 // examples/uammd_as_a_library/neighbour_list.cu:159-167 uses them: positions from any iterator, a Grid (or a Box and a cut-off), a stream.
@@ -1480,100 +1600,109 @@ public:
 };
 }  // namespace BD
 
-// ---- BDHI::FCM ----------------------------------------------------------------------------------------------------------------------------
+#endif   // !DOUBLE_PRECISION
+
+// ---- BDHI::Parameters (Integrator/BDHI/BDHI.cuh:13-24) -----------------------------------------------------------------------------------
 namespace BDHI {
 struct Parameters {
-  std::vector<real3> K;
+  std::vector<real3> K;   // the 3x3 shear matrix as three rows
   real temperature = 0, viscosity = 1, hydrodynamicRadius = -1, tolerance = 1e-3, dt = 0;
   bool is2D = false;
   Box box;
-  // FCM_impl::Parameters, FCM_impl.cuh:47-54
-  int3 cells = make_int3(-1, -1, -1);
-  uint seed = 0;
-  bool adaptBoxSize = false;
 };
-// FCM_ns::Kernels (BDHI/FCM/FCM_kernels.cuh): the windows FCM_impl can be instantiated with.  Each tag fills the
-// C-ABI window for a cell size h and a tolerance, returns fixHydrodynamicRadius(.., h), and has adviseGridSize.
-namespace FCM_ns {
-namespace Kernels {
-struct Gaussian {  // :22-58
-  static real make(real h, real tol, uammd_ibm_kernel *k) { float a = 0; uammd::detail::check(uammd_fcm_gaussian_kernel(h, tol, k, &a)); return a; }
-  static real adviseGridSize(real a, real tol) { return uammd_fcm_advise_grid_size(a, tol); }
-};
-struct BarnettMagland {  // :82-155
-  static int computeSupport(real tol) {
-    real w = std::max(1.5, int(-std::log10(tol) + 2) / 2.0);
-    w = std::min(real(9.0), w);
-    return (int)std::ceil(w);
-  }
-  static real computeUpsampling(real w) { return 1.36409985665115 * std::pow(w, -0.53028415751646); }
-  static real make(real h, real tol, uammd_ibm_kernel *k) {
-    const int w = computeSupport(tol);
-    const real alpha = w * 0.5;
-    uammd::detail::check(uammd_ibm_barnett_magland_kernel(alpha, real(1.8 * w * 2), (int)std::ceil(2 * alpha), h, k));
-    return h / computeUpsampling(k->support[0]);
-  }
-  static real adviseGridSize(real a, real tol) { return a * computeUpsampling(computeSupport(tol)); }
-};
-namespace detail {
-inline void gridWindow(int kind, int support, real h, uammd_ibm_kernel *k) {
-  *k = uammd_ibm_kernel{};
-  k->kind = kind;
-  k->support[0] = k->support[1] = k->support[2] = support;
-  k->rmax = std::numeric_limits<float>::infinity();
-  k->invh[0] = k->invh[1] = k->invh[2] = real(1.0) / h;
-}
-}  // namespace detail
-namespace Peskin {
-struct threePoint {  // :159-176
-  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN3, 3, h, k); return h; }
-  static real adviseGridSize(real a, real) { return a; }
-};
-struct fourPoint {  // :178-196
-  static constexpr real fac = 1.31;
-  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN4, 4, h, k); return h * fac; }
-  static real adviseGridSize(real a, real) { return a / fac; }
-};
-}  // namespace Peskin
-namespace GaussianFlexible {
-struct sixPoint {  // :199-219
-  static constexpr real fac = 1.5195;
-  static real make(real h, real, uammd_ibm_kernel *k) { detail::gridWindow(UAMMD_IBM_KERNEL_SIXPOINT, 6, h, k); return h * fac; }
-  static real adviseGridSize(real a, real) { return a / fac; }
-};
-}  // namespace GaussianFlexible
-struct GaussianTorque {};  // :60-80, built by uammd_fcm_torque_gaussian_kernel
-}  // namespace Kernels
-}  // namespace FCM_ns
-
+template <class T> using cached_vector = uninitialized_cached_vector<T>;   // BDHI/FCM/utils.cuh:15
 }  // namespace BDHI
 
-// ---- misc/IBM_kernels.cuh:26-240: the windows UAMMD ships, as HOST descriptors (the device evaluation lives in the library: a
-// user-written window is a device functor and needs hipcc, include/uammd/device/).  describe() is what IBM<> hands to the C ABI. ----
+namespace detail {
+// the window descriptor the library takes, in the working precision (uammd_hip.h)
+#if defined(DOUBLE_PRECISION)
+using IBMDescriptor = uammd_ibm_kernel_f64;
+#else
+using IBMDescriptor = uammd_ibm_kernel;
+#endif
+inline IBMDescriptor gridWindow(int kind, int support, real h) {   // a window defined per grid cell (Peskin, six-point): no free parameters
+  IBMDescriptor k{};
+  k.kind = kind;
+  k.support[0] = k.support[1] = k.support[2] = support;
+  k.rmax = std::numeric_limits<real>::infinity();
+  k.invh[0] = k.invh[1] = k.invh[2] = real(1.0) / h;
+  return k;
+}
+UAMMD_HOSTDEV inline float expR(float x) { return ::expf(x); }
+UAMMD_HOSTDEV inline double expR(double x) { return ::exp(x); }
+UAMMD_HOSTDEV inline float sqrtR(float x) { return ::sqrtf(x); }
+UAMMD_HOSTDEV inline double sqrtR(double x) { return ::sqrt(x); }
+UAMMD_HOSTDEV inline float fmaR(float a, float b, float c) { return ::fmaf(a, b, c); }
+UAMMD_HOSTDEV inline double fmaR(double a, double b, double c) { return ::fma(a, b, c); }
+UAMMD_HOSTDEV inline float ceilR(float x) { return ::ceilf(x); }
+UAMMD_HOSTDEV inline double ceilR(double x) { return ::ceil(x); }
+// the two Gaussian windows of FCM choose their support the same way (FCM_kernels.cuh:36-44, :67-75): walk out in steps of h / 2 until the
+// window is below the tolerance
+template <class Phi> inline int supportForTolerance(Phi phi, real h, real tolerance) {
+  const real dr = real(0.5) * h;
+  real r = dr;
+  while (phi(r) > tolerance) r += dr;
+  return std::max(3, int(2 * r / h + 0.5));
+}
+}  // namespace detail
+
+// ---- misc/IBM_kernels.cuh:26-240: the windows UAMMD ships.  Each is a small value type with phi(r) callable from host AND device code (a
+// kernel of IBM<> in the user's TU evaluates it there), and describe(): the same window as the library's descriptor, which the host-only
+// path of IBM<> and FCM_impl hand to the C ABI. ----
 namespace IBM_kernels {
-class Gaussian {  // phi(r) = exp(-r^2 / (2 width^2)) / sqrt(2 pi width^2), :28-40.  support: nodes per axis (the reference asks the caller's getSupport)
+class Gaussian {  // phi(r) = exp(-r^2 / (2 width^2)) / sqrt(2 pi width^2), :28-40
   real prefactor, tau;
 public:
-  int support;
-  explicit Gaussian(real width, int support_ = 0) : prefactor(std::pow(2.0 * M_PI * width * width, -0.5)), tau(-0.5 / (width * width)), support(support_) {}
-  real phi(real r, real3 = real3()) const { return prefactor * std::exp(tau * r * r); }
-  uammd_ibm_kernel describe() const {
+  int support;    // nodes per axis when used with IBM<> directly (the reference asks a wrapping kernel for it)
+  explicit Gaussian(real width, int support_ = 0)
+      : prefactor(real(std::pow(2.0 * M_PI * double(width) * double(width), -0.5))), tau(real(-0.5 / (double(width) * double(width)))), support(support_) {}
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return prefactor * detail::expR(tau * r * r); }
+  detail::IBMDescriptor describe() const {
     if (support <= 0) throw std::invalid_argument("IBM_kernels::Gaussian: give the support (nodes per axis) to spread or gather with it");
-    uammd_ibm_kernel k{};
+    detail::IBMDescriptor k{};
     k.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
     k.support[0] = k.support[1] = k.support[2] = support;
-    k.prefactor = prefactor; k.tau = tau; k.rmax = std::numeric_limits<float>::infinity();
+    k.prefactor = prefactor; k.tau = tau; k.rmax = std::numeric_limits<real>::infinity();
     return k;
   }
 };
-struct BarnettMagland {  // :82-112; alpha = half width of the window, in length units
+// "exponential of a semicircle" (:82-112): phi(r) = exp(beta (sqrt(1 - (r / alpha)^2) - 1)) / norm inside |r| < alpha, alpha = half width
+class BarnettMagland {
+  real invnorm;
+public:
   real alpha, beta;
   int support;
-  BarnettMagland(real alpha_, real beta_, int support_ = 0) : alpha(alpha_), beta(beta_), support(support_) {}
-  uammd_ibm_kernel describe() const {
+  BarnettMagland(real alpha_, real beta_, int support_ = 0) : alpha(alpha_), beta(beta_), support(support_) {
+#if defined(DOUBLE_PRECISION)
+    // norm = 2 int_0^alpha: composite Simpson rule on 20000 intervals, compensated sum (:44-79, :93-97)
+    const int Nr = 20000;
+    const double dx = double(alpha) / Nr;
+    double sum = 0, c = 0;
+    for (int i = 0; i <= Nr; ++i) {
+      const double w = (i == 0 || i == Nr) ? 1.0 : ((i % 2) ? 4.0 : 2.0);
+      const double y = w * shape(real(i * dx)) - c, t = sum + y;
+      c = (t - sum) - y;
+      sum = t;
+    }
+    invnorm = real(1.0 / (2.0 * dx / 3.0 * sum));
+#else
+    uammd_ibm_kernel k;   // (the library's evaluation of the same rule in single precision: one value for the host and the device side)
+    uammd::detail::check(uammd_ibm_barnett_magland_kernel(alpha, beta, std::max(support, 1), real(1.0), &k));
+    invnorm = k.prefactor;
+#endif
+  }
+  UAMMD_HOSTDEV real shape(real r) const {
+    const real z = r / alpha, dz2 = real(1.0) - z * z;
+    return dz2 < real(0.0) ? real(0.0) : detail::expR(beta * (detail::sqrtR(dz2) - real(1.0)));
+  }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return shape(r) * invnorm; }
+  detail::IBMDescriptor describe(real lengthUnit = real(1.0)) const {
     if (support <= 0) throw std::invalid_argument("IBM_kernels::BarnettMagland: give the support (nodes per axis) to spread or gather with it");
-    uammd_ibm_kernel k;
-    uammd::detail::check(uammd_ibm_barnett_magland_kernel(alpha, beta, support, real(1.0), &k));
+    detail::IBMDescriptor k{};
+    k.kind = UAMMD_IBM_KERNEL_BARNETT_MAGLAND;
+    k.support[0] = k.support[1] = k.support[2] = support;
+    k.prefactor = invnorm; k.tau = beta; k.rmax = alpha;
+    k.invh[0] = k.invh[1] = k.invh[2] = lengthUnit;   // (this field carries the wrapper's length unit for this window)
     return k;
   }
 };
@@ -1582,166 +1711,459 @@ struct threePoint {  // :118-137
   real invh;
   static constexpr int support = 3;
   explicit threePoint(real h) : invh(real(1.0) / h) {}
-  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN3, 3, real(1.0) / invh, &k); return k; }
+  UAMMD_HOSTDEV real phi(real rr, real3 = real3()) const {
+    const real r = (rr < 0 ? -rr : rr) * invh;
+    if (r < real(0.5)) return invh * real(1 / 3.0) * (real(1.0) + detail::sqrtR(detail::fmaR(real(-3.0) * r, r, real(1.0))));
+    if (r < real(1.5)) {
+      const real omr = real(1.0) - r;
+      return invh * real(1 / 6.0) * (detail::fmaR(real(-3.0), r, real(5.0)) - detail::sqrtR(detail::fmaR(real(-3.0) * omr, omr, real(1.0))));
+    }
+    return 0;
+  }
+  detail::IBMDescriptor describe() const { return detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN3, 3, real(1.0) / invh); }
 };
 struct fourPoint {  // :140-160
   real invh;
   static constexpr int support = 4;
   explicit fourPoint(real h) : invh(real(1.0) / h) {}
-  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN4, 4, real(1.0) / invh, &k); return k; }
+  UAMMD_HOSTDEV real phi(real rr, real3 = real3()) const {
+    const real r = (rr < 0 ? -rr : rr) * invh;
+    if (r < real(1.0)) return invh * real(0.125) * (detail::fmaR(real(-2.0), r, real(3.0)) + detail::sqrtR(detail::fmaR(real(4.0) * r, real(1.0) - r, real(1.0))));
+    if (r < real(2.0))
+      return invh * real(0.125) * (detail::fmaR(real(-2.0), r, real(5.0)) - detail::sqrtR(detail::fmaR(-(real(4.0) * r), r, detail::fmaR(real(12.0), r, real(-7.0)))));
+    return 0;
+  }
+  detail::IBMDescriptor describe() const { return detail::gridWindow(UAMMD_IBM_KERNEL_PESKIN4, 4, real(1.0) / invh); }
 };
 }  // namespace Peskin
 namespace GaussianFlexible {
-struct sixPoint {  // :168-236
+struct sixPoint {  // the C3 six-point window of Bao, Kaye and Peskin with K = 59/60 - sqrt(29)/20 (:162-236)
   real invh;
   static constexpr int support = 6;
   explicit sixPoint(real h, real = 1e-7) : invh(real(1.0) / h) {}
-  uammd_ibm_kernel describe() const { uammd_ibm_kernel k; BDHI::FCM_ns::Kernels::detail::gridWindow(UAMMD_IBM_KERNEL_SIXPOINT, 6, real(1.0) / invh, &k); return k; }
+  UAMMD_HOSTDEV real phi(real rr, real3 = real3()) const {
+    const real r = (rr < 0 ? -rr : rr) * invh;
+    if (r >= real(3.0)) return 0;
+    const real K = real(0.714075092976608);
+    const real R = r - detail::ceilR(r) + real(1.0), R2 = R * R, R3 = R2 * R;
+    const real b = real(9.0 / 4.0) - real(1.5) * (K + R2) + (real(22. / 3) - real(7.0) * K) * R - real(7. / 3.) * R3;
+    const real g = real(0.25) * (real(0.5) * (real(161.0) / real(36.0) - real(59.0) / real(6.0) * K + real(5.0) * K * K) * R2 +
+                                 real(1.0) / real(3.0) * (real(-109.0) / real(24.0) + real(5.0) * K) * R2 * R2 + real(5.0) / real(18.0) * R3 * R3);
+    const real pre = real(1.0) / (real(2.0) * real(28.0)) * (-b + detail::sqrtR(b * b - real(4.0) * real(28.0) * g));   // the branch-independent root
+    real v;
+    if (r <= real(0.0)) { const real t = r + real(1.0); v = real(2.0) * pre + real(0.25) + real(1. / 6) * (real(4.0) - real(3.0) * K) * t - real(1. / 6) * t * t * t; }
+    else if (r <= real(1.0)) v = real(2.0) * pre + real(5. / 8) - real(0.25) * (K + r * r);
+    else if (r <= real(2.0)) { const real t = r + real(-1.0); v = real(-3.0) * pre + real(0.25) - real(1. / 6.) * (real(4.0) - real(3.0) * K) * t + real(1. / 6) * t * t * t; }
+    else { const real t = r + real(-2.0); v = pre - real(1. / 16) + real(1. / 8) * (K + t * t) - real(1. / 12) * (real(3.0) * K - real(1.0)) * t - real(1. / 12) * t * t * t; }
+    return v * invh;
+  }
+  detail::IBMDescriptor describe() const { return detail::gridWindow(UAMMD_IBM_KERNEL_SIXPOINT, 6, real(1.0) / invh); }
 };
 }  // namespace GaussianFlexible
 }  // namespace IBM_kernels
 
+// ---- FCM_ns::Kernels (BDHI/FCM/FCM_kernels.cuh): the windows FCM_impl is instantiated with — an IBM window plus what FCM needs to know
+// about it: Kernel(h, tolerance), support, fixHydrodynamicRadius(.., h), adviseGridSize(a, tolerance). ----
+namespace BDHI {
+namespace FCM_ns {
+namespace Kernels {
+class Gaussian {  // :22-58
+  uammd::detail::IBMDescriptor desc{};
+  real a = 0;
+public:
+  int support;
+  real rmax;
+  Gaussian(real h, real tolerance) {
+#if defined(DOUBLE_PRECISION)
+    uammd::detail::check(uammd_fcm_gaussian_kernel_f64(h, tolerance, &desc, &a));
+#else
+    uammd::detail::check(uammd_fcm_gaussian_kernel(h, tolerance, &desc, &a));
+#endif
+    support = desc.support[0];
+    rmax = desc.rmax;
+  }
+  static real adviseGridSize(real hydrodynamicRadius, real tolerance) {
+#if defined(DOUBLE_PRECISION)
+    return uammd_fcm_advise_grid_size_f64(hydrodynamicRadius, tolerance);
+#else
+    return uammd_fcm_advise_grid_size(hydrodynamicRadius, tolerance);
+#endif
+  }
+  real fixHydrodynamicRadius(real, real) const { return a; }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return r >= rmax ? real(0) : desc.prefactor * uammd::detail::expR(desc.tau * r * r); }
+  const uammd::detail::IBMDescriptor &describe() const { return desc; }
+};
+class GaussianTorque {  // :60-80
+  uammd::detail::IBMDescriptor desc{};
+public:
+  int support;
+  real rmax;
+  GaussianTorque(real width, real h, real tolerance) {
+    desc.kind = UAMMD_IBM_KERNEL_GAUSSIAN;
+    desc.prefactor = real(std::pow(2.0 * M_PI * double(width) * double(width), -0.5));
+    desc.tau = real(-0.5 / (double(width) * double(width)));
+    const real pre = desc.prefactor, tau = desc.tau;
+    support = uammd::detail::supportForTolerance([pre, tau](real r) { return pre * uammd::detail::expR(tau * r * r); }, h, tolerance);
+    desc.support[0] = desc.support[1] = desc.support[2] = support;
+    desc.rmax = rmax = real(support) * h;
+  }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return r >= rmax ? real(0) : desc.prefactor * uammd::detail::expR(desc.tau * r * r); }
+  const uammd::detail::IBMDescriptor &describe() const { return desc; }
+};
+class BarnettMagland {  // :82-155
+  IBM_kernels::BarnettMagland bm;
+  real a;
+  static int computeSupport(real tol) {
+    real w = std::max(1.5, int(-std::log10(tol) + 2) / 2.0);
+    w = std::min(real(9.0), w);
+    return (int)std::ceil(w);
+  }
+  static real computeUpsampling(real w) { return 1.36409985665115 * std::pow(w, -0.53028415751646); }
+  static IBM_kernels::BarnettMagland make(real tolerance) {
+    const int w = computeSupport(tolerance);
+    return IBM_kernels::BarnettMagland(real(w * 0.5), real(1.8 * w * 2), (int)std::ceil(2 * (w * 0.5)));
+  }
+public:
+  int support;
+  BarnettMagland(real h, real tolerance) : bm(make(tolerance)), a(h), support(bm.support) {}
+  static real adviseGridSize(real hydrodynamicRadius, real tolerance) { return hydrodynamicRadius * computeUpsampling(computeSupport(tolerance)); }
+  real fixHydrodynamicRadius(real, real h) const { return h / computeUpsampling(support); }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return bm.phi(r / a) / a; }
+  uammd::detail::IBMDescriptor describe() const { return bm.describe(a); }
+};
+namespace Peskin {
+class threePoint {  // :159-176
+  IBM_kernels::Peskin::threePoint kern;
+public:
+  static constexpr int support = 3;
+  threePoint(real h, real) : kern(h) {}
+  static real adviseGridSize(real hydrodynamicRadius, real) { return hydrodynamicRadius; }
+  real fixHydrodynamicRadius(real, real h) const { return h; }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return kern.phi(r); }
+  uammd::detail::IBMDescriptor describe() const { return kern.describe(); }
+};
+class fourPoint {  // :178-196
+  IBM_kernels::Peskin::fourPoint kern;
+public:
+  static constexpr int support = 4;
+  static constexpr real fac = 1.31;
+  fourPoint(real h, real) : kern(h) {}
+  static real adviseGridSize(real hydrodynamicRadius, real) { return hydrodynamicRadius / fac; }
+  real fixHydrodynamicRadius(real, real h) const { return h * fac; }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return kern.phi(r); }
+  uammd::detail::IBMDescriptor describe() const { return kern.describe(); }
+};
+}  // namespace Peskin
+namespace GaussianFlexible {
+class sixPoint {  // :199-219
+  IBM_kernels::GaussianFlexible::sixPoint kern;
+public:
+  static constexpr int support = 6;
+  static constexpr real fac = 1.5195;
+  sixPoint(real h, real) : kern(h) {}
+  static real adviseGridSize(real hydrodynamicRadius, real) { return hydrodynamicRadius / fac; }
+  real fixHydrodynamicRadius(real, real h) const { return h * fac; }
+  UAMMD_HOSTDEV real phi(real r, real3 = real3()) const { return kern.phi(r); }
+  uammd::detail::IBMDescriptor describe() const { return kern.describe(); }
+};
+}  // namespace GaussianFlexible
+}  // namespace Kernels
+}  // namespace FCM_ns
+}  // namespace BDHI
+
 // ---- misc/IBM.cuh:63-203: IBM<Kernel, Grid, Index3D> — spread particle quantities to a grid, gather grid quantities to the particles
-// (library mode: no ParticleData, device pointers in, device pointers out).  Kernel is a host descriptor with describe() (IBM_kernels
-// above); Index3D is the linear node index i + nx (j + ny k) whose nx may exceed the grid's (a padded, in-place-FFT layout); the
-// quantity is real or real3 per particle / node.  Default weights only (value * phiX * phiY * phiZ, quadrature weight = cell volume):
-// user WeightCompute / QuadratureWeights functors are device code. ----
+// (library mode: no ParticleData; iterators in, iterators out).  Two ways down:
+//   * the LIBRARY path — a window UAMMD ships (it has describe()), real4 positions, real or real3 quantities through plain device pointers,
+//     the default weights and node indexing: one call of uammd_ibm_spread / uammd_ibm_gather (their _f64 forms under DOUBLE_PRECISION).
+//     Any C++ compiler.
+//   * the TEMPLATE path — anything else (a user's kernel, int or vector quantities, thrust iterators, real3 positions, WeightCompute /
+//     QuadratureWeights / Index3D functors): include/uammd/device/IBM.hip.hpp, compiled with the user's TU by hipcc.
+// A grid with cellDim.z == 1 is treated as 2D (IBM.cuh:182-194). ----
 namespace IBM_ns {
 struct LinearIndex3D {
-  LinearIndex3D(int nx_, int ny_, int nz_) : nx(nx_), ny(ny_), nz(nz_) {}
-  int operator()(int3 c) const { return (*this)(c.x, c.y, c.z); }
-  int operator()(int i, int j, int k) const { return i + nx * (j + ny * k); }
+  UAMMD_HOSTDEV LinearIndex3D(int nx_, int ny_, int nz_) : nx(nx_), ny(ny_), nz(nz_) {}
+  UAMMD_HOSTDEV int operator()(int3 c) const { return (*this)(c.x, c.y, c.z); }
+  UAMMD_HOSTDEV int operator()(int i, int j, int k) const { return i + nx * (j + ny * k); }
   int nx, ny, nz;
 };
+namespace detail {
+template <class K, class = void> struct has_describe : std::false_type {};
+template <class K> struct has_describe<K, decltype(void(std::declval<const K &>().describe()))> : std::true_type {};
+template <class P> struct pointee { using type = void; };
+template <class T> struct pointee<T *> { using type = typename std::remove_cv<T>::type; };
+// can this call go to the C ABI as it is?
+template <class Kernel, class GridT, class Index3D, class Pos, class Q, class G> struct LibraryPath {
+  using P = typename pointee<Pos>::type;
+  using QT = typename pointee<Q>::type;
+  using GT = typename pointee<G>::type;
+  static constexpr bool value = has_describe<Kernel>::value && std::is_same<GridT, uammd::Grid>::value && std::is_same<Index3D, LinearIndex3D>::value &&
+                                std::is_same<P, real4>::value && std::is_same<QT, GT>::value && (std::is_same<QT, real>::value || std::is_same<QT, real3>::value);
+};
+}  // namespace detail
 }  // namespace IBM_ns
+}  // namespace uammd
+#if defined(__HIPCC__)
+#include "device/IBM.hip.hpp"
+#endif
+namespace uammd {
+#if !defined(__HIPCC__)
+namespace IBM_ns {   // (named so that signatures with defaulted functor arguments read the same in a host-only TU; they hold device code under hipcc)
+struct DefaultQuadratureWeights {};
+struct DefaultWeightCompute {};
+}  // namespace IBM_ns
+#endif
 template <class Kernel, class GridT = uammd::Grid, class Index3D = IBM_ns::LinearIndex3D> class IBM {
-  static_assert(std::is_same<Index3D, IBM_ns::LinearIndex3D>::value, "the host IBM<> takes IBM_ns::LinearIndex3D; another node indexing is a device functor (hipcc)");
   shared_ptr<Kernel> kernel;
   GridT grid;
   Index3D cell2index;
-  template <class Q> static int components() {
-    static_assert(sizeof(Q) == sizeof(real) || sizeof(Q) == 3 * sizeof(real), "IBM<>: the quantity is real or real3");
-    return (int)(sizeof(Q) / sizeof(real));
+  template <class Q> static int components() { return (int)(sizeof(Q) / sizeof(real)); }
+  // ---- library path ----
+  template <class Q> void spreadLibrary(const real4 *pos, const Q *v, Q *gridData, int N, hipStream_t st) const {
+    int per[3];
+    const int cd[3] = {grid.cellDim.x, grid.cellDim.y, grid.cellDim.z};
+    const auto k = kernel->describe();
+#if defined(DOUBLE_PRECISION)
+    double L[3];
+    grid.box.toArrays(L, per);
+    uammd::detail::check(uammd_ibm_spread_f64((const double *)pos, 4, (const double *)v, components<Q>(), N, L, per, cd, cell2index.nx, &k, (double *)gridData, (void *)st));
+#else
+    float L[3];
+    grid.box.toArrays(L, per);
+    uammd::detail::check(uammd_ibm_spread((const float *)pos, 4, (const float *)v, components<Q>(), N, L, per, cd, cell2index.nx, &k, (float *)gridData, (void *)st));
+#endif
   }
-  struct Geometry { float L[3]; int per[3], cd[3]; };
-  Geometry geometry() const {
-    Geometry g;
-    grid.box.toArrays(g.L, g.per);
-    g.cd[0] = grid.cellDim.x; g.cd[1] = grid.cellDim.y; g.cd[2] = grid.cellDim.z;
-    return g;
+  template <class Q> void gatherLibrary(const real4 *pos, Q *Jq, const Q *gridData, int N, hipStream_t st) const {
+    int per[3];
+    const int cd[3] = {grid.cellDim.x, grid.cellDim.y, grid.cellDim.z};
+    const auto k = kernel->describe();
+#if defined(DOUBLE_PRECISION)
+    double L[3];
+    grid.box.toArrays(L, per);
+    uammd::detail::check(uammd_ibm_gather_f64((const double *)pos, 4, (double *)Jq, components<Q>(), N, L, per, cd, cell2index.nx, &k, (const double *)gridData, (void *)st));
+#else
+    float L[3];
+    grid.box.toArrays(L, per);
+    uammd::detail::check(uammd_ibm_gather((const float *)pos, 4, (float *)Jq, components<Q>(), N, L, per, cd, cell2index.nx, &k, (const float *)gridData, (void *)st));
+#endif
   }
+  template <class Pos, class Q, class G> void spreadDefault(std::true_type, Pos pos, Q v, G gridData, int N, hipStream_t st) const {
+    spreadLibrary(pos, v, gridData, N, st);
+  }
+  template <class Pos, class R, class G> void gatherDefault(std::true_type, Pos pos, R Jq, G gridData, int N, hipStream_t st) const {
+    gatherLibrary(pos, Jq, gridData, N, st);
+  }
+#if defined(__HIPCC__)
+  // ---- template path ----
+  template <class Pos, class Q, class G> void spreadDefault(std::false_type, Pos pos, Q v, G gridData, int N, hipStream_t st) const {
+    spread(pos, v, gridData, IBM_ns::DefaultWeightCompute(), N, st);
+  }
+  template <class Pos, class R, class G> void gatherDefault(std::false_type, Pos pos, R Jq, G gridData, int N, hipStream_t st) const {
+    gather(pos, Jq, gridData, IBM_ns::DefaultQuadratureWeights(), IBM_ns::DefaultWeightCompute(), N, st);
+  }
+#else
+  template <class Pos, class Q, class G> void spreadDefault(std::false_type, Pos, Q, G, int, hipStream_t) const {
+    static_assert(sizeof(Pos) == 0, "IBM<>: a user-defined kernel or non-pointer / non-real quantities need the device template: compile this TU with hipcc");
+  }
+  template <class Pos, class R, class G> void gatherDefault(std::false_type, Pos, R, G, int, hipStream_t) const {
+    static_assert(sizeof(Pos) == 0, "IBM<>: a user-defined kernel or non-pointer / non-real quantities need the device template: compile this TU with hipcc");
+  }
+#endif
+  // (in a DOUBLE_PRECISION TU compiled by hipcc every call takes the template path: the library's double build holds the Gaussian and Peskin
+  // windows only, the template holds whatever phi says)
+  template <class Pos, class Q, class G> struct UseLibrary
+      : std::integral_constant<bool, IBM_ns::detail::LibraryPath<Kernel, GridT, Index3D, Pos, Q, G>::value
+#if defined(DOUBLE_PRECISION) && defined(__HIPCC__)
+                                         && false
+#endif
+                               > {};
 public:
   IBM(shared_ptr<Kernel> kern, GridT a_grid, Index3D index) : kernel(kern), grid(a_grid), cell2index(index) {}
   IBM(shared_ptr<Kernel> kern, GridT a_grid) : IBM(kern, a_grid, Index3D(a_grid.cellDim.x, a_grid.cellDim.y, a_grid.cellDim.z)) {}
-  // gridData[node] += sum_i v[i] phi(node - pos[i])   (IBM.cuh:118-138; a grid with cellDim.z == 1 is 2D, :182-194)
-  template <class Q> void spread(const real4 *pos, const Q *v, Q *gridData, int numberParticles, hipStream_t st = 0) const {
-    const Geometry g = geometry();
-    const uammd_ibm_kernel k = kernel->describe();
-    detail::check(uammd_ibm_spread((const float *)pos, 4, (const float *)v, components<Q>(), numberParticles, g.L, g.per, g.cd, cell2index.nx, &k,
-                                   (float *)gridData, (void *)st));
+  // gridData[node] += sum_i weightCompute(v[i], phi(node - pos[i]))   (IBM.cuh:118-138)
+  template <class Pos, class Q, class G> void spread(Pos pos, Q v, G gridData, int numberParticles, hipStream_t st = 0) const {
+    spreadDefault(UseLibrary<Pos, Q, G>(), pos, v, gridData, numberParticles, st);
   }
-  // Jq[i] += sum_node gridData[node] phi(node - pos[i]) cellVolume   (IBM.cuh:140-180)
-  template <class Q> void gather(const real4 *pos, Q *Jq, const Q *gridData, int numberParticles, hipStream_t st = 0) const {
-    const Geometry g = geometry();
-    const uammd_ibm_kernel k = kernel->describe();
-    detail::check(uammd_ibm_gather((const float *)pos, 4, (float *)Jq, components<Q>(), numberParticles, g.L, g.per, g.cd, cell2index.nx, &k,
-                                   (const float *)gridData, (void *)st));
+  // Jq[i] += sum_node qw(node) weightCompute(gridData[node], phi(node - pos[i]))   (IBM.cuh:140-180)
+  template <class Pos, class R, class G> void gather(Pos pos, R Jq, G gridData, int numberParticles, hipStream_t st = 0) const {
+    gatherDefault(UseLibrary<Pos, R, G>(), pos, Jq, gridData, numberParticles, st);
   }
+#if defined(__HIPCC__)
+  template <class Pos, class Q, class G, class WeightCompute, class = typename std::enable_if<!std::is_integral<WeightCompute>::value>::type>
+  void spread(Pos pos, Q v, G gridData, WeightCompute weightCompute, int numberParticles, hipStream_t st = 0) const {
+    if (grid.cellDim.z == 1) spread<true>(pos, v, gridData, weightCompute, numberParticles, st);
+    else spread<false>(pos, v, gridData, weightCompute, numberParticles, st);
+  }
+  template <bool is2D, class Pos, class Q, class G, class WeightCompute, class = typename std::enable_if<!std::is_integral<WeightCompute>::value>::type>
+  void spread(Pos pos, Q v, G gridData, WeightCompute weightCompute, int numberParticles, hipStream_t st = 0) const {
+    IBM_ns::detail::launchSpread<is2D>(*kernel, grid, cell2index, pos, v, gridData, weightCompute, numberParticles, st);
+    uammd::detail::hipCheck(hipGetLastError(), "IBM::spread");
+  }
+  template <bool is2D, class Pos, class Q, class G> void spread(Pos pos, Q v, G gridData, int numberParticles, hipStream_t st = 0) const {
+    spread<is2D>(pos, v, gridData, IBM_ns::DefaultWeightCompute(), numberParticles, st);
+  }
+  template <class Pos, class R, class G, class QuadratureWeights, class WeightCompute>
+  void gather(Pos pos, R Jq, G gridData, QuadratureWeights qw, WeightCompute wc, int numberParticles, hipStream_t st = 0) const {
+    if (grid.cellDim.z == 1) gather<true>(pos, Jq, gridData, qw, wc, numberParticles, st);
+    else gather<false>(pos, Jq, gridData, qw, wc, numberParticles, st);
+  }
+  template <bool is2D, class Pos, class R, class G, class QuadratureWeights, class WeightCompute>
+  void gather(Pos pos, R Jq, G gridData, QuadratureWeights qw, WeightCompute wc, int numberParticles, hipStream_t st = 0) const {
+    IBM_ns::detail::launchGather<is2D>(*kernel, grid, cell2index, pos, Jq, gridData, qw, wc, numberParticles, st);
+    uammd::detail::hipCheck(hipGetLastError(), "IBM::gather");
+  }
+  template <bool is2D, class Pos, class R, class G> void gather(Pos pos, R Jq, G gridData, int numberParticles, hipStream_t st = 0) const {
+    gather<is2D>(pos, Jq, gridData, IBM_ns::DefaultQuadratureWeights(), IBM_ns::DefaultWeightCompute(), numberParticles, st);
+  }
+#endif
   shared_ptr<Kernel> getKernel() { return kernel; }
 };
 
 namespace BDHI {
+// FCM_impl (BDHI/FCM/FCM_impl.cuh:36-130): the solver without ParticleData — positions, forces (and torques) in, velocities out.
+// Kernel / KernelTorque are the windows of FCM_ns::Kernels: the library evaluates them from their describe()d parameters (a user-written
+// FCM window is not a library window: spreading it needs IBM<> above with the user's TU).
 template <class Kernel = FCM_ns::Kernels::Gaussian, class KernelTorque = FCM_ns::Kernels::GaussianTorque> class FCM_impl {
+  static_assert(IBM_ns::detail::has_describe<Kernel>::value && IBM_ns::detail::has_describe<KernelTorque>::value,
+                "FCM_impl takes the windows of BDHI::FCM_ns::Kernels (the library evaluates them); spread a window of your own with IBM<>");
+#if defined(DOUBLE_PRECISION)
+  uammd_fcm_f64 *h = nullptr;
+#else
   uammd_fcm *h = nullptr;
+#endif
   Box box;
   real viscosity, hydrodynamicRadius;
+  uint seed = 0, seed2 = 0;
+  shared_ptr<Kernel> kernel;
+  shared_ptr<KernelTorque> kernelTorque;
 public:
-  using Parameters = BDHI::Parameters;
-  explicit FCM_impl(Parameters par) : box(par.box), viscosity(par.viscosity) {
-    if (par.box.boxSize.x <= 0 || par.cells.x <= 0) throw std::runtime_error("Invalid arguments");  // FCM_impl.cuh:74-82
+  struct Parameters : BDHI::Parameters {   // FCM_impl.cuh:47-54
+    int3 cells = make_int3(-1, -1, -1);    // number of Fourier nodes in each direction
+    uint seed = 0;
+    std::shared_ptr<Kernel> kernel = nullptr;
+    std::shared_ptr<KernelTorque> kernelTorque = nullptr;
+    bool adaptBoxSize = false;
+  };
+  explicit FCM_impl(Parameters par)
+      : box(par.box), viscosity(par.viscosity), hydrodynamicRadius(par.hydrodynamicRadius), seed(par.seed), kernel(par.kernel), kernelTorque(par.kernelTorque) {
+    // FCM_impl.cuh:56-92, in its order
+    if (box.boxSize.x == real(0.0) && box.boxSize.y == real(0.0) && box.boxSize.z == real(0.0))
+      System::log<System::CRITICAL>("[BDHI::FCM] Box of size zero detected, cannot work without a box! (make sure a box parameter was passed)");
+    if (seed == 0) seed = (uint)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (par.box.boxSize.x <= 0 || par.cells.x <= 0) throw std::runtime_error("Invalid arguments");
+    if (!par.kernel || !par.kernelTorque) {
+      System::log<System::EXCEPTION>("FCM_impl requires instances of the spreading kernels");
+      throw std::runtime_error("Invalid arguments");
+    }
+#if defined(DOUBLE_PRECISION)
+    uammd_fcm_parameters_f64 p{};
+#else
     uammd_fcm_parameters p{};
+    p.seed = seed;
+    p.hydrodynamicRadius = hydrodynamicRadius;
+#endif
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
     p.cells[0] = par.cells.x; p.cells[1] = par.cells.y; p.cells[2] = par.cells.z;
     p.viscosity = par.viscosity;
-    p.seed = par.seed;
-    const real hx = p.boxSize[0] / p.cells[0], hy = p.boxSize[1] / p.cells[1], hz = p.boxSize[2] / p.cells[2];
-    const real hmin = std::min(hx, std::min(hy, hz));
-    // initializeKernel + fixHydrodynamicRadius (BDHI_FCM.cuh:49-66, :104-106)
-    hydrodynamicRadius = p.hydrodynamicRadius = Kernel::make(hmin, par.tolerance, &p.kernel);
-    if (p.kernel.support[0] >= p.cells[0] || p.kernel.support[1] >= p.cells[1] || p.kernel.support[2] >= p.cells[2])   // BDHI_FCM.cuh:58-64: said, not fatal
-      System::log<System::ERROR>("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
-    detail::check(uammd_fcm_create(&p, &h));
-    uammd_ibm_kernel kt;  // initializeKernelTorque, BDHI_FCM.cuh:69-80
-    detail::check(uammd_fcm_torque_gaussian_kernel(hydrodynamicRadius, hmin, par.tolerance, &kt));
-    detail::check(uammd_fcm_set_torque_kernel(h, &kt));
+    p.kernel = kernel->describe();
+#if defined(DOUBLE_PRECISION)
+    uammd::detail::check(uammd_fcm_create_f64(&p, &h));   // (linear velocities; torques are not in the library's double-precision build)
+#else
+    uammd::detail::check(uammd_fcm_create(&p, &h));
+    const uammd_ibm_kernel kt = kernelTorque->describe();
+    uammd::detail::check(uammd_fcm_set_torque_kernel(h, &kt));
+#endif
   }
   FCM_impl(const FCM_impl &) = delete;
+#if defined(DOUBLE_PRECISION)
+  ~FCM_impl() { uammd_fcm_destroy_f64(h); }
+#else
   ~FCM_impl() { uammd_fcm_destroy(h); }
+#endif
   real getHydrodynamicRadius() { return hydrodynamicRadius; }
   real getSelfMobility() { return (real)uammd_fcm_self_mobility(hydrodynamicRadius, viscosity, box.boxSize.x); }
   Box getBox() { return box; }
   // linear velocities into d_linearVelocity (real3[N])
   void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, real3 *d_linearVelocity, int N, real temperature,
                                         real prefactor, hipStream_t st) {
-    detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
-                                          (float *)d_linearVelocity, (void *)st));
+#if defined(DOUBLE_PRECISION)
+    if (temperature > 0) ++seed2;   // addBrownianNoise's counter, FCM_impl.cuh:517-523
+    uammd::detail::check(uammd_fcm_displacements_thermal_f64(h, (const double *)pos, (const double *)force, N, temperature, prefactor, seed, seed2,
+                                                             (double *)d_linearVelocity, (void *)st));
+#else
+    uammd::detail::check(uammd_fcm_displacements(h, (const float *)pos, (const float *)force, N, temperature, prefactor,
+                                                 (float *)d_linearVelocity, (void *)st));
+#endif
   }
+#if !defined(DOUBLE_PRECISION)
   // computeHydrodynamicDisplacements followed by integrateEulerMaruyamaD (BDHI_FCM.cu:67-92) in one library call: pos += v dt in place
   // positionsKept: pos is exactly what the previous call left (UAMMD_FCM_STEP_POSITIONS_KEPT: that call's binning is used)
   void stepEulerMaruyama(real4 *pos, const real4 *force, real3 *d_linearVelocity, int N, real temperature, real prefactor, real dt,
                          bool positionsKept, hipStream_t st) {
-    detail::check(uammd_fcm_step_euler_maruyama(h, (float *)pos, (const float *)force, N, temperature, prefactor, dt,
-                                                (float *)d_linearVelocity, positionsKept ? UAMMD_FCM_STEP_POSITIONS_KEPT : 0, (void *)st));
+    uammd::detail::check(uammd_fcm_step_euler_maruyama(h, (float *)pos, (const float *)force, N, temperature, prefactor, dt,
+                                                       (float *)d_linearVelocity, positionsKept ? UAMMD_FCM_STEP_POSITIONS_KEPT : 0, (void *)st));
   }
+#endif
   // The reference's own signature (FCM_impl.cuh:126-129): owning containers returned by value, the second one empty without torques
   std::pair<cached_vector<real3>, cached_vector<real3>> computeHydrodynamicDisplacements(real4 *pos, real4 *force, real4 *torque,
                                                                                          int numberParticles, real temperature,
                                                                                          real prefactor, hipStream_t st) {
     cached_vector<real3> linear((size_t)numberParticles), angular(torque ? (size_t)numberParticles : 0);
-    computeHydrodynamicDisplacements(pos, force, torque, linear.data(), angular.data(), numberParticles, temperature, prefactor, st);
+    computeHydrodynamicDisplacements(pos, force, torque, linear.raw(), angular.raw(), numberParticles, temperature, prefactor, st);
     return std::make_pair(std::move(linear), std::move(angular));
   }
   // with torques (FCM_impl.cuh:306-358): linear and angular velocities; torque == nullptr falls back to the call above
   void computeHydrodynamicDisplacements(const real4 *pos, const real4 *force, const real4 *torque, real3 *d_linearVelocity,
                                         real3 *d_angularVelocity, int N, real temperature, real prefactor, hipStream_t st) {
     if (!torque) return computeHydrodynamicDisplacements(pos, force, d_linearVelocity, N, temperature, prefactor, st);
-    detail::check(uammd_fcm_displacements_torque(h, (const float *)pos, (const float *)force, (const float *)torque, N, temperature,
-                                                 prefactor, (float *)d_linearVelocity, (float *)d_angularVelocity, (void *)st));
+#if defined(DOUBLE_PRECISION)
+    (void)d_angularVelocity;
+    throw std::runtime_error("[BDHI::FCM] torques are not part of the double-precision build of the library (single precision has them)");
+#else
+    uammd::detail::check(uammd_fcm_displacements_torque(h, (const float *)pos, (const float *)force, (const float *)torque, N, temperature,
+                                                        prefactor, (float *)d_linearVelocity, (float *)d_angularVelocity, (void *)st));
+#endif
   }
 };
 namespace detail_fcm {
-template <class Kernel = FCM_ns::Kernels::Gaussian>
-inline BDHI::Parameters initialize(BDHI::Parameters par, System &sys) {  // BDHI_FCM.cuh:29-66, :98-110
+// initializeGrid, initializeKernel, initializeKernelTorque and fixHydrodynamicRadius as BDHI::FCM's and FCMIntegrator's constructors string
+// them together (BDHI_FCM.cuh:29-80, :98-110)
+template <class Kernel, class KernelTorque>
+inline typename FCM_impl<Kernel, KernelTorque>::Parameters initialize(typename FCM_impl<Kernel, KernelTorque>::Parameters par, System &sys) {
   if (par.seed == 0) par.seed = sys.rng().next32();
+  real h = 0;
   if (par.cells.x <= 0) {
     if (par.hydrodynamicRadius <= 0) System::log<System::CRITICAL>("[BDHI::FCM] I need an hydrodynamic radius if cell dimensions are not provided!");
-    const real h = Kernel::adviseGridSize(par.hydrodynamicRadius, par.tolerance);
-    int c[3] = {(int)(par.box.boxSize.x / h), (int)(par.box.boxSize.y / h), (int)(par.box.boxSize.z / h)};
-    for (int &v : c) {  // nextFFTWiseSize3D, utils/Grid.cuh:142-213
-      for (;; ++v) {
-        int m = v;
-        if (m % 2) continue;
-        for (int p : {2, 3, 5, 7, 11}) while (m % p == 0) m /= p;
-        if (m == 1) break;
-      }
-    }
-    par.cells = make_int3(c[0], c[1], c[2]);
-    if (par.adaptBoxSize) par.box = Box(make_real3(c[0] * h, c[1] * h, c[2] * h));
+    h = Kernel::adviseGridSize(par.hydrodynamicRadius, par.tolerance);
+    par.cells = nextFFTWiseSize3D(make_int3(par.box.boxSize / h));
+    if (par.adaptBoxSize) par.box = Box(make_real3(par.cells) * h);
+  }
+  const Grid grid(par.box, par.cells);
+  const real hmin = std::min(grid.cellSize.x, std::min(grid.cellSize.y, grid.cellSize.z));
+  if (!par.kernel) par.kernel = std::make_shared<Kernel>(hmin, par.tolerance);
+  if (par.kernel->support >= grid.cellDim.x || par.kernel->support >= grid.cellDim.y || par.kernel->support >= grid.cellDim.z)   // said, not fatal (:58-64)
+    System::log<System::ERROR>("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
+  par.hydrodynamicRadius = par.kernel->fixHydrodynamicRadius(par.hydrodynamicRadius, grid.cellSize.x);
+  if (!par.kernelTorque) {
+    const real width = par.hydrodynamicRadius / real(std::pow(6 * std::sqrt(M_PI), 1 / 3.));
+    par.kernelTorque = std::make_shared<KernelTorque>(width, hmin, par.tolerance);
   }
   return par;
 }
 }  // namespace detail_fcm
 class FCM {  // the Method concept of BDHI::EulerMaruyama (BDHI_FCM.cuh:84-147)
+  using Kernel = FCM_ns::Kernels::Gaussian;
+  using KernelTorque = FCM_ns::Kernels::GaussianTorque;
+  using FCM_super = FCM_impl<Kernel, KernelTorque>;
   shared_ptr<ParticleData> pd;
   shared_ptr<ParticleGroup> pg;  // nullptr = all the particles
-  shared_ptr<FCM_impl<>> fcm;
+  shared_ptr<FCM_super> fcm;
   real temperature, dt;
   detail::DeviceArray<real4> posRows, forceRows;
 public:
-  using Parameters = BDHI::Parameters;
+  using Parameters = FCM_super::Parameters;
   FCM(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_FCM.cuh:98-110
       : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), temperature(par.temperature), dt(par.dt) {
-    fcm = make_shared<FCM_impl<>>(detail_fcm::initialize(par, *pd->getSystem()));
+    fcm = make_shared<FCM_super>(detail_fcm::initialize<Kernel, KernelTorque>(par, *pd->getSystem()));
   }
   FCM(shared_ptr<ParticleData> pd, Parameters par) : FCM(make_shared<ParticleGroup>(pd, "All"), par) {}
   void setup_step(hipStream_t = 0) {}
@@ -1757,10 +2179,12 @@ public:
   real getHydrodynamicRadius() { return fcm->getHydrodynamicRadius(); }
   real getSelfMobility() { return fcm->getSelfMobility(); }
 };
+#if !defined(DOUBLE_PRECISION)
 // BDHI_FCM.cuh:155-199, BDHI_FCM.cu:7-119.  The reference fixes Kernel = Gaussian; the template parameter exposes the
 // alternatives it keeps commented out in FCM_impl.cuh:39-42.
 template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : public Integrator {
-  shared_ptr<FCM_impl<Kernel>> fcm;
+  using KernelTorque = FCM_ns::Kernels::GaussianTorque;
+  shared_ptr<FCM_impl<Kernel, KernelTorque>> fcm;
   detail::DeviceArray<real3> linearV, angularV;
   real temperature, dt;
   uint steps = 0;
@@ -1769,16 +2193,16 @@ template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : publi
   scoped_connection posWriteConnection, reorderConnection;  // dropped with the integrator
   detail::DeviceArray<real4> posRows, forceRows, torqueRows;  // the rows of a proper subgroup, gathered
 public:
-  using Parameters = BDHI::Parameters;
+  using Parameters = typename FCM_impl<Kernel, KernelTorque>::Parameters;
   FCMIntegratorT(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_FCM.cuh:167-174
       : Integrator(group, "BDHI::FCMIntegrator"), linearV(group->getNumberParticles()), angularV(group->getNumberParticles()),
         temperature(par.temperature), dt(par.dt) {
-    fcm = make_shared<FCM_impl<Kernel>>(detail_fcm::initialize<Kernel>(par, *sys));
+    fcm = make_shared<FCM_impl<Kernel, KernelTorque>>(detail_fcm::initialize<Kernel, KernelTorque>(par, *sys));
     posWriteConnection = pd->getPosWriteRequestedSignal()->connect([this]() { posTouched = true; });
     reorderConnection = pd->getReorderSignal()->connect([this]() { posTouched = true; });
   }
   FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par) : FCMIntegratorT(make_shared<ParticleGroup>(pd, "All"), par) {}
-  shared_ptr<FCM_impl<Kernel>> getFCM_impl() { return fcm; }
+  shared_ptr<FCM_impl<Kernel, KernelTorque>> getFCM_impl() { return fcm; }
   void forwardTime() override {
     steps++;
     for (auto &u : updatables) u->updateSimulationTime(steps * dt);
@@ -1814,6 +2238,7 @@ public:
   }
 };
 using FCMIntegrator = FCMIntegratorT<>;
+#endif
 }  // namespace BDHI
 
 // ---- BDHI::PSE (Integrator/BDHI/BDHI_PSE.cuh:79-176) and BDHI::EulerMaruyama<Method> (BDHI_EulerMaruyama.cu:125-166) --------------
@@ -1824,6 +2249,88 @@ struct Parameters : BDHI::Parameters {  // PSE/utils.cuh:17-24
   real shearStrain = 0;
 };
 }  // namespace pse_ns
+#if defined(DOUBLE_PRECISION)
+// DOUBLE_PRECISION build: the same interface on the `_f64` entry points — far field with rocFFT in double, near field over all pairs with the
+// minimum image (the reference's double-precision tests hold one particle or a handful; the tuned cell-list / pair-record near field is
+// the single-precision build below), near-field noise through the double-precision Lanczos solver.  No shear in this build.
+class PSE {
+  shared_ptr<ParticleData> pd;
+  shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_PSE.cuh:171)
+  detail::DeviceArray<real4> posRows, forceRows;
+  int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
+  const double *positions(const property_ptr<real4> &pos, hipStream_t st) { return (const double *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st); }
+  uammd_pse_near_f64 *nearField = nullptr;
+  uammd_fcm_f64 *farField = nullptr;
+  uammd_lanczos_f64 *solver = nullptr;
+  real hydrodynamicRadius, M0, temperature, dt, tolerance;
+  uint seedNear = 0, seedFar = 0;
+  void far(const real4 *force, real3 *MF, real T, real prefactor, hipStream_t st) {
+    const uint seed2 = T > 0 ? pd->getSystem()->rng().next32() : 0u;  // FarField.cuh:499
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_fcm_displacements_thermal_f64(farField, positions(pos, st), (const double *)force, numberParticles(), T, prefactor, seedFar, seed2,
+                                                      (double *)MF, (void *)st));
+  }
+  void nearDeterministic(const real4 *force, real3 *MF, hipStream_t st) {   // NearField::Mdot, NearField.cuh:239-250: nothing without forces
+    if (!force) return;
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_near_mdot_f64(nearField, positions(pos, st), (const double *)force, 4, numberParticles(), (double *)MF, (void *)st));
+  }
+  void nearStochastic(real3 *BdW, real T, real prefactor, hipStream_t st) {
+    if (T == real(0.0)) return;
+    const uint seed2 = pd->getSystem()->rng().next32();  // NearField.cuh:276
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_near_stochastic_f64(nearField, solver, positions(pos, st), numberParticles(), T, prefactor, seedNear, seed2, tolerance,
+                                                (double *)BdW, (void *)st, nullptr));
+  }
+public:
+  using Parameters = pse_ns::Parameters;
+  PSE(shared_ptr<ParticleData> pd, Parameters par) : PSE(make_shared<ParticleGroup>(pd, "All"), par) {}  // BDHI_PSE.cuh:85-86
+  PSE(shared_ptr<ParticleGroup> group, Parameters par)
+      : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), hydrodynamicRadius(par.hydrodynamicRadius), temperature(par.temperature),
+        dt(par.dt), tolerance(par.tolerance) {
+    M0 = (real)uammd_fcm_self_mobility(par.hydrodynamicRadius, par.viscosity, par.box.boxSize.x);
+    const real3 L3 = par.box.boxSize;
+    if (L3.x == real(0.0) && L3.y == real(0.0) && L3.z == real(0.0)) throw std::invalid_argument("Box of size zero detected");
+    if (par.tolerance > 0.1) throw std::invalid_argument("Tolerance too high");  // PSE/initialization.cu:11-29
+    if (par.shearStrain != real(0.0)) throw std::invalid_argument("[BDHI::PSE] the double-precision build of the library has no sheared boxes");
+    const double L[3] = {L3.x, L3.y, L3.z};
+    auto &rng = pd->getSystem()->rng();
+    seedNear = rng.next32();  // NearField ctor first, then FarField (initialization.cu:57-59)
+    detail::check(uammd_pse_near_create_f64(L, par.viscosity, par.hydrodynamicRadius, par.tolerance, par.psi, &nearField, nullptr, nullptr));
+    seedFar = rng.next32();
+    int c[3];
+    detail::check(uammd_pse_far_raw_cells_f64(L, par.psi, par.tolerance, c));
+    for (int &v : c) v = detail::nextFFTWiseSize(v);
+    detail::check(uammd_pse_far_create_f64(L, c, par.viscosity, par.hydrodynamicRadius, par.tolerance, par.psi, par.shearStrain, &farField, nullptr, nullptr));
+    detail::check(uammd_lanczos_create_f64(&solver));
+  }
+  PSE(const PSE &) = delete;
+  ~PSE() {
+    uammd_lanczos_destroy_f64(solver);
+    uammd_pse_near_destroy_f64(nearField);
+    uammd_fcm_destroy_f64(farField);
+  }
+  void setup_step(hipStream_t = 0) {}
+  void finish_step(hipStream_t = 0) {}
+  void computeMF(real3 *MF, hipStream_t st = 0) {  // :92-120
+    const int N = numberParticles();
+    detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    const real4 *force = detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st);
+    far(force, MF, temperature, real(1.0 / std::sqrt(dt)), st);
+    nearDeterministic(force, MF, st);
+  }
+  void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
+  void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
+    detail::check(uammd_fill_zero(MF, sizeof(real3) * numberParticles(), (void *)st));
+    nearDeterministic(force, MF, st);
+    nearStochastic(MF, T, noise_prefactor, st);
+    far(force, MF, T, noise_prefactor, st);
+  }
+  real getHydrodynamicRadius() { return hydrodynamicRadius; }
+  real getSelfMobility() { return M0; }
+};
+#else
 class PSE {
   shared_ptr<ParticleData> pd;
   shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_PSE.cuh:171)
@@ -1936,7 +2443,7 @@ public:
   void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
     const int N = numberParticles();
     detail::check(uammd_fill_zero(MF, sizeof(real3) * N, (void *)st));
-    {
+    if (force) {   // NearField::Mdot does nothing without forces (NearField.cuh:239-250)
       auto pos = pd->getPos(access::gpu, access::read);
       detail::check(uammd_pse_near_mdot(nearField, positions(pos, st), (const float *)force, N, (float *)MF, (void *)st));
     }
@@ -1950,7 +2457,11 @@ public:
   real getHydrodynamicRadius() { return hydrodynamicRadius; }
   real getSelfMobility() { return M0; }
 };
+#endif
 
+#if defined(DOUBLE_PRECISION)
+}  // namespace BDHI
+#else   // (single-precision backends only, down to Poisson: see PRECISION at the top)
 // BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67): open boundaries, dense RPY mobility, matrix free
 class Lanczos {
   shared_ptr<ParticleData> pd;
@@ -2394,17 +2905,32 @@ public:
   real getNearFieldCutOff() const { return info.nearFieldCutOff; }
 };
 
+#endif   // !DOUBLE_PRECISION
+
 namespace lanczos {
-struct MatrixDot {
+struct MatrixDot {   // misc/LanczosAlgorithm/MatrixDot.h:7-25
   void setSize(int newsize) { m_size = newsize; }
   virtual void operator()(real *v, real *Mv) = 0;
   virtual ~MatrixDot() = default;
 protected:
   int m_size = 0;
 };
-class Solver {
+// any callable (v, Mv) as a MatrixDot (MatrixDot.h:14-23)
+template <class Foo> struct MatrixDotAdaptor : public MatrixDot {
+  Foo foo;
+  explicit MatrixDotAdaptor(Foo f) : foo(std::move(f)) {}
+  void operator()(real *v, real *Mv) override { foo(v, Mv); }
+};
+template <class Foo> MatrixDotAdaptor<typename std::decay<Foo>::type> createMatrixDotAdaptor(Foo &&foo) {
+  return MatrixDotAdaptor<typename std::decay<Foo>::type>(std::forward<Foo>(foo));
+}
+class Solver {   // misc/LanczosAlgorithm.cuh:32-83
+#if defined(DOUBLE_PRECISION)
+  uammd_lanczos_f64 *h = nullptr;
+#else
   uammd_lanczos *h = nullptr;
-  static int trampoline(void *ctx, const float *v, float *Mv, int n, void *) {
+#endif
+  static int trampoline(void *ctx, const real *v, real *Mv, int n, void *) {
     try {
       auto *dot = static_cast<MatrixDot *>(ctx);
       dot->setSize(n);
@@ -2413,18 +2939,53 @@ class Solver {
     } catch (...) { return -99; }
   }
 public:
+#if defined(DOUBLE_PRECISION)
+  Solver() { detail::check(uammd_lanczos_create_f64(&h)); }
+  ~Solver() { uammd_lanczos_destroy_f64(h); }
+#else
   Solver() { detail::check(uammd_lanczos_create(&h)); }
-  Solver(const Solver &) = delete;
   ~Solver() { uammd_lanczos_destroy(h); }
+#endif
+  Solver(const Solver &) = delete;
+  // Bv = sqrt(M) v to the tolerance; returns the number of iterations it took
   int run(MatrixDot *dot, real *Bv, const real *v, real tolerance, int N, hipStream_t st = 0) {
     int it = 0;
+#if defined(DOUBLE_PRECISION)
+    const int rc = uammd_lanczos_run_f64(h, &Solver::trampoline, dot, Bv, v, tolerance, N, (void *)st, &it);
+#else
     const int rc = uammd_lanczos_run(h, &Solver::trampoline, dot, Bv, v, tolerance, N, (void *)st, &it);
+#endif
     if (rc != 0) throw std::runtime_error(uammd_hip_last_error());  // "[Lanczos] Could not converge", LanczosAlgorithm.cu:227
     return it;
   }
   int run(MatrixDot &dot, real *Bv, const real *v, real tolerance, int N, hipStream_t st = 0) { return run(&dot, Bv, v, tolerance, N, st); }
+  int run(std::function<void(real *, real *)> dot, real *Bv, const real *v, real tolerance, int N, hipStream_t st = 0) {   // :46-50
+    auto adaptor = createMatrixDotAdaptor(std::move(dot));
+    return run(&adaptor, Bv, v, tolerance, N, st);
+  }
+  // exactly numberIterations steps, no convergence test; returns the residual between the last two estimates (:54-67)
+  real runIterations(MatrixDot *dot, real *Bz, const real *z, int numberIterations, int N) {
+    real residual = 0;
+#if defined(DOUBLE_PRECISION)
+    const int rc = uammd_lanczos_run_iterations_f64(h, &Solver::trampoline, dot, Bz, z, numberIterations, N, nullptr, &residual);
+#else
+    const int rc = uammd_lanczos_run_iterations(h, &Solver::trampoline, dot, Bz, z, numberIterations, N, nullptr, &residual);
+#endif
+    if (rc != 0) throw std::runtime_error(uammd_hip_last_error());
+    return residual;
+  }
+  real runIterations(MatrixDot &dot, real *Bv, const real *v, int numberIterations, int N) { return runIterations(&dot, Bv, v, numberIterations, N); }
+  real runIterations(std::function<void(real *, real *)> dot, real *Bv, const real *v, int numberIterations, int N) {
+    auto adaptor = createMatrixDotAdaptor(std::move(dot));
+    return runIterations(&adaptor, Bv, v, numberIterations, N);
+  }
+#if defined(DOUBLE_PRECISION)
+  void setIterationHardLimit(int newLimit) { detail::check(uammd_lanczos_set_iteration_hard_limit_f64(h, newLimit)); }
+  int getLastRunRequiredSteps() { int s = 0; detail::check(uammd_lanczos_get_last_run_required_steps_f64(h, &s)); return s; }
+#else
   void setIterationHardLimit(int newLimit) { detail::check(uammd_lanczos_set_iteration_hard_limit(h, newLimit)); }
   int getLastRunRequiredSteps() { int s = 0; detail::check(uammd_lanczos_get_last_run_required_steps(h, &s)); return s; }
+#endif
 };
 }  // namespace lanczos
 
@@ -2439,6 +3000,7 @@ inline std::vector<real4> initLatticeSC(real3 L, uint N) {
   return pos;
 }
 
+#if !defined(DOUBLE_PRECISION)
 // ---- multi-GPU (new: the reference is single GPU) -----------------------------------------------------------------------------------------
 // One process per GPU.  Rank 0 makes the 128-byte id (Comm::uniqueId) and hands it to the other processes by whatever the program
 // uses to start them (MPI_Bcast, a file, a socket); every process then constructs its Comm after selecting its device.  The ranks form
@@ -2482,6 +3044,7 @@ public:
   void allToAll(const void *send, void *recv, size_t bytesPerPeer, hipStream_t st = 0) { detail::check(uammd_comm_alltoall(h, send, recv, bytesPerPeer, (void *)st)); }
   void allReduceSum(real *buf, int n, hipStream_t st = 0) { detail::check(uammd_comm_allreduce_sum(h, buf, n, (void *)st)); }
 };
+#endif   // !DOUBLE_PRECISION
 
 }  // namespace uammd
 

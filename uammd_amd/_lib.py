@@ -107,6 +107,10 @@ SIGNATURES = {
     "uammd_lanczos_create_f64": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy_f64": (_i, [_vp]),
     "uammd_lanczos_run_f64": (_i, [_vp, MATVEC64, _vp, _vp, _vp, _d, _i, _vp, C.POINTER(_i)]),
+    "uammd_lanczos_run_iterations_f64": (_i, [_vp, MATVEC64, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(_d)]),
+    "uammd_fcm_displacements_thermal_f64": (_i, [_vp, _vp, _vp, _i, _d, _d, _u, _u, _vp, _vp]),
+    "uammd_pse_near_stochastic_f64": (_i, [_vp, _vp, _vp, _i, _d, _d, _u, _u, _d, _vp, _vp, C.POINTER(_i)]),
+    "uammd_convert_f64_to_f32": (_i, [_vp, _vp, C.c_size_t, _vp]),
     "uammd_lanczos_set_iteration_hard_limit_f64": (_i, [_vp, _i]),
     "uammd_lanczos_get_last_run_required_steps_f64": (_i, [_vp, C.POINTER(_i)]),
     "uammd_hip_last_error": (C.c_char_p, []),
@@ -262,6 +266,7 @@ SIGNATURES = {
     "uammd_lanczos_create": (_i, [C.POINTER(_vp)]),
     "uammd_lanczos_destroy": (_i, [_vp]),
     "uammd_lanczos_run": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, C.POINTER(_i)]),
+    "uammd_lanczos_run_iterations": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.POINTER(_f)]),
     "uammd_lanczos_set_iteration_hard_limit": (_i, [_vp, _i]),
     "uammd_lanczos_set_option": (_i, [_vp, C.c_char_p, _i]),
     "uammd_lanczos_set_allreduce": (_i, [_vp, _vp, _vp, _i]),

@@ -470,6 +470,12 @@ __global__ void __launch_bounds__(kBlock) k_iota(int *__restrict__ v, int n) {
 }
 
 template <int BYTES> struct Elem { char b[BYTES]; };
+struct Elem24 { uint2 v[3]; };   // real3 and real4 of the DOUBLE_PRECISION build, moved as 8- / 16-byte words
+struct Elem32 { uint4 v[2]; };
+__global__ void __launch_bounds__(kBlock) k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, size_t count) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < count) out[t] = (float)in[t];
+}
 // thrust::fill over pg->getPropertyIterator(property): zero the members' elements only
 __global__ void __launch_bounds__(kBlock) k_zero_indexed(uint *__restrict__ v, const int *__restrict__ index, int n, int words) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
@@ -978,6 +984,8 @@ int uammd_gather(const void *d_in, const int *d_index, void *d_out, int n, int e
     case 8: hipLaunchKernelGGL(k_gather<uint2>, g, b, 0, st, (const uint2 *)d_in, d_index, (uint2 *)d_out, n); break;
     case 12: hipLaunchKernelGGL(k_gather<Elem<12>>, g, b, 0, st, (const Elem<12> *)d_in, d_index, (Elem<12> *)d_out, n); break;
     case 16: hipLaunchKernelGGL(k_gather<uint4>, g, b, 0, st, (const uint4 *)d_in, d_index, (uint4 *)d_out, n); break;
+    case 24: hipLaunchKernelGGL(k_gather<Elem24>, g, b, 0, st, (const Elem24 *)d_in, d_index, (Elem24 *)d_out, n); break;   // real3, real = double
+    case 32: hipLaunchKernelGGL(k_gather<Elem32>, g, b, 0, st, (const Elem32 *)d_in, d_index, (Elem32 *)d_out, n); break;   // real4, real = double
     default: set_last_error("uammd_gather: unsupported element size %d", elem_bytes); return -1;
   }
   UH_CHECK(hipGetLastError());
@@ -993,6 +1001,8 @@ int uammd_scatter(const void *d_in, const int *d_index, void *d_out, int n, int 
     case 8: hipLaunchKernelGGL(k_scatter<uint2>, g, b, 0, st, (const uint2 *)d_in, d_index, (uint2 *)d_out, n); break;
     case 12: hipLaunchKernelGGL(k_scatter<Elem<12>>, g, b, 0, st, (const Elem<12> *)d_in, d_index, (Elem<12> *)d_out, n); break;
     case 16: hipLaunchKernelGGL(k_scatter<uint4>, g, b, 0, st, (const uint4 *)d_in, d_index, (uint4 *)d_out, n); break;
+    case 24: hipLaunchKernelGGL(k_scatter<Elem24>, g, b, 0, st, (const Elem24 *)d_in, d_index, (Elem24 *)d_out, n); break;   // real3, real = double
+    case 32: hipLaunchKernelGGL(k_scatter<Elem32>, g, b, 0, st, (const Elem32 *)d_in, d_index, (Elem32 *)d_out, n); break;   // real4, real = double
     default: set_last_error("uammd_scatter: unsupported element size %d", elem_bytes); return -1;
   }
   UH_CHECK(hipGetLastError());
@@ -1082,6 +1092,16 @@ int uammd_celllist_update_gj1(uammd_celllist *hh, float *d_pos, int numberPartic
 
 int uammd_fill_zero(void *d_ptr, size_t bytes, void *stream) {
   UH_CHECK(hipMemsetAsync(d_ptr, 0, bytes, (hipStream_t)stream));
+  return 0;
+}
+
+// positions of a DOUBLE_PRECISION ParticleData rounded to single precision: the keys of ParticleData::sortParticles (a memory-locality
+// order, not a result) come from the single-precision cell list
+int uammd_convert_f64_to_f32(const double *d_in, float *d_out, size_t count, void *stream) {
+  if (count == 0) return 0;
+  if (!d_in || !d_out) { set_last_error("uammd_convert_f64_to_f32: null argument"); return -1; }
+  hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, d_in, d_out, count);
+  UH_CHECK(hipGetLastError());
   return 0;
 }
 

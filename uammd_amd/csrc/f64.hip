@@ -20,6 +20,7 @@
 // single precision by construction and stays that way: `real` = float is UAMMD's default and the benchmarked configuration.
 #include "celllist.hpp"
 #include "ibm.hpp"
+#include "saru.hpp"
 
 #include <rocfft/rocfft.h>
 
@@ -168,12 +169,45 @@ static int check_kernel64(const char *fn, const uammd_ibm_kernel_f64 *k) {
 // ---- Fourier space, FCM (FCM/utils.cuh:27-74, FCM_impl.cuh:375-397) and PSE far field (FarField.cuh:53-158) ------------------------------
 struct Pse64 { double rh, split, eta, shear; bool on; };
 
-__global__ void __launch_bounds__(256) k_kspace64(double2 *__restrict__ g0, size_t planeC, int3 nk, real3d L, double viscosity, Pse64 pse) {
+// ---- Fourier noise (FCM_impl.cuh:437-512, FarField.cuh:235-308) in GATHER form, as the single-precision operator does it (fcm.hip:
+// fcm_kspace_node): a node adds its own draw and, on the kx = 0 / Nyquist planes, the conjugate of its partner's regenerated draw —
+// no node is written twice.  The draws are Saru's single-precision Gaussians promoted to double, which is what the reference's
+// DOUBLE_PRECISION build does (FCM/utils.cuh:117-131: make_real2(saru.gf(0, sc))). ----
+struct C3d { double xr, xi, yr, yi, zr, zi; };
+UH_D bool is_nyquist64(int3 c, int3 n) {  // FCM/utils.cuh:133-167
+  const bool X = (c.x == n.x - c.x) && (n.x % 2 == 0), Y = (c.y == n.y - c.y) && (n.y % 2 == 0), Z = (c.z == n.z - c.z) && (n.z % 2 == 0);
+  return (X && c.y == 0 && c.z == 0) || (X && Y && c.z == 0) || (c.x == 0 && Y && c.z == 0) || (X && c.y == 0 && Z) ||
+         (c.x == 0 && c.y == 0 && Z) || (c.x == 0 && Y && Z) || (X && Y && Z);
+}
+UH_D bool noise_skipped64(int id, int3 c, int3 n) {  // FCM_impl.cuh:456-463
+  return id == 0 || (c.x == 0 && c.y == 0 && 2 * c.z >= n.z + 1) || (c.x == 0 && 2 * c.y >= n.y + 1);
+}
+UH_D C3d draw_noise64(double prefactor, uint id, uint seed1, uint seed2, bool nyquist) {
+  Saru rng(id, seed1, seed2);
+  const float sc = (float)(0.707106781186547 * prefactor);
+  const float2 a = rng.gf(0.0f, sc), b = rng.gf(0.0f, sc), c = rng.gf(0.0f, sc);
+  C3d n{a.x, a.y, b.x, b.y, c.x, c.y};
+  if (nyquist) {
+    const double q = 1.41421356237310;
+    n.xr *= q; n.xi = 0.0; n.yr *= q; n.yi = 0.0; n.zr *= q; n.zi = 0.0;
+  }
+  return n;
+}
+UH_D C3d project64(const real3d &dk, double invk2, const C3d &f) {   // (I - dk dk / k^2) f, FCM/utils.cuh:70-74 and FarField.cuh:53-73
+  const double sr = dot3(real3d{f.xr, f.yr, f.zr}, dk) * invk2, si = dot3(real3d{f.xi, f.yi, f.zi}, dk) * invk2;
+  return C3d{fma(-dk.x, sr, f.xr), fma(-dk.x, si, f.xi), fma(-dk.y, sr, f.yr), fma(-dk.y, si, f.yi), fma(-dk.z, sr, f.zr), fma(-dk.z, si, f.zi)};
+}
+
+// One thread per Fourier node, in place: forceFourier2Vel (FCM_impl.cuh:375-397 / FarField.cuh:137-158) when the grid holds transformed
+// forces, plus the noise when noisePrefactor != 0.
+__global__ void __launch_bounds__(256) k_kspace64(double2 *__restrict__ g0, size_t planeC, int3 nk, real3d L, double viscosity, Pse64 pse,
+                                                  bool haveForce, double noisePrefactor, uint seed1, uint seed2) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int nkx = nk.x / 2 + 1;
   const size_t total = (size_t)nk.z * nk.y * nkx;
   if (t >= total) return;
-  int3 ik = make_int3((int)(t % nkx), (int)((t / nkx) % nk.y), (int)(t / ((size_t)nkx * nk.y)));  // indexToWaveNumber
+  const int3 cell = make_int3((int)(t % nkx), (int)((t / nkx) % nk.y), (int)(t / ((size_t)nkx * nk.y)));
+  int3 ik = cell;  // indexToWaveNumber
   ik.x -= nk.x * (ik.x >= nkx);
   ik.y -= nk.y * (ik.y >= (nk.y / 2 + 1));
   ik.z -= nk.z * (ik.z >= (nk.z / 2 + 1));
@@ -182,9 +216,13 @@ __global__ void __launch_bounds__(256) k_kspace64(double2 *__restrict__ g0, size
   if (t == 0) { g0[0] = zero; g1[0] = zero; g2[0] = zero; return; }
   const double twopi = 2.0 * 3.14159265358979323846;
   const real3d k{(twopi / L.x) * (double)ik.x, (twopi / L.y) * (double)ik.y, (twopi / L.z) * (double)ik.z};
-  const double2 fx = g0[t], fy = g1[t], fz = g2[t];
-  if (pse.on) {  // forceFourier2Vel of the far field: project(B f) with the sheared wave vector, no Nyquist zeroing
-    const double k2 = dot3(k, k);
+  const double k2 = dot3(k, k);
+  C3d v{0, 0, 0, 0, 0, 0};
+  double Bsq;       // sqrt of the operator's scalar, for the noise
+  real3d pk;        // the vector the projector is built from
+  double invp2;
+  bool noiseAfterProjection;   // PSE: sqrt(B) multiplies the PROJECTED draw (FarField.cuh:286-290); FCM: the draw, then the projection
+  if (pse.on) {
     real3d kE = k;
     kE.y = fma(-pse.shear, k.x, k.y);
     const double kE2 = dot3(kE, kE);
@@ -195,24 +233,54 @@ __global__ void __launch_bounds__(256) k_kspace64(double2 *__restrict__ g0, size
     const double hashimoto = (1.0 + kEw) * exp(tau) / kE2;
     double B = sink * sink * invk2 * hashimoto / (viscosity * pse.rh * pse.rh);
     B /= (double)nk.x * (double)nk.y * (double)nk.z;
-    const real3d re{fx.x * B, fy.x * B, fz.x * B}, im{fx.y * B, fy.y * B, fz.y * B};
-    const double kfr = dot3(kE, re) * invk2, kfi = dot3(kE, im) * invk2;
-    g0[t] = make_double2(fma(-kE.x, kfr, re.x), fma(-kE.x, kfi, im.x));
-    g1[t] = make_double2(fma(-kE.y, kfr, re.y), fma(-kE.y, kfi, im.y));
-    g2[t] = make_double2(fma(-kE.z, kfr, re.z), fma(-kE.z, kfi, im.z));
-    return;
+    if (haveForce) {
+      const double2 fx = g0[t], fy = g1[t], fz = g2[t];
+      v = project64(kE, invk2, C3d{fx.x * B, fx.y * B, fy.x * B, fy.y * B, fz.x * B, fz.y * B});
+    }
+    Bsq = sqrt(B); pk = kE; invp2 = invk2; noiseAfterProjection = true;
+  } else {
+    // getGradientFourier: unpaired (Nyquist) components are zero in the projector (FCM/utils.cuh:41-51)
+    const real3d dk{ik.x == (nk.x - ik.x) ? 0.0 : k.x, ik.y == (nk.y - ik.y) ? 0.0 : k.y, ik.z == (nk.z - ik.z) ? 0.0 : k.z};
+    const double invk2 = 1.0 / k2;
+    if (haveForce) {
+      const double2 fx = g0[t], fy = g1[t], fz = g2[t];
+      const double B = 1.0 / (viscosity * k2);
+      const double sc = B / ((double)nk.x * (double)nk.y * (double)nk.z);  // the FFT normalisation lives here (FCM_impl.cuh:392)
+      const C3d pr = project64(dk, invk2, C3d{fx.x, fx.y, fy.x, fy.y, fz.x, fz.y});
+      v = C3d{pr.xr * sc, pr.xi * sc, pr.yr * sc, pr.yi * sc, pr.zr * sc, pr.zi * sc};
+    }
+    Bsq = sqrt(1.0 / (k2 * viscosity)); pk = dk; invp2 = invk2; noiseAfterProjection = false;
   }
-  const double k2 = dot3(k, k);
-  // getGradientFourier: unpaired (Nyquist) components are zero in the projector (FCM/utils.cuh:41-51)
-  const real3d dk{ik.x == (nk.x - ik.x) ? 0.0 : k.x, ik.y == (nk.y - ik.y) ? 0.0 : k.y, ik.z == (nk.z - ik.z) ? 0.0 : k.z};
-  const double invk2 = 1.0 / k2;
-  const real3d dki{dk.x * invk2, dk.y * invk2, dk.z * invk2};
-  const double sr = dot3(real3d{fx.x, fy.x, fz.x}, dki), si = dot3(real3d{fx.y, fy.y, fz.y}, dki);
-  const double B = 1.0 / (viscosity * k2);
-  const double sc = B / ((double)nk.x * (double)nk.y * (double)nk.z);  // the FFT normalisation lives here (FCM_impl.cuh:392)
-  g0[t] = make_double2(fma(-dk.x, sr, fx.x) * sc, fma(-dk.x, si, fx.y) * sc);
-  g1[t] = make_double2(fma(-dk.y, sr, fy.x) * sc, fma(-dk.y, si, fy.y) * sc);
-  g2[t] = make_double2(fma(-dk.z, sr, fz.x) * sc, fma(-dk.z, si, fz.y) * sc);
+  if (noisePrefactor != 0.0) {
+    const int id = (int)t;
+    const bool own = !noise_skipped64(id, cell, nk);
+    int idp = -1;   // conjugate partner: only stored (and only written by the reference) on the kx == 0 / kx == nx - kx planes
+    if (cell.x == 0 || cell.x == nk.x - cell.x) {
+      const int3 pc = make_int3(cell.x, (cell.y > 0) * (nk.y - cell.y), (cell.z > 0) * (nk.z - cell.z));
+      const int cand = pc.x + nkx * (pc.y + pc.z * nk.y);
+      if (cand != id && !noise_skipped64(cand, pc, nk) && !is_nyquist64(pc, nk)) idp = cand;
+    }
+    auto shaped = [&](C3d f) -> C3d {
+      if (noiseAfterProjection) {
+        const C3d z = project64(pk, invp2, f);
+        return C3d{z.xr * Bsq, z.xi * Bsq, z.yr * Bsq, z.yi * Bsq, z.zr * Bsq, z.zi * Bsq};
+      }
+      return project64(pk, invp2, C3d{f.xr * Bsq, f.xi * Bsq, f.yr * Bsq, f.yi * Bsq, f.zr * Bsq, f.zi * Bsq});
+    };
+    C3d mine{0, 0, 0, 0, 0, 0}, theirs = mine;
+    if (own) mine = shaped(draw_noise64(noisePrefactor, (uint)id, seed1, seed2, is_nyquist64(cell, nk)));
+    if (idp >= 0) {
+      C3d f = draw_noise64(noisePrefactor, (uint)idp, seed1, seed2, false);
+      f.xi = -f.xi; f.yi = -f.yi; f.zi = -f.zi;
+      theirs = shaped(f);
+    }
+    const C3d first = (idp >= 0 && idp < id) ? theirs : mine, second = (idp >= 0 && idp < id) ? mine : theirs;   // (a sequential sweep's order)
+    v.xr += first.xr; v.xi += first.xi; v.yr += first.yr; v.yi += first.yi; v.zr += first.zr; v.zi += first.zi;
+    v.xr += second.xr; v.xi += second.xi; v.yr += second.yr; v.yi += second.yi; v.zr += second.zr; v.zi += second.zi;
+  }
+  g0[t] = make_double2(v.xr, v.xi);
+  g1[t] = make_double2(v.yr, v.yi);
+  g2[t] = make_double2(v.zr, v.zi);
 }
 
 struct FCM64 {
@@ -318,7 +386,7 @@ __global__ void __launch_bounds__(128) k_pse_near64(const double *__restrict__ p
 }
 
 struct PSENear64 {
-  DeviceBuffer table;
+  DeviceBuffer table, noise;
   int nPointsTable = 0;
   double rcut = 0, L[3] = {0, 0, 0};
 };
@@ -427,30 +495,52 @@ int uammd_fcm_destroy_f64(uammd_fcm_f64 *h) {
   delete reinterpret_cast<FCM64 *>(h);
   return 0;
 }
-// FCM_impl::computeHydrodynamicDisplacements (FCM_impl.cuh:652-693) at T = 0: d_velocity real3[N] = M F (overwritten; a PSE far-field
-// handle ADDS, as FarField does).  d_pos / d_force real4[N].
-int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int N, double *d_velocity, void *stream) {
-  if (!h || (N > 0 && (!d_pos || !d_force || !d_velocity))) { set_last_error("uammd_fcm_displacements_f64: null argument"); return -1; }
+// FCM_impl::computeHydrodynamicDisplacements (FCM_impl.cuh:652-693) / FarField::computeHydrodynamicDisplacements (FarField.cuh:569-589):
+// d_velocity real3[N] = M F + prefactor sqrt(2 T M) dW (overwritten; a PSE far-field handle ADDS, as FarField does).  d_pos / d_force
+// real4[N]; d_force may be NULL (noise only: deterministicPart of FarField.cuh:451-467).  seed1 / seed2 key the Fourier noise as
+// Saru(node, seed1, seed2).
+int uammd_fcm_displacements_thermal_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int N, double temperature, double prefactor,
+                                        unsigned int seed1, unsigned int seed2, double *d_velocity, void *stream) {
+  if (!h || (N > 0 && (!d_pos || !d_velocity))) { set_last_error("uammd_fcm_displacements_thermal_f64: null argument"); return -1; }
   if (N <= 0) return 0;
   FCM64 *f = reinterpret_cast<FCM64 *>(h);
   hipStream_t st = (hipStream_t)stream;
   double *g = (double *)f->gridBuf.ptr;
   const FastDiv dsx = make_fastdiv(f->kern.support.x), dsxy = make_fastdiv(f->kern.support.x * f->kern.support.y);
   const dim3 gp((N + 3) / 4), bp(256);
-  UH_CHECK(hipMemsetAsync(g, 0, sizeof(double) * 3 * f->planeReal, st));
-  hipLaunchKernelGGL((k_ibm64<3, true>), gp, bp, 0, st, d_pos, 4, d_force, 4, (double *)nullptr, g, N, f->grid, f->nxpad, (size_t)1, f->planeReal,
-                     f->kern, dsx, dsxy, false, false);
+  const bool thermal = temperature > 0.0 && prefactor != 0.0;
+  if (!d_force && !thermal) {   // nothing to add: M 0 = 0
+    if (!f->accumulate) UH_CHECK(hipMemsetAsync(d_velocity, 0, sizeof(double) * 3 * (size_t)N, st));
+    return 0;
+  }
   UH_ROCFFT64(rocfft_execution_info_set_stream(f->info, st));
   void *bufs[1] = {g};
-  UH_ROCFFT64(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+  if (d_force) {
+    UH_CHECK(hipMemsetAsync(g, 0, sizeof(double) * 3 * f->planeReal, st));
+    hipLaunchKernelGGL((k_ibm64<3, true>), gp, bp, 0, st, d_pos, 4, d_force, 4, (double *)nullptr, g, N, f->grid, f->nxpad, (size_t)1, f->planeReal,
+                       f->kern, dsx, dsxy, false, false);
+    UH_ROCFFT64(rocfft_execute(f->fwd, bufs, nullptr, f->info));
+  }
+  double noisePrefactor = 0.0;
+  if (thermal) {
+    const double dV = f->grid.cellVolume;
+    const double fourierNormalization = 1.0 / ((double)f->grid.cellDim.x * f->grid.cellDim.y * f->grid.cellDim.z);
+    noisePrefactor = f->pse.on ? prefactor * std::sqrt(2 * temperature / dV)                             // FarField.cuh:503: the 1 / N lives in B
+                               : prefactor * std::sqrt(fourierNormalization * 2 * temperature / dV);    // FCM_impl.cuh:527-530
+  }
   const size_t total = f->planeCplx;
   hipLaunchKernelGGL(k_kspace64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (double2 *)g, f->planeCplx, f->grid.cellDim,
-                     real3d{f->L[0], f->L[1], f->L[2]}, f->viscosity, f->pse);
+                     real3d{f->L[0], f->L[1], f->L[2]}, f->viscosity, f->pse, d_force != nullptr, noisePrefactor, seed1, seed2);
   UH_ROCFFT64(rocfft_execute(f->inv, bufs, nullptr, f->info));
   hipLaunchKernelGGL((k_ibm64<3, false>), gp, bp, 0, st, d_pos, 4, (const double *)nullptr, 3, d_velocity, g, N, f->grid, f->nxpad, (size_t)1,
                      f->planeReal, f->kern, dsx, dsxy, false, !f->accumulate);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+// the deterministic part alone (T = 0)
+int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int N, double *d_velocity, void *stream) {
+  if (N > 0 && !d_force) { set_last_error("uammd_fcm_displacements_f64: null argument"); return -1; }
+  return uammd_fcm_displacements_thermal_f64(h, d_pos, d_force, N, 0.0, 0.0, 0u, 0u, d_velocity, stream);
 }
 
 // ---- PSE (Integrator/BDHI/PSE) ------------------------------------------------------------------------------------------------------------
@@ -550,6 +640,41 @@ int uammd_pse_near_mdot_f64(uammd_pse_near_f64 *h, const double *d_pos, const do
                      real3d{p->L[0], p->L[1], p->L[2]}, p->rcut, (const double2 *)p->table.ptr, p->nPointsTable - 1, d_MF, false);
   UH_CHECK(hipGetLastError());
   return 0;
+}
+
+// NearField::computeStochasticDisplacements (NearField.cuh:255-284): d_BdW real3[N] = sqrt(M_near) dW * prefactor sqrt(2 T) — the Lanczos
+// result OVERWRITES d_BdW, as lanczos->run does there — noise = SaruTransform (:218-228) keyed (particle, seed1, seed2), the solver's
+// tolerance the near field's.  `solver` is the caller's lanczos handle (kept between steps for its adaptive check schedule).
+static int pse_near64_dot(void *ctx, const double *d_v, double *d_Mv, int n, void *stream) {
+  struct Ctx { PSENear64 *p; const double *pos; };
+  const Ctx *c = static_cast<const Ctx *>(ctx);
+  const int N = n / 3;
+  hipLaunchKernelGGL(k_pse_near64, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->pos, d_v, 3, N,
+                     real3d{c->p->L[0], c->p->L[1], c->p->L[2]}, c->p->rcut, (const double2 *)c->p->table.ptr, c->p->nPointsTable - 1, d_Mv, true);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+__global__ void __launch_bounds__(256) k_pse_noise64(double *__restrict__ out3, int N, double variance, uint seed1, uint seed2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  Saru rng((uint)i, seed1, seed2);
+  const float2 a = rng.gf(0.0f, 1.0f);
+  const float2 b = rng.gf(0.0f, 1.0f);
+  out3[3 * (size_t)i] = (double)a.x * variance;
+  out3[3 * (size_t)i + 1] = (double)a.y * variance;
+  out3[3 * (size_t)i + 2] = (double)b.x * variance;
+}
+int uammd_pse_near_stochastic_f64(uammd_pse_near_f64 *h, uammd_lanczos_f64 *solver, const double *d_pos, int N, double temperature, double prefactor,
+                                  unsigned int seed1, unsigned int seed2, double tolerance, double *d_BdW, void *stream, int *iterations) {
+  if (iterations) *iterations = 0;
+  if (!h || !solver || (N > 0 && (!d_pos || !d_BdW))) { set_last_error("uammd_pse_near_stochastic_f64: null argument"); return -1; }
+  if (temperature == 0.0 || N <= 0) return 0;
+  PSENear64 *p = reinterpret_cast<PSENear64 *>(h);
+  if (int e = p->noise.reserve(sizeof(double) * 3 * (size_t)N)) return e;
+  hipLaunchKernelGGL(k_pse_noise64, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double *)p->noise.ptr, N,
+                     prefactor * std::sqrt(2 * temperature), seed1, seed2);
+  UH_CHECK(hipGetLastError());
+  struct Ctx { PSENear64 *p; const double *pos; } ctx{p, d_pos};
+  return uammd_lanczos_run_f64(solver, &pse_near64_dot, &ctx, d_BdW, (const double *)p->noise.ptr, tolerance, 3 * N, stream, iterations);
 }
 
 }  // extern "C"

@@ -958,6 +958,106 @@ static int lanczos_run(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *
 }
 
 
+// Solver::runIterations (misc/LanczosAlgorithm/LanczosAlgorithm.cu:183-200): exactly numberIterations Lanczos steps, no convergence test;
+// the estimate after the last-but-one step becomes "the previous estimate", the estimate after the last step is the result, and the
+// return value (in *residual) is eq. 27's |Bz_m - Bz_(m-1)| / |Bz_(m-1)| between the two (inf / NaN with a single iteration: there is
+// no previous estimate — as in the reference).  The plain four-launch iteration; the two estimates through the host's QL.
+template <class T, class MatVec>
+static int lanczos_run_iterations(LanczosT<T> *L, MatVec dot, void *ctx, T *d_Bv, const T *d_v, int numberIterations, int n, void *stream,
+                                  T *residual) {
+  if (!L || !dot || !d_Bv || !d_v || n < 1 || numberIterations < 1) { set_last_error("uammd_lanczos_run_iterations: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const int cap = std::max(L->iterationHardLimit, numberIterations) + 2;
+  if (L->capCols < cap || L->capN < n) {
+    UH_CHECK(hipStreamSynchronize(st));
+    if (int e = L->V.reserve(sizeof(T) * (size_t)n * cap)) return e;
+    if (int e = L->w.reserve(sizeof(T) * (size_t)n)) return e;
+    if (int e = L->Bold.reserve(sizeof(T) * (size_t)n)) return e;
+    if (int e = L->parts.reserve(sizeof(T) * 2 * kLParts * kLBatch)) return e;
+    if (int e = L->scal.reserve(sizeof(T) * (2 * cap + 2))) return e;
+    if (int e = L->ycoef.reserve(sizeof(T) * std::max(cap, kLBatch * kLDevM))) return e;
+    L->capCols = cap;
+    L->capN = n;
+  }
+  if (!L->partsB.ptr) { if (int e = L->partsB.reserve(sizeof(T) * kLParts)) return e; }
+  T *V = (T *)L->V.ptr, *w = (T *)L->w.ptr, *Bold = (T *)L->Bold.ptr, *parts = (T *)L->parts.ptr, *partsB = (T *)L->partsB.ptr;
+  T *scal = (T *)L->scal.ptr, *ycoef = (T *)L->ycoef.ptr;
+  // (scal = [|z|, hdiag[capCols], hsup[capCols]] with the stride of the handle's capacity, which run() may have made larger than cap)
+  const int stride = L->capCols;
+  T *hdiag = scal + 1, *hsup = scal + 1 + stride;
+  const int g = lgrid(n);
+  const int np = L->reduce ? 1 : g;
+  auto complete = [&](T *p) -> int {
+    if (!L->reduce) return 0;
+    hipLaunchKernelGGL(k_l_collapse<T>, dim3(1), dim3(kLB), 0, st, p, g);
+    return L->reduce(L->reduceCtx, (float *)p, 1, stream);
+  };
+  L->zparts = nullptr;
+  L->znp = 0;
+  UH_CHECK(hipMemsetAsync(Bold, 0, sizeof(T) * (size_t)n, st));
+  hipLaunchKernelGGL(k_l_norm2<T>, dim3(g), dim3(kLB), 0, st, d_v, n, parts);
+  if (int rc = complete(parts)) return rc;
+  hipLaunchKernelGGL(k_l_first<T>, dim3(g), dim3(kLB), 0, st, d_v, n, (const T *)parts, np, V, scal);
+  std::vector<T> hbuf(2 * (size_t)stride + 2), yy;
+  std::vector<double> dd, ee, zz;
+  T err = T(0);
+  for (int i = 0; i < numberIterations; ++i) {
+    T *vi = V + (size_t)i * n;
+    if (int rc = dot(ctx, vi, w, n, stream)) {
+      if (!uammd_hip_last_error()[0]) set_last_error("uammd_lanczos_run_iterations: the matrix-vector callback failed (%d)", rc);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_l_a<T>, dim3(g), dim3(kLB), 0, st, w, i > 0 ? (const T *)(V + (size_t)(i - 1) * n) : nullptr, (const T *)vi, n,
+                       i > 0 ? (const T *)(hsup + i - 1) : nullptr, parts);
+    if (int rc = complete(parts)) return rc;
+    hipLaunchKernelGGL(k_l_b<T>, dim3(g), dim3(kLB), 0, st, w, (const T *)vi, n, (const T *)parts, np, hdiag + i, partsB, (T *)nullptr);
+    if (int rc = complete(partsB)) return rc;
+    hipLaunchKernelGGL(k_l_c<T>, dim3(g), dim3(kLB), 0, st, (const T *)w, n, (const T *)partsB, np, (const T *)(hdiag + i), (const T *)scal,
+                       hsup + i, V + (size_t)(i + 1) * n, L->ownsFirstElement);
+    if (i < numberIterations - 2) continue;
+    const int m = i + 1;   // computeCurrentResultEstimation with the Krylov space of this iteration
+    UH_CHECK(hipMemcpyAsync(hbuf.data(), scal, sizeof(T) * (2 * (size_t)stride + 1), hipMemcpyDeviceToHost, st));
+    UH_CHECK(hipStreamSynchronize(st));
+    dd.assign(m, 0.0);
+    ee.assign(m, 0.0);
+    zz.assign((size_t)m * m, 0.0);
+    for (int k = 0; k < m; ++k) { dd[k] = hbuf[1 + k]; zz[(size_t)k * m + k] = 1.0; }
+    for (int k = 0; k + 1 < m; ++k) ee[k] = hbuf[1 + stride + k];
+    if (int info = tridiag_ql(dd, ee, zz, m)) {
+      set_last_error("[Lanczos] Could not diagonalize tridiagonal krylov matrix, steqr failed with code %d", info);
+      return -20;
+    }
+    yy.assign(m, T(0));
+    for (int r = 0; r < m; ++r) {
+      double sacc = 0.0;
+      for (int j = 0; j < m; ++j) sacc += zz[(size_t)r * m + j] * std::sqrt(dd[j]) * zz[j];
+      yy[r] = (T)sacc;
+    }
+    UH_CHECK(hipMemcpyAsync(ycoef, yy.data(), sizeof(T) * m, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_l_estimate<T>, dim3(g), dim3(kLB), 0, st, (const T *)V, n, m, (const T *)ycoef, (const T *)scal, d_Bv, Bold, parts);
+    if (i == numberIterations - 1) {   // computeError: against the estimate of the step before (zero when there was none)
+      if (int rc = complete(parts)) return rc;
+      if (int rc = complete(parts + kLParts)) return rc;
+      std::vector<T> hp(2 * kLParts);
+      UH_CHECK(hipMemcpyAsync(hp.data(), parts, sizeof(T) * 2 * kLParts, hipMemcpyDeviceToHost, st));
+      UH_CHECK(hipStreamSynchronize(st));
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < np; ++k) { a += hp[k]; b += hp[kLParts + k]; }
+      err = (T)std::fabs(std::sqrt(b) / std::sqrt(a));
+      if (std::isnan(err)) {
+        set_last_error("[Lanczos] Unknown error (found NaN in result guess) at iteration %d", numberIterations);
+        return -21;
+      }
+    } else {
+      UH_CHECK(hipStreamSynchronize(st));   // (yy is reused by the next estimate: its upload must have left the host)
+    }
+  }
+  UH_CHECK(hipGetLastError());
+  if (residual) *residual = err;
+  return 0;
+}
+
+
 extern "C" {
 
 int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, float tolerance, int n, void *stream,
@@ -984,6 +1084,15 @@ int uammd_lanczos_run(uammd_lanczos *hh, uammd_matvec_fn dot, void *ctx, float *
     }
   }
   return rc;
+}
+
+int uammd_lanczos_run_iterations(uammd_lanczos *h, uammd_matvec_fn dot, void *ctx, float *d_Bv, const float *d_v, int numberIterations, int n,
+                                 void *stream, float *residual) {
+  return lanczos_run_iterations<float>(reinterpret_cast<Lanczos *>(h), dot, ctx, d_Bv, d_v, numberIterations, n, stream, residual);
+}
+int uammd_lanczos_run_iterations_f64(uammd_lanczos_f64 *h, uammd_matvec_fn_f64 dot, void *ctx, double *d_Bv, const double *d_v,
+                                     int numberIterations, int n, void *stream, double *residual) {
+  return lanczos_run_iterations<double>(reinterpret_cast<LanczosT<double> *>(h), dot, ctx, d_Bv, d_v, numberIterations, n, stream, residual);
 }
 
 // ---- DOUBLE_PRECISION build (global/defines.h:9-11): lanczos::Solver with real = double, e.g. the reference's own test
