@@ -759,24 +759,37 @@ def preflight(hip, args, world, rank, dist):
     return report
 
 
-def run_lj_distributed(hip, args, world, rank, dist):
-    """N > 1 (or --force-distributed): z-slab domain decomposition, one slab of `--particles` particles per rank
-    (weak scaling: the global box grows along z), halo exchange + migration over torch.distributed P2P."""
+def run_lj_distributed(hip, args, world, rank, dist, strong=False):
+    """N > 1 (or --force-distributed): z-slab domain decomposition, halo exchange + migration through the run's communicator.
+    weak (default): one slab of `--particles` particles per rank, the global box L x L x N L grows along z with N.
+    strong: the ONE box of `--particles` particles (BASELINE's "LJ 1e6": L = 107.72, 43 planes of cells) cut into N slabs of L / N —
+    5.4 planes of cells per rank at N = 8, of which 2 are halo on either side: the harder and the named case."""
     import ctypes as C
     from uammd_amd._lib import check, load
     from uammd_amd.parallel import DistributedLJ, SlabDecomposition
     lib = load()
-    n = args.particles
-    L1 = 107.7217345 * (n / 1_000_000) ** (1.0 / 3.0)
+    n_total = args.particles * (1 if strong else world)
+    L1 = 107.7217345 * (args.particles / 1_000_000) ** (1.0 / 3.0)
     rc, dt, T = 2.5, 0.005, 1.0
     noise = math.sqrt(2 * dt * 1.0 * T)
     # cached exchange: skin 0.6 sigma, ownership + halo lists refreshed every 20 steps; DistributedLJ.check_skin() verifies after the
     # run that no particle out-ran the skin between two refreshes
-    d = SlabDecomposition([L1, L1, L1 * world], rc, rank, world, skin=args.skin, comm=ABI_COMM)
-    pos = torch.from_numpy(lattice(n, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
+    d = SlabDecomposition([L1, L1, L1 if strong else L1 * world], rc, rank, world, skin=args.skin, comm=ABI_COMM)
+    if strong:
+        # every rank makes the same lattice of the whole box and keeps the sites of its slab (global ids = lattice sites)
+        allpos = lattice(args.particles, L1, 1234)
+        mine = np.nonzero((allpos[:, 2] >= d.zlo) & (allpos[:, 2] < d.zhi))[0]
+        local = allpos[mine].copy()
+        local[:, 2] -= d.zc
+        pos = torch.from_numpy(np.ascontiguousarray(local)).cuda()
+        ids = torch.from_numpy(mine.astype(np.int32)).cuda()
+        del allpos
+    else:
+        pos = torch.from_numpy(lattice(args.particles, L1, 1234 + rank)).cuda()          # local frame: z' in [-L1/2, L1/2)
+        ids = torch.arange(args.particles, dtype=torch.int32, device="cuda") + rank * args.particles
+    n = int(pos.shape[0])
     vel = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     check(lib.uammd_verletnvt_initial_velocities(C.c_void_p(vel.data_ptr()), None, math.sqrt(3 * T), 0, n, 77 + rank, None))
-    ids = torch.arange(n, dtype=torch.int32, device="cuda") + rank * n
     pot = hip.Potential.LJ()
     pot.setPotParameters(0, 0, pot.InputPairParameters(rc, 1.0, 1.0, False))
     cl = hip.CellList()
@@ -906,13 +919,13 @@ def run_lj_distributed(hip, args, world, rank, dist):
         el = _allreduce(dist, [el], "MAX")[0]
         total = _allreduce(dist, [total], "SUM")[0]
     assert torch.isfinite(pos).all()
-    assert abs(total - n * world) < 0.5, "particles were lost or duplicated in migration"
+    assert abs(total - n_total) < 0.5, "particles were lost or duplicated in migration"
     sim.check_skin()
     if sim.max_drift is not None:   # (how much of the skin the timed region used: the cached exchange is exact while this stays below it)
         SLAB_STEP["largest_displacement_between_refreshes"] = float(sim.max_drift)
     tot, cnt = cl.profile_read()
     k_ms = tot / max(cnt, 1)
-    return n * world * args.steps / el, el / args.steps * 1e3, k_ms, L1
+    return n_total * args.steps / el, el / args.steps * 1e3, k_ms, L1
 
 
 def main():
@@ -1120,6 +1133,17 @@ def main():
             "roofline": {"bound": "valu", "kernel": "LJ traversal (k_lj_tile4), owned + ghost particles",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
+        if world > 1 and os.environ.get("UAMMD_BENCH_NO_STRONG") != "1":
+            # the STRONG-scaling line beside the weak headline: BASELINE's one 1e6 box over the N GPUs (at N = 1 it IS the single-domain line)
+            _settle()
+            sv, sms, sk, _ = run_lj_distributed(hip, args, world, rank, dist, strong=True)
+            width = L1 / world
+            out["lj_strong"] = {"value": sv, "unit": "particle-steps/s", "ms_per_step": sms, "scaling": "strong", "n_gpus": world,
+                                "particles_total": n, "particles_per_gpu": n / world, "box": [L1, L1, L1], "slab_width": width,
+                                "cell_planes_per_gpu": width / 2.5, "halo_fraction": 2 * (2.5 + 3 * args.skin) / width,
+                                "kernel_ms": sk, "steps": args.steps,
+                                "workload": f"LJ NVT: the ONE box of {n} particles (rho*=0.8, L = {L1:.4f}) cut into {world} z slabs; "
+                                            "same step, halo and migration code as the weak line"}
         if args.workload == "both":
             out["fcm"] = run_fcm_distributed(hip, args, world, rank, dist)
             out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)

@@ -249,3 +249,28 @@ def test_fcm_slab_processes_match_single_gpu(hip, world, tmp_path):
     for k in range(3):
         err = np.linalg.norm(got[k] - v_ref[k]) / np.linalg.norm(v_ref[k])
         assert err <= 1e-5, (k, err)                                                       # (ii)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_strong_scaling_line_on_one_device(world):
+    """bench.py --gpus N with every rank on cuda:0 (gloo, host-staged messages): the launcher, the preflight and BOTH LJ lines — the weak
+    headline (one slab of --particles per rank) and the strong one (the ONE box of --particles cut into N slabs: BASELINE's "LJ 1e6 ...
+    1/2/4/8 GPU" read literally) — run to the end, conserve the particles (asserted inside bench.py) and report consistent sizes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UAMMD_BENCH_SAME_DEVICE="1", UAMMD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    n = 131072
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--workload", "lj", "--particles", str(n), "--steps", "40",
+                        "--warmup", "10", "--equilibrate", "60", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" not in line, line
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["config"]["particles_per_gpu"] == n
+    strong = line["lj_strong"]
+    assert strong["scaling"] == "strong" and strong["particles_total"] == n and strong["n_gpus"] == world
+    L = 107.7217345 * (n / 1e6) ** (1 / 3)
+    assert abs(strong["slab_width"] - L / world) < 1e-6 and strong["value"] > 0 and strong["ms_per_step"] > 0
