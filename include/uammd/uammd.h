@@ -1558,44 +1558,126 @@ public:
 };
 }  // namespace VerletNVT
 
-// ---- BD::EulerMaruyama -------------------------------------------------------------------------------------------------------------------
+// ---- BD: Brownian dynamics without hydrodynamic interactions (Integrator/BrownianDynamics.cuh:57-183, .cu) ------------------------------------
 namespace BD {
 struct Parameters {
-  std::vector<real3> K;
+  std::vector<real3> K = std::vector<real3>(3, real3());   // shear matrix, row by row
   real temperature = 0, viscosity = 1.0, hydrodynamicRadius = -1.0, dt = 0.0;
   bool is2D = false;
 };
-class EulerMaruyama : public Integrator {
+// what the four schemes share (BrownianDynamics.cuh:67-110, .cu:9-117): self mobility 1 / (6 pi eta a) — a from the parameters or, when it
+// is left at -1 and the particles carry radii, per particle —, the shear matrix, the seed (third draw of the System generator), forces
+class BaseBrownianIntegrator : public Integrator {
 public:
   using Parameters = BD::Parameters;
-private:
-  Parameters par;
-  real selfMobility;
-  uint seed;
-  int steps = 0;
-  hipStream_t st = 0;
-public:
-  EulerMaruyama(shared_ptr<ParticleGroup> pg, Parameters par) : Integrator(pg, "BD::EulerMaruyama"), par(par) {  // BrownianDynamics.cuh:113-121
+  BaseBrownianIntegrator(shared_ptr<ParticleGroup> pg, Parameters par)
+      : Integrator(pg, "BD::BaseBrownianIntegrator"), temperature(par.temperature), dt(par.dt), is2D(par.is2D) {
+    sys->rng().next32();
+    sys->rng().next32();
     seed = sys->rng().next32();
-    selfMobility = 1.0 / (6.0 * M_PI * par.viscosity);  // BrownianDynamics.cu:12-23
-    if (par.hydrodynamicRadius != real(-1.0)) selfMobility /= par.hydrodynamicRadius;
+    selfMobility = real(1.0 / (6.0 * M_PI * par.viscosity));
+    if (par.hydrodynamicRadius != real(-1.0)) {
+      selfMobility /= par.hydrodynamicRadius;
+      hydrodynamicRadius = par.hydrodynamicRadius;
+    } else if (!pd->isRadiusAllocated()) hydrodynamicRadius = real(1.0);
+    if (par.K.size() == 3)
+      for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
+    for (float k : K) sheared = sheared || k != 0.0f;
   }
-  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}
-  void forwardTime() override {  // BrownianDynamics.cu:146-170
-    steps++;
-    for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
-    if (steps == 1) for (auto &u : updatables) { u->updateTemperature(par.temperature); u->updateTimeStep(par.dt); }
+  BaseBrownianIntegrator(shared_ptr<ParticleData> pd, Parameters par) : BaseBrownianIntegrator(make_shared<ParticleGroup>(pd, "All"), par) {}
+  real sumEnergy() override {   // 3/2 kT to every member's energy (:82-92)
+    auto energy = pd->getEnergy(access::cpu, access::readwrite);
+    auto index = pg->getIndexIterator(access::cpu);
+    for (int k = 0; k < pg->getNumberParticles(); ++k) energy[index[k]] += real(1.5) * temperature;
+    return 0;
+  }
+protected:
+  float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool sheared = false;
+  real selfMobility, hydrodynamicRadius = real(-1.0), temperature, dt;
+  bool is2D;
+  hipStream_t st = 0;
+  int steps = 0;
+  uint seed;
+  void updateInteractors() {   // .cu:77-88
+    for (auto &u : updatables) u->updateSimulationTime(steps * dt);
+    if (steps == 1) for (auto &u : updatables) { u->updateTemperature(temperature); u->updateTimeStep(dt); }
+  }
+  void computeCurrentForces() {   // .cu:90-106
     resetGroupForces(st);
     for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
-    float K[9] = {0};
-    const bool shear = par.K.size() == 3;
-    if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
-    auto radius = (par.hydrodynamicRadius == real(-1.0)) ? pd->getRadiusIfAllocated(access::gpu, access::read) : property_ptr<real>();
+  }
+  // getParticleRadiusIfAvailable (.cu:108-117)
+  property_ptr<real> radiusIfUsed() { return (hydrodynamicRadius == real(-1.0)) ? pd->getRadiusIfAllocated(access::gpu, access::read) : property_ptr<real>(); }
+  // one launch of the library's kernel for the scheme (0 = EulerMaruyama)
+  void advance(int scheme, int substep, real4 *aux, const int *originalIndex) {
+    auto radius = radiusIfUsed();
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto force = pd->getForce(access::gpu, access::read);
-    detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)force.raw(), shear ? K : nullptr, selfMobility,
-                                          radius.raw(), par.dt, par.is2D, par.temperature, groupSize(), (uint)steps, seed,
-                                          (void *)st));
+    if (scheme == 0)
+      detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)force.raw(), sheared ? K : nullptr, selfMobility, radius.raw(), dt,
+                                            is2D, temperature, groupSize(), (uint)steps, seed, (void *)st));
+    else
+      detail::check(uammd_bd_scheme_step(scheme, substep, (float *)pos.raw(), (float *)aux, groupIndex(), originalIndex, (const float *)force.raw(),
+                                         sheared ? K : nullptr, selfMobility, radius.raw(), dt, is2D, temperature, groupSize(), (uint)steps, seed, (void *)st));
+  }
+};
+class EulerMaruyama : public BaseBrownianIntegrator {   // x += dt (K x + M F) + sqrt(2 T M dt) dW (.cu:119-170)
+public:
+  EulerMaruyama(shared_ptr<ParticleGroup> pg, Parameters par) : BaseBrownianIntegrator(pg, par) {}
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}
+  void forwardTime() override {
+    steps++;
+    updateInteractors();
+    computeCurrentForces();
+    advance(0, 0, nullptr, nullptr);
+  }
+};
+class MidPoint : public BaseBrownianIntegrator {   // two force evaluations per step (.cu:172-232)
+  detail::DeviceArray<real4> initialPositions;
+public:
+  MidPoint(shared_ptr<ParticleGroup> pg, Parameters par) : BaseBrownianIntegrator(pg, par) {}
+  MidPoint(shared_ptr<ParticleData> pd, Parameters par) : MidPoint(make_shared<ParticleGroup>(pd, "All"), par) {}
+  void forwardTime() override {
+    steps++;
+    updateInteractors();
+    initialPositions.resize(groupSize());
+    computeCurrentForces();
+    advance(UAMMD_BD_MIDPOINT, 0, initialPositions.d, nullptr);
+    computeCurrentForces();
+    advance(UAMMD_BD_MIDPOINT, 1, initialPositions.d, nullptr);
+  }
+};
+class AdamsBashforth : public BaseBrownianIntegrator {   // forces 3/2 F_n - 1/2 F_(n-1) (.cu:234-308)
+  detail::DeviceArray<real4> previousForces, forceRows;
+  void storeCurrentForces() {   // the members' forces, in the group's order (.cu:248-257)
+    const int N = groupSize();
+    previousForces.resize(N);
+    auto force = pd->getForce(access::gpu, access::read);
+    if (subgroup) detail::check(uammd_gather(force.raw(), groupIndex(), previousForces.d, N, (int)sizeof(real4), (void *)st));
+    else detail::hipCheck(hipMemcpyAsync(previousForces.d, force.raw(), sizeof(real4) * (size_t)N, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+  }
+public:
+  AdamsBashforth(shared_ptr<ParticleGroup> pg, Parameters par) : BaseBrownianIntegrator(pg, par) {}
+  AdamsBashforth(shared_ptr<ParticleData> pd, Parameters par) : AdamsBashforth(make_shared<ParticleGroup>(pd, "All"), par) {}
+  void forwardTime() override {
+    steps++;
+    if (steps == 1) { updateInteractors(); computeCurrentForces(); }
+    storeCurrentForces();
+    updateInteractors();
+    computeCurrentForces();
+    advance(UAMMD_BD_ADAMS_BASHFORTH, 0, previousForces.d, nullptr);
+  }
+};
+class Leimkuhler : public BaseBrownianIntegrator {   // noise (dW_n + dW_(n-1)) / 2 (.cu:310-384)
+public:
+  Leimkuhler(shared_ptr<ParticleGroup> pg, Parameters par) : BaseBrownianIntegrator(pg, par) {}
+  Leimkuhler(shared_ptr<ParticleData> pd, Parameters par) : Leimkuhler(make_shared<ParticleGroup>(pd, "All"), par) {}
+  void forwardTime() override {
+    steps++;
+    updateInteractors();
+    computeCurrentForces();
+    advance(UAMMD_BD_LEIMKUHLER, 0, nullptr, pd->getIdOrderedIndices(access::gpu));
   }
 };
 }  // namespace BD

@@ -280,6 +280,16 @@ int uammd_bd_euler_maruyama(float *d_pos, const int *d_index, const float *d_for
                             int numberParticles, unsigned int stepNum, unsigned int seed, void *stream);
 int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_linearVelocity, int numberParticles,
                              float dt, void *stream);
+/* The other schemes of Integrator/BrownianDynamics.cuh:121-183 / .cu:160-387 — BD::MidPoint (two calls per step: substep 0 after the
+ * first force evaluation, 1 after the second; d_aux real4[N] keeps the step's starting positions), BD::AdamsBashforth (d_aux real4[N] = the
+ * previous step's forces in group order) and BD::Leimkuhler (d_originalIndex = ParticleData::getIdOrderedIndices, nullable = identity).
+ * Arguments as uammd_bd_euler_maruyama.  MidPoint and AdamsBashforth key their noise by the GROUP index, as the reference does. */
+#define UAMMD_BD_MIDPOINT 1
+#define UAMMD_BD_ADAMS_BASHFORTH 2
+#define UAMMD_BD_LEIMKUHLER 3
+int uammd_bd_scheme_step(int scheme, int substep, float *d_pos, float *d_aux, const int *d_index, const int *d_originalIndex, const float *d_force,
+                         const float K[9], float selfMobility, const float *d_radius, float dt, int is2D, float temperature, int numberParticles,
+                         unsigned int stepNum, unsigned int seed, void *stream);
 /* BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113): pos += dt (K pos + MF) + sqrt2Tdt BdW;
  * d_MF, d_BdW real3[N] (d_BdW nullable), K row-major 3x3 (nullable) */
 int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_MF, const float *d_BdW, const float K[9],

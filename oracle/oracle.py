@@ -323,6 +323,25 @@ class Oracle:
                                           _p(radius), self.creal(dt), int(is2D), self.creal(temperature), n,
                                           C.c_uint(step_num), C.c_uint(seed))
 
+    def bd_midpoint(self, step, pos4, initial4, force4, self_mobility, dt, temperature, step_num, seed, K=None, radius=None, index=None, is2D=False):
+        K9 = None if K is None else self.r(K).reshape(9)
+        n = len(pos4) if index is None else len(index)
+        self.lib.oracle_bd_midpoint(int(step), _p(pos4), _p(initial4), _p(index), _p(force4), _p(K9), self.creal(self_mobility), _p(radius),
+                                    self.creal(dt), int(is2D), self.creal(temperature), n, C.c_uint(step_num), C.c_uint(seed))
+
+    def bd_adams_bashforth(self, pos4, previous4, force4, self_mobility, dt, temperature, step_num, seed, K=None, radius=None, index=None, is2D=False):
+        K9 = None if K is None else self.r(K).reshape(9)
+        n = len(pos4) if index is None else len(index)
+        self.lib.oracle_bd_adams_bashforth(_p(pos4), _p(previous4), _p(index), _p(force4), _p(K9), self.creal(self_mobility), _p(radius),
+                                           self.creal(dt), int(is2D), self.creal(temperature), n, C.c_uint(step_num), C.c_uint(seed))
+
+    def bd_leimkuhler(self, pos4, force4, self_mobility, dt, temperature, step_num, seed, K=None, radius=None, index=None, original_index=None,
+                      is2D=False):
+        K9 = None if K is None else self.r(K).reshape(9)
+        n = len(pos4) if index is None else len(index)
+        self.lib.oracle_bd_leimkuhler(_p(pos4), _p(index), _p(original_index), _p(force4), _p(K9), self.creal(self_mobility), _p(radius),
+                                      self.creal(dt), int(is2D), self.creal(temperature), n, C.c_uint(step_num), C.c_uint(seed))
+
     def fcm_euler_maruyama(self, pos4, linear_v3, dt, index=None):
         self.lib.oracle_fcm_euler_maruyama(_p(pos4), _p(index), _p(self.r(linear_v3)), len(pos4), self.creal(dt))
 

@@ -146,6 +146,122 @@ ORACLE_API void oracle_bd_euler_maruyama(real4 *pos, const int *indexIterator, c
   }
 }
 
+/* BD::MidPoint, MidPoint_ns::integrateGPU<step> (BrownianDynamics.cu:178-214).  step 0: half a step of drift from the CURRENT forces plus a
+ * draw of variance T M dt, the starting position kept in initialPositions[id]; step 1: a whole step from the kept position with the forces
+ * at the midpoint, the SAME first draw (the generator is keyed (id, stepNum, seed) both times) and a second one.  The generator is keyed
+ * by the GROUP index id, not the particle index i (:203). */
+ORACLE_API void oracle_bd_midpoint(int step, real4 *pos, real4 *initialPositions, const int *indexIterator, const real4 *force, const real *K9,
+                                   real selfMobility, const real *radius, real dt, int is2D, real temperature, int N, uint stepNum, uint seed) {
+  real3 Kx = mk3(0, 0, 0), Ky = Kx, Kz = Kx;
+  if (K9) { Kx = mk3(K9[0], K9[1], K9[2]); Ky = mk3(K9[3], K9[4], K9[5]); Kz = mk3(K9[6], K9[7], K9[8]); }
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    real3 p;
+    if (step == 0) {
+      p = mk3(pos[i].x, pos[i].y, pos[i].z);
+      initialPositions[id] = pos[i];
+    } else {
+      p = mk3(initialPositions[id].x, initialPositions[id].y, initialPositions[id].z);
+    }
+    const real M = selfMobility * (radius ? ((real)1.0 / radius[i]) : (real)1.0);
+    real3 KR = mk3(dot3(Kx, p), dot3(Ky, p), dot3(Kz, p));
+    real3 f = mk3(force[i].x, force[i].y, force[i].z);
+    if (step == 0) {
+      f.x *= (real)0.5; f.y *= (real)0.5; f.z *= (real)0.5;
+      KR.x *= (real)0.5; KR.y *= (real)0.5; KR.z *= (real)0.5;
+    }
+    p.x = FMA(dt, FMA(M, f.x, KR.x), p.x);
+    p.y = FMA(dt, FMA(M, f.y, KR.y), p.y);
+    p.z = FMA(dt, FMA(M, f.z, KR.z), p.z);
+    if (temperature > (real)0.0) {
+      const real B = SQRT(temperature * M * dt);
+      Saru rng = saru3((uint)id, stepNum, seed);
+      real3 dW;
+      real tmp;
+      gf_real(&rng, 0, B, &dW.x, &dW.y);
+      gf_real(&rng, 0, B, &dW.z, &tmp);
+      p.x += dW.x; p.y += dW.y; p.z += dW.z;
+      if (step == 1) {
+        gf_real(&rng, 0, B, &dW.x, &dW.y);
+        gf_real(&rng, 0, B, &dW.z, &tmp);
+        p.x += dW.x; p.y += dW.y; p.z += dW.z;
+      }
+    }
+    pos[i].x = p.x;
+    pos[i].y = p.y;
+    if (!is2D) pos[i].z = p.z;
+  }
+}
+
+/* BD::AdamsBashforth, AdamsBashforth_ns::integrateGPU (BrownianDynamics.cu:262-289): x += dt (K x + M (3/2 F_n - 1/2 F_(n-1))) + sqrt(2 T M dt) dW,
+ * previousForces in GROUP order, the generator keyed by the group index. */
+ORACLE_API void oracle_bd_adams_bashforth(real4 *pos, const real4 *previousForces, const int *indexIterator, const real4 *force, const real *K9,
+                                          real selfMobility, const real *radius, real dt, int is2D, real temperature, int N, uint stepNum,
+                                          uint seed) {
+  real3 Kx = mk3(0, 0, 0), Ky = Kx, Kz = Kx;
+  if (K9) { Kx = mk3(K9[0], K9[1], K9[2]); Ky = mk3(K9[3], K9[4], K9[5]); Kz = mk3(K9[6], K9[7], K9[8]); }
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    real3 p = mk3(pos[i].x, pos[i].y, pos[i].z);
+    const real M = selfMobility * (radius ? ((real)1.0 / radius[i]) : (real)1.0);
+    const real3 KR = mk3(dot3(Kx, p), dot3(Ky, p), dot3(Kz, p));
+    /* 1.5 fn - 0.5 fprev: one fused multiply-add on the product 1.5 fn */
+    const real ax = FMA((real)-0.5, previousForces[id].x, (real)1.5 * force[i].x);
+    const real ay = FMA((real)-0.5, previousForces[id].y, (real)1.5 * force[i].y);
+    const real az = FMA((real)-0.5, previousForces[id].z, (real)1.5 * force[i].z);
+    p.x = FMA(dt, FMA(M, ax, KR.x), p.x);
+    p.y = FMA(dt, FMA(M, ay, KR.y), p.y);
+    p.z = FMA(dt, FMA(M, az, KR.z), p.z);
+    if (temperature > (real)0.0) {
+      const real B = SQRT((real)2.0 * temperature * M * dt);
+      Saru rng = saru3((uint)id, stepNum, seed);
+      real3 dW;
+      real tmp;
+      gf_real(&rng, 0, B, &dW.x, &dW.y);
+      gf_real(&rng, 0, B, &dW.z, &tmp);
+      p.x += dW.x; p.y += dW.y; p.z += dW.z;
+    }
+    pos[i].x = p.x;
+    pos[i].y = p.y;
+    if (!is2D) pos[i].z = p.z;
+  }
+}
+
+/* BD::Leimkuhler, Leimkuhler_ns::integrateGPU (BrownianDynamics.cu:313-345): Euler drift, noise sqrt(T M dt / 2) (dW_n + dW_(n-1)) with
+ * dW_k = unit Gaussians keyed (originalIndex[i], k, seed): this step's second draw is the next step's first. */
+ORACLE_API void oracle_bd_leimkuhler(real4 *pos, const int *indexIterator, const int *originalIndex, const real4 *force, const real *K9,
+                                     real selfMobility, const real *radius, real dt, int is2D, real temperature, int N, uint stepNum, uint seed) {
+  real3 Kx = mk3(0, 0, 0), Ky = Kx, Kz = Kx;
+  if (K9) { Kx = mk3(K9[0], K9[1], K9[2]); Ky = mk3(K9[3], K9[4], K9[5]); Kz = mk3(K9[6], K9[7], K9[8]); }
+  for (int id = 0; id < N; id++) {
+    const int i = indexIterator ? indexIterator[id] : id;
+    real3 R = mk3(pos[i].x, pos[i].y, pos[i].z);
+    const real3 F = mk3(force[i].x, force[i].y, force[i].z);
+    const real3 KR = mk3(dot3(Kx, R), dot3(Ky, R), dot3(Kz, R));
+    const real M = selfMobility * (radius ? ((real)1.0 / radius[i]) : (real)1.0);
+    R.x = FMA(dt, FMA(M, F.x, KR.x), R.x);
+    R.y = FMA(dt, FMA(M, F.y, KR.y), R.y);
+    R.z = FMA(dt, FMA(M, F.z, KR.z), R.z);
+    if (temperature > 0) {
+      const int ori = originalIndex ? originalIndex[i] : i;
+      const real B = SQRT((real)0.5 * temperature * M * dt);
+      Saru a = saru3((uint)ori, stepNum, seed), b = saru3((uint)ori, stepNum - 1u, seed);
+      real3 da, db;
+      real tmp;
+      gf_real(&a, 0, 1, &da.x, &da.y);
+      gf_real(&a, 0, 1, &da.z, &tmp);
+      gf_real(&b, 0, 1, &db.x, &db.y);
+      gf_real(&b, 0, 1, &db.z, &tmp);
+      R.x = FMA(B, da.x + db.x, R.x);
+      R.y = FMA(B, da.y + db.y, R.y);
+      R.z = FMA(B, da.z + db.z, R.z);
+    }
+    pos[i].x = R.x;
+    pos[i].y = R.y;
+    if (!is2D) pos[i].z = R.z;
+  }
+}
+
 /* BDHI_FCM.cu:67-92 without orientations: pos[i] += linearV[id]*dt */
 ORACLE_API void oracle_fcm_euler_maruyama(real4 *pos, const int *indexIterator, const real *linearV3, int N, real dt) {
   for (int id = 0; id < N; id++) {

@@ -283,3 +283,39 @@ def test_reference_unit_tests_run(name, tmp_path):
         print(out[-3000:])
         failed = re.findall(r"^\[  FAILED  \] (\S+)$", out, flags=re.M)
     assert r.returncode == 0 and not failed, failed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", ["EulerMaruyama", "MidPoint", "AdamsBashforth", "Leimkuhler"])
+def test_reference_bd_program_free_diffusion(scheme, tmp_path):
+    """examples/_build/ref_test_BD = the reference's test/BD/BD.cu (compiled from where it lies), run as its test.bash runs it — free
+    particles, dt = 1, viscosity 1 / (6 pi), a = 1, T = 1: D0 = 1 — and judged by that script's criterion: the slope of the mean square
+    displacement per coordinate against 2 D0 dt (the script fits the first five lags of the msd tool's output; here the frames are read
+    directly).  The script loops over AdamsBashforth, MidPoint and EulerMaruyama; Leimkuhler, whose noise is correlated over one step,
+    is judged on lags 5..15."""
+    exe = os.path.join(EX, "_build", "ref_test_BD")
+    if not os.path.exists(exe):
+        pytest.skip("ref_test_BD was not built (no reference tree where `make -C examples` ran)")
+    n, steps = 4096, 24
+    (tmp_path / "data.main").write_text(f"""scheme {scheme}
+potential none
+boxSize 32 32 32
+numberSteps {steps}
+printSteps 1
+relaxSteps -1
+dt         1
+numberParticles {n}
+temperature    1
+viscosity   {1 / (6 * np.pi):.14g}
+hydrodynamicRadius 1
+outfile {tmp_path / 'pos.dat'}
+""")
+    r = subprocess.run([exe, "data.main"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    frames = np.loadtxt(tmp_path / "pos.dat", comments="#", usecols=(0, 1, 2)).reshape(steps, n, 3)
+    lags = range(5, 16) if scheme == "Leimkuhler" else range(1, 6)
+    msd = np.array([((frames[lag:] - frames[:-lag]) ** 2).mean((0, 1)) for lag in lags])
+    t = np.array(list(lags), float)
+    slope = np.array([np.polyfit(t, msd[:, c], 1)[0] for c in range(3)])
+    print(scheme, "msd slope / (2 D0 dt):", slope / 2.0)
+    assert np.all(np.abs(slope / 2.0 - 1) < 0.05), slope

@@ -5,6 +5,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -95,3 +96,82 @@ def test_gronbech_jensen_deterministic_limit(o32):
 def test_initial_velocities_amplitude(o32):
     v = o32.verletnvt_initial_velocities(50000, math.sqrt(3 * 2.0), 77)
     assert abs(v.std() - math.sqrt(6.0)) < 0.03 and abs(v.mean()) < 0.03
+
+
+def _bd_free_run(o32, scheme, n, steps, dt, T, M, seed):
+    """free particles under one of the three other BD schemes (Integrator/BrownianDynamics.cu:160-387), as their forwardTime strings the calls"""
+    pos = np.zeros((n, 4), np.float32)
+    force = np.zeros((n, 4), np.float32)
+    aux = np.zeros((n, 4), np.float32)
+    traj = [pos[:, :3].astype(np.float64).copy()]
+    for step in range(1, steps + 1):
+        if scheme == "MidPoint":
+            o32.bd_midpoint(0, pos, aux, force, M, dt, T, step, seed)
+            o32.bd_midpoint(1, pos, aux, force, M, dt, T, step, seed)
+        elif scheme == "AdamsBashforth":
+            o32.bd_adams_bashforth(pos, aux, force, M, dt, T, step, seed)
+        else:
+            o32.bd_leimkuhler(pos, force, M, dt, T, step, seed)
+        traj.append(pos[:, :3].astype(np.float64).copy())
+    return np.array(traj)
+
+
+@pytest.mark.parametrize("scheme", ["MidPoint", "AdamsBashforth", "Leimkuhler"])
+def test_bd_other_schemes_free_diffusion(o32, scheme):
+    """the criterion of the reference's test/BD/test.bash: the mean square displacement of free particles grows as 2 D0 t per coordinate
+    (D0 = T M).  Leimkuhler's noise (dW_n + dW_(n-1)) / 2 is correlated over one step: <dx^2>(n steps) = (2 n - 1) T M dt, the same slope."""
+    n, dt, T, M = 20000, 0.1, 1.0, 1.0 / (6 * math.pi)
+    traj = _bd_free_run(o32, scheme, n, 12, dt, T, M, 4321)
+    msd = ((traj - traj[0]) ** 2).mean(1)                      # [step][coordinate]
+    slope = (msd[12] - msd[4]) / 8
+    assert np.all(np.abs(slope / (2 * T * M * dt) - 1) < 0.04), slope / (2 * T * M * dt)
+    if scheme == "Leimkuhler":
+        assert np.all(np.abs(msd[1] / (T * M * dt) - 1) < 0.04)
+    else:
+        assert np.all(np.abs(msd[1] / (2 * T * M * dt) - 1) < 0.04)
+
+
+def test_bd_other_schemes_deterministic_limits(o32):
+    """T = 0: with a constant force MidPoint's two sub-steps land where one Euler step does; AdamsBashforth with F_(n-1) = F_n is Euler;
+    with F_(n-1) = 0 it moves by 3/2 of it; Leimkuhler without noise is Euler.  Members of a group only, shear included."""
+    n, dt, M = 64, 0.05, 0.7
+    rng = np.random.default_rng(5)
+    pos0 = np.zeros((n, 4), np.float32); pos0[:, :3] = rng.normal(0, 1, (n, 3)); pos0[:, 3] = np.arange(n)
+    force = np.zeros((n, 4), np.float32); force[:, :3] = rng.normal(0, 1, (n, 3))
+    index = np.arange(0, n, 2, dtype=np.int32)
+    euler = pos0.copy()
+    o32.bd_euler_maruyama(euler, force, M, dt, 0.0, 1, 1, index=None)
+    noshear = euler.copy()
+    noshear[1::2] = pos0[1::2]
+    mid, aux = pos0.copy(), np.zeros((len(index), 4), np.float32)
+    o32.bd_midpoint(0, mid, aux, force, M, dt, 0.0, 1, 1, index=index)
+    assert np.array_equal(aux, pos0[index])
+    half = pos0[index, :3] + 0.5 * dt * M * force[index, :3]
+    assert np.allclose(mid[index, :3], half, atol=1e-6)
+    o32.bd_midpoint(1, mid, aux, force, M, dt, 0.0, 1, 1, index=index)
+    assert np.allclose(mid[:, :3], noshear[:, :3], atol=1e-6) and np.array_equal(mid[:, 3], pos0[:, 3])
+    ab = pos0.copy()
+    o32.bd_adams_bashforth(ab, force[index].copy(), force, M, dt, 0.0, 1, 1, index=index)
+    assert np.allclose(ab[:, :3], noshear[:, :3], atol=1e-6)
+    ab = pos0.copy()
+    o32.bd_adams_bashforth(ab, np.zeros((len(index), 4), np.float32), force, M, dt, 0.0, 1, 1, index=index)
+    assert np.allclose(ab[index, :3], pos0[index, :3] + 1.5 * dt * M * force[index, :3], atol=1e-6) and np.array_equal(ab[1::2], pos0[1::2])
+    lk = pos0.copy()
+    o32.bd_leimkuhler(lk, force, M, dt, 0.0, 1, 1, index=index)
+    assert np.allclose(lk[:, :3], noshear[:, :3], atol=1e-6)
+    K = np.array([[0, 0.3, 0], [0, 0, 0], [0.1, 0, 0]], np.float32)
+    sh = pos0.copy()
+    o32.bd_leimkuhler(sh, force, M, dt, 0.0, 1, 1, K=K)
+    expect = pos0[:, :3] + dt * (pos0[:, :3] @ K.T + M * force[:, :3])
+    assert np.allclose(sh[:, :3], expect, atol=1e-6)
+
+
+def test_bd_leimkuhler_shares_draws_between_steps(o32):
+    """this step's second draw is the next step's first (keyed (particle, step, seed)): x_2 - x_0 = B (dW_2 + 2 dW_1 + dW_0)"""
+    n, dt, T, M = 50000, 0.2, 1.0, 0.3
+    pos = np.zeros((n, 4), np.float32)
+    force = np.zeros((n, 4), np.float32)
+    o32.bd_leimkuhler(pos, force, M, dt, T, 1, 9)
+    o32.bd_leimkuhler(pos, force, M, dt, T, 2, 9)
+    var = pos[:, :3].astype(np.float64).var(0)
+    assert np.all(np.abs(var / (0.5 * T * M * dt * 6) - 1) < 0.03), var   # 1 + 4 + 1

@@ -33,7 +33,10 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
          # correction — the ones that are plain programs (the *_test.cu files beside them need gtest / gmock, which this image lacks); FCM.cu, PSE.cu and
          # FIB.cu are also BUILT and RUN on the GPU (tests/test_cxx_interface.py::test_reference_acceptance_programs_run)
          "../test/BDHI/FCM/FCM.cu", "../test/BDHI/PSE/PSE.cu", "../test/BDHI/FIB/FIB.cu", "../test/BDHI/Lanczos_Cholesky/BDHI.cu",
-         "../test/BDHI/quasi2D/q2D.cu"]
+         "../test/BDHI/quasi2D/q2D.cu",
+         # round 6: the program test/BD/test.bash drives (BD::EulerMaruyama, MidPoint, AdamsBashforth, Leimkuhler; PairForces with the
+         # test's own Soft / Repulsive potentials; Poisson) — built by examples/Makefile and RUN per scheme by tests/test_cxx_interface.py
+         "../test/BD/BD.cu"]
 # The reference's own UNIT TESTS of the starred rows of SURVEY 8 (GoogleTest programs; test/CMakeLists.txt:4,9 compiles them with
 # -DMAXLOGLEVEL=1 -DDOUBLE_PRECISION): the same front-end pass with tests/cxx/gtest_lite standing in for <gtest/gtest.h> / <gmock/gmock.h>
 # and, for the dense products test_lanczos.cu makes with cuBLAS itself, the hipBLAS spellings.  examples/Makefile BUILDS them and

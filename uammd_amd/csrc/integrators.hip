@@ -146,6 +146,69 @@ __global__ void __launch_bounds__(kIB) k_bd_euler_maruyama(float4 *__restrict__ 
   pos[i] = p;
 }
 
+// The other three schemes of Integrator/BrownianDynamics.cu — one streaming kernel, the scheme a template parameter:
+//   SCHEME 1, SUB 0 / 1  MidPoint (:178-214): half a step from the current forces (the starting point kept in aux[id]), then a whole step
+//                        from the kept point with the midpoint's forces; variance T M dt per draw, the second sub-step repeats the first
+//                        draw and adds another; the generator keyed by the GROUP index id
+//   SCHEME 2             AdamsBashforth (:262-289): forces 3/2 F_n - 1/2 F_(n-1) (aux[id] = F_(n-1) in group order), sqrt(2 T M dt), keyed by id
+//   SCHEME 3             Leimkuhler (:313-345): Euler drift, noise sqrt(T M dt / 2) (dW_n + dW_(n-1)), keyed by originalIndex[i]
+template <int SCHEME, int SUB>
+__global__ void __launch_bounds__(kIB) k_bd_scheme(float4 *__restrict__ pos, float4 *__restrict__ aux, const int *__restrict__ index,
+                                                   const int *__restrict__ originalIndex, const float4 *__restrict__ force, Shear K,
+                                                   float selfMobility, const float *__restrict__ radius, float dt, int is2D, float temperature,
+                                                   int N, uint stepNum, uint seed) {
+  const int id = blockIdx.x * kIB + threadIdx.x;
+  if (id >= N) return;
+  const int i = index ? index[id] : id;
+  float4 p = pos[i];
+  if (SCHEME == 1) {
+    if (SUB == 0) aux[id] = p;
+    else { const float4 q = aux[id]; p.x = q.x; p.y = q.y; p.z = q.z; }
+  }
+  const float4 F = force[i];
+  const real3f R{p.x, p.y, p.z};
+  float KRx = dot3(real3f{K.Kx.x, K.Kx.y, K.Kx.z}, R), KRy = dot3(real3f{K.Ky.x, K.Ky.y, K.Ky.z}, R), KRz = dot3(real3f{K.Kz.x, K.Kz.y, K.Kz.z}, R);
+  const float M = selfMobility * (radius ? (1.0f / radius[i]) : 1.0f);
+  float fx = F.x, fy = F.y, fz = F.z;
+  if (SCHEME == 1 && SUB == 0) { fx *= 0.5f; fy *= 0.5f; fz *= 0.5f; KRx *= 0.5f; KRy *= 0.5f; KRz *= 0.5f; }
+  if (SCHEME == 2) {
+    const float4 Fp = aux[id];
+    fx = fmaf(-0.5f, Fp.x, 1.5f * F.x); fy = fmaf(-0.5f, Fp.y, 1.5f * F.y); fz = fmaf(-0.5f, Fp.z, 1.5f * F.z);
+  }
+  float rx = fmaf(dt, fmaf(M, fx, KRx), p.x), ry = fmaf(dt, fmaf(M, fy, KRy), p.y), rz = fmaf(dt, fmaf(M, fz, KRz), p.z);
+  if (temperature > 0.0f) {
+    if (SCHEME == 3) {
+      const uint ori = (uint)(originalIndex ? originalIndex[i] : i);
+      const float B = sqrtf(0.5f * temperature * M * dt);
+      Saru a(ori, stepNum, seed), b(ori, stepNum - 1u, seed);
+      const float2 a01 = a.gf(0.0f, 1.0f);
+      const float a2 = a.gf(0.0f, 1.0f).x;
+      const float2 b01 = b.gf(0.0f, 1.0f);
+      const float b2 = b.gf(0.0f, 1.0f).x;
+      rx = fmaf(B, a01.x + b01.x, rx); ry = fmaf(B, a01.y + b01.y, ry); rz = fmaf(B, a2 + b2, rz);
+    } else {
+      const float B = SCHEME == 1 ? sqrtf(temperature * M * dt) : sqrtf(2.0f * temperature * M * dt);
+      Saru rng((uint)id, stepNum, seed);
+      const float2 d01 = rng.gf(0.0f, B);
+      const float d2 = rng.gf(0.0f, B).x;
+      rx += d01.x; ry += d01.y; rz += d2;
+      if (SCHEME == 1 && SUB == 1) {
+        const float2 e01 = rng.gf(0.0f, B);
+        const float e2 = rng.gf(0.0f, B).x;
+        rx += e01.x; ry += e01.y; rz += e2;
+      }
+    }
+  }
+  p.x = rx;
+  p.y = ry;
+  if (!is2D) p.z = rz;
+  if (SCHEME == 1 && SUB == 1) {   // (only x, y, z come from the kept point: pos[i].w is the particle's own)
+    const float w = pos[i].w;
+    p.w = w;
+  }
+  pos[i] = p;
+}
+
 __global__ void __launch_bounds__(kIB) k_fcm_euler_maruyama(float4 *__restrict__ pos, const int *__restrict__ index,
                                                             const float *__restrict__ linearV, int N, float dt) {
   const int id = blockIdx.x * kIB + threadIdx.x;
@@ -306,6 +369,34 @@ int uammd_bd_euler_maruyama(float *d_pos, const int *d_index, const float *d_for
   }
   hipLaunchKernelGGL(k_bd_euler_maruyama, dim3(nb(N)), dim3(kIB), 0, (hipStream_t)stream, (float4 *)d_pos, d_index,
                      (const float4 *)d_force, S, selfMobility, d_radius, dt, is2D, temperature, N, stepNum, seed);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int uammd_bd_scheme_step(int scheme, int substep, float *d_pos, float *d_aux, const int *d_index, const int *d_originalIndex, const float *d_force,
+                         const float K[9], float selfMobility, const float *d_radius, float dt, int is2D, float temperature, int N,
+                         unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_force || ((scheme == UAMMD_BD_MIDPOINT || scheme == UAMMD_BD_ADAMS_BASHFORTH) && !d_aux)) {
+    set_last_error("uammd_bd_scheme_step: null argument");
+    return -1;
+  }
+  Shear S{make_float3(0, 0, 0), make_float3(0, 0, 0), make_float3(0, 0, 0)};
+  if (K) {
+    S.Kx = make_float3(K[0], K[1], K[2]);
+    S.Ky = make_float3(K[3], K[4], K[5]);
+    S.Kz = make_float3(K[6], K[7], K[8]);
+  }
+  const dim3 g(nb(N)), b(kIB);
+  hipStream_t st = (hipStream_t)stream;
+#define UH_BD_LAUNCH(SC, SU) hipLaunchKernelGGL((k_bd_scheme<SC, SU>), g, b, 0, st, (float4 *)d_pos, (float4 *)d_aux, d_index, d_originalIndex, \
+                                                (const float4 *)d_force, S, selfMobility, d_radius, dt, is2D, temperature, N, stepNum, seed)
+  if (scheme == UAMMD_BD_MIDPOINT && substep == 0) UH_BD_LAUNCH(1, 0);
+  else if (scheme == UAMMD_BD_MIDPOINT && substep == 1) UH_BD_LAUNCH(1, 1);
+  else if (scheme == UAMMD_BD_ADAMS_BASHFORTH) UH_BD_LAUNCH(2, 0);
+  else if (scheme == UAMMD_BD_LEIMKUHLER) UH_BD_LAUNCH(3, 0);
+  else { set_last_error("uammd_bd_scheme_step: unknown scheme %d / sub-step %d", scheme, substep); return -1; }
+#undef UH_BD_LAUNCH
   UH_CHECK(hipGetLastError());
   return 0;
 }

@@ -11,7 +11,7 @@ libuammd_hip.so.  Citations (relative to /root/reference/src):
   PairForces                   Interactor/PairForces.cuh:23-64, PairForces.cu:43-78
   Integrator / Interactor      Integrator/Integrator.cuh:33-125, Interactor/Interactor.cuh:56-119
   VerletNVT.{Basic,GronbechJensen}  Integrator/VerletNVT.cuh, VerletNVT/Basic.cu, GronbechJensen.cu
-  BD.EulerMaruyama             Integrator/BrownianDynamics.cuh/.cu
+  BD.EulerMaruyama, MidPoint, AdamsBashforth, Leimkuhler   Integrator/BrownianDynamics.cuh/.cu
 """
 import ctypes as C
 import math
@@ -806,5 +806,67 @@ class _BDEulerMaruyama(Integrator):
                                                par.temperature, pd.N, self.steps, self.seed, current_stream()))
 
 
+class _BDOtherScheme(_BDEulerMaruyama):
+    """BD::MidPoint / AdamsBashforth / Leimkuhler (Integrator/BrownianDynamics.cuh:121-183, .cu:160-387): the same parameters and force
+    loop as EulerMaruyama, the position update through uammd_bd_scheme_step."""
+    scheme = 0
+
+    def __init__(self, pd, par):
+        super().__init__(pd, par)
+        self.aux = None
+
+    def _forces(self):
+        self.pd.getForce("write").zero_()
+        for it in self.interactors:
+            it.sum(force=True)
+
+    def _advance(self, substep):
+        pd, par = self.pd, self.par
+        K = None
+        if par.K is not None:
+            K = (C.c_float * 9)(*[float(x) for x in np.asarray(par.K, dtype=np.float32).reshape(9)])
+        radius = pd.getRadius("read") if self.radius_from_pd else None
+        check(self.lib.uammd_bd_scheme_step(self.scheme, substep, _ptr(pd.getPos("readwrite")), _ptr(self.aux), None, None, _ptr(pd.getForce("read")),
+                                            K, self.selfMobility, _ptr(radius), par.dt, int(par.is2D), par.temperature, pd.N, self.steps, self.seed,
+                                            current_stream()))
+
+
+class _BDMidPoint(_BDOtherScheme):
+    scheme = 1
+
+    def forwardTime(self):
+        self.steps += 1
+        if self.aux is None:
+            self.aux = torch.empty_like(self.pd.getPos("read"))
+        self._forces()
+        self._advance(0)
+        self._forces()
+        self._advance(1)
+
+
+class _BDAdamsBashforth(_BDOtherScheme):
+    scheme = 2
+
+    def forwardTime(self):
+        self.steps += 1
+        if self.steps == 1:
+            self._forces()
+        self.aux = self.pd.getForce("read").clone()   # storeCurrentForces
+        self._forces()
+        self._advance(0)
+
+
+class _BDLeimkuhler(_BDOtherScheme):
+    scheme = 3
+
+    def forwardTime(self):
+        self.steps += 1
+        self._forces()
+        self._advance(0)
+
+
 class BD:
     EulerMaruyama = _BDEulerMaruyama
+    MidPoint = _BDMidPoint
+    AdamsBashforth = _BDAdamsBashforth
+    Leimkuhler = _BDLeimkuhler
