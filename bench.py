@@ -590,6 +590,13 @@ def _start_watchdog(rank, world, n_gpus):
             if dl is not None and time.monotonic() > dl:
                 msg = f"rank {rank} of {world}: stage '{STAGE}' did not finish within its wall-clock budget"
                 print("bench.py: " + msg, file=sys.stderr, flush=True)
+                fb = _WATCHDOG.get("fallback")
+                if fb is not None:   # an OPTIONAL stage ran out of time: the run's result so far is complete — print it with the stage's failure noted
+                    if rank == 0:
+                        fb = dict(fb)
+                        fb[_WATCHDOG.get("fallback_key", "optional_stage")] = {"error": msg, "stage": STAGE}
+                        emit_result(fb)
+                    os._exit(0)
                 if rank == 0:
                     emit_result({"metric": "particle-steps/s (LJ 1e6, rho*=0.8) + FCM-BDHI steps/s @128^3, 1/2/4/8 GPU", "value": None,
                                  "unit": "particle-steps/s", "n_gpus": n_gpus, "error": msg, "stage": STAGE})
@@ -1133,22 +1140,37 @@ def main():
             "roofline": {"bound": "valu", "kernel": "LJ traversal (k_lj_tile4), owned + ghost particles",
                          "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
-        if world > 1 and os.environ.get("UAMMD_BENCH_NO_STRONG") != "1":
-            # the STRONG-scaling line beside the weak headline: BASELINE's one 1e6 box over the N GPUs (at N = 1 it IS the single-domain line)
-            _settle()
-            sv, sms, sk, _ = run_lj_distributed(hip, args, world, rank, dist, strong=True)
-            width = L1 / world
-            out["lj_strong"] = {"value": sv, "unit": "particle-steps/s", "ms_per_step": sms, "scaling": "strong", "n_gpus": world,
-                                "particles_total": n, "particles_per_gpu": n / world, "box": [L1, L1, L1], "slab_width": width,
-                                "cell_planes_per_gpu": width / 2.5, "halo_fraction": 2 * (2.5 + 3 * args.skin) / width,
-                                "kernel_ms": sk, "steps": args.steps,
-                                "workload": f"LJ NVT: the ONE box of {n} particles (rho*=0.8, L = {L1:.4f}) cut into {world} z slabs; "
-                                            "same step, halo and migration code as the weak line"}
         if args.workload == "both":
             out["fcm"] = run_fcm_distributed(hip, args, world, rank, dist)
             out["fcm_c5"] = run_fcm_c5(hip, args, world, rank, dist)
+        out["comm"] = comm_info
+        if world > 1 and os.environ.get("UAMMD_BENCH_NO_STRONG") != "1":
+            # the STRONG-scaling line beside the weak headline: BASELINE's one 1e6 box over the N GPUs (at N = 1 it IS the single-domain
+            # line).  Run LAST and as an optional stage: everything above is complete, and whatever happens here — a rank that raises, a
+            # collective that never returns — the line printed is the result so far with the failure noted under "lj_strong".
+            _settle()
+            _WATCHDOG["fallback"], _WATCHDOG["fallback_key"] = out, "lj_strong"
+            stage("strong-scaling LJ line (optional)", min(args.max_seconds, 420.0))
+            serr = None
+            try:
+                sv, sms, sk, _ = run_lj_distributed(hip, args, world, rank, dist, strong=True)
+                width = L1 / world
+                out["lj_strong"] = {"value": sv, "unit": "particle-steps/s", "ms_per_step": sms, "scaling": "strong", "n_gpus": world,
+                                    "particles_total": n, "particles_per_gpu": n / world, "box": [L1, L1, L1], "slab_width": width,
+                                    "cell_planes_per_gpu": width / 2.5, "halo_fraction": 2 * (2.5 + 3 * args.skin) / width,
+                                    "kernel_ms": sk, "steps": args.steps,
+                                    "workload": f"LJ NVT: the ONE box of {n} particles (rho*=0.8, L = {L1:.4f}) cut into {world} z slabs; "
+                                                "same step, halo and migration code as the weak line"}
+            except Exception as e:   # (the other ranks may be waiting for this one inside a collective: the stage's budget ends them)
+                serr = f"{type(e).__name__}: {e}"
+                print(f"bench.py: rank {rank}: strong-scaling line failed: {serr}", file=sys.stderr, flush=True)
+                out["lj_strong"] = {"error": serr}
+                if rank == 0:
+                    emit_result(out)
+                os._exit(0)   # (no orderly shutdown with peers that may be stuck in a collective: their own watchdogs end them)
+            _WATCHDOG["fallback"] = None
+            stage("done")
         if rank == 0:
-            out["comm"] = comm_info
             emit_result(out)
         if dist is not None:
             dist.destroy_process_group()

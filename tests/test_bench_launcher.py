@@ -40,3 +40,18 @@ def test_a_stage_that_never_finishes_ends_in_a_json_error_line_not_a_hang():
     assert r.returncode == 4, (r.returncode, r.stderr[-500:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] is None and "did not finish" in line["error"] and line["stage"] == "a collective that never completes" and line["n_gpus"] == 2
+
+
+def test_an_optional_stage_that_hangs_keeps_the_result_so_far():
+    """The strong-scaling LJ line runs LAST and as an optional stage (bench.py: `_WATCHDOG["fallback"]`): when it never finishes, rank 0
+    prints the run's complete result so far — with the failure noted under the stage's key — and the processes exit 0."""
+    import json
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench._start_watchdog(0, 2, 2); "
+            "bench._WATCHDOG['fallback'] = {'metric': 'm', 'value': 123.0, 'n_gpus': 2}; bench._WATCHDOG['fallback_key'] = 'lj_strong'; "
+            "bench.stage('strong-scaling LJ line (optional)', 1.0); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 123.0 and "did not finish" in line["lj_strong"]["error"] and "error" not in line

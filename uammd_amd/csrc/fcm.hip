@@ -1282,14 +1282,33 @@ UH_D real3f wavevector(int3 ik, real3f L) {  // FCM/utils.cuh:37-39
 UH_D real3f gradient_fourier(int3 ik, int3 nk, real3f k) {  // FCM/utils.cuh:41-51: unpaired (Nyquist) components -> 0
   return real3f{ik.x == (nk.x - ik.x) ? 0.0f : k.x, ik.y == (nk.y - ik.y) ? 0.0f : k.y, ik.z == (nk.z - ik.z) ? 0.0f : k.z};
 }
-UH_D real3f project(float k2, real3f dk, real3f fr) {  // FCM/utils.cuh:70-74
-  const float invk2 = 1.0f / k2;
+// 1 / x for the Fourier-space operator: the hardware reciprocal refined by one Newton step (<= 1 ulp; host pass: the division).  The
+// fused z pass is bound by its vector instruction count at C5 (SQ_INSTS_VALU x 4 cycles = 94 % of the SIMD cycles,
+// profiles/r06_pmc_fft_z_fused.txt) and an IEEE division is ~12 of them, four per node; results within 1e-7 of the divided form.
+UH_D float op_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+#else
+  return 1.0f / x;
+#endif
+}
+UH_D float op_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);   // (1 ulp; the IEEE-correct sqrtf is a ten-instruction sequence without fast math)
+#else
+  return sqrtf(x);
+#endif
+}
+UH_D real3f project_inv(float invk2, real3f dk, real3f fr) {  // FCM/utils.cuh:70-74
   const float s = dot3(fr, real3f{dk.x * invk2, dk.y * invk2, dk.z * invk2});
   return real3f{fmaf(-dk.x, s, fr.x), fmaf(-dk.y, s, fr.y), fmaf(-dk.z, s, fr.z)};
 }
+UH_D real3f project(float k2, real3f dk, real3f fr) { return project_inv(op_rcp(k2), dk, fr); }
 UH_D C3 project(float k2, real3f dk, C3 f) {
-  const real3f re = project(k2, dk, real3f{f.xr, f.yr, f.zr});
-  const real3f im = project(k2, dk, real3f{f.xi, f.yi, f.zi});
+  const float invk2 = op_rcp(k2);
+  const real3f re = project_inv(invk2, dk, real3f{f.xr, f.yr, f.zr});
+  const real3f im = project_inv(invk2, dk, real3f{f.xi, f.yi, f.zi});
   return C3{re.x, im.x, re.y, im.y, re.z, im.z};
 }
 UH_D bool is_nyquist(int3 c, int3 n) {  // FCM/utils.cuh:133-167
@@ -1325,19 +1344,19 @@ UH_D float pse_greens(real3f k, const PseGreens &p, float viscosity, int3 n) {  
   if (k2 == 0.0f) return 0.0f;
   const real3f kE = pse_shear(k, p.shear);
   const float kE2 = dot3(kE, kE), kN2 = k2;
-  const float kmod = sqrtf(kE2);
-  const float invk2 = 1.0f / kE2;
+  const float kmod = op_sqrt(kE2);
+  const float invk2 = op_rcp(kE2);
   const float sink = sinf(kmod * p.rh);
-  const float kEw = kE2 / (4.0f * p.split * p.split);
-  const float kNU = kN2 / (4.0f * p.split * p.split);
+  const float inv4xi2 = 1.0f / (4.0f * p.split * p.split);   // (wave-uniform)
+  const float kEw = kE2 * inv4xi2;
+  const float kNU = kN2 * inv4xi2;
   const float tau = fmaf(p.eta, kNU, -kEw);
-  const float hashimoto = (1.0f + kEw) * expf(tau) / kE2;
-  float B = sink * sink * invk2 * hashimoto / (viscosity * p.rh * p.rh);
-  B /= (float)(n.x * n.y * n.z);
-  return B;
+  const float hashimoto = (1.0f + kEw) * expf(tau) * invk2;
+  const float scale = 1.0f / ((viscosity * p.rh * p.rh) * (float)(n.x * n.y * n.z));   // (wave-uniform: 1 / (eta a^2 N))
+  return sink * sink * invk2 * hashimoto * scale;
 }
 UH_D C3 pse_project(real3f k, const C3 &f) {  // FarField.cuh:53-73
-  const float invk2 = 1.0f / dot3(k, k);
+  const float invk2 = op_rcp(dot3(k, k));
   const float kfr = dot3(k, real3f{f.xr, f.yr, f.zr}) * invk2;
   const float kfi = dot3(k, real3f{f.xi, f.yi, f.zi}) * invk2;
   return C3{fmaf(-k.x, kfr, f.xr), fmaf(-k.x, kfi, f.xi), fmaf(-k.y, kfr, f.yr), fmaf(-k.y, kfi, f.yi), fmaf(-k.z, kfr, f.zr),
@@ -1350,6 +1369,7 @@ UH_D C3 pse_project(real3f k, const C3 &f) {  // FarField.cuh:53-73
 UH_D C3 fcm_kspace_node(int3 cell, int id, int3 nk, int nkx, real3f L, float viscosity, bool haveForce, float noisePrefactor, uint seed1,
                         uint seed2, const PseGreens &pse, const C3 &in) {
   C3 v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float invCells = 1.0f / (float)(nk.x * nk.y * nk.z);   // (wave-uniform: the compiler keeps it out of the node loops)
   // indexToWaveNumber (FCM/utils.cuh:27-35) from the cell coordinates it would recompute by division
   const int3 ik = make_int3(cell.x - nk.x * (cell.x >= nkx), cell.y - nk.y * (cell.y >= nk.y / 2 + 1),
                             cell.z - nk.z * (cell.z >= nk.z / 2 + 1));
@@ -1365,7 +1385,7 @@ UH_D C3 fcm_kspace_node(int3 cell, int id, int3 nk, int nkx, real3f L, float vis
         v = pse_project(ks, C3{a.x * B, a.y * B, b.x * B, b.y * B, c.x * B, c.y * B});
       }
       if (noisePrefactor != 0.0f) {  // fourierBrownianNoise, FarField.cuh:235-308, in gather form
-        const float Bsq = sqrtf(B);
+        const float Bsq = op_sqrt(B);
         const bool own = !noise_skipped(id, cell, nk);
         int idp = -1;
         if (cell.x == 0 || cell.x == nk.x - cell.x) {
@@ -1393,13 +1413,13 @@ UH_D C3 fcm_kspace_node(int3 cell, int id, int3 nk, int nkx, real3f L, float vis
   }
   if (haveForce && id != 0) {  // forceFourier2Vel, FCM_impl.cuh:375-397
     const float2 a = make_float2(in.xr, in.xi), b = make_float2(in.yr, in.yi), c = make_float2(in.zr, in.zi);
-    const float B = 1.0f / (viscosity * k2);
-    const float sc = B / (float)(nk.x * nk.y * nk.z);
+    const float B = op_rcp(viscosity * k2);
+    const float sc = B * invCells;
     const C3 pr = project(k2, dk, C3{a.x, a.y, b.x, b.y, c.x, c.y});
     v = C3{pr.xr * sc, pr.xi * sc, pr.yr * sc, pr.yi * sc, pr.zr * sc, pr.zi * sc};
   }
   if (noisePrefactor != 0.0f && id != 0) {  // fourierBrownianNoise, FCM_impl.cuh:437-512, in gather form
-    const float Bsq = sqrtf(1.0f / (k2 * viscosity));
+    const float Bsq = op_sqrt(op_rcp(k2 * viscosity));
     const bool own = !noise_skipped(id, cell, nk);
     // conjugate partner: only stored (and only written by the reference) on the kx == 0 / kx == nx - kx planes
     int idp = -1;
@@ -1661,9 +1681,11 @@ static int fcm_fft_forward_xy(FCM *f, float *g, hipStream_t st) {
     if (dev < 0 || dev >= 64 || !attrSet[dev]) {
       UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      UH_CHECK(hipFuncSetAttribute((const void *)k_fft_xy_r2c_plane<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       if (dev >= 0 && dev < 64) attrSet[dev] = true;
     }
     if (is_pow2(nx) && is_pow2(ny)) hipLaunchKernelGGL(k_fft_xy_r2c_plane<true>, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, nx, ny);
+    else if (lds <= 80 * 1024) hipLaunchKernelGGL((k_fft_xy_r2c_plane<false, true>), dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, nx, ny);   // two planes per CU
     else hipLaunchKernelGGL(k_fft_xy_r2c_plane<false>, dim3(3 * nz), dim3(kPlaneThreads), lds, st, g, nx, ny);
     return 0;
   }

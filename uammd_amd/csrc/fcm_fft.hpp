@@ -554,8 +554,13 @@ __global__ void __launch_bounds__(kFftThreads) k_fft_x_r2c(float *__restrict__ g
 // hipFuncSetAttribute.  Replaces k_fft_x_r2c + k_fft_lines<-1> where the plane fits (fcm_plane_fft_usable).
 // LDS: exp(-2 pi i k / nx), k < nx | exp(-2 pi i k / ny), k < ny | the plane
 constexpr int kPlaneThreads = 1024;
-template <bool P2>
-__global__ void __launch_bounds__(kPlaneThreads) k_fft_xy_r2c_plane(float *__restrict__ g, int nxArg, int nyArg) {
+// DENSE: held to 64 vector registers so that TWO workgroups share a CU where the plane's LDS lets them (<= 80 KB): the mixed-radix
+// instantiation wants 91 registers, which leaves one workgroup of 16 waves per CU and the 3 nz planes take two rounds of the chip — at
+// 108^3 (the PSE far field: 324 planes, 47.5 KB each) 25 spilled registers cost less than the second round: solve 0.1848 -> 0.1785 ms.
+// (The power-of-two instantiation needs 62 registers either way.)
+template <bool P2, bool DENSE = false>
+__global__ void __launch_bounds__(kPlaneThreads) __attribute__((amdgpu_waves_per_eu(DENSE ? 8 : 1, 8)))
+k_fft_xy_r2c_plane(float *__restrict__ g, int nxArg, int nyArg) {
   extern __shared__ float2 lds[];
   const int nx = fft_len<P2>(nxArg), ny = fft_len<P2>(nyArg);
   const int nh = nx >> 1, LS = nh + 1, nxpad = nx + 2;
