@@ -192,6 +192,34 @@ def test_fcm_grid_beyond_the_infinity_cache_not_a_power_of_two(hip, o32, n, ncel
         assert err <= 1e-5
 
 
+@pytest.mark.parametrize("n,cells,tol", [(100_000, [108, 108, 108], 1e-3), (100_000, [108, 108, 108], 1e-4), (60_000, [90, 108, 72], 1e-3)],
+                         ids=["108^3-support6", "108^3-support8", "90x108x72"])
+def test_fcm_nine_node_tiles_vs_oracle(hip, o32, n, cells, tol):
+    """Grids whose axes divide by 9 and not by 8 (108 = 12 x 9: the PSE far field's grid; 90 = 10 x 9) spread on NINE-node tiles (round 6:
+    the spread kernel's second instantiation, three matrix products per step; 72 keeps 8): the solve against the oracle at T = 0 and T = 1,
+    two supports, a mixed grid — and twenty steps of the slot layout (records in fixed-capacity tile slots, the preparation inside the
+    update kernel) against the same steps with the 9-node edge switched off are covered by test_gpu_ibm_fcm.py's slot-layout test."""
+    from oracle.fcm import FCMOracle
+    L = [float(c) for c in cells]
+    rng = np.random.default_rng(1234)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * np.asarray(L, np.float32)
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = np.random.default_rng(4321).normal(0, 1, (n, 3))
+    k, a_eff = hip.Kernels.Gaussian(1.0, tol)
+    fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 1.0, 1234, a_eff)
+    ofcm = FCMOracle(o32, L, cells, tolerance=tol, viscosity=1.0, seed=1234)
+    dp, df = torch.from_numpy(pos).cuda(), torch.from_numpy(force).cuda()
+    for T in (0.0, 1.0):
+        pf = 1 / math.sqrt(0.01) if T > 0 else 0.0
+        for rep in range(2 if T == 0 else 1):   # (T = 0 twice: a repeated solve on untouched arrays; with T > 0 every call draws a new field, seed2)
+            v = fcm.computeHydrodynamicDisplacements(dp, df, n, T, pf).cpu().numpy()
+        vref = ofcm.displacements(pos, force, temperature=T, prefactor=pf) if T > 0 else ofcm.displacements(pos, force)
+        err = np.linalg.norm(v - vref) / np.linalg.norm(vref)
+        print(f"[FCM {cells}, {n} particles, support {k.support[0]}] T={T} rel L2 err vs oracle {err:.2e}")
+        assert err <= 1e-5
+
+
 def test_fcm_c5_eight_slabs_equal_single_gpu(hip):
     """C5 decomposed as BASELINE.json names it (256^3 grid, 8 z-slabs of 32 planes, all-to-all transposes) with all 8
     ranks run in this process on one MI355X (exchanges = tensor copies) against the single-GPU solver."""

@@ -583,13 +583,15 @@ def test_fcm_step_bins_ahead(hip, o32, cells, n):
     assert np.array_equal(ex["ahead"], ex["noflag"]) and np.array_equal(ex["ahead"], ex["unfused"])
 
 
-@pytest.mark.parametrize("cells,n,cluster", [((64, 64, 64), 20001, 0), ((64, 64, 64), 6000, 900), ((128, 128, 128), 100000, 0), ((48, 40, 56), 9000, 300)])
+@pytest.mark.parametrize("cells,n,cluster", [((64, 64, 64), 20001, 0), ((64, 64, 64), 6000, 900), ((128, 128, 128), 100000, 0), ((48, 40, 56), 9000, 300),
+                                             ((54, 54, 54), 12000, 0), ((54, 36, 45), 7000, 700)])
 def test_fcm_step_slot_layout(hip, cells, n, cluster):
     """Round 5: a step that is told the array is untouched finds its WHOLE preparation done by the previous step's update kernel
     (k_fcm_step_prep: update + binning + stencils in one launch, spread records in fixed-capacity tile slots, no scan).  The same steps
     with the slot layout off (the compact, scanned layout of rounds 2-4) give the same trajectory at rounding level — with a cluster
     that overflows its tiles' slots (the overflow records every tile tests), across the periodic sorted solve that refreshes the entries'
-    order ("slot_refresh"), with a step without forces in between, and with tile edges other than eight (48 x 40 x 56)."""
+    order ("slot_refresh"), with a step without forces in between, with tile edges other than eight (48 x 40 x 56) and on the nine-node
+    tiles of round 6 (54 = 6 x 9; 54 x 36 x 45 = 6 x 4 x 5 tiles of edge 9, with a cluster that overflows its tiles' slots)."""
     L = np.asarray(cells, np.float32)
     k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
     dt = 0.01

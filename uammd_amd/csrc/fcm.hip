@@ -483,6 +483,10 @@ __global__ void __launch_bounds__(256) k_fcm_step_prep(float4 *__restrict__ pos,
 #endif
 constexpr int kSpWeightWordsMax = UAMMD_SP_WORDS;
 constexpr int kSpWT = 3 * kTile;      // LDS words per listed particle: its weights at the tile's 8 nodes along x, y, z
+// The kernel's layouts are sized by a compile-time tile edge E: 8 (every grid whose axes divide by 4..8) or 9 — round 6, for grids like the
+// PSE far field's 108 = 12 x 9, which otherwise takes 6-node tiles: 5832 tiles listing 137 particles each (799 k particle-tile pairs, 32 %
+// of each matrix product used) against 1728 tiles listing 268 (463 k pairs; 27 of 32 rows and 81 of 96 columns in THREE products per step).
+constexpr int kTileMax = 9;
 constexpr int kSpPerThread = UAMMD_SP_PER_THREAD;       // candidates per thread and round of phase A (768 per round; a C4 tile sees ~660)
 struct SpEntry {
   int o;  // stencil origin in the tile's frame (may be negative), biased by 24 and packed in 7-bit fields: ox | oy << 7 | oz << 14
@@ -491,8 +495,8 @@ struct SpEntry {
 };
 // dynamic LDS: float wts[weightWords + 32] | SpEntry list[257]
 // (+1: phase C reads 8 words per 5-word entry); the four private tiles of the final sum alias the same block
-static size_t spread_lds_bytes(int weightWords, int waves = 4) {
-  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * waves * 3 * kTile * kTile * kTile;
+static size_t spread_lds_bytes(int weightWords, int waves = 4, int edge = kTile) {
+  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * waves * 3 * edge * edge * edge;
   return a > b ? a : b;
 }
 // two waves per tile where a tile lists few particles (measured at C5, ~26 listed: see DESIGN 5.4), four otherwise
@@ -502,10 +506,12 @@ static int spread_waves(int N, int3 ntiles, int3 support, int3 tdim, int option)
   const double listed = perTile * (1.0 + (support.x - 1) / (double)tdim.x) * (1.0 + (support.y - 1) / (double)tdim.y) * (1.0 + (support.z - 1) / (double)tdim.z);
   return listed > 48.0 ? 4 : 2;
 }
+static int spread_edge(int3 tdim) { return (tdim.x > kTile || tdim.y > kTile || tdim.z > kTile) ? kTileMax : kTile; }
 static int spread_weight_words(int N, int3 ntiles, int3 support, int3 tdim) {
   const double perTile = (double)N / ((double)ntiles.x * ntiles.y * ntiles.z);
   const double listed = perTile * (1.0 + (support.x - 1) / (double)tdim.x) * (1.0 + (support.y - 1) / (double)tdim.y) * (1.0 + (support.z - 1) / (double)tdim.z);
-  return listed > 64.0 ? kSpWeightWordsMax : kSpWeightWordsMax / 2;
+  const int full = spread_edge(tdim) == kTileMax ? 256 * 3 * kTileMax : kSpWeightWordsMax;   // (256 listed particles either way)
+  return listed > 64.0 ? full : full / 2;
 }
 // W = waves per workgroup: 4, or 2 where the tiles are sparse (spread_waves) — a tile then costs the same chain of round trips for a
 // few matrix steps: twice the tiles in flight for the same waves.  Measured at C5 (256^3, 6 particles per tile, ~26 listed): 179 / 168 /
@@ -519,11 +525,13 @@ __device__ unsigned long long g_spread_tl[8];
 // SLOTS: the records come from fixed-capacity tile slots written by k_fcm_step_prep (FcmPrep::cap > 0) instead of the compact,
 // scanned layout: 27 populations instead of 27 range bounds, a 28th range for the overflow records (usually empty), the forces of the
 // LISTED particles fetched by particle index in phase B, and the other parity's counters handed back zeroed.
-template <int W, bool SLOTS = false>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8)))
+template <int W, bool SLOTS = false, int E = kTile>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(E == kTile ? 5 : 4, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
                   FcmPrep pr, int weightWords) {
-  constexpr int T3 = kTile * kTile * kTile;
+  constexpr int T3 = E * E * E;
+  constexpr int WT = 3 * E;                 // LDS words per listed particle: its weights at the tile's E nodes along x, y, z
+  constexpr int NM = (E * E + 31) / 32;     // matrix products per step: the tile's E^2 (x, y) columns in blocks of 32
   // the list + weights of phases A-C and the four private tiles of the final sum are never live together: one LDS block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   struct { float *wts; SpEntry *list; } sh{reinterpret_cast<float *>(smem), reinterpret_cast<SpEntry *>(smem + sizeof(float) * (size_t)(weightWords + 32))};
@@ -544,18 +552,30 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
 #endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   typedef float f32x16 __attribute__((ext_vector_type(16)));
-  f32x16 acc0 = {0.f}, acc1 = {0.f};  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
+  f32x16 accs[NM];  // this wave's private copy of the tile: MFMA accumulators (layout at the store below)
+#pragma unroll
+  for (int m = 0; m < NM; ++m) accs[m] = f32x16{0.f};
   const int half = lane >> 5, l32 = lane & 31;
   const int aKz = l32 / 3, aC = l32 - 3 * (l32 / 3);  // A operand row n = l32 = 3 kz + c
-  const bool aValid = l32 < 3 * kTile;
-  const int bX = l32 & 7, bY = l32 >> 3;              // B operand column xy = l32 (+ 32 for the second MFMA: y + 4)
+  const bool aValid = l32 < 3 * E;
+  // B operand: product m holds the columns xy = l32 + 32 m, x = xy mod E, y = xy div E (E = 8: x = l32 & 7, y = (l32 >> 3) + 4 m); a
+  // column beyond E^2 (the tail of the last product when E = 9) carries a zero weight
+  int bAtX[NM], bAtY[NM];
+  bool bValid[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int col = l32 + 32 * m;
+    bValid[m] = col < E * E;
+    bAtX[m] = bValid[m] ? col % E : 0;
+    bAtY[m] = E + (bValid[m] ? col / E : 0);
+  }
   const int tile = (int)xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tx = tile % ntiles.x, ty = (tile / ntiles.x) % ntiles.y, tz = tile / (ntiles.x * ntiles.y);
   const int3 td = pr.tdim;
   const int x0 = tx * td.x, y0 = ty * td.y, z0 = tz * td.z;
   const int sx = support.x, sy = support.y, sz = support.z;
   const int wstride = pr.wstride;
-  const int capEntries = min(kThreads, weightWords / kSpWT);
+  const int capEntries = min(kThreads, weightWords / WT);
   const int numTiles = ntiles.x * ntiles.y * ntiles.z;
   int myTile = numTiles, myShift = 0;  // threads < kRanges: their range's tile and packed shift
   if (threadIdx.x < kRanges) {
@@ -625,17 +645,17 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     float4 myForce = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SLOTS && (int)threadIdx.x < count) myForce = pr.forceById[__float_as_int(sh.list[threadIdx.x].fx)];  // (in flight with the weights)
     {
-      const int r = threadIdx.x & 31, axis = r >> 3, t = r & 7;
+      const int r = threadIdx.x & 31, axis = r / E, t = r - E * (r / E);
       const int sa = axis == 0 ? sx : (axis == 1 ? sy : sz), aoff = axis == 0 ? 0 : (axis == 1 ? sx : sx + sy);
       const int pp0 = threadIdx.x >> 5;
-      if (r < kSpWT && !(UAMMD_SP_ABLATE & 1))
+      if (r < WT && !(UAMMD_SP_ABLATE & 1))
         staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
             [&](int j) {
               const SpEntry &en = sh.list[pp0 + (kThreads / 32) * j];
               const int i = t - (((en.o >> (7 * axis)) & 127) - 24);
               return (unsigned)i < (unsigned)sa ? pr.weights[(size_t)wstride * en.slot + aoff + i] : 0.0f;
             },
-            [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * kSpWT + r] = v; });
+            [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * WT + r] = v; });
     }
     if (SLOTS && (int)threadIdx.x < count) { SpEntry &en = sh.list[threadIdx.x]; en.fx = myForce.x; en.fy = myForce.y; en.fz = myForce.z; }
     __syncthreads();
@@ -649,7 +669,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     // off one at a time: A 19, B 12, C 41, prologue + reduction + store 12; with the MFMA form C is ~22 and the call 65 us.)
     const int mineCount = (count - wave + W - 1) / W;  // entries wave, wave + W, ... of the list
     __builtin_amdgcn_s_setprio(0);  // (the arithmetic phase yields to the workgroups that are issuing loads: see the kernel's top)
-    const int zAt = 16 + (aValid ? aKz : 0);  // (rows 24..31 of the A operand carry no plane: force 0, any word)
+    const int zAt = 2 * E + (aValid ? aKz : 0);  // (rows 3 E..31 of the A operand carry no plane: force 0, any word)
     // (Measured and not kept, round 5: the list put in the order [y < 4 only | both halves | y >= 4 only] — 8 of 13 possible y origins
     // leave one half of the tile's columns, i.e. one of the two products, untouched — and a step issuing only the products its two
     // particles need: 31 % fewer matrix instructions, 45.4 -> 50.7 us.  Switching the phases off one at a time (UAMMD_SP_ABLATE) prices
@@ -660,12 +680,16 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       const bool real = idx < mineCount;  // an odd tail re-reads the wave's first entry with zero force
       const int e = wave + W * (real ? idx : 0);
       const float fc = (real && aValid) ? reinterpret_cast<const float *>(&sh.list[e].fx)[aC] : 0.0f;
-      const float *wt = sh.wts + e * kSpWT;
+      const float *wt = sh.wts + e * WT;
       const float av = wt[zAt] * fc;
-      const float wx = wt[bX];
-      const float b0 = wx * wt[8 + bY], b1 = wx * wt[12 + bY];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+      float b[NM];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float w = wt[bAtX[m]] * wt[bAtY[m]];
+        b[m] = (E == kTile || bValid[m]) ? w : 0.0f;
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m) accs[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[m], accs[m], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();
@@ -786,22 +810,24 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   }
   SP_STAMP(1);  // candidates tested, list complete
   if (listCount > 0) spread_list(listCount);
-  if (UAMMD_SP_ABLATE & 4) { if (acc0[0] + acc1[0] == 123.456f) g0[0] = 1.f; return; }
+  if (UAMMD_SP_ABLATE & 4) { if (accs[0][0] + accs[NM - 1][0] == 123.456f) g0[0] = 1.f; return; }
   {
-    // accumulator v of lane l is row n = 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32; rows 24..31 (v >= 12) are unused
-    float *mine = acc + wave * 3 * T3;  // node (x, y, z) of the tile = xy + 64 z
+    // accumulator v of lane l is row n = 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32 of its product; rows 3 E..31 are unused
+    float *mine = acc + wave * 3 * T3;  // node (x, y, z) of the tile = xy + E^2 z
 #pragma unroll
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < (E == kTile ? 12 : 16); ++v) {
       const int nrow = 8 * (v / 4) + 4 * half + (v % 4);
+      if (E != kTile && nrow >= 3 * E) continue;
       const int kz = nrow / 3, c = nrow - 3 * kz;
-      mine[c * T3 + 64 * kz + l32] = acc0[v];
-      mine[c * T3 + 64 * kz + 32 + l32] = acc1[v];
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        if (E == kTile || bValid[m]) mine[c * T3 + E * E * kz + 32 * m + l32] = accs[m][v];
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < T3; i += kThreads) {
-    const int lx = i % kTile, ly = (i / kTile) % kTile, lz = i / (kTile * kTile);
-    if (lx >= td.x || ly >= td.y || lz >= td.z) continue;  // (a tile edge shorter than the layout's 8: those rows belong to a neighbour)
+    const int lx = i % E, ly = (i / E) % E, lz = i / (E * E);
+    if (lx >= td.x || ly >= td.y || lz >= td.z) continue;  // (a tile edge shorter than the layout's E: those rows belong to a neighbour)
     const size_t node = (size_t)(x0 + lx) + (size_t)nxpad * (size_t)(y0 + ly) + zstride * (size_t)(z0 + lz);
     if (W == 4) {
       g0[node] = (acc[i] + acc[3 * T3 + i]) + (acc[6 * T3 + i] + acc[9 * T3 + i]);
@@ -1861,11 +1887,17 @@ static int fcm_prepare_tiles(FCM *f, const float *d_pos, const float *d_force, i
 // that satisfies this — 8 for power-of-two grids, 6 for the 108^3 grid of the PSE far field at psi = 0.5, 5 for 100, 7 for 84.  The
 // kernels' LDS / matrix layouts are sized for 8; a shorter tile leaves rows and columns unused (and unwritten).
 static bool fcm_tiles_usable(const int cells[3], const int support[3], int3 *tdim, bool only8 = false) {
+  static const bool nine = getenv("UAMMD_FCM_NO_TILE9") == nullptr;   // (A/B runs: the 9-node edge of round 6 off)
   int T[3];
   for (int a = 0; a < 3; ++a) {
     T[a] = 0;
-    for (int t = kTile; t >= (only8 ? kTile : 4); --t)
+    // 8 where it divides the axis; then 9 (the spread's second instantiation: 108, 162, 180, 198, 270 ...) before the shorter edges
+    const int order[6] = {8, 9, 7, 6, 5, 4};
+    for (int k = 0; k < (only8 ? 1 : 6); ++k) {
+      const int t = order[k];
+      if (t == 9 && !nine) continue;
       if (cells[a] % t == 0 && cells[a] / t >= 3 && support[a] <= 2 * (t - 1)) { T[a] = t; break; }
+    }
     if (!T[a]) return false;
   }
   *tdim = make_int3(T[0], T[1], T[2]);
@@ -2098,26 +2130,22 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
   }
   if (half != 2) f->lastSolveSlots = slots;  // (the second half of a solve reads what the first half prepared)
   if (d_force && half != 2) {
-    if (tiles && slots) {
+    if (tiles) {
       const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
       const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
       const int sw = spread_waves(N, f->ntiles, f->kern.support, f->tdim, f->spreadWaves);
-      if (sw == 2)
-        hipLaunchKernelGGL((k_fcm_spread_tile<2, true>), dim3(nt), dim3(128), spread_lds_bytes(ww, 2), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                           zs, f->kern.support, f->ntiles, pr, ww);
-      else
-        hipLaunchKernelGGL((k_fcm_spread_tile<4, true>), dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                           zs, f->kern.support, f->ntiles, pr, ww);
-    } else if (tiles) {
-      const int nt = f->ntiles.x * f->ntiles.y * f->ntiles.z;
-      const int ww = spread_weight_words(N, f->ntiles, f->kern.support, f->tdim);
-      const int sw = spread_waves(N, f->ntiles, f->kern.support, f->tdim, f->spreadWaves);
-      if (sw == 2)
-        hipLaunchKernelGGL(k_fcm_spread_tile<2>, dim3(nt), dim3(128), spread_lds_bytes(ww, 2), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                           zs, f->kern.support, f->ntiles, pr, ww);
-      else
-      hipLaunchKernelGGL(k_fcm_spread_tile<4>, dim3(nt), dim3(256), spread_lds_bytes(ww), st, g, f->grid.cellDim, f->nxpad, f->planeReal,
-                         zs, f->kern.support, f->ntiles, pr, ww);
+      const int edge = spread_edge(f->tdim);
+      const dim3 sg(nt), sb(64 * sw);
+      const size_t lds = spread_lds_bytes(ww, sw, edge);
+#define UH_SPREAD(W, S, E) hipLaunchKernelGGL((k_fcm_spread_tile<W, S, E>), sg, sb, lds, st, g, f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, pr, ww)
+      if (edge == kTileMax) {
+        if (sw == 2) { if (slots) UH_SPREAD(2, true, kTileMax); else UH_SPREAD(2, false, kTileMax); }
+        else { if (slots) UH_SPREAD(4, true, kTileMax); else UH_SPREAD(4, false, kTileMax); }
+      } else {
+        if (sw == 2) { if (slots) UH_SPREAD(2, true, kTile); else UH_SPREAD(2, false, kTile); }
+        else { if (slots) UH_SPREAD(4, true, kTile); else UH_SPREAD(4, false, kTile); }
+      }
+#undef UH_SPREAD
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
@@ -2307,7 +2335,15 @@ int uammd_fcm_set_option(uammd_fcm *h, const char *name, int value) {
   if (std::string(name) == "bin_by_slot") { reinterpret_cast<FCM *>(h)->binBySlot = value != 0; return 0; }
   if (std::string(name) == "spread_waves") { reinterpret_cast<FCM *>(h)->spreadWaves = value; return 0; }
   if (std::string(name) == "gather_per_wave") { reinterpret_cast<FCM *>(h)->gatherPerWave = value; return 0; }
-  if (std::string(name) == "tile_gather") { reinterpret_cast<FCM *>(h)->tileGather = value != 0; return 0; }
+  if (std::string(name) == "tile_gather") {
+    // (the staged window is loaded in aligned x pairs and is 16 nodes wide: an even tile edge along x, edge + support - 1 <= 16; elsewhere the
+    // option is accepted and the global gather runs)
+    FCM *f = reinterpret_cast<FCM *>(h);
+    const bool fits = f->tdim.x % 2 == 0 && f->tdim.x + f->kern.support.x - 1 <= 16 && f->tdim.y + f->kern.support.y - 1 <= 16 &&
+                      f->tdim.z + f->kern.support.z - 1 <= 16;
+    f->tileGather = value != 0 && fits;
+    return 0;
+  }
   if (std::string(name) == "interleaved_gather") { reinterpret_cast<FCM *>(h)->interGather = value != 0; return 0; }
   if (std::string(name) == "z_tile_log2" && (value == 0 || value == 2 || value == 3 || value == 4)) { reinterpret_cast<FCM *>(h)->zTileLog2 = value; return 0; }
   if (std::string(name) == "custom_fft") { reinterpret_cast<FCM *>(h)->customFFT = value != 0; return 0; }
