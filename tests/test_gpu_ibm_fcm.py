@@ -584,7 +584,10 @@ def test_fcm_step_bins_ahead(hip, o32, cells, n):
 
 
 @pytest.mark.parametrize("cells,n,cluster", [((64, 64, 64), 20001, 0), ((64, 64, 64), 6000, 900), ((128, 128, 128), 100000, 0), ((48, 40, 56), 9000, 300),
-                                             ((54, 54, 54), 12000, 0), ((54, 36, 45), 7000, 700)])
+                                             ((54, 54, 54), 12000, 0), ((54, 36, 45), 7000, 700),
+                                             # sparse tiles (two waves per tile): the speculative first round of the slot layout — alone, and with
+                                             # a cluster whose tiles hold more than the 16 slots it requests ahead (the rest in the second round)
+                                             ((64, 64, 64), 2500, 0), ((64, 64, 64), 3000, 500), ((54, 54, 54), 1200, 0)])
 def test_fcm_step_slot_layout(hip, cells, n, cluster):
     """Round 5: a step that is told the array is untouched finds its WHOLE preparation done by the previous step's update kernel
     (k_fcm_step_prep: update + binning + stencils in one launch, spread records in fixed-capacity tile slots, no scan).  The same steps

@@ -525,10 +525,17 @@ __device__ unsigned long long g_spread_tl[8];
 // SLOTS: the records come from fixed-capacity tile slots written by k_fcm_step_prep (FcmPrep::cap > 0) instead of the compact,
 // scanned layout: 27 populations instead of 27 range bounds, a 28th range for the overflow records (usually empty), the forces of the
 // LISTED particles fetched by particle index in phase B, and the other parity's counters handed back zeroed.
-template <int W, bool SLOTS = false, int E = kTile>
+// SPEC (slot layout, two waves per tile, eight source tiles: the sparse case, e.g. C5 with 6 particles per tile): the first kSpecSlots
+// slots of each of the eight source tiles are requested TOGETHER with the tiles' populations — the slots sit at fixed addresses, so the
+// records need not wait for the counts — and a tile's life has two dependent round trips in front of its matrix steps instead of three.
+// Round 5 measured the same idea at C4 (47 slots of 27 tiles, 660 real records among 1269 requested) and dropped it: 45.6 -> 48.4 us; where
+// a tile lists ~26 particles the requested 128 records cost nothing and the round trip is a quarter of the tile's life.
+template <int W, bool SLOTS = false, int E = kTile, bool SPEC = false>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(E == kTile ? 5 : 4, 8)))
 k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_t zstride, int3 support, int3 ntiles,
                   FcmPrep pr, int weightWords) {
+  static_assert(!SPEC || SLOTS, "the speculative first round belongs to the slot layout");
+  constexpr int kSpecSlots = 8 * W;   // 8 source tiles x 8 W slots = one record per thread: 16 slots of a sparse tile (W = 2), 32 of a dense one
   constexpr int T3 = E * E * E;
   constexpr int WT = 3 * E;                 // LDS words per listed particle: its weights at the tile's E nodes along x, y, z
   constexpr int NM = (E * E + 31) / 32;     // matrix products per step: the tile's E^2 (x, y) columns in blocks of 32
@@ -578,6 +585,19 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
   const int capEntries = min(kThreads, weightWords / WT);
   const int numTiles = ntiles.x * ntiles.y * ntiles.z;
   int myTile = numTiles, myShift = 0;  // threads < kRanges: their range's tile and packed shift
+  __shared__ int rCount[SPEC ? 8 : 1];
+  unsigned long long specRec = 0ull;
+  int specShift = 0;
+  if (SPEC) {   // thread (k, j) = (source tile, slot): its record is on its way while the populations are read
+    const int k = threadIdx.x / kSpecSlots, j = threadIdx.x & (kSpecSlots - 1);   // 8 x 8 W = the workgroup's threads
+    const int dx = -(k & 1), dy = -((k >> 1) & 1), dz = -(k >> 2);          // (ox1 = oy1 = oz1 = 2: the launch chose SPEC for that)
+    int ux = tx + dx, uy = ty + dy, uz = tz + dz;
+    if (ux < 0) ux += ntiles.x;
+    if (uy < 0) uy += ntiles.y;
+    if (uz < 0) uz += ntiles.z;
+    specShift = (td.x * dx + 16) | (td.y * dy + 16) << 7 | (td.z * dz + 16) << 14;
+    if (j < pr.cap) specRec = pr.rec[(size_t)(ux + ntiles.x * (uy + ntiles.y * uz)) * pr.cap + j];
+  }
   if (threadIdx.x < kRanges) {
     const int nb = threadIdx.x;
     // the tiles whose particles can reach this one: offsets -k .. 0 per axis (stencil_tile)
@@ -598,6 +618,11 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       const int c = pr.slotCount[myTile];
       s = myTile * pr.cap;
       e = s + (nb < 27 ? min(c, pr.cap) : c);  // (range 27: every overflow record, whatever its tile)
+      if (SPEC && nb < 8) {   // the speculative round takes the range's first slots: what is left of it starts behind them
+        const int took = min(min(c, pr.cap), kSpecSlots);
+        rCount[nb] = took;
+        s += took;
+      }
     } else {
       s = pr.tileStart[myTile];
       e = pr.tileStart[myTile + 1];
@@ -735,6 +760,18 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
     }
     __syncthreads();
   };
+  if (SPEC) {   // the records requested with the populations: slot j of source tile k is real iff j < the tile's population
+    bool live[kU];
+    int org[kU], key[kU];
+    float fx[kU], fy[kU], fz[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) { live[u] = false; org[u] = 0; key[u] = 0; fx[u] = fy[u] = fz[u] = 0.f; }
+    live[0] = (int)(threadIdx.x & (kSpecSlots - 1)) < rCount[threadIdx.x / kSpecSlots];
+    org[0] = specShift + (int)(specRec >> 42);
+    key[0] = (int)(specRec & 0x1fffffull);
+    fx[0] = __int_as_float((int)((specRec >> 21) & 0x1fffffull));
+    take_round(live, org, key, fx, fy, fz);
+  }
   const int perRound = min(capEntries, kThreads) * kU;
   for (int c0 = 0; c0 < total; c0 += perRound) {
     // phase A: kU candidates per thread, their records in flight together.  owner[] maps a candidate of this round to its range
@@ -2138,7 +2175,21 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
       const dim3 sg(nt), sb(64 * sw);
       const size_t lds = spread_lds_bytes(ww, sw, edge);
 #define UH_SPREAD(W, S, E) hipLaunchKernelGGL((k_fcm_spread_tile<W, S, E>), sg, sb, lds, st, g, f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, pr, ww)
-      if (edge == kTileMax) {
+      // (SPEC: see the kernel — two waves per tile, exactly eight source tiles, slots deep enough)
+      static const bool specOn = getenv("UAMMD_FCM_NO_SPEC") == nullptr;
+      const bool eight = (f->kern.support.x - 2 + f->tdim.x) / f->tdim.x == 1 && (f->kern.support.y - 2 + f->tdim.y) / f->tdim.y == 1 &&
+                         (f->kern.support.z - 2 + f->tdim.z) / f->tdim.z == 1;
+      // (dense tiles, four waves, 8 x 32 slots: measured at C4 with no gain — 0.1578 / 0.1580 / 0.1593 against 0.1578 / 0.1589 / 0.1594 ms —
+      // since the records' round trip hides behind the other tiles' matrix steps there; kept behind UAMMD_FCM_SPEC_DENSE=1 for A/B runs)
+      static const bool specDense = getenv("UAMMD_FCM_SPEC_DENSE") != nullptr;
+      // (the round lists up to one record per thread at once: the list and its weights must hold a workgroup's worth — capEntries >= 64 W)
+      const bool spec = specOn && slots && eight && pr.cap >= 8 * sw && ww / (3 * edge) >= 64 * sw && (sw == 2 || specDense);
+#define UH_SPREAD_SPEC(W, E) hipLaunchKernelGGL((k_fcm_spread_tile<W, true, E, true>), sg, sb, lds, st, g, f->grid.cellDim, f->nxpad, f->planeReal, zs, f->kern.support, f->ntiles, pr, ww)
+      if (spec) {
+        if (sw == 2) { if (edge == kTileMax) UH_SPREAD_SPEC(2, kTileMax); else UH_SPREAD_SPEC(2, kTile); }
+        else { if (edge == kTileMax) UH_SPREAD_SPEC(4, kTileMax); else UH_SPREAD_SPEC(4, kTile); }
+      }
+      else if (edge == kTileMax) {
         if (sw == 2) { if (slots) UH_SPREAD(2, true, kTileMax); else UH_SPREAD(2, false, kTileMax); }
         else { if (slots) UH_SPREAD(4, true, kTileMax); else UH_SPREAD(4, false, kTileMax); }
       } else {
@@ -2146,6 +2197,7 @@ static int fcm_displacements_impl(uammd_fcm *h, const float *d_pos, const float 
         else { if (slots) UH_SPREAD(4, true, kTile); else UH_SPREAD(4, false, kTile); }
       }
 #undef UH_SPREAD
+#undef UH_SPREAD_SPEC
     } else {
       UH_CHECK(hipMemsetAsync(g, 0, sizeof(float) * 3 * f->planeReal, st));
       hipLaunchKernelGGL((k_fcm_ibm<true>), gp, bp, 0, st, (const float4 *)d_pos, (const float4 *)d_force,
