@@ -2541,6 +2541,60 @@ public:
 };
 #endif
 
+// BDHI::EulerMaruyama<Method> (Integrator/BDHI/BDHI_EulerMaruyama.cuh:55-110, .cu:30-166): Method = FCM, PSE (both precisions), Lanczos, Cholesky
+template <class Method> class EulerMaruyama : public Integrator {
+  using Parameters_t = typename Method::Parameters;
+  Parameters_t par;
+  shared_ptr<Method> bdhi;
+  detail::DeviceArray<real3> MF, BdW;
+  int steps = 0;
+  hipStream_t stream = 0;
+public:
+  using Parameters = Parameters_t;
+  EulerMaruyama(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_EulerMaruyama.cuh:67, .cu:30-60
+      : Integrator(group, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(group, par)), MF(group->getNumberParticles()),
+        BdW(group->getNumberParticles() + 1) {}
+  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}  // :69-70
+  shared_ptr<Method> getScheme() { return bdhi; }  // :81
+  real getHydrodynamicRadius() { return bdhi->getHydrodynamicRadius(); }
+  real getSelfMobility() { return bdhi->getSelfMobility(); }
+  shared_ptr<Method> getMethod() { return bdhi; }
+private:
+  // computeMF then computeBdW (BDHI_EulerMaruyama.cu:140-150) — or, for a method that can interleave the two (PSE: its far field behind
+  // the Lanczos solve's one wait), its computeMFandBdW
+  template <class M> auto mobilityAndNoise(M &m, int) -> decltype(m.computeMFandBdW(MF.d, BdW.d, stream), void()) {
+    m.computeMFandBdW(MF.d, BdW.d, stream);
+  }
+  template <class M> void mobilityAndNoise(M &m, long) {
+    m.computeMF(MF.d, stream);
+    m.computeBdW(BdW.d, stream);
+  }
+public:
+  void forwardTime() override {
+    steps++;
+    for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
+    if (steps == 1)
+      for (auto &u : updatables) { u->updateTimeStep(par.dt); u->updateTemperature(par.temperature); u->updateBox(par.box); u->updateViscosity(par.viscosity); }
+    resetGroupForces(stream);  // .cu:115-123
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
+    bdhi->setup_step(stream);
+    if (par.temperature > 0) mobilityAndNoise(*bdhi, 0);
+    else bdhi->computeMF(MF.d, stream);
+    const real sqrt2Tdt = std::sqrt(2 * par.dt * par.temperature);
+    bdhi->finish_step(stream);
+    real K[9] = {0};
+    const bool shear = par.K.size() == 3;
+    if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi_euler_maruyama_f64((double *)pos.raw(), groupIndex(), (const double *)MF.d, par.temperature > 0 ? (const double *)BdW.d : nullptr,
+                                                shear ? K : nullptr, groupSize(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
+#else
+    detail::check(uammd_bdhi_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)MF.d, par.temperature > 0 ? (const float *)BdW.d : nullptr,
+                                            shear ? K : nullptr, groupSize(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
+#endif
+  }
+};
 #if defined(DOUBLE_PRECISION)
 }  // namespace BDHI
 #else   // (single-precision backends only, down to Poisson: see PRECISION at the top)
@@ -2658,54 +2712,6 @@ public:
   }
 };
 
-template <class Method> class EulerMaruyama : public Integrator {
-  using Parameters_t = typename Method::Parameters;
-  Parameters_t par;
-  shared_ptr<Method> bdhi;
-  detail::DeviceArray<real3> MF, BdW;
-  int steps = 0;
-  hipStream_t stream = 0;
-public:
-  using Parameters = Parameters_t;
-  EulerMaruyama(shared_ptr<ParticleGroup> group, Parameters par)  // BDHI_EulerMaruyama.cuh:67, .cu:30-60
-      : Integrator(group, "BDHI::EulerMaruyama"), par(par), bdhi(make_shared<Method>(group, par)), MF(group->getNumberParticles()),
-        BdW(group->getNumberParticles() + 1) {}
-  EulerMaruyama(shared_ptr<ParticleData> pd, Parameters par) : EulerMaruyama(make_shared<ParticleGroup>(pd, "All"), par) {}  // :69-70
-  shared_ptr<Method> getScheme() { return bdhi; }  // :81
-  real getHydrodynamicRadius() { return bdhi->getHydrodynamicRadius(); }
-  real getSelfMobility() { return bdhi->getSelfMobility(); }
-  shared_ptr<Method> getMethod() { return bdhi; }
-private:
-  // computeMF then computeBdW (BDHI_EulerMaruyama.cu:140-150) — or, for a method that can interleave the two (PSE: its far field behind
-  // the Lanczos solve's one wait), its computeMFandBdW
-  template <class M> auto mobilityAndNoise(M &m, int) -> decltype(m.computeMFandBdW(MF.d, BdW.d, stream), void()) {
-    m.computeMFandBdW(MF.d, BdW.d, stream);
-  }
-  template <class M> void mobilityAndNoise(M &m, long) {
-    m.computeMF(MF.d, stream);
-    m.computeBdW(BdW.d, stream);
-  }
-public:
-  void forwardTime() override {
-    steps++;
-    for (auto &u : updatables) u->updateSimulationTime(steps * par.dt);
-    if (steps == 1)
-      for (auto &u : updatables) { u->updateTimeStep(par.dt); u->updateTemperature(par.temperature); u->updateBox(par.box); u->updateViscosity(par.viscosity); }
-    resetGroupForces(stream);  // .cu:115-123
-    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, stream); }
-    bdhi->setup_step(stream);
-    if (par.temperature > 0) mobilityAndNoise(*bdhi, 0);
-    else bdhi->computeMF(MF.d, stream);
-    const real sqrt2Tdt = std::sqrt(2 * par.dt * par.temperature);
-    bdhi->finish_step(stream);
-    float K[9] = {0};
-    const bool shear = par.K.size() == 3;
-    if (shear) for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
-    auto pos = pd->getPos(access::gpu, access::readwrite);
-    detail::check(uammd_bdhi_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)MF.d, par.temperature > 0 ? (const float *)BdW.d : nullptr,
-                                            shear ? K : nullptr, groupSize(), sqrt2Tdt, par.dt, par.is2D, (void *)stream));
-  }
-};
 }  // namespace BDHI
 
 // ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------

@@ -808,6 +808,9 @@ int uammd_fcm_displacements_f64(uammd_fcm_f64 *h, const double *d_pos, const dou
  * (FCM_impl.cuh:437-542, FarField.cuh:235-308,471-501); d_force may be NULL (noise only) */
 int uammd_fcm_displacements_thermal_f64(uammd_fcm_f64 *h, const double *d_pos, const double *d_force, int numberParticles, double temperature,
                                         double prefactor, unsigned int seed1, unsigned int seed2, double *d_velocity, void *stream);
+/* BDHI::EulerMaruyama_ns::integrateGPUD with real = double (see uammd_bdhi_euler_maruyama) */
+int uammd_bdhi_euler_maruyama_f64(double *d_pos, const int *d_index, const double *d_MF, const double *d_BdW, const double K[9], int numberParticles,
+                                  double sqrt2Tdt, double dt, int is2D, void *stream);
 int uammd_pse_far_raw_cells_f64(const double boxSize[3], double psi, double tolerance, int cells_out[3]);
 int uammd_pse_far_create_f64(const double boxSize[3], const int cells[3], double viscosity, double hydrodynamicRadius,
                              double tolerance, double psi, double shearStrain, uammd_fcm_f64 **out, int *support_out,

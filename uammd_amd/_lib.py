@@ -111,6 +111,7 @@ SIGNATURES = {
     "uammd_fcm_displacements_thermal_f64": (_i, [_vp, _vp, _vp, _i, _d, _d, _u, _u, _vp, _vp]),
     "uammd_pse_near_stochastic_f64": (_i, [_vp, _vp, _vp, _i, _d, _d, _u, _u, _d, _vp, _vp, C.POINTER(_i)]),
     "uammd_convert_f64_to_f32": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "uammd_bdhi_euler_maruyama_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp]),
     "uammd_lanczos_set_iteration_hard_limit_f64": (_i, [_vp, _i]),
     "uammd_lanczos_get_last_run_required_steps_f64": (_i, [_vp, C.POINTER(_i)]),
     "uammd_hip_last_error": (C.c_char_p, []),

@@ -677,4 +677,41 @@ int uammd_pse_near_stochastic_f64(uammd_pse_near_f64 *h, uammd_lanczos_f64 *solv
   return uammd_lanczos_run_f64(solver, &pse_near64_dot, &ctx, d_BdW, (const double *)p->noise.ptr, tolerance, 3 * N, stream, iterations);
 }
 
+// BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113) with real = double: pos += dt (K pos + MF) + sqrt2Tdt BdW
+struct Shear9d { double k[9]; };
+__global__ void __launch_bounds__(256) k_bdhi_euler_maruyama64(double *__restrict__ pos, const int *__restrict__ index, const double *__restrict__ MF,
+                                                               const double *__restrict__ BdW, Shear9d K, bool haveK, int N, double sqrt2Tdt,
+                                                               double dt, bool is2D) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  const size_t i = (size_t)(index ? index[id] : id);
+  double x = pos[4 * i], y = pos[4 * i + 1], z = pos[4 * i + 2];
+  if (haveK) {
+    const double krx = fma(K.k[2], z, fma(K.k[1], y, K.k[0] * x));
+    const double kry = fma(K.k[5], z, fma(K.k[4], y, K.k[3] * x));
+    const double krz = is2D ? 0.0 : fma(K.k[8], z, fma(K.k[7], y, K.k[6] * x));
+    x = fma(krx, dt, x); y = fma(kry, dt, y); z = fma(krz, dt, z);
+  }
+  x = fma(MF[3 * (size_t)id], dt, x);
+  y = fma(MF[3 * (size_t)id + 1], dt, y);
+  z = fma(MF[3 * (size_t)id + 2], dt, z);
+  if (BdW) {
+    x = fma(sqrt2Tdt, BdW[3 * (size_t)id], x);
+    y = fma(sqrt2Tdt, BdW[3 * (size_t)id + 1], y);
+    z = fma(sqrt2Tdt, is2D ? 0.0 : BdW[3 * (size_t)id + 2], z);
+  }
+  pos[4 * i] = x; pos[4 * i + 1] = y; pos[4 * i + 2] = z;
+}
+int uammd_bdhi_euler_maruyama_f64(double *d_pos, const int *d_index, const double *d_MF, const double *d_BdW, const double K[9], int N,
+                                  double sqrt2Tdt, double dt, int is2D, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_MF) { set_last_error("uammd_bdhi_euler_maruyama_f64: null argument"); return -1; }
+  Shear9d k{};
+  if (K) for (int t = 0; t < 9; ++t) k.k[t] = K[t];
+  hipLaunchKernelGGL(k_bdhi_euler_maruyama64, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_pos, d_index, d_MF, d_BdW, k, K != nullptr, N,
+                     sqrt2Tdt, dt, is2D != 0);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

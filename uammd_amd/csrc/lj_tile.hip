@@ -309,6 +309,62 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     a0 = cb + (k0 << 5);
     a1 = cb + (k1 << 5);
   };
+#ifdef UAMMD_TILE_POP3
+  // VARIANT (tools/variants_tile.sh pop3; measured and not kept): THREE pairs per iteration — fewer loop and word-advance
+  // instructions per pair, more dead slots (a word's hit count is rarely a multiple of three).
+  auto pop3 = [&](bool &live0, bool &live1, bool &live2, uint &a0, uint &a1, uint &a2) {
+    const uint tw = *(const LdsU *)(uintptr_t)(myMask + 256u * wi1 + 256u);
+    const uint tb = *(const LdsU *)(uintptr_t)(wabsTab + 4u * wi1 + 4u);
+    unsigned long long adv, co;
+    asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(adv) : "v"(cw));
+    adv &= more;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cw) : "v"(cw), "v"(nw), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cb) : "v"(cb), "v"(nb), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nw) : "v"(nw), "v"(tw), "s"(adv));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nb) : "v"(nb), "v"(tb), "s"(adv));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(wi1), "=s"(co) : "v"(wi1), "s"(adv));
+    asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(more) : "v"(wi1), "s"(nW));
+    live0 = cw != 0;
+    const uint k0 = (uint)__builtin_clz_or_neg1(cw);
+    cw &= ~(0x80000000u >> (k0 & 31u));
+    live1 = cw != 0;
+    const uint k1 = (uint)__builtin_clz_or_neg1(cw);
+    cw &= ~(0x80000000u >> (k1 & 31u));
+    live2 = cw != 0;
+    const uint k2 = (uint)__builtin_clz_or_neg1(cw);
+    cw &= ~(0x80000000u >> (k2 & 31u));
+    a0 = cb + (k0 << 5);
+    a1 = cb + (k1 << 5);
+    a2 = cb + (k2 << 5);
+  };
+  bool lN0, lN1, lN2;
+  uint a0, a1, a2;
+  pop3(lN0, lN1, lN2, a0, a1, a2);
+  f4t cN0 = *(const LdsF4 *)(uintptr_t)a0, cN1 = *(const LdsF4 *)(uintptr_t)a1, cN2 = *(const LdsF4 *)(uintptr_t)a2;
+  while (__any(lN0) || more != 0) {
+    TILE_MARK("drain_body", PBC);
+    const f4t c0 = cN0, c1 = cN1, c2 = cN2;
+    const bool l0 = lN0, l1 = lN1, l2 = lN2;
+    pop3(lN0, lN1, lN2, a0, a1, a2);
+    cN0 = *(const LdsF4 *)(uintptr_t)a0;
+    cN1 = *(const LdsF4 *)(uintptr_t)a1;
+    cN2 = *(const LdsF4 *)(uintptr_t)a2;
+    real3f r0, r1, r2;
+    float f0, f1, f2, e0, e1, e2;
+    if (NT != 0) {
+      tile_eval<PBC, WE, NT == 2>(box, p1, pi, c0, r0, f0, e0);
+      tile_eval<PBC, WE, NT == 2>(box, p1, pi, c1, r1, f1, e1);
+      tile_eval<PBC, WE, NT == 2>(box, p1, pi, c2, r2, f2, e2);
+    } else {
+      tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c0.w), pi, c0, r0, f0, e0);
+      tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c1.w), pi, c1, r1, f1, e1);
+      tile_eval<PBC, WE>(box, lj_lookup(tbl, ntypes, (int)pi.w, (int)c2.w), pi, c2, r2, f2, e2);
+    }
+    lj_acc<WE, WV>(acc, r0, l0 ? f0 : 0.0f, l0 ? e0 : 0.0f);
+    lj_acc<WE, WV>(acc, r1, l1 ? f1 : 0.0f, l1 ? e1 : 0.0f);
+    lj_acc<WE, WV>(acc, r2, l2 ? f2 : 0.0f, l2 ? e2 : 0.0f);
+  }
+#else
   bool lN0, lN1;
   uint a0, a1;
   pop2(lN0, lN1, a0, a1);
@@ -332,6 +388,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
     lj_acc<WE, WV>(acc, r0, l0 ? f0 : 0.0f, l0 ? e0 : 0.0f);
     lj_acc<WE, WV>(acc, r1, l1 ? f1 : 0.0f, l1 ? e1 : 0.0f);
   }
+#endif
   TILE_MARK("drain_end", PBC);
 }
 
