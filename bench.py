@@ -284,7 +284,7 @@ def run_fcm(hip, args, world, rank, dist):
     G = 12 * 2 * (cells[0] // 2 + 1) * cells[1] * cells[2]
     nodes = cells[0] * cells[1] * cells[2]
     # (round 5: one preparation launch — position, velocity and entry in; position, stencil origin, 72 B of weights and the 8-byte record out)
-    out["kernel_rooflines"] = read_kernel_fractions("r05_kernel_stats_fcm_c4.txt", {
+    out["kernel_rooflines"] = read_kernel_fractions("r06_kernel_stats_fcm_c4.txt", {
         "k_fcm_spread_tile": G + 4.3 * n * (16 + 72), "k_fft_xy_r2c_plane": 2 * G, "k_fft_z_fused": 2 * G, "k_fft_lines": 2 * G,
         "k_fft_x_c2r": G + 16 * nodes, "k_fcm_gather_col": 16 * nodes + n * (16 + 72 + 12), "k_fcm_gather_half": 16 * nodes + n * (16 + 72 + 12),
         "k_fcm_step_prep": n * (16 + 12 + 16 + 16 + 16 + 72 + 8)})

@@ -1,7 +1,4 @@
-// Forwarding header: same include path as the reference's src/Interactor/SpectralEwaldPoisson.cuh.
+// Forwarding header: same include path as the reference's src/Interactor/SpectralEwaldPoisson.cuh (Poisson; both precisions).
 // The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).
 #pragma once
-#if defined(DOUBLE_PRECISION)
-#error "SpectralEwaldPoisson.cuh: this module has a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
-#endif
 #include "../uammd.h"

@@ -22,8 +22,9 @@
 // FCM, the pair-record PSE near field — is single precision by construction; its DOUBLE_PRECISION build is the `_f64` part of the C ABI
 // (layout-generic kernels, rocFFT in double).  A DOUBLE_PRECISION program therefore gets: System, Box, Grid, ParticleData (+ sortParticles),
 // ParticleGroup, ParticleSorter, uninitialized_cached_vector, IBM<Kernel> (any kernel, device template), the FCM kernels, FCM_impl,
-// BDHI::FCM, BDHI::PSE, BDHI::EulerMaruyama<Method>, lanczos::Solver.  The classes whose backend exists in single precision only
-// (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, BDHI::Lanczos / Cholesky, BDHI2D, FIB, ICM, Poisson, Comm) are not
+// BDHI::FCM, BDHI::PSE, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver — every class the reference's unit
+// tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) construct.  The classes whose backend exists in single
+// precision only (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, BDHI::Lanczos / Cholesky, FIB, ICM, Comm) are not
 // declared in that build: their forwarding headers stop the compilation with a message instead of silently computing in float.
 //
 // This header is plain host C++14: compile with any C++ compiler,
@@ -2715,6 +2716,7 @@ public:
 }  // namespace BDHI
 
 // ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------
+#endif   // !DOUBLE_PRECISION (the region reopens after BDHI2D, which has both precisions)
 // ---- BDHI::True2D / BDHI::Quasi2D (Integrator/Hydro/BDHI_quasi2D.cuh:155-257): hydrodynamics of particles confined to a plane ------
 namespace BDHI {
 namespace BDHI2D_ns {
@@ -2722,7 +2724,11 @@ struct True2D { static constexpr int id = UAMMD_BDHI2D_TRUE2D; static constexpr 
 struct Quasi2D { static constexpr int id = UAMMD_BDHI2D_QUASI2D; static constexpr bool hasThermalDrift() { return true; } };
 }  // namespace BDHI2D_ns
 template <class HydroKernel> class BDHI2D : public Integrator {
+#if defined(DOUBLE_PRECISION)
+  uammd_bdhi2d_f64 *h = nullptr;
+#else
   uammd_bdhi2d *h = nullptr;
+#endif
   detail::DeviceArray<real2> particleVels;
   Box box;
   real temperature, dt, viscosity;
@@ -2738,16 +2744,29 @@ public:
   BDHI2D(shared_ptr<ParticleGroup> group, Parameters par)
       : Integrator(group, "BDHI::BDHI2D"), particleVels(group->getNumberParticles()), box(make_real3(par.box.boxSize.x, par.box.boxSize.y, 0)),
         temperature(par.temperature), dt(par.dt), viscosity(par.viscosity) {
+#if defined(DOUBLE_PRECISION)
+    uammd_bdhi2d_parameters_f64 p{};
+#else
     uammd_bdhi2d_parameters p{};
+#endif
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y;
     p.hydrodynamicRadius = par.hydrodynamicRadius; p.viscosity = par.viscosity; p.temperature = par.temperature; p.dt = par.dt;
     p.cells[0] = par.cells.x; p.cells[1] = par.cells.y;
     p.seed = sys->rng().next32();  // .cu:28
     p.kernel = HydroKernel::id;
-    if (uammd_bdhi2d_create(&p, &h, cellsOut, &support) != 0) throw std::runtime_error(uammd_hip_last_error());  // "Invalid box" / "Invalid hydrodynamic radius"
+    // "Invalid box" / "Invalid hydrodynamic radius"
+#if defined(DOUBLE_PRECISION)
+    if (uammd_bdhi2d_create_f64(&p, &h, cellsOut, &support) != 0) throw std::runtime_error(uammd_hip_last_error());
+#else
+    if (uammd_bdhi2d_create(&p, &h, cellsOut, &support) != 0) throw std::runtime_error(uammd_hip_last_error());
+#endif
   }
   BDHI2D(const BDHI2D &) = delete;
+#if defined(DOUBLE_PRECISION)
+  ~BDHI2D() { uammd_bdhi2d_destroy_f64(h); }
+#else
   ~BDHI2D() { uammd_bdhi2d_destroy(h); }
+#endif
   int2 getCells() const { return make_int2(cellsOut[0], cellsOut[1]); }
   int getSupport() const { return support; }
   void forwardTime() override {
@@ -2760,19 +2779,28 @@ public:
     {
       auto pos = pd->getPos(access::gpu, access::read);
       auto force = pd->getForce(access::gpu, access::read);
-      detail::check(uammd_bdhi2d_velocities(h, (const float *)detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, st),
-                                            interactors.empty() ? nullptr : (const float *)detail::groupRows((const real4 *)force.raw(), subgroup.get(), forceRows, st),
-                                            N, (float *)particleVels.d, (void *)st));
+      const real4 *posRowsNow = detail::groupRows((const real4 *)pos.raw(), subgroup.get(), posRows, st);
+      const real4 *forceRowsNow = interactors.empty() ? nullptr : detail::groupRows((const real4 *)force.raw(), subgroup.get(), forceRows, st);
+#if defined(DOUBLE_PRECISION)
+      detail::check(uammd_bdhi2d_velocities_f64(h, (const double *)posRowsNow, (const double *)forceRowsNow, N, (double *)particleVels.d, (void *)st));
+#else
+      detail::check(uammd_bdhi2d_velocities(h, (const float *)posRowsNow, (const float *)forceRowsNow, N, (float *)particleVels.d, (void *)st));
+#endif
     }
     auto pos = pd->getPos(access::gpu, access::readwrite);
     real4 *rows = subgroup ? posRows.d : pos.raw();  // (a proper subgroup: the gathered rows above, moved, then written back through the index)
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi2d_update_positions_f64((double *)rows, (const double *)particleVels.d, N, dt, (void *)st));
+#else
     detail::check(uammd_bdhi2d_update_positions((float *)rows, (const float *)particleVels.d, N, dt, (void *)st));
+#endif
     detail::scatterRows((const real4 *)rows, pos.raw(), subgroup.get(), st);
   }
 };
 using True2D = BDHI2D<BDHI2D_ns::True2D>;
 using Quasi2D = BDHI2D<BDHI2D_ns::Quasi2D>;
 }  // namespace BDHI
+#if !defined(DOUBLE_PRECISION)   // (single-precision backends only again, down to Poisson)
 
 // ---- BDHI::FIB (Integrator/BDHI/FIB/FIB.cuh:131-236): fluctuating immersed boundary on a staggered grid ------------------------------
 namespace BDHI {
@@ -2918,10 +2946,17 @@ public:
 };
 }  // namespace Hydro
 
-// ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald ----------------------
+#endif   // !DOUBLE_PRECISION
+
+// ---- Poisson (Interactor/SpectralEwaldPoisson.cuh:83-136): triply periodic electrostatics, spectral Ewald (both precisions) -----
 class Poisson : public Interactor {
+#if defined(DOUBLE_PRECISION)
+  uammd_poisson_f64 *h = nullptr;
+  uammd_poisson_info_f64 info{};
+#else
   uammd_poisson *h = nullptr;
   uammd_poisson_info info{};
+#endif
   detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
   detail::DeviceArray<real> chargeRows, energyRows;
   int numberParticles() const { return subgroup ? subgroup->getNumberParticles() : pd->getNumParticles(); }
@@ -2938,17 +2973,29 @@ public:
   };
   Poisson(shared_ptr<ParticleData> pd, Parameters par) : Poisson(make_shared<ParticleGroup>(pd, "All"), par) {}  // SpectralEwaldPoisson.cuh:103-104
   Poisson(shared_ptr<ParticleGroup> group, Parameters par) : Interactor(group, "IBM::Poisson") {
+#if defined(DOUBLE_PRECISION)
+    uammd_poisson_parameters_f64 p{};
+#else
     uammd_poisson_parameters p{};
+#endif
     p.boxSize[0] = par.box.boxSize.x; p.boxSize[1] = par.box.boxSize.y; p.boxSize[2] = par.box.boxSize.z;
     p.epsilon = par.epsilon; p.tolerance = par.tolerance; p.gw = par.gw; p.split = par.split; p.upsampling = par.upsampling;
+#if defined(DOUBLE_PRECISION)
+    if (uammd_poisson_create_f64(&p, &h, &info) != 0) {
+#else
     if (uammd_poisson_create(&p, &h, &info) != 0) {
+#endif
       const std::string msg = uammd_hip_last_error();
       if (msg.find("[Poisson]") != std::string::npos) throw std::invalid_argument(msg);  // .cu:95-102, :111-116
       throw std::runtime_error(msg);
     }
   }
   Poisson(const Poisson &) = delete;
+#if defined(DOUBLE_PRECISION)
+  ~Poisson() { uammd_poisson_destroy_f64(h); }
+#else
   ~Poisson() { uammd_poisson_destroy(h); }
+#endif
   // far field (always adds q E to the forces AND q phi to the energies, .cu:561-579), then the near-field passes
   void sum(Computables comp, hipStream_t st = 0) override {
     if (comp.virial) throw std::runtime_error("[Poisson] not implemented");
@@ -2959,9 +3006,13 @@ public:
     ParticleGroup *g = subgroup.get();  // a proper subgroup: the members' rows gathered, the sums written back through the group's index
     real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, st));
     real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, st));
-    detail::check(uammd_poisson_sum(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, st),
-                                    detail::groupRows((const real *)charge.raw(), g, chargeRows, st), numberParticles(), (float *)f, e, comp.force,
-                                    comp.energy, (void *)st));
+    const real4 *posNow = detail::groupRows((const real4 *)pos.raw(), g, posRows, st);
+    const real *chargeNow = detail::groupRows((const real *)charge.raw(), g, chargeRows, st);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_poisson_sum_f64(h, (const double *)posNow, chargeNow, numberParticles(), (double *)f, e, comp.force, comp.energy, (void *)st));
+#else
+    detail::check(uammd_poisson_sum(h, (const float *)posNow, chargeNow, numberParticles(), (float *)f, e, comp.force, comp.energy, (void *)st));
+#endif
     detail::scatterRows((const real4 *)f, force.raw(), g, st);
     detail::scatterRows((const real *)e, energy.raw(), g, st);
   }
@@ -2978,9 +3029,13 @@ public:
       ParticleGroup *g = subgroup.get();
       real4 *f = const_cast<real4 *>(detail::groupRows((const real4 *)force.raw(), g, forceRows, nullptr));
       real *e = const_cast<real *>(detail::groupRows((const real *)energy.raw(), g, energyRows, nullptr));
-      detail::check(uammd_poisson_field_potential(h, (const float *)detail::groupRows((const real4 *)pos.raw(), g, posRows, nullptr),
-                                                  detail::groupRows((const real *)charge.raw(), g, chargeRows, nullptr), N, (float *)fp.d, (float *)f, e,
-                                                  nullptr));
+      const real4 *posNow = detail::groupRows((const real4 *)pos.raw(), g, posRows, nullptr);
+      const real *chargeNow = detail::groupRows((const real *)charge.raw(), g, chargeRows, nullptr);
+#if defined(DOUBLE_PRECISION)
+      detail::check(uammd_poisson_field_potential_f64(h, (const double *)posNow, chargeNow, N, (double *)fp.d, (double *)f, e, nullptr));
+#else
+      detail::check(uammd_poisson_field_potential(h, (const float *)posNow, chargeNow, N, (float *)fp.d, (float *)f, e, nullptr));
+#endif
       detail::scatterRows((const real4 *)f, force.raw(), g, nullptr);
       detail::scatterRows((const real *)e, energy.raw(), g, nullptr);
     }
@@ -2992,8 +3047,6 @@ public:
   int getSupport() const { return info.support; }
   real getNearFieldCutOff() const { return info.nearFieldCutOff; }
 };
-
-#endif   // !DOUBLE_PRECISION
 
 namespace lanczos {
 struct MatrixDot {   // misc/LanczosAlgorithm/MatrixDot.h:7-25

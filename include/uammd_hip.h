@@ -811,6 +811,41 @@ int uammd_fcm_displacements_thermal_f64(uammd_fcm_f64 *h, const double *d_pos, c
 /* BDHI::EulerMaruyama_ns::integrateGPUD with real = double (see uammd_bdhi_euler_maruyama) */
 int uammd_bdhi_euler_maruyama_f64(double *d_pos, const int *d_index, const double *d_MF, const double *d_BdW, const double K[9], int numberParticles,
                                   double sqrt2Tdt, double dt, int is2D, void *stream);
+/* BDHI::True2D / BDHI::Quasi2D with real = double (see uammd_bdhi2d_create: Integrator/Hydro/BDHI_quasi2D.cuh:155-257, .cu:61-88, :179-541;
+ * the reference's test/BDHI/quasi2D/quasi2d_test.cu is compiled with -DDOUBLE_PRECISION).  d_pos / d_force real4[N] of doubles, d_vel real2[N]. */
+typedef struct uammd_bdhi2d_f64 uammd_bdhi2d_f64;
+typedef struct {
+  double boxSize[2];
+  double hydrodynamicRadius, viscosity, temperature, dt;
+  int cells[2];
+  unsigned int seed;
+  int kernel; /* UAMMD_BDHI2D_* */
+} uammd_bdhi2d_parameters_f64;
+int uammd_bdhi2d_create_f64(const uammd_bdhi2d_parameters_f64 *par, uammd_bdhi2d_f64 **out, int cells[2], int *support);
+int uammd_bdhi2d_destroy_f64(uammd_bdhi2d_f64 *h);
+int uammd_bdhi2d_velocities_f64(uammd_bdhi2d_f64 *h, const double *d_pos, const double *d_force, int numberParticles, double *d_vel, void *stream);
+int uammd_bdhi2d_update_positions_f64(double *d_pos, const double *d_vel, int numberParticles, double dt, void *stream);
+/* Poisson with real = double (see uammd_poisson_create: Interactor/SpectralEwaldPoisson.cuh:83-136; the reference's
+ * test/Potentials/Poisson/TriplyPeriodic tests are compiled with -DDOUBLE_PRECISION, the quadrupole at tolerance 1e-14 / support 41).  Near
+ * field over all pairs with the minimum image.  d_pos / d_force / d_fieldPotential real4[N] of doubles, d_charge / d_energy real[N]. */
+typedef struct uammd_poisson_f64 uammd_poisson_f64;
+typedef struct {
+  double boxSize[3];
+  double epsilon, tolerance, gw, split, upsampling;
+} uammd_poisson_parameters_f64;
+typedef struct {
+  int cells[3];
+  int support;
+  double nearFieldCutOff;
+  int nTable;
+  double h;
+} uammd_poisson_info_f64;
+int uammd_poisson_create_f64(const uammd_poisson_parameters_f64 *par, uammd_poisson_f64 **out, uammd_poisson_info_f64 *info);
+int uammd_poisson_destroy_f64(uammd_poisson_f64 *h);
+int uammd_poisson_sum_f64(uammd_poisson_f64 *h, const double *d_pos, const double *d_charge, int numberParticles, double *d_force, double *d_energy,
+                          int nearForce, int nearEnergy, void *stream);
+int uammd_poisson_field_potential_f64(uammd_poisson_f64 *h, const double *d_pos, const double *d_charge, int numberParticles, double *d_fieldPotential,
+                                      double *d_force, double *d_energy, void *stream);
 int uammd_pse_far_raw_cells_f64(const double boxSize[3], double psi, double tolerance, int cells_out[3]);
 int uammd_pse_far_create_f64(const double boxSize[3], const int cells[3], double viscosity, double hydrodynamicRadius,
                              double tolerance, double psi, double shearStrain, uammd_fcm_f64 **out, int *support_out,

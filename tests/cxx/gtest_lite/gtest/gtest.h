@@ -1,7 +1,7 @@
 // gtest_lite — a single-header stand-in for the parts of GoogleTest the reference's unit tests use, so that those tests (test/utils,
 // test/misc/ibm, test/misc/lanczos, test/BDHI/FCM, test/BDHI/PSE: written against <gtest/gtest.h> + <gmock/gmock.h>, which the reference
 // fetches from the network at configure time, test/CMakeLists.txt:10-16) compile UNCHANGED against include/uammd and run on the GPU box.
-// Own code (no GoogleTest source): TEST() registration, EXPECT_* / ASSERT_* with streamed messages, ASSERT_THAT / EXPECT_THAT with the
+// Own code (no GoogleTest source): TEST() / TEST_F() registration (fixtures derive from ::testing::Test: SetUp, TearDown), EXPECT_* / ASSERT_* with streamed messages, ASSERT_THAT / EXPECT_THAT with the
 // DoubleNear matcher, gtest-style progress lines, --gtest_filter / --gtest_list_tests, exit status 1 when any test failed.  The header
 // defines main() (the tests link gtest_main in the reference) unless GTEST_LITE_NO_MAIN is defined.
 #ifndef UAMMD_TESTS_GTEST_LITE_H
@@ -149,6 +149,22 @@ public:
 inline DoubleNearMatcher DoubleNear(double expected, double maxAbsError) { return DoubleNearMatcher(expected, maxAbsError); }
 inline DoubleNearMatcher FloatNear(float expected, float maxAbsError) { return DoubleNearMatcher(expected, maxAbsError); }
 
+// the base of a fixture: TEST_F(Fixture, name) runs SetUp(), the body as a member of a class derived from Fixture, TearDown()
+class Test {
+public:
+  virtual ~Test() {}
+protected:
+  virtual void SetUp() {}
+  virtual void TearDown() {}
+  virtual void TestBody() = 0;
+public:
+  void gtlRun() {
+    SetUp();
+    struct AtEnd { Test *t; ~AtEnd() { t->TearDown(); } } atEnd{this};   // (also when the body throws, as GoogleTest does)
+    TestBody();
+  }
+};
+
 inline void InitGoogleTest(int *, char **) {}
 inline void InitGoogleMock(int *, char **) {}
 
@@ -219,6 +235,11 @@ inline int gtlArgc() { return ::testing::internal::argcSlot(); }
 inline char **gtlArgv() { return ::testing::internal::argvSlot(); }
 
 #define GTL_NAME_(suite, name) suite##_##name##_gtl_test
+#define TEST_F(fixture, name)                                                                                 \
+  class GTL_NAME_(fixture, name) : public fixture { void TestBody() override; };                              \
+  static void GTL_NAME_(fixture, name##_run)() { GTL_NAME_(fixture, name) t; t.gtlRun(); }                     \
+  static ::testing::internal::Registrar GTL_NAME_(fixture, name##_registrar)(#fixture, #name, &GTL_NAME_(fixture, name##_run)); \
+  void GTL_NAME_(fixture, name)::TestBody()
 #define TEST(suite, name)                                                                                     \
   static void GTL_NAME_(suite, name)();                                                                       \
   static ::testing::internal::Registrar GTL_NAME_(suite, name##_registrar)(#suite, #name, &GTL_NAME_(suite, name)); \

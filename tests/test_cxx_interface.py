@@ -259,7 +259,12 @@ def test_user_side_saru_matches_the_golden_streams():
 #   utils/ParticleSorter.cu (2)         misc/ibm/test_ibm_regular.cu (7: constant kernel counts, Peskin 1e-10, adjoint 1e-4)
 #   misc/lanczos/test_lanczos.cu (7: identity .. dense SPD up to 511 x 511, 1e-7)   BDHI/FCM/fcm_test.cu (2: Hasimoto 1e-8 at 288^3)
 #   BDHI/PSE/pse_test.cu (4: Hasimoto 1e-8, self diffusion 1e-2)
-REF_GTESTS = {"ParticleSorter": 2, "test_ibm_regular": 7, "test_lanczos": 7, "fcm_test": 2, "pse_test": 4}
+# and, for the other consumers of the spread / FFT / gather engine (their double-precision builds are csrc/f64.hip):
+#   BDHI/quasi2D/quasi2d_test.cu (5: self mobility of True2D / Quasi2D at seven box sizes 1e-3, fluctuation-dissipation 1e-2)
+#   Potentials/Poisson/TriplyPeriodic/test_poisson.cu (2: three charges against the analytic field 1e-3; L -> infinity extrapolation over
+#   109 box sizes x 6 distances 1e-4)      .../test_tp_quadrupole.cu (1: point quadrupole, tolerance 1e-14, window support 41: field 1e-8)
+REF_GTESTS = {"ParticleSorter": 2, "test_ibm_regular": 7, "test_lanczos": 7, "fcm_test": 2, "pse_test": 4, "quasi2d_test": 5, "test_poisson": 2,
+              "test_tp_quadrupole": 1}
 
 
 @pytest.mark.gpu
@@ -275,9 +280,13 @@ def test_reference_unit_tests_run(name, tmp_path):
     ran = re.search(r"\[==========\] (\d+) tests ran", out)
     assert ran and int(ran.group(1)) == REF_GTESTS[name], "not every TEST of the file ran"
     failed = re.findall(r"^\[  FAILED  \] (\S+)$", out, flags=re.M)
-    if failed and all("SelfDiffusion" in f for f in set(failed)):
-        # <dx^2> over 1000 draws against 2 T M0 with an absolute bar of 1e-2 is a 2.6-sigma criterion per component, and System seeds
-        # itself from the clock (System.h:90-96), as in the reference: one repetition of exactly those TESTs
+    # Statistical TESTs, seeded from the clock as in the reference (System.h:90-96; std::random_device in quasi2d_test.cu): pse_test's
+    # <dx^2> over 1000 draws against 2 T M0 with an absolute bar of 1e-2 is a 2.6-sigma criterion per component (one repetition);
+    # quasi2d_test's 50000 one-step variances against 1 % are a 1.6-sigma criterion per component (sqrt(2 / 50000) = 0.63 %: a run fails
+    # one time in five with a correct sampler — measured: five of six passed): up to three repetitions of exactly those TESTs.
+    repeats = 3 if name == "quasi2d_test" else 1
+    while failed and repeats > 0 and all("SelfDiffusion" in f or "FluctuationDissipation" in f for f in set(failed)):
+        repeats -= 1
         r = subprocess.run([exe, "--gtest_filter=" + ":".join(sorted(set(failed)))], cwd=tmp_path, capture_output=True, text=True, timeout=1200)
         out = r.stdout + r.stderr
         print(out[-3000:])

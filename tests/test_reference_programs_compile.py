@@ -42,7 +42,10 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
 # and, for the dense products test_lanczos.cu makes with cuBLAS itself, the hipBLAS spellings.  examples/Makefile BUILDS them and
 # tests/test_cxx_interface.py::test_reference_unit_tests_run RUNS them on the GPU.
 GTEST = ["../test/utils/ParticleSorter.cu", "../test/misc/ibm/test_ibm_regular.cu", "../test/misc/lanczos/test_lanczos.cu",
-         "../test/BDHI/FCM/fcm_test.cu", "../test/BDHI/PSE/pse_test.cu"]
+         "../test/BDHI/FCM/fcm_test.cu", "../test/BDHI/PSE/pse_test.cu",
+         # the other consumers of the engine: BDHI::True2D / Quasi2D and the triply periodic Poisson solver
+         "../test/BDHI/quasi2D/quasi2d_test.cu", "../test/Potentials/Poisson/TriplyPeriodic/test_poisson.cu",
+         "../test/Potentials/Poisson/TriplyPeriodic/test_tp_quadrupole.cu"]
 # Not in the corpus, and why: advanced/ParameterUpdatable.cu says cuda::std::plus (libcu++, a CUDA toolkit library, not UAMMD),
 # advanced/execution_policy.cu includes <cuda_profiler_api.h>; integration_schemes/icm.cu needs Hydro/ICM_Compressible (out of
 # scope), as do the programs on modules outside SURVEY 8 (Bonds, DoublyPeriodic, SPH, MCNVT, LBM, generic_simulation);
@@ -73,7 +76,8 @@ def _compile(job):
     elif kind == "gtest":
         src, _ = _source(rel, tmp, ".hip")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DDOUBLE_PRECISION", "-DMAXLOGLEVEL=1", "-include", "hipblas/hipblas.h",
-               "-I", os.path.dirname(os.path.join(REF, rel)), "-I", os.path.join(ROOT, "tests", "cxx", "gtest_lite")] + INC + [src]
+               "-I", os.path.dirname(os.path.join(REF, rel)), "-I", os.path.join(REF, "../test/Potentials/Poisson/common"),
+               "-I", os.path.join(ROOT, "tests", "cxx", "gtest_lite")] + INC + [src]
     else:
         src, _ = _source(rel, tmp, ".hip")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fsyntax-only", "-I", os.path.dirname(os.path.join(REF, rel))] + INC + [src]

@@ -57,9 +57,23 @@ class BDHI2DParameters(C.Structure):
                 ("dt", C.c_float), ("cells", C.c_int * 2), ("seed", C.c_uint), ("kernel", C.c_int)]
 
 
+class BDHI2DParametersF64(C.Structure):
+    _fields_ = [("boxSize", C.c_double * 2), ("hydrodynamicRadius", C.c_double), ("viscosity", C.c_double), ("temperature", C.c_double),
+                ("dt", C.c_double), ("cells", C.c_int * 2), ("seed", C.c_uint), ("kernel", C.c_int)]
+
+
 class PoissonParameters(C.Structure):
     _fields_ = [("boxSize", C.c_float * 3), ("epsilon", C.c_float), ("tolerance", C.c_float), ("gw", C.c_float),
                 ("split", C.c_float), ("upsampling", C.c_float)]
+
+
+class PoissonParametersF64(C.Structure):
+    _fields_ = [("boxSize", C.c_double * 3), ("epsilon", C.c_double), ("tolerance", C.c_double), ("gw", C.c_double),
+                ("split", C.c_double), ("upsampling", C.c_double)]
+
+
+class PoissonInfoF64(C.Structure):
+    _fields_ = [("cells", C.c_int * 3), ("support", C.c_int), ("nearFieldCutOff", C.c_double), ("nTable", C.c_int), ("h", C.c_double)]
 
 
 class PoissonInfo(C.Structure):
@@ -206,6 +220,14 @@ SIGNATURES = {
     "uammd_bdhi2d_velocities": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "uammd_bdhi2d_update_positions": (_i, [_vp, _vp, _i, _f, _vp]),
     "uammd_bdhi2d_get_counter": (_i, [_vp, C.POINTER(_u)]),
+    "uammd_poisson_create_f64": (_i, [C.POINTER(PoissonParametersF64), C.POINTER(_vp), C.POINTER(PoissonInfoF64)]),
+    "uammd_poisson_destroy_f64": (_i, [_vp]),
+    "uammd_poisson_sum_f64": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "uammd_poisson_field_potential_f64": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi2d_create_f64": (_i, [C.POINTER(BDHI2DParametersF64), C.POINTER(_vp), C.POINTER(C.c_int * 2), C.POINTER(_i)]),
+    "uammd_bdhi2d_destroy_f64": (_i, [_vp]),
+    "uammd_bdhi2d_velocities_f64": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "uammd_bdhi2d_update_positions_f64": (_i, [_vp, _vp, _i, _d, _vp]),
     "uammd_poisson_create": (_i, [C.POINTER(PoissonParameters), C.POINTER(_vp), C.POINTER(PoissonInfo)]),
     "uammd_poisson_destroy": (_i, [_vp]),
     "uammd_poisson_set_option": (_i, [_vp, C.c_char_p, _i]),

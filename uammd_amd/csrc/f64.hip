@@ -60,6 +60,10 @@ UH_D double phi64_axis(const Kern64 &k, int axis, double r) {
     case kKernelGaussian: return (r >= k.rmax) ? 0.0 : k.prefactor * exp(k.tau * r * r);  // FCM_kernels.cuh:55-57
     case kKernelPeskin3: return phi64_peskin3(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
     case kKernelPeskin4: return phi64_peskin4(axis == 0 ? k.invhx : (axis == 1 ? k.invhy : k.invhz), r);
+    // BDHI2D_ns::Gaussian / GaussianThermalDrift<dir> (Integrator/Hydro/BDHI_quasi2D.cuh:112-153); phiZ = 1 (k_ibm64)
+    case kKernelGauss2D: return k.prefactor * exp(k.tau * r * r);
+    case kKernelGauss2DDriftX: return k.prefactor * exp(k.tau * r * r) * (axis == 0 ? r : 1.0);
+    case kKernelGauss2DDriftY: return k.prefactor * exp(k.tau * r * r) * (axis == 1 ? r : 1.0);
     default: return 1.0;  // the constant window of the reference's test (test_ibm_regular.cu:11-14)
   }
 }
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(256) k_ibm64(const double *__restrict__ pos, i
     } else {
       const int cz = g.pbc_z(celli.z + (t - sx - sy) - P.z);
       if (cz >= 0) v = phi64_axis(kern, 2, g.distanceToCellCenter(pi, make_int3(celli.x, celli.y, cz)).z);
-      if (is2D && (kern.kind == kKernelPeskin3 || kern.kind == kKernelPeskin4)) v = 1.0;  // test_ibm_regular.cu:83-85
+      if (is2D && (kern.kind == kKernelPeskin3 || kern.kind == kKernelPeskin4 || kern.kind >= kKernelGauss2D)) v = 1.0;  // test_ibm_regular.cu:83-85
     }
     w[t] = v;
   }
@@ -390,6 +394,362 @@ struct PSENear64 {
   int nPointsTable = 0;
   double rcut = 0, L[3] = {0, 0, 0};
 };
+
+
+// ---- BDHI::True2D / BDHI::Quasi2D with real = double (Integrator/Hydro/BDHI_quasi2D.cu:61-88, :179-541; the single-precision build and
+// the account of the gather-form noise: quasi2d.hip).  Spread and gather are k_ibm64<2, .> on the two component planes. ----
+UH_D double2 hydro_kernel64(int mode, double k2, double a) {   // BDHI2D_ns::True2D / Quasi2D::operator(), .cuh:88-92, :100-109
+  if (mode == UAMMD_BDHI2D_TRUE2D) return make_double2(0.0, 1.0 / (k2 * k2));
+  const double k = sqrt(k2);
+  const double invk3 = 1.0 / (k2 * k);
+  const double inv_sqrtpi = 0.564189583547756;
+  const double kp = k * a * inv_sqrtpi;
+  const double fk = 0.5 * invk3 * (erfc(kp) * (0.5 + kp * kp) * exp(kp * kp) - kp * inv_sqrtpi);
+  const double gk = 0.5 * invk3 * erfc(kp) * exp(kp * kp);
+  return make_double2(fk, gk);
+}
+UH_D double2 wave_number64(int ix, int iy, int nx, int ny, double Lx, double Ly) {  // cellToWaveNumber, .cu:314-320
+  const double px = (2.0 * M_PI) / Lx, py = (2.0 * M_PI) / Ly;
+  return make_double2((double)(ix - nx * (ix >= (nx / 2 + 1))) * px, (double)(iy - ny * (iy >= (ny / 2 + 1))) * py);
+}
+UH_D double2 project2d64(double2 k, double2 f, double fk, double gk) {  // projectFourier for one real 2-vector, .cu:324-343
+  const double dperp = fma(f.y, -k.x, f.x * k.y);
+  const double dpar = fma(f.y, k.y, f.x * k.x);
+  return make_double2(fma(k.x * fk, dpar, k.y * gk * dperp), fma(k.y * fk, dpar, -k.x * gk * dperp));
+}
+struct Cplx2d { double xr, xi, yr, yi; };
+// the noise term of an OWNER node (fourierBrownianNoise, .cu:368-432); the draws are Saru's single-precision Gaussians promoted to double
+UH_D Cplx2d noise_factor2d64(int id, int ix, int iy, int nx, int ny, double Lx, double Ly, int mode, double a, double prefactor, uint seed,
+                             uint step) {
+  const bool isXnyquist = (ix == (nx - ix)) && (nx % 2 == 0);
+  const bool isYnyquist = (iy == (ny - iy)) && (ny % 2 == 0);
+  const bool isNyquist = (isYnyquist && ix == 0) || (isXnyquist && isYnyquist);
+  Saru saru((uint)id, step, seed);
+  const float sc = (float)(0.707106781186547 * prefactor);
+  const float2 a1 = saru.gf(0.0f, sc), a2 = saru.gf(0.0f, sc);
+  double2 n1 = make_double2(a1.x, a1.y), n2 = make_double2(a2.x, a2.y);
+  if (isNyquist) {
+    n1.x *= 1.41421356237310; n2.x *= 1.41421356237310;
+    n1.y = 0.0; n2.y = 0.0;
+  }
+  const double2 k = wave_number64(ix, iy, nx, ny, Lx, Ly);
+  const double k2 = fma(k.y, k.y, k.x * k.x);
+  const double2 fg = hydro_kernel64(mode, k2, a);
+  const double fs = sqrt(fg.x), gs = sqrt(fg.y);
+  Cplx2d f;
+  f.xr = fma(fs * n2.x, k.x, gs * n1.x * k.y); f.xi = fma(fs * n2.y, k.x, gs * n1.y * k.y);
+  f.yr = fma(fs * n2.x, k.y, gs * n1.x * (-k.x)); f.yi = fma(fs * n2.y, k.y, gs * n1.y * (-k.x));
+  return f;
+}
+// forceFourier2Vel + fourierBrownianNoise in gather form on the two component planes, complex[ny][nkx] each
+__global__ void __launch_bounds__(256) k_q2d_kspace64(double2 *__restrict__ gx, double2 *__restrict__ gy, int nx, int ny, double Lx, double Ly,
+                                                      int mode, double a, double viscosity, bool deterministic, double noisePrefactor,
+                                                      uint seed, uint step) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int nkx = nx / 2 + 1;
+  if (id >= ny * nkx) return;
+  const int ix = id % nkx, iy = id / nkx;
+  Cplx2d v{0, 0, 0, 0};
+  if (id != 0) {
+    if (deterministic) {
+      const double2 k = wave_number64(ix, iy, nx, ny, Lx, Ly);
+      const double k2 = fma(k.y, k.y, k.x * k.x);
+      const double2 fg = hydro_kernel64(mode, k2, a);
+      const double fk = fg.x / (viscosity * (double)(nx * ny)), gk = fg.y / (viscosity * (double)(nx * ny));
+      const double2 fx = gx[id], fy = gy[id];
+      const double2 vr = project2d64(k, make_double2(fx.x, fy.x), fk, gk), vi = project2d64(k, make_double2(fx.y, fy.y), fk, gk);
+      v = Cplx2d{vr.x, vi.x, vr.y, vi.y};
+    }
+    if (noisePrefactor != 0.0) {
+      const bool selfConjColumn = ix == 0 || ix == nx - ix;
+      if (selfConjColumn && iy > ny - iy) {   // owned by the conjugate partner (ix, ny - iy): its factor, conjugated (.cu:422-428)
+        const int jy = ny - iy;
+        const Cplx2d f = noise_factor2d64(ix + nkx * jy, ix, jy, nx, ny, Lx, Ly, mode, a, noisePrefactor, seed, step);
+        v.xr += f.xr; v.xi += -f.xi; v.yr += f.yr; v.yi += -f.yi;
+      } else {
+        const bool isXnyquist = (ix == (nx - ix)) && (nx % 2 == 0);
+        if (isXnyquist && iy == 0) v = Cplx2d{0, 0, 0, 0};  // .cu:393-395: this node's deterministic part is wiped
+        const Cplx2d f = noise_factor2d64(id, ix, iy, nx, ny, Lx, Ly, mode, a, noisePrefactor, seed, step);
+        v.xr += f.xr; v.xi += f.xi; v.yr += f.yr; v.yi += f.yi;
+      }
+    }
+  }
+  gx[id] = make_double2(v.xr, v.xi);
+  gy[id] = make_double2(v.yr, v.yi);
+}
+// euler_functor (.cu:509-541): pos += make_real4(vel * dt)
+__global__ void __launch_bounds__(256) k_q2d_update64(double *__restrict__ pos, const double2 *__restrict__ vel, int N, double dt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const double2 v = vel[i];
+  pos[4 * (size_t)i] = fma(v.x, dt, pos[4 * (size_t)i]);
+  pos[4 * (size_t)i + 1] = fma(v.y, dt, pos[4 * (size_t)i + 1]);
+}
+struct BDHI2D64 {
+  uammd_bdhi2d_parameters_f64 par{};
+  GridT<double> grid{};
+  Kern64 kern{}, kernDriftX{}, kernDriftY{};
+  int nxpad = 0;
+  size_t planeReal = 0, planeCplx = 0;
+  DeviceBuffer gridBuf, work, drift;   // drift: the thermal drift's constant "quantities" {-T, 0} and {0, -T}
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  unsigned int counter = 0;
+  ~BDHI2D64() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+int next_fft_wise_axis(int n);   // quasi2d.hip
+static int q2d64_plans(BDHI2D64 *q) {
+  if (int e = rocfft_setup_once()) return e;
+  const size_t nx = q->grid.cellDim.x, ny = q->grid.cellDim.y, nkx = nx / 2 + 1;
+  const size_t len[2] = {nx, ny};
+  const size_t rstr[2] = {1, (size_t)q->nxpad}, cstr[2] = {1, nkx};
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 2, rstr,
+                                                      q->planeReal, 2, cstr, q->planeCplx));
+  UH_ROCFFT64(rocfft_plan_create(&q->fwd, rocfft_placement_inplace, rocfft_transform_type_real_forward, rocfft_precision_double, 2, len, 2, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr, 2, cstr,
+                                                      q->planeCplx, 2, rstr, q->planeReal));
+  UH_ROCFFT64(rocfft_plan_create(&q->inv, rocfft_placement_inplace, rocfft_transform_type_real_inverse, rocfft_precision_double, 2, len, 2, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  size_t wf = 0, wi = 0;
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(q->fwd, &wf));
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(q->inv, &wi));
+  const size_t w = std::max(wf, wi);
+  UH_ROCFFT64(rocfft_execution_info_create(&q->info));
+  if (w) {
+    if (int e = q->work.reserve(w)) return e;
+    UH_ROCFFT64(rocfft_execution_info_set_work_buffer(q->info, q->work.ptr, w));
+  }
+  return 0;
+}
+
+
+// ---- Poisson with real = double (Interactor/SpectralEwaldPoisson.cu:15-62 closed forms, :71-160 set-up, :222-329 near field, :332-360 and
+// :410-559 far field; the single-precision build with its tile-owned spread and column gather: poisson.hip).  Spread and gather are
+// k_ibm64 on planar grids; the near field runs over ALL pairs with the minimum image (the reference's own precondition: cut-off <= L/2,
+// .cu:111-116) — the double-precision tests hold three charges or a thousand. ----
+static double greens64(double r2, double gw, double split, double epsilon) {  // .cu:15-38
+  double G = 0;
+  if (r2 > gw * gw * gw * gw) {
+    const double r = std::sqrt(r2);
+    const double farw = std::sqrt(4 * gw * gw + 1 / (split * split));
+    G = (1.0 / (4.0 * M_PI * epsilon * r) * (std::erf(r / (2 * gw)) - std::erf(r / farw)));
+  } else {
+    const double pi32 = std::pow(M_PI, 1.5);
+    const double gw2 = gw * gw;
+    const double invsp2 = 1.0 / (split * split);
+    const double selfterm = 1.0 / (4 * pi32 * gw) - 1.0 / (2 * pi32 * std::sqrt(4 * gw2 + invsp2));
+    const double r2term = 1.0 / (6.0 * pi32 * std::pow(4.0 * gw2 + invsp2, 1.5)) - 1.0 / (48.0 * pi32 * gw2 * gw);
+    const double r4term = 1.0 / (640.0 * pi32 * gw2 * gw2 * gw) - 1.0 / (20.0 * pi32 * std::pow(4 * gw2 + invsp2, 2.5));
+    G = 1.0 / epsilon * (selfterm + r2 * r2term + r2 * r2 * r4term);
+  }
+  return G;
+}
+static double greens_field64(double r, double gw, double split, double epsilon) {  // .cu:40-62
+  const double r2 = r * r;
+  const double gw2 = gw * gw;
+  const double newgw = std::sqrt(gw2 + 1 / (4.0 * split * split));
+  const double newgw2 = newgw * newgw;
+  double fmod = 0;
+  if (r2 > gw * gw * gw * gw) {
+    const double invrterm = std::exp(-0.25 * r2 / newgw2) / std::sqrt(M_PI * newgw2) - std::exp(-0.25 * r2 / gw2) / std::sqrt(M_PI * gw2);
+    const double invr2term = std::erf(0.5 * r / newgw) - std::erf(0.5 * r / gw);
+    fmod += 1 / (4 * M_PI) * (invrterm / r - invr2term / r2);
+  } else if (r2 > 0) {
+    const double pi32 = std::pow(M_PI, 1.5);
+    const double rterm = 1 / (24 * pi32) * (1.0 / (gw2 * gw) - 1 / (newgw2 * newgw));
+    const double r3term = 1 / (160 * pi32) * (1.0 / (newgw2 * newgw2 * newgw) - 1.0 / (gw2 * gw2 * gw));
+    fmod += r * rterm + r2 * r * r3term;
+  }
+  return fmod / epsilon;
+}
+struct Table64 {
+  const double *table;
+  int Nm1;
+  double rmax, interval, dr;
+};
+// TabulatedFunction::operator() with LinearInterpolation (misc/TabulatedFunction.cuh:63-75, :148-157), rmin = 0
+UH_D double table_get64(const Table64 &t, double rs) {
+  const double r = rs * t.interval;
+  if (rs >= t.rmax) return 0.0;
+  if (r <= 0.0) return t.table[0];
+  const int i = (int)(r * (double)t.Nm1);
+  const double r0 = (double)i * t.dr;
+  const double v0 = t.table[i], v1 = t.table[i + 1];
+  const double w = (r - r0) * (double)t.Nm1;
+  return fma(w, v1, fma(-w, v0, v0));
+}
+// chargeFourier2FieldAndPotential (.cu:433-476); planes: Ex, Ey, Ez, phi, each complex[nz][ny][nkx]
+__global__ void __launch_bounds__(256) k_poisson_convolve64(const double2 *__restrict__ qk, double2 *__restrict__ planes, size_t planeCplx, int3 n,
+                                                            real3d L, double epsilon) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int nkx = n.x / 2 + 1;
+  if (id >= (size_t)nkx * n.y * n.z) return;
+  const int cx = (int)(id % nkx), cy = (int)((id / nkx) % n.y), cz = (int)(id / ((size_t)nkx * n.y));
+  const double2 zero = make_double2(0.0, 0.0);
+  double2 ex = zero, ey = zero, ez = zero, ph = zero;
+  const bool xn = (cx == n.x - cx) && (n.x % 2 == 0), yn = (cy == n.y - cy) && (n.y % 2 == 0), zn = (cz == n.z - cz) && (n.z % 2 == 0);
+  const bool nyquist = (xn && cy == 0 && cz == 0) || (xn && yn && cz == 0) || (cx == 0 && yn && cz == 0) || (xn && cy == 0 && zn) ||
+                       (cx == 0 && cy == 0 && zn) || (cx == 0 && yn && zn) || (xn && yn && zn);
+  if (!(cx == 0 && cy == 0 && cz == 0) && !nyquist) {
+    const double px = (2.0 * M_PI) / L.x, py = (2.0 * M_PI) / L.y, pz = (2.0 * M_PI) / L.z;
+    double kx = (double)cx * px, ky = (double)cy * py, kz = (double)cz * pz;
+    if (cx >= n.x / 2 + 1) kx -= (double)n.x * px;
+    if (cy >= n.y / 2 + 1) ky -= (double)n.y * py;
+    if (cz >= n.z / 2 + 1) kz -= (double)n.z * pz;
+    const double k2 = fma(kz, kz, fma(ky, ky, kx * kx));
+    const double2 fk = qk[id];
+    const double B = 1.0 / (k2 * epsilon * ((double)n.x * (double)n.y * (double)n.z));
+    ex = make_double2(kx * fk.y * B, -kx * fk.x * B);
+    ey = make_double2(ky * fk.y * B, -ky * fk.x * B);
+    ez = make_double2(kz * fk.y * B, -kz * fk.x * B);
+    ph = make_double2(fk.x * B, fk.y * B);
+  }
+  planes[id] = ex;
+  planes[planeCplx + id] = ey;
+  planes[2 * planeCplx + id] = ez;
+  planes[3 * planeCplx + id] = ph;
+}
+// UnZip2Real4 (.cu:529-559) after the gather: force += q E, energy += q phi, fieldPotential += (E, phi)
+__global__ void __launch_bounds__(256) k_poisson_unzip64(const double *__restrict__ gathered, const double *__restrict__ charge, int N,
+                                                         double *__restrict__ force, double *__restrict__ energy, double *__restrict__ fieldPotential) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const double ex = gathered[4 * (size_t)i], ey = gathered[4 * (size_t)i + 1], ez = gathered[4 * (size_t)i + 2], ph = gathered[4 * (size_t)i + 3];
+  const double q = charge[i];
+  if (force) { force[4 * (size_t)i] += q * ex; force[4 * (size_t)i + 1] += q * ey; force[4 * (size_t)i + 2] += q * ez; }
+  if (energy) energy[i] += q * ph;
+  if (fieldPotential) {
+    fieldPotential[4 * (size_t)i] += ex; fieldPotential[4 * (size_t)i + 1] += ey; fieldPotential[4 * (size_t)i + 2] += ez; fieldPotential[4 * (size_t)i + 3] += ph;
+  }
+}
+// NearField{Force,Energy,FieldPotential}Transverser (.cu:222-329) over all pairs, the self pair included.  MODE 0: force4 += (total, 0);
+// 1: energy += total; 2: fieldPotential4 += (E, phi)
+template <int MODE>
+__global__ void __launch_bounds__(128) k_poisson_near64(const double *__restrict__ pos, const double *__restrict__ charge, int N, real3d L,
+                                                        Table64 tabF, Table64 tabP, double *__restrict__ out) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  const real3d pi{pos[4 * (size_t)i], pos[4 * (size_t)i + 1], pos[4 * (size_t)i + 2]};
+  const double qi = charge[i];
+  double tx = 0, ty = 0, tz = 0, tw = 0;
+  for (int j = 0; j < N; ++j) {
+    const double qj = charge[j];
+    real3d rij{pos[4 * (size_t)j] - pi.x, pos[4 * (size_t)j + 1] - pi.y, pos[4 * (size_t)j + 2] - pi.z};
+    rij.x -= floor(rij.x / L.x + 0.5) * L.x;   // Box::apply_pbc (utils/Box.cuh:51-58)
+    rij.y -= floor(rij.y / L.y + 0.5) * L.y;
+    rij.z -= floor(rij.z / L.z + 0.5) * L.z;
+    const double r2 = dot3(rij, rij);
+    if (MODE == 1) tw += qi * qj * table_get64(tabP, r2);
+    else if (MODE == 0) {
+      const double r = sqrt(r2);
+      const double fmod = -qi * qj * table_get64(tabF, r);
+      if (r2 > 0.0) { const double invr = 1.0 / r; tx += invr * (fmod * rij.x); ty += invr * (fmod * rij.y); tz += invr * (fmod * rij.z); }
+    } else {
+      tw += qj * table_get64(tabP, r2);
+      if (r2 > 0.0) {
+        const double r = sqrt(r2);
+        const double fmod = -qj * table_get64(tabF, r);
+        const double invr = 1.0 / r;
+        tx += invr * (fmod * rij.x); ty += invr * (fmod * rij.y); tz += invr * (fmod * rij.z);
+      }
+    }
+  }
+  if (MODE == 1) out[i] += tw;
+  else {
+    out[4 * (size_t)i] += tx; out[4 * (size_t)i + 1] += ty; out[4 * (size_t)i + 2] += tz;
+    if (MODE == 2) out[4 * (size_t)i + 3] += tw;
+  }
+}
+struct Poisson64 {
+  uammd_poisson_parameters_f64 par{};
+  double L[3] = {0, 0, 0};
+  int cells[3] = {0, 0, 0};
+  GridT<double> grid{};
+  Kern64 kern{};
+  int nxpad = 0;
+  size_t planeReal = 0, planeCplx = 0;
+  double cutoff = 0;
+  int ntable = 0;
+  DeviceBuffer tableField, tablePotential, gridQ, planes, gathered, work;
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  ~Poisson64() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+static int poisson64_plans(Poisson64 *p) {
+  if (int e = rocfft_setup_once()) return e;
+  const size_t nx = p->cells[0], ny = p->cells[1], nz = p->cells[2], nkx = nx / 2 + 1;
+  const size_t lengths[3] = {nx, ny, nz};
+  const size_t rstr[3] = {1, (size_t)p->nxpad, (size_t)p->nxpad * ny}, cstr[3] = {1, nkx, nkx * ny};
+  rocfft_plan_description d = nullptr;
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr, 3, rstr,
+                                                      p->planeReal, 3, cstr, p->planeCplx));
+  UH_ROCFFT64(rocfft_plan_create(&p->fwd, rocfft_placement_inplace, rocfft_transform_type_real_forward, rocfft_precision_double, 3, lengths, 1, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  UH_ROCFFT64(rocfft_plan_description_create(&d));
+  UH_ROCFFT64(rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr, 3, cstr,
+                                                      p->planeCplx, 3, rstr, p->planeReal));
+  UH_ROCFFT64(rocfft_plan_create(&p->inv, rocfft_placement_inplace, rocfft_transform_type_real_inverse, rocfft_precision_double, 3, lengths, 4, d));
+  UH_ROCFFT64(rocfft_plan_description_destroy(d));
+  size_t wf = 0, wi = 0;
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(p->fwd, &wf));
+  UH_ROCFFT64(rocfft_plan_get_work_buffer_size(p->inv, &wi));
+  const size_t w = std::max(wf, wi);
+  UH_ROCFFT64(rocfft_execution_info_create(&p->info));
+  if (w) {
+    if (int e = p->work.reserve(w)) return e;
+    UH_ROCFFT64(rocfft_execution_info_set_work_buffer(p->info, p->work.ptr, w));
+  }
+  return 0;
+}
+static Table64 view64(const DeviceBuffer &b, int ntable, double rmax) {
+  return Table64{(const double *)b.ptr, ntable - 1, rmax, 1.0 / rmax, 1.0 / (double)(ntable - 1)};
+}
+// farField (.cu:332-360): any of d_force / d_energy / d_fieldPotential may be null
+static int poisson64_far(Poisson64 *p, const double *d_pos, const double *d_charge, int N, double *d_force, double *d_energy, double *d_fieldPotential,
+                         hipStream_t st) {
+  double *gq = (double *)p->gridQ.ptr;
+  const FastDiv dsx = make_fastdiv(p->kern.support.x), dsxy = make_fastdiv(p->kern.support.x * p->kern.support.y);
+  const dim3 gp((N + 3) / 4), bp(256);
+  UH_CHECK(hipMemsetAsync(gq, 0, sizeof(double) * p->planeReal, st));
+  hipLaunchKernelGGL((k_ibm64<1, true>), gp, bp, 0, st, d_pos, 4, d_charge, 1, (double *)nullptr, gq, N, p->grid, p->nxpad, (size_t)1, (size_t)1, p->kern,
+                     dsx, dsxy, false, false);
+  UH_ROCFFT64(rocfft_execution_info_set_stream(p->info, (void *)st));
+  void *bq[1] = {gq};
+  UH_ROCFFT64(rocfft_execute(p->fwd, bq, nullptr, p->info));
+  const int3 n = p->grid.cellDim;
+  const size_t total = p->planeCplx;
+  hipLaunchKernelGGL(k_poisson_convolve64, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double2 *)gq, (double2 *)p->planes.ptr,
+                     p->planeCplx, n, real3d{p->L[0], p->L[1], p->L[2]}, p->par.epsilon);
+  void *bpl[1] = {p->planes.ptr};
+  UH_ROCFFT64(rocfft_execute(p->inv, bpl, nullptr, p->info));
+  if (int e = p->gathered.reserve(sizeof(double) * 4 * (size_t)N)) return e;
+  hipLaunchKernelGGL((k_ibm64<4, false>), gp, bp, 0, st, d_pos, 4, (const double *)nullptr, 4, (double *)p->gathered.ptr, (double *)p->planes.ptr, N, p->grid,
+                     p->nxpad, (size_t)1, p->planeReal, p->kern, dsx, dsxy, false, true);
+  hipLaunchKernelGGL(k_poisson_unzip64, dim3((N + 255) / 256), dim3(256), 0, st, (const double *)p->gathered.ptr, d_charge, N, d_force, d_energy,
+                     d_fieldPotential);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+template <int MODE> static int poisson64_near(Poisson64 *p, const double *d_pos, const double *d_charge, int N, double *d_out, hipStream_t st) {
+  hipLaunchKernelGGL((k_poisson_near64<MODE>), dim3((N + 127) / 128), dim3(128), 0, st, d_pos, d_charge, N, real3d{p->L[0], p->L[1], p->L[2]},
+                     view64(p->tableField, p->ntable, p->cutoff), view64(p->tablePotential, p->ntable, p->cutoff * p->cutoff), d_out);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+int next_fft_wise_axis(int n);   // quasi2d.hip
 
 static double fcm_upsampling64(double tolerance) {  // FCM_kernels.cuh:24-30
   const double amin = 0.55, amax = 1.65;
@@ -711,6 +1071,243 @@ int uammd_bdhi_euler_maruyama_f64(double *d_pos, const int *d_index, const doubl
   hipLaunchKernelGGL(k_bdhi_euler_maruyama64, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_pos, d_index, d_MF, d_BdW, k, K != nullptr, N,
                      sqrt2Tdt, dt, is2D != 0);
   UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- BDHI::True2D / Quasi2D, real = double (the single-precision entry points: quasi2d.hip) ---------------------------------------------
+int uammd_bdhi2d_create_f64(const uammd_bdhi2d_parameters_f64 *par, uammd_bdhi2d_f64 **out, int cells[2], int *support) {
+  if (!par || !out || (par->kernel != UAMMD_BDHI2D_TRUE2D && par->kernel != UAMMD_BDHI2D_QUASI2D)) {
+    set_last_error("uammd_bdhi2d_create_f64: bad arguments");
+    return -1;
+  }
+  if (par->boxSize[0] == 0.0 && par->boxSize[1] == 0.0) { set_last_error("Invalid box"); return -2; }              // .cu:46-52
+  if (!(par->hydrodynamicRadius > 0)) { set_last_error("Invalid hydrodynamic radius"); return -2; }                // .cu:53-57
+  if (!(par->viscosity > 0) || !(par->boxSize[0] > 0) || !(par->boxSize[1] > 0)) { set_last_error("uammd_bdhi2d_create_f64: bad arguments"); return -1; }
+  BDHI2D64 *q = new (std::nothrow) BDHI2D64();
+  if (!q) { set_last_error("uammd_bdhi2d_create_f64: out of host memory"); return -3; }
+  q->par = *par;
+  const double a = par->hydrodynamicRadius;
+  int cd[2] = {par->cells[0], par->cells[1]};
+  if (cd[0] <= 0) {  // initializeGrid, .cu:61-73
+    const double h = a * 0.8;
+    cd[0] = next_fft_wise_axis((int)(par->boxSize[0] / h));
+    cd[1] = next_fft_wise_axis((int)(par->boxSize[1] / h));
+  }
+  const double L3[3] = {par->boxSize[0], par->boxSize[1], 0.0};
+  const int per[3] = {1, 1, 0};
+  q->grid = make_grid<double>(make_box<double>(L3, per), make_int3(cd[0], cd[1], 1));
+  int s = ((int)(3.0 * a * cd[0] / par->boxSize[0]) + 1) * 2 + 1;  // initializeInterpolationKernel, .cu:75-88
+  if (s > cd[0]) s = cd[0];
+  if (s > kMaxSupport || s > cd[1]) {
+    set_last_error("uammd_bdhi2d_create_f64: window support %d is larger than the grid or than the %d nodes per axis one wave evaluates", s, kMaxSupport);
+    delete q;
+    return -2;
+  }
+  const double w = par->kernel == UAMMD_BDHI2D_TRUE2D ? std::pow(a * 0.66556976637237890625, 2) : std::pow(a / std::sqrt(M_PI), 2);
+  q->kern = Kern64{kKernelGauss2D, make_int3(s, s, 1), std::sqrt(1.0 / (2.0 * M_PI * w)), -1.0 / (2.0 * w), INFINITY, 0.0, 0.0, 0.0};
+  q->kernDriftX = q->kern;
+  q->kernDriftX.kind = kKernelGauss2DDriftX;
+  q->kernDriftX.prefactor = -std::sqrt(1.0 / (2.0 * M_PI * w * w));
+  q->kernDriftY = q->kernDriftX;
+  q->kernDriftY.kind = kKernelGauss2DDriftY;
+  q->nxpad = 2 * (cd[0] / 2 + 1);
+  q->planeReal = (size_t)q->nxpad * cd[1];
+  q->planeCplx = (size_t)(cd[0] / 2 + 1) * cd[1];
+  int e = q->gridBuf.reserve(sizeof(double) * 2 * q->planeReal);
+  if (!e) e = q->drift.reserve(sizeof(double) * 4);
+  if (!e) {
+    const double T = par->temperature, c[4] = {-T, 0.0, 0.0, -T};
+    if (hipMemcpy(q->drift.ptr, c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess) { set_last_error("uammd_bdhi2d_create_f64: hipMemcpy failed"); e = -4; }
+  }
+  if (!e) e = q2d64_plans(q);
+  if (e) { delete q; return e; }
+  if (cells) { cells[0] = cd[0]; cells[1] = cd[1]; }
+  if (support) *support = s;
+  *out = reinterpret_cast<uammd_bdhi2d_f64 *>(q);
+  return 0;
+}
+int uammd_bdhi2d_destroy_f64(uammd_bdhi2d_f64 *h) {
+  delete reinterpret_cast<BDHI2D64 *>(h);
+  return 0;
+}
+int uammd_bdhi2d_velocities_f64(uammd_bdhi2d_f64 *h, const double *d_pos, const double *d_force, int N, double *d_vel, void *stream) {
+  if (!h) { set_last_error("uammd_bdhi2d_velocities_f64: null argument"); return -1; }
+  if (N <= 0) return 0;
+  if (!d_pos || !d_vel) { set_last_error("uammd_bdhi2d_velocities_f64: null argument"); return -1; }
+  BDHI2D64 *q = reinterpret_cast<BDHI2D64 *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  const double T = q->par.temperature;
+  const bool drift = q->par.kernel == UAMMD_BDHI2D_QUASI2D && T > 0;  // hasThermalDrift() and temperature > 0
+  const bool deterministic = d_force != nullptr || drift;
+  double *g = (double *)q->gridBuf.ptr;
+  const dim3 gp((N + 3) / 4), bp(256);
+  const FastDiv dsx = make_fastdiv(q->kern.support.x), dsxy = make_fastdiv(q->kern.support.x * q->kern.support.y);
+  const int nx = q->grid.cellDim.x, ny = q->grid.cellDim.y;
+  UH_ROCFFT64(rocfft_execution_info_set_stream(q->info, (void *)st));
+  void *bufs[1] = {g};
+  const double *c = (const double *)q->drift.ptr;
+#define UH_Q2D_SPREAD(quantity, qstride, kernel)                                                                                                 \
+  hipLaunchKernelGGL((k_ibm64<2, true>), gp, bp, 0, st, d_pos, 4, quantity, qstride, (double *)nullptr, g, N, q->grid, q->nxpad, (size_t)1, q->planeReal, \
+                     kernel, dsx, dsxy, true, false)
+  if (deterministic) {
+    UH_CHECK(hipMemsetAsync(g, 0, sizeof(double) * 2 * q->planeReal, st));
+    if (drift) {  // spreadThermalDrift, .cu:234-257: every particle spreads the constant (-T, 0) with the x window, (0, -T) with the y window
+      UH_Q2D_SPREAD(c, 0, q->kernDriftX);
+      UH_Q2D_SPREAD(c + 2, 0, q->kernDriftY);
+    }
+    if (d_force) UH_Q2D_SPREAD(d_force, 4, q->kern);   // spreadParticleForces, .cu:268-283
+    UH_ROCFFT64(rocfft_execute(q->fwd, bufs, nullptr, q->info));
+  }
+#undef UH_Q2D_SPREAD
+  if (!deterministic && !(T > 0)) {  // nothing moves the particles
+    UH_CHECK(hipMemsetAsync(d_vel, 0, sizeof(double) * 2 * (size_t)N, st));
+    return 0;
+  }
+  double noisePrefactor = 0.0;
+  if (T > 0) {  // addStochastichTermFourier, .cu:450-469
+    q->counter++;
+    noisePrefactor = std::sqrt(2.0 * T / (q->par.viscosity * q->par.dt * q->par.boxSize[0] * q->par.boxSize[1]));
+  }
+  const int total = (int)q->planeCplx;
+  hipLaunchKernelGGL(k_q2d_kspace64, dim3((total + 255) / 256), dim3(256), 0, st, (double2 *)g, (double2 *)g + q->planeCplx, nx, ny, q->par.boxSize[0],
+                     q->par.boxSize[1], q->par.kernel, q->par.hydrodynamicRadius, q->par.viscosity, deterministic, noisePrefactor, q->par.seed,
+                     q->counter);
+  UH_ROCFFT64(rocfft_execute(q->inv, bufs, nullptr, q->info));
+  hipLaunchKernelGGL((k_ibm64<2, false>), gp, bp, 0, st, d_pos, 4, (const double *)nullptr, 2, d_vel, g, N, q->grid, q->nxpad, (size_t)1, q->planeReal,
+                     q->kern, dsx, dsxy, true, true);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+int uammd_bdhi2d_update_positions_f64(double *d_pos, const double *d_vel, int N, double dt, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_vel) { set_last_error("uammd_bdhi2d_update_positions_f64: null argument"); return -1; }
+  hipLaunchKernelGGL(k_q2d_update64, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_pos, (const double2 *)d_vel, N, dt);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- Poisson, real = double (the single-precision entry points: poisson.hip) ------------------------------------------------------------
+int uammd_poisson_create_f64(const uammd_poisson_parameters_f64 *par, uammd_poisson_f64 **out, uammd_poisson_info_f64 *info) {
+  if (!par || !out) { set_last_error("uammd_poisson_create_f64: null argument"); return -1; }
+  if (!(par->boxSize[0] > 0) || !(par->boxSize[1] > 0) || !(par->boxSize[2] > 0) || !(par->epsilon > 0) || !(par->gw > 0) || !(par->tolerance > 0)) {
+    set_last_error("uammd_poisson_create_f64: box, epsilon, gw and tolerance must be positive");
+    return -2;
+  }
+  Poisson64 *p = new (std::nothrow) Poisson64();
+  if (!p) { set_last_error("uammd_poisson_create_f64: out of host memory"); return -3; }
+  p->par = *par;
+  const double gw = par->gw, split = par->split, epsilon = par->epsilon, tolerance = par->tolerance;
+  for (int a = 0; a < 3; ++a) p->L[a] = par->boxSize[a];
+  // grid (.cu:75-90)
+  const double fw = split > 0 ? std::sqrt(gw * gw + 1.0 / (4.0 * split * split)) : gw;
+  double h;
+  if (par->upsampling > 0) h = 1.0 / par->upsampling;
+  else h = (1.3 - std::min((-std::log10(tolerance)) / 10.0, 0.9)) * fw;
+  h = std::min(h, p->L[0] / 32.0);
+  for (int a = 0; a < 3; ++a) p->cells[a] = next_fft_wise_axis((int)(p->L[a] / h));
+  const int per[3] = {1, 1, 1};
+  p->grid = make_grid<double>(make_box<double>(p->L, per), make_int3(p->cells[0], p->cells[1], p->cells[2]));
+  const double hx = p->grid.cellSize.x;
+  // window (SpectralEwaldPoisson.cuh:65-70, .cu:93-104)
+  const double prefactor = std::cbrt(std::pow(2 * M_PI * fw * fw, -1.5));
+  const double tau = -1.0 / (2.0 * fw * fw);
+  const double rmax = std::sqrt(std::log(tolerance * std::sqrt(2 * M_PI * fw * fw)) / tau);
+  int support = std::max(3, (int)(2 * rmax / hx + 0.5));
+  if (support > p->cells[0] / 2 - 1) {
+    set_last_error("[Poisson] Kernel support (%d) is too large for this configuration (max is %d), try increasing splitting "
+                   "parameter or decrasing tolerance", support, p->cells[0] / 2 - 1);
+    delete p;
+    return -2;
+  }
+  support = std::min(support, p->cells[0] / 2 - 2);
+  if (support > kMaxSupport) {
+    set_last_error("uammd_poisson_create_f64: window support %d exceeds the %d nodes per axis one wave evaluates", support, kMaxSupport);
+    delete p;
+    return -2;
+  }
+  p->kern = Kern64{kKernelGaussian, make_int3(support, support, support), prefactor, tau, INFINITY, 0.0, 0.0, 0.0};   // Poisson_ns::Gaussian::phi has no cut
+  // near field cut-off and tables (.cu:105-118, :140-160).  The reference marches r from the far-field width in steps of gw / 1000 until
+  // |G(r)| <= tolerance (tens of millions of erf pairs at gw = 1e-3); G decreases monotonically from there on, so the same first step is found by
+  // marching a thousand steps at a time and then the last thousand one by one.
+  if (split > 0) {
+    const long double step = 0.001l * gw;
+    auto above = [&](long double r) { return std::fabs(greens64((double)(r * r), gw, split, epsilon)) > tolerance; };
+    long long nSteps = 0;
+    {
+      long long coarse = 0;
+      while (above((long double)fw + (long double)((coarse + 1) * 1000) * step)) ++coarse;
+      nSteps = coarse * 1000;
+      do { ++nSteps; } while (above((long double)fw + (long double)nSteps * step));
+    }
+    p->cutoff = (double)((long double)fw + (long double)nSteps * step);
+    if (p->cutoff > p->L[0] / 2.0) {
+      set_last_error("[Poisson] Near field cut off is too large, increase splitting parameter.");
+      delete p;
+      return -2;
+    }
+    p->ntable = std::max(4096, (int)std::min((double)(1 << 16), p->cutoff / (gw * tolerance * 1e3)));
+    const int Nm1 = p->ntable - 1;
+    std::vector<double> tf(p->ntable), tp(p->ntable);
+    const double rmaxF = p->cutoff, rmaxP = p->cutoff * p->cutoff;
+    for (int i = 0; i <= Nm1; ++i) {  // TabulatedFunction ctor, misc/TabulatedFunction.cuh:103-117
+      tf[i] = greens_field64((i / (double)Nm1) * rmaxF, gw, split, epsilon);
+      tp[i] = greens64((i / (double)Nm1) * rmaxP, gw, split, epsilon);
+    }
+    int e = p->tableField.reserve(sizeof(double) * tf.size());
+    if (!e) e = p->tablePotential.reserve(sizeof(double) * tp.size());
+    if (e) { delete p; return e; }
+    if (hipMemcpy(p->tableField.ptr, tf.data(), sizeof(double) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->tablePotential.ptr, tp.data(), sizeof(double) * tp.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      set_last_error("uammd_poisson_create_f64: table upload failed");
+      delete p;
+      return -4;
+    }
+  }
+  p->nxpad = 2 * (p->cells[0] / 2 + 1);
+  p->planeReal = (size_t)p->nxpad * p->cells[1] * p->cells[2];
+  p->planeCplx = (size_t)(p->cells[0] / 2 + 1) * p->cells[1] * p->cells[2];
+  int e = p->gridQ.reserve(sizeof(double) * p->planeReal);
+  if (!e) e = p->planes.reserve(sizeof(double) * 4 * p->planeReal);
+  if (!e) e = poisson64_plans(p);
+  if (e) { delete p; return e; }
+  if (info) {
+    for (int a = 0; a < 3; ++a) info->cells[a] = p->cells[a];
+    info->support = support;
+    info->nearFieldCutOff = p->cutoff;
+    info->nTable = p->ntable;
+    info->h = hx;
+  }
+  *out = reinterpret_cast<uammd_poisson_f64 *>(p);
+  return 0;
+}
+int uammd_poisson_destroy_f64(uammd_poisson_f64 *h) {
+  delete reinterpret_cast<Poisson64 *>(h);
+  return 0;
+}
+int uammd_poisson_sum_f64(uammd_poisson_f64 *h, const double *d_pos, const double *d_charge, int N, double *d_force, double *d_energy, int nearForce,
+                          int nearEnergy, void *stream) {
+  if (!h) { set_last_error("uammd_poisson_sum_f64: null argument"); return -1; }
+  if (N <= 0) return 0;
+  if (!d_pos || !d_charge) { set_last_error("uammd_poisson_sum_f64: null argument"); return -1; }
+  if ((nearForce && !d_force) || (nearEnergy && !d_energy)) { set_last_error("uammd_poisson_sum_f64: missing output array"); return -1; }
+  Poisson64 *p = reinterpret_cast<Poisson64 *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = poisson64_far(p, d_pos, d_charge, N, d_force, d_energy, nullptr, st)) return e;
+  if (p->par.split > 0) {
+    if (nearForce) if (int e = poisson64_near<0>(p, d_pos, d_charge, N, d_force, st)) return e;
+    if (nearEnergy) if (int e = poisson64_near<1>(p, d_pos, d_charge, N, d_energy, st)) return e;
+  }
+  return 0;
+}
+int uammd_poisson_field_potential_f64(uammd_poisson_f64 *h, const double *d_pos, const double *d_charge, int N, double *d_fieldPotential, double *d_force,
+                                      double *d_energy, void *stream) {
+  if (!h) { set_last_error("uammd_poisson_field_potential_f64: null argument"); return -1; }
+  if (N <= 0) return 0;
+  if (!d_pos || !d_charge || !d_fieldPotential) { set_last_error("uammd_poisson_field_potential_f64: null argument"); return -1; }
+  Poisson64 *p = reinterpret_cast<Poisson64 *>(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = poisson64_far(p, d_pos, d_charge, N, d_force, d_energy, d_fieldPotential, st)) return e;
+  if (p->par.split > 0) if (int e = poisson64_near<2>(p, d_pos, d_charge, N, d_fieldPotential, st)) return e;
   return 0;
 }
 

@@ -49,7 +49,7 @@ struct BDHI2D {
   }
 };
 
-static int next_fft_wise2(int n) {  // nextFFTWiseSize3D (utils/Grid.cuh:142-213), one axis
+int next_fft_wise_axis(int n) {  // nextFFTWiseSize3D (utils/Grid.cuh:142-213), one axis
   static const int primes[5] = {2, 3, 5, 7, 11}, maxExp[5] = {64, 64, 5, 4, 3};
   for (int c = std::max(n, 1);; ++c) {
     if (c % 2) continue;
@@ -255,8 +255,8 @@ int uammd_bdhi2d_create(const uammd_bdhi2d_parameters *par, uammd_bdhi2d **out, 
   if (cd[0] <= 0) {  // initializeGrid, .cu:61-73
     const double h = a * 0.8;
     const float hr = (float)h;
-    cd[0] = next_fft_wise2((int)(par->boxSize[0] / hr));
-    cd[1] = next_fft_wise2((int)(par->boxSize[1] / hr));
+    cd[0] = next_fft_wise_axis((int)(par->boxSize[0] / hr));
+    cd[1] = next_fft_wise_axis((int)(par->boxSize[1] / hr));
   }
   const float L3[3] = {par->boxSize[0], par->boxSize[1], 0.0f};
   const int per[3] = {1, 1, 0};
