@@ -235,3 +235,55 @@ def test_pse_against_the_double_oracle(f64, o64):
     MF = p.computeMF(_dev(pos), _dev(f)).cpu().numpy()
     exp = ref.computeHydrodynamicDisplacements(pos, f, 0.0, 0.0)
     assert np.abs(MF - exp).max() <= 1e-11 * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("mode", ["Quasi2D", "True2D"])
+def test_bdhi2d_step_vs_oracle(f64, o64, mode):
+    """uammd_bdhi2d_*_f64 against the double-precision oracle (Integrator/Hydro/BDHI_quasi2D.cu:179-541): forces only, forces + thermal
+    drift + noise (the same Saru streams), noise only; two steps each (the noise counter advances).  Same arithmetic, another summation
+    order in the spread: 1e-11 of the largest velocity at T = 0; with noise 2e-6 — the draws are Saru's single-precision Gaussians in both
+    (promoted to double, as the reference's DOUBLE_PRECISION build does), and Box-Muller's logf / sincosf differ between libm and the
+    device by an ulp of a float."""
+    from oracle.quasi2d import BDHI2DOracle
+    n, a, visc, T, dt, seed, L = 300, 1.1, 1.3, 0.7, 0.05, 90210, (36.0, 50.0)
+    rng = np.random.default_rng(2)
+    pos = np.zeros((n, 4))
+    pos[:, 0] = rng.uniform(-0.7, 0.7, n) * L[0]      # some particles outside the primary box
+    pos[:, 1] = rng.uniform(-0.7, 0.7, n) * L[1]
+    force = np.zeros((n, 4))
+    force[:, :2] = rng.normal(0, 1, (n, 2))
+    for temperature, with_forces in [(0.0, True), (T, True), (T, False)]:
+        bd = f64.BDHI2D(mode, L, a, visc, temperature, dt, seed)
+        ref = BDHI2DOracle(o64, mode, L, a, visc, temperature, dt, seed=seed)
+        assert bd.cells == [int(ref.cells[0]), int(ref.cells[1])] and bd.support == ref.support
+        dpos, rpos = _dev(pos), pos.copy()
+        for step in range(2):
+            v = bd.forwardTime(dpos, _dev(force) if with_forces else None).cpu().numpy()
+            rv = ref.forwardTime(rpos, force if with_forces else None)
+            assert np.abs(v - rv).max() <= (2e-6 if temperature > 0 else 1e-11) * np.abs(rv).max(), (mode, temperature, with_forces, step)
+        assert np.abs(dpos.cpu().numpy() - rpos).max() <= (1e-6 if temperature > 0 else 1e-12)
+
+
+def test_poisson_vs_oracle(f64, o64):
+    """uammd_poisson_*_f64 against the double-precision oracle (Interactor/SpectralEwaldPoisson.cu): forces, energies and the field /
+    potential at the particles of a neutral random set; grid, window support, near cut-off and table size equal."""
+    from oracle.poisson import PoissonOracle
+    n, L, eps, gw, tol, split = 400, 24.0, 1.7, 0.35, 1e-6, 0.9
+    rng = np.random.default_rng(5)
+    pos = np.zeros((n, 4))
+    pos[:, :3] = rng.uniform(-0.6, 0.6, (n, 3)) * L
+    q = rng.normal(0, 1, n)
+    q -= q.mean()
+    ps = f64.Poisson(L, eps, gw, tol, split)
+    ref = PoissonOracle(o64, L, eps, gw, tol, split)
+    assert ps.cells == [int(c) for c in ref.cells] and ps.support == ref.support and ps.ntable == ref.ntable
+    assert abs(ps.nearFieldCutOff - float(ref.nearFieldCutOff)) <= 1e-12 * ps.nearFieldCutOff
+    f, e = torch.zeros((n, 4), dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+    ps.sum(_dev(pos), _dev(q), f, e, True, True)
+    rf, re = np.zeros((n, 4)), np.zeros(n)
+    ref.sum(pos, q, rf, re, True, True)
+    assert np.abs(f.cpu().numpy() - rf).max() <= 1e-10 * np.abs(rf).max()
+    assert np.abs(e.cpu().numpy() - re).max() <= 1e-10 * np.abs(re).max()
+    fp = ps.computeFieldPotentialAtParticles(_dev(pos), _dev(q)).cpu().numpy()
+    rfp = ref.computeFieldPotentialAtParticles(pos, q)
+    assert np.abs(fp - rfp).max() <= 1e-10 * np.abs(rfp).max()

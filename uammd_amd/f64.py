@@ -204,3 +204,75 @@ class LanczosSolver:
             raise err[0]
         check(rc)
         return int(it.value)
+
+
+class BDHI2D:
+    """BDHI::True2D / BDHI::Quasi2D with real = double (Integrator/Hydro/BDHI_quasi2D.cuh:155-257): one step's particle velocities
+    (real2[N]) and the position update.  mode: "True2D" | "Quasi2D"."""
+
+    def __init__(self, mode, L, hydrodynamicRadius, viscosity, temperature, dt, seed, cells=(-1, -1)):
+        self.lib = _lib.load()
+        Lx, Ly = (L, L) if np.isscalar(L) else (L[0], L[1])
+        p = _lib.BDHI2DParametersF64()
+        p.boxSize[0], p.boxSize[1] = float(Lx), float(Ly)
+        p.hydrodynamicRadius, p.viscosity, p.temperature, p.dt = float(hydrodynamicRadius), float(viscosity), float(temperature), float(dt)
+        p.cells[0], p.cells[1] = int(cells[0]), int(cells[1])
+        p.seed, p.kernel = int(seed), {"True2D": 0, "Quasi2D": 1}[mode]
+        h, cd, sup = C.c_void_p(), (C.c_int * 2)(0, 0), C.c_int(0)
+        check(self.lib.uammd_bdhi2d_create_f64(C.byref(p), C.byref(h), C.byref(cd), C.byref(sup)))
+        self.h, self.cells, self.support, self.dt = h, [int(cd[0]), int(cd[1])], int(sup.value), float(dt)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_bdhi2d_destroy_f64(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def velocities(self, pos, force=None):
+        n = pos.shape[0]
+        vel = torch.empty((n, 2), dtype=torch.float64, device=pos.device)
+        check(self.lib.uammd_bdhi2d_velocities_f64(self.h, _ptr(pos), _ptr(force), n, _ptr(vel), _stream()))
+        return vel
+
+    def forwardTime(self, pos, force=None):
+        vel = self.velocities(pos, force)
+        check(self.lib.uammd_bdhi2d_update_positions_f64(_ptr(pos), _ptr(vel), pos.shape[0], self.dt, _stream()))
+        return vel
+
+
+class Poisson:
+    """Poisson with real = double (Interactor/SpectralEwaldPoisson.cuh:83-136): sum(force, energy) and the field / potential at the
+    particles.  Near field over all pairs."""
+
+    def __init__(self, L, epsilon, gw, tolerance=1e-5, split=-1.0, upsampling=-1.0):
+        self.lib = _lib.load()
+        p = _lib.PoissonParametersF64()
+        L3 = np.broadcast_to(np.asarray(L, dtype=np.float64), (3,))
+        for a in range(3):
+            p.boxSize[a] = float(L3[a])
+        p.epsilon, p.tolerance, p.gw, p.split, p.upsampling = float(epsilon), float(tolerance), float(gw), float(split), float(upsampling)
+        h, info = C.c_void_p(), _lib.PoissonInfoF64()
+        if self.lib.uammd_poisson_create_f64(C.byref(p), C.byref(h), C.byref(info)) != 0:
+            msg = self.lib.uammd_hip_last_error().decode()
+            raise ValueError(msg) if "[Poisson]" in msg else RuntimeError(msg)
+        self.h = h
+        self.cells, self.support, self.nearFieldCutOff, self.ntable = [int(c) for c in info.cells], int(info.support), float(info.nearFieldCutOff), int(info.nTable)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.uammd_poisson_destroy_f64(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def sum(self, pos, charge, force4, energy, force=True, energy_flag=False):
+        check(self.lib.uammd_poisson_sum_f64(self.h, _ptr(pos), _ptr(charge), pos.shape[0], _ptr(force4), _ptr(energy), int(force), int(energy_flag), _stream()))
+
+    def computeFieldPotentialAtParticles(self, pos, charge):
+        n = pos.shape[0]
+        fp = torch.zeros((n, 4), dtype=torch.float64, device=pos.device)
+        check(self.lib.uammd_poisson_field_potential_f64(self.h, _ptr(pos), _ptr(charge), n, _ptr(fp), None, None, _stream()))
+        return fp
