@@ -1240,6 +1240,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "timed_blocks": {"repeats": len(blocks), "steps_each": args.steps, "ms_per_step_median": ms_per_step,
                          "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
+                         # (the first and the last tenth of the blocks: the liquid 320 steps after the lattice is not the equilibrated one —
+                         # measured with --equilibrate 300 / 20000 and three blocks each: traversal kernel 135.3 / 143.5 us, step 0.1849 /
+                         # 0.1932 ms — so the first blocks of a 12 s region run ~5 % faster than its median, which is the equilibrated liquid's)
+                         "ms_per_step_first_tenth": float(np.median(blocks[:max(1, len(blocks) // 10)])) / args.steps * 1e3,
+                         "ms_per_step_last_tenth": float(np.median(blocks[-max(1, len(blocks) // 10):])) / args.steps * 1e3,
                          "timed_seconds_total": float(sum(blocks))},
         "config": {"workload": "LJ NVT: 1e6 particles per GPU, rho*=0.8, rc=2.5, " +
                                ("CellList rebuilt every step, sortParticles every 500 steps with hintSortByHash(box, rc), " if args.nl == "cell" else
