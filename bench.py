@@ -278,6 +278,17 @@ def run_fcm(hip, args, world, rank, dist):
                         "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "traffic": read_traffic("traffic_fcm_step.json"),
                         "algorithmic_bytes_per_step": fcm_bytes_per_step(n, cells)}}
+    if world == 1:   # the deterministic step (T = 0: no Fourier-space noise) beside the thermal one
+        pd0, integ0, _, _ = fcm_setup(hip, n, cells, L, seed=1234 + rank, T=0.0)
+        for _ in range(args.fcm_warmup):
+            integ0.forwardTime()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.fcm_steps):
+            integ0.forwardTime()
+        torch.cuda.synchronize()
+        out["deterministic_T0"] = {"ms_per_step": (time.perf_counter() - t0) / args.fcm_steps * 1e3, "steps": args.fcm_steps}
+        del integ0, pd0
     # every kernel of the step against the HBM roof on ITS OWN algorithmic bytes (G = one pass over the 3-component complex grid, 25.6 MB
     # at C4; the gather reads the float4 grid, 16 B per node; a particle's prepared stencil is 16 + 72 B), durations from the committed
     # rocprofv3 summary of tools/time_fcm.py

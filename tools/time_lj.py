@@ -50,7 +50,7 @@ for algo in algos:
         ref = got
     err = np.abs(got[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 50
+    reps = int(os.environ.get("REPS", "50"))
     e0.record()
     for _ in range(reps):
         cl.transverse_lj(pot.device_table(), 1, box, f, None, None, None, algo)

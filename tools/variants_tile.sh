@@ -3,7 +3,7 @@
 # tools/time_lj.py through UAMMD_HIP_LIB: tools/variants_tile.sh build|run
 cd "$(dirname "$0")/.."
 NAMES=(${VNAMES:-base alignbit nounit timeline})
-declare -A FLAGS=([base]="" [alignbit]="-DUAMMD_TILE_ALIGNBIT" [nounit]="-DUAMMD_TILE_NOUNIT" [timeline]="-DUAMMD_TILE_TIMELINE" [old]="-DUAMMD_TILE_ALIGNBIT -DUAMMD_TILE_NOUNIT" [pop3]="-DUAMMD_TILE_POP3")
+declare -A FLAGS=([base]="" [alignbit]="-DUAMMD_TILE_ALIGNBIT" [nounit]="-DUAMMD_TILE_NOUNIT" [timeline]="-DUAMMD_TILE_TIMELINE" [old]="-DUAMMD_TILE_ALIGNBIT -DUAMMD_TILE_NOUNIT" [pop3]="-DUAMMD_TILE_POP3" [reload]="-DUAMMD_TILE_RELOAD_NEXT" [nonewton]="-DUAMMD_TILE_NO_NEWTON" [both]="-DUAMMD_TILE_RELOAD_NEXT -DUAMMD_TILE_NO_NEWTON")
 if [ "$1" = build ]; then
   mkdir -p tools/_build
   for n in "${NAMES[@]}"; do

@@ -102,7 +102,9 @@ UH_D void tile_eval(const BoxT<float> &box, const LJParams &p, const float4 &ri,
   const float r2 = dot3(r12, r12);
   const bool in = (r2 != 0.0f) & !(r2 >= p.cutOff2);
   float r = __builtin_amdgcn_rcpf(r2);
+#ifndef UAMMD_TILE_NO_NEWTON   // (variant, tools/variants_tile.sh nonewton: the bare v_rcp_f32, 1 ulp — measured)
   r = fmaf(fmaf(-r2, r, 1.0f), r, r);
+#endif
   const float invr2 = UNIT ? r : p.sigma2 * r;
   const float invr6 = invr2 * invr2 * invr2;
   const float f = UNIT ? fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2 : p.epsilonDivSigma2 * fmaf(-48.0f, invr6, 24.0f) * invr6 * invr2;
@@ -271,7 +273,7 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
   __builtin_amdgcn_s_setprio(0);  // (see k_lj_tile4: the drain yields to waves that are loading or scanning)
   // ---- drain: every lane walks its own hit words (bit j from the top of word w = slot 2 j + h of the word) ----
   // cw / cb = the word being consumed and the LDS address of its slot h, nw / nb = the next one; word nW of every lane is zero and a
-  // lane never moves past word nW - 1 (the look-ahead reads words nW and nW + 1: rows of the table that exist, never consumed).  A lane
+  // lane never moves past word nW - 1 (the look-ahead reads word nW: a row of the table that exists, never consumed).  A lane
   // without a set bit in cw takes a dead slot: ffbh(0) = -1 addresses slot -2 of the word — staged data of another row or the two
   // guard slots in front of the buffer, finite either way — with weight 0.
   *(LdsU *)(uintptr_t)(myMask + 256u * nW) = 0u;
@@ -287,18 +289,20 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
   // next word when this one is used up, then take the TWO highest set bits; a word with an odd number of hits leaves one dead slot:
   // 19 iterations per tile against 35 with one pair per iteration on a model liquid.
   auto pop2 = [&](bool &live0, bool &live1, uint &a0, uint &a1) {
-    const uint tw = *(const LdsU *)(uintptr_t)(myMask + 256u * wi1 + 256u);
-    const uint tb = *(const LdsU *)(uintptr_t)(wabsTab + 4u * wi1 + 4u);
     // advance: cw == 0 and words left.  (Lane masks by hand: from `wi1 += adv` the compiler makes a select and an add, from a ballot
-    // of adv a select and a compare; the mask of the compare is the carry-in of one v_addc.)
+    // of adv a select and a compare; the mask of the compare is the carry-in of one v_addc.)  The look-ahead holds ONE word: a lane that
+    // advances takes it, and the word after its new index is requested at once (a lane that stays re-reads the same one) — the request
+    // has the whole iteration to arrive.  (Round 6; until then the word after the next was requested at the top of the iteration and
+    // selected a few instructions later, two more selects per iteration: 0.1344 -> 0.1328 ms per launch, tools/time_lj.py with REPS=2000,
+    // four interleaved runs each, +- 0.0002.)
     unsigned long long adv, co;
     asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(adv) : "v"(cw));
     adv &= more;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cw) : "v"(cw), "v"(nw), "s"(adv));
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cb) : "v"(cb), "v"(nb), "s"(adv));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nw) : "v"(nw), "v"(tw), "s"(adv));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nb) : "v"(nb), "v"(tb), "s"(adv));
     asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(wi1), "=s"(co) : "v"(wi1), "s"(adv));
+    nw = *(const LdsU *)(uintptr_t)(myMask + 256u * wi1);
+    nb = *(const LdsU *)(uintptr_t)(wabsTab + 4u * wi1);
     asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(more) : "v"(wi1), "s"(nW));
     live0 = cw != 0;
     const uint k0 = (uint)__builtin_clz_or_neg1(cw);
@@ -369,7 +373,11 @@ UH_D void tile_words(Acc &acc, uint nW, uint candBase, uint tab, uint wbaseV, ui
   uint a0, a1;
   pop2(lN0, lN1, a0, a1);
   f4t cN0 = *(const LdsF4 *)(uintptr_t)a0, cN1 = *(const LdsF4 *)(uintptr_t)a1;
-  while (__any(lN0) || more != 0) {  // some lane still holds a pair or has words left (empty trailing words are walked through)
+  // some lane still holds a pair or has words left (empty trailing words are walked through).  (The condition as ONE scalar word and a
+  // for loop: written `while (__any(lN0) || more != 0)` the compiler split the loop into two blocks around the test and carried the three
+  // force sums through register copies — four v_mov per iteration and non-destructive v_fma; this form is a single block with v_fmac
+  // accumulators: 61 -> 57 vector instructions per iteration, 0.1328 -> 0.1314 ms per launch, tools/time_lj.py with REPS=2000.)
+  for (unsigned long long busy = __builtin_amdgcn_ballot_w64(lN0) | more; busy != 0; busy = __builtin_amdgcn_ballot_w64(lN0) | more) {
     TILE_MARK("drain_body", PBC);
     const f4t c0 = cN0, c1 = cN1;
     const bool l0 = lN0, l1 = lN1;
