@@ -954,7 +954,7 @@ def main():
     ap.add_argument("--min-timed-seconds", type=float, default=12.0, help="with --repeats 0: repeat the timed --steps block until the LJ headline has timed at least this much GPU work")
     ap.add_argument("--repeats", type=int, default=0, help="how many times the timed --steps block is run (0 = as many as --min-timed-seconds asks, at least 10 for blocks of <= 100 steps); "
                                                            "value / ms_per_step are the median block, the spread is reported")
-    ap.add_argument("--equilibrate", type=int, default=300, help="untimed steps that melt the lattice before warm-up (part of the synthetic input)")
+    ap.add_argument("--equilibrate", type=int, default=2000, help="untimed steps that melt the lattice before warm-up (part of the synthetic input; 2000 = the warm-up of the reference's benchmark.cu:129-157, SURVEY 8d)")
     ap.add_argument("--workload", default="both", choices=["lj", "fcm", "both", "pse"])
     ap.add_argument("--pse-steps", type=int, default=50)
     ap.add_argument("--cpu-pse-steps", type=int, default=5)
@@ -1251,9 +1251,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "timed_blocks": {"repeats": len(blocks), "steps_each": args.steps, "ms_per_step_median": ms_per_step,
                          "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_max": max(blocks) / args.steps * 1e3,
-                         # (the first and the last tenth of the blocks: the liquid 320 steps after the lattice is not the equilibrated one —
-                         # measured with --equilibrate 300 / 20000 and three blocks each: traversal kernel 135.3 / 143.5 us, step 0.1849 /
-                         # 0.1932 ms — so the first blocks of a 12 s region run ~5 % faster than its median, which is the equilibrated liquid's)
+                         # (the first and the last tenth of the blocks: a liquid a few thousand steps after the lattice is not the equilibrated
+                         # one — measured with --equilibrate 300 / 20000 and three blocks each: traversal kernel 135.3 / 143.5 us, step 0.1849
+                         # / 0.1932 ms; on FIXED positions 40 000 launches in a row run as fast as 2000 (0.1304 / 0.1311 ms, tools/time_lj.py):
+                         # it is the liquid that changes, not the clocks — so the first blocks of a 12 s region run ~4 % faster than its
+                         # median, which is the equilibrated liquid's)
                          "ms_per_step_first_tenth": float(np.median(blocks[:max(1, len(blocks) // 10)])) / args.steps * 1e3,
                          "ms_per_step_last_tenth": float(np.median(blocks[-max(1, len(blocks) // 10):])) / args.steps * 1e3,
                          "timed_seconds_total": float(sum(blocks))},

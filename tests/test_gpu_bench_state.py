@@ -1,10 +1,10 @@
 """The state bench.py TIMES, pinned against the oracle ("pin the state you time").
 
-Every other parity input is a jittered lattice.  bench.py's headline runs on an LJ LIQUID: bench.lj_setup()'s lattice melted for 300
+Every other parity input is a jittered lattice.  bench.py's headline runs on an LJ LIQUID: bench.lj_setup()'s lattice melted for 2000
 steps of VerletNVT::GronbechJensen (Integrator/VerletNVT/GronbechJensen.cu:28-62,88-115) with PairForces<LJ, CellList>.  A liquid has
 occupancy fluctuations (they are what send a 2 x 2 x 2-cell brick to the tile kernel's dense fallback) and pairs at r ~ 0.9 sigma; here
 
-* test_c3_melted_state_vs_oracle builds EXACTLY that state with the product (bench.lj_setup + 300 fused steps, C3: 1e6 particles),
+* test_c3_melted_state_vs_oracle builds EXACTLY that state with the product (bench.lj_setup + 2000 fused steps, C3: 1e6 particles),
   pulls the positions, and compares the product's cell tables (word for word) and forces / energy / virial (<= 1e-5) with the
   oracle on those positions, for AUTO (the tile kernel bench.py times) and EXACT; and asserts through uammd_lj_tile_stats how many
   bricks took the dense fallback (none at rho* = 0.8);
@@ -95,7 +95,7 @@ def test_c3_melted_state_vs_oracle(hip, o32):
     bench = _bench()
     n, L, rc = 1_000_000, 107.7217345, 2.5
     pd, box, pot, verlet, pf, pos0 = bench.lj_setup(hip, n, L, seed=1234)   # bench.py's rank-0 input
-    for _ in range(300):                                                    # bench.py --equilibrate (default)
+    for _ in range(2000):                                                   # bench.py --equilibrate (default)
         verlet.forwardTime()
     torch.cuda.synchronize()
     # a liquid, not the lattice: the particles have moved by a good fraction of sigma
@@ -105,7 +105,7 @@ def test_c3_melted_state_vs_oracle(hip, o32):
     pd.sortParticles()                                                      # bench.py sorts before the timed region
     verlet.forwardTime()
     torch.cuda.synchronize()
-    stats, occ = _compare_state(hip, o32, pd, box, pot, pf, n, rc, "C3 melted 300 steps",
+    stats, occ = _compare_state(hip, o32, pd, box, pot, pf, n, rc, "C3 melted 2000 steps",
                                 [("auto = tile4", 0, True), ("exact", 9, False)])
     st = stats["auto = tile4"]
     assert st["bricks"] == 22 ** 3
