@@ -207,6 +207,47 @@ def test_reference_acceptance_programs_run(tmp_path):
 
 
 @pytest.mark.gpu
+def test_reference_acceptance_programs_double_precision(tmp_path):
+    """The reference's acceptance programs built as THEIR OWN Makefiles build them, with -DDOUBLE_PRECISION (test/BDHI/FCM/Makefile:9,
+    test/BDHI/quasi2D/Makefile:2), and run as their scripts run them:
+    * test/BDHI/FCM/FCM.cu selfMobilityCubicBox at the script's tolerance of 1e-14 (test.bash:33,44-58) — twenty boxes of 8 .. 128
+      hydrodynamic radii, the first of them smaller than the spreading kernel (support 27 on a 24^3 grid: the reference prints its ERROR
+      line and goes on, and so does the double-precision build) — judged by the script's own criterion: from the fifth row on every
+      |1 - M / M0| <= 2 / (L1 / rh)^6 + tolerance with L1 the first row's box;
+    * test/BDHI/quasi2D/q2D.cu selfMobility for both hydrodynamic kernels as checkSelfMobility writes its input (test.bash:98-125; the script
+      plots |1 - M / M0| against L / a and has no number to pass): the deviation falls with the box and is below 5e-3 at L = 64 a,
+      1.5e-3 at 128 a, 1e-3 at 256 a."""
+    fcm = os.path.join(EX, "_build", "ref_test_dp_FCM")
+    q2d = os.path.join(EX, "_build", "ref_test_dp_q2D")
+    if not (os.path.exists(fcm) and os.path.exists(q2d)):
+        pytest.skip("the double-precision acceptance programs were not built (no reference tree where `make -C examples` ran)")
+    tol = 1e-14
+    r = subprocess.run([fcm, "selfMobilityCubicBox", "0", "1", "1", str(tol), "0"], cwd=tmp_path, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Kernel support is too big" in r.stderr
+    rows = [[float(x) for x in l.split()] for l in open(tmp_path / "selfMobilityCubicBox.test") if l.strip()]
+    assert len(rows) == 20
+    bar = 2.0 / rows[0][0] ** 6 + tol
+    worst = max(abs(v) for row in rows[4:] for v in row[1:])
+    print("FCM, double precision, tolerance 1e-14: largest |1 - M/M0| from the fifth box on %.3e, the script's bar %.3e" % (worst, bar))
+    assert worst <= bar
+    a, vis = 1.3, 1.7
+    for scheme in ("quasi2D", "true2D"):
+        devs = []
+        for l in (32, 64, 128, 256):
+            M0 = 1.0 / (6 * np.pi * vis * a) / (1 + 4.41 / l) if scheme == "quasi2D" else (np.log(l) - 1.3105329259115095183) / (4 * np.pi * vis)
+            (tmp_path / "in.q2d").write_text(f"scheme {scheme}\ntest selfMobility\nboxSize {l * a:.15g} {l * a:.15g}\ncells -1 -1\ndt 1\nviscosity {vis}\n"
+                                             f"temperature 0\nhydrodynamicRadius {a}\ntolerance 1e-6\nF {a / M0:.15g}\noutput /dev/stdout\n")
+            r = subprocess.run([q2d, "in.q2d"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            vals = [float(l.split()[0]) for l in r.stdout.splitlines() if l.strip()]   # (a line is the real3 M: the script reads column 1)
+            assert vals, r.stdout[-500:] + r.stderr[-500:]
+            devs.append(max(abs(1.0 - v / M0) for v in vals))
+        print("q2D %s, double precision: |1 - M/M0| at L/a = 32, 64, 128, 256: %s" % (scheme, " ".join("%.2e" % d for d in devs)))
+        assert devs[1] <= 5e-3 and devs[2] <= 1.5e-3 and devs[3] <= 1e-3 and devs[3] <= devs[0]   # (measured 2.7e-3 / 6.5e-4 / 7.7e-5 and 1.1e-3 / 7.8e-4 / 6.2e-4)
+
+
+@pytest.mark.gpu
 def test_reference_rpy_acceptance_pipeline(tmp_path):
     """test/BDHI/Lanczos_Cholesky of the reference, as its test.bash runs it: BDHI.cu (EulerMaruyama<BDHI::Lanczos> on 5000 spheres of two
     radii, the big one pulled; a user Interactor writing through the CPU accessors and getIdOrderedIndices) built against include/uammd,

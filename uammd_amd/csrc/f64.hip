@@ -832,11 +832,19 @@ int uammd_ibm_gather_f64(const double *d_pos, int posStride, double *d_out, int 
 int uammd_fcm_create_f64(const uammd_fcm_parameters_f64 *par, uammd_fcm_f64 **out) {
   if (!par || !out) { set_last_error("uammd_fcm_create_f64: null argument"); return -1; }
   if (int e = check_kernel64("uammd_fcm_create_f64", &par->kernel)) return e;
-  for (int a = 0; a < 3; ++a)
-    if (par->cells[a] < 2 || par->kernel.support[a] > par->cells[a] || !(par->boxSize[a] > 0)) {
+  for (int a = 0; a < 3; ++a) {
+    // A support that is not smaller than the grid: the reference logs an ERROR and goes on (BDHI_FCM.cuh:58-64) — its acceptance script
+    // walks through such boxes at its tolerance of 1e-14 (test/BDHI/FCM/test.bash:33, FCM.cu selfMobilityCubicBox) — and the stencil
+    // wraps as far as the reference's own Grid::pbc_cell goes (one +- n): the grid must hold half a support (uammd_fcm_create's rule).
+    if (par->cells[a] >= 2 && par->boxSize[a] > 0 && 2 * par->cells[a] < par->kernel.support[a] + 1) {
+      set_last_error("[BDHI::FCM] Kernel support is too big, try lowering the tolerance or increasing the box size!.");
+      return -2;
+    }
+    if (par->cells[a] < 2 || !(par->boxSize[a] > 0)) {
       set_last_error("uammd_fcm_create_f64: bad grid (cells %d %d %d, support %d)", par->cells[0], par->cells[1], par->cells[2], par->kernel.support[0]);
       return -2;
     }
+  }
   FCM64 *f = new FCM64();
   const int periodic[3] = {1, 1, 1};
   f->grid = make_grid<double>(make_box<double>(par->boxSize, periodic), make_int3(par->cells[0], par->cells[1], par->cells[2]));
