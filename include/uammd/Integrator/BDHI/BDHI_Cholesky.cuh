@@ -1,6 +1,3 @@
-// Forwarding header: same include path as the reference's src/Integrator/BDHI/BDHI_Cholesky.cuh.
+// Forwarding header: same include path as the reference's src/Integrator/BDHI/BDHI_Cholesky.cuh (both precisions).
 #pragma once
-#if defined(DOUBLE_PRECISION)
-#error "BDHI_Cholesky.cuh: this module has a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
-#endif
 #include "../../uammd.h"

@@ -1,7 +1,4 @@
-// Forwarding header: same include path as the reference's src/Integrator/BDHI/BDHI_Lanczos.cuh.
+// Forwarding header: same include path as the reference's src/Integrator/BDHI/BDHI_Lanczos.cuh (both precisions).
 // The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).
 #pragma once
-#if defined(DOUBLE_PRECISION)
-#error "BDHI_Lanczos.cuh: this module has a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
-#endif
 #include "../../uammd.h"

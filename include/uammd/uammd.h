@@ -22,10 +22,11 @@
 // FCM, the pair-record PSE near field — is single precision by construction; its DOUBLE_PRECISION build is the `_f64` part of the C ABI
 // (layout-generic kernels, rocFFT in double).  A DOUBLE_PRECISION program therefore gets: System, Box, Grid, ParticleData (+ sortParticles),
 // ParticleGroup, ParticleSorter, uninitialized_cached_vector, IBM<Kernel> (any kernel, device template), the FCM kernels, FCM_impl,
-// BDHI::FCM, BDHI::PSE, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver — every class the reference's unit
-// tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) construct.  The classes whose backend exists in single
-// precision only (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, BDHI::Lanczos / Cholesky, FIB, ICM, Comm) are not
-// declared in that build: their forwarding headers stop the compilation with a message instead of silently computing in float.
+// BDHI::FCM, BDHI::PSE, BDHI::Lanczos, BDHI::Cholesky, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver —
+// every class the reference's unit tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) and its double-precision
+// acceptance programs of path B (test/BDHI/{FCM, quasi2D, Lanczos_Cholesky}) construct.  The classes whose backend exists in single
+// precision only (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, FIB, ICM, Comm) are not declared in that build: their
+// forwarding headers stop the compilation with a message instead of silently computing in float.
 //
 // This header is plain host C++14: compile with any C++ compiler,
 //     g++ -std=c++14 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude main.cpp \
@@ -2596,10 +2597,7 @@ public:
 #endif
   }
 };
-#if defined(DOUBLE_PRECISION)
-}  // namespace BDHI
-#else   // (single-precision backends only, down to Poisson: see PRECISION at the top)
-// BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67): open boundaries, dense RPY mobility, matrix free
+// BDHI::Lanczos (Integrator/BDHI/BDHI_Lanczos.cuh:20-67): open boundaries, dense RPY mobility, matrix free (both precisions)
 class Lanczos {
   shared_ptr<ParticleData> pd;
   shared_ptr<ParticleGroup> pg;  // nullptr = all the particles (BDHI_Lanczos.cuh:51)
@@ -2607,7 +2605,11 @@ class Lanczos {
   detail::DeviceArray<real> radiusRows;
   int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
   BDHI::Parameters par;
+#if defined(DOUBLE_PRECISION)
+  uammd_lanczos_f64 *solver = nullptr;
+#else
   uammd_lanczos *solver = nullptr;
+#endif
   detail::DeviceArray<real3> noise;
   Xorshift128plus gen;  // the reference uses cuRAND here (stream unpinned): Box-Muller on the System generator family instead
 public:
@@ -2617,11 +2619,19 @@ public:
       : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), par(par), noise(group->getNumberParticles()) {
     if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
       System::log<System::CRITICAL>("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the individual particle radius.");
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_lanczos_create_f64(&solver));
+#else
     detail::check(uammd_lanczos_create(&solver));
+#endif
     gen.setSeed(pd->getSystem()->rng().next());
   }
   Lanczos(const Lanczos &) = delete;
+#if defined(DOUBLE_PRECISION)
+  ~Lanczos() { uammd_lanczos_destroy_f64(solver); }
+#else
   ~Lanczos() { uammd_lanczos_destroy(solver); }
+#endif
   void setup_step(hipStream_t = 0) {}
   void finish_step(hipStream_t = 0) {}
   real getHydrodynamicRadius() { return par.hydrodynamicRadius; }
@@ -2630,10 +2640,16 @@ public:
     auto pos = pd->getPos(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::read);
     auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_rpy_nbody_mdot((const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
-                                       (const float *)detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, st), 4,
-                                       detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st), par.hydrodynamicRadius,
-                                       par.viscosity, numberParticles(), (float *)MF, (void *)st));
+    const real4 *posNow = detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st);
+    const real4 *forceNow = detail::groupRows((const real4 *)force.raw(), pg.get(), forceRows, st);
+    const real *radiusNow = detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_rpy_nbody_mdot_f64((const double *)posNow, (const double *)forceNow, 4, radiusNow, par.hydrodynamicRadius, par.viscosity,
+                                           numberParticles(), (double *)MF, (void *)st));
+#else
+    detail::check(uammd_rpy_nbody_mdot((const float *)posNow, (const float *)forceNow, 4, radiusNow, par.hydrodynamicRadius, par.viscosity,
+                                       numberParticles(), (float *)MF, (void *)st));
+#endif
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) {
     if (!(par.temperature > real(0.0))) return;
@@ -2651,9 +2667,15 @@ public:
     detail::hipCheck(hipMemcpy(noise.d, h.data(), sizeof(real3) * N, hipMemcpyHostToDevice), "hipMemcpy");
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = par.hydrodynamicRadius > 0 ? property_ptr<real>() : pd->getRadiusIfAllocated(access::gpu, access::read);
-    detail::check(uammd_rpy_lanczos_bdw(solver, (const float *)detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st),
-                                        detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st), par.hydrodynamicRadius, par.viscosity, N,
-                                        (const float *)noise.d, par.tolerance, (float *)BdW, (void *)st, nullptr));
+    const real4 *posNow = detail::groupRows((const real4 *)pos.raw(), pg.get(), posRows, st);
+    const real *radiusNow = detail::groupRows((const real *)radius.raw(), pg.get(), radiusRows, st);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_rpy_lanczos_bdw_f64(solver, (const double *)posNow, radiusNow, par.hydrodynamicRadius, par.viscosity, N, (const double *)noise.d,
+                                            par.tolerance, (double *)BdW, (void *)st, nullptr));
+#else
+    detail::check(uammd_rpy_lanczos_bdw(solver, (const float *)posNow, radiusNow, par.hydrodynamicRadius, par.viscosity, N, (const float *)noise.d,
+                                        par.tolerance, (float *)BdW, (void *)st, nullptr));
+#endif
   }
 };
 
@@ -2665,7 +2687,11 @@ class Cholesky {
   int numberParticles() const { return pg ? pg->getNumberParticles() : pd->getNumParticles(); }
   const int *index() { return pg ? pg->getIndicesRawPtr(access::gpu) : nullptr; }
   BDHI::Parameters par;
+#if defined(DOUBLE_PRECISION)
+  uammd_bdhi_cholesky_f64 *h = nullptr;
+#else
   uammd_bdhi_cholesky *h = nullptr;
+#endif
   Xorshift128plus gen;  // cuRAND in the reference (stream unpinned): Box-Muller on the System generator family instead
 public:
   using Parameters = BDHI::Parameters;
@@ -2673,11 +2699,19 @@ public:
   Cholesky(shared_ptr<ParticleGroup> group, Parameters par) : pd(group->getParticleData()), pg(detail::subsetOrNull(group)), par(par) {
     if (par.hydrodynamicRadius < 0 && !pd->isRadiusAllocated())
       System::log<System::CRITICAL>("[BDHI::Cholesky] You need to provide Cholesky with either an hydrodynamic radius or via the individual particle radius.");
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi_cholesky_create_f64(numberParticles(), par.viscosity, par.hydrodynamicRadius, &h));
+#else
     detail::check(uammd_bdhi_cholesky_create(numberParticles(), par.viscosity, par.hydrodynamicRadius, &h));
+#endif
     gen.setSeed(pd->getSystem()->rng().next());
   }
   Cholesky(const Cholesky &) = delete;
+#if defined(DOUBLE_PRECISION)
+  ~Cholesky() { uammd_bdhi_cholesky_destroy_f64(h); }
+#else
   ~Cholesky() { uammd_bdhi_cholesky_destroy(h); }
+#endif
   void init() {}
   void finish_step(hipStream_t = 0) {}
   real getHydrodynamicRadius() { return par.hydrodynamicRadius; }
@@ -2685,13 +2719,21 @@ public:
   void setup_step(hipStream_t st = 0) {
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi_cholesky_setup_step_f64(h, (const double *)pos.raw(), index(), radius.raw(), (void *)st));
+#else
     detail::check(uammd_bdhi_cholesky_setup_step(h, (const float *)pos.raw(), index(), radius.raw(), (void *)st));
+#endif
   }
   void computeMF(real3 *MF, hipStream_t st = 0) {
     auto pos = pd->getPos(access::gpu, access::read);
     auto force = pd->getForce(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi_cholesky_mf_f64(h, (const double *)pos.raw(), (const double *)force.raw(), index(), radius.raw(), (double *)MF, (void *)st));
+#else
     detail::check(uammd_bdhi_cholesky_mf(h, (const float *)pos.raw(), (const float *)force.raw(), index(), radius.raw(), (float *)MF, (void *)st));
+#endif
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) {
     const int N = numberParticles();
@@ -2709,14 +2751,16 @@ public:
     detail::hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize");
     auto pos = pd->getPos(access::gpu, access::read);
     auto radius = pd->getRadiusIfAllocated(access::gpu, access::read);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bdhi_cholesky_bdw_f64(h, (const double *)pos.raw(), index(), radius.raw(), (double *)BdW, (void *)st));
+#else
     detail::check(uammd_bdhi_cholesky_bdw(h, (const float *)pos.raw(), index(), radius.raw(), (float *)BdW, (void *)st));
+#endif
   }
 };
 
 }  // namespace BDHI
 
-// ---- lanczos::Solver ----------------------------------------------------------------------------------------------------------------------
-#endif   // !DOUBLE_PRECISION (the region reopens after BDHI2D, which has both precisions)
 // ---- BDHI::True2D / BDHI::Quasi2D (Integrator/Hydro/BDHI_quasi2D.cuh:155-257): hydrodynamics of particles confined to a plane ------
 namespace BDHI {
 namespace BDHI2D_ns {

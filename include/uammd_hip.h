@@ -871,6 +871,21 @@ int uammd_lanczos_run_iterations_f64(uammd_lanczos_f64 *h, uammd_matvec_fn_f64 d
                                      int numberIterations, int n, void *stream, double *residual);
 int uammd_lanczos_set_iteration_hard_limit_f64(uammd_lanczos_f64 *h, int limit);
 int uammd_lanczos_get_last_run_required_steps_f64(uammd_lanczos_f64 *h, int *steps);
+/* BDHI::Lanczos and BDHI::Cholesky with real = double (see uammd_rpy_nbody_mdot, uammd_rpy_lanczos_bdw, uammd_bdhi_cholesky_*: Integrator/BDHI/
+ * BDHI_Lanczos.cu:56-188, BDHI_Cholesky.cu:34-262).  The reference's acceptance test of the two (test/BDHI/Lanczos_Cholesky) is compiled with
+ * -DDOUBLE_PRECISION (its Makefile:3) and its bar of 1e-7 is for that build.  rocSOLVER dpotrf, rocBLAS dsymv / dtrmv. */
+int uammd_rpy_nbody_mdot_f64(const double *d_pos, const double *d_v, int vstride, const double *d_radius, double hydrodynamicRadius, double viscosity,
+                             int numberParticles, double *d_Mv, void *stream);
+int uammd_rpy_lanczos_bdw_f64(uammd_lanczos_f64 *solver, const double *d_pos, const double *d_radius, double hydrodynamicRadius, double viscosity,
+                              int numberParticles, const double *d_noise, double tolerance, double *d_BdW, void *stream, int *iterations);
+typedef struct uammd_bdhi_cholesky_f64 uammd_bdhi_cholesky_f64;
+int uammd_bdhi_cholesky_create_f64(int numberParticles, double viscosity, double hydrodynamicRadius, uammd_bdhi_cholesky_f64 **out);
+int uammd_bdhi_cholesky_destroy_f64(uammd_bdhi_cholesky_f64 *h);
+int uammd_bdhi_cholesky_setup_step_f64(uammd_bdhi_cholesky_f64 *h, const double *d_pos, const int *d_index, const double *d_radius, void *stream);
+int uammd_bdhi_cholesky_mf_f64(uammd_bdhi_cholesky_f64 *h, const double *d_pos, const double *d_force, const int *d_index, const double *d_radius,
+                               double *d_MF, void *stream);
+int uammd_bdhi_cholesky_bdw_f64(uammd_bdhi_cholesky_f64 *h, const double *d_pos, const int *d_index, const double *d_radius, double *d_BdW,
+                                void *stream);
 
 #ifdef __cplusplus
 }

@@ -248,6 +248,32 @@ def test_reference_acceptance_programs_double_precision(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["Lanczos", "Cholesky"])
+def test_reference_rpy_acceptance_pipeline_double_precision(mode, tmp_path):
+    """test/BDHI/Lanczos_Cholesky as its test.bash runs it, built as its Makefile builds it (-DDOUBLE_PRECISION, Makefile:3): BDHI.cu on 5000
+    spheres of two radii, the big one pulled, its positions piped into the reference's checker process.cpp — and judged by the script's OWN
+    criterion for both modes (test.bash:24-47): the largest deviation of f(r) and of g(r) from the Rotne-Prager-Yamakawa formulas for
+    unequal spheres <= 1e-7.  (EulerMaruyama<BDHI::Lanczos> takes the matrix-free product uammd_rpy_nbody_mdot_f64, EulerMaruyama<BDHI::
+    Cholesky> the dense matrix with rocBLAS dsymv.)  Ten steps instead of the script's hundred; the seed named so that a run is
+    repeatable (BDHI.cu:16,127 seeds from the clock otherwise)."""
+    prog = os.path.join(EX, "_build", "ref_test_dp_BDHI")
+    proc = os.path.join(EX, "_build", "ref_process_bdhi")
+    if not (os.path.exists(prog) and os.path.exists(proc)):
+        pytest.skip("the acceptance program was not built (no reference tree where `make -C examples` ran)")
+    (tmp_path / "data.main").write_text("N 5000\nboxSize 4 4 4\nradius_min 0.38173\nradius_max 1.89538\noutfile /dev/stdout\ntemperature 0\n"
+                                        "viscosity 1.2131\ndt 10\ntolerance 1e-8\nnsteps 10\nprintSteps 1\nmode %s\nseed 20260930\n" % mode)
+    run = subprocess.run([prog], cwd=tmp_path, capture_output=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    chk = subprocess.run([proc], cwd=tmp_path, input=run.stdout, capture_output=True, timeout=600)
+    assert chk.returncode == 0, chk.stderr[-2000:]
+    d = np.array([[float(x) for x in l.split()[:3]] for l in chk.stdout.decode().splitlines() if l.strip() and not l.startswith("#")])
+    assert d.shape[0] > 40000
+    print("RPY acceptance, double precision, %s: %d pairs; largest deviation of f %.2e, of g %.2e (the script's bar: 1e-7 each)" %
+          (mode, d.shape[0], d[:, 1].max(), d[:, 2].max()))
+    assert d[:, 1].max() <= 1e-7 and d[:, 2].max() <= 1e-7
+
+
+@pytest.mark.gpu
 def test_reference_rpy_acceptance_pipeline(tmp_path):
     """test/BDHI/Lanczos_Cholesky of the reference, as its test.bash runs it: BDHI.cu (EulerMaruyama<BDHI::Lanczos> on 5000 spheres of two
     radii, the big one pulled; a user Interactor writing through the CPU accessors and getIdOrderedIndices) built against include/uammd,

@@ -287,3 +287,66 @@ def test_poisson_vs_oracle(f64, o64):
     fp = ps.computeFieldPotentialAtParticles(_dev(pos), _dev(q)).cpu().numpy()
     rfp = ref.computeFieldPotentialAtParticles(pos, q)
     assert np.abs(fp - rfp).max() <= 1e-10 * np.abs(rfp).max()
+
+
+@pytest.mark.parametrize("sizes", ["equal", "different"])
+def test_rpy_open_boundary_f64_vs_oracle(hip, o64, sizes):
+    """uammd_rpy_nbody_mdot_f64 (BDHI::Lanczos::computeMF with real = double, BDHI_Lanczos.cu:120-160) against the double-precision oracle:
+    the same j order and FMA placement, 1e-13 of max|Mv|; uammd_bdhi_cholesky_*_f64 (BDHI_Cholesky.cu: dense matrix, dsymv) gives the same
+    product to the rounding of another summation order; its factor (dpotrf, applied by dtrmv to unit vectors on a set of 24 spheres)
+    reproduces the oracle's dense matrix: B B^T = M to 1e-12."""
+    import ctypes as C
+    from oracle.pse import rpy_nbody_mdot
+    from uammd_amd import _lib
+    check, lib = _lib.check, _lib.load()
+    rng = np.random.default_rng(6)
+    n, visc = 700, 1.1
+    pos = np.zeros((n, 4))
+    pos[:, :3] = rng.uniform(-9, 9, (n, 3))
+    pos[1, :3] = pos[0, :3]                                   # coincident pair: the r = 0 branch between different particles
+    radius = rng.uniform(0.4, 1.1, n) if sizes == "different" else None
+    rh = -1.0 if sizes == "different" else 0.8
+    f4 = np.zeros((n, 4))
+    f4[:, :3] = rng.normal(0, 1, (n, 3))
+    dpos, df, drad = _dev(pos), _dev(f4), (_dev(radius) if radius is not None else None)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    MF = torch.full((n, 3), 3.0, dtype=torch.float64, device="cuda")
+    check(lib.uammd_rpy_nbody_mdot_f64(ptr(dpos), ptr(df), 4, ptr(drad), rh, visc, n, ptr(MF), None))
+    torch.cuda.synchronize()
+    expect = rpy_nbody_mdot(o64, pos, f4, visc, rh, radius)
+    got = MF.cpu().numpy()
+    assert np.abs(got - expect).max() <= 1e-13 * np.abs(expect).max()
+    h = C.c_void_p()
+    check(lib.uammd_bdhi_cholesky_create_f64(n, visc, rh, C.byref(h)))
+    try:
+        check(lib.uammd_bdhi_cholesky_setup_step_f64(h, ptr(dpos), None, ptr(drad), None))
+        MF2 = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        check(lib.uammd_bdhi_cholesky_mf_f64(h, ptr(dpos), ptr(df), None, ptr(drad), ptr(MF2), None))
+        torch.cuda.synchronize()
+        assert np.abs(MF2.cpu().numpy() - expect).max() <= 1e-12 * np.abs(expect).max()
+    finally:
+        lib.uammd_bdhi_cholesky_destroy_f64(h)
+    # the factor: B = U^T column by column (computeBdW maps the draws w to B w, BDHI_Cholesky.cu:235-262)
+    from oracle.pse import rpy_dense
+    m = 24
+    p24 = np.zeros((m, 4))
+    p24[:, :3] = rng.uniform(-3, 3, (m, 3))
+    r24 = rng.uniform(0.4, 1.1, m) if sizes == "different" else None
+    M = rpy_dense(o64, p24, r24, rh, visc).astype(np.float64)
+    M = np.triu(M) + np.triu(M, 1).T          # (the reference fills the upper triangle)
+    h = C.c_void_p()
+    check(lib.uammd_bdhi_cholesky_create_f64(m, visc, rh, C.byref(h)))
+    try:
+        d24, dr24 = _dev(p24), (_dev(r24) if r24 is not None else None)
+        B = np.zeros((3 * m, 3 * m))
+        for k in range(3 * m):
+            e = np.zeros(3 * m)
+            e[k] = 1.0
+            de = _dev(e)
+            check(lib.uammd_bdhi_cholesky_setup_step_f64(h, ptr(d24), None, ptr(dr24), None))
+            check(lib.uammd_bdhi_cholesky_bdw_f64(h, ptr(d24), None, ptr(dr24), ptr(de), None))
+            torch.cuda.synchronize()
+            B[:, k] = de.cpu().numpy()
+        assert np.abs(B @ B.T - M).max() <= 1e-12 * np.abs(M).max()
+    finally:
+        lib.uammd_bdhi_cholesky_destroy_f64(h)

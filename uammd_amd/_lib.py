@@ -297,6 +297,13 @@ SIGNATURES = {
     "uammd_lanczos_get_last_run_required_steps": (_i, [_vp, C.POINTER(_i)]),
     "uammd_rpy_nbody_mdot": (_i, [_vp, _vp, _i, _vp, _f, _f, _i, _vp, _vp]),
     "uammd_rpy_lanczos_bdw": (_i, [_vp, _vp, _vp, _f, _f, _i, _vp, _f, _vp, _vp, C.POINTER(_i)]),
+    "uammd_rpy_nbody_mdot_f64": (_i, [_vp, _vp, _i, _vp, _d, _d, _i, _vp, _vp]),
+    "uammd_rpy_lanczos_bdw_f64": (_i, [_vp, _vp, _vp, _d, _d, _i, _vp, _d, _vp, _vp, C.POINTER(_i)]),
+    "uammd_bdhi_cholesky_create_f64": (_i, [_i, _d, _d, C.POINTER(_vp)]),
+    "uammd_bdhi_cholesky_destroy_f64": (_i, [_vp]),
+    "uammd_bdhi_cholesky_setup_step_f64": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi_cholesky_mf_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uammd_bdhi_cholesky_bdw_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)

@@ -1371,63 +1371,68 @@ static int pse_lanczos_fused(void *ctx, LanczosFusedArgs *a, int n, void *stream
 }
 
 // ---- BDHI::Lanczos: dense open-boundary RPY mobility, matrix free (Integrator/BDHI/BDHI_Lanczos.cu:56-118, BDHI.cuh:27-96) ----
-UH_D void rpy_different_sizes(float M0, float r, float ai, float aj, float &c1, float &c2) {
-  const float asum = ai + aj;
-  const float asub = fabsf(ai - aj);
+// (templates over `real`: the double-precision instantiation is the DOUBLE_PRECISION build of the module, which is how the reference's own
+// acceptance test of it is compiled — test/BDHI/Lanczos_Cholesky/Makefile:3 — and where its bar of 1e-7 applies)
+template <class T> UH_D T rpy_fma(T a, T b, T c);
+template <> UH_D float rpy_fma<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> UH_D double rpy_fma<double>(double a, double b, double c) { return fma(a, b, c); }
+template <class T> UH_D void rpy_different_sizes(T M0, T r, T ai, T aj, T &c1, T &c2) {
+  const T asum = ai + aj;
+  const T asub = ai > aj ? ai - aj : aj - ai;
   if (r > asum) {
-    const float invr = 1.0f / r;
-    const float pref = M0 * 3.0f * 0.25f * invr;
-    const float denom = fmaf(ai, ai, aj * aj) / (3.0f * r * r);
-    c1 = pref * (1.0f + denom);
-    c2 = pref * fmaf(-3.0f, denom, 1.0f) * invr * invr;
+    const T invr = T(1) / r;
+    const T pref = M0 * T(3) * T(0.25) * invr;
+    const T denom = rpy_fma(ai, ai, aj * aj) / (T(3) * r * r);
+    c1 = pref * (T(1) + denom);
+    c2 = pref * rpy_fma(T(-3), denom, T(1)) * invr * invr;
   } else if (r > asub) {
-    const float pref = M0 / (ai * aj * 32.0f * r * r * r);
-    float num = fmaf(3.0f * r, r, asub * asub);
-    c1 = pref * fmaf(16.0f * r * r * r, asum, -(num * num));
-    num = fmaf(-r, r, asub * asub);
-    c2 = pref * (3.0f * num * num) / (r * r);
+    const T pref = M0 / (ai * aj * T(32) * r * r * r);
+    T num = rpy_fma(T(3) * r, r, asub * asub);
+    c1 = pref * rpy_fma(T(16) * r * r * r, asum, -(num * num));
+    num = rpy_fma(-r, r, asub * asub);
+    c2 = pref * (T(3) * num * num) / (r * r);
   } else {
     c1 = M0 / (ai > aj ? ai : aj);
-    c2 = 0.0f;
+    c2 = T(0);
   }
 }
 
 // NBody::transverse with NbodyMatrixFreeMobilityDot: thread per particle i, all j in ascending order through LDS tiles
-// (positions + radius in one float4, v in another); Mv[i] = total (overwrites).
-template <int VSTRIDE>
-__global__ void __launch_bounds__(128) k_rpy_nbody(const float4 *__restrict__ pos, const float *__restrict__ v,
-                                                    const float *__restrict__ radius, float rh, float M0, int N,
-                                                    float *__restrict__ Mv) {
-  __shared__ float4 tp[128], tv[128];
+// (positions + radius in one real4, v in another); Mv[i] = total (overwrites).
+template <int VSTRIDE, class T>
+__global__ void __launch_bounds__(128) k_rpy_nbody(const T *__restrict__ pos, const T *__restrict__ v, const T *__restrict__ radius, T rh, T M0, int N,
+                                                    T *__restrict__ Mv) {
+  __shared__ T tp[128][4], tv[128][3];
   const int i = blockIdx.x * 128 + threadIdx.x;
   const bool active = i < N;
-  const float4 pi = active ? pos[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float ai = active ? (radius ? radius[i] : rh) : 1.0f;
-  float tx = 0.f, ty = 0.f, tz = 0.f;
+  const T pix = active ? pos[4 * (size_t)i] : T(0), piy = active ? pos[4 * (size_t)i + 1] : T(0), piz = active ? pos[4 * (size_t)i + 2] : T(0);
+  const T ai = active ? (radius ? radius[i] : rh) : T(1);
+  T tx = 0, ty = 0, tz = 0;
   for (int base = 0; base < N; base += 128) {
     const int j = base + threadIdx.x;
     if (j < N) {
-      const float4 p = pos[j];
-      tp[threadIdx.x] = make_float4(p.x, p.y, p.z, radius ? radius[j] : rh);
-      const float *vj = v + (size_t)VSTRIDE * j;
-      tv[threadIdx.x] = make_float4(vj[0], vj[1], vj[2], 0.f);
+      tp[threadIdx.x][0] = pos[4 * (size_t)j]; tp[threadIdx.x][1] = pos[4 * (size_t)j + 1]; tp[threadIdx.x][2] = pos[4 * (size_t)j + 2];
+      tp[threadIdx.x][3] = radius ? radius[j] : rh;
+      const T *vj = v + (size_t)VSTRIDE * j;
+      tv[threadIdx.x][0] = vj[0]; tv[threadIdx.x][1] = vj[1]; tv[threadIdx.x][2] = vj[2];
     }
     __syncthreads();
     const int cnt = min(128, N - base);
     if (active) {
       for (int t = 0; t < cnt; ++t) {
-        const float4 pj = tp[t], vj = tv[t];
-        const real3f rij{pi.x - pj.x, pi.y - pj.y, pi.z - pj.z};
-        const float r = sqrtf(dot3(rij, rij));
-        float f, g;
-        rpy_different_sizes(M0, r, ai, pj.w, f, g);
-        if (r == 0.0f) {
-          tx += f * vj.x; ty += f * vj.y; tz += f * vj.z;
+        const T rx = pix - tp[t][0], ry = piy - tp[t][1], rz = piz - tp[t][2];
+        const T vx = tv[t][0], vy = tv[t][1], vz = tv[t][2];
+        const T r2 = rpy_fma(rz, rz, rpy_fma(ry, ry, rx * rx));   // dot3's order
+        const T r = sqrt(r2);
+        T f, g;
+        rpy_different_sizes<T>(M0, r, ai, tp[t][3], f, g);
+        if (r == T(0)) {
+          tx += f * vx; ty += f * vy; tz += f * vz;
         } else {
-          const float gv = g * dot3(rij, real3f{vj.x, vj.y, vj.z});
-          tx += fmaf(gv, rij.x, f * vj.x);
-          ty += fmaf(gv, rij.y, f * vj.y);
-          tz += fmaf(gv, rij.z, f * vj.z);
+          const T gv = g * rpy_fma(rz, vz, rpy_fma(ry, vy, rx * vx));
+          tx += rpy_fma(gv, rx, f * vx);
+          ty += rpy_fma(gv, ry, f * vy);
+          tz += rpy_fma(gv, rz, f * vz);
         }
       }
     }
@@ -1436,13 +1441,15 @@ __global__ void __launch_bounds__(128) k_rpy_nbody(const float4 *__restrict__ po
   if (active) { Mv[3 * (size_t)i] = tx; Mv[3 * (size_t)i + 1] = ty; Mv[3 * (size_t)i + 2] = tz; }
 }
 
-struct RpyDotCtx { const float *pos, *radius; float rh, M0; int N; };
-static int rpy_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) {
-  const RpyDotCtx *c = static_cast<const RpyDotCtx *>(ctx);
-  hipLaunchKernelGGL((k_rpy_nbody<3>), dim3((c->N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)c->pos, d_v,
-                     c->radius, c->rh, c->M0, c->N, d_Mv);
+template <class T> struct RpyDotCtxT { const T *pos, *radius; T rh, M0; int N; };
+using RpyDotCtx = RpyDotCtxT<float>;
+template <class T> static int rpy_lanczos_dot_t(void *ctx, const T *d_v, T *d_Mv, int n, void *stream) {
+  const RpyDotCtxT<T> *c = static_cast<const RpyDotCtxT<T> *>(ctx);
+  hipLaunchKernelGGL((k_rpy_nbody<3, T>), dim3((c->N + 127) / 128), dim3(128), 0, (hipStream_t)stream, c->pos, d_v, c->radius, c->rh, c->M0, c->N, d_Mv);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+static int rpy_lanczos_dot(void *ctx, const float *d_v, float *d_Mv, int n, void *stream) { return rpy_lanczos_dot_t<float>(ctx, d_v, d_Mv, n, stream); }
+static int rpy_lanczos_dot64(void *ctx, const double *d_v, double *d_Mv, int n, void *stream) { return rpy_lanczos_dot_t<double>(ctx, d_v, d_Mv, n, stream); }
 
 }  // namespace uammd_hip
 
@@ -1795,11 +1802,26 @@ int uammd_rpy_nbody_mdot(const float *d_pos, const float *d_v, int vstride, cons
   }
   const float M0 = (float)(1 / (6 * M_PI * viscosity));
   if (vstride == 3)
-    hipLaunchKernelGGL((k_rpy_nbody<3>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)d_pos, d_v,
-                       d_radius, hydrodynamicRadius, M0, N, d_Mv);
+    hipLaunchKernelGGL((k_rpy_nbody<3, float>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_pos, d_v, d_radius, hydrodynamicRadius, M0, N, d_Mv);
   else
-    hipLaunchKernelGGL((k_rpy_nbody<4>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const float4 *)d_pos, d_v,
-                       d_radius, hydrodynamicRadius, M0, N, d_Mv);
+    hipLaunchKernelGGL((k_rpy_nbody<4, float>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_pos, d_v, d_radius, hydrodynamicRadius, M0, N, d_Mv);
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+// ... with real = double
+int uammd_rpy_nbody_mdot_f64(const double *d_pos, const double *d_v, int vstride, const double *d_radius, double hydrodynamicRadius, double viscosity,
+                             int N, double *d_Mv, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_v || !d_Mv || (vstride != 3 && vstride != 4)) { set_last_error("uammd_rpy_nbody_mdot_f64: bad arguments"); return -1; }
+  if (!d_radius && !(hydrodynamicRadius > 0)) {
+    set_last_error("[BDHI::Lanczos] You need to provide Lanczos with either an hydrodynamic radius or via the individual particle radius.");
+    return -2;
+  }
+  const double M0 = 1 / (6 * M_PI * viscosity);
+  if (vstride == 3)
+    hipLaunchKernelGGL((k_rpy_nbody<3, double>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_pos, d_v, d_radius, hydrodynamicRadius, M0, N, d_Mv);
+  else
+    hipLaunchKernelGGL((k_rpy_nbody<4, double>), dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_pos, d_v, d_radius, hydrodynamicRadius, M0, N, d_Mv);
   UH_CHECK(hipGetLastError());
   return 0;
 }
@@ -1815,6 +1837,17 @@ int uammd_rpy_lanczos_bdw(uammd_lanczos *solver, const float *d_pos, const float
   RpyDotCtx ctx{d_pos, d_radius, hydrodynamicRadius, (float)(1 / (6 * M_PI * viscosity)), N};
   int it = 0;
   const int rc = uammd_lanczos_run(solver, &rpy_lanczos_dot, &ctx, d_BdW, d_noise, tolerance, 3 * N, stream, &it);
+  if (iterations) *iterations = it;
+  return rc;
+}
+int uammd_rpy_lanczos_bdw_f64(uammd_lanczos_f64 *solver, const double *d_pos, const double *d_radius, double hydrodynamicRadius, double viscosity, int N,
+                              const double *d_noise, double tolerance, double *d_BdW, void *stream, int *iterations) {
+  if (iterations) *iterations = 0;
+  if (N <= 0) return 0;
+  if (!solver || !d_pos || !d_noise || !d_BdW) { set_last_error("uammd_rpy_lanczos_bdw_f64: null argument"); return -1; }
+  RpyDotCtxT<double> ctx{d_pos, d_radius, hydrodynamicRadius, 1 / (6 * M_PI * viscosity), N};
+  int it = 0;
+  const int rc = uammd_lanczos_run_f64(solver, &rpy_lanczos_dot64, &ctx, d_BdW, d_noise, tolerance, 3 * N, stream, &it);
   if (iterations) *iterations = it;
   return rc;
 }
