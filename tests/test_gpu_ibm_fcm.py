@@ -640,6 +640,44 @@ def test_fcm_step_slot_layout(hip, cells, n, cluster):
         assert np.array_equal(a[:, 3], pos[:, 3])
 
 
+def test_fcm_step_dropped_binning_leaves_no_stale_counts(hip):
+    """A step whose update falls back to the compact binning (k_fcm_update_bin: every slot_refresh-th step, or when the entries' order is
+    reported scrambled) leaves tile counts pending for the next solve.  If that solve does not claim them (the caller does not vouch for
+    the array, or it is a plain solve) and takes the slot layout instead, the counts must be marked as garbage: the next sorted solve once
+    took them for zeroed, ranked its particles on top of them and wrote its rows past the arrays (round 6: a memory fault of
+    test_fcm_step_bins_ahead run on its own, whenever the host ran far enough ahead of the device to read the scrambled-order report late).
+    Forced here without any dependence on timing: slot_refresh = 2 makes every third step fall back, unclaimed binnings alternate with
+    claimed ones and with plain solves; the trajectory equals the slot-less handle's at rounding level."""
+    cells, n = (64, 64, 64), 20001
+    L = np.asarray(cells, np.float32)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    dt = 0.01
+    rng = np.random.default_rng(11)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+
+    def run(slots):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        fcm.set_option("slots", 1 if slots else 0)
+        fcm.set_option("slot_refresh", 2)
+        dp, df = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(force).cuda()
+        for s in range(24):
+            if s % 5 == 3:   # a plain solve between two steps: whatever is pending is dropped
+                fcm.computeHydrodynamicDisplacements(dp, df, n, 0.0, 0.0)
+            fcm.stepEulerMaruyama(dp, df, n, 0.0, 1 / math.sqrt(dt), dt, positions_kept=(s % 2 == 1 and s % 5 != 3))
+        torch.cuda.synchronize()
+        return dp.cpu().numpy()
+
+    a, b = run(True), run(False)
+    assert np.isfinite(a).all()
+    moved = np.abs(b[:, :3] - pos[:, :3]).max()
+    assert moved > 0.05
+    d = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
+    assert (d > 2e-5 * moved + 4 * np.spacing(np.float32(L.max()))).sum() <= 3 and d.max() <= 1e-3 * moved
+
+
 def test_fcm_slot_layout_survives_a_relayout_of_the_callers_arrays(hip):
     """The slot layout's entry order is an index permutation left by the last sorted solve.  A caller that re-lays its arrays out with
     the same N (ParticleData::sortParticles, a compaction after migration) changes which particle an index means: the results must not

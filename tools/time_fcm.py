@@ -22,7 +22,7 @@ out = torch.empty((n, 3), dtype=torch.float32, device="cuda")
 for _ in range(10):
     fcm.computeHydrodynamicDisplacements(dp, df, n, float(os.environ.get("T", 1.0)), 10.0, out=out)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 100
+reps = int(os.environ.get("REPS", "100"))
 e0.record()
 for _ in range(reps):
     fcm.computeHydrodynamicDisplacements(dp, df, n, float(os.environ.get("T", 1.0)), 10.0, out=out)

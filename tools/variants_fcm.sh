@@ -2,7 +2,7 @@
 # A/B builds of fcm.hip with -D flags into tools/_build/libf_<name>.so, timed with tools/time_fcm.py through UAMMD_HIP_LIB:
 #   tools/variants_fcm.sh build   (here)      tools/variants_fcm.sh run   (on the GPU box)
 cd "$(dirname "$0")/.."
-declare -A FLAGS=([base]="" [w6144p4]="-DUAMMD_SP_WORDS=6144 -DUAMMD_SP_PER_THREAD=4" [p4]="-DUAMMD_SP_PER_THREAD=4" [p2]="-DUAMMD_SP_PER_THREAD=2" [p1]="-DUAMMD_SP_PER_THREAD=1" [ab1]="-DUAMMD_SP_ABLATE=1" [ab2]="-DUAMMD_SP_ABLATE=2" [ab4]="-DUAMMD_SP_ABLATE=4" [ab8]="-DUAMMD_SP_ABLATE=8" [ab3]="-DUAMMD_SP_ABLATE=3" [ab6]="-DUAMMD_SP_ABLATE=6" [ab7]="-DUAMMD_SP_ABLATE=7" [ab15]="-DUAMMD_SP_ABLATE=15" [w6144]="-DUAMMD_SP_WORDS=6144" [timeline]="-DUAMMD_SPREAD_TIMELINE" [pl1]="-DUAMMD_PREP_LANES=1" [pl2]="-DUAMMD_PREP_LANES=2" [pl4]="-DUAMMD_PREP_LANES=4" [pl8]="-DUAMMD_PREP_LANES=8" [zp256]="-DUAMMD_ZP_THREADS=256" [zp512]="-DUAMMD_ZP_THREADS=512" [plane64]="-DUAMMD_PLANE_ATTR=__attribute__((amdgpu_waves_per_eu(8,8)))")
+declare -A FLAGS=([base]="" [w6144p4]="-DUAMMD_SP_WORDS=6144 -DUAMMD_SP_PER_THREAD=4" [p4]="-DUAMMD_SP_PER_THREAD=4" [p2]="-DUAMMD_SP_PER_THREAD=2" [p1]="-DUAMMD_SP_PER_THREAD=1" [ab1]="-DUAMMD_SP_ABLATE=1" [ab2]="-DUAMMD_SP_ABLATE=2" [ab4]="-DUAMMD_SP_ABLATE=4" [ab8]="-DUAMMD_SP_ABLATE=8" [ab3]="-DUAMMD_SP_ABLATE=3" [ab6]="-DUAMMD_SP_ABLATE=6" [ab7]="-DUAMMD_SP_ABLATE=7" [ab15]="-DUAMMD_SP_ABLATE=15" [w6144]="-DUAMMD_SP_WORDS=6144" [timeline]="-DUAMMD_SPREAD_TIMELINE" [pl1]="-DUAMMD_PREP_LANES=1" [pl2]="-DUAMMD_PREP_LANES=2" [pl4]="-DUAMMD_PREP_LANES=4" [pl8]="-DUAMMD_PREP_LANES=8" [zp256]="-DUAMMD_ZP_THREADS=256" [zp512]="-DUAMMD_ZP_THREADS=512" [branchy]="-DUAMMD_SP_BRANCHY" [plane64]="-DUAMMD_PLANE_ATTR=__attribute__((amdgpu_waves_per_eu(8,8)))")
 NAMES=(${VNAMES:-base w6144p4 p4 p2 w6144})
 if [ "$1" = build ]; then
   mkdir -p tools/_build

@@ -673,6 +673,7 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
       const int r = threadIdx.x & 31, axis = r / E, t = r - E * (r / E);
       const int sa = axis == 0 ? sx : (axis == 1 ? sy : sz), aoff = axis == 0 ? 0 : (axis == 1 ? sx : sx + sy);
       const int pp0 = threadIdx.x >> 5;
+#ifdef UAMMD_SP_BRANCHY   // (round 5's form, tools/variants_fcm.sh: every staged element behind two branches — in range? does the stencil reach?)
       if (r < WT && !(UAMMD_SP_ABLATE & 1))
         staged_copy<8, float>(0, (count - pp0 + kThreads / 32 - 1) / (kThreads / 32), 1,
             [&](int j) {
@@ -681,6 +682,30 @@ k_fcm_spread_tile(float *__restrict__ g0, int3 n, int nxpad, size_t plane, size_
               return (unsigned)i < (unsigned)sa ? pr.weights[(size_t)wstride * en.slot + aoff + i] : 0.0f;
             },
             [&](int j, float v) { sh.wts[(pp0 + (kThreads / 32) * j) * WT + r] = v; });
+#else
+      // Eight listed particles per round, their words requested together, WITHOUT branches: an element past the thread's last one repeats
+      // the last (the same word stored twice), a word the stencil does not reach loads the stencil's first weight and keeps 0 — the
+      // compiler cannot speculate a load, so the guarded form was two exec-mask branches per element.  (tools/time_fcm.py, 1000 solves per
+      // figure, three interleaved runs: C4 0.1554 / 0.1559 / 0.1556 -> 0.1548 / 0.1546 / 0.1546 ms, 108^3 0.1679 / 0.1673 / 0.1680 ->
+      // 0.1658 / 0.1656 / 0.1658, C5 within its run-to-run spread.)
+      const int mine = (count - pp0 + kThreads / 32 - 1) / (kThreads / 32);
+      if (r < WT && mine > 0 && !(UAMMD_SP_ABLATE & 1)) {
+        for (int j0 = 0; j0 < mine; j0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = min(j0 + u, mine - 1);
+            const SpEntry &en = sh.list[pp0 + (kThreads / 32) * j];
+            const int i = t - (((en.o >> (7 * axis)) & 127) - 24);
+            const bool reach = (unsigned)i < (unsigned)sa;
+            const float w = pr.weights[(size_t)wstride * en.slot + aoff + (reach ? i : 0)];
+            v[u] = reach ? w : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sh.wts[(pp0 + (kThreads / 32) * min(j0 + u, mine - 1)) * WT + r] = v[u];
+        }
+      }
+#endif
     }
     if (SLOTS && (int)threadIdx.x < count) { SpEntry &en = sh.list[threadIdx.x]; en.fx = myForce.x; en.fy = myForce.y; en.fz = myForce.z; }
     __syncthreads();
@@ -2134,6 +2159,10 @@ static int fcm_prepare_best(FCM *f, const float *d_pos, const float *d_force, in
                  f->kern.support.x + f->kern.support.y + f->kern.support.z, f->tdim, (unsigned long long *)f->prepRec.ptr,
                  (int *)f->prepOvfTile.ptr, f->slotCap, counts + (size_t)f->slotParity * (nt + 2),
                  counts + (size_t)(f->slotParity ^ 1) * (nt + 2), f->slotFlagDev, (const float4 *)d_force};
+  // (a compact binning that k_fcm_update_bin left pending — the step fell back to it, e.g. because the entries' order was reported scrambled —
+  // is dropped here: its counts are still in tileCount, which the next sorted solve must not take for zeroed.  Found in round 6 as a memory
+  // fault of test_fcm_step_bins_ahead run on its own: ranks from stale counts sent k_fcm_prepare's rows past the arrays)
+  if (f->binnedPending) f->tileCountZero = false;
   f->binnedPending = false;
   // (no forces: no spread to hand the other parity's counters back zeroed)
   if (!d_force) UH_CHECK(hipMemsetAsync(out->slotCountNext, 0, sizeof(int) * (size_t)(nt + 2), st));
@@ -2335,6 +2364,7 @@ static bool fcm_step_prep_launch(FCM *f, float *d_pos, const float *v, int N, fl
   f->slotPos = (const void *)d_pos;
   f->slotN = N;
   f->slotSteps++;
+  if (f->binnedPending) f->tileCountZero = false;   // (see fcm_prepare_best)
   f->binnedPending = false;
   return true;
 }
