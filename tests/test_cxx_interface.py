@@ -373,7 +373,9 @@ def test_reference_bd_program_free_diffusion(scheme, tmp_path):
     exe = os.path.join(EX, "_build", "ref_test_BD")
     if not os.path.exists(exe):
         pytest.skip("ref_test_BD was not built (no reference tree where `make -C examples` ran)")
-    n, steps = 4096, 24
+    # (Leimkuhler is judged on lags 5 .. 15: windows that long are few and overlap in a short run — with 4096 particles and 24 frames
+    # the fitted slope scattered by ~5 %, the bar itself, and the test failed every other run; 16384 particles and 64 frames: ~1 %)
+    n, steps = (16384, 64) if scheme == "Leimkuhler" else (4096, 24)
     (tmp_path / "data.main").write_text(f"""scheme {scheme}
 potential none
 boxSize 32 32 32
