@@ -678,6 +678,76 @@ def test_fcm_step_dropped_binning_leaves_no_stale_counts(hip):
     assert (d > 2e-5 * moved + 4 * np.spacing(np.float32(L.max()))).sum() <= 3 and d.max() <= 1e-3 * moved
 
 
+@pytest.mark.parametrize("wait", [False, True], ids=["queued", "waited"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_fcm_step_random_call_sequences(hip, seed, wait):
+    """The FCM handle keeps state from call to call (a pending slot-layout preparation, a pending compact binning, counters of two parities,
+    the entries' order, the scrambled-order report read without a wait) and chooses among three preparations per solve.  A random sequence of
+    80 calls — steps that vouch for the array and steps that do not, plain solves with and without forces, with and without noise, particles
+    moved behind the library's back, a permutation of the caller's arrays, short slot_refresh — against the same sequence on a handle with the
+    slot layout and the binning ahead switched off: the same trajectory at rounding level (T = 0 in the steps: the noise stream advances
+    per solve on either handle).  Both ways of running it matter, because the handle reads the device's reports without waiting: queued
+    WITHOUT a wait in between (the host runs ahead and reads them late) and with a wait after every call (it reads them at once) take
+    different preparations.  Round 6 found one bug with each: a memory fault of a sorted solve (queued) and wrong stencil rows (waited),
+    both from tile counters that an unclaimed compact binning had left non-zero."""
+    cells, n = (64, 64, 64), 15000
+    L = np.asarray(cells, np.float32)
+    k, a_eff = hip.Kernels.Gaussian(1.0, 1e-3)
+    dt = 0.01
+    rng = np.random.default_rng(100 + seed)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    force = np.zeros((n, 4), np.float32)
+    force[:, :3] = rng.normal(0, 1, (n, 3))
+    ops = []
+    for _ in range(80):
+        u = rng.uniform()
+        if u < 0.55: ops.append(("step", bool(rng.uniform() < 0.7)))
+        elif u < 0.70: ops.append(("solve", bool(rng.uniform() < 0.5), float(rng.choice([0.0, 0.4]))))
+        elif u < 0.80: ops.append(("move", float(rng.uniform(0.1, 3.0))))
+        elif u < 0.88: ops.append(("permute", int(rng.integers(1 << 30))))
+        else: ops.append(("noforce_step",))
+
+    def run(tuned):
+        fcm = hip.BDHI.FCM_impl(hip.Box(L), cells, k, 0.9, 5, a_eff)
+        if tuned:
+            fcm.set_option("slot_refresh", 3)
+        else:
+            fcm.set_option("slots", 0)
+            fcm.set_option("bin_ahead", 0)
+        dp, df = torch.from_numpy(pos.copy()).cuda(), torch.from_numpy(force).cuda()
+        touched = True
+        for op in ops:
+            if op[0] == "step":
+                fcm.stepEulerMaruyama(dp, df, n, 0.0, 1 / math.sqrt(dt), dt, positions_kept=op[1] and not touched)
+                touched = False
+            elif op[0] == "noforce_step":
+                fcm.stepEulerMaruyama(dp, None, n, 0.0, 1 / math.sqrt(dt), dt, positions_kept=not touched)
+                touched = False
+            elif op[0] == "solve":
+                fcm.computeHydrodynamicDisplacements(dp, df if op[1] else None, n, op[2], 1.0)
+            elif op[0] == "move":
+                dp[:, :3] += op[1]
+                touched = True
+            else:
+                perm = torch.from_numpy(np.random.default_rng(op[1]).permutation(n)).cuda()
+                dp, df = dp[perm].contiguous(), df[perm].contiguous()
+                touched = True
+            if wait and tuned:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return dp.cpu().numpy(), df.cpu().numpy()
+
+    (a, fa), (b, fb) = run(True), run(False)
+    assert np.isfinite(a).all() and np.array_equal(fa, fb)
+    steps = sum(1 for op in ops if op[0] in ("step", "noforce_step"))
+    d = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
+    scale = np.abs(b[:, :3]).max()
+    # (rounding level per step; the few particles that sit on a cell centre to within rounding may differ by the kernel's tolerance, as in
+    # test_fcm_step_slot_layout)
+    assert (d > 4e-6 * scale * max(steps, 1) ** 0.5 + 1e-5).sum() <= 5 and d.max() <= 5e-3, (float(d.max()), int((d > 1e-4).sum()))
+
+
 def test_fcm_slot_layout_survives_a_relayout_of_the_callers_arrays(hip):
     """The slot layout's entry order is an index permutation left by the last sorted solve.  A caller that re-lays its arrays out with
     the same N (ParticleData::sortParticles, a compaction after migration) changes which particle an index means: the results must not

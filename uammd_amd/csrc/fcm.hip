@@ -2400,6 +2400,13 @@ int uammd_fcm_step_euler_maruyama(uammd_fcm *h, float *d_pos, const float *d_for
     pr.tileOf = (int *)f->prepTileOf.ptr; pr.rank = (int *)f->prepRank.ptr; pr.tileCount = (int *)f->prepTileCount.ptr;
     pr.origin = (int4 *)f->prepOrigin.ptr;   // (the stencils of the solve above: slot -> particle)
     pr.tdim = f->tdim;
+    // the binning counts on top of tileCount: zero after a sorted solve's tile scan, but NOT after a slot-layout solve that dropped an
+    // earlier unclaimed binning (fcm_prepare_best) — then they are zeroed here.  (Round 6, found by tests/test_gpu_ibm_fcm.py::
+    // test_fcm_step_random_call_sequences: ranks on top of stale counts, then a sorted solve that claimed them: wrong stencil rows.)
+    if (!f->tileCountZero) {
+      UH_CHECK(hipMemsetAsync(pr.tileCount, 0, sizeof(int) * (size_t)(f->ntiles.x * f->ntiles.y * f->ntiles.z), st));
+      f->tileCountZero = true;
+    }
   }
   hipLaunchKernelGGL(k_fcm_update_bin, dim3((N + 255) / 256), dim3(256), 0, st, (float4 *)d_pos, (const float *)v, N, dt, f->grid, f->ntiles,
                      pr, bin, bin && f->binBySlot, f->kern.support);
