@@ -636,3 +636,80 @@ def test_kept_lists_step_aside_in_a_box_of_three_cells(hip, o32):
     s = (C.c_longlong * 4)()
     check(pse.lib.uammd_pse_near_list_stats(pse.near, s))
     assert s[3] == 0 and s[1] == 0 and s[0] == 3
+
+
+@pytest.mark.parametrize("wait", [False, True], ids=["queued", "waited"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pse_random_call_sequences(hip, seed, wait):
+    """The PSE near field keeps state from call to call (a kept candidate list with its displacement bound, pair records built ahead and
+    verified after the solve, the Lanczos check schedule, the far field queued from inside the solve) and reads the device's reports
+    without waiting.  A random sequence of 40 calls on EulerMaruyama<PSE> at T > 0 — steps, particles moved together or jiggled one by
+    one behind the lists' back, sortParticles, plain computeMF calls — against the same sequence on a handle with the pair records, the
+    optimistic builds, the deferred checks and the fused recurrence switched off: the same trajectory to rounding (the draws are keyed by
+    particle and by the System generator's stream, which both handles consume alike).  Queued without a wait and with a wait after every
+    call: the two take different paths through the handle's state (tests/test_gpu_ibm_fcm.py::test_fcm_step_random_call_sequences found
+    two bugs of the FCM handle that way)."""
+    import math
+    from uammd_amd._lib import check
+    n, L = 20000, 64.0
+    rng = np.random.default_rng(200 + seed)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3)) * L
+    force = torch.from_numpy(rng.normal(0, 1, (n, 4)).astype(np.float32)).cuda()
+    force[:, 3] = 0
+    ops = []
+    for _ in range(40):
+        u = rng.uniform()
+        if u < 0.6: ops.append(("step",))
+        elif u < 0.72: ops.append(("move", float(rng.uniform(0.05, 2.0))))
+        elif u < 0.82: ops.append(("sort",))
+        elif u < 0.92: ops.append(("mf",))
+        else: ops.append(("jiggle", int(rng.integers(1 << 30))))
+
+    class Forces:
+        def __init__(self, pd): self.pd = pd
+        def sum(self, force_=False, energy=False, virial=False, **kw): self.pd.getForce("readwrite").add_(force)
+        def updateSimulationTime(self, t): pass
+        def updateTimeStep(self, dt): pass
+        def updateTemperature(self, T): pass
+        def updateBox(self, box): pass
+
+    def run(tuned, wait_):
+        pd = hip.ParticleData(n, seed=77)
+        pd.setPos(pos.copy())
+        par = hip.BDHI.PSE.Parameters(temperature=0.5, viscosity=1.0, hydrodynamicRadius=1.0, dt=0.01, box=hip.Box(L), tolerance=1e-3, psi=0.5)
+        em = hip.BDHI.EulerMaruyama(pd, par, Method=hip.BDHI.PSE)
+        pse = em.bdhi
+        if not tuned:
+            for name in ("pair_list", "optimistic_records", "defer_checks", "fuse_recurrence"):
+                check(pse.lib.uammd_pse_near_set_option(pse.near, name.encode(), 0))
+        em.addInteractor(Forces(pd))
+        MF = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        for op in ops:
+            if op[0] == "step":
+                em.forwardTime()
+            elif op[0] == "move":
+                pd.getPos("readwrite")[:, :3] += op[1]
+            elif op[0] == "sort":
+                pd.hintSortByHash(hip.Box(L), [5.3] * 3)
+                pd.sortParticles()
+            elif op[0] == "mf":
+                pd.getForce("write").zero_()
+                em.interactors[0].sum(True)
+                pse.computeMF(MF)
+            else:
+                g = torch.Generator(device="cuda").manual_seed(op[1])
+                pd.getPos("readwrite")[:, :3] += 0.3 * torch.randn((n, 3), generator=g, device="cuda")
+            if wait_:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return pd.getPos("read").cpu().numpy()   # (the same calls permute both handles' arrays alike)
+
+    ref = run(False, True)
+    out = run(True, wait)
+    d = np.abs(out[:, :3] - ref[:, :3])
+    d = np.minimum(d, L - d).max(axis=1)
+    nsteps = sum(1 for op in ops if op[0] == "step")
+    assert nsteps > 10 and np.isfinite(out).all()
+    # a step's noise displacement is ~ sqrt(2 T M0 dt) = 0.02: a lost or stale list shows at that size; rounding stays below 5e-5
+    assert d.max() <= 5e-5, (float(d.max()), int((d > 5e-5).sum()))
