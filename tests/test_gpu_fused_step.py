@@ -147,3 +147,63 @@ def test_traversal_with_second_half_step_on_a_list_with_ghosts(hip, case):
     assert float(f0[:n_owned, :3].abs().max()) > 1.0 and not _same(v0[:n_owned], vel0[:n_owned])
     assert _same(f0, f1) and _same(v0, v1)
     assert _same(v1[n_owned:], vel0[n_owned:]) and bool((f1[n_owned:] == 123.0).all())
+
+
+@pytest.mark.parametrize("wait", [False, True], ids=["queued", "waited"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_md_random_call_sequences(hip, seed, wait):
+    """The MD step keeps state from call to call as well (a cell list that rebuilds lazily on the position-write and reorder signals, the
+    fused step's own build standing in for update(), the sorter's hint).  A random sequence of 50 calls on VerletNVT::GronbechJensen with
+    PairForces<LJ, CellList> — steps, the whole system shifted by up to three sigma, particles jiggled one by one, sortParticles, plain
+    force evaluations — with the tile kernel (AUTO) against the same sequence with the exact kernels: the same trajectory to rounding
+    (the thermostat's streams are keyed by array row on both, and both permute their arrays alike); queued and with a wait after every
+    call."""
+    from util import lattice_positions
+    n = 20000
+    L = (n / 0.8) ** (1 / 3)
+    rng = np.random.default_rng(300 + seed)
+    pos0 = lattice_positions(n, L, seed=5, jitter=0.1)
+    ops = []
+    for _ in range(50):
+        u = rng.uniform()
+        if u < 0.62: ops.append(("step",))
+        elif u < 0.72: ops.append(("shift", float(rng.uniform(0.05, 3.0))))
+        elif u < 0.82: ops.append(("sort",))
+        elif u < 0.92: ops.append(("jiggle", int(rng.integers(1 << 30))))
+        else: ops.append(("forces",))
+
+    def run(algo, wait_):
+        pd = hip.ParticleData(n, seed=1234)
+        pd.setPos(pos0.copy())
+        box = hip.Box(L)
+        pot = hip.Potential.LJ()
+        pot.setPotParameters(0, 0, pot.InputPairParameters(2.5, 1.0, 1.0, False))
+        integ = hip.VerletNVT.GronbechJensen(pd, hip.VerletNVT.GronbechJensen.Parameters(temperature=1.0, dt=0.002, friction=1.0))
+        pf = hip.PairForces(pd, box, pot)
+        pf.algo = algo
+        integ.addInteractor(pf)
+        pd.hintSortByHash(box, [2.5] * 3)
+        for op in ops:
+            if op[0] == "step":
+                integ.forwardTime()
+            elif op[0] == "shift":
+                pd.getPos("readwrite")[:, :3] += op[1]
+            elif op[0] == "sort":
+                pd.sortParticles()
+            elif op[0] == "jiggle":
+                g = torch.Generator(device="cuda").manual_seed(op[1])
+                pd.getPos("readwrite")[:, :3] += 0.02 * torch.randn((n, 3), generator=g, device="cuda")
+            else:
+                pd.getForce("write").zero_()
+                pf.sum(force=True)
+            if wait_:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        out = np.zeros((n, 3))
+        out[pd.id.cpu().numpy().astype(np.int64)] = pd.getPos("read").cpu().numpy()[:, :3]
+        return out, integ.fused_steps
+
+    ref, _ = run(9, True)
+    got, fused = run(0, wait)
+    assert fused == sum(1 for op in ops if op[0] == "step") and np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 5e-5
