@@ -20,6 +20,28 @@
 #define UAMMD_HOSTDEV
 #endif
 
+// cospi / sinpi on the HOST: CUDA's math headers have them for host code (the reference's tests call cospi from host functions,
+// test/misc/ibm/test_ibm.cu:33); the HIP headers define the device functions only and glibc gains them with C23.  Reduced to [0, 1/2]
+// before the multiplication by pi, so that the half-integers give exact zeros.
+#include <cmath>
+#if defined(__HIPCC__)
+#define UAMMD_HOST_ONLY inline __host__
+#else
+#define UAMMD_HOST_ONLY inline
+#endif
+#if defined(__HIPCC__) || !defined(__GLIBC_PREREQ) || !__GLIBC_PREREQ(2, 41)
+UAMMD_HOST_ONLY double cospi(double x) {
+  x = std::fmod(std::fabs(x), 2.0);
+  if (x > 1.0) x = 2.0 - x;
+  if (x == 0.5) return 0.0;
+  const double pi = 3.14159265358979323846;
+  return x < 0.25 ? std::cos(pi * x) : (x > 0.75 ? -std::cos(pi * (1.0 - x)) : std::sin(pi * (0.5 - x)));
+}
+UAMMD_HOST_ONLY double sinpi(double x) { return cospi(x - 0.5); }
+UAMMD_HOST_ONLY float cospif(float x) { return (float)cospi((double)x); }
+UAMMD_HOST_ONLY float sinpif(float x) { return (float)sinpi((double)x); }
+#endif
+
 #define UAMMD_VERSION "3.0.0"
 #if !defined(DOUBLE_PRECISION) && !defined(SINGLE_PRECISION)
 #define SINGLE_PRECISION

@@ -41,7 +41,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("custom_potential", []), ("ibm_library_mode", []), ("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
                                        ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []), ("particle_group", ["600", "7"]),
-                                       ("custom_transverser", []), ("module_lifetime", []), ("particle_sorter", []), ("tabulated_function", []), ("container", []), ("dp_euler_maruyama", [])])
+                                       ("custom_transverser", []), ("module_lifetime", []), ("particle_sorter", []), ("tabulated_function", []), ("container", []), ("chebyshev_grid", []), ("dp_euler_maruyama", [])])
 def test_examples_run(prog, args):
     _make()
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
@@ -324,13 +324,16 @@ def test_user_side_saru_matches_the_golden_streams():
 # The reference's own GoogleTest programs of the starred rows (SURVEY 8c's pins), built by examples/Makefile from where they lie with
 # -DDOUBLE_PRECISION -DMAXLOGLEVEL=1 (test/CMakeLists.txt:4,9) against include/uammd + tests/cxx/gtest_lite; every TEST at its own tolerance:
 #   utils/ParticleSorter.cu (2)         misc/ibm/test_ibm_regular.cu (7: constant kernel counts, Peskin 1e-10, adjoint 1e-4)
+#   misc/ibm/test_ibm.cu (5: IBM<Kernel, Grid> with the USER's grid, support and quadrature: Gaussian with a per-particle support on
+#   chebyshev::doublyperiodic::Grid (misc/ChevyshevUtils.cuh), complex quantity, every node of 16^3 / 128^3 against the analytic window
+#   incl. which nodes are exactly zero; spread then gather with Clenshaw-Curtis weights against the closed form, 1e-11)
 #   misc/lanczos/test_lanczos.cu (7: identity .. dense SPD up to 511 x 511, 1e-7)   BDHI/FCM/fcm_test.cu (2: Hasimoto 1e-8 at 288^3)
 #   BDHI/PSE/pse_test.cu (4: Hasimoto 1e-8, self diffusion 1e-2)
 # and, for the other consumers of the spread / FFT / gather engine (their double-precision builds are csrc/f64.hip):
 #   BDHI/quasi2D/quasi2d_test.cu (5: self mobility of True2D / Quasi2D at seven box sizes 1e-3, fluctuation-dissipation 1e-2)
 #   Potentials/Poisson/TriplyPeriodic/test_poisson.cu (2: three charges against the analytic field 1e-3; L -> infinity extrapolation over
 #   109 box sizes x 6 distances 1e-4)      .../test_tp_quadrupole.cu (1: point quadrupole, tolerance 1e-14, window support 41: field 1e-8)
-REF_GTESTS = {"ParticleSorter": 2, "test_ibm_regular": 7, "test_lanczos": 7, "fcm_test": 2, "pse_test": 4, "quasi2d_test": 5, "test_poisson": 2,
+REF_GTESTS = {"ParticleSorter": 2, "test_ibm_regular": 7, "test_ibm": 5, "test_lanczos": 7, "fcm_test": 2, "pse_test": 4, "quasi2d_test": 5, "test_poisson": 2,
               "test_tp_quadrupole": 1}
 
 

@@ -41,7 +41,7 @@ HIPCC = ["basic_concepts/3-more_system.cu", "basic_concepts/4-uammd_types.cu", "
 # -DMAXLOGLEVEL=1 -DDOUBLE_PRECISION): the same front-end pass with tests/cxx/gtest_lite standing in for <gtest/gtest.h> / <gmock/gmock.h>
 # and, for the dense products test_lanczos.cu makes with cuBLAS itself, the hipBLAS spellings.  examples/Makefile BUILDS them and
 # tests/test_cxx_interface.py::test_reference_unit_tests_run RUNS them on the GPU.
-GTEST = ["../test/utils/ParticleSorter.cu", "../test/misc/ibm/test_ibm_regular.cu", "../test/misc/lanczos/test_lanczos.cu",
+GTEST = ["../test/utils/ParticleSorter.cu", "../test/misc/ibm/test_ibm_regular.cu", "../test/misc/ibm/test_ibm.cu", "../test/misc/lanczos/test_lanczos.cu",
          "../test/BDHI/FCM/fcm_test.cu", "../test/BDHI/PSE/pse_test.cu",
          # the other consumers of the engine: BDHI::True2D / Quasi2D and the triply periodic Poisson solver
          "../test/BDHI/quasi2D/quasi2d_test.cu", "../test/Potentials/Poisson/TriplyPeriodic/test_poisson.cu",
