@@ -493,10 +493,11 @@ struct SpEntry {
   int slot;
   float fx, fy, fz;
 };
-// dynamic LDS: float wts[weightWords + 32] | SpEntry list[257]
-// (+1: phase C reads 8 words per 5-word entry); the four private tiles of the final sum alias the same block
+// dynamic LDS: float wts[weightWords + 32] | SpEntry list[64 waves + 1]   (a list never holds more entries than the workgroup has threads;
+// +1: phase C reads 8 words per 5-word entry); the waves' private tiles of the final sum alias the same block.  Two-wave tiles with
+// 129 entries instead of 257: 15.6 KB per workgroup, ten of them on a CU — as many as the registers allow — instead of nine.
 static size_t spread_lds_bytes(int weightWords, int waves = 4, int edge = kTile) {
-  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * 257, b = sizeof(float) * waves * 3 * edge * edge * edge;
+  const size_t a = sizeof(float) * (size_t)(weightWords + 32) + sizeof(SpEntry) * (64 * waves + 1), b = sizeof(float) * waves * 3 * edge * edge * edge;
   return a > b ? a : b;
 }
 // two waves per tile where a tile lists few particles (measured at C5, ~26 listed: see DESIGN 5.4), four otherwise
