@@ -1,7 +1,4 @@
 // Forwarding header: same include path as the reference's src/Integrator/BrownianDynamics.cuh.
-// The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).
+// The whole host interface of the MI355X build lives in uammd.h (C++14, no device code).  Both precisions (uammd.h, PRECISION).
 #pragma once
-#if defined(DOUBLE_PRECISION)
-#error "BrownianDynamics.cuh: this module has a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
-#endif
 #include "../uammd.h"

@@ -22,10 +22,10 @@
 // FCM, the pair-record PSE near field — is single precision by construction; its DOUBLE_PRECISION build is the `_f64` part of the C ABI
 // (layout-generic kernels, rocFFT in double).  A DOUBLE_PRECISION program therefore gets: System, Box, Grid, ParticleData (+ sortParticles),
 // ParticleGroup, ParticleSorter, uninitialized_cached_vector, IBM<Kernel> (any kernel, device template), the FCM kernels, FCM_impl,
-// BDHI::FCM, BDHI::PSE, BDHI::Lanczos, BDHI::Cholesky, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver —
-// every class the reference's unit tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) and its double-precision
-// acceptance programs of path B (test/BDHI/{FCM, quasi2D, Lanczos_Cholesky}) construct.  The classes whose backend exists in single
-// precision only (CellList, VerletList, PairForces, VerletNVT, BD, FCMIntegrator, FIB, ICM, Comm) are not declared in that build: their
+// BDHI::FCM, BDHI::PSE, BDHI::Lanczos, BDHI::Cholesky, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver, the
+// four BD schemes — every class the reference's unit tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) and its
+// double-precision acceptance programs of path B (test/BDHI/{FCM, quasi2D, Lanczos_Cholesky}) construct.  The classes whose backend exists in
+// single precision only (CellList, VerletList, PairForces, VerletNVT, FCMIntegrator, FIB, ICM, Comm) are not declared in that build: their
 // forwarding headers stop the compilation with a message instead of silently computing in float.
 //
 // This header is plain host C++14: compile with any C++ compiler,
@@ -1560,7 +1560,11 @@ public:
 };
 }  // namespace VerletNVT
 
+#endif   // !DOUBLE_PRECISION
+
 // ---- BD: Brownian dynamics without hydrodynamic interactions (Integrator/BrownianDynamics.cuh:57-183, .cu) ------------------------------------
+// (both precisions: with -DDOUBLE_PRECISION — test/BD/Makefile:2 builds the reference's BD test so — the position update is
+// uammd_bd_scheme_step_f64; the draws stay float Gaussians there too, as Saru::gf makes them in the reference's double build)
 namespace BD {
 struct Parameters {
   std::vector<real3> K = std::vector<real3>(3, real3());   // shear matrix, row by row
@@ -1584,7 +1588,7 @@ public:
     } else if (!pd->isRadiusAllocated()) hydrodynamicRadius = real(1.0);
     if (par.K.size() == 3)
       for (int i = 0; i < 3; ++i) { K[3 * i] = par.K[i].x; K[3 * i + 1] = par.K[i].y; K[3 * i + 2] = par.K[i].z; }
-    for (float k : K) sheared = sheared || k != 0.0f;
+    for (real k : K) sheared = sheared || k != real(0.0);
   }
   BaseBrownianIntegrator(shared_ptr<ParticleData> pd, Parameters par) : BaseBrownianIntegrator(make_shared<ParticleGroup>(pd, "All"), par) {}
   real sumEnergy() override {   // 3/2 kT to every member's energy (:82-92)
@@ -1594,7 +1598,7 @@ public:
     return 0;
   }
 protected:
-  float K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  real K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool sheared = false;
   real selfMobility, hydrodynamicRadius = real(-1.0), temperature, dt;
   bool is2D;
@@ -1616,12 +1620,17 @@ protected:
     auto radius = radiusIfUsed();
     auto pos = pd->getPos(access::gpu, access::readwrite);
     auto force = pd->getForce(access::gpu, access::read);
+#if defined(DOUBLE_PRECISION)
+    detail::check(uammd_bd_scheme_step_f64(scheme, substep, (double *)pos.raw(), (double *)aux, groupIndex(), originalIndex, (const double *)force.raw(),
+                                           sheared ? K : nullptr, selfMobility, radius.raw(), dt, is2D, temperature, groupSize(), (uint)steps, seed, (void *)st));
+#else
     if (scheme == 0)
       detail::check(uammd_bd_euler_maruyama((float *)pos.raw(), groupIndex(), (const float *)force.raw(), sheared ? K : nullptr, selfMobility, radius.raw(), dt,
                                             is2D, temperature, groupSize(), (uint)steps, seed, (void *)st));
     else
       detail::check(uammd_bd_scheme_step(scheme, substep, (float *)pos.raw(), (float *)aux, groupIndex(), originalIndex, (const float *)force.raw(),
                                          sheared ? K : nullptr, selfMobility, radius.raw(), dt, is2D, temperature, groupSize(), (uint)steps, seed, (void *)st));
+#endif
   }
 };
 class EulerMaruyama : public BaseBrownianIntegrator {   // x += dt (K x + M F) + sqrt(2 T M dt) dW (.cu:119-170)
@@ -1683,8 +1692,6 @@ public:
   }
 };
 }  // namespace BD
-
-#endif   // !DOUBLE_PRECISION
 
 // ---- BDHI::Parameters (Integrator/BDHI/BDHI.cuh:13-24) -----------------------------------------------------------------------------------
 namespace BDHI {

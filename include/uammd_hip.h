@@ -290,6 +290,12 @@ int uammd_fcm_euler_maruyama(float *d_pos, const int *d_index, const float *d_li
 int uammd_bd_scheme_step(int scheme, int substep, float *d_pos, float *d_aux, const int *d_index, const int *d_originalIndex, const float *d_force,
                          const float K[9], float selfMobility, const float *d_radius, float dt, int is2D, float temperature, int numberParticles,
                          unsigned int stepNum, unsigned int seed, void *stream);
+/* ... and the four schemes with real = double (d_pos, d_aux, d_force double4[N], d_radius double[N]; UAMMD_BD_EULER_MARUYAMA is the scheme of
+ * uammd_bd_euler_maruyama).  The draws are float Gaussians, as in the reference's double build (Saru::gf). */
+#define UAMMD_BD_EULER_MARUYAMA 0
+int uammd_bd_scheme_step_f64(int scheme, int substep, double *d_pos, double *d_aux, const int *d_index, const int *d_originalIndex,
+                             const double *d_force, const double K[9], double selfMobility, const double *d_radius, double dt, int is2D,
+                             double temperature, int numberParticles, unsigned int stepNum, unsigned int seed, void *stream);
 /* BDHI::EulerMaruyama_ns::integrateGPUD (Integrator/BDHI/BDHI_EulerMaruyama.cu:82-113): pos += dt (K pos + MF) + sqrt2Tdt BdW;
  * d_MF, d_BdW real3[N] (d_BdW nullable), K row-major 3x3 (nullable) */
 int uammd_bdhi_euler_maruyama(float *d_pos, const int *d_index, const float *d_MF, const float *d_BdW, const float K[9],

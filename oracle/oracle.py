@@ -317,7 +317,7 @@ class Oracle:
 
     def bd_euler_maruyama(self, pos4, force4, self_mobility, dt, temperature, step_num, seed, K=None, radius=None,
                           index=None, is2D=False):
-        n = len(pos4)
+        n = len(pos4) if index is None else len(index)
         K9 = None if K is None else self.r(K).reshape(9)
         self.lib.oracle_bd_euler_maruyama(_p(pos4), _p(index), _p(force4), _p(K9), self.creal(self_mobility),
                                           _p(radius), self.creal(dt), int(is2D), self.creal(temperature), n,

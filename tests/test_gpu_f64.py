@@ -350,3 +350,67 @@ def test_rpy_open_boundary_f64_vs_oracle(hip, o64, sizes):
         assert np.abs(B @ B.T - M).max() <= 1e-12 * np.abs(M).max()
     finally:
         lib.uammd_bdhi_cholesky_destroy_f64(h)
+
+
+@pytest.mark.parametrize("T", [0.0, 1.0])
+@pytest.mark.parametrize("scheme", ["EulerMaruyama", "MidPoint", "AdamsBashforth", "Leimkuhler"])
+def test_bd_schemes_f64_vs_oracle(hip, o64, scheme, T):
+    """The four BD schemes with real = double (Integrator/BrownianDynamics.cu:119-144, :178-214, :262-289, :313-345 as test/BD/Makefile:2
+    builds them) through uammd_bd_scheme_step_f64 against the double build of the oracle's restatement, three steps as forwardTime strings
+    the calls: a proper subgroup, shear, per-particle radii, forces that change between the calls.  T = 0: the same bits.  T > 0: the draws
+    are FLOAT Gaussians in both (Saru::gf) and differ by libm vs device logf / sinf — 4e-5 of the noise amplitude, as in single precision."""
+    import ctypes as C
+    from uammd_amd._lib import check, load
+    lib = load()
+    n, dt, M, seed = 6000, 0.1, 1.0 / (6 * math.pi), 24680
+    rng = np.random.default_rng(3)
+    pos = np.zeros((n, 4), np.float64)
+    pos[:, :3] = rng.uniform(-0.5, 0.5, (n, 3))
+    pos[:, 3] = rng.integers(0, 3, n)
+    radius = rng.uniform(0.5, 1.5, n)
+    index = np.sort(rng.choice(n, 4000, replace=False)).astype(np.int32)
+    original = rng.permutation(n).astype(np.int32)
+    K = np.array([[0, 0.1, 0], [0, 0, 0], [0.2, 0, 0]], np.float64)
+    Kc = (C.c_double * 9)(*[float(x) for x in K.reshape(9)])
+    code = {"EulerMaruyama": 0, "MidPoint": 1, "AdamsBashforth": 2, "Leimkuhler": 3}[scheme]
+    rp, dp = pos.copy(), torch.from_numpy(pos.copy()).cuda()
+    raux, daux = np.zeros((len(index), 4), np.float64), torch.zeros((len(index), 4), dtype=torch.float64, device="cuda")
+    dindex, dorig, dradius = torch.from_numpy(index).cuda(), torch.from_numpy(original).cuda(), torch.from_numpy(radius).cuda()
+    P = lambda t: C.c_void_p(t.data_ptr())
+
+    def forces(k):
+        f = np.zeros((n, 4), np.float64)
+        f[:, :3] = np.random.default_rng(100 + k).normal(0, 1, (n, 3))
+        return f
+
+    def gpu(sub, f, step):
+        check(lib.uammd_bd_scheme_step_f64(code, sub, P(dp), P(daux), P(dindex), P(dorig), P(f), Kc, M, P(dradius), dt, 0, T, len(index), step, seed, None))
+
+    B = math.sqrt(2 * T * M * dt / 0.5)   # the largest noise amplitude among the members (radius >= 0.5)
+    for step in range(1, 4):
+        f0, f1 = forces(2 * step), forces(2 * step + 1)
+        if scheme == "EulerMaruyama":
+            o64.bd_euler_maruyama(rp, f0, M, dt, T, step, seed, K=K, radius=radius, index=index)
+            gpu(0, torch.from_numpy(f0).cuda(), step)
+        elif scheme == "MidPoint":
+            o64.bd_midpoint(0, rp, raux, f0, M, dt, T, step, seed, K=K, radius=radius, index=index)
+            gpu(0, torch.from_numpy(f0).cuda(), step)
+            o64.bd_midpoint(1, rp, raux, f1, M, dt, T, step, seed, K=K, radius=radius, index=index)
+            gpu(1, torch.from_numpy(f1).cuda(), step)
+        elif scheme == "AdamsBashforth":
+            raux[:] = f0[index]
+            daux.copy_(torch.from_numpy(f0[index]))
+            o64.bd_adams_bashforth(rp, raux, f1, M, dt, T, step, seed, K=K, radius=radius, index=index)
+            gpu(0, torch.from_numpy(f1).cuda(), step)
+        else:
+            o64.bd_leimkuhler(rp, f0, M, dt, T, step, seed, K=K, radius=radius, index=index, original_index=original)
+            gpu(0, torch.from_numpy(f0).cuda(), step)
+        torch.cuda.synchronize()
+        got = dp.cpu().numpy()
+        if T == 0:
+            assert np.array_equal(got, rp), np.abs(got - rp).max()
+        else:
+            assert np.abs(got - rp).max() <= 4e-5 * B * step
+            assert np.array_equal(got[:, 3], rp[:, 3])
+        others = np.setdiff1d(np.arange(n), index)
+        assert np.array_equal(got[others], pos[others])      # nobody outside the group moved

@@ -190,6 +190,7 @@ SIGNATURES = {
     "uammd_bd_euler_maruyama": (_i, [_vp, _vp, _vp, C.POINTER(_f), _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
     "uammd_fcm_euler_maruyama": (_i, [_vp, _vp, _vp, _i, _f, _vp]),
     "uammd_bd_scheme_step": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _f, _i, _f, _i, _u, _u, _vp]),
+    "uammd_bd_scheme_step_f64": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _i, _d, _i, _u, _u, _vp]),
     "uammd_bdhi_euler_maruyama": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _f, _f, _i, _vp]),
     "uammd_fill_zero": (_i, [_vp, C.c_size_t, _vp]),
     "uammd_fill_zero_indexed": (_i, [_vp, _vp, _i, _i, _vp]),

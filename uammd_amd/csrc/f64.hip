@@ -1082,6 +1082,94 @@ int uammd_bdhi_euler_maruyama_f64(double *d_pos, const int *d_index, const doubl
   return 0;
 }
 
+// ---- BD::EulerMaruyama / MidPoint / AdamsBashforth / Leimkuhler with real = double (Integrator/BrownianDynamics.cu:119-144, :178-214,
+// :262-289, :313-345; single precision: integrators.hip).  One streaming kernel, the scheme a template parameter; the same expressions
+// as the single-precision kernels in double.  The draws stay FLOAT Gaussians, as in the reference's double build: Saru::gf takes and
+// returns floats (third_party/saruprng.cuh:291-301), the amplitude is rounded to float on the way in.
+//   SCHEME 0             EulerMaruyama: sqrt(2 T M dt), the generator keyed by the particle index i
+//   SCHEME 1, SUB 0 / 1  MidPoint: half a step from the current forces (the starting point kept in aux[id]), then a whole step from the
+//                        kept point with the midpoint's forces; sqrt(T M dt) per draw, the second sub-step repeats the first draw and
+//                        adds another; keyed by the GROUP index id
+//   SCHEME 2             AdamsBashforth: forces 3/2 F_n - 1/2 F_(n-1) (aux[id] = F_(n-1) in group order), sqrt(2 T M dt), keyed by id
+//   SCHEME 3             Leimkuhler: Euler drift, noise sqrt(T M dt / 2) (dW_n + dW_(n-1)), keyed by originalIndex[i]
+}  // extern "C"
+struct Shear9c { double k[9]; };
+template <int SCHEME, int SUB>
+__global__ void __launch_bounds__(256) k_bd_scheme64(double *__restrict__ pos, double *__restrict__ aux, const int *__restrict__ index,
+                                                     const int *__restrict__ originalIndex, const double *__restrict__ force, Shear9c K,
+                                                     double selfMobility, const double *__restrict__ radius, double dt, int is2D,
+                                                     double temperature, int N, uint stepNum, uint seed) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= N) return;
+  const size_t i = (size_t)(index ? index[id] : id);
+  double px = pos[4 * i], py = pos[4 * i + 1], pz = pos[4 * i + 2];
+  if (SCHEME == 1) {
+    if (SUB == 0) { aux[4 * (size_t)id] = px; aux[4 * (size_t)id + 1] = py; aux[4 * (size_t)id + 2] = pz; aux[4 * (size_t)id + 3] = pos[4 * i + 3]; }
+    else { px = aux[4 * (size_t)id]; py = aux[4 * (size_t)id + 1]; pz = aux[4 * (size_t)id + 2]; }
+  }
+  double fx = force[4 * i], fy = force[4 * i + 1], fz = force[4 * i + 2];
+  double KRx = fma(K.k[2], pz, fma(K.k[1], py, K.k[0] * px)), KRy = fma(K.k[5], pz, fma(K.k[4], py, K.k[3] * px)),
+         KRz = fma(K.k[8], pz, fma(K.k[7], py, K.k[6] * px));
+  const double M = selfMobility * (radius ? (1.0 / radius[i]) : 1.0);
+  if (SCHEME == 1 && SUB == 0) { fx *= 0.5; fy *= 0.5; fz *= 0.5; KRx *= 0.5; KRy *= 0.5; KRz *= 0.5; }
+  if (SCHEME == 2) {
+    const double qx = aux[4 * (size_t)id], qy = aux[4 * (size_t)id + 1], qz = aux[4 * (size_t)id + 2];
+    fx = fma(-0.5, qx, 1.5 * fx); fy = fma(-0.5, qy, 1.5 * fy); fz = fma(-0.5, qz, 1.5 * fz);
+  }
+  double rx = fma(dt, fma(M, fx, KRx), px), ry = fma(dt, fma(M, fy, KRy), py), rz = fma(dt, fma(M, fz, KRz), pz);
+  if (temperature > 0.0) {
+    if (SCHEME == 3) {
+      const uint ori = (uint)(originalIndex ? originalIndex[i] : (int)i);
+      const double B = sqrt(0.5 * temperature * M * dt);
+      Saru a(ori, stepNum, seed), b(ori, stepNum - 1u, seed);
+      const float2 a01 = a.gf(0.0f, 1.0f);
+      const float a2 = a.gf(0.0f, 1.0f).x;
+      const float2 b01 = b.gf(0.0f, 1.0f);
+      const float b2 = b.gf(0.0f, 1.0f).x;
+      rx = fma(B, (double)a01.x + (double)b01.x, rx); ry = fma(B, (double)a01.y + (double)b01.y, ry); rz = fma(B, (double)a2 + (double)b2, rz);
+    } else {
+      const float B = (float)(SCHEME == 1 ? sqrt(temperature * M * dt) : sqrt(2.0 * temperature * M * dt));
+      Saru rng(SCHEME == 0 ? (uint)i : (uint)id, stepNum, seed);
+      const float2 d01 = rng.gf(0.0f, B);
+      const float d2 = rng.gf(0.0f, B).x;
+      rx += (double)d01.x; ry += (double)d01.y; rz += (double)d2;
+      if (SCHEME == 1 && SUB == 1) {
+        const float2 e01 = rng.gf(0.0f, B);
+        const float e2 = rng.gf(0.0f, B).x;
+        rx += (double)e01.x; ry += (double)e01.y; rz += (double)e2;
+      }
+    }
+  }
+  pos[4 * i] = rx;
+  pos[4 * i + 1] = ry;
+  if (!is2D) pos[4 * i + 2] = rz;   // (pos[i].w is the particle's own: never written)
+}
+extern "C" {
+int uammd_bd_scheme_step_f64(int scheme, int substep, double *d_pos, double *d_aux, const int *d_index, const int *d_originalIndex,
+                             const double *d_force, const double K[9], double selfMobility, const double *d_radius, double dt, int is2D,
+                             double temperature, int N, unsigned int stepNum, unsigned int seed, void *stream) {
+  if (N <= 0) return 0;
+  if (!d_pos || !d_force || ((scheme == UAMMD_BD_MIDPOINT || scheme == UAMMD_BD_ADAMS_BASHFORTH) && !d_aux)) {
+    set_last_error("uammd_bd_scheme_step_f64: null argument");
+    return -1;
+  }
+  Shear9c S{};
+  if (K) for (int t = 0; t < 9; ++t) S.k[t] = K[t];
+  const dim3 g((N + 255) / 256), b(256);
+  hipStream_t st = (hipStream_t)stream;
+#define UH_BD64(SC, SU) hipLaunchKernelGGL((k_bd_scheme64<SC, SU>), g, b, 0, st, d_pos, d_aux, d_index, d_originalIndex, d_force, S, selfMobility, \
+                                           d_radius, dt, is2D, temperature, N, stepNum, seed)
+  if (scheme == UAMMD_BD_EULER_MARUYAMA) UH_BD64(0, 0);
+  else if (scheme == UAMMD_BD_MIDPOINT && substep == 0) UH_BD64(1, 0);
+  else if (scheme == UAMMD_BD_MIDPOINT && substep == 1) UH_BD64(1, 1);
+  else if (scheme == UAMMD_BD_ADAMS_BASHFORTH) UH_BD64(2, 0);
+  else if (scheme == UAMMD_BD_LEIMKUHLER) UH_BD64(3, 0);
+  else { set_last_error("uammd_bd_scheme_step_f64: unknown scheme %d / sub-step %d", scheme, substep); return -1; }
+#undef UH_BD64
+  UH_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ---- BDHI::True2D / Quasi2D, real = double (the single-precision entry points: quasi2d.hip) ---------------------------------------------
 int uammd_bdhi2d_create_f64(const uammd_bdhi2d_parameters_f64 *par, uammd_bdhi2d_f64 **out, int cells[2], int *support) {
   if (!par || !out || (par->kernel != UAMMD_BDHI2D_TRUE2D && par->kernel != UAMMD_BDHI2D_QUASI2D)) {

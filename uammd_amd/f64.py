@@ -276,3 +276,49 @@ class Poisson:
         fp = torch.zeros((n, 4), dtype=torch.float64, device=pos.device)
         check(self.lib.uammd_poisson_field_potential_f64(self.h, _ptr(pos), _ptr(charge), n, _ptr(fp), None, None, _stream()))
         return fp
+
+
+class BD:
+    """BD::EulerMaruyama / MidPoint / AdamsBashforth / Leimkuhler with real = double (Integrator/BrownianDynamics.cuh:57-183): positions and
+    forces double[N, 4]; `forces(pos)` fills the force array before each position update, as the scheme's interactors would (None: free
+    particles).  seed: the reference takes the System generator's third draw."""
+    SCHEMES = {"EulerMaruyama": 0, "MidPoint": 1, "AdamsBashforth": 2, "Leimkuhler": 3}
+
+    def __init__(self, scheme, temperature, viscosity, hydrodynamicRadius, dt, seed, K=None, is2D=False, forces=None):
+        self.lib = _lib.load()
+        self.scheme = self.SCHEMES[scheme]
+        self.temperature, self.dt, self.is2D, self.seed = float(temperature), float(dt), bool(is2D), int(seed) & 0xFFFFFFFF
+        self.selfMobility = 1.0 / (6.0 * math.pi * float(viscosity) * float(hydrodynamicRadius))
+        self.K = None if K is None else (C.c_double * 9)(*[float(x) for x in np.asarray(K, dtype=np.float64).reshape(9)])
+        self.forces, self.steps, self.aux, self.force = forces, 0, None, None
+
+    def _eval(self, pos):
+        if self.force is None or self.force.shape != pos.shape:
+            self.force = torch.zeros_like(pos)
+        self.force.zero_()
+        if self.forces is not None:
+            self.forces(pos, self.force)
+
+    def _advance(self, pos, substep, original_index=None):
+        check(self.lib.uammd_bd_scheme_step_f64(self.scheme, substep, _ptr(pos), _ptr(self.aux), None, _ptr(original_index), _ptr(self.force), self.K,
+                                                self.selfMobility, None, self.dt, int(self.is2D), self.temperature, pos.shape[0], self.steps, self.seed,
+                                                _stream()))
+
+    def forwardTime(self, pos, original_index=None):
+        self.steps += 1
+        if self.scheme == 1:       # MidPoint: two force evaluations (BrownianDynamics.cu:216-232)
+            if self.aux is None:
+                self.aux = torch.empty_like(pos)
+            self._eval(pos)
+            self._advance(pos, 0)
+            self._eval(pos)
+            self._advance(pos, 1)
+        elif self.scheme == 2:     # AdamsBashforth: the previous step's forces are kept (:291-308)
+            if self.steps == 1:
+                self._eval(pos)
+            self.aux = self.force.clone()
+            self._eval(pos)
+            self._advance(pos, 0)
+        else:
+            self._eval(pos)
+            self._advance(pos, 0, original_index if self.scheme == 3 else None)
