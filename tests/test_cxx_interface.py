@@ -99,13 +99,13 @@ def test_signal_semantics_host_only(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,expect", [("ref_NeighbourListIterator", "mean FPS"), ("ref_neighbour_list", None), ("ref_signals", "No work needs to be done"),
-                                         ("ref_temporary_memory", None)])
+                                         ("ref_temporary_memory", None), ("ref_execution_policy", "0 1 2")])
 def test_more_reference_programs_run(prog, expect, tmp_path):
-    """The reference's examples/advanced/{NeighbourListIterator,signals,temporary_memory}.cu and uammd_as_a_library/neighbour_list.cu,
+    """The reference's examples/advanced/{NeighbourListIterator,signals,temporary_memory,execution_policy}.cu and uammd_as_a_library/neighbour_list.cu,
     compiled from where they lie by hipcc against include/uammd (examples/Makefile, the documented user-side spellings replaced) and RUN:
     a kernel of the program's own over CellList::getNeighbourContainer() driving 500 steps of VerletNVT, BasicNeighbourListBase on a
     thrust vector with the list walked from a kernel, from thrust and downloaded, signal / connection objects, thrust vectors on
-    System::allocator_thrust."""
+    System::allocator_thrust, thrust::sort under uammd::cached_device_execution_policy.on(stream)."""
     exe = os.path.join(EX, "_build", prog)
     if not os.path.exists(exe):
         pytest.skip(prog + " was not built (no reference tree where `make -C examples` ran)")
