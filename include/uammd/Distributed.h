@@ -11,6 +11,9 @@
 // examples/lj_slab.cpp and examples/fcm_slab.cpp use a file), then every rank builds its Comm and its driver.
 #ifndef UAMMD_DISTRIBUTED_H
 #define UAMMD_DISTRIBUTED_H
+#if defined(DOUBLE_PRECISION)
+#error "Distributed.h: the slab drivers have a single-precision backend only on MI355X (uammd.h, PRECISION): build without -DDOUBLE_PRECISION"
+#endif
 #include "uammd.h"
 
 #include <chrono>
