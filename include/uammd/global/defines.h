@@ -29,7 +29,12 @@
 #else
 #define UAMMD_HOST_ONLY inline
 #endif
-#if defined(__HIPCC__) || !defined(__GLIBC_PREREQ) || !__GLIBC_PREREQ(2, 41)
+#if defined(__GLIBC_PREREQ)
+#if __GLIBC_PREREQ(2, 41)
+#define UAMMD_LIBM_HAS_COSPI   // (glibc 2.41 declares the C23 functions itself)
+#endif
+#endif
+#if !defined(UAMMD_LIBM_HAS_COSPI)
 UAMMD_HOST_ONLY double cospi(double x) {
   x = std::fmod(std::fabs(x), 2.0);
   if (x > 1.0) x = 2.0 - x;
