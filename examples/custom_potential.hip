@@ -43,6 +43,33 @@ struct Yukawa {
 };
 
 // the reference's examples/misc/LJ.cu:35-66 shape: a wall acting on one species, arrays chosen by the functor
+// a soft repulsion whose strength follows the simulation time (the pattern of the reference's examples/advanced/ParameterUpdatable.cu:126-201)
+struct GrowingRepulsion : public ParameterUpdatable {
+  real temperature = -1, dt = -1, time = -1, boxL = -1, viscosity = -1;
+  int timeCalls = 0;
+  real getCutOff() { return real(2.0); }
+  struct Transverser {
+    real4 *force;
+    Box box;
+    real strength;
+    __device__ real3 compute(real4 pi, real4 pj) {
+      const real3 rij = box.apply_pbc(make_real3(pj) - make_real3(pi));
+      const real r2 = dot(rij, rij);
+      if (r2 > 0 && r2 < real(4.0)) return rij * (-strength * (real(4.0) - r2));
+      return make_real3(0);
+    }
+    __device__ void set(int id, real3 total) { force[id] += make_real4(total, 0); }
+  };
+  Transverser getTransverser(Interactor::Computables, Box box, std::shared_ptr<ParticleData> pd) {
+    return Transverser{pd->getForce(access::gpu, access::readwrite).raw(), box, real(1.0) + (time > 0 ? time : real(0))};
+  }
+  void updateTemperature(real v) override { temperature = v; }
+  void updateTimeStep(real v) override { dt = v; }
+  void updateSimulationTime(real v) override { time = v; ++timeCalls; }
+  void updateBox(Box b) override { boxL = b.boxSize.x; }
+  void updateViscosity(real v) override { viscosity = v; }
+};
+
 struct HarmonicWall : public ParameterUpdatable {
   real zwall, k = 0.1;
   real lastTime = -1;
@@ -215,6 +242,43 @@ int main() {
     std::printf("ExternalForces: wall on the %d particles of type 1 + drag on odd ids: max |dF| %.2e, max |dE| %.2e, functor saw t = %.2f\n",
                 species1->getNumberParticles(), worst, worstE, wall->lastTime);
     if (worst > 1e-5 || worstE > 1e-5 || wall->lastTime != real(3.25) || species1->getNumberParticles() != (N + 2) / 3) { ++fails; std::printf("FAIL ExternalForces\n"); }
+  }
+  {  // a Potential that is ParameterUpdatable hears what its PairForces hears (ParameterUpdatableDelegate, PairForces.cuh:25,40-44): through
+     // an integrator — time every step, temperature and time step once — and directly; its Transverser follows the time
+    const int N = 512;
+    auto pd = std::make_shared<ParticleData>(N);
+    {
+      auto pos = pd->getPos(access::cpu, access::write);
+      std::mt19937 gen(9);
+      std::uniform_real_distribution<real> u(-8, 8);
+      for (int i = 0; i < N; ++i) pos[i] = make_real4(u(gen), u(gen), u(gen), 0);
+    }
+    using PF = PairForces<GrowingRepulsion>;
+    PF::Parameters par;
+    par.box = Box(real(16));
+    auto pot = std::make_shared<GrowingRepulsion>();
+    auto pf = std::make_shared<PF>(pd, par, pot);
+    VerletNVT::GronbechJensen::Parameters ipar;
+    ipar.temperature = real(0.75); ipar.dt = real(0.002); ipar.friction = real(1.0);
+    auto verlet = std::make_shared<VerletNVT::GronbechJensen>(pd, ipar);
+    verlet->addInteractor(pf);
+    for (int s = 0; s < 5; ++s) verlet->forwardTime();
+    const bool heard = pot->temperature == real(0.75) && pot->dt == real(0.002) && pot->timeCalls == 5 && std::fabs(pot->time - real(4 * 0.002)) < 1e-7;
+    pf->updateBox(Box(real(20)));
+    pf->updateViscosity(real(3.5));
+    pf->updateSimulationTime(real(2.0));   // strength(t) = 1 + t
+    { auto f = pd->getForce(access::cpu, access::write); std::fill(f.begin(), f.end(), real4()); }
+    pf->sum({.force = true, .energy = false, .virial = false});
+    double f3 = 0;
+    { auto f = pd->getForce(access::cpu, access::read); for (int i = 0; i < N; ++i) f3 += std::fabs(f[i].x) + std::fabs(f[i].y) + std::fabs(f[i].z); }
+    pf->updateSimulationTime(real(0.0));
+    { auto f = pd->getForce(access::cpu, access::write); std::fill(f.begin(), f.end(), real4()); }
+    pf->sum({.force = true, .energy = false, .virial = false});
+    double f1 = 0;
+    { auto f = pd->getForce(access::cpu, access::read); for (int i = 0; i < N; ++i) f1 += std::fabs(f[i].x) + std::fabs(f[i].y) + std::fabs(f[i].z); }
+    std::printf("ParameterUpdatable Potential behind PairForces: heard T = %.2f, dt = %.3f, %d time updates (last %.4f), box %.0f, viscosity %.1f; sum |f| at strength 3 / at strength 1 = %.5f\n",
+                (double)pot->temperature, (double)pot->dt, pot->timeCalls, (double)pot->time, (double)pot->boxL, (double)pot->viscosity, f3 / f1);
+    if (!heard || pot->boxL != real(20) || pot->viscosity != real(3.5) || !(f1 > 0) || std::fabs(f3 / f1 - 3.0) > 1e-4) { ++fails; std::printf("FAIL ParameterUpdatable Potential\n"); }
   }
   std::printf(fails ? "FAILED\n" : "ok\n");
   return fails;

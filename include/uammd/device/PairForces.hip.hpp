@@ -148,17 +148,30 @@ template <class Tr> int transverseList(VerletList &nl, Tr &tr, const int *global
 
 // The primary template (uammd.h declares it and specialises it for Potential::LJ): any MyPotential with getCutOff() and
 // getTransverser(Computables, Box, shared_ptr<ParticleData>), on the CellList or the VerletList.
+namespace pairforces_detail {
+// ParameterUpdatableDelegate<Potential> (misc/ParameterUpdatable.h:84-103, PairForces.cuh:25,40-44, PairForces.cu:40): every parameter
+// update PairForces receives goes on to its Potential when the Potential is ParameterUpdatable — a Potential whose strength follows the
+// simulation time or the temperature (examples/advanced/ParameterUpdatable.cu:126-201) depends on it
+template <class P> std::enable_if_t<std::is_base_of<ParameterUpdatable, P>::value, ParameterUpdatable *> updatable(P *p) { return p; }
+template <class P> std::enable_if_t<!std::is_base_of<ParameterUpdatable, P>::value, ParameterUpdatable *> updatable(P *) { return nullptr; }
+}  // namespace pairforces_detail
+
 template <class MyPotential, class NL> class PairForces : public Interactor {
   Box box;
   shared_ptr<MyPotential> pot;
   shared_ptr<NL> nl;
+  ParameterUpdatable *delegate() { return pairforces_detail::updatable(pot.get()); }
 public:
   struct Parameters { Box box; shared_ptr<NL> nl = nullptr; };
   PairForces(shared_ptr<ParticleData> pd, Parameters par, shared_ptr<MyPotential> pot = make_shared<MyPotential>())
       : Interactor(pd, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
   PairForces(shared_ptr<ParticleGroup> pg, Parameters par, shared_ptr<MyPotential> pot = make_shared<MyPotential>())
       : Interactor(pg, "PairForces"), box(par.box), pot(pot), nl(par.nl) {}
-  void updateBox(Box b) override { box = b; }
+  void updateBox(Box b) override { box = b; if (auto *d = delegate()) d->updateBox(b); }
+  void updateTimeStep(real v) override { if (auto *d = delegate()) d->updateTimeStep(v); }
+  void updateSimulationTime(real v) override { if (auto *d = delegate()) d->updateSimulationTime(v); }
+  void updateTemperature(real v) override { if (auto *d = delegate()) d->updateTemperature(v); }
+  void updateViscosity(real v) override { if (auto *d = delegate()) d->updateViscosity(v); }
   shared_ptr<MyPotential> getPotential() { return pot; }
   template <class Transverser> void sumTransverser(Transverser &tr, hipStream_t st) {  // PairForces.cu:43-68
     const real rcut = pot->getCutOff();

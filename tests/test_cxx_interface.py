@@ -155,15 +155,18 @@ def test_reference_parameter_updatable_program_steps(tmp_path):
     cuda::std::plus as thrust::plus): VerletNVT::GronbechJensen over ExternalForces<MovingWall> — a functor that is ParameterUpdatable and
     reads the simulation time in its device code —, a small Interactor that overrides updateSimulationTime, and PairForces with a
     Potential of the program's own whose Transverser is rebuilt when the temperature or the time changes.  The program hard-codes 1e6
-    steps: it is given a few seconds, must have written frames by then (one per 1000 steps), and is stopped."""
+    steps: it is given a few seconds, must have written twelve frames by then (one per 1000 steps; t = 60), and is stopped.  (Twelve: while
+    PairForces did not hand the parameter updates on to its Potential — ParameterUpdatableDelegate, PairForces.cuh:25 — the example's
+    epsilon(t) stayed at its initial 0, the particles overlapped freely under the wall's pull, 0 * inf made a NaN and the cell list
+    refused the positions after 1000 to 10000 steps; the same system through Potential::LJ runs on: tools/pu_physics_check.py.)"""
     import time
     exe = os.path.join(EX, "_build", "ref_ParameterUpdatable")
     if not os.path.exists(exe):
         pytest.skip("ref_ParameterUpdatable was not built (no reference tree where `make -C examples` ran)")
     with open(tmp_path / "out.txt", "w") as out, open(tmp_path / "err.txt", "w") as err:
         p = subprocess.Popen([exe], cwd=tmp_path, stdout=out, stderr=err)
-        deadline = time.time() + 60
-        while time.time() < deadline and p.poll() is None and os.path.getsize(tmp_path / "out.txt") < 5 * 16384 * 40:   # (a frame is ~0.6 MB)
+        deadline = time.time() + 120
+        while time.time() < deadline and p.poll() is None and os.path.getsize(tmp_path / "out.txt") < 14 * 16384 * 40:   # (a frame is ~0.6 MB)
             time.sleep(0.5)
         running = p.poll() is None
         if running:
@@ -173,8 +176,8 @@ def test_reference_parameter_updatable_program_steps(tmp_path):
     errors = open(tmp_path / "err.txt").read()
     assert running or p.returncode == 0, errors[-3000:]
     frames = text.split("#Lx=")[1:]
-    assert len(frames) >= 3, (len(frames), errors[-2000:])
-    rows = np.array([[float(x) for x in line.split()[:3]] for line in frames[1].splitlines()[1:16385]])
+    assert len(frames) >= 12, (len(frames), errors[-2000:])
+    rows = np.array([[float(x) for x in line.split()[:3]] for line in frames[10].splitlines()[1:16385]])
     assert rows.shape == (16384, 3) and np.isfinite(rows).all()
     assert np.abs(rows[:, 0]).max() <= 16.0 + 1e-3 and np.abs(rows[:, 2]).max() <= 20.0 + 1e-3      # inside the box it prints (apply_pbc)
     assert "ERROR" not in errors and "EXCEPTION" not in errors, errors[-3000:]

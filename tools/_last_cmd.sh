@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-# the GPU suite with its files in reverse order (order dependence between files)
-python -m pytest $(ls tests/test_*.py | tac) -m gpu -q -x 2>&1 | tail -5
+examples/_build/custom_potential | tail -3
+python -m pytest tests/test_cxx_interface.py -m gpu -q -x -k "parameter_updatable or examples_run" 2>&1 | tail -3
