@@ -149,6 +149,53 @@ def test_more_reference_programs_run(prog, expect, tmp_path):
         assert expect in r.stdout + r.stderr
 
 
+# Every other program of the compile corpus (tests/test_reference_programs_compile.py), built in full by examples/Makefile and RUN: the
+# thirteen tutorials of basic_concepts/, LJMultipleTypes, checkpoint, customPotentials, error_handling (which provokes the exceptions it
+# shows how to handle), the FCM / BDHI / q2D integrator examples, the Poisson and ExternalForces examples, electrostatic_forces.
+REF_EXAMPLES = ["1-system", "2-hello_world", "3-more_system", "4-uammd_types", "5-particle_data", "6-particle_data2", "7-moving_particles", "8-interacting_particles",
+                "9-reading_parameters", "10-initial_configuration", "11-measuring_things", "12-your-first-integrator", "13-your-first-interactor", "LJMultipleTypes",
+                "checkpoint", "customPotentials", "error_handling", "FCM", "BDHI", "q2D", "Poisson", "external", "electrostatic_forces"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REF_EXAMPLES)
+def test_reference_example_programs_run(name, tmp_path):
+    """Each program runs in a directory of its own to its end, or for 20 s where it hard-codes a long run (BDHI.cu), without an abort, an
+    uncaught exception or a non-finite number in what it prints; q2D.cu is given the parameter file its main() asks for (both schemes)."""
+    exe = os.path.join(EX, "_build", "ref_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("ref_%s was not built (no reference tree where `make -C examples` ran)" % name)
+    runs = [[]]
+    if name == "q2D":
+        runs = []
+        for scheme in ("quasi2D", "true2D"):
+            (tmp_path / ("data." + scheme)).write_text("boxSize 64 64\nnumberSteps 2000\nprintSteps 500\ndt 0.01\nrelaxSteps 0\nviscosity 1\ntemperature 1\n"
+                                                      "hydrodynamicRadius 1\nscheme %s\nnumberParticles 4096\nloadParticles 0\noutput pos.%s\n" % (scheme, scheme))
+            runs.append(["data." + scheme])
+    for args in runs:
+        with open(tmp_path / "out.txt", "w") as out, open(tmp_path / "err.txt", "w") as err:
+            p = subprocess.Popen([exe] + args, cwd=tmp_path, stdout=out, stderr=err)
+            try:
+                p.wait(timeout=20)
+                stopped = False
+            except subprocess.TimeoutExpired:
+                p.terminate()
+                p.wait(timeout=30)
+                stopped = True
+        text, errors = open(tmp_path / "out.txt").read(), open(tmp_path / "err.txt").read()
+        assert stopped or p.returncode == 0, (p.returncode, errors[-2000:])
+        assert "terminate called" not in errors and "Aborted" not in errors, errors[-2000:]
+        if name != "error_handling":
+            assert "EXCEPTION" not in errors and "ERROR" not in errors, errors[-2000:]
+        words = text.split()
+        assert not any(w.lower() in ("nan", "-nan", "inf", "-inf") for w in words[:200000]), "a non-finite number in the output"
+    if name == "q2D":
+        for scheme in ("quasi2D", "true2D"):
+            rows = [l.split() for l in open(tmp_path / ("pos." + scheme)) if not l.startswith("#")]
+            a = np.array([[float(x) for x in r[:2]] for r in rows if len(r) >= 2])
+            assert a.shape == (4 * 4096, 2) and np.isfinite(a).all()
+
+
 @pytest.mark.gpu
 def test_reference_parameter_updatable_program_steps(tmp_path):
     """examples/_build/ref_ParameterUpdatable = the reference's examples/advanced/ParameterUpdatable.cu compiled from where it lies (its
