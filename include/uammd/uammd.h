@@ -337,10 +337,19 @@ public:
 };
 
 // ---- System/System.h -----------------------------------------------------------------------------------------------
+// System.h:37-46.  `device` is the device the System found current (or set: --device); `cuda_arch` is the reference's name for the
+// device's architecture as a number — 950 for gfx950 (the digits of hipDeviceProp_t::gcnArchName), 0 when there is no device.
+struct SystemParameters {
+  int device = -1;
+  int cuda_arch = 0;
+  int minimumCudaArch = 200;
+  bool managedMemoryAvailable = false;
+};
 class System {
   Xorshift128plus m_rng;
   int m_argc = 0;
   char **m_argv = nullptr;
+  SystemParameters sysPar;
 public:
   enum LogLevel { CRITICAL = 0, ERROR, EXCEPTION, WARNING, MESSAGE, STDERR, STDOUT, DEBUG, DEBUG1, DEBUG2, DEBUG3, DEBUG4, DEBUG5, DEBUG6, DEBUG7 };
   System() : System(0, nullptr) {}
@@ -351,7 +360,17 @@ public:
     for (int i = 1; argv && i < argc; ++i)
       if (std::string(argv[i]) == "--device" && i + 1 < argc) dev = std::atoi(argv[i + 1]);  // System.h:128-139
     if (dev >= 0) detail::check(uammd_hip_set_device(dev));
+    int current = -1;
+    if (hipGetDevice(&current) == hipSuccess && current >= 0) {
+      sysPar.device = current;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, current) == hipSuccess) {
+        for (const char *c = prop.gcnArchName; *c && *c != ':'; ++c) if (*c >= '0' && *c <= '9') sysPar.cuda_arch = 10 * sysPar.cuda_arch + (*c - '0');
+        sysPar.managedMemoryAvailable = prop.managedMemory != 0;
+      }
+    } else (void)hipGetLastError();
   }
+  const SystemParameters getSystemParameters() const { return sysPar; }   // System.h:299
   Xorshift128plus &rng() { return m_rng; }
   int getargc() const { return m_argc; }                          // System.h:282-290
   const char **getargv() const { return (const char **)m_argv; }
@@ -1102,7 +1121,9 @@ protected:
 public:
   void addInteractor(shared_ptr<Interactor> an_interactor) { interactors.push_back(an_interactor); addUpdatable(an_interactor); }
   std::vector<shared_ptr<Interactor>> getInteractors() { return interactors; }
-  void addUpdatable(shared_ptr<ParameterUpdatable> u) { updatables.push_back(u); }
+  // (Integrator.cuh:109-124: the reference keeps a std::set — an object added twice, e.g. as an interactor and as an updatable, hears once)
+  void addUpdatable(shared_ptr<ParameterUpdatable> u) { if (std::find(updatables.begin(), updatables.end(), u) == updatables.end()) updatables.push_back(u); }
+  std::vector<shared_ptr<ParameterUpdatable>> getUpdatables() { return updatables; }
 };
 
 #if !defined(DOUBLE_PRECISION)   // (single-precision backends only: see PRECISION at the top)

@@ -47,6 +47,29 @@ int main() {
     assert(none.size() == 0 && none.begin() == none.end());
   }
   assert(pool.blocksLive() == live0);       // every block went back to the pool
+  {  // System::getSystemParameters (System.h:37-46,299) and the Integrator's set of updatables (Integrator.cuh:90-124)
+    auto sys = std::make_shared<System>();
+    const SystemParameters sp = sys->getSystemParameters();
+    std::printf("device %d, architecture %d, managed memory %d\n", sp.device, sp.cuda_arch, (int)sp.managedMemoryAvailable);
+    assert(sp.device >= 0 && sp.cuda_arch == 950);
+    struct Heard : public Interactor {
+      using Interactor::Interactor;
+      int times = 0;
+      void sum(Computables, hipStream_t) override {}
+      void updateSimulationTime(real) override { ++times; }
+    };
+    auto pd = std::make_shared<ParticleData>(8, sys);
+    BD::EulerMaruyama::Parameters par;
+    par.dt = real(0.1); par.hydrodynamicRadius = 1; par.viscosity = 1;
+    BD::EulerMaruyama bd(pd, par);
+    auto in = std::make_shared<Heard>(pd, "heard");
+    bd.addInteractor(in);
+    bd.addUpdatable(in);                    // the same object again: a set, it hears each update once
+    assert(bd.getUpdatables().size() == 1 && bd.getInteractors().size() == 1);
+    bd.forwardTime();
+    bd.forwardTime();
+    assert(in->times == 2);
+  }
   std::printf("container: ok\n");
   return 0;
 }
