@@ -99,6 +99,27 @@ int main(int argc, char *argv[]) {
     auto it = pl->getIndexIterator(access::cpu);
     bad += id[it[0]] != 3 || id[it[1]] != 5 || id[it[2]] != 9;
   }
+  {  // a group emptied and filled again by hand (ParticleGroup.cuh:221-227): by id from the host, by current index from the device;
+     // the membership is by id, so it follows the particles through a sort
+    pl->clear();
+    bad += pl->getNumberParticles() != 0;
+    const int byId[2] = {42, 7};
+    pl->addParticlesById(access::cpu, byId, 2);
+    int target = -1;
+    { auto id = pd->getId(access::cpu, access::read); for (int i = 0; i < N; ++i) if (id[i] == 1234 % N) target = i; }
+    int *d_idx = nullptr;
+    detail::hipCheck(hipMalloc((void **)&d_idx, sizeof(int)), "hipMalloc");
+    detail::hipCheck(hipMemcpy(d_idx, &target, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy");
+    pl->addParticlesByCurrentIndex(access::gpu, d_idx, 1);
+    (void)hipFree(d_idx);
+    bad += pl->getNumberParticles() != 3;
+    pd->sortParticles();
+    auto id = pd->getId(access::cpu, access::read);
+    auto it = pl->getIndexIterator(access::cpu);
+    const bool ok = id[it[0]] == 42 && id[it[1]] == 7 && id[it[2]] == 1234 % N;
+    std::printf("group refilled by id and by current index, after a sort: members' ids %d %d %d\n", id[it[0]], id[it[1]], id[it[2]]);
+    bad += !ok;
+  }
   sys->finish();
   return bad;
 }

@@ -31,7 +31,21 @@ int main(int argc, char *argv[]) {
   (void)hipMemcpy(&v, MF.d, sizeof(v), hipMemcpyDeviceToHost);
   const double m0 = pse->getSelfMobility();
   std::printf("PSE self mobility %.7f expected %.7f (off-diagonal %.2e %.2e)\n", v.y, m0, v.x, v.z);
-  const bool ok1 = std::abs(v.y - m0) < par.tolerance && std::abs(v.x) < par.tolerance && std::abs(v.z) < par.tolerance;
+  bool ok1 = std::abs(v.y - m0) < par.tolerance && std::abs(v.x) < par.tolerance && std::abs(v.z) < par.tolerance;
+  {  // computeMF = computeMFFarField + computeMFNearField (BDHI_PSE.cuh:92-120), the forces taken from the ParticleData
+    { auto f = pd->getForce(access::cpu, access::write); f[0] = fx; }
+    detail::DeviceArray<real3> whole(1), parts(1);
+    pse->computeMF(whole.d, 0);
+    detail::check(uammd_fill_zero(parts.d, sizeof(real3), nullptr));
+    pse->computeMFFarField(parts.d, 0);
+    pse->computeMFNearField(parts.d, 0);
+    pse->computeDivM(parts.d, 0);
+    real3 a, b;
+    (void)hipMemcpy(&a, whole.d, sizeof(a), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&b, parts.d, sizeof(b), hipMemcpyDeviceToHost);
+    std::printf("computeMF %.7f = far + near %.7f\n", a.y, b.y);
+    ok1 = ok1 && std::abs(a.y - b.y) < 1e-6 && std::abs(a.y - m0) < par.tolerance;
+  }
   // a thermal step: the particle must move, finitely
   par.temperature = 1.0;
   par.dt = 0.01;

@@ -1020,6 +1020,31 @@ public:
     init();
   }
   ParticleGroup(const ParticleGroup &) = delete;
+  // ParticleGroup.cuh:221-227,498-600: an emptied group filled again by hand — by id, or by the particles' CURRENT indices in the
+  // ParticleData (translated to ids at once: the membership is by id and survives reorders); `loc` says where the array lives.
+  // Members keep the order they were added in.
+  void clear() { myParticlesIds.clear(); allParticlesInGroup = false; needsIndexUpdate = true; }
+  void addParticlesById(access::location loc, const int *ids, int N) {
+    if (N <= 0) return;
+    if (allParticlesInGroup) { myParticlesIds.resize(pd->getNumParticles()); for (size_t k = 0; k < myParticlesIds.size(); ++k) myParticlesIds[k] = (int)k; }
+    const size_t before = myParticlesIds.size();
+    myParticlesIds.resize(before + N);
+    if (loc == access::gpu) detail::hipCheck(hipMemcpy(myParticlesIds.data() + before, ids, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost), "hipMemcpy");
+    else std::copy(ids, ids + N, myParticlesIds.begin() + before);
+    allParticlesInGroup = false;
+    needsIndexUpdate = true;
+  }
+  void addParticlesByCurrentIndex(access::location loc, const int *indices, int N) {
+    if (N <= 0) return;
+    std::vector<int> idx(N);
+    if (loc == access::gpu) detail::hipCheck(hipMemcpy(idx.data(), indices, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost), "hipMemcpy");
+    else std::copy(indices, indices + N, idx.begin());
+    {
+      auto id = pd->getId(access::cpu, access::read);
+      for (int &v : idx) v = id[v];
+    }
+    addParticlesById(access::cpu, idx.data(), N);
+  }
   int getNumberParticles() const { return allParticlesInGroup ? pd->getNumParticles() : (int)myParticlesIds.size(); }
   shared_ptr<ParticleData> getParticleData() { return pd; }
   std::string getName() const { return name; }
@@ -2433,6 +2458,16 @@ public:
     nearDeterministic(force, MF, st);
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
+  // the two halves of computeMF on their own (:101-120): each ADDS its part for the particles' current forces to MF
+  void computeMFNearField(real3 *MF, hipStream_t st = 0) {
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    nearDeterministic(detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st), MF, st);
+  }
+  void computeMFFarField(real3 *MF, hipStream_t st = 0) {
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    far(detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st), MF, temperature, real(1.0 / std::sqrt(dt)), st);
+  }
+  void computeDivM(real3 *, hipStream_t = 0) {}   // (:125: the divergence of the PSE mobility is zero)
   void computeHydrodynamicDisplacements(real4 *force, real3 *MF, real T, real noise_prefactor, hipStream_t st = 0) {  // :135-155
     detail::check(uammd_fill_zero(MF, sizeof(real3) * numberParticles(), (void *)st));
     nearDeterministic(force, MF, st);
@@ -2518,6 +2553,18 @@ public:
     detail::check(uammd_pse_near_mdot(nearField, positions(pos, st), (const float *)force, N, (float *)MF, (void *)st));
   }
   void computeBdW(real3 *BdW, hipStream_t st = 0) { nearStochastic(BdW, temperature, 1.0, st); }
+  // the two halves of computeMF on their own (:101-120): each ADDS its part for the particles' current forces to MF
+  void computeMFNearField(real3 *MF, hipStream_t st = 0) {
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    const real4 *force = detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st);
+    auto pos = pd->getPos(access::gpu, access::read);
+    detail::check(uammd_pse_near_mdot(nearField, positions(pos, st), (const float *)force, numberParticles(), (float *)MF, (void *)st));
+  }
+  void computeMFFarField(real3 *MF, hipStream_t st = 0) {
+    auto forceAll = pd->getForce(access::gpu, access::read);
+    far(detail::groupRows((const real4 *)forceAll.raw(), pg.get(), forceRows, st), MF, temperature, real(1.0 / std::sqrt(dt)), st);
+  }
+  void computeDivM(real3 *, hipStream_t = 0) {}   // (:125: the divergence of the PSE mobility is zero)
   // computeMF and computeBdW (:92-126) as EulerMaruyama runs them when T > 0, queued so that the step's one wait for the GPU — the Lanczos
   // solve's convergence check — has work behind it: near-field list and pair records, the solve, the FAR FIELD from inside the solve
   // (uammd_pse_near_set_interleave: behind the check's kernels, while the host is busy with the check), then the near-field M F.  The same
