@@ -414,3 +414,32 @@ def test_bd_schemes_f64_vs_oracle(hip, o64, scheme, T):
             assert np.array_equal(got[:, 3], rp[:, 3])
         others = np.setdiff1d(np.arange(n), index)
         assert np.array_equal(got[others], pos[others])      # nobody outside the group moved
+
+
+@pytest.mark.parametrize("scheme", ["EulerMaruyama", "MidPoint", "AdamsBashforth", "Leimkuhler"])
+def test_bd_python_mirror_f64(f64, scheme):
+    """uammd_amd.f64.BD (the Python mirror of the double-precision BD classes): a constant force at T = 0 moves every particle by
+    n dt M F to rounding, whatever the scheme; at T > 0 free particles spread with <x^2> = 2 T M dt n per axis (Leimkuhler: n - 1/2)."""
+    n, dt, steps = 4096, 0.125, 8
+    rng = np.random.default_rng(5)
+    start = np.zeros((n, 4)); start[:, :3] = rng.uniform(-3, 3, (n, 3))
+    pull = torch.tensor([0.25, -0.5, 1.0, 0.0], dtype=torch.float64, device="cuda")
+
+    def forces(pos, force):
+        force += pull
+
+    bd = f64.BD(scheme, 0.0, 1.0 / (6 * math.pi), 1.0, dt, 1234, forces=forces)
+    pos = _dev(start)
+    for _ in range(steps):
+        bd.forwardTime(pos)
+    torch.cuda.synchronize()
+    expect = start[:, :3] + steps * dt * np.array([0.25, -0.5, 1.0])
+    assert np.abs(pos.cpu().numpy()[:, :3] - expect).max() < 1e-13
+    T = 0.7
+    bd = f64.BD(scheme, T, 1.0 / (6 * math.pi), 1.0, dt, 4321)
+    pos = torch.zeros((16384, 4), dtype=torch.float64, device="cuda")
+    for _ in range(steps):
+        bd.forwardTime(pos)
+    msd = float((pos[:, :3] ** 2).mean())
+    expected = 2 * T * dt * (steps - 0.5 if scheme == "Leimkuhler" else steps)
+    assert abs(msd / expected - 1) < 0.03, (msd, expected)      # 49152 samples of a sum of 8 steps: the estimate's own deviation is ~0.7 %
