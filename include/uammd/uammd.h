@@ -22,10 +22,10 @@
 // FCM, the pair-record PSE near field — is single precision by construction; its DOUBLE_PRECISION build is the `_f64` part of the C ABI
 // (layout-generic kernels, rocFFT in double).  A DOUBLE_PRECISION program therefore gets: System, Box, Grid, ParticleData (+ sortParticles),
 // ParticleGroup, ParticleSorter, uninitialized_cached_vector, IBM<Kernel> (any kernel, device template), the FCM kernels, FCM_impl,
-// BDHI::FCM, BDHI::PSE, BDHI::Lanczos, BDHI::Cholesky, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver, the
+// BDHI::FCM, BDHI::FCMIntegrator (no rotation), BDHI::PSE, BDHI::Lanczos, BDHI::Cholesky, BDHI::EulerMaruyama<Method>, BDHI::True2D / Quasi2D, Poisson, lanczos::Solver, the
 // four BD schemes — every class the reference's unit tests (test/CMakeLists.txt:19-28, minus the doubly periodic and Chebyshev ones) and its
 // double-precision acceptance programs of path B (test/BDHI/{FCM, quasi2D, Lanczos_Cholesky}) construct.  The classes whose backend exists in
-// single precision only (CellList, VerletList, PairForces, VerletNVT, FCMIntegrator, FIB, ICM, Comm) are not declared in that build: their
+// single precision only (CellList, VerletList, PairForces, VerletNVT, FIB, ICM, Comm) are not declared in that build: their
 // forwarding headers stop the compilation with a message instead of silently computing in float.
 //
 // This header is plain host C++14: compile with any C++ compiler,
@@ -2373,6 +2373,48 @@ public:
     detail::check(uammd_fcm_euler_maruyama_dir((float *)pos.raw(), (float *)dir.raw(), groupIndex(), (const float *)linearV.d,
                                                dir.raw() ? (const float *)angularV.d : nullptr, N, dt, (void *)st));
   }
+};
+using FCMIntegrator = FCMIntegratorT<>;
+#else
+// DOUBLE_PRECISION build of the same integrator (BDHI_FCM.cuh:155-199, BDHI_FCM.cu:7-119): the solve through FCM_impl's `_f64` entry
+// points, the update pos += v dt through uammd_bdhi_euler_maruyama_f64.  No rotation in this build: particles with directions or torques
+// are refused, as FCM_impl's double build refuses torques.
+template <class Kernel = FCM_ns::Kernels::Gaussian> class FCMIntegratorT : public Integrator {
+  using KernelTorque = FCM_ns::Kernels::GaussianTorque;
+  shared_ptr<FCM_impl<Kernel, KernelTorque>> fcm;
+  detail::DeviceArray<real3> linearV;
+  real temperature, dt;
+  uint steps = 0;
+  hipStream_t st = 0;
+  detail::DeviceArray<real4> posRows, forceRows;  // the rows of a proper subgroup, gathered
+public:
+  using Parameters = typename FCM_impl<Kernel, KernelTorque>::Parameters;
+  FCMIntegratorT(shared_ptr<ParticleGroup> group, Parameters par)
+      : Integrator(group, "BDHI::FCMIntegrator"), linearV(group->getNumberParticles()), temperature(par.temperature), dt(par.dt) {
+    fcm = make_shared<FCM_impl<Kernel, KernelTorque>>(detail_fcm::initialize<Kernel, KernelTorque>(par, *sys));
+  }
+  FCMIntegratorT(shared_ptr<ParticleData> pd, Parameters par) : FCMIntegratorT(make_shared<ParticleGroup>(pd, "All"), par) {}
+  shared_ptr<FCM_impl<Kernel, KernelTorque>> getFCM_impl() { return fcm; }
+  void forwardTime() override {
+    steps++;
+    for (auto &u : updatables) u->updateSimulationTime(steps * dt);
+    if (steps == 1) for (auto &u : updatables) { u->updateTimeStep(dt); u->updateTemperature(temperature); u->updateBox(fcm->getBox()); }
+    if (pd->isDirAllocated() || pd->isTorqueAllocated())
+      throw std::runtime_error("[BDHI::FCMIntegrator] rotation (directions / torques) is not part of the double-precision build on MI355X");
+    resetGroupForces(st);
+    for (auto &f : interactors) { Interactor::Computables c; c.force = true; f->sum(c, st); }
+    const int N = groupSize();
+    {
+      auto pos = pd->getPos(access::gpu, access::read);
+      auto force = pd->getForce(access::gpu, access::read);
+      fcm->computeHydrodynamicDisplacements(detail::groupRows(pos.raw(), subgroup.get(), posRows, st), detail::groupRows(force.raw(), subgroup.get(), forceRows, st),
+                                            linearV.d, N, temperature, 1.0 / std::sqrt(dt), st);
+    }
+    auto pos = pd->getPos(access::gpu, access::readwrite);
+    detail::check(uammd_bdhi_euler_maruyama_f64((double *)pos.raw(), groupIndex(), (const double *)linearV.d, nullptr, nullptr, N, 0.0, dt, 0, (void *)st));
+  }
+  real getHydrodynamicRadius() { return fcm->getHydrodynamicRadius(); }
+  real getSelfMobility() { return fcm->getSelfMobility(); }
 };
 using FCMIntegrator = FCMIntegratorT<>;
 #endif

@@ -58,7 +58,7 @@ inline Lattice describe(BRAVAISLAT kind) {
 inline std::vector<real4> initLattice(real3 L, uint N, BRAVAISLAT lat) {
   using namespace initial_conditions_detail;
   const Lattice l = describe(lat);
-  float box[3] = {L.x, L.y, l.planar ? 1.0f : L.z};
+  float box[3] = {(float)L.x, (float)L.y, l.planar ? 1.0f : (float)L.z};   // (the generator works in float whatever `real` is: bravais.h)
   const int ncells = (int)std::ceil((float)N / (1.f * l.nsites));
   const float volume = box[0] * box[1] * box[2];
   const double density = (double)((float)ncells / volume);

@@ -79,9 +79,57 @@ template <class Method> static int diffusing(shared_ptr<System> sys, const char 
   return (msd / expected > lowest && msd / expected < highest && std::abs(mean) < 5 * std::sqrt(msd / (3.0 * N))) ? 0 : 1;
 }
 
+// BDHI::FCMIntegrator with real = double (BDHI_FCM.cuh:155-199): the same two checks through the integrator class of the FCM module
+static int fcmIntegrator(shared_ptr<System> sys) {
+  int bad = 0;
+  BDHI::FCMIntegrator::Parameters par;
+  par.viscosity = 1.0; par.hydrodynamicRadius = 1.0; par.dt = 0.25; par.tolerance = 1e-4;
+  {
+    auto pd = std::make_shared<ParticleData>(1, sys);
+    { auto pos = pd->getPos(access::cpu, access::write); pos[0] = make_real4(0.3, -1.2, 2.1, 0); }
+    par.temperature = 0; par.box = Box(32.0);
+    auto fcm = std::make_shared<BDHI::FCMIntegrator>(pd, par);
+    fcm->addInteractor(std::make_shared<PullX>(pd, "pull"));
+    fcm->forwardTime();
+    real4 after;
+    { auto pos = pd->getPos(access::cpu, access::read); after = pos[0]; }
+    const double M = (after.x - 0.3) / par.dt, M0 = fcm->getSelfMobility();
+    std::printf("FCMIntegrator: pulled particle, mobility %.8f expected %.8f\n", M, M0);
+    bad += !(std::abs(M / M0 - 1) < 1e-3 && std::abs(after.y + 1.2) + std::abs(after.z - 2.1) < 1e-9);
+  }
+  {
+    const int N = 2048;
+    const real L = 128.0, T = 0.5;
+    auto pd = std::make_shared<ParticleData>(N, sys);
+    std::vector<real4> start(N);
+    {
+      std::mt19937 gen(4321);
+      std::uniform_real_distribution<double> u(-0.5 * L, 0.5 * L);
+      auto pos = pd->getPos(access::cpu, access::write);
+      for (int i = 0; i < N; ++i) start[i] = pos[i] = make_real4(u(gen), u(gen), u(gen), 0);
+    }
+    par.temperature = T; par.box = Box(L);
+    auto fcm = std::make_shared<BDHI::FCMIntegrator>(pd, par);
+    fcm->forwardTime();
+    double msd = 0;
+    {
+      auto pos = pd->getPos(access::cpu, access::read);
+      for (int i = 0; i < N; ++i) {
+        const double dx = pos[i].x - start[i].x, dy = pos[i].y - start[i].y, dz = pos[i].z - start[i].z;
+        msd += (dx * dx + dy * dy + dz * dz) / (3.0 * N);
+      }
+    }
+    const double expected = 2 * T * fcm->getSelfMobility() * par.dt;
+    std::printf("FCMIntegrator: one free step of %d particles at T = %.1f, <dx^2> = %.6f, 2 T M0 dt = %.6f\n", N, (double)T, msd, expected);
+    bad += !(msd / expected > 0.92 && msd / expected < 1.08);
+  }
+  return bad;
+}
+
 int main(int argc, char *argv[]) {
   auto sys = std::make_shared<System>(argc, argv);
   int bad = 0;
+  bad += fcmIntegrator(sys);
   bad += pulled<BDHI::PSE>(sys, "EulerMaruyama<PSE>");
   bad += pulled<BDHI::FCM>(sys, "EulerMaruyama<FCM>");
   bad += diffusing<BDHI::PSE>(sys, "EulerMaruyama<PSE>", 0.5, 0.92, 1.08);

@@ -127,3 +127,29 @@ def test_headers_carry_no_cuda_shim():
             code = re.sub(r"//.*|/\*.*?\*/", "", text, flags=re.S)
             assert not re.search(r"\b(typedef|using)\b[^;]*\bcudaStream_t\b", code), f
             assert not re.search(r"#\s*define\s+cuda\w+", code), f
+
+
+def test_corpus_with_double_precision_compiles_or_is_refused_by_name(tmp_path):
+    """The same programs with -DDOUBLE_PRECISION (several of the reference's Makefiles build theirs so): a program either passes the front
+    end — everything it uses has a double-precision build — or stops at the forwarding header of a module whose backend is single
+    precision only, with the message that says so; never with an undeclared name or a type error from inside the headers."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(rel):
+        src, _ = _source(rel, tmp_path, ".hip")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fsyntax-only", "-DDOUBLE_PRECISION", "-I", os.path.dirname(os.path.join(REF, rel))] + INC + [src]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return rel, r.returncode, r.stderr
+
+    with ThreadPoolExecutor(8) as pool:
+        results = list(pool.map(one, GXX + HIPCC))
+    compiled, refused = [], []
+    for rel, rc, err in results:
+        if rc == 0:
+            compiled.append(rel)
+        else:
+            assert "single-precision backend only" in err, (rel, [l for l in err.splitlines() if "error" in l][:4])
+            refused.append(rel)
+    # the programs of path B and of the host-side classes build in double; what needs CellList / PairForces / VerletNVT / FIB does not
+    assert len(compiled) >= 24 and "integration_schemes/others/FCM.cu" in compiled and "basic_concepts/13-your-first-interactor.cu" in compiled, compiled
+    assert "misc/LJ.cu" in refused and "../test/BDHI/FIB/FIB.cu" in refused, refused
