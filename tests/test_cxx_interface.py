@@ -74,7 +74,7 @@ def test_header_has_no_oracle_or_cpu_fallback():
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("custom_potential", []), ("ibm_library_mode", []), ("bd_readme", ["100000"]), ("lj_benchmark", ["131072", "50", "64"]),
                                        ("fcm_selfmobility", []), ("pse_selfmobility", []), ("poisson_two_charges", []), ("checkpoint", []), ("quasi2d_selfmobility", []), ("particle_group", []), ("particle_group", ["600", "7"]),
-                                       ("custom_transverser", []), ("nbody", []), ("module_lifetime", []), ("particle_sorter", []), ("tabulated_function", []), ("container", []), ("chebyshev_grid", []), ("dp_euler_maruyama", []), ("dp_bd", [])])
+                                       ("custom_transverser", []), ("nbody", []), ("module_lifetime", []), ("particle_sorter", []), ("tabulated_function", []), ("container", []), ("chebyshev_grid", []), ("api_corners", []), ("dp_euler_maruyama", []), ("dp_bd", [])])
 def test_examples_run(prog, args):
     _make()
     r = subprocess.run([os.path.join(EX, "_build", prog)] + args, capture_output=True, text=True, timeout=300)
